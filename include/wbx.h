@@ -1,0 +1,193 @@
+/*
+ * wbx.h -- C ABI of libwbx_hip.so, the MI355X (gfx950) engine behind the
+ * WeatherBench-X scoring hot path (Statistic.compute -> Aggregator reduce).
+ *
+ * The reference (google-research/weatherbenchX) is pure Python: the "FFI" a
+ * maintainer would bind is the set of whole-array xarray/NumPy calls inside
+ * the plugin classes.  Every entry point below names the reference call
+ * site(s) it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain C types only; all data pointers are DEVICE pointers unless the
+ *    name says host (`h_`); the caller owns every buffer.
+ *  - every function returns 0 on success or a negative wbx_status; the
+ *    message is retrievable with wbx_last_error() (thread local).
+ *  - all work is enqueued on the context's HIP stream and is asynchronous;
+ *    wbx_ctx_synchronize() (or reading through wbx_memcpy_d2h) orders it.
+ *  - a context is single-threaded; distinct contexts are independent.
+ *
+ * Two-stage reduction:
+ *   stage 1  (HBM-bound)  per-point statistics fused with an UNWEIGHTED partial
+ *            sum over every reduced dimension that weights/bin masks do not
+ *            depend on -> fp64 partial[key][chunk][lane][j]
+ *   stage 2  (tiny)       partial (x) W, W = product of weights and bin masks,
+ *            -> sum_weighted_statistics / sum_weights accumulators.
+ */
+#ifndef WBX_H_
+#define WBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WBX_ABI_VERSION 1
+
+typedef enum wbx_status {
+  WBX_OK = 0,
+  WBX_ERR_INVALID = -1,    /* bad argument / unsupported combination */
+  WBX_ERR_HIP = -2,        /* a HIP runtime call failed              */
+  WBX_ERR_NO_DEVICE = -3,  /* no gfx950 device visible               */
+  WBX_ERR_FFT = -4         /* rocFFT failure                         */
+} wbx_status;
+
+typedef struct wbx_ctx wbx_ctx; /* opaque: device id, stream, timers, scratch */
+
+/* element type of the statistic inputs */
+typedef enum wbx_dtype { WBX_F32 = 0, WBX_F64 = 1 } wbx_dtype;
+
+/* ---- fused per-point statistic families ---------------------------------
+ * Lane order is part of the ABI.
+ * WBX_DET3  inputs (p,t):    e=p-t, |e|, e^2
+ *           replaces deterministic.py:91-123 (Error, AbsoluteError, SquaredError)
+ * WBX_DET6  inputs (p,t,c):  e, |e|, e^2, (p-c)^2, (t-c)^2, (p-c)(t-c)
+ *           + deterministic.py:222-259 (SquaredPredictionAnomaly,
+ *           SquaredTargetAnomaly, AnomalyCovariance); c is gathered through
+ *           the plan's gather table (metrics/base.py:382-406 `.sel(dayofyear,hour)`)
+ * WBX_PASS1 input (p):       p          (any already-materialised statistic;
+ *           replaces the xr.dot of aggregation.py:335 for user-defined stats)
+ */
+typedef enum wbx_det_func { WBX_DET3 = 0, WBX_DET6 = 1, WBX_PASS1 = 2 } wbx_det_func;
+#define WBX_DET3_LANES 3
+#define WBX_DET6_LANES 6
+#define WBX_PASS1_LANES 1
+
+/* ensemble lanes (probabilistic.py:116-336, wrappers.py:116-148):
+ *  0 CRPSSkill            mean_m |p_m - t|
+ *  1 CRPSSpread           sum_{m,m'} |p_m - p_m'| / (M (M - fair))
+ *  2 EnsembleVariance     var_m(p, ddof=1)
+ *  3 UnbiasedEnsembleMeanSquaredError  (mean_m p - t)^2 - var/M
+ *  4 SquaredError of the ensemble mean (mean_m p - t)^2   (EnsembleMean + SquaredError)
+ */
+#define WBX_ENS_LANES 5
+typedef enum wbx_ens_algo {
+  WBX_ENS_SORT = 0,     /* rank / sorting-network form, probabilistic.py:214-240 (use_sort=True)  */
+  WBX_ENS_PAIRWISE = 1  /* O(M^2) pairwise form,        probabilistic.py:241-247 (use_sort=False) */
+} wbx_ens_algo;
+
+#define WBX_FLAG_MASKED 1u /* input 3 (uint8 mask, nonzero = valid) is present: aggregation.py:339-352 */
+#define WBX_FLAG_SKIPNA 2u /* NaN statistic values are dropped and counted out: aggregation.py:353-355 */
+#define WBX_FLAG_FAIR   4u /* ensemble: fair CRPS spread (divide by M(M-1)):   probabilistic.py:239,247 */
+
+#define WBX_MAX_INPUTS 4 /* 0 = predictions, 1 = targets, 2 = climatology, 3 = mask(uint8) */
+
+/* Stage-1 plan.  The host flattens the statistic's index space into
+ *   key   : every (key) index gets its own partial sum      [nkey]
+ *   depth : summed inside stage 1, split in nchunk chunks   [ndepth]
+ *   x     : the innermost, thread-mapped dimension          [nx]
+ * and hands the kernel per-input ELEMENT offset tables, so any dim order /
+ * any stride (the loaders' layout is arbitrary, data_loaders/xarray_loaders.py:185-188)
+ * is consumed in place, without a transposed copy.
+ * element address of input i at (key k, depth d, x):
+ *     in[i] + key_off[i][k] + depth_off[i][d] + x * xstride[i]
+ *     (+ gather_tab[gather_key[k] * n_gather_depth + gather_depth[d]] for i == 2)
+ * All table pointers are device pointers; a NULL table means all zeros.
+ */
+typedef struct wbx_s1_plan {
+  int64_t nkey;
+  int64_t ndepth;
+  int64_t nx;
+  int32_t x_kept;        /* 1: keep one partial per x (nj = nx); 0: sum x away (nj = 1) */
+  int32_t nchunk;        /* depth is cut into nchunk pieces of depth_chunk rows          */
+  int64_t depth_chunk;
+  int64_t xstride[WBX_MAX_INPUTS];
+  const int64_t* key_off[WBX_MAX_INPUTS];   /* [nkey]   */
+  const int64_t* depth_off[WBX_MAX_INPUTS]; /* [ndepth] */
+  const int32_t* gather_key;   /* [nkey]   or NULL */
+  const int32_t* gather_depth; /* [ndepth] or NULL */
+  const int64_t* gather_tab;   /* [n_gather_key * n_gather_depth] or NULL */
+  int32_t n_gather_depth;
+  uint32_t flags;        /* WBX_FLAG_* */
+  int32_t block_threads; /* 64, 128 or 256 */
+  int32_t vec;           /* 1 or 4: x elements per lane per load (4 needs 16-B alignment of every row) */
+} wbx_s1_plan;
+
+/* number of fp64 values stage 1 writes:
+ *   nkey * nchunk * nlanes_total * nj, nlanes_total = lanes * (1 + (flags & (MASKED|SKIPNA) ? 1 : 0))
+ * layout partial[key][chunk][lane][j]; with MASKED/SKIPNA the count lanes follow the value lanes. */
+int wbx_s1_partial_len(const wbx_s1_plan* plan, int lanes, int64_t* n_out);
+
+/* ---- context ------------------------------------------------------------- */
+int wbx_abi_version(void);
+const char* wbx_last_error(void);
+int wbx_device_count(int* n_out);
+/* `hip_stream` may be NULL (library creates its own) or an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream) so launches order with the caller's work. */
+int wbx_ctx_create(int device_id, void* hip_stream, wbx_ctx** out);
+int wbx_ctx_destroy(wbx_ctx* ctx);
+int wbx_ctx_synchronize(wbx_ctx* ctx);
+int wbx_ctx_device_name(wbx_ctx* ctx, char* buf, size_t buflen);
+
+/* device memory helpers for hosts without their own allocator */
+int wbx_malloc(wbx_ctx* ctx, size_t bytes, void** dptr_out);
+int wbx_free(wbx_ctx* ctx, void* dptr);
+int wbx_memcpy_h2d(wbx_ctx* ctx, void* dptr, const void* h_src, size_t bytes);
+int wbx_memcpy_d2h(wbx_ctx* ctx, void* h_dst, const void* dptr, size_t bytes); /* synchronises */
+int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes);
+
+/* HIP-event timer on the context stream (bench.py's roofline leg). */
+int wbx_timer_start(wbx_ctx* ctx);
+int wbx_timer_stop(wbx_ctx* ctx, float* ms_out); /* synchronises on the stop event */
+
+/* ---- stage 1: deterministic ----------------------------------------------
+ * Replaces Statistic.compute + the stat-side einsum of Aggregator.aggregate_stat_var
+ * (metrics/base.py:184-197, deterministic.py:91-123,222-259, aggregation.py:337-366). */
+int wbx_det_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /*wbx_det_func*/,
+                    int dtype /*wbx_dtype*/, const void* p, const void* t, const void* c,
+                    const uint8_t* mask, double* partial_out);
+
+/* ---- stage 1: ensemble ---------------------------------------------------
+ * p has an extra member axis of length M and element stride `member_stride`
+ * that is NOT part of key/depth/x.  Replaces probabilistic.py:116-336. */
+int wbx_ens_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M,
+                    int64_t member_stride, int algo /*wbx_ens_algo*/, const void* p,
+                    const void* t, double* partial_out);
+
+/* ---- stage 2: weighted / binned contraction --------------------------------
+ * partial is viewed as [nA][nBk][nBr][nchunk][nlane][nj];  W as [nBk][nBr][nj][nbin].
+ *   sum_j = 1: out[nA][nBk][nlane][nbin]      = sum_{Br,chunk,j} partial * W
+ *   sum_j = 0: out[nA][nBk][nlane][nj][nbin]  = sum_{Br,chunk}   partial * W
+ * Plain multiply-add with no zero skipping, so NaN * 0 = NaN poisons a bin exactly
+ * as the reference's xr.dot does (aggregation.py:272-277,335). */
+typedef struct wbx_s2_plan {
+  int64_t nA, nBk, nBr, nchunk, nlane, nj, nbin;
+  int32_t sum_j;
+} wbx_s2_plan;
+int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial,
+                 const double* W, double* out);
+
+/* ---- materialisation of per-point statistics --------------------------------
+ * Statistic.compute()'s full-resolution result (metrics/base.py:135-158) for callers
+ * that really want it (unaggregated pipelines, beam_pipeline.py:563-595).
+ * Uses the same plan tables with nchunk == 1, writes out[key][depth][x] (C order, fp64)
+ * for one lane of the family. */
+int wbx_det_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int lane,
+                const void* p, const void* t, const void* c, double* out);
+int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride,
+                int algo, int lane, const void* p, const void* t, double* out);
+
+/* ---- zonal energy spectrum ---------------------------------------------------
+ * Not in the reference snapshot.  field: `nrows` rows of `nlon` fp32 values,
+ * row r at field + row_off[r] (element offsets, longitude contiguous).
+ * power_out[group[r]][k] += scale[r] * |rfft(row)_k / nlon|^2 * (k == 0 ? 1 : 2), k = 0..nlon/2.
+ * power_out has ngroup * (nlon/2 + 1) fp64 values and is overwritten. */
+int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, const int64_t* row_off,
+                       const int32_t* group, const double* scale, int64_t nrows, int32_t nlon,
+                       int32_t ngroup, double* power_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WBX_H_ */

@@ -1,0 +1,349 @@
+"""CPU oracle: a plain-NumPy float64 restatement of WeatherBench-X's scoring hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under weatherbenchx_amd/ imports this module; it is used by tests/,
+by __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg, as the checker / the timed CPU baseline.
+
+The reference (google-research/weatherbenchX, pure Python on xarray/NumPy) cannot be imported in the build
+container or on the GPU box (no xarray/jax/absl/apache_beam), so parity is pinned the other way
+round: this restatement reproduces every analytic / brute-force known answer the reference's own tests hold
+for the path (tests/test_oracle_reference_pins.py restates them; list in SURVEY section 8c), and the HIP
+path is then compared against this restatement.  Zonal spectra have no reference at all:
+"parity unpinned" for that function.
+
+Every function names the reference lines it follows (paths relative to the reference checkout).
+Arrays are plain ndarrays plus a tuple of dimension names; all arithmetic is float64 on float64-cast
+inputs (the reference's own numerics follow the input dtype).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------
+# name-based broadcasting helpers (what xarray does for the reference)
+
+
+def union_dims(*dim_tuples):
+  out = []
+  for dims in dim_tuples:
+    for d in dims:
+      if d not in out:
+        out.append(d)
+  return tuple(out)
+
+
+def expand_to(arr, dims, out_dims):
+  """View of `arr` (named `dims`) broadcastable against an array named `out_dims`."""
+  arr = np.asarray(arr)
+  perm = [dims.index(d) for d in out_dims if d in dims]
+  arr = np.transpose(arr, perm)
+  index = tuple(slice(None) if d in dims else None for d in out_dims)
+  return arr[index]
+
+
+def f64(x):
+  return np.asarray(x, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------------
+# weights and bin masks
+
+
+def latitude_cell_bounds(lat_rad):
+  """weatherbenchX/weighting.py:62-79: mid-points, ends extended half a cell and clipped to +-pi/2."""
+  lat_rad = np.asarray(lat_rad)
+  diff = np.diff(lat_rad)
+  lower = max(lat_rad[0] - diff[0] / 2, -np.pi / 2)
+  upper = min(lat_rad[-1] + diff[-1] / 2, np.pi / 2)
+  return np.concatenate([[lower], (lat_rad[:-1] + lat_rad[1:]) / 2, [upper]])
+
+
+def grid_area_weights(lat_deg, normalized=True):
+  """weatherbenchX/weighting.py:82-88,105-130: sin(upper) - sin(lower), descending latitudes allowed."""
+  lat_deg = np.asarray(lat_deg, dtype=np.float64)
+  d = np.diff(lat_deg)
+  assert np.all(d > 0) or np.all(d < 0), 'Points must be strictly monotonic'
+  flip = lat_deg[0] > lat_deg[1]
+  lat = lat_deg[::-1] if flip else lat_deg
+  b = latitude_cell_bounds(np.deg2rad(lat))
+  w = np.sin(b[1:]) - np.sin(b[:-1])
+  if flip:
+    w = w[::-1]
+  if normalized:
+    w = w / w.mean()
+  return w
+
+
+def region_masks(lat_deg, lon_deg, regions, land_sea_mask=None):
+  """weatherbenchX/binning.py:52-89,166-201 -> (names, bool[region, lat, lon]); inclusive bounds,
+  longitudes modulo 360 with wrap-around; optional `{name}_land` copies."""
+  lat = np.asarray(lat_deg)[:, None]
+  lon = np.mod(np.asarray(lon_deg), 360)[None, :]
+  names, masks = [], []
+  for name, ((lat0, lat1), (lon0, lon1)) in regions.items():
+    if lat0 >= lat1:
+      raise ValueError('lat_lims[0] must be smaller than lat_lims[1]')
+    lat_m = (lat >= lat0) & (lat <= lat1)
+    l0, l1 = np.mod(lon0, 360), np.mod(lon1, 360)
+    lon_m = ((lon >= l0) & (lon <= l1)) if l1 > l0 else ((lon <= l1) | (lon >= l0))
+    names.append(name)
+    masks.append(lat_m & lon_m)
+  masks = np.stack(masks)
+  if land_sea_mask is not None:
+    land = masks & np.asarray(land_sea_mask).astype(bool)[None]
+    masks = np.concatenate([masks, land])
+    names = names + [f'{n}_land' for n in names]
+  return names, masks
+
+
+# --------------------------------------------------------------------------------------------------
+# per-point statistics (weatherbenchX/metrics/deterministic.py, probabilistic.py)
+
+
+def error(p, t):
+  """deterministic.py:91-100."""
+  return f64(p) - f64(t)
+
+
+def absolute_error(p, t):
+  """deterministic.py:103-112."""
+  return np.abs(f64(p) - f64(t))
+
+
+def squared_error(p, t):
+  """deterministic.py:115-123."""
+  return (f64(p) - f64(t)) ** 2
+
+
+def wind_vector_squared_error(pu, pv, tu, tv):
+  """deterministic.py:174-219."""
+  return (f64(pu) - f64(tu)) ** 2 + (f64(pv) - f64(tv)) ** 2
+
+
+def squared_prediction_anomaly(p, c):
+  """deterministic.py:222-232."""
+  return (f64(p) - f64(c)) ** 2
+
+
+def squared_target_anomaly(t, c):
+  """deterministic.py:235-245."""
+  return (f64(t) - f64(c)) ** 2
+
+
+def anomaly_covariance(p, t, c):
+  """deterministic.py:248-259."""
+  return (f64(p) - f64(c)) * (f64(t) - f64(c))
+
+
+def align_climatology(clim, clim_dims, valid_time, vt_dims):
+  """metrics/base.py:382-403: climatology[dayofyear, (hour), ...] gathered at valid_time.
+  `valid_time` datetime64 array named vt_dims; clim_dims starts with ('dayofyear',) or ('dayofyear','hour')
+  with dayofyear coordinate 1..366 and hour coordinate 0,6,12,18 spacing 24/nhour."""
+  vt = np.asarray(valid_time).astype('datetime64[ns]')
+  doy = (vt.astype('datetime64[D]') - vt.astype('datetime64[Y]').astype('datetime64[D]')).astype(np.int64)
+  if len(clim_dims) > 1 and clim_dims[1] == 'hour':
+    nh = np.asarray(clim).shape[1]
+    hour = (vt - vt.astype('datetime64[D]')).astype('timedelta64[h]').astype(np.int64)
+    out = np.asarray(clim)[doy, hour // (24 // nh)]
+    rest = clim_dims[2:]
+  else:
+    out = np.asarray(clim)[doy]
+    rest = clim_dims[1:]
+  return out, tuple(vt_dims) + tuple(rest)
+
+
+def _move_member_last(p, p_dims, ensemble_dim):
+  ax = p_dims.index(ensemble_dim)
+  return np.moveaxis(f64(p), ax, -1), tuple(d for d in p_dims if d != ensemble_dim)
+
+
+def crps_skill(p, p_dims, t, t_dims, ensemble_dim):
+  """probabilistic.py:116-145: mean_m |p_m - t|."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  out_dims = union_dims(dims, t_dims)
+  pe = expand_to(pm, dims + (ensemble_dim,), out_dims + (ensemble_dim,))
+  te = expand_to(f64(t), t_dims, out_dims)[..., None]
+  return np.abs(pe - te).mean(axis=-1), out_dims
+
+
+def rankdata_ordinal(x, axis=-1):
+  """probabilistic.py:148-158: ordinal ranks 1..M via argsort + put_along_axis."""
+  x = np.swapaxes(np.asarray(x), axis, -1)
+  order = np.argsort(x, axis=-1)
+  ranks = np.empty(order.shape, dtype=np.int64)
+  np.put_along_axis(ranks, order, np.broadcast_to(np.arange(1, x.shape[-1] + 1), x.shape), axis=-1)
+  return np.swapaxes(ranks, axis, -1)
+
+
+def crps_spread(p, p_dims, ensemble_dim, fair=True, use_sort=False):
+  """probabilistic.py:165-247: rank form (:231-240) or pairwise form (:241-247)."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  m = pm.shape[-1]
+  if m < 2:
+    raise ValueError('Cannot estimate CRPS spread with n_ensemble < 2.')
+  if use_sort:
+    rank = rankdata_ordinal(pm, axis=-1)
+    return 2 * ((2 * rank - m - 1) * pm).mean(axis=-1) / (m - int(fair)), dims
+  total = np.zeros(pm.shape[:-1])
+  for i in range(m):  # O(M^2) without the M x M x grid temporary
+    total += np.abs(pm - pm[..., i:i + 1]).sum(axis=-1)
+  return total / (m * (m - int(fair))), dims
+
+
+def ensemble_variance(p, p_dims, ensemble_dim):
+  """probabilistic.py:250-273: var(ddof=1)."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  return pm.var(axis=-1, ddof=1), dims
+
+
+def unbiased_ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):
+  """probabilistic.py:276-336: (mean_m p - t)^2 - var/M."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  m = pm.shape[-1]
+  out_dims = union_dims(dims, t_dims)
+  mean = expand_to(pm.mean(axis=-1), dims, out_dims)
+  var = expand_to(pm.var(axis=-1, ddof=1), dims, out_dims)
+  te = expand_to(f64(t), t_dims, out_dims)
+  return (mean - te) ** 2 - var / m, out_dims
+
+
+def ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):
+  """wrappers.py:116-148 (EnsembleMean) followed by deterministic.py:115-123."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  out_dims = union_dims(dims, t_dims)
+  return (expand_to(pm.mean(axis=-1), dims, out_dims) - expand_to(f64(t), t_dims, out_dims)) ** 2, out_dims
+
+
+# --------------------------------------------------------------------------------------------------
+# aggregation (weatherbenchX/aggregation.py:297-366)
+
+
+def aggregate(stat, dims, reduce_dims, weights=(), bin_masks=(), mask=None, mask_dims=None, skipna=False):
+  """Aggregator.aggregate_stat_var: returns (sum_weighted_statistics, sum_weights, out_dims).
+
+  weights:   sequence of (array, dims)              -- product of all (aggregation.py:311-314)
+  bin_masks: sequence of (bin_dim_name, bool array, dims incl. the bin dim) (aggregation.py:320-330)
+  mask:      optional boolean validity array named mask_dims (`masked=True` with a mask coordinate,
+             aggregation.py:339-352); skipna drops NaN statistic values (aggregation.py:353-355).
+  Output dims: surviving statistic dims in order, then the bin dims in order.  A variable lacking a reduce dim
+  returns None (aggregation.py:305-309)."""
+  dims = tuple(dims)
+  if not set(reduce_dims) <= set(dims):
+    return None
+  stat = f64(stat)
+  valid = np.ones(stat.shape, dtype=bool)
+  if mask is not None:
+    valid = valid & np.broadcast_to(expand_to(np.asarray(mask, dtype=bool), tuple(mask_dims), dims), stat.shape)
+  if skipna:
+    valid = valid & ~np.isnan(stat)
+  if mask is not None or skipna:
+    stat = np.where(valid, stat, 0.0)
+  ones = valid.astype(np.float64)
+  letters = {}
+
+  def L(d):
+    if d not in letters:
+      letters[d] = chr(ord('a') + len(letters))
+    return letters[d]
+
+  operands, specs = [], []
+  for arr, wd in weights:
+    operands.append(f64(arr))
+    specs.append(''.join(L(d) for d in wd))
+  bin_names = []
+  for name, m, md in bin_masks:
+    if not (set(md) - {name}) <= set(dims):
+      return None
+    operands.append(np.asarray(m, dtype=np.float64))
+    specs.append(''.join(L(d) for d in md))
+    bin_names.append(name)
+  out_dims = tuple(d for d in dims if d not in set(reduce_dims)) + tuple(bin_names)
+  sspec = ''.join(L(d) for d in dims)
+  ospec = ''.join(L(d) for d in out_dims)
+  expr = ','.join([sspec] + specs) + '->' + ospec
+  with np.errstate(all='ignore'):
+    sws = np.einsum(expr, stat, *operands)
+    sw = np.einsum(expr, ones, *operands)
+  return sws, sw, out_dims
+
+
+# --------------------------------------------------------------------------------------------------
+# metrics from mean statistics (deterministic.py:312-425, probabilistic.py:606-688, 864-1003)
+
+
+def rmse(mean_se):
+  return np.sqrt(mean_se)
+
+
+def acc(mean_cov, mean_spa, mean_sta):
+  return mean_cov / (np.sqrt(mean_spa) * np.sqrt(mean_sta))
+
+
+def crps(mean_skill, mean_spread):
+  return mean_skill - 0.5 * mean_spread
+
+
+def unbiased_spread_skill_ratio(mean_var, mean_uemse):
+  return np.sqrt(mean_var / mean_uemse)
+
+
+# --------------------------------------------------------------------------------------------------
+# zonal energy spectrum -- NOT in the reference snapshot: parity unpinned.  Definition of
+# the build (WeatherBench-2 lineage): F_k = rfft(f)/n, S_k = |F_k|^2 * (1 if k == 0 else 2).
+
+
+def zonal_power_spectrum(field, lon_axis=-1):
+  f = f64(field)
+  n = f.shape[lon_axis]
+  F = np.fft.rfft(f, axis=lon_axis) / n
+  power = (F.real ** 2 + F.imag ** 2)
+  factor = np.full(power.shape[lon_axis], 2.0)
+  factor[0] = 1.0
+  shape = [1] * power.ndim
+  shape[lon_axis] = -1
+  return power * factor.reshape(shape)
+
+
+# --------------------------------------------------------------------------------------------------
+# "reference structure" CPU path for timing: one pass per statistic with full-size temporaries in the
+# input dtype, np.einsum for the weighted reduction and a second einsum on ones_like for sum_weights,
+# exactly the shape of work of aggregation.py:337-366 + deterministic.py:91-259.
+
+
+def reference_structure_deterministic(p, t, c, lat_weights, reduce_axes=(0, 3, 4)):
+  """p, t, c: float32 [init, lead, level, lat, lon]; lat_weights float64[lat].  Returns the six mean statistics
+  (Error, AbsoluteError, SquaredError, SquaredPredictionAnomaly, SquaredTargetAnomaly, AnomalyCovariance)."""
+  del reduce_axes
+  out = {}
+  stats = {
+      'Error': lambda: p - t,
+      'AbsoluteError': lambda: abs(p - t),
+      'SquaredError': lambda: (p - t) ** 2,
+      'SquaredPredictionAnomaly': lambda: (p - c) ** 2,
+      'SquaredTargetAnomaly': lambda: (t - c) ** 2,
+      'AnomalyCovariance': lambda: (p - c) * (t - c),
+  }
+  for name, fn in stats.items():
+    stat = fn()
+    sws = np.einsum('abcde,d->bc', stat, lat_weights)
+    sw = np.einsum('abcde,d->bc', np.ones_like(stat), lat_weights)
+    out[name] = sws / sw
+  return out
+
+
+def reference_structure_ensemble(p, t, lat_weights):
+  """p float32 [member, lat, lon], t float32 [lat, lon]: CRPS (rank form, fair), variance, unbiased MSE,
+  ensemble-mean SE -- the public-benchmark ensemble suite (public_benchmark/run_benchmark_evaluation.py:341-353)."""
+  m = p.shape[0]
+  out = {}
+  skill = np.abs(p - t[None]).mean(axis=0)
+  rank = rankdata_ordinal(p, axis=0)
+  spread = 2 * ((2 * rank - m - 1) * p).mean(axis=0) / (m - 1)
+  var = p.var(axis=0, ddof=1)
+  mean = p.mean(axis=0)
+  stats = {'CRPSSkill': skill, 'CRPSSpread': spread, 'EnsembleVariance': var,
+           'UnbiasedEnsembleMeanSquaredError': (mean - t) ** 2 - var / m, 'EnsembleMeanSquaredError': (mean - t) ** 2}
+  for name, stat in stats.items():
+    sws = np.einsum('de,d->', stat, lat_weights)
+    sw = np.einsum('de,d->', np.ones_like(stat), lat_weights)
+    out[name] = sws / sw
+  return out

@@ -1,0 +1,152 @@
+"""NumPy interpreter of the stage-1 / stage-2 plans (TEST INFRASTRUCTURE, CPU only).
+
+Mirrors what csrc/wbx_s1.hpp, wbx_det.hip, wbx_ens_impl.hpp and wbx_s2.hip do with the tables the planner
+emits, so that planner + Aggregator + labeled-array logic can be verified without a GPU.  It is installed by
+monkeypatching the launch functions of weatherbenchx_amd.engine inside the `backend` fixture only.
+"""
+import numpy as np
+
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import planner
+
+
+class _Buf:
+  def __init__(self, arr):
+    self.ptr = arr
+
+
+class FakeCtx:
+  device_id = 0
+
+  def upload(self, arr):
+    return _Buf(np.array(arr, copy=True))
+
+
+def _to_device(ctx, da, dtype_code):
+  cache = da.__dict__.setdefault('_wbx_dev_fake', {})
+  if dtype_code not in cache:
+    want = np.float32 if dtype_code == _hip.F32 else np.float64
+    host = np.ascontiguousarray(np.asarray(da.values), dtype=want)
+    st = [int(s // host.itemsize) for s in host.strides] if host.ndim else []
+    lay = planner.InputLayout(strides=dict(zip(da.dims, st)), itemsize=host.itemsize, base_alignment=256)
+    cache[dtype_code] = engine._Dev(host.reshape(-1), lay, dtype_code, host, host.nbytes)
+  return cache[dtype_code]
+
+
+def _mask_to_device(ctx, mask):
+  host = np.ascontiguousarray(np.asarray(mask.values).astype(bool).astype(np.uint8))
+  st = [int(s) for s in host.strides] if host.ndim else []
+  return engine._Dev(host.reshape(-1), planner.InputLayout(strides=dict(zip(mask.dims, st)), itemsize=1,
+                                                           base_alignment=256), 'u8', host, host.nbytes)
+
+
+def _offsets(plan, i):
+  ko = plan.key_off[i] if plan.key_off[i] is not None else np.zeros(plan.nkey, dtype=np.int64)
+  do = plan.depth_off[i] if plan.depth_off[i] is not None else np.zeros(plan.ndepth, dtype=np.int64)
+  off = ko[:, None, None] + do[None, :, None] + (np.arange(plan.nx, dtype=np.int64) * plan.xstride[i])[None, None, :]
+  if i == 2 and plan.gather_tab is not None:
+    gk = plan.gather_key if plan.gather_key is not None else np.zeros(plan.nkey, dtype=np.int32)
+    gd = plan.gather_depth if plan.gather_depth is not None else np.zeros(plan.ndepth, dtype=np.int32)
+    off = off + plan.gather_tab[gk.astype(np.int64)[:, None] * plan.n_gather_depth + gd[None, :]][:, :, None]
+  return off
+
+
+def _det_lanes(func, v):
+  p = v[0].astype(np.float64)
+  if func == _hip.PASS1:
+    return [p]
+  t = v[1].astype(np.float64)
+  e = p - t
+  lanes = [e, np.abs(e), e * e]
+  if func == _hip.DET6:
+    c = v[2].astype(np.float64)
+    lanes += [(p - c) ** 2, (t - c) ** 2, (p - c) * (t - c)]
+  return lanes
+
+
+def _ens_lanes(plan, devs, ens, flags):
+  m, mstride, algo = ens
+  off_p = _offsets(plan, 0)
+  members = np.stack([devs[0].ptr[off_p + k * mstride] for k in range(m)], axis=-1).astype(np.float64)
+  t = devs[1].ptr[_offsets(plan, 1)].astype(np.float64)
+  fair = 1.0 if flags & _hip.FLAG_FAIR else 0.0
+  d = members - t[..., None]
+  skill = np.abs(d).mean(axis=-1)
+  if algo == _hip.ENS_SORT:
+    srt = np.sort(members, axis=-1)
+    coef = 2 * np.arange(1, m + 1) - m - 1
+    spread = 2 * (srt * coef).sum(axis=-1) / (m * (m - fair))
+    spread = np.where(np.isnan(members).any(axis=-1), np.nan, spread)
+  else:
+    spread = np.abs(members[..., :, None] - members[..., None, :]).sum(axis=(-1, -2)) / (m * (m - fair))
+  with np.errstate(all='ignore'):
+    var = members.var(axis=-1, ddof=1) if m > 1 else np.full(skill.shape, np.nan)
+  md = d.mean(axis=-1)
+  return [skill, spread, var, md * md - var / m, md * md]
+
+
+def _chunked(plan, arr):
+  """[nkey, D, nx] -> [nkey, nchunk, nj]"""
+  out = np.zeros((plan.nkey, plan.nchunk, plan.nj))
+  for c in range(plan.nchunk):
+    d0, d1 = c * plan.depth_chunk, min((c + 1) * plan.depth_chunk, plan.ndepth)
+    blk = arr[:, d0:d1, :]
+    out[:, c, :] = blk.sum(axis=1) if plan.x_kept else blk.sum(axis=(1, 2))[:, None]
+  return out
+
+
+def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None):
+  with np.errstate(all='ignore'):
+    if kind == 'det':
+      nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]
+      vals = [devs[i].ptr[_offsets(plan, i)] for i in range(nin)]
+      lanes = _det_lanes(func, vals)
+    else:
+      lanes = _ens_lanes(plan, devs, ens, plan.flags)
+    counted = bool(plan.flags & 3)
+    cols = []
+    if counted:
+      valid = np.ones(lanes[0].shape, dtype=bool)
+      if plan.flags & _hip.FLAG_MASKED:
+        valid = devs[3].ptr[_offsets(plan, 3)] != 0
+      oks = [valid & ~(np.isnan(l) if plan.flags & _hip.FLAG_SKIPNA else False) for l in lanes]
+      cols = [_chunked(plan, np.where(ok, l, 0.0)) for ok, l in zip(oks, lanes)]
+      cols += [_chunked(plan, ok.astype(np.float64)) for ok in oks]
+    else:
+      cols = [_chunked(plan, l) for l in lanes]
+    partial = np.stack(cols, axis=2)  # [nkey, nchunk, lane, nj]
+  assert partial.shape[2] == nlanes_total
+  return _Buf(partial.reshape(plan.partial_shape(nlanes_total)))
+
+
+def _run_map(ctx, kind, dplan, plan, devs, dtype_code, lane, func=0, ens=None):
+  with np.errstate(all='ignore'):
+    if kind == 'det':
+      nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]
+      lanes = _det_lanes(func, [devs[i].ptr[_offsets(plan, i)] for i in range(nin)])
+    else:
+      lanes = _ens_lanes(plan, devs, ens, plan.flags)
+  return np.ascontiguousarray(lanes[lane]).reshape(-1)
+
+
+def _run_s2(ctx, s2, partial, w_buf):
+  part = np.asarray(partial).reshape(s2.nA, s2.nBk, s2.nBr, s2.nchunk, s2.nlane, s2.nj)
+  w = np.asarray(w_buf.ptr).reshape(s2.nBk, s2.nBr, s2.nj, s2.nbin)
+  with np.errstate(all='ignore'):
+    if s2.sum_j:
+      out = np.einsum('abrclj,brjn->abln', part, w)[:, :, :, None, :]
+    else:
+      out = np.einsum('abrclj,brjn->abljn', part, w)
+  return out
+
+
+def install(monkeypatch):
+  ctx = FakeCtx()
+  monkeypatch.setattr(_hip, 'default_context', lambda device_id=None: ctx)
+  monkeypatch.setattr(engine, '_to_device', _to_device)
+  monkeypatch.setattr(engine, '_mask_to_device', _mask_to_device)
+  monkeypatch.setattr(engine, '_device_plan', lambda c, plan: plan)
+  monkeypatch.setattr(engine, '_run_s1', _run_s1)
+  monkeypatch.setattr(engine, '_run_map', _run_map)
+  monkeypatch.setattr(engine, '_run_s2', _run_s2)

@@ -1,0 +1,172 @@
+"""Pins the CPU oracle (oracle/wbx_oracle.py) to the known answers of the reference's own tests.
+
+The reference cannot be imported here, so each case below restates a reference test --
+its inputs and its analytic / brute-force expected value -- and checks the oracle against it:
+  weatherbenchX/aggregation_test.py:69-169, weatherbenchX/metrics/metrics_test.py:44-98, 501-544,
+  603-660, 947-1006, weatherbenchX/weighting_test.py:24-46, weatherbenchX/binning_test.py:27-60.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+
+LAT = np.linspace(-90, 90, 19)
+LON = np.linspace(0, 360, 36, endpoint=False)
+
+
+def test_rmse_of_zeros_vs_ones_is_one_and_sum_of_states_keeps_it():
+  # aggregation_test.py:69-103
+  dims = ('lead_time', 'init_time', 'latitude', 'longitude', 'level')
+  p = np.zeros((2, 2, 19, 36, 3), np.float32)
+  t = np.ones_like(p)
+  sws, sw, out_dims = O.aggregate(O.squared_error(p, t), dims, ['init_time', 'latitude', 'longitude'])
+  assert out_dims == ('lead_time', 'level')
+  np.testing.assert_allclose(O.rmse(sws / sw), np.ones((2, 3)))
+  np.testing.assert_allclose(O.rmse((sws + sws) / (sw + sw)), np.ones((2, 3)))
+
+
+def test_variable_without_reduce_dim_is_dropped():
+  # aggregation_test.py:105-119
+  p = np.zeros((2, 19, 36))
+  assert O.aggregate(p, ('init_time', 'latitude', 'longitude'), ['level', 'latitude', 'longitude']) is None
+
+
+def test_nan_handling_masked_and_skipna():
+  # aggregation_test.py:121-169
+  dims = ('init_time', 'latitude', 'longitude')
+  p = np.zeros((2, 19, 36))
+  t = np.where(LAT[None, :, None] > 0, np.ones_like(p), np.nan)
+  se = O.squared_error(p, t)
+  sws, sw, _ = O.aggregate(se, dims, list(dims))
+  assert np.isnan(sws / sw)
+  mask = ~np.isnan(t)
+  sws, sw, _ = O.aggregate(se, dims, list(dims), mask=mask, mask_dims=dims)
+  np.testing.assert_allclose(sws / sw, 1.0)
+  sws, sw, _ = O.aggregate(se, dims, list(dims), skipna=True)
+  np.testing.assert_allclose(sws / sw, 1.0)
+
+
+def test_two_times_two_weighting_scales_both_accumulators_by_four():
+  # aggregation_test.py:171-221
+  dims = ('init_time', 'latitude', 'longitude')
+  se = O.squared_error(np.zeros((2, 19, 36)), np.ones((2, 19, 36)))
+  two = (np.full(se.shape, 2.0), dims)
+  a = O.aggregate(se, dims, list(dims))
+  b = O.aggregate(se, dims, list(dims), weights=[two, two])
+  np.testing.assert_allclose(b[0], 4 * a[0])
+  np.testing.assert_allclose(b[1], 4 * a[1])
+  np.testing.assert_allclose(b[0] / b[1], a[0] / a[1])
+
+
+def test_two_region_binnings_give_both_bin_dims():
+  # aggregation_test.py:223-246
+  dims = ('lead_time', 'init_time', 'latitude', 'longitude', 'level')
+  se = O.squared_error(np.zeros((2, 2, 19, 36, 3)), np.ones((2, 2, 19, 36, 3)))
+  n1, m1 = O.region_masks(LAT, LON, {'north': ((0, 90), (0, 360)), 'south': ((-90, 0), (0, 360))})
+  n2, m2 = O.region_masks(LAT, LON, {'east': ((-90, 90), (0, 180)), 'west': ((-90, 90), (180, 360))})
+  _, _, out_dims = O.aggregate(se, dims, ['init_time', 'latitude', 'longitude'],
+                               bin_masks=[('bins1', m1, ('bins1', 'latitude', 'longitude')),
+                                          ('bins2', m2, ('bins2', 'latitude', 'longitude'))])
+  assert set(out_dims) == {'bins1', 'bins2', 'lead_time', 'level'}
+
+
+def test_squared_error_of_t_plus_one_has_mean_one():
+  # metrics_test.py:44-98
+  t = np.zeros((11, 19, 19, 36), np.float32)
+  se = O.squared_error(t[:, :2] + 1, t[:, :2])
+  assert se.mean() == 1.0 and se.shape == (11, 2, 19, 36)
+
+
+def test_wind_vector_rmse_is_sqrt_two():
+  # metrics_test.py:501-544
+  z = np.zeros((2, 19, 36, 3))
+  se = O.wind_vector_squared_error(z, z, z + 1, z + 1)
+  sws, sw, _ = O.aggregate(se, ('time', 'latitude', 'longitude', 'level'), ['time', 'latitude', 'longitude'])
+  np.testing.assert_allclose(np.sqrt(sws / sw), np.sqrt(2) * np.ones(3))
+
+
+@pytest.mark.parametrize('m,use_sort,fair', list(itertools.product([4, 5], [False, True], [True, False])))
+def test_crps_equals_inline_brute_force(m, use_sort, fair):
+  # metrics_test.py:603-660: spread = mean |x_i - x_j| over all pairs * M/(M - fair); skill = mean |t - x|.
+  rng = np.random.default_rng(m)
+  p = rng.random((2, 19, 36, m))
+  t = rng.random((2, 19, 36))
+  dims = ('time', 'latitude', 'longitude', 'realization')
+  skill, sdims = O.crps_skill(p, dims, t, dims[:3], 'realization')
+  spread, _ = O.crps_spread(p, dims, 'realization', fair=fair, use_sort=use_sort)
+  ms = O.aggregate(skill, sdims, ['latitude', 'longitude'])
+  mp = O.aggregate(spread, sdims, ['latitude', 'longitude'])
+  got = O.crps(ms[0] / ms[1], mp[0] / mp[1])
+  brute_spread = np.abs(p[..., :, None] - p[..., None, :]).mean(axis=(1, 2, 3, 4)) * (m / (m - int(fair)))
+  brute_skill = np.abs(t[..., None] - p).mean(axis=(1, 2, 3))
+  np.testing.assert_allclose(got, brute_skill - 0.5 * brute_spread, rtol=1e-12)
+
+
+def test_rank_and_pairwise_spread_agree_per_point():
+  rng = np.random.default_rng(0)
+  p = rng.normal(size=(7, 51))
+  a, _ = O.crps_spread(p, ('x', 'number'), 'number', fair=True, use_sort=True)
+  b, _ = O.crps_spread(p, ('x', 'number'), 'number', fair=True, use_sort=False)
+  np.testing.assert_allclose(a, b, rtol=1e-12)
+
+
+def test_unbiased_spread_skill_is_close_to_one():
+  # metrics_test.py:947-981: iid predictions and targets -> ratio ~ 1 within 4/sqrt(N*M)
+  m = 5
+  t = np.random.default_rng(0).random((2, 19, 36))
+  p = np.random.default_rng(1).random((2, 19, 36, m))
+  dims = ('time', 'latitude', 'longitude', 'realization')
+  var, vd = O.ensemble_variance(p, dims, 'realization')
+  ue, _ = O.unbiased_ensemble_mean_squared_error(p, dims, t, dims[:3], 'realization')
+  a = O.aggregate(var, vd, list(vd))
+  b = O.aggregate(ue, vd, list(vd))
+  ratio = O.unbiased_spread_skill_ratio(a[0] / a[1], b[0] / b[1])
+  assert abs(ratio - 1) < 4 / np.sqrt(t.size * m)
+
+
+def test_acc_is_one_when_prediction_equals_target():
+  # metrics_test.py:983-1006: climatology = target - 1 for every (dayofyear, hour)
+  t = np.zeros((2, 1, 19, 36, 3), np.float32)  # lead, init, lat, lon, level
+  clim = np.full((366, 4, 19, 36, 3), -1.0)
+  init = np.array(['2020-01-01'], dtype='datetime64[ns]')
+  lead = np.array([0, 24], dtype='timedelta64[h]').astype('timedelta64[ns]')
+  vt = init[None, :] + lead[:, None]
+  c, cdims = O.align_climatology(clim, ('dayofyear', 'hour', 'latitude', 'longitude', 'level'), vt,
+                                 ('lead_time', 'init_time'))
+  assert cdims == ('lead_time', 'init_time', 'latitude', 'longitude', 'level')
+  dims = cdims
+  spa = O.aggregate(O.squared_prediction_anomaly(t, c), dims, ['latitude', 'longitude'])
+  sta = O.aggregate(O.squared_target_anomaly(t, c), dims, ['latitude', 'longitude'])
+  cov = O.aggregate(O.anomaly_covariance(t, t, c), dims, ['latitude', 'longitude'])
+  np.testing.assert_allclose(O.acc(cov[0] / cov[1], spa[0] / spa[1], sta[0] / sta[1]), 1.0)
+
+
+def test_grid_area_weights_known_values():
+  # weighting_test.py:24-46 + SURVEY F5 spot values
+  w = O.grid_area_weights(LAT)
+  assert abs(w.mean() - 1.0) < 1e-12 and w.shape == LAT.shape
+  np.testing.assert_allclose([w[0], w[9]], [0.0361504, 1.6559591], rtol=1e-6)
+  w025 = O.grid_area_weights(np.linspace(-90, 90, 721))
+  np.testing.assert_allclose([w025[0], w025[360]], [8.5793e-4, 1.5729767], rtol=1e-5)
+  np.testing.assert_allclose(O.grid_area_weights(np.linspace(-90, 90, 721), normalized=False).sum(), 2.0, rtol=1e-12)
+  # regional, un-normalised weights equal the global ones on the overlap
+  full = O.grid_area_weights(LAT, normalized=False)
+  sel = (LAT >= -30) & (LAT <= 30)
+  np.testing.assert_allclose(O.grid_area_weights(LAT[sel], normalized=False)[1:-1], full[sel][1:-1])
+  # descending latitude gives the reversed vector
+  np.testing.assert_allclose(O.grid_area_weights(LAT[::-1]), w[::-1])
+
+
+def test_region_masks_shapes_and_wraparound():
+  # binning_test.py:27-60
+  names, m = O.region_masks(LAT, LON, {'region1': ((20, 90), (-180, 180))})
+  assert m.shape == (1, 19, 36)
+  names, m = O.region_masks(LAT, LON, {'region1': ((20, 90), (-180, 180)), 'region2': ((-90, -20), (-180, 180))},
+                            land_sea_mask=(LAT[:, None] > 0) & np.ones((19, 36), bool))
+  assert m.shape == (4, 19, 36) and names[2:] == ['region1_land', 'region2_land']
+  # (0, 360) -> (0, 0) after mod: everything; europe wraps through 0
+  _, m = O.region_masks(LAT, LON, {'g': ((-90, 90), (0, 360)), 'eu': ((35, 75), (-12.5, 42.5))})
+  assert m[0].all()
+  assert m[1][:, LON == 350].any() and m[1][:, LON == 40].any() and not m[1][:, LON == 100].any()

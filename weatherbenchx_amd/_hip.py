@@ -1,0 +1,226 @@
+"""ctypes binding of libwbx_hip.so (the C ABI declared in include/wbx.h).
+
+There is NO CPU fallback: if the shared library is missing, or no gfx950 device is visible, every
+compute entry point raises `WbxUnavailableError`.  Host-side planning (planner.py) never needs it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_LIB_NAME = 'libwbx_hip.so'
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+MAX_INPUTS = 4
+F32, F64 = 0, 1
+DET3, DET6, PASS1 = 0, 1, 2
+DET_LANES = {DET3: 3, DET6: 6, PASS1: 1}
+ENS_LANES = 5
+ENS_SORT, ENS_PAIRWISE = 0, 1
+FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR = 1, 2, 4
+
+# every symbol include/wbx.h declares (tests check the built library exports all of them)
+EXPORTED_SYMBOLS = (
+    'wbx_abi_version', 'wbx_last_error', 'wbx_device_count', 'wbx_ctx_create', 'wbx_ctx_destroy',
+    'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
+    'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
+    'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_det_map', 'wbx_ens_map',
+    'wbx_zonal_spectrum',
+)
+
+
+class WbxUnavailableError(RuntimeError):
+  """libwbx_hip.so missing or no MI355X visible -- the product path has no CPU fallback."""
+
+
+class WbxError(RuntimeError):
+  pass
+
+
+class S1PlanStruct(C.Structure):
+  _fields_ = [
+      ('nkey', C.c_int64), ('ndepth', C.c_int64), ('nx', C.c_int64),
+      ('x_kept', C.c_int32), ('nchunk', C.c_int32), ('depth_chunk', C.c_int64),
+      ('xstride', C.c_int64 * MAX_INPUTS),
+      ('key_off', C.c_void_p * MAX_INPUTS),
+      ('depth_off', C.c_void_p * MAX_INPUTS),
+      ('gather_key', C.c_void_p), ('gather_depth', C.c_void_p), ('gather_tab', C.c_void_p),
+      ('n_gather_depth', C.c_int32), ('flags', C.c_uint32),
+      ('block_threads', C.c_int32), ('vec', C.c_int32),
+  ]
+
+
+class S2PlanStruct(C.Structure):
+  _fields_ = [(n, C.c_int64) for n in ('nA', 'nBk', 'nBr', 'nchunk', 'nlane', 'nj', 'nbin')] + [('sum_j', C.c_int32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib_path() -> str:
+  return _LIB_PATH
+
+
+def load_library():
+  """Loads libwbx_hip.so (no device needed) and declares prototypes."""
+  global _lib
+  with _lib_lock:
+    if _lib is not None:
+      return _lib
+    if not os.path.exists(_LIB_PATH):
+      raise WbxUnavailableError(
+          f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+          '(make -C weatherbenchx_amd/csrc). There is no CPU fallback.')
+    try:
+      lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # missing ROCm runtime etc.
+      raise WbxUnavailableError(f'cannot load {_LIB_PATH}: {e}') from e
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.wbx_last_error.restype = C.c_char_p
+    lib.wbx_abi_version.restype = i32
+    protos = {
+        'wbx_device_count': [C.POINTER(i32)],
+        'wbx_ctx_create': [i32, vp, C.POINTER(vp)],
+        'wbx_ctx_destroy': [vp],
+        'wbx_ctx_synchronize': [vp],
+        'wbx_ctx_device_name': [vp, C.c_char_p, C.c_size_t],
+        'wbx_malloc': [vp, C.c_size_t, C.POINTER(vp)],
+        'wbx_free': [vp, vp],
+        'wbx_memcpy_h2d': [vp, vp, vp, C.c_size_t],
+        'wbx_memcpy_d2h': [vp, vp, vp, C.c_size_t],
+        'wbx_memset': [vp, vp, i32, C.c_size_t],
+        'wbx_timer_start': [vp],
+        'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
+        'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],
+        'wbx_det_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp],
+        'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp],
+        'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
+        'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
+        'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
+        'wbx_zonal_spectrum': [vp, vp, vp, vp, vp, i64, C.c_int32, C.c_int32, vp],
+    }
+    for name, argtypes in protos.items():
+      fn = getattr(lib, name)
+      fn.argtypes = argtypes
+      fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+  if rc != 0:
+    msg = load_library().wbx_last_error().decode(errors='replace')
+    if rc == -3:
+      raise WbxUnavailableError(f'{what}: {msg}')
+    raise WbxError(f'{what} failed (status {rc}): {msg}')
+
+
+def device_count() -> int:
+  lib = load_library()
+  n = C.c_int(0)
+  rc = lib.wbx_device_count(C.byref(n))
+  return int(n.value) if rc == 0 else 0
+
+
+def is_available() -> bool:
+  try:
+    return device_count() > 0
+  except WbxUnavailableError:
+    return False
+
+
+class DeviceBuffer:
+  """Device allocation owned by a Context (freed on garbage collection)."""
+
+  def __init__(self, ctx: 'Context', nbytes: int):
+    self.ctx = ctx
+    self.nbytes = int(nbytes)
+    p = C.c_void_p(0)
+    check(ctx.lib.wbx_malloc(ctx.handle, self.nbytes, C.byref(p)), 'wbx_malloc')
+    self.ptr = p.value or 0
+
+  def __del__(self):
+    try:
+      if getattr(self, 'ptr', 0) and self.ctx.handle:
+        self.ctx.lib.wbx_free(self.ctx.handle, C.c_void_p(self.ptr))
+        self.ptr = 0
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+class Context:
+  """One device + one HIP stream (wbx_ctx).  `torch_stream=True` adopts torch's current stream so
+  launches order with tensors produced by torch on that stream."""
+
+  def __init__(self, device_id: int = 0, stream_ptr: int | None = None):
+    self.lib = load_library()
+    h = C.c_void_p(0)
+    check(self.lib.wbx_ctx_create(int(device_id), C.c_void_p(stream_ptr or 0), C.byref(h)), 'wbx_ctx_create')
+    self.handle = h
+    self.device_id = int(device_id)
+
+  def close(self):
+    if getattr(self, 'handle', None):
+      self.lib.wbx_ctx_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  def synchronize(self):
+    check(self.lib.wbx_ctx_synchronize(self.handle), 'wbx_ctx_synchronize')
+
+  def device_name(self) -> str:
+    buf = C.create_string_buffer(256)
+    check(self.lib.wbx_ctx_device_name(self.handle, buf, 256), 'wbx_ctx_device_name')
+    return buf.value.decode()
+
+  # memory ------------------------------------------------------------------------------------
+  def alloc(self, nbytes: int) -> DeviceBuffer:
+    return DeviceBuffer(self, max(int(nbytes), 8))
+
+  def upload(self, arr: np.ndarray) -> DeviceBuffer:
+    arr = np.ascontiguousarray(arr)
+    buf = self.alloc(arr.nbytes)
+    if arr.nbytes:
+      check(self.lib.wbx_memcpy_h2d(self.handle, C.c_void_p(buf.ptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes),
+            'wbx_memcpy_h2d')
+    return buf
+
+  def download(self, ptr: int, shape, dtype=np.float64) -> np.ndarray:
+    out = np.empty(shape, dtype=dtype)
+    if out.nbytes:
+      check(self.lib.wbx_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes),
+            'wbx_memcpy_d2h')
+    return out
+
+  def timer_start(self):
+    check(self.lib.wbx_timer_start(self.handle), 'wbx_timer_start')
+
+  def timer_stop(self) -> float:
+    ms = C.c_float(0)
+    check(self.lib.wbx_timer_stop(self.handle, C.byref(ms)), 'wbx_timer_stop')
+    return float(ms.value)
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device_id: int | None = None) -> Context:
+  """Process-wide context per device.  Uses LOCAL_RANK as the default device (one process per GPU)."""
+  if device_id is None:
+    device_id = int(os.environ.get('WBX_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    n = device_count()
+    if n == 0:
+      raise WbxUnavailableError('no HIP device visible (libwbx_hip has no CPU path)')
+    device_id %= n
+  if device_id not in _default_ctx:
+    _default_ctx[device_id] = Context(device_id)
+  return _default_ctx[device_id]

@@ -1,0 +1,296 @@
+"""Aggregator / AggregationState (counterpart of weatherbenchX/aggregation.py:27-435).
+
+Same dataclasses, methods and error behaviour as the reference; the arithmetic of
+`Aggregator.aggregate_stat_var` -- the two `xr.dot` passes of aggregation.py:357-362 -- runs on the
+GPU: stage 1 (fused statistic + unweighted partial sums, csrc/wbx_s1.hpp) then stage 2
+(partial x W contraction, csrc/wbx_s2.hip).  Accumulators are always float64 (the reference follows
+the input dtype).  Output dims: surviving statistic dims in their original order, then the
+bin dims in `bin_by` order (unpinned by the reference, SURVEY F11: compare by name).
+"""
+from __future__ import annotations
+
+import collections
+import dataclasses
+from typing import Any, Callable, Collection, Hashable, Iterable, Mapping, Sequence
+
+import numpy as np
+
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import lazy
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd import xarray_tree
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic as _det
+
+
+def combining_sum(data_arrays: Sequence[xr.DataArray]) -> xr.DataArray:
+  """Sum with a zero-filled OUTER join of the coordinates (aggregation.py:27-60)."""
+  if not data_arrays:
+    return sum([])
+  total = data_arrays[0]
+  for nxt in data_arrays[1:]:
+    a, b = xr.align(total, nxt, join='outer', fill_value=0)
+    total = a + b
+  return total
+
+
+@dataclasses.dataclass
+class AggregationState:
+  """sum_weighted_statistics / sum_weights accumulator pair (aggregation.py:63-265)."""
+
+  sum_weighted_statistics: Any
+  sum_weights: Any
+
+  @classmethod
+  def zero(cls) -> 'AggregationState':
+    return cls(sum_weighted_statistics=None, sum_weights=None)
+
+  def __add__(self, other: 'AggregationState') -> 'AggregationState':
+    return self.sum([self, other])
+
+  @classmethod
+  def sum(cls, aggregation_states: Iterable['AggregationState']) -> 'AggregationState':
+    pairs = [(s.sum_weighted_statistics, s.sum_weights) for s in aggregation_states
+             if s.sum_weighted_statistics is not None]
+    if not pairs:
+      return cls.zero()
+    sws, sw = xarray_tree.map_structure(lambda *leaves: combining_sum(leaves), *pairs)
+    return cls(sws, sw)
+
+  def mean_statistics(self) -> Any:
+    return xarray_tree.map_structure(lambda num, den: num / den, self.sum_weighted_statistics, self.sum_weights)
+
+  def metric_values(self, metrics: Mapping[str, metrics_base.Metric]) -> xr.Dataset:
+    """Dataset of `<metric>.<variable>` values (aggregation.py:122-148)."""
+    per_metric = metrics_base.compute_metrics_from_statistics(metrics, self.mean_statistics())
+    out = xr.Dataset()
+    for metric_name, per_var in per_metric.items():
+      for var_name, da in per_var.items():
+        out[f'{metric_name}.{var_name}'] = da
+    return out
+
+  def sum_along_dims(self, dims: Collection[str]) -> 'AggregationState':
+    if self.sum_weighted_statistics is None:
+      return self
+    return self.map(lambda x: x.sum(list(dims), skipna=False))
+
+  def dot(self, *arrays: xr.DataArray, dim) -> 'AggregationState':
+    return self.map(lambda x: xr.dot(x, *arrays, dim=dim))
+
+  @classmethod
+  def map_multi(cls, func: Callable[..., xr.DataArray], *agg_states: 'AggregationState') -> 'AggregationState':
+    if any(a.sum_weighted_statistics is None for a in agg_states):
+      raise ValueError('Cannot map a zero AggregationState.')
+    return cls(xarray_tree.map_structure(func, *[a.sum_weighted_statistics for a in agg_states]),
+               xarray_tree.map_structure(func, *[a.sum_weights for a in agg_states]))
+
+  def map(self, func: Callable[[xr.DataArray], xr.DataArray]) -> 'AggregationState':
+    return self.map_multi(func, self)
+
+  # -- persistence: nested dict ("data tree") and flat '#'-separated Dataset (aggregation.py:203-265) ----
+  def to_data_tree(self) -> dict:
+    """Nested dict mirror of xr.DataTree: leaves are {'sum_weighted_statistics': da, 'sum_weights': da}."""
+    if isinstance(self.sum_weighted_statistics, xr.DataArray):
+      return {'sum_weighted_statistics': self.sum_weighted_statistics, 'sum_weights': self.sum_weights}
+    if isinstance(self.sum_weighted_statistics, Mapping):
+      return {k: AggregationState(self.sum_weighted_statistics[k], self.sum_weights[k]).to_data_tree()
+              for k in self.sum_weighted_statistics.keys()}
+    raise TypeError('Bad type for AggregationState.sum_weighted_statistics.')
+
+  @classmethod
+  def from_data_tree(cls, data_tree: Mapping, name=None) -> 'AggregationState':
+    if set(data_tree.keys()) == {'sum_weighted_statistics', 'sum_weights'} and isinstance(
+        data_tree['sum_weights'], xr.DataArray):
+      return cls(data_tree['sum_weighted_statistics'].rename(name), data_tree['sum_weights'].rename(name))
+    children = {k: cls.from_data_tree(v, name=k) for k, v in data_tree.items()}
+    return cls({k: v.sum_weighted_statistics for k, v in children.items()},
+               {k: v.sum_weights for k, v in children.items()})
+
+  def to_dataset(self, separator='#') -> xr.Dataset:
+    flat = {}
+
+    def walk(node, path):
+      if isinstance(node.get('sum_weights'), xr.DataArray) and len(node) == 2:
+        for leaf in ('sum_weighted_statistics', 'sum_weights'):
+          flat[separator.join(path + [leaf])] = node[leaf]
+      else:
+        for k, v in node.items():
+          walk(v, path + [str(k)])
+    walk(self.to_data_tree(), [])
+    return xr.Dataset(flat)
+
+  @classmethod
+  def from_dataset(cls, dataset: Mapping, separator='#') -> 'AggregationState':
+    tree: dict = {}
+    for full, da in dataset.items():
+      *path, leaf = str(full).split(separator)
+      node = tree
+      for part in path:
+        node = node.setdefault(part, {})
+      node[leaf] = da
+    return cls.from_data_tree(tree)
+
+
+def _weight_product(stat: xr.DataArray, weigh_by, bin_by):
+  """-> (W as a labeled array or None, bin dim names) or None when a bin mask needs dims the statistic lacks."""
+  stat_dims = set(stat.dims)
+  names = [b.bin_dim_name for b in bin_by or []]
+  if len(set(names)) != len(names):
+    raise ValueError('Bin dimension names must be unique.')
+  w = None
+  for method in weigh_by or []:
+    wi = xr.as_dataarray(method.weights(stat)).astype(np.float64)
+    w = wi if w is None else w * wi
+  for method in bin_by or []:
+    mask = xr.as_dataarray(method.create_bin_mask(stat))
+    if not (set(mask.dims) - {method.bin_dim_name}) <= stat_dims:
+      return None  # cannot bin on dims that are not evaluation-unit dims (aggregation.py:320-330)
+    mask = mask.astype(np.float64)
+    w = mask if w is None else w * mask
+  return w, tuple(names)
+
+
+@dataclasses.dataclass
+class Aggregator:
+  """Weighted / binned reduction over `reduce_dims` (aggregation.py:268-408); see the reference for the
+  NaN note: with skipna=False a NaN anywhere in the reduced set makes every bin NaN."""
+
+  reduce_dims: Collection[str]
+  bin_by: Sequence[binning.Binning] | None = None
+  weigh_by: Sequence[weighting.Weighting] | None = None
+  masked: bool = False
+  skipna: bool = False
+
+  # ---- reference-compatible single-array entry point -------------------------------------------------
+  def aggregation_fn(self, stat: xr.DataArray) -> xr.DataArray | None:
+    """sum over reduce_dims of stat * weights * bin masks (aggregation.py:297-335)."""
+    state = self._aggregate(xr.as_dataarray(stat), use_mask=False, skipna=False)
+    return None if state is None else state.sum_weighted_statistics
+
+  def aggregate_stat_var(self, stat: xr.DataArray) -> AggregationState | None:
+    """One statistic of one variable -> AggregationState, or None if a reduce/bin dim is missing
+    (aggregation.py:337-366)."""
+    stat = xr.as_dataarray(stat)
+    return self._aggregate(stat, use_mask=self.masked and 'mask' in stat.coords, skipna=self.skipna)
+
+  def aggregate_stat_vars(self, stats: Mapping[Hashable, xr.DataArray]) -> AggregationState:
+    per_var = {name: self.aggregate_stat_var(s) for name, s in stats.items() if s is not None}
+    per_var = {k: v for k, v in per_var.items() if v is not None}
+    return AggregationState({k: v.sum_weighted_statistics for k, v in per_var.items()},
+                            {k: v.sum_weights for k, v in per_var.items()})
+
+  def aggregate_statistics(self, statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> AggregationState:
+    per_stat = {name: self.aggregate_stat_vars(stats) for name, stats in statistics.items()}
+    return AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
+                            {k: v.sum_weights for k, v in per_stat.items()})
+
+  # ---- implementation ---------------------------------------------------------------------------------
+  def _aggregate(self, stat: xr.DataArray, *, use_mask: bool, skipna: bool) -> AggregationState | None:
+    reduce_set = set(self.reduce_dims)
+    if not reduce_set <= set(stat.dims):
+      return None  # variables without every reduce dim are dropped (aggregation.py:305-309)
+    wp = self._cached_weight_product(stat)
+    if wp is None:
+      return None
+    w_da, bin_dims = wp
+
+    if isinstance(stat, _det._SumOfStatistics) and stat.is_lazy and not use_mask and not skipna:  # pylint: disable=protected-access
+      parts = [self._aggregate(term, use_mask=False, skipna=False) for term in stat._terms]  # pylint: disable=protected-access
+      sws = parts[0].sum_weighted_statistics
+      for p in parts[1:]:
+        sws = sws + p.sum_weighted_statistics
+      return AggregationState(sws, parts[0].sum_weights)
+
+    if isinstance(stat, lazy.LazyStatistic) and stat.is_lazy:
+      values, counts, out_dims, frame_coords, lane, scale = self._reduce_lazy(stat, w_da, bin_dims, use_mask, skipna)
+    else:
+      values, counts, out_dims = self._reduce_materialised(stat, w_da, bin_dims, use_mask, skipna)
+      frame_coords, lane, scale = stat._coords, 0, 1.0  # pylint: disable=protected-access
+
+    final_dims = tuple(d for d in stat.dims if d in out_dims) + tuple(bin_dims)
+    coords = {k: v for k, v in frame_coords.items() if set(v[0]) <= set(final_dims) and k != 'mask'}
+    if w_da is not None:
+      for k, v in w_da._coords.items():  # pylint: disable=protected-access
+        if set(v[0]) <= set(final_dims):
+          coords.setdefault(k, v)
+
+    def wrap(arr):
+      da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
+      da = da.transpose(*final_dims)
+      return xr.DataArray(np.ascontiguousarray(da.values), dims=final_dims, coords=coords, name=stat.name,
+                          attrs=stat.attrs, _raw_coords=True)
+
+    return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
+
+  def _cached_weight_product(self, stat: xr.DataArray):
+    """W = prod(weights) * prod(bin masks) is rebuilt by the reference for every (statistic, variable)
+    call (aggregation.py:311-330).  For the built-in coordinate-only plugins it is cached per
+    (statistic dims, coordinates of the dims W depends on)."""
+    known = (weighting.GridAreaWeighting, binning.Regions, binning.LandSea)
+    if not all(isinstance(m, known) for m in list(self.weigh_by or []) + list(self.bin_by or [])):
+      return _weight_product(stat, self.weigh_by, self.bin_by)
+    cache = self.__dict__.setdefault('_w_products', {})
+    hints = self.__dict__.setdefault('_w_dep_hints', {})
+    frame = (stat.dims, stat.shape)
+    dep = hints.get(frame)
+    if dep is not None:
+      key = (frame, tuple((d, hash(np.asarray(stat._coords[d][1]).tobytes()) if d in stat._coords else None)  # pylint: disable=protected-access
+                          for d in dep))
+      if key in cache:
+        return cache[key]
+    wp = _weight_product(stat, self.weigh_by, self.bin_by)
+    if wp is None:
+      return None
+    w_da, bin_dims = wp
+    dep = tuple(d for d in (w_da.dims if w_da is not None else ()) if d not in bin_dims)
+    hints[frame] = dep
+    key = (frame, tuple((d, hash(np.asarray(stat._coords[d][1]).tobytes()) if d in stat._coords else None)  # pylint: disable=protected-access
+                        for d in dep))
+    if len(cache) > 16:
+      cache.clear()
+    cache[key] = wp
+    return wp
+
+  def _cache_key(self, w_da, bin_dims, use_mask, skipna, extra=()):
+    return (id(self), tuple(sorted(self.reduce_dims)), use_mask, skipna, tuple(bin_dims),
+            None if w_da is None else (w_da.dims, w_da.shape), extra)
+
+  def _reduce_lazy(self, stat: lazy.LazyStatistic, w_da, bin_dims, use_mask, skipna):
+    grp = stat._group  # pylint: disable=protected-access
+    mean_dims = stat._mean_dims  # pylint: disable=protected-access
+    ens_params = stat._ens_params  # pylint: disable=protected-access
+    if grp.kind == 'ens' and (use_mask or skipna):
+      raise NotImplementedError('masked / skipna aggregation of fused ensemble statistics is not supported yet; '
+                                'aggregate with masked=False, skipna=False')
+    extra = (tuple(sorted(ens_params.items())) if ens_params else (), mean_dims)
+    key = self._cache_key(w_da, bin_dims, use_mask, skipna, extra)
+    hit = grp.cache.get(key)
+    if hit is None:
+      hit = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna, ens_params=ens_params,
+                       extra_reduce=mean_dims)
+      grp.cache[key] = hit
+    values, counts, out_dims = hit
+    scale = 1.0
+    for d in mean_dims:  # mean over d == sum over d / n; the count carries the same factor
+      scale /= grp.sizes[d]
+    return values, counts, out_dims, grp.coords, stat._lane, scale  # pylint: disable=protected-access
+
+  def _reduce_materialised(self, stat: xr.DataArray, w_da, bin_dims, use_mask, skipna):
+    """Any DataArray (user-defined statistics, numpy or torch payload): the PASS1 family."""
+    mask = stat.coords['mask'] if use_mask else None
+    if mask is not None:
+      mask = xr.DataArray(mask.values.astype(bool), dims=mask.dims)
+    plain = xr.DataArray(stat.data, dims=stat.dims)
+    if not xr._is_float(plain.data):  # pylint: disable=protected-access
+      plain = plain.astype(np.float64)
+    return engine.reduce_statistics('det', [plain], stat.dims, stat.sizes, self.reduce_dims, w_da, bin_dims,
+                                    func=_hip.PASS1, mask=mask, skipna=skipna)
+
+
+def compute_metric_values_for_single_chunk(metrics, aggregator: Aggregator, predictions, targets) -> xr.Dataset:
+  """statistics -> aggregate -> metric values for one chunk (aggregation.py:411-435)."""
+  statistics = metrics_base.compute_unique_statistics_for_all_metrics(metrics, predictions, targets)
+  return aggregator.aggregate_statistics(statistics).metric_values(metrics)

@@ -1,0 +1,47 @@
+// Shared host-side plumbing of libwbx_hip.so: context object, error reporting, HIP checks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/wbx.h"
+
+struct wbx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_start = nullptr;
+  hipEvent_t ev_stop = nullptr;
+  // scratch for rocFFT (spectrum) and plans live in wbx_spectrum.hip
+  void* fft_state = nullptr;
+};
+
+namespace wbx {
+
+char* last_error_buf();  // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+}  // namespace wbx
+
+#define WBX_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      return wbx::fail(WBX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                             \
+  } while (0)
+
+#define WBX_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return wbx::fail(WBX_ERR_INVALID, __VA_ARGS__); \
+  } while (0)

@@ -1,0 +1,145 @@
+// Context, memory helpers and HIP-event timers of libwbx_hip.so (see include/wbx.h).
+#include "wbx_common.hpp"
+
+namespace wbx {
+char* last_error_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+}  // namespace wbx
+
+extern "C" int wbx_abi_version(void) { return WBX_ABI_VERSION; }
+
+extern "C" const char* wbx_last_error(void) { return wbx::last_error_buf(); }
+
+extern "C" int wbx_device_count(int* n_out) {
+  WBX_REQUIRE(n_out != nullptr, "n_out is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *n_out = 0;
+    return wbx::fail(WBX_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *n_out = n;
+  return 0;
+}
+
+extern "C" int wbx_ctx_create(int device_id, void* hip_stream, wbx_ctx** out) {
+  WBX_REQUIRE(out != nullptr, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return wbx::fail(WBX_ERR_NO_DEVICE, "no HIP device visible (libwbx_hip has no CPU path)");
+  WBX_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range [0,%d)", device_id, n);
+  WBX_HIP(hipSetDevice(device_id));
+  wbx_ctx* c = new wbx_ctx();
+  c->device = device_id;
+  if (hip_stream) {
+    c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    c->own_stream = false;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete c;
+      return wbx::fail(WBX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    c->own_stream = true;
+  }
+  if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    delete c;
+    return wbx::fail(WBX_ERR_HIP, "hipEventCreate failed");
+  }
+  *out = c;
+  return 0;
+}
+
+namespace wbx {
+void spectrum_release(wbx_ctx* ctx);
+}
+
+extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  wbx::spectrum_release(ctx);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int wbx_ctx_synchronize(wbx_ctx* ctx) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  WBX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_ctx_device_name(wbx_ctx* ctx, char* buf, size_t buflen) {
+  WBX_REQUIRE(ctx != nullptr && buf != nullptr && buflen > 0, "bad arguments");
+  hipDeviceProp_t prop;
+  WBX_HIP(hipGetDeviceProperties(&prop, ctx->device));
+  snprintf(buf, buflen, "%s|%s|cus=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+extern "C" int wbx_malloc(wbx_ctx* ctx, size_t bytes, void** dptr_out) {
+  WBX_REQUIRE(ctx != nullptr && dptr_out != nullptr, "bad arguments");
+  *dptr_out = nullptr;
+  if (bytes == 0) return 0;
+  WBX_HIP(hipSetDevice(ctx->device));
+  WBX_HIP(hipMalloc(dptr_out, bytes));
+  return 0;
+}
+
+extern "C" int wbx_free(wbx_ctx* ctx, void* dptr) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (!dptr) return 0;
+  WBX_HIP(hipSetDevice(ctx->device));
+  WBX_HIP(hipStreamSynchronize(ctx->stream));
+  WBX_HIP(hipFree(dptr));
+  return 0;
+}
+
+extern "C" int wbx_memcpy_h2d(wbx_ctx* ctx, void* dptr, const void* h_src, size_t bytes) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (bytes == 0) return 0;
+  WBX_REQUIRE(dptr != nullptr && h_src != nullptr, "NULL pointer");
+  WBX_HIP(hipSetDevice(ctx->device));
+  // pageable source: the async copy returns once the source has been staged.
+  WBX_HIP(hipMemcpyAsync(dptr, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  WBX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_memcpy_d2h(wbx_ctx* ctx, void* h_dst, const void* dptr, size_t bytes) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (bytes == 0) return 0;
+  WBX_REQUIRE(dptr != nullptr && h_dst != nullptr, "NULL pointer");
+  WBX_HIP(hipSetDevice(ctx->device));
+  WBX_HIP(hipMemcpyAsync(h_dst, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  WBX_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (bytes == 0) return 0;
+  WBX_REQUIRE(dptr != nullptr, "NULL pointer");
+  WBX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_timer_start(wbx_ctx* ctx) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  WBX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_timer_stop(wbx_ctx* ctx, float* ms_out) {
+  WBX_REQUIRE(ctx != nullptr && ms_out != nullptr, "bad arguments");
+  WBX_HIP(hipEventRecord(ctx->ev_stop, ctx->stream));
+  WBX_HIP(hipEventSynchronize(ctx->ev_stop));
+  WBX_HIP(hipEventElapsedTime(ms_out, ctx->ev_start, ctx->ev_stop));
+  return 0;
+}

@@ -1,0 +1,192 @@
+// Deterministic statistic families for the stage-1 skeleton (wbx_s1.hpp).
+//
+// Reference semantics restated (weatherbenchX/metrics/deterministic.py):
+//   Error :91-100            e  = p - t
+//   AbsoluteError :103-112   |e|
+//   SquaredError :115-123    e^2
+//   SquaredPredictionAnomaly :222-232   (p - c)^2
+//   SquaredTargetAnomaly :235-245       (t - c)^2
+//   AnomalyCovariance :248-259          (p - c)(t - c)
+// and the mask / skipna pre-processing of Aggregator.aggregate_stat_var
+// (weatherbenchX/aggregation.py:339-357): masked-out or (skipna) NaN statistic values
+// become 0 and are counted out of sum_weights through the paired count lane.
+//
+// All arithmetic is fp64 on the widened inputs, so results follow the reference evaluated
+// on float64-cast inputs to summation-order round-off.
+#include "wbx_s1.hpp"
+
+namespace wbx {
+
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+  using type = float4;
+};
+template <>
+struct Vec4<double> {
+  using type = double4;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x, int64_t xs, T (&v)[V]) {
+  const T* p = reinterpret_cast<const T*>(base) + off;
+  if constexpr (V == 4) {
+    if (xs == 1) {
+      using V4 = typename Vec4<T>::type;
+      V4 q = *reinterpret_cast<const V4*>(p + x);
+      v[0] = q.x;
+      v[1] = q.y;
+      v[2] = q.z;
+      v[3] = q.w;
+    } else {  // xs == 0: broadcast along x
+      T s = p[0];
+      v[0] = v[1] = v[2] = v[3] = s;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) v[k] = p[(x + k) * xs];
+  }
+}
+
+// FUNC: 0 = DET3 (p,t), 1 = DET6 (p,t,c), 2 = PASS1 (p).  MM: masked / skipna handling.
+template <typename T, int FUNC, bool MM>
+struct DetOp {
+  static constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
+  static constexpr int NLANE = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
+  static constexpr int NACC = NLANE * (MM ? 2 : 1);
+  static constexpr int XR_UNROLL = 2, XK_UNROLL = 4;
+
+  __device__ __forceinline__ static void lanes(double p, double t, double c, double (&val)[NLANE]) {
+    if constexpr (FUNC == WBX_PASS1) {
+      val[0] = p;
+    } else {
+      const double e = p - t;
+      val[0] = e;
+      val[1] = fabs(e);
+      val[2] = e * e;
+      if constexpr (FUNC == WBX_DET6) {
+        const double pa = p - c, ta = t - c;
+        val[3] = pa * pa;
+        val[4] = ta * ta;
+        val[5] = pa * ta;
+      }
+    }
+  }
+
+  __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                                double (&val)[NLANE]) {
+    T p[1], t[1] = {0}, c[1] = {0};
+    load_x<T, 1>(a.in[0], ro[0], x, a.xstride[0], p);
+    if constexpr (NIN > 1) load_x<T, 1>(a.in[1], ro[1], x, a.xstride[1], t);
+    if constexpr (NIN > 2) load_x<T, 1>(a.in[2], ro[2], x, a.xstride[2], c);
+    lanes((double)p[0], (double)t[0], (double)c[0], val);
+  }
+
+  template <int V, bool XK>
+  __device__ __forceinline__ static void accum(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                               double (&acc)[XK ? V : 1][NACC]) {
+    T p[V], t[V] = {}, c[V] = {};
+    load_x<T, V>(a.in[0], ro[0], x, a.xstride[0], p);
+    if constexpr (NIN > 1) load_x<T, V>(a.in[1], ro[1], x, a.xstride[1], t);
+    if constexpr (NIN > 2) load_x<T, V>(a.in[2], ro[2], x, a.xstride[2], c);
+    uint8_t m[V];
+    if constexpr (MM) {
+      if (a.flags & WBX_FLAG_MASKED) {
+        load_x<uint8_t, V>(a.in[3], ro[3], x, a.xstride[3], m);
+      } else {
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = 1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      double val[NLANE];
+      lanes((double)p[k], NIN > 1 ? (double)t[k] : 0.0, NIN > 2 ? (double)c[k] : 0.0, val);
+      double(&A)[NACC] = acc[XK ? k : 0];
+      if constexpr (!MM) {
+#pragma unroll
+        for (int l = 0; l < NLANE; ++l) A[l] += val[l];
+      } else {
+        const bool skipna = a.flags & WBX_FLAG_SKIPNA;
+#pragma unroll
+        for (int l = 0; l < NLANE; ++l) {
+          const bool ok = m[k] != 0 && !(skipna && val[l] != val[l]);
+          A[l] += ok ? val[l] : 0.0;
+          A[NLANE + l] += ok ? 1.0 : 0.0;
+        }
+      }
+    }
+  }
+};
+
+template <typename T, int FUNC>
+static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  const bool mm = plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA);
+  if (mm) return launch_partial<DetOp<T, FUNC, true>, 1>(ctx, plan, a);
+  if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, false>, 4>(ctx, plan, a);
+  return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);
+}
+
+template <typename T>
+static int dispatch_func(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, S1Args& a, bool map) {
+  switch (func) {
+    case WBX_DET3:
+      return map ? launch_map<DetOp<T, WBX_DET3, false>>(ctx, plan, a) : dispatch_partial<T, WBX_DET3>(ctx, plan, a);
+    case WBX_DET6:
+      return map ? launch_map<DetOp<T, WBX_DET6, false>>(ctx, plan, a) : dispatch_partial<T, WBX_DET6>(ctx, plan, a);
+    case WBX_PASS1:
+      return map ? launch_map<DetOp<T, WBX_PASS1, false>>(ctx, plan, a) : dispatch_partial<T, WBX_PASS1>(ctx, plan, a);
+  }
+  return fail(WBX_ERR_INVALID, "unknown deterministic family %d", func);
+}
+
+static int det_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                      const void* c, const uint8_t* mask, double* out, bool map, int lane) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (int rc = check_plan(plan)) return rc;
+  WBX_REQUIRE(out != nullptr || plan->nkey == 0, "output pointer is NULL");
+  WBX_REQUIRE(p != nullptr || plan->nkey * plan->ndepth * plan->nx == 0, "predictions pointer is NULL");
+  if (func != WBX_PASS1) WBX_REQUIRE(t != nullptr || plan->nkey * plan->ndepth * plan->nx == 0, "targets pointer is NULL");
+  if (func == WBX_DET6) WBX_REQUIRE(c != nullptr || plan->nkey * plan->ndepth * plan->nx == 0, "climatology pointer is NULL");
+  if (plan->flags & WBX_FLAG_MASKED) WBX_REQUIRE(mask != nullptr, "WBX_FLAG_MASKED set but mask is NULL");
+  if (plan->vec == 4) {
+    const uintptr_t al = dtype == WBX_F32 ? 15 : 31;
+    WBX_REQUIRE((((uintptr_t)p) & al) == 0 && (((uintptr_t)t) & al) == 0 && (((uintptr_t)c) & al) == 0,
+                "vec=4 needs 16/32-byte aligned inputs");
+  }
+  WBX_HIP(hipSetDevice(ctx->device));
+  S1Args a;
+  fill_args(plan, a);
+  a.in[0] = p;
+  a.in[1] = t;
+  a.in[2] = c;
+  a.in[3] = mask;
+  a.out = out;
+  a.lane = lane;
+  if (dtype == WBX_F32) return dispatch_func<float>(ctx, plan, func, a, map);
+  if (dtype == WBX_F64) return dispatch_func<double>(ctx, plan, func, a, map);
+  return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
+}
+
+}  // namespace wbx
+
+extern "C" int wbx_det_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p,
+                               const void* t, const void* c, const uint8_t* mask, double* partial_out) {
+  return wbx::det_common(ctx, plan, func, dtype, p, t, c, mask, partial_out, false, 0);
+}
+
+extern "C" int wbx_det_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int lane, const void* p,
+                           const void* t, const void* c, double* out) {
+  const int nl = func == WBX_DET6 ? 6 : (func == WBX_DET3 ? 3 : 1);
+  if (lane < 0 || lane >= nl) return wbx::fail(WBX_ERR_INVALID, "lane %d out of range for family %d", lane, func);
+  return wbx::det_common(ctx, plan, func, dtype, p, t, c, nullptr, out, true, lane);
+}
+
+extern "C" int wbx_s1_partial_len(const wbx_s1_plan* plan, int lanes, int64_t* n_out) {
+  if (!plan || !n_out || lanes <= 0) return wbx::fail(WBX_ERR_INVALID, "bad arguments to wbx_s1_partial_len");
+  const int64_t nj = plan->x_kept ? plan->nx : 1;
+  const int64_t nl = (int64_t)lanes * ((plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) ? 2 : 1);
+  *n_out = plan->nkey * plan->nchunk * nl * nj;
+  return 0;
+}

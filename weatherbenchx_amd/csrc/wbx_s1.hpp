@@ -1,0 +1,238 @@
+// Stage-1 skeleton: fused per-point statistic + unweighted fp64 partial sums.
+//
+// Index space (built by the host planner, weatherbenchx_amd/planner.py):
+//   key   k in [0,nkey)   one partial per key            -> blockIdx
+//   depth d in [0,D)      summed here, cut in nchunk chunks -> blockIdx
+//   x     in [0,nx)       innermost, lane-mapped dimension
+// Two kernels share every Op (statistic family):
+//   s1_xr : x is summed away.   One wave sweeps one row at a time with V-wide loads,
+//           the waves of a block interleave over the chunk's rows, fp64 lane partials
+//           are folded with wave shuffles + LDS, one write per (key,chunk,lane).
+//   s1_xk : x is kept (latitude-fastest real data, or x is a surviving dim).  One lane
+//           owns V x-positions and walks the chunk's rows; no cross-lane traffic at all.
+// Both are pure streaming reads: algorithmic bytes = the inputs, once.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "wbx_common.hpp"
+
+namespace wbx {
+
+struct S1Args {
+  const void* in[WBX_MAX_INPUTS];
+  const int64_t* key_off[WBX_MAX_INPUTS];
+  const int64_t* depth_off[WBX_MAX_INPUTS];
+  int64_t xstride[WBX_MAX_INPUTS];
+  const int32_t* gk;
+  const int32_t* gd;
+  const int64_t* gtab;
+  int32_t ngd;
+  int64_t nkey, D, nx, dchunk;
+  int32_t nchunk, nxtile;
+  uint32_t flags;
+  double* out;
+  // ensemble
+  int32_t M;
+  int64_t mstride;
+  // map kernels
+  int32_t lane;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Row base offsets (elements) of every input for (key, depth row).
+template <int NIN>
+__device__ __forceinline__ void key_bases(const S1Args& a, int64_t key, int64_t (&kb)[WBX_MAX_INPUTS]) {
+#pragma unroll
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i) kb[i] = (i < NIN || i == 3) && a.key_off[i] ? a.key_off[i][key] : 0;
+}
+
+template <int NIN>
+__device__ __forceinline__ void row_bases(const S1Args& a, const int64_t (&kb)[WBX_MAX_INPUTS], int64_t key,
+                                          int64_t d, int64_t (&ro)[WBX_MAX_INPUTS]) {
+#pragma unroll
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i)
+    ro[i] = kb[i] + (((i < NIN || i == 3) && a.depth_off[i]) ? a.depth_off[i][d] : 0);
+  if (NIN > 2 && a.gtab) ro[2] += a.gtab[(int64_t)(a.gk ? a.gk[key] : 0) * a.ngd + (a.gd ? a.gd[d] : 0)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// x summed away.  grid = nkey * nchunk blocks, block = 64..256 threads.
+template <class Op, int V>
+__global__ void __launch_bounds__(256) s1_xr_kernel(S1Args a) {
+  constexpr int NA = Op::NACC;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nwave = blockDim.x >> 6;
+  const int64_t b = blockIdx.x;
+  const int64_t key = b / a.nchunk;
+  const int chunk = (int)(b - key * a.nchunk);
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+
+  int64_t kb[WBX_MAX_INPUTS];
+  key_bases<Op::NIN>(a, key, kb);
+  double acc[1][NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) acc[0][l] = 0.0;
+
+  for (int64_t d = d0 + wave; d < d1; d += nwave) {
+    int64_t ro[WBX_MAX_INPUTS];
+    row_bases<Op::NIN>(a, kb, key, d, ro);
+#pragma unroll Op::XR_UNROLL
+    for (int64_t x = (int64_t)lane * V; x < a.nx; x += 64 * V) Op::template accum<V, false>(a, ro, x, acc);
+  }
+
+  __shared__ double red[4][NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) {
+    double v = wave_sum(acc[0][l]);
+    if (lane == 0) red[wave][l] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NA) {
+    double s = 0.0;
+    for (int w = 0; w < nwave; ++w) s += red[w][threadIdx.x];
+    a.out[(key * a.nchunk + chunk) * NA + threadIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// x kept.  grid = nkey * nxtile * nchunk blocks; a block covers blockDim*V consecutive x.
+template <class Op, int V>
+__global__ void __launch_bounds__(256) s1_xk_kernel(S1Args a) {
+  constexpr int NA = Op::NACC;
+  int64_t b = blockIdx.x;
+  const int chunk = (int)(b % a.nchunk);
+  b /= a.nchunk;
+  const int xt = (int)(b % a.nxtile);
+  const int64_t key = b / a.nxtile;
+  const int64_t x = ((int64_t)xt * blockDim.x + threadIdx.x) * V;
+  if (x >= a.nx) return;
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+
+  int64_t kb[WBX_MAX_INPUTS];
+  key_bases<Op::NIN>(a, key, kb);
+  double acc[V][NA];
+#pragma unroll
+  for (int k = 0; k < V; ++k)
+#pragma unroll
+    for (int l = 0; l < NA; ++l) acc[k][l] = 0.0;
+
+#pragma unroll Op::XK_UNROLL
+  for (int64_t d = d0; d < d1; ++d) {
+    int64_t ro[WBX_MAX_INPUTS];
+    row_bases<Op::NIN>(a, kb, key, d, ro);
+    Op::template accum<V, true>(a, ro, x, acc);
+  }
+  double* o = a.out + ((key * a.nchunk + chunk) * NA) * a.nx + x;
+#pragma unroll
+  for (int l = 0; l < NA; ++l)
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[(int64_t)l * a.nx + k] = acc[k][l];
+}
+
+// ---------------------------------------------------------------------------------------------
+// materialise one lane: out[key][d][x].  grid = nkey * D * nxtile.
+template <class Op>
+__global__ void __launch_bounds__(256) s1_map_kernel(S1Args a) {
+  int64_t b = blockIdx.x;
+  const int xt = (int)(b % a.nxtile);
+  b /= a.nxtile;
+  const int64_t d = b % a.D;
+  const int64_t key = b / a.D;
+  const int64_t x = (int64_t)xt * blockDim.x + threadIdx.x;
+  if (x >= a.nx) return;
+  int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
+  key_bases<Op::NIN>(a, key, kb);
+  row_bases<Op::NIN>(a, kb, key, d, ro);
+  double val[Op::NLANE];
+  Op::values(a, ro, x, val);
+  double r = 0.0;
+#pragma unroll
+  for (int l = 0; l < Op::NLANE; ++l)
+    if (l == a.lane) r = val[l];
+  a.out[(key * a.D + d) * a.nx + x] = r;
+}
+
+inline int fill_args(const wbx_s1_plan* plan, S1Args& a) {
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i) {
+    a.key_off[i] = plan->key_off[i];
+    a.depth_off[i] = plan->depth_off[i];
+    a.xstride[i] = plan->xstride[i];
+  }
+  a.gk = plan->gather_key;
+  a.gd = plan->gather_depth;
+  a.gtab = plan->gather_tab;
+  a.ngd = plan->n_gather_depth > 0 ? plan->n_gather_depth : 1;
+  a.nkey = plan->nkey;
+  a.D = plan->ndepth;
+  a.nx = plan->nx;
+  a.dchunk = plan->depth_chunk;
+  a.nchunk = plan->nchunk;
+  a.flags = plan->flags;
+  return 0;
+}
+
+inline int check_plan(const wbx_s1_plan* p) {
+  WBX_REQUIRE(p != nullptr, "plan is NULL");
+  WBX_REQUIRE(p->nkey >= 0 && p->ndepth >= 0 && p->nx >= 0, "negative plan extent");
+  WBX_REQUIRE(p->nchunk >= 1 && p->depth_chunk >= 1, "nchunk/depth_chunk must be >= 1");
+  WBX_REQUIRE((int64_t)p->nchunk * p->depth_chunk >= p->ndepth, "chunks do not cover depth");
+  WBX_REQUIRE(p->block_threads == 64 || p->block_threads == 128 || p->block_threads == 256,
+              "block_threads must be 64, 128 or 256 (got %d)", p->block_threads);
+  WBX_REQUIRE(p->vec == 1 || p->vec == 4, "vec must be 1 or 4 (got %d)", p->vec);
+  if (p->vec == 4) {
+    WBX_REQUIRE(p->nx % 4 == 0, "vec=4 needs nx %% 4 == 0");
+    for (int i = 0; i < 3; ++i)
+      WBX_REQUIRE(p->xstride[i] == 0 || p->xstride[i] == 1, "vec=4 needs unit/zero x strides");
+  }
+  return 0;
+}
+
+// Launch helpers -----------------------------------------------------------------------------
+template <class Op, int V>
+int launch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  if (plan->nkey == 0) return 0;
+  const int64_t nj = plan->x_kept ? plan->nx : 1;
+  if (plan->ndepth == 0 || plan->nx == 0) {
+    // empty reduction: sums are zero
+    size_t n = (size_t)plan->nkey * plan->nchunk * Op::NACC * (size_t)nj;
+    if (n) WBX_HIP(hipMemsetAsync(a.out, 0, n * sizeof(double), ctx->stream));
+    return 0;
+  }
+  if (plan->x_kept) {
+    const int64_t per_block = (int64_t)plan->block_threads * V;
+    a.nxtile = (int)((plan->nx + per_block - 1) / per_block);
+    const int64_t grid = plan->nkey * a.nxtile * plan->nchunk;
+    WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+    hipLaunchKernelGGL((s1_xk_kernel<Op, V>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a);
+  } else {
+    const int64_t grid = plan->nkey * plan->nchunk;
+    WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+    hipLaunchKernelGGL((s1_xr_kernel<Op, V>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a);
+  }
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <class Op>
+int launch_map(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return 0;
+  a.nxtile = (int)((plan->nx + 255) / 256);
+  const int64_t grid = plan->nkey * plan->ndepth * a.nxtile;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+  hipLaunchKernelGGL((s1_map_kernel<Op>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace wbx

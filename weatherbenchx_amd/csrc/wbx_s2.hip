@@ -1,0 +1,130 @@
+// Stage 2: weighted / binned contraction of the stage-1 partial sums.
+//
+// Replaces the weight- and bin-mask operands of the reference's single xr.dot
+// (weatherbenchX/aggregation.py:311-335): W = prod(weights) * prod(bin masks) is built once per
+// (aggregator, grid) on the host in float64 (O(lat*lon*bins), data independent) and contracted here.
+// The products are plain multiply-adds with no zero skipping, so a NaN partial poisons every bin
+// (NaN * 0 = NaN) exactly as documented at aggregation.py:272-277.
+//
+//   partial [nA][nBk][nBr][nchunk][nlane][nj]      W [nBk][nBr][nj][nbin]
+//   sum_j=1: out[nA][nBk][nlane][nbin]     = sum_{Br,chunk,j}
+//   sum_j=0: out[nA][nBk][nlane][nj][nbin] = sum_{Br,chunk}
+// Summation order is fixed by the launch geometry, so results are run-to-run reproducible.
+#include "wbx_s1.hpp"
+
+namespace wbx {
+
+constexpr int BG = 8;  // bins per register group
+
+// one block per (A, Bk, lane); threads stride over the flattened (Br, chunk, j) contraction.
+__global__ void __launch_bounds__(256) s2_sumj_kernel(wbx_s2_plan p, const double* __restrict__ partial,
+                                                      const double* __restrict__ W, double* __restrict__ out) {
+  int64_t b = blockIdx.x;
+  const int64_t lane = b % p.nlane;
+  b /= p.nlane;
+  const int64_t bk = b % p.nBk;
+  const int64_t A = b / p.nBk;
+  const int64_t ncj = p.nchunk * p.nj;
+  const int64_t ncontr = p.nBr * ncj;
+  const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ double red[4][BG];
+  const double* pbase = partial + (A * p.nBk + bk) * p.nBr * p.nchunk * p.nlane * p.nj;
+  const double* wbase = W + bk * p.nBr * p.nj * p.nbin;
+  for (int64_t b0 = 0; b0 < p.nbin; b0 += BG) {
+    double acc[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) acc[g] = 0.0;
+    for (int64_t c = threadIdx.x; c < ncontr; c += blockDim.x) {
+      const int64_t br = c / ncj;
+      const int64_t r = c - br * ncj;
+      const int64_t ch = r / p.nj;
+      const int64_t j = r - ch * p.nj;
+      const double v = pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
+      const double* w = wbase + (br * p.nj + j) * p.nbin + b0;
+#pragma unroll
+      for (int g = 0; g < BG; ++g)
+        if (b0 + g < p.nbin) acc[g] += v * w[g];
+    }
+#pragma unroll
+    for (int g = 0; g < BG; ++g) {
+      double s = wave_sum(acc[g]);
+      if (tl == 0) red[wv][g] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < BG && b0 + threadIdx.x < p.nbin) {
+      double s = 0.0;
+      for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) s += red[w2][threadIdx.x];
+      out[((A * p.nBk + bk) * p.nlane + lane) * p.nbin + b0 + threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// thread per j; grid = nA * nBk * nlane * njtile.
+__global__ void __launch_bounds__(256) s2_keepj_kernel(wbx_s2_plan p, int njtile, const double* __restrict__ partial,
+                                                       const double* __restrict__ W, double* __restrict__ out) {
+  int64_t b = blockIdx.x;
+  const int64_t jt = b % njtile;
+  b /= njtile;
+  const int64_t lane = b % p.nlane;
+  b /= p.nlane;
+  const int64_t bk = b % p.nBk;
+  const int64_t A = b / p.nBk;
+  const int64_t j = jt * blockDim.x + threadIdx.x;
+  if (j >= p.nj) return;
+  const double* pbase = partial + (A * p.nBk + bk) * p.nBr * p.nchunk * p.nlane * p.nj;
+  const double* wbase = W + bk * p.nBr * p.nj * p.nbin;
+  double* obase = out + ((((A * p.nBk + bk) * p.nlane + lane) * p.nj) + j) * p.nbin;
+  for (int64_t b0 = 0; b0 < p.nbin; b0 += BG) {
+    double acc[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) acc[g] = 0.0;
+    for (int64_t br = 0; br < p.nBr; ++br) {
+      const double* w = wbase + (br * p.nj + j) * p.nbin + b0;
+      for (int64_t ch = 0; ch < p.nchunk; ++ch) {
+        const double v = pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
+#pragma unroll
+        for (int g = 0; g < BG; ++g)
+          if (b0 + g < p.nbin) acc[g] += v * w[g];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < BG; ++g)
+      if (b0 + g < p.nbin) obase[b0 + g] = acc[g];
+  }
+}
+
+}  // namespace wbx
+
+extern "C" int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* W,
+                            double* out) {
+  WBX_REQUIRE(ctx != nullptr && plan != nullptr, "ctx/plan is NULL");
+  const wbx_s2_plan& p = *plan;
+  WBX_REQUIRE(p.nA >= 0 && p.nBk >= 0 && p.nBr >= 0 && p.nchunk >= 0 && p.nlane >= 0 && p.nj >= 0 && p.nbin >= 0,
+              "negative extent in stage-2 plan");
+  const int64_t nout = p.nA * p.nBk * p.nlane * (p.sum_j ? 1 : p.nj) * p.nbin;
+  if (nout == 0) return 0;
+  WBX_REQUIRE(out != nullptr, "out is NULL");
+  WBX_HIP(hipSetDevice(ctx->device));
+  if (p.nBr * p.nchunk * (p.sum_j ? p.nj : 1) == 0) {
+    WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
+    return 0;
+  }
+  WBX_REQUIRE(partial != nullptr && W != nullptr, "partial/W is NULL");
+  if (p.sum_j) {
+    const int64_t grid = p.nA * p.nBk * p.nlane;
+    WBX_REQUIRE(grid < (int64_t)1 << 31, "stage-2 grid too large");
+    const int64_t ncontr = p.nBr * p.nchunk * p.nj;
+    const int threads = ncontr >= 256 ? 256 : (ncontr >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(wbx::s2_sumj_kernel, dim3((unsigned)grid), dim3(threads), 0, ctx->stream, p, partial, W, out);
+  } else {
+    const int threads = p.nj >= 256 ? 256 : (p.nj >= 128 ? 128 : 64);
+    const int njtile = (int)((p.nj + threads - 1) / threads);
+    const int64_t grid = p.nA * p.nBk * p.nlane * njtile;
+    WBX_REQUIRE(grid < (int64_t)1 << 31, "stage-2 grid too large");
+    hipLaunchKernelGGL(wbx::s2_keepj_kernel, dim3((unsigned)grid), dim3(threads), 0, ctx->stream, p, njtile, partial,
+                       W, out);
+  }
+  WBX_HIP(hipGetLastError());
+  return 0;
+}

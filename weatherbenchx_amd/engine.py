@@ -1,0 +1,301 @@
+"""Runs planned reductions on the device through the C ABI (the only place compute is launched).
+
+reduce_statistics()  = stage 1 (wbx_det_partial / wbx_ens_partial) + stage 2 (wbx_contract)
+materialise()        = wbx_det_map / wbx_ens_map (full-resolution statistic, on demand)
+
+Inputs may be host numpy arrays (uploaded once and cached on the DataArray object) or torch
+tensors already resident in HBM (consumed in place through their strides: no copy, no transpose).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import planner
+from weatherbenchx_amd import xarray_lite as xr
+
+_is_torch = xr._is_torch  # pylint: disable=protected-access
+
+
+class _Dev:
+  """A device-resident input: pointer + layout (+ whatever keeps the memory alive)."""
+
+  def __init__(self, ptr, layout, dtype_code, keep, nbytes):
+    self.ptr, self.layout, self.dtype_code, self.keep, self.nbytes = ptr, layout, dtype_code, keep, nbytes
+
+
+def _sync_torch_producers(arrays):
+  for a in arrays:
+    if a is not None and _is_torch(a) and a.is_cuda:
+      import torch  # pylint: disable=g-import-not-at-top
+      torch.cuda.current_stream(a.device).synchronize()
+      return
+
+
+def _common_dtype(datas) -> int:
+  f64 = False
+  for d in datas:
+    if d is None:
+      continue
+    name = str(d.dtype).replace('torch.', '')
+    if name != 'float32':
+      f64 = True
+  return _hip.F64 if f64 else _hip.F32
+
+
+def _to_device(ctx: _hip.Context, da: xr.DataArray, dtype_code: int) -> _Dev:
+  """Device view of a DataArray's payload in dtype `dtype_code` (cached per object and dtype)."""
+  cache = da.__dict__.setdefault('_wbx_dev', {})
+  if dtype_code in cache:
+    return cache[dtype_code]
+  data = da.data
+  want = np.float32 if dtype_code == _hip.F32 else np.float64
+  if _is_torch(data) and data.is_cuda:
+    import torch  # pylint: disable=g-import-not-at-top
+    tdt = torch.float32 if dtype_code == _hip.F32 else torch.float64
+    t = data if data.dtype == tdt else data.to(tdt)
+    if t is not data:
+      torch.cuda.current_stream(t.device).synchronize()
+    lay = planner.layout_of(t, da.dims)
+    dev = _Dev(int(t.data_ptr()), lay, dtype_code, t, t.numel() * t.element_size())
+  else:
+    host = xr._to_numpy(data)  # pylint: disable=protected-access
+    host = np.ascontiguousarray(host, dtype=want)
+    buf = ctx.upload(host)
+    st = [int(s // host.itemsize) for s in host.strides] if host.ndim else []
+    lay = planner.InputLayout(strides=dict(zip(da.dims, st)), itemsize=host.itemsize, base_alignment=256)
+    dev = _Dev(buf.ptr, lay, dtype_code, buf, host.nbytes)
+  cache[dtype_code] = dev
+  return dev
+
+
+def _mask_to_device(ctx, mask: xr.DataArray) -> _Dev:
+  cache = mask.__dict__.setdefault('_wbx_dev', {})
+  if 'u8' in cache:
+    return cache['u8']
+  host = np.ascontiguousarray(xr._to_numpy(mask.data).astype(bool).astype(np.uint8))  # pylint: disable=protected-access
+  buf = ctx.upload(host)
+  st = [int(s) for s in host.strides] if host.ndim else []
+  dev = _Dev(buf.ptr, planner.InputLayout(strides=dict(zip(mask.dims, st)), itemsize=1, base_alignment=256),
+             'u8', buf, host.nbytes)
+  cache['u8'] = dev
+  return dev
+
+
+class _PlanOnDevice:
+  """ctypes plan struct + the device copies of its tables."""
+
+  def __init__(self, ctx: _hip.Context, plan: planner.S1Plan):
+    self.keep = []
+    s = _hip.S1PlanStruct()
+    s.nkey, s.ndepth, s.nx = plan.nkey, plan.ndepth, plan.nx
+    s.x_kept, s.nchunk, s.depth_chunk = int(plan.x_kept), plan.nchunk, plan.depth_chunk
+    for i in range(_hip.MAX_INPUTS):
+      s.xstride[i] = plan.xstride[i]
+      s.key_off[i] = self._up(ctx, plan.key_off[i])
+      s.depth_off[i] = self._up(ctx, plan.depth_off[i])
+    s.gather_key = self._up(ctx, plan.gather_key)
+    s.gather_depth = self._up(ctx, plan.gather_depth)
+    s.gather_tab = self._up(ctx, plan.gather_tab)
+    s.n_gather_depth = plan.n_gather_depth
+    s.flags = plan.flags
+    s.block_threads = plan.block_threads
+    s.vec = plan.vec
+    self.struct = s
+
+  def _up(self, ctx, tab):
+    if tab is None:
+      return None
+    buf = ctx.upload(np.ascontiguousarray(tab))
+    self.keep.append(buf)
+    return buf.ptr
+
+
+def _plan_signature(plan: planner.S1Plan):
+  def h(t):
+    return None if t is None else (t.shape, hash(t.tobytes()))
+  return (plan.dims, tuple(plan.sizes.items()), plan.x_dim, plan.x_kept, plan.a_dims, plan.bk_dims, plan.br_dims,
+          plan.depth_dims, plan.nchunk, plan.depth_chunk, tuple(plan.xstride), tuple(h(t) for t in plan.key_off),
+          tuple(h(t) for t in plan.depth_off), h(plan.gather_key), h(plan.gather_depth), h(plan.gather_tab),
+          plan.flags, plan.block_threads, plan.vec)
+
+
+_plan_cache: dict = {}
+_w_cache: dict = {}
+
+
+def _device_plan(ctx, plan: planner.S1Plan) -> _PlanOnDevice:
+  key = (ctx.device_id, _plan_signature(plan))
+  if key not in _plan_cache:
+    if len(_plan_cache) > 64:
+      _plan_cache.clear()
+    _plan_cache[key] = _PlanOnDevice(ctx, plan)
+  return _plan_cache[key]
+
+
+def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
+  """Dense W on the device, cached on the (aggregator-cached) labeled W object per stage-1 geometry."""
+  sig = (ctx.device_id, plan.bk_dims, plan.br_dims, plan.x_dim if plan.x_kept else None, plan.nj,
+         tuple(plan.sizes[d] for d in plan.bk_dims + plan.br_dims), tuple(bin_dims))
+  store = _w_cache if w_da is None else w_da.__dict__.setdefault('_wbx_w', {})
+  if sig not in store:
+    if len(store) > 32:
+      store.clear()
+    w, bin_shape = dense_w(plan, w_da, bin_dims)
+    store[sig] = (ctx.upload(w), w.shape, bin_shape)
+  return store[sig]
+
+
+def clear_caches():
+  _plan_cache.clear()
+  _w_cache.clear()
+
+
+def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Sequence[_Dev | None], dtype_code: int,
+            nlanes_total: int, func: int = 0, ens=None) -> _hip.DeviceBuffer:
+  n = int(np.prod(plan.partial_shape(nlanes_total), dtype=np.int64))
+  out = ctx.alloc(n * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  if kind == 'det':
+    _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                       ptr(devs[2]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_det_partial')
+  else:
+    m, mstride, algo = ens
+    _hip.check(ctx.lib.wbx_ens_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(algo),
+                                       ptr(devs[0]), ptr(devs[1]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
+  return out
+
+
+def _run_map(ctx, kind: str, dplan, plan: planner.S1Plan, devs, dtype_code: int, lane: int, func: int = 0,
+             ens=None) -> np.ndarray:
+  n = plan.nkey * plan.ndepth * plan.nx
+  out = ctx.alloc(n * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  if kind == 'det':
+    _hip.check(ctx.lib.wbx_det_map(ctx.handle, C.byref(dplan.struct), func, dtype_code, lane, ptr(devs[0]),
+                                   ptr(devs[1]), ptr(devs[2]), C.c_void_p(out.ptr)), 'wbx_det_map')
+  else:
+    m, mstride, algo = ens
+    _hip.check(ctx.lib.wbx_ens_map(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(algo),
+                                   lane, ptr(devs[0]), ptr(devs[1]), C.c_void_p(out.ptr)), 'wbx_ens_map')
+  return ctx.download(out.ptr, (n,), np.float64)
+
+
+def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
+  st = _hip.S2PlanStruct(s2.nA, s2.nBk, s2.nBr, s2.nchunk, s2.nlane, s2.nj, s2.nbin, int(s2.sum_j))
+  shape = s2.out_shape()
+  n = int(np.prod(shape, dtype=np.int64))
+  out = ctx.alloc(n * 8)
+  _hip.check(ctx.lib.wbx_contract(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.ptr),
+                                  C.c_void_p(out.ptr)), 'wbx_contract')
+  return ctx.download(out.ptr, shape, np.float64)
+
+
+def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
+  """W as float64 [nBk][nBr][nj][nbin] from the labeled product of weights and bin masks."""
+  bin_dims = tuple(bin_dims)
+  wd = plan.bk_dims + plan.br_dims + ((plan.x_dim,) if plan.x_kept and plan.x_dim is not None else ())
+  if w_da is None:
+    w_da = xr.DataArray(np.float64(1.0))
+  extra = [d for d in w_da.dims if d not in wd and d not in bin_dims]
+  if extra:
+    raise ValueError(f'weights/bin masks depend on dims {extra} that stage 1 does not keep')
+  shape_full = [plan.sizes[d] for d in wd] + [w_da.sizes[d] for d in bin_dims]
+  present = [d for d in list(wd) + list(bin_dims) if d in w_da.dims]
+  w = w_da.transpose(*present).values.astype(np.float64)
+  idx = tuple(slice(None) if d in w_da.dims else None for d in list(wd) + list(bin_dims))
+  w = np.broadcast_to(w[idx], shape_full)
+  nbin = int(np.prod([w_da.sizes[d] for d in bin_dims], dtype=np.int64)) if bin_dims else 1
+  w = np.ascontiguousarray(w.reshape(plan.n(plan.bk_dims), plan.n(plan.br_dims), plan.nj, nbin))
+  return w, tuple(w_da.sizes[d] for d in bin_dims)
+
+
+def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Sequence, sizes: dict, reduce_dims,
+                      w_da: xr.DataArray | None, bin_dims: Sequence, *, func: int = 0, mask: xr.DataArray | None = None,
+                      skipna: bool = False, gather: planner.GatherSpec | None = None, ens=None,
+                      ctx: _hip.Context | None = None):
+  """Fused statistics + weighted/binned reduction.
+
+  Returns (values, counts, out_dims): `values[lane]` is an ndarray over out_dims =
+  (A dims..., Bk dims..., [x dim], bin dims...); `counts` is the matching sum of W over valid
+  elements -- per lane when mask/skipna is active, else a single array shared by every lane.
+  """
+  ctx = ctx or _hip.default_context()
+  wdep = set(w_da.dims) - set(bin_dims) if w_da is not None else set()
+  member_dim = ens['member_dim'] if ens else None
+  datas = [i.data if i is not None else None for i in inputs]
+  dtype_code = _common_dtype(datas)
+  _sync_torch_producers(datas)
+  devs = [(_to_device(ctx, i, dtype_code) if i is not None else None) for i in inputs]
+  while len(devs) < 4:
+    devs.append(None)
+  flags = 0
+  if mask is not None:
+    flags |= _hip.FLAG_MASKED
+    devs[3] = _mask_to_device(ctx, mask)
+  if skipna:
+    flags |= _hip.FLAG_SKIPNA
+  if ens and ens.get('fair', True):
+    flags |= _hip.FLAG_FAIR
+  layouts = [d.layout if d is not None else None for d in devs]
+  plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
+                               allow_vec4=(kind == 'det'))
+  nl = _hip.DET_LANES[func] if kind == 'det' else _hip.ENS_LANES
+  counted = bool(flags & 3)
+  nl_total = nl * (2 if counted else 1)
+  dplan = _device_plan(ctx, plan)
+  ens_args = None
+  if kind == 'ens':
+    ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
+  partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args)
+  w_buf, w_shape, bin_shape = _device_w(ctx, plan, w_da, bin_dims)
+  s2 = planner.build_s2_plan(plan, nl_total, w_shape[-1])
+  out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
+
+  x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()
+  out_dims = plan.a_dims + plan.bk_dims + x_out + tuple(bin_dims)
+  lead_shape = [plan.sizes[d] for d in plan.a_dims] + [plan.sizes[d] for d in plan.bk_dims]
+  tail_shape = [plan.sizes[d] for d in x_out] + list(bin_shape)
+
+  def lane_array(l):
+    return out[:, :, l].reshape(lead_shape + tail_shape)
+
+  values = [lane_array(l) for l in range(nl)]
+  if counted:
+    counts = [lane_array(nl + l) for l in range(nl)]
+  else:
+    # data-independent: (elements folded per partial) * sum of W, computed by the same stage-2 kernel
+    ones = np.full((1, s2.nBk, s2.nBr, 1, 1, s2.nj), float(plan.reduced_count_per_partial()), dtype=np.float64)
+    s2c = planner.S2Plan(nA=1, nBk=s2.nBk, nBr=s2.nBr, nchunk=1, nlane=1, nj=s2.nj, nbin=s2.nbin, sum_j=s2.sum_j)
+    ones_buf = ctx.upload(ones)
+    cnt = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
+    cnt = np.broadcast_to(cnt[:, :, 0], (s2.nA,) + cnt[:, :, 0].shape[1:]).reshape(lead_shape + tail_shape)
+    counts = [cnt] * nl
+  return values, counts, out_dims
+
+
+def materialise(kind: str, inputs: Sequence[xr.DataArray | None], dims: Sequence, sizes: dict, lane: int, *,
+                func: int = 0, gather: planner.GatherSpec | None = None, ens=None,
+                ctx: _hip.Context | None = None) -> np.ndarray:
+  """Full-resolution statistic (one lane) as a float64 ndarray over `dims`."""
+  ctx = ctx or _hip.default_context()
+  datas = [i.data if i is not None else None for i in inputs]
+  dtype_code = _common_dtype(datas)
+  _sync_torch_producers(datas)
+  devs = [(_to_device(ctx, i, dtype_code) if i is not None else None) for i in inputs]
+  while len(devs) < 4:
+    devs.append(None)
+  layouts = [d.layout if d is not None else None for d in devs]
+  flags = _hip.FLAG_FAIR if (ens and ens.get('fair', True)) else 0
+  plan = planner.build_s1_plan(dims, sizes, layouts, (), gather=gather, flags=flags, allow_vec4=False, map_mode=True)
+  dplan = _device_plan(ctx, plan)
+  ens_args = None
+  if kind == 'ens':
+    ens_args = (ens['M'], devs[0].layout.stride(ens['member_dim']), ens['algo'])
+  flat = _run_map(ctx, kind, dplan, plan, devs, dtype_code, int(lane), func=func, ens=ens_args)
+  order = plan.key_dims + plan.depth_dims + ((plan.x_dim,) if plan.x_dim is not None else ())
+  arr = flat.reshape([plan.sizes[d] for d in order])
+  return np.transpose(arr, [order.index(d) for d in dims]) if tuple(order) != tuple(dims) else arr

@@ -1,0 +1,309 @@
+"""Deferred per-point statistics: how an unfused plugin API is lowered to fused kernels.
+
+The reference contract is "Statistic.compute returns a full-resolution array, the Aggregator reduces it"
+(weatherbenchX/metrics/base.py:135-158, weatherbenchX/aggregation.py:337-366).  Materialising that
+array on the GPU would double HBM traffic, so the built-in statistics return a `LazyStatistic`: a
+DataArray (dims, coords, mask coordinate all present) whose payload is only computed -- by the HIP map
+kernel -- if somebody actually reads `.data`/`.values`.  Statistics built from the same
+(predictions, targets[, climatology]) arrays share one `FusedGroup`; the Aggregator asks the group for
+all lanes at once, which is one stage-1 launch that reads every input exactly once.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Sequence
+
+import numpy as np
+
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import planner
+from weatherbenchx_amd import xarray_lite as xr
+
+DET_LANE = {'Error': 0, 'AbsoluteError': 1, 'SquaredError': 2, 'SquaredPredictionAnomaly': 3,
+            'SquaredTargetAnomaly': 4, 'AnomalyCovariance': 5}
+ENS_LANE = {'CRPSSkill': 0, 'CRPSSpread': 1, 'EnsembleVariance': 2, 'UnbiasedEnsembleMeanSquaredError': 3,
+            'EnsembleMeanSquaredError': 4}
+
+
+def _stat_frame(arrays: Sequence[xr.DataArray], drop_dims=()):
+  """dims / sizes / coords of the broadcast of `arrays` (what `a - b` would carry), without computing it."""
+  dims, sizes = [], {}
+  for a in arrays:
+    for d, n in a.sizes.items():
+      if d in drop_dims:
+        continue
+      if d not in dims:
+        dims.append(d)
+        sizes[d] = n
+      elif sizes[d] != n:
+        raise ValueError(f'cannot broadcast: size mismatch along {d!r} ({sizes[d]} vs {n})')
+  coords = {}
+  dropped = set()
+  for a in arrays:
+    for k, (cd, cv) in a._coords.items():  # pylint: disable=protected-access
+      if set(cd) & set(drop_dims) or k in dropped:
+        continue
+      if k in coords:
+        d0, v0 = coords[k]
+        if d0 != cd or not xr._values_equal(v0, cv):  # pylint: disable=protected-access
+          if k in dims:
+            raise _NeedsAlignment(k)
+          del coords[k]
+          dropped.add(k)
+      else:
+        coords[k] = (cd, cv)
+  return tuple(dims), sizes, coords
+
+
+class _NeedsAlignment(Exception):
+  pass
+
+
+class ClimatologyRef:
+  """Climatology variable + the positions selected by valid_time (metrics/base.py:382-403)."""
+
+  def __init__(self, source: xr.DataArray, over_dims: tuple, positions: dict):
+    self.source = source          # dims e.g. (dayofyear, hour, level, latitude, longitude)
+    self.over_dims = over_dims    # statistic dims the selection varies over, e.g. (init_time, lead_time)
+    self.positions = positions    # climatology dim -> int positions, shape = sizes of over_dims
+
+  def aligned_dims(self):
+    return self.over_dims + tuple(d for d in self.source.dims if d not in self.positions)
+
+  def aligned_view(self) -> xr.DataArray:
+    """The aligned climatology as a labeled array (only used when the gather cannot be fused)."""
+    src = self.source
+    order =[src.dims.index(d) for d in self.positions] + [i for i, d in enumerate(src.dims) if d not in self.positions]
+    data = xr._transpose(src.data, order)  # pylint: disable=protected-access
+    gather = tuple(np.asarray(self.positions[d]).reshape(-1) for d in self.positions)
+    if xr._is_torch(data):  # pylint: disable=protected-access
+      import torch  # pylint: disable=g-import-not-at-top
+      gather = tuple(torch.as_tensor(g, device=data.device) for g in gather)
+    g = data[gather]
+    shape = tuple(np.asarray(next(iter(self.positions.values()))).shape)
+    g = g.reshape(shape + tuple(xr._shape(g)[1:]))  # pylint: disable=protected-access
+    coords = {k: v for k, v in src._coords.items() if not set(v[0]) & set(self.positions)}  # pylint: disable=protected-access
+    return xr.DataArray(g, dims=self.aligned_dims(), coords=coords, _raw_coords=True)
+
+
+class FusedGroup:
+  """All fused statistics over one (predictions, targets[, climatology]) triple."""
+
+  def __init__(self, kind: str, p: xr.DataArray, t: xr.DataArray, ens=None):
+    self.kind = kind
+    self.p, self.t = p, t
+    self.ens = ens  # {'member_dim', 'M'}
+    self.clim: ClimatologyRef | None = None
+    self._clim_key = None
+    drop = (ens['member_dim'],) if ens else ()
+    self.dims, self.sizes, self.coords = _stat_frame([p, t], drop_dims=drop)
+    self.cache: dict = {}
+
+  def attach_climatology(self, ref: ClimatologyRef, key) -> bool:
+    if self.clim is None:
+      # frame check: aligned climatology dims must already be statistic dims (it only broadcasts)
+      for d in ref.aligned_dims():
+        if d not in self.dims:
+          return False
+      for d in ref.source.dims:
+        if d in self.dims and d in ref.source._coords and d in self.coords:  # pylint: disable=protected-access
+          if not xr._values_equal(ref.source._coords[d][1], self.coords[d][1]):  # pylint: disable=protected-access
+            return False
+      self.clim, self._clim_key = ref, key
+      return True
+    return self._clim_key == key
+
+  @property
+  def mask(self) -> xr.DataArray | None:
+    if 'mask' in self.coords:
+      cd, cv = self.coords['mask']
+      return xr.DataArray(np.asarray(cv), dims=cd)
+    return None
+
+  # -- execution ---------------------------------------------------------------------------------
+  def _gather(self):
+    """planner.GatherSpec + the climatology array as device input (layout-dependent, so built lazily)."""
+    return self.clim
+
+  def inputs_and_func(self):
+    if self.kind == 'ens':
+      return [self.p, self.t], 0
+    if self.clim is not None:
+      return [self.p, self.t, self.clim.source], _hip.DET6
+    return [self.p, self.t], _hip.DET3
+
+  def reduce(self, reduce_dims, w_da, bin_dims, *, use_mask: bool, skipna: bool, ens_params=None, extra_reduce=()):
+    inputs, func = self.inputs_and_func()
+    mask = self.mask if use_mask else None
+    ens = None
+    if self.kind == 'ens':
+      ens = dict(self.ens, **(ens_params or {}))
+    return _reduce_with_gather(self.kind, inputs, self.dims, self.sizes, tuple(reduce_dims) + tuple(extra_reduce), w_da,
+                               bin_dims, func=func, mask=mask, skipna=skipna, clim=self.clim, ens=ens)
+
+  def materialise(self, lane: int, ens_params=None) -> np.ndarray:
+    inputs, func = self.inputs_and_func()
+    ens = dict(self.ens, **(ens_params or {})) if self.kind == 'ens' else None
+    gather, inputs = _gather_spec(self.clim, inputs, self.dims)
+    return engine.materialise(self.kind, inputs, self.dims, self.sizes, lane, func=func, gather=gather, ens=ens)
+
+
+def _gather_spec(clim: ClimatologyRef | None, inputs, dims):
+  """Element-offset gather table for the climatology input, from its device layout."""
+  if clim is None:
+    return None, inputs
+  ctx = _hip.default_context()
+  datas = [i.data for i in inputs]
+  dtype_code = engine._common_dtype(datas)  # pylint: disable=protected-access
+  dev = engine._to_device(ctx, clim.source, dtype_code)  # pylint: disable=protected-access
+  table = np.zeros(tuple(np.asarray(next(iter(clim.positions.values()))).shape), dtype=np.int64)
+  for d, pos in clim.positions.items():
+    table = table + np.asarray(pos, dtype=np.int64) * dev.layout.stride(d)
+  return planner.GatherSpec(dims=tuple(clim.over_dims), table=table), inputs
+
+
+def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, *, func, mask, skipna, clim, ens):
+  gather, inputs = _gather_spec(clim, inputs, dims)
+  try:
+    return engine.reduce_statistics(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, func=func, mask=mask,
+                                    skipna=skipna, gather=gather, ens=ens)
+  except ValueError as e:
+    if clim is None or 'innermost' not in str(e):
+      raise
+    # the selection runs along the contiguous dim: align the climatology first, then fuse as usual
+    aligned = clim.aligned_view()
+    inputs = list(inputs[:2]) + [aligned]
+    return engine.reduce_statistics(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, func=func, mask=mask,
+                                    skipna=skipna, gather=None, ens=ens)
+
+
+def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=None) -> FusedGroup:
+  """The FusedGroup shared by every statistic built from these very (p, t) objects."""
+  table = p.__dict__.setdefault('_wbx_groups', {})
+  key = (kind, id(t), ens['member_dim'] if ens else None, clim_key)
+  hit = table.get(key)
+  if hit is not None and hit[0]() is t:
+    return hit[1]
+  grp = FusedGroup(kind, p, t, ens=ens)
+  table[key] = (weakref.ref(t), grp)
+  return grp
+
+
+class LazyStatistic(xr.DataArray):
+  """A per-point statistic that is a DataArray in every respect, evaluated on demand by a HIP kernel."""
+
+  def __init__(self, group: FusedGroup, lane: int, name=None, ens_params=None, mean_dims=()):
+    # deliberately no super().__init__: the payload does not exist yet
+    self._data = None
+    self._dims = tuple(d for d in group.dims if d not in mean_dims)
+    self.name = name
+    self.attrs = {}
+    dset = set(self._dims)
+    self._coords = {k: v for k, v in group.coords.items() if set(v[0]) <= dset}
+    self._group = group
+    self._lane = lane
+    self._ens_params = ens_params
+    self._mean_dims = tuple(mean_dims)
+
+  @property
+  def is_lazy(self) -> bool:
+    return self._data is None
+
+  @property
+  def data(self):
+    if self._data is None:
+      arr = self._group.materialise(self._lane, self._ens_params)
+      if self._mean_dims:
+        axes = tuple(self._group.dims.index(d) for d in self._mean_dims)
+        arr = arr.mean(axis=axes)
+      self._data = arr
+    return self._data
+
+  @property
+  def shape(self):
+    return tuple(self._group.sizes[d] for d in self._dims)
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)
+
+  def mean(self, dim=None, skipna=None, **kw):
+    """Mean over a dim that nothing else depends on stays lazy (EnsembleAveragedStatistic,
+    probabilistic.py:35-69): it becomes one more reduced dim of the fused launch."""
+    dims = (dim,) if isinstance(dim, str) else tuple(dim or ())
+    if (self.is_lazy and dims and not skipna and all(d in self._dims for d in dims)
+        and self._group.kind == 'det'):
+      return LazyStatistic(self._group, self._lane, name=self.name, ens_params=self._ens_params,
+                           mean_dims=self._mean_dims + dims)
+    return super().mean(dim, skipna=skipna, **kw)
+
+
+class LazyEnsembleMean(xr.DataArray):
+  """`predictions.mean(ensemble_dim)` (wrappers.py:116-148) that remembers where it came from, so
+  SquaredError of it is served by the ensemble kernel's lane 4 without a second pass over the members."""
+
+  def __init__(self, source: xr.DataArray, ensemble_dim: str):
+    self._data = None
+    self._dims = tuple(d for d in source.dims if d != ensemble_dim)
+    self.name = source.name
+    self.attrs = dict(source.attrs)
+    dset = set(self._dims)
+    self._coords = {k: v for k, v in source._coords.items() if set(v[0]) <= dset}  # pylint: disable=protected-access
+    self._source = source
+    self._ensemble_dim = ensemble_dim
+
+  @property
+  def is_lazy(self) -> bool:
+    return self._data is None
+
+  @property
+  def data(self):
+    if self._data is None:
+      self._data = xr.DataArray.mean(self._source, self._ensemble_dim, skipna=False).data
+    return self._data
+
+  @property
+  def shape(self):
+    return tuple(self._source.sizes[d] for d in self._dims)
+
+  @property
+  def dtype(self):
+    return self._source.dtype
+
+
+# ---- constructors used by the metric classes ---------------------------------------------------------
+def _aligned(p: xr.DataArray, t: xr.DataArray):
+  try:
+    _stat_frame([p, t])
+    return p, t
+  except _NeedsAlignment:
+    return xr.align(p, t, join='inner')
+
+
+def det_statistic(stat_name: str, p, t, climatology_ref: ClimatologyRef | None = None, clim_key=None) -> xr.DataArray:
+  p, t = xr.as_dataarray(p), xr.as_dataarray(t)
+  if isinstance(p, LazyEnsembleMean) and p.is_lazy and stat_name == 'SquaredError':
+    return ens_statistic('EnsembleMeanSquaredError', p._source, t, p._ensemble_dim)  # pylint: disable=protected-access
+  p, t = _aligned(p, t)
+  # one group per (p, t): Error/AbsoluteError/SquaredError and the anomaly statistics of the FIRST
+  # climatology share a launch; a second, different climatology gets its own group.
+  grp = _group_for('det', p, t)
+  if climatology_ref is not None and not grp.attach_climatology(climatology_ref, clim_key):
+    grp = _group_for('det', p, t, clim_key=clim_key)
+    if not grp.attach_climatology(climatology_ref, clim_key):
+      raise ValueError('climatology does not broadcast against predictions/targets '
+                       f'(climatology dims {climatology_ref.aligned_dims()}, statistic dims {grp.dims})')
+  return LazyStatistic(grp, DET_LANE[stat_name], name=p.name)
+
+
+def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fair=True) -> xr.DataArray:
+  p, t = xr.as_dataarray(p), xr.as_dataarray(t)
+  if ensemble_dim not in p.dims:
+    raise ValueError(f'Dimension {ensemble_dim} not found in {p.dims}')
+  if ensemble_dim in t.dims:
+    raise NotImplementedError('targets with an ensemble dimension are not fused yet (SURVEY 8f-3)')
+  m = p.sizes[ensemble_dim]
+  grp = _group_for('ens', p, t, ens={'member_dim': ensemble_dim, 'M': m})
+  params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair)}
+  return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params)

@@ -1,0 +1,213 @@
+"""Deterministic statistics and metrics (counterpart of weatherbenchX/metrics/deterministic.py:91-425).
+
+Per-point arithmetic lives in csrc/wbx_det.hip; the classes here only name the lane they need.
+"""
+from __future__ import annotations
+
+from collections.abc import Hashable
+from typing import Mapping, Sequence, Union
+
+import numpy as np
+
+from weatherbenchx_amd import lazy
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd import xarray_tree
+from weatherbenchx_amd.metrics import base
+
+
+def _sqrt(da: xr.DataArray) -> xr.DataArray:
+  return np.sqrt(da)
+
+
+class Error(base.PerVariableStatistic):
+  """predictions - targets (deterministic.py:91-100)."""
+
+  def _compute_per_variable(self, predictions, targets):
+    return lazy.det_statistic('Error', predictions, targets)
+
+
+class AbsoluteError(base.PerVariableStatistic):
+  """|predictions - targets| (deterministic.py:103-112)."""
+
+  def _compute_per_variable(self, predictions, targets):
+    return lazy.det_statistic('AbsoluteError', predictions, targets)
+
+
+class SquaredError(base.PerVariableStatistic):
+  """(predictions - targets)**2 (deterministic.py:115-123)."""
+
+  def _compute_per_variable(self, predictions, targets):
+    return lazy.det_statistic('SquaredError', predictions, targets)
+
+
+class PredictionPassthrough(base.PerVariableStatistic):
+  """Predictions carried through with the targets' coordinates (deterministic.py:126-147)."""
+
+  def __init__(self, copy_nans_from_targets: bool = False):
+    self._copy_nans_from_targets = copy_nans_from_targets
+
+  def _compute_per_variable(self, predictions, targets):
+    out = predictions + xr.zeros_like(targets)
+    return out.where(~targets.isnull()) if self._copy_nans_from_targets else out
+
+
+class TargetPassthrough(base.PerVariableStatistic):
+  """Targets carried through with the predictions' coordinates (deterministic.py:150-171)."""
+
+  def __init__(self, copy_nans_from_predictions: bool = False):
+    self._copy_nans_from_predictions = copy_nans_from_predictions
+
+  def _compute_per_variable(self, predictions, targets):
+    out = targets + xr.zeros_like(predictions)
+    return out.where(~predictions.isnull()) if self._copy_nans_from_predictions else out
+
+
+class _SumOfStatistics(xr.DataArray):
+  """Marker for `a + b` of two lazy statistics (wind vector SE): the Aggregator reduces the terms
+  separately -- the reduction is linear -- and adds the accumulators."""
+
+  def __init__(self, terms):
+    first = terms[0]
+    self._data = None
+    self._dims = first.dims
+    self.name = None
+    self.attrs = {}
+    self._coords = dict(first._coords)  # pylint: disable=protected-access
+    self._terms = list(terms)
+
+  @property
+  def is_lazy(self):
+    return self._data is None
+
+  @property
+  def data(self):
+    if self._data is None:
+      total = self._terms[0].data
+      for t in self._terms[1:]:
+        total = total + t.data
+      self._data = total
+    return self._data
+
+  @property
+  def shape(self):
+    return self._terms[0].shape
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)
+
+
+class WindVectorSquaredError(base.Statistic):
+  """(u_p - u_t)**2 + (v_p - v_t)**2 per (u, v, name) triple (deterministic.py:174-219)."""
+
+  def __init__(self, u_name: Sequence[str], v_name: Sequence[str], vector_name: Sequence[str]):
+    self._u_name, self._v_name, self._vector_name = u_name, v_name, vector_name
+    if not len(u_name) == len(v_name) == len(vector_name):
+      raise ValueError('u_name, v_name, and vector_name must have the same length')
+
+  @property
+  def unique_name(self) -> str:
+    return 'WindVectorSquaredError_' + '_'.join(self._vector_name)
+
+  def compute(self, predictions, targets):
+    out = {}
+    for u, v, name in zip(self._u_name, self._v_name, self._vector_name):
+      se_u = lazy.det_statistic('SquaredError', predictions[u], targets[u])
+      se_v = lazy.det_statistic('SquaredError', predictions[v], targets[v])
+      if se_u.dims == se_v.dims and se_u.shape == se_v.shape:
+        out[name] = _SumOfStatistics([se_u, se_v])
+      else:
+        out[name] = se_u + se_v
+    return out
+
+
+class SquaredPredictionAnomaly(base.PerVariableStatisticWithClimatology):
+  """(predictions - climatology)**2 (deterministic.py:222-232)."""
+
+  def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
+    return lazy.det_statistic('SquaredPredictionAnomaly', predictions, targets, aligned_climatology,
+                              clim_key=id(aligned_climatology.source.data))
+
+
+class SquaredTargetAnomaly(base.PerVariableStatisticWithClimatology):
+  """(targets - climatology)**2 (deterministic.py:235-245)."""
+
+  def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
+    return lazy.det_statistic('SquaredTargetAnomaly', predictions, targets, aligned_climatology,
+                              clim_key=id(aligned_climatology.source.data))
+
+
+class AnomalyCovariance(base.PerVariableStatisticWithClimatology):
+  """(predictions - climatology) * (targets - climatology) (deterministic.py:248-259)."""
+
+  def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
+    return lazy.det_statistic('AnomalyCovariance', predictions, targets, aligned_climatology,
+                              clim_key=id(aligned_climatology.source.data))
+
+
+# Metrics that are the plain mean of a statistic (deterministic.py:305-309).
+Bias = Error
+MAE = AbsoluteError
+MSE = SquaredError
+PredictionAverage = PredictionPassthrough
+TargetAverage = TargetPassthrough
+
+
+class RMSE(base.PerVariableMetric):
+  """sqrt(mean SquaredError) (deterministic.py:312-324)."""
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {'SquaredError': SquaredError()}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return _sqrt(statistic_values['SquaredError'])
+
+
+class WindVectorRMSE(base.Metric):
+  """sqrt(mean WindVectorSquaredError) (deterministic.py:327-371)."""
+
+  def __init__(self, u_name: Union[str, list], v_name: Union[str, list], vector_name: Union[str, list]):
+    as_list = lambda x: [x] if isinstance(x, str) else x
+    self._u_name, self._v_name, self._vector_name = as_list(u_name), as_list(v_name), as_list(vector_name)
+    if not len(self._u_name) == len(self._v_name) == len(self._vector_name):
+      raise ValueError('u_name, v_name, and vector_name must have the same length')
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {'WindVectorSquaredError': WindVectorSquaredError(self._u_name, self._v_name, self._vector_name)}
+
+  def values_from_mean_statistics(self, statistic_values):
+    return xarray_tree.map_structure(_sqrt, statistic_values['WindVectorSquaredError'])
+
+
+class ACC(base.PerVariableMetric):
+  """Anomaly correlation coefficient: cov / (sqrt(spa) * sqrt(sta)) (deterministic.py:374-400)."""
+
+  def __init__(self, climatology):
+    self._climatology = climatology
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    c = self._climatology
+    return {'SquaredPredictionAnomaly': SquaredPredictionAnomaly(climatology=c),
+            'SquaredTargetAnomaly': SquaredTargetAnomaly(climatology=c),
+            'AnomalyCovariance': AnomalyCovariance(climatology=c)}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return statistic_values['AnomalyCovariance'] / (
+        _sqrt(statistic_values['SquaredPredictionAnomaly']) * _sqrt(statistic_values['SquaredTargetAnomaly']))
+
+
+class PredictionActivity(base.PerVariableMetric):
+  """Std-dev of prediction anomalies: sqrt(mean spa) (deterministic.py:403-425)."""
+
+  def __init__(self, climatology):
+    self._climatology = climatology
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {'SquaredPredictionAnomaly': SquaredPredictionAnomaly(climatology=self._climatology)}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return _sqrt(statistic_values['SquaredPredictionAnomaly'])

@@ -1,0 +1,224 @@
+"""Ensemble statistics and metrics (counterpart of the CRPS / spread-skill part of
+weatherbenchX/metrics/probabilistic.py:28-336, 606-688, 864-1003).
+
+Per-point arithmetic lives in csrc/wbx_ens_impl.hpp (one lane owns one grid point's M members in
+VGPRs: sorting-network rank form for `use_sort=True`, pairwise form for `use_sort=False`).
+Not fused yet (raise NotImplementedError): targets that carry the ensemble dim, `which='targets'`,
+`skipna_ensemble=True`.
+"""
+from __future__ import annotations
+
+from typing import Mapping
+
+import numpy as np
+
+from weatherbenchx_amd import lazy
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base
+
+ENSEMBLE_DIM = 'number'
+
+
+def _sqrt(da):
+  return np.sqrt(da)
+
+
+def _no_skipna(flag: bool, who: str):
+  if flag:
+    raise NotImplementedError(f'{who}: skipna_ensemble=True is not fused yet (SURVEY 8f-3)')
+
+
+class EnsembleAveragedStatistic(base.Statistic):
+  """Mean of a wrapped statistic over the ensemble dim (probabilistic.py:35-69)."""
+
+  def __init__(self, wrapped_statistic: base.Statistic, *, ensemble_dim: str, skipna_ensemble: bool):
+    self._wrapped_statistic = wrapped_statistic
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def unique_name(self) -> str:
+    return self._wrapped_statistic.unique_name + '_each_' + self._ensemble_dim
+
+  def compute(self, predictions, targets):
+    out = {}
+    for name, da in self._wrapped_statistic.compute(predictions, targets).items():
+      if self._ensemble_dim not in da.dims:
+        raise ValueError(f'Dimension {self._ensemble_dim} not found in {da.dims}')
+      out[name] = da.mean(dim=self._ensemble_dim, skipna=self._skipna_ensemble)
+    return out
+
+
+class EnsembleAveragedMetric(base.Metric):
+  """Any metric with its statistics averaged over the ensemble dim (probabilistic.py:72-113)."""
+
+  def __init__(self, wrapped_metric: base.Metric, *, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._wrapped_metric = wrapped_metric
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {name: EnsembleAveragedStatistic(stat, ensemble_dim=self._ensemble_dim,
+                                            skipna_ensemble=self._skipna_ensemble)
+            for name, stat in self._wrapped_metric.statistics.items()}
+
+  def values_from_mean_statistics(self, statistic_values):
+    return self._wrapped_metric.values_from_mean_statistics(statistic_values)
+
+
+class CRPSSkill(base.PerVariableStatistic):
+  """E|X - Y| (probabilistic.py:116-145)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def unique_name(self) -> str:
+    return f'CRPSSkill_{self._ensemble_dim}'
+
+  def _compute_per_variable(self, predictions, targets):
+    _no_skipna(self._skipna_ensemble, 'CRPSSkill')
+    return lazy.ens_statistic('CRPSSkill', predictions, targets, self._ensemble_dim)
+
+
+class CRPSSpread(base.PerVariableStatistic):
+  """E|X - X'| estimate, fair or not, rank or pairwise form (probabilistic.py:165-247).
+  As in the reference, `unique_name` ignores use_sort / skipna_ensemble (probabilistic.py:189-192)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, use_sort: bool = False, fair: bool = True,
+               which: str = 'predictions', skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._use_sort = use_sort
+    self._which = which
+    self._fair = fair
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def unique_name(self) -> str:
+    return f"CRPSSpread_{self._ensemble_dim}_{'fair' if self._fair else 'unfair'}_{self._which}"
+
+  def _compute_per_variable(self, predictions, targets):
+    if self._which == 'targets':
+      raise NotImplementedError("CRPSSpread(which='targets') is not fused yet (SURVEY 8f-3)")
+    if self._which != 'predictions':
+      raise ValueError(f'Unhandled {self._which=}')
+    if self._skipna_ensemble and self._use_sort:
+      raise ValueError('skipna_ensemble is not supported with use_sort=True.')
+    _no_skipna(self._skipna_ensemble, 'CRPSSpread')
+    if self._ensemble_dim not in predictions.dims:
+      raise ValueError(f'Dimension {self._ensemble_dim} not found in {predictions.dims}')
+    if predictions.sizes[self._ensemble_dim] < 2:
+      raise ValueError('Cannot estimate CRPS spread with n_ensemble < 2.')
+    return lazy.ens_statistic('CRPSSpread', predictions, targets, self._ensemble_dim, use_sort=self._use_sort,
+                              fair=self._fair)
+
+
+class EnsembleVariance(base.PerVariableStatistic):
+  """Unbiased (ddof=1) variance over the ensemble dim (probabilistic.py:250-273)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def unique_name(self) -> str:
+    return f'EnsembleVariance_{self._ensemble_dim}_skipna_ensemble_{self._skipna_ensemble}'
+
+  def _compute_per_variable(self, predictions, targets):
+    _no_skipna(self._skipna_ensemble, 'EnsembleVariance')
+    return lazy.ens_statistic('EnsembleVariance', predictions, targets, self._ensemble_dim)
+
+
+class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
+  """(mean_m X - Y)**2 - var_m(X)/M (probabilistic.py:276-336)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def unique_name(self) -> str:
+    return f'UnbiasedEnsembleMeanSquaredError_{self._ensemble_dim}_skipna_ensemble_{self._skipna_ensemble}'
+
+  def _compute_per_variable(self, predictions, targets):
+    _no_skipna(self._skipna_ensemble, 'UnbiasedEnsembleMeanSquaredError')
+    return lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim)
+
+
+class CRPSEnsemble(base.PerVariableMetric):
+  """CRPS = E|X - Y| - 0.5 E|X - X'| (probabilistic.py:606-688)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, use_sort: bool = False, fair: bool = True,
+               skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._use_sort = use_sort
+    self._fair = fair
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {
+        'CRPSSkill': CRPSSkill(ensemble_dim=self._ensemble_dim, skipna_ensemble=self._skipna_ensemble),
+        'CRPSSpread': CRPSSpread(ensemble_dim=self._ensemble_dim, use_sort=self._use_sort, fair=self._fair,
+                                 skipna_ensemble=self._skipna_ensemble),
+    }
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return statistic_values['CRPSSkill'] - 0.5 * statistic_values['CRPSSpread']
+
+
+class UnbiasedEnsembleMeanRMSE(base.PerVariableMetric):
+  """sqrt(mean UnbiasedEnsembleMeanSquaredError) (probabilistic.py:864-894)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {'UnbiasedEnsembleMeanSquaredError': UnbiasedEnsembleMeanSquaredError(
+        ensemble_dim=self._ensemble_dim, skipna_ensemble=self._skipna_ensemble)}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return _sqrt(statistic_values['UnbiasedEnsembleMeanSquaredError'])
+
+
+def SpreadSkillRatio(**unused_kwargs):  # pylint: disable=invalid-name
+  # Same behaviour as the reference: the class was withdrawn (probabilistic.py:897-902).
+  raise ValueError('SpreadSkillRatio is no longer supported as it was not correctly implemented. '
+                   'Please use UnbiasedSpreadSkillRatio instead and see the docstring of that class for more details.')
+
+
+class UnbiasedSpreadSkillRatio(base.PerVariableMetric):
+  """sqrt(mean EnsembleVariance / mean UnbiasedEnsembleMeanSquaredError) (probabilistic.py:905-967)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    kw = dict(ensemble_dim=self._ensemble_dim, skipna_ensemble=self._skipna_ensemble)
+    return {'EnsembleVariance': EnsembleVariance(**kw),
+            'UnbiasedEnsembleMeanSquaredError': UnbiasedEnsembleMeanSquaredError(**kw)}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return _sqrt(statistic_values['EnsembleVariance'] / statistic_values['UnbiasedEnsembleMeanSquaredError'])
+
+
+class EnsembleRootMeanVariance(base.PerVariableMetric):
+  """sqrt(mean EnsembleVariance) (probabilistic.py:970-1003)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {'EnsembleVariance': EnsembleVariance(ensemble_dim=self._ensemble_dim,
+                                                 skipna_ensemble=self._skipna_ensemble)}
+
+  def _values_from_mean_statistics_per_variable(self, mean_statistic_values):
+    return _sqrt(mean_statistic_values['EnsembleVariance'])

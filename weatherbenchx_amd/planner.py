@@ -1,0 +1,275 @@
+"""Host-side planning of the two-stage reduction (pure numpy; no device needed).
+
+A statistic's index space (named dims) is split for stage 1 (csrc/wbx_s1.hpp) into
+  x      the innermost dim of the predictions' memory layout (coalescing),
+  key    dims that must survive stage 1: dims the caller keeps, plus every dim the weights or
+         bin masks depend on (their product W is applied in stage 2),
+  depth  the remaining reduced dims: summed inside stage 1.
+Key dims are ordered A (kept, W-independent), Bk (kept, W-dependent), Br (reduced, W-dependent) so
+stage 2 (csrc/wbx_s2.hip) sees partial[A][Bk][Br][chunk][lane][j] and W[Bk][Br][j][bin].
+
+This replaces the dimension bookkeeping xarray's `xr.dot` does inside
+weatherbenchX/aggregation.py:297-335, for arbitrary loader dim orders
+(data_loaders/xarray_loaders.py:185-188; real data is latitude-fastest).
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Sequence
+
+import numpy as np
+
+MAX_INPUTS = 4
+TARGET_BLOCKS = 4096  # >> 256 CUs * resident blocks, so the tail is short
+
+
+@dataclasses.dataclass
+class InputLayout:
+  """Element strides of one input along the statistic's dims (0 / missing = broadcast)."""
+  strides: dict  # dim -> element stride
+  itemsize: int = 4
+  base_alignment: int = 16  # bytes the base pointer is aligned to
+
+  def stride(self, dim) -> int:
+    return int(self.strides.get(dim, 0))
+
+
+@dataclasses.dataclass
+class GatherSpec:
+  """Indirect addressing of input 2 (climatology): element offset table over `dims`.
+  metrics/base.py:397-403 `.sel(dayofyear=..., hour=...)` becomes table[init, lead] * slice_stride."""
+  dims: tuple
+  table: np.ndarray  # int64, shape = sizes of dims
+
+
+@dataclasses.dataclass
+class S1Plan:
+  dims: tuple           # statistic dims (ordered)
+  sizes: dict
+  x_dim: object         # may be None (0-d statistic)
+  x_kept: bool
+  sum_j: bool           # stage 2 sums over x
+  a_dims: tuple
+  bk_dims: tuple
+  br_dims: tuple
+  depth_dims: tuple
+  nkey: int
+  ndepth: int
+  nx: int
+  nchunk: int
+  depth_chunk: int
+  xstride: list
+  key_off: list         # per input: int64[nkey] or None
+  depth_off: list       # per input: int64[ndepth] or None
+  gather_key: np.ndarray | None
+  gather_depth: np.ndarray | None
+  gather_tab: np.ndarray | None
+  n_gather_depth: int
+  flags: int
+  block_threads: int
+  vec: int
+
+  @property
+  def nj(self) -> int:
+    return self.nx if self.x_kept else 1
+
+  @property
+  def key_dims(self) -> tuple:
+    return self.a_dims + self.bk_dims + self.br_dims
+
+  def n(self, dims) -> int:
+    return int(np.prod([self.sizes[d] for d in dims], dtype=np.int64)) if dims else 1
+
+  def partial_shape(self, nlanes_total: int) -> tuple:
+    return (self.n(self.a_dims), self.n(self.bk_dims), self.n(self.br_dims), self.nchunk, nlanes_total, self.nj)
+
+  def reduced_count_per_partial(self) -> int:
+    """Number of statistic elements folded into one stage-1 partial (all chunks together)."""
+    return self.ndepth * (1 if self.x_kept else self.nx)
+
+
+def _offset_table(dims: Sequence, sizes: dict, layout: InputLayout) -> np.ndarray | None:
+  """Flattened (C order over `dims`) element offsets; None when identically zero."""
+  if not dims:
+    return None
+  if all(layout.stride(d) == 0 for d in dims):
+    return None
+  off = np.zeros((), dtype=np.int64)
+  for d in dims:
+    off = off[..., None] + np.arange(sizes[d], dtype=np.int64) * layout.stride(d)
+  return np.ascontiguousarray(off.reshape(-1))
+
+
+def _gather_index(dims: Sequence, sizes: dict, gdims: Sequence) -> tuple[np.ndarray | None, int]:
+  """Index into the gather-table axes restricted to `gdims` for each flattened position of `dims`."""
+  sub = [d for d in dims if d in gdims]
+  n = int(np.prod([sizes[d] for d in sub], dtype=np.int64)) if sub else 1
+  if not sub:
+    return None, 1
+  idx = np.zeros((), dtype=np.int64)
+  mult = 1
+  mults = {}
+  for d in reversed(sub):
+    mults[d] = mult
+    mult *= sizes[d]
+  for d in dims:
+    step = mults.get(d, 0)
+    idx = idx[..., None] + np.arange(sizes[d], dtype=np.int64) * step
+  return np.ascontiguousarray(idx.reshape(-1).astype(np.int32)), n
+
+
+def choose_x_dim(dims: Sequence, sizes: dict, layout: InputLayout, exclude=()):
+  """The contiguous-most dim of the predictions (stride 1 preferred)."""
+  cands = [d for d in dims if d not in exclude and sizes[d] > 1 and layout.stride(d) != 0]
+  if not cands:
+    cands = [d for d in dims if d not in exclude]
+    return cands[-1] if cands else None
+  return min(cands, key=lambda d: (abs(layout.stride(d)), -list(dims).index(d)))
+
+
+def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | None], reduce_dims,
+                  wdep_dims=(), gather: GatherSpec | None = None, flags: int = 0, allow_vec4: bool = True,
+                  target_blocks: int = TARGET_BLOCKS, force_x_dim=None, map_mode: bool = False) -> S1Plan:
+  """Plans stage 1.  `layouts[i]` is None for unused inputs.  `map_mode` keeps every dim (nchunk=1)."""
+  dims = tuple(dims)
+  sizes = {d: int(sizes[d]) for d in dims}
+  reduce_set = set(reduce_dims) & set(dims)
+  wdep = set(wdep_dims) & set(dims)
+  lay0 = layouts[0]
+  x_dim = force_x_dim if force_x_dim is not None else choose_x_dim(dims, sizes, lay0)
+  nx = sizes[x_dim] if x_dim is not None else 1
+  if map_mode:
+    x_kept, sum_j = True, False
+  else:
+    x_kept = (x_dim is None) or (x_dim not in reduce_set) or (x_dim in wdep)
+    sum_j = x_kept and x_dim is not None and x_dim in reduce_set
+  others = [d for d in dims if d != x_dim]
+  if map_mode:
+    # out[key][depth][x] must be the C-order array over dims with x last: put all other dims in key
+    a_dims, bk_dims, br_dims, depth_dims = tuple(others), (), (), ()
+  else:
+    a_dims = tuple(d for d in others if d not in reduce_set and d not in wdep)
+    bk_dims = tuple(d for d in others if d not in reduce_set and d in wdep)
+    br_dims = tuple(d for d in others if d in reduce_set and d in wdep)
+    depth_dims = tuple(d for d in others if d in reduce_set and d not in wdep)
+  key_dims = a_dims + bk_dims + br_dims
+  nkey = int(np.prod([sizes[d] for d in key_dims], dtype=np.int64)) if key_dims else 1
+  ndepth = int(np.prod([sizes[d] for d in depth_dims], dtype=np.int64)) if depth_dims else 1
+
+  xstride, key_off, depth_off = [], [], []
+  for lay in layouts:
+    if lay is None:
+      xstride.append(0)
+      key_off.append(None)
+      depth_off.append(None)
+    else:
+      xstride.append(lay.stride(x_dim) if x_dim is not None else 0)
+      key_off.append(_offset_table(key_dims, sizes, lay))
+      depth_off.append(_offset_table(depth_dims, sizes, lay))
+  while len(xstride) < MAX_INPUTS:
+    xstride.append(0)
+    key_off.append(None)
+    depth_off.append(None)
+
+  gk = gd = gtab = None
+  ngd = 1
+  if gather is not None:
+    if x_dim in gather.dims:
+      raise ValueError(f'gather dim {x_dim!r} is the innermost dim; align the climatology on the host instead')
+    gk, ngk = _gather_index(key_dims, sizes, gather.dims)
+    gd, ngd = _gather_index(depth_dims, sizes, gather.dims)
+    # table reordered to [gather-key combos][gather-depth combos]
+    kd = [d for d in key_dims if d in gather.dims]
+    dd = [d for d in depth_dims if d in gather.dims]
+    tab = np.asarray(gather.table, dtype=np.int64)
+    tab = np.transpose(tab, [gather.dims.index(d) for d in kd + dd])
+    gtab = np.ascontiguousarray(tab.reshape(ngk * ngd))
+
+  # launch geometry
+  block_threads = 256
+  if x_kept:
+    vec = 1
+    nxtile = -(-nx // (block_threads * vec))
+    blocks_per_chunk = nkey * nxtile
+  else:
+    blocks_per_chunk = nkey
+  if map_mode:
+    nchunk, depth_chunk = 1, max(ndepth, 1)
+  else:
+    nchunk = int(min(max(ndepth, 1), max(1, -(-target_blocks // max(blocks_per_chunk, 1)))))
+    depth_chunk = -(-max(ndepth, 1) // nchunk)
+    nchunk = -(-max(ndepth, 1) // depth_chunk)
+  if not x_kept:
+    rows = depth_chunk
+    block_threads = 256 if rows >= 4 else (128 if rows >= 2 else 64)
+    if nx <= 64 and rows < 4:
+      block_threads = 64
+
+  vec = 1
+  if allow_vec4 and not (flags & 3) and nx % 4 == 0 and nx >= 4 and x_dim is not None:
+    ok = True
+    for i, lay in enumerate(layouts[:3]):
+      if lay is None:
+        continue
+      if lay.itemsize != 4 or lay.base_alignment % 16 != 0:
+        ok = False
+        break
+      xs = xstride[i]
+      if xs not in (0, 1):
+        ok = False
+        break
+      if xs == 1:
+        for tab in (key_off[i], depth_off[i]):
+          if tab is not None and np.any(tab % 4):
+            ok = False
+        if i == 2 and gtab is not None and np.any(gtab % 4):
+          ok = False
+    if ok:
+      vec = 4
+
+  return S1Plan(dims=dims, sizes=sizes, x_dim=x_dim, x_kept=bool(x_kept), sum_j=bool(sum_j), a_dims=a_dims,
+                bk_dims=bk_dims, br_dims=br_dims, depth_dims=depth_dims, nkey=nkey, ndepth=ndepth, nx=nx,
+                nchunk=int(nchunk), depth_chunk=int(depth_chunk), xstride=[int(v) for v in xstride[:MAX_INPUTS]],
+                key_off=key_off[:MAX_INPUTS], depth_off=depth_off[:MAX_INPUTS], gather_key=gk, gather_depth=gd,
+                gather_tab=gtab, n_gather_depth=int(ngd), flags=int(flags), block_threads=int(block_threads),
+                vec=int(vec))
+
+
+@dataclasses.dataclass
+class S2Plan:
+  nA: int
+  nBk: int
+  nBr: int
+  nchunk: int
+  nlane: int
+  nj: int
+  nbin: int
+  sum_j: bool
+
+  def out_shape(self) -> tuple:
+    return (self.nA, self.nBk, self.nlane, 1 if self.sum_j else self.nj, self.nbin)
+
+
+def build_s2_plan(s1: S1Plan, nlanes_total: int, nbin: int) -> S2Plan:
+  return S2Plan(nA=s1.n(s1.a_dims), nBk=s1.n(s1.bk_dims), nBr=s1.n(s1.br_dims), nchunk=s1.nchunk,
+                nlane=int(nlanes_total), nj=s1.nj, nbin=int(nbin), sum_j=bool(s1.sum_j))
+
+
+def layout_of(array, dims_of_array: Sequence) -> InputLayout:
+  """InputLayout of a numpy array / torch tensor whose axes are named `dims_of_array`."""
+  if hasattr(array, 'stride') and callable(array.stride):  # torch
+    st = [int(s) for s in array.stride()]
+    itemsize = int(array.element_size())
+    ptr = int(array.data_ptr())
+  else:
+    itemsize = int(array.dtype.itemsize)
+    st = []
+    for s in array.strides:
+      if s % itemsize:
+        raise ValueError('array strides are not a multiple of the item size')
+      st.append(int(s // itemsize))
+    ptr = int(array.__array_interface__['data'][0])
+  align = 256
+  while align > 1 and ptr % align:
+    align //= 2
+  return InputLayout(strides=dict(zip(dims_of_array, st)), itemsize=itemsize, base_alignment=align)

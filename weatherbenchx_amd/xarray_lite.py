@@ -1,0 +1,1309 @@
+"""Minimal labeled arrays: the subset of xarray's DataArray/Dataset the scoring path uses.
+
+xarray is not installed in the build container nor on the GPU box, so the drop-in
+surface ("xarray in / xarray out", weatherbenchX/metrics/base.py:135-158,
+weatherbenchX/aggregation.py:337-366) is provided against this stand-in.  Anything that looks like
+an `xr.DataArray` (`.dims`, `.coords`, `.values`/`.data`) is accepted through `as_dataarray`.
+
+Semantics reproduced (upstream-xarray behaviour the reference relies on):
+  * arithmetic broadcasts by dimension NAME, result dims = dims of the left operand followed by the
+    new dims of the right one; index coordinates are inner-joined; non-conflicting non-index
+    coordinates (e.g. the boolean `mask` coordinate, data_loaders/base.py:25-56) are carried into
+    the result -- that is how a target mask reaches `Aggregator.aggregate_stat_var`.
+  * reductions take `skipna` (default True for floats, like xarray).
+  * `dot`, `align(join='outer', fill_value=...)`, `concat`, `sel` (labels, label slices, vectorised
+    DataArray indexers as used by the climatology alignment, metrics/base.py:397-403).
+
+`.data` may be a numpy array or a torch tensor (CPU or ROCm device); torch is only touched when a
+tensor is actually passed in.
+"""
+from __future__ import annotations
+
+import numbers
+from collections.abc import Mapping
+from typing import Any, Hashable, Iterable, Sequence
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------------
+# backend helpers (numpy / torch duck typing)
+def _is_torch(x) -> bool:
+  return type(x).__module__.split('.')[0] == 'torch'
+
+
+def _torch():
+  import torch  # pylint: disable=g-import-not-at-top
+
+  return torch
+
+
+def _to_numpy(x) -> np.ndarray:
+  if _is_torch(x):
+    return x.detach().cpu().numpy()
+  return np.asarray(x)
+
+
+def _shape(x):
+  return tuple(int(s) for s in x.shape)
+
+
+def _transpose(x, axes):
+  if _is_torch(x):
+    return x.permute(*axes) if len(axes) else x
+  return np.transpose(x, axes)
+
+
+def _expand(x, ndim_before_total_index):
+  """x[..., None] style reshape; `ndim_before_total_index` is a tuple indexer."""
+  return x[ndim_before_total_index]
+
+
+def _isnan(x):
+  if _is_torch(x):
+    t = _torch()
+    return t.isnan(x) if x.is_floating_point() else t.zeros_like(x, dtype=t.bool)
+  if np.issubdtype(x.dtype, np.floating) or np.issubdtype(x.dtype, np.complexfloating):
+    return np.isnan(x)
+  if x.dtype.kind in 'mM':
+    return np.isnat(x)
+  return np.zeros(x.shape, dtype=bool)
+
+
+def _where(cond, a, b):
+  if _is_torch(cond) or _is_torch(a) or _is_torch(b):
+    t = _torch()
+    dev = next(v.device for v in (cond, a, b) if _is_torch(v))
+    cond = cond if _is_torch(cond) else t.as_tensor(np.asarray(cond), device=dev)
+    if not _is_torch(a):
+      a = t.as_tensor(a, device=dev, dtype=b.dtype if _is_torch(b) else None)
+    if not _is_torch(b):
+      b = t.as_tensor(b, device=dev, dtype=a.dtype)
+    return t.where(cond.bool(), a, b)
+  return np.where(cond, a, b)
+
+
+def _is_float(x) -> bool:
+  if _is_torch(x):
+    return x.is_floating_point()
+  return np.issubdtype(np.asarray(x).dtype, np.floating)
+
+
+def _reduce(x, op: str, axes: tuple[int, ...], skipna: bool, ddof: int = 0):
+  """Reduction over `axes` for numpy / torch data."""
+  if not axes:
+    if op == 'count':
+      return (~_isnan(x)).astype(np.int64) if not _is_torch(x) else (~_isnan(x)).long()
+    if op == 'var':
+      return x * 0.0 if ddof == 0 else x * np.nan
+    return x
+  if _is_torch(x):
+    t = _torch()
+    if op == 'count':
+      return (~t.isnan(x)).sum(dim=axes) if x.is_floating_point() else t.full(
+          [s for i, s in enumerate(x.shape) if i not in axes], int(np.prod([x.shape[i] for i in axes])))
+    nan = skipna and x.is_floating_point()
+    if op == 'sum':
+      return t.nansum(x, dim=axes) if nan else x.sum(dim=axes)
+    if op == 'mean':
+      return t.nanmean(x, dim=axes) if nan else x.mean(dim=axes)
+    if op == 'var':
+      if nan:
+        cnt = (~t.isnan(x)).sum(dim=axes, keepdim=True)
+        mu = t.nansum(x, dim=axes, keepdim=True) / cnt
+        ss = t.nansum((x - mu) ** 2, dim=axes)
+        return ss / (cnt.squeeze(axes) - ddof)
+      return x.var(dim=axes, correction=ddof)
+    if op in ('min', 'max'):
+      return getattr(t, 'a' + op)(x, dim=axes)
+    if op == 'any':
+      return x.bool().any(dim=axes) if len(axes) == 1 else x.bool().flatten().any()
+    if op == 'all':
+      return x.bool().all(dim=axes) if len(axes) == 1 else x.bool().flatten().all()
+    raise ValueError(op)
+  x = np.asarray(x)
+  nan = skipna and np.issubdtype(x.dtype, np.floating)
+  if op == 'count':
+    return (~_isnan(x)).sum(axis=axes)
+  with np.errstate(all='ignore'):
+    if op == 'sum':
+      return np.nansum(x, axis=axes) if nan else x.sum(axis=axes)
+    if op == 'mean':
+      return np.nanmean(x, axis=axes) if nan else x.mean(axis=axes)
+    if op == 'var':
+      return np.nanvar(x, axis=axes, ddof=ddof) if nan else x.var(axis=axes, ddof=ddof)
+    if op == 'min':
+      return np.nanmin(x, axis=axes) if nan else x.min(axis=axes)
+    if op == 'max':
+      return np.nanmax(x, axis=axes) if nan else x.max(axis=axes)
+    if op == 'any':
+      return x.any(axis=axes)
+    if op == 'all':
+      return x.all(axis=axes)
+  raise ValueError(op)
+
+
+def _values_equal(a: np.ndarray, b: np.ndarray) -> bool:
+  a, b = np.asarray(a), np.asarray(b)
+  if a.shape != b.shape:
+    return False
+  try:
+    return bool(np.array_equal(a, b, equal_nan=True))
+  except TypeError:
+    return bool(np.array_equal(a, b))
+
+
+# --------------------------------------------------------------------------------------------------
+class _Coords(Mapping):
+  """Read/write view on a DataArray's coordinates (name -> DataArray)."""
+
+  def __init__(self, owner: 'DataArray'):
+    self._o = owner
+
+  def __getitem__(self, key):
+    dims, vals = self._o._coords[key]
+    sub = {k: v for k, v in self._o._coords.items() if k != key and set(v[0]) <= set(dims)}
+    sub[key] = (dims, vals)
+    return DataArray(vals, dims=dims, coords=sub, name=key, _raw_coords=True)
+
+  def __setitem__(self, key, value):
+    self._o._set_coord(key, value)
+
+  def __delitem__(self, key):
+    del self._o._coords[key]
+
+  def __iter__(self):
+    return iter(self._o._coords)
+
+  def __len__(self):
+    return len(self._o._coords)
+
+  def __contains__(self, key):
+    return key in self._o._coords
+
+  def __repr__(self):
+    return 'Coordinates(' + ', '.join(f'{k}{list(v[0])}' for k, v in self._o._coords.items()) + ')'
+
+
+class _DtAccessor:
+  """`.dt` for datetime64 arrays: the two fields the climatology alignment needs."""
+
+  def __init__(self, da: 'DataArray'):
+    self._da = da
+
+  def _field(self, fn):
+    v = _to_numpy(self._da.data).astype('datetime64[ns]')
+    return self._da.copy(data=fn(v))
+
+  @property
+  def dayofyear(self):
+    def f(v):
+      years = v.astype('datetime64[Y]')
+      return ((v.astype('datetime64[D]') - years.astype('datetime64[D]')).astype(np.int64) + 1)
+    return self._field(f)
+
+  @property
+  def hour(self):
+    def f(v):
+      return ((v - v.astype('datetime64[D]')).astype('timedelta64[h]').astype(np.int64))
+    return self._field(f)
+
+
+def _normalise_coord(name, value, owner_dims, owner_sizes):
+  """-> (dims, np.ndarray)."""
+  if isinstance(value, DataArray):
+    dims, vals = value.dims, _to_numpy(value.data)
+  elif isinstance(value, tuple) and len(value) == 2 and (isinstance(value[0], (str, tuple, list))):
+    dims = (value[0],) if isinstance(value[0], str) else tuple(value[0])
+    vals = _to_numpy(value[1])
+  elif hasattr(value, 'dims') and hasattr(value, 'values'):
+    dims, vals = tuple(value.dims), np.asarray(value.values)
+  else:
+    vals = _to_numpy(value) if not np.isscalar(value) else np.asarray(value)
+    if vals.ndim == 0:
+      dims = ()
+    elif vals.ndim == 1 and name in owner_dims:
+      dims = (name,)
+    else:
+      raise ValueError(f'cannot infer dims of coordinate {name!r} with shape {vals.shape}')
+  for d, n in zip(dims, vals.shape):
+    if d not in owner_dims:
+      raise ValueError(f'coordinate {name!r} has dim {d!r} not on the array {owner_dims}')
+    if owner_sizes[d] != n:
+      raise ValueError(f'coordinate {name!r} size mismatch on {d!r}: {n} vs {owner_sizes[d]}')
+  return tuple(dims), vals
+
+
+class DataArray:
+  """N-d array with named dims and coordinates (numpy or torch payload)."""
+
+  __array_priority__ = 60
+
+  def __init__(self, data=np.nan, dims=None, coords=None, name=None, attrs=None, *, _raw_coords=False):
+    if isinstance(data, DataArray):
+      coords = coords if coords is not None else data._coords
+      dims = dims if dims is not None else data.dims
+      name = name if name is not None else data.name
+      data = data.data
+      _raw_coords = True
+    if not _is_torch(data) and not isinstance(data, np.ndarray):
+      data = np.asarray(data)
+    if dims is None:
+      if isinstance(coords, (list, tuple)) and coords and isinstance(coords[0], tuple):
+        dims = tuple(c[0] for c in coords)
+        coords = {c[0]: c[1] for c in coords}
+      elif isinstance(coords, Mapping) and len(coords) == data.ndim and data.ndim > 0:
+        dims = tuple(coords.keys())
+      else:
+        dims = tuple(f'dim_{i}' for i in range(data.ndim))
+    if isinstance(dims, str):
+      dims = (dims,)
+    dims = tuple(dims)
+    if len(dims) != data.ndim:
+      raise ValueError(f'dims {dims} do not match data with shape {_shape(data)}')
+    if len(set(dims)) != len(dims):
+      raise ValueError(f'duplicate dimension names: {dims}')
+    self._data = data
+    self._dims = dims
+    self.name = name
+    self.attrs = dict(attrs) if attrs else {}
+    self._coords: dict[Hashable, tuple[tuple, np.ndarray]] = {}
+    if coords:
+      sizes = dict(zip(dims, _shape(data)))
+      for k, v in dict(coords).items():
+        if _raw_coords:
+          cd, cv = v
+          if set(cd) <= set(dims):
+            self._coords[k] = (tuple(cd), cv)
+        else:
+          self._coords[k] = _normalise_coord(k, v, dims, sizes)
+
+  # ---- basic properties ------------------------------------------------------------------------
+  @property
+  def data(self):
+    return self._data
+
+  @property
+  def values(self) -> np.ndarray:
+    return _to_numpy(self.data)
+
+  @property
+  def dims(self) -> tuple:
+    return self._dims
+
+  @property
+  def shape(self) -> tuple:
+    return _shape(self._data)
+
+  @property
+  def sizes(self) -> dict:
+    return dict(zip(self.dims, self.shape))
+
+  @property
+  def ndim(self) -> int:
+    return len(self._dims)
+
+  @property
+  def size(self) -> int:
+    return int(np.prod(self.shape, dtype=np.int64))
+
+  @property
+  def dtype(self):
+    d = self.data
+    if _is_torch(d):
+      return np.dtype(str(d.dtype).replace('torch.', ''))
+    return d.dtype
+
+  @property
+  def coords(self) -> _Coords:
+    return _Coords(self)
+
+  @property
+  def dt(self) -> _DtAccessor:
+    return _DtAccessor(self)
+
+  @property
+  def T(self):
+    return self.transpose()
+
+  def _set_coord(self, key, value):
+    self._coords[key] = _normalise_coord(key, value, self.dims, self.sizes)
+
+  def __getattr__(self, name):
+    # only called when normal lookup fails: expose coords / dims as attributes
+    if name.startswith('_'):
+      raise AttributeError(name)
+    coords = self.__dict__.get('_coords', {})
+    if name in coords:
+      return _Coords(self)[name]
+    if name in self.__dict__.get('_dims', ()):
+      return self[name]
+    raise AttributeError(f'{type(self).__name__!r} object has no attribute {name!r}')
+
+  def __len__(self):
+    return self.shape[0]
+
+  def __repr__(self):
+    return (f'<wbx DataArray {self.name!r} ({", ".join(f"{d}: {n}" for d, n in self.sizes.items())}) '
+            f'{self.dtype} coords={list(self._coords)}>')
+
+  def __array__(self, dtype=None, copy=None):
+    v = self.values
+    return v.astype(dtype) if dtype is not None else v
+
+  def __bool__(self):
+    return bool(self.values)
+
+  def __float__(self):
+    return float(self.values)
+
+  def item(self):
+    return self.values.item()
+
+  # ---- construction helpers ----------------------------------------------------------------------
+  def _replace(self, data=None, dims=None, coords=None, name='__keep__'):
+    out = DataArray.__new__(DataArray)
+    out._data = self.data if data is None else data
+    out._dims = self._dims if dims is None else tuple(dims)
+    out.name = self.name if name == '__keep__' else name
+    out.attrs = dict(self.attrs)
+    src = self._coords if coords is None else coords
+    dset = set(out._dims)
+    out._coords = {k: v for k, v in src.items() if set(v[0]) <= dset}
+    return out
+
+  def copy(self, deep=True, data=None):
+    if data is not None:
+      if not _is_torch(data):
+        data = np.asarray(data)
+      if _shape(data) != self.shape:
+        raise ValueError(f'copy(data=...) shape {_shape(data)} != {self.shape}')
+      return self._replace(data=data)
+    d = self.data
+    if deep:
+      d = d.clone() if _is_torch(d) else np.array(d, copy=True)
+    return self._replace(data=d)
+
+  def rename(self, new_name_or_dict=None, **names):
+    if isinstance(new_name_or_dict, Mapping) or names:
+      m = dict(new_name_or_dict or {}, **names)
+      dims = tuple(m.get(d, d) for d in self.dims)
+      coords = {m.get(k, k): (tuple(m.get(d, d) for d in cd), cv) for k, (cd, cv) in self._coords.items()}
+      return self._replace(dims=dims, coords=coords)
+    return self._replace(name=new_name_or_dict)
+
+  def astype(self, dtype):
+    d = self.data
+    if _is_torch(d):
+      t = _torch()
+      dt = dtype if isinstance(dtype, t.dtype) else getattr(t, np.dtype(dtype).name)
+      return self._replace(data=d.to(dt))
+    return self._replace(data=d.astype(dtype))
+
+  def compute(self):
+    return self
+
+  def load(self):
+    return self
+
+  def assign_coords(self, coords=None, **kw):
+    out = self._replace()
+    for k, v in dict(coords or {}, **kw).items():
+      out._set_coord(k, v)
+    return out
+
+  def drop_vars(self, names, errors='raise'):
+    names = [names] if isinstance(names, str) else list(names)
+    return self._replace(coords={k: v for k, v in self._coords.items() if k not in names})
+
+  drop = drop_vars
+
+  def reset_coords(self, names=None, drop=True):
+    names = [names] if isinstance(names, str) else names
+    keep = {k: v for k, v in self._coords.items()
+            if (k in self.dims) or (names is not None and k not in names)}
+    return self._replace(coords=keep)
+
+  # ---- indexing ----------------------------------------------------------------------------------
+  def __getitem__(self, key):
+    if isinstance(key, str):
+      if key in self._coords:
+        return _Coords(self)[key]
+      if key in self.dims:  # default integer index
+        n = self.sizes[key]
+        return DataArray(np.arange(n), dims=(key,), name=key)
+      raise KeyError(key)
+    if isinstance(key, Mapping):
+      return self.isel(key)
+    if not isinstance(key, tuple):
+      key = (key,)
+    if any(k is Ellipsis for k in key):
+      i = next(i for i, k in enumerate(key) if k is Ellipsis)
+      key = key[:i] + (slice(None),) * (self.ndim - len(key) + 1) + key[i + 1:]
+    return self.isel({d: k for d, k in zip(self.dims, key)})
+
+  def __setitem__(self, key, value):
+    if isinstance(key, Mapping):
+      idx = tuple(key.get(d, slice(None)) for d in self.dims)
+    else:
+      idx = key
+    if isinstance(value, DataArray):
+      value = value.data
+    self._data[idx] = value
+
+  def isel(self, indexers=None, drop=False, **kw):
+    indexers = dict(indexers or {}, **kw)
+    for d in indexers:
+      if d not in self.dims:
+        raise ValueError(f'dimension {d!r} not in {self.dims}')
+    data = self.data
+    idx = []
+    new_dims = []
+    for d in self.dims:
+      k = indexers.get(d, slice(None))
+      if isinstance(k, DataArray):
+        k = k.values
+      if isinstance(k, (list, tuple)):
+        k = np.asarray(k)
+      if isinstance(k, np.ndarray) and k.ndim == 0:
+        k = int(k)
+      idx.append(k)
+      if not isinstance(k, numbers.Integral):
+        new_dims.append(d)
+    # apply one axis at a time to avoid numpy's joint fancy indexing semantics
+    out = data
+    ax = 0
+    for k in idx:
+      sel = (slice(None),) * ax + (k,)
+      if isinstance(k, np.ndarray) and _is_torch(out):
+        k2 = _torch().as_tensor(k, device=out.device)
+        sel = (slice(None),) * ax + (k2,)
+      out = out[sel]
+      if not isinstance(k, numbers.Integral):
+        ax += 1
+    coords = {}
+    for name, (cd, cv) in self._coords.items():
+      cidx = tuple(indexers.get(d, slice(None)) for d in cd)
+      cidx = tuple(np.asarray(c.values if isinstance(c, DataArray) else c) if isinstance(c, (list, tuple, DataArray))
+                   else c for c in cidx)
+      v = cv
+      ax2 = 0
+      ndims = []
+      for d, k in zip(cd, cidx):
+        if isinstance(k, np.ndarray) and k.ndim == 0:
+          k = int(k)
+        v = v[(slice(None),) * ax2 + (k,)]
+        if not isinstance(k, numbers.Integral):
+          ax2 += 1
+          ndims.append(d)
+      if drop and not ndims and any(d in indexers for d in cd):
+        continue
+      coords[name] = (tuple(ndims), v)
+    return self._replace(data=out, dims=new_dims, coords=coords)
+
+  def _index_positions(self, dim, labels, method=None):
+    if dim not in self._coords:
+      raise KeyError(f'no index coordinate for dimension {dim!r}')
+    index = np.asarray(self._coords[dim][1])
+    labels_arr = np.asarray(labels)
+    if index.dtype.kind == 'M':
+      labels_arr = labels_arr.astype(index.dtype)
+    elif index.dtype.kind == 'm':
+      labels_arr = labels_arr.astype(index.dtype)
+    flat = labels_arr.reshape(-1)
+    order = np.argsort(index, kind='stable')
+    pos = np.searchsorted(index[order], flat)
+    pos = np.clip(pos, 0, len(index) - 1)
+    found = order[pos]
+    ok = index[found] == flat
+    if not np.all(ok):
+      missing = flat[~ok][:5]
+      raise KeyError(f'labels {missing!r} not found in index of {dim!r}')
+    return found.reshape(labels_arr.shape)
+
+  def sel(self, indexers=None, drop=False, method=None, **kw):
+    indexers = dict(indexers or {}, **kw)
+    out = self
+    vector = {}
+    for d, lab in indexers.items():
+      if d not in out.dims:
+        raise ValueError(f'dimension {d!r} not in {out.dims}')
+      if isinstance(lab, slice):
+        index = np.asarray(out._coords[d][1])
+        lo = lab.start if lab.start is not None else index.min()
+        hi = lab.stop if lab.stop is not None else index.max()
+        if index.dtype.kind in 'mM':
+          lo, hi = np.asarray(lo).astype(index.dtype), np.asarray(hi).astype(index.dtype)
+        keep = np.nonzero((index >= lo) & (index <= hi))[0]
+        if len(index) > 1 and index[0] > index[-1] and lab.start is not None and lab.stop is not None and lo > hi:
+          keep = np.nonzero((index <= lab.start) & (index >= lab.stop))[0]
+        out = out.isel({d: keep})
+      elif isinstance(lab, DataArray) and lab.ndim > 0:
+        vector[d] = lab
+      else:
+        lab_arr = np.asarray(lab.values if isinstance(lab, DataArray) else lab)
+        pos = out._index_positions(d, lab_arr)
+        out = out.isel({d: pos if pos.ndim else int(pos)}, drop=drop)
+    if vector:
+      out = out._vector_sel(vector)
+    return out
+
+  def _vector_sel(self, vector: dict):
+    """Pointwise (vectorised) label selection with DataArray indexers sharing dims."""
+    idx_arrays = broadcast(*vector.values())
+    new_dims = idx_arrays[0].dims
+    new_shape = idx_arrays[0].shape
+    pos = {d: self._index_positions(d, ia.values) for d, ia in zip(vector, idx_arrays)}
+    first_axis = min(self.dims.index(d) for d in vector)
+    keep_dims = [d for d in self.dims if d not in vector]
+    for nd in new_dims:
+      if nd in keep_dims:
+        raise ValueError(f'indexer dim {nd!r} collides with an existing dim')
+    # move indexed dims to the front, gather, then place the new dims at `first_axis`
+    order = [self.dims.index(d) for d in vector] + [self.dims.index(d) for d in keep_dims]
+    data = _transpose(self.data, order)
+    gather = tuple(pos[d].reshape(-1) for d in vector)
+    if _is_torch(data):
+      gather = tuple(_torch().as_tensor(g, device=data.device) for g in gather)
+    gathered = data[gather]  # [npoints, *keep]
+    gathered = gathered.reshape(tuple(new_shape) + tuple(_shape(gathered)[1:]))
+    n_new = len(new_dims)
+    n_before = sum(1 for d in keep_dims if self.dims.index(d) < first_axis)
+    cur_dims = list(new_dims) + keep_dims
+    tgt_dims = keep_dims[:n_before] + list(new_dims) + keep_dims[n_before:]
+    gathered = _transpose(gathered, [cur_dims.index(d) for d in tgt_dims])
+    coords = {k: v for k, v in self._coords.items() if not (set(v[0]) & set(vector))}
+    for ia in idx_arrays:
+      for k, v in ia._coords.items():
+        coords.setdefault(k, v)
+    for d, ia in zip(vector, idx_arrays):
+      coords[d] = (tuple(new_dims), np.asarray(self._coords[d][1])[pos[d]])
+    del n_new
+    return self._replace(data=gathered, dims=tgt_dims, coords=coords)
+
+  # ---- shape manipulation --------------------------------------------------------------------------
+  def transpose(self, *dims, missing_dims='raise'):
+    if not dims:
+      dims = self.dims[::-1]
+    if Ellipsis in dims:
+      i = dims.index(Ellipsis)
+      rest = [d for d in self.dims if d not in dims]
+      dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
+    dims = tuple(d for d in dims if d in self.dims) if missing_dims == 'ignore' else tuple(dims)
+    if set(dims) != set(self.dims) or len(dims) != self.ndim:
+      raise ValueError(f'transpose dims {dims} must be a permutation of {self.dims}')
+    axes = [self.dims.index(d) for d in dims]
+    return self._replace(data=_transpose(self.data, axes), dims=dims)
+
+  def expand_dims(self, dim=None, axis=0, **dim_kwargs):
+    if dim is None:
+      dim = {}
+    elif isinstance(dim, str):
+      dim = {dim: 1}
+    elif isinstance(dim, (list, tuple)):
+      dim = {d: 1 for d in dim}
+    dim = dict(dim, **dim_kwargs)
+    out = self
+    for k, (name, spec) in enumerate(dim.items()):
+      if name in out.dims:
+        raise ValueError(f'dimension {name!r} already exists')
+      coord = None
+      if isinstance(spec, numbers.Integral):
+        n = int(spec)
+      else:
+        coord = np.asarray(spec.values if isinstance(spec, DataArray) else spec)
+        n = len(coord)
+      d = out.data
+      ax = axis + k if axis >= 0 else out.ndim + 1 + axis
+      if _is_torch(d):
+        d = d.unsqueeze(ax).expand(*d.shape[:ax], n, *d.shape[ax:])
+      else:
+        d = np.broadcast_to(np.expand_dims(d, ax), d.shape[:ax] + (n,) + d.shape[ax:])
+      dims = out.dims[:ax] + (name,) + out.dims[ax:]
+      coords = dict(out._coords)
+      if name in coords and coords[name][0] == ():
+        if coord is None and n == 1:
+          coord = np.asarray([coords[name][1]]).reshape(1)
+        del coords[name]
+      if coord is not None:
+        coords[name] = ((name,), coord)
+      out = out._replace(data=d, dims=dims, coords=coords)
+    return out
+
+  def squeeze(self, dim=None, drop=False):
+    dims = [d for d, n in self.sizes.items() if n == 1] if dim is None else ([dim] if isinstance(dim, str) else dim)
+    return self.isel({d: 0 for d in dims}, drop=drop)
+
+  def broadcast_like(self, other, exclude=None):
+    return broadcast(self, other)[0] if not exclude else self
+
+  # ---- elementwise -----------------------------------------------------------------------------------
+  def isnull(self):
+    return self._replace(data=_isnan(self.data))
+
+  def notnull(self):
+    return self._replace(data=~_isnan(self.data))
+
+  def fillna(self, value):
+    return self.where(self.notnull(), value)
+
+  def where(self, cond, other=np.nan, drop=False):
+    if not isinstance(cond, DataArray):
+      cond = np.asarray(cond)
+      cond = DataArray(cond, dims=self.dims[self.ndim - cond.ndim:])
+    if isinstance(other, DataArray):
+      return _binary(self, cond, None, ternary_other=other)
+    return _binary(self, cond, lambda a, c: _where(c, a, other))
+
+  def clip(self, min=None, max=None):  # pylint: disable=redefined-builtin
+    d = self.data
+    d = d.clamp(min=min, max=max) if _is_torch(d) else np.clip(d, min, max)
+    return self._replace(data=d)
+
+  def _unary(self, np_fn, torch_name=None):
+    d = self.data
+    if _is_torch(d):
+      return self._replace(data=getattr(_torch(), torch_name or np_fn.__name__)(d))
+    with np.errstate(all='ignore'):
+      return self._replace(data=np_fn(d))
+
+  def __abs__(self):
+    return self._unary(np.abs, 'abs')
+
+  def __neg__(self):
+    return self._replace(data=-self.data)
+
+  def __pos__(self):
+    return self
+
+  def __invert__(self):
+    return self._replace(data=~self.data)
+
+  def round(self, decimals=0):
+    d = self.data
+    return self._replace(data=d.round(decimals=decimals) if _is_torch(d) else np.round(d, decimals))
+
+  # numpy ufuncs applied to DataArrays (np.logical_and(lat >= a, lat <= b), np.sqrt(da), np.mod(lon, 360) ...)
+  def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+    if method != '__call__' or kwargs.get('out') is not None:
+      return NotImplemented
+    arrays = [x for x in inputs if isinstance(x, DataArray)]
+    if len(inputs) == 1:
+      with np.errstate(all='ignore'):
+        return arrays[0]._replace(data=ufunc(_host_or_same(arrays[0].data), **kwargs))
+    if len(inputs) == 2:
+      a, b = inputs
+      if not isinstance(a, DataArray):
+        a = DataArray(np.asarray(a))
+      if not isinstance(b, DataArray):
+        b = DataArray(np.asarray(b))
+
+      def fn(x, y):
+        with np.errstate(all='ignore'):
+          return ufunc(_host_or_same(x), _host_or_same(y), **kwargs)
+      return _binary(a, b, fn)
+    return NotImplemented
+
+  # ---- reductions ------------------------------------------------------------------------------------
+  def _reduce(self, op, dim=None, skipna=None, keep_attrs=None, ddof=0, **unused):
+    if dim is None or dim is Ellipsis:
+      dims = self.dims
+    elif isinstance(dim, str):
+      dims = (dim,)
+    else:
+      dims = tuple(dim)
+    for d in dims:
+      if d not in self.dims:
+        raise ValueError(f'dimension {d!r} not found in {self.dims}')
+    axes = tuple(self.dims.index(d) for d in dims)
+    if skipna is None:
+      skipna = _is_float(self.data)
+    data = _reduce(self.data, op, axes, bool(skipna), ddof)
+    new_dims = tuple(d for d in self.dims if d not in dims)
+    coords = {k: v for k, v in self._coords.items() if not (set(v[0]) & set(dims))}
+    if not _is_torch(data):
+      data = np.asarray(data)
+    return self._replace(data=data, dims=new_dims, coords=coords)
+
+  def sum(self, dim=None, skipna=None, **kw):
+    return self._reduce('sum', dim, skipna, **kw)
+
+  def mean(self, dim=None, skipna=None, **kw):
+    return self._reduce('mean', dim, skipna, **kw)
+
+  def var(self, dim=None, skipna=None, ddof=0, **kw):
+    return self._reduce('var', dim, skipna, ddof=ddof, **kw)
+
+  def std(self, dim=None, skipna=None, ddof=0, **kw):
+    return self._reduce('var', dim, skipna, ddof=ddof, **kw)._unary(np.sqrt, 'sqrt')
+
+  def min(self, dim=None, skipna=None, **kw):
+    return self._reduce('min', dim, skipna, **kw)
+
+  def max(self, dim=None, skipna=None, **kw):
+    return self._reduce('max', dim, skipna, **kw)
+
+  def count(self, dim=None, **kw):
+    return self._reduce('count', dim, False, **kw)
+
+  def any(self, dim=None, **kw):
+    return self._reduce('any', dim, False, **kw)
+
+  def all(self, dim=None, **kw):
+    return self._reduce('all', dim, False, **kw)
+
+  def equals(self, other) -> bool:
+    return (isinstance(other, DataArray) and self.dims == other.dims
+            and _values_equal(self.values, other.values))
+
+  def identical(self, other) -> bool:
+    return self.equals(other) and self.name == other.name
+
+  def to_dataset(self, name=None):
+    return Dataset({name or self.name: self})
+
+
+def _host_or_same(x):
+  return _to_numpy(x) if _is_torch(x) else x
+
+
+def as_dataarray(x) -> DataArray:
+  """Accepts DataArray, anything xarray-like (.dims/.coords/.values) or array-likes."""
+  if isinstance(x, DataArray):
+    return x
+  if hasattr(x, 'dims') and hasattr(x, 'coords') and hasattr(x, 'values'):
+    coords = {}
+    for k in x.coords:
+      c = x.coords[k]
+      coords[k] = (tuple(c.dims), np.asarray(c.values))
+    data = getattr(x, 'data', None)
+    if data is None or not (isinstance(data, np.ndarray) or _is_torch(data)):
+      data = np.asarray(x.values)
+    return DataArray(data, dims=tuple(x.dims), coords=coords, name=getattr(x, 'name', None),
+                     attrs=getattr(x, 'attrs', None), _raw_coords=True)
+  return DataArray(x)
+
+
+# --------------------------------------------------------------------------------------------------
+# alignment / broadcasting / binary ops
+def _join_indexes(arrays: Sequence[DataArray], join: str, exclude=()):
+  """-> {dim: joined index ndarray} for dims whose index coords differ between arrays."""
+  joined = {}
+  dims = []
+  for a in arrays:
+    for d in a.dims:
+      if d not in dims and d not in exclude:
+        dims.append(d)
+  for d in dims:
+    idxs = [np.asarray(a._coords[d][1]) for a in arrays if d in a.dims and d in a._coords]
+    if len(idxs) < 2:
+      continue
+    first = idxs[0]
+    if all(_values_equal(first, o) for o in idxs[1:]):
+      continue
+    if join == 'exact':
+      raise ValueError(f'indexes along {d!r} are not equal')
+    if join == 'inner':
+      cur = first
+      for o in idxs[1:]:
+        cur = cur[np.isin(cur, o)]
+      joined[d] = cur
+    elif join == 'outer':
+      cur = first
+      for o in idxs[1:]:
+        cur = np.union1d(cur, o)
+      joined[d] = cur
+    elif join == 'left':
+      joined[d] = first
+    else:
+      raise ValueError(join)
+  return joined
+
+
+def _reindex(a: DataArray, dim: str, new_index: np.ndarray, fill_value):
+  old = np.asarray(a._coords[dim][1])
+  order = np.argsort(old, kind='stable')
+  pos = np.clip(np.searchsorted(old[order], new_index), 0, max(len(old) - 1, 0))
+  src = order[pos] if len(old) else np.zeros(len(new_index), dtype=np.int64)
+  ok = old[src] == new_index if len(old) else np.zeros(len(new_index), dtype=bool)
+  out = a.isel({dim: src})
+  if not np.all(ok):
+    ax = out.dims.index(dim)
+    data = out.data
+    data = data.clone() if _is_torch(data) else np.array(data, copy=True)
+    fv = fill_value
+    if isinstance(fv, float) and np.isnan(fv) and not _is_float(data):
+      data = data.double() if _is_torch(data) else data.astype(np.float64)
+    sel = (slice(None),) * ax + (np.nonzero(~ok)[0],)
+    data[sel] = fv
+    out = out._replace(data=data)
+  out._coords[dim] = ((dim,), np.asarray(new_index))
+  return out
+
+
+def align(*arrays: DataArray, join='inner', fill_value=np.nan, exclude=()):
+  arrays = [as_dataarray(a) for a in arrays]
+  joined = _join_indexes(arrays, join, exclude=tuple(exclude))
+  out = []
+  for a in arrays:
+    for d, idx in joined.items():
+      if d in a.dims and d in a._coords and not _values_equal(a._coords[d][1], idx):
+        a = _reindex(a, d, idx, fill_value)
+    out.append(a)
+  return tuple(out)
+
+
+def broadcast(*arrays: DataArray):
+  arrays = [as_dataarray(a) for a in arrays]
+  dims, sizes = [], {}
+  for a in arrays:
+    for d, n in a.sizes.items():
+      if d not in dims:
+        dims.append(d)
+        sizes[d] = n
+      elif sizes[d] != n:
+        raise ValueError(f'size mismatch along {d!r}: {sizes[d]} vs {n}')
+  coords = {}
+  for a in arrays:
+    for k, v in a._coords.items():
+      coords.setdefault(k, v)
+  out = []
+  for a in arrays:
+    data = _bcast_data(a, dims, sizes)
+    out.append(a._replace(data=data, dims=dims, coords=coords))
+  return tuple(out)
+
+
+def _bcast_data(a: DataArray, dims, sizes):
+  """Payload of `a` transposed/expanded (as a broadcast view) to `dims`."""
+  present = [d for d in dims if d in a.dims]
+  data = _transpose(a.data, [a.dims.index(d) for d in present]) if tuple(present) != a.dims else a.data
+  idx = tuple(slice(None) if d in a.dims else None for d in dims)
+  data = data[idx] if len(idx) else data
+  shape = tuple(sizes[d] for d in dims)
+  if _shape(data) != shape:
+    data = data.expand(*shape) if _is_torch(data) else np.broadcast_to(data, shape)
+  return data
+
+
+def _merge_coords(a: DataArray, b: DataArray, out_dims):
+  coords = dict(a._coords)
+  for k, (cd, cv) in b._coords.items():
+    if k in coords:
+      ad, av = coords[k]
+      if ad != cd or not _values_equal(av, cv):
+        if k not in out_dims:  # conflicting non-index coordinate: dropped (xarray semantics)
+          del coords[k]
+    else:
+      coords[k] = (cd, cv)
+  dset = set(out_dims)
+  return {k: v for k, v in coords.items() if set(v[0]) <= dset}
+
+
+def _binary(a, b, fn, reflexive=False, ternary_other=None):
+  if not isinstance(a, DataArray):
+    a = DataArray(np.asarray(a)) if not _is_torch(a) else DataArray(a)
+  if not isinstance(b, DataArray):
+    if hasattr(b, 'dims') and hasattr(b, 'values'):
+      b = as_dataarray(b)
+    else:
+      b = DataArray(b if _is_torch(b) else np.asarray(b))
+  operands = [a, b]
+  if isinstance(ternary_other, DataArray):
+    operands.append(ternary_other)
+  joined = _join_indexes(operands, 'inner')
+  if joined:
+    operands = [o.isel({d: o._index_positions(d, idx) for d, idx in joined.items() if d in o.dims and d in o._coords})
+                for o in operands]
+  a, b = operands[0], operands[1]
+  dims, sizes = [], {}
+  for o in operands:
+    for d, n in o.sizes.items():
+      if d not in dims:
+        dims.append(d)
+        sizes[d] = n
+      elif sizes[d] != n:
+        raise ValueError(f'cannot broadcast: size mismatch along {d!r} ({sizes[d]} vs {n})')
+  da, db = _bcast_data(a, dims, sizes), _bcast_data(b, dims, sizes)
+  da, db = _coerce_pair(da, db)
+  if isinstance(ternary_other, DataArray):
+    dc = _bcast_data(operands[2], dims, sizes)
+    data = _where(db, da, dc)
+  else:
+    data = fn(db, da) if reflexive else fn(da, db)
+  coords = _merge_coords(a, b, dims)
+  out = a._replace(data=data, dims=dims, coords=coords, name=a.name if a.name == b.name or b.name is None else None)
+  return out
+
+
+def _coerce_pair(x, y):
+  """Bring a numpy operand onto the torch operand's device."""
+  if _is_torch(x) and not _is_torch(y):
+    y = _torch().as_tensor(np.ascontiguousarray(y), device=x.device)
+  elif _is_torch(y) and not _is_torch(x):
+    x = _torch().as_tensor(np.ascontiguousarray(x), device=y.device)
+  return x, y
+
+
+def _install_operators():
+  import operator  # pylint: disable=g-import-not-at-top
+
+  def np_safe(op):
+    def f(x, y):
+      if _is_torch(x) or _is_torch(y):
+        return op(x, y)
+      with np.errstate(all='ignore'):
+        return op(x, y)
+    return f
+
+  ops = {
+      'add': operator.add, 'sub': operator.sub, 'mul': operator.mul, 'truediv': operator.truediv,
+      'floordiv': operator.floordiv, 'mod': operator.mod, 'pow': operator.pow,
+      'and': operator.and_, 'or': operator.or_, 'xor': operator.xor,
+      'lt': operator.lt, 'le': operator.le, 'gt': operator.gt, 'ge': operator.ge,
+      'eq': operator.eq, 'ne': operator.ne,
+  }
+  for name, op in ops.items():
+    f = np_safe(op)
+
+    def fwd(self, other, _f=f):
+      if isinstance(other, (Dataset,)):
+        return NotImplemented
+      return _binary(self, other, _f)
+
+    def rev(self, other, _f=f):
+      return _binary(self, other, _f, reflexive=True)
+    setattr(DataArray, f'__{name}__', fwd)
+    if name not in ('lt', 'le', 'gt', 'ge', 'eq', 'ne'):
+      setattr(DataArray, f'__r{name}__', rev)
+  DataArray.__hash__ = None  # __eq__ is elementwise
+
+
+# --------------------------------------------------------------------------------------------------
+class Dataset(Mapping):
+  """Dict of DataArrays sharing coordinates (just enough for the scoring path)."""
+
+  def __init__(self, data_vars=None, coords=None, attrs=None):
+    self._vars: dict[Hashable, DataArray] = {}
+    self.attrs = dict(attrs) if attrs else {}
+    self._extra_coords = {}
+    if coords:
+      for k, v in dict(coords).items():
+        vals = np.asarray(v.values if isinstance(v, DataArray) else v)
+        dims = v.dims if isinstance(v, DataArray) else ((k,) if vals.ndim == 1 else ())
+        self._extra_coords[k] = (tuple(dims), vals)
+    for k, v in dict(data_vars or {}).items():
+      self[k] = v
+
+  def __setitem__(self, key, value):
+    if isinstance(value, tuple) and len(value) == 2 and not isinstance(value, DataArray):
+      dims, data = value
+      dims = (dims,) if isinstance(dims, str) else tuple(dims)
+      value = DataArray(data, dims=dims)
+    elif not isinstance(value, DataArray):
+      value = as_dataarray(value) if hasattr(value, 'dims') else DataArray(value)
+    value = value._replace(name=key)
+    for ck, (cd, cv) in self._extra_coords.items():
+      if ck not in value._coords and set(cd) <= set(value.dims) and all(
+          value.sizes[d] == n for d, n in zip(cd, np.shape(cv))):
+        value._coords[ck] = (cd, cv)
+    self._vars[key] = value
+
+  def __getitem__(self, key):
+    if isinstance(key, (list, tuple)) and not isinstance(key, str):
+      out = Dataset(attrs=self.attrs)
+      out._extra_coords = dict(self._extra_coords)
+      for k in key:
+        out._vars[k] = self._vars[k]
+      return out
+    if key in self._vars:
+      return self._vars[key]
+    c = self.coords
+    if key in c:
+      cd, cv = c[key]
+      return DataArray(cv, dims=cd, coords={key: (cd, cv)}, name=key, _raw_coords=True)
+    raise KeyError(key)
+
+  def __delitem__(self, key):
+    del self._vars[key]
+
+  def __iter__(self):
+    return iter(self._vars)
+
+  def __len__(self):
+    return len(self._vars)
+
+  def __contains__(self, key):
+    return key in self._vars
+
+  def __getattr__(self, name):
+    if name.startswith('_'):
+      raise AttributeError(name)
+    try:
+      return self[name]
+    except KeyError as e:
+      raise AttributeError(name) from e
+
+  def __repr__(self):
+    return f'<wbx Dataset vars={list(self._vars)} sizes={self.sizes}>'
+
+  @property
+  def data_vars(self):
+    return self._vars
+
+  @property
+  def coords(self) -> dict:
+    out = dict(self._extra_coords)
+    for v in self._vars.values():
+      for k, c in v._coords.items():
+        out.setdefault(k, c)
+    return out
+
+  @property
+  def sizes(self) -> dict:
+    out = {}
+    for v in self._vars.values():
+      out.update(v.sizes)
+    return out
+
+  @property
+  def dims(self):
+    return self.sizes
+
+  def _map(self, fn, keep_coords=True):
+    out = Dataset(attrs=self.attrs)
+    if keep_coords:
+      out._extra_coords = dict(self._extra_coords)
+    for k, v in self._vars.items():
+      r = fn(v)
+      if r is not None:
+        out._vars[k] = r._replace(name=k) if isinstance(r, DataArray) else r
+    return out
+
+  def map(self, fn, **kw):
+    return self._map(lambda v: fn(v, **kw))
+
+  def _present(self, indexers, v):
+    return {d: k for d, k in indexers.items() if d in v.dims}
+
+  def isel(self, indexers=None, drop=False, **kw):
+    ind = dict(indexers or {}, **kw)
+    return self._map(lambda v: v.isel(self._present(ind, v), drop=drop), keep_coords=False)
+
+  def sel(self, indexers=None, drop=False, **kw):
+    ind = dict(indexers or {}, **kw)
+    return self._map(lambda v: v.sel(self._present(ind, v), drop=drop), keep_coords=False)
+
+  def rename(self, names=None, **kw):
+    m = dict(names or {}, **kw)
+    out = Dataset(attrs=self.attrs)
+    out._extra_coords = {m.get(k, k): (tuple(m.get(d, d) for d in cd), cv) for k, (cd, cv) in self._extra_coords.items()}
+    for k, v in self._vars.items():
+      out._vars[m.get(k, k)] = v.rename({a: b for a, b in m.items() if a in v.dims or a in v._coords})._replace(
+          name=m.get(k, k))
+    return out
+
+  def expand_dims(self, dim=None, axis=0, **kw):
+    return self._map(lambda v: v.expand_dims(dim, axis=axis, **kw))
+
+  def transpose(self, *dims):
+    return self._map(lambda v: v.transpose(*[d for d in dims if d in v.dims or d is Ellipsis], missing_dims='ignore')
+                     if dims else v.transpose())
+
+  def where(self, cond, other=np.nan):
+    return self._map(lambda v: v.where(cond[v.name] if isinstance(cond, Dataset) else cond, other))
+
+  def astype(self, dtype):
+    return self._map(lambda v: v.astype(dtype))
+
+  def copy(self, deep=True):
+    return self._map(lambda v: v.copy(deep=deep))
+
+  def compute(self):
+    return self
+
+  def drop_vars(self, names, errors='raise'):
+    names = [names] if isinstance(names, str) else list(names)
+    out = self._map(lambda v: v.drop_vars([n for n in names if n in v._coords]))
+    for n in names:
+      out._vars.pop(n, None)
+      out._extra_coords.pop(n, None)
+    return out
+
+  def assign_coords(self, coords=None, **kw):
+    c = dict(coords or {}, **kw)
+    return self._map(lambda v: v.assign_coords({k: x for k, x in c.items()
+                                                if (k in v.dims or not np.ndim(getattr(x, 'values', x)))}))
+
+  def _reduce(self, op, dim=None, **kw):
+    def f(v):
+      d = [x for x in ([dim] if isinstance(dim, str) else (dim or v.dims)) if x in v.dims]
+      return getattr(v, op)(d, **kw)
+    return self._map(f, keep_coords=False)
+
+  def mean(self, dim=None, **kw):
+    return self._reduce('mean', dim, **kw)
+
+  def sum(self, dim=None, **kw):
+    return self._reduce('sum', dim, **kw)
+
+  def isnull(self):
+    return self._map(lambda v: v.isnull())
+
+  def equals(self, other):
+    return set(self) == set(other) and all(self[k].equals(other[k]) for k in self)
+
+  def _arith(self, other, op, reflexive=False):
+    def f(v):
+      o = other[v.name] if isinstance(other, (Dataset, dict)) else other
+      return op(o, v) if reflexive else op(v, o)
+    keys = [k for k in self if not isinstance(other, (Dataset, dict)) or k in other]
+    out = Dataset(attrs=self.attrs)
+    out._extra_coords = dict(self._extra_coords)
+    for k in keys:
+      out._vars[k] = f(self._vars[k])._replace(name=k)
+    return out
+
+
+def _install_dataset_operators():
+  import operator  # pylint: disable=g-import-not-at-top
+
+  for name, op in {'add': operator.add, 'sub': operator.sub, 'mul': operator.mul,
+                   'truediv': operator.truediv, 'pow': operator.pow}.items():
+    setattr(Dataset, f'__{name}__', lambda self, other, _op=op: self._arith(other, _op))
+    setattr(Dataset, f'__r{name}__', lambda self, other, _op=op: self._arith(other, _op, reflexive=True))
+  Dataset.__abs__ = lambda self: self._map(abs)
+  Dataset.__neg__ = lambda self: self._map(operator.neg)
+
+
+_install_operators()
+_install_dataset_operators()
+
+
+# --------------------------------------------------------------------------------------------------
+# module-level functions mirroring the xarray names the reference calls
+def ones_like(x, dtype=None):
+  return _full_like(x, 1, dtype)
+
+
+def zeros_like(x, dtype=None):
+  return _full_like(x, 0, dtype)
+
+
+def full_like(x, fill_value, dtype=None):
+  return _full_like(x, fill_value, dtype)
+
+
+def _full_like(x, value, dtype):
+  if isinstance(x, Dataset):
+    return x._map(lambda v: _full_like(v, value, dtype))
+  x = as_dataarray(x)
+  d = x.data
+  if _is_torch(d):
+    t = _torch()
+    data = t.full_like(d, value, dtype=getattr(t, np.dtype(dtype).name) if dtype is not None else None)
+  else:
+    data = np.full(x.shape, value, dtype=dtype or x.dtype)
+  return x._replace(data=data)
+
+
+def concat(arrays: Iterable[DataArray], dim: str, **unused) -> DataArray:
+  arrays = [as_dataarray(a) for a in arrays]
+  if not arrays:
+    raise ValueError('need at least one array to concatenate')
+  first = arrays[0]
+  if dim not in first.dims:
+    arrays = [a.expand_dims(dim) if dim not in a.dims else a for a in arrays]
+    first = arrays[0]
+  others = [d for d in first.dims if d != dim]
+  # broadcast/transposed to the first array's layout
+  norm = []
+  for a in arrays:
+    if set(a.dims) != set(first.dims):
+      a = broadcast(a, first.isel({dim: slice(0, 1)}).drop_vars([dim] if dim in first._coords else []))[0] \
+          if set(a.dims) < set(first.dims) else a
+    norm.append(a.transpose(*first.dims))
+  ax = first.dims.index(dim)
+  datas = [a.data for a in norm]
+  if any(_is_torch(d) for d in datas):
+    t = _torch()
+    dev = next(d.device for d in datas if _is_torch(d))
+    data = t.cat([d if _is_torch(d) else t.as_tensor(d, device=dev) for d in datas], dim=ax)
+  else:
+    data = np.concatenate(datas, axis=ax)
+  coords = {k: v for k, v in first._coords.items() if dim not in v[0]}
+  for k, (cd, cv) in first._coords.items():
+    if dim in cd and all(k in a._coords for a in norm):
+      cax = cd.index(dim)
+      coords[k] = (cd, np.concatenate([np.asarray(a._coords[k][1]) for a in norm], axis=cax))
+  del others
+  return first._replace(data=data, coords=coords)
+
+
+def dot(*arrays, dim=None, dims=None) -> DataArray:
+  """Generalised sum-product over `dim` (xr.dot): einsum by dimension name, float64 accumulation
+  follows the operands' promoted dtype like np.einsum."""
+  if dims is not None and dim is None:
+    dim = dims
+  arrays = [as_dataarray(a) for a in arrays]
+  all_dims = []
+  for a in arrays:
+    for d in a.dims:
+      if d not in all_dims:
+        all_dims.append(d)
+  if dim is None:
+    counts = {d: sum(d in a.dims for a in arrays) for d in all_dims}
+    dim = [d for d in all_dims if counts[d] > 1]
+  elif dim is Ellipsis:
+    dim = list(all_dims)
+  elif isinstance(dim, str):
+    dim = [dim]
+  dim = [d for d in dim if d in all_dims]
+  out_dims = [d for d in all_dims if d not in dim]
+  letters = {d: chr(ord('a') + i) if i < 26 else chr(ord('A') + i - 26) for i, d in enumerate(all_dims)}
+  spec = ','.join(''.join(letters[d] for d in a.dims) for a in arrays) + '->' + ''.join(letters[d] for d in out_dims)
+  datas = [a.data for a in arrays]
+  if any(_is_torch(d) for d in datas):
+    t = _torch()
+    dev = next(d.device for d in datas if _is_torch(d))
+    dt = t.float64 if any((not _is_torch(d) and np.asarray(d).dtype == np.float64) or
+                          (_is_torch(d) and d.dtype == t.float64) for d in datas) else None
+    ops = [(d if _is_torch(d) else t.as_tensor(np.ascontiguousarray(d), device=dev)) for d in datas]
+    ops = [o.to(dt) if dt is not None else (o.float() if o.dtype == t.bool else o) for o in ops]
+    data = t.einsum(spec, *ops)
+  else:
+    ops = [d.astype(np.float64) if d.dtype == bool and i else d for i, d in enumerate(datas)]
+    with np.errstate(all='ignore'):
+      data = np.einsum(spec, *ops)
+  coords = {}
+  for a in arrays:
+    for k, v in a._coords.items():
+      if set(v[0]) <= set(out_dims):
+        coords.setdefault(k, v)
+  return DataArray(data, dims=out_dims, coords=coords, _raw_coords=True)
+
+
+def merge(objects, **unused) -> Dataset:
+  out = Dataset()
+  for o in objects:
+    if isinstance(o, Dataset):
+      for k, v in o.items():
+        out[k] = v
+    else:
+      out[o.name] = o
+  return out
+
+
+def assert_allclose(a, b, rtol=1e-5, atol=1e-8, check_dim_order=True):
+  """xr.testing.assert_allclose: same dims (optionally order-insensitive), close values, equal NaNs."""
+  if isinstance(a, (Dataset, dict)):
+    assert set(a) == set(b), f'variables differ: {set(a)} vs {set(b)}'
+    for k in a:
+      assert_allclose(a[k], b[k], rtol=rtol, atol=atol, check_dim_order=check_dim_order)
+    return
+  a, b = as_dataarray(a), as_dataarray(b)
+  if not check_dim_order:
+    assert set(a.dims) == set(b.dims), f'dims differ: {a.dims} vs {b.dims}'
+    b = b.transpose(*a.dims)
+  assert a.dims == b.dims, f'dims differ: {a.dims} vs {b.dims}'
+  np.testing.assert_allclose(a.values, b.values, rtol=rtol, atol=atol, equal_nan=True)
