@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Benchmark of the scoring hot path on MI355X (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[1]): area-weighted RMSE / MSE / MAE / bias / ACC / prediction activity on one
+variable block float32[40 init, 10 lead, 5 level, 721 lat, 1440 lon] for predictions and targets plus a
+(dayofyear, hour)-indexed climatology, reduced over (init_time, latitude, longitude) with GridAreaWeighting --
+through the drop-in API (Statistic.compute -> Aggregator.aggregate_statistics -> metric_values), inputs resident
+in HBM.  A "step" is one such pass.  With --gpus N every rank owns a block of the same size (weak scaling) and
+the packed fp64 accumulators are summed with ONE all-reduce (RCCL) per step.
+
+value    = (points per step x 6 metrics x N) / wall time per step (max over ranks), evals/s
+roofline = algorithmic bytes (12 B/point: p, t, c read once) / mean stage-1 kernel duration (HIP events on the
+           launch stream, separate pass), against 8.0 TB/s
+cpu_baseline = the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
+           statistics; oracle/wbx_oracle.py) on a 2 init x 2 lead sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--inits', type=int, default=40)
+  ap.add_argument('--leads', type=int, default=10)
+  ap.add_argument('--levels', type=int, default=5)
+  ap.add_argument('--layout', choices=['lon_fastest', 'lat_fastest'], default='lon_fastest')
+  ap.add_argument('--no-ens', action='store_true', help='skip the ensemble (configs[2]) side measurement')
+  ap.add_argument('--ens-slices', type=int, default=8)
+  ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+  ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
+  return ap.parse_args()
+
+
+def main():
+  args = parse()
+  import torch
+  import torch.distributed as dist
+  from weatherbenchx_amd import _hip, aggregation, distributed, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import deterministic, probabilistic, wrappers
+
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+  torch.cuda.set_device(local_rank)
+  dev = torch.device('cuda', local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+  ctx = _hip.default_context(local_rank)
+
+  nlat, nlon = (721, 1440) if not args.small else (73, 144)
+  ni, nl, nlev = (args.inits, args.leads, args.levels) if not args.small else (4, 3, 2)
+  lat = np.linspace(-90, 90, nlat)
+  lon = np.linspace(0, 360, nlon, endpoint=False)
+  init_time = np.datetime64('2020-01-01T00', 'ns') + np.arange(ni) * np.timedelta64(24, 'h')
+  lead_time = (np.arange(nl) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  ndoy = int(ni + (nl * 6) // 24 + 2)
+  coords = {'init_time': init_time, 'lead_time': lead_time, 'level': np.arange(nlev), 'latitude': lat, 'longitude': lon}
+  sp = ('latitude', 'longitude') if args.layout == 'lon_fastest' else ('longitude', 'latitude')
+  dims = ('init_time', 'lead_time', 'level') + sp
+  cdims = ('dayofyear', 'hour', 'level') + sp
+  shape = tuple(len(coords[d]) for d in dims)
+  gen = torch.Generator(device=dev)
+  gen.manual_seed(1234 + rank)
+
+  def randn(shp, offset=0.0, scale=1.0):
+    return torch.randn(shp, generator=gen, device=dev, dtype=torch.float32) * scale + offset
+
+  cshape = (ndoy, 4) + shape[2:]
+  clim_t = randn(cshape, 280.0, 10.0)
+  clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=cdims, coords={
+      'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), **{d: coords[d] for d in cdims[2:]}})})
+  p_t = randn(shape, 280.0)
+  t_t = randn(shape, 280.0)
+  p = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}
+  t = {'z': xr.DataArray(t_t, dims=dims, coords=coords)}
+  torch.cuda.synchronize()
+
+  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(),
+             'bias': deterministic.Bias(), 'acc': deterministic.ACC(clim),
+             'prediction_activity': deterministic.PredictionActivity(clim)}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                               weigh_by=[weighting.GridAreaWeighting()])
+  from weatherbenchx_amd.metrics import base as metrics_base
+
+  def fresh(d):
+    # new DataArray objects every step: nothing (statistics, plans results) is cached across steps
+    return {k: xr.DataArray(v.data, dims=v.dims, coords={c: v[c].values for c in v.dims}) for k, v in d.items()}
+
+  def step():
+    pp, tt = fresh(p), fresh(t)
+    stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, pp, tt)
+    state = agg.aggregate_statistics(stats)
+    if world > 1:
+      state = distributed.all_reduce_state(state)
+    return state.metric_values(metrics)
+
+  def sync():
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    out = step()
+  sync()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    out = step()
+  sync()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tt_ = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+    dt = float(tt_.item())
+  ms_per_step = dt / args.steps * 1e3
+  points = int(np.prod(shape, dtype=np.int64))
+  n_metrics = len(metrics)
+  value = points * n_metrics * world / (ms_per_step * 1e-3)
+
+  # ---- roofline leg: HIP events around the dominant (stage-1) kernel, separate pass -------------------
+  engine.S1_EVENT_LOG = []
+  for _ in range(max(3, min(args.steps, 10))):
+    step()
+  log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'det']
+  engine.S1_EVENT_LOG = None
+  k_ms = float(np.mean([e['ms'] for e in log]))
+  alg_bytes = points * 12
+  achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+  roofline = {'bound': 'hbm', 'kernel': 's1_xr_kernel<DetOp<float,DET6>,4>' if log[0]['vec'] == 4 and not log[0]['x_kept']
+              else ('s1_xk_kernel<DetOp<float,DET6>>' if log[0]['x_kept'] else 's1_xr_kernel<DetOp<float,DET6>,1>'),
+              'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+              'kernel_ms': round(k_ms, 4), 'algorithmic_bytes_per_launch': alg_bytes, 'traffic': None}
+
+  result = {
+      'metric': 'grid-point·metric evals/s (area-weighted RMSE/MSE/MAE/bias/ACC/activity, 0.25deg 721x1440)',
+      'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f64', 'data': 'synthetic',
+      'config': {'workload': f'configs[1]: f32[{ni} init,{nl} lead,{nlev} level,{nlat},{nlon}] p,t + (doy,hour) climatology, '
+                             f'reduce (init_time,latitude,longitude), GridAreaWeighting, {args.layout}',
+                 'points_per_step_per_gpu': points, 'metrics': list(metrics), 'input_dtype': 'f32',
+                 'accumulators': 'f64', 'layout': args.layout, 'sharding': f'{world} x (init x lead) blocks, 1 all-reduce/step'},
+      'roofline': roofline,
+  }
+
+  # sanity: values must be finite and physically plausible (sigma=1 errors -> rmse ~ sqrt(2))
+  r = float(np.asarray(out['rmse.z'].values).mean())
+  assert np.isfinite(r) and abs(r - np.sqrt(2.0)) < 0.01, r
+  result['check'] = {'rmse_mean': r, 'acc_mean': float(np.asarray(out['acc.z'].values).mean())}
+
+  # ---- ensemble side measurement (configs[2] shape: 51 members, CRPS + spread/skill) ---------------------
+  if not args.no_ens and world == 1:
+    m = 51
+    ns = args.ens_slices if not args.small else 2
+    nvar = 6 if not args.small else 2
+    tv = {f'v{i}': randn((ns, nlat, nlon), 280.0) for i in range(nvar)}
+    pe = {k: xr.DataArray(v[:, None] + randn((ns, m, nlat, nlon)), dims=('lead_time', 'number', 'latitude', 'longitude'),
+                          coords={'latitude': lat, 'longitude': lon}) for k, v in tv.items()}
+    te = {k: xr.DataArray(v, dims=('lead_time', 'latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+          for k, v in tv.items()}
+    torch.cuda.synchronize()
+    emetrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True),
+                'unbiased_spread_skill': probabilistic.UnbiasedSpreadSkillRatio(),
+                'unbiased_mean_rmse': probabilistic.UnbiasedEnsembleMeanRMSE(),
+                'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
+    eagg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+    def estep():
+      return aggregation.compute_metric_values_for_single_chunk(emetrics, eagg, fresh(pe), fresh(te))
+    for _ in range(2):
+      eout = estep()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      eout = estep()
+    sync()
+    e_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    engine.S1_EVENT_LOG = []
+    for _ in range(3):
+      estep()
+    elog = [e['ms'] for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+    engine.S1_EVENT_LOG = None
+    epoints = ns * nlat * nlon  # per variable launch
+    ek_ms = float(np.mean(elog))
+    e_bytes = epoints * (m + 1) * 4
+    e_ach = e_bytes / (ek_ms * 1e-3) / 1e9
+    result['ensemble'] = {
+        'workload': f'configs[2]: {nvar} vars x f32[{ns} slices,{m} members,{nlat},{nlon}], CRPS(rank form, fair) + '
+                    'unbiased spread/skill + unbiased-mean RMSE + mean RMSE',
+        'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
+        'roofline': {'bound': 'hbm', 'kernel': 's1_xr_kernel<EnsOpF32<51,true,SORT>,1>', 'achieved': round(e_ach, 1),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(e_ach / HBM_PEAK_GBS, 4),
+                     'kernel_ms': round(ek_ms, 4), 'algorithmic_bytes_per_launch': e_bytes, 'traffic': None},
+        'check': {'crps_v0': float(np.asarray(eout['crps.v0'].values).mean())}}
+    del pe, te, tv
+
+  # ---- CPU baseline (rank 0, N=1): oracle's reference-structure NumPy path on a bounded sample -------------
+  if not args.no_cpu and world == 1 and rank == 0:
+    from oracle import wbx_oracle as O
+    si, sl = min(2, ni), min(2, nl)
+    idx = (slice(0, si), slice(0, sl))
+    ph, th = p_t[idx].cpu().numpy(), t_t[idx].cpu().numpy()
+    ch = clim_t[:si, :sl].cpu().numpy()  # any aligned climatology of the same shape: the CPU work is identical
+    if args.layout == 'lat_fastest':
+      ph, th, ch = (np.ascontiguousarray(np.swapaxes(a, -1, -2)) for a in (ph, th, ch))
+    w = O.grid_area_weights(lat)
+    t0 = time.perf_counter()
+    O.reference_structure_deterministic(ph, th, ch, w)
+    cdt = time.perf_counter() - t0
+    spoints = int(np.prod(ph.shape))
+    result['cpu_baseline'] = {'value': spoints * n_metrics / cdt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+                              'sample': f'{si} init x {sl} lead x {nlev} level x {nlat} x {nlon} of the same workload '
+                                        f'({spoints} points, {cdt:.1f} s; NumPy elementwise + einsum, single thread)',
+                              'host_cpus': os.cpu_count()}
+  if rank == 0:
+    print(json.dumps(result))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/ from the float64 oracle.
+
+The reference holds no stored arrays for this path (its fixtures are generated in-test) and cannot
+be imported here, so the vectors come from oracle/wbx_oracle.py AFTER it passed the restated reference tests
+(tests/test_oracle_reference_pins.py).  Inputs are stored too (float32), so the fixtures do not depend on the
+NumPy RNG implementation.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import wbx_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def config1():
+  """BASELINE.json configs[0]: RMSE + bias, 64x32 grid, 2 variables, 3 lead times (2 inits), area weights,
+  regions {global, northern-hemisphere} (evaluation_scripts/run_example_evaluation.py:172-185)."""
+  lat = np.linspace(-87.1875, 87.1875, 32)
+  lon = np.arange(64) * 5.625
+  rp, rt = np.random.default_rng(0), np.random.default_rng(1)
+  dims3 = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  dims2 = ('init_time', 'lead_time', 'latitude', 'longitude')
+  data = {}
+  for name, dims, shape in (('2m_temperature', dims2, (2, 3, 32, 64)), ('geopotential', dims3, (2, 3, 3, 32, 64))):
+    data[name] = (dims, rp.normal(size=shape).astype(np.float32), rt.normal(size=shape).astype(np.float32))
+  w = (O.grid_area_weights(lat), ('latitude',))
+  regions = {'global': ((-90, 90), (0, 360)), 'northern-hemisphere': ((20, 90), (0, 360))}
+  _, masks = O.region_masks(lat, lon, regions)
+  bins = ('region', masks, ('region', 'latitude', 'longitude'))
+  out = {'latitude': lat, 'longitude': lon}
+  for name, (dims, p, t) in data.items():
+    out[f'{name}__p'], out[f'{name}__t'] = p, t
+    for stat, fn in (('Error', O.error), ('SquaredError', O.squared_error)):
+      sws, sw, od = O.aggregate(fn(p, t), dims, ['init_time', 'latitude', 'longitude'], weights=[w], bin_masks=[bins])
+      out[f'{name}__{stat}__sws'], out[f'{name}__{stat}__sw'] = sws, sw
+    out[f'{name}__rmse'] = O.rmse(out[f'{name}__SquaredError__sws'] / out[f'{name}__SquaredError__sw'])
+    out[f'{name}__bias'] = out[f'{name}__Error__sws'] / out[f'{name}__Error__sw']
+  np.savez_compressed(os.path.join(HERE, 'config1_rmse_bias.npz'), **out)
+
+
+def ensembles():
+  """19x36 mock grid, M = 4 and 5 (weatherbenchX/metrics/metrics_test.py:610-660 sizes), every ensemble lane."""
+  lat = np.linspace(-90, 90, 19)
+  out = {'latitude': lat}
+  for m in (4, 5):
+    rng = np.random.default_rng(100 + m)
+    t = (rng.normal(size=(2, 19, 36)) + 280).astype(np.float32)
+    p = (t[:, None] + rng.normal(size=(2, m, 19, 36))).astype(np.float32)
+    pd, td = ('time', 'realization', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+    out[f'm{m}__p'], out[f'm{m}__t'] = p, t
+    w = (O.grid_area_weights(lat), ('latitude',))
+    lanes = {
+        'CRPSSkill': O.crps_skill(p, pd, t, td, 'realization')[0],
+        'CRPSSpread_fair': O.crps_spread(p, pd, 'realization', fair=True, use_sort=True)[0],
+        'CRPSSpread_unfair': O.crps_spread(p, pd, 'realization', fair=False, use_sort=False)[0],
+        'EnsembleVariance': O.ensemble_variance(p, pd, 'realization')[0],
+        'UnbiasedEnsembleMeanSquaredError': O.unbiased_ensemble_mean_squared_error(p, pd, t, td, 'realization')[0],
+        'EnsembleMeanSquaredError': O.ensemble_mean_squared_error(p, pd, t, td, 'realization')[0],
+    }
+    for k, v in lanes.items():
+      sws, sw, _ = O.aggregate(v, td, ['latitude', 'longitude'], weights=[w])
+      out[f'm{m}__{k}__mean'] = sws / sw
+      out[f'm{m}__{k}__point'] = v[0, 3, :5]
+  np.savez_compressed(os.path.join(HERE, 'ensemble_19x36.npz'), **out)
+
+
+def weights_and_spectrum():
+  out = {'w721': O.grid_area_weights(np.linspace(-90, 90, 721)),
+         'w721_desc_unnorm': O.grid_area_weights(np.linspace(90, -90, 721), normalized=False)}
+  rng = np.random.default_rng(4)
+  f = rng.normal(size=(16, 32)).astype(np.float32)
+  out['spec_field'] = f
+  out['spec_power'] = O.zonal_power_spectrum(f)
+  np.savez_compressed(os.path.join(HERE, 'weights_spectrum.npz'), **out)
+
+
+if __name__ == '__main__':
+  config1()
+  ensembles()
+  weights_and_spectrum()
+  print('golden vectors written to', HERE)

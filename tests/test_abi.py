@@ -1,0 +1,57 @@
+"""The C-ABI library loads and exports every symbol include/wbx.h declares (no GPU, no compute calls),
+and the product path fails loudly -- never falls back to CPU -- when no device is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from weatherbenchx_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+  text = open(os.path.join(ROOT, 'include', 'wbx.h')).read()
+  text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+  return set(re.findall(r'\b(wbx_[a-z0-9_]+)\s*\(', text))
+
+
+def test_library_exports_every_declared_symbol():
+  assert os.path.exists(_hip.lib_path()), 'libwbx_hip.so is not built: run __graft_entry__.build()'
+  lib = ctypes.CDLL(_hip.lib_path())
+  declared = _header_symbols()
+  assert declared == set(_hip.EXPORTED_SYMBOLS)
+  for name in declared:
+    assert hasattr(lib, name), f'{name} declared in include/wbx.h but not exported'
+  assert _hip.load_library().wbx_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+  # 3*8 + 2*4 + 8 + 4*8 + 4*8 + 4*8 + 3*8 + 4*4 = 176 bytes, 8-byte aligned
+  assert ctypes.sizeof(_hip.S1PlanStruct) == 176
+  assert ctypes.sizeof(_hip.S2PlanStruct) == 64
+
+
+def test_no_cpu_fallback_without_a_device():
+  if _hip.is_available():
+    pytest.skip('a HIP device is visible')
+  import numpy as np
+  from weatherbenchx_amd import aggregation
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import deterministic
+  p = {'v': xr.DataArray(np.zeros((4, 8), np.float32), dims=('latitude', 'longitude'))}
+  with pytest.raises(_hip.WbxUnavailableError):
+    aggregation.compute_metric_values_for_single_chunk({'rmse': deterministic.RMSE()},
+                                                       aggregation.Aggregator(reduce_dims=['latitude', 'longitude']), p, p)
+  with pytest.raises(_hip.WbxUnavailableError):
+    deterministic.SquaredError().compute(p, p)['v'].values  # materialisation also needs the device
+
+
+def test_product_code_never_imports_the_oracle():
+  pkg = os.path.join(ROOT, 'weatherbenchx_amd')
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith('.py'):
+        src = open(os.path.join(dirpath, f)).read()
+        assert 'from oracle' not in src and 'import oracle' not in src, f'{f} imports the oracle'

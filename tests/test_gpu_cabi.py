@@ -1,0 +1,231 @@
+"""GPU-only parity tests that go straight through the C ABI (libwbx_hip.so) -- edge cases, error behaviour and
+size-independent properties at BASELINE.json's full grid (721 x 1440), where the oracle would be too slow
+to brute-force everything.  Tolerance: rtol 1e-6 (north_star); fp64 accumulation actually gives ~1e-12."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import planner
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import probabilistic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+@pytest.fixture(scope='module')
+def ctx():
+  assert _hip.is_available(), 'gpu tests need libwbx_hip.so and a HIP device'
+  return _hip.default_context(0)
+
+
+def _reduce(inputs, dims, sizes, reduce_dims, func, **kw):
+  return engine.reduce_statistics('det', inputs, dims, sizes, reduce_dims, None, (), func=func, **kw)
+
+
+def test_device_is_gfx950(ctx):
+  assert 'gfx950' in ctx.device_name()
+
+
+@pytest.mark.parametrize('nx', [1, 3, 4, 63, 64, 65, 255, 257, 1024, 1444])
+def test_ragged_row_lengths_both_modes(ctx, nx):
+  rng = np.random.default_rng(nx)
+  p = xr.DataArray(rng.normal(size=(5, 7, nx)).astype(np.float32), dims=('a', 'b', 'x'))
+  t = xr.DataArray(rng.normal(size=(5, 7, nx)).astype(np.float32), dims=('a', 'b', 'x'))
+  sizes = {'a': 5, 'b': 7, 'x': nx}
+  e = p.values.astype(np.float64) - t.values
+  # x summed (XR kernel; vec4 when nx % 4 == 0)
+  vals, cnt, od = _reduce([p, t], p.dims, sizes, ['b', 'x'], _hip.DET3)
+  assert od == ('a',)
+  np.testing.assert_allclose(vals[2], (e * e).sum(axis=(1, 2)), rtol=1e-12)
+  np.testing.assert_allclose(cnt[0], 7 * nx)
+  # x kept (XK kernel)
+  vals, cnt, od = _reduce([p, t], p.dims, sizes, ['a', 'b'], _hip.DET3)
+  assert od == ('x',)
+  np.testing.assert_allclose(vals[1], np.abs(e).sum(axis=(0, 1)), rtol=1e-12)
+  np.testing.assert_allclose(vals[0], e.sum(axis=(0, 1)), rtol=1e-9, atol=1e-12)
+
+
+def test_empty_reductions(ctx):
+  p = xr.DataArray(np.zeros((3, 0, 8), np.float32), dims=('a', 'b', 'x'))
+  vals, cnt, od = _reduce([p, p], p.dims, {'a': 3, 'b': 0, 'x': 8}, ['b', 'x'], _hip.DET3)
+  np.testing.assert_array_equal(vals[2], np.zeros(3))
+  np.testing.assert_array_equal(cnt[2], np.zeros(3))
+  q = xr.DataArray(np.zeros((0, 4), np.float32), dims=('a', 'x'))
+  vals, _, od = _reduce([q, q], q.dims, {'a': 0, 'x': 4}, ['x'], _hip.DET3)
+  assert vals[0].shape == (0,)
+
+
+def test_vec4_and_scalar_paths_agree(ctx):
+  rng = np.random.default_rng(0)
+  base = rng.normal(size=(6, 9, 130)).astype(np.float32)
+  p = xr.DataArray(base[:, :, :128], dims=('a', 'b', 'x'))       # sliced view -> contiguous upload, nx % 4 == 0
+  t = xr.DataArray(base[:, :, 1:129].copy(), dims=('a', 'b', 'x'))
+  sizes = {'a': 6, 'b': 9, 'x': 128}
+  lays = [engine._to_device(ctx, v, _hip.F32).layout for v in (p, t)]
+  plan4 = planner.build_s1_plan(p.dims, sizes, lays, ['b', 'x'])
+  plan1 = planner.build_s1_plan(p.dims, sizes, lays, ['b', 'x'], allow_vec4=False)
+  assert plan4.vec == 4 and plan1.vec == 1
+  outs = []
+  for plan in (plan4, plan1):
+    devs = [engine._to_device(ctx, v, _hip.F32) for v in (p, t)] + [None, None]
+    buf = engine._run_s1(ctx, 'det', engine._device_plan(ctx, plan), plan, devs, _hip.F32, 3, func=_hip.DET3)
+    outs.append(ctx.download(buf.ptr, plan.partial_shape(3)))
+  np.testing.assert_allclose(outs[0].sum(axis=3), outs[1].sum(axis=3), rtol=1e-13)
+
+
+def test_bad_arguments_return_error_codes(ctx):
+  lib = ctx.lib
+  plan = _hip.S1PlanStruct()
+  plan.nkey, plan.ndepth, plan.nx, plan.nchunk, plan.depth_chunk, plan.block_threads, plan.vec = 1, 1, 4, 1, 1, 100, 1
+  rc = lib.wbx_det_partial(ctx.handle, C.byref(plan), _hip.DET3, _hip.F32, None, None, None, None, None)
+  assert rc == -1 and b'block_threads' in lib.wbx_last_error()
+  plan.block_threads = 64
+  rc = lib.wbx_det_partial(ctx.handle, C.byref(plan), 7, _hip.F32, C.c_void_p(8), C.c_void_p(8), None, None, C.c_void_p(8))
+  assert rc == -1 and b'unknown deterministic family' in lib.wbx_last_error()
+  rc = lib.wbx_ens_partial(ctx.handle, C.byref(plan), _hip.F32, 0, 1, 0, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8))
+  assert rc == -1 and b'ensemble size' in lib.wbx_last_error()
+  with pytest.raises(_hip.WbxError, match='lane'):
+    _hip.check(lib.wbx_det_map(ctx.handle, C.byref(plan), _hip.DET3, _hip.F32, 5, C.c_void_p(8), C.c_void_p(8), None,
+                               C.c_void_p(8)), 'wbx_det_map')
+  h = C.c_void_p(0)
+  assert lib.wbx_ctx_create(99, None, C.byref(h)) == -1
+
+
+def test_nan_poisons_every_bin_but_skipna_counts_it_out(ctx):
+  from weatherbenchx_amd import binning
+  lat, lon = np.linspace(-85, 85, 18), np.arange(36) * 10.0
+  pv = np.ones((18, 36), np.float32)
+  pv[15, 3] = np.nan  # northern hemisphere only
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'v': xr.DataArray(pv, dims=('latitude', 'longitude'), coords=coords)}
+  t = {'v': xr.DataArray(np.zeros((18, 36), np.float32), dims=('latitude', 'longitude'), coords=coords)}
+  regions = binning.Regions({'north': ((0, 90), (0, 360)), 'south': ((-90, 0), (0, 360))})
+  m = {'mse': deterministic.MSE()}
+  res = aggregation.compute_metric_values_for_single_chunk(
+      m, aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], bin_by=[regions]), p, t)
+  assert np.isnan(res['mse.v'].values).all()  # NaN * 0 = NaN: aggregation.py:272-277
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], bin_by=[regions], skipna=True)
+  state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(m, p, t))
+  np.testing.assert_allclose(state.sum_weights['SquaredError']['v'].values, [9 * 36 - 1, 9 * 36])
+  np.testing.assert_allclose(state.metric_values(m)['mse.v'].values, [1.0, 1.0])
+
+
+# ---- full-grid properties (721 x 1440, BASELINE.json sizes) ------------------------------------------------
+NLAT, NLON = 721, 1440
+LAT = np.linspace(-90, 90, NLAT)
+LON = np.linspace(0, 360, NLON, endpoint=False)
+
+
+def _torch_field(shape, seed, offset=280.0):
+  import torch
+  g = torch.Generator(device='cuda')
+  g.manual_seed(seed)
+  return torch.randn(shape, generator=g, device='cuda', dtype=torch.float32) + offset
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_full_grid_constant_error_is_exact_and_layouts_agree(ctx, layout):
+  import torch
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  dims = ('init_time', 'lead_time', 'level') + sp
+  n = {'init_time': 3, 'lead_time': 2, 'level': 2, 'latitude': NLAT, 'longitude': NLON}
+  shape = tuple(n[d] for d in dims)
+  tt = _torch_field(shape, 1)
+  pt = tt + 1.5
+  coords = {'latitude': LAT, 'longitude': LON}
+  p = {'z': xr.DataArray(pt, dims=dims, coords=coords)}
+  t = {'z': xr.DataArray(tt, dims=dims, coords=coords)}
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  # fp32(t + 1.5) - t is 1.5 up to fp32 rounding of the sum: |e - 1.5| <= ulp(281.5)/2 ~ 1.5e-5
+  for k in ('rmse.z', 'mae.z', 'bias.z'):
+    assert res[k].shape == (2, 2)
+    np.testing.assert_allclose(res[k].values, 1.5, rtol=2e-5)
+  # exact cross-check against torch fp64 on the same device data (independent code path)
+  e = (pt.double() - tt.double())
+  w = torch.as_tensor(O.grid_area_weights(LAT), device='cuda')
+  wshape = [1] * 5
+  wshape[dims.index('latitude')] = NLAT
+  red = tuple(dims.index(d) for d in ('init_time', 'latitude', 'longitude'))
+  want = ((e * e) * w.reshape(wshape)).sum(dim=red) / (w.sum() * NLON * 3)
+  np.testing.assert_allclose(res['rmse.z'].values, np.sqrt(want.cpu().numpy()), rtol=1e-10)
+
+
+def test_full_grid_chunking_is_invisible(ctx):
+  """Splitting depth in many chunks or few must not change the sums (different launch geometry, same bytes)."""
+  dims = ('init_time', 'latitude', 'longitude')
+  pt, tt = _torch_field((8, NLAT, NLON), 2), _torch_field((8, NLAT, NLON), 3)
+  p, t = xr.DataArray(pt, dims=dims), xr.DataArray(tt, dims=dims)
+  sizes = {'init_time': 8, 'latitude': NLAT, 'longitude': NLON}
+  lays = [planner.layout_of(v.data, dims) for v in (p, t)]
+  outs = []
+  for target in (1, 64, 100000):
+    plan = planner.build_s1_plan(dims, sizes, lays, ['init_time', 'longitude'], wdep_dims=['latitude'],
+                                 target_blocks=target)
+    devs = [engine._to_device(ctx, v, _hip.F32) for v in (p, t)] + [None, None]
+    buf = engine._run_s1(ctx, 'det', engine._device_plan(ctx, plan), plan, devs, _hip.F32, 3, func=_hip.DET3)
+    outs.append(ctx.download(buf.ptr, plan.partial_shape(3)).sum(axis=(3, 5)))
+  np.testing.assert_allclose(outs[0], outs[1], rtol=1e-12)
+  np.testing.assert_allclose(outs[0], outs[2], rtol=1e-12)
+
+
+@pytest.mark.parametrize('use_sort', [True, False])
+def test_full_grid_ensemble_closed_form(ctx, use_sort):
+  """Members t + k*d (k = 0..M-1): skill = d(M-1)/2, fair spread = d(M+1)/3, var = d^2 M(M+1)/12 -- exact."""
+  import torch
+  m, d = 51, 0.25
+  tt = _torch_field((NLAT, NLON), 4, offset=0.0).round()  # integers: t + k*d is exact in fp32
+  k = torch.arange(m, device='cuda', dtype=torch.float32)
+  perm = torch.randperm(m, device='cuda')
+  pt = tt[None] + (k[perm] * d)[:, None, None]
+  coords = {'latitude': LAT, 'longitude': LON}
+  p = {'v': xr.DataArray(pt, dims=('number', 'latitude', 'longitude'), coords=coords)}
+  t = {'v': xr.DataArray(tt, dims=('latitude', 'longitude'), coords=coords)}
+  metrics = {'skill': probabilistic.CRPSSkill(), 'spread': probabilistic.CRPSSpread(use_sort=use_sort),
+             'var': probabilistic.EnsembleVariance(), 'crps': probabilistic.CRPSEnsemble(use_sort=use_sort)}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  np.testing.assert_allclose(res['skill.v'].values, d * (m - 1) / 2, rtol=1e-12)
+  np.testing.assert_allclose(res['spread.v'].values, d * (m + 1) / 3, rtol=1e-6 if not use_sort else 1e-12)
+  np.testing.assert_allclose(res['var.v'].values, d * d * m * (m + 1) / 12, rtol=1e-10)
+  np.testing.assert_allclose(res['crps.v'].values, d * (m - 1) / 2 - 0.5 * d * (m + 1) / 3, rtol=1e-6)
+
+
+def test_oracle_parity_on_a_full_grid_slice(ctx):
+  """One 721x1440 field pair + 5 members: every fused lane against the float64 oracle."""
+  rng = np.random.default_rng(7)
+  tv = (rng.normal(size=(NLAT, NLON)) + 280).astype(np.float32)
+  pv = (tv[None] + rng.normal(size=(5, NLAT, NLON))).astype(np.float32)
+  coords = {'latitude': LAT, 'longitude': LON}
+  p = {'v': xr.DataArray(pv, dims=('number', 'latitude', 'longitude'), coords=coords)}
+  t = {'v': xr.DataArray(tv, dims=('latitude', 'longitude'), coords=coords)}
+  metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  pd, td = ('number', 'latitude', 'longitude'), ('latitude', 'longitude')
+  w = (O.grid_area_weights(LAT), ('latitude',))
+
+  def mean(a):
+    sws, sw, _ = O.aggregate(a, td, list(td), weights=[w])
+    return sws / sw
+  want = O.crps(mean(O.crps_skill(pv, pd, tv, td, 'number')[0]), mean(O.crps_spread(pv, pd, 'number', use_sort=True)[0]))
+  np.testing.assert_allclose(res['crps.v'].values, want, rtol=RTOL)
+  want = O.unbiased_spread_skill_ratio(mean(O.ensemble_variance(pv, pd, 'number')[0]),
+                                       mean(O.unbiased_ensemble_mean_squared_error(pv, pd, tv, td, 'number')[0]))
+  np.testing.assert_allclose(res['ssr.v'].values, want, rtol=RTOL)
+  # deterministic suite on member 0
+  p0 = {'v': xr.DataArray(pv[0], dims=td, coords=coords)}
+  r = aggregation.compute_metric_values_for_single_chunk({'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()},
+                                                         agg, p0, t)
+  np.testing.assert_allclose(r['rmse.v'].values, np.sqrt(mean(O.squared_error(pv[0], tv))), rtol=RTOL)
+  np.testing.assert_allclose(r['bias.v'].values, mean(O.error(pv[0], tv)), rtol=RTOL, atol=1e-9)

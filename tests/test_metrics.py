@@ -1,0 +1,337 @@
+"""Statistic / Metric behaviour, restating weatherbenchX/metrics/metrics_test.py:44-98, 501-544, 603-660,
+947-1006, 1276-1308 and metrics/base_test.py:24-91 against the drop-in classes, plus parity of every fused
+lane against the float64 oracle on random data in several memory layouts (tolerance: rtol 1e-6 as north_star
+states; the fp64 accumulators actually land at ~1e-12)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import mock_data
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import probabilistic
+from weatherbenchx_amd.metrics import wrappers
+
+RTOL = 1e-6
+
+
+def compute_all_metrics(metrics, predictions, targets, reduce_dims, **kw):
+  """metrics/metrics_test_utils.py:86-95."""
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, predictions, targets)
+  return aggregation.Aggregator(reduce_dims=reduce_dims, **kw).aggregate_statistics(stats).metric_values(metrics)
+
+
+# ---- protocol (base_test.py) -------------------------------------------------------------------------
+def test_per_variable_statistics_on_subsets_of_variables(backend):
+  class Stat1(metrics_base.PerVariableStatistic):
+    def _compute_per_variable(self, predictions, targets):
+      return None if targets.name == 'a' else predictions
+
+  class Stat2(metrics_base.PerVariableStatistic):
+    def _compute_per_variable(self, predictions, targets):
+      return None if targets.name == 'b' else targets
+
+  class Metric(metrics_base.PerVariableMetric):
+    statistics = {'stat1': Stat1(), 'stat2': Stat2()}
+
+    def _values_from_mean_statistics_per_variable(self, stats):
+      return stats['stat1'] + stats['stat2']
+
+  predictions = xr.Dataset(dict(a=xr.DataArray(1.0), b=xr.DataArray(2.0), c=xr.DataArray(3.0)))
+  targets = xr.Dataset(dict(a=xr.DataArray(10.0), b=xr.DataArray(20.0), c=xr.DataArray(30.0)))
+  result = compute_all_metrics({'metric': Metric(), 'stat1': Stat1(), 'stat2': Stat2()}, predictions, targets, [])
+  assert 'stat1.a' not in result and 'stat1.b' in result and 'stat1.c' in result
+  assert 'stat2.a' in result and 'stat2.b' not in result and 'stat2.c' in result
+  assert set(k for k in result if k.startswith('metric.')) == {'metric.c'}
+  np.testing.assert_allclose(result['metric.c'].values, 33.0)
+
+
+def test_statistic_only_for_common_variables_and_plain_dict(backend):
+  class Stat(metrics_base.PerVariableStatistic):
+    def _compute_per_variable(self, predictions, targets):
+      return abs(predictions - targets)
+
+  predictions = xr.Dataset(dict(a=xr.DataArray(1.0), b=xr.DataArray(2.0)))
+  targets = dict(b=xr.DataArray(20.0), c=xr.DataArray(30.0))
+  result = Stat().compute(predictions, targets)
+  assert isinstance(result, dict) and list(result) == ['b']
+
+
+def test_failed_statistic_is_wrapped_in_value_error(backend):
+  class Boom(metrics_base.PerVariableStatistic):
+    def _compute_per_variable(self, predictions, targets):
+      raise RuntimeError('boom')
+
+  with pytest.raises(ValueError, match='Failed to compute statistic Boom'):
+    metrics_base.compute_unique_statistics_for_all_metrics({'b': Boom()}, {'a': xr.DataArray(1.0)},
+                                                           {'a': xr.DataArray(1.0)})
+
+
+def test_statistics_are_deduplicated_by_unique_name(backend):
+  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE()}
+  p = {'v': xr.DataArray(np.ones((3, 4), np.float32), dims=('latitude', 'longitude'))}
+  t = {'v': xr.DataArray(np.zeros((3, 4), np.float32), dims=('latitude', 'longitude'))}
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t)
+  assert list(stats) == ['SquaredError']
+
+
+# ---- deterministic known answers ---------------------------------------------------------------------
+@pytest.mark.parametrize('split_variables', [False, True])
+def test_statistics_computation(backend, split_variables):
+  target = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-20T00',
+                                          variables_2d=['2m_temperature', '10m_wind_speed'])
+  prediction = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00',
+                                              variables_2d=['2m_temperature', '10m_wind_speed']) + 1
+  if split_variables:
+    target, prediction = dict(target), dict(prediction)
+  metrics = {'rmse': deterministic.RMSE()}
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, prediction, target)
+  assert set(stats['SquaredError']) == set(target)
+  assert stats['SquaredError']['2m_temperature'].mean() == 1.0      # materialised by the map kernel
+  assert stats['SquaredError']['geopotential'].shape == prediction['geopotential'].shape
+  for v in stats['SquaredError']:
+    assert metrics_base.compute_metric_from_statistics(metrics['rmse'], stats)[v].dims == stats['SquaredError'][v].dims
+
+
+def test_wind_vector_rmse(backend):
+  names2d = ['10m_u_component_of_wind', '10m_v_component_of_wind']
+  names3d = ['u_component_of_wind', 'v_component_of_wind']
+  target = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-20T00', variables_2d=names2d,
+                                          variables_3d=names3d) + 1
+  prediction = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00',
+                                              variables_2d=names2d, variables_3d=names3d)
+  metrics = {'vector_rmse': deterministic.WindVectorRMSE(['u_component_of_wind', '10m_u_component_of_wind'],
+                                                         ['v_component_of_wind', '10m_v_component_of_wind'],
+                                                         ['wind', '10m_wind'])}
+  results = compute_all_metrics(metrics, prediction, target, ['time', 'latitude', 'longitude'])
+  assert set(results) == {'vector_rmse.wind', 'vector_rmse.10m_wind'}
+  np.testing.assert_allclose(results['vector_rmse.wind'].values, np.sqrt(2))
+  np.testing.assert_allclose(results['vector_rmse.10m_wind'].values, np.sqrt(2))
+  assert set(results['vector_rmse.wind'].dims) == {'prediction_timedelta', 'level'}
+
+
+def test_acc_is_one(backend):
+  prediction = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-02T00').rename(
+      time='init_time', prediction_timedelta='lead_time')
+  target = prediction.copy()
+  climatology = target.isel(init_time=0, lead_time=0, drop=True).expand_dims(
+      dayofyear=np.arange(1, 367), hour=np.array([0, 6, 12, 18])) - 1
+  metrics = {'acc': deterministic.ACC(climatology=climatology),
+             'activity': deterministic.PredictionActivity(climatology=climatology)}
+  results = compute_all_metrics(metrics, prediction, target, ['latitude', 'longitude'])
+  for v in ('acc.2m_temperature', 'acc.geopotential', 'activity.geopotential'):
+    np.testing.assert_allclose(results[v].values, 1.0)
+
+
+# ---- ensemble known answers ----------------------------------------------------------------------------
+@pytest.mark.parametrize('m,use_sort,fair', list(itertools.product([4, 5], [False, True], [True, False])))
+def test_crps_equals_brute_force(backend, m, use_sort, fair):
+  targets = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True, seed=10)
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True,
+                                               ensemble_size=m, seed=11)
+  metrics = {'crps': probabilistic.CRPSEnsemble(ensemble_dim='realization', use_sort=use_sort, fair=fair)}
+  results = compute_all_metrics(metrics, predictions, targets, ['latitude', 'longitude'])
+  for v in ['2m_temperature', 'geopotential']:
+    p, t = predictions[v], targets[v]
+    spread = abs(p - p.rename(realization='dummy')).mean(('latitude', 'longitude', 'realization', 'dummy'),
+                                                         skipna=False) * (m / (m - int(fair)))
+    skill = abs(t - p).mean(('latitude', 'longitude', 'realization'), skipna=False)
+    xr.assert_allclose(skill - 0.5 * spread, results[f'crps.{v}'], rtol=1e-9, check_dim_order=False)
+
+
+def test_crps_spread_needs_two_members(backend):
+  p = {'v': xr.DataArray(np.zeros((1, 3)), dims=('number', 'x'))}
+  t = {'v': xr.DataArray(np.zeros(3), dims=('x',))}
+  with pytest.raises(ValueError, match='Failed to compute statistic CRPSSpread') as info:
+    metrics_base.compute_unique_statistics_for_all_metrics({'c': probabilistic.CRPSEnsemble()}, p, t)
+  assert 'n_ensemble < 2' in str(info.value.__cause__)
+  with pytest.raises(ValueError, match='SpreadSkillRatio is no longer supported'):
+    probabilistic.SpreadSkillRatio(ensemble_dim='number')
+
+
+def test_spread_skill_ratio_near_one(backend):
+  m = 5
+  targets = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', variables_3d=[],
+                                       random=True, seed=0)
+  predictions = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', variables_3d=[],
+                                           ensemble_size=m, random=True, seed=1)
+  metrics = {'ssr': probabilistic.UnbiasedSpreadSkillRatio(ensemble_dim='realization'),
+             'rmv': probabilistic.EnsembleRootMeanVariance(ensemble_dim='realization'),
+             'urmse': probabilistic.UnbiasedEnsembleMeanRMSE(ensemble_dim='realization')}
+  results = compute_all_metrics(metrics, predictions, targets, ['time', 'latitude', 'longitude'])
+  n = np.prod(list(targets['2m_temperature'].shape))
+  assert abs(float(results['ssr.2m_temperature'].values) - 1) < 4 / np.sqrt(n * m)
+  np.testing.assert_allclose(results['rmv.2m_temperature'].values / results['urmse.2m_temperature'].values,
+                             results['ssr.2m_temperature'].values)
+
+
+def test_ensemble_averaged_metric_equals_reducing_over_members(backend):
+  targets = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True, seed=3)
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True,
+                                               ensemble_size=5, seed=4)
+  expected = compute_all_metrics({'rmse': deterministic.RMSE()}, predictions, targets,
+                                 ['latitude', 'longitude', 'realization'])
+  actual = compute_all_metrics({'rmse': probabilistic.EnsembleAveragedMetric(deterministic.RMSE(),
+                                                                             ensemble_dim='realization')},
+                               predictions, targets, ['latitude', 'longitude'])
+  for v in expected:
+    xr.assert_allclose(actual[v], expected[v], rtol=1e-10, check_dim_order=False)
+
+
+def test_mean_rmse_through_wrapped_metric(backend):
+  rng = np.random.default_rng(5)
+  p = {'v': xr.DataArray(rng.normal(size=(6, 7, 8)).astype(np.float32), dims=('number', 'latitude', 'longitude'))}
+  t = {'v': xr.DataArray(rng.normal(size=(7, 8)).astype(np.float32), dims=('latitude', 'longitude'))}
+  metrics = {'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')]),
+             'crps': probabilistic.CRPSEnsemble(use_sort=True)}
+  res = compute_all_metrics(metrics, p, t, ['latitude', 'longitude'])
+  want = np.sqrt(((p['v'].values.astype(np.float64).mean(0) - t['v'].values) ** 2).mean())
+  np.testing.assert_allclose(res['mean_rmse.v'].values, want, rtol=RTOL)
+  stat = list(metrics['mean_rmse'].statistics.values())[0]
+  assert stat.unique_name == "SquaredError_predictions_ensemble_mean_self._ensemble_dim='number'_self._skipna=False"
+
+
+# ---- parity against the oracle in several memory layouts ----------------------------------------------
+LAT = np.linspace(-87.1875, 87.1875, 32)
+LON = np.arange(64) * 5.625
+LAYOUTS = {
+    'lon_fastest': ('init_time', 'lead_time', 'level', 'latitude', 'longitude'),
+    'lat_fastest': ('init_time', 'lead_time', 'level', 'longitude', 'latitude'),   # real WeatherBench chunks
+    'level_fastest': ('lead_time', 'init_time', 'latitude', 'longitude', 'level'),  # the reference's mock layout
+}
+SIZES = {'init_time': 2, 'lead_time': 3, 'level': 3, 'latitude': 32, 'longitude': 64}
+
+
+def _field(rng, dims, dtype, offset=0.0):
+  shape = [SIZES[d] for d in dims]
+  coords = {'latitude': LAT, 'longitude': LON, 'level': np.array([500, 700, 850]),
+            'init_time': np.array(['2020-01-01T00', '2020-01-02T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(3) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  return xr.DataArray((rng.normal(size=shape) + offset).astype(dtype), dims=dims, coords={d: coords[d] for d in dims})
+
+
+REGIONS = {'global': ((-90, 90), (0, 360)), 'northern-hemisphere': ((20, 90), (0, 360)),
+           'europe': ((35, 75), (-12.5, 42.5))}
+
+
+@pytest.mark.parametrize('layout', list(LAYOUTS))
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('reduce_dims', [('init_time', 'latitude', 'longitude'), ('latitude', 'longitude'),
+                                         ('init_time',), ('lead_time', 'level'), ()])
+def test_deterministic_suite_matches_oracle(backend, layout, dtype, reduce_dims):
+  rng = np.random.default_rng(0)
+  dims = LAYOUTS[layout]
+  p, t = _field(rng, dims, dtype, 280.0), _field(rng, dims, dtype, 280.0)
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias()}
+  agg = aggregation.Aggregator(reduce_dims=list(reduce_dims), weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS)])
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'z': p}, {'z': t})
+  state = agg.aggregate_statistics(stats)
+  w = (O.grid_area_weights(LAT), ('latitude',))
+  _, masks = O.region_masks(LAT, LON, REGIONS)
+  bins = ('region', masks, ('region', 'latitude', 'longitude'))
+  for name, fn in (('Error', O.error), ('AbsoluteError', O.absolute_error), ('SquaredError', O.squared_error)):
+    sws, sw, out_dims = O.aggregate(fn(p.values, t.values), dims, reduce_dims, weights=[w], bin_masks=[bins])
+    got = state.sum_weighted_statistics[name]['z']
+    assert set(got.dims) == set(out_dims)
+    np.testing.assert_allclose(got.transpose(*out_dims).values, sws, rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(state.sum_weights[name]['z'].transpose(*out_dims).values, sw, rtol=RTOL)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_acc_with_climatology_gather_matches_oracle(backend, layout):
+  rng = np.random.default_rng(1)
+  dims = LAYOUTS[layout]
+  cdims = ('dayofyear', 'hour') + tuple(d for d in dims if d not in ('init_time', 'lead_time'))
+  cshape = [366, 4] + [SIZES[d] for d in cdims[2:]]
+  clim_vals = (rng.normal(size=cshape) * 10 + 280).astype(np.float32)
+  clim = xr.Dataset({'z': xr.DataArray(clim_vals, dims=cdims, coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'latitude': LAT, 'longitude': LON,
+      'level': np.array([500, 700, 850])})})
+  p, t = _field(rng, dims, np.float32, 280.0), _field(rng, dims, np.float32, 280.0)
+  metrics = {'acc': deterministic.ACC(clim), 'rmse': deterministic.RMSE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                               weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'z': p}, {'z': t})
+  vt = p['init_time'].values[:, None] + p['lead_time'].values[None, :]
+  c, c_dims = O.align_climatology(clim_vals, cdims, vt, ('init_time', 'lead_time'))
+  c = O.expand_to(c, c_dims, dims)
+  w = (O.grid_area_weights(LAT), ('latitude',))
+  means = {}
+  for name, arr in (('spa', O.squared_prediction_anomaly(p.values, c)), ('sta', O.squared_target_anomaly(t.values, c)),
+                    ('cov', O.anomaly_covariance(p.values, t.values, c)), ('se', O.squared_error(p.values, t.values))):
+    sws, sw, out_dims = O.aggregate(arr, dims, ['init_time', 'latitude', 'longitude'], weights=[w])
+    means[name] = sws / sw
+  np.testing.assert_allclose(res['acc.z'].transpose(*out_dims).values, O.acc(means['cov'], means['spa'], means['sta']),
+                             rtol=RTOL)
+  np.testing.assert_allclose(res['rmse.z'].transpose(*out_dims).values, O.rmse(means['se']), rtol=RTOL)
+
+
+@pytest.mark.parametrize('member_layout', ['member_slow', 'member_fast'])
+@pytest.mark.parametrize('m,dtype', [(5, np.float32), (51, np.float32), (7, np.float64), (70, np.float32)])
+@pytest.mark.parametrize('use_sort', [True, False])
+def test_ensemble_suite_matches_oracle(backend, member_layout, m, dtype, use_sort):
+  rng = np.random.default_rng(2)
+  nlat, nlon = 16, 24
+  lat, lon = np.linspace(-84.375, 84.375, nlat), np.arange(nlon) * 15.0
+  tv = rng.normal(size=(2, nlat, nlon)).astype(dtype) + 280
+  if member_layout == 'member_slow':
+    pdims = ('lead_time', 'number', 'latitude', 'longitude')
+    pv = (tv[:, None] + rng.normal(size=(2, m, nlat, nlon))).astype(dtype)
+  else:
+    pdims = ('lead_time', 'latitude', 'longitude', 'number')
+    pv = (tv[..., None] + rng.normal(size=(2, nlat, nlon, m))).astype(dtype)
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'t2m': xr.DataArray(pv, dims=pdims, coords=coords)}
+  t = {'t2m': xr.DataArray(tv, dims=('lead_time', 'latitude', 'longitude'), coords=coords)}
+  metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=use_sort),
+             'ssr': probabilistic.UnbiasedSpreadSkillRatio(),
+             'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  tdims = ('lead_time', 'latitude', 'longitude')
+  w = (O.grid_area_weights(lat), ('latitude',))
+
+  def mean(arr, d):
+    sws, sw, _ = O.aggregate(arr, d, ['latitude', 'longitude'], weights=[w])
+    return sws / sw
+  skill, sd = O.crps_skill(pv, pdims, tv, tdims, 'number')
+  spread, _ = O.crps_spread(pv, pdims, 'number', fair=True, use_sort=use_sort)
+  var, _ = O.ensemble_variance(pv, pdims, 'number')
+  ue, _ = O.unbiased_ensemble_mean_squared_error(pv, pdims, tv, tdims, 'number')
+  em, _ = O.ensemble_mean_squared_error(pv, pdims, tv, tdims, 'number')
+  np.testing.assert_allclose(res['crps.t2m'].values, O.crps(mean(skill, sd), mean(spread, sd)), rtol=RTOL)
+  np.testing.assert_allclose(res['ssr.t2m'].values, O.unbiased_spread_skill_ratio(mean(var, sd), mean(ue, sd)), rtol=RTOL)
+  np.testing.assert_allclose(res['mean_rmse.t2m'].values, np.sqrt(mean(em, sd)), rtol=RTOL)
+
+
+def test_nan_member_poisons_ensemble_statistics(backend):
+  rng = np.random.default_rng(3)
+  pv = rng.normal(size=(8, 4, 6)).astype(np.float32)
+  pv[3, 1, 2] = np.nan
+  p = {'v': xr.DataArray(pv, dims=('number', 'latitude', 'longitude'))}
+  t = {'v': xr.DataArray(rng.normal(size=(4, 6)).astype(np.float32), dims=('latitude', 'longitude'))}
+  for use_sort in (True, False):
+    stats = metrics_base.compute_unique_statistics_for_all_metrics(
+        {'crps': probabilistic.CRPSEnsemble(use_sort=use_sort)}, p, t)
+    for s in stats.values():
+      vals = s['v'].values
+      assert np.isnan(vals[1, 2]) and np.isfinite(np.delete(vals.reshape(-1), 1 * 6 + 2)).all()
+
+
+def test_materialised_statistics_match_oracle(backend):
+  rng = np.random.default_rng(4)
+  p = xr.DataArray(rng.normal(size=(3, 5, 4)).astype(np.float32), dims=('latitude', 'longitude', 'level'))
+  t = xr.DataArray(rng.normal(size=(5, 3)).astype(np.float32), dims=('longitude', 'latitude'))  # broadcast + transposed
+  se = deterministic.SquaredError().compute({'v': p}, {'v': t})['v']
+  assert se.dims == ('latitude', 'longitude', 'level') and se.shape == (3, 5, 4)
+  want = O.squared_error(p.values, O.expand_to(t.values, t.dims, p.dims))
+  np.testing.assert_allclose(se.values, want, rtol=1e-12)
+  # arithmetic on a lazy statistic materialises it transparently
+  np.testing.assert_allclose((se * 2).values, 2 * want, rtol=1e-12)

@@ -1,0 +1,119 @@
+"""Chunked == unchunked evaluation, restating weatherbenchX/beam_pipeline_test.py:82-284 (1x1 chunks vs one
+chunk for five reduce_dims sets, two named aggregators), weatherbenchX/time_chunks_test.py:20-57 and
+weatherbenchX/xarray_tree_test.py against the Beam-free chunk loop."""
+import numpy as np
+import pytest
+
+import mock_data
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import pipeline
+from weatherbenchx_amd import time_chunks
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd import xarray_tree
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+
+
+def _datasets():
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00',
+                                               lead_start_days=0, lead_stop_days=1, random=True, seed=0)
+  targets = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', random=True, seed=1)
+  return predictions, targets
+
+
+def _loader(predictions, targets):
+  """What PredictionsFromXarray / TargetsFromXarray hand to the chunk loop (xarray_loaders.py:185-256):
+  predictions[init_time, lead_time, ...]; targets selected at valid_time = init + lead with the same dims."""
+  pred = predictions.rename({'time': 'init_time', 'prediction_timedelta': 'lead_time'})
+
+  def load(init_times, lead_times):
+    p = {k: v.sel(init_time=init_times, lead_time=lead_times).transpose('init_time', 'lead_time', ...)
+         for k, v in pred.items()}
+    vt = init_times[:, None] + lead_times[None, :]
+    t = {}
+    for k, v in targets.items():
+      sel = v.sel(time=xr.DataArray(vt, dims=('init_time', 'lead_time')))
+      t[k] = sel.drop_vars('time').assign_coords(init_time=init_times, lead_time=lead_times)
+    return p, t
+  return load
+
+
+@pytest.mark.parametrize('reduce_dims', [['init_time', 'latitude', 'longitude'], ['init_time'], ['lead_time'],
+                                         ['latitude', 'longitude'], []])
+def test_chunked_equals_single_chunk(backend, reduce_dims):
+  predictions, targets = _datasets()
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+  assert len(times) == 4
+  load = _loader(predictions, targets)
+  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE()}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims)
+  p, t = load(init_times, lead_times)
+  direct = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+  direct_metrics = direct.metric_values(metrics)
+  state = pipeline.evaluate_chunks(times, load, metrics, agg)[None]
+  chunked_metrics = state.metric_values(metrics)
+  assert set(direct_metrics) == set(chunked_metrics)
+  for k in direct_metrics:
+    xr.assert_allclose(direct_metrics[k], chunked_metrics[k], atol=1e-5, check_dim_order=False)
+  xarray_tree.map_structure(lambda a, b: xr.assert_allclose(a, b, atol=1e-5, check_dim_order=False),
+                            (direct.sum_weighted_statistics, direct.sum_weights),
+                            (state.sum_weighted_statistics, state.sum_weights))
+
+
+def test_multiple_named_aggregators(backend):
+  predictions, targets = _datasets()
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+  load = _loader(predictions, targets)
+  metrics = {'rmse': deterministic.RMSE()}
+  aggs = {'init_time,latitude,longitude': aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude']),
+          'init_time': aggregation.Aggregator(reduce_dims=['init_time'])}
+  states = pipeline.evaluate_chunks(times, load, metrics, aggs)
+  p, t = load(init_times, lead_times)
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t)
+  for name, agg in aggs.items():
+    want = agg.aggregate_statistics(stats).metric_values(metrics)
+    got = states[name].metric_values(metrics)
+    for k in want:
+      xr.assert_allclose(want[k], got[k], atol=1e-5, check_dim_order=False)
+  assert pipeline.resolve_out_path('/tmp/metrics.nc', 'init_time') == '/tmp/metrics_init_time.nc'
+  assert pipeline.resolve_out_path('/tmp/metrics.nc', None) == '/tmp/metrics.nc'
+
+
+def test_time_chunks_lengths_and_offsets():
+  init_times = np.arange('2020-01-01T00', '2020-01-02T00', np.timedelta64(6, 'h'), dtype='datetime64[ns]')
+  lead_times = np.arange(0, 18, 6, dtype='timedelta64[h]')
+  assert len(list(time_chunks.TimeChunks(init_times, lead_times))) == 1
+  chunks = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=2, lead_time_chunk_size=2)
+  assert len(list(chunks)) == 4 and len(chunks) == 4
+  offs = [(o.init_time, o.lead_time) for o, _ in chunks.iter_with_chunk_offsets()]
+  assert offs == [(0, 0), (0, 2), (2, 0), (2, 2)]
+  assert chunks[1][1].tolist() == lead_times[2:].astype('timedelta64[ns]').tolist()
+  sl = slice(np.timedelta64(0, 'h'), np.timedelta64(6, 'h'))
+  assert len(list(time_chunks.TimeChunks(init_times, sl, init_time_chunk_size=2))) == 2
+  with pytest.raises(ValueError):
+    time_chunks.TimeChunks(init_times, sl, lead_time_chunk_size=2)
+  with pytest.raises(ValueError):
+    time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=-1)
+  with pytest.raises(IndexError):
+    chunks[4]  # pylint: disable=pointless-statement
+
+
+def test_xarray_tree_map_structure():
+  a = xr.DataArray(np.arange(3.0), dims=['x'], coords={'x': [0, 1, 2]})
+  ds = xr.Dataset({'a': a, 'b': a + 1})
+  doubled = xarray_tree.map_structure(lambda v: v * 2, ds)
+  assert isinstance(doubled, xr.Dataset) and doubled['b'].values.tolist() == [2, 4, 6]
+  dropped = xarray_tree.map_structure(lambda v: None if v.name == 'a' else v, ds)
+  assert list(dropped) == ['b']
+  nested = xarray_tree.map_structure(lambda x, y: x + y, {'k': [a, a]}, {'k': [a, a]})
+  assert nested['k'][1].values.tolist() == [0, 2, 4]
+  as_dict = xarray_tree.map_structure(lambda v: 3, ds)
+  assert as_dict == {'a': 3, 'b': 3}
+  with pytest.raises(TypeError):
+    xarray_tree.map_structure(3, ds)
+  with pytest.raises(ValueError):
+    xarray_tree.map_structure(lambda x: x)

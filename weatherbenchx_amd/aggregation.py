@@ -220,7 +220,7 @@ class Aggregator:
     def wrap(arr):
       da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
       da = da.transpose(*final_dims)
-      return xr.DataArray(np.ascontiguousarray(da.values), dims=final_dims, coords=coords, name=stat.name,
+      return xr.DataArray(np.array(da.values, order="C", copy=True), dims=final_dims, coords=coords, name=stat.name,
                           attrs=stat.attrs, _raw_coords=True)
 
     return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))

@@ -159,6 +159,8 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
   n = int(np.prod(plan.partial_shape(nlanes_total), dtype=np.int64))
   out = ctx.alloc(n * 8)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  if S1_EVENT_LOG is not None:  # bench.py's roofline leg: HIP events on the launch stream
+    ctx.timer_start()
   if kind == 'det':
     _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
                                        ptr(devs[2]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_det_partial')
@@ -166,7 +168,14 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
     m, mstride, algo = ens
     _hip.check(ctx.lib.wbx_ens_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(algo),
                                        ptr(devs[0]), ptr(devs[1]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
+  if S1_EVENT_LOG is not None:
+    S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop(), 'vec': plan.vec, 'x_kept': plan.x_kept,
+                         'grid': plan.nkey * plan.nchunk, 'block': plan.block_threads})
   return out
+
+
+# When set to a list, every stage-1 launch is bracketed by HIP events (synchronising) and logged here.
+S1_EVENT_LOG = None
 
 
 def _run_map(ctx, kind: str, dplan, plan: planner.S1Plan, devs, dtype_code: int, lane: int, func: int = 0,

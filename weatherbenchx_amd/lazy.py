@@ -37,6 +37,8 @@ def _stat_frame(arrays: Sequence[xr.DataArray], drop_dims=()):
         dims.append(d)
         sizes[d] = n
       elif sizes[d] != n:
+        if all(d in x._coords for x in arrays if d in x.dims):  # pylint: disable=protected-access
+          raise _NeedsAlignment(d)  # labeled dims of different length: inner join like xarray arithmetic
         raise ValueError(f'cannot broadcast: size mismatch along {d!r} ({sizes[d]} vs {n})')
   coords = {}
   dropped = set()

@@ -939,9 +939,9 @@ def _binary(a, b, fn, reflexive=False, ternary_other=None):
 def _coerce_pair(x, y):
   """Bring a numpy operand onto the torch operand's device."""
   if _is_torch(x) and not _is_torch(y):
-    y = _torch().as_tensor(np.ascontiguousarray(y), device=x.device)
+    y = _torch().as_tensor(np.array(y, order="C"), device=x.device)
   elif _is_torch(y) and not _is_torch(x):
-    x = _torch().as_tensor(np.ascontiguousarray(x), device=y.device)
+    x = _torch().as_tensor(np.array(x, order="C"), device=y.device)
   return x, y
 
 
