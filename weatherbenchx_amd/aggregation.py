@@ -268,6 +268,17 @@ class Aggregator:
     extra = (tuple(sorted(ens_params.items())) if ens_params else (), mean_dims)
     key = self._cache_key(w_da, bin_dims, use_mask, skipna, extra)
     hit = grp.cache.get(key)
+    if hit is None and grp.kind == 'ens' and stat._lane != lazy.ENS_LANE['CRPSSpread']:  # pylint: disable=protected-access
+      # only the spread lane depends on (algorithm, fair): every other lane is served by whatever ensemble
+      # launch already ran for this aggregator, else by the cheaper rank-form kernel.
+      for k2, v2 in grp.cache.items():
+        if k2[:-1] == key[:-1] and k2[-1][1] == mean_dims:
+          hit = v2
+          break
+      if hit is None:
+        ens_params = {'algo': _hip.ENS_SORT, 'fair': True}
+        key = self._cache_key(w_da, bin_dims, use_mask, skipna, (tuple(sorted(ens_params.items())), mean_dims))
+        hit = grp.cache.get(key)
     if hit is None:
       hit = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna, ens_params=ens_params,
                        extra_reduce=mean_dims)

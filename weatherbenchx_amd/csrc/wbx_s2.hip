@@ -16,15 +16,22 @@ namespace wbx {
 
 constexpr int BG = 8;  // bins per register group
 
-// one block per (A, Bk, lane); threads stride over the flattened (Br, chunk, j) contraction.
-__global__ void __launch_bounds__(256) s2_sumj_kernel(wbx_s2_plan p, const double* __restrict__ partial,
-                                                      const double* __restrict__ W, double* __restrict__ out) {
+// one block per (A, Bk, lane[, j]); threads stride over the flattened (Br, chunk[, j]) contraction.
+// fixed_j = 0: j is contracted (sum_j).  fixed_j = 1: j is kept and few (< 64): one block per j.
+__global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed_j, const double* __restrict__ partial,
+                                                        const double* __restrict__ W, double* __restrict__ out) {
   int64_t b = blockIdx.x;
+  int64_t jf = 0;
+  if (fixed_j) {
+    jf = b % p.nj;
+    b /= p.nj;
+  }
   const int64_t lane = b % p.nlane;
   b /= p.nlane;
   const int64_t bk = b % p.nBk;
   const int64_t A = b / p.nBk;
-  const int64_t ncj = p.nchunk * p.nj;
+  const int64_t njc = fixed_j ? 1 : p.nj;
+  const int64_t ncj = p.nchunk * njc;
   const int64_t ncontr = p.nBr * ncj;
   const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ double red[4][BG];
@@ -37,8 +44,8 @@ __global__ void __launch_bounds__(256) s2_sumj_kernel(wbx_s2_plan p, const doubl
     for (int64_t c = threadIdx.x; c < ncontr; c += blockDim.x) {
       const int64_t br = c / ncj;
       const int64_t r = c - br * ncj;
-      const int64_t ch = r / p.nj;
-      const int64_t j = r - ch * p.nj;
+      const int64_t ch = r / njc;
+      const int64_t j = fixed_j ? jf : r - ch * njc;
       const double v = pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
       const double* w = wbase + (br * p.nj + j) * p.nbin + b0;
 #pragma unroll
@@ -54,7 +61,8 @@ __global__ void __launch_bounds__(256) s2_sumj_kernel(wbx_s2_plan p, const doubl
     if (threadIdx.x < BG && b0 + threadIdx.x < p.nbin) {
       double s = 0.0;
       for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) s += red[w2][threadIdx.x];
-      out[((A * p.nBk + bk) * p.nlane + lane) * p.nbin + b0 + threadIdx.x] = s;
+      const int64_t o = fixed_j ? (((A * p.nBk + bk) * p.nlane + lane) * p.nj + jf) : ((A * p.nBk + bk) * p.nlane + lane);
+      out[o * p.nbin + b0 + threadIdx.x] = s;
     }
     __syncthreads();
   }
@@ -111,12 +119,14 @@ extern "C" int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double*
     return 0;
   }
   WBX_REQUIRE(partial != nullptr && W != nullptr, "partial/W is NULL");
-  if (p.sum_j) {
-    const int64_t grid = p.nA * p.nBk * p.nlane;
+  if (p.sum_j || p.nj < 64) {
+    const int fixed_j = p.sum_j ? 0 : 1;
+    const int64_t grid = p.nA * p.nBk * p.nlane * (fixed_j ? p.nj : 1);
     WBX_REQUIRE(grid < (int64_t)1 << 31, "stage-2 grid too large");
-    const int64_t ncontr = p.nBr * p.nchunk * p.nj;
+    const int64_t ncontr = p.nBr * p.nchunk * (fixed_j ? 1 : p.nj);
     const int threads = ncontr >= 256 ? 256 : (ncontr >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(wbx::s2_sumj_kernel, dim3((unsigned)grid), dim3(threads), 0, ctx->stream, p, partial, W, out);
+    hipLaunchKernelGGL(wbx::s2_reduce_kernel, dim3((unsigned)grid), dim3(threads), 0, ctx->stream, p, fixed_j, partial, W,
+                       out);
   } else {
     const int threads = p.nj >= 256 ? 256 : (p.nj >= 128 ? 128 : 64);
     const int njtile = (int)((p.nj + threads - 1) / threads);
