@@ -179,13 +179,18 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
                 int algo, int lane, const void* p, const void* t, double* out);
 
 /* ---- zonal energy spectrum ---------------------------------------------------
- * Not in the reference snapshot.  field: `nrows` rows of `nlon` fp32 values,
- * row r at field + row_off[r] (element offsets, longitude contiguous).
- * power_out[group[r]][k] += scale[r] * |rfft(row)_k / nlon|^2 * (k == 0 ? 1 : 2), k = 0..nlon/2.
- * power_out has ngroup * (nlon/2 + 1) fp64 values and is overwritten. */
-int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, const int64_t* row_off,
-                       const int32_t* group, const double* scale, int64_t nrows, int32_t nlon,
-                       int32_t ngroup, double* power_out);
+ * Not in the reference snapshot (no spectrum metric, no test) -> parity unpinned; definition of the
+ * build (WeatherBench-2 lineage): F = rfft(row) / nlon, S_k = |F_k|^2 * (k == 0 ? 1 : 2), k = 0..nlon/2.
+ * `field` holds nrows rows consumed IN PLACE: element i of row r is field[r * row_stride + i * lon_stride]
+ * (lon-fastest: lon_stride 1, row_stride nlon; latitude-fastest real data: lon_stride nlat, row_stride 1).
+ * Batched 1-D R2C rocFFT along longitude, then a HIP |.|^2 reduction:
+ *   power_out[group[r]][k] (+)= scale[r] * S_k(row r)
+ * group[nrows] (int32 in [0, ngroup)) and scale[nrows] (float64, e.g. area weight / count) are device arrays;
+ * power_out is float64[ngroup][nlon/2 + 1]; accumulate = 0 overwrites it, 1 adds to it (fp64 atomics, so the
+ * summation order -- not the value beyond ~1e-16 relative -- may differ between runs). */
+int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride, int64_t nrows,
+                       int32_t nlon, const int32_t* group, const double* scale, int32_t ngroup,
+                       int32_t accumulate, double* power_out);
 
 #ifdef __cplusplus
 }

@@ -150,3 +150,28 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_s1', _run_s1)
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
+
+
+def _run_spectrum(field, lon_dim, group, scale, ngroup):
+  """NumPy stand-in for wbx_zonal_spectrum (rows = non-longitude dims in the field's own order)."""
+  vals = np.asarray(field.values)
+  if vals.dtype != np.float32:
+    raise TypeError('zonal spectra take float32 fields (rocFFT single precision); cast the input')
+  ax = field.dims.index(lon_dim)
+  rows = np.moveaxis(vals.astype(np.float64), ax, -1).reshape(-1, vals.shape[ax])
+  n = rows.shape[1]
+  F = np.fft.rfft(rows.astype(np.float32).astype(np.float64), axis=1) / n
+  power = F.real ** 2 + F.imag ** 2
+  power[:, 1:] *= 2
+  out = np.zeros((ngroup, n // 2 + 1))
+  np.add.at(out, np.asarray(group), power * np.asarray(scale)[:, None])
+  return out
+
+
+_install_without_spectrum = install
+
+
+def install(monkeypatch):  # noqa: F811
+  _install_without_spectrum(monkeypatch)
+  from weatherbenchx_amd import spectra
+  monkeypatch.setattr(spectra, '_run_spectrum', _run_spectrum)

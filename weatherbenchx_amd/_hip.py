@@ -101,7 +101,7 @@ def load_library():
         'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
-        'wbx_zonal_spectrum': [vp, vp, vp, vp, vp, i64, C.c_int32, C.c_int32, vp],
+        'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
     for name, argtypes in protos.items():
       fn = getattr(lib, name)

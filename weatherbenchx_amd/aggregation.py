@@ -24,6 +24,7 @@ from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd import xarray_tree
 from weatherbenchx_amd.metrics import base as metrics_base
 from weatherbenchx_amd.metrics import deterministic as _det
+from weatherbenchx_amd import spectra
 
 
 def combining_sum(data_arrays: Sequence[xr.DataArray]) -> xr.DataArray:
@@ -204,6 +205,11 @@ class Aggregator:
         sws = sws + p.sum_weighted_statistics
       return AggregationState(sws, parts[0].sum_weights)
 
+    if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy and not use_mask and not skipna:
+      fused = self._reduce_spectrum(stat, w_da, bin_dims)
+      if fused is not None:
+        return fused
+
     if isinstance(stat, lazy.LazyStatistic) and stat.is_lazy:
       values, counts, out_dims, frame_coords, lane, scale = self._reduce_lazy(stat, w_da, bin_dims, use_mask, skipna)
     else:
@@ -288,6 +294,42 @@ class Aggregator:
     for d in mean_dims:  # mean over d == sum over d / n; the count carries the same factor
       scale /= grp.sizes[d]
     return values, counts, out_dims, grp.coords, stat._lane, scale  # pylint: disable=protected-access
+
+  def _reduce_spectrum(self, stat: 'spectra.LazySpectrum', w_da, bin_dims):
+    """Weighted mean of zonal spectra over rows (time, latitude, ...) without materialising per-row spectra:
+    the row weights ride into the |F|^2 reduction kernel (csrc/wbx_spectrum.hip)."""
+    k_dim = stat._k_dim  # pylint: disable=protected-access
+    if k_dim in set(self.reduce_dims):
+      return None  # summing over wavenumber: use the generic path on the materialised spectrum
+    row_dims = [d for d in stat.dims if d != k_dim]
+    if w_da is not None and (k_dim in w_da.dims or stat._lon_dim in w_da.dims):  # pylint: disable=protected-access
+      if stat._lon_dim in w_da.dims:  # pylint: disable=protected-access
+        raise ValueError('bin masks / weights that depend on longitude cannot be applied to a zonal spectrum')
+      return None
+    kept = [d for d in row_dims if d not in set(self.reduce_dims)]
+    w = w_da if w_da is not None else xr.DataArray(np.float64(1.0))
+    bins = [dict(zip(bin_dims, idx)) for idx in np.ndindex(*[w.sizes[b] for b in bin_dims])] if bin_dims else [{}]
+    vals, cnts = [], []
+    sizes = {d: stat.sizes[d] for d in row_dims}
+    for sel in bins:
+      wb = w.isel(sel) if sel else w
+      arr, dims = stat.reduce_rows(wb, kept)
+      vals.append(arr)
+      full = np.broadcast_to(xr._bcast_data(wb.astype(np.float64), row_dims, sizes), [sizes[d] for d in row_dims])  # pylint: disable=protected-access
+      c = full.sum(axis=tuple(i for i, d in enumerate(row_dims) if d not in kept))
+      cnts.append(np.broadcast_to(c[..., None], arr.shape))
+    out_dims = tuple(dims) + tuple(bin_dims)
+    bshape = [w.sizes[b] for b in bin_dims]
+    v = np.stack(vals, axis=-1).reshape(list(vals[0].shape) + bshape)
+    c = np.stack(cnts, axis=-1).reshape(list(vals[0].shape) + bshape)
+    coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(out_dims)}  # pylint: disable=protected-access
+    if w_da is not None:
+      for k, x in w_da._coords.items():  # pylint: disable=protected-access
+        if set(x[0]) <= set(out_dims):
+          coords.setdefault(k, x)
+    mk = lambda a: xr.DataArray(np.array(a, dtype=np.float64), dims=out_dims, coords=coords, name=stat.name,
+                                _raw_coords=True)
+    return AggregationState(mk(v), mk(c))
 
   def _reduce_materialised(self, stat: xr.DataArray, w_da, bin_dims, use_mask, skipna):
     """Any DataArray (user-defined statistics, numpy or torch payload): the PASS1 family."""
