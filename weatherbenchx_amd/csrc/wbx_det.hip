@@ -17,15 +17,11 @@
 
 namespace wbx {
 
+// 4-wide vector types that only promise element alignment: gfx950 global loads may be unaligned, so rows
+// that start at any element (e.g. 721-long latitude rows) still get one global_load_dwordx4 per lane.
 template <typename T>
-struct Vec4;
-template <>
-struct Vec4<float> {
-  using type = float4;
-};
-template <>
-struct Vec4<double> {
-  using type = double4;
+struct Vec4 {
+  typedef T type __attribute__((ext_vector_type(4), aligned(sizeof(T))));
 };
 
 template <typename T, int V>
@@ -55,7 +51,7 @@ struct DetOp {
   static constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   static constexpr int NLANE = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   static constexpr int NACC = NLANE * (MM ? 2 : 1);
-  static constexpr int XR_UNROLL = 2, XK_UNROLL = 4;
+  static constexpr int XR_UNROLL = 2, XK_UNROLL = 4, MIN_WAVES = 1;
 
   __device__ __forceinline__ static void lanes(double p, double t, double c, double (&val)[NLANE]) {
     if constexpr (FUNC == WBX_PASS1) {
@@ -150,11 +146,6 @@ static int det_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype
   if (func != WBX_PASS1) WBX_REQUIRE(t != nullptr || plan->nkey * plan->ndepth * plan->nx == 0, "targets pointer is NULL");
   if (func == WBX_DET6) WBX_REQUIRE(c != nullptr || plan->nkey * plan->ndepth * plan->nx == 0, "climatology pointer is NULL");
   if (plan->flags & WBX_FLAG_MASKED) WBX_REQUIRE(mask != nullptr, "WBX_FLAG_MASKED set but mask is NULL");
-  if (plan->vec == 4) {
-    const uintptr_t al = dtype == WBX_F32 ? 15 : 31;
-    WBX_REQUIRE((((uintptr_t)p) & al) == 0 && (((uintptr_t)t) & al) == 0 && (((uintptr_t)c) & al) == 0,
-                "vec=4 needs 16/32-byte aligned inputs");
-  }
   WBX_HIP(hipSetDevice(ctx->device));
   S1Args a;
   fill_args(plan, a);

@@ -13,7 +13,7 @@ struct EnsOpGeneric {
   static constexpr int NIN = 2;
   static constexpr int NLANE = WBX_ENS_LANES;
   static constexpr int NACC = WBX_ENS_LANES;
-  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = 1;
 
   __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
                                                 double (&val)[NLANE]) {

@@ -18,6 +18,10 @@
 #include "wbx_s1.hpp"
 #include "wbx_sortnet_gen.hpp"
 
+#ifndef WBX_ENS_MIN_WAVES
+#define WBX_ENS_MIN_WAVES 4  // waves per SIMD the ensemble kernels are register-budgeted for (<= 128 VGPRs)
+#endif
+
 namespace wbx {
 
 struct EnsLanes {
@@ -30,7 +34,7 @@ struct EnsOpF32 {
   static constexpr int NIN = 2;
   static constexpr int NLANE = WBX_ENS_LANES;
   static constexpr int NACC = WBX_ENS_LANES;
-  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = WBX_ENS_MIN_WAVES;
 
   __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
                                                 double (&val)[NLANE]) {

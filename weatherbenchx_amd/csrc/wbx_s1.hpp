@@ -65,7 +65,7 @@ __device__ __forceinline__ void row_bases(const S1Args& a, const int64_t (&kb)[W
 // ---------------------------------------------------------------------------------------------
 // x summed away.  grid = nkey * nchunk blocks, block = 64..256 threads.
 template <class Op, int V>
-__global__ void __launch_bounds__(256) s1_xr_kernel(S1Args a) {
+__global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xr_kernel(S1Args a) {
   constexpr int NA = Op::NACC;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) s1_xr_kernel(S1Args a) {
 // ---------------------------------------------------------------------------------------------
 // x kept.  grid = nkey * nxtile * nchunk blocks; a block covers blockDim*V consecutive x.
 template <class Op, int V>
-__global__ void __launch_bounds__(256) s1_xk_kernel(S1Args a) {
+__global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xk_kernel(S1Args a) {
   constexpr int NA = Op::NACC;
   int64_t b = blockIdx.x;
   const int chunk = (int)(b % a.nchunk);
@@ -126,17 +126,28 @@ __global__ void __launch_bounds__(256) s1_xk_kernel(S1Args a) {
 #pragma unroll
     for (int l = 0; l < NA; ++l) acc[k][l] = 0.0;
 
+  const int nvalid = a.nx - x < V ? (int)(a.nx - x) : V;  // < V only for the last lane of a ragged row
+  if (V == 1 || nvalid == V) {
 #pragma unroll Op::XK_UNROLL
-  for (int64_t d = d0; d < d1; ++d) {
-    int64_t ro[WBX_MAX_INPUTS];
-    row_bases<Op::NIN>(a, kb, key, d, ro);
-    Op::template accum<V, true>(a, ro, x, acc);
+    for (int64_t d = d0; d < d1; ++d) {
+      int64_t ro[WBX_MAX_INPUTS];
+      row_bases<Op::NIN>(a, kb, key, d, ro);
+      Op::template accum<V, true>(a, ro, x, acc);
+    }
+  } else {
+    for (int64_t d = d0; d < d1; ++d) {
+      int64_t ro[WBX_MAX_INPUTS];
+      row_bases<Op::NIN>(a, kb, key, d, ro);
+      for (int k = 0; k < nvalid; ++k)
+        Op::template accum<1, true>(a, ro, x + k, reinterpret_cast<double(&)[1][NA]>(acc[k]));
+    }
   }
   double* o = a.out + ((key * a.nchunk + chunk) * NA) * a.nx + x;
 #pragma unroll
   for (int l = 0; l < NA; ++l)
 #pragma unroll
-    for (int k = 0; k < V; ++k) o[(int64_t)l * a.nx + k] = acc[k][l];
+    for (int k = 0; k < V; ++k)
+      if (k < nvalid) o[(int64_t)l * a.nx + k] = acc[k][l];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -191,7 +202,7 @@ inline int check_plan(const wbx_s1_plan* p) {
               "block_threads must be 64, 128 or 256 (got %d)", p->block_threads);
   WBX_REQUIRE(p->vec == 1 || p->vec == 4, "vec must be 1 or 4 (got %d)", p->vec);
   if (p->vec == 4) {
-    WBX_REQUIRE(p->nx % 4 == 0, "vec=4 needs nx %% 4 == 0");
+    WBX_REQUIRE(p->x_kept || p->nx % 4 == 0, "vec=4 with x summed needs nx %% 4 == 0");
     for (int i = 0; i < 3; ++i)
       WBX_REQUIRE(p->xstride[i] == 0 || p->xstride[i] == 1, "vec=4 needs unit/zero x strides");
   }
