@@ -82,3 +82,36 @@ def test_pack_unpack_round_trip_and_sharding():
   np.testing.assert_allclose(back.sum_weights['s']['b'].values, 4.0)
   assert distributed.shard_chunks(list(range(7)), 1, 3) == [1, 4]
   assert distributed.all_reduce_state(st) is st  # no process group: identity
+
+
+def _ragged_worker(rank, world_size, port, out_dir):
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+  import torch.distributed as dist
+  from weatherbenchx_amd import distributed
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.aggregation import AggregationState
+  dist.init_process_group('gloo', rank=rank, world_size=world_size)
+  try:
+    n = 3 + rank  # rank 1 packs one value more
+    st = AggregationState({'s': {'v': xr.DataArray(np.ones(n), dims=['x'])}},
+                          {'s': {'v': xr.DataArray(np.ones(n), dims=['x'])}})
+    try:
+      distributed.all_reduce_state(st)
+      outcome = 'no error'
+    except (ValueError, RuntimeError) as e:  # gloo itself may reject mismatched sizes first
+      outcome = type(e).__name__
+    open(os.path.join(out_dir, f'ragged{rank}.txt'), 'w').write(outcome)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_ragged_shards_fail_loudly(tmp_path):
+  import socket
+  import torch.multiprocessing as mp
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  outcomes = [open(os.path.join(tmp_path, f'ragged{r}.txt')).read() for r in (0, 1)]
+  assert all(o != 'no error' for o in outcomes), outcomes

@@ -64,15 +64,14 @@ def all_reduce_state(state: AggregationState, group=None) -> AggregationState:
   if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
     return state
   flat, layout, items = pack_state(state)
-  # layouts must agree: compare a cheap fingerprint first (catches ragged shards early and loudly)
-  fp = torch.tensor([len(layout), flat.size], dtype=torch.int64)
   backend = dist.get_backend(group)
   dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-  fp = fp.to(dev)
-  lo, hi = fp.clone(), fp.clone()
-  dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
-  dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
-  if not torch.equal(lo, hi):
+  # fixed-size fingerprint first (one MIN all-reduce of [n, -n] gives min and max of the packed length): ranks that
+  # disagree must fail loudly BEFORE the payload collective, which would otherwise crash or hang on ragged sizes.
+  n = float(flat.size + 1000003 * len(layout))
+  fp = torch.tensor([n, -n], dtype=torch.float64, device=dev)
+  dist.all_reduce(fp, op=dist.ReduceOp.MIN, group=group)
+  if float(fp[0]) != -float(fp[1]):
     raise ValueError('AggregationState layouts differ between ranks; cannot all-reduce')
   buf = torch.from_numpy(flat).to(dev)
   dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)

@@ -152,6 +152,17 @@ class PerVariableStatisticWithClimatology(Statistic):
 
   @final
   def _compute_per_variable(self, predictions, targets, climatology):
+    # ACC asks for the same alignment three times per variable (base.py:403): resolve it once per
+    # (predictions object, climatology variable).
+    cache = predictions.__dict__.setdefault('_wbx_clim_refs', {})
+    hit = cache.get(id(climatology))
+    if hit is None or hit[0] is not climatology:
+      hit = (climatology, self._climatology_ref(predictions, climatology))
+      cache[id(climatology)] = hit
+    return self._compute_per_variable_with_aligned_climatology(predictions, targets, hit[1])
+
+  @staticmethod
+  def _climatology_ref(predictions, climatology) -> 'lazy.ClimatologyRef':
     if 'valid_time' in predictions.coords or 'valid_time' in predictions.dims:
       valid_time = predictions['valid_time']
     elif (('init_time' in predictions.coords or 'init_time' in predictions.dims)
@@ -166,8 +177,7 @@ class PerVariableStatisticWithClimatology(Statistic):
       if 'hour' in climatology.dims:
         labels['hour'] = valid_time.dt.hour
     positions = {d: climatology._index_positions(d, lab.values) for d, lab in labels.items()}  # pylint: disable=protected-access
-    ref = lazy.ClimatologyRef(climatology, tuple(valid_time.dims), positions)
-    return self._compute_per_variable_with_aligned_climatology(predictions, targets, ref)
+    return lazy.ClimatologyRef(climatology, tuple(valid_time.dims), positions)
 
   @abc.abstractmethod
   def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):

@@ -900,7 +900,24 @@ def _merge_coords(a: DataArray, b: DataArray, out_dims):
   return {k: v for k, v in coords.items() if set(v[0]) <= dset}
 
 
+def _same_frame(a: 'DataArray', b: 'DataArray') -> bool:
+  """Same dims and the very same coordinate arrays (the common case for accumulators of one launch)."""
+  if a._dims != b._dims or a._coords.keys() != b._coords.keys():  # pylint: disable=protected-access
+    return False
+  return all(v[1] is b._coords[k][1] and v[0] == b._coords[k][0] for k, v in a._coords.items())  # pylint: disable=protected-access
+
+
 def _binary(a, b, fn, reflexive=False, ternary_other=None):
+  # fast paths: scalar operand, or two arrays on the identical frame -> no joins, no broadcasting
+  if ternary_other is None and isinstance(a, DataArray):
+    if isinstance(b, (numbers.Number, np.generic)) and not isinstance(b, (bool, np.bool_)):
+      return a._replace(data=fn(b, a.data) if reflexive else fn(a.data, b))  # pylint: disable=protected-access
+    if isinstance(b, DataArray) and _same_frame(a, b) and _shape(a.data) == _shape(b.data):
+      da, db = _coerce_pair(a.data, b.data)
+      out = a._replace(data=fn(db, da) if reflexive else fn(da, db))  # pylint: disable=protected-access
+      if a.name != b.name and b.name is not None:
+        out.name = None
+      return out
   if not isinstance(a, DataArray):
     a = DataArray(np.asarray(a)) if not _is_torch(a) else DataArray(a)
   if not isinstance(b, DataArray):
