@@ -153,7 +153,7 @@ int wbx_det_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /*wbx_det_fu
  * that is NOT part of key/depth/x.  Replaces probabilistic.py:116-336. */
 int wbx_ens_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M,
                     int64_t member_stride, int algo /*wbx_ens_algo*/, const void* p,
-                    const void* t, double* partial_out);
+                    const void* t, const uint8_t* mask, double* partial_out);
 
 /* ---- stage 2: weighted / binned contraction --------------------------------
  * partial is viewed as [nA][nBk][nBr][nchunk][nlane][nj];  W as [nBk][nBr][nj][nbin].

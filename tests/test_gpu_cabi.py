@@ -91,7 +91,7 @@ def test_bad_arguments_return_error_codes(ctx):
   plan.block_threads = 64
   rc = lib.wbx_det_partial(ctx.handle, C.byref(plan), 7, _hip.F32, C.c_void_p(8), C.c_void_p(8), None, None, C.c_void_p(8))
   assert rc == -1 and b'unknown deterministic family' in lib.wbx_last_error()
-  rc = lib.wbx_ens_partial(ctx.handle, C.byref(plan), _hip.F32, 0, 1, 0, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8))
+  rc = lib.wbx_ens_partial(ctx.handle, C.byref(plan), _hip.F32, 0, 1, 0, C.c_void_p(8), C.c_void_p(8), None, C.c_void_p(8))
   assert rc == -1 and b'ensemble size' in lib.wbx_last_error()
   with pytest.raises(_hip.WbxError, match='lane'):
     _hip.check(lib.wbx_det_map(ctx.handle, C.byref(plan), _hip.DET3, _hip.F32, 5, C.c_void_p(8), C.c_void_p(8), None,

@@ -97,7 +97,7 @@ def load_library():
         'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
         'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],
         'wbx_det_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp],
-        'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp],
+        'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp, vp],
         'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],

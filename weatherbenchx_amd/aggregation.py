@@ -268,9 +268,6 @@ class Aggregator:
     grp = stat._group  # pylint: disable=protected-access
     mean_dims = stat._mean_dims  # pylint: disable=protected-access
     ens_params = stat._ens_params  # pylint: disable=protected-access
-    if grp.kind == 'ens' and (use_mask or skipna):
-      raise NotImplementedError('masked / skipna aggregation of fused ensemble statistics is not supported yet; '
-                                'aggregate with masked=False, skipna=False')
     extra = (tuple(sorted(ens_params.items())) if ens_params else (), mean_dims)
     key = self._cache_key(w_da, bin_dims, use_mask, skipna, extra)
     hit = grp.cache.get(key)

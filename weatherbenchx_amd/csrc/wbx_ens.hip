@@ -20,21 +20,24 @@ struct EnsOpGeneric {
     const int M = a.M;
     const T* pp = reinterpret_cast<const T*>(a.in[0]) + ro[0] + x * a.xstride[0];
     const double td = (double)(reinterpret_cast<const T*>(a.in[1])[ro[1] + x * a.xstride[1]]);
-    double sum = 0.0, sq = 0.0, sabs = 0.0, pair_total = 0.0;
+    double se = 0.0, sq = 0.0, sabs = 0.0, pair_total = 0.0;
+    const double x0 = (double)pp[0];
+    const double x0t = x0 - td;  // member-only lanes use e = x - x0 and stay finite for a NaN target
     for (int i = 0; i < M; ++i) {
       const double xi = (double)pp[(int64_t)i * a.mstride];
-      const double d = xi - td;
-      sum += d;
-      sq = fma(d, d, sq);
-      sabs += fabs(d);
+      const double e = xi - x0;
+      se += e;
+      sq = fma(e, e, sq);
+      sabs += fabs(e + x0t);
       double row = 0.0;
       for (int j = 0; j < i; ++j) row += fabs(xi - (double)pp[(int64_t)j * a.mstride]);
       pair_total += row;
     }
     const double dM = (double)M;
     const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
-    const double mean_d = sum / dM;
-    const double var = (sq - sum * mean_d) / (dM - 1.0);
+    const double mean_e = se / dM;
+    const double mean_d = x0t + mean_e;
+    const double var = (sq - se * mean_e) / (dM - 1.0);
     val[0] = sabs / dM;
     val[1] = 2.0 * pair_total / (dM * (dM - fair));
     val[2] = var;
@@ -54,13 +57,14 @@ struct EnsOpGeneric {
 };
 
 static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride, int algo,
-                      const void* p, const void* t, double* out, bool map, int lane) {
+                      const void* p, const void* t, const uint8_t* mask, double* out, bool map, int lane) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (int rc = check_plan(plan)) return rc;
   WBX_REQUIRE(plan->vec == 1, "ensemble kernels use vec=1");
-  WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)), "ensemble kernels do not take mask/skipna flags");
+  if (plan->flags & WBX_FLAG_MASKED) WBX_REQUIRE(mask != nullptr, "WBX_FLAG_MASKED set but mask is NULL");
   WBX_REQUIRE(M >= 1, "ensemble size must be >= 1 (got %d)", M);
-  WBX_REQUIRE(algo == WBX_ENS_SORT || algo == WBX_ENS_PAIRWISE, "unknown ensemble algorithm %d", algo);
+  WBX_REQUIRE(algo == WBX_ENS_SORT || algo == WBX_ENS_PAIRWISE || (algo == WBX_ENS_DIAG_LOADONLY && (M == 50 || M == 51)),
+              "unknown ensemble algorithm %d", algo);
   const bool empty = plan->nkey * plan->ndepth * plan->nx == 0;
   WBX_REQUIRE(empty || (p != nullptr && t != nullptr), "predictions/targets pointer is NULL");
   WBX_REQUIRE(out != nullptr || plan->nkey == 0, "output pointer is NULL");
@@ -69,14 +73,12 @@ static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, i
   fill_args(plan, a);
   a.in[0] = p;
   a.in[1] = t;
+  a.in[3] = mask;
   a.out = out;
   a.M = M;
   a.mstride = member_stride;
   a.lane = lane;
-  if (dtype == WBX_F64) {
-    using Op = EnsOpGeneric<double>;
-    return map ? launch_map<Op>(ctx, plan, a) : launch_partial<Op, 1>(ctx, plan, a);
-  }
+  if (dtype == WBX_F64) return launch_ens_op<EnsOpGeneric<double>>(ctx, plan, a, map);
   WBX_REQUIRE(dtype == WBX_F32, "unknown dtype %d", dtype);
   if (M == 51) return launch_ens_m51(ctx, plan, a, algo, map);
   if (M == 50) return launch_ens_m50(ctx, plan, a, algo, map);
@@ -85,19 +87,18 @@ static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, i
   if (M <= 16) return launch_ens_m16(ctx, plan, a, algo, map);
   if (M <= 32) return launch_ens_m32(ctx, plan, a, algo, map);
   if (M <= 64) return launch_ens_m64(ctx, plan, a, algo, map);
-  using Op = EnsOpGeneric<float>;
-  return map ? launch_map<Op>(ctx, plan, a) : launch_partial<Op, 1>(ctx, plan, a);
+  return launch_ens_op<EnsOpGeneric<float>>(ctx, plan, a, map);
 }
 
 }  // namespace wbx
 
 extern "C" int wbx_ens_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride,
-                               int algo, const void* p, const void* t, double* partial_out) {
-  return wbx::ens_common(ctx, plan, dtype, M, member_stride, algo, p, t, partial_out, false, 0);
+                               int algo, const void* p, const void* t, const uint8_t* mask, double* partial_out) {
+  return wbx::ens_common(ctx, plan, dtype, M, member_stride, algo, p, t, mask, partial_out, false, 0);
 }
 
 extern "C" int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride, int algo,
                            int lane, const void* p, const void* t, double* out) {
   if (lane < 0 || lane >= WBX_ENS_LANES) return wbx::fail(WBX_ERR_INVALID, "ensemble lane %d out of range", lane);
-  return wbx::ens_common(ctx, plan, dtype, M, member_stride, algo, p, t, out, true, lane);
+  return wbx::ens_common(ctx, plan, dtype, M, member_stride, algo, p, t, nullptr, out, true, lane);
 }

@@ -19,10 +19,13 @@
 #include "wbx_sortnet_gen.hpp"
 
 #ifndef WBX_ENS_MIN_WAVES
-#define WBX_ENS_MIN_WAVES 4  // waves per SIMD the ensemble kernels are register-budgeted for (<= 128 VGPRs)
+#define WBX_ENS_MIN_WAVES 1  // 4 (<= 128 VGPRs) spills 132 B and measured 0.63 ms vs 0.37 ms on MI355X: keep 140 VGPRs, 3 waves/SIMD
 #endif
 
 namespace wbx {
+
+// not part of the ABI enum: stage-1 memory-pattern diagnostic used by tools/kbench.py (lane 0 = sum_m p - t)
+constexpr int WBX_ENS_DIAG_LOADONLY = 99;
 
 struct EnsLanes {
   double skill, spread, var, uemse, emse;
@@ -36,15 +39,43 @@ struct EnsOpF32 {
   static constexpr int NACC = WBX_ENS_LANES;
   static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = WBX_ENS_MIN_WAVES;
 
-  __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
-                                                double (&val)[NLANE]) {
+  // One grid point's inputs in VGPRs.  load() only issues the (coalesced-across-lanes) member loads; compute() is
+  // pure register work, so the skeleton can keep the NEXT point's loads in flight while this one is reduced.
+  struct Regs {
+    float xm[MP];
+    float t;
+  };
+  // (Register double-buffering of the next point was tried on MI355X: 255 VGPRs, 2 waves/SIMD, 0.49 ms vs 0.39 ms -- dropped.)
+
+  __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
     const int M = EXACT ? MP : a.M;
     const float* pp = reinterpret_cast<const float*>(a.in[0]) + ro[0] + x * a.xstride[0];
-    const double td = (double)(reinterpret_cast<const float*>(a.in[1])[ro[1] + x * a.xstride[1]]);
-    float xm[MP];
+    r.t = reinterpret_cast<const float*>(a.in[1])[ro[1] + x * a.xstride[1]];
 #pragma unroll
-    for (int m = 0; m < MP; ++m) xm[m] = (EXACT || m < M) ? pp[(int64_t)m * a.mstride] : INFINITY;
+    for (int m = 0; m < MP; ++m) r.xm[m] = (EXACT || m < M) ? pp[(int64_t)m * a.mstride] : INFINITY;
+  }
 
+  __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                                double (&val)[NLANE]) {
+    Regs r;
+    load(a, ro, x, r);
+    compute(a, r, val);
+  }
+
+  __device__ __forceinline__ static void compute(const S1Args& a, Regs& r, double (&val)[NLANE]) {
+    const int M = EXACT ? MP : a.M;
+    const double td = (double)r.t;
+    float(&xm)[MP] = r.xm;
+
+    if constexpr (ALGO == WBX_ENS_DIAG_LOADONLY) {  // diagnostic: the member loads with (almost) no arithmetic
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < MP; ++m)
+        if (EXACT || m < M) s += xm[m];
+      val[0] = (double)s - td;
+      val[1] = val[2] = val[3] = val[4] = 0.0;
+      return;
+    }
     double pair_total = 0.0;
     float poison = 0.f;  // NaN iff any member is NaN/inf (v_min/v_max would silently drop a NaN)
     if constexpr (ALGO == WBX_ENS_PAIRWISE) {
@@ -65,21 +96,26 @@ struct EnsOpF32 {
           xm, [](float u, float v) { return fminf(u, v); }, [](float u, float v) { return fmaxf(u, v); });
     }
 
-    double sum = 0.0, sq = 0.0, sabs = 0.0, dot = 0.0;
+    // Member-only quantities (spread, variance) are accumulated on e = x - x0 so that they stay finite when the
+    // target is NaN (the reference's spread / variance never look at the target); x0 = first register member.
+    const double x0 = (double)xm[0];
+    const double x0t = x0 - td;  // NaN iff the target is NaN
+    double se = 0.0, sq = 0.0, sabs = 0.0, dot = 0.0;
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
       if (EXACT || m < M) {
-        const double d = (double)xm[m] - td;
-        sum += d;
-        sq = fma(d, d, sq);
-        sabs += fabs(d);
-        if constexpr (ALGO == WBX_ENS_SORT) dot = fma((double)(2 * (m + 1) - M - 1), d, dot);
+        const double e = (double)xm[m] - x0;
+        se += e;
+        sq = fma(e, e, sq);
+        sabs += fabs(e + x0t);
+        if constexpr (ALGO == WBX_ENS_SORT) dot = fma((double)(2 * (m + 1) - M - 1), e, dot);
       }
     }
     const double dM = (double)M;
     const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
-    const double mean_d = sum / dM;                              // mean_m p - t
-    const double var = (sq - sum * mean_d) / (dM - 1.0);         // ddof = 1
+    const double mean_e = se / dM;
+    const double mean_d = x0t + mean_e;                       // mean_m p - t
+    const double var = (sq - se * mean_e) / (dM - 1.0);       // ddof = 1
     double spread;
     if constexpr (ALGO == WBX_ENS_SORT) {
       spread = 2.0 * dot / (dM * (dM - fair));
@@ -110,14 +146,53 @@ struct EnsOpF32 {
   }
 };
 
+// Mask / skipna handling of Aggregator.aggregate_stat_var (aggregation.py:339-357) around any ensemble core:
+// masked-out or (skipna) NaN statistic values become 0 and are counted out through the paired count lanes.
+template <class Core>
+struct EnsMasked {
+  static constexpr int NIN = Core::NIN;
+  static constexpr int NLANE = Core::NLANE;
+  static constexpr int NACC = 2 * Core::NLANE;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = Core::MIN_WAVES;
+
+  __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                                double (&val)[NLANE]) {
+    Core::values(a, ro, x, val);
+  }
+
+  template <int V, bool XK>
+  __device__ __forceinline__ static void accum(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                               double (&acc)[XK ? V : 1][NACC]) {
+    static_assert(V == 1, "ensemble op is one point per lane");
+    double val[NLANE];
+    Core::values(a, ro, x, val);
+    const bool valid =
+        (a.flags & WBX_FLAG_MASKED) ? reinterpret_cast<const uint8_t*>(a.in[3])[ro[3] + x * a.xstride[3]] != 0 : true;
+    const bool skipna = a.flags & WBX_FLAG_SKIPNA;
+#pragma unroll
+    for (int l = 0; l < NLANE; ++l) {
+      const bool ok = valid && !(skipna && val[l] != val[l]);
+      acc[0][l] += ok ? val[l] : 0.0;
+      acc[0][NLANE + l] += ok ? 1.0 : 0.0;
+    }
+  }
+};
+
+template <class Op>
+int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
+  if (map) return launch_map<Op>(ctx, plan, a);
+  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) return launch_partial<EnsMasked<Op>, 1>(ctx, plan, a);
+  return launch_partial<Op, 1>(ctx, plan, a);
+}
+
 template <int MP, bool EXACT>
 int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo, bool map) {
-  if (algo == WBX_ENS_SORT) {
-    using Op = EnsOpF32<MP, EXACT, WBX_ENS_SORT>;
-    return map ? launch_map<Op>(ctx, plan, a) : launch_partial<Op, 1>(ctx, plan, a);
+  if (algo == WBX_ENS_SORT) return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_SORT>>(ctx, plan, a, map);
+  if (algo == WBX_ENS_DIAG_LOADONLY) {
+    if (!EXACT || map) return fail(WBX_ERR_INVALID, "the load-only diagnostic exists for the exact-M partial kernels only");
+    return launch_partial<EnsOpF32<MP, EXACT, WBX_ENS_DIAG_LOADONLY>, 1>(ctx, plan, a);
   }
-  using Op = EnsOpF32<MP, EXACT, WBX_ENS_PAIRWISE>;
-  return map ? launch_map<Op>(ctx, plan, a) : launch_partial<Op, 1>(ctx, plan, a);
+  return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_PAIRWISE>>(ctx, plan, a, map);
 }
 
 // one translation unit per bucket (parallel build)

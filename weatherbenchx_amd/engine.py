@@ -207,7 +207,7 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
     else:
       m, mstride, algo = ens
       _hip.check(ctx.lib.wbx_ens_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride),
-                                         int(algo), ptr(devs[0]), ptr(devs[1]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
+                                         int(algo), ptr(devs[0]), ptr(devs[1]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop() / reps, 'reps': reps, 'vec': plan.vec,
                          'x_kept': plan.x_kept, 'grid': plan.nkey * plan.nchunk, 'block': plan.block_threads})
