@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 _LIB_NAME = 'libwbx_hip.so'
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+_LIB_PATH = os.environ.get('WBX_LIBRARY_PATH') or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 MAX_INPUTS = 4
 F32, F64 = 0, 1

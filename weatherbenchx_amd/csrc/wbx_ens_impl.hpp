@@ -47,6 +47,13 @@ struct EnsOpF32 {
   };
   // (Register double-buffering of the next point was tried on MI355X: 255 VGPRs, 2 waves/SIMD, 0.49 ms vs 0.39 ms -- dropped.)
 
+  // Measured alternatives on MI355X (tools/kbench.py, M = 51, 8 x 721 x 1440 points, 0.375 ms baseline):
+  //   * SGPR buffer descriptors + scalar member offsets (no 64-bit VGPR addresses): 0.373 ms rank form (noise),
+  //     but 0.60 ms vs 0.52 ms for the pair form -> not kept;
+  //   * __launch_bounds__ for 4 waves/SIMD (128 VGPRs): 88-164 B of spills, 0.60-0.63 ms -> not kept;
+  //   * register double-buffering of the next point: 255 VGPRs, 2 waves/SIMD, 0.49 ms -> not kept.
+  // The load-only diagnostic (WBX_ENS_DIAG_LOADONLY) streams the same 52 dword streams at 6.0 TB/s, so what is
+  // left is VALU time (~2000 instructions per 64 points) that 3 waves/SIMD only partly overlap with the loads.
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
     const int M = EXACT ? MP : a.M;
     const float* pp = reinterpret_cast<const float*>(a.in[0]) + ro[0] + x * a.xstride[0];
