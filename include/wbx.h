@@ -168,6 +168,12 @@ typedef struct wbx_s2_plan {
 int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial,
                  const double* W, double* out);
 
+/* Same contraction for W = wt[Bk][Br][j] * mask[Bk][Br][j][bin] with BOOLEAN masks and nbin <= 64 (Regions / LandSea
+ * binning, binning.py:92-201, times GridAreaWeighting): `wt` is float64[nBk][nBr][nj]; bit b of bits[nBk][nBr][nj]
+ * says whether the point belongs to bin b.  Result layout and NaN semantics are identical to wbx_contract. */
+int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* wt,
+                      const uint64_t* bits, double* out);
+
 /* ---- materialisation of per-point statistics --------------------------------
  * Statistic.compute()'s full-resolution result (metrics/base.py:135-158) for callers
  * that really want it (unaggregated pipelines, beam_pipeline.py:563-595).

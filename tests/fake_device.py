@@ -132,7 +132,13 @@ def _run_map(ctx, kind, dplan, plan, devs, dtype_code, lane, func=0, ens=None):
 
 def _run_s2(ctx, s2, partial, w_buf):
   part = np.asarray(partial).reshape(s2.nA, s2.nBk, s2.nBr, s2.nchunk, s2.nlane, s2.nj)
-  w = np.asarray(w_buf.ptr).reshape(s2.nBk, s2.nBr, s2.nj, s2.nbin)
+  if w_buf.kind == 'bits':
+    wt = np.asarray(w_buf.bufs[0].ptr).reshape(s2.nBk, s2.nBr, s2.nj)
+    bits = np.asarray(w_buf.bufs[1].ptr).reshape(s2.nBk, s2.nBr, s2.nj)
+    member = ((bits[..., None] >> np.arange(s2.nbin, dtype=np.uint64)) & np.uint64(1)).astype(np.float64)
+    w = wt[..., None] * member
+  else:
+    w = np.asarray(w_buf.bufs[0].ptr).reshape(s2.nBk, s2.nBr, s2.nj, s2.nbin)
   with np.errstate(all='ignore'):
     if s2.sum_j:
       out = np.einsum('abrclj,brjn->abln', part, w)[:, :, :, None, :]

@@ -363,3 +363,43 @@ def test_masked_and_skipna_ensemble_aggregation(backend):
   # without either, the NaN targets poison the skill term
   agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'])
   assert np.isnan(aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, {'v': t})['crps.v'].values)
+
+
+MANY_REGIONS = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'nh': ((20, 90), (0, 360)),
+                'sh': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)), 'namerica': ((25, 60), (240, 285)),
+                'ausnz': ((-45, -12.5), (120, 175))}
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest', 'level_fastest'])
+@pytest.mark.parametrize('reduce_dims', [('init_time', 'latitude', 'longitude'), ('latitude',), ('init_time',)])
+@pytest.mark.parametrize('with_nan', [False, True])
+def test_many_boolean_bins_use_membership_bits(backend, layout, reduce_dims, with_nan):
+  """>= 5 boolean bins (here 7 regions x {all, land} = 14) go through the bit-mask contraction
+  (wbx_contract_bits); results and the NaN-poisons-every-bin rule must equal the dense xr.dot semantics."""
+  from weatherbenchx_amd import engine
+  rng = np.random.default_rng(11)
+  dims = LAYOUTS[layout]
+  p, t = _field(rng, dims, np.float32, 280.0), _field(rng, dims, np.float32, 280.0)
+  if with_nan:
+    idx = {'init_time': 1, 'lead_time': 2, 'level': 0, 'latitude': 30, 'longitude': 5}  # a point in 'nh' only
+    p.data[tuple(idx[d] for d in dims)] = np.nan
+  land = rng.random((32, 64)) > 0.6
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': LAT, 'longitude': LON})
+  agg = aggregation.Aggregator(reduce_dims=list(reduce_dims), weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(MANY_REGIONS, land_sea_mask=lsm)])
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'z': p}, {'z': t})
+  state = agg.aggregate_statistics(stats)
+  w = (O.grid_area_weights(LAT), ('latitude',))
+  names, masks = O.region_masks(LAT, LON, MANY_REGIONS, land_sea_mask=land)
+  sws, sw, out_dims = O.aggregate(O.squared_error(p.values, t.values), dims, reduce_dims, weights=[w],
+                                  bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))])
+  got = state.sum_weighted_statistics['SquaredError']['z']
+  assert list(got['region'].values) == names and len(names) == 14
+  np.testing.assert_allclose(got.transpose(*out_dims).values, sws, rtol=RTOL, atol=1e-9)
+  np.testing.assert_allclose(state.sum_weights['SquaredError']['z'].transpose(*out_dims).values, sw, rtol=RTOL)
+  if with_nan and 'latitude' in reduce_dims and 'longitude' in reduce_dims:
+    assert np.isnan(got.values).any()
+  # the bit path really was taken
+  w_da, _ = agg._cached_weight_product(stats['SquaredError']['z'])
+  assert any(v.kind == 'bits' for v in w_da.__dict__['_wbx_w'].values())
+  assert engine.BITS_MIN_BINS <= 14 <= 64

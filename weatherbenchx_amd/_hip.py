@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     'wbx_abi_version', 'wbx_last_error', 'wbx_device_count', 'wbx_ctx_create', 'wbx_ctx_destroy',
     'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
     'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
-    'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_det_map', 'wbx_ens_map',
+    'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_map', 'wbx_ens_map',
     'wbx_zonal_spectrum',
 )
 
@@ -99,6 +99,7 @@ def load_library():
         'wbx_det_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp],
         'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp, vp],
         'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
+        'wbx_contract_bits': [vp, C.POINTER(S2PlanStruct), vp, vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
         'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],

@@ -145,13 +145,20 @@ def _weight_product(stat: xr.DataArray, weigh_by, bin_by):
   for method in weigh_by or []:
     wi = xr.as_dataarray(method.weights(stat)).astype(np.float64)
     w = wi if w is None else w * wi
+  masks, all_bool = None, True
   for method in bin_by or []:
     mask = xr.as_dataarray(method.create_bin_mask(stat))
     if not (set(mask.dims) - {method.bin_dim_name}) <= stat_dims:
       return None  # cannot bin on dims that are not evaluation-unit dims (aggregation.py:320-330)
-    mask = mask.astype(np.float64)
-    w = mask if w is None else w * mask
-  return w, tuple(names)
+    all_bool = all_bool and mask.dtype == np.bool_
+    masks = mask if masks is None else (masks & mask if all_bool else masks.astype(np.float64) * mask.astype(np.float64))
+  if masks is None:
+    return w, tuple(names)
+  product = masks.astype(np.float64) if w is None else w * masks.astype(np.float64)
+  if all_bool:
+    # boolean masks: the engine may contract with the (weights, membership bits) factors instead of the dense product
+    product.__dict__['_wbx_factors'] = (w, masks)
+  return product, tuple(names)
 
 
 @dataclasses.dataclass

@@ -17,6 +17,8 @@ struct wbx_ctx {
   hipEvent_t ev_stop = nullptr;
   // scratch for rocFFT (spectrum) and plans live in wbx_spectrum.hip
   void* fft_state = nullptr;
+  void* s2_scratch = nullptr;  // split partials of wbx_contract_bits
+  size_t s2_scratch_size = 0;
 };
 
 namespace wbx {

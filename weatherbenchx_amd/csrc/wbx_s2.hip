@@ -102,7 +102,152 @@ __global__ void __launch_bounds__(256) s2_keepj_kernel(wbx_s2_plan p, int njtile
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Bit-mask form of the same contraction, for W = wt[Bk][Br][j] * mask[Bk][Br][j][bin] with boolean masks and at most
+// 64 bins (Regions / LandSea binning of weatherbenchX/binning.py:92-201 times GridAreaWeighting): the dense W of the
+// public benchmark's 34 bins at 0.25 degree would be 282 MB and cost 34 multiply-adds per element; here one uint64
+// carries a point's membership in every bin.  Per element: m = p * wt once, then per bin 4 integer/fp ops
+// (v_bfe_i32 -> all-ones/zero, two v_and, v_add_f64).  NaN * 0 = NaN is kept by a poison term (m * 0) that is
+// added to EVERY bin, exactly like the reference's xr.dot (aggregation.py:272-277).
+template <int NB>
+__global__ void __launch_bounds__(256) s2_bits_kernel(wbx_s2_plan p, int rows_per_block, int nsplit,
+                                                      const double* __restrict__ partial,
+                                                      const double* __restrict__ wt,
+                                                      const unsigned long long* __restrict__ bits,
+                                                      double* __restrict__ out) {
+  // sum_j = 1: grid = nA*nBk*nlane*nsplit; block = rows [split*rows_per_block, ...) x all j; out = tmp[row][split][bin]
+  // sum_j = 0: grid = nA*nBk*nlane*njtile (nsplit = njtile); block = all rows x 256 j;       out = final [..][j][bin]
+  int64_t b = blockIdx.x;
+  const int split = (int)(b % nsplit);
+  b /= nsplit;
+  const int64_t lane = b % p.nlane;
+  b /= p.nlane;
+  const int64_t bk = b % p.nBk;
+  const int64_t A = b / p.nBk;
+  const double* pbase = partial + (A * p.nBk + bk) * p.nBr * p.nchunk * p.nlane * p.nj;
+  const double* wbase = wt + bk * p.nBr * p.nj;
+  const unsigned long long* bbase = bits + bk * p.nBr * p.nj;
+  double acc[NB];
+#pragma unroll
+  for (int g = 0; g < NB; ++g) acc[g] = 0.0;
+  double poison = 0.0;
+  const int64_t r0 = p.sum_j ? (int64_t)split * rows_per_block : 0;
+  const int64_t r1 = p.sum_j ? (r0 + rows_per_block < p.nBr ? r0 + rows_per_block : p.nBr) : p.nBr;
+  const int64_t j0 = p.sum_j ? threadIdx.x : (int64_t)split * blockDim.x + threadIdx.x;
+  const int64_t jstep = p.sum_j ? blockDim.x : p.nj;  // sum_j = 0: exactly one j per thread
+  for (int64_t br = r0; br < r1; ++br) {
+    for (int64_t j = j0; j < p.nj; j += jstep) {
+      double v = 0.0;
+      for (int64_t ch = 0; ch < p.nchunk; ++ch) v += pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
+      const double m = v * wbase[br * p.nj + j];
+      poison = fma(m, 0.0, poison);
+      const unsigned long long bw = bbase[br * p.nj + j];
+      const int lo = (int)(unsigned)bw, hi = (int)(unsigned)(bw >> 32);
+      const long long mb = __double_as_longlong(m);
+#pragma unroll
+      for (int g = 0; g < NB; ++g) {
+        const int word = g < 32 ? lo : hi;
+        const long long sel = (long long)((word << (31 - (g & 31))) >> 31);  // 0 or -1 (all ones)
+        acc[g] += __longlong_as_double(mb & sel);
+      }
+    }
+  }
+  if (!p.sum_j) {
+    if (j0 < p.nj) {
+      double* o = out + ((((A * p.nBk + bk) * p.nlane + lane) * p.nj) + j0) * p.nbin;
+      for (int g = 0; g < NB && g < p.nbin; ++g) o[g] = acc[g] + poison;
+    }
+    return;
+  }
+  __shared__ double red[4][NB];
+  const int tl = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < NB; ++g) {
+    const double s = wave_sum(acc[g] + poison);
+    if (tl == 0) red[wv][g] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NB && threadIdx.x < p.nbin) {
+    double s = 0.0;
+    for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) s += red[w2][threadIdx.x];
+    out[(((A * p.nBk + bk) * p.nlane + lane) * nsplit + split) * p.nbin + threadIdx.x] = s;
+  }
+}
+
+// tmp[row][split][bin] -> out[row][bin]
+__global__ void __launch_bounds__(256) s2_bits_finish_kernel(int64_t nrow, int nsplit, int nbin,
+                                                             const double* __restrict__ tmp, double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrow * nbin) return;
+  const int64_t row = i / nbin;
+  const int bin = (int)(i - row * nbin);
+  double s = 0.0;
+  for (int k = 0; k < nsplit; ++k) s += tmp[(row * nsplit + k) * nbin + bin];
+  out[i] = s;
+}
+
 }  // namespace wbx
+
+extern "C" int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* wt,
+                                 const uint64_t* bits, double* out) {
+  using namespace wbx;
+  WBX_REQUIRE(ctx != nullptr && plan != nullptr, "ctx/plan is NULL");
+  const wbx_s2_plan& p = *plan;
+  WBX_REQUIRE(p.nA >= 0 && p.nBk >= 0 && p.nBr >= 0 && p.nchunk >= 0 && p.nlane >= 0 && p.nj >= 0, "negative extent");
+  WBX_REQUIRE(p.nbin >= 1 && p.nbin <= 64, "wbx_contract_bits handles 1..64 bins (got %lld)", (long long)p.nbin);
+  const int64_t nrow = p.nA * p.nBk * p.nlane;
+  const int64_t nout = nrow * (p.sum_j ? 1 : p.nj) * p.nbin;
+  if (nout == 0) return 0;
+  WBX_REQUIRE(out != nullptr, "out is NULL");
+  WBX_HIP(hipSetDevice(ctx->device));
+  if (p.nBr * p.nchunk * (p.sum_j ? p.nj : 1) == 0) {
+    WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
+    return 0;
+  }
+  WBX_REQUIRE(partial != nullptr && wt != nullptr && bits != nullptr, "partial/wt/bits is NULL");
+  const unsigned long long* b64 = reinterpret_cast<const unsigned long long*>(bits);
+  int rows_per_block = 1, nsplit = 1;
+  double* dst = out;
+  if (p.sum_j) {
+    // enough blocks to fill the chip: split the Br rows; each block covers whole rows of nj
+    int64_t want = (4096 + nrow - 1) / nrow;
+    if (want > p.nBr) want = p.nBr;
+    if (want < 1) want = 1;
+    rows_per_block = (int)((p.nBr + want - 1) / want);
+    nsplit = (int)((p.nBr + rows_per_block - 1) / rows_per_block);
+    const size_t need = (size_t)nrow * nsplit * p.nbin * sizeof(double);
+    if (ctx->s2_scratch_size < need) {
+      if (ctx->s2_scratch) {
+        WBX_HIP(hipStreamSynchronize(ctx->stream));
+        WBX_HIP(hipFree(ctx->s2_scratch));
+      }
+      WBX_HIP(hipMalloc(&ctx->s2_scratch, need));
+      ctx->s2_scratch_size = need;
+    }
+    dst = reinterpret_cast<double*>(ctx->s2_scratch);
+  } else {
+    nsplit = (int)((p.nj + 255) / 256);
+  }
+  const int64_t grid = nrow * nsplit;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "stage-2 grid too large");
+  if (p.nbin <= 16)
+    hipLaunchKernelGGL((s2_bits_kernel<16>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p, rows_per_block, nsplit,
+                       partial, wt, b64, dst);
+  else if (p.nbin <= 32)
+    hipLaunchKernelGGL((s2_bits_kernel<32>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p, rows_per_block, nsplit,
+                       partial, wt, b64, dst);
+  else
+    hipLaunchKernelGGL((s2_bits_kernel<64>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p, rows_per_block, nsplit,
+                       partial, wt, b64, dst);
+  WBX_HIP(hipGetLastError());
+  if (p.sum_j) {
+    const int64_t n = nrow * p.nbin;
+    hipLaunchKernelGGL(s2_bits_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, nrow, nsplit,
+                       (int)p.nbin, dst, out);
+    WBX_HIP(hipGetLastError());
+  }
+  return 0;
+}
 
 extern "C" int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* W,
                             double* out) {

@@ -136,16 +136,61 @@ def _device_plan(ctx, plan: planner.S1Plan) -> _PlanOnDevice:
   return _plan_cache[key]
 
 
+class _WOnDevice:
+  """Stage-2 operand: dense W, or (weights, membership bits) for boolean bin masks."""
+
+  def __init__(self, kind, bufs, shape, bin_shape):
+    self.kind, self.bufs, self.shape, self.bin_shape = kind, bufs, shape, bin_shape
+
+
+BITS_MIN_BINS = 5  # below this the dense contraction is just as cheap
+
+
+def pack_bits(plan: planner.S1Plan, weights, masks, bin_dims):
+  """(wt float64[nBk][nBr][nj], bits uint64[nBk][nBr][nj], nbin, bin_shape) from the labeled factors."""
+  wd = plan.bk_dims + plan.br_dims + ((plan.x_dim,) if plan.x_kept and plan.x_dim is not None else ())
+  shape_w = [plan.sizes[d] for d in wd]
+  sizes = {d: plan.sizes[d] for d in wd}
+  if weights is None:
+    wt = np.ones(shape_w, dtype=np.float64)
+  else:
+    extra = [d for d in weights.dims if d not in wd]
+    if extra:
+      raise ValueError(f'weights depend on dims {extra} that stage 1 does not keep')
+    wt = np.broadcast_to(xr._bcast_data(weights.astype(np.float64), wd, sizes), shape_w)  # pylint: disable=protected-access
+  bin_dims = tuple(bin_dims)
+  bin_shape = tuple(masks.sizes[d] for d in bin_dims)
+  nbin = int(np.prod(bin_shape, dtype=np.int64))
+  extra = [d for d in masks.dims if d not in wd and d not in bin_dims]
+  if extra:
+    raise ValueError(f'bin masks depend on dims {extra} that stage 1 does not keep')
+  all_dims = list(wd) + list(bin_dims)
+  msizes = dict(sizes, **{d: masks.sizes[d] for d in bin_dims})
+  m = np.broadcast_to(xr._bcast_data(masks, all_dims, msizes), shape_w + list(bin_shape))  # pylint: disable=protected-access
+  m = m.reshape(shape_w + [nbin]).astype(bool)
+  bits = np.zeros(shape_w, dtype=np.uint64)
+  for b in range(nbin):
+    bits |= m[..., b].astype(np.uint64) << np.uint64(b)
+  shape4 = (plan.n(plan.bk_dims), plan.n(plan.br_dims), plan.nj, nbin)
+  return (np.ascontiguousarray(wt.reshape(shape4[:3])), np.ascontiguousarray(bits.reshape(shape4[:3])), shape4, bin_shape)
+
+
 def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
-  """Dense W on the device, cached on the (aggregator-cached) labeled W object per stage-1 geometry."""
+  """Stage-2 operand on the device, cached on the (aggregator-cached) labeled W object per stage-1 geometry."""
   sig = (ctx.device_id, plan.bk_dims, plan.br_dims, plan.x_dim if plan.x_kept else None, plan.nj,
          tuple(plan.sizes[d] for d in plan.bk_dims + plan.br_dims), tuple(bin_dims))
   store = _w_cache if w_da is None else w_da.__dict__.setdefault('_wbx_w', {})
   if sig not in store:
     if len(store) > 32:
       store.clear()
-    w, bin_shape = dense_w(plan, w_da, bin_dims)
-    store[sig] = (ctx.upload(w), w.shape, bin_shape)
+    factors = None if w_da is None else w_da.__dict__.get('_wbx_factors')
+    nbin = int(np.prod([w_da.sizes[d] for d in bin_dims], dtype=np.int64)) if (w_da is not None and bin_dims) else 1
+    if factors is not None and BITS_MIN_BINS <= nbin <= 64:
+      wt, bits, shape4, bin_shape = pack_bits(plan, factors[0], factors[1], bin_dims)
+      store[sig] = _WOnDevice('bits', (ctx.upload(wt), ctx.upload(bits)), shape4, bin_shape)
+    else:
+      w, bin_shape = dense_w(plan, w_da, bin_dims)
+      store[sig] = _WOnDevice('dense', (ctx.upload(w),), w.shape, bin_shape)
   return store[sig]
 
 
@@ -240,8 +285,12 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
   shape = s2.out_shape()
   n = int(np.prod(shape, dtype=np.int64))
   out = _scratch(ctx, 's2out', n * 8)
-  _hip.check(ctx.lib.wbx_contract(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.ptr),
-                                  C.c_void_p(out.ptr)), 'wbx_contract')
+  if w_buf.kind == 'bits':
+    _hip.check(ctx.lib.wbx_contract_bits(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.bufs[0].ptr),
+                                         C.c_void_p(w_buf.bufs[1].ptr), C.c_void_p(out.ptr)), 'wbx_contract_bits')
+  else:
+    _hip.check(ctx.lib.wbx_contract(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.bufs[0].ptr),
+                                    C.c_void_p(out.ptr)), 'wbx_contract')
   return ctx.download(out.ptr, shape, np.float64)
 
 
@@ -300,8 +349,9 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   if kind == 'ens':
     ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
   partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args)
-  w_buf, w_shape, bin_shape = _device_w(ctx, plan, w_da, bin_dims)
-  s2 = planner.build_s2_plan(plan, nl_total, w_shape[-1])
+  w_buf = _device_w(ctx, plan, w_da, bin_dims)
+  bin_shape = w_buf.bin_shape
+  s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
   out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
 
   x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()
