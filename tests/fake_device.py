@@ -71,6 +71,16 @@ def _ens_lanes(plan, devs, ens, flags):
   members = np.stack([devs[0].ptr[off_p + k * mstride] for k in range(m)], axis=-1).astype(np.float64)
   t = devs[1].ptr[_offsets(plan, 1)].astype(np.float64)
   fair = 1.0 if flags & _hip.FLAG_FAIR else 0.0
+  if flags & _hip.FLAG_SKIPNA_ENS:
+    with np.errstate(all='ignore'):
+      n = (~np.isnan(members)).sum(axis=-1).astype(np.float64)
+      d = members - t[..., None]
+      skill = np.nansum(np.abs(d), axis=-1) / n
+      spread = np.nansum(np.abs(members[..., :, None] - members[..., None, :]), axis=(-1, -2)) / (n * (n - fair))
+      mean = np.nansum(members, axis=-1) / n
+      var = np.nansum((members - mean[..., None]) ** 2, axis=-1) / (n - 1)
+      md = mean - t
+    return [skill, spread, var, md * md - var / n, md * md]
   d = members - t[..., None]
   skill = np.abs(d).mean(axis=-1)
   if algo == _hip.ENS_SORT:

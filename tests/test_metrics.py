@@ -403,3 +403,65 @@ def test_many_boolean_bins_use_membership_bits(backend, layout, reduce_dims, wit
   w_da, _ = agg._cached_weight_product(stats['SquaredError']['z'])
   assert any(v.kind == 'bits' for v in w_da.__dict__['_wbx_w'].values())
   assert engine.BITS_MIN_BINS <= 14 <= 64
+
+
+@pytest.mark.parametrize('m,fair', list(itertools.product([4, 5], [True, False])))
+def test_crps_with_nan_member_equals_dropping_it(backend, m, fair):
+  # metrics_test.py:1199-1274: skipna_ensemble=True with one all-NaN member == the ensemble without that member
+  targets = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True, seed=20)
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True,
+                                               ensemble_size=m, seed=21)
+  with_nan = predictions.copy(deep=True)
+  with_nan['2m_temperature'][{'realization': 0}] = np.nan
+  kw = dict(ensemble_dim='realization', use_sort=False, fair=fair)
+  skip = {'crps': probabilistic.CRPSEnsemble(skipna_ensemble=True, **kw),
+          'ssr': probabilistic.UnbiasedSpreadSkillRatio(ensemble_dim='realization', skipna_ensemble=True)}
+  plain = {'crps': probabilistic.CRPSEnsemble(skipna_ensemble=False, **kw),
+           'ssr': probabilistic.UnbiasedSpreadSkillRatio(ensemble_dim='realization')}
+  got = compute_all_metrics(skip, with_nan, targets, ['latitude', 'longitude'])
+  dropped = compute_all_metrics(plain, predictions.isel(realization=slice(1, None)), targets, ['latitude', 'longitude'])
+  full = compute_all_metrics(plain, predictions, targets, ['latitude', 'longitude'])
+  for k in ('crps', 'ssr'):
+    xr.assert_allclose(got[f'{k}.2m_temperature'], dropped[f'{k}.2m_temperature'], rtol=1e-9, check_dim_order=False)
+    xr.assert_allclose(got[f'{k}.geopotential'], full[f'{k}.geopotential'], rtol=1e-9, check_dim_order=False)
+  with pytest.raises(ValueError, match='Failed to compute statistic CRPSSpread') as info:
+    compute_all_metrics({'c': probabilistic.CRPSEnsemble(ensemble_dim='realization', use_sort=True,
+                                                         skipna_ensemble=True)}, with_nan, targets, ['latitude'])
+  assert 'not supported with use_sort=True' in str(info.value.__cause__)
+
+
+@pytest.mark.parametrize('m,use_sort,fair', list(itertools.product([4, 5], [False, True], [True, False])))
+def test_crps_ensemble_distance(backend, m, use_sort, fair):
+  # metrics_test.py:673-752
+  targets = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True,
+                                           ensemble_size=m + 1, seed=0)
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', random=True,
+                                               ensemble_size=m, seed=1)
+  no_ens = targets.isel(realization=0, drop=True)
+  no_spread = no_ens.expand_dims(realization=np.arange(m + 1))  # ensemble dim first: a different layout on purpose
+  dist = {'crps': probabilistic.CRPSEnsembleDistance(ensemble_dim='realization', use_sort=use_sort, fair=fair)}
+  plain = {'crps': probabilistic.CRPSEnsemble(ensemble_dim='realization', use_sort=use_sort, fair=fair)}
+  rd = ['latitude', 'longitude', 'time']
+  a = compute_all_metrics(dist, predictions, targets, rd)
+  b = compute_all_metrics(dist, predictions, no_spread, rd)
+  c = compute_all_metrics(plain, predictions, no_ens, rd)
+  stderr = 1 / np.sqrt(np.prod([m * targets['geopotential'].sizes[d] for d in rd]))
+  for v in ['2m_temperature', 'geopotential']:
+    if fair:
+      np.testing.assert_allclose(a[f'crps.{v}'].values, 0, atol=5 * stderr)
+    xr.assert_allclose(b[f'crps.{v}'], c[f'crps.{v}'], atol=5 * stderr, check_dim_order=False)
+  # brute force for one variable (float64 oracle, explicit double loop)
+  p = predictions['2m_temperature'].values.astype(np.float64)
+  t = targets['2m_temperature'].values.astype(np.float64)
+  skill = np.abs(p[..., :, None] - t[..., None, :]).mean(axis=(-1, -2))
+  sp = np.abs(p[..., :, None] - p[..., None, :]).sum(axis=(-1, -2)) / (m * (m - int(fair)))
+  st = np.abs(t[..., :, None] - t[..., None, :]).sum(axis=(-1, -2)) / ((m + 1) * (m + 1 - int(fair)))
+  want = (skill - 0.5 * sp - 0.5 * st).mean(axis=(1, 2, 3))  # dims: prediction_timedelta, time, lat, lon
+  np.testing.assert_allclose(a['crps.2m_temperature'].values, want, rtol=1e-9)
+
+
+def test_unbiased_mse_rejects_ensemble_targets(backend):
+  p = {'v': xr.DataArray(np.zeros((3, 4)), dims=('number', 'x'))}
+  with pytest.raises(ValueError, match='Failed to compute statistic') as info:
+    metrics_base.compute_unique_statistics_for_all_metrics({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, p, p)
+  assert isinstance(info.value.__cause__, NotImplementedError)

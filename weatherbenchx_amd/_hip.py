@@ -20,7 +20,7 @@ DET3, DET6, PASS1 = 0, 1, 2
 DET_LANES = {DET3: 3, DET6: 6, PASS1: 1}
 ENS_LANES = 5
 ENS_SORT, ENS_PAIRWISE = 0, 1
-FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR = 1, 2, 4
+FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR, FLAG_SKIPNA_ENS = 1, 2, 4, 8
 
 # every symbol include/wbx.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = (

@@ -23,7 +23,6 @@ from weatherbenchx_amd import weighting
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd import xarray_tree
 from weatherbenchx_amd.metrics import base as metrics_base
-from weatherbenchx_amd.metrics import deterministic as _det
 from weatherbenchx_amd import spectra
 
 
@@ -205,11 +204,13 @@ class Aggregator:
       return None
     w_da, bin_dims = wp
 
-    if isinstance(stat, _det._SumOfStatistics) and stat.is_lazy and not use_mask and not skipna:  # pylint: disable=protected-access
+    if isinstance(stat, lazy.LinearCombination) and stat.is_lazy and not use_mask and not skipna:
       parts = [self._aggregate(term, use_mask=False, skipna=False) for term in stat._terms]  # pylint: disable=protected-access
       sws = parts[0].sum_weighted_statistics
       for p in parts[1:]:
         sws = sws + p.sum_weighted_statistics
+      if stat._scale != 1.0:  # pylint: disable=protected-access
+        sws = sws * stat._scale  # pylint: disable=protected-access
       return AggregationState(sws, parts[0].sum_weights)
 
     if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy and not use_mask and not skipna:
@@ -281,12 +282,13 @@ class Aggregator:
     if hit is None and grp.kind == 'ens' and stat._lane != lazy.ENS_LANE['CRPSSpread']:  # pylint: disable=protected-access
       # only the spread lane depends on (algorithm, fair): every other lane is served by whatever ensemble
       # launch already ran for this aggregator, else by the cheaper rank-form kernel.
+      want_skip = bool(ens_params and ens_params.get('skipna'))
       for k2, v2 in grp.cache.items():
-        if k2[:-1] == key[:-1] and k2[-1][1] == mean_dims:
+        if k2[:-1] == key[:-1] and k2[-1][1] == mean_dims and dict(k2[-1][0]).get('skipna', False) == want_skip:
           hit = v2
           break
       if hit is None:
-        ens_params = {'algo': _hip.ENS_SORT, 'fair': True}
+        ens_params = {'algo': _hip.ENS_PAIRWISE if want_skip else _hip.ENS_SORT, 'fair': True, 'skipna': want_skip}
         key = self._cache_key(w_da, bin_dims, use_mask, skipna, (tuple(sorted(ens_params.items())), mean_dims))
         hit = grp.cache.get(key)
     if hit is None:

@@ -20,23 +20,32 @@ struct EnsOpGeneric {
     const int M = a.M;
     const T* pp = reinterpret_cast<const T*>(a.in[0]) + ro[0] + x * a.xstride[0];
     const double td = (double)(reinterpret_cast<const T*>(a.in[1])[ro[1] + x * a.xstride[1]]);
-    double se = 0.0, sq = 0.0, sabs = 0.0, pair_total = 0.0;
-    const double x0 = (double)pp[0];
-    const double x0t = x0 - td;  // member-only lanes use e = x - x0 and stay finite for a NaN target
+    // skipna_ensemble (probabilistic.py:139-145, 206-216, 271-273, 303-336): NaN members are missing members; the
+    // ensemble size becomes the per-point count of non-NaN values.
+    const bool skip = a.flags & WBX_FLAG_SKIPNA_ENS;
+    double se = 0.0, sq = 0.0, sabs = 0.0, pair_total = 0.0, x0 = 0.0;
+    int n = 0;
     for (int i = 0; i < M; ++i) {
       const double xi = (double)pp[(int64_t)i * a.mstride];
+      if (skip && xi != xi) continue;
+      if (n == 0) x0 = xi;  // member-only lanes use e = x - x0 and stay finite for a NaN target
+      ++n;
       const double e = xi - x0;
       se += e;
       sq = fma(e, e, sq);
-      sabs += fabs(e + x0t);
+      sabs += fabs(xi - td);
       double row = 0.0;
-      for (int j = 0; j < i; ++j) row += fabs(xi - (double)pp[(int64_t)j * a.mstride]);
+      for (int j = 0; j < i; ++j) {
+        const double xj = (double)pp[(int64_t)j * a.mstride];
+        if (skip && xj != xj) continue;
+        row += fabs(xi - xj);
+      }
       pair_total += row;
     }
-    const double dM = (double)M;
+    const double dM = (double)n;
     const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
     const double mean_e = se / dM;
-    const double mean_d = x0t + mean_e;
+    const double mean_d = (x0 - td) + mean_e;
     const double var = (sq - se * mean_e) / (dM - 1.0);
     val[0] = sabs / dM;
     val[1] = 2.0 * pair_total / (dM * (dM - fair));
@@ -79,6 +88,7 @@ static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, i
   a.mstride = member_stride;
   a.lane = lane;
   if (dtype == WBX_F64) return launch_ens_op<EnsOpGeneric<double>>(ctx, plan, a, map);
+  if (plan->flags & WBX_FLAG_SKIPNA_ENS) return launch_ens_op<EnsOpGeneric<float>>(ctx, plan, a, map);
   WBX_REQUIRE(dtype == WBX_F32, "unknown dtype %d", dtype);
   if (M == 51) return launch_ens_m51(ctx, plan, a, algo, map);
   if (M == 50) return launch_ens_m50(ctx, plan, a, algo, map);

@@ -340,6 +340,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
     flags |= _hip.FLAG_SKIPNA
   if ens and ens.get('fair', True):
     flags |= _hip.FLAG_FAIR
+  if ens and ens.get('skipna', False):
+    flags |= _hip.FLAG_SKIPNA_ENS
   layouts = [d.layout if d is not None else None for d in devs]
   plan, dplan = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
   nl = _hip.DET_LANES[func] if kind == 'det' else _hip.ENS_LANES
@@ -397,6 +399,8 @@ def materialise(kind: str, inputs: Sequence[xr.DataArray | None], dims: Sequence
     devs.append(None)
   layouts = [d.layout if d is not None else None for d in devs]
   flags = _hip.FLAG_FAIR if (ens and ens.get('fair', True)) else 0
+  if ens and ens.get('skipna', False):
+    flags |= _hip.FLAG_SKIPNA_ENS
   plan = planner.build_s1_plan(dims, sizes, layouts, (), gather=gather, flags=flags, allow_vec4=False, map_mode=True)
   dplan = _device_plan(ctx, plan)
   ens_args = None

@@ -299,13 +299,61 @@ def det_statistic(stat_name: str, p, t, climatology_ref: ClimatologyRef | None =
   return LazyStatistic(grp, DET_LANE[stat_name], name=p.name)
 
 
-def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fair=True) -> xr.DataArray:
+def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fair=True,
+                  skipna_ensemble=False) -> xr.DataArray:
   p, t = xr.as_dataarray(p), xr.as_dataarray(t)
   if ensemble_dim not in p.dims:
     raise ValueError(f'Dimension {ensemble_dim} not found in {p.dims}')
   if ensemble_dim in t.dims:
-    raise NotImplementedError('targets with an ensemble dimension are not fused yet (SURVEY 8f-3)')
+    raise ValueError(f'targets must not carry {ensemble_dim!r} here (select a member or use target_members())')
   m = p.sizes[ensemble_dim]
   grp = _group_for('ens', p, t, ens={'member_dim': ensemble_dim, 'M': m})
-  params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair)}
+  params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair),
+            'skipna': bool(skipna_ensemble)}
   return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params)
+
+
+def target_members(t: xr.DataArray, ensemble_dim: str):
+  """The members of an ensemble-valued target as separate (cached) views: statistics that are linear in the target
+  member index are evaluated per member and averaged (LinearCombination)."""
+  cache = t.__dict__.setdefault('_wbx_members', {})
+  if ensemble_dim not in cache:
+    cache[ensemble_dim] = [t.isel({ensemble_dim: j}, drop=True) for j in range(t.sizes[ensemble_dim])]
+  return cache[ensemble_dim]
+
+
+class LinearCombination(xr.DataArray):
+  """scale * sum(terms) of lazy statistics on the same frame.  The weighted reduction is linear, so the Aggregator
+  reduces every term with its own fused launch and combines the accumulators (WindVectorSquaredError =
+  SE(u) + SE(v), deterministic.py:174-219; CRPSSkill against an ensemble of targets, probabilistic.py:134-145)."""
+
+  def __init__(self, terms, scale: float = 1.0, name=None):
+    first = terms[0]
+    self._data = None
+    self._dims = first.dims
+    self.name = name
+    self.attrs = {}
+    self._coords = dict(first._coords)  # pylint: disable=protected-access
+    self._terms = list(terms)
+    self._scale = float(scale)
+
+  @property
+  def is_lazy(self):
+    return self._data is None
+
+  @property
+  def data(self):
+    if self._data is None:
+      total = self._terms[0].data
+      for t in self._terms[1:]:
+        total = total + t.data
+      self._data = total * self._scale if self._scale != 1.0 else total
+    return self._data
+
+  @property
+  def shape(self):
+    return self._terms[0].shape
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)

@@ -62,41 +62,6 @@ class TargetPassthrough(base.PerVariableStatistic):
     return out.where(~predictions.isnull()) if self._copy_nans_from_predictions else out
 
 
-class _SumOfStatistics(xr.DataArray):
-  """Marker for `a + b` of two lazy statistics (wind vector SE): the Aggregator reduces the terms
-  separately -- the reduction is linear -- and adds the accumulators."""
-
-  def __init__(self, terms):
-    first = terms[0]
-    self._data = None
-    self._dims = first.dims
-    self.name = None
-    self.attrs = {}
-    self._coords = dict(first._coords)  # pylint: disable=protected-access
-    self._terms = list(terms)
-
-  @property
-  def is_lazy(self):
-    return self._data is None
-
-  @property
-  def data(self):
-    if self._data is None:
-      total = self._terms[0].data
-      for t in self._terms[1:]:
-        total = total + t.data
-      self._data = total
-    return self._data
-
-  @property
-  def shape(self):
-    return self._terms[0].shape
-
-  @property
-  def dtype(self):
-    return np.dtype(np.float64)
-
-
 class WindVectorSquaredError(base.Statistic):
   """(u_p - u_t)**2 + (v_p - v_t)**2 per (u, v, name) triple (deterministic.py:174-219)."""
 
@@ -115,7 +80,7 @@ class WindVectorSquaredError(base.Statistic):
       se_u = lazy.det_statistic('SquaredError', predictions[u], targets[u])
       se_v = lazy.det_statistic('SquaredError', predictions[v], targets[v])
       if se_u.dims == se_v.dims and se_u.shape == se_v.shape:
-        out[name] = _SumOfStatistics([se_u, se_v])
+        out[name] = lazy.LinearCombination([se_u, se_v])
       else:
         out[name] = se_u + se_v
     return out

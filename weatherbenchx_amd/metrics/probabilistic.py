@@ -3,8 +3,9 @@ weatherbenchX/metrics/probabilistic.py:28-336, 606-688, 864-1003).
 
 Per-point arithmetic lives in csrc/wbx_ens_impl.hpp (one lane owns one grid point's M members in
 VGPRs: sorting-network rank form for `use_sort=True`, pairwise form for `use_sort=False`).
-Not fused yet (raise NotImplementedError): targets that carry the ensemble dim, `which='targets'`,
-`skipna_ensemble=True`.
+`skipna_ensemble=True` and float64 / M > 64 members run on the generic (memory re-reading, fp64 pair form) kernel;
+targets that carry the ensemble dim are handled member by member (CRPSSkill, `which='targets'`).  Only
+UnbiasedEnsembleMeanSquaredError against an ensemble of targets raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -21,11 +22,6 @@ ENSEMBLE_DIM = 'number'
 
 def _sqrt(da):
   return np.sqrt(da)
-
-
-def _no_skipna(flag: bool, who: str):
-  if flag:
-    raise NotImplementedError(f'{who}: skipna_ensemble=True is not fused yet (SURVEY 8f-3)')
 
 
 class EnsembleAveragedStatistic(base.Statistic):
@@ -79,8 +75,16 @@ class CRPSSkill(base.PerVariableStatistic):
     return f'CRPSSkill_{self._ensemble_dim}'
 
   def _compute_per_variable(self, predictions, targets):
-    _no_skipna(self._skipna_ensemble, 'CRPSSkill')
-    return lazy.ens_statistic('CRPSSkill', predictions, targets, self._ensemble_dim)
+    if self._ensemble_dim in targets.dims:
+      # mean over both ensemble dims of |p_i - t_j| (probabilistic.py:134-145) = mean over target members of the
+      # per-member skill: linear, so one fused launch per target member
+      if self._skipna_ensemble:
+        raise NotImplementedError('skipna_ensemble with ensemble-valued targets is not supported')
+      members = lazy.target_members(targets, self._ensemble_dim)
+      terms = [lazy.ens_statistic('CRPSSkill', predictions, tj, self._ensemble_dim) for tj in members]
+      return lazy.LinearCombination(terms, scale=1.0 / len(terms), name=predictions.name)
+    return lazy.ens_statistic('CRPSSkill', predictions, targets, self._ensemble_dim,
+                              skipna_ensemble=self._skipna_ensemble)
 
 
 class CRPSSpread(base.PerVariableStatistic):
@@ -100,19 +104,24 @@ class CRPSSpread(base.PerVariableStatistic):
     return f"CRPSSpread_{self._ensemble_dim}_{'fair' if self._fair else 'unfair'}_{self._which}"
 
   def _compute_per_variable(self, predictions, targets):
-    if self._which == 'targets':
-      raise NotImplementedError("CRPSSpread(which='targets') is not fused yet (SURVEY 8f-3)")
-    if self._which != 'predictions':
+    if self._which == 'predictions':
+      da = predictions
+    elif self._which == 'targets':
+      da = targets
+    else:
       raise ValueError(f'Unhandled {self._which=}')
+    if self._ensemble_dim not in da.dims:
+      raise ValueError(f'Dimension {self._ensemble_dim} not found in {da.dims}')
+    if not self._skipna_ensemble and da.sizes[self._ensemble_dim] < 2:
+      raise ValueError('Cannot estimate CRPS spread with n_ensemble < 2.')
     if self._skipna_ensemble and self._use_sort:
       raise ValueError('skipna_ensemble is not supported with use_sort=True.')
-    _no_skipna(self._skipna_ensemble, 'CRPSSpread')
-    if self._ensemble_dim not in predictions.dims:
-      raise ValueError(f'Dimension {self._ensemble_dim} not found in {predictions.dims}')
-    if predictions.sizes[self._ensemble_dim] < 2:
-      raise ValueError('Cannot estimate CRPS spread with n_ensemble < 2.')
-    return lazy.ens_statistic('CRPSSpread', predictions, targets, self._ensemble_dim, use_sort=self._use_sort,
-                              fair=self._fair)
+    # the spread only looks at `da`; any member-free companion field serves as the kernel's target operand
+    other = targets if self._which == 'predictions' else predictions
+    if self._ensemble_dim in other.dims or self._which == 'targets':
+      other = lazy.target_members(da, self._ensemble_dim)[0]
+    return lazy.ens_statistic('CRPSSpread', da, other, self._ensemble_dim, use_sort=self._use_sort, fair=self._fair,
+                              skipna_ensemble=self._skipna_ensemble)
 
 
 class EnsembleVariance(base.PerVariableStatistic):
@@ -127,8 +136,9 @@ class EnsembleVariance(base.PerVariableStatistic):
     return f'EnsembleVariance_{self._ensemble_dim}_skipna_ensemble_{self._skipna_ensemble}'
 
   def _compute_per_variable(self, predictions, targets):
-    _no_skipna(self._skipna_ensemble, 'EnsembleVariance')
-    return lazy.ens_statistic('EnsembleVariance', predictions, targets, self._ensemble_dim)
+    other = targets if self._ensemble_dim not in targets.dims else lazy.target_members(targets, self._ensemble_dim)[0]
+    return lazy.ens_statistic('EnsembleVariance', predictions, other, self._ensemble_dim,
+                              skipna_ensemble=self._skipna_ensemble)
 
 
 class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
@@ -143,8 +153,13 @@ class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
     return f'UnbiasedEnsembleMeanSquaredError_{self._ensemble_dim}_skipna_ensemble_{self._skipna_ensemble}'
 
   def _compute_per_variable(self, predictions, targets):
-    _no_skipna(self._skipna_ensemble, 'UnbiasedEnsembleMeanSquaredError')
-    return lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim)
+    if self._ensemble_dim not in predictions.dims:
+      raise ValueError(f'Dimension {self._ensemble_dim} not found in {predictions.dims}')
+    if self._ensemble_dim in targets.dims:
+      raise NotImplementedError('UnbiasedEnsembleMeanSquaredError against ensemble-valued targets is not fused yet '
+                                '(SURVEY 8f-3)')
+    return lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim,
+                              skipna_ensemble=self._skipna_ensemble)
 
 
 class CRPSEnsemble(base.PerVariableMetric):
@@ -167,6 +182,32 @@ class CRPSEnsemble(base.PerVariableMetric):
 
   def _values_from_mean_statistics_per_variable(self, statistic_values):
     return statistic_values['CRPSSkill'] - 0.5 * statistic_values['CRPSSpread']
+
+
+class CRPSEnsembleDistance(base.PerVariableMetric):
+  """E|X - Y| - 0.5 E|X - X'| - 0.5 E|Y - Y'| for ensemble-valued predictions AND targets
+  (probabilistic.py:691-782)."""
+
+  def __init__(self, ensemble_dim: str = ENSEMBLE_DIM, use_sort: bool = False, fair: bool = True,
+               skipna_ensemble: bool = False):
+    self._ensemble_dim = ensemble_dim
+    self._use_sort = use_sort
+    self._fair = fair
+    self._skipna_ensemble = skipna_ensemble
+
+  @property
+  def statistics(self) -> Mapping[str, base.Statistic]:
+    return {
+        'CRPSSkill': CRPSSkill(ensemble_dim=self._ensemble_dim),
+        'CRPSSpread': CRPSSpread(ensemble_dim=self._ensemble_dim, use_sort=self._use_sort, fair=self._fair,
+                                 skipna_ensemble=self._skipna_ensemble),
+        'CRPSTargetSpread': CRPSSpread(ensemble_dim=self._ensemble_dim, use_sort=self._use_sort, fair=self._fair,
+                                       which='targets'),
+    }
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return (statistic_values['CRPSSkill'] - 0.5 * statistic_values['CRPSSpread']
+            - 0.5 * statistic_values['CRPSTargetSpread'])
 
 
 class UnbiasedEnsembleMeanRMSE(base.PerVariableMetric):
