@@ -214,6 +214,39 @@ def main():
         'check': {'crps_v0': float(np.asarray(eout['crps.v0'].values).mean())}}
     del pe, te, tv
 
+    # ---- zonal spectra side measurement (configs[3] shape: 37 levels; rocFFT + |F|^2 reduction) ------------------
+    from weatherbenchx_amd import spectra
+    nt_s, nlev_s = (8, 37) if not args.small else (2, 3)
+    sdims = ('lead_time', 'level', 'latitude', 'longitude')
+    scoords = {'latitude': lat, 'longitude': lon}
+    sp_p = {'z': xr.DataArray(randn((nt_s, nlev_s, nlat, nlon), 280.0), dims=sdims, coords=scoords)}
+    sp_t = {'z': xr.DataArray(randn((nt_s, nlev_s, nlat, nlon), 280.0), dims=sdims, coords=scoords)}
+    torch.cuda.synchronize()
+    smetrics = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+    sagg = aggregation.Aggregator(reduce_dims=['lead_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+    def sstep():
+      return aggregation.compute_metric_values_for_single_chunk(smetrics, sagg, fresh(sp_p), fresh(sp_t))
+    for _ in range(3):
+      sout = sstep()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      sout = sstep()
+    sync()
+    s_ms = (time.perf_counter() - t0) / args.steps * 1e3
+    spoints = nt_s * nlev_s * nlat * nlon
+    parseval = float(np.asarray(sout['spectrum_p.z'].values)[0].sum())
+    result['spectrum'] = {
+        'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{nlat},{nlon}] each, area-weighted '
+                    'mean over (lead_time, latitude); batched R2C rocFFT + fp64 |F|^2 reduction; parity unpinned '
+                    '(no reference implementation, SURVEY F3)',
+        'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms,
+        'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
+        'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
+    del sp_p, sp_t
+
   # ---- CPU baseline (rank 0, N=1): oracle's reference-structure NumPy path on a bounded sample -------------
   if not args.no_cpu and world == 1 and rank == 0:
     from oracle import wbx_oracle as O

@@ -168,7 +168,7 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
 
 
-def _run_spectrum(field, lon_dim, group, scale, ngroup):
+def _run_spectrum(field, lon_dim, group, scale, ngroup, cache=None):
   """NumPy stand-in for wbx_zonal_spectrum (rows = non-longitude dims in the field's own order)."""
   vals = np.asarray(field.values)
   if vals.dtype != np.float32:

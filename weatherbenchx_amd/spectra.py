@@ -24,63 +24,82 @@ from weatherbenchx_amd.metrics import base
 EARTH_RADIUS_M = 6371.0e3
 
 
-def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: np.ndarray, ngroup: int) -> np.ndarray:
-  """power[ngroup][nk]; rows = all non-longitude dims in the field's own order."""
+class _BatchGeometry:
+  """How the rows of a field (all dims but longitude) map onto uniformly strided rocFFT batches."""
+
+  def __init__(self, dims, sizes_by_dim, layout, lon_dim):
+    row_dims = [d for d in dims if d != lon_dim]
+    sizes = [sizes_by_dim[d] for d in row_dims]
+    strides = [layout.stride(d) for d in row_dims]
+    self.lon_stride = layout.stride(lon_dim)
+    order = np.argsort(strides)[::-1] if row_dims else []
+    # the largest suffix (in stride order) that nests uniformly: stride[i] == stride[i+1] * size[i+1]
+    inner = []
+    for idx in order[::-1]:
+      if not inner or strides[idx] == strides[inner[-1]] * sizes[inner[-1]]:
+        inner.append(idx)
+      else:
+        break
+    inner_set = set(inner)
+    outer = [i for i in range(len(row_dims)) if i not in inner_set]
+    self.batch = int(np.prod([sizes[i] for i in inner], dtype=np.int64)) if inner else 1
+    self.row_stride = strides[inner[0]] if inner else 1
+    nrows = int(np.prod(sizes, dtype=np.int64)) if sizes else 1
+    row_index = np.arange(nrows, dtype=np.int64).reshape(sizes or [1])
+    perm = outer + sorted(inner, key=lambda i: -strides[i])
+    self.row_index = np.transpose(row_index, perm).reshape(-1, self.batch) if row_dims else row_index.reshape(1, 1)
+    off = np.zeros((), dtype=np.int64)
+    for i in outer:
+      off = off[..., None] + np.arange(sizes[i], dtype=np.int64) * strides[i]
+    self.outer_offsets = np.asarray(off).reshape(-1)
+    # rows walked in C order by every slab?  then group/scale can be addressed by pointer offset
+    self.c_order = all(bool(np.all(np.diff(r) == 1)) for r in self.row_index) if self.batch > 1 else True
+    self.permutation = None if self.c_order else self.row_index.reshape(-1)
+
+
+_geometry_cache: dict = {}
+
+
+def _geometry(field: xr.DataArray, layout, lon_dim) -> _BatchGeometry:
+  key = (field.dims, field.shape, tuple(sorted(layout.strides.items(), key=str)), lon_dim)
+  if key not in _geometry_cache:
+    if len(_geometry_cache) > 32:
+      _geometry_cache.clear()
+    _geometry_cache[key] = _BatchGeometry(field.dims, field.sizes, layout, lon_dim)
+  return _geometry_cache[key]
+
+
+def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: np.ndarray, ngroup: int,
+                  cache: dict | None = None) -> np.ndarray:
+  """power[ngroup][nk]; rows = all non-longitude dims in the field's own order.  `cache` (owned by the caller,
+  e.g. the aggregator's weight object) keeps the uploaded group/scale arrays between chunks."""
   ctx = _hip.default_context()
   data = field.data
   engine._sync_torch_producers([data])  # pylint: disable=protected-access
-  dev = engine._to_device(ctx, field, _hip.F32)  # pylint: disable=protected-access
   if engine._common_dtype([data]) != _hip.F32:  # pylint: disable=protected-access
     raise TypeError('zonal spectra take float32 fields (rocFFT single precision); cast the input')
+  dev = engine._to_device(ctx, field, _hip.F32)  # pylint: disable=protected-access
   nlon = field.sizes[lon_dim]
   nk = nlon // 2 + 1
-  row_dims = [d for d in field.dims if d != lon_dim]
-  lon_stride = dev.layout.stride(lon_dim)
-  # rows must form ONE uniformly strided batch for rocFFT: collapse the row dims if their strides nest,
-  # otherwise loop over the outer dims.
-  sizes = [field.sizes[d] for d in row_dims]
-  strides = [dev.layout.stride(d) for d in row_dims]
-  order = np.argsort(strides)[::-1] if row_dims else []
-  # find the largest suffix (in stride order) that is uniformly nested: stride[i] == stride[i+1] * size[i+1]
-  inner = []
-  for idx in order[::-1]:
-    if not inner or strides[idx] == strides[inner[-1]] * sizes[inner[-1]]:
-      inner.append(idx)
-    else:
-      break
-  inner_set = set(inner)
-  outer = [i for i in range(len(row_dims)) if i not in inner_set]
-  batch = int(np.prod([sizes[i] for i in inner], dtype=np.int64)) if inner else 1
-  row_stride = strides[inner[0]] if inner else 1
-  g_dev = ctx.upload(np.ascontiguousarray(group, dtype=np.int32))
-  s_dev = ctx.upload(np.ascontiguousarray(scale, dtype=np.float64))
-  out = ctx.alloc(max(ngroup * nk, 1) * 8)
-  # row index (C order over row_dims) of each (outer combo, inner position)
-  row_index = np.arange(int(np.prod(sizes, dtype=np.int64)) if sizes else 1, dtype=np.int64).reshape(sizes or [1])
-  inner_by_stride_desc = sorted(inner, key=lambda i: -strides[i])
-  perm = outer + inner_by_stride_desc
-  row_index = np.transpose(row_index, perm).reshape(-1, batch) if row_dims else row_index.reshape(1, 1)
-  outer_offsets = np.zeros((), dtype=np.int64)
-  for i in outer:
-    outer_offsets = outer_offsets[..., None] + np.arange(sizes[i], dtype=np.int64) * strides[i]
-  outer_offsets = np.asarray(outer_offsets).reshape(-1)
-  first = True
-  for o, base_off in enumerate(outer_offsets):
-    rows = row_index[o]
-    contiguous_rows = bool(np.all(np.diff(rows) == 1)) if rows.size > 1 else True
-    if contiguous_rows:
-      g_ptr, s_ptr = g_dev.ptr + 4 * int(rows[0]), s_dev.ptr + 8 * int(rows[0])
-      keep = None
-    else:  # the batch walks the rows in another order than C order: permute group/scale for this slab
-      keep = (ctx.upload(np.ascontiguousarray(group[rows], dtype=np.int32)),
-              ctx.upload(np.ascontiguousarray(scale[rows], dtype=np.float64)))
-      g_ptr, s_ptr = keep[0].ptr, keep[1].ptr
-    _hip.check(ctx.lib.wbx_zonal_spectrum(ctx.handle, C.c_void_p(dev.ptr + 4 * int(base_off)), int(lon_stride),
-                                          int(row_stride), int(batch), int(nlon), C.c_void_p(g_ptr), C.c_void_p(s_ptr),
-                                          int(ngroup), 0 if first else 1, C.c_void_p(out.ptr)), 'wbx_zonal_spectrum')
-    first = False
-    if keep is not None:
-      ctx.synchronize()
+  geo = _geometry(field, dev.layout, lon_dim)
+  ckey = (id(geo), ngroup)
+  bufs = cache.get(ckey) if cache is not None else None
+  if bufs is None:
+    g = np.ascontiguousarray(group, dtype=np.int32)
+    sc = np.ascontiguousarray(scale, dtype=np.float64)
+    if geo.permutation is not None:  # slabs walk the rows in another order than C order
+      g, sc = g[geo.permutation], sc[geo.permutation]
+    bufs = (ctx.upload(g), ctx.upload(sc), geo)
+    if cache is not None:
+      cache[ckey] = bufs
+  g_dev, s_dev = bufs[0], bufs[1]
+  out = engine._scratch(ctx, 'spectrum', max(ngroup * nk, 1) * 8)  # pylint: disable=protected-access
+  for o, base_off in enumerate(geo.outer_offsets):
+    first_row = int(geo.row_index[o][0]) if geo.permutation is None else o * geo.batch
+    _hip.check(ctx.lib.wbx_zonal_spectrum(ctx.handle, C.c_void_p(dev.ptr + 4 * int(base_off)), int(geo.lon_stride),
+                                          int(geo.row_stride), int(geo.batch), int(nlon),
+                                          C.c_void_p(g_dev.ptr + 4 * first_row), C.c_void_p(s_dev.ptr + 8 * first_row),
+                                          int(ngroup), 0 if o == 0 else 1, C.c_void_p(out.ptr)), 'wbx_zonal_spectrum')
   return ctx.download(out.ptr, (ngroup, nk), np.float64)
 
 
@@ -122,20 +141,28 @@ class LazySpectrum(xr.DataArray):
     """sum over the non-kept row dims of weight * spectrum -> array over (kept_dims..., k)."""
     row_dims = [d for d in self._source.dims if d != self._lon_dim]
     sizes = {d: self._source.sizes[d] for d in row_dims}
-    shape = [sizes[d] for d in row_dims]
-    w = (row_weight * self.row_scale()).astype(np.float64)
-    scale = np.broadcast_to(xr._bcast_data(w, row_dims, sizes), shape).reshape(-1)  # pylint: disable=protected-access
     kept = [d for d in row_dims if d in kept_dims]
-    g = np.zeros((), dtype=np.int64)
-    mult = 1
-    mults = {}
-    for d in reversed(kept):
-      mults[d] = mult
-      mult *= sizes[d]
-    for d in row_dims:
-      g = g[..., None] + np.arange(sizes[d], dtype=np.int64) * mults.get(d, 0)
-    group = np.broadcast_to(g, shape).reshape(-1)
-    out = _run_spectrum(self._source, self._lon_dim, group, scale, int(mult))
+    ngroup = int(np.prod([sizes[d] for d in kept], dtype=np.int64)) if kept else 1
+    # group / scale per row are data independent: built once per (weight object, frame) and kept on the device
+    store = row_weight.__dict__.setdefault('_wbx_spectrum', {})
+    fkey = (tuple(row_dims), tuple(sizes[d] for d in row_dims), tuple(kept), self._circumference)
+    entry = store.get(fkey)
+    if entry is None:
+      shape = [sizes[d] for d in row_dims]
+      w = (row_weight * self.row_scale()).astype(np.float64)
+      scale = np.broadcast_to(xr._bcast_data(w, row_dims, sizes), shape).reshape(-1)  # pylint: disable=protected-access
+      g = np.zeros((), dtype=np.int64)
+      mult, mults = 1, {}
+      for d in reversed(kept):
+        mults[d] = mult
+        mult *= sizes[d]
+      for d in row_dims:
+        g = g[..., None] + np.arange(sizes[d], dtype=np.int64) * mults.get(d, 0)
+      entry = {'group': np.broadcast_to(g, shape).reshape(-1), 'scale': scale, 'dev': {}}
+      if len(store) > 8:
+        store.clear()
+      store[fkey] = entry
+    out = _run_spectrum(self._source, self._lon_dim, entry['group'], entry['scale'], ngroup, cache=entry['dev'])
     return out.reshape([sizes[d] for d in kept] + [self._nk]), tuple(kept) + (self._k_dim,)
 
   @property
