@@ -12,7 +12,7 @@ value    = (points per step x 6 metrics x N) / wall time per step (max over rank
 roofline = algorithmic bytes (12 B/point: p, t, c read once) / mean stage-1 kernel duration (HIP events on the
            launch stream, separate pass), against 8.0 TB/s
 cpu_baseline = the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
-           statistics; oracle/wbx_oracle.py) on a 2 init x 2 lead sample, rank 0, N=1 only.
+           statistics; oracle/wbx_oracle.py) on a 10 init x 5 lead sample (~4 s), rank 0, N=1 only.
 """
 import argparse
 import json
@@ -145,8 +145,13 @@ def main():
   k_ms = float(np.mean([e['ms'] for e in log]))
   alg_bytes = points * 12
   achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-  roofline = {'bound': 'hbm', 'kernel': 's1_xr_kernel<DetOp<float,DET6>,4>' if log[0]['vec'] == 4 and not log[0]['x_kept']
-              else ('s1_xk_kernel<DetOp<float,DET6>>' if log[0]['x_kept'] else 's1_xr_kernel<DetOp<float,DET6>,1>'),
+  if log[0].get('plane_rows'):
+    kname = f"s1_xp_kernel<DetOp<float,DET6>> (LDS plane mode, R={log[0]['plane_rows']})"
+  elif log[0]['x_kept']:
+    kname = f"s1_xk_kernel<DetOp<float,DET6>,{log[0]['vec']}>"
+  else:
+    kname = f"s1_xr_kernel<DetOp<float,DET6>,{log[0]['vec']}>"
+  roofline = {'bound': 'hbm', 'kernel': kname,
               'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
               'kernel_ms': round(k_ms, 4), 'algorithmic_bytes_per_launch': alg_bytes, 'traffic': None}
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 1
+#define WBX_ABI_VERSION 2
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -114,6 +114,11 @@ typedef struct wbx_s1_plan {
   uint32_t flags;        /* WBX_FLAG_* */
   int32_t block_threads; /* 64, 128 or 256 */
   int32_t vec;           /* 1 or 4: x elements per lane per load (4 needs 16-B alignment of every row) */
+  int32_t plane_rows;    /* 0, or R > 0 ("plane mode", x kept, deterministic families, fp32): every group of R consecutive
+                            depth rows starting at a multiple of R is ONE contiguous span of R*nx elements in every input
+                            (latitude-fastest chunks: rows = longitudes). The span is fetched with aligned 16-B loads
+                            through LDS instead of ragged per-row dword loads. depth_chunk must be a multiple of R. */
+  int32_t reserved_;
 } wbx_s1_plan;
 
 /* number of fp64 values stage 1 writes:

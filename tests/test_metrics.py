@@ -465,3 +465,47 @@ def test_unbiased_mse_rejects_ensemble_targets(backend):
   with pytest.raises(ValueError, match='Failed to compute statistic') as info:
     metrics_base.compute_unique_statistics_for_all_metrics({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, p, p)
   assert isinstance(info.value.__cause__, NotImplementedError)
+
+
+@pytest.mark.parametrize('nlon,expect_rows', [(24, 8), (25, 5), (29, 0)])
+def test_latitude_fastest_plane_mode_matches_oracle(backend, nlon, expect_rows):
+  """Latitude-fastest chunks with >= 64 latitudes take the LDS 'plane mode' kernel (aligned 16-B loads of R-row
+  spans) when R divides the number of longitudes; results must equal the oracle exactly like the generic path."""
+  from weatherbenchx_amd import engine, planner
+  rng = np.random.default_rng(12)
+  nlat = 91
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * (360.0 / nlon)
+  dims = ('init_time', 'lead_time', 'level', 'longitude', 'latitude')
+  shape = (3, 2, 2, nlon, nlat)
+  coords = {'latitude': lat, 'longitude': lon, 'level': np.array([500, 850]),
+            'init_time': np.array(['2020-01-01T00', '2020-01-02T00', '2020-01-03T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(2) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  p = xr.DataArray((rng.normal(size=shape) + 280).astype(np.float32), dims=dims, coords=coords)
+  t = xr.DataArray((rng.normal(size=shape) + 280).astype(np.float32), dims=dims, coords=coords)
+  cdims = ('dayofyear', 'hour', 'level', 'longitude', 'latitude')
+  cv = (rng.normal(size=(5, 4, 2, nlon, nlat)) * 10 + 280).astype(np.float32)
+  clim = xr.Dataset({'z': xr.DataArray(cv, dims=cdims, coords={'dayofyear': np.arange(1, 6), 'hour': np.array([0, 6, 12, 18]),
+                                                               'level': coords['level'], 'longitude': lon, 'latitude': lat})})
+  metrics = {'acc': deterministic.ACC(clim), 'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'z': p}, {'z': t})
+  vt = coords['init_time'][:, None] + coords['lead_time'][None, :]
+  c, cd = O.align_climatology(cv, cdims, vt, ('init_time', 'lead_time'))
+  c = O.expand_to(c, cd, dims)
+  w = (O.grid_area_weights(lat), ('latitude',))
+
+  def mean(a):
+    sws, sw, od = O.aggregate(a, dims, ['init_time', 'latitude', 'longitude'], weights=[w])
+    return sws / sw
+  np.testing.assert_allclose(res['rmse.z'].values, np.sqrt(mean(O.squared_error(p.values, t.values))), rtol=RTOL)
+  np.testing.assert_allclose(res['bias.z'].values, mean(O.error(p.values, t.values)), rtol=RTOL, atol=1e-9)
+  want = O.acc(mean(O.anomaly_covariance(p.values, t.values, c)), mean(O.squared_prediction_anomaly(p.values, c)),
+               mean(O.squared_target_anomaly(t.values, c)))
+  np.testing.assert_allclose(res['acc.z'].values, want, rtol=RTOL)
+  # the planner really chose (or rejected) plane mode
+  lays = [planner.InputLayout(strides=dict(zip(dims, [int(s // 4) for s in a.values.strides])), itemsize=4,
+                              base_alignment=256) for a in (p, t)]
+  plan = planner.build_s1_plan(dims, dict(zip(dims, shape)), lays, ['init_time', 'latitude', 'longitude'],
+                               wdep_dims=['latitude'])
+  assert plan.x_dim == 'latitude' and plan.x_kept and plan.plane_rows == expect_rows
+  assert plan.depth_chunk % max(plan.plane_rows, 1) == 0

@@ -13,6 +13,8 @@
 //
 // All arithmetic is fp64 on the widened inputs, so results follow the reference evaluated
 // on float64-cast inputs to summation-order round-off.
+#include <type_traits>
+
 #include "wbx_s1.hpp"
 
 namespace wbx {
@@ -119,6 +121,18 @@ struct DetOp {
 template <typename T, int FUNC>
 static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   const bool mm = plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA);
+  if (plan->plane_rows > 0) {
+    if constexpr (std::is_same<T, float>::value) {
+      WBX_REQUIRE(!mm, "plane mode does not take mask/skipna flags");
+      for (int i = 0; i < DetOp<T, FUNC, false>::NIN; ++i)
+        WBX_REQUIRE(plan->xstride[i] == 1 && (((uintptr_t)a.in[i]) & 15) == 0,
+                    "plane mode needs unit x stride and 16-byte aligned inputs");
+      if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);
+      return launch_plane<DetOp<T, FUNC, false>>(ctx, plan, a);
+    } else {
+      return fail(WBX_ERR_INVALID, "plane mode is fp32 only");
+    }
+  }
   if (mm) return launch_partial<DetOp<T, FUNC, true>, 1>(ctx, plan, a);
   if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, false>, 4>(ctx, plan, a);
   return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);

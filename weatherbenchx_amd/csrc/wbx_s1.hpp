@@ -151,6 +151,130 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xk_kernel(S1Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// x kept, "plane mode": latitude-fastest chunks (real WeatherBench data) have rows of nx = 721 floats,
+// so per-row loads can never be 16-B aligned.  But consecutive depth rows (longitudes) are adjacent in memory: a
+// group of R rows is one contiguous span of R*nx floats.  The block fetches that span with ALIGNED dwordx4 loads
+// (span start rounded down to 16 B, next group prefetched into registers while this one is reduced), parks it in
+// LDS, and every lane then reads its own x column from LDS (consecutive lanes -> consecutive banks, conflict free).
+// grid = nkey * nchunk, block = round_up(nx, 64) threads, dynamic LDS = NIN * (R*nx + 8) floats.
+template <class Op>
+__global__ void __launch_bounds__(1024, 6) s1_xp_kernel(S1Args a, int R) {  // <= 80 VGPRs: two 768-thread blocks per CU
+  constexpr int NA = Op::NACC;
+  constexpr int NIN = Op::NIN;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  const int T = blockDim.x;
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t key = b / a.nchunk;
+  const int chunk = (int)(b - key * a.nchunk);
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+  const int nx = (int)a.nx;
+  const int slot = R * nx + 8;  // floats per input in LDS (span + alignment slack)
+  const int nvec = (R * nx + 3 + 3) / 4;  // float4s that cover any span of R*nx floats with a lead of <= 3
+  constexpr int MAXV = 2;  // float4s per thread per input (host guarantees nvec <= MAXV * T)
+
+  int64_t kb[WBX_MAX_INPUTS];
+  key_bases<NIN>(a, key, kb);
+  double acc[NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) acc[l] = 0.0;
+
+  float4 regs[NIN][MAXV];
+  int lead[NIN], lead_next[NIN];
+
+  auto prefetch = [&](int64_t d, int (&ld)[NIN]) {
+    int64_t ro[WBX_MAX_INPUTS];
+    row_bases<NIN>(a, kb, key, d, ro);
+    const int rows = (int)(d1 - d < R ? d1 - d : R);
+    const int n = rows * nx;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const float* base = reinterpret_cast<const float*>(a.in[i]);
+      const int64_t start = ro[i];
+      const int64_t a0 = start & ~(int64_t)3;
+      ld[i] = (int)(start - a0);
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int k = tid + v * T;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < nvec) {
+          const int e0 = 4 * k;  // first element of this float4, relative to a0
+          if (e0 + 3 < ld[i] + n) {
+            q = *reinterpret_cast<const float4*>(base + a0 + e0);  // fully inside [a0, span end): aligned 16-B load
+          } else if (e0 < ld[i] + n) {  // straddles the span end: never read past the last element
+            float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < 4; ++c)
+              if (e0 + c < ld[i] + n) tmp[c] = base[a0 + e0 + c];
+            q = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+          }
+        }
+        regs[i][v] = q;
+      }
+    }
+  };
+
+  if (d0 < d1) prefetch(d0, lead);
+  for (int64_t d = d0; d < d1; d += R) {
+    // registers -> LDS
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int k = tid + v * T;
+        if (k < nvec) *reinterpret_cast<float4*>(lds_raw + i * slot + 4 * k) = regs[i][v];
+      }
+    int cur_lead[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) cur_lead[i] = lead[i];
+    __syncthreads();
+    if (d + R < d1) {  // next group's loads fly while this group is reduced
+      prefetch(d + R, lead_next);
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) lead[i] = lead_next[i];
+    }
+    if (tid < nx) {
+      const int rows = (int)(d1 - d < R ? d1 - d : R);
+      for (int r = 0; r < rows; ++r) {
+        const float pv = lds_raw[0 * slot + cur_lead[0] + r * nx + tid];
+        const float tv = NIN > 1 ? lds_raw[1 * slot + cur_lead[NIN > 1 ? 1 : 0] + r * nx + tid] : 0.f;
+        const float cv = NIN > 2 ? lds_raw[2 * slot + cur_lead[NIN > 2 ? 2 : 0] + r * nx + tid] : 0.f;
+        double val[Op::NLANE];
+        Op::lanes((double)pv, (double)tv, (double)cv, val);
+#pragma unroll
+        for (int l = 0; l < Op::NLANE; ++l) acc[l] += val[l];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < nx) {
+    double* o = a.out + ((key * a.nchunk + chunk) * NA) * a.nx + tid;
+#pragma unroll
+    for (int l = 0; l < NA; ++l) o[(int64_t)l * a.nx] = acc[l];
+  }
+}
+
+template <class Op>
+int launch_plane(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  const int R = plan->plane_rows;
+  const int threads = (int)((plan->nx + 63) / 64) * 64;
+  WBX_REQUIRE(plan->x_kept && R > 0 && threads <= 1024, "plane mode needs x kept and nx <= 1024");
+  WBX_REQUIRE(plan->depth_chunk % R == 0 || plan->nchunk == 1, "plane mode needs depth_chunk %% plane_rows == 0");
+  const int nvec = (int)((R * plan->nx + 6) / 4);
+  WBX_REQUIRE(nvec <= 2 * threads, "plane_rows too large for the block (R*nx/4 > 2*threads)");
+  const size_t lds = (size_t)Op::NIN * (size_t)(R * plan->nx + 8) * sizeof(float);
+  WBX_REQUIRE(lds <= 80 * 1024, "plane mode LDS footprint %zu exceeds 80 KiB (two blocks per CU)", lds);
+  if (lds > 48 * 1024)
+    WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s1_xp_kernel<Op>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int64_t grid = plan->nkey * plan->nchunk;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+  hipLaunchKernelGGL((s1_xp_kernel<Op>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, a, R);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // materialise one lane: out[key][d][x].  grid = nkey * D * nxtile.
 template <class Op>
 __global__ void __launch_bounds__(256) s1_map_kernel(S1Args a) {

@@ -104,6 +104,7 @@ class _PlanOnDevice:
     s.flags = plan.flags
     s.block_threads = plan.block_threads
     s.vec = plan.vec
+    s.plane_rows = plan.plane_rows
     self.struct = s
 
   def _up(self, ctx, tab):
@@ -120,7 +121,7 @@ def _plan_signature(plan: planner.S1Plan):
   return (plan.dims, tuple(plan.sizes.items()), plan.x_dim, plan.x_kept, plan.a_dims, plan.bk_dims, plan.br_dims,
           plan.depth_dims, plan.nchunk, plan.depth_chunk, tuple(plan.xstride), tuple(h(t) for t in plan.key_off),
           tuple(h(t) for t in plan.depth_off), h(plan.gather_key), h(plan.gather_depth), h(plan.gather_tab),
-          plan.flags, plan.block_threads, plan.vec)
+          plan.flags, plan.block_threads, plan.vec, plan.plane_rows)
 
 
 _plan_cache: dict = {}
@@ -255,7 +256,8 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
                                          int(algo), ptr(devs[0]), ptr(devs[1]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop() / reps, 'reps': reps, 'vec': plan.vec,
-                         'x_kept': plan.x_kept, 'grid': plan.nkey * plan.nchunk, 'block': plan.block_threads})
+                         'x_kept': plan.x_kept, 'plane_rows': plan.plane_rows, 'grid': plan.nkey * plan.nchunk,
+                         'block': plan.block_threads})
   return out
 
 

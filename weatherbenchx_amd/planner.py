@@ -68,6 +68,7 @@ class S1Plan:
   flags: int
   block_threads: int
   vec: int
+  plane_rows: int = 0
 
   @property
   def nj(self) -> int:
@@ -226,7 +227,32 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
     if ok:
       vec = 4
 
-  return S1Plan(dims=dims, sizes=sizes, x_dim=x_dim, x_kept=bool(x_kept), sum_j=bool(sum_j), a_dims=a_dims,
+  # "plane mode" for x-kept fp32 reductions whose rows cannot be 16-B aligned (latitude-fastest chunks, nx = 721):
+  # groups of R consecutive depth rows are one contiguous span, fetched with aligned loads through LDS.
+  plane_rows = 0
+  if (allow_vec4 and x_kept and not map_mode and not (flags & 3) and vec == 1 and x_dim is not None
+      and depth_dims and 64 <= nx <= 1024):
+    inner = depth_dims[-1]
+    used = [lay for lay in layouts[:3] if lay is not None]
+    ok = all(lay.itemsize == 4 and lay.base_alignment % 16 == 0 and lay.stride(x_dim) == 1
+             and lay.stride(inner) == nx for lay in used)
+    if gather is not None and inner in gather.dims:
+      ok = False
+    if ok:
+      threads = -(-nx // 64) * 64
+      for r in (8, 6, 5, 4, 3, 2):
+        lds = len(used) * (r * nx + 8) * 4
+        if sizes[inner] % r == 0 and lds <= 80 * 1024 and (r * nx + 6) // 4 <= 2 * threads:
+          plane_rows = r
+          break
+    if plane_rows:
+      # one block per (key, chunk) covers every x: re-balance the chunking, chunk = multiple of R rows
+      nchunk = int(min(max(ndepth // plane_rows, 1), max(1, -(-target_blocks // max(nkey, 1)))))
+      depth_chunk = -(-ndepth // nchunk)
+      depth_chunk = -(-depth_chunk // plane_rows) * plane_rows
+      nchunk = -(-ndepth // depth_chunk)
+
+  return S1Plan(plane_rows=int(plane_rows), dims=dims, sizes=sizes, x_dim=x_dim, x_kept=bool(x_kept), sum_j=bool(sum_j), a_dims=a_dims,
                 bk_dims=bk_dims, br_dims=br_dims, depth_dims=depth_dims, nkey=nkey, ndepth=ndepth, nx=nx,
                 nchunk=int(nchunk), depth_chunk=int(depth_chunk), xstride=[int(v) for v in xstride[:MAX_INPUTS]],
                 key_off=key_off[:MAX_INPUTS], depth_off=depth_off[:MAX_INPUTS], gather_key=gk, gather_depth=gd,
