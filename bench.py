@@ -155,6 +155,19 @@ def main():
               'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
               'kernel_ms': round(k_ms, 4), 'algorithmic_bytes_per_launch': alg_bytes, 'traffic': None}
 
+  # HBM traffic per launch from the separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on gfx950,
+  # + WRITE_SIZE), committed under profiles/ -- PMC collection cannot run inside the timed process.
+  def pmc_traffic(kernel_key):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files or args.small or (ni, nl, nlev) != (40, 10, 5):
+      return None
+    table = json.load(open(files[-1]))
+    entry = table.get(kernel_key.split(' (')[0])
+    return None if not entry else entry.get('traffic_bytes_per_launch')
+  roofline['traffic'] = pmc_traffic(kname)
+  roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+
   result = {
       'metric': 'grid-point·metric evals/s (area-weighted RMSE/MSE/MAE/bias/ACC/activity, 0.25deg 721x1440)',
       'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -215,7 +228,8 @@ def main():
         'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
         'roofline': {'bound': 'hbm', 'kernel': 's1_xr_kernel<EnsOpF32<51,true,SORT>,1>', 'achieved': round(e_ach, 1),
                      'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(e_ach / HBM_PEAK_GBS, 4),
-                     'kernel_ms': round(ek_ms, 4), 'algorithmic_bytes_per_launch': e_bytes, 'traffic': None},
+                     'kernel_ms': round(ek_ms, 4), 'algorithmic_bytes_per_launch': e_bytes,
+                     'traffic': pmc_traffic('s1_xr_kernel<EnsOpF32<51,true,SORT>,1>') if ns == 8 else None},
         'check': {'crps_v0': float(np.asarray(eout['crps.v0'].values).mean())}}
     del pe, te, tv
 

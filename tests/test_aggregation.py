@@ -25,12 +25,7 @@ def _aggregate(metrics, predictions, targets, **kw):
   return aggregation.Aggregator(**kw).aggregate_statistics(stats)
 
 
-def add_nan_mask(data):
-  """data_loaders/base.py:25-56: boolean `mask` coordinate, True = valid."""
-  data = dict(data)
-  for var in data:
-    data[var].coords['mask'] = ~np.isnan(data[var])
-  return data
+from weatherbenchx_amd.data import add_nan_mask_to_data as add_nan_mask  # data_loaders/base.py:25-56
 
 
 def test_expected_output(backend):

@@ -41,16 +41,33 @@ __global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed
     double acc[BG];
 #pragma unroll
     for (int g = 0; g < BG; ++g) acc[g] = 0.0;
-    for (int64_t c = threadIdx.x; c < ncontr; c += blockDim.x) {
-      const int64_t br = c / ncj;
-      const int64_t r = c - br * ncj;
-      const int64_t ch = r / njc;
-      const int64_t j = fixed_j ? jf : r - ch * njc;
-      const double v = pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
-      const double* w = wbase + (br * p.nj + j) * p.nbin + b0;
+    if (!fixed_j && p.nj >= 64) {
+      // long rows (x kept in stage 1, summed here): lanes walk j, rows/chunks are plain loops -- no 64-bit divides
+      for (int64_t br = 0; br < p.nBr; ++br) {
+        const double* wrow = wbase + br * p.nj * p.nbin + b0;
+        for (int64_t ch = 0; ch < p.nchunk; ++ch) {
+          const double* prow = pbase + ((br * p.nchunk + ch) * p.nlane + lane) * p.nj;
+          for (int64_t j = threadIdx.x; j < p.nj; j += blockDim.x) {
+            const double v = prow[j];
+            const double* w = wrow + j * p.nbin;
 #pragma unroll
-      for (int g = 0; g < BG; ++g)
-        if (b0 + g < p.nbin) acc[g] += v * w[g];
+            for (int g = 0; g < BG; ++g)
+              if (b0 + g < p.nbin) acc[g] += v * w[g];
+          }
+        }
+      }
+    } else {
+      for (int64_t c = threadIdx.x; c < ncontr; c += blockDim.x) {
+        const int64_t br = c / ncj;
+        const int64_t r = c - br * ncj;
+        const int64_t ch = r / njc;
+        const int64_t j = fixed_j ? jf : r - ch * njc;
+        const double v = pbase[((br * p.nchunk + ch) * p.nlane + lane) * p.nj + j];
+        const double* w = wbase + (br * p.nj + j) * p.nbin + b0;
+#pragma unroll
+        for (int g = 0; g < BG; ++g)
+          if (b0 + g < p.nbin) acc[g] += v * w[g];
+      }
     }
 #pragma unroll
     for (int g = 0; g < BG; ++g) {
