@@ -229,3 +229,58 @@ def test_oracle_parity_on_a_full_grid_slice(ctx):
                                                          agg, p0, t)
   np.testing.assert_allclose(r['rmse.v'].values, np.sqrt(mean(O.squared_error(pv[0], tv))), rtol=RTOL)
   np.testing.assert_allclose(r['bias.v'].values, mean(O.error(pv[0], tv)), rtol=RTOL, atol=1e-9)
+
+
+# ---- device-resident torch inputs with non-trivial strides (views are consumed in place, never copied) ------------
+def _np(t):
+  return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('case', ['permuted', 'strided_slices', 'broadcast_target', 'member_fast_view'])
+def test_torch_views_are_consumed_in_place(ctx, case):
+  import torch
+  g = torch.Generator(device='cuda')
+  g.manual_seed(5)
+  lat, lon = np.linspace(-80, 80, 17), np.arange(40) * 9.0
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  w = (O.grid_area_weights(lat), ('latitude',))
+  if case == 'member_fast_view':
+    base = torch.randn((3, 17, 40, 9), generator=g, device='cuda') + 280          # members fastest in memory
+    pt = base.permute(3, 0, 1, 2)[1:8]                                             # -> (number=7, time, lat, lon) view
+    tt = torch.randn((3, 17, 40), generator=g, device='cuda') + 280
+    assert not pt.is_contiguous()
+    p = {'v': xr.DataArray(pt, dims=('number', 'time', 'latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})}
+    t = {'v': xr.DataArray(tt, dims=('time', 'latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})}
+    res = aggregation.compute_metric_values_for_single_chunk({'crps': probabilistic.CRPSEnsemble(use_sort=True)}, agg, p, t)
+    pd, td = ('number', 'time', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+    skill = O.crps_skill(_np(pt), pd, _np(tt), td, 'number')[0]
+    spread = O.crps_spread(_np(pt), pd, 'number', use_sort=True)[0]
+    a = O.aggregate(skill, td, ['latitude', 'longitude'], weights=[w])
+    b = O.aggregate(spread, td, ['latitude', 'longitude'], weights=[w])
+    np.testing.assert_allclose(res['crps.v'].values, O.crps(a[0] / a[1], b[0] / b[1]), rtol=RTOL)
+    return
+  if case == 'permuted':
+    base_p = torch.randn((40, 3, 17), generator=g, device='cuda') + 280            # (lon, time, lat) in memory
+    base_t = torch.randn((17, 40, 3), generator=g, device='cuda') + 280            # (lat, lon, time) in memory
+    pt, tt = base_p.permute(1, 2, 0), base_t.permute(2, 0, 1)                      # both viewed as (time, lat, lon)
+  elif case == 'strided_slices':
+    pt = (torch.randn((6, 34, 83), generator=g, device='cuda') + 280)[::2, ::2, 3::2]
+    tt = (torch.randn((3, 17, 120), generator=g, device='cuda') + 280)[:, :, ::3]
+  else:  # target without a time dim, broadcast along it
+    pt = torch.randn((3, 17, 40), generator=g, device='cuda') + 280
+    tt = torch.randn((17, 40), generator=g, device='cuda') + 280
+  assert pt.shape == (3, 17, 40)
+  tdims = ('time', 'latitude', 'longitude') if tt.dim() == 3 else ('latitude', 'longitude')
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'v': xr.DataArray(pt, dims=('time', 'latitude', 'longitude'), coords=coords)}
+  t = {'v': xr.DataArray(tt, dims=tdims, coords=coords)}
+  res = aggregation.compute_metric_values_for_single_chunk({'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()},
+                                                           agg, p, t)
+  dims = ('time', 'latitude', 'longitude')
+  te = O.expand_to(_np(tt), tdims, dims)
+  for name, fn, post in (('rmse', O.squared_error, np.sqrt), ('bias', O.error, lambda v: v)):
+    sws, sw, _ = O.aggregate(fn(_np(pt), te), dims, ['latitude', 'longitude'], weights=[w])
+    np.testing.assert_allclose(res[f'{name}.v'].values, post(sws / sw), rtol=RTOL, atol=1e-9)
+  # and the per-point statistic through the map kernel
+  se = deterministic.SquaredError().compute(p, t)['v']
+  np.testing.assert_allclose(se.values, O.squared_error(_np(pt), te), rtol=1e-12)

@@ -79,6 +79,26 @@ def det():
             f'dchunk={plan.depth_chunk} {ms:7.4f} ms {nbytes / ms / 1e6:7.1f} GB/s {nbytes / ms / 1e6 / 80:5.1f}%')
 
 
+def ens_latfast():
+  """IFS-ENS style chunk (init, number, lead, longitude, latitude): latitude fastest, members slow."""
+  m, nl = 51, 8
+  t = xr.DataArray(torch.randn(nl, NLON, NLAT, device='cuda') + 280, dims=('lead_time', 'longitude', 'latitude'))
+  p = xr.DataArray(t.data[None] + torch.randn(m, nl, NLON, NLAT, device='cuda'),
+                   dims=('number', 'lead_time', 'longitude', 'latitude'))
+  torch.cuda.synchronize()
+  devs = [engine._to_device(ctx, p, _hip.F32), engine._to_device(ctx, t, _hip.F32), None, None]
+  lays = [d.layout if d else None for d in devs]
+  sizes = {'lead_time': nl, 'latitude': NLAT, 'longitude': NLON}
+  nbytes = nl * NLAT * NLON * (m + 1) * 4
+  for tb in (1024, 4096, 16384):
+    plan = planner.build_s1_plan(('lead_time', 'longitude', 'latitude'), sizes, lays, ['latitude', 'longitude'],
+                                 wdep_dims=['latitude'], allow_vec4=False, flags=_hip.FLAG_FAIR, target_blocks=tb)
+    for name, algo in (('sort', 0), ('loadonly', 99)):
+      ms = time_s1('ens', plan, devs, 5, ens=(m, devs[0].layout.stride('number'), algo))
+      print(f'ens M=51 lat-fastest x_kept={plan.x_kept} block={plan.block_threads} nkey={plan.nkey} nchunk={plan.nchunk} '
+            f'{name:9s} {ms:7.4f} ms  {nbytes / ms / 1e6:7.1f} GB/s  {nbytes / ms / 1e6 / 80:5.1f}% of 8 TB/s')
+
+
 if __name__ == '__main__':
   which = sys.argv[1] if len(sys.argv) > 1 else 'ens'
-  {'ens': ens, 'det': det}[which]()
+  {'ens': ens, 'det': det, 'ens_latfast': ens_latfast}[which]()
