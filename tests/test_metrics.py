@@ -509,3 +509,23 @@ def test_latitude_fastest_plane_mode_matches_oracle(backend, nlon, expect_rows):
                                wdep_dims=['latitude'])
   assert plan.x_dim == 'latitude' and plan.x_kept and plan.plane_rows == expect_rows
   assert plan.depth_chunk % max(plan.plane_rows, 1) == 0
+
+
+def test_user_defined_climatology_statistic_gets_an_aligned_array(backend):
+  """Plugins subclassing PerVariableStatisticWithClimatology receive something that behaves like the aligned
+  climatology DataArray of the reference (metrics/base.py:397-406)."""
+  class AnomalyError(metrics_base.PerVariableStatisticWithClimatology):
+    def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
+      assert set(aligned_climatology.dims) <= set(predictions.dims)
+      return abs((predictions - aligned_climatology) - (targets - aligned_climatology))
+
+  rng = np.random.default_rng(13)
+  dims = LAYOUTS['lon_fastest']
+  p, t = _field(rng, dims, np.float32), _field(rng, dims, np.float32)
+  cdims = ('dayofyear', 'hour', 'level', 'latitude', 'longitude')
+  clim = xr.Dataset({'z': xr.DataArray(rng.normal(size=(366, 4, 3, 32, 64)).astype(np.float32), dims=cdims, coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'level': np.array([500, 700, 850]),
+      'latitude': LAT, 'longitude': LON})})
+  res = compute_all_metrics({'ae': AnomalyError(clim), 'mae': deterministic.MAE()}, {'z': p}, {'z': t},
+                            ['latitude', 'longitude'])
+  xr.assert_allclose(res['ae.z'], res['mae.z'], rtol=1e-5, check_dim_order=False)  # fp32 plugin arithmetic vs fused fp64

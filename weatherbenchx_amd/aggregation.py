@@ -9,7 +9,6 @@ bin dims in `bin_by` order (unpinned by the reference, SURVEY F11: compare by na
 """
 from __future__ import annotations
 
-import collections
 import dataclasses
 from typing import Any, Callable, Collection, Hashable, Iterable, Mapping, Sequence
 

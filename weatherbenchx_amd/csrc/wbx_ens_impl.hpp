@@ -27,10 +27,6 @@ namespace wbx {
 // not part of the ABI enum: stage-1 memory-pattern diagnostic used by tools/kbench.py (lane 0 = sum_m p - t)
 constexpr int WBX_ENS_DIAG_LOADONLY = 99;
 
-struct EnsLanes {
-  double skill, spread, var, uemse, emse;
-};
-
 // MP: register bucket (compile time).  EXACT: M == MP known at compile time.
 template <int MP, bool EXACT, int ALGO>
 struct EnsOpF32 {

@@ -9,8 +9,6 @@ collective is latency bound and is issued once per job / step, never per chunk.
 """
 from __future__ import annotations
 
-from typing import Any
-
 import numpy as np
 
 from weatherbenchx_amd import xarray_lite as xr

@@ -62,21 +62,46 @@ class _NeedsAlignment(Exception):
   pass
 
 
-class ClimatologyRef:
-  """Climatology variable + the positions selected by valid_time (metrics/base.py:382-403)."""
+class ClimatologyRef(xr.DataArray):
+  """The climatology aligned with valid_time (metrics/base.py:382-403) -- as an index table, not a copy.
+
+  Built-in statistics only read `.source` / `.positions` and let the stage-1 kernel gather whole climatology fields
+  in place.  For user-defined `PerVariableStatisticWithClimatology` plugins it still IS the aligned DataArray the
+  reference would hand over: touching `.data` / doing arithmetic materialises the gather (on the device for torch
+  payloads)."""
 
   def __init__(self, source: xr.DataArray, over_dims: tuple, positions: dict):
     self.source = source          # dims e.g. (dayofyear, hour, level, latitude, longitude)
-    self.over_dims = over_dims    # statistic dims the selection varies over, e.g. (init_time, lead_time)
+    self.over_dims = tuple(over_dims)    # statistic dims the selection varies over, e.g. (init_time, lead_time)
     self.positions = positions    # climatology dim -> int positions, shape = sizes of over_dims
+    self._data = None
+    self._dims = self.aligned_dims()
+    self.name = source.name
+    self.attrs = dict(source.attrs)
+    self._coords = {k: v for k, v in source._coords.items() if not set(v[0]) & set(positions)}  # pylint: disable=protected-access
 
   def aligned_dims(self):
     return self.over_dims + tuple(d for d in self.source.dims if d not in self.positions)
 
+  @property
+  def shape(self):
+    first = np.asarray(next(iter(self.positions.values())))
+    return tuple(first.shape) + tuple(self.source.sizes[d] for d in self.source.dims if d not in self.positions)
+
+  @property
+  def dtype(self):
+    return self.source.dtype
+
+  @property
+  def data(self):
+    if self._data is None:
+      self._data = self.aligned_view().data
+    return self._data
+
   def aligned_view(self) -> xr.DataArray:
-    """The aligned climatology as a labeled array (only used when the gather cannot be fused)."""
+    """The aligned climatology as a plain labeled array (a gather of whole fields)."""
     src = self.source
-    order =[src.dims.index(d) for d in self.positions] + [i for i, d in enumerate(src.dims) if d not in self.positions]
+    order = [src.dims.index(d) for d in self.positions] + [i for i, d in enumerate(src.dims) if d not in self.positions]
     data = xr._transpose(src.data, order)  # pylint: disable=protected-access
     gather = tuple(np.asarray(self.positions[d]).reshape(-1) for d in self.positions)
     if xr._is_torch(data):  # pylint: disable=protected-access
@@ -124,10 +149,6 @@ class FusedGroup:
     return None
 
   # -- execution ---------------------------------------------------------------------------------
-  def _gather(self):
-    """planner.GatherSpec + the climatology array as device input (layout-dependent, so built lazily)."""
-    return self.clim
-
   def inputs_and_func(self):
     if self.kind == 'ens':
       return [self.p, self.t], 0

@@ -10,11 +10,8 @@ import abc
 from collections.abc import Iterator, Mapping
 from typing import Hashable, final
 
-import numpy as np
-
 from weatherbenchx_amd import lazy
 from weatherbenchx_amd import xarray_lite as xr
-from weatherbenchx_amd import xarray_tree
 
 
 class Metric(abc.ABC):

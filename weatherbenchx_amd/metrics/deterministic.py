@@ -4,7 +4,6 @@ Per-point arithmetic lives in csrc/wbx_det.hip; the classes here only name the l
 """
 from __future__ import annotations
 
-from collections.abc import Hashable
 from typing import Mapping, Sequence, Union
 
 import numpy as np

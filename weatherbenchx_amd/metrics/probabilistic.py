@@ -14,7 +14,6 @@ from typing import Mapping
 import numpy as np
 
 from weatherbenchx_amd import lazy
-from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base
 
 ENSEMBLE_DIM = 'number'

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import numbers
 from collections.abc import Mapping
-from typing import Any, Hashable, Iterable, Sequence
+from typing import Hashable, Iterable, Sequence
 
 import numpy as np
 
@@ -52,11 +52,6 @@ def _transpose(x, axes):
   if _is_torch(x):
     return x.permute(*axes) if len(axes) else x
   return np.transpose(x, axes)
-
-
-def _expand(x, ndim_before_total_index):
-  """x[..., None] style reshape; `ndim_before_total_index` is a tuple indexer."""
-  return x[ndim_before_total_index]
 
 
 def _isnan(x):
