@@ -79,6 +79,27 @@ def det():
             f'dchunk={plan.depth_chunk} {ms:7.4f} ms {nbytes / ms / 1e6:7.1f} GB/s {nbytes / ms / 1e6 / 80:5.1f}%')
 
 
+def det_masked():
+  """Deterministic family with the mask / skipna count lanes (public-benchmark default masked=True with NaN targets)."""
+  ni, nl, nz = 16, 10, 5
+  shape = (ni, nl, nz, NLAT, NLON)
+  dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  arrs = [xr.DataArray(torch.randn(shape, device='cuda') + 280, dims=dims) for _ in range(3)]
+  mask = xr.DataArray(np.random.default_rng(0).random((NLAT, NLON)) > 0.3, dims=('latitude', 'longitude'))
+  torch.cuda.synchronize()
+  devs = [engine._to_device(ctx, a, _hip.F32) for a in arrs] + [engine._mask_to_device(ctx, mask)]
+  lays = [d.layout if d else None for d in devs]
+  sizes = dict(zip(dims, shape))
+  nbytes = int(np.prod(shape)) * 12
+  for name, flags, use in (('plain', 0, devs[:3] + [None]), ('masked', _hip.FLAG_MASKED, devs),
+                           ('skipna', _hip.FLAG_SKIPNA, devs[:3] + [None])):
+    plan = planner.build_s1_plan(dims, sizes, [d.layout if d else None for d in use], ['init_time', 'latitude', 'longitude'],
+                                 wdep_dims=['latitude'], flags=flags)
+    ms = time_s1('det', plan, use, 12 if flags else 6, func=_hip.DET6)
+    print(f'det DET6 {name:7s} vec={plan.vec} x_kept={plan.x_kept} {ms:7.4f} ms {nbytes / ms / 1e6:7.1f} GB/s '
+          f'{nbytes / ms / 1e6 / 80:5.1f}%')
+
+
 def ens_latfast():
   """IFS-ENS style chunk (init, number, lead, longitude, latitude): latitude fastest, members slow."""
   m, nl = 51, 8
@@ -101,4 +122,4 @@ def ens_latfast():
 
 if __name__ == '__main__':
   which = sys.argv[1] if len(sys.argv) > 1 else 'ens'
-  {'ens': ens, 'det': det, 'ens_latfast': ens_latfast}[which]()
+  {'ens': ens, 'det': det, 'ens_latfast': ens_latfast, 'det_masked': det_masked}[which]()

@@ -133,6 +133,9 @@ static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
       return fail(WBX_ERR_INVALID, "plane mode is fp32 only");
     }
   }
+  // count-lane variant stays on one element per lane: the 4-wide form was measured SLOWER on MI355X (masked 2.62 vs
+  // 2.30 ms, skipna 2.39 vs 1.73 ms on f32[16,10,5,721,1440]) -- 24 fp64 accumulators + selects cost more occupancy
+  // than the wider loads return.
   if (mm) return launch_partial<DetOp<T, FUNC, true>, 1>(ctx, plan, a);
   if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, false>, 4>(ctx, plan, a);
   return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);

@@ -327,7 +327,7 @@ inline int check_plan(const wbx_s1_plan* p) {
   WBX_REQUIRE(p->vec == 1 || p->vec == 4, "vec must be 1 or 4 (got %d)", p->vec);
   if (p->vec == 4) {
     WBX_REQUIRE(p->x_kept || p->nx % 4 == 0, "vec=4 with x summed needs nx %% 4 == 0");
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < WBX_MAX_INPUTS; ++i)
       WBX_REQUIRE(p->xstride[i] == 0 || p->xstride[i] == 1, "vec=4 needs unit/zero x strides");
   }
   return 0;

@@ -212,10 +212,11 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
   vec = 1
   if allow_vec4 and not (flags & 3) and nx >= 4 and nx % 4 == 0 and x_dim is not None:
     ok = True
-    for i, lay in enumerate(layouts[:3]):
+    for i, lay in enumerate(layouts[:4]):
       if lay is None:
         continue
-      if lay.itemsize != 4 or lay.base_alignment % 16 != 0 or xstride[i] not in (0, 1):
+      want_item = 1 if i == 3 else 4  # input 3 is the uint8 mask: four mask bytes per lane = one dword
+      if lay.itemsize != want_item or lay.base_alignment % 16 != 0 or xstride[i] not in (0, 1):
         ok = False
         break
       if xstride[i] == 1:
