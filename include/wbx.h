@@ -121,9 +121,9 @@ typedef struct wbx_s1_plan {
   int32_t reserved_;
 } wbx_s1_plan;
 
-/* number of fp64 values stage 1 writes:
- *   nkey * nchunk * nlanes_total * nj, nlanes_total = lanes * (1 + (flags & (MASKED|SKIPNA) ? 1 : 0))
- * layout partial[key][chunk][lane][j]; with MASKED/SKIPNA the count lanes follow the value lanes. */
+/* number of fp64 values stage 1 writes: nkey * nchunk * nlanes_total * nj, layout partial[key][chunk][lane][j].
+ * Count lanes follow the value lanes: none without flags; ONE shared count lane with MASKED alone (validity is the
+ * same for every statistic: nlanes_total = lanes + 1); one per value lane with SKIPNA (nlanes_total = 2 * lanes). */
 int wbx_s1_partial_len(const wbx_s1_plan* plan, int lanes, int64_t* n_out);
 
 /* ---- context ------------------------------------------------------------- */

@@ -120,9 +120,13 @@ def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=
       valid = np.ones(lanes[0].shape, dtype=bool)
       if plan.flags & _hip.FLAG_MASKED:
         valid = devs[3].ptr[_offsets(plan, 3)] != 0
-      oks = [valid & ~(np.isnan(l) if plan.flags & _hip.FLAG_SKIPNA else False) for l in lanes]
-      cols = [_chunked(plan, np.where(ok, l, 0.0)) for ok, l in zip(oks, lanes)]
-      cols += [_chunked(plan, ok.astype(np.float64)) for ok in oks]
+      if plan.flags & _hip.FLAG_SKIPNA:
+        oks = [valid & ~np.isnan(l) for l in lanes]
+        cols = [_chunked(plan, np.where(ok, l, 0.0)) for ok, l in zip(oks, lanes)]
+        cols += [_chunked(plan, ok.astype(np.float64)) for ok in oks]
+      else:  # mask only: one shared count lane
+        cols = [_chunked(plan, np.where(valid, l, 0.0)) for l in lanes]
+        cols.append(_chunked(plan, np.broadcast_to(valid, lanes[0].shape).astype(np.float64)))
     else:
       cols = [_chunked(plan, l) for l in lanes]
     partial = np.stack(cols, axis=2)  # [nkey, nchunk, lane, nj]

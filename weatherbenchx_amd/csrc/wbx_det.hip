@@ -47,12 +47,14 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
   }
 }
 
-// FUNC: 0 = DET3 (p,t), 1 = DET6 (p,t,c), 2 = PASS1 (p).  MM: masked / skipna handling.
-template <typename T, int FUNC, bool MM>
+// FUNC: 0 = DET3 (p,t), 1 = DET6 (p,t,c), 2 = PASS1 (p).
+// MM: 0 = no count lanes; 1 = mask only (ONE count lane shared by every value lane: validity does not depend on the
+// statistic); 2 = skipna, with or without a mask (one count lane per value lane: a NaN may hit some statistics only).
+template <typename T, int FUNC, int MM>
 struct DetOp {
   static constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   static constexpr int NLANE = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
-  static constexpr int NACC = NLANE * (MM ? 2 : 1);
+  static constexpr int NACC = NLANE + (MM == 1 ? 1 : (MM == 2 ? NLANE : 0));
   static constexpr int XR_UNROLL = 2, XK_UNROLL = 4, MIN_WAVES = 1;
 
   __device__ __forceinline__ static void lanes(double p, double t, double c, double (&val)[NLANE]) {
@@ -102,14 +104,18 @@ struct DetOp {
       double val[NLANE];
       lanes((double)p[k], NIN > 1 ? (double)t[k] : 0.0, NIN > 2 ? (double)c[k] : 0.0, val);
       double(&A)[NACC] = acc[XK ? k : 0];
-      if constexpr (!MM) {
+      if constexpr (MM == 0) {
 #pragma unroll
         for (int l = 0; l < NLANE; ++l) A[l] += val[l];
+      } else if constexpr (MM == 1) {
+        const bool ok = m[k] != 0;
+#pragma unroll
+        for (int l = 0; l < NLANE; ++l) A[l] += ok ? val[l] : 0.0;
+        A[NLANE] += ok ? 1.0 : 0.0;
       } else {
-        const bool skipna = a.flags & WBX_FLAG_SKIPNA;
 #pragma unroll
         for (int l = 0; l < NLANE; ++l) {
-          const bool ok = m[k] != 0 && !(skipna && val[l] != val[l]);
+          const bool ok = m[k] != 0 && !(val[l] != val[l]);
           A[l] += ok ? val[l] : 0.0;
           A[NLANE + l] += ok ? 1.0 : 0.0;
         }
@@ -124,11 +130,11 @@ static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   if (plan->plane_rows > 0) {
     if constexpr (std::is_same<T, float>::value) {
       WBX_REQUIRE(!mm, "plane mode does not take mask/skipna flags");
-      for (int i = 0; i < DetOp<T, FUNC, false>::NIN; ++i)
+      for (int i = 0; i < DetOp<T, FUNC, 0>::NIN; ++i)
         WBX_REQUIRE(plan->xstride[i] == 1 && (((uintptr_t)a.in[i]) & 15) == 0,
                     "plane mode needs unit x stride and 16-byte aligned inputs");
-      if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);
-      return launch_plane<DetOp<T, FUNC, false>>(ctx, plan, a);
+      if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
+      return launch_plane<DetOp<T, FUNC, 0>>(ctx, plan, a);
     } else {
       return fail(WBX_ERR_INVALID, "plane mode is fp32 only");
     }
@@ -136,20 +142,21 @@ static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   // count-lane variant stays on one element per lane: the 4-wide form was measured SLOWER on MI355X (masked 2.62 vs
   // 2.30 ms, skipna 2.39 vs 1.73 ms on f32[16,10,5,721,1440]) -- 24 fp64 accumulators + selects cost more occupancy
   // than the wider loads return.
-  if (mm) return launch_partial<DetOp<T, FUNC, true>, 1>(ctx, plan, a);
-  if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, false>, 4>(ctx, plan, a);
-  return launch_partial<DetOp<T, FUNC, false>, 1>(ctx, plan, a);
+  if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<DetOp<T, FUNC, 2>, 1>(ctx, plan, a);
+  if (mm) return launch_partial<DetOp<T, FUNC, 1>, 1>(ctx, plan, a);
+  if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, 0>, 4>(ctx, plan, a);
+  return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
 }
 
 template <typename T>
 static int dispatch_func(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, S1Args& a, bool map) {
   switch (func) {
     case WBX_DET3:
-      return map ? launch_map<DetOp<T, WBX_DET3, false>>(ctx, plan, a) : dispatch_partial<T, WBX_DET3>(ctx, plan, a);
+      return map ? launch_map<DetOp<T, WBX_DET3, 0>>(ctx, plan, a) : dispatch_partial<T, WBX_DET3>(ctx, plan, a);
     case WBX_DET6:
-      return map ? launch_map<DetOp<T, WBX_DET6, false>>(ctx, plan, a) : dispatch_partial<T, WBX_DET6>(ctx, plan, a);
+      return map ? launch_map<DetOp<T, WBX_DET6, 0>>(ctx, plan, a) : dispatch_partial<T, WBX_DET6>(ctx, plan, a);
     case WBX_PASS1:
-      return map ? launch_map<DetOp<T, WBX_PASS1, false>>(ctx, plan, a) : dispatch_partial<T, WBX_PASS1>(ctx, plan, a);
+      return map ? launch_map<DetOp<T, WBX_PASS1, 0>>(ctx, plan, a) : dispatch_partial<T, WBX_PASS1>(ctx, plan, a);
   }
   return fail(WBX_ERR_INVALID, "unknown deterministic family %d", func);
 }
@@ -194,7 +201,8 @@ extern "C" int wbx_det_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int 
 extern "C" int wbx_s1_partial_len(const wbx_s1_plan* plan, int lanes, int64_t* n_out) {
   if (!plan || !n_out || lanes <= 0) return wbx::fail(WBX_ERR_INVALID, "bad arguments to wbx_s1_partial_len");
   const int64_t nj = plan->x_kept ? plan->nx : 1;
-  const int64_t nl = (int64_t)lanes * ((plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) ? 2 : 1);
+  const int64_t nl = (plan->flags & WBX_FLAG_SKIPNA) ? 2 * (int64_t)lanes
+                     : ((plan->flags & WBX_FLAG_MASKED) ? (int64_t)lanes + 1 : (int64_t)lanes);
   *n_out = plan->nkey * plan->nchunk * nl * nj;
   return 0;
 }

@@ -151,11 +151,11 @@ struct EnsOpF32 {
 
 // Mask / skipna handling of Aggregator.aggregate_stat_var (aggregation.py:339-357) around any ensemble core:
 // masked-out or (skipna) NaN statistic values become 0 and are counted out through the paired count lanes.
-template <class Core>
+template <class Core, bool SKIPNA>
 struct EnsMasked {
   static constexpr int NIN = Core::NIN;
   static constexpr int NLANE = Core::NLANE;
-  static constexpr int NACC = 2 * Core::NLANE;
+  static constexpr int NACC = Core::NLANE + (SKIPNA ? Core::NLANE : 1);  // same count-lane convention as DetOp
   static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = Core::MIN_WAVES;
 
   __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
@@ -171,12 +171,17 @@ struct EnsMasked {
     Core::values(a, ro, x, val);
     const bool valid =
         (a.flags & WBX_FLAG_MASKED) ? reinterpret_cast<const uint8_t*>(a.in[3])[ro[3] + x * a.xstride[3]] != 0 : true;
-    const bool skipna = a.flags & WBX_FLAG_SKIPNA;
+    if constexpr (!SKIPNA) {
 #pragma unroll
-    for (int l = 0; l < NLANE; ++l) {
-      const bool ok = valid && !(skipna && val[l] != val[l]);
-      acc[0][l] += ok ? val[l] : 0.0;
-      acc[0][NLANE + l] += ok ? 1.0 : 0.0;
+      for (int l = 0; l < NLANE; ++l) acc[0][l] += valid ? val[l] : 0.0;
+      acc[0][NLANE] += valid ? 1.0 : 0.0;
+    } else {
+#pragma unroll
+      for (int l = 0; l < NLANE; ++l) {
+        const bool ok = valid && !(val[l] != val[l]);
+        acc[0][l] += ok ? val[l] : 0.0;
+        acc[0][NLANE + l] += ok ? 1.0 : 0.0;
+      }
     }
   }
 };
@@ -184,7 +189,8 @@ struct EnsMasked {
 template <class Op>
 int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
   if (map) return launch_map<Op>(ctx, plan, a);
-  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) return launch_partial<EnsMasked<Op>, 1>(ctx, plan, a);
+  if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<EnsMasked<Op, true>, 1>(ctx, plan, a);
+  if (plan->flags & WBX_FLAG_MASKED) return launch_partial<EnsMasked<Op, false>, 1>(ctx, plan, a);
   return launch_partial<Op, 1>(ctx, plan, a);
 }
 

@@ -348,7 +348,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   plan, dplan = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
   nl = _hip.DET_LANES[func] if kind == 'det' else _hip.ENS_LANES
   counted = bool(flags & 3)
-  nl_total = nl * (2 if counted else 1)
+  shared_count = counted and not (flags & _hip.FLAG_SKIPNA)  # mask only: one count lane for every statistic
+  nl_total = nl + 1 if shared_count else nl * (2 if counted else 1)
   ens_args = None
   if kind == 'ens':
     ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
@@ -368,7 +369,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
 
   values = [lane_array(l) for l in range(nl)]
   if counted:
-    counts = [lane_array(nl + l) for l in range(nl)]
+    counts = [lane_array(nl)] * nl if shared_count else [lane_array(nl + l) for l in range(nl)]
   else:
     # data-independent: (elements folded per partial) * sum of W, computed by the same stage-2 kernel
     ckey = (id(w_buf), s2.nBk, s2.nBr, s2.nj, s2.nbin, s2.sum_j, plan.reduced_count_per_partial())
