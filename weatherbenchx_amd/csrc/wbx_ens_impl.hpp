@@ -47,7 +47,10 @@ struct EnsOpF32 {
   //   * SGPR buffer descriptors + scalar member offsets (no 64-bit VGPR addresses): 0.373 ms rank form (noise),
   //     but 0.60 ms vs 0.52 ms for the pair form -> not kept;
   //   * __launch_bounds__ for 4 waves/SIMD (128 VGPRs): 88-164 B of spills, 0.60-0.63 ms -> not kept;
-  //   * register double-buffering of the next point: 255 VGPRs, 2 waves/SIMD, 0.49 ms -> not kept.
+  //   * register double-buffering of the next point: 255 VGPRs, 2 waves/SIMD, 0.49 ms -> not kept;
+  //   * 2 / 4 interleaved fp64 accumulation chains instead of one: 0.39 ms either way -> not kept.
+  // rocprofv3 SQ counters (tools/pmc_ens.sh): WAIT_ANY (memory) 12 %, the VALU pipe is ~saturated: 1453 VALU
+  // instructions per 64 points (877 v_min/v_max for the 415-comparator network, ~430 fp64), i.e. VALU-, not HBM-bound.
   // The load-only diagnostic (WBX_ENS_DIAG_LOADONLY) streams the same 52 dword streams at 6.0 TB/s, so what is
   // left is VALU time (~2000 instructions per 64 points) that 3 waves/SIMD only partly overlap with the loads.
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
