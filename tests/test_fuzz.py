@@ -1,0 +1,101 @@
+"""Randomised planner / Aggregator checks against the oracle: random dim orders, sizes, reduce sets, weights on
+random dims, boolean bins on random dims, masks and skipna -- every combination the two-stage reduction has to
+map onto (key, depth, x).  Runs on the NumPy plan interpreter (CPU) and on the HIP library (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+
+ALL_DIMS = ['init_time', 'lead_time', 'level', 'latitude', 'longitude', 'tile']
+
+
+class VectorWeighting(weighting.Weighting):
+  """Weights along one arbitrary dim (a user-defined Weighting plugin)."""
+
+  def __init__(self, dim, values):
+    self.dim, self.values = dim, values
+
+  def weights(self, statistic):
+    if self.dim not in statistic.dims:
+      return xr.DataArray(1.0)
+    return xr.DataArray(self.values, dims=(self.dim,))
+
+
+class RandomBins(binning.Binning):
+  """Boolean bins over one or two arbitrary dims (a user-defined Binning plugin)."""
+
+  def __init__(self, name, dims, mask):
+    super().__init__(name)
+    self.dims, self.mask = dims, mask
+
+  def create_bin_mask(self, statistic):
+    return xr.DataArray(self.mask, dims=(self.bin_dim_name,) + tuple(self.dims))
+
+
+@pytest.mark.parametrize('seed', range(80))
+def test_random_layouts_and_aggregators(backend, seed):
+  rng = np.random.default_rng(1000 + seed)
+  ndim = int(rng.integers(1, 6))
+  dims = list(rng.permutation(ALL_DIMS)[:ndim])
+  sizes = {d: int(rng.integers(1, 7)) for d in dims}
+  if rng.random() < 0.5:
+    sizes[dims[-1]] = int(rng.choice([4, 8, 64, 65]))  # exercise the 4-wide / multi-wave paths too
+  shape = [sizes[d] for d in dims]
+  dtype = np.float32 if rng.random() < 0.7 else np.float64
+  p = xr.DataArray(rng.normal(size=shape).astype(dtype), dims=dims)
+  # the target may miss some dims (broadcast) and be stored in another order
+  tdims = [d for d in dims if rng.random() < 0.8] or dims[:1]
+  tperm = list(rng.permutation(tdims))
+  t = xr.DataArray(rng.normal(size=[sizes[d] for d in tperm]).astype(dtype), dims=tperm)
+  reduce_dims = [d for d in dims if rng.random() < 0.5]
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.3:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  bins, oracle_b = [], []
+  for k in range(int(rng.integers(0, 3))):
+    bd = list(rng.permutation(dims)[:int(rng.integers(1, min(2, ndim) + 1))])
+    nb = int(rng.choice([2, 3, 7]))
+    mask = rng.random([nb] + [sizes[d] for d in bd]) > 0.4
+    bins.append(RandomBins(f'bin{k}', bd, mask))
+    oracle_b.append((f'bin{k}', mask, (f'bin{k}',) + tuple(bd)))
+  mode = rng.choice(['plain', 'nan_plain', 'masked', 'skipna'])
+  pv = p.values.copy()
+  mask_arr = None
+  if mode != 'plain' and pv.size:
+    idx = tuple(int(rng.integers(0, s)) for s in shape)
+    pv[idx] = np.nan
+    p = xr.DataArray(pv, dims=dims)
+  if mode == 'masked':
+    mdims = [d for d in dims if rng.random() < 0.7] or dims[-1:]
+    mask_arr = rng.random([sizes[d] for d in mdims]) > 0.2
+    full = np.broadcast_to(O.expand_to(mask_arr, tuple(mdims), tuple(dims)), shape)
+    mask_arr = mask_arr & ~np.isnan(np.where(full, pv, 0.0)).any(axis=tuple(i for i, d in enumerate(dims) if d not in mdims))
+    p.coords['mask'] = xr.DataArray(mask_arr, dims=mdims)
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, bin_by=bins or None,
+                               masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+  metrics = {'mse': deterministic.MSE(), 'bias': deterministic.Bias()}
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t})
+  state = agg.aggregate_statistics(stats)
+  te = O.expand_to(t.values, tuple(t.dims), tuple(dims))
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(p.coords['mask'].dims))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  for name, fn in (('SquaredError', O.squared_error), ('Error', O.error)):
+    want = O.aggregate(fn(p.values, te), tuple(dims), reduce_dims, weights=oracle_w, bin_masks=oracle_b, **okw)
+    got_s, got_w = state.sum_weighted_statistics[name].get('v'), state.sum_weights[name].get('v')
+    assert want is not None and got_s is not None
+    sws, sw, out_dims = want
+    assert set(got_s.dims) == set(out_dims), (got_s.dims, out_dims)
+    np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12)
