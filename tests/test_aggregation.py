@@ -142,3 +142,30 @@ def test_state_algebra():
   s = aggregation.combining_sum([a, b])
   np.testing.assert_allclose(s.values, [1, 12, 20])
   np.testing.assert_array_equal(s['x'].values, [0, 1, 2])
+
+
+def test_aggregators_metrics_and_chunks_pickle_without_device_state(backend):
+  """Beam pickles DoFns (metrics, aggregators) and chunks to workers (beam_pipeline.py:140-160): caches that hold
+  device buffers must not travel, and everything must work again after unpickling."""
+  import pickle
+  predictions, targets = _test_data()
+  predictions, targets = dict(predictions), dict(targets)
+  metrics = {'rmse': deterministic.RMSE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions({'n': ((0, 90), (0, 360)), 's': ((-90, 0), (0, 360))})])
+  before = _values(agg, metrics, predictions, targets)
+  agg2, metrics2, p2, t2 = pickle.loads(pickle.dumps((agg, metrics, predictions, targets)))
+  assert not any(k.startswith('_w_') for k in agg2.__dict__)
+  assert not any(k.startswith('_wbx_') for da in p2.values() for k in da.__dict__)
+  after = _values(agg2, metrics2, p2, t2)
+  for k in before:
+    np.testing.assert_allclose(before[k].values, after[k].values)
+  # a lazy statistic pickles as its materialised values
+  stat = deterministic.SquaredError().compute(predictions, targets)['geopotential']
+  back = pickle.loads(pickle.dumps(stat))
+  np.testing.assert_allclose(back.values, 1.0)
+
+
+def _values(agg, metrics, predictions, targets):
+  stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, predictions, targets)
+  return agg.aggregate_statistics(stats).metric_values(metrics)

@@ -529,3 +529,19 @@ def test_user_defined_climatology_statistic_gets_an_aligned_array(backend):
   res = compute_all_metrics({'ae': AnomalyError(clim), 'mae': deterministic.MAE()}, {'z': p}, {'z': t},
                             ['latitude', 'longitude'])
   xr.assert_allclose(res['ae.z'], res['mae.z'], rtol=1e-5, check_dim_order=False)  # fp32 plugin arithmetic vs fused fp64
+
+
+def test_prediction_and_target_passthrough(backend):
+  # metrics_test.py:1008-1029
+  predictions = xr.DataArray(np.array([[1.0, 2.0], [np.nan, 4.0]]), dims=['x', 'y'])
+  targets = xr.DataArray(np.array([[5.0, np.nan], [7.0, 8.0]]), dims=['x', 'y'])
+  r = deterministic.PredictionPassthrough(copy_nans_from_targets=False)._compute_per_variable(predictions, targets)
+  np.testing.assert_array_equal(r.values, [[1.0, 2.0], [np.nan, 4.0]])
+  r = deterministic.PredictionPassthrough(copy_nans_from_targets=True)._compute_per_variable(predictions, targets)
+  np.testing.assert_array_equal(r.values, [[1.0, np.nan], [np.nan, 4.0]])
+  r = deterministic.TargetPassthrough(copy_nans_from_predictions=True)._compute_per_variable(predictions, targets)
+  np.testing.assert_array_equal(r.values, [[5.0, np.nan], [np.nan, 8.0]])
+  # as metrics (PredictionAverage / TargetAverage) they go through the PASS1 family
+  res = compute_all_metrics({'pa': deterministic.PredictionAverage(), 'ta': deterministic.TargetAverage()},
+                            {'v': predictions.fillna(0.0)}, {'v': targets.fillna(0.0)}, ['x', 'y'])
+  np.testing.assert_allclose([res['pa.v'].values, res['ta.v'].values], [7.0 / 4, 20.0 / 4])

@@ -170,6 +170,13 @@ class Aggregator:
   masked: bool = False
   skipna: bool = False
 
+  def __getstate__(self):
+    # cached weight products hold device buffers: drop them when the aggregator is pickled to a worker
+    return {k: v for k, v in self.__dict__.items() if not k.startswith('_w_')}
+
+  def __setstate__(self, state):
+    self.__dict__.update(state)
+
   # ---- reference-compatible single-array entry point -------------------------------------------------
   def aggregation_fn(self, stat: xr.DataArray) -> xr.DataArray | None:
     """sum over reduce_dims of stat * weights * bin masks (aggregation.py:297-335)."""

@@ -62,7 +62,7 @@ class _NeedsAlignment(Exception):
   pass
 
 
-class ClimatologyRef(xr.DataArray):
+class ClimatologyRef(xr.LazyPickleMixin, xr.DataArray):
   """The climatology aligned with valid_time (metrics/base.py:382-403) -- as an index table, not a copy.
 
   Built-in statistics only read `.source` / `.positions` and let the stage-1 kernel gather whole climatology fields
@@ -213,7 +213,7 @@ def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=N
   return grp
 
 
-class LazyStatistic(xr.DataArray):
+class LazyStatistic(xr.LazyPickleMixin, xr.DataArray):
   """A per-point statistic that is a DataArray in every respect, evaluated on demand by a HIP kernel."""
 
   def __init__(self, group: FusedGroup, lane: int, name=None, ens_params=None, mean_dims=()):
@@ -262,7 +262,7 @@ class LazyStatistic(xr.DataArray):
     return super().mean(dim, skipna=skipna, **kw)
 
 
-class LazyEnsembleMean(xr.DataArray):
+class LazyEnsembleMean(xr.LazyPickleMixin, xr.DataArray):
   """`predictions.mean(ensemble_dim)` (wrappers.py:116-148) that remembers where it came from, so
   SquaredError of it is served by the ensemble kernel's lane 4 without a second pass over the members."""
 
@@ -343,7 +343,7 @@ def target_members(t: xr.DataArray, ensemble_dim: str):
   return cache[ensemble_dim]
 
 
-class LinearCombination(xr.DataArray):
+class LinearCombination(xr.LazyPickleMixin, xr.DataArray):
   """scale * sum(terms) of lazy statistics on the same frame.  The weighted reduction is linear, so the Aggregator
   reduces every term with its own fused launch and combines the accumulators (WindVectorSquaredError =
   SE(u) + SE(v), deterministic.py:174-219; CRPSSkill against an ensemble of targets, probabilistic.py:134-145)."""

@@ -103,7 +103,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
   return ctx.download(out.ptr, (ngroup, nk), np.float64)
 
 
-class LazySpectrum(xr.DataArray):
+class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
   """Per-row zonal spectrum of a field: a DataArray whose payload is only computed on demand."""
 
   def __init__(self, source: xr.DataArray, lon_dim: str, k_dim: str, circumference: bool, lat_dim: str):

@@ -338,6 +338,17 @@ class DataArray:
   def __len__(self):
     return self.shape[0]
 
+  def __getstate__(self):
+    # device-side caches (uploaded copies, fused groups, packed weights) never travel: Beam-style workers pickle
+    # metrics / aggregators / chunks (weatherbenchX/beam_pipeline.py:140-160) and rebuild them on first use.
+    state = {k: v for k, v in self.__dict__.items() if not k.startswith('_wbx_')}
+    if state.get('_data', 0) is None:  # lazy payloads are materialised by pickling (they reference device state)
+      state['_data'] = self.data
+    return state
+
+  def __setstate__(self, state):
+    self.__dict__.update(state)
+
   def __repr__(self):
     return (f'<wbx DataArray {self.name!r} ({", ".join(f"{d}: {n}" for d, n in self.sizes.items())}) '
             f'{self.dtype} coords={list(self._coords)}>')
@@ -756,6 +767,19 @@ class DataArray:
 
   def to_dataset(self, name=None):
     return Dataset({name or self.name: self})
+
+
+def rebuild_plain(data, dims, coords, name, attrs):
+  """Unpickle helper: lazy DataArray subclasses travel as plain, materialised DataArrays."""
+  return DataArray(data, dims=dims, coords=coords, name=name, attrs=attrs, _raw_coords=True)
+
+
+class LazyPickleMixin:
+  """Lazy payloads reference device state (fused groups, sources); pickling materialises them."""
+
+  def __reduce__(self):
+    data = _to_numpy(self.data)
+    return (rebuild_plain, (data, self.dims, dict(self._coords), self.name, dict(self.attrs)))
 
 
 def _host_or_same(x):
