@@ -181,6 +181,17 @@ int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial,
 int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* wt,
                       const uint64_t* bits, double* out);
 
+/* ---- fused binned reduction (small depth, many boolean bins) -------------------------------------------------
+ * Statistic, weight and bin membership in ONE pass over p, t, c -- for chunks where little is reduced before the
+ * weight/bin-dependent dims, so that the stage-1 partials would be larger than the inputs (the public benchmark's
+ * 1 init x 12 lead chunks with 34 region x land/sea bins, run_benchmark_evaluation.py:97-131,369-382).
+ * The plan's keys must be ordered [nA][nBk][nBr] (as for wbx_contract); x is summed; `w_on_x` says whether wt / bits
+ * are indexed [nBk][nBr][nx] (W depends on x) or [nBk][nBr][1].  out[nA][nBk][lanes_total][nbin], lanes_total and NaN
+ * semantics exactly as wbx_det_partial + wbx_contract_bits.  The plan's nchunk / x_kept / vec are ignored. */
+int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                   const void* c, const uint8_t* mask, const double* wt, const uint64_t* bits, int64_t nA,
+                   int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, double* out);
+
 /* ---- materialisation of per-point statistics --------------------------------
  * Statistic.compute()'s full-resolution result (metrics/base.py:135-158) for callers
  * that really want it (unaggregated pipelines, beam_pipeline.py:563-595).

@@ -134,6 +134,35 @@ def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=
   return _Buf(partial.reshape(plan.partial_shape(nlanes_total)))
 
 
+def _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf):
+  """wbx_det_binned: weights and membership applied per point (no unweighted partials)."""
+  nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
+  nbin = w_buf.shape[-1]
+  nj = plan.nj if plan.x_kept else 1
+  with np.errstate(all='ignore'):
+    nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]
+    lanes = _det_lanes(func, [devs[i].ptr[_offsets(plan, i)] for i in range(nin)])
+    if plan.flags & 3:
+      valid = np.ones(lanes[0].shape, dtype=bool)
+      if plan.flags & _hip.FLAG_MASKED:
+        valid = devs[3].ptr[_offsets(plan, 3)] != 0
+      if plan.flags & _hip.FLAG_SKIPNA:
+        oks = [valid & ~np.isnan(l) for l in lanes]
+        lanes = [np.where(ok, l, 0.0) for ok, l in zip(oks, lanes)] + [ok.astype(np.float64) for ok in oks]
+      else:
+        lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
+    assert len(lanes) == nl_total
+    wt = np.asarray(w_buf.bufs[0].ptr).reshape(nBk, nBr, nj)
+    bits = np.asarray(w_buf.bufs[1].ptr).reshape(nBk, nBr, nj)
+    member = ((bits[..., None] >> np.arange(nbin, dtype=np.uint64)) & np.uint64(1)).astype(np.float64)
+    out = np.empty((nA, nBk, nl_total, 1, nbin))
+    for l, v in enumerate(lanes):
+      v = v.reshape(nA, nBk, nBr, plan.ndepth, plan.nx) * wt[None, :, :, None, :]
+      out[:, :, l, 0, :] = np.einsum('abrdx,brxn->abn', v, np.broadcast_to(member, (nBk, nBr, nj, nbin)) if nj > 1
+                                     else np.broadcast_to(member, (nBk, nBr, 1, nbin)).repeat(plan.nx, axis=2))
+  return out
+
+
 def _run_map(ctx, kind, dplan, plan, devs, dtype_code, lane, func=0, ens=None):
   with np.errstate(all='ignore'):
     if kind == 'det':
@@ -170,6 +199,7 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_s1', _run_s1)
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
+  monkeypatch.setattr(engine, '_run_binned', _run_binned)
 
 
 def _run_spectrum(field, lon_dim, group, scale, ngroup, cache=None):

@@ -373,10 +373,13 @@ MANY_REGIONS = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)
 @pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest', 'level_fastest'])
 @pytest.mark.parametrize('reduce_dims', [('init_time', 'latitude', 'longitude'), ('latitude',), ('init_time',)])
 @pytest.mark.parametrize('with_nan', [False, True])
-def test_many_boolean_bins_use_membership_bits(backend, layout, reduce_dims, with_nan):
+@pytest.mark.parametrize('binned', ['never', 'always'])
+def test_many_boolean_bins_use_membership_bits(backend, monkeypatch, layout, reduce_dims, with_nan, binned):
   """>= 5 boolean bins (here 7 regions x {all, land} = 14) go through the bit-mask contraction
-  (wbx_contract_bits); results and the NaN-poisons-every-bin rule must equal the dense xr.dot semantics."""
+  (wbx_contract_bits) or the fused wbx_det_binned kernel; results and the NaN-poisons-every-bin rule must equal
+  the dense xr.dot semantics."""
   from weatherbenchx_amd import engine
+  monkeypatch.setattr(engine, 'BINNED_MODE', binned)
   rng = np.random.default_rng(11)
   dims = LAYOUTS[layout]
   p, t = _field(rng, dims, np.float32, 280.0), _field(rng, dims, np.float32, 280.0)
@@ -403,6 +406,60 @@ def test_many_boolean_bins_use_membership_bits(backend, layout, reduce_dims, wit
   w_da, _ = agg._cached_weight_product(stats['SquaredError']['z'])
   assert any(v.kind == 'bits' for v in w_da.__dict__['_wbx_w'].values())
   assert engine.BITS_MIN_BINS <= 14 <= 64
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('mode', ['plain', 'masked', 'skipna'])
+def test_fused_binned_kernel_equals_two_stage_path(backend, monkeypatch, layout, mode):
+  """The public benchmark's chunk shape (1 init x leads x levels, 34 region x land/sea bins, masked=True;
+  run_benchmark_evaluation.py:97-131,369-382) runs through wbx_det_binned: it must agree with the two-stage path
+  for every deterministic family (DET3, DET6 with climatology gather, PASS1 wrappers) and the count lanes."""
+  from weatherbenchx_amd import engine
+  rng = np.random.default_rng(5)
+  dims = ('init_time', 'lead_time', 'level') + (('latitude', 'longitude') if layout == 'lon_fastest' else
+                                                 ('longitude', 'latitude'))
+  sizes = {'init_time': 1, 'lead_time': 3, 'level': 2, 'latitude': 32, 'longitude': 64}
+  coords = {'init_time': np.array(['2020-01-01T00'], 'datetime64[ns]'),
+            'lead_time': np.arange(3) * np.timedelta64(6, 'h'), 'level': [500, 850], 'latitude': LAT, 'longitude': LON}
+  shape = tuple(sizes[d] for d in dims)
+  p = xr.DataArray((rng.normal(size=shape) + 280).astype(np.float32), dims=dims, coords=coords)
+  tv = (rng.normal(size=shape) + 280).astype(np.float32)
+  if mode != 'plain':
+    tv[rng.random(shape) < 0.1] = np.nan
+  t = xr.DataArray(tv, dims=dims, coords=coords)
+  if mode == 'masked':
+    t.coords['mask'] = ~np.isnan(t)
+  clim = xr.DataArray((rng.normal(size=(366, 4, 2, 32, 64)) + 280).astype(np.float32),
+                      dims=('dayofyear', 'hour', 'level', 'latitude', 'longitude'),
+                      coords={'dayofyear': np.arange(1, 367), 'hour': [0, 6, 12, 18], 'level': [500, 850],
+                              'latitude': LAT, 'longitude': LON})
+  land = rng.random((32, 64)) > 0.6
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': LAT, 'longitude': LON})
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE(), 'acc': deterministic.ACC({'z': clim}),
+             'bias': deterministic.Bias()}
+  results, calls = {}, []
+  inner = engine._run_binned
+  monkeypatch.setattr(engine, '_run_binned', lambda *a, **k: (calls.append(engine.BINNED_MODE), inner(*a, **k))[1])
+  for binned in ('never', 'always'):
+    monkeypatch.setattr(engine, 'BINNED_MODE', binned)
+    engine.clear_caches()
+    agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                                 weigh_by=[weighting.GridAreaWeighting()],
+                                 bin_by=[binning.Regions(MANY_REGIONS, land_sea_mask=lsm)],
+                                 masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+    results[binned] = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'z': p}, {'z': t})
+  assert calls and set(calls) == {'always'}
+  for k, v in results['never'].items():
+    assert v.sizes['region'] == 14
+    xr.assert_allclose(results['always'][k], v, rtol=1e-9, atol=1e-12, check_dim_order=False)
+  if mode == 'plain':
+    w = (O.grid_area_weights(LAT), ('latitude',))
+    names, masks = O.region_masks(LAT, LON, MANY_REGIONS, land_sea_mask=land)
+    sws, sw, out_dims = O.aggregate(O.squared_error(p.values, t.values), dims, ['init_time', 'latitude', 'longitude'],
+                                    weights=[w], bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))])
+    np.testing.assert_allclose(results['always']['rmse.z'].transpose(*out_dims).values, np.sqrt(sws / sw), rtol=RTOL)
+  else:
+    assert np.isfinite(results['always']['rmse.z'].values).all()  # NaN targets are masked / skipped, not propagated
 
 
 @pytest.mark.parametrize('m,fair', list(itertools.product([4, 5], [True, False])))

@@ -10,16 +10,7 @@ from weatherbenchx_amd import _hip, aggregation, binning, weighting
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base as mb, deterministic
 
-REGIONS = {
-    'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'northern-hemisphere': ((20, 90), (0, 360)),
-    'southern-hemisphere': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)),
-    'north-america': ((25, 60), (360 - 120, 360 - 75)), 'north-atlantic': ((25, 65), (360 - 70, 360 - 10)),
-    'north-pacific': ((25, 60), (145, 360 - 130)), 'east-asia': ((25, 60), (102.5, 150)),
-    'ausnz': ((-45, -12.5), (120, 175)), 'arctic': ((60, 90), (0, 360)), 'antarctic': ((-90, -60), (0, 360)),
-    'northern-africa': ((5, 32.5), (-12.5, 37.5)), 'southern-africa': ((-30, 5), (12.5, 37.5)),
-    'south-america': ((-40, 5), (-75, -45)), 'west-asia': ((15, 60), (42.5, 102.5)),
-    'south-east-asia': ((-12.5, 25), (95, 125)),
-}
+from wb_regions import REGIONS  # noqa: E402
 ni, nl, nlev = (int(sys.argv[1]) if len(sys.argv) > 1 else 40), 4, 5
 nlat, nlon = 721, 1440
 lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)

@@ -296,6 +296,46 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
   return ctx.download(out.ptr, shape, np.float64)
 
 
+# 'auto': the fused binned kernel runs when the stage-1 partials would exceed BINNED_PARTIAL_RATIO x the input bytes
+# (little is reduced before the weight/bin-dependent dims); 'never' / 'always' (whenever eligible) are for A/B timing.
+BINNED_MODE = 'auto'
+BINNED_PARTIAL_RATIO = 0.25
+
+
+def _binned_eligible(kind, plan: planner.S1Plan, w_buf, devs, nl_total: int, nin: int) -> bool:
+  if kind != 'det' or w_buf.kind != 'bits' or BINNED_MODE == 'never':
+    return False
+  if plan.x_kept and not plan.sum_j:  # x survives into the output: the two-stage path keeps it
+    return False
+  if BINNED_MODE == 'always':
+    return True
+  partial_bytes = int(np.prod(plan.partial_shape(nl_total), dtype=np.int64)) * 8
+  input_bytes = plan.nkey * plan.ndepth * plan.nx * devs[0].layout.itemsize * nin
+  return partial_bytes > BINNED_PARTIAL_RATIO * input_bytes
+
+
+def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_code: int, nl_total: int, func: int,
+                w_buf) -> np.ndarray:
+  """wbx_det_binned: out[nA][nBk][lanes][1][nbin] (same shape as the sum_j stage-2 result)."""
+  nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
+  nbin = w_buf.shape[-1]
+  shape = (nA, nBk, nl_total, 1, nbin)
+  out = _scratch(ctx, 's2out', int(np.prod(shape, dtype=np.int64)) * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  reps = 1
+  if S1_EVENT_LOG is not None:
+    reps = max(1, int(S1_EVENT_REPEAT))
+    ctx.timer_start()
+  for _ in range(reps):
+    _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                      ptr(devs[2]), ptr(devs[3]), C.c_void_p(w_buf.bufs[0].ptr),
+                                      C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, int(plan.x_kept and plan.nj > 1), nbin,
+                                      C.c_void_p(out.ptr)), 'wbx_det_binned')
+  if S1_EVENT_LOG is not None:
+    S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin})
+  return ctx.download(out.ptr, shape, np.float64)
+
+
 def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
   """W as float64 [nBk][nBr][nj][nbin] from the labeled product of weights and bin masks."""
   bin_dims = tuple(bin_dims)
@@ -353,11 +393,14 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   ens_args = None
   if kind == 'ens':
     ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
-  partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args)
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
-  out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
+  if _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
+    out = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
+  else:
+    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args)
+    out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
 
   x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()
   out_dims = plan.a_dims + plan.bk_dims + x_out + tuple(bin_dims)
