@@ -26,11 +26,20 @@ p_t, t_t = torch.randn(shape, device='cuda') + 280, torch.randn(shape, device='c
 clim_t = torch.randn((10, 4) + shape[2:], device='cuda') + 280
 clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=('dayofyear', 'hour') + dims[2:], coords={
     'dayofyear': np.arange(1, 11), 'hour': np.array([0, 6, 12, 18]), **{d: coords[d] for d in dims[2:]}})})
-lsm = xr.DataArray(np.random.default_rng(0).random((nlat, nlon)) > 0.7, dims=('latitude', 'longitude'),
+# land-sea mask: spatially coherent "continents" by default (like the real one); 'random' = worst case for the
+# wave-level bin skipping of wbx_det_binned
+if len(sys.argv) > 3 and sys.argv[3] == 'random':
+  land = np.random.default_rng(0).random((nlat, nlon)) > 0.7
+else:
+  land = (np.sin(np.deg2rad(lon) * 3)[None, :] * np.cos(np.deg2rad(lat) * 2.5)[:, None]) > 0.35
+lsm = xr.DataArray(land, dims=('latitude', 'longitude'),
                    coords={'latitude': lat, 'longitude': lon})
 metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'bias': deterministic.Bias(),
            'acc': deterministic.ACC(clim), 'prediction_activity': deterministic.PredictionActivity(clim)}
 ctx = _hip.default_context(0)
+if os.environ.get('NREGIONS'):  # diagnostic: fewer regions (the bit path is forced)
+  REGIONS = dict(list(REGIONS.items())[:int(os.environ['NREGIONS'])])
+  engine.BITS_MIN_BINS = 1
 pts = int(np.prod(shape))
 for name, mode, agg in (
     ('no bins', 'auto', aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
@@ -41,6 +50,8 @@ for name, mode, agg in (
     ('34 bins fused', 'always', aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
                                                        weigh_by=[weighting.GridAreaWeighting()],
                                                        bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True))):
+  if os.environ.get('ONLY_FUSED') and mode != 'always':
+    continue
   engine.BINNED_MODE = mode
   def step():
     pp = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}

@@ -3,13 +3,21 @@
 // The two-stage path (wbx_det_partial + wbx_contract_bits) has to keep every dimension the bin masks depend on
 // (latitude AND longitude for Regions x land/sea) in the stage-1 partials.  When little is reduced before them --
 // the public benchmark's chunks are 1 init x 12 leads (public_benchmark/run_benchmark_evaluation.py:97-101) -- those
-// partials are 6 lanes x 8 B per grid point, 4x the inputs, and stage 2 re-reads them per lane.  This kernel instead
-// re-derives the statistics per bin group straight from p, t, c (L2 / Infinity-Cache served on the repeats) and
-// accumulates  acc[bin][lane] = fma(w(point) * stat(point), member(bin, point), acc)  in registers:
-//   grid  = nA * nBk * ngroup * nsplit     (bin group of BG bins, split of the nBr*D reduced rows)
-//   block = 4 waves; waves interleave over rows, lanes over x (any stride); block fold -> tmp[..][split][lane][bin]
-// A second tiny kernel sums the splits.  Same semantics as aggregation.py:297-366: NaN * 0 = NaN poisons every bin of
-// a lane (member is 0.0 / 1.0 and the FMA propagates it), mask / skipna count lanes follow the conventions of wbx_det_partial.
+// partials are 6 lanes x 8 B per grid point, 4x the inputs, and stage 2 re-reads them per lane.  This kernel reads
+// p, t, c once and accumulates  acc[bin][lane] = fma(w(point) * stat(point), member(bin, point), acc)  in registers.
+//
+// There are too many (bin, lane) accumulators for one register file (34 bins x 7 lanes), but bins are regions: a
+// spatially compact patch of the grid touches only a few of them.  So one WAVE owns one patch
+//     patch = (cell (A, Bk), 64 consecutive x, a range of the nBr * D reduced rows)
+// scans the patch's membership words once (8 B / point, L2 resident) for the union of its bins, deals the set bits of
+// the union to K register "slots" (a table in SGPRs), and sweeps its rows accumulating only those; a patch with more
+// than K bins takes another sweep for the next K.  Per 64-point tile the wave ORs the membership words across lanes
+// (DPP) and skips the slots no point of the tile is in.  Waves write tmp[cell][patch][lane][bin] (pre-zeroed) and a
+// second kernel sums the patches.  No LDS, no block barrier: the block is one wave.
+//
+// Semantics as aggregation.py:297-366: NaN * 0 = NaN poisons every bin of a lane (`poison`, added to all bins by the
+// second kernel; inside a visited bin the 0.0 / 1.0 membership FMA propagates it), mask / skipna count lanes follow
+// the conventions of wbx_det_partial.
 #include <type_traits>
 
 #include "wbx_s1.hpp"
@@ -20,136 +28,261 @@ struct BinnedArgs {
   const double* wt;                  // [nBk][nBr][nj]
   const unsigned long long* bits;    // [nBk][nBr][nj]
   int64_t nBk, nBr, nj;              // nj = nx if W depends on x, else 1
-  int32_t nbin, ngroup, nsplit;
+  int32_t nbin, nxt, nrs;            // x tiles, row splits: npatch = nrs * nxt
   int64_t rows_per_split;            // rows = nBr * D
-  double* tmp;                       // [nA][nBk][ngroup][nsplit][NACC][BG]
+  int64_t ncell, nblocks;            // nA * nBk, ncell * npatch
+  double* tmp;                       // [cell][patch][NA][nbin], zeroed
+  double* tmp_poison;                // [cell][patch][NA]
+  unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
 };
 
-template <typename T>
-__device__ __forceinline__ T ld1(const void* base, int64_t off, int64_t x, int64_t xs) {
-  return reinterpret_cast<const T*>(base)[off + x * xs];
+__device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// MM: 0 none, 1 mask only (one shared count lane), 2 skipna (count lane per value lane)
-template <typename T, int FUNC, int MM, int BG>
-__global__ void __launch_bounds__(256) det_binned_kernel(S1Args a, BinnedArgs g) {
+// OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, true);  // row_ror:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);  // row_ror:8  -> every lane holds its row's OR
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  return ((unsigned long long)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
+}
+
+// uni[bk][patch] |= OR of bits over the patch's (rows, 64 x); the 4 waves of a block interleave over the rows
+__global__ void __launch_bounds__(256) binned_union_kernel(BinnedArgs g, int64_t D, int64_t nx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t b = blockIdx.x;
+  const int xt = (int)(b % g.nxt);
+  b /= g.nxt;
+  const int rs = (int)(b % g.nrs);
+  const int64_t bk = b / g.nrs;
+  const int64_t R = g.nBr * D;
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  const bool live = (int64_t)xt * 64 + lane < nx;
+  const int64_t xw = g.nj > 1 ? (live ? (int64_t)xt * 64 + lane : nx - 1) : 0;
+  unsigned long long mine = 0ull;
+  for (int64_t br = rbeg / D + wave; br <= (rend - 1) / D; br += 4) mine |= g.bits[(bk * g.nBr + br) * g.nj + xw];
+  const unsigned long long all = wave_or64(live ? mine : 0ull);
+  if (lane == 0 && all) atomicOr(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt], all);
+}
+
+// MM: 0 none, 1 mask only (one shared count lane), 2 skipna (count lane per value lane), 3 skipna + mask.
+// K = accumulator slots, PD = rows of p, t, c in flight.
+template <typename T, int FUNC, int MM, int K, int PD>
+__global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) {
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
-  constexpr int NC = MM == 1 ? 1 : (MM == 2 ? NL : 0);
+  constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
   constexpr int NA = NL + NC;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-  int64_t b = blockIdx.x;
-  const int split = (int)(b % g.nsplit);
-  b /= g.nsplit;
-  const int grp = (int)(b % g.ngroup);
-  b /= g.ngroup;
-  const int64_t bk = b % g.nBk;
-  const int64_t A = b / g.nBk;
-  const int bin0 = grp * BG;
-
-  double acc[NA][BG];
-#pragma unroll
-  for (int l = 0; l < NA; ++l)
-#pragma unroll
-    for (int q = 0; q < BG; ++q) acc[l][q] = 0.0;
+  const int lane = threadIdx.x;
+  // Workgroup i runs on XCD i % 8.  Logical ids are dealt so that each XCD walks a contiguous range in order, with the
+  // cell as the fastest index: the waves resident on one XCD at a time are the same patch of many cells, so the
+  // patch's wt / bits rows (which do not depend on A) are fetched into that XCD's L2 once and hit by the others.
+  // Without this the 16 B / point of wt + bits miss L2 for every cell and cost as much fabric bandwidth as p, t, c.
+  const int64_t per_xcd = (g.nblocks + 7) / 8;
+  int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (b >= g.nblocks) return;
+  const int64_t cell = b % g.ncell;
+  b /= g.ncell;
+  const int xt = (int)(b % g.nxt);
+  const int rs = (int)(b / g.nxt);
+  const int64_t bk = cell % g.nBk;
+  const int64_t A = cell / g.nBk;
   const int64_t R = g.nBr * a.D;
-  const int64_t r0 = (int64_t)split * g.rows_per_split;
-  const int64_t r1 = r0 + g.rows_per_split < R ? r0 + g.rows_per_split : R;
-  for (int64_t r = r0 + wave; r < r1; r += nwave) {
-    const int64_t br = r / a.D;
-    const int64_t d = r - br * a.D;
-    const int64_t key = (A * g.nBk + bk) * g.nBr + br;
-    int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
-    key_bases<NIN>(a, key, kb);
-    row_bases<NIN>(a, kb, key, d, ro);
-    const int64_t wrow = (bk * g.nBr + br) * g.nj;
-    for (int64_t x = lane; x < a.nx; x += 64) {
-      const double p = (double)ld1<T>(a.in[0], ro[0], x, a.xstride[0]);
-      const double t = NIN > 1 ? (double)ld1<T>(a.in[1], ro[1], x, a.xstride[1]) : 0.0;
-      const double c = NIN > 2 ? (double)ld1<T>(a.in[2], ro[2], x, a.xstride[2]) : 0.0;
-      double val[NA];
-      if constexpr (FUNC == WBX_PASS1) {
-        val[0] = p;
-      } else {
-        const double e = p - t;
-        val[0] = e;
-        val[1] = fabs(e);
-        val[2] = e * e;
-        if constexpr (FUNC == WBX_DET6) {
-          const double pa = p - c, ta = t - c;
-          val[3] = pa * pa;
-          val[4] = ta * ta;
-          val[5] = pa * ta;
-        }
-      }
-      if constexpr (MM != 0) {
-        const bool valid = (a.flags & WBX_FLAG_MASKED) ? ld1<uint8_t>(a.in[3], ro[3], x, a.xstride[3]) != 0 : true;
-        if constexpr (MM == 1) {
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  constexpr bool has_mask = MM == 1 || MM == 3;
+
+  // lanes beyond a ragged nx re-read the last element and never accumulate
+  const bool live = (int64_t)xt * 64 + lane < a.nx;
+  const int64_t x = live ? (int64_t)xt * 64 + lane : a.nx - 1;
+  const int64_t xw = g.nj > 1 ? x : 0;
+  int64_t xoff[WBX_MAX_INPUTS];
 #pragma unroll
-          for (int l = 0; l < NL; ++l) val[l] = valid ? val[l] : 0.0;
-          val[NL] = valid ? 1.0 : 0.0;
-        } else {
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i) xoff[i] = x * a.xstride[i];
+
+  const int64_t patch = (int64_t)rs * g.nxt + xt;
+  // union of the patch's bins (binned_union_kernel: it does not depend on A, so it is computed once per launch)
+  unsigned long long todo = __builtin_nontemporal_load(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch]);
+  todo = (unsigned long long)readlane64((int64_t)todo, 0);
+  double* const out = g.tmp + (cell * ((int64_t)g.nrs * g.nxt) + patch) * (NA * (int64_t)g.nbin);
+  bool first = true;
+  do {
+    // ---- deal the next K bins of the union to the slots (wave-uniform)
+    int sbin[K];
+    unsigned long long smask[K];  // one bit per dealt slot, 0 for the unused ones
 #pragma unroll
-          for (int l = 0; l < NL; ++l) {
-            const bool ok = valid && !(val[l] != val[l]);
-            val[NL + l] = ok ? 1.0 : 0.0;
-            val[l] = ok ? val[l] : 0.0;
+    for (int q = 0; q < K; ++q) {
+      sbin[q] = todo ? __builtin_ctzll(todo) : 0;
+      smask[q] = todo & (~todo + 1ull);
+      todo &= todo - 1ull;
+    }
+    double acc[NA][K];
+    double poison[NA];
+#pragma unroll
+    for (int l = 0; l < NA; ++l) {
+      poison[l] = 0.0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) acc[l][q] = 0.0;
+    }
+
+    for (int64_t rb = rbeg; rb < rend; rb += 64) {
+      // lane j resolves row rb + j through the plan's tables; the sweep below broadcasts them one by one
+      const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
+      const int64_t br = rmine / a.D;
+      const int64_t d = rmine - br * a.D;
+      const int64_t key = (A * g.nBk + bk) * g.nBr + br;
+      int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
+      key_bases<NIN>(a, key, kb);
+      row_bases<NIN>(a, kb, key, d, ro);
+      const int64_t wrow_v = (bk * g.nBr + br) * g.nj;
+      const int nrow = (int)(rend - rb < 64 ? rend - rb : 64);
+
+      // p, t, c (and the mask) stream from HBM: PD rows in flight per wave.  wt / bits are L2 hits: one row ahead.
+      T rp[PD], rt[PD], rc[PD];
+      uint8_t rv[PD];
+      auto fetch_ptc = [&](int j, int u) {
+        rp[u] = reinterpret_cast<const T*>(a.in[0])[readlane64(ro[0], j) + xoff[0]];
+        if constexpr (NIN > 1) rt[u] = reinterpret_cast<const T*>(a.in[1])[readlane64(ro[1], j) + xoff[1]];
+        if constexpr (NIN > 2) rc[u] = reinterpret_cast<const T*>(a.in[2])[readlane64(ro[2], j) + xoff[2]];
+        rv[u] = 1;
+        if constexpr (has_mask) rv[u] = reinterpret_cast<const uint8_t*>(a.in[3])[readlane64(ro[3], j) + xoff[3]];
+      };
+      double w_cur, w_nxt = 0.0;
+      unsigned long long bits_cur, bits_nxt = 0ull;
+      auto fetch_bw = [&](int j, double& w, unsigned long long& bw) {
+        const int64_t wi = readlane64(wrow_v, j) + xw;
+        bw = g.bits[wi];
+        w = g.wt[wi];
+      };
+      auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, unsigned long long bw) {
+        const bool ok = live && tv != 0;
+        const unsigned long long tile = wave_or64(ok ? bw : 0ull);  // bins any point of this tile is in
+        if (ok) {
+          const double p = (double)tp, t = (double)tt, c = (double)tc;
+          double val[NA];
+          if constexpr (FUNC == WBX_PASS1) {
+            val[0] = p;
+          } else {
+            const double e = p - t;
+            val[0] = e;
+            val[1] = fabs(e);
+            val[2] = e * e;
+            if constexpr (FUNC == WBX_DET6) {
+              const double pa = p - c, ta = t - c;
+              val[3] = pa * pa;
+              val[4] = ta * ta;
+              val[5] = pa * ta;
+            }
+          }
+          if constexpr (MM == 1) val[NL] = 1.0;
+          if constexpr (MM >= 2) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+              const bool fin = !(val[l] != val[l]);
+              val[NL + l] = fin ? 1.0 : 0.0;
+              val[l] = fin ? val[l] : 0.0;
+            }
+          }
+          double m[NA];
+#pragma unroll
+          for (int l = 0; l < NA; ++l) {
+            m[l] = val[l] * w;
+            poison[l] = fma(m[l], 0.0, poison[l]);
+          }
+#pragma unroll
+          for (int q = 0; q < K; ++q) {
+            if (tile & smask[q]) {  // wave-uniform
+              // membership as 0.0 / 1.0: exact, and NaN * 0 stays NaN
+              const double f = __hiloint2double((bw & smask[q]) ? 0x3FF00000 : 0, 0);
+#pragma unroll
+              for (int l = 0; l < NA; ++l) acc[l][q] = fma(m[l], f, acc[l][q]);
+            }
           }
         }
-      }
-      const int64_t wi = wrow + (g.nj > 1 ? x : 0);
-      const double w = g.wt[wi];
-      const unsigned long long bw = g.bits[wi] >> bin0;
-      const unsigned word = (unsigned)bw;
-      double m[NA];
+      };
+      // Every load below is unconditional (row indices are clamped, the surplus ones re-read the block's last row):
+      // the compiler can then count the loads in flight and wait for exactly the oldest (s_waitcnt vmcnt(n)); a load
+      // under a branch would make it drain the whole queue, prefetches included, once per tile.
+      const int last = nrow - 1;
 #pragma unroll
-      for (int l = 0; l < NA; ++l) m[l] = val[l] * w;
+      for (int u = 0; u < PD; ++u) fetch_ptc(u < last ? u : last, u);
+      fetch_bw(0, w_cur, bits_cur);
+      for (int j = 0; j < nrow; j += PD) {
 #pragma unroll
-      for (int q = 0; q < BG; ++q) {
-        // membership as 0.0 / 1.0: the FMA keeps IEEE NaN * 0 = NaN, i.e. a NaN statistic poisons every bin exactly
-        // as (stat * weights * mask).sum() does in the reference (aggregation.py:335)
-        const double f = __hiloint2double(((word >> q) & 1u) ? 0x3FF00000 : 0, 0);
-#pragma unroll
-        for (int l = 0; l < NA; ++l) acc[l][q] = fma(m[l], f, acc[l][q]);
+        for (int u = 0; u < PD; ++u) {
+          const int jj = j + u;
+          const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
+          const uint8_t tv = rv[u];
+          fetch_ptc(jj + PD < last ? jj + PD : last, u);
+          fetch_bw(jj + 1 < last ? jj + 1 : last, w_nxt, bits_nxt);
+          if (jj < nrow) accumulate(tp, tt, tc, tv, w_cur, bits_cur);  // wave-uniform
+          w_cur = w_nxt;
+          bits_cur = bits_nxt;
+        }
       }
     }
-  }
-  __shared__ double red[4][NA * BG];
+
+    // ---- fold the lanes; one write per (visited bin, lane)
 #pragma unroll
-  for (int l = 0; l < NA; ++l)
+    for (int q = 0; q < K; ++q) {
+      if (smask[q]) {
 #pragma unroll
-    for (int q = 0; q < BG; ++q) {
-      const double s = wave_sum(acc[l][q]);
-      if (lane == 0) red[wave][l * BG + q] = s;
+        for (int l = 0; l < NA; ++l) {
+          const double sum = wave_sum(acc[l][q]);
+          if (lane == 0) out[(int64_t)l * g.nbin + sbin[q]] = sum;
+        }
+      }
     }
-  __syncthreads();
-  if (threadIdx.x < NA * BG) {
-    double s = 0.0;
-    for (int w2 = 0; w2 < nwave; ++w2) s += red[w2][threadIdx.x];
-    g.tmp[((((A * g.nBk + bk) * g.ngroup + grp) * g.nsplit + split) * (NA * BG)) + threadIdx.x] = s;
-  }
+    if (first) {
+#pragma unroll
+      for (int l = 0; l < NA; ++l) {
+        const double sum = wave_sum(poison[l]);
+        if (lane == 0) g.tmp_poison[(cell * ((int64_t)g.nrs * g.nxt) + patch) * NA + l] = sum;
+      }
+      first = false;
+    }
+  } while (todo);
 }
 
-// tmp[cell][group][split][lane][q] -> out[cell][lane][bin]
-__global__ void __launch_bounds__(256) det_binned_finish(int64_t ncell, int ngroup, int nsplit, int nacc, int bg, int nbin,
-                                                         const double* __restrict__ tmp, double* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ncell * nacc * nbin) return;
-  const int bin = (int)(i % nbin);
-  const int l = (int)((i / nbin) % nacc);
-  const int64_t cell = i / ((int64_t)nbin * nacc);
-  const int grp = bin / bg, q = bin - grp * bg;
+// out[cell][lane][bin] = sum over patches of tmp[cell][patch][lane][bin] + poison[cell][patch][lane].
+// One block per (cell, lane): thread (pg, bin) sums every (256 / nbin)-th patch, LDS folds the pg.
+__global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, int nacc, int nbin,
+                                                         const double* __restrict__ tmp,
+                                                         const double* __restrict__ poison, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int64_t cell = blockIdx.x / nacc;
+  const int l = (int)(blockIdx.x % nacc);
+  const int ng = 256 / nbin;
+  const int bin = threadIdx.x % nbin, pg = threadIdx.x / nbin;
   double s = 0.0;
-  for (int k = 0; k < nsplit; ++k) s += tmp[(((cell * ngroup + grp) * nsplit + k) * nacc + l) * bg + q];
-  out[i] = s;
+  if (pg < ng)
+    for (int64_t k = pg; k < npatch; k += ng)
+      s += tmp[((cell * npatch + k) * nacc + l) * nbin + bin] + poison[(cell * npatch + k) * nacc + l];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < nbin) {
+    for (int q = 1; q < ng; ++q) s += red[q * nbin + threadIdx.x];
+    out[(cell * nacc + l) * nbin + threadIdx.x] = s;
+  }
 }
 
-template <typename T, int FUNC, int MM>
-static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
+template <typename T, int FUNC, int MM, int K, int PD>
+static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
                          int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
-  constexpr int NA = NL + (MM == 1 ? 1 : (MM == 2 ? NL : 0));
-  constexpr int BG = NA <= 4 ? 8 : (NA <= 7 ? 6 : 4);  // accumulators per lane: NA * BG fp64 (<= 48)
+  constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   BinnedArgs g;
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
@@ -157,38 +290,66 @@ static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const
   g.nBr = nBr;
   g.nj = nj;
   g.nbin = nbin;
-  g.ngroup = (nbin + BG - 1) / BG;
   const int64_t rows = nBr * plan->ndepth;
   const int64_t cells = nA * nBk;
-  int64_t want = (8192 + cells * g.ngroup - 1) / (cells * g.ngroup);  // blocks per (cell, group)
-  if (want > (rows + 3) / 4) want = (rows + 3) / 4;                   // >= 4 rows per block (one per wave)
+  g.nxt = (int)((plan->nx + 63) / 64);
+  // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
+  // (the lane fold at the end of a patch costs about as much as 10 rows)
+  int64_t want = (16384 + cells * g.nxt - 1) / (cells * g.nxt);
+  if (want > (rows + 63) / 64) want = (rows + 63) / 64;
   if (want < 1) want = 1;
   g.rows_per_split = (rows + want - 1) / want;
-  g.nsplit = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
-  const size_t need = (size_t)cells * g.ngroup * g.nsplit * NA * BG * sizeof(double);
+  g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  const size_t n_tmp = (size_t)cells * npatch * NA * nbin, n_poison = (size_t)cells * npatch * NA;
+  const size_t n_uni = (size_t)nBk * npatch;
+  const size_t need = (n_tmp + n_poison + n_uni) * sizeof(double);
   if (ctx->s2_scratch_size < need) {
     if (ctx->s2_scratch) {
       WBX_HIP(hipStreamSynchronize(ctx->stream));
       WBX_HIP(hipFree(ctx->s2_scratch));
+      ctx->s2_scratch = nullptr;
+      ctx->s2_scratch_size = 0;
     }
     WBX_HIP(hipMalloc(&ctx->s2_scratch, need));
     ctx->s2_scratch_size = need;
   }
   g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
-  const int64_t grid = cells * g.ngroup * g.nsplit;
+  g.uni = reinterpret_cast<unsigned long long*>(g.tmp + n_tmp);
+  g.tmp_poison = g.tmp + n_tmp + n_uni;
+  WBX_HIP(hipMemsetAsync(g.tmp, 0, (n_tmp + n_uni) * sizeof(double), ctx->stream));
+  g.ncell = cells;
+  g.nblocks = cells * npatch;
+  const int64_t grid = (g.nblocks + 7) / 8 * 8;
   WBX_REQUIRE(grid < (int64_t)1 << 31, "binned grid too large");
-  hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, BG>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, a, g);
+  hipLaunchKernelGGL(binned_union_kernel, dim3((unsigned)(nBk * npatch)), dim3(256), 0, ctx->stream, g,
+                     (int64_t)plan->ndepth, (int64_t)plan->nx);
   WBX_HIP(hipGetLastError());
-  const int64_t n = cells * NA * nbin;
-  hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cells, g.ngroup,
-                     g.nsplit, NA, BG, nbin, g.tmp, out);
+  hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g);
+  WBX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)(cells * NA)), dim3(256), 0, ctx->stream, npatch, NA, nbin, g.tmp,
+                     g.tmp_poison, out);
   WBX_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, int FUNC, int MM>
+static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out) {
+  constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
+  constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
+  // Slots: 2 * NA * K accumulator VGPRs + ~70 working registers must stay <= 168 for 3 waves / SIMD.  Measured on the
+  // public-benchmark chunk (DET6, 34 bins): K = 6 / 8 / 12 -> 0.92 / 0.85 / 0.95 ms; 2 rows of p, t, c in flight are
+  // enough (4: 1.01 ms, the extra registers cost a wave).
+  constexpr int K = NA <= 1 ? 32 : (NA <= 2 ? 24 : (NA <= 3 ? 16 : (NA <= 4 ? 12 : (NA <= 6 ? 8 : (NA <= 7 ? 6 : 3)))));
+  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out);
 }
 
 template <typename T, int FUNC>
 static int binned_mm(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits, int64_t nA,
                      int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out) {
+  if ((plan->flags & WBX_FLAG_SKIPNA) && (plan->flags & WBX_FLAG_MASKED))
+    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out);
   if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out);
   if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out);
   return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out);

@@ -298,8 +298,10 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
 
 # 'auto': the fused binned kernel runs when the stage-1 partials would exceed BINNED_PARTIAL_RATIO x the input bytes
 # (little is reduced before the weight/bin-dependent dims); 'never' / 'always' (whenever eligible) are for A/B timing.
+# Measured on MI355X (34 region bins, 0.25 deg): fused ~0.44 ms per GB of inputs; two-stage ~0.2 ms per GB of inputs
+# plus ~5 ms per GB of partials -> break-even where the partials are ~5 % of the inputs.
 BINNED_MODE = 'auto'
-BINNED_PARTIAL_RATIO = 0.25
+BINNED_PARTIAL_RATIO = 0.05
 
 
 def _binned_eligible(kind, plan: planner.S1Plan, w_buf, devs, nl_total: int, nin: int) -> bool:
