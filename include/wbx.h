@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 2
+#define WBX_ABI_VERSION 3
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -143,6 +143,22 @@ int wbx_free(wbx_ctx* ctx, void* dptr);
 int wbx_memcpy_h2d(wbx_ctx* ctx, void* dptr, const void* h_src, size_t bytes);
 int wbx_memcpy_d2h(wbx_ctx* ctx, void* h_dst, const void* dptr, size_t bytes); /* synchronises */
 int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes);
+
+/* Deferred results.  The reference's chunk loop (beam_pipeline.py:161-250 per chunk, CombinePerKey at :509) only
+ * needs a chunk's sums when it combines them; reading them back synchronously after every chunk leaves the GPU idle
+ * while the host prepares the next one.  With these the host enqueues the read-back of chunk k into pinned memory,
+ * records a fence, launches chunk k+1 and waits on the fence of chunk k only when it combines it.
+ *   wbx_host_alloc / wbx_host_free   page-locked host memory (hipHostMalloc)
+ *   wbx_memcpy_d2h_async             enqueued on the context stream; `h_pinned` must come from wbx_host_alloc
+ *   wbx_fence_*                      hipEvent (no timing) recorded on the context stream; wait blocks the host only */
+typedef struct wbx_fence wbx_fence;
+int wbx_host_alloc(wbx_ctx* ctx, size_t bytes, void** h_out);
+int wbx_host_free(wbx_ctx* ctx, void* h_ptr);
+int wbx_memcpy_d2h_async(wbx_ctx* ctx, void* h_pinned, const void* dptr, size_t bytes);
+int wbx_fence_create(wbx_ctx* ctx, wbx_fence** out);
+int wbx_fence_record(wbx_ctx* ctx, wbx_fence* fence);
+int wbx_fence_wait(wbx_fence* fence);
+int wbx_fence_destroy(wbx_fence* fence);
 
 /* HIP-event timer on the context stream (bench.py's roofline leg). */
 int wbx_timer_start(wbx_ctx* ctx);

@@ -83,6 +83,46 @@ def test_multiple_named_aggregators(backend):
   assert pipeline.resolve_out_path('/tmp/metrics.nc', None) == '/tmp/metrics.nc'
 
 
+def test_deferred_results_equal_synchronous_results(backend):
+  """engine.deferred_results(): aggregate_statistics returns before the sums have arrived; the AggregationState
+  waits on first use, states combine (CombiningSum, beam_pipeline.py:509-510) and pickle like synchronous ones."""
+  import pickle
+  from weatherbenchx_amd import binning, engine, weighting
+  predictions, targets = _datasets()
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  load = _loader(predictions, targets)
+  # WindVectorRMSE is a LinearCombination of two fused reductions: its terms are combined on the host, so the
+  # aggregator has to resolve them itself
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE(),
+             'wind': deterministic.WindVectorRMSE('geopotential', 'geopotential', 'wind')}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                               weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions({'global': ((-90, 90), (0, 360)), 'nh': ((20, 90), (0, 360))})])
+  chunks = [load(init_times[i:i + 1], lead_times) for i in range(len(init_times))]
+  sync_states = [agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+                 for p, t in chunks]
+  want = aggregation.AggregationState.sum(sync_states).metric_values(metrics)
+  with engine.deferred_results():
+    assert engine.deferred_active() is not None
+    states = [agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+              for p, t in chunks]  # every chunk is launched before any result is looked at
+    clone = pickle.loads(pickle.dumps(states[0]))  # pickling waits
+    total = aggregation.AggregationState.sum(states)
+    got = total.metric_values(metrics)
+  assert engine.deferred_active() is None
+  for k in want:
+    xr.assert_allclose(got[k], want[k], rtol=1e-12, atol=0, check_dim_order=False)
+  xarray_tree.map_structure(lambda a, b: xr.assert_allclose(a, b, rtol=1e-12, atol=0),
+                            clone.sum_weighted_statistics, sync_states[0].sum_weighted_statistics)
+  # single-variable entry points carry their own fence
+  with engine.deferred_results():
+    stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, *chunks[0])
+    one = agg.aggregate_stat_var(stats['SquaredError']['geopotential'])
+    arr = agg.aggregation_fn(stats['SquaredError']['geopotential'])  # a bare DataArray: resolved before returning
+    np.testing.assert_allclose(arr.values, one.wait().sum_weighted_statistics.values, rtol=1e-12)
+
+
 def test_time_chunks_lengths_and_offsets():
   init_times = np.arange('2020-01-01T00', '2020-01-02T00', np.timedelta64(6, 'h'), dtype='datetime64[ns]')
   lead_times = np.arange(0, 18, 6, dtype='timedelta64[h]')

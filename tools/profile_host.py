@@ -43,4 +43,4 @@ for _ in range(50):
   step()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+st.sort_stats('tottime').print_stats(40)

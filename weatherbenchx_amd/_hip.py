@@ -29,7 +29,8 @@ EXPORTED_SYMBOLS = (
     'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
     'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
     'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_det_map', 'wbx_ens_map',
-    'wbx_zonal_spectrum',
+    'wbx_zonal_spectrum', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
+    'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy',
 )
 
 
@@ -94,6 +95,13 @@ def load_library():
         'wbx_memcpy_h2d': [vp, vp, vp, C.c_size_t],
         'wbx_memcpy_d2h': [vp, vp, vp, C.c_size_t],
         'wbx_memset': [vp, vp, i32, C.c_size_t],
+        'wbx_host_alloc': [vp, C.c_size_t, C.POINTER(vp)],
+        'wbx_host_free': [vp, vp],
+        'wbx_memcpy_d2h_async': [vp, vp, vp, C.c_size_t],
+        'wbx_fence_create': [vp, C.POINTER(vp)],
+        'wbx_fence_record': [vp, vp],
+        'wbx_fence_wait': [vp],
+        'wbx_fence_destroy': [vp],
         'wbx_timer_start': [vp],
         'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
         'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],
@@ -155,6 +163,50 @@ class DeviceBuffer:
       pass
 
 
+class PinnedBlock:
+  """Page-locked host memory from the context's pool, exposed through the array interface: `np.asarray(block)` is a
+  float64 view that keeps the block alive; when the last view dies the memory goes back to the pool."""
+
+  def __init__(self, ctx: 'Context', ptr: int, capacity: int, nbytes: int):
+    self._ctx, self._ptr, self._capacity = ctx, ptr, capacity
+    self.__array_interface__ = {'shape': (nbytes // 8,), 'typestr': '<f8', 'data': (ptr, False), 'version': 3}
+
+  @property
+  def ptr(self) -> int:
+    return self._ptr
+
+  def __del__(self):
+    try:
+      self._ctx._pinned_free.setdefault(self._capacity, []).append(self._ptr)  # pylint: disable=protected-access
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+class Fence:
+  """hipEvent recorded on the context stream: `wait()` blocks the host until everything enqueued before it is done."""
+
+  def __init__(self, ctx: 'Context'):
+    self._lib = ctx.lib
+    h = C.c_void_p(0)
+    check(ctx.lib.wbx_fence_create(ctx.handle, C.byref(h)), 'wbx_fence_create')
+    self._h = h
+    check(ctx.lib.wbx_fence_record(ctx.handle, h), 'wbx_fence_record')
+    self._done = False
+
+  def wait(self):
+    if not self._done:
+      check(self._lib.wbx_fence_wait(self._h), 'wbx_fence_wait')
+      self._done = True
+
+  def __del__(self):
+    try:
+      if self._h:
+        self._lib.wbx_fence_destroy(self._h)
+        self._h = None
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
 class Context:
   """One device + one HIP stream (wbx_ctx).  `torch_stream=True` adopts torch's current stream so
   launches order with tensors produced by torch on that stream."""
@@ -165,9 +217,14 @@ class Context:
     check(self.lib.wbx_ctx_create(int(device_id), C.c_void_p(stream_ptr or 0), C.byref(h)), 'wbx_ctx_create')
     self.handle = h
     self.device_id = int(device_id)
+    self._pinned_free: dict[int, list[int]] = {}  # capacity -> free page-locked blocks
 
   def close(self):
     if getattr(self, 'handle', None):
+      for blocks in getattr(self, '_pinned_free', {}).values():
+        for ptr in blocks:
+          self.lib.wbx_host_free(self.handle, C.c_void_p(ptr))
+      self._pinned_free = {}
       self.lib.wbx_ctx_destroy(self.handle)
       self.handle = None
 
@@ -203,6 +260,27 @@ class Context:
       check(self.lib.wbx_memcpy_d2h(self.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes),
             'wbx_memcpy_d2h')
     return out
+
+  def download_async(self, ptr: int, shape) -> np.ndarray:
+    """Enqueues the read-back of float64 `shape` into pooled page-locked memory and returns the (not yet valid) view;
+    the caller orders its reads with a Fence recorded afterwards."""
+    n = int(np.prod(shape, dtype=np.int64))
+    nbytes = n * 8
+    capacity = max(4096, 1 << (max(nbytes, 1) - 1).bit_length())
+    free = self._pinned_free.get(capacity)
+    if free:
+      hptr = free.pop()
+    else:
+      p = C.c_void_p(0)
+      check(self.lib.wbx_host_alloc(self.handle, capacity, C.byref(p)), 'wbx_host_alloc')
+      hptr = p.value
+    block = PinnedBlock(self, hptr, capacity, nbytes)
+    if nbytes:
+      check(self.lib.wbx_memcpy_d2h_async(self.handle, C.c_void_p(hptr), C.c_void_p(ptr), nbytes), 'wbx_memcpy_d2h_async')
+    return np.asarray(block).reshape(shape)
+
+  def fence(self) -> Fence:
+    return Fence(self)
 
   def timer_start(self):
     check(self.lib.wbx_timer_start(self.handle), 'wbx_timer_start')

@@ -42,6 +42,21 @@ class AggregationState:
 
   sum_weighted_statistics: Any
   sum_weights: Any
+  # Set by an Aggregator running inside engine.deferred_results(): the arrays above are views of page-locked memory
+  # that the GPU is still filling.  Every method below waits on it first; code that reaches into the two trees
+  # directly must call wait() itself.
+  _fence: Any = dataclasses.field(default=None, repr=False, compare=False)
+
+  def wait(self) -> 'AggregationState':
+    """Blocks until the sums of a deferred aggregation have arrived (no-op otherwise)."""
+    if self._fence is not None:
+      self._fence.wait()
+      self._fence = None
+    return self
+
+  def __getstate__(self):
+    self.wait()
+    return {'sum_weighted_statistics': self.sum_weighted_statistics, 'sum_weights': self.sum_weights, '_fence': None}
 
   @classmethod
   def zero(cls) -> 'AggregationState':
@@ -52,6 +67,7 @@ class AggregationState:
 
   @classmethod
   def sum(cls, aggregation_states: Iterable['AggregationState']) -> 'AggregationState':
+    aggregation_states = [s.wait() for s in aggregation_states]
     pairs = [(s.sum_weighted_statistics, s.sum_weights) for s in aggregation_states
              if s.sum_weighted_statistics is not None]
     if not pairs:
@@ -60,6 +76,7 @@ class AggregationState:
     return cls(sws, sw)
 
   def mean_statistics(self) -> Any:
+    self.wait()
     return xarray_tree.map_structure(lambda num, den: num / den, self.sum_weighted_statistics, self.sum_weights)
 
   def metric_values(self, metrics: Mapping[str, metrics_base.Metric]) -> xr.Dataset:
@@ -81,7 +98,7 @@ class AggregationState:
 
   @classmethod
   def map_multi(cls, func: Callable[..., xr.DataArray], *agg_states: 'AggregationState') -> 'AggregationState':
-    if any(a.sum_weighted_statistics is None for a in agg_states):
+    if any(a.wait().sum_weighted_statistics is None for a in agg_states):
       raise ValueError('Cannot map a zero AggregationState.')
     return cls(xarray_tree.map_structure(func, *[a.sum_weighted_statistics for a in agg_states]),
                xarray_tree.map_structure(func, *[a.sum_weights for a in agg_states]))
@@ -92,6 +109,7 @@ class AggregationState:
   # -- persistence: nested dict ("data tree") and flat '#'-separated Dataset (aggregation.py:203-265) ----
   def to_data_tree(self) -> dict:
     """Nested dict mirror of xr.DataTree: leaves are {'sum_weighted_statistics': da, 'sum_weights': da}."""
+    self.wait()
     if isinstance(self.sum_weighted_statistics, xr.DataArray):
       return {'sum_weighted_statistics': self.sum_weighted_statistics, 'sum_weights': self.sum_weights}
     if isinstance(self.sum_weighted_statistics, Mapping):
@@ -131,6 +149,20 @@ class AggregationState:
         node = node.setdefault(part, {})
       node[leaf] = da
     return cls.from_data_tree(tree)
+
+
+def _resolve_now():
+  """Inside engine.deferred_results(): waits for every read-back enqueued so far (host arithmetic follows)."""
+  d = engine.deferred_active()
+  if d is not None:
+    d.mark().wait()
+
+
+def _fenced(state):
+  d = engine.deferred_active()
+  if d is not None and state is not None:
+    state._fence = d.mark()  # pylint: disable=protected-access
+  return state
 
 
 def _weight_product(stat: xr.DataArray, weigh_by, bin_by):
@@ -181,24 +213,31 @@ class Aggregator:
   def aggregation_fn(self, stat: xr.DataArray) -> xr.DataArray | None:
     """sum over reduce_dims of stat * weights * bin masks (aggregation.py:297-335)."""
     state = self._aggregate(xr.as_dataarray(stat), use_mask=False, skipna=False)
+    _resolve_now()  # a bare DataArray cannot carry a fence
     return None if state is None else state.sum_weighted_statistics
 
   def aggregate_stat_var(self, stat: xr.DataArray) -> AggregationState | None:
     """One statistic of one variable -> AggregationState, or None if a reduce/bin dim is missing
     (aggregation.py:337-366)."""
+    return _fenced(self._stat_var(stat))
+
+  def aggregate_stat_vars(self, stats: Mapping[Hashable, xr.DataArray]) -> AggregationState:
+    return _fenced(self._stat_vars(stats))
+
+  def aggregate_statistics(self, statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> AggregationState:
+    per_stat = {name: self._stat_vars(stats) for name, stats in statistics.items()}
+    return _fenced(AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
+                                    {k: v.sum_weights for k, v in per_stat.items()}))
+
+  def _stat_var(self, stat: xr.DataArray) -> AggregationState | None:
     stat = xr.as_dataarray(stat)
     return self._aggregate(stat, use_mask=self.masked and 'mask' in stat.coords, skipna=self.skipna)
 
-  def aggregate_stat_vars(self, stats: Mapping[Hashable, xr.DataArray]) -> AggregationState:
-    per_var = {name: self.aggregate_stat_var(s) for name, s in stats.items() if s is not None}
+  def _stat_vars(self, stats: Mapping[Hashable, xr.DataArray]) -> AggregationState:
+    per_var = {name: self._stat_var(s) for name, s in stats.items() if s is not None}
     per_var = {k: v for k, v in per_var.items() if v is not None}
     return AggregationState({k: v.sum_weighted_statistics for k, v in per_var.items()},
                             {k: v.sum_weights for k, v in per_var.items()})
-
-  def aggregate_statistics(self, statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> AggregationState:
-    per_stat = {name: self.aggregate_stat_vars(stats) for name, stats in statistics.items()}
-    return AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
-                            {k: v.sum_weights for k, v in per_stat.items()})
 
   # ---- implementation ---------------------------------------------------------------------------------
   def _aggregate(self, stat: xr.DataArray, *, use_mask: bool, skipna: bool) -> AggregationState | None:
@@ -212,6 +251,7 @@ class Aggregator:
 
     if isinstance(stat, lazy.LinearCombination) and stat.is_lazy and not use_mask and not skipna:
       parts = [self._aggregate(term, use_mask=False, skipna=False) for term in stat._terms]  # pylint: disable=protected-access
+      _resolve_now()  # the terms are combined on the host
       sws = parts[0].sum_weighted_statistics
       for p in parts[1:]:
         sws = sws + p.sum_weighted_statistics
@@ -237,13 +277,21 @@ class Aggregator:
         if set(v[0]) <= set(final_dims):
           coords.setdefault(k, v)
 
+    pending = engine.deferred_active() is not None
+    if pending and scale != 1.0:
+      _resolve_now()  # scaling reads the sums
+      pending = False
+
     def wrap(arr):
       da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
       da = da.transpose(*final_dims)
-      return xr.DataArray(np.array(da.values, order="C", copy=True), dims=final_dims, coords=coords, name=stat.name,
-                          attrs=stat.attrs, _raw_coords=True)
+      # deferred: keep the (possibly strided) view of the page-locked buffer the GPU is still writing -- no reads here
+      data = da.data if pending else np.array(da.values, order="C", copy=True)
+      return xr.DataArray(data, dims=final_dims, coords=coords, name=stat.name, attrs=stat.attrs, _raw_coords=True)
 
-    return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
+    if scale != 1.0:
+      return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
+    return AggregationState(wrap(values[lane]), wrap(counts[lane]))
 
   def _cached_weight_product(self, stat: xr.DataArray):
     """W = prod(weights) * prod(bin masks) is rebuilt by the reference for every (statistic, variable)

@@ -123,6 +123,66 @@ extern "C" int wbx_memcpy_d2h(wbx_ctx* ctx, void* h_dst, const void* dptr, size_
   return 0;
 }
 
+// ---- deferred results: pinned host memory, asynchronous read-back, fences ---------------------------------
+extern "C" int wbx_host_alloc(wbx_ctx* ctx, size_t bytes, void** h_out) {
+  WBX_REQUIRE(ctx != nullptr && h_out != nullptr, "NULL argument");
+  WBX_HIP(hipSetDevice(ctx->device));
+  WBX_HIP(hipHostMalloc(h_out, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+
+extern "C" int wbx_host_free(wbx_ctx* ctx, void* h_ptr) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (h_ptr) WBX_HIP(hipHostFree(h_ptr));
+  return 0;
+}
+
+extern "C" int wbx_memcpy_d2h_async(wbx_ctx* ctx, void* h_pinned, const void* dptr, size_t bytes) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (bytes == 0) return 0;
+  WBX_REQUIRE(dptr != nullptr && h_pinned != nullptr, "NULL pointer");
+  WBX_HIP(hipSetDevice(ctx->device));
+  WBX_HIP(hipMemcpyAsync(h_pinned, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+struct wbx_fence {
+  hipEvent_t ev;
+};
+
+extern "C" int wbx_fence_create(wbx_ctx* ctx, wbx_fence** out) {
+  WBX_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+  WBX_HIP(hipSetDevice(ctx->device));
+  wbx_fence* f = new wbx_fence;
+  hipError_t e = hipEventCreateWithFlags(&f->ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    delete f;
+    WBX_HIP(e);
+  }
+  *out = f;
+  return 0;
+}
+
+extern "C" int wbx_fence_record(wbx_ctx* ctx, wbx_fence* f) {
+  WBX_REQUIRE(ctx != nullptr && f != nullptr, "NULL argument");
+  WBX_HIP(hipEventRecord(f->ev, ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_fence_wait(wbx_fence* f) {
+  WBX_REQUIRE(f != nullptr, "fence is NULL");
+  WBX_HIP(hipEventSynchronize(f->ev));
+  return 0;
+}
+
+extern "C" int wbx_fence_destroy(wbx_fence* f) {
+  if (f) {
+    (void)hipEventDestroy(f->ev);
+    delete f;
+  }
+  return 0;
+}
+
 extern "C" int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (bytes == 0) return 0;

@@ -61,6 +61,7 @@ def all_reduce_state(state: AggregationState, group=None) -> AggregationState:
 
   if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
     return state
+  state.wait()
   flat, layout, items = pack_state(state)
   backend = dist.get_backend(group)
   dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')

@@ -8,6 +8,7 @@ tensors already resident in HBM (consumed in place through their strides: no cop
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Sequence
 
@@ -282,6 +283,66 @@ def _run_map(ctx, kind: str, dplan, plan: planner.S1Plan, devs, dtype_code: int,
   return ctx.download(out.ptr, (n,), np.float64)
 
 
+class DeferredResults:
+  """Active inside `deferred_results()`: stage-2 / binned outputs are read back asynchronously into page-locked
+  memory and `reduce_statistics` returns views whose CONTENT is valid only after the fence of `mark()` is waited on."""
+
+  def __init__(self):
+    self.ctxs = {}       # contexts with read-backs enqueued since the last mark()
+    self.keepalive = []  # payloads the enqueued kernels read (torch tensors, cached device buffers)
+
+  def mark(self):
+    """Fence covering every read-back enqueued so far (a no-op object when there was none)."""
+    fences = [ctx.fence() for ctx in self.ctxs.values()]
+    keep, self.ctxs, self.keepalive = self.keepalive, {}, []
+    return ResultFence(fences, keep)
+
+
+class ResultFence:
+  """Holds the kernels' inputs until they have run: torch's caching allocator would otherwise hand a dropped
+  tensor's memory to the next chunk while a kernel on the wbx stream is still reading it."""
+
+  def __init__(self, fences=(), keepalive=()):
+    self._fences = list(fences)
+    self._keepalive = list(keepalive)
+
+  def wait(self):
+    for f in self._fences:
+      f.wait()
+    self._fences = []
+    self._keepalive = []
+
+
+_deferred: DeferredResults | None = None
+
+
+@contextlib.contextmanager
+def deferred_results():
+  """Opt-in overlap of the host with the GPU: inside the block `Aggregator.aggregate_statistics` returns at once with
+  an AggregationState that waits for its own results on first use (`state.wait()`, or any of its methods).  Reading
+  the raw arrays of such a state before that is undefined.  pipeline.evaluate_chunks and bench.py use it to launch
+  chunk k+1 before combining chunk k."""
+  global _deferred
+  prev, mine = _deferred, DeferredResults()
+  _deferred = mine
+  try:
+    yield mine
+  finally:
+    _deferred = prev
+    mine.mark().wait()
+
+
+def deferred_active() -> DeferredResults | None:
+  return _deferred
+
+
+def _download(ctx, ptr: int, shape) -> np.ndarray:
+  if _deferred is not None:
+    _deferred.ctxs[id(ctx)] = ctx
+    return ctx.download_async(ptr, shape)
+  return ctx.download(ptr, shape, np.float64)
+
+
 def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
   st = _hip.S2PlanStruct(s2.nA, s2.nBk, s2.nBr, s2.nchunk, s2.nlane, s2.nj, s2.nbin, int(s2.sum_j))
   shape = s2.out_shape()
@@ -293,7 +354,7 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
   else:
     _hip.check(ctx.lib.wbx_contract(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.bufs[0].ptr),
                                     C.c_void_p(out.ptr)), 'wbx_contract')
-  return ctx.download(out.ptr, shape, np.float64)
+  return _download(ctx, out.ptr, shape)
 
 
 # 'auto': the fused binned kernel runs when the stage-1 partials would exceed BINNED_PARTIAL_RATIO x the input bytes
@@ -335,7 +396,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
                                       C.c_void_p(out.ptr)), 'wbx_det_binned')
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin})
-  return ctx.download(out.ptr, shape, np.float64)
+  return _download(ctx, out.ptr, shape)
 
 
 def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
@@ -367,6 +428,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   (A dims..., Bk dims..., [x dim], bin dims...); `counts` is the matching sum of W over valid
   elements -- per lane when mask/skipna is active, else a single array shared by every lane.
   """
+  global _deferred
   ctx = ctx or _hip.default_context()
   wdep = set(w_da.dims) - set(bin_dims) if w_da is not None else set()
   member_dim = ens['member_dim'] if ens else None
@@ -387,6 +449,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   if ens and ens.get('skipna', False):
     flags |= _hip.FLAG_SKIPNA_ENS
   layouts = [d.layout if d is not None else None for d in devs]
+  if _deferred is not None:
+    _deferred.keepalive.append((datas, devs))
   plan, dplan = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
   nl = _hip.DET_LANES[func] if kind == 'det' else _hip.ENS_LANES
   counted = bool(flags & 3)
@@ -423,7 +487,11 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
       ones = np.full((1, s2.nBk, s2.nBr, 1, 1, s2.nj), float(plan.reduced_count_per_partial()), dtype=np.float64)
       s2c = planner.S2Plan(nA=1, nBk=s2.nBk, nBr=s2.nBr, nchunk=1, nlane=1, nj=s2.nj, nbin=s2.nbin, sum_j=s2.sum_j)
       ones_buf = ctx.upload(ones)
-      cnt = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
+      saved, _deferred = _deferred, None  # computed once per geometry and cached: read it back synchronously
+      try:
+        cnt = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
+      finally:
+        _deferred = saved
       if len(_count_cache) > 64:
         _count_cache.clear()
       _count_cache[ckey] = (cnt, w_buf)  # keep w_buf alive so its id stays unique

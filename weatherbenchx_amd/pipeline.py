@@ -14,6 +14,7 @@ import numpy as np
 
 from weatherbenchx_amd import aggregation
 from weatherbenchx_amd import distributed
+from weatherbenchx_amd import engine
 from weatherbenchx_amd import time_chunks as tc
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base as metrics_base
@@ -46,20 +47,35 @@ def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[s
   # acc[agg][type][stat][var][(init_off, lead_off)] -> DataArray
   acc = {name: {'sum_weighted_statistics': {}, 'sum_weights': {}} for name in aggregators}
   work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
-  for offsets, (init_chunk, lead_chunk) in work:
-    predictions, targets = load_chunk(init_chunk, lead_chunk)
-    for stat_name, stats in metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets):
-      for var_name, stat in stats.items():
-        for agg_name, agg in aggregators.items():
-          state = agg.aggregate_stat_var(stat)
-          if state is None:
-            continue
-          dims = state.sum_weighted_statistics.dims
-          key = (offsets.init_time if 'init_time' in dims else None, offsets.lead_time if 'lead_time' in dims else None)
-          for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics),
-                           ('sum_weights', state.sum_weights)):
-            slot = acc[agg_name][kind].setdefault(stat_name, {}).setdefault(str(var_name), {})
-            slot[key] = da if key not in slot else aggregation.combining_sum([slot[key], da])
+
+  def commit(entries):
+    # CombiningSum of one chunk's accumulators (beam_pipeline.py:509-510); waits for that chunk's read-back only
+    for state, agg_name, stat_name, var_name, key in entries:
+      state.wait()
+      for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
+        slot = acc[agg_name][kind].setdefault(stat_name, {}).setdefault(str(var_name), {})
+        slot[key] = da if key not in slot else aggregation.combining_sum([slot[key], da])
+
+  # Software pipeline over chunks: the sums of chunk k are read back asynchronously and combined only after the
+  # kernels of chunk k+1 have been enqueued, so the GPU never waits for the host-side bookkeeping.
+  with engine.deferred_results():
+    previous = []
+    for offsets, (init_chunk, lead_chunk) in work:
+      predictions, targets = load_chunk(init_chunk, lead_chunk)
+      entries = []
+      for stat_name, stats in metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets):
+        for var_name, stat in stats.items():
+          for agg_name, agg in aggregators.items():
+            state = agg.aggregate_stat_var(stat)
+            if state is None:
+              continue
+            dims = state.sum_weighted_statistics.dims
+            key = (offsets.init_time if 'init_time' in dims else None,
+                   offsets.lead_time if 'lead_time' in dims else None)
+            entries.append((state, agg_name, stat_name, var_name, key))
+      commit(previous)
+      previous = entries
+    commit(previous)
   out = {}
   for agg_name in aggregators:
     trees = {}
