@@ -284,3 +284,72 @@ def test_torch_views_are_consumed_in_place(ctx, case):
   # and the per-point statistic through the map kernel
   se = deterministic.SquaredError().compute(p, t)['v']
   np.testing.assert_allclose(se.values, O.squared_error(_np(pt), te), rtol=1e-12)
+
+
+@pytest.mark.parametrize('nlane,nchunk,nj,nbin', [(1, 1, 64, 5), (3, 1, 200, 14), (5, 1, 130, 34), (6, 3, 97, 34),
+                                                  (7, 1, 64, 64), (10, 2, 70, 20), (12, 1, 257, 9), (2, 1, 1440, 40)])
+def test_stage2_patch_kernel_equals_dense_contraction(ctx, monkeypatch, nlane, nchunk, nj, nbin):
+  """wbx_contract_bits over full-map partials takes the patch kernel (wbx_s2_patch.hip); it must equal the dense
+  contraction  out[a,b,l,bin] = sum_{r,c,j} partial[a,b,r,c,l,j] * wt[b,r,j] * member[b,r,j,bin]  including the
+  NaN-poisons-every-bin rule and more bins in a patch than accumulator slots."""
+  monkeypatch.setenv('WBX_S2_PATCH_MIN', '0')
+  rng = np.random.default_rng(nlane * 1000 + nj)
+  nA, nBk, nBr = 3, 2, 37
+  partial = rng.normal(size=(nA, nBk, nBr, nchunk, nlane, nj))
+  partial[1, 0, 5, 0, 0, 3] = np.nan  # lane 0 of cell (1, 0) is poisoned for every bin
+  wt = rng.random((nBk, nBr, nj)) + 0.5
+  member = rng.random((nBk, nBr, nj, nbin)) < 0.3
+  member[..., 0] = True
+  member[:, :, :, nbin - 1] = False  # an empty bin
+  bits = np.zeros((nBk, nBr, nj), np.uint64)
+  for b in range(nbin):
+    bits |= member[..., b].astype(np.uint64) << np.uint64(b)
+  with np.errstate(invalid='ignore'):
+    want = np.einsum('abrclj,brjn->abln', partial, wt[..., None] * member)
+  plan = _hip.S2PlanStruct(nA, nBk, nBr, nchunk, nlane, nj, nbin, 1)
+  bufs = [ctx.upload(partial), ctx.upload(wt), ctx.upload(bits)]
+  out = ctx.alloc(want.size * 8)
+  _hip.check(ctx.lib.wbx_contract_bits(ctx.handle, C.byref(plan), C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
+                                       C.c_void_p(bufs[2].ptr), C.c_void_p(out.ptr)), 'wbx_contract_bits')
+  got = ctx.download(out.ptr, want.shape, np.float64)
+  assert np.isnan(got[1, 0, 0]).all() and np.isnan(want[1, 0, 0]).all()
+  np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+  assert (got[..., nbin - 1][~np.isnan(got[..., nbin - 1])] == 0).all()
+  # the block-per-(cell, lane) kernel gives the same numbers
+  monkeypatch.setenv('WBX_S2_PATCH_MIN', str(1 << 40))
+  _hip.check(ctx.lib.wbx_contract_bits(ctx.handle, C.byref(plan), C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
+                                       C.c_void_p(bufs[2].ptr), C.c_void_p(out.ptr)), 'wbx_contract_bits')
+  np.testing.assert_allclose(ctx.download(out.ptr, want.shape, np.float64), got, rtol=1e-12, atol=1e-12)
+
+
+def test_ensemble_crps_per_region_uses_the_patch_contraction(ctx, monkeypatch):
+  """CRPS per region x land/sea (the public benchmark's probabilistic configuration) on a 1-init chunk: the ensemble
+  kernel writes a full-map partial and wbx_contract_bits bins it; result == oracle."""
+  from weatherbenchx_amd import binning
+  monkeypatch.setenv('WBX_S2_PATCH_MIN', '0')
+  rng = np.random.default_rng(3)
+  nlat, nlon, m = 48, 128, 8
+  lat, lon = np.linspace(-87, 87, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  tv = rng.normal(size=(2, nlat, nlon)).astype(np.float32)
+  pv = (tv[:, None] + rng.normal(size=(2, m, nlat, nlon))).astype(np.float32)
+  coords = {'lead_time': np.arange(2) * np.timedelta64(6, 'h'), 'latitude': lat, 'longitude': lon}
+  t = xr.DataArray(tv, dims=('lead_time', 'latitude', 'longitude'), coords=coords)
+  p = xr.DataArray(pv, dims=('lead_time', 'number', 'latitude', 'longitude'), coords=coords)
+  regions = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'nh': ((20, 90), (0, 360)),
+             'sh': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)), 'namerica': ((25, 60), (240, 285))}
+  land = rng.random((nlat, nlon)) > 0.6
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(regions, land_sea_mask=lsm)])
+  got = aggregation.compute_metric_values_for_single_chunk({'crps': probabilistic.CRPSEnsemble(use_sort=True)}, agg,
+                                                           {'v': p}, {'v': t})['crps.v']
+  pd, td = ('lead_time', 'number', 'latitude', 'longitude'), ('lead_time', 'latitude', 'longitude')
+  skill = O.crps_skill(pv, pd, tv, td, 'number')[0]
+  spread = O.crps_spread(pv, pd, 'number', use_sort=True)[0]
+  w = (O.grid_area_weights(lat), ('latitude',))
+  names, masks = O.region_masks(lat, lon, regions, land_sea_mask=land)
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  a = O.aggregate(skill, td, ['latitude', 'longitude'], weights=[w], bin_masks=bm)
+  b = O.aggregate(spread, td, ['latitude', 'longitude'], weights=[w], bin_masks=bm)
+  assert list(got['region'].values) == names
+  np.testing.assert_allclose(got.transpose(*a[2]).values, O.crps(a[0] / a[1], b[0] / b[1]), rtol=RTOL)

@@ -64,9 +64,22 @@ for name, mode, agg in (
   for _ in range(n):
     out = step()
   ms = (time.perf_counter() - t0) / n * 1e3
+  # the same chunks through the software pipeline of pipeline.evaluate_chunks (read-back deferred one chunk)
+  t0 = time.perf_counter()
+  with engine.deferred_results():
+    prev = None
+    for _ in range(n * 3):
+      pp = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}
+      tt = {'z': xr.DataArray(t_t, dims=dims, coords=coords)}
+      cur = agg.aggregate_statistics(mb.compute_unique_statistics_for_all_metrics(metrics, pp, tt))
+      if prev is not None:
+        out = prev.metric_values(metrics)
+      prev = cur
+    out = prev.metric_values(metrics)
+  ms_pipe = (time.perf_counter() - t0) / (n * 3) * 1e3
   engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
   step()
   k_ms = [e['ms'] for e in engine.S1_EVENT_LOG]
   engine.S1_EVENT_LOG = None
-  print(f'{layout} ni={ni} {name:18s}: {ms:7.2f} ms/chunk ({pts * 12 / ms / 1e6:7.1f} GB/s algorithmic, {pts * 12 / 1e9:.2f} GB)  '
+  print(f'{layout} ni={ni} {name:18s}: {ms:7.2f} ms/chunk sync, {ms_pipe:6.2f} pipelined ({pts * 12 / ms_pipe / 1e6:7.1f} GB/s algorithmic, {pts * 12 / 1e9:.2f} GB)  '
         f'stage-1/fused kernels {sum(k_ms):.2f} ms   acc[0]={np.asarray(out["acc.z"].values).reshape(-1)[0]:.4f}')

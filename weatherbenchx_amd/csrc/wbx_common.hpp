@@ -33,6 +33,13 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Sum over the 64 lanes of a wave (every lane gets the total; all lanes must be active).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 }  // namespace wbx
 
 #define WBX_HIP(expr)                                                                   \

@@ -20,62 +20,10 @@
 // the conventions of wbx_det_partial.
 #include <type_traits>
 
+#include "wbx_patch.hpp"
 #include "wbx_s1.hpp"
 
 namespace wbx {
-
-struct BinnedArgs {
-  const double* wt;                  // [nBk][nBr][nj]
-  const unsigned long long* bits;    // [nBk][nBr][nj]
-  int64_t nBk, nBr, nj;              // nj = nx if W depends on x, else 1
-  int32_t nbin, nxt, nrs;            // x tiles, row splits: npatch = nrs * nxt
-  int64_t rows_per_split;            // rows = nBr * D
-  int64_t ncell, nblocks;            // nA * nBk, ncell * npatch
-  double* tmp;                       // [cell][patch][NA][nbin], zeroed
-  double* tmp_poison;                // [cell][patch][NA]
-  unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
-};
-
-__device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
-  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
-  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-
-// OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
-__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
-  int x = (int)v;
-  x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, true);  // row_ror:4
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);  // row_ror:8  -> every lane holds its row's OR
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3
-  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
-}
-
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-  return ((unsigned long long)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
-}
-
-// uni[bk][patch] |= OR of bits over the patch's (rows, 64 x); the 4 waves of a block interleave over the rows
-__global__ void __launch_bounds__(256) binned_union_kernel(BinnedArgs g, int64_t D, int64_t nx) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t b = blockIdx.x;
-  const int xt = (int)(b % g.nxt);
-  b /= g.nxt;
-  const int rs = (int)(b % g.nrs);
-  const int64_t bk = b / g.nrs;
-  const int64_t R = g.nBr * D;
-  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
-  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
-  const bool live = (int64_t)xt * 64 + lane < nx;
-  const int64_t xw = g.nj > 1 ? (live ? (int64_t)xt * 64 + lane : nx - 1) : 0;
-  unsigned long long mine = 0ull;
-  for (int64_t br = rbeg / D + wave; br <= (rend - 1) / D; br += 4) mine |= g.bits[(bk * g.nBr + br) * g.nj + xw];
-  const unsigned long long all = wave_or64(live ? mine : 0ull);
-  if (lane == 0 && all) atomicOr(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt], all);
-}
 
 // MM: 0 none, 1 mask only (one shared count lane), 2 skipna (count lane per value lane), 3 skipna + mask.
 // K = accumulator slots, PD = rows of p, t, c in flight.
@@ -86,17 +34,9 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
   constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
   constexpr int NA = NL + NC;
   const int lane = threadIdx.x;
-  // Workgroup i runs on XCD i % 8.  Logical ids are dealt so that each XCD walks a contiguous range in order, with the
-  // cell as the fastest index: the waves resident on one XCD at a time are the same patch of many cells, so the
-  // patch's wt / bits rows (which do not depend on A) are fetched into that XCD's L2 once and hit by the others.
-  // Without this the 16 B / point of wt + bits miss L2 for every cell and cost as much fabric bandwidth as p, t, c.
-  const int64_t per_xcd = (g.nblocks + 7) / 8;
-  int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (b >= g.nblocks) return;
-  const int64_t cell = b % g.ncell;
-  b /= g.ncell;
-  const int xt = (int)(b % g.nxt);
-  const int rs = (int)(b / g.nxt);
+  int64_t cell;
+  int xt, rs;
+  if (!patch_decode(g, cell, xt, rs)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t A = cell / g.nBk;
   const int64_t R = g.nBr * a.D;
@@ -256,81 +196,17 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
   } while (todo);
 }
 
-// out[cell][lane][bin] = sum over patches of tmp[cell][patch][lane][bin] + poison[cell][patch][lane].
-// One block per (cell, lane): thread (pg, bin) sums every (256 / nbin)-th patch, LDS folds the pg.
-__global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, int nacc, int nbin,
-                                                         const double* __restrict__ tmp,
-                                                         const double* __restrict__ poison, double* __restrict__ out) {
-  __shared__ double red[256];
-  const int64_t cell = blockIdx.x / nacc;
-  const int l = (int)(blockIdx.x % nacc);
-  const int ng = 256 / nbin;
-  const int bin = threadIdx.x % nbin, pg = threadIdx.x / nbin;
-  double s = 0.0;
-  if (pg < ng)
-    for (int64_t k = pg; k < npatch; k += ng)
-      s += tmp[((cell * npatch + k) * nacc + l) * nbin + bin] + poison[(cell * npatch + k) * nacc + l];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x < nbin) {
-    for (int q = 1; q < ng; ++q) s += red[q * nbin + threadIdx.x];
-    out[(cell * nacc + l) * nbin + threadIdx.x] = s;
-  }
-}
-
 template <typename T, int FUNC, int MM, int K, int PD>
 static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
                          int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   BinnedArgs g;
-  g.wt = wt;
-  g.bits = reinterpret_cast<const unsigned long long*>(bits);
-  g.nBk = nBk;
-  g.nBr = nBr;
-  g.nj = nj;
-  g.nbin = nbin;
-  const int64_t rows = nBr * plan->ndepth;
-  const int64_t cells = nA * nBk;
-  g.nxt = (int)((plan->nx + 63) / 64);
-  // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
-  // (the lane fold at the end of a patch costs about as much as 10 rows)
-  int64_t want = (16384 + cells * g.nxt - 1) / (cells * g.nxt);
-  if (want > (rows + 63) / 64) want = (rows + 63) / 64;
-  if (want < 1) want = 1;
-  g.rows_per_split = (rows + want - 1) / want;
-  g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
-  const int64_t npatch = (int64_t)g.nrs * g.nxt;
-  const size_t n_tmp = (size_t)cells * npatch * NA * nbin, n_poison = (size_t)cells * npatch * NA;
-  const size_t n_uni = (size_t)nBk * npatch;
-  const size_t need = (n_tmp + n_poison + n_uni) * sizeof(double);
-  if (ctx->s2_scratch_size < need) {
-    if (ctx->s2_scratch) {
-      WBX_HIP(hipStreamSynchronize(ctx->stream));
-      WBX_HIP(hipFree(ctx->s2_scratch));
-      ctx->s2_scratch = nullptr;
-      ctx->s2_scratch_size = 0;
-    }
-    WBX_HIP(hipMalloc(&ctx->s2_scratch, need));
-    ctx->s2_scratch_size = need;
-  }
-  g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
-  g.uni = reinterpret_cast<unsigned long long*>(g.tmp + n_tmp);
-  g.tmp_poison = g.tmp + n_tmp + n_uni;
-  WBX_HIP(hipMemsetAsync(g.tmp, 0, (n_tmp + n_uni) * sizeof(double), ctx->stream));
-  g.ncell = cells;
-  g.nblocks = cells * npatch;
+  if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin)) return rc;
   const int64_t grid = (g.nblocks + 7) / 8 * 8;
-  WBX_REQUIRE(grid < (int64_t)1 << 31, "binned grid too large");
-  hipLaunchKernelGGL(binned_union_kernel, dim3((unsigned)(nBk * npatch)), dim3(256), 0, ctx->stream, g,
-                     (int64_t)plan->ndepth, (int64_t)plan->nx);
-  WBX_HIP(hipGetLastError());
   hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g);
   WBX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)(cells * NA)), dim3(256), 0, ctx->stream, npatch, NA, nbin, g.tmp,
-                     g.tmp_poison, out);
-  WBX_HIP(hipGetLastError());
-  return 0;
+  return patch_finish(ctx, g, NA, out);
 }
 
 template <typename T, int FUNC, int MM>

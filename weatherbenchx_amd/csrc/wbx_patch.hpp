@@ -1,0 +1,157 @@
+// Shared pieces of the "patch" reductions (wbx_det_binned.hip: fused statistics + bins; wbx_s2_patch.hip: stage 2 over
+// full-map partials): per-wave patches of the (row, x) plane, the union of a patch's bins, slot dealing, the final sum
+// over patches.  See the header comment of wbx_det_binned.hip for the design.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "wbx_common.hpp"
+
+namespace wbx {
+
+struct BinnedArgs {
+  const double* wt;                  // [nBk][nBr][nj]
+  const unsigned long long* bits;    // [nBk][nBr][nj]
+  int64_t nBk, nBr, nj;              // nj = nx if W depends on x, else 1
+  int32_t nbin, nxt, nrs;            // x tiles, row splits: npatch = nrs * nxt
+  int64_t rows_per_split;            // rows = nBr * D
+  int64_t ncell, nblocks;            // nA * nBk, ncell * npatch
+  double* tmp;                       // [cell][patch][NA][nbin], zeroed
+  double* tmp_poison;                // [cell][patch][NA]
+  unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
+};
+
+__device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, true);  // row_ror:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, true);  // row_ror:8  -> every lane holds its row's OR
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, true);  // row_bcast:15 into rows 1, 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, true);  // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  return ((unsigned long long)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
+}
+
+// uni[bk][patch] |= OR of bits over the patch's (rows, 64 x); the 4 waves of a block interleave over the rows
+static __global__ void __launch_bounds__(256) binned_union_kernel(BinnedArgs g, int64_t D, int64_t nx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t b = blockIdx.x;
+  const int xt = (int)(b % g.nxt);
+  b /= g.nxt;
+  const int rs = (int)(b % g.nrs);
+  const int64_t bk = b / g.nrs;
+  const int64_t R = g.nBr * D;
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  const bool live = (int64_t)xt * 64 + lane < nx;
+  const int64_t xw = g.nj > 1 ? (live ? (int64_t)xt * 64 + lane : nx - 1) : 0;
+  unsigned long long mine = 0ull;
+  for (int64_t br = rbeg / D + wave; br <= (rend - 1) / D; br += 4) mine |= g.bits[(bk * g.nBr + br) * g.nj + xw];
+  const unsigned long long all = wave_or64(live ? mine : 0ull);
+  if (lane == 0 && all) atomicOr(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt], all);
+}
+
+// out[cell][lane][bin] = sum over patches of tmp[cell][patch][lane][bin] + poison[cell][patch][lane].
+// One block per (cell, lane): thread (pg, bin) sums every (256 / nbin)-th patch, LDS folds the pg.
+static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, int nacc, int nbin,
+                                                         const double* __restrict__ tmp,
+                                                         const double* __restrict__ poison, double* __restrict__ out) {
+  __shared__ double red[256];
+  const int64_t cell = blockIdx.x / nacc;
+  const int l = (int)(blockIdx.x % nacc);
+  const int ng = 256 / nbin;
+  const int bin = threadIdx.x % nbin, pg = threadIdx.x / nbin;
+  double s = 0.0;
+  if (pg < ng)
+    for (int64_t k = pg; k < npatch; k += ng)
+      s += tmp[((cell * npatch + k) * nacc + l) * nbin + bin] + poison[(cell * npatch + k) * nacc + l];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < nbin) {
+    for (int q = 1; q < ng; ++q) s += red[q * nbin + threadIdx.x];
+    out[(cell * nacc + l) * nbin + threadIdx.x] = s;
+  }
+}
+
+
+// Patch geometry, scratch (tmp | uni | poison) and the union pre-kernel.  rows = nBr * D reduced rows of nx points per
+// cell; nacc = accumulated lanes.
+inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
+                       int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin) {
+  g.wt = wt;
+  g.bits = reinterpret_cast<const unsigned long long*>(bits);
+  g.nBk = nBk;
+  g.nBr = nBr;
+  g.nj = nj;
+  g.nbin = nbin;
+  const int64_t rows = nBr * D;
+  g.nxt = (int)((nx + 63) / 64);
+  // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
+  // (the lane fold at the end of a patch costs about as much as 10 rows)
+  int64_t want = (16384 + cells * g.nxt - 1) / (cells * g.nxt);
+  if (want > (rows + 63) / 64) want = (rows + 63) / 64;
+  if (want < 1) want = 1;
+  g.rows_per_split = (rows + want - 1) / want;
+  g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
+  const size_t n_uni = (size_t)nBk * npatch;
+  const size_t need = (n_tmp + n_poison + n_uni) * sizeof(double);
+  if (ctx->s2_scratch_size < need) {
+    if (ctx->s2_scratch) {
+      WBX_HIP(hipStreamSynchronize(ctx->stream));
+      WBX_HIP(hipFree(ctx->s2_scratch));
+      ctx->s2_scratch = nullptr;
+      ctx->s2_scratch_size = 0;
+    }
+    WBX_HIP(hipMalloc(&ctx->s2_scratch, need));
+    ctx->s2_scratch_size = need;
+  }
+  g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
+  g.uni = reinterpret_cast<unsigned long long*>(g.tmp + n_tmp);
+  g.tmp_poison = g.tmp + n_tmp + n_uni;
+  WBX_HIP(hipMemsetAsync(g.tmp, 0, (n_tmp + n_uni) * sizeof(double), ctx->stream));
+  g.ncell = cells;
+  g.nblocks = cells * npatch;
+  WBX_REQUIRE((g.nblocks + 7) / 8 * 8 < (int64_t)1 << 31, "patch grid too large");
+  hipLaunchKernelGGL(binned_union_kernel, dim3((unsigned)(nBk * npatch)), dim3(256), 0, ctx->stream, g, D, nx);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out) {
+  hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)(g.ncell * nacc)), dim3(256), 0, ctx->stream,
+                     (int64_t)g.nrs * g.nxt, nacc, (int)g.nbin, g.tmp, g.tmp_poison, out);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+// Block -> (cell, x tile, row split).  Workgroup i runs on XCD i % 8.  Logical ids are dealt so that each XCD walks a
+// contiguous range in order, with the cell as the fastest index: the waves resident on one XCD at a time are the same
+// patch of many cells, so the patch's wt / bits rows (which do not depend on A) are fetched into that XCD's L2 once
+// and hit by the others.  Without this the 16 B / point of wt + bits miss L2 for every cell and cost as much fabric
+// bandwidth as the data.
+__device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs) {
+  const int64_t per_xcd = (g.nblocks + 7) / 8;
+  int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (b >= g.nblocks) return false;
+  cell = b % g.ncell;
+  b /= g.ncell;
+  xt = (int)(b % g.nxt);
+  rs = (int)(b / g.nxt);
+  return true;
+}
+
+}  // namespace wbx

@@ -40,12 +40,6 @@ struct S1Args {
   int32_t lane;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // Row base offsets (elements) of every input for (key, depth row).
 template <int NIN>
 __device__ __forceinline__ void key_bases(const S1Args& a, int64_t key, int64_t (&kb)[WBX_MAX_INPUTS]) {

@@ -203,6 +203,10 @@ __global__ void __launch_bounds__(256) s2_bits_finish_kernel(int64_t nrow, int n
   out[i] = s;
 }
 
+bool s2_patch_eligible(const wbx_s2_plan& p);
+int s2_patch(wbx_ctx* ctx, const wbx_s2_plan& p, const double* partial, const double* wt, const uint64_t* bits,
+             double* out);
+
 }  // namespace wbx
 
 extern "C" int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* wt,
@@ -222,6 +226,7 @@ extern "C" int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const do
     return 0;
   }
   WBX_REQUIRE(partial != nullptr && wt != nullptr && bits != nullptr, "partial/wt/bits is NULL");
+  if (s2_patch_eligible(p)) return s2_patch(ctx, p, partial, wt, bits, out);  // full-map partials: wbx_s2_patch.hip
   const unsigned long long* b64 = reinterpret_cast<const unsigned long long*>(bits);
   int rows_per_block = 1, nsplit = 1;
   double* dst = out;
