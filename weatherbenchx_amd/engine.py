@@ -359,10 +359,11 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
 
 # 'auto': the fused binned kernel runs when the stage-1 partials would exceed BINNED_PARTIAL_RATIO x the input bytes
 # (little is reduced before the weight/bin-dependent dims); 'never' / 'always' (whenever eligible) are for A/B timing.
-# Measured on MI355X (34 region bins, 0.25 deg): fused ~0.44 ms per GB of inputs; two-stage ~0.2 ms per GB of inputs
-# plus ~5 ms per GB of partials -> break-even where the partials are ~5 % of the inputs.
+# Measured on MI355X (34 region bins, 0.25 deg): fused ~0.43 ms per GB of inputs; two-stage ~0.2 ms per GB of inputs
+# plus ~0.52 ms per GB of partials (written by stage 1, read back by the stage-2 patch kernel) -> break-even where
+# the partials are ~45 % of the inputs (about 10 inits per chunk for the 6-lane family).
 BINNED_MODE = 'auto'
-BINNED_PARTIAL_RATIO = 0.05
+BINNED_PARTIAL_RATIO = 0.45
 
 
 def _binned_eligible(kind, plan: planner.S1Plan, w_buf, devs, nl_total: int, nin: int) -> bool:
