@@ -353,3 +353,31 @@ def test_ensemble_crps_per_region_uses_the_patch_contraction(ctx, monkeypatch):
   b = O.aggregate(spread, td, ['latitude', 'longitude'], weights=[w], bin_masks=bm)
   assert list(got['region'].values) == names
   np.testing.assert_allclose(got.transpose(*a[2]).values, O.crps(a[0] / a[1], b[0] / b[1]), rtol=RTOL)
+
+
+@pytest.mark.parametrize('nx', [64, 130, 1440])
+@pytest.mark.parametrize('skipna', [False, True])
+def test_masked_reduction_with_depth_independent_mask(ctx, nx, skipna):
+  """(lat, lon) validity mask under a reduction over (init_time, longitude): the key's mask row is staged in LDS
+  (s1_xr_kernel<.., MROW>), with dword mask loads when nx % 4 == 0; masked-out points contribute exactly 0 even when
+  they hold NaN / inf, and the count lane is the number of valid points (aggregation.py:339-357)."""
+  rng = np.random.default_rng(nx)
+  shape = (5, 2, 6, nx)
+  dims = ('init_time', 'lead_time', 'latitude', 'longitude')
+  pv, tv = rng.normal(size=shape).astype(np.float32), rng.normal(size=shape).astype(np.float32)
+  valid = rng.random((6, nx)) > 0.3
+  tv[:, :, ~valid] = np.nan
+  pv[0, 0, ~valid] = np.inf
+  if skipna:
+    tv[1, 1, 2, 5] = np.nan  # an additional NaN under a valid mask point: skipna counts it out, mask alone would poison
+  p, t = xr.DataArray(pv, dims=dims), xr.DataArray(tv, dims=dims)
+  mask = xr.DataArray(valid, dims=('latitude', 'longitude'))
+  vals, cnt, od = engine.reduce_statistics('det', [p, t], dims, dict(zip(dims, shape)), ['init_time', 'longitude'], None,
+                                           (), func=_hip.DET3, mask=mask, skipna=skipna)
+  assert od == ('lead_time', 'latitude')
+  e = pv.astype(np.float64) - tv
+  ok = np.broadcast_to(valid, shape) & (~np.isnan(e) if skipna else True)
+  want = np.where(ok, e * e, 0.0).sum(axis=(0, 3))
+  np.testing.assert_allclose(vals[2], want, rtol=1e-12)
+  np.testing.assert_allclose(vals[1], np.where(ok, np.abs(e), 0.0).sum(axis=(0, 3)), rtol=1e-12)
+  np.testing.assert_allclose(cnt[2], ok.sum(axis=(0, 3)))

@@ -29,7 +29,19 @@ struct Vec4 {
 template <typename T, int V>
 __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x, int64_t xs, T (&v)[V]) {
   const T* p = reinterpret_cast<const T*>(base) + off;
-  if constexpr (V == 4) {
+  if constexpr (V == 4 && sizeof(T) == 1) {
+    // four mask bytes = one aligned dword (the planner only picks vec = 4 when every mask row starts 4-byte aligned)
+    if (xs == 1) {
+      const uint32_t q = *reinterpret_cast<const uint32_t*>(p + x);
+      v[0] = (T)(q & 0xffu);
+      v[1] = (T)((q >> 8) & 0xffu);
+      v[2] = (T)((q >> 16) & 0xffu);
+      v[3] = (T)(q >> 24);
+    } else {
+      T s = p[0];
+      v[0] = v[1] = v[2] = v[3] = s;
+    }
+  } else if constexpr (V == 4) {
     if (xs == 1) {
       using V4 = typename Vec4<T>::type;
       V4 q = *reinterpret_cast<const V4*>(p + x);
@@ -49,12 +61,16 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
 
 // FUNC: 0 = DET3 (p,t), 1 = DET6 (p,t,c), 2 = PASS1 (p).
 // MM: 0 = no count lanes; 1 = mask only (ONE count lane shared by every value lane: validity does not depend on the
-// statistic); 2 = skipna, with or without a mask (one count lane per value lane: a NaN may hit some statistics only).
+// statistic); 2 = skipna without a mask, 3 = skipna with a mask (one count lane per value lane: a NaN may hit some
+// statistics only).  Whether the mask is read is a template parameter, not a run-time flag: a load under a branch
+// makes the compiler drain the whole load queue (s_waitcnt vmcnt(0)) instead of waiting for the oldest load.
 template <typename T, int FUNC, int MM>
 struct DetOp {
   static constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   static constexpr int NLANE = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
-  static constexpr int NACC = NLANE + (MM == 1 ? 1 : (MM == 2 ? NLANE : 0));
+  static constexpr int NACC = NLANE + (MM == 1 ? 1 : (MM >= 2 ? NLANE : 0));
+  static constexpr bool HAS_MASK = MM == 1 || MM == 3;
+  static constexpr bool MROW_OK = HAS_MASK;
   static constexpr int XR_UNROLL = 2, XK_UNROLL = 4, MIN_WAVES = 1;
 
   __device__ __forceinline__ static void lanes(double p, double t, double c, double (&val)[NLANE]) {
@@ -86,21 +102,47 @@ struct DetOp {
   template <int V, bool XK>
   __device__ __forceinline__ static void accum(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
                                                double (&acc)[XK ? V : 1][NACC]) {
+    uint8_t m[V];
+    if constexpr (HAS_MASK) load_x<uint8_t, V>(a.in[3], ro[3], x, a.xstride[3], m);
+    fold<V, XK>(a, ro, x, acc, m);
+  }
+
+  // mask row staged in LDS by the kernel (unit x stride)
+  template <int V>
+  __device__ __forceinline__ static void accum_mrow(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                                    double (&acc)[1][NACC], const uint8_t* mrow) {
+    uint8_t m[V];
+    if constexpr (V == 4) {
+      const uint32_t q = *reinterpret_cast<const uint32_t*>(mrow + x);
+      m[0] = (uint8_t)(q & 0xffu);
+      m[1] = (uint8_t)((q >> 8) & 0xffu);
+      m[2] = (uint8_t)((q >> 16) & 0xffu);
+      m[3] = (uint8_t)(q >> 24);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) m[k] = mrow[x + k];
+    }
+    fold<V, false>(a, ro, x, acc, m);
+  }
+
+  template <int V, bool XK>
+  __device__ __forceinline__ static void fold(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                              double (&acc)[XK ? V : 1][NACC], const uint8_t (&m)[V]) {
     T p[V], t[V] = {}, c[V] = {};
     load_x<T, V>(a.in[0], ro[0], x, a.xstride[0], p);
     if constexpr (NIN > 1) load_x<T, V>(a.in[1], ro[1], x, a.xstride[1], t);
     if constexpr (NIN > 2) load_x<T, V>(a.in[2], ro[2], x, a.xstride[2], c);
-    uint8_t m[V];
-    if constexpr (MM) {
-      if (a.flags & WBX_FLAG_MASKED) {
-        load_x<uint8_t, V>(a.in[3], ro[3], x, a.xstride[3], m);
-      } else {
-#pragma unroll
-        for (int k = 0; k < V; ++k) m[k] = 1;
-      }
-    }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
+      bool valid = true;
+      if constexpr (HAS_MASK) {
+        // a masked-out point contributes 0 to every lane whatever its values (aggregation.py:339-357): zeroing the
+        // three INPUTS (p = t = c = 0 -> every statistic is exactly 0) costs 3 selects instead of 2 per fp64 lane
+        valid = m[k] != 0;
+        p[k] = valid ? p[k] : T(0);
+        if constexpr (NIN > 1) t[k] = valid ? t[k] : T(0);
+        if constexpr (NIN > 2) c[k] = valid ? c[k] : T(0);
+      }
       double val[NLANE];
       lanes((double)p[k], NIN > 1 ? (double)t[k] : 0.0, NIN > 2 ? (double)c[k] : 0.0, val);
       double(&A)[NACC] = acc[XK ? k : 0];
@@ -108,16 +150,15 @@ struct DetOp {
 #pragma unroll
         for (int l = 0; l < NLANE; ++l) A[l] += val[l];
       } else if constexpr (MM == 1) {
-        const bool ok = m[k] != 0;
 #pragma unroll
-        for (int l = 0; l < NLANE; ++l) A[l] += ok ? val[l] : 0.0;
-        A[NLANE] += ok ? 1.0 : 0.0;
+        for (int l = 0; l < NLANE; ++l) A[l] += val[l];
+        A[NLANE] += valid ? 1.0 : 0.0;
       } else {
 #pragma unroll
         for (int l = 0; l < NLANE; ++l) {
-          const bool ok = m[k] != 0 && !(val[l] != val[l]);
-          A[l] += ok ? val[l] : 0.0;
-          A[NLANE + l] += ok ? 1.0 : 0.0;
+          const bool fin = !(val[l] != val[l]);
+          A[l] += fin ? val[l] : 0.0;
+          A[NLANE + l] += (fin && valid) ? 1.0 : 0.0;
         }
       }
     }
@@ -142,8 +183,18 @@ static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   // count-lane variant stays on one element per lane: the 4-wide form was measured SLOWER on MI355X (masked 2.62 vs
   // 2.30 ms, skipna 2.39 vs 1.73 ms on f32[16,10,5,721,1440]) -- 24 fp64 accumulators + selects cost more occupancy
   // than the wider loads return.
-  if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<DetOp<T, FUNC, 2>, 1>(ctx, plan, a);
-  if (mm) return launch_partial<DetOp<T, FUNC, 1>, 1>(ctx, plan, a);
+  const bool masked = plan->flags & WBX_FLAG_MASKED;
+  if (plan->flags & WBX_FLAG_SKIPNA) {
+    if (masked) return launch_partial<DetOp<T, FUNC, 3>, 1>(ctx, plan, a);
+    return launch_partial<DetOp<T, FUNC, 2>, 1>(ctx, plan, a);
+  }
+  if (masked) {
+    // (lat, lon) mask under a reduction over init_time: same mask row for every depth row of a key -> LDS
+    const bool mrow = !plan->x_kept && plan->depth_off[3] == nullptr && plan->xstride[3] == 1 &&
+                      plan->nx <= WBX_MROW_MAX && plan->ndepth > 1;
+    if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, 1>, 4>(ctx, plan, a, mrow);
+    return launch_partial<DetOp<T, FUNC, 1>, 1>(ctx, plan, a, mrow);
+  }
   if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, 0>, 4>(ctx, plan, a);
   return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
 }

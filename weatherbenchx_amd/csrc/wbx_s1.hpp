@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "wbx_common.hpp"
 
@@ -58,7 +59,17 @@ __device__ __forceinline__ void row_bases(const S1Args& a, const int64_t (&kb)[W
 
 // ---------------------------------------------------------------------------------------------
 // x summed away.  grid = nkey * nchunk blocks, block = 64..256 threads.
-template <class Op, int V>
+// MROW: the validity mask does not depend on the depth dims (a (lat, lon) mask under an (init) reduction): the key's
+// mask row is staged in LDS once per block instead of being re-read from L2 for every depth row.
+constexpr int WBX_MROW_MAX = 8192;
+
+// Ops that provide accum_mrow() declare `static constexpr bool MROW_OK = true`.
+template <class Op, class = void>
+struct op_has_mrow : std::false_type {};
+template <class Op>
+struct op_has_mrow<Op, std::void_t<decltype(Op::MROW_OK)>> : std::integral_constant<bool, Op::MROW_OK> {};
+
+template <class Op, int V, bool MROW = false>
 __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xr_kernel(S1Args a) {
   constexpr int NA = Op::NACC;
   const int lane = threadIdx.x & 63;
@@ -76,11 +87,23 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xr_kernel(S1Args a) {
 #pragma unroll
   for (int l = 0; l < NA; ++l) acc[0][l] = 0.0;
 
+  __shared__ __attribute__((aligned(16))) uint8_t smask[MROW ? WBX_MROW_MAX : 16];
+  if constexpr (MROW) {
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(a.in[3]) + kb[3];
+    for (int64_t i = threadIdx.x; i < a.nx; i += blockDim.x) smask[i] = src[i];
+    __syncthreads();
+  }
+
   for (int64_t d = d0 + wave; d < d1; d += nwave) {
     int64_t ro[WBX_MAX_INPUTS];
     row_bases<Op::NIN>(a, kb, key, d, ro);
 #pragma unroll Op::XR_UNROLL
-    for (int64_t x = (int64_t)lane * V; x < a.nx; x += 64 * V) Op::template accum<V, false>(a, ro, x, acc);
+    for (int64_t x = (int64_t)lane * V; x < a.nx; x += 64 * V) {
+      if constexpr (MROW)
+        Op::template accum_mrow<V>(a, ro, x, acc, smask);
+      else
+        Op::template accum<V, false>(a, ro, x, acc);
+    }
   }
 
   __shared__ double red[4][NA];
@@ -329,7 +352,7 @@ inline int check_plan(const wbx_s1_plan* p) {
 
 // Launch helpers -----------------------------------------------------------------------------
 template <class Op, int V>
-int launch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+int launch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool mask_row_in_lds = false) {
   if (plan->nkey == 0) return 0;
   const int64_t nj = plan->x_kept ? plan->nx : 1;
   if (plan->ndepth == 0 || plan->nx == 0) {
@@ -347,6 +370,13 @@ int launch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   } else {
     const int64_t grid = plan->nkey * plan->nchunk;
     WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+    if constexpr (op_has_mrow<Op>::value) {
+      if (mask_row_in_lds) {
+        hipLaunchKernelGGL((s1_xr_kernel<Op, V, true>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a);
+        WBX_HIP(hipGetLastError());
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((s1_xr_kernel<Op, V>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a);
   }
   WBX_HIP(hipGetLastError());
