@@ -1,0 +1,49 @@
+#!/bin/bash
+# Regenerates everything under profiles/ for one round on the GPU box (run through gpurun, then copy
+# gpurun_out/prof/{summary.txt,pmc_traffic.json,bench_*.json,*_kernel_stats.csv} into profiles/rNN_*).
+# Every profiler pass is its own bounded command; --pmc passes carry no trace domain besides --kernel-trace.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/prof
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench lines, without any profiler attached
+timeout 400 python $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err
+timeout 200 python $R/bench.py --layout lat_fastest --no-ens --no-cpu > $O/bench_n1_lat_fastest.json 2>> $O/bench_n1.err
+# 2. kernel traces (durations that bench.py's HIP-event figures must agree with)
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_bench -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_bench_lat -o r1 -- python $R/bench.py --layout lat_fastest --steps 5 --warmup 2 --no-cpu --no-ens > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_public_chunk -o r1 -- python $R/tools/kbench_binned.py lat_fastest 5 > /dev/null 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/trace_ens_regions -o r1 -- python $R/tools/bench_ens_regions.py > /dev/null 2>&1
+# 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
+timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o r1 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2>&1
+timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o r1 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu > /dev/null 2>&1
+timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_lat -o r1 -- python $R/bench.py --layout lat_fastest --steps 2 --warmup 1 --no-cpu --no-ens > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_public_chunk -o r1 -- python $R/tools/kbench_binned.py lat_fastest 3 > /dev/null 2>&1
+DBS=$(ls $O/*/r1_results.db 2>/dev/null)
+python $R/profiles/summarize_rocpd.py $DBS > $O/summary.txt 2> $O/summary.err
+python - <<PY
+import glob, json, sqlite3
+out = {}
+for db in sorted(glob.glob('$O/pmc_*/r1_results.db')):
+  cur = sqlite3.connect(db).cursor()
+  try:
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                       "where kernel_name like '%wbx::%' group by 1, 2").fetchall()
+  except sqlite3.Error as e:
+    out.setdefault('_errors', []).append(f'{db}: {e}')
+    continue
+  for k, c, n, v in rows:
+    e = out.setdefault(k.replace('void ', '').split('(')[0], {})
+    run = db.split('/')[-2]
+    if c == 'FETCH_SIZE':
+      e.update({'FETCH_SIZE_KiB_avg': v, 'launches': n, 'hbm_read_bytes': v * 1024 * 2, 'fetch_run': run})
+    elif c == 'WRITE_SIZE':
+      e.update({'WRITE_SIZE_KiB_avg': v, 'hbm_write_bytes': v * 1024, 'write_run': run})
+for k, e in out.items():
+  if isinstance(e, dict) and 'hbm_read_bytes' in e:
+    e['traffic_bytes_per_launch'] = e['hbm_read_bytes'] + e.get('hbm_write_bytes', 0.0)
+json.dump(out, open('$O/pmc_raw.json', 'w'), indent=1)
+PY
+for d in trace_bench trace_bench_lat trace_public_chunk trace_ens_regions; do cp $O/$d/r1_kernel_stats.csv $O/${d}_kernel_stats.csv 2>/dev/null; done
+rm -rf $O/*/  # the databases stay on the box; only the summaries travel back
+ls -la $O
