@@ -517,10 +517,30 @@ def test_crps_ensemble_distance(backend, m, use_sort, fair):
   np.testing.assert_allclose(a['crps.2m_temperature'].values, want, rtol=1e-9)
 
 
-def test_unbiased_mse_rejects_ensemble_targets(backend):
-  p = {'v': xr.DataArray(np.zeros((3, 4)), dims=('number', 'x'))}
+@pytest.mark.parametrize('np_members,nt_members', [(5, 3), (4, 2)])
+def test_unbiased_mse_with_an_ensemble_of_targets(backend, np_members, nt_members):
+  """probabilistic.py:320-336: (mean p - mean t)^2 - var_p / M - var_t / N per point, area-weighted.  Here it is
+  the mean over target members of the fused UEMSE lanes minus the target-variance lane (LinearCombination)."""
+  rng = np.random.default_rng(31)
+  lat = np.linspace(-80, 80, 9)
+  pv = rng.normal(size=(np_members, 2, 9, 12)).astype(np.float32) + 2.0
+  tv = rng.normal(size=(2, nt_members, 9, 12)).astype(np.float32)
+  p = {'v': xr.DataArray(pv, dims=('number', 'lead_time', 'latitude', 'longitude'), coords={'latitude': lat})}
+  t = {'v': xr.DataArray(tv, dims=('lead_time', 'number', 'latitude', 'longitude'), coords={'latitude': lat})}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  got = aggregation.compute_metric_values_for_single_chunk({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, agg, p, t)
+  p64, t64 = pv.astype(np.float64), tv.astype(np.float64)
+  stat = ((p64.mean(0) - t64.mean(1)) ** 2 - p64.var(0, ddof=1) / np_members - t64.var(1, ddof=1) / nt_members)
+  w = O.grid_area_weights(lat)[None, :, None]
+  want = np.sqrt((stat * w).sum(axis=(1, 2)) / (np.broadcast_to(w, stat.shape).sum(axis=(1, 2))))
+  np.testing.assert_allclose(got['u.v'].values, want, rtol=RTOL)
+  # the un-fused route (materialised statistic) agrees
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, p, t)
+  (name, per_var), = stats.items()
+  np.testing.assert_allclose(per_var['v'].values, stat, rtol=1e-5, atol=1e-6)
   with pytest.raises(ValueError, match='Failed to compute statistic') as info:
-    metrics_base.compute_unique_statistics_for_all_metrics({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, p, p)
+    metrics_base.compute_unique_statistics_for_all_metrics(
+        {'u': probabilistic.UnbiasedEnsembleMeanRMSE(skipna_ensemble=True)}, p, t)
   assert isinstance(info.value.__cause__, NotImplementedError)
 
 

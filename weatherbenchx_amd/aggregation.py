@@ -252,9 +252,10 @@ class Aggregator:
     if isinstance(stat, lazy.LinearCombination) and stat.is_lazy and not use_mask and not skipna:
       parts = [self._aggregate(term, use_mask=False, skipna=False) for term in stat._terms]  # pylint: disable=protected-access
       _resolve_now()  # the terms are combined on the host
-      sws = parts[0].sum_weighted_statistics
-      for p in parts[1:]:
-        sws = sws + p.sum_weighted_statistics
+      coeffs = stat._coeffs  # pylint: disable=protected-access
+      sws = parts[0].sum_weighted_statistics if coeffs[0] == 1.0 else parts[0].sum_weighted_statistics * coeffs[0]
+      for p, c in zip(parts[1:], coeffs[1:]):
+        sws = sws + (p.sum_weighted_statistics if c == 1.0 else p.sum_weighted_statistics * c)
       if stat._scale != 1.0:  # pylint: disable=protected-access
         sws = sws * stat._scale  # pylint: disable=protected-access
       return AggregationState(sws, parts[0].sum_weights)

@@ -344,12 +344,16 @@ def target_members(t: xr.DataArray, ensemble_dim: str):
 
 
 class LinearCombination(xr.LazyPickleMixin, xr.DataArray):
-  """scale * sum(terms) of lazy statistics on the same frame.  The weighted reduction is linear, so the Aggregator
-  reduces every term with its own fused launch and combines the accumulators (WindVectorSquaredError =
-  SE(u) + SE(v), deterministic.py:174-219; CRPSSkill against an ensemble of targets, probabilistic.py:134-145)."""
+  """scale * sum(coeff_i * term_i) of lazy statistics on the same frame.  The weighted reduction is linear, so the
+  Aggregator reduces every term with its own fused launch and combines the accumulators (WindVectorSquaredError =
+  SE(u) + SE(v), deterministic.py:174-219; CRPSSkill / UnbiasedEnsembleMeanSquaredError against an ensemble of
+  targets, probabilistic.py:134-145, 320-336)."""
 
-  def __init__(self, terms, scale: float = 1.0, name=None):
+  def __init__(self, terms, scale: float = 1.0, name=None, coeffs=None):
     first = terms[0]
+    self._coeffs = [1.0] * len(terms) if coeffs is None else [float(c) for c in coeffs]
+    if len(self._coeffs) != len(terms):
+      raise ValueError('one coefficient per term')
     self._data = None
     self._dims = first.dims
     self.name = name
@@ -365,9 +369,9 @@ class LinearCombination(xr.LazyPickleMixin, xr.DataArray):
   @property
   def data(self):
     if self._data is None:
-      total = self._terms[0].data
-      for t in self._terms[1:]:
-        total = total + t.data
+      total = self._terms[0].data * self._coeffs[0] if self._coeffs[0] != 1.0 else self._terms[0].data
+      for t, c in zip(self._terms[1:], self._coeffs[1:]):
+        total = total + (t.data * c if c != 1.0 else t.data)
       self._data = total * self._scale if self._scale != 1.0 else total
     return self._data
 

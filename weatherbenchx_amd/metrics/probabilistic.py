@@ -4,8 +4,8 @@ weatherbenchX/metrics/probabilistic.py:28-336, 606-688, 864-1003).
 Per-point arithmetic lives in csrc/wbx_ens_impl.hpp (one lane owns one grid point's M members in
 VGPRs: sorting-network rank form for `use_sort=True`, pairwise form for `use_sort=False`).
 `skipna_ensemble=True` and float64 / M > 64 members run on the generic (memory re-reading, fp64 pair form) kernel;
-targets that carry the ensemble dim are handled member by member (CRPSSkill, `which='targets'`).  Only
-UnbiasedEnsembleMeanSquaredError against an ensemble of targets raises NotImplementedError.
+targets that carry the ensemble dim are handled member by member (CRPSSkill, UnbiasedEnsembleMeanSquaredError,
+`which='targets'`); only their combination with skipna_ensemble=True raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -155,8 +155,20 @@ class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
     if self._ensemble_dim not in predictions.dims:
       raise ValueError(f'Dimension {self._ensemble_dim} not found in {predictions.dims}')
     if self._ensemble_dim in targets.dims:
-      raise NotImplementedError('UnbiasedEnsembleMeanSquaredError against ensemble-valued targets is not fused yet '
-                                '(SURVEY 8f-3)')
+      # (mean p - mean t)^2 - var_p / M - var_t / N (probabilistic.py:320-336).  With
+      #   mean_j (a - t_j)^2 = (a - mean t)^2 + (N - 1) / N * var_t      (var_t with ddof = 1)
+      # this is  mean_j UEMSE(p, t_j) - var_t : N fused launches against single target members plus the variance
+      # lane of one launch over the target ensemble -- linear, so the accumulators are combined after the reduction.
+      if self._skipna_ensemble:
+        raise NotImplementedError('skipna_ensemble with ensemble-valued targets is not supported')
+      members = lazy.target_members(targets, self._ensemble_dim)
+      n = len(members)
+      if n < 2:
+        raise ValueError('an ensemble of targets needs at least 2 members (its variance has ddof=1)')
+      terms = [lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, tj, self._ensemble_dim)
+               for tj in members]
+      terms.append(lazy.ens_statistic('EnsembleVariance', targets, members[0], self._ensemble_dim))
+      return lazy.LinearCombination(terms, coeffs=[1.0 / n] * n + [-1.0], name=predictions.name)
     return lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim,
                               skipna_ensemble=self._skipna_ensemble)
 
