@@ -197,6 +197,21 @@ int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial,
 int wbx_contract_bits(wbx_ctx* ctx, const wbx_s2_plan* plan, const double* partial, const double* wt,
                       const uint64_t* bits, double* out);
 
+/* ---- stage 1: indicator ("categorical") statistics --------------------------------------------------------
+ * Per point a 0/1 (or member-fraction) vector along a NEW dimension of `ncat` categories:
+ *   WBX_CAT_EXCEED  ErrorExceedance (deterministic.py:262-295) and, with M > 1 members at `member_stride`,
+ *                   EnsembleErrorExceedance (probabilistic.py:836-861): lane k = fraction of non-NaN members with
+ *                   |p_m - t| > thresholds[k]; NaN when every member's error is NaN.  `thresholds` is a DEVICE
+ *                   float64[ncat]; NaN thresholds compare false (the host patches those lanes to NaN).
+ *   WBX_CAT_RANK    RankHistogram (probabilistic.py:1306-1343): lane r = [#{m : p_m < t} == r], ncat = M + 1.
+ * partial_out[nkey][nchunk][lanes_total][nj] exactly like wbx_det_partial, lanes_total = ncat (+1 with
+ * WBX_FLAG_MASKED, x2 with WBX_FLAG_SKIPNA), so wbx_contract / wbx_contract_bits consume it unchanged.
+ * Per-thread fp64 counters live in LDS columns (the category index is data dependent): lanes_total <= 128. */
+typedef enum wbx_cat_func { WBX_CAT_EXCEED = 0, WBX_CAT_RANK = 1 } wbx_cat_func;
+int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int ncat, int M,
+                    int64_t member_stride, const void* p, const void* t, const double* thresholds,
+                    const uint8_t* mask, double* partial_out);
+
 /* ---- fused binned reduction (small depth, many boolean bins) -------------------------------------------------
  * Statistic, weight and bin membership in ONE pass over p, t, c -- for chunks where little is reduced before the
  * weight/bin-dependent dims, so that the stage-1 partials would be larger than the inputs (the public benchmark's

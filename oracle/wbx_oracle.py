@@ -216,6 +216,42 @@ def ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):
 # --------------------------------------------------------------------------------------------------
 # aggregation (weatherbenchX/aggregation.py:297-366)
 
+# ---- indicator statistics (a new trailing dimension of categories) ------------------------------------------
+def error_exceedance(p, p_dims, t, t_dims, thresholds, threshold_dim='error_exceedance_thresholds'):
+  """deterministic.py:262-295: float(|p - t| > thr_k), NaN where |p - t| or thr_k is NaN."""
+  out_dims = union_dims(p_dims, t_dims)
+  ae = np.abs(expand_to(f64(p), p_dims, out_dims) - expand_to(f64(t), t_dims, out_dims))[..., None]
+  thr = f64(thresholds).reshape((1,) * len(out_dims) + (-1,))
+  with np.errstate(invalid='ignore'):
+    out = (ae > thr).astype(np.float64)
+  out = np.where(np.isnan(ae), np.nan, out)
+  out = np.where(np.isnan(thr), np.nan, out)
+  return out, out_dims + (threshold_dim,)
+
+
+def ensemble_error_exceedance(p, p_dims, t, t_dims, thresholds, ensemble_dim,
+                              threshold_dim='error_exceedance_thresholds'):
+  """probabilistic.py:836-861: the member mean (xarray default skipna=True) of the exceedance indicators."""
+  full, dims = error_exceedance(p, p_dims, t, t_dims, thresholds, threshold_dim)
+  ax = dims.index(ensemble_dim)
+  with np.errstate(invalid='ignore'), __import__('warnings').catch_warnings():
+    __import__('warnings').simplefilter('ignore', RuntimeWarning)
+    out = np.nanmean(full, axis=ax)
+  return out, tuple(d for d in dims if d != ensemble_dim)
+
+
+def rank_histogram(p, p_dims, t, t_dims, ensemble_dim, rank_dim='rank'):
+  """probabilistic.py:1306-1343: one-hot of #{m : p_m < t} over M + 1 ranks (comparisons with NaN are False)."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  out_dims = union_dims(dims, t_dims)
+  pe = expand_to(pm, dims + (ensemble_dim,), out_dims + (ensemble_dim,))
+  te = expand_to(f64(t), t_dims, out_dims)[..., None]
+  with np.errstate(invalid='ignore'):
+    ranks = (pe < te).astype(np.int64).sum(axis=-1)
+  m = pm.shape[-1]
+  return (ranks[..., None] == np.arange(m + 1)).astype(np.float64), out_dims + (rank_dim,)
+
+
 
 def aggregate(stat, dims, reduce_dims, weights=(), bin_masks=(), mask=None, mask_dims=None, skipna=False):
   """Aggregator.aggregate_stat_var: returns (sum_weighted_statistics, sum_weights, out_dims).

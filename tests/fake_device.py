@@ -106,12 +106,28 @@ def _chunked(plan, arr):
   return out
 
 
-def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None):
+def _cat_lanes(plan, devs, cat):
+  cfunc, ncat, m, mstride, thr = cat
+  off_p = _offsets(plan, 0)
+  members = np.stack([devs[0].ptr[off_p + k * mstride] for k in range(m)], axis=-1).astype(np.float64)
+  t = devs[1].ptr[_offsets(plan, 1)].astype(np.float64)[..., None]
+  if cfunc == _hip.CAT_RANK:
+    r = (members < t).sum(axis=-1)
+    return [(r == k).astype(np.float64) for k in range(ncat)]
+  ae = np.abs(members - t)
+  n = (~np.isnan(ae)).sum(axis=-1).astype(np.float64)
+  thresholds = np.asarray(thr.ptr, dtype=np.float64)
+  return [(ae > thresholds[k]).sum(axis=-1) / np.where(n > 0, n, np.nan) for k in range(ncat)]
+
+
+def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None):
   with np.errstate(all='ignore'):
     if kind == 'det':
       nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]
       vals = [devs[i].ptr[_offsets(plan, i)] for i in range(nin)]
       lanes = _det_lanes(func, vals)
+    elif kind == 'cat':
+      lanes = _cat_lanes(plan, devs, cat)
     else:
       lanes = _ens_lanes(plan, devs, ens, plan.flags)
     counted = bool(plan.flags & 3)

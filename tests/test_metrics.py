@@ -622,3 +622,84 @@ def test_prediction_and_target_passthrough(backend):
   res = compute_all_metrics({'pa': deterministic.PredictionAverage(), 'ta': deterministic.TargetAverage()},
                             {'v': predictions.fillna(0.0)}, {'v': targets.fillna(0.0)}, ['x', 'y'])
   np.testing.assert_allclose([res['pa.v'].values, res['ta.v'].values], [7.0 / 4, 20.0 / 4])
+
+
+def test_error_exceedance_reference_table(backend):
+  # metrics_test.py:1031-1046 through the product: per-point values (nothing reduced)
+  predictions = xr.DataArray(np.array([0, -1, 1, np.nan]), dims=['x'], name='v')
+  targets = xr.DataArray(np.array([0, 0, 0, 0.0]), dims=['x'], name='v')
+  result = deterministic.ErrorExceedance(thresholds=xr.DataArray([0, 0.5, 1, np.nan], dims=['y']))._compute_per_variable(
+      predictions, targets)
+  assert result.dims == ('x', 'y')
+  np.testing.assert_array_equal(result.values, np.array([[0, 0, 0, np.nan], [1, 1, 0, np.nan], [1, 1, 0, np.nan],
+                                                         [np.nan] * 4]))
+
+
+def test_rank_histogram_reference_table(backend):
+  # metrics_test.py:1310-1370: per element (reduce_dims=[]) and aggregated over (batch, space)
+  p = {'geopotential': xr.DataArray(
+      np.array([[[0.6, 0.2], [0.7, 0.3], [0.8, 0.4], [0.9, 0.5], [1.0, 0.6]],
+                [[0.7, 0.6], [0.8, 0.7], [0.9, 0.8], [1.0, 0.9], [1.1, 1.0]]]), dims=['batch', 'number', 'space'])}
+  t = {'geopotential': xr.DataArray(np.array([[0.55, 0.65], [0.75, 0.85]]), dims=['batch', 'space'])}
+  metrics = {'rank_histogram': probabilistic.RankHistogram()}
+  want = np.array([[[1., 0., 0., 0., 0., 0.], [0., 0., 0., 0., 0., 1.]],
+                   [[0., 1., 0., 0., 0., 0.], [0., 0., 0., 1., 0., 0.]]])
+  per_element = compute_all_metrics(metrics, p, t, [])['rank_histogram.geopotential']
+  assert list(per_element['rank'].values) == [0, 1, 2, 3, 4, 5]
+  np.testing.assert_allclose(per_element.transpose('batch', 'space', 'rank').values, want)
+  aggregated = compute_all_metrics(metrics, p, t, ['batch', 'space'])['rank_histogram.geopotential']
+  np.testing.assert_allclose(aggregated.values, want.mean(axis=(0, 1)))
+
+
+@pytest.mark.parametrize('mode', ['plain', 'masked', 'skipna'])
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_indicator_statistics_match_oracle(backend, mode, layout):
+  """ErrorExceedance / EnsembleErrorExceedance / RankHistogram, area-weighted and binned by region, against the
+  oracle; NaN thresholds, NaN members (skipped in the member mean) and NaN targets (masked / skipna) included."""
+  rng = np.random.default_rng(17)
+  m = 5
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  tdims = ('lead_time',) + sp
+  pdims = ('lead_time', 'number') + sp
+  n = {'lead_time': 3, 'number': m, 'latitude': 32, 'longitude': 64}
+  tv = rng.normal(size=[n[d] for d in tdims]).astype(np.float32)
+  pv = (rng.normal(size=[n[d] for d in pdims]) * 1.5).astype(np.float32)
+  pv[0, 1] = np.nan                       # one member is all-NaN at lead 0: skipped by the member mean
+  if mode != 'plain':
+    tv[rng.random(tv.shape) < 0.1] = np.nan
+  coords = {'latitude': LAT, 'longitude': LON}
+  t = xr.DataArray(tv, dims=tdims, coords=coords)
+  if mode == 'masked':
+    t.coords['mask'] = ~np.isnan(t)
+  p = xr.DataArray(pv, dims=pdims, coords=coords)
+  thresholds = [0.5, np.nan, 2.0]
+  regions = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360))}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(regions)], masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+  metrics = {'exc': probabilistic.EnsembleErrorExceedance(thresholds), 'rank': probabilistic.RankHistogram(),
+             'det_exc': deterministic.ErrorExceedance(thresholds)}
+  p0 = xr.DataArray(pv[:, 0], dims=tdims, coords=coords)
+  got = aggregation.compute_metric_values_for_single_chunk({k: metrics[k] for k in ('exc', 'rank')}, agg, {'v': p},
+                                                           {'v': t})
+  got_det = aggregation.compute_metric_values_for_single_chunk({'det_exc': metrics['det_exc']}, agg, {'v': p0}, {'v': t})
+  w = (O.grid_area_weights(LAT), ('latitude',))
+  names, masks = O.region_masks(LAT, LON, regions)
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  kw = {}
+  if mode == 'masked':
+    kw = dict(mask=~np.isnan(tv), mask_dims=tdims)
+  if mode == 'skipna':
+    kw = dict(skipna=True)
+
+  def mean_of(stat, dims):
+    sws, sw, od = O.aggregate(stat, dims, ['latitude', 'longitude'], weights=[w], bin_masks=bm, **kw)
+    with np.errstate(all='ignore'):
+      return sws / sw, od
+
+  want, od = mean_of(*O.ensemble_error_exceedance(pv, pdims, tv, tdims, thresholds, 'number'))
+  np.testing.assert_allclose(got['exc.v'].transpose(*od).values, want, rtol=RTOL, equal_nan=True)
+  want, od = mean_of(*O.rank_histogram(pv, pdims, tv, tdims, 'number'))
+  np.testing.assert_allclose(got['rank.v'].transpose(*od).values, want, rtol=RTOL, equal_nan=True)
+  np.testing.assert_allclose(np.nansum(want, axis=od.index('rank')), 1.0)  # a histogram
+  want, od = mean_of(*O.error_exceedance(pv[:, 0], tdims, tv, tdims, thresholds))
+  np.testing.assert_allclose(got_det['det_exc.v'].transpose(*od).values, want, rtol=RTOL, equal_nan=True)

@@ -3,7 +3,7 @@
 The reference cannot be imported here, so each case below restates a reference test --
 its inputs and its analytic / brute-force expected value -- and checks the oracle against it:
   weatherbenchX/aggregation_test.py:69-169, weatherbenchX/metrics/metrics_test.py:44-98, 501-544,
-  603-660, 947-1006, weatherbenchX/weighting_test.py:24-46, weatherbenchX/binning_test.py:27-60.
+  603-660, 947-1046, 1310-1370, weatherbenchX/weighting_test.py:24-46, weatherbenchX/binning_test.py:27-60.
 """
 import itertools
 
@@ -170,3 +170,31 @@ def test_region_masks_shapes_and_wraparound():
   _, m = O.region_masks(LAT, LON, {'g': ((-90, 90), (0, 360)), 'eu': ((35, 75), (-12.5, 42.5))})
   assert m[0].all()
   assert m[1][:, LON == 350].any() and m[1][:, LON == 40].any() and not m[1][:, LON == 100].any()
+
+
+def test_error_exceedance_table_with_nan_row_and_column():
+  # metrics_test.py:1031-1046
+  out, dims = O.error_exceedance(np.array([0, -1, 1, np.nan]), ('x',), np.zeros(4), ('x',), [0, 0.5, 1, np.nan], 'y')
+  assert dims == ('x', 'y')
+  np.testing.assert_array_equal(out, np.array([[0, 0, 0, np.nan], [1, 1, 0, np.nan], [1, 1, 0, np.nan],
+                                                [np.nan] * 4]))
+  # probabilistic.py:836-861: the member mean of the same table (NaN members are skipped, all-NaN stays NaN)
+  ens, dims = O.ensemble_error_exceedance(np.array([[0.0, 2.0], [3.0, np.nan], [np.nan, np.nan]]), ('p', 'number'),
+                                          np.zeros(3), ('p',), [1.0], 'number', 'y')
+  assert dims == ('p', 'y')
+  np.testing.assert_array_equal(ens, np.array([[0.5], [1.0], [np.nan]]))
+
+
+def test_rank_histogram_one_hot_table_and_its_mean():
+  # metrics_test.py:1310-1370
+  p = np.array([[[0.6, 0.2], [0.7, 0.3], [0.8, 0.4], [0.9, 0.5], [1.0, 0.6]],
+                [[0.7, 0.6], [0.8, 0.7], [0.9, 0.8], [1.0, 0.9], [1.1, 1.0]]])
+  t = np.array([[0.55, 0.65], [0.75, 0.85]])
+  out, dims = O.rank_histogram(p, ('batch', 'number', 'space'), t, ('batch', 'space'), 'number')
+  assert dims == ('batch', 'space', 'rank')
+  want = np.array([[[1., 0., 0., 0., 0., 0.], [0., 0., 0., 0., 0., 1.]],
+                   [[0., 1., 0., 0., 0., 0.], [0., 0., 0., 1., 0., 0.]]])
+  np.testing.assert_array_equal(out, want)
+  sws, sw, out_dims = O.aggregate(out, dims, ['batch', 'space'])
+  assert out_dims == ('rank',)
+  np.testing.assert_allclose(sws / sw, want.mean(axis=(0, 1)))

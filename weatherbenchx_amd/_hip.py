@@ -19,6 +19,7 @@ F32, F64 = 0, 1
 DET3, DET6, PASS1 = 0, 1, 2
 DET_LANES = {DET3: 3, DET6: 6, PASS1: 1}
 DET_INPUTS = {DET3: 2, DET6: 3, PASS1: 1}
+CAT_EXCEED, CAT_RANK = 0, 1
 ENS_LANES = 5
 ENS_SORT, ENS_PAIRWISE = 0, 1
 FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR, FLAG_SKIPNA_ENS = 1, 2, 4, 8
@@ -28,7 +29,7 @@ EXPORTED_SYMBOLS = (
     'wbx_abi_version', 'wbx_last_error', 'wbx_device_count', 'wbx_ctx_create', 'wbx_ctx_destroy',
     'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
     'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
-    'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_det_map', 'wbx_ens_map',
+    'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_cat_partial', 'wbx_det_map', 'wbx_ens_map',
     'wbx_zonal_spectrum', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy',
 )
@@ -110,6 +111,7 @@ def load_library():
         'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
         'wbx_contract_bits': [vp, C.POINTER(S2PlanStruct), vp, vp, vp, vp],
         'wbx_det_binned': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int32, C.c_int32, vp],
+        'wbx_cat_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, i32, i64, vp, vp, vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
         'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],

@@ -260,6 +260,10 @@ class Aggregator:
         sws = sws * stat._scale  # pylint: disable=protected-access
       return AggregationState(sws, parts[0].sum_weights)
 
+    if (isinstance(stat, lazy.LazyCategorical) and stat.is_lazy and stat._cat_dim not in reduce_set  # pylint: disable=protected-access
+        and (w_da is None or stat._cat_dim not in w_da.dims)):  # pylint: disable=protected-access
+      return self._reduce_categorical(stat, w_da, bin_dims, use_mask, skipna)
+
     if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy and not use_mask and not skipna:
       fused = self._reduce_spectrum(stat, w_da, bin_dims)
       if fused is not None:
@@ -355,6 +359,32 @@ class Aggregator:
     for d in mean_dims:  # mean over d == sum over d / n; the count carries the same factor
       scale /= grp.sizes[d]
     return values, counts, out_dims, grp.coords, stat._lane, scale  # pylint: disable=protected-access
+
+  def _reduce_categorical(self, stat: 'lazy.LazyCategorical', w_da, bin_dims, use_mask, skipna):
+    """Indicator statistics: every category is a lane of ONE launch (wbx_cat_partial); the categories come back as
+    the statistic's trailing dimension."""
+    grp = stat._group  # pylint: disable=protected-access
+    cat_dim = stat._cat_dim  # pylint: disable=protected-access
+    values, counts, out_dims = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna)
+    _resolve_now()  # the lanes are stacked on the host
+    v = np.stack([np.asarray(a, np.float64) for a in values], axis=0)
+    c = np.stack([np.asarray(a, np.float64) for a in counts], axis=0)
+    nan_cat = stat.nan_categories()
+    if nan_cat.any():  # deterministic.py:293-294: NaN thresholds make the statistic NaN (counted out under skipna)
+      v[nan_cat] = 0.0 if skipna else np.nan
+      if skipna:
+        c[nan_cat] = 0.0
+    dims_in = (cat_dim,) + tuple(out_dims)
+    final_dims = tuple(d for d in stat.dims if d in dims_in) + tuple(bin_dims)
+    coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(final_dims) and k != 'mask'}  # pylint: disable=protected-access
+    if w_da is not None:
+      for k, x in w_da._coords.items():  # pylint: disable=protected-access
+        if set(x[0]) <= set(final_dims):
+          coords.setdefault(k, x)
+    order = [dims_in.index(d) for d in final_dims]
+    mk = lambda a: xr.DataArray(np.ascontiguousarray(np.transpose(a, order)), dims=final_dims, coords=coords,
+                                name=stat.name, attrs=stat.attrs, _raw_coords=True)
+    return AggregationState(mk(v), mk(c))
 
   def _reduce_spectrum(self, stat: 'spectra.LazySpectrum', w_da, bin_dims):
     """Weighted mean of zonal spectra over rows (time, latitude, ...) without materialising per-row spectra:

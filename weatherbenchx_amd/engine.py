@@ -215,6 +215,7 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags):
 
 
 _fast_plan_cache: dict = {}
+_thr_cache: dict = {}
 _count_cache: dict = {}
 _scratch_bufs: dict = {}
 
@@ -236,10 +237,11 @@ def clear_caches():
   _fast_plan_cache.clear()
   _count_cache.clear()
   _scratch_bufs.clear()
+  _thr_cache.clear()
 
 
 def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Sequence[_Dev | None], dtype_code: int,
-            nlanes_total: int, func: int = 0, ens=None) -> _hip.DeviceBuffer:
+            nlanes_total: int, func: int = 0, ens=None, cat=None) -> _hip.DeviceBuffer:
   n = int(np.prod(plan.partial_shape(nlanes_total), dtype=np.int64))
   out = _scratch(ctx, 'partial', n * 8)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
@@ -251,6 +253,11 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
     if kind == 'det':
       _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]),
                                          ptr(devs[1]), ptr(devs[2]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_det_partial')
+    elif kind == 'cat':
+      cfunc, ncat, m, mstride, thr = cat
+      _hip.check(ctx.lib.wbx_cat_partial(ctx.handle, C.byref(dplan.struct), int(cfunc), dtype_code, int(ncat), int(m),
+                                         int(mstride), ptr(devs[0]), ptr(devs[1]), ptr(thr), ptr(devs[3]),
+                                         C.c_void_p(out.ptr)), 'wbx_cat_partial')
     else:
       m, mstride, algo = ens
       _hip.check(ctx.lib.wbx_ens_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride),
@@ -421,9 +428,12 @@ def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence)
 
 def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Sequence, sizes: dict, reduce_dims,
                       w_da: xr.DataArray | None, bin_dims: Sequence, *, func: int = 0, mask: xr.DataArray | None = None,
-                      skipna: bool = False, gather: planner.GatherSpec | None = None, ens=None,
+                      skipna: bool = False, gather: planner.GatherSpec | None = None, ens=None, cat=None,
                       ctx: _hip.Context | None = None):
   """Fused statistics + weighted/binned reduction.
+
+  kind 'det' / 'ens' / 'cat' (indicator statistics: `cat` = {'func', 'ncat', 'thresholds' (float64 ndarray or None),
+  'member_dim' (or None), 'M'}; one value lane per category).
 
   Returns (values, counts, out_dims): `values[lane]` is an ndarray over out_dims =
   (A dims..., Bk dims..., [x dim], bin dims...); `counts` is the matching sum of W over valid
@@ -432,7 +442,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   global _deferred
   ctx = ctx or _hip.default_context()
   wdep = set(w_da.dims) - set(bin_dims) if w_da is not None else set()
-  member_dim = ens['member_dim'] if ens else None
+  member_dim = ens['member_dim'] if ens else (cat.get('member_dim') if cat else None)
   datas = [i.data if i is not None else None for i in inputs]
   dtype_code = _common_dtype(datas)
   _sync_torch_producers(datas)
@@ -453,20 +463,31 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   if _deferred is not None:
     _deferred.keepalive.append((datas, devs))
   plan, dplan = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
-  nl = _hip.DET_LANES[func] if kind == 'det' else _hip.ENS_LANES
+  nl = _hip.DET_LANES[func] if kind == 'det' else (int(cat['ncat']) if kind == 'cat' else _hip.ENS_LANES)
   counted = bool(flags & 3)
   shared_count = counted and not (flags & _hip.FLAG_SKIPNA)  # mask only: one count lane for every statistic
   nl_total = nl + 1 if shared_count else nl * (2 if counted else 1)
-  ens_args = None
+  ens_args = cat_args = None
   if kind == 'ens':
     ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
+  if kind == 'cat':
+    thr = None
+    if cat.get('thresholds') is not None:
+      tkey = (ctx.device_id, np.asarray(cat['thresholds'], np.float64).tobytes())
+      thr = _thr_cache.get(tkey)
+      if thr is None:
+        if len(_thr_cache) > 64:
+          _thr_cache.clear()
+        thr = _thr_cache[tkey] = ctx.upload(np.asarray(cat['thresholds'], np.float64))
+    cat_args = (cat['func'], nl, cat.get('M', 1) if member_dim else 1,
+                devs[0].layout.stride(member_dim) if member_dim else 0, thr)
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
   if _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
     out = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
   else:
-    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args)
+    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args)
     out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
 
   x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()

@@ -117,13 +117,14 @@ class ClimatologyRef(xr.LazyPickleMixin, xr.DataArray):
 class FusedGroup:
   """All fused statistics over one (predictions, targets[, climatology]) triple."""
 
-  def __init__(self, kind: str, p: xr.DataArray, t: xr.DataArray, ens=None):
+  def __init__(self, kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, cat=None):
     self.kind = kind
     self.p, self.t = p, t
     self.ens = ens  # {'member_dim', 'M'}
+    self.cat = cat  # indicator statistics: {'func', 'ncat', 'thresholds', 'member_dim', 'M'}
     self.clim: ClimatologyRef | None = None
     self._clim_key = None
-    drop = (ens['member_dim'],) if ens else ()
+    drop = (ens['member_dim'],) if ens else ((cat['member_dim'],) if cat and cat.get('member_dim') else ())
     self.dims, self.sizes, self.coords = _stat_frame([p, t], drop_dims=drop)
     self.cache: dict = {}
 
@@ -150,7 +151,7 @@ class FusedGroup:
 
   # -- execution ---------------------------------------------------------------------------------
   def inputs_and_func(self):
-    if self.kind == 'ens':
+    if self.kind in ('ens', 'cat'):
       return [self.p, self.t], 0
     if self.clim is not None:
       return [self.p, self.t, self.clim.source], _hip.DET6
@@ -162,6 +163,9 @@ class FusedGroup:
     ens = None
     if self.kind == 'ens':
       ens = dict(self.ens, **(ens_params or {}))
+    if self.kind == 'cat':
+      return engine.reduce_statistics('cat', inputs, self.dims, self.sizes, tuple(reduce_dims) + tuple(extra_reduce),
+                                      w_da, bin_dims, mask=mask, skipna=skipna, cat=self.cat)
     return _reduce_with_gather(self.kind, inputs, self.dims, self.sizes, tuple(reduce_dims) + tuple(extra_reduce), w_da,
                                bin_dims, func=func, mask=mask, skipna=skipna, clim=self.clim, ens=ens)
 
@@ -201,14 +205,14 @@ def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, 
                                     skipna=skipna, gather=None, ens=ens)
 
 
-def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=None) -> FusedGroup:
+def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=None, cat=None) -> FusedGroup:
   """The FusedGroup shared by every statistic built from these very (p, t) objects."""
   table = p.__dict__.setdefault('_wbx_groups', {})
   key = (kind, id(t), ens['member_dim'] if ens else None, clim_key)
   hit = table.get(key)
   if hit is not None and hit[0]() is t:
     return hit[1]
-  grp = FusedGroup(kind, p, t, ens=ens)
+  grp = FusedGroup(kind, p, t, ens=ens, cat=cat)
   table[key] = (weakref.ref(t), grp)
   return grp
 
@@ -332,6 +336,75 @@ def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fa
   params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair),
             'skipna': bool(skipna_ensemble)}
   return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params)
+
+
+class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
+  """An indicator statistic (ErrorExceedance, EnsembleErrorExceedance, RankHistogram): the frame of (p, t) plus ONE new
+  trailing dimension of categories.  The Aggregator reduces all categories in one launch (wbx_cat_partial); reading
+  `.data` evaluates the same kernel without reducing anything."""
+
+  def __init__(self, group: FusedGroup, cat_dim: str, cat_coord, name=None):
+    self._data = None
+    self._dims = tuple(group.dims) + (cat_dim,)
+    self.name = name
+    self.attrs = {}
+    self._coords = dict(group.coords)
+    if cat_coord is not None:
+      self._coords[cat_dim] = ((cat_dim,), np.asarray(cat_coord))
+    self._group = group
+    self._cat_dim = cat_dim
+
+  @property
+  def is_lazy(self) -> bool:
+    return self._data is None
+
+  @property
+  def ncat(self) -> int:
+    return int(self._group.cat['ncat'])
+
+  def nan_categories(self) -> np.ndarray:
+    """Categories whose threshold is NaN: the reference makes the statistic NaN there (deterministic.py:293-294)."""
+    thr = self._group.cat.get('thresholds')
+    return np.zeros(self.ncat, bool) if thr is None else np.isnan(np.asarray(thr, np.float64))
+
+  @property
+  def data(self):
+    if self._data is None:
+      grp = self._group
+      values, _, out_dims = grp.reduce((), None, (), use_mask=False, skipna=False)
+      arr = np.stack([np.asarray(v, np.float64) for v in values], axis=-1)
+      arr = np.transpose(arr, [out_dims.index(d) for d in grp.dims] + [len(out_dims)])
+      arr[..., self.nan_categories()] = np.nan
+      self._data = np.ascontiguousarray(arr)
+    return self._data
+
+  @property
+  def shape(self):
+    return tuple(self._group.sizes[d] for d in self._group.dims) + (self.ncat,)
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)
+
+
+def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, ensemble_dim=None) -> xr.DataArray:
+  p, t = xr.as_dataarray(p), xr.as_dataarray(t)
+  if ensemble_dim is not None:
+    if ensemble_dim not in p.dims:
+      raise ValueError(f'Dimension {ensemble_dim} not found in {p.dims}')
+    if ensemble_dim in t.dims:
+      raise ValueError(f'targets must not carry {ensemble_dim!r} here')
+  else:
+    p, t = _aligned(p, t)
+  if cat_dim in p.dims or cat_dim in t.dims:
+    raise ValueError(f'{cat_dim!r} is already a dimension of the inputs')
+  thr = None if thresholds is None else np.asarray(thresholds, np.float64).reshape(-1)
+  ncat = (p.sizes[ensemble_dim] + 1) if func == _hip.CAT_RANK else int(thr.size)
+  cat = {'func': int(func), 'ncat': ncat, 'thresholds': thr, 'member_dim': ensemble_dim,
+         'M': p.sizes[ensemble_dim] if ensemble_dim else 1}
+  key = ('cat', int(func), cat_dim, None if thr is None else thr.tobytes())
+  grp = _group_for('cat', p, t, ens=None, clim_key=(key, ensemble_dim), cat=cat)
+  return LazyCategorical(grp, cat_dim, cat_coord, name=p.name)
 
 
 def target_members(t: xr.DataArray, ensemble_dim: str):

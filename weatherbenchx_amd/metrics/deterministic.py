@@ -8,6 +8,7 @@ from typing import Mapping, Sequence, Union
 
 import numpy as np
 
+from weatherbenchx_amd import _hip
 from weatherbenchx_amd import lazy
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd import xarray_tree
@@ -83,6 +84,32 @@ class WindVectorSquaredError(base.Statistic):
       else:
         out[name] = se_u + se_v
     return out
+
+
+def _threshold_array(thresholds, name):
+  """(values float64[K], dim name, coordinate or None) of a 1-D thresholds spec (deterministic.py:265-290)."""
+  if isinstance(thresholds, (xr.Dataset, dict)):
+    thresholds = thresholds[name]
+  if isinstance(thresholds, xr.DataArray):
+    if thresholds.ndim != 1:
+      raise NotImplementedError('thresholds that depend on data dimensions are not fused; pass a 1-D DataArray')
+    dim = thresholds.dims[0]
+    coord = thresholds.coords[dim].values if dim in thresholds.coords else None
+    return np.asarray(thresholds.values, np.float64), dim, coord
+  values = np.asarray(list(thresholds), np.float64)
+  return values, 'error_exceedance_thresholds', values
+
+
+class ErrorExceedance(base.PerVariableStatistic):
+  """float(|p - t| > threshold) along a new thresholds dimension, NaN where the error or the threshold is NaN
+  (deterministic.py:262-295).  All thresholds are lanes of one fused launch (csrc/wbx_cat.hip)."""
+
+  def __init__(self, thresholds):
+    self._thresholds = thresholds
+
+  def _compute_per_variable(self, predictions, targets):
+    values, dim, coord = _threshold_array(self._thresholds, predictions.name)
+    return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, dim, coord, thresholds=values)
 
 
 class SquaredPredictionAnomaly(base.PerVariableStatisticWithClimatology):

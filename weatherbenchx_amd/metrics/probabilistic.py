@@ -13,8 +13,10 @@ from typing import Mapping
 
 import numpy as np
 
+from weatherbenchx_amd import _hip
 from weatherbenchx_amd import lazy
 from weatherbenchx_amd.metrics import base
+from weatherbenchx_amd.metrics import deterministic
 
 ENSEMBLE_DIM = 'number'
 
@@ -193,6 +195,40 @@ class CRPSEnsemble(base.PerVariableMetric):
 
   def _values_from_mean_statistics_per_variable(self, statistic_values):
     return statistic_values['CRPSSkill'] - 0.5 * statistic_values['CRPSSpread']
+
+
+class EnsembleErrorExceedance(deterministic.ErrorExceedance):
+  """Error exceedance averaged over the ensemble members, NaN members skipped (probabilistic.py:836-861): per
+  threshold the fraction of members whose absolute error exceeds it -- counted in registers while the members
+  stream by once (csrc/wbx_cat.hip)."""
+
+  def __init__(self, thresholds, ensemble_dim: str = ENSEMBLE_DIM):
+    super().__init__(thresholds=thresholds)
+    self._ensemble_dim = ensemble_dim
+
+  def _compute_per_variable(self, predictions, targets):
+    values, dim, coord = deterministic._threshold_array(self._thresholds, predictions.name)  # pylint: disable=protected-access
+    return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, dim, coord, thresholds=values,
+                              ensemble_dim=self._ensemble_dim)
+
+
+class RankHistogram(base.PerVariableStatistic):
+  """One-hot of the target's rank among the M members along a new `rank` dimension of M + 1 bins
+  (probabilistic.py:1306-1343)."""
+
+  def __init__(self, *, ensemble_dim: str = ENSEMBLE_DIM):
+    self._ensemble_dim = ensemble_dim
+
+  @property
+  def unique_name(self) -> str:
+    return f'RankHistogram_{self._ensemble_dim}'
+
+  def _compute_per_variable(self, predictions, targets):
+    if self._ensemble_dim not in predictions.dims:
+      raise ValueError(f'Dimension {self._ensemble_dim} not found in {predictions.dims}')
+    m = predictions.sizes[self._ensemble_dim]
+    return lazy.cat_statistic(_hip.CAT_RANK, predictions, targets, 'rank', np.arange(m + 1),
+                              ensemble_dim=self._ensemble_dim)
 
 
 class CRPSEnsembleDistance(base.PerVariableMetric):
