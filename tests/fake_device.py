@@ -216,6 +216,7 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
   monkeypatch.setattr(engine, '_run_binned', _run_binned)
+  monkeypatch.setattr(engine, 'new_context', lambda: FakeCtx())
 
 
 def _run_spectrum(field, lon_dim, group, scale, ngroup, cache=None):

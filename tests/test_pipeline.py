@@ -123,6 +123,36 @@ def test_deferred_results_equal_synchronous_results(backend):
     np.testing.assert_allclose(arr.values, one.wait().sum_weighted_statistics.values, rtol=1e-12)
 
 
+def test_chunk_feeder_prefetch_equals_serial_loading(backend):
+  """prefetch=1: a feeder thread loads and stages chunk k+1 (own context / copy stream) while chunk k is aggregated;
+  results are identical, loader exceptions surface in the caller."""
+  predictions, targets = _datasets()
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+  load = _loader(predictions, targets)
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'])
+  serial = pipeline.evaluate_chunks(times, load, metrics, agg)[None].metric_values(metrics)
+  calls = []
+
+  def counting_load(i, l):
+    calls.append(__import__('threading').current_thread().name)
+    return load(i, l)
+  fed = pipeline.evaluate_chunks(times, counting_load, metrics, agg, prefetch=1)[None].metric_values(metrics)
+  assert len(calls) == len(times) and set(calls) == {'wbx-chunk-feeder'}
+  for k in serial:
+    xr.assert_allclose(fed[k], serial[k], rtol=1e-12, atol=0)
+
+  def failing_load(i, l):
+    if len(calls) >= len(times) + 2:
+      raise OSError('disk on fire')
+    calls.append('x')
+    return load(i, l)
+  with pytest.raises(OSError, match='disk on fire'):
+    pipeline.evaluate_chunks(times, failing_load, metrics, agg, prefetch=2)
+
+
 def test_time_chunks_lengths_and_offsets():
   init_times = np.arange('2020-01-01T00', '2020-01-02T00', np.timedelta64(6, 'h'), dtype='datetime64[ns]')
   lead_times = np.arange(0, 18, 6, dtype='timedelta64[h]')

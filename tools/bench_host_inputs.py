@@ -61,3 +61,27 @@ for _ in range(2):
   ctx.synchronize()
   dt = time.perf_counter() - t0
 print(f'raw wbx_memcpy_h2d from pageable memory: {a.nbytes / dt / 1e9:6.1f} GB/s')
+
+# ---- the same chunks through pipeline.evaluate_chunks, with and without the chunk feeder ------------------
+from weatherbenchx_amd import pipeline, time_chunks
+nchunk = 8
+inits = np.datetime64('2020-01-01T00', 'ns') + np.arange(nchunk) * np.timedelta64(12, 'h')
+leads = coords['lead_time']
+times = time_chunks.TimeChunks(inits, leads, init_time_chunk_size=1)
+
+
+def load(init_chunk, lead_chunk):
+  i = int((init_chunk[0] - inits[0]) / np.timedelta64(12, 'h'))
+  p, t = bufs[i % 3]
+  cc = dict(coords, init_time=init_chunk)
+  # a loader hands over freshly decoded arrays: copy, like reading from storage would
+  return ({'z': xr.DataArray(p.copy(), dims=dims, coords=cc)}, {'z': xr.DataArray(t.copy(), dims=dims, coords=cc)})
+
+
+for prefetch in (0, 1):
+  pipeline.evaluate_chunks(times, load, metrics, agg, prefetch=prefetch)
+  t0 = time.perf_counter()
+  state = pipeline.evaluate_chunks(times, load, metrics, agg, prefetch=prefetch)[None]
+  ms = (time.perf_counter() - t0) / nchunk * 1e3
+  r = float(np.asarray(state.metric_values(metrics)['rmse.z'].values).reshape(-1)[0])
+  print(f'evaluate_chunks(prefetch={prefetch}): {ms:7.1f} ms/chunk = {nbytes / ms / 1e6:6.1f} GB/s incl. the loader copy   rmse={r:.4f}')

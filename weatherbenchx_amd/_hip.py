@@ -147,22 +147,46 @@ def is_available() -> bool:
 
 
 class DeviceBuffer:
-  """Device allocation owned by a Context (freed on garbage collection)."""
+  """Device allocation owned by a Context.  On garbage collection the memory goes back to the context's free list
+  (same-size chunks arrive over and over in the chunk loop, and hipFree synchronises the whole device), up to
+  DEVICE_POOL_LIMIT_BYTES cached per context; beyond that it is freed."""
 
   def __init__(self, ctx: 'Context', nbytes: int):
     self.ctx = ctx
     self.nbytes = int(nbytes)
-    p = C.c_void_p(0)
-    check(ctx.lib.wbx_malloc(ctx.handle, self.nbytes, C.byref(p)), 'wbx_malloc')
-    self.ptr = p.value or 0
+    with ctx._pool_lock:  # pylint: disable=protected-access
+      free = ctx._dev_free.get(self.nbytes)  # pylint: disable=protected-access
+      ptr = free.pop() if free else 0
+      if ptr:
+        ctx._dev_cached -= self.nbytes  # pylint: disable=protected-access
+    if not ptr:
+      p = C.c_void_p(0)
+      rc = ctx.lib.wbx_malloc(ctx.handle, self.nbytes, C.byref(p))
+      if rc != 0 and ctx._dev_cached:  # pylint: disable=protected-access
+        ctx.release_pool()  # out of memory with idle cached blocks: give them back and retry
+        rc = ctx.lib.wbx_malloc(ctx.handle, self.nbytes, C.byref(p))
+      check(rc, 'wbx_malloc')
+      ptr = p.value or 0
+    self.ptr = ptr
 
   def __del__(self):
     try:
-      if getattr(self, 'ptr', 0) and self.ctx.handle:
-        self.ctx.lib.wbx_free(self.ctx.handle, C.c_void_p(self.ptr))
-        self.ptr = 0
+      ctx = self.ctx
+      if getattr(self, 'ptr', 0) and ctx.handle:
+        with ctx._pool_lock:  # pylint: disable=protected-access
+          if ctx._dev_cached + self.nbytes <= DEVICE_POOL_LIMIT_BYTES:  # pylint: disable=protected-access
+            ctx._dev_free.setdefault(self.nbytes, []).append(self.ptr)  # pylint: disable=protected-access
+            ctx._dev_cached += self.nbytes  # pylint: disable=protected-access
+            self.ptr = 0
+        if self.ptr:
+          ctx.lib.wbx_free(ctx.handle, C.c_void_p(self.ptr))
+          self.ptr = 0
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+# Upper bound on idle device memory a context keeps for reuse (MI355X: 288 GB of HBM3E).
+DEVICE_POOL_LIMIT_BYTES = int(os.environ.get('WBX_DEVICE_POOL_BYTES', 32 << 30))
 
 
 class PinnedBlock:
@@ -220,9 +244,21 @@ class Context:
     self.handle = h
     self.device_id = int(device_id)
     self._pinned_free: dict[int, list[int]] = {}  # capacity -> free page-locked blocks
+    self._dev_free: dict[int, list[int]] = {}     # nbytes -> idle device blocks (see DeviceBuffer)
+    self._dev_cached = 0
+    self._pool_lock = threading.Lock()
+
+  def release_pool(self):
+    """hipFree every idle cached device block."""
+    with self._pool_lock:
+      blocks, self._dev_free, self._dev_cached = self._dev_free, {}, 0
+    for ptrs in blocks.values():
+      for ptr in ptrs:
+        self.lib.wbx_free(self.handle, C.c_void_p(ptr))
 
   def close(self):
     if getattr(self, 'handle', None):
+      self.release_pool()
       for blocks in getattr(self, '_pinned_free', {}).values():
         for ptr in blocks:
           self.lib.wbx_host_free(self.handle, C.c_void_p(ptr))

@@ -231,6 +231,21 @@ def _scratch(ctx, slot: str, nbytes: int):
   return buf
 
 
+def new_context() -> _hip.Context:
+  """A second context (own HIP stream) on the default device -- the chunk feeder's copy stream."""
+  return _hip.Context(_hip.default_context().device_id)
+
+
+def stage_inputs(ctx, arrays: Sequence[xr.DataArray]):
+  """Uploads the host payloads of `arrays` through `ctx` and caches the device copies on the DataArray objects, in the
+  dtype reduce_statistics would pick for them together; device-resident payloads are left alone."""
+  arrays = [a for a in arrays if a is not None]
+  dtype_code = _common_dtype([a.data for a in arrays])
+  for a in arrays:
+    if not (_is_torch(a.data) and a.data.is_cuda):
+      _to_device(ctx, a, dtype_code)
+
+
 def clear_caches():
   _plan_cache.clear()
   _w_cache.clear()
