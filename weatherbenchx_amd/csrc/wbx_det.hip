@@ -44,7 +44,7 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
   } else if constexpr (V == 4) {
     if (xs == 1) {
       using V4 = typename Vec4<T>::type;
-      V4 q = *reinterpret_cast<const V4*>(p + x);
+      V4 q = __builtin_nontemporal_load(reinterpret_cast<const V4*>(p + x));  // see ld_stream (element-aligned type)
       v[0] = q.x;
       v[1] = q.y;
       v[2] = q.z;
@@ -55,7 +55,12 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < V; ++k) v[k] = p[(x + k) * xs];
+    for (int k = 0; k < V; ++k) {
+      if constexpr (sizeof(T) > 1)
+        v[k] = ld_stream(p + (x + k) * xs);
+      else
+        v[k] = p[(x + k) * xs];  // mask bytes are re-read by every depth row: keep them cached
+    }
   }
 }
 

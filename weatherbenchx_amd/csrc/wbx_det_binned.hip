@@ -93,9 +93,9 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
       T rp[PD], rt[PD], rc[PD];
       uint8_t rv[PD];
       auto fetch_ptc = [&](int j, int u) {
-        rp[u] = reinterpret_cast<const T*>(a.in[0])[readlane64(ro[0], j) + xoff[0]];
-        if constexpr (NIN > 1) rt[u] = reinterpret_cast<const T*>(a.in[1])[readlane64(ro[1], j) + xoff[1]];
-        if constexpr (NIN > 2) rc[u] = reinterpret_cast<const T*>(a.in[2])[readlane64(ro[2], j) + xoff[2]];
+        rp[u] = ld_stream(reinterpret_cast<const T*>(a.in[0]) + readlane64(ro[0], j) + xoff[0]);
+        if constexpr (NIN > 1) rt[u] = ld_stream(reinterpret_cast<const T*>(a.in[1]) + readlane64(ro[1], j) + xoff[1]);
+        if constexpr (NIN > 2) rc[u] = ld_stream(reinterpret_cast<const T*>(a.in[2]) + readlane64(ro[2], j) + xoff[2]);
         rv[u] = 1;
         if constexpr (has_mask) rv[u] = reinterpret_cast<const uint8_t*>(a.in[3])[readlane64(ro[3], j) + xoff[3]];
       };

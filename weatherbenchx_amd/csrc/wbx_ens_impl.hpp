@@ -56,9 +56,9 @@ struct EnsOpF32 {
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
     const int M = EXACT ? MP : a.M;
     const float* pp = reinterpret_cast<const float*>(a.in[0]) + ro[0] + x * a.xstride[0];
-    r.t = reinterpret_cast<const float*>(a.in[1])[ro[1] + x * a.xstride[1]];
+    r.t = ld_stream(reinterpret_cast<const float*>(a.in[1]) + ro[1] + x * a.xstride[1]);
 #pragma unroll
-    for (int m = 0; m < MP; ++m) r.xm[m] = (EXACT || m < M) ? pp[(int64_t)m * a.mstride] : INFINITY;
+    for (int m = 0; m < MP; ++m) r.xm[m] = (EXACT || m < M) ? ld_stream(pp + (int64_t)m * a.mstride) : INFINITY;
   }
 
   __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,

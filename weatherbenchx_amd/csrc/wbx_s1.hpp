@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(1024, 6) s1_xp_kernel(S1Args a, int R) {  // <
         if (k < nvec) {
           const int e0 = 4 * k;  // first element of this float4, relative to a0
           if (e0 + 3 < ld[i] + n) {
-            q = *reinterpret_cast<const float4*>(base + a0 + e0);  // fully inside [a0, span end): aligned 16-B load
+            typedef float f4_t __attribute__((ext_vector_type(4)));
+            const f4_t w = ld_stream(reinterpret_cast<const f4_t*>(base + a0 + e0));  // inside [a0, span end): aligned 16 B
+            q = make_float4(w.x, w.y, w.z, w.w);
           } else if (e0 < ld[i] + n) {  // straddles the span end: never read past the last element
             float tmp[4] = {0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < 4; ++c)

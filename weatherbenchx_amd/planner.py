@@ -205,6 +205,10 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
     block_threads = 256 if rows >= 4 else (128 if rows >= 2 else 64)
     if nx <= 64 and rows < 4:
       block_threads = 64
+    if nkey * nchunk >= 16384:
+      # plenty of blocks already: one wave per block sweeps its rows without any block-level sync
+      # (configs[1] with non-temporal loads: 64 / 128 / 256 threads -> 81.1 / 80.6 / 78.5 % of the HBM peak)
+      block_threads = 64
 
   # 16 B per lane per load, only when every row of every streamed input starts 16-B aligned and nx % 4 == 0.
   # (Measured on MI355X: UNALIGNED dwordx4 on 721-long latitude rows runs 6.8 ms vs 4.8 ms for dword loads on
