@@ -9,8 +9,8 @@
 // There are too many (bin, lane) accumulators for one register file (34 bins x 7 lanes), but bins are regions: a
 // spatially compact patch of the grid touches only a few of them.  So one WAVE owns one patch
 //     patch = (cell (A, Bk), 64 consecutive x, a range of the nBr * D reduced rows)
-// scans the patch's membership words once (8 B / point, L2 resident) for the union of its bins, deals the set bits of
-// the union to K register "slots" (a table in SGPRs), and sweeps its rows accumulating only those; a patch with more
+// reads the union of the patch's bins (one 64-bit word per patch from binned_union_kernel, wbx_patch.hpp), deals its
+// set bits to K register "slots" (bit masks in SGPRs), and sweeps its rows accumulating only those; a patch with more
 // than K bins takes another sweep for the next K.  Per 64-point tile the wave ORs the membership words across lanes
 // (DPP) and skips the slots no point of the tile is in.  Waves write tmp[cell][patch][lane][bin] (pre-zeroed) and a
 // second kernel sums the patches.  No LDS, no block barrier: the block is one wave.
@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
 
   const int64_t patch = (int64_t)rs * g.nxt + xt;
   // union of the patch's bins (binned_union_kernel: it does not depend on A, so it is computed once per launch)
-  unsigned long long todo = __builtin_nontemporal_load(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch]);
+  unsigned long long todo = g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch];
   todo = (unsigned long long)readlane64((int64_t)todo, 0);
   double* const out = g.tmp + (cell * ((int64_t)g.nrs * g.nxt) + patch) * (NA * (int64_t)g.nbin);
   bool first = true;
@@ -68,6 +68,9 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
       smask[q] = todo & (~todo + 1ull);
       todo &= todo - 1ull;
     }
+    unsigned long long sweep = 0ull;  // the bins of this sweep
+#pragma unroll
+    for (int q = 0; q < K; ++q) sweep |= smask[q];
     double acc[NA][K];
     double poison[NA];
 #pragma unroll
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) 
       };
       auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, unsigned long long bw) {
         const bool ok = live && tv != 0;
-        const unsigned long long tile = wave_or64(ok ? bw : 0ull);  // bins any point of this tile is in
+        const unsigned long long tile = wave_or64_of(ok ? bw : 0ull, sweep);  // swept bins some point of the tile is in
         if (ok) {
           const double p = (double)tp, t = (double)tt, c = (double)tc;
           double val[NA];

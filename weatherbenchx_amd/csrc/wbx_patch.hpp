@@ -44,6 +44,15 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
   return ((unsigned long long)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
 }
 
+// wave_or64(v) & want, reducing only the 32-bit halves `want` (wave-uniform) has bits in: the slots of one sweep
+// usually sit in one half of the membership word, which halves the DPP work per tile.
+__device__ __forceinline__ unsigned long long wave_or64_of(unsigned long long v, unsigned long long want) {
+  unsigned long long r = 0ull;
+  if ((uint32_t)want) r = wave_or32((uint32_t)v);
+  if ((uint32_t)(want >> 32)) r |= (unsigned long long)wave_or32((uint32_t)(v >> 32)) << 32;
+  return r;
+}
+
 // uni[bk][patch] |= OR of bits over the patch's (rows, 64 x); the 4 waves of a block interleave over the rows
 static __global__ void __launch_bounds__(256) binned_union_kernel(BinnedArgs g, int64_t D, int64_t nx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

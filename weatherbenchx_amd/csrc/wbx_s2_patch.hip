@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64) s2_patch_kernel(const double* __restrict__
   const bool live = (int64_t)xt * 64 + lane < g.nj;
   const int64_t x = live ? (int64_t)xt * 64 + lane : g.nj - 1;
   const int64_t patch = (int64_t)rs * g.nxt + xt;
-  unsigned long long todo = __builtin_nontemporal_load(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch]);
+  unsigned long long todo = g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch];
   todo = (unsigned long long)readlane64((int64_t)todo, 0);
   double* const out = g.tmp + (cell * ((int64_t)g.nrs * g.nxt) + patch) * (NL * (int64_t)g.nbin);
   const int64_t row_stride = nchunk * NL * g.nj;  // elements between consecutive Br rows of one cell
@@ -41,6 +41,9 @@ __global__ void __launch_bounds__(64) s2_patch_kernel(const double* __restrict__
       smask[q] = todo & (~todo + 1ull);
       todo &= todo - 1ull;
     }
+    unsigned long long sweep = 0ull;  // the bins of this sweep
+#pragma unroll
+    for (int q = 0; q < K; ++q) sweep |= smask[q];
     double acc[NL][K];
     double poison[NL];
 #pragma unroll
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(64) s2_patch_kernel(const double* __restrict__
       for (int q = 0; q < K; ++q) acc[l][q] = 0.0;
     }
     auto accumulate = [&](const double (&v)[NL], double w, unsigned long long bw) {
-      const unsigned long long tile = wave_or64(live ? bw : 0ull);
+      const unsigned long long tile = wave_or64_of(live ? bw : 0ull, sweep);
       if (live) {
         double m[NL];
 #pragma unroll
