@@ -334,6 +334,13 @@ class ResultFence:
     self._fences = []
     self._keepalive = []
 
+  def __del__(self):
+    # a state dropped without ever being looked at: its inputs must still outlive the kernels that read them
+    try:
+      self.wait()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
 
 _deferred: DeferredResults | None = None
 
