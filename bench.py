@@ -256,7 +256,7 @@ def main():
         'check': {'crps_v0': float(np.asarray(eout['crps.v0'].values).mean())}}
     del pe, te, tv
 
-    # ---- zonal spectra side measurement (configs[3] shape: 37 levels; rocFFT + |F|^2 reduction) ------------------
+    # ---- zonal spectra side measurement (configs[3] shape: 37 levels; fused FFT + |F|^2 reduction) ------------------
     from weatherbenchx_amd import spectra
     nt_s, nlev_s = (8, 37) if not args.small else (2, 3)
     sdims = ('lead_time', 'level', 'latitude', 'longitude')
@@ -281,7 +281,7 @@ def main():
     parseval = float(np.asarray(sout['spectrum_p.z'].values)[0].sum())
     result['spectrum'] = {
         'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{nlat},{nlon}] each, area-weighted '
-                    'mean over (lead_time, latitude); batched R2C rocFFT + fp64 |F|^2 reduction; parity unpinned '
+                    'mean over (lead_time, latitude); fused in-LDS mixed-radix FFT + fp64 |F|^2 reduction (one pass over the field); parity unpinned '
                     '(no reference implementation, SURVEY F3)',
         'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms,
         'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),

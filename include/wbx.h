@@ -238,7 +238,8 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
  * build (WeatherBench-2 lineage): F = rfft(row) / nlon, S_k = |F_k|^2 * (k == 0 ? 1 : 2), k = 0..nlon/2.
  * `field` holds nrows rows consumed IN PLACE: element i of row r is field[r * row_stride + i * lon_stride]
  * (lon-fastest: lon_stride 1, row_stride nlon; latitude-fastest real data: lon_stride nlat, row_stride 1).
- * Batched 1-D R2C rocFFT along longitude, then a HIP |.|^2 reduction:
+ * Contiguous rows with 2/3/5-smooth length: one fused kernel (in-LDS FFT + |.|^2 reduction, the field is read once);
+ * otherwise a batched 1-D R2C rocFFT along longitude, then a HIP |.|^2 reduction:
  *   power_out[group[r]][k] (+)= scale[r] * S_k(row r)
  * group[nrows] (int32 in [0, ngroup)) and scale[nrows] (float64, e.g. area weight / count) are device arrays;
  * power_out is float64[ngroup][nlon/2 + 1]; accumulate = 0 overwrites it, 1 adds to it (fp64 atomics, so the

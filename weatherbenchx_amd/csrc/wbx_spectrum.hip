@@ -6,8 +6,11 @@
 // complex scratch stays bounded; each tile's |F_k|^2 is scaled and added to its group's spectrum.
 #include <rocfft/rocfft.h>
 
+#include <cmath>
+#include <cstdlib>
 #include <map>
 #include <tuple>
+#include <vector>
 
 #include "wbx_common.hpp"
 
@@ -23,6 +26,7 @@ struct FftPlan {
 struct FftState {
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, FftPlan> plans;  // (nlon, lon_stride, row_stride, batch)
   void* scratch = nullptr;  // complex tile
+  std::map<int, void*> twiddles;  // nlon -> device float2[n/2] + float2[n/2 + 1] of the fused path
   size_t scratch_size = 0;
   bool setup = false;
 };
@@ -39,6 +43,7 @@ void spectrum_release(wbx_ctx* ctx) {
   if (!st) return;
   for (auto& kv : st->plans) destroy_plan(kv.second);
   if (st->scratch) (void)hipFree(st->scratch);
+  for (auto& kv : st->twiddles) (void)hipFree(kv.second);
   if (st->setup) rocfft_cleanup();
   delete st;
   ctx->fft_state = nullptr;
@@ -108,6 +113,216 @@ __global__ void __launch_bounds__(256) power_kernel(const float2* __restrict__ F
   unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused path: row -> LDS -> mixed-radix FFT -> |F|^2 * scale -> per-group sums, reading the field ONCE.
+//
+// The rocFFT route moves 5x the field through HBM (R2C = complex FFT of length n/2 writing a temporary + a
+// post-processing kernel writing the Hermitian output, then power_kernel reading it back).  Here ONE WAVE owns one
+// row at a time: the n reals are viewed as n/2 complex numbers in a wave-private LDS buffer and transformed by
+// Stockham passes of radix 4 / 2 / 5 / 3.  In a pass every lane first reads the inputs of all its butterflies into
+// registers, then writes the outputs back into the SAME buffer -- LDS executes a wave's instructions in order, so no
+// barrier and no ping-pong buffer are needed (the 4 waves of a block only share the twiddle tables).  The n/2 + 1
+// Hermitian coefficients come from the usual even/odd split, and |F_k|^2 * (k ? 2 : 1) / n^2 * scale[row] is added to
+// fp64 accumulators in registers (lane l owns wavenumbers l, l + 64, ...).  Consecutive rows of a wave normally belong
+// to one group (lead, level): the accumulators are flushed with fp64 atomics only when the group changes.  Used when
+// rows are contiguous (lon_stride == 1, 8-byte aligned), n <= 2048 and n / 2 has no prime factor above 5; everything
+// else takes the rocFFT route.
+struct FusedSpec {
+  int n, n2, npass;
+  int radix[16];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+
+template <int R>
+__device__ __forceinline__ void butterfly(float2 (&v)[R]) {
+  if constexpr (R == 2) {
+    const float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  } else if constexpr (R == 3) {
+    const float2 t1 = cadd(v[1], v[2]);
+    const float2 t2 = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
+    const float2 d = csub(v[1], v[2]);
+    const float2 t3 = make_float2(0.8660254037844386f * d.x, 0.8660254037844386f * d.y);
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(t2, mul_mi(t3));
+    v[2] = cadd(t2, mul_pi(t3));
+  } else if constexpr (R == 4) {
+    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
+    v[0] = cadd(t0, t2);
+    v[2] = csub(t0, t2);
+    v[1] = cadd(t1, mul_mi(t3));
+    v[3] = cadd(t1, mul_pi(t3));
+  } else {  // R == 5
+    constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f, s1 = 0.9510565162951535f,
+                    s2 = 0.5877852522924731f;
+    const float2 a = v[0];
+    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    v[0] = make_float2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
+    const float2 m1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
+    const float2 m2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
+    const float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const float2 n2v = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    v[1] = cadd(m1, mul_mi(n1));
+    v[4] = cadd(m1, mul_pi(n1));
+    v[2] = cadd(m2, mul_mi(n2v));
+    v[3] = cadd(m2, mul_pi(n2v));
+  }
+}
+
+// One in-place Stockham pass of radix R over the wave's n2 points; a lane owns butterflies lane, lane + 64, ...
+// (at most NB of them).  All reads precede all writes.
+template <int R, int NB>
+__device__ __forceinline__ void wave_pass(float2* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
+                                          float inv_ns, int lane) {
+  const int nb = n2 / R;
+  const int tstep = n2 / (ns * R);  // exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
+  float2 v[NB][R];
+  int base[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int j = lane + 64 * i;
+    if (j < nb) {
+      const int q = (int)(((float)j + 0.5f) * inv_ns);  // j / ns, exact for j < 2^22
+      const int k = j - q * ns;
+      base[i] = (j - k) * R + k;
+      const int kstep = k * tstep;  // integer multiplies are quarter rate: one per butterfly, then additions
+      int ti = 0;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        v[i][t] = buf[j + t * nb];
+        if (t > 0 && ns > 1) v[i][t] = cmul(v[i][t], tw[ti]);
+        ti += kstep;
+      }
+      butterfly<R>(v[i]);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // reads above, writes below (same wave: LDS keeps program order)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int j = lane + 64 * i;
+    if (j < nb) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) buf[base[i] + t * ns] = v[i][t];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int R>
+__device__ __forceinline__ void wave_pass_any(float2* buf, const float2* tw, int n2, int ns, float inv_ns, int lane) {
+  const int nbl = (n2 / R + 63) / 64;  // butterflies per lane
+  if (nbl <= 1) wave_pass<R, 1>(buf, tw, n2, ns, inv_ns, lane);
+  else if (nbl <= 2) wave_pass<R, 2>(buf, tw, n2, ns, inv_ns, lane);
+  else if (nbl <= 3) wave_pass<R, 3>(buf, tw, n2, ns, inv_ns, lane);
+  else wave_pass<R, 4>(buf, tw, n2, ns, inv_ns, lane);  // fused_factor() admits at most 256 butterflies per pass
+}
+
+// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 + 1) / 64).
+template <int KPT>
+__global__ void __launch_bounds__(256, 3) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
+                                                          int rows_per_wave, FusedSpec fs,
+                                                          const float2* __restrict__ tw_pass_g,
+                                                          const float2* __restrict__ tw_real_g,
+                                                          const int32_t* __restrict__ group,
+                                                          const double* __restrict__ scale, double* __restrict__ power) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int n2 = fs.n2, nk = n2 + 1;
+  float2* tw_pass = reinterpret_cast<float2*>(lds_raw);
+  float2* tw_real = tw_pass + n2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float2* buf = tw_real + nk + (nk & 1) + (int64_t)wave * n2;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) tw_pass[i] = tw_pass_g[i];
+  for (int i = threadIdx.x; i < nk; i += blockDim.x) tw_real[i] = tw_real_g[i];
+  __syncthreads();
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r0 = w * rows_per_wave;
+  const int64_t r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
+  if (r0 >= r1) return;
+  const double inv_nn = 1.0 / ((double)fs.n * (double)fs.n);
+  double acc[KPT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) acc[i] = 0.0;
+  int32_t cur = group[r0];
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  for (int64_t r = r0; r < r1; ++r) {
+    const int32_t g = group[r];
+    if (g != cur) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < KPT; ++i) {
+        const int k = lane + 64 * i;
+        if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
+        acc[i] = 0.0;
+      }
+      cur = g;
+    }
+    const f2_t* row = reinterpret_cast<const f2_t*>(field + r * row_stride);
+    for (int j = lane; j < n2; j += 64) {
+      const f2_t q = __builtin_nontemporal_load(row + j);
+      buf[j] = make_float2(q.x, q.y);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int ns = 1;
+    for (int p = 0; p < fs.npass; ++p) {
+      const int rdx = fs.radix[p];
+      const float inv_ns = 1.0f / (float)ns;
+      if (rdx == 4)
+        wave_pass_any<4>(buf, tw_pass, n2, ns, inv_ns, lane);
+      else if (rdx == 2)
+        wave_pass_any<2>(buf, tw_pass, n2, ns, inv_ns, lane);
+      else if (rdx == 3)
+        wave_pass_any<3>(buf, tw_pass, n2, ns, inv_ns, lane);
+      else
+        wave_pass_any<5>(buf, tw_pass, n2, ns, inv_ns, lane);
+      ns *= rdx;
+    }
+    // Hermitian unpack of the half-length transform Z: X_k = E_k + exp(-2 pi i k / n) O_k with
+    // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0)
+    const double sc = scale[r] * inv_nn;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const int k = lane + 64 * i;
+      if (k < nk) {
+        const float2 zk = buf[k == n2 ? 0 : k];
+        const float2 zc = buf[k == 0 ? 0 : n2 - k];
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
+        const float2 x = cadd(e, cmul(tw_real[k], o));
+        const double re = (double)x.x, im = (double)x.y;
+        acc[i] += (re * re + im * im) * (k == 0 ? 1.0 : 2.0) * sc;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next row
+  }
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int k = lane + 64 * i;
+    if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
+  }
+}
+
+static bool fused_factor(int n, FusedSpec& fs) {
+  if (n < 4 || (n & 1) || n > 2048) return false;
+  int m = n / 2;
+  fs.n = n;
+  fs.n2 = m;
+  fs.npass = 0;
+  while (m % 4 == 0) { fs.radix[fs.npass++] = 4; m /= 4; }
+  while (m % 2 == 0) { fs.radix[fs.npass++] = 2; m /= 2; }
+  while (m % 5 == 0) { fs.radix[fs.npass++] = 5; m /= 5; }
+  while (m % 3 == 0) { fs.radix[fs.npass++] = 3; m /= 3; }
+  if (m != 1 || fs.npass > 16) return false;
+  for (int p = 0; p < fs.npass; ++p)
+    if (fs.n2 / fs.radix[p] > 256) return false;  // a lane keeps <= 4 butterflies of a pass in registers
+  return true;
+}
+
 }  // namespace wbx
 
 extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride,
@@ -130,6 +345,52 @@ extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_
     ctx->fft_state = st;
     WBX_FFT(rocfft_setup());
     st->setup = true;
+  }
+  FusedSpec fs;
+  const char* force = getenv("WBX_SPECTRUM_PATH");  // "rocfft" pins the library route (A/B timing, tests)
+  if (!(force && force[0] == 'r') && lon_stride == 1 && (row_stride % 2) == 0 && (((uintptr_t)field) & 7) == 0 &&
+      fused_factor(nlon, fs)) {
+    const int n2 = fs.n2;
+    void*& tw = st->twiddles[nlon];
+    if (!tw) {
+      std::vector<float2> host((size_t)n2 + n2 + 1);
+      for (int m = 0; m < n2; ++m) {
+        const double a = -2.0 * M_PI * (double)m / (double)n2;
+        host[m] = make_float2((float)cos(a), (float)sin(a));
+      }
+      for (int k = 0; k <= n2; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)nlon;
+        host[n2 + k] = make_float2((float)cos(a), (float)sin(a));
+      }
+      WBX_HIP(hipMalloc(&tw, host.size() * sizeof(float2)));
+      WBX_HIP(hipMemcpyAsync(tw, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+      WBX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const float2* tw_pass = reinterpret_cast<const float2*>(tw);
+    const float2* tw_real = tw_pass + n2;
+    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 4 * n2) * sizeof(float2);  // tables + 4 wave-private rows
+    // a wave sweeps a contiguous run of rows (one group for most of it); ~8 waves per SIMD's worth of runs
+    int64_t waves = 256 * 4 * 8;
+    if (waves > nrows) waves = nrows;
+    const int rows_per_wave = (int)((nrows + waves - 1) / waves);
+    waves = (nrows + rows_per_wave - 1) / rows_per_wave;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const int kpt = (nk + 63) / 64;
+#define WBX_LAUNCH_FUSED(KPT)                                                                                       \
+    do {                                                                                                              \
+      if (lds > 48 * 1024)                                                                                            \
+        WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+      hipLaunchKernelGGL(zspec_fused_kernel<KPT>, dim3(blocks), dim3(256), lds, ctx->stream, field, row_stride,     \
+                         nrows, rows_per_wave, fs, tw_pass, tw_real, group, scale, power_out);                        \
+    } while (0)
+    if (kpt <= 4) WBX_LAUNCH_FUSED(4);
+    else if (kpt <= 8) WBX_LAUNCH_FUSED(8);
+    else if (kpt <= 12) WBX_LAUNCH_FUSED(12);
+    else WBX_LAUNCH_FUSED(17);
+#undef WBX_LAUNCH_FUSED
+    WBX_HIP(hipGetLastError());
+    return 0;
   }
   // tile of rows: <= 256 MiB of complex scratch
   int64_t tile = ((int64_t)256 << 20) / ((int64_t)nk * 8);

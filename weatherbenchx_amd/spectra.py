@@ -1,4 +1,4 @@
-"""Zonal power / energy spectra: batched rocFFT along longitude + HIP |F|^2 reduction.
+"""Zonal power / energy spectra: fused in-LDS FFT + |F|^2 reduction (rocFFT for odd / strided rows).
 
 There is NO spectrum metric (and no test) in the reference snapshot, so this component has
 "parity unpinned"; the definition follows the WeatherBench-2 lineage the reference's README points to:
