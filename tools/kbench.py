@@ -47,7 +47,7 @@ def ens():
 
 
 def det():
-  ni, nl, nz = 16, 10, 5
+  ni, nl, nz = int(os.environ.get('KB_NI', 16)), 10, 5
   shape = (ni, nl, nz, NLAT, NLON)
   dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
   arrs = [xr.DataArray(torch.randn(shape, device='cuda') + 280, dims=dims) for _ in range(3)]

@@ -41,6 +41,13 @@ __device__ __forceinline__ T ld_stream(const T* p) {
   return __builtin_nontemporal_load(p);
 }
 
+// Broadcast of lane j's 64-bit value to the whole wave (result in SGPRs).
+__device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
 // Sum over the 64 lanes of a wave (every lane gets the total; all lanes must be active).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -19,6 +19,10 @@
 
 namespace wbx {
 
+#ifndef WBX_CLIM_STREAM
+#define WBX_CLIM_STREAM true
+#endif
+
 // 4-wide vector types that only promise element alignment: gfx950 global loads may be unaligned, so rows
 // that start at any element (e.g. 721-long latitude rows) still get one global_load_dwordx4 per lane.
 template <typename T>
@@ -26,7 +30,7 @@ struct Vec4 {
   typedef T type __attribute__((ext_vector_type(4), aligned(sizeof(T))));
 };
 
-template <typename T, int V>
+template <typename T, int V, bool STREAM = true>
 __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x, int64_t xs, T (&v)[V]) {
   const T* p = reinterpret_cast<const T*>(base) + off;
   if constexpr (V == 4 && sizeof(T) == 1) {
@@ -44,7 +48,11 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
   } else if constexpr (V == 4) {
     if (xs == 1) {
       using V4 = typename Vec4<T>::type;
-      V4 q = __builtin_nontemporal_load(reinterpret_cast<const V4*>(p + x));  // see ld_stream (element-aligned type)
+      V4 q;
+      if constexpr (STREAM)
+        q = __builtin_nontemporal_load(reinterpret_cast<const V4*>(p + x));  // see ld_stream (element-aligned type)
+      else
+        q = *reinterpret_cast<const V4*>(p + x);
       v[0] = q.x;
       v[1] = q.y;
       v[2] = q.z;
@@ -56,7 +64,7 @@ __device__ __forceinline__ void load_x(const void* base, int64_t off, int64_t x,
   } else {
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      if constexpr (sizeof(T) > 1)
+      if constexpr (sizeof(T) > 1 && STREAM)
         v[k] = ld_stream(p + (x + k) * xs);
       else
         v[k] = p[(x + k) * xs];  // mask bytes are re-read by every depth row: keep them cached
@@ -136,7 +144,7 @@ struct DetOp {
     T p[V], t[V] = {}, c[V] = {};
     load_x<T, V>(a.in[0], ro[0], x, a.xstride[0], p);
     if constexpr (NIN > 1) load_x<T, V>(a.in[1], ro[1], x, a.xstride[1], t);
-    if constexpr (NIN > 2) load_x<T, V>(a.in[2], ro[2], x, a.xstride[2], c);
+    if constexpr (NIN > 2) load_x<T, V, WBX_CLIM_STREAM>(a.in[2], ro[2], x, a.xstride[2], c);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       bool valid = true;
@@ -190,7 +198,11 @@ static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   // than the wider loads return.
   const bool masked = plan->flags & WBX_FLAG_MASKED;
   if (plan->flags & WBX_FLAG_SKIPNA) {
-    if (masked) return launch_partial<DetOp<T, FUNC, 3>, 1>(ctx, plan, a);
+    if (masked) {
+      if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, 3>, 4>(ctx, plan, a);
+      return launch_partial<DetOp<T, FUNC, 3>, 1>(ctx, plan, a);
+    }
+    if (plan->vec == 4) return launch_partial<DetOp<T, FUNC, 2>, 4>(ctx, plan, a);
     return launch_partial<DetOp<T, FUNC, 2>, 1>(ctx, plan, a);
   }
   if (masked) {

@@ -22,12 +22,6 @@ struct BinnedArgs {
   unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
 };
 
-__device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
-  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);
-  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), j);
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-
 // OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
 __device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
   int x = (int)v;

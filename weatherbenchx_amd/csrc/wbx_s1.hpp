@@ -94,15 +94,26 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xr_kernel(S1Args a) {
     __syncthreads();
   }
 
-  for (int64_t d = d0 + wave; d < d1; d += nwave) {
-    int64_t ro[WBX_MAX_INPUTS];
-    row_bases<Op::NIN>(a, kb, key, d, ro);
+  // Row offsets come from tables (depth offsets per input, the climatology gather: two dependent lookups).  Resolving
+  // them row by row puts that latency in front of every row's loads (a row is only ~6 loads per lane); instead lane l
+  // resolves the wave's l-th row up front and the sweep broadcasts the results (configs[1]: 4.05 -> 3.9 ms).
+  for (int64_t dbatch = d0 + wave; dbatch < d1; dbatch += (int64_t)64 * nwave) {
+    const int64_t dmine = dbatch + (int64_t)lane * nwave;
+    int64_t rov[WBX_MAX_INPUTS];
+    row_bases<Op::NIN>(a, kb, key, dmine < d1 ? dmine : d1 - 1, rov);
+    const int64_t left = (d1 - dbatch + nwave - 1) / nwave;
+    const int nrow = (int)(left < 64 ? left : 64);
+    for (int l = 0; l < nrow; ++l) {
+      int64_t ro[WBX_MAX_INPUTS];
+#pragma unroll
+      for (int i = 0; i < WBX_MAX_INPUTS; ++i) ro[i] = (i < Op::NIN || i == 3) ? readlane64(rov[i], l) : 0;
 #pragma unroll Op::XR_UNROLL
-    for (int64_t x = (int64_t)lane * V; x < a.nx; x += 64 * V) {
-      if constexpr (MROW)
-        Op::template accum_mrow<V>(a, ro, x, acc, smask);
-      else
-        Op::template accum<V, false>(a, ro, x, acc);
+      for (int64_t x = (int64_t)lane * V; x < a.nx; x += 64 * V) {
+        if constexpr (MROW)
+          Op::template accum_mrow<V>(a, ro, x, acc, smask);
+        else
+          Op::template accum<V, false>(a, ro, x, acc);
+      }
     }
   }
 
@@ -144,6 +155,9 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xk_kernel(S1Args a) {
     for (int l = 0; l < NA; ++l) acc[k][l] = 0.0;
 
   const int nvalid = a.nx - x < V ? (int)(a.nx - x) : V;  // < V only for the last lane of a ragged row
+  // (row offsets are resolved row by row here: the 4x unrolled loop already batches the table lookups of four rows;
+  // the lane-parallel resolution of s1_xr_kernel defeats that unrolling and measured slower: 0.39 -> 0.44 ms on the
+  // latitude-fastest ensemble chunk)
   if (V == 1 || nvalid == V) {
 #pragma unroll Op::XK_UNROLL
     for (int64_t d = d0; d < d1; ++d) {

@@ -214,7 +214,7 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
   # (Measured on MI355X: UNALIGNED dwordx4 on 721-long latitude rows runs 6.8 ms vs 4.8 ms for dword loads on
   # configs[1], so ragged / odd rows deliberately stay on the scalar path.)
   vec = 1
-  if allow_vec4 and not (flags & 2) and nx >= 4 and nx % 4 == 0 and x_dim is not None:  # 2 = skipna: scalar path
+  if allow_vec4 and nx >= 4 and nx % 4 == 0 and x_dim is not None:
     ok = True
     for i, lay in enumerate(layouts[:4]):
       if lay is None:
