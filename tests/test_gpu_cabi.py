@@ -381,3 +381,73 @@ def test_masked_reduction_with_depth_independent_mask(ctx, nx, skipna):
   np.testing.assert_allclose(vals[2], want, rtol=1e-12)
   np.testing.assert_allclose(vals[1], np.where(ok, np.abs(e), 0.0).sum(axis=(0, 3)), rtol=1e-12)
   np.testing.assert_allclose(cnt[2], ok.sum(axis=(0, 3)))
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('mode', ['plain', 'masked', 'skipna'])
+def test_region_binned_paths_on_a_one_degree_grid(ctx, monkeypatch, layout, mode):
+  """17 regions x land/sea (34 bins) on a 181 x 360 grid, several x tiles / row splits / sweeps per patch: the fused
+  kernel (wbx_det_binned), the two-stage path with the stage-2 patch kernel and the oracle must agree for RMSE, ACC
+  and bias, including NaN targets under masked / skipna and a NaN that poisons every bin without them."""
+  import sys
+  import os
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  from wb_regions import REGIONS
+  from weatherbenchx_amd import binning
+  rng = np.random.default_rng(23)
+  nlat, nlon = 181, 360
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * 1.0
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  dims = ('init_time', 'lead_time', 'level') + sp
+  sizes = {'init_time': 2, 'lead_time': 3, 'level': 2, 'latitude': nlat, 'longitude': nlon}
+  coords = {'init_time': np.datetime64('2020-01-01T00', 'ns') + np.arange(2) * np.timedelta64(12, 'h'),
+            'lead_time': np.arange(3) * np.timedelta64(6, 'h'), 'level': [500, 850], 'latitude': lat, 'longitude': lon}
+  shape = tuple(sizes[d] for d in dims)
+  pv = (rng.normal(size=shape) + 280).astype(np.float32)
+  tv = (rng.normal(size=shape) + 280).astype(np.float32)
+  if mode == 'plain':
+    tv[(1, 2, 1) + ((90, 10) if layout == 'lon_fastest' else (10, 90))] = np.nan  # poisons every bin of that cell
+  else:
+    tv[rng.random(shape) < 0.05] = np.nan
+  p = xr.DataArray(pv, dims=dims, coords=coords)
+  t = xr.DataArray(tv, dims=dims, coords=coords)
+  if mode == 'masked':
+    t.coords['mask'] = ~np.isnan(t)
+  cdims = ('dayofyear', 'hour', 'level') + sp
+  cv = (rng.normal(size=(3, 4, 2) + tuple(sizes[d] for d in sp)) + 280).astype(np.float32)
+  clim = xr.DataArray(cv, dims=cdims, coords={'dayofyear': [1, 2, 3], 'hour': [0, 6, 12, 18], 'level': [500, 850],
+                                              'latitude': lat, 'longitude': lon})
+  land = rng.random((nlat, nlon)) > 0.6
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  metrics = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC({'z': clim}), 'bias': deterministic.Bias()}
+  monkeypatch.setenv('WBX_S2_PATCH_MIN', '0')
+  results = {}
+  for binned in ('always', 'never'):
+    monkeypatch.setattr(engine, 'BINNED_MODE', binned)
+    engine.clear_caches()
+    agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                                 weigh_by=[weighting.GridAreaWeighting()],
+                                 bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)],
+                                 masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+    results[binned] = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'z': p}, {'z': t})
+  for k in results['never']:
+    np.testing.assert_allclose(results['always'][k].values, results['never'][k].values, rtol=1e-9, atol=1e-12,
+                               equal_nan=True)
+  # oracle for the squared error
+  w = (O.grid_area_weights(lat), ('latitude',))
+  names, masks = O.region_masks(lat, lon, REGIONS, land_sea_mask=land)
+  kw = {}
+  if mode == 'masked':
+    kw = dict(mask=~np.isnan(tv), mask_dims=dims)
+  if mode == 'skipna':
+    kw = dict(skipna=True)
+  sws, sw, od = O.aggregate(O.squared_error(pv, tv), dims, ['init_time', 'latitude', 'longitude'], weights=[w],
+                            bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))], **kw)
+  with np.errstate(all='ignore'):
+    want = np.sqrt(sws / sw)
+  got = results['always']['rmse.z']
+  assert list(got['region'].values) == names and len(names) == 34
+  np.testing.assert_allclose(got.transpose(*od).values, want, rtol=RTOL, equal_nan=True)
+  if mode == 'plain':
+    assert np.isnan(got.sel(lead_time=coords['lead_time'][2], level=850).values).all()
+    assert np.isfinite(got.sel(lead_time=coords['lead_time'][0], level=850).values).all()
