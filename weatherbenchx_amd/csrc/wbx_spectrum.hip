@@ -133,28 +133,43 @@ struct FusedSpec {
   int radix[16];
 };
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
-__device__ __forceinline__ float2 mul_pi(float2 a) { return make_float2(-a.y, a.x); }  // a * (+i)
+// A wave transforms TWO rows at once: every quantity is a pair (row A, row B) in one 64-bit register pair, so the
+// butterflies and twiddle products compile to packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32) and both rows
+// share the twiddle loads, the index arithmetic and the LDS instructions (one ds_read_b128 / ds_write_b128 per point).
+typedef float v2 __attribute__((ext_vector_type(2)));
+typedef float v4 __attribute__((ext_vector_type(4)));
+struct C2 {
+  v2 re, im;  // (row A, row B)
+};
+__device__ __forceinline__ C2 cadd(C2 a, C2 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ C2 csub(C2 a, C2 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ C2 mul_mi(C2 a) { return {a.im, -a.re}; }  // a * (-i)
+__device__ __forceinline__ C2 mul_pi(C2 a) { return {-a.im, a.re}; }  // a * (+i)
+__device__ __forceinline__ C2 cscale(C2 a, float s) { return {a.re * s, a.im * s}; }
+__device__ __forceinline__ C2 ctw(C2 a, float2 w) {  // a * (w.x + i w.y), the same twiddle for both rows
+  return {a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x};
+}
+__device__ __forceinline__ C2 ld_c2(const v4* p) {
+  const v4 q = *p;
+  return {{q.x, q.y}, {q.z, q.w}};
+}
+__device__ __forceinline__ void st_c2(v4* p, C2 a) { *p = (v4){a.re.x, a.re.y, a.im.x, a.im.y}; }
 
 template <int R>
-__device__ __forceinline__ void butterfly(float2 (&v)[R]) {
+__device__ __forceinline__ void butterfly(C2 (&v)[R]) {
   if constexpr (R == 2) {
-    const float2 a = v[0], b = v[1];
+    const C2 a = v[0], b = v[1];
     v[0] = cadd(a, b);
     v[1] = csub(a, b);
   } else if constexpr (R == 3) {
-    const float2 t1 = cadd(v[1], v[2]);
-    const float2 t2 = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
-    const float2 d = csub(v[1], v[2]);
-    const float2 t3 = make_float2(0.8660254037844386f * d.x, 0.8660254037844386f * d.y);
+    const C2 t1 = cadd(v[1], v[2]);
+    const C2 t2 = csub(v[0], cscale(t1, 0.5f));
+    const C2 t3 = cscale(csub(v[1], v[2]), 0.8660254037844386f);
     v[0] = cadd(v[0], t1);
     v[1] = cadd(t2, mul_mi(t3));
     v[2] = cadd(t2, mul_pi(t3));
   } else if constexpr (R == 4) {
-    const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
+    const C2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
     v[0] = cadd(t0, t2);
     v[2] = csub(t0, t2);
     v[1] = cadd(t1, mul_mi(t3));
@@ -162,13 +177,13 @@ __device__ __forceinline__ void butterfly(float2 (&v)[R]) {
   } else {  // R == 5
     constexpr float c1 = 0.30901699437494745f, c2 = -0.8090169943749475f, s1 = 0.9510565162951535f,
                     s2 = 0.5877852522924731f;
-    const float2 a = v[0];
-    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    v[0] = make_float2(a.x + t1.x + t2.x, a.y + t1.y + t2.y);
-    const float2 m1 = make_float2(a.x + c1 * t1.x + c2 * t2.x, a.y + c1 * t1.y + c2 * t2.y);
-    const float2 m2 = make_float2(a.x + c2 * t1.x + c1 * t2.x, a.y + c2 * t1.y + c1 * t2.y);
-    const float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
-    const float2 n2v = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    const C2 a = v[0];
+    const C2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    v[0] = cadd(a, cadd(t1, t2));
+    const C2 m1 = cadd(a, cadd(cscale(t1, c1), cscale(t2, c2)));
+    const C2 m2 = cadd(a, cadd(cscale(t1, c2), cscale(t2, c1)));
+    const C2 n1 = cadd(cscale(t3, s1), cscale(t4, s2));
+    const C2 n2v = csub(cscale(t3, s2), cscale(t4, s1));
     v[1] = cadd(m1, mul_mi(n1));
     v[4] = cadd(m1, mul_pi(n1));
     v[2] = cadd(m2, mul_mi(n2v));
@@ -176,14 +191,14 @@ __device__ __forceinline__ void butterfly(float2 (&v)[R]) {
   }
 }
 
-// One in-place Stockham pass of radix R over the wave's n2 points; a lane owns butterflies lane, lane + 64, ...
-// (at most NB of them).  All reads precede all writes.
+// One in-place Stockham pass of radix R over the wave's n2 points (two rows each); a lane owns butterflies lane,
+// lane + 64, ... (at most NB of them).  All reads precede all writes.
 template <int R, int NB>
-__device__ __forceinline__ void wave_pass(float2* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
+__device__ __forceinline__ void wave_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
                                           float inv_ns, int lane) {
   const int nb = n2 / R;
   const int tstep = n2 / (ns * R);  // exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
-  float2 v[NB][R];
+  C2 v[NB][R];
   int base[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -196,8 +211,8 @@ __device__ __forceinline__ void wave_pass(float2* __restrict__ buf, const float2
       int ti = 0;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-        v[i][t] = buf[j + t * nb];
-        if (t > 0 && ns > 1) v[i][t] = cmul(v[i][t], tw[ti]);
+        v[i][t] = ld_c2(buf + j + t * nb);
+        if (t > 0 && ns > 1) v[i][t] = ctw(v[i][t], tw[ti]);
         ti += kstep;
       }
       butterfly<R>(v[i]);
@@ -209,14 +224,14 @@ __device__ __forceinline__ void wave_pass(float2* __restrict__ buf, const float2
     const int j = lane + 64 * i;
     if (j < nb) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) buf[base[i] + t * ns] = v[i][t];
+      for (int t = 0; t < R; ++t) st_c2(buf + base[i] + t * ns, v[i][t]);
     }
   }
   __builtin_amdgcn_wave_barrier();
 }
 
 template <int R>
-__device__ __forceinline__ void wave_pass_any(float2* buf, const float2* tw, int n2, int ns, float inv_ns, int lane) {
+__device__ __forceinline__ void wave_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int lane) {
   const int nbl = (n2 / R + 63) / 64;  // butterflies per lane
   if (nbl <= 1) wave_pass<R, 1>(buf, tw, n2, ns, inv_ns, lane);
   else if (nbl <= 2) wave_pass<R, 2>(buf, tw, n2, ns, inv_ns, lane);
@@ -226,18 +241,18 @@ __device__ __forceinline__ void wave_pass_any(float2* buf, const float2* tw, int
 
 // tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 + 1) / 64).
 template <int KPT>
-__global__ void __launch_bounds__(256, 3) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
-                                                          int rows_per_wave, FusedSpec fs,
-                                                          const float2* __restrict__ tw_pass_g,
-                                                          const float2* __restrict__ tw_real_g,
-                                                          const int32_t* __restrict__ group,
-                                                          const double* __restrict__ scale, double* __restrict__ power) {
+__global__ void __launch_bounds__(256, 2) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
+                                                             int rows_per_wave, FusedSpec fs,
+                                                             const float2* __restrict__ tw_pass_g,
+                                                             const float2* __restrict__ tw_real_g,
+                                                             const int32_t* __restrict__ group,
+                                                             const double* __restrict__ scale, double* __restrict__ power) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int n2 = fs.n2, nk = n2 + 1;
   float2* tw_pass = reinterpret_cast<float2*>(lds_raw);
   float2* tw_real = tw_pass + n2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float2* buf = tw_real + nk + (nk & 1) + (int64_t)wave * n2;
+  v4* buf = reinterpret_cast<v4*>(tw_real + nk + (nk & 1)) + (int64_t)wave * n2;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) tw_pass[i] = tw_pass_g[i];
   for (int i = threadIdx.x; i < nk; i += blockDim.x) tw_real[i] = tw_real_g[i];
   __syncthreads();
@@ -250,22 +265,24 @@ __global__ void __launch_bounds__(256, 3) zspec_fused_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < KPT; ++i) acc[i] = 0.0;
   int32_t cur = group[r0];
-  typedef float f2_t __attribute__((ext_vector_type(2)));
-  for (int64_t r = r0; r < r1; ++r) {
-    const int32_t g = group[r];
-    if (g != cur) {  // wave-uniform
+  auto flush = [&](int32_t next) {
 #pragma unroll
-      for (int i = 0; i < KPT; ++i) {
-        const int k = lane + 64 * i;
-        if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
-        acc[i] = 0.0;
-      }
-      cur = g;
+    for (int i = 0; i < KPT; ++i) {
+      const int k = lane + 64 * i;
+      if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
+      acc[i] = 0.0;
     }
-    const f2_t* row = reinterpret_cast<const f2_t*>(field + r * row_stride);
+    cur = next;
+  };
+  for (int64_t r = r0; r < r1; r += 2) {
+    const bool two = r + 1 < r1;  // wave-uniform; a missing second row is a row of zeros with scale 0
+    const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
+    const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
+    const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
     for (int j = lane; j < n2; j += 64) {
-      const f2_t q = __builtin_nontemporal_load(row + j);
-      buf[j] = make_float2(q.x, q.y);
+      const v2 a = __builtin_nontemporal_load(rowa + j);
+      const v2 b = two ? __builtin_nontemporal_load(rowb + j) : (v2){0.f, 0.f};
+      buf[j] = (v4){a.x, b.x, a.y, b.y};
     }
     __builtin_amdgcn_wave_barrier();
     int ns = 1;
@@ -284,27 +301,32 @@ __global__ void __launch_bounds__(256, 3) zspec_fused_kernel(const float* __rest
     }
     // Hermitian unpack of the half-length transform Z: X_k = E_k + exp(-2 pi i k / n) O_k with
     // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0)
-    const double sc = scale[r] * inv_nn;
+    const double sca = scale[r] * inv_nn, scb = two ? scale[r + 1] * inv_nn : 0.0;
+    if (ga != cur) flush(ga);  // wave-uniform
+    const bool split = gb != ga;  // the pair straddles a group boundary (rare): row B goes out through its own atomics
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = lane + 64 * i;
       if (k < nk) {
-        const float2 zk = buf[k == n2 ? 0 : k];
-        const float2 zc = buf[k == 0 ? 0 : n2 - k];
-        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        const float2 o = make_float2(0.5f * (zk.y + zc.y), -0.5f * (zk.x - zc.x));
-        const float2 x = cadd(e, cmul(tw_real[k], o));
-        const double re = (double)x.x, im = (double)x.y;
-        acc[i] += (re * re + im * im) * (k == 0 ? 1.0 : 2.0) * sc;
+        const C2 zk = ld_c2(buf + (k == n2 ? 0 : k));
+        const C2 zc = ld_c2(buf + (k == 0 ? 0 : n2 - k));
+        const C2 e = {(zk.re + zc.re) * 0.5f, (zk.im - zc.im) * 0.5f};
+        const C2 o = {(zk.im + zc.im) * 0.5f, (zc.re - zk.re) * 0.5f};
+        const C2 x = cadd(e, ctw(o, tw_real[k]));
+        const double dbl = k == 0 ? 1.0 : 2.0;
+        const double pa = ((double)x.re.x * (double)x.re.x + (double)x.im.x * (double)x.im.x) * dbl * sca;
+        const double pb = ((double)x.re.y * (double)x.re.y + (double)x.im.y * (double)x.im.y) * dbl * scb;
+        if (split) {
+          acc[i] += pa;
+          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], pb);
+        } else {
+          acc[i] += pa + pb;
+        }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next row
+    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair of rows
   }
-#pragma unroll
-  for (int i = 0; i < KPT; ++i) {
-    const int k = lane + 64 * i;
-    if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
-  }
+  flush(cur);
 }
 
 static bool fused_factor(int n, FusedSpec& fs) {
@@ -368,11 +390,12 @@ extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_
     }
     const float2* tw_pass = reinterpret_cast<const float2*>(tw);
     const float2* tw_real = tw_pass + n2;
-    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 4 * n2) * sizeof(float2);  // tables + 4 wave-private rows
+    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 8 * n2) * sizeof(float2);  // tables + 4 wave-private row PAIRS
     // a wave sweeps a contiguous run of rows (one group for most of it); ~8 waves per SIMD's worth of runs
     int64_t waves = 256 * 4 * 8;
-    if (waves > nrows) waves = nrows;
-    const int rows_per_wave = (int)((nrows + waves - 1) / waves);
+    if (waves > (nrows + 1) / 2) waves = (nrows + 1) / 2;
+    int rows_per_wave = (int)((nrows + waves - 1) / waves);
+    rows_per_wave += rows_per_wave & 1;  // whole pairs
     waves = (nrows + rows_per_wave - 1) / rows_per_wave;
     const unsigned blocks = (unsigned)((waves + 3) / 4);
     const int kpt = (nk + 63) / 64;
