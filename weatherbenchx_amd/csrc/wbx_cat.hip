@@ -37,11 +37,13 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
   const bool masked = a.flags & WBX_FLAG_MASKED, skipna = a.flags & WBX_FLAG_SKIPNA;
   const bool valid = masked ? cat_ld<uint8_t>(a.in[3], ro[3] + x * a.xstride[3]) != 0 : true;
   const int nc = c.ncat;
-  const double t = (double)cat_ld<T>(a.in[1], ro[1] + x * a.xstride[1]);
-  const int64_t p0 = ro[0] + x * a.xstride[0];
+  const T tnat = cat_ld<T>(a.in[1], ro[1] + x * a.xstride[1]);
+  const double t = (double)tnat;
+  const T* pm = reinterpret_cast<const T*>(a.in[0]) + ro[0] + x * a.xstride[0];  // members: pm[m * mstride]
   if (c.func == WBX_CAT_RANK) {
     int r = 0;
-    for (int m = 0; m < a.M; ++m) r += ((double)cat_ld<T>(a.in[0], p0 + m * a.mstride) < t) ? 1 : 0;
+#pragma unroll 8
+    for (int m = 0; m < a.M; ++m) r += (ld_stream(pm + (int64_t)m * a.mstride) < tnat) ? 1 : 0;  // NaN compares false
     if (valid) col[r * stride] += 1.0;
     if (skipna) {
       for (int k = 0; k < nc; ++k) col[(nc + k) * stride] += valid ? 1.0 : 0.0;
@@ -57,8 +59,9 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
     double thr[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) thr[q] = k0 + q < nc ? c.thr[k0 + q] : INFINITY;
+#pragma unroll 4
     for (int m = 0; m < a.M; ++m) {
-      const double ae = fabs((double)cat_ld<T>(a.in[0], p0 + m * a.mstride) - t);
+      const double ae = fabs((double)ld_stream(pm + (int64_t)m * a.mstride) - t);
       n += (ae == ae) ? 1 : 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) cnt[q] += (ae > thr[q]) ? 1 : 0;  // NaN > x is false
