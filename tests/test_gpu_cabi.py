@@ -451,3 +451,37 @@ def test_region_binned_paths_on_a_one_degree_grid(ctx, monkeypatch, layout, mode
   if mode == 'plain':
     assert np.isnan(got.sel(lead_time=coords['lead_time'][2], level=850).values).all()
     assert np.isfinite(got.sel(lead_time=coords['lead_time'][0], level=850).values).all()
+
+
+def test_rccl_all_reduce_of_a_packed_state_single_rank(ctx):
+  """The RCCL leg of distributed.all_reduce_state (backend 'nccl' = RCCL on ROCm) on the one GPU a test box has:
+  pack -> H2D -> fingerprint MIN all-reduce -> payload SUM all-reduce -> D2H -> unpack must be the identity for a
+  one-rank group.  (World size 2 runs on gloo in tests/test_distributed.py; N > 1 on RCCL is the driver's scaling run.)"""
+  import socket
+  import torch
+  import torch.distributed as dist
+  from weatherbenchx_amd import distributed
+  if dist.is_initialized():
+    pytest.skip('a process group already exists in this process')
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  torch.cuda.set_device(0)
+  dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                          device_id=torch.device('cuda', 0))
+  try:
+    rng = np.random.default_rng(0)
+    p = xr.DataArray(rng.normal(size=(3, 16, 32)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
+                     coords={'latitude': np.linspace(-80, 80, 16)})
+    t = xr.DataArray(rng.normal(size=(3, 16, 32)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
+                     coords={'latitude': np.linspace(-80, 80, 16)})
+    metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+    agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+    with engine.deferred_results():
+      state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t}))
+      reduced = distributed.all_reduce_state(state, force=True)  # waits for the deferred sums first
+    want, got = state.metric_values(metrics), reduced.metric_values(metrics)
+    for k in want:
+      np.testing.assert_array_equal(got[k].values, want[k].values)
+  finally:
+    dist.destroy_process_group()

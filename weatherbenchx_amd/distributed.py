@@ -54,12 +54,13 @@ def unpack_state(flat: np.ndarray, items) -> AggregationState:
   return AggregationState(out['sws'], out['sw'])
 
 
-def all_reduce_state(state: AggregationState, group=None) -> AggregationState:
-  """Sum of every rank's AggregationState (all ranks must hold the same statistics / shapes)."""
+def all_reduce_state(state: AggregationState, group=None, *, force: bool = False) -> AggregationState:
+  """Sum of every rank's AggregationState (all ranks must hold the same statistics / shapes).  `force` runs the
+  collectives even in a one-rank group (the RCCL plumbing check of tests/test_gpu_cabi.py)."""
   import torch  # pylint: disable=g-import-not-at-top
   import torch.distributed as dist  # pylint: disable=g-import-not-at-top
 
-  if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+  if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
     return state
   state.wait()
   flat, layout, items = pack_state(state)
