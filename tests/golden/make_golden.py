@@ -70,6 +70,45 @@ def ensembles():
   np.savez_compressed(os.path.join(HERE, 'ensemble_19x36.npz'), **out)
 
 
+def regions_and_indicators():
+  """32x64 grid, 7 regions x land/sea = 14 bins (the public benchmark's binning, run_benchmark_evaluation.py:369-382,
+  at test size) with NaN targets under masked=True; ErrorExceedance / EnsembleErrorExceedance / RankHistogram
+  (deterministic.py:262-295, probabilistic.py:836-861, 1306-1343) for a 5-member ensemble."""
+  lat = np.linspace(-87.1875, 87.1875, 32)
+  lon = np.arange(64) * 5.625
+  rng = np.random.default_rng(77)
+  regions = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'nh': ((20, 90), (0, 360)),
+             'sh': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)), 'namerica': ((25, 60), (240, 285)),
+             'ausnz': ((-45, -12.5), (120, 175))}
+  land = rng.random((32, 64)) > 0.6
+  names, masks = O.region_masks(lat, lon, regions, land_sea_mask=land)
+  dims = ('lead_time', 'latitude', 'longitude')
+  p = (rng.normal(size=(3, 32, 64)) + 280).astype(np.float32)
+  t = (rng.normal(size=(3, 32, 64)) + 280).astype(np.float32)
+  t[rng.random(t.shape) < 0.08] = np.nan
+  valid = ~np.isnan(t)
+  w = (O.grid_area_weights(lat), ('latitude',))
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  out = {'latitude': lat, 'longitude': lon, 'land': land, 'region_names': np.array(names), 'p': p, 't': t,
+         'region_lims': np.array([[v[0][0], v[0][1], v[1][0], v[1][1]] for v in regions.values()]),
+         'region_keys': np.array(list(regions))}
+  for stat, fn in (('SquaredError', O.squared_error), ('AbsoluteError', O.absolute_error)):
+    sws, sw, od = O.aggregate(fn(p, t), dims, ['latitude', 'longitude'], weights=[w], bin_masks=bm, mask=valid,
+                              mask_dims=dims)
+    out[f'{stat}__sws'], out[f'{stat}__sw'] = sws, sw
+  m = 5
+  pe = (np.nan_to_num(t, nan=280.0)[:, None] + rng.normal(size=(3, m, 32, 64)) * 1.5).astype(np.float32)
+  pd = ('lead_time', 'number', 'latitude', 'longitude')
+  thresholds = np.array([0.5, 1.0, 2.5])
+  out['pe'], out['thresholds'] = pe, thresholds
+  for name, (stat, sd) in (('EnsembleErrorExceedance', O.ensemble_error_exceedance(pe, pd, t, dims, thresholds, 'number')),
+                           ('RankHistogram', O.rank_histogram(pe, pd, t, dims, 'number')),
+                           ('ErrorExceedance', O.error_exceedance(pe[:, 0], dims, t, dims, thresholds))):
+    sws, sw, od = O.aggregate(stat, sd, ['latitude', 'longitude'], weights=[w], skipna=True)
+    out[f'{name}__sws'], out[f'{name}__sw'] = sws, sw
+  np.savez_compressed(os.path.join(HERE, 'regions_indicators.npz'), **out)
+
+
 def weights_and_spectrum():
   out = {'w721': O.grid_area_weights(np.linspace(-90, 90, 721)),
          'w721_desc_unnorm': O.grid_area_weights(np.linspace(90, -90, 721), normalized=False)}
@@ -84,4 +123,5 @@ if __name__ == '__main__':
   config1()
   ensembles()
   weights_and_spectrum()
+  regions_and_indicators()
   print('golden vectors written to', HERE)
