@@ -703,3 +703,51 @@ def test_indicator_statistics_match_oracle(backend, mode, layout):
   np.testing.assert_allclose(np.nansum(want, axis=od.index('rank')), 1.0)  # a histogram
   want, od = mean_of(*O.error_exceedance(pv[:, 0], tdims, tv, tdims, thresholds))
   np.testing.assert_allclose(got_det['det_exc.v'].transpose(*od).values, want, rtol=RTOL, equal_nan=True)
+
+
+@pytest.mark.parametrize('mask_order', ['lon_lat', 'lat_lon'])
+def test_plane_mode_with_a_validity_mask(backend, mask_order):
+  """Latitude-fastest chunk + masked=True with a mask coordinate on the targets (SST-style NaNs): when the mask is
+  stored in the data's (longitude, latitude) order its spans ride through LDS with the data (plane mode); a
+  (latitude, longitude) mask takes the generic x-kept kernel.  Both must equal the oracle."""
+  from weatherbenchx_amd import planner
+  rng = np.random.default_rng(21)
+  nlat, nlon = 91, 24
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * 15.0
+  dims = ('init_time', 'lead_time', 'longitude', 'latitude')
+  shape = (3, 2, nlon, nlat)
+  coords = {'latitude': lat, 'longitude': lon,
+            'init_time': np.array(['2020-01-01T00', '2020-01-02T00', '2020-01-03T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(2) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  pv = (rng.normal(size=shape) + 280).astype(np.float32)
+  tv = (rng.normal(size=shape) + 280).astype(np.float32)
+  valid = rng.random((nlon, nlat)) > 0.3
+  tv[:, :, ~valid] = np.nan
+  pv[0, 0, ~valid] = np.inf  # masked-out points contribute exactly 0 whatever they hold
+  p = xr.DataArray(pv, dims=dims, coords=coords)
+  t = xr.DataArray(tv, dims=dims, coords=coords)
+  if mask_order == 'lon_lat':
+    t.coords['mask'] = xr.DataArray(valid, dims=('longitude', 'latitude'))
+  else:
+    t.coords['mask'] = xr.DataArray(np.ascontiguousarray(valid.T), dims=('latitude', 'longitude'))
+  metrics = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
+                               weigh_by=[weighting.GridAreaWeighting()], masked=True)
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'z': p}, {'z': t})
+  w = (O.grid_area_weights(lat), ('latitude',))
+  full_valid = np.broadcast_to(valid, shape)
+  with np.errstate(invalid='ignore'):
+    se, e = O.squared_error(pv, tv), O.error(pv, tv)
+  sws, sw, _ = O.aggregate(se, dims, ['init_time', 'latitude', 'longitude'], weights=[w], mask=full_valid, mask_dims=dims)
+  np.testing.assert_allclose(res['rmse.z'].values, np.sqrt(sws / sw), rtol=RTOL)
+  sws, sw, _ = O.aggregate(e, dims, ['init_time', 'latitude', 'longitude'], weights=[w], mask=full_valid, mask_dims=dims)
+  np.testing.assert_allclose(res['bias.z'].values, sws / sw, rtol=RTOL, atol=1e-9)
+  lays = [planner.InputLayout(strides=dict(zip(dims, [int(s // 4) for s in a.strides])), itemsize=4, base_alignment=256)
+          for a in (pv, tv)] + [None]
+  mdims = ('longitude', 'latitude') if mask_order == 'lon_lat' else ('latitude', 'longitude')
+  mshape = (nlon, nlat) if mask_order == 'lon_lat' else (nlat, nlon)
+  lays.append(planner.InputLayout(strides=dict(zip(mdims, (mshape[1], 1))), itemsize=1, base_alignment=256))
+  plan = planner.build_s1_plan(dims, dict(zip(dims, shape)), lays, ['init_time', 'latitude', 'longitude'],
+                               wdep_dims=['latitude'], flags=1)
+  assert plan.x_dim == 'latitude' and plan.x_kept
+  assert plan.plane_rows == (8 if mask_order == 'lon_lat' else 0)

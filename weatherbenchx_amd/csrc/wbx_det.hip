@@ -180,22 +180,24 @@ struct DetOp {
 
 template <typename T, int FUNC>
 static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
-  const bool mm = plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA);
   if (plan->plane_rows > 0) {
     if constexpr (std::is_same<T, float>::value) {
-      WBX_REQUIRE(!mm, "plane mode does not take mask/skipna flags");
+      WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA), "plane mode does not take the skipna flag");
       for (int i = 0; i < DetOp<T, FUNC, 0>::NIN; ++i)
         WBX_REQUIRE(plan->xstride[i] == 1 && (((uintptr_t)a.in[i]) & 15) == 0,
                     "plane mode needs unit x stride and 16-byte aligned inputs");
+      if (plan->flags & WBX_FLAG_MASKED) {
+        WBX_REQUIRE(plan->xstride[3] == 1 && (((uintptr_t)a.in[3]) & 3) == 0,
+                    "plane mode needs a unit-stride, 4-byte aligned mask");
+        if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 1>, 1>(ctx, plan, a);
+        return launch_plane<DetOp<T, FUNC, 1>>(ctx, plan, a);
+      }
       if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
       return launch_plane<DetOp<T, FUNC, 0>>(ctx, plan, a);
     } else {
       return fail(WBX_ERR_INVALID, "plane mode is fp32 only");
     }
   }
-  // count-lane variant stays on one element per lane: the 4-wide form was measured SLOWER on MI355X (masked 2.62 vs
-  // 2.30 ms, skipna 2.39 vs 1.73 ms on f32[16,10,5,721,1440]) -- 24 fp64 accumulators + selects cost more occupancy
-  // than the wider loads return.
   const bool masked = plan->flags & WBX_FLAG_MASKED;
   if (plan->flags & WBX_FLAG_SKIPNA) {
     if (masked) {

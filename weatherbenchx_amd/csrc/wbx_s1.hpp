@@ -213,12 +213,39 @@ __global__ void __launch_bounds__(1024, 6) s1_xp_kernel(S1Args a, int R) {  // <
 
   float4 regs[NIN][MAXV];
   int lead[NIN], lead_next[NIN];
+  // validity mask (Op::MROW_OK ops with WBX_FLAG_MASKED): the span's R * nx mask bytes ride along as dwords
+  constexpr bool MASKED = op_has_mrow<Op>::value;
+  uint8_t* lds_mask = reinterpret_cast<uint8_t*>(lds_raw + NIN * slot);
+  const int nvec_m = (R * nx + 3 + 3) / 4;  // dwords covering any span of R*nx bytes with a lead of <= 3
+  uint32_t mregs[MAXV] = {};
+  int mlead = 0, mlead_next = 0;
 
-  auto prefetch = [&](int64_t d, int (&ld)[NIN]) {
+  auto prefetch = [&](int64_t d, int (&ld)[NIN], int& ml) {
     int64_t ro[WBX_MAX_INPUTS];
     row_bases<NIN>(a, kb, key, d, ro);
     const int rows = (int)(d1 - d < R ? d1 - d : R);
     const int n = rows * nx;
+    if constexpr (MASKED) {
+      const uint8_t* mbase = reinterpret_cast<const uint8_t*>(a.in[3]);
+      const int64_t start = ro[3];
+      const int64_t a0 = start & ~(int64_t)3;
+      ml = (int)(start - a0);
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int k = tid + v * T;
+        uint32_t q = 0;
+        if (k < nvec_m) {
+          const int e0 = 4 * k;
+          if (e0 + 3 < ml + n) {
+            q = *reinterpret_cast<const uint32_t*>(mbase + a0 + e0);
+          } else if (e0 < ml + n) {  // straddles the span end: never read past the last byte
+            for (int c = 0; c < 4; ++c)
+              if (e0 + c < ml + n) q |= (uint32_t)mbase[a0 + e0 + c] << (8 * c);
+          }
+        }
+        mregs[v] = q;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       const float* base = reinterpret_cast<const float*>(a.in[i]);
@@ -247,7 +274,7 @@ __global__ void __launch_bounds__(1024, 6) s1_xp_kernel(S1Args a, int R) {  // <
     }
   };
 
-  if (d0 < d1) prefetch(d0, lead);
+  if (d0 < d1) prefetch(d0, lead, mlead);
   for (int64_t d = d0; d < d1; d += R) {
     // registers -> LDS
 #pragma unroll
@@ -257,21 +284,38 @@ __global__ void __launch_bounds__(1024, 6) s1_xp_kernel(S1Args a, int R) {  // <
         const int k = tid + v * T;
         if (k < nvec) *reinterpret_cast<float4*>(lds_raw + i * slot + 4 * k) = regs[i][v];
       }
+    if constexpr (MASKED) {
+#pragma unroll
+      for (int v = 0; v < MAXV; ++v) {
+        const int k = tid + v * T;
+        if (k < nvec_m) *reinterpret_cast<uint32_t*>(lds_mask + 4 * k) = mregs[v];
+      }
+    }
     int cur_lead[NIN];
 #pragma unroll
     for (int i = 0; i < NIN; ++i) cur_lead[i] = lead[i];
+    const int cur_mlead = mlead;
     __syncthreads();
     if (d + R < d1) {  // next group's loads fly while this group is reduced
-      prefetch(d + R, lead_next);
+      prefetch(d + R, lead_next, mlead_next);
 #pragma unroll
       for (int i = 0; i < NIN; ++i) lead[i] = lead_next[i];
+      mlead = mlead_next;
     }
     if (tid < nx) {
       const int rows = (int)(d1 - d < R ? d1 - d : R);
       for (int r = 0; r < rows; ++r) {
-        const float pv = lds_raw[0 * slot + cur_lead[0] + r * nx + tid];
-        const float tv = NIN > 1 ? lds_raw[1 * slot + cur_lead[NIN > 1 ? 1 : 0] + r * nx + tid] : 0.f;
-        const float cv = NIN > 2 ? lds_raw[2 * slot + cur_lead[NIN > 2 ? 2 : 0] + r * nx + tid] : 0.f;
+        float pv = lds_raw[0 * slot + cur_lead[0] + r * nx + tid];
+        float tv = NIN > 1 ? lds_raw[1 * slot + cur_lead[NIN > 1 ? 1 : 0] + r * nx + tid] : 0.f;
+        float cv = NIN > 2 ? lds_raw[2 * slot + cur_lead[NIN > 2 ? 2 : 0] + r * nx + tid] : 0.f;
+        if constexpr (MASKED) {
+          // masked-out points contribute exactly 0 whatever they hold (aggregation.py:339-357); count lane = validity
+          const bool valid = lds_mask[cur_mlead + r * nx + tid] != 0;
+          pv = valid ? pv : 0.f;
+          tv = valid ? tv : 0.f;
+          cv = valid ? cv : 0.f;
+          acc[Op::NLANE] += valid ? 1.0 : 0.0;
+        }
         double val[Op::NLANE];
         Op::lanes((double)pv, (double)tv, (double)cv, val);
 #pragma unroll
@@ -295,7 +339,8 @@ int launch_plane(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   WBX_REQUIRE(plan->depth_chunk % R == 0 || plan->nchunk == 1, "plane mode needs depth_chunk %% plane_rows == 0");
   const int nvec = (int)((R * plan->nx + 6) / 4);
   WBX_REQUIRE(nvec <= 2 * threads, "plane_rows too large for the block (R*nx/4 > 2*threads)");
-  const size_t lds = (size_t)Op::NIN * (size_t)(R * plan->nx + 8) * sizeof(float);
+  const size_t lds = (size_t)Op::NIN * (size_t)(R * plan->nx + 8) * sizeof(float) +
+                     (op_has_mrow<Op>::value ? (size_t)(R * plan->nx + 16) : 0);
   WBX_REQUIRE(lds <= 80 * 1024, "plane mode LDS footprint %zu exceeds 80 KiB (two blocks per CU)", lds);
   if (lds > 48 * 1024)
     WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s1_xp_kernel<Op>),

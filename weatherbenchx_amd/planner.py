@@ -235,18 +235,27 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
   # "plane mode" for x-kept fp32 reductions whose rows cannot be 16-B aligned (latitude-fastest chunks, nx = 721):
   # groups of R consecutive depth rows are one contiguous span, fetched with aligned loads through LDS.
   plane_rows = 0
-  if (allow_vec4 and x_kept and not map_mode and not (flags & 3) and vec == 1 and x_dim is not None
+  if (allow_vec4 and x_kept and not map_mode and not (flags & 2) and vec == 1 and x_dim is not None
       and depth_dims and 64 <= nx <= 1024):
     inner = depth_dims[-1]
     used = [lay for lay in layouts[:3] if lay is not None]
     ok = all(lay.itemsize == 4 and lay.base_alignment % 16 == 0 and lay.stride(x_dim) == 1
              and lay.stride(inner) == nx for lay in used)
+    mask_bytes = 0
+    if flags & 1:
+      # the validity mask rides along when its spans are contiguous too (same (inner, x) order as the data; it may
+      # broadcast over every other dim)
+      mlay = layouts[3] if len(layouts) > 3 else None
+      ok = ok and mlay is not None and mlay.itemsize == 1 and mlay.base_alignment % 4 == 0 \
+          and mlay.stride(x_dim) == 1 and mlay.stride(inner) == nx
     if gather is not None and inner in gather.dims:
       ok = False
     if ok:
       threads = -(-nx // 64) * 64
       for r in (8, 6, 5, 4, 3, 2):
-        lds = len(used) * (r * nx + 8) * 4
+        if flags & 1:
+          mask_bytes = r * nx + 16
+        lds = len(used) * (r * nx + 8) * 4 + mask_bytes
         if sizes[inner] % r == 0 and lds <= 80 * 1024 and (r * nx + 6) // 4 <= 2 * threads:
           plane_rows = r
           break
