@@ -485,3 +485,52 @@ def test_rccl_all_reduce_of_a_packed_state_single_rank(ctx):
       np.testing.assert_array_equal(got[k].values, want[k].values)
   finally:
     dist.destroy_process_group()
+
+
+def test_full_grid_region_bins_size_independent_properties(ctx, monkeypatch):
+  """721 x 1440, 17 regions x land/sea (the public benchmark's binning): (i) the 'global' bin equals the unbinned
+  aggregation, accumulator by accumulator; (ii) every '<region>_land' accumulator is <= its '<region>' one;
+  (iii) the fused kernel and the two-stage path agree; (iv) doubling the predictions' error quadruples every bin's
+  squared-error sum (linearity of the accumulators in the statistic)."""
+  import os
+  import sys
+  sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+  from wb_regions import REGIONS
+  from weatherbenchx_amd import binning
+  rng = np.random.default_rng(5)
+  nlat, nlon = 721, 1440
+  lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  dims = ('lead_time', 'longitude', 'latitude')  # latitude-fastest, like the real archives
+  coords = {'lead_time': np.arange(2) * np.timedelta64(6, 'h'), 'latitude': lat, 'longitude': lon}
+  tv = rng.normal(size=(2, nlon, nlat)).astype(np.float32)
+  ev = rng.normal(size=(2, nlon, nlat)).astype(np.float32)
+  t = xr.DataArray(tv, dims=dims, coords=coords)
+  p1 = xr.DataArray(tv + ev, dims=dims, coords=coords)
+  p2 = xr.DataArray(tv + 2 * ev, dims=dims, coords=coords)
+  land = rng.random((nlat, nlon)) > 0.7
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  kw = dict(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+  def state(p, **extra):
+    agg = aggregation.Aggregator(**kw, **extra)
+    stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'v': p}, {'v': t})
+    s = agg.aggregate_statistics(stats)
+    return s.sum_weighted_statistics['SquaredError']['v'], s.sum_weights['SquaredError']['v']
+  plain_s, plain_w = state(p1)
+  bins = dict(bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)])
+  monkeypatch.setattr(engine, 'BINNED_MODE', 'always')
+  fused_s, fused_w = state(p1, **bins)
+  fused2_s, _ = state(p2, **bins)
+  monkeypatch.setattr(engine, 'BINNED_MODE', 'never')
+  engine.clear_caches()
+  two_s, two_w = state(p1, **bins)
+  names = list(fused_s['region'].values)
+  assert len(names) == 34
+  np.testing.assert_allclose(fused_s.sel(region='global').values, plain_s.values, rtol=1e-12)
+  np.testing.assert_allclose(fused_w.sel(region='global').values, plain_w.values, rtol=1e-12)
+  for r in REGIONS:
+    assert (fused_s.sel(region=f'{r}_land').values <= fused_s.sel(region=r).values * (1 + 1e-12)).all()
+    assert (fused_w.sel(region=f'{r}_land').values <= fused_w.sel(region=r).values * (1 + 1e-12)).all()
+  np.testing.assert_allclose(fused_s.transpose(*two_s.dims).values, two_s.values, rtol=1e-11)
+  np.testing.assert_allclose(fused_w.transpose(*two_w.dims).values, two_w.values, rtol=1e-12)
+  np.testing.assert_allclose(fused2_s.values, 4.0 * fused_s.values, rtol=1e-5)  # fp32 rounding of t + 2e vs t + e
