@@ -36,8 +36,11 @@ def test_golden_spectrum_fixture(backend):
   np.testing.assert_allclose(s.values, g['spec_power'], rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize('team', [None, '64', '128', '256'])
 @pytest.mark.parametrize('nlon', [32, 45, 1440])
-def test_parseval_constant_and_sinusoid(backend, nlon):
+def test_parseval_constant_and_sinusoid(backend, monkeypatch, nlon, team):
+  if team is not None:  # threads per row pair of the fused FFT kernel (csrc/wbx_spectrum.hip)
+    monkeypatch.setenv('WBX_SPECTRUM_TEAM', team)
   rng = np.random.default_rng(nlon)
   x = 2 * np.pi * np.arange(nlon) / nlon
   rows = np.stack([rng.normal(size=nlon), np.full(nlon, 3.0), 1.5 * np.cos(5 * x + 0.3), 2.0 + np.sin(x)])

@@ -191,18 +191,27 @@ __device__ __forceinline__ void butterfly(C2 (&v)[R]) {
   }
 }
 
-// One in-place Stockham pass of radix R over the wave's n2 points (two rows each); a lane owns butterflies lane,
-// lane + 64, ... (at most NB of them).  All reads precede all writes.
-template <int R, int NB>
-__device__ __forceinline__ void wave_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
-                                          float inv_ns, int lane) {
+// G threads (one wave, or a block of 2 / 4 waves) work on one pair of rows at a time.
+template <int G>
+__device__ __forceinline__ void team_sync() {
+  if constexpr (G == 64)
+    __builtin_amdgcn_wave_barrier();  // same wave: LDS keeps program order
+  else
+    __syncthreads();
+}
+
+// One in-place Stockham pass of radix R over the team's n2 points (two rows each); thread t owns butterflies t, t + G,
+// ... (at most NB of them).  All reads precede all writes.
+template <int R, int NB, int G>
+__device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
+                                          float inv_ns, int tid) {
   const int nb = n2 / R;
   const int tstep = n2 / (ns * R);  // exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
   C2 v[NB][R];
   int base[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int j = lane + 64 * i;
+    const int j = tid + G * i;
     if (j < nb) {
       const int q = (int)(((float)j + 0.5f) * inv_ns);  // j / ns, exact for j < 2^22
       const int k = j - q * ns;
@@ -218,48 +227,57 @@ __device__ __forceinline__ void wave_pass(v4* __restrict__ buf, const float2* __
       butterfly<R>(v[i]);
     }
   }
-  __builtin_amdgcn_wave_barrier();  // reads above, writes below (same wave: LDS keeps program order)
+  team_sync<G>();  // reads above, writes below
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int j = lane + 64 * i;
+    const int j = tid + G * i;
     if (j < nb) {
 #pragma unroll
       for (int t = 0; t < R; ++t) st_c2(buf + base[i] + t * ns, v[i][t]);
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  team_sync<G>();
 }
 
-template <int R>
-__device__ __forceinline__ void wave_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int lane) {
-  const int nbl = (n2 / R + 63) / 64;  // butterflies per lane
-  if (nbl <= 1) wave_pass<R, 1>(buf, tw, n2, ns, inv_ns, lane);
-  else if (nbl <= 2) wave_pass<R, 2>(buf, tw, n2, ns, inv_ns, lane);
-  else if (nbl <= 3) wave_pass<R, 3>(buf, tw, n2, ns, inv_ns, lane);
-  else wave_pass<R, 4>(buf, tw, n2, ns, inv_ns, lane);  // fused_factor() admits at most 256 butterflies per pass
+template <int R, int G>
+__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int tid) {
+  // fused_factor() admits at most 256 butterflies per pass
+  constexpr int NBMAX = 256 / G;
+  const int nbl = (n2 / R + G - 1) / G;  // butterflies per thread
+  if constexpr (NBMAX >= 4) {
+    if (nbl > 3) return team_pass<R, 4, G>(buf, tw, n2, ns, inv_ns, tid);
+    if (nbl > 2) return team_pass<R, 3, G>(buf, tw, n2, ns, inv_ns, tid);
+  }
+  if constexpr (NBMAX >= 2) {
+    if (nbl > 1) return team_pass<R, 2, G>(buf, tw, n2, ns, inv_ns, tid);
+  }
+  team_pass<R, 1, G>(buf, tw, n2, ns, inv_ns, tid);
 }
 
-// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 + 1) / 64).
-template <int KPT>
-__global__ void __launch_bounds__(256, 2) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
-                                                             int rows_per_wave, FusedSpec fs,
-                                                             const float2* __restrict__ tw_pass_g,
-                                                             const float2* __restrict__ tw_real_g,
-                                                             const int32_t* __restrict__ group,
-                                                             const double* __restrict__ scale, double* __restrict__ power) {
+// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 + 1) / G).
+// G = 64: a block is 4 independent one-wave teams sharing the twiddle tables; G = 128 / 256: the block IS the team
+// (its __syncthreads are team barriers), sweeping its own run of row pairs.
+template <int KPT, int G>
+__global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
+                                                          int rows_per_team, FusedSpec fs,
+                                                          const float2* __restrict__ tw_pass_g,
+                                                          const float2* __restrict__ tw_real_g,
+                                                          const int32_t* __restrict__ group,
+                                                          const double* __restrict__ scale, double* __restrict__ power) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int NTEAM = G == 64 ? 4 : 1;
   const int n2 = fs.n2, nk = n2 + 1;
   float2* tw_pass = reinterpret_cast<float2*>(lds_raw);
   float2* tw_real = tw_pass + n2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v4* buf = reinterpret_cast<v4*>(tw_real + nk + (nk & 1)) + (int64_t)wave * n2;
+  const int tid = threadIdx.x % G, team = threadIdx.x / G;
+  v4* buf = reinterpret_cast<v4*>(tw_real + nk + (nk & 1)) + (int64_t)team * n2;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) tw_pass[i] = tw_pass_g[i];
   for (int i = threadIdx.x; i < nk; i += blockDim.x) tw_real[i] = tw_real_g[i];
   __syncthreads();
-  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t r0 = w * rows_per_wave;
-  const int64_t r1 = r0 + rows_per_wave < nrows ? r0 + rows_per_wave : nrows;
-  if (r0 >= r1) return;
+  const int64_t w = (int64_t)blockIdx.x * NTEAM + team;
+  const int64_t r0 = w * rows_per_team;
+  int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
+  if (r0 >= r1) return;  // G == 64: only wave-level syncs follow; G > 64: the whole block leaves together
   const double inv_nn = 1.0 / ((double)fs.n * (double)fs.n);
   double acc[KPT];
 #pragma unroll
@@ -268,45 +286,45 @@ __global__ void __launch_bounds__(256, 2) zspec_fused_kernel(const float* __rest
   auto flush = [&](int32_t next) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int k = lane + 64 * i;
+      const int k = tid + G * i;
       if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
       acc[i] = 0.0;
     }
     cur = next;
   };
   for (int64_t r = r0; r < r1; r += 2) {
-    const bool two = r + 1 < r1;  // wave-uniform; a missing second row is a row of zeros with scale 0
+    const bool two = r + 1 < r1;  // team-uniform; a missing second row is a row of zeros with scale 0
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
     const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
-    for (int j = lane; j < n2; j += 64) {
+    for (int j = tid; j < n2; j += G) {
       const v2 a = __builtin_nontemporal_load(rowa + j);
       const v2 b = two ? __builtin_nontemporal_load(rowb + j) : (v2){0.f, 0.f};
       buf[j] = (v4){a.x, b.x, a.y, b.y};
     }
-    __builtin_amdgcn_wave_barrier();
+    team_sync<G>();
     int ns = 1;
     for (int p = 0; p < fs.npass; ++p) {
       const int rdx = fs.radix[p];
       const float inv_ns = 1.0f / (float)ns;
       if (rdx == 4)
-        wave_pass_any<4>(buf, tw_pass, n2, ns, inv_ns, lane);
+        team_pass_any<4, G>(buf, tw_pass, n2, ns, inv_ns, tid);
       else if (rdx == 2)
-        wave_pass_any<2>(buf, tw_pass, n2, ns, inv_ns, lane);
+        team_pass_any<2, G>(buf, tw_pass, n2, ns, inv_ns, tid);
       else if (rdx == 3)
-        wave_pass_any<3>(buf, tw_pass, n2, ns, inv_ns, lane);
+        team_pass_any<3, G>(buf, tw_pass, n2, ns, inv_ns, tid);
       else
-        wave_pass_any<5>(buf, tw_pass, n2, ns, inv_ns, lane);
+        team_pass_any<5, G>(buf, tw_pass, n2, ns, inv_ns, tid);
       ns *= rdx;
     }
     // Hermitian unpack of the half-length transform Z: X_k = E_k + exp(-2 pi i k / n) O_k with
     // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0)
     const double sca = scale[r] * inv_nn, scb = two ? scale[r + 1] * inv_nn : 0.0;
-    if (ga != cur) flush(ga);  // wave-uniform
+    if (ga != cur) flush(ga);  // team-uniform
     const bool split = gb != ga;  // the pair straddles a group boundary (rare): row B goes out through its own atomics
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
-      const int k = lane + 64 * i;
+      const int k = tid + G * i;
       if (k < nk) {
         const C2 zk = ld_c2(buf + (k == n2 ? 0 : k));
         const C2 zc = ld_c2(buf + (k == 0 ? 0 : n2 - k));
@@ -324,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) zspec_fused_kernel(const float* __rest
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair of rows
+    team_sync<G>();  // buf is overwritten by the next pair of rows
   }
   flush(cur);
 }
@@ -390,27 +408,39 @@ extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_
     }
     const float2* tw_pass = reinterpret_cast<const float2*>(tw);
     const float2* tw_real = tw_pass + n2;
-    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 8 * n2) * sizeof(float2);  // tables + 4 wave-private row PAIRS
-    // a wave sweeps a contiguous run of rows (one group for most of it); ~8 waves per SIMD's worth of runs
-    int64_t waves = 256 * 4 * 8;
-    if (waves > (nrows + 1) / 2) waves = (nrows + 1) / 2;
-    int rows_per_wave = (int)((nrows + waves - 1) / waves);
-    rows_per_wave += rows_per_wave & 1;  // whole pairs
-    waves = (nrows + rows_per_wave - 1) / rows_per_wave;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
-    const int kpt = (nk + 63) / 64;
-#define WBX_LAUNCH_FUSED(KPT)                                                                                       \
+    // threads per row pair: more threads = fewer registers per thread and more waves per LDS byte (n = 1440, configs[3]:
+    // 64 / 128 / 256 threads -> 2.16 / 2.00 / 1.75 ms per step); short rows keep one wave busy
+    int G = n2 <= 128 ? 64 : (n2 <= 256 ? 128 : 256);
+    if (const char* e = getenv("WBX_SPECTRUM_TEAM")) G = atoi(e);  // tests drive every team size
+    WBX_REQUIRE(G == 64 || G == 128 || G == 256, "WBX_SPECTRUM_TEAM must be 64, 128 or 256");
+    const int nteam = G == 64 ? 4 : 1;
+    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
+    // a team sweeps a contiguous run of rows (one group for most of it)
+    int64_t teams = (int64_t)256 * 4 * 8 * 64 / G;
+    if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;
+    int rows_per_team = (int)((nrows + teams - 1) / teams);
+    rows_per_team += rows_per_team & 1;  // whole pairs
+    teams = (nrows + rows_per_team - 1) / rows_per_team;
+    const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
+    const int kpt = (nk + G - 1) / G;
+#define WBX_LAUNCH_FUSED(KPT, GG)                                                                                   \
     do {                                                                                                              \
       if (lds > 48 * 1024)                                                                                            \
-        WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT>),                          \
+        WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG>),                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-      hipLaunchKernelGGL(zspec_fused_kernel<KPT>, dim3(blocks), dim3(256), lds, ctx->stream, field, row_stride,     \
-                         nrows, rows_per_wave, fs, tw_pass, tw_real, group, scale, power_out);                        \
+      hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
+                         nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, power_out);                        \
     } while (0)
-    if (kpt <= 4) WBX_LAUNCH_FUSED(4);
-    else if (kpt <= 8) WBX_LAUNCH_FUSED(8);
-    else if (kpt <= 12) WBX_LAUNCH_FUSED(12);
-    else WBX_LAUNCH_FUSED(17);
+    if (G == 256) {
+      if (kpt <= 3) WBX_LAUNCH_FUSED(3, 256); else WBX_LAUNCH_FUSED(5, 256);
+    } else if (G == 128) {
+      if (kpt <= 6) WBX_LAUNCH_FUSED(6, 128); else WBX_LAUNCH_FUSED(9, 128);
+    } else {
+      if (kpt <= 4) WBX_LAUNCH_FUSED(4, 64);
+      else if (kpt <= 8) WBX_LAUNCH_FUSED(8, 64);
+      else if (kpt <= 12) WBX_LAUNCH_FUSED(12, 64);
+      else WBX_LAUNCH_FUSED(17, 64);
+    }
 #undef WBX_LAUNCH_FUSED
     WBX_HIP(hipGetLastError());
     return 0;
