@@ -167,7 +167,11 @@ def main():
   k_ms = float(np.mean([e['ms'] for e in log]))
   alg_bytes = points * 12
   achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-  if log[0].get('plane_rows'):
+  if log[0].get('flat'):
+    kname = 's1_xf_kernel<DetOp<float,DET6>> (latitude weights folded into stage 1, flat float4 sweep)'
+  elif log[0].get('x_weighted'):
+    kname = 's1_xr_kernel<XWeighted<DetOp<float,DET6>>,1> (latitude weights folded into stage 1)'
+  elif log[0].get('plane_rows'):
     kname = f"s1_xp_kernel<DetOp<float,DET6>> (LDS plane mode, R={log[0]['plane_rows']})"
   elif log[0]['x_kept']:
     kname = f"s1_xk_kernel<DetOp<float,DET6>,{log[0]['vec']}>"

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 3
+#define WBX_ABI_VERSION 4
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -119,6 +119,12 @@ typedef struct wbx_s1_plan {
                             (latitude-fastest chunks: rows = longitudes). The span is fetched with aligned 16-B loads
                             through LDS instead of ragged per-row dword loads. depth_chunk must be a multiple of R. */
   int32_t reserved_;
+  const double* x_weights; /* NULL, or DEVICE float64[nx]: every lane of the point at x is multiplied by x_weights[x] inside
+                              stage 1 and x is SUMMED there (x_kept = 0) -- for weights that depend on the innermost dim
+                              only and no bins (GridAreaWeighting on latitude-fastest data).  wbx_det_partial, fp32, no
+                              mask / skipna, with plane_rows = R > 0, R % 4 == 0: the R contiguous, 16-B aligned depth
+                              rows are streamed as one flat float4 array (element e takes x_weights[e mod nx]);
+                              depth_chunk % 4 == 0, ndepth % R == 0, nx <= 2045. */
 } wbx_s1_plan;
 
 /* number of fp64 values stage 1 writes: nkey * nchunk * nlanes_total * nj, layout partial[key][chunk][lane][j].

@@ -98,6 +98,8 @@ def _ens_lanes(plan, devs, ens, flags):
 
 def _chunked(plan, arr):
   """[nkey, D, nx] -> [nkey, nchunk, nj]"""
+  if getattr(plan, 'x_weights', None) is not None:  # weights on x folded into stage 1 (value and count lanes alike)
+    arr = arr * np.asarray(plan.x_weights)[None, None, :]
   out = np.zeros((plan.nkey, plan.nchunk, plan.nj))
   for c in range(plan.nchunk):
     d0, d1 = c * plan.depth_chunk, min((c + 1) * plan.depth_chunk, plan.ndepth)

@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol():
   assert declared == set(_hip.EXPORTED_SYMBOLS)
   for name in declared:
     assert hasattr(lib, name), f'{name} declared in include/wbx.h but not exported'
-  assert _hip.load_library().wbx_abi_version() == 3
+  assert _hip.load_library().wbx_abi_version() == 4
 
 
 def test_struct_layout_matches_header():
-  # 3*8 + 2*4 + 8 + 4*8 + 4*8 + 4*8 + 3*8 + 6*4 = 184 bytes, 8-byte aligned
-  assert ctypes.sizeof(_hip.S1PlanStruct) == 184
+  # 3*8 + 2*4 + 8 + 4*8 + 4*8 + 4*8 + 3*8 + 6*4 + 8 = 192 bytes, 8-byte aligned
+  assert ctypes.sizeof(_hip.S1PlanStruct) == 192
   assert ctypes.sizeof(_hip.S2PlanStruct) == 64
 
 

@@ -751,3 +751,61 @@ def test_plane_mode_with_a_validity_mask(backend, mask_order):
                                wdep_dims=['latitude'], flags=1)
   assert plan.x_dim == 'latitude' and plan.x_kept
   assert plan.plane_rows == (8 if mask_order == 'lon_lat' else 0)
+
+
+@pytest.mark.parametrize('mode', ['plain', 'masked', 'skipna'])
+def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
+  """Latitude-fastest data + GridAreaWeighting and no bins: the weights depend on the innermost dim only, so the
+  deterministic family applies them inside stage 1 (plan.x_weights, flat float4 sweep over the contiguous planes) and
+  sums latitude there.  Masks / skipna and the ensemble family keep latitude for stage 2 (measured faster).  Every
+  route must equal the un-folded one and the oracle."""
+  from weatherbenchx_amd import engine
+  rng = np.random.default_rng(33)
+  nlat, nlon, m = 91, 24, 5
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * 15.0
+  dims = ('lead_time', 'longitude', 'latitude')
+  edims = ('lead_time', 'number', 'longitude', 'latitude')
+  coords = {'latitude': lat, 'longitude': lon, 'lead_time': (np.arange(3) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  tv = (rng.normal(size=(3, nlon, nlat)) + 280).astype(np.float32)
+  pv = (rng.normal(size=(3, nlon, nlat)) + 280).astype(np.float32)
+  ev = (tv[:, None] + rng.normal(size=(3, m, nlon, nlat))).astype(np.float32)
+  if mode != 'plain':
+    tv[rng.random(tv.shape) < 0.1] = np.nan
+  t = xr.DataArray(tv, dims=dims, coords=coords)
+  if mode == 'masked':
+    t.coords['mask'] = ~np.isnan(t)
+  p = xr.DataArray(pv, dims=dims, coords=coords)
+  e = xr.DataArray(ev, dims=edims, coords=coords)
+  det = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
+  ens = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
+  logs, results = {}, {}
+  for fold in (True, False):
+    monkeypatch.setattr(engine, 'FOLD_X_WEIGHTS', fold)
+    engine.clear_caches()
+    seen = []
+    inner = engine._planned
+    monkeypatch.setattr(engine, '_planned', lambda *a, **k: (seen.append(inner(*a, **k)[0]), inner(*a, **k))[1])
+    agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                                 masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+    results[fold] = dict(aggregation.compute_metric_values_for_single_chunk(det, agg, {'v': p}, {'v': t}))
+    results[fold].update(aggregation.compute_metric_values_for_single_chunk(ens, agg, {'v': e}, {'v': t}))
+    logs[fold] = seen
+    monkeypatch.setattr(engine, '_planned', inner)
+  used = [pl for pl in logs[True] if pl.x_weights is not None]
+  assert bool(used) == (mode == 'plain') and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
+  assert logs[False] and all(pl.x_weights is None and pl.x_kept for pl in logs[False])
+  for k, v in results[False].items():
+    np.testing.assert_allclose(results[True][k].values, v.values, rtol=1e-9, equal_nan=True)
+  w = (O.grid_area_weights(lat), ('latitude',))
+  kw = {}
+  if mode == 'masked':
+    kw = dict(mask=~np.isnan(tv), mask_dims=dims)
+  if mode == 'skipna':
+    kw = dict(skipna=True)
+  with np.errstate(invalid='ignore'):
+    sws, sw, _ = O.aggregate(O.squared_error(pv, tv), dims, ['latitude', 'longitude'], weights=[w], **kw)
+  np.testing.assert_allclose(results[True]['rmse.v'].values, np.sqrt(sws / sw), rtol=RTOL, equal_nan=True)
+  if mode == 'plain':
+    sk = O.aggregate(O.crps_skill(ev, edims, tv, dims, 'number')[0], dims, ['latitude', 'longitude'], weights=[w])
+    sp = O.aggregate(O.crps_spread(ev, edims, 'number', use_sort=True)[0], dims, ['latitude', 'longitude'], weights=[w])
+    np.testing.assert_allclose(results[True]['crps.v'].values, O.crps(sk[0] / sk[1], sp[0] / sp[1]), rtol=RTOL)

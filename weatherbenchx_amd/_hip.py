@@ -52,7 +52,7 @@ class S1PlanStruct(C.Structure):
       ('depth_off', C.c_void_p * MAX_INPUTS),
       ('gather_key', C.c_void_p), ('gather_depth', C.c_void_p), ('gather_tab', C.c_void_p),
       ('n_gather_depth', C.c_int32), ('flags', C.c_uint32),
-      ('block_threads', C.c_int32), ('vec', C.c_int32), ('plane_rows', C.c_int32), ('reserved_', C.c_int32),
+      ('block_threads', C.c_int32), ('vec', C.c_int32), ('plane_rows', C.c_int32), ('reserved_', C.c_int32), ('x_weights', C.c_void_p),
   ]
 
 

@@ -180,6 +180,19 @@ struct DetOp {
 
 template <typename T, int FUNC>
 static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  if (plan->x_weights != nullptr && plan->plane_rows > 0) {  // folded weights over contiguous planes: flat float4 sweep
+    if constexpr (std::is_same<T, float>::value) {
+      WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)), "flat x-weighted mode does not take mask/skipna flags");
+      for (int i = 0; i < DetOp<T, FUNC, 0>::NIN; ++i)
+        WBX_REQUIRE(plan->xstride[i] == 1 && (((uintptr_t)a.in[i]) & 15) == 0,
+                    "flat x-weighted mode needs unit x stride and 16-byte aligned inputs");
+      if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
+      return launch_flat_weighted<DetOp<T, FUNC, 0>>(ctx, plan, a);
+    } else {
+      return fail(WBX_ERR_INVALID, "flat x-weighted mode is fp32 only");
+    }
+  }
+  WBX_REQUIRE(plan->x_weights == nullptr, "x_weights needs the flat mode (plane_rows > 0, fp32, no mask)");
   if (plan->plane_rows > 0) {
     if constexpr (std::is_same<T, float>::value) {
       WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA), "plane mode does not take the skipna flag");

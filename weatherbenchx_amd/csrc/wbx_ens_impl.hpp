@@ -192,6 +192,7 @@ struct EnsMasked {
 template <class Op>
 int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
   if (map) return launch_map<Op>(ctx, plan, a);
+  WBX_REQUIRE(plan->x_weights == nullptr, "x_weights is not supported by the ensemble kernels");
   if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<EnsMasked<Op, true>, 1>(ctx, plan, a);
   if (plan->flags & WBX_FLAG_MASKED) return launch_partial<EnsMasked<Op, false>, 1>(ctx, plan, a);
   return launch_partial<Op, 1>(ctx, plan, a);

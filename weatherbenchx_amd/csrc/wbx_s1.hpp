@@ -34,6 +34,7 @@ struct S1Args {
   int32_t nchunk, nxtile;
   uint32_t flags;
   double* out;
+  const double* xw;  // per-x weights folded into stage 1 (plan->x_weights) or NULL
   // ensemble
   int32_t M;
   int64_t mstride;
@@ -59,6 +60,15 @@ __device__ __forceinline__ void row_bases(const S1Args& a, const int64_t (&kb)[W
 
 // ---------------------------------------------------------------------------------------------
 // x summed away.  grid = nkey * nchunk blocks, block = 64..256 threads.
+// ---------------------------------------------------------------------------------------------
+// Weights that depend on the innermost dim only (area weights on latitude-fastest data) can be applied INSIDE stage 1
+// (plan->x_weights), so that x is summed here like any other reduced dim; s1_xf_kernel below does that for contiguous
+// planes.  (A generic per-row variant -- every op wrapped so that its lanes are multiplied by w[x] on the x-summed
+// kernel with dword loads -- measured slower than keeping x: 52 % vs 76 % for DET6 on 721-float rows, 0.50 vs 0.46 ms
+// for the 51-member ensemble, 43 % vs 69 % with a mask; it was removed.)
+constexpr int WBX_XW_MAX = 2048;
+static __shared__ double wbx_xw_lds[WBX_XW_MAX];
+
 // MROW: the validity mask does not depend on the depth dims (a (lat, lon) mask under an (init) reduction): the key's
 // mask row is staged in LDS once per block instead of being re-read from L2 for every depth row.
 constexpr int WBX_MROW_MAX = 8192;
@@ -352,6 +362,97 @@ int launch_plane(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// x summed with folded x-weights, "flat" variant for latitude-fastest planes: R consecutive depth rows (longitudes) of
+// nx = 721 floats are one contiguous, 16-B aligned span, so the x-summed sweep does not have to respect row boundaries
+// at all: the span is streamed as float4s (aligned non-temporal dwordx4, exactly like the lon-fastest kernel) and the
+// element at flat position e simply takes the weight w[e mod nx] from the LDS copy (padded by 3 for the wrap).
+// Needs R % 4 == 0 (4 rows = nx float4s exactly, chunks cut at row quads) and no mask.  grid = nkey * nchunk.
+template <class Op>
+__global__ void __launch_bounds__(256) s1_xf_kernel(S1Args a, int R) {
+  constexpr int NA = Op::NACC;
+  constexpr int NIN = Op::NIN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nx = (int)a.nx;
+  const int64_t b = blockIdx.x;
+  const int64_t key = b / a.nchunk;
+  const int chunk = (int)(b - key * a.nchunk);
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+  const int nt = blockDim.x, nwave = nt >> 6;
+  for (int i = tid; i < nx + 3; i += nt) wbx_xw_lds[i] = a.xw[i < nx ? i : i - nx];
+  __syncthreads();
+
+  int64_t kb[WBX_MAX_INPUTS];
+  key_bases<NIN>(a, key, kb);
+  double acc[NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) acc[l] = 0.0;
+
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const int qpp = R / 4;  // row quads per plane; one quad = nx float4s
+  int64_t g = d0 / 4;
+  const int64_t g1 = d1 / 4;
+  while (g < g1) {
+    const int64_t plane = g / qpp;
+    const int j0 = (int)(g - plane * qpp);
+    const int64_t left = g1 - g;
+    const int nj = (int)(left < qpp - j0 ? left : qpp - j0);
+    int64_t ro[WBX_MAX_INPUTS];
+    row_bases<NIN>(a, kb, key, plane * R, ro);
+    const int64_t q0 = (int64_t)j0 * nx, q1 = q0 + (int64_t)nj * nx;  // float4 range of this plane segment
+    const f4_t* pp = reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[0]) + ro[0]);
+    const f4_t* pt = NIN > 1 ? reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[1]) + ro[1]) : nullptr;
+    const f4_t* pc = NIN > 2 ? reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[2]) + ro[2]) : nullptr;
+    int m = (int)((4 * (q0 + tid)) % nx);  // latitude of the thread's first element
+    const int step = (4 * nt) % nx;
+#pragma unroll 2
+    for (int64_t q = q0 + tid; q < q1; q += nt) {
+      const f4_t p4 = ld_stream(pp + q);
+      f4_t t4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (NIN > 1) t4 = ld_stream(pt + q);
+      if constexpr (NIN > 2) c4 = ld_stream(pc + q);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double val[Op::NLANE];
+        Op::lanes((double)p4[k], (double)t4[k], (double)c4[k], val);
+        const double w = wbx_xw_lds[m + k];
+#pragma unroll
+        for (int l = 0; l < Op::NLANE; ++l) acc[l] = fma(val[l], w, acc[l]);
+      }
+      m += step;
+      m = m >= nx ? m - nx : m;
+    }
+    g += nj;
+  }
+  __shared__ double red[4][NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) {
+    const double v = wave_sum(acc[l]);
+    if (lane == 0) red[wave][l] = v;
+  }
+  __syncthreads();
+  if (tid < NA) {
+    double sum = 0.0;
+    for (int w = 0; w < nwave; ++w) sum += red[w][tid];
+    a.out[(key * a.nchunk + chunk) * NA + tid] = sum;
+  }
+}
+
+template <class Op>
+int launch_flat_weighted(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  const int R = plan->plane_rows;
+  WBX_REQUIRE(!plan->x_kept && plan->x_weights && R > 0 && R % 4 == 0 && plan->nx + 3 <= WBX_XW_MAX,
+              "flat x-weighted mode needs x summed, plane_rows %% 4 == 0 and nx <= %d", WBX_XW_MAX - 3);
+  WBX_REQUIRE(plan->depth_chunk % 4 == 0 && plan->ndepth % R == 0, "flat x-weighted mode needs depth_chunk %% 4 == 0 and whole planes");
+  const int64_t grid = plan->nkey * plan->nchunk;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+  hipLaunchKernelGGL((s1_xf_kernel<Op>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a, R);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // materialise one lane: out[key][d][x].  grid = nkey * D * nxtile.
 template <class Op>
@@ -392,6 +493,7 @@ inline int fill_args(const wbx_s1_plan* plan, S1Args& a) {
   a.dchunk = plan->depth_chunk;
   a.nchunk = plan->nchunk;
   a.flags = plan->flags;
+  a.xw = plan->x_weights;
   return 0;
 }
 

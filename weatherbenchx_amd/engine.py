@@ -106,6 +106,7 @@ class _PlanOnDevice:
     s.block_threads = plan.block_threads
     s.vec = plan.vec
     s.plane_rows = plan.plane_rows
+    s.x_weights = self._up(ctx, plan.x_weights)
     self.struct = s
 
   def _up(self, ctx, tab):
@@ -122,7 +123,7 @@ def _plan_signature(plan: planner.S1Plan):
   return (plan.dims, tuple(plan.sizes.items()), plan.x_dim, plan.x_kept, plan.a_dims, plan.bk_dims, plan.br_dims,
           plan.depth_dims, plan.nchunk, plan.depth_chunk, tuple(plan.xstride), tuple(h(t) for t in plan.key_off),
           tuple(h(t) for t in plan.depth_off), h(plan.gather_key), h(plan.gather_depth), h(plan.gather_tab),
-          plan.flags, plan.block_threads, plan.vec, plan.plane_rows)
+          plan.flags, plan.block_threads, plan.vec, plan.plane_rows, h(plan.x_weights))
 
 
 _plan_cache: dict = {}
@@ -196,9 +197,10 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
   return store[sig]
 
 
-def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags):
+def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None):
   """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads."""
   sig = (id(ctx), kind, tuple(dims), tuple(sizes[d] for d in dims),
+         None if x_weights is None else hash(x_weights.tobytes()),
          tuple(None if l is None else (tuple(sorted(l.strides.items(), key=str)), l.itemsize, l.base_alignment % 16 == 0)
                for l in layouts),
          tuple(sorted(reduce_dims, key=str)), tuple(sorted(wdep, key=str)), flags,
@@ -206,7 +208,10 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags):
   hit = _fast_plan_cache.get(sig)
   if hit is None:
     plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
-                                 allow_vec4=(kind == 'det'))
+                                 allow_vec4=(kind == 'det' and x_weights is None), fold_x=x_weights is not None)
+    if x_weights is not None and plan.plane_rows > 0:
+      assert not plan.x_kept and plan.vec == 1 and plan.nx == x_weights.size
+      plan.x_weights = np.ascontiguousarray(x_weights, dtype=np.float64)
     if len(_fast_plan_cache) > 64:
       _fast_plan_cache.clear()
     hit = (plan, _device_plan(ctx, plan))
@@ -279,7 +284,8 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
                                          int(algo), ptr(devs[0]), ptr(devs[1]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop() / reps, 'reps': reps, 'vec': plan.vec,
-                         'x_kept': plan.x_kept, 'plane_rows': plan.plane_rows, 'grid': plan.nkey * plan.nchunk,
+                         'x_kept': plan.x_kept, 'plane_rows': plan.plane_rows, 'x_weighted': plan.x_weights is not None,
+                         'flat': plan.x_weights is not None and plan.plane_rows > 0, 'grid': plan.nkey * plan.nchunk,
                          'block': plan.block_threads})
   return out
 
@@ -392,6 +398,7 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
 # plus ~0.52 ms per GB of partials (written by stage 1, read back by the stage-2 patch kernel) -> break-even where
 # the partials are ~45 % of the inputs (about 10 inits per chunk for the 6-lane family).
 BINNED_MODE = 'auto'
+FOLD_X_WEIGHTS = True  # False: keep x for stage 2 (plane mode / x-kept kernels), for A/B timing and tests
 BINNED_PARTIAL_RATIO = 0.45
 
 
@@ -484,7 +491,21 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   layouts = [d.layout if d is not None else None for d in devs]
   if _deferred is not None:
     _deferred.keepalive.append((datas, devs))
-  plan, dplan = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
+  # Weights that depend on the innermost (contiguous) dim ONLY and no bins -- GridAreaWeighting on latitude-fastest
+  # data -- are folded into stage 1 (plan.x_weights): x is then summed there on the x-summed kernel instead of being
+  # kept as nx partials per key for stage 2.
+  x_weights = None
+  hit = None
+  if FOLD_X_WEIGHTS and kind == 'det' and not flags and w_da is not None and not bin_dims and len(w_da.dims) == 1:
+    x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
+    if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:
+      xw = np.ascontiguousarray(w_da.values, dtype=np.float64)
+      hit = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, set(), gather, flags, xw)
+      if hit[0].plane_rows > 0 and dtype_code == _hip.F32:  # the flat float4 sweep applies (contiguous aligned planes)
+        x_weights, wdep, w_da = xw, set(), None
+      else:
+        hit = None
+  plan, dplan = hit if hit is not None else _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
   nl = _hip.DET_LANES[func] if kind == 'det' else (int(cat['ncat']) if kind == 'cat' else _hip.ENS_LANES)
   counted = bool(flags & 3)
   shared_count = counted and not (flags & _hip.FLAG_SKIPNA)  # mask only: one count lane for every statistic
@@ -542,6 +563,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
     else:
       cnt = cnt[0]
     cnt = np.broadcast_to(cnt[:, :, 0], (s2.nA,) + cnt[:, :, 0].shape[1:]).reshape(lead_shape + tail_shape)
+    if x_weights is not None:  # sum of the folded weights over the reduced elements: (others reduced) * sum_x w[x]
+      cnt = cnt * (float(x_weights.sum()) / plan.nx)
     counts = [cnt] * nl
   return values, counts, out_dims
 

@@ -69,6 +69,7 @@ class S1Plan:
   block_threads: int
   vec: int
   plane_rows: int = 0
+  x_weights: np.ndarray | None = None  # float64[nx]: weights on the innermost dim folded into stage 1 (x is summed there)
 
   @property
   def nj(self) -> int:
@@ -130,8 +131,11 @@ def choose_x_dim(dims: Sequence, sizes: dict, layout: InputLayout, exclude=()):
 
 def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | None], reduce_dims,
                   wdep_dims=(), gather: GatherSpec | None = None, flags: int = 0, allow_vec4: bool = True,
-                  target_blocks: int = TARGET_BLOCKS, force_x_dim=None, map_mode: bool = False) -> S1Plan:
-  """Plans stage 1.  `layouts[i]` is None for unused inputs.  `map_mode` keeps every dim (nchunk=1)."""
+                  target_blocks: int = TARGET_BLOCKS, force_x_dim=None, map_mode: bool = False,
+                  fold_x: bool = False) -> S1Plan:
+  """Plans stage 1.  `layouts[i]` is None for unused inputs.  `map_mode` keeps every dim (nchunk=1).  `fold_x`: the
+  caller folds weights on the innermost dim into stage 1 (S1Plan.x_weights), so x is summed here; when the inner depth
+  rows are contiguous the flat float4 sweep is planned (plane_rows = their count, see s1_xf_kernel)."""
   dims = tuple(dims)
   sizes = {d: int(sizes[d]) for d in dims}
   reduce_set = set(reduce_dims) & set(dims)
@@ -264,6 +268,28 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
       nchunk = int(min(max(ndepth // plane_rows, 1), max(1, -(-target_blocks // max(nkey, 1)))))
       depth_chunk = -(-ndepth // nchunk)
       depth_chunk = -(-depth_chunk // plane_rows) * plane_rows
+      nchunk = -(-ndepth // depth_chunk)
+
+  if fold_x and not x_kept and not map_mode and not (flags & 3) and x_dim is not None and depth_dims and nx + 3 <= 2048:
+    inner = depth_dims[-1]
+    r = sizes[inner]
+    used = [(i, lay) for i, lay in enumerate(layouts[:3]) if lay is not None]
+    ok = r % 4 == 0 and all(lay.itemsize == 4 and lay.base_alignment % 16 == 0 and lay.stride(x_dim) == 1
+                            and lay.stride(inner) == nx for _, lay in used)
+    if gather is not None and inner in gather.dims:
+      ok = False
+    if ok:
+      for i, _ in used:
+        for tab in (key_off[i], None if depth_off[i] is None else depth_off[i][::r]):
+          if tab is not None and np.any(tab % 4):
+            ok = False
+        if i == 2 and gtab is not None and np.any(gtab % 4):
+          ok = False
+    if ok:
+      # measured on configs[1] (latitude-fastest): 256 threads x 4096 blocks 3.77 ms, 128 x 8192 3.76, 64 x 16384 4.05
+      plane_rows, vec, block_threads = r, 1, 256
+      rc = int(min(max(ndepth // 4, 1), max(1, -(-target_blocks // max(nkey, 1)))))
+      depth_chunk = -(-(-(-ndepth // rc)) // 4) * 4
       nchunk = -(-ndepth // depth_chunk)
 
   return S1Plan(plane_rows=int(plane_rows), dims=dims, sizes=sizes, x_dim=x_dim, x_kept=bool(x_kept), sum_j=bool(sum_j), a_dims=a_dims,
