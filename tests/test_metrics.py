@@ -742,6 +742,12 @@ def test_plane_mode_with_a_validity_mask(backend, mask_order):
   np.testing.assert_allclose(res['rmse.z'].values, np.sqrt(sws / sw), rtol=RTOL)
   sws, sw, _ = O.aggregate(e, dims, ['init_time', 'latitude', 'longitude'], weights=[w], mask=full_valid, mask_dims=dims)
   np.testing.assert_allclose(res['bias.z'].values, sws / sw, rtol=RTOL, atol=1e-9)
+  # latitude kept (zonal statistics): nothing can be folded, the LDS plane kernel carries the mask spans itself
+  agg_k = aggregation.Aggregator(reduce_dims=['init_time', 'longitude'], masked=True)
+  res_k = aggregation.compute_metric_values_for_single_chunk({'mse': deterministic.MSE()}, agg_k, {'z': p}, {'z': t})
+  sws, sw, od = O.aggregate(se, dims, ['init_time', 'longitude'], mask=full_valid, mask_dims=dims)
+  with np.errstate(invalid='ignore', divide='ignore'):
+    np.testing.assert_allclose(res_k['mse.z'].transpose(*od).values, sws / sw, rtol=RTOL, equal_nan=True)
   lays = [planner.InputLayout(strides=dict(zip(dims, [int(s // 4) for s in a.strides])), itemsize=4, base_alignment=256)
           for a in (pv, tv)] + [None]
   mdims = ('longitude', 'latitude') if mask_order == 'lon_lat' else ('latitude', 'longitude')
@@ -757,7 +763,8 @@ def test_plane_mode_with_a_validity_mask(backend, mask_order):
 def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
   """Latitude-fastest data + GridAreaWeighting and no bins: the weights depend on the innermost dim only, so the
   deterministic family applies them inside stage 1 (plan.x_weights, flat float4 sweep over the contiguous planes) and
-  sums latitude there.  Masks / skipna and the ensemble family keep latitude for stage 2 (measured faster).  Every
+  sums latitude there, also under a validity mask stored like the data.  skipna and the ensemble family keep latitude
+  for stage 2 (measured faster).  Every
   route must equal the un-folded one and the oracle."""
   from weatherbenchx_amd import engine
   rng = np.random.default_rng(33)
@@ -792,7 +799,7 @@ def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
     logs[fold] = seen
     monkeypatch.setattr(engine, '_planned', inner)
   used = [pl for pl in logs[True] if pl.x_weights is not None]
-  assert bool(used) == (mode == 'plain') and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
+  assert bool(used) == (mode in ('plain', 'masked')) and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
   assert logs[False] and all(pl.x_weights is None and pl.x_kept for pl in logs[False])
   for k, v in results[False].items():
     np.testing.assert_allclose(results[True][k].values, v.values, rtol=1e-9, equal_nan=True)

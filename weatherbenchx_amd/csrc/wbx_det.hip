@@ -182,10 +182,16 @@ template <typename T, int FUNC>
 static int dispatch_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   if (plan->x_weights != nullptr && plan->plane_rows > 0) {  // folded weights over contiguous planes: flat float4 sweep
     if constexpr (std::is_same<T, float>::value) {
-      WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)), "flat x-weighted mode does not take mask/skipna flags");
+      WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA), "flat x-weighted mode does not take the skipna flag");
       for (int i = 0; i < DetOp<T, FUNC, 0>::NIN; ++i)
         WBX_REQUIRE(plan->xstride[i] == 1 && (((uintptr_t)a.in[i]) & 15) == 0,
                     "flat x-weighted mode needs unit x stride and 16-byte aligned inputs");
+      if (plan->flags & WBX_FLAG_MASKED) {
+        WBX_REQUIRE(plan->xstride[3] == 1 && (((uintptr_t)a.in[3]) & 3) == 0,
+                    "flat x-weighted mode needs a unit-stride, 4-byte aligned mask");
+        if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 1>, 1>(ctx, plan, a);
+        return launch_flat_weighted<DetOp<T, FUNC, 1>>(ctx, plan, a);
+      }
       if (plan->nkey == 0 || plan->ndepth == 0 || plan->nx == 0) return launch_partial<DetOp<T, FUNC, 0>, 1>(ctx, plan, a);
       return launch_flat_weighted<DetOp<T, FUNC, 0>>(ctx, plan, a);
     } else {

@@ -405,6 +405,8 @@ __global__ void __launch_bounds__(256) s1_xf_kernel(S1Args a, int R) {
     const f4_t* pp = reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[0]) + ro[0]);
     const f4_t* pt = NIN > 1 ? reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[1]) + ro[1]) : nullptr;
     const f4_t* pc = NIN > 2 ? reinterpret_cast<const f4_t*>(reinterpret_cast<const float*>(a.in[2]) + ro[2]) : nullptr;
+    const uint32_t* pm = nullptr;  // validity mask: the same flat walk over its (contiguous) plane, 4 bytes per float4
+    if constexpr (op_has_mrow<Op>::value) pm = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.in[3]) + ro[3]);
     int m = (int)((4 * (q0 + tid)) % nx);  // latitude of the thread's first element
     const int step = (4 * nt) % nx;
 #pragma unroll 2
@@ -413,11 +415,22 @@ __global__ void __launch_bounds__(256) s1_xf_kernel(S1Args a, int R) {
       f4_t t4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (NIN > 1) t4 = ld_stream(pt + q);
       if constexpr (NIN > 2) c4 = ld_stream(pc + q);
+      uint32_t mq = 0xffffffffu;
+      if constexpr (op_has_mrow<Op>::value) mq = pm[q];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double val[Op::NLANE];
-        Op::lanes((double)p4[k], (double)t4[k], (double)c4[k], val);
+        float pv = p4[k], tv = t4[k], cv = c4[k];
         const double w = wbx_xw_lds[m + k];
+        if constexpr (op_has_mrow<Op>::value) {
+          // masked-out points contribute exactly 0 whatever they hold (aggregation.py:339-357); count lane = sum of w
+          const bool valid = ((mq >> (8 * k)) & 0xffu) != 0;
+          pv = valid ? pv : 0.f;
+          tv = valid ? tv : 0.f;
+          cv = valid ? cv : 0.f;
+          acc[Op::NLANE] += valid ? w : 0.0;
+        }
+        double val[Op::NLANE];
+        Op::lanes((double)pv, (double)tv, (double)cv, val);
 #pragma unroll
         for (int l = 0; l < Op::NLANE; ++l) acc[l] = fma(val[l], w, acc[l]);
       }

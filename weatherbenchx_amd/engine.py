@@ -496,7 +496,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   # kept as nx partials per key for stage 2.
   x_weights = None
   hit = None
-  if FOLD_X_WEIGHTS and kind == 'det' and not flags and w_da is not None and not bin_dims and len(w_da.dims) == 1:
+  if (FOLD_X_WEIGHTS and kind == 'det' and not (flags & ~_hip.FLAG_MASKED) and w_da is not None and not bin_dims
+      and len(w_da.dims) == 1):
     x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
     if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:
       xw = np.ascontiguousarray(w_da.values, dtype=np.float64)

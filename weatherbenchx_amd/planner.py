@@ -270,12 +270,18 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
       depth_chunk = -(-depth_chunk // plane_rows) * plane_rows
       nchunk = -(-ndepth // depth_chunk)
 
-  if fold_x and not x_kept and not map_mode and not (flags & 3) and x_dim is not None and depth_dims and nx + 3 <= 2048:
+  if fold_x and not x_kept and not map_mode and not (flags & 2) and x_dim is not None and depth_dims and nx + 3 <= 2048:
     inner = depth_dims[-1]
     r = sizes[inner]
     used = [(i, lay) for i, lay in enumerate(layouts[:3]) if lay is not None]
     ok = r % 4 == 0 and all(lay.itemsize == 4 and lay.base_alignment % 16 == 0 and lay.stride(x_dim) == 1
                             and lay.stride(inner) == nx for _, lay in used)
+    if flags & 1:  # the mask is walked flat alongside the data: same (inner, x) order, planes 4-byte aligned
+      mlay = layouts[3] if len(layouts) > 3 else None
+      ok = ok and mlay is not None and mlay.itemsize == 1 and mlay.base_alignment % 4 == 0 \
+          and mlay.stride(x_dim) == 1 and mlay.stride(inner) == nx
+      if ok:
+        used = used + [(3, mlay)]
     if gather is not None and inner in gather.dims:
       ok = False
     if ok:
