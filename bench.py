@@ -231,12 +231,22 @@ def main():
 
     def estep():
       return aggregation.compute_metric_values_for_single_chunk(emetrics, eagg, fresh(pe), fresh(te))
-    for _ in range(2):
-      eout = estep()
+
+    def erun(n):  # software-pipelined like the main loop: launch step k+1, then turn step k's sums into metric values
+      out_, prev = None, None
+      with engine.deferred_results():
+        for _ in range(n):
+          cur = eagg.aggregate_statistics(
+              metrics_base.compute_unique_statistics_for_all_metrics(emetrics, fresh(pe), fresh(te)))
+          if prev is not None:
+            out_ = prev.metric_values(emetrics)
+          prev = cur
+        out_ = prev.metric_values(emetrics)
+      return out_
+    eout = erun(2)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-      eout = estep()
+    eout = erun(args.steps)
     sync()
     e_ms = (time.perf_counter() - t0) / args.steps * 1e3
     engine.S1_EVENT_LOG = []
