@@ -254,6 +254,16 @@ int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int
                        int32_t nlon, const int32_t* group, const double* scale, int32_t ngroup,
                        int32_t accumulate, double* power_out);
 
+/* The same over `nslab` slabs of `rows_per_slab` uniformly strided rows each: row i of slab o starts at
+ * field + h_slab_offsets[o] + i * row_stride (h_slab_offsets is a HOST int64 array of element offsets; group / scale are
+ * indexed by o * rows_per_slab + i).  A latitude-fastest field [lead, level, longitude, latitude] is lead x level slabs
+ * of `latitude` adjacent rows (row_stride 1, lon_stride = nlat): those are transposed tile by tile into contiguous rows
+ * and fed to the fused kernel in one call instead of one strided library batch per slab. */
+int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride,
+                             int64_t rows_per_slab, int64_t nslab, const int64_t* h_slab_offsets, int32_t nlon,
+                             const int32_t* group, const double* scale, int32_t ngroup, int32_t accumulate,
+                             double* power_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,13 +61,16 @@ def test_parseval_constant_and_sinusoid(backend, monkeypatch, nlon, team):
   np.testing.assert_allclose(s, O.zonal_power_spectrum(r32), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('nlon', [48, 45, 50])  # fused (4*2*3), odd -> library route, fused with radix 5
 @pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
-def test_area_weighted_mean_spectrum_matches_oracle(backend, layout):
+def test_area_weighted_mean_spectrum_matches_oracle(backend, layout, nlon):
+  """lat_fastest = lead x level slabs of adjacent latitude rows with strided longitude: one wbx_zonal_spectrum_slabs
+  call (rows transposed tile by tile into the fused kernel, or one library batch per slab for odd lengths)."""
   rng = np.random.default_rng(0)
-  lat, lon = np.linspace(-80, 80, 9), np.arange(48) * 7.5
+  lat, lon = np.linspace(-80, 80, 9), np.arange(nlon) * (360.0 / nlon)
   dims = ('lead_time', 'level', 'latitude', 'longitude') if layout == 'lon_fastest' else \
       ('lead_time', 'level', 'longitude', 'latitude')
-  shape = {'lead_time': 3, 'level': 2, 'latitude': 9, 'longitude': 48}
+  shape = {'lead_time': 3, 'level': 2, 'latitude': 9, 'longitude': nlon}
   vals = rng.normal(size=[shape[d] for d in dims]).astype(np.float32)
   f = _field(vals, dims, lat=lat, lon=lon)
   metrics = {'spec': spectra.ZonalPowerSpectrum(), 'espec': spectra.ZonalEnergySpectrum()}

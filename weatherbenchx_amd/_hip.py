@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
     'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
     'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_cat_partial', 'wbx_det_map', 'wbx_ens_map',
-    'wbx_zonal_spectrum', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
+    'wbx_zonal_spectrum', 'wbx_zonal_spectrum_slabs', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy',
 )
 
@@ -115,6 +115,7 @@ def load_library():
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
         'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
+        'wbx_zonal_spectrum_slabs': [vp, vp, i64, i64, i64, i64, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
     for name, argtypes in protos.items():
       fn = getattr(lib, name)

@@ -363,88 +363,99 @@ static bool fused_factor(int n, FusedSpec& fs) {
   return true;
 }
 
-}  // namespace wbx
-
-extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride,
-                                  int64_t nrows, int32_t nlon, const int32_t* group, const double* scale,
-                                  int32_t ngroup, int32_t accumulate, double* power_out) {
-  using namespace wbx;
-  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
-  WBX_REQUIRE(nlon >= 2 && nrows >= 0 && ngroup >= 0, "bad spectrum extents (nlon=%d, nrows=%lld)", nlon, (long long)nrows);
-  WBX_REQUIRE(lon_stride >= 1 && row_stride >= 1, "strides must be positive");
-  const int nk = nlon / 2 + 1;
-  WBX_REQUIRE(power_out != nullptr || ngroup == 0, "power_out is NULL");
-  WBX_HIP(hipSetDevice(ctx->device));
-  if (!accumulate && ngroup > 0)
-    WBX_HIP(hipMemsetAsync(power_out, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  if (nrows == 0) return 0;
-  WBX_REQUIRE(field && group && scale, "field/group/scale is NULL");
-  auto* st = reinterpret_cast<FftState*>(ctx->fft_state);
-  if (!st) {
-    st = new FftState();
-    ctx->fft_state = st;
-    WBX_FFT(rocfft_setup());
-    st->setup = true;
-  }
-  FusedSpec fs;
-  const char* force = getenv("WBX_SPECTRUM_PATH");  // "rocfft" pins the library route (A/B timing, tests)
-  if (!(force && force[0] == 'r') && lon_stride == 1 && (row_stride % 2) == 0 && (((uintptr_t)field) & 7) == 0 &&
-      fused_factor(nlon, fs)) {
-    const int n2 = fs.n2;
-    void*& tw = st->twiddles[nlon];
-    if (!tw) {
-      std::vector<float2> host((size_t)n2 + n2 + 1);
-      for (int m = 0; m < n2; ++m) {
-        const double a = -2.0 * M_PI * (double)m / (double)n2;
-        host[m] = make_float2((float)cos(a), (float)sin(a));
-      }
-      for (int k = 0; k <= n2; ++k) {
-        const double a = -2.0 * M_PI * (double)k / (double)nlon;
-        host[n2 + k] = make_float2((float)cos(a), (float)sin(a));
-      }
-      WBX_HIP(hipMalloc(&tw, host.size() * sizeof(float2)));
-      WBX_HIP(hipMemcpyAsync(tw, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
-      WBX_HIP(hipStreamSynchronize(ctx->stream));
+// Launches zspec_fused_kernel over `nrows` contiguous rows (row r at field + r * row_stride, unit longitude stride).
+static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const float* field, int64_t row_stride,
+                        int64_t nrows, const int32_t* group, const double* scale, double* power_out) {
+  const int nlon = fs.n, nk = fs.n2 + 1;
+  (void)nlon;
+  const int n2 = fs.n2;
+  void*& tw = st->twiddles[nlon];
+  if (!tw) {
+    std::vector<float2> host((size_t)n2 + n2 + 1);
+    for (int m = 0; m < n2; ++m) {
+      const double a = -2.0 * M_PI * (double)m / (double)n2;
+      host[m] = make_float2((float)cos(a), (float)sin(a));
     }
-    const float2* tw_pass = reinterpret_cast<const float2*>(tw);
-    const float2* tw_real = tw_pass + n2;
-    // threads per row pair: more threads = fewer registers per thread and more waves per LDS byte (n = 1440, configs[3]:
-    // 64 / 128 / 256 threads -> 2.16 / 2.00 / 1.75 ms per step); short rows keep one wave busy
-    int G = n2 <= 128 ? 64 : (n2 <= 256 ? 128 : 256);
-    if (const char* e = getenv("WBX_SPECTRUM_TEAM")) G = atoi(e);  // tests drive every team size
-    WBX_REQUIRE(G == 64 || G == 128 || G == 256, "WBX_SPECTRUM_TEAM must be 64, 128 or 256");
-    const int nteam = G == 64 ? 4 : 1;
-    const size_t lds = (size_t)(n2 + nk + (nk & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
-    // a team sweeps a contiguous run of rows (one group for most of it)
-    int64_t teams = (int64_t)256 * 4 * 8 * 64 / G;
-    if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;
-    int rows_per_team = (int)((nrows + teams - 1) / teams);
-    rows_per_team += rows_per_team & 1;  // whole pairs
-    teams = (nrows + rows_per_team - 1) / rows_per_team;
-    const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
-    const int kpt = (nk + G - 1) / G;
+    for (int k = 0; k <= n2; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)nlon;
+      host[n2 + k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    WBX_HIP(hipMalloc(&tw, host.size() * sizeof(float2)));
+    WBX_HIP(hipMemcpyAsync(tw, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  const float2* tw_pass = reinterpret_cast<const float2*>(tw);
+  const float2* tw_real = tw_pass + n2;
+  // threads per row pair: more threads = fewer registers per thread and more waves per LDS byte (n = 1440, configs[3]:
+  // 64 / 128 / 256 threads -> 2.16 / 2.00 / 1.75 ms per step); short rows keep one wave busy
+  int G = n2 <= 128 ? 64 : (n2 <= 256 ? 128 : 256);
+  if (const char* e = getenv("WBX_SPECTRUM_TEAM")) G = atoi(e);  // tests drive every team size
+  WBX_REQUIRE(G == 64 || G == 128 || G == 256, "WBX_SPECTRUM_TEAM must be 64, 128 or 256");
+  const int nteam = G == 64 ? 4 : 1;
+  const size_t lds = (size_t)(n2 + nk + (nk & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
+  // a team sweeps a contiguous run of rows (one group for most of it)
+  int64_t teams = (int64_t)256 * 4 * 8 * 64 / G;
+  if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;
+  int rows_per_team = (int)((nrows + teams - 1) / teams);
+  rows_per_team += rows_per_team & 1;  // whole pairs
+  teams = (nrows + rows_per_team - 1) / rows_per_team;
+  const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
+  const int kpt = (nk + G - 1) / G;
 #define WBX_LAUNCH_FUSED(KPT, GG)                                                                                   \
-    do {                                                                                                              \
-      if (lds > 48 * 1024)                                                                                            \
-        WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG>),                      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-      hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
-                         nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, power_out);                        \
-    } while (0)
-    if (G == 256) {
-      if (kpt <= 3) WBX_LAUNCH_FUSED(3, 256); else WBX_LAUNCH_FUSED(5, 256);
-    } else if (G == 128) {
-      if (kpt <= 6) WBX_LAUNCH_FUSED(6, 128); else WBX_LAUNCH_FUSED(9, 128);
-    } else {
-      if (kpt <= 4) WBX_LAUNCH_FUSED(4, 64);
-      else if (kpt <= 8) WBX_LAUNCH_FUSED(8, 64);
-      else if (kpt <= 12) WBX_LAUNCH_FUSED(12, 64);
-      else WBX_LAUNCH_FUSED(17, 64);
-    }
-#undef WBX_LAUNCH_FUSED
-    WBX_HIP(hipGetLastError());
-    return 0;
+  do {                                                                                                              \
+    if (lds > 48 * 1024)                                                                                            \
+      WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+    hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
+                       nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, power_out);                        \
+  } while (0)
+  if (G == 256) {
+    if (kpt <= 3) WBX_LAUNCH_FUSED(3, 256); else WBX_LAUNCH_FUSED(5, 256);
+  } else if (G == 128) {
+    if (kpt <= 6) WBX_LAUNCH_FUSED(6, 128); else WBX_LAUNCH_FUSED(9, 128);
+  } else {
+    if (kpt <= 4) WBX_LAUNCH_FUSED(4, 64);
+    else if (kpt <= 8) WBX_LAUNCH_FUSED(8, 64);
+    else if (kpt <= 12) WBX_LAUNCH_FUSED(12, 64);
+    else WBX_LAUNCH_FUSED(17, 64);
   }
+#undef WBX_LAUNCH_FUSED
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+// scratch[(row - row0) * nlon + j] = field[slab_off[row / rps] + (row % rps) + j * lon_stride] for rows of unit row
+// stride (latitude-fastest fields: the rows of a slab are adjacent, longitude is strided): 64 x 64 tiles through LDS,
+// reads coalesced along the rows, writes coalesced along longitude.
+__global__ void __launch_bounds__(256) transpose_rows_kernel(const float* __restrict__ field, int64_t lon_stride,
+                                                             const int64_t* __restrict__ slab_off, int64_t rps,
+                                                             int64_t row0, int64_t nrows, int nlon,
+                                                             float* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int64_t rb = (int64_t)blockIdx.y * 64;             // first row of the tile, relative to row0
+  const int jb = blockIdx.x * 64;
+  for (int dj = ty; dj < 64; dj += 4) {
+    const int64_t r = rb + tx;
+    const int j = jb + dj;
+    if (r < nrows && j < nlon) {
+      const int64_t gr = row0 + r;
+      const int64_t slab = gr / rps;
+      tile[dj][tx] = __builtin_nontemporal_load(field + (slab_off ? slab_off[slab] : 0) + (gr - slab * rps) + (int64_t)j * lon_stride);
+    }
+  }
+  __syncthreads();
+  for (int dr = ty; dr < 64; dr += 4) {
+    const int64_t r = rb + dr;
+    const int j = jb + tx;
+    if (r < nrows && j < nlon) out[r * nlon + j] = tile[tx][dr];
+  }
+}
+
+// rocFFT route for one slab: batched strided R2C + power_kernel, in row tiles of <= 256 MiB of complex scratch.
+static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t lon_stride, int64_t row_stride,
+                        int64_t nrows, int32_t nlon, const int32_t* group, const double* scale, double* power_out) {
+  const int nk = nlon / 2 + 1;
   // tile of rows: <= 256 MiB of complex scratch
   int64_t tile = ((int64_t)256 << 20) / ((int64_t)nk * 8);
   if (tile < 1) tile = 1;
@@ -473,4 +484,105 @@ extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_
     WBX_HIP(hipGetLastError());
   }
   return 0;
+}
+
+}  // namespace wbx
+
+static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride, int64_t rps,
+                               int64_t nslab, const int64_t* h_slab_offsets, int32_t nlon, const int32_t* group,
+                               const double* scale, int32_t ngroup, int32_t accumulate, double* power_out) {
+  using namespace wbx;
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  WBX_REQUIRE(nlon >= 2 && rps >= 0 && nslab >= 0 && ngroup >= 0, "bad spectrum extents (nlon=%d, rows=%lld x %lld)", nlon,
+              (long long)nslab, (long long)rps);
+  WBX_REQUIRE(lon_stride >= 1 && row_stride >= 1, "strides must be positive");
+  WBX_REQUIRE(nslab <= 1 || h_slab_offsets != nullptr, "slab offsets are NULL");
+  const int nk = nlon / 2 + 1;
+  const int64_t nrows = rps * nslab;
+  WBX_REQUIRE(power_out != nullptr || ngroup == 0, "power_out is NULL");
+  WBX_HIP(hipSetDevice(ctx->device));
+  if (!accumulate && ngroup > 0)
+    WBX_HIP(hipMemsetAsync(power_out, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+  if (nrows == 0) return 0;
+  WBX_REQUIRE(field && group && scale, "field/group/scale is NULL");
+  auto* st = reinterpret_cast<FftState*>(ctx->fft_state);
+  if (!st) {
+    st = new FftState();
+    ctx->fft_state = st;
+    WBX_FFT(rocfft_setup());
+    st->setup = true;
+  }
+  FusedSpec fs;
+  const char* force = getenv("WBX_SPECTRUM_PATH");  // "rocfft" pins the library route (A/B timing, tests)
+  const bool fused_ok = !(force && force[0] == 'r') && fused_factor(nlon, fs);
+  if (fused_ok && lon_stride == 1 && (row_stride % 2) == 0) {
+    // contiguous rows: straight into the fused kernel, slab by slab (a slab = rows at a uniform stride)
+    bool aligned = (((uintptr_t)field) & 7) == 0;
+    for (int64_t o = 0; o < nslab && aligned; ++o) aligned = ((nslab > 1 ? h_slab_offsets[o] : 0) % 2) == 0;
+    if (aligned) {
+      for (int64_t o = 0; o < nslab; ++o) {
+        const int64_t off = nslab > 1 ? h_slab_offsets[o] : (h_slab_offsets ? h_slab_offsets[0] : 0);
+        if (int rc = launch_fused(ctx, st, fs, field + off, row_stride, rps, group + o * rps, scale + o * rps, power_out))
+          return rc;
+      }
+      return 0;
+    }
+  }
+  if (fused_ok && row_stride == 1 && lon_stride > 1) {
+    // latitude-fastest fields (rows adjacent, longitude strided): transpose row tiles into a contiguous scratch, then the
+    // fused kernel -- 3 passes over the field instead of one strided rocFFT batch per slab (configs[3], 296 slabs of
+    // 721 rows: 27.6 ms -> see DESIGN.md)
+    int64_t tile = ((int64_t)256 << 20) / ((int64_t)nlon * 4);
+    tile -= tile & 1;
+    if (tile < 2) tile = 2;
+    if (tile > nrows) tile = nrows;
+    const size_t need = (size_t)tile * nlon * sizeof(float) + (size_t)(nslab > 1 ? nslab : 1) * sizeof(int64_t);
+    if (st->scratch_size < need) {
+      if (st->scratch) {
+        WBX_HIP(hipStreamSynchronize(ctx->stream));
+        WBX_HIP(hipFree(st->scratch));
+        st->scratch = nullptr;
+        st->scratch_size = 0;
+      }
+      WBX_HIP(hipMalloc(&st->scratch, need));
+      st->scratch_size = need;
+    }
+    float* rows = reinterpret_cast<float*>(st->scratch);
+    int64_t* d_off = nullptr;
+    if (nslab > 1 || (h_slab_offsets && h_slab_offsets[0] != 0)) {
+      d_off = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(st->scratch) + (size_t)tile * nlon * sizeof(float));
+      WBX_HIP(hipMemcpyAsync(d_off, h_slab_offsets, (size_t)nslab * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+      WBX_HIP(hipStreamSynchronize(ctx->stream));  // the host array may go away after the call
+    }
+    for (int64_t r0 = 0; r0 < nrows; r0 += tile) {
+      const int64_t n = r0 + tile <= nrows ? tile : nrows - r0;
+      dim3 grid((unsigned)((nlon + 63) / 64), (unsigned)((n + 63) / 64));
+      hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, ctx->stream, field, lon_stride, d_off, rps, r0, n, (int)nlon, rows);
+      WBX_HIP(hipGetLastError());
+      if (int rc = launch_fused(ctx, st, fs, rows, nlon, n, group + r0, scale + r0, power_out)) return rc;
+    }
+    return 0;
+  }
+  // library route, one strided batch per slab
+  for (int64_t o = 0; o < nslab; ++o) {
+    const int64_t off = h_slab_offsets ? h_slab_offsets[o] : 0;
+    if (int rc = rocfft_route(ctx, st, field + off, lon_stride, row_stride, rps, nlon, group + o * rps, scale + o * rps, power_out))
+      return rc;
+  }
+  return 0;
+}
+
+extern "C" int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride,
+                                  int64_t nrows, int32_t nlon, const int32_t* group, const double* scale,
+                                  int32_t ngroup, int32_t accumulate, double* power_out) {
+  return zonal_spectrum_impl(ctx, field, lon_stride, row_stride, nrows, 1, nullptr, nlon, group, scale, ngroup, accumulate,
+                             power_out);
+}
+
+extern "C" int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride,
+                                        int64_t rows_per_slab, int64_t nslab, const int64_t* h_slab_offsets, int32_t nlon,
+                                        const int32_t* group, const double* scale, int32_t ngroup, int32_t accumulate,
+                                        double* power_out) {
+  return zonal_spectrum_impl(ctx, field, lon_stride, row_stride, rows_per_slab, nslab, h_slab_offsets, nlon, group, scale,
+                             ngroup, accumulate, power_out);
 }

@@ -94,12 +94,13 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
       cache[ckey] = bufs
   g_dev, s_dev = bufs[0], bufs[1]
   out = engine._scratch(ctx, 'spectrum', max(ngroup * nk, 1) * 8)  # pylint: disable=protected-access
-  for o, base_off in enumerate(geo.outer_offsets):
-    first_row = int(geo.row_index[o][0]) if geo.permutation is None else o * geo.batch
-    _hip.check(ctx.lib.wbx_zonal_spectrum(ctx.handle, C.c_void_p(dev.ptr + 4 * int(base_off)), int(geo.lon_stride),
-                                          int(geo.row_stride), int(geo.batch), int(nlon),
-                                          C.c_void_p(g_dev.ptr + 4 * first_row), C.c_void_p(s_dev.ptr + 8 * first_row),
-                                          int(ngroup), 0 if o == 0 else 1, C.c_void_p(out.ptr)), 'wbx_zonal_spectrum')
+  # one call for every slab (lead x level slabs of adjacent latitude rows for latitude-fastest fields); group / scale are
+  # already in slab-major row order (geo.permutation)
+  offs = np.ascontiguousarray(geo.outer_offsets, dtype=np.int64)
+  _hip.check(ctx.lib.wbx_zonal_spectrum_slabs(ctx.handle, C.c_void_p(dev.ptr), int(geo.lon_stride), int(geo.row_stride),
+                                              int(geo.batch), int(offs.size), offs.ctypes.data_as(C.c_void_p), int(nlon),
+                                              C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr), int(ngroup), 0,
+                                              C.c_void_p(out.ptr)), 'wbx_zonal_spectrum_slabs')
   return ctx.download(out.ptr, (ngroup, nk), np.float64)
 
 
