@@ -13,11 +13,14 @@ from weatherbenchx_amd.metrics import base as mb, probabilistic
 from wb_regions import REGIONS
 
 m, nl, nlat, nlon = 51, 8, 721, 1440
+LATFAST = len(sys.argv) > 1 and sys.argv[1] == 'lat_fastest'
+SP = ('longitude', 'latitude') if LATFAST else ('latitude', 'longitude')
 lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
 coords = {'lead_time': (np.arange(nl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]'), 'latitude': lat,
           'longitude': lon}
-t_t = torch.randn((nl, nlat, nlon), device='cuda') + 280
-p_t = t_t[:, None] + torch.randn((nl, m, nlat, nlon), device='cuda')
+sshape = (nlon, nlat) if LATFAST else (nlat, nlon)
+t_t = torch.randn((nl,) + sshape, device='cuda') + 280
+p_t = t_t[:, None] + torch.randn((nl, m) + sshape, device='cuda')
 land = (np.sin(np.deg2rad(lon) * 3)[None, :] * np.cos(np.deg2rad(lat) * 2.5)[:, None]) > 0.35
 lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
 metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
@@ -28,8 +31,8 @@ for name, agg in (('no bins', aggregation.Aggregator(reduce_dims=['latitude', 'l
                                                      weigh_by=[weighting.GridAreaWeighting()],
                                                      bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)]))):
   def launch():
-    pp = {'v': xr.DataArray(p_t, dims=('lead_time', 'number', 'latitude', 'longitude'), coords=coords)}
-    tt = {'v': xr.DataArray(t_t, dims=('lead_time', 'latitude', 'longitude'), coords=coords)}
+    pp = {'v': xr.DataArray(p_t, dims=('lead_time', 'number') + SP, coords=coords)}
+    tt = {'v': xr.DataArray(t_t, dims=('lead_time',) + SP, coords=coords)}
     return agg.aggregate_statistics(mb.compute_unique_statistics_for_all_metrics(metrics, pp, tt))
   for _ in range(3):
     out = launch().metric_values(metrics)
