@@ -192,7 +192,10 @@ struct EnsMasked {
 template <class Op>
 int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
   if (map) return launch_map<Op>(ctx, plan, a);
-  WBX_REQUIRE(plan->x_weights == nullptr, "x_weights is not supported by the ensemble kernels");
+  if (plan->x_weights != nullptr) {  // latitude weights folded into stage 1, flat sweep over contiguous planes
+    WBX_REQUIRE(!(plan->flags & ~WBX_FLAG_FAIR), "flat x-weighted mode does not take mask/skipna flags");
+    return launch_flat_weighted1<Op>(ctx, plan, a);
+  }
   if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<EnsMasked<Op, true>, 1>(ctx, plan, a);
   if (plan->flags & WBX_FLAG_MASKED) return launch_partial<EnsMasked<Op, false>, 1>(ctx, plan, a);
   return launch_partial<Op, 1>(ctx, plan, a);

@@ -466,6 +466,83 @@ int launch_flat_weighted(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   return 0;
 }
 
+
+// The same flat sweep for ops that work one point at a time (the ensemble family: a point's M members sit at
+// ro[0] + e + m * mstride, so walking e over the contiguous plane needs no row structure either).  Any nx, any row
+// count; chunks are cut at rows.  grid = nkey * nchunk, block = plan->block_threads.
+template <class Op>
+__global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xf1_kernel(S1Args a, int R) {
+  constexpr int NL = Op::NLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nwave = nt >> 6;
+  const int nx = (int)a.nx;
+  const int64_t b = blockIdx.x;
+  const int64_t key = b / a.nchunk;
+  const int chunk = (int)(b - key * a.nchunk);
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+  for (int i = tid; i < nx; i += nt) wbx_xw_lds[i] = a.xw[i];
+  __syncthreads();
+  int64_t kb[WBX_MAX_INPUTS];
+  key_bases<Op::NIN>(a, key, kb);
+  double acc[NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+  const int step = nt % nx;
+  int64_t d = d0;
+  while (d < d1) {
+    const int64_t plane = d / R;
+    const int64_t j0 = d - plane * R;
+    const int64_t nj = d1 - d < R - j0 ? d1 - d : R - j0;
+    int64_t ro[WBX_MAX_INPUTS];
+    row_bases<Op::NIN>(a, kb, key, plane * R, ro);
+    const int64_t e0 = j0 * nx, e1 = (j0 + nj) * nx;
+    // lanes start on a 64-element boundary of the plane (planes are normally 128-B aligned, rows of 721 are not), so
+    // every wave load covers whole cache lines; the lanes in front of e0 sit the first trip out
+    int64_t e = (e0 & ~(int64_t)63) + tid;
+    int m = (int)((e - e0 + nx) % nx);
+    if (e < e0) {
+      e += nt;
+      m += step;
+      m = m >= nx ? m - nx : m;
+    }
+    for (; e < e1; e += nt) {
+      double val[NL];
+      Op::values(a, ro, e, val);
+      const double w = wbx_xw_lds[m];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) acc[l] = fma(val[l], w, acc[l]);
+      m += step;
+      m = m >= nx ? m - nx : m;
+    }
+    d += nj;
+  }
+  __shared__ double red[4][NL];
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const double v = wave_sum(acc[l]);
+    if (lane == 0) red[wave][l] = v;
+  }
+  __syncthreads();
+  if (tid < NL) {
+    double sum = 0.0;
+    for (int w = 0; w < nwave; ++w) sum += red[w][tid];
+    a.out[(key * a.nchunk + chunk) * NL + tid] = sum;
+  }
+}
+
+template <class Op>
+int launch_flat_weighted1(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  const int R = plan->plane_rows;
+  WBX_REQUIRE(!plan->x_kept && plan->x_weights && R > 0 && plan->nx <= WBX_XW_MAX && plan->ndepth % R == 0,
+              "flat x-weighted mode needs x summed, whole planes and nx <= %d", WBX_XW_MAX);
+  WBX_REQUIRE(plan->xstride[0] == 1 && plan->xstride[1] == 1, "flat x-weighted mode needs unit x stride");
+  const int64_t grid = plan->nkey * plan->nchunk;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+  hipLaunchKernelGGL((s1_xf1_kernel<Op>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a, R);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // materialise one lane: out[key][d][x].  grid = nkey * D * nxtile.
 template <class Op>

@@ -208,7 +208,8 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
   hit = _fast_plan_cache.get(sig)
   if hit is None:
     plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
-                                 allow_vec4=(kind == 'det' and x_weights is None), fold_x=x_weights is not None)
+                                 allow_vec4=(kind == 'det' and x_weights is None),
+                                 fold_x=False if x_weights is None else (True if kind == 'det' else 'point'))
     if x_weights is not None and plan.plane_rows > 0:
       assert not plan.x_kept and plan.vec == 1 and plan.nx == x_weights.size
       plan.x_weights = np.ascontiguousarray(x_weights, dtype=np.float64)
@@ -496,8 +497,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   # kept as nx partials per key for stage 2.
   x_weights = None
   hit = None
-  if (FOLD_X_WEIGHTS and kind == 'det' and not (flags & ~_hip.FLAG_MASKED) and w_da is not None and not bin_dims
-      and len(w_da.dims) == 1):
+  fold_ok = (kind == 'det' and not (flags & ~_hip.FLAG_MASKED)) or (kind == 'ens' and not (flags & ~_hip.FLAG_FAIR))
+  if FOLD_X_WEIGHTS and fold_ok and w_da is not None and not bin_dims and len(w_da.dims) == 1:
     x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
     if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:
       xw = np.ascontiguousarray(w_da.values, dtype=np.float64)

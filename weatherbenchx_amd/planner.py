@@ -135,7 +135,8 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
                   fold_x: bool = False) -> S1Plan:
   """Plans stage 1.  `layouts[i]` is None for unused inputs.  `map_mode` keeps every dim (nchunk=1).  `fold_x`: the
   caller folds weights on the innermost dim into stage 1 (S1Plan.x_weights), so x is summed here; when the inner depth
-  rows are contiguous the flat float4 sweep is planned (plane_rows = their count, see s1_xf_kernel)."""
+  rows are contiguous the flat float4 sweep is planned (plane_rows = their count, see s1_xf_kernel); fold_x='point' plans
+  the one-point-per-lane flavour of it (s1_xf1_kernel, ensemble statistics)."""
   dims = tuple(dims)
   sizes = {d: int(sizes[d]) for d in dims}
   reduce_set = set(reduce_dims) & set(dims)
@@ -270,7 +271,19 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
       depth_chunk = -(-depth_chunk // plane_rows) * plane_rows
       nchunk = -(-ndepth // depth_chunk)
 
-  if fold_x and not x_kept and not map_mode and not (flags & 2) and x_dim is not None and depth_dims and nx + 3 <= 2048:
+  if fold_x == 'point':
+    # one point per lane (ensemble kernels): the generic chunking stands, rows only have to be one contiguous run
+    if not x_kept and not (flags & ~4) and x_dim is not None and depth_dims and nx <= 2048 and gather is None:
+      inner = depth_dims[-1]
+      if all(lay.itemsize == 4 and lay.stride(x_dim) == 1 and lay.stride(inner) == nx
+             for lay in layouts[:2] if lay is not None):
+        plane_rows, vec = sizes[inner], 1
+        # measured on 8 x 51 x 1440 x 721 (threads, rows per block): (64, 1..2) 0.48 ms, (128, 2..4) 0.41-0.43,
+        # (256, 4..8) 0.407, (256, 15) 0.415; the x-kept kernel on the same data 0.452, longitude-fastest data 0.397
+        block_threads = 256
+        depth_chunk = min(max(depth_chunk, -(-2816 // nx)), ndepth)
+        nchunk = -(-ndepth // depth_chunk)
+  elif fold_x and not x_kept and not map_mode and not (flags & 2) and x_dim is not None and depth_dims and nx + 3 <= 2048:
     inner = depth_dims[-1]
     r = sizes[inner]
     used = [(i, lay) for i, lay in enumerate(layouts[:3]) if lay is not None]
