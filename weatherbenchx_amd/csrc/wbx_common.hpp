@@ -11,6 +11,7 @@
 
 struct wbx_ctx {
   int device = 0;
+  int num_cus = 256;  // hipDeviceProp_t::multiProcessorCount
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_start = nullptr;

@@ -34,6 +34,8 @@ extern "C" int wbx_ctx_create(int device_id, void* hip_stream, wbx_ctx** out) {
   WBX_HIP(hipSetDevice(device_id));
   wbx_ctx* c = new wbx_ctx();
   c->device = device_id;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->num_cus = cus;
   if (hip_stream) {
     c->stream = reinterpret_cast<hipStream_t>(hip_stream);
     c->own_stream = false;

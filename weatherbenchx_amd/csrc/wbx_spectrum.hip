@@ -200,64 +200,102 @@ __device__ __forceinline__ void team_sync() {
     __syncthreads();
 }
 
-// One in-place Stockham pass of radix R over the team's n2 points (two rows each); thread t owns butterflies t, t + G,
-// ... (at most NB of them).  All reads precede all writes.
-template <int R, int NB, int G>
+// One in-place pass of radix R over the team's n2 points (two rows each); thread t owns butterflies t, t + G, ... (at
+// most NB of them).  The passes are the TRANSPOSED Stockham flow graph (the DFT matrix is symmetric, so running the
+// transposed passes in reverse order is the same transform): butterfly j = q * ns + k gathers its inputs at stride ns,
+// (j - k) * R + k + t * ns, multiplies OUTPUT t by exp(-2 pi i k t / (ns R)) and stores it at j + t * nb -- consecutive
+// lanes store consecutive points.  LDS stores are the expensive direction on CDNA4 (ds_write_b128 ~13 cycles against 4 for
+// a read, and an N-way bank conflict multiplies that), so the strided side is the read.  ns shrinks from n2 / R to 1.
+// FIRST (ns == nb): the inputs k + t * nb are taken straight from the two rows in global memory (coalesced), the raw
+// rows never visit the LDS.  All LDS reads precede all writes.
+template <int R, int NB, int G, bool FIRST>
 __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
-                                          float inv_ns, int tid) {
+                                          float inv_ns, int tid, const v2* __restrict__ rowa,
+                                          const v2* __restrict__ rowb, bool two) {
   const int nb = n2 / R;
   const int tstep = n2 / (ns * R);  // exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
   C2 v[NB][R];
-  int base[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int j = tid + G * i;
     if (j < nb) {
-      const int q = (int)(((float)j + 0.5f) * inv_ns);  // j / ns, exact for j < 2^22
-      const int k = j - q * ns;
-      base[i] = (j - k) * R + k;
-      const int kstep = k * tstep;  // integer multiplies are quarter rate: one per butterfly, then additions
-      int ti = 0;
+      int k = j, base = j;
+      if constexpr (!FIRST) {
+        const int q = (int)(((float)j + 0.5f) * inv_ns);  // j / ns, exact for j < 2^22
+        k = j - q * ns;
+        base = (j - k) * R + k;
+      }
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-        v[i][t] = ld_c2(buf + j + t * nb);
-        if (t > 0 && ns > 1) v[i][t] = ctw(v[i][t], tw[ti]);
-        ti += kstep;
+        if constexpr (FIRST) {
+          const v2 a = __builtin_nontemporal_load(rowa + j + t * nb);
+          const v2 b = two ? __builtin_nontemporal_load(rowb + j + t * nb) : (v2){0.f, 0.f};
+          v[i][t] = {{a.x, b.x}, {a.y, b.y}};
+        } else {
+          v[i][t] = ld_c2(buf + base + t * ns);
+        }
       }
       butterfly<R>(v[i]);
+      if (ns > 1) {
+        const int kstep = k * tstep;  // integer multiplies are quarter rate: one per butterfly, then additions
+        int ti = kstep;
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+          v[i][t] = ctw(v[i][t], tw[ti]);
+          ti += kstep;
+        }
+      }
     }
   }
-  team_sync<G>();  // reads above, writes below
+  if constexpr (!FIRST) team_sync<G>();  // reads above, writes below
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int j = tid + G * i;
     if (j < nb) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) st_c2(buf + base[i] + t * ns, v[i][t]);
+      for (int t = 0; t < R; ++t) st_c2(buf + j + t * nb, v[i][t]);
     }
   }
   team_sync<G>();
 }
 
-template <int R, int G>
-__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int tid) {
+template <int R, int G, bool FIRST>
+__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int tid,
+                                              const v2* rowa, const v2* rowb, bool two) {
   // fused_factor() admits at most 256 butterflies per pass
   constexpr int NBMAX = 256 / G;
   const int nbl = (n2 / R + G - 1) / G;  // butterflies per thread
   if constexpr (NBMAX >= 4) {
-    if (nbl > 3) return team_pass<R, 4, G>(buf, tw, n2, ns, inv_ns, tid);
-    if (nbl > 2) return team_pass<R, 3, G>(buf, tw, n2, ns, inv_ns, tid);
+    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
   }
   if constexpr (NBMAX >= 2) {
-    if (nbl > 1) return team_pass<R, 2, G>(buf, tw, n2, ns, inv_ns, tid);
+    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
   }
-  team_pass<R, 1, G>(buf, tw, n2, ns, inv_ns, tid);
+  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
 }
 
-// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 + 1) / G).
+template <int G, bool FIRST>
+__device__ __forceinline__ void team_pass_radix(int rdx, v4* buf, const float2* tw, int n2, int ns, int tid,
+                                                const v2* rowa, const v2* rowb, bool two) {
+  const float inv_ns = 1.0f / (float)ns;
+  if (rdx == 4)
+    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+  else if (rdx == 2)
+    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+  else if (rdx == 3)
+    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+  else
+    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+}
+
+// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 / 2 + 1) / G).
 // G = 64: a block is 4 independent one-wave teams sharing the twiddle tables; G = 128 / 256: the block IS the team
 // (its __syncthreads are team barriers), sweeping its own run of row pairs.
-template <int KPT, int G>
+// R0 > 0 (G == 256 only: one first-pass butterfly per thread): the first pass has radix R0 and its inputs -- the raw
+// rows -- are fetched into registers one row pair AHEAD, right after the previous pair's first pass has consumed them, so
+// the HBM latency runs under the remaining passes instead of in front of every pair.
+template <int KPT, int G, int R0>
 __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
                                                           int rows_per_team, FusedSpec fs,
                                                           const float2* __restrict__ tw_pass_g,
@@ -269,7 +307,10 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
   const int n2 = fs.n2, nk = n2 + 1;
   float2* tw_pass = reinterpret_cast<float2*>(lds_raw);
   float2* tw_real = tw_pass + n2;
-  const int tid = threadIdx.x % G, team = threadIdx.x / G;
+  // team index in an SGPR: the row bookkeeping (group / scale look-ups, row pointers) then compiles to scalar loads on
+  // lgkmcnt, which do not drain the vector-memory counter the prefetched rows are in flight on
+  const int tid = G == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+  const int team = G == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   v4* buf = reinterpret_cast<v4*>(tw_real + nk + (nk & 1)) + (int64_t)team * n2;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) tw_pass[i] = tw_pass_g[i];
   for (int i = threadIdx.x; i < nk; i += blockDim.x) tw_real[i] = tw_real_g[i];
@@ -279,66 +320,101 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
   int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
   if (r0 >= r1) return;  // G == 64: only wave-level syncs follow; G > 64: the whole block leaves together
   const double inv_nn = 1.0 / ((double)fs.n * (double)fs.n);
-  double acc[KPT];
+  const int nh = n2 / 2;  // a thread owns wavenumbers k = tid + G i <= nh and their mirrors n2 - k
+  double acc[KPT], accm[KPT];
 #pragma unroll
-  for (int i = 0; i < KPT; ++i) acc[i] = 0.0;
+  for (int i = 0; i < KPT; ++i) acc[i] = accm[i] = 0.0;
   int32_t cur = group[r0];
   auto flush = [&](int32_t next) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = tid + G * i;
-      if (k < nk) unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc[i]);
-      acc[i] = 0.0;
+      if (k <= nh) {
+        unsafeAtomicAdd(&power[(int64_t)cur * nk + k], k == 0 ? acc[i] : 2.0 * acc[i]);
+        if (n2 - k != k) unsafeAtomicAdd(&power[(int64_t)cur * nk + n2 - k], 2.0 * accm[i]);
+      }
+      acc[i] = accm[i] = 0.0;
     }
     cur = next;
   };
+  constexpr int RP = R0 > 0 ? R0 : 1;
+  v2 pa[RP], pb[RP];  // prefetched inputs of this thread's first-pass butterfly (rows A and B)
+  const int nb0 = R0 > 0 ? n2 / RP : 0;
+  auto fetch = [&](int64_t r) {
+    const bool two = r + 1 < r1;
+    const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
+    const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
+    const int j = tid < nb0 ? tid : nb0 - 1;  // idle threads re-read a valid point: no branch around the loads
+#pragma unroll
+    for (int t = 0; t < RP; ++t) {
+      pa[t] = __builtin_nontemporal_load(rowa + j + t * nb0);
+      pb[t] = __builtin_nontemporal_load(rowb + j + t * nb0);
+    }
+  };
+  if constexpr (R0 > 0) fetch(r0);
   for (int64_t r = r0; r < r1; r += 2) {
     const bool two = r + 1 < r1;  // team-uniform; a missing second row is a row of zeros with scale 0
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
     const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
-    for (int j = tid; j < n2; j += G) {
-      const v2 a = __builtin_nontemporal_load(rowa + j);
-      const v2 b = two ? __builtin_nontemporal_load(rowb + j) : (v2){0.f, 0.f};
-      buf[j] = (v4){a.x, b.x, a.y, b.y};
+    int ns = n2 / fs.radix[0];
+    if constexpr (R0 > 0) {
+      C2 v[RP];
+#pragma unroll
+      for (int t = 0; t < RP; ++t) v[t] = {{pa[t].x, two ? pb[t].x : 0.f}, {pa[t].y, two ? pb[t].y : 0.f}};
+      if (r + 2 < r1) fetch(r + 2);
+      if (tid < nb0) {
+        butterfly<RP>(v);
+        if (ns > 1) {  // ns == nb0, k == tid, twiddle step n2 / (ns R0) == 1
+          int ti = tid;
+#pragma unroll
+          for (int t = 1; t < RP; ++t) {
+            v[t] = ctw(v[t], tw_pass[ti]);
+            ti += tid;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < RP; ++t) st_c2(buf + tid + t * nb0, v[t]);
+      }
+      team_sync<G>();
+    } else {
+      team_pass_radix<G, true>(fs.radix[0], buf, tw_pass, n2, ns, tid, rowa, rowb, two);
     }
-    team_sync<G>();
-    int ns = 1;
-    for (int p = 0; p < fs.npass; ++p) {
-      const int rdx = fs.radix[p];
-      const float inv_ns = 1.0f / (float)ns;
-      if (rdx == 4)
-        team_pass_any<4, G>(buf, tw_pass, n2, ns, inv_ns, tid);
-      else if (rdx == 2)
-        team_pass_any<2, G>(buf, tw_pass, n2, ns, inv_ns, tid);
-      else if (rdx == 3)
-        team_pass_any<3, G>(buf, tw_pass, n2, ns, inv_ns, tid);
-      else
-        team_pass_any<5, G>(buf, tw_pass, n2, ns, inv_ns, tid);
-      ns *= rdx;
+    for (int p = 1; p < fs.npass; ++p) {
+      ns /= fs.radix[p];
+      team_pass_radix<G, false>(fs.radix[p], buf, tw_pass, n2, ns, tid, rowa, rowb, two);
     }
-    // Hermitian unpack of the half-length transform Z: X_k = E_k + exp(-2 pi i k / n) O_k with
-    // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0)
+    // Hermitian unpack of the half-length transform Z: X_k = E_k + W^k O_k with W = exp(-2 pi i / n),
+    // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0).  The mirrored
+    // coefficient comes from the same two points: X_{n2-k} = conj(E_k - W^k O_k), so a thread takes k <= n2 / 2 and
+    // n2 - k together (half the LDS reads and twiddle products).  |X|^2 in packed fp32 (the transform itself is fp32),
+    // widened once per row for the fp64 sums; the factor 2 of k > 0 is applied when the sums are flushed.
     const double sca = scale[r] * inv_nn, scb = two ? scale[r + 1] * inv_nn : 0.0;
     if (ga != cur) flush(ga);  // team-uniform
     const bool split = gb != ga;  // the pair straddles a group boundary (rare): row B goes out through its own atomics
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = tid + G * i;
-      if (k < nk) {
-        const C2 zk = ld_c2(buf + (k == n2 ? 0 : k));
-        const C2 zc = ld_c2(buf + (k == 0 ? 0 : n2 - k));
+      if (k <= nh) {
+        const int km = n2 - k;
+        const C2 zk = ld_c2(buf + k);
+        const C2 zc = ld_c2(buf + (k == 0 ? 0 : km));
         const C2 e = {(zk.re + zc.re) * 0.5f, (zk.im - zc.im) * 0.5f};
         const C2 o = {(zk.im + zc.im) * 0.5f, (zc.re - zk.re) * 0.5f};
-        const C2 x = cadd(e, ctw(o, tw_real[k]));
-        const double dbl = k == 0 ? 1.0 : 2.0;
-        const double pa = ((double)x.re.x * (double)x.re.x + (double)x.im.x * (double)x.im.x) * dbl * sca;
-        const double pb = ((double)x.re.y * (double)x.re.y + (double)x.im.y * (double)x.im.y) * dbl * scb;
+        const C2 wo = ctw(o, tw_real[k]);
+        const C2 x = cadd(e, wo), xm = csub(e, wo);
+        const v2 p = x.re * x.re + x.im * x.im, pm = xm.re * xm.re + xm.im * xm.im;  // (row A, row B)
+        const bool mirror = km != k;
         if (split) {
-          acc[i] += pa;
-          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], pb);
+          acc[i] = fma((double)p.x, sca, acc[i]);
+          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], (double)p.y * scb * (k == 0 ? 1.0 : 2.0));
+          if (mirror) {
+            accm[i] = fma((double)pm.x, sca, accm[i]);
+            unsafeAtomicAdd(&power[(int64_t)gb * nk + km], (double)pm.y * scb * 2.0);
+          }
         } else {
-          acc[i] += pa + pb;
+          acc[i] = fma((double)p.x, sca, fma((double)p.y, scb, acc[i]));
+          if (mirror) accm[i] = fma((double)pm.x, sca, fma((double)pm.y, scb, accm[i]));
         }
       }
     }
@@ -393,32 +469,49 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
   WBX_REQUIRE(G == 64 || G == 128 || G == 256, "WBX_SPECTRUM_TEAM must be 64, 128 or 256");
   const int nteam = G == 64 ? 4 : 1;
   const size_t lds = (size_t)(n2 + nk + (nk & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
-  // a team sweeps a contiguous run of rows (one group for most of it)
-  int64_t teams = (int64_t)256 * 4 * 8 * 64 / G;
-  if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;
-  int rows_per_team = (int)((nrows + teams - 1) / teams);
-  rows_per_team += rows_per_team & 1;  // whole pairs
-  teams = (nrows + rows_per_team - 1) / rows_per_team;
-  const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
-  const int kpt = (nk + G - 1) / G;
-#define WBX_LAUNCH_FUSED(KPT, GG)                                                                                   \
+  const int kpt = (n2 / 2 + 1 + G - 1) / G;
+  int rounds = 3;  // a few sets of blocks per resident slot: the last set's imbalance is a fraction of one set
+  if (const char* e = getenv("WBX_SPECTRUM_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : 1;
+  // A team sweeps a contiguous run of rows (one group for most of it).  Blocks all take the same time, so the grid is a
+  // whole number of resident sets (blocks per CU from the occupancy query: LDS and VGPRs both limit it): 2048 blocks on
+  // 1280 resident slots ran as 1.6 rounds, the last one 60 % empty.
+#define WBX_LAUNCH_FUSED_R(KPT, GG, RR)                                                                                 \
   do {                                                                                                              \
-    if (lds > 48 * 1024)                                                                                            \
-      WBX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG>),                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-    hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
+    const void* fn = reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG, RR>);                               \
+    if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    int per_cu = 0;                                                                                                 \
+    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GG == 64 ? 256 : GG, lds));                   \
+    int64_t teams = (int64_t)(per_cu > 0 ? per_cu : 1) * ctx->num_cus * nteam * rounds;                             \
+    if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;                                                           \
+    int rows_per_team = (int)((nrows + teams - 1) / teams);                                                         \
+    rows_per_team += rows_per_team & 1; /* whole pairs */                                                           \
+    teams = (nrows + rows_per_team - 1) / rows_per_team;                                                            \
+    const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);                                                \
+    hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG, RR>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
                        nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, power_out);                        \
   } while (0)
+#define WBX_LAUNCH_FUSED(KPT, GG) WBX_LAUNCH_FUSED_R(KPT, GG, 0)
+#define WBX_LAUNCH_FUSED_256(KPT)                                  \
+  do {                                                             \
+    if (!prefetch) WBX_LAUNCH_FUSED_R(KPT, 256, 0);                \
+    else if (fs.radix[0] == 4) WBX_LAUNCH_FUSED_R(KPT, 256, 4);    \
+    else if (fs.radix[0] == 2) WBX_LAUNCH_FUSED_R(KPT, 256, 2);    \
+    else if (fs.radix[0] == 5) WBX_LAUNCH_FUSED_R(KPT, 256, 5);    \
+    else WBX_LAUNCH_FUSED_R(KPT, 256, 3);                          \
+  } while (0)
+  static const bool prefetch = getenv("WBX_SPECTRUM_PREFETCH") == nullptr || atoi(getenv("WBX_SPECTRUM_PREFETCH")) != 0;
   if (G == 256) {
-    if (kpt <= 3) WBX_LAUNCH_FUSED(3, 256); else WBX_LAUNCH_FUSED(5, 256);
+    if (kpt <= 2) WBX_LAUNCH_FUSED_256(2); else WBX_LAUNCH_FUSED_256(3);
   } else if (G == 128) {
-    if (kpt <= 6) WBX_LAUNCH_FUSED(6, 128); else WBX_LAUNCH_FUSED(9, 128);
+    if (kpt <= 3) WBX_LAUNCH_FUSED(3, 128); else WBX_LAUNCH_FUSED(5, 128);
   } else {
-    if (kpt <= 4) WBX_LAUNCH_FUSED(4, 64);
-    else if (kpt <= 8) WBX_LAUNCH_FUSED(8, 64);
-    else if (kpt <= 12) WBX_LAUNCH_FUSED(12, 64);
-    else WBX_LAUNCH_FUSED(17, 64);
+    if (kpt <= 2) WBX_LAUNCH_FUSED(2, 64);
+    else if (kpt <= 4) WBX_LAUNCH_FUSED(4, 64);
+    else if (kpt <= 6) WBX_LAUNCH_FUSED(6, 64);
+    else WBX_LAUNCH_FUSED(9, 64);
   }
+#undef WBX_LAUNCH_FUSED_256
+#undef WBX_LAUNCH_FUSED_R
 #undef WBX_LAUNCH_FUSED
   WBX_HIP(hipGetLastError());
   return 0;
