@@ -108,3 +108,24 @@ def test_latitude_band_bins_and_longitude_dependent_masks(backend):
   vals = f.values.astype(np.float64)
   np.testing.assert_allclose(st.sum_weighted_statistics.values,
                              (vals ** 2).mean(axis=-1) + 0.5 * stat['v'].values[..., -1], rtol=1e-4)
+
+
+def test_spectra_under_deferred_results(backend):
+  """engine.deferred_results(): the spectrum read-back is enqueued like every other result; a state launched for
+  chunk k + 1 before chunk k is looked at still yields chunk k's numbers (own page-locked block per read-back)."""
+  from weatherbenchx_amd import engine
+  rng = np.random.default_rng(5)
+  lat, lon = np.linspace(-80, 80, 9), np.arange(48) * 7.5
+  dims = ('lead_time', 'latitude', 'longitude')
+  fields = [_field(rng.normal(size=(3, 9, 48)).astype(np.float32), dims, lat=lat, lon=lon) for _ in range(3)]
+  metrics = {'spec': spectra.ZonalPowerSpectrum()}
+  agg = aggregation.Aggregator(reduce_dims=['lead_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+  def launch(f):
+    return agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': f}, {'v': f}))
+  want = [launch(f).metric_values(metrics)['spec.v'].values.copy() for f in fields]
+  with engine.deferred_results():
+    states = [launch(f) for f in fields]  # all launched before any is read
+    got = [s.metric_values(metrics)['spec.v'].values.copy() for s in states]
+  for g, w in zip(got, want):
+    np.testing.assert_allclose(g, w, rtol=1e-10)  # fp64 atomics: the order of the adds differs from run to run

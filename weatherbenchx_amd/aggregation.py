@@ -402,25 +402,38 @@ class Aggregator:
     bins = [dict(zip(bin_dims, idx)) for idx in np.ndindex(*[w.sizes[b] for b in bin_dims])] if bin_dims else [{}]
     vals, cnts = [], []
     sizes = {d: stat.sizes[d] for d in row_dims}
+    if len(bins) > 1 and engine.deferred_active() is not None:  # the per-bin results are stacked on the host right away
+      with engine.synchronous_results():
+        return self._reduce_spectrum(stat, w_da, bin_dims)
     for sel in bins:
       wb = w.isel(sel) if sel else w
       arr, dims = stat.reduce_rows(wb, kept)
       vals.append(arr)
-      full = np.broadcast_to(xr._bcast_data(wb.astype(np.float64), row_dims, sizes), [sizes[d] for d in row_dims])  # pylint: disable=protected-access
-      c = full.sum(axis=tuple(i for i, d in enumerate(row_dims) if d not in kept))
+      # sum of the row weights per kept row: data independent, kept with the weight object like the device tables
+      ckey = (tuple(row_dims), tuple(sizes[d] for d in row_dims), tuple(kept))
+      cstore = wb.__dict__.setdefault('_wbx_spectrum_counts', {})
+      c = cstore.get(ckey)
+      if c is None:
+        full = np.broadcast_to(xr._bcast_data(wb.astype(np.float64), row_dims, sizes), [sizes[d] for d in row_dims])  # pylint: disable=protected-access
+        c = full.sum(axis=tuple(i for i, d in enumerate(row_dims) if d not in kept))
+        if len(cstore) > 8:
+          cstore.clear()
+        cstore[ckey] = c
       cnts.append(np.broadcast_to(c[..., None], arr.shape))
     out_dims = tuple(dims) + tuple(bin_dims)
     bshape = [w.sizes[b] for b in bin_dims]
-    v = np.stack(vals, axis=-1).reshape(list(vals[0].shape) + bshape)
+    if len(vals) == 1:  # a view: under deferred_results() the numbers arrive when the state's fence is waited on
+      v = vals[0].reshape(list(vals[0].shape) + bshape)
+    else:
+      v = np.stack(vals, axis=-1).reshape(list(vals[0].shape) + bshape)
     c = np.stack(cnts, axis=-1).reshape(list(vals[0].shape) + bshape)
     coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(out_dims)}  # pylint: disable=protected-access
     if w_da is not None:
       for k, x in w_da._coords.items():  # pylint: disable=protected-access
         if set(x[0]) <= set(out_dims):
           coords.setdefault(k, x)
-    mk = lambda a: xr.DataArray(np.array(a, dtype=np.float64), dims=out_dims, coords=coords, name=stat.name,
-                                _raw_coords=True)
-    return AggregationState(mk(v), mk(c))
+    mk = lambda a: xr.DataArray(a, dims=out_dims, coords=coords, name=stat.name, _raw_coords=True)
+    return AggregationState(mk(np.asarray(v, dtype=np.float64)), mk(np.array(c, dtype=np.float64)))
 
   def _reduce_materialised(self, stat: xr.DataArray, w_da, bin_dims, use_mask, skipna):
     """Any DataArray (user-defined statistics, numpy or torch payload): the PASS1 family."""

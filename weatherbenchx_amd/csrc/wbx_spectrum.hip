@@ -27,6 +27,7 @@ struct FftState {
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, FftPlan> plans;  // (nlon, lon_stride, row_stride, batch)
   void* scratch = nullptr;  // complex tile
   std::map<int, void*> twiddles;  // nlon -> device float2[n/2] + float2[n/2 + 1] of the fused path
+  std::map<std::pair<const void*, size_t>, int> occupancy;  // (fused kernel, dynamic LDS bytes) -> resident blocks per CU
   size_t scratch_size = 0;
   bool setup = false;
 };
@@ -289,7 +290,7 @@ __device__ __forceinline__ void team_pass_radix(int rdx, v4* buf, const float2* 
     team_pass_any<5, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
 }
 
-// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2.  KPT >= ceil((n2 / 2 + 1) / G).
+// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2 / 2 (only those are copied to the LDS).  KPT >= ceil((n2 / 2 + 1) / G).
 // G = 64: a block is 4 independent one-wave teams sharing the twiddle tables; G = 128 / 256: the block IS the team
 // (its __syncthreads are team barriers), sweeping its own run of row pairs.
 // R0 > 0 (G == 256 only: one first-pass butterfly per thread): the first pass has radix R0 and its inputs -- the raw
@@ -311,9 +312,10 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
   // lgkmcnt, which do not drain the vector-memory counter the prefetched rows are in flight on
   const int tid = G == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   const int team = G == 64 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  v4* buf = reinterpret_cast<v4*>(tw_real + nk + (nk & 1)) + (int64_t)team * n2;
+  const int ntr = n2 / 2 + 1;  // the mirrored unpack needs k <= n2 / 2 only
+  v4* buf = reinterpret_cast<v4*>(tw_real + ntr + (ntr & 1)) + (int64_t)team * n2;
   for (int i = threadIdx.x; i < n2; i += blockDim.x) tw_pass[i] = tw_pass_g[i];
-  for (int i = threadIdx.x; i < nk; i += blockDim.x) tw_real[i] = tw_real_g[i];
+  for (int i = threadIdx.x; i < ntr; i += blockDim.x) tw_real[i] = tw_real_g[i];
   __syncthreads();
   const int64_t w = (int64_t)blockIdx.x * NTEAM + team;
   const int64_t r0 = w * rows_per_team;
@@ -442,9 +444,7 @@ static bool fused_factor(int n, FusedSpec& fs) {
 // Launches zspec_fused_kernel over `nrows` contiguous rows (row r at field + r * row_stride, unit longitude stride).
 static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const float* field, int64_t row_stride,
                         int64_t nrows, const int32_t* group, const double* scale, double* power_out) {
-  const int nlon = fs.n, nk = fs.n2 + 1;
-  (void)nlon;
-  const int n2 = fs.n2;
+  const int nlon = fs.n, n2 = fs.n2;
   void*& tw = st->twiddles[nlon];
   if (!tw) {
     std::vector<float2> host((size_t)n2 + n2 + 1);
@@ -468,7 +468,8 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
   if (const char* e = getenv("WBX_SPECTRUM_TEAM")) G = atoi(e);  // tests drive every team size
   WBX_REQUIRE(G == 64 || G == 128 || G == 256, "WBX_SPECTRUM_TEAM must be 64, 128 or 256");
   const int nteam = G == 64 ? 4 : 1;
-  const size_t lds = (size_t)(n2 + nk + (nk & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
+  const int ntr = n2 / 2 + 1;
+  const size_t lds = (size_t)(n2 + ntr + (ntr & 1) + 2 * nteam * n2) * sizeof(float2);  // tables + one row PAIR per team
   const int kpt = (n2 / 2 + 1 + G - 1) / G;
   int rounds = 3;  // a few sets of blocks per resident slot: the last set's imbalance is a fraction of one set
   if (const char* e = getenv("WBX_SPECTRUM_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : 1;
@@ -478,10 +479,14 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
 #define WBX_LAUNCH_FUSED_R(KPT, GG, RR)                                                                                 \
   do {                                                                                                              \
     const void* fn = reinterpret_cast<const void*>(&zspec_fused_kernel<KPT, GG, RR>);                               \
-    if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-    int per_cu = 0;                                                                                                 \
-    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GG == 64 ? 256 : GG, lds));                   \
-    int64_t teams = (int64_t)(per_cu > 0 ? per_cu : 1) * ctx->num_cus * nteam * rounds;                             \
+    int& per_cu = st->occupancy[std::make_pair(fn, lds)]; /* queried once per (kernel, LDS size) */                 \
+    if (per_cu == 0) {                                                                                              \
+      if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+      WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GG == 64 ? 256 : GG, lds));                 \
+      if (per_cu <= 0) per_cu = 1;                                                                                  \
+    }                                                                                                               \
+    if (getenv("WBX_SPECTRUM_DEBUG")) fprintf(stderr, "zspec: G=%d lds=%zu blocks/CU=%d\n", GG, lds, per_cu);             \
+    int64_t teams = (int64_t)per_cu * ctx->num_cus * nteam * rounds;                                                \
     if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;                                                           \
     int rows_per_team = (int)((nrows + teams - 1) / teams);                                                         \
     rows_per_team += rows_per_team & 1; /* whole pairs */                                                           \

@@ -372,6 +372,18 @@ def deferred_active() -> DeferredResults | None:
   return _deferred
 
 
+@contextlib.contextmanager
+def synchronous_results():
+  """Inside an enclosing `deferred_results()` block: read-backs issued here are complete when the call returns (for
+  callers that post-process the numbers on the host right away)."""
+  global _deferred
+  saved, _deferred = _deferred, None
+  try:
+    yield
+  finally:
+    _deferred = saved
+
+
 def _download(ctx, ptr: int, shape) -> np.ndarray:
   if _deferred is not None:
     _deferred.ctxs[id(ctx)] = ctx

@@ -101,7 +101,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
                                               int(geo.batch), int(offs.size), offs.ctypes.data_as(C.c_void_p), int(nlon),
                                               C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr), int(ngroup), 0,
                                               C.c_void_p(out.ptr)), 'wbx_zonal_spectrum_slabs')
-  return ctx.download(out.ptr, (ngroup, nk), np.float64)
+  return engine._download(ctx, out.ptr, (ngroup, nk))  # pylint: disable=protected-access
 
 
 class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
@@ -170,7 +170,8 @@ class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
   def data(self):
     if self._data is None:
       row_dims = [d for d in self._source.dims if d != self._lon_dim]
-      arr, dims = self.reduce_rows(xr.DataArray(np.float64(1.0)), row_dims)
+      with engine.synchronous_results():
+        arr, dims = self.reduce_rows(xr.DataArray(np.float64(1.0)), row_dims)
       self._data = np.transpose(arr, [dims.index(d) for d in self._dims])
     return self._data
 
