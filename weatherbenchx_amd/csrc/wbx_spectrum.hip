@@ -132,6 +132,10 @@ __global__ void __launch_bounds__(256) power_kernel(const float2* __restrict__ F
 struct FusedSpec {
   int n, n2, npass;
   int radix[16];
+  // per pass, worked out on the host (the device has no integer divide: each n2 / (ns R) or ns / R in the pass loop was a
+  // ~30-instruction sequence, as much as the butterfly itself): input stride, twiddle step n2 / (ns R), 1 / ns
+  int ns[16], tstep[16];
+  float inv_ns[16];
 };
 
 // A wave transforms TWO rows at once: every quantity is a pair (row A, row B) in one 64-bit register pair, so the
@@ -210,11 +214,10 @@ __device__ __forceinline__ void team_sync() {
 // FIRST (ns == nb): the inputs k + t * nb are taken straight from the two rows in global memory (coalesced), the raw
 // rows never visit the LDS.  All LDS reads precede all writes.
 template <int R, int NB, int G, bool FIRST>
-__device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns,
+__device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns, int tstep,
                                           float inv_ns, int tid, const v2* __restrict__ rowa,
                                           const v2* __restrict__ rowb, bool two) {
-  const int nb = n2 / R;
-  const int tstep = n2 / (ns * R);  // exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
+  const int nb = n2 / R;  // tstep = n2 / (ns R): exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
   C2 v[NB][R];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -261,33 +264,34 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
 }
 
 template <int R, int G, bool FIRST>
-__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, float inv_ns, int tid,
+__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, int tstep, float inv_ns, int tid,
                                               const v2* rowa, const v2* rowb, bool two) {
   // fused_factor() admits at most 256 butterflies per pass
   constexpr int NBMAX = 256 / G;
   const int nbl = (n2 / R + G - 1) / G;  // butterflies per thread
   if constexpr (NBMAX >= 4) {
-    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
-    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
   }
   if constexpr (NBMAX >= 2) {
-    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
   }
-  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
 }
 
 template <int G, bool FIRST>
-__device__ __forceinline__ void team_pass_radix(int rdx, v4* buf, const float2* tw, int n2, int ns, int tid,
+__device__ __forceinline__ void team_pass_radix(const FusedSpec& fs, int p, v4* buf, const float2* tw, int tid,
                                                 const v2* rowa, const v2* rowb, bool two) {
-  const float inv_ns = 1.0f / (float)ns;
+  const int rdx = fs.radix[p], n2 = fs.n2, ns = fs.ns[p], tstep = fs.tstep[p];
+  const float inv_ns = fs.inv_ns[p];
   if (rdx == 4)
-    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
   else if (rdx == 2)
-    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
   else if (rdx == 3)
-    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
   else
-    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
 }
 
 // tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2 / 2 (only those are copied to the LDS).  KPT >= ceil((n2 / 2 + 1) / G).
@@ -359,7 +363,6 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
     const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
-    int ns = n2 / fs.radix[0];
     if constexpr (R0 > 0) {
       C2 v[RP];
 #pragma unroll
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
       if (r + 2 < r1) fetch(r + 2);
       if (tid < nb0) {
         butterfly<RP>(v);
-        if (ns > 1) {  // ns == nb0, k == tid, twiddle step n2 / (ns R0) == 1
+        if (nb0 > 1) {  // ns == nb0, k == tid, twiddle step n2 / (ns R0) == 1
           int ti = tid;
 #pragma unroll
           for (int t = 1; t < RP; ++t) {
@@ -380,12 +383,9 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
       }
       team_sync<G>();
     } else {
-      team_pass_radix<G, true>(fs.radix[0], buf, tw_pass, n2, ns, tid, rowa, rowb, two);
+      team_pass_radix<G, true>(fs, 0, buf, tw_pass, tid, rowa, rowb, two);
     }
-    for (int p = 1; p < fs.npass; ++p) {
-      ns /= fs.radix[p];
-      team_pass_radix<G, false>(fs.radix[p], buf, tw_pass, n2, ns, tid, rowa, rowb, two);
-    }
+    for (int p = 1; p < fs.npass; ++p) team_pass_radix<G, false>(fs, p, buf, tw_pass, tid, rowa, rowb, two);
     // Hermitian unpack of the half-length transform Z: X_k = E_k + W^k O_k with W = exp(-2 pi i / n),
     // E_k = (Z_k + conj Z_{n2-k}) / 2, O_k = (Z_k - conj Z_{n2-k}) / (2i), k = 0..n2 (Z_{n2} = Z_0).  The mirrored
     // coefficient comes from the same two points: X_{n2-k} = conj(E_k - W^k O_k), so a thread takes k <= n2 / 2 and
@@ -436,8 +436,14 @@ static bool fused_factor(int n, FusedSpec& fs) {
   while (m % 5 == 0) { fs.radix[fs.npass++] = 5; m /= 5; }
   while (m % 3 == 0) { fs.radix[fs.npass++] = 3; m /= 3; }
   if (m != 1 || fs.npass > 16) return false;
-  for (int p = 0; p < fs.npass; ++p)
+  int ns = fs.n2;
+  for (int p = 0; p < fs.npass; ++p) {
     if (fs.n2 / fs.radix[p] > 256) return false;  // a lane keeps <= 4 butterflies of a pass in registers
+    ns /= fs.radix[p];
+    fs.ns[p] = ns;
+    fs.tstep[p] = fs.n2 / (ns * fs.radix[p]);
+    fs.inv_ns[p] = 1.0f / (float)ns;
+  }
   return true;
 }
 
