@@ -147,13 +147,17 @@ inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out
 // and hit by the others.  Without this the 16 B / point of wt + bits miss L2 for every cell and cost as much fabric
 // bandwidth as the data.
 __device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs) {
-  const int64_t per_xcd = (g.nblocks + 7) / 8;
-  int64_t b = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (b >= g.nblocks) return false;
-  cell = b % g.ncell;
-  b /= g.ncell;
-  xt = (int)(b % g.nxt);
-  rs = (int)(b / g.nxt);
+  // 32-bit arithmetic (the launcher checks nblocks < 2^31): a 64-bit divide is a ~100-instruction sequence on this ISA,
+  // and a patch is only a few thousand instructions long
+  const uint32_t nblocks = (uint32_t)g.nblocks, ncell = (uint32_t)g.ncell, nxt = (uint32_t)g.nxt;
+  const uint32_t per_xcd = (nblocks + 7u) >> 3;
+  uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (b >= nblocks) return false;
+  const uint32_t q = b / ncell;
+  cell = (int64_t)(b - q * ncell);
+  const uint32_t q2 = q / nxt;
+  xt = (int)(q - q2 * nxt);
+  rs = (int)q2;
   return true;
 }
 
