@@ -222,9 +222,15 @@ int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, 
  * Statistic, weight and bin membership in ONE pass over p, t, c -- for chunks where little is reduced before the
  * weight/bin-dependent dims, so that the stage-1 partials would be larger than the inputs (the public benchmark's
  * 1 init x 12 lead chunks with 34 region x land/sea bins, run_benchmark_evaluation.py:97-131,369-382).
- * The plan's keys must be ordered [nA][nBk][nBr] (as for wbx_contract); x is summed; `w_on_x` says whether wt / bits
- * are indexed [nBk][nBr][nx] (W depends on x) or [nBk][nBr][1].  out[nA][nBk][lanes_total][nbin], lanes_total and NaN
- * semantics exactly as wbx_det_partial + wbx_contract_bits.  The plan's nchunk / x_kept / vec are ignored. */
+ * The plan's keys must be ordered [nA][nBk][nBr] (as for wbx_contract); x is summed; `w_on_x` (WBX_BINNED_* flags) says
+ * whether wt / bits are indexed [nBk][nBr][nx] (WBX_BINNED_W_ON_X: W depends on x) or [nBk][nBr][1], and whether the
+ * weights come factored: WBX_BINNED_WT_X_ONLY -> wt[nBk][nx] (GridAreaWeighting, weighting.py:62-130, on
+ * latitude-fastest chunks), WBX_BINNED_WT_ROW_ONLY -> wt[nBk][nBr] (the same on longitude-fastest chunks); `bits` keeps
+ * its full index either way.  out[nA][nBk][lanes_total][nbin], lanes_total and NaN semantics exactly as
+ * wbx_det_partial + wbx_contract_bits.  The plan's nchunk / x_kept / vec are ignored. */
+#define WBX_BINNED_W_ON_X 1
+#define WBX_BINNED_WT_X_ONLY 2
+#define WBX_BINNED_WT_ROW_ONLY 4
 int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
                    const void* c, const uint8_t* mask, const double* wt, const uint64_t* bits, int64_t nA,
                    int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, double* out);

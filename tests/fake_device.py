@@ -171,6 +171,11 @@ def _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf):
         lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
     assert len(lanes) == nl_total
     wt = np.asarray(w_buf.bufs[0].ptr).reshape(nBk, nBr, nj)
+    if w_buf.factored is not None and engine.SEPARABLE_BINNED_WEIGHTS:  # the factored form the kernel would be handed
+      flag, buf = w_buf.factored
+      fac = np.asarray(buf.ptr)
+      wt = np.broadcast_to(fac.reshape(nBk, 1, nj) if flag == _hip.BINNED_WT_X_ONLY else fac.reshape(nBk, nBr, 1),
+                           (nBk, nBr, nj))
     bits = np.asarray(w_buf.bufs[1].ptr).reshape(nBk, nBr, nj)
     member = ((bits[..., None] >> np.arange(nbin, dtype=np.uint64)) & np.uint64(1)).astype(np.float64)
     out = np.empty((nA, nBk, nl_total, 1, nbin))

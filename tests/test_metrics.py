@@ -462,6 +462,46 @@ def test_fused_binned_kernel_equals_two_stage_path(backend, monkeypatch, layout,
     assert np.isfinite(results['always']['rmse.z'].values).all()  # NaN targets are masked / skipped, not propagated
 
 
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('weights', ['area', 'area_x_level', 'none'])
+def test_binned_kernel_factored_weights(backend, monkeypatch, layout, weights):
+  """wbx_det_binned takes weights that depend on x only (latitude weights on latitude-fastest data) or on the rows only
+  (longitude-fastest) in factored form, WBX_BINNED_WT_X_ONLY / WBX_BINNED_WT_ROW_ONLY; weights that also depend on a
+  kept dim stay separable per (kept) cell; the dense operand must give the same sums."""
+  from weatherbenchx_amd import _hip, engine
+  rng = np.random.default_rng(11)
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  dims = ('lead_time', 'level') + sp
+  sizes = {'lead_time': 2, 'level': 3, 'latitude': 32, 'longitude': 64}
+  coords = {'lead_time': np.arange(2) * np.timedelta64(6, 'h'), 'level': [300, 500, 850], 'latitude': LAT, 'longitude': LON}
+  shape = tuple(sizes[d] for d in dims)
+  p = xr.DataArray(rng.normal(size=shape).astype(np.float32), dims=dims, coords=coords)
+  t = xr.DataArray(rng.normal(size=shape).astype(np.float32), dims=dims, coords=coords)
+  lsm = xr.DataArray(rng.random((32, 64)) > 0.5, dims=('latitude', 'longitude'), coords={'latitude': LAT, 'longitude': LON})
+
+  class LevelWeights(weighting.Weighting):
+    def weights(self, statistic):
+      return xr.DataArray(np.array([1.0, 2.0, 0.5]), dims=('level',), coords={'level': [300, 500, 850]})
+  wby = {'area': [weighting.GridAreaWeighting()], 'area_x_level': [weighting.GridAreaWeighting(), LevelWeights()],
+         'none': []}[weights]
+  monkeypatch.setattr(engine, 'BINNED_MODE', 'always')
+  out, flags = {}, {}
+  for sep in (True, False):
+    monkeypatch.setattr(engine, 'SEPARABLE_BINNED_WEIGHTS', sep)
+    engine.clear_caches()
+    monkeypatch.setattr(engine, 'S1_EVENT_LOG', [])
+    agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=wby,
+                                 bin_by=[binning.Regions(MANY_REGIONS, land_sea_mask=lsm)])
+    out[sep] = aggregation.compute_metric_values_for_single_chunk({'rmse': deterministic.RMSE()}, agg, {'z': p}, {'z': t})
+    flags[sep] = {e.get('w_flags') for e in engine.S1_EVENT_LOG if e['kind'] == 'det_binned'}
+    monkeypatch.setattr(engine, 'S1_EVENT_LOG', None)
+  np.testing.assert_allclose(out[True]['rmse.z'].values, out[False]['rmse.z'].values, rtol=1e-12)
+  if backend != 'emulated':  # the NumPy plan interpreter does not keep an event log
+    assert flags[False] == {_hip.BINNED_W_ON_X}
+    want = _hip.BINNED_WT_X_ONLY if (layout == 'lat_fastest' or weights == 'none') else _hip.BINNED_WT_ROW_ONLY
+    assert flags[True] == {_hip.BINNED_W_ON_X | want}
+
+
 @pytest.mark.parametrize('m,fair', list(itertools.product([4, 5], [True, False])))
 def test_crps_with_nan_member_equals_dropping_it(backend, m, fair):
   # metrics_test.py:1199-1274: skipna_ensemble=True with one all-NaN member == the ensemble without that member

@@ -19,3 +19,17 @@ for f in sorted(glob.glob('$OUT/*/*counter_collection.csv')):
     if 'binned_kernel' in k:
       print(k, {n: (len(v), sum(v) / len(v)) for n, v in c.items()})
 PY
+# memory-side counters (their own pass): texture-address / data busy, L2 hit rate, stalls
+cd /tmp
+timeout 200 rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE --kernel-trace -d $OUT/d -o pmc --output-format csv -- python $REPO/tools/kbench_binned.py $LAYOUT 3 > $OUT/d.log 2>&1
+python - <<PY
+import csv, collections, glob
+for f in sorted(glob.glob('$OUT/d/*counter_collection.csv')):
+  agg = collections.defaultdict(lambda: collections.defaultdict(list))
+  for row in csv.DictReader(open(f)):
+    agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
+  for k, c in agg.items():
+    if 'binned_kernel' in k:
+      print(k, {n: (len(v), sum(v) / len(v)) for n, v in c.items()})
+PY
+tail -3 $OUT/d.log

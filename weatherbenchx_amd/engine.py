@@ -144,9 +144,11 @@ class _WOnDevice:
 
   def __init__(self, kind, bufs, shape, bin_shape):
     self.kind, self.bufs, self.shape, self.bin_shape = kind, bufs, shape, bin_shape
+    self.factored = None  # (WBX_BINNED_WT_* flag, device buffer) when the weights of a 'bits' operand separate
 
 
 BITS_MIN_BINS = 5  # below this the dense contraction is just as cheap
+SEPARABLE_BINNED_WEIGHTS = True  # False: always hand wbx_det_binned the dense wt[nBk][nBr][nj] (A/B timing and tests)
 
 
 def pack_bits(plan: planner.S1Plan, weights, masks, bin_dims):
@@ -191,6 +193,12 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
     if factors is not None and BITS_MIN_BINS <= nbin <= 64:
       wt, bits, shape4, bin_shape = pack_bits(plan, factors[0], factors[1], bin_dims)
       store[sig] = _WOnDevice('bits', (ctx.upload(wt), ctx.upload(bits)), shape4, bin_shape)
+      # weights that depend on x only / on the rows only (GridAreaWeighting on latitude- / longitude-fastest data):
+      # wbx_det_binned then keeps them in a register / resolves them per row instead of loading 8 bytes per point
+      if SEPARABLE_BINNED_WEIGHTS and wt.shape[2] > 1 and np.array_equal(wt, np.broadcast_to(wt[:, :1, :], wt.shape)):
+        store[sig].factored = (_hip.BINNED_WT_X_ONLY, ctx.upload(np.ascontiguousarray(wt[:, 0, :])))
+      elif SEPARABLE_BINNED_WEIGHTS and np.array_equal(wt, np.broadcast_to(wt[:, :, :1], wt.shape)):
+        store[sig].factored = (_hip.BINNED_WT_ROW_ONLY, ctx.upload(np.ascontiguousarray(wt[:, :, 0])))
     else:
       w, bin_shape = dense_w(plan, w_da, bin_dims)
       store[sig] = _WOnDevice('dense', (ctx.upload(w),), w.shape, bin_shape)
@@ -435,17 +443,23 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   shape = (nA, nBk, nl_total, 1, nbin)
   out = _scratch(ctx, 's2out', int(np.prod(shape, dtype=np.int64)) * 8)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  w_flags = _hip.BINNED_W_ON_X if (plan.x_kept and plan.nj > 1) else 0
+  wt_buf = w_buf.bufs[0]
+  if w_buf.factored is not None and SEPARABLE_BINNED_WEIGHTS:
+    w_flags |= w_buf.factored[0]
+    wt_buf = w_buf.factored[1]
   reps = 1
   if S1_EVENT_LOG is not None:
     reps = max(1, int(S1_EVENT_REPEAT))
     ctx.timer_start()
   for _ in range(reps):
     _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
-                                      ptr(devs[2]), ptr(devs[3]), C.c_void_p(w_buf.bufs[0].ptr),
-                                      C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, int(plan.x_kept and plan.nj > 1), nbin,
+                                      ptr(devs[2]), ptr(devs[3]), C.c_void_p(wt_buf.ptr),
+                                      C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags, nbin,
                                       C.c_void_p(out.ptr)), 'wbx_det_binned')
   if S1_EVENT_LOG is not None:
-    S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin})
+    S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin,
+                         'w_flags': w_flags})
   return _download(ctx, out.ptr, shape)
 
 
