@@ -1,0 +1,69 @@
+"""Turns what tools/profile_round.sh brings back (gpurun_out/prof/) into the tracked files of one round:
+  rNN_bench_n1.json, rNN_bench_n1_lat_fastest.json   the bench lines, no profiler attached
+  rNN_rocprofv3_summary.txt                          per-run kernel tables (rocprofv3 --kernel-trace) + counter tables
+  rNN_kernel_stats.csv                               the kernel-trace tables as one CSV (run, kernel, calls, ...)
+  rNN_pmc_traffic.json                               HBM bytes per launch per kernel (FETCH_SIZE x2 + WRITE_SIZE), keyed
+                                                     by the names bench.py uses for its roofline entries
+usage: python profiles/make_round_files.py gpurun_out/prof r01"""
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+out = lambda name: os.path.join(here, f'{tag}_{name}')
+shutil.copy(os.path.join(src, 'bench_n1.json'), out('bench_n1.json'))
+shutil.copy(os.path.join(src, 'bench_n1_lat_fastest.json'), out('bench_n1_lat_fastest.json'))
+text = open(os.path.join(src, 'summary.txt')).read()
+text = re.sub(r'== \S*/prof/', '== ', text)  # scratch path of the GPU box
+open(out('rocprofv3_summary.txt'), 'w').write(text)
+
+rows, run = [], None
+for line in text.split('\n'):
+  if line.startswith('== '):
+    run = line[3:].split('/')[0]
+    continue
+  m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', line)
+  if m and run and run.startswith('trace_'):
+    rows.append([run] + list(m.groups()))
+with open(out('kernel_stats.csv'), 'w', newline='') as f:
+  w = csv.writer(f)
+  w.writerow(['run', 'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct'])
+  w.writerows(rows)
+
+
+def bench_key(name: str) -> str:
+  """rocprofv3's demangled name -> the label bench.py prints (template arguments spelled out)."""
+  n = name.replace('wbx::', '')
+  n = re.sub(r'DetOp<float, 1, \d>', 'DetOp<float,DET6>', n)
+  n = re.sub(r'EnsOpF32<51, true, 0>', 'EnsOpF32<51,true,SORT>', n)
+  m = re.match(r's1_xr_kernel<(.*?), (\d), (?:false|true)>', n)
+  if m:
+    return f's1_xr_kernel<{m.group(1)},{m.group(2)}>'
+  m = re.match(r's1_xf_kernel<(.*?) ?>$', n)
+  if m:
+    return f's1_xf_kernel<{m.group(1)}>'
+  m = re.match(r'det_binned_kernel<float, 1, (\d), (\d+), (\d), (\d)>', n)
+  if m:
+    return f'det_binned_kernel<float,DET6,MM={m.group(1)},K={m.group(2)},PD={m.group(3)},WM={m.group(4)}>'
+  m = re.match(r'zspec_fused_kernel<(\d), (\d+), (\d)>', n)
+  if m:
+    return f'zspec_fused_kernel<{m.group(1)},{m.group(2)},{m.group(3)}> (zonal spectrum, n=1440)'
+  return n
+
+
+raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
+traffic = {}
+for name, e in raw.items():
+  if not isinstance(e, dict) or 'hbm_read_bytes' not in e:
+    continue
+  traffic[bench_key(name)] = dict(e, rocprof_name=name)
+traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python '
+                    'bench.py --steps 2 --warmup 1 --no-cpu` (+ --layout lat_fastest, + tools/kbench_binned.py for the '
+                    'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
+                    '(gfx950 reports half of wide coalesced reads)')
+json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
+print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])
