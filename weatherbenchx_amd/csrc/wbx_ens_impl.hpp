@@ -95,9 +95,17 @@ struct EnsOpF32 {
         }
       }
     } else {
+      {  // two members per instruction (v_pk_fma_f32): x * 0 + p is NaN iff x is NaN or +-inf
+        typedef float pk2 __attribute__((ext_vector_type(2)));
+        pk2 pz = {0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < MP; ++m)
-        if (EXACT || m < M) poison = fmaf(xm[m], 0.f, poison);
+        for (int m = 0; m + 1 < MP; m += 2) {
+          const pk2 x2 = {xm[m], (EXACT || m + 1 < M) ? xm[m + 1] : 0.f};
+          if (EXACT || m < M) pz = x2 * (pk2){0.f, 0.f} + pz;
+        }
+        if ((MP & 1) && (EXACT || MP - 1 < M)) pz.x = fmaf(xm[MP - 1], 0.f, pz.x);
+        poison = pz.x + pz.y;
+      }
       SortNet<MP>::sort(
           xm, [](float u, float v) { return fminf(u, v); }, [](float u, float v) { return fmaxf(u, v); });
     }
@@ -117,21 +125,25 @@ struct EnsOpF32 {
         if constexpr (ALGO == WBX_ENS_SORT) dot = fma((double)(2 * (m + 1) - M - 1), e, dot);
       }
     }
+    // M and `fair` are the same for every point of the launch: the three reciprocals are loop invariant (hoisted by the
+    // compiler), and the five fp64 divisions per point (~10 instructions each) become multiplications -- within 1 ulp
+    // of the divisions of the float64 restatement.
     const double dM = (double)M;
     const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
-    const double mean_e = se / dM;
+    const double inv_m = 1.0 / dM, inv_m1 = 1.0 / (dM - 1.0), spread_scale = 2.0 / (dM * (dM - fair));
+    const double mean_e = se * inv_m;
     const double mean_d = x0t + mean_e;                       // mean_m p - t
-    const double var = (sq - se * mean_e) / (dM - 1.0);       // ddof = 1
+    const double var = (sq - se * mean_e) * inv_m1;           // ddof = 1
     double spread;
     if constexpr (ALGO == WBX_ENS_SORT) {
-      spread = 2.0 * dot / (dM * (dM - fair));
+      spread = dot * spread_scale;
     } else {
-      spread = 2.0 * pair_total / (dM * (dM - fair));
+      spread = pair_total * spread_scale;
     }
-    val[0] = sabs / dM;
+    val[0] = sabs * inv_m;
     val[1] = spread;
     val[2] = var;
-    val[3] = mean_d * mean_d - var / dM;
+    val[3] = mean_d * mean_d - var * inv_m;
     val[4] = mean_d * mean_d;
     if constexpr (ALGO == WBX_ENS_SORT) {
       if (poison != poison) {  // reference: a NaN member makes every ensemble statistic NaN
