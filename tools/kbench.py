@@ -11,7 +11,7 @@ from weatherbenchx_amd import _hip, engine, planner
 from weatherbenchx_amd import xarray_lite as xr
 
 ctx = _hip.default_context(0)
-NLAT, NLON = 721, 1440
+NLAT, NLON = int(os.environ.get('KB_NLAT', 721)), 1440
 
 
 def time_s1(kind, plan, devs, nl, reps=20, **kw):

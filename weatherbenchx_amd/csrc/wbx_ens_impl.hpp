@@ -107,7 +107,20 @@ struct EnsOpF32 {
         poison = pz.x + pz.y;
       }
       SortNet<MP>::sort(
-          xm, [](float u, float v) { return fminf(u, v); }, [](float u, float v) { return fmaxf(u, v); });
+          xm,
+          // the bare instructions: fminf / fmaxf make the compiler canonicalise every loaded member first (one extra
+          // v_max_f32 x, x each) to quiet signalling NaNs, which v_min / v_max in IEEE mode do themselves; NaN members
+          // are caught by the probe above, not by the network
+          [](float u, float v) {
+            float r;
+            asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
+            return r;
+          },
+          [](float u, float v) {
+            float r;
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
+            return r;
+          });
     }
 
     // Member-only quantities (spread, variance) are accumulated on e = x - x0 so that they stay finite when the
