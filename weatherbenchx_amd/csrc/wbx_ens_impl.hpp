@@ -123,21 +123,27 @@ struct EnsOpF32 {
           });
     }
 
-    // Member-only quantities (spread, variance) are accumulated on e = x - x0 so that they stay finite when the
-    // target is NaN (the reference's spread / variance never look at the target); x0 = first register member.
+    // Everything is accumulated on e = x - shift (variance and spread are shift invariant).  shift = the target when it
+    // is finite, so |x - t| is |e| itself (one fp64 add per member less than a separate x0 shift); with a NaN / infinite
+    // target the shift falls back to the first register member, so that the member-only quantities (spread, variance)
+    // stay finite -- the reference's spread / variance never look at the target -- and the target's NaN / inf reaches
+    // the skill lanes through x0t below.
     const double x0 = (double)xm[0];
-    const double x0t = x0 - td;  // NaN iff the target is NaN
+    const bool tfin = (td - td) == 0.0;
+    const double shift = tfin ? td : x0;
+    const double x0t = shift - td;  // 0 for a finite target, else NaN / -+inf
     double se = 0.0, sq = 0.0, sabs = 0.0, dot = 0.0;
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
       if (EXACT || m < M) {
-        const double e = (double)xm[m] - x0;
+        const double e = (double)xm[m] - shift;
         se += e;
         sq = fma(e, e, sq);
-        sabs += fabs(e + x0t);
+        sabs += fabs(e);
         if constexpr (ALGO == WBX_ENS_SORT) dot = fma((double)(2 * (m + 1) - M - 1), e, dot);
       }
     }
+    sabs += fabs(x0t);  // mean |x - t| is NaN / inf with the target
     // M and `fair` are the same for every point of the launch: the three reciprocals are loop invariant (hoisted by the
     // compiler), and the five fp64 divisions per point (~10 instructions each) become multiplications -- within 1 ulp
     // of the divisions of the float64 restatement.
