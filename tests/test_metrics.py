@@ -804,8 +804,8 @@ def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
   """Latitude-fastest data + GridAreaWeighting and no bins: the weights depend on the innermost dim only, so the
   deterministic family applies them inside stage 1 (plan.x_weights, flat float4 sweep over the contiguous planes) and
   sums latitude there, also under a validity mask stored like the data; the ensemble family does the same one point per
-  lane (s1_xf1_kernel) when no mask / skipna is active.  skipna keeps latitude for stage 2 (measured faster).  Every
-  route must equal the un-folded one and the oracle."""
+  lane (s1_xf1_kernel), masks and skipna included.  The deterministic family under skipna keeps latitude for stage 2
+  (measured faster).  Every route must equal the un-folded one and the oracle."""
   from weatherbenchx_amd import engine
   rng = np.random.default_rng(33)
   nlat, nlon, m = 91, 24, 5
@@ -839,8 +839,9 @@ def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
     logs[fold] = seen
     monkeypatch.setattr(engine, '_planned', inner)
   used = [pl for pl in logs[True] if pl.x_weights is not None]
-  assert bool(used) == (mode in ('plain', 'masked')) and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
-  assert len({id(pl) for pl in used}) == {'plain': 2, 'masked': 1, 'skipna': 0}[mode]  # deterministic + ensemble plans
+  assert used and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
+  # deterministic + ensemble plans; skipna keeps the deterministic family on the x-kept kernel (measured faster)
+  assert len({id(pl) for pl in used}) == {'plain': 2, 'masked': 2, 'skipna': 1}[mode]
   assert logs[False] and all(pl.x_weights is None and pl.x_kept for pl in logs[False])
   for k, v in results[False].items():
     np.testing.assert_allclose(results[True][k].values, v.values, rtol=1e-9, equal_nan=True)

@@ -224,7 +224,9 @@ template <class Op>
 int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
   if (map) return launch_map<Op>(ctx, plan, a);
   if (plan->x_weights != nullptr) {  // latitude weights folded into stage 1, flat sweep over contiguous planes
-    WBX_REQUIRE(!(plan->flags & ~WBX_FLAG_FAIR), "flat x-weighted mode does not take mask/skipna flags");
+    WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA_ENS), "flat x-weighted mode does not take skipna_ensemble");
+    if (plan->flags & WBX_FLAG_SKIPNA) return launch_flat_weighted1<EnsMasked<Op, true>>(ctx, plan, a);
+    if (plan->flags & WBX_FLAG_MASKED) return launch_flat_weighted1<EnsMasked<Op, false>>(ctx, plan, a);
     return launch_flat_weighted1<Op>(ctx, plan, a);
   }
   if (plan->flags & WBX_FLAG_SKIPNA) return launch_partial<EnsMasked<Op, true>, 1>(ctx, plan, a);

@@ -472,7 +472,7 @@ int launch_flat_weighted(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
 // count; chunks are cut at rows.  grid = nkey * nchunk, block = plan->block_threads.
 template <class Op>
 __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xf1_kernel(S1Args a, int R) {
-  constexpr int NL = Op::NLANE;
+  constexpr int NA = Op::NACC;  // value lanes + the count lanes of the masked / skipna wrappers: all take the weight
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = blockDim.x, nwave = nt >> 6;
   const int nx = (int)a.nx;
   const int64_t b = blockIdx.x;
@@ -484,9 +484,9 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xf1_kernel(S1Args a, in
   __syncthreads();
   int64_t kb[WBX_MAX_INPUTS];
   key_bases<Op::NIN>(a, key, kb);
-  double acc[NL];
+  double acc[NA];
 #pragma unroll
-  for (int l = 0; l < NL; ++l) acc[l] = 0.0;
+  for (int l = 0; l < NA; ++l) acc[l] = 0.0;
   const int step = nt % nx;
   int64_t d = d0;
   while (d < d1) {
@@ -506,27 +506,29 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xf1_kernel(S1Args a, in
       m = m >= nx ? m - nx : m;
     }
     for (; e < e1; e += nt) {
-      double val[NL];
-      Op::values(a, ro, e, val);
+      double one[1][NA];
+#pragma unroll
+      for (int l = 0; l < NA; ++l) one[0][l] = 0.0;
+      Op::template accum<1, false>(a, ro, e, one);
       const double w = wbx_xw_lds[m];
 #pragma unroll
-      for (int l = 0; l < NL; ++l) acc[l] = fma(val[l], w, acc[l]);
+      for (int l = 0; l < NA; ++l) acc[l] = fma(one[0][l], w, acc[l]);
       m += step;
       m = m >= nx ? m - nx : m;
     }
     d += nj;
   }
-  __shared__ double red[4][NL];
+  __shared__ double red[4][NA];
 #pragma unroll
-  for (int l = 0; l < NL; ++l) {
+  for (int l = 0; l < NA; ++l) {
     const double v = wave_sum(acc[l]);
     if (lane == 0) red[wave][l] = v;
   }
   __syncthreads();
-  if (tid < NL) {
+  if (tid < NA) {
     double sum = 0.0;
     for (int w = 0; w < nwave; ++w) sum += red[w][tid];
-    a.out[(key * a.nchunk + chunk) * NL + tid] = sum;
+    a.out[(key * a.nchunk + chunk) * NA + tid] = sum;
   }
 }
 
@@ -536,6 +538,7 @@ int launch_flat_weighted1(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   WBX_REQUIRE(!plan->x_kept && plan->x_weights && R > 0 && plan->nx <= WBX_XW_MAX && plan->ndepth % R == 0,
               "flat x-weighted mode needs x summed, whole planes and nx <= %d", WBX_XW_MAX);
   WBX_REQUIRE(plan->xstride[0] == 1 && plan->xstride[1] == 1, "flat x-weighted mode needs unit x stride");
+  if (plan->flags & WBX_FLAG_MASKED) WBX_REQUIRE(plan->xstride[3] == 1, "flat x-weighted mode needs a mask stored like the data");
   const int64_t grid = plan->nkey * plan->nchunk;
   WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
   hipLaunchKernelGGL((s1_xf1_kernel<Op>), dim3((unsigned)grid), dim3(plan->block_threads), 0, ctx->stream, a, R);

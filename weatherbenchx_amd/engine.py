@@ -523,7 +523,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   # kept as nx partials per key for stage 2.
   x_weights = None
   hit = None
-  fold_ok = (kind == 'det' and not (flags & ~_hip.FLAG_MASKED)) or (kind == 'ens' and not (flags & ~_hip.FLAG_FAIR))
+  fold_ok = (kind == 'det' and not (flags & ~_hip.FLAG_MASKED)) or (kind == 'ens' and not (flags & _hip.FLAG_SKIPNA_ENS))
   if FOLD_X_WEIGHTS and fold_ok and w_da is not None and not bin_dims and len(w_da.dims) == 1:
     x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
     if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:

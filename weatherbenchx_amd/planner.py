@@ -273,10 +273,14 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
 
   if fold_x == 'point':
     # one point per lane (ensemble kernels): the generic chunking stands, rows only have to be one contiguous run
-    if not x_kept and not (flags & ~4) and x_dim is not None and depth_dims and nx <= 2048 and gather is None:
+    if not x_kept and not (flags & ~7) and x_dim is not None and depth_dims and nx <= 2048 and gather is None:
       inner = depth_dims[-1]
-      if all(lay.itemsize == 4 and lay.stride(x_dim) == 1 and lay.stride(inner) == nx
-             for lay in layouts[:2] if lay is not None):
+      ok = all(lay.itemsize == 4 and lay.stride(x_dim) == 1 and lay.stride(inner) == nx
+               for lay in layouts[:2] if lay is not None)
+      if flags & 1:  # the validity mask is walked flat alongside the data: same (inner, x) order
+        mlay = layouts[3] if len(layouts) > 3 else None
+        ok = ok and mlay is not None and mlay.itemsize == 1 and mlay.stride(x_dim) == 1 and mlay.stride(inner) == nx
+      if ok:
         plane_rows, vec = sizes[inner], 1
         # measured on 8 x 51 x 1440 x 721 (threads, rows per block): (64, 1..2) 0.48 ms, (128, 2..4) 0.41-0.43,
         # (256, 4..8) 0.407, (256, 15) 0.415; the x-kept kernel on the same data 0.452, longitude-fastest data 0.397
