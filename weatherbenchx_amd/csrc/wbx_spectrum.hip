@@ -133,8 +133,11 @@ struct FusedSpec {
   int n, n2, npass;
   int radix[16];
   // per pass, worked out on the host (the device has no integer divide: each n2 / (ns R) or ns / R in the pass loop was a
-  // ~30-instruction sequence, as much as the butterfly itself): input stride, twiddle step n2 / (ns R), 1 / ns
-  int ns[16], tstep[16];
+  // ~30-instruction sequence, as much as the butterfly itself): input stride, 1 / ns, and where the pass's twiddles
+  // start in the packed table: exp(-2 pi i k t / (ns R)) sits at toff + (t - 1) ns + k, so the lanes of a wave
+  // (consecutive k) read consecutive entries -- the one shared exp(-2 pi i m / n2) table was read at stride t k n2/(ns R),
+  // an up to 8-way bank conflict per twiddle load.  The passes need n2 - 1 entries in all.
+  int ns[16], toff[16];
   float inv_ns[16];
 };
 
@@ -214,10 +217,10 @@ __device__ __forceinline__ void team_sync() {
 // FIRST (ns == nb): the inputs k + t * nb are taken straight from the two rows in global memory (coalesced), the raw
 // rows never visit the LDS.  All LDS reads precede all writes.
 template <int R, int NB, int G, bool FIRST>
-__device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns, int tstep,
+__device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns, int toff,
                                           float inv_ns, int tid, const v2* __restrict__ rowa,
                                           const v2* __restrict__ rowb, bool two) {
-  const int nb = n2 / R;  // tstep = n2 / (ns R): exp(-2 pi i t k / (ns R)) = tw[t * k * tstep]
+  const int nb = n2 / R;  // exp(-2 pi i t k / (ns R)) = tw[toff + (t - 1) ns + k]
   C2 v[NB][R];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -241,13 +244,9 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
       }
       butterfly<R>(v[i]);
       if (ns > 1) {
-        const int kstep = k * tstep;  // integer multiplies are quarter rate: one per butterfly, then additions
-        int ti = kstep;
+        const float2* twk = tw + toff + k;
 #pragma unroll
-        for (int t = 1; t < R; ++t) {
-          v[i][t] = ctw(v[i][t], tw[ti]);
-          ti += kstep;
-        }
+        for (int t = 1; t < R; ++t) v[i][t] = ctw(v[i][t], twk[(t - 1) * ns]);
       }
     }
   }
@@ -264,37 +263,37 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
 }
 
 template <int R, int G, bool FIRST>
-__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, int tstep, float inv_ns, int tid,
+__device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, int toff, float inv_ns, int tid,
                                               const v2* rowa, const v2* rowb, bool two) {
   // fused_factor() admits at most 256 butterflies per pass
   constexpr int NBMAX = 256 / G;
   const int nbl = (n2 / R + G - 1) / G;  // butterflies per thread
   if constexpr (NBMAX >= 4) {
-    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
-    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
   }
   if constexpr (NBMAX >= 2) {
-    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
   }
-  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
 }
 
 template <int G, bool FIRST>
 __device__ __forceinline__ void team_pass_radix(const FusedSpec& fs, int p, v4* buf, const float2* tw, int tid,
                                                 const v2* rowa, const v2* rowb, bool two) {
-  const int rdx = fs.radix[p], n2 = fs.n2, ns = fs.ns[p], tstep = fs.tstep[p];
+  const int rdx = fs.radix[p], n2 = fs.n2, ns = fs.ns[p], toff = fs.toff[p];
   const float inv_ns = fs.inv_ns[p];
   if (rdx == 4)
-    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
   else if (rdx == 2)
-    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
   else if (rdx == 3)
-    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
   else
-    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, tstep, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
 }
 
-// tw_pass[m] = exp(-2 pi i m / n2), m < n2;  tw_real[k] = exp(-2 pi i k / n), k <= n2 / 2 (only those are copied to the LDS).  KPT >= ceil((n2 / 2 + 1) / G).
+// tw_pass = the packed per-pass twiddles (n2 - 1 entries, FusedSpec::toff);  tw_real[k] = exp(-2 pi i k / n), k <= n2 / 2 (only those are copied to the LDS).  KPT >= ceil((n2 / 2 + 1) / G).
 // G = 64: a block is 4 independent one-wave teams sharing the twiddle tables; G = 128 / 256: the block IS the team
 // (its __syncthreads are team barriers), sweeping its own run of row pairs.
 // R0 > 0 (G == 256 only: one first-pass butterfly per thread): the first pass has radix R0 and its inputs -- the raw
@@ -370,13 +369,9 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
       if (r + 2 < r1) fetch(r + 2);
       if (tid < nb0) {
         butterfly<RP>(v);
-        if (nb0 > 1) {  // ns == nb0, k == tid, twiddle step n2 / (ns R0) == 1
-          int ti = tid;
+        if (nb0 > 1) {  // ns == nb0, k == tid; the first pass's twiddles open the packed table
 #pragma unroll
-          for (int t = 1; t < RP; ++t) {
-            v[t] = ctw(v[t], tw_pass[ti]);
-            ti += tid;
-          }
+          for (int t = 1; t < RP; ++t) v[t] = ctw(v[t], tw_pass[(t - 1) * nb0 + tid]);
         }
 #pragma unroll
         for (int t = 0; t < RP; ++t) st_c2(buf + tid + t * nb0, v[t]);
@@ -436,12 +431,13 @@ static bool fused_factor(int n, FusedSpec& fs) {
   while (m % 5 == 0) { fs.radix[fs.npass++] = 5; m /= 5; }
   while (m % 3 == 0) { fs.radix[fs.npass++] = 3; m /= 3; }
   if (m != 1 || fs.npass > 16) return false;
-  int ns = fs.n2;
+  int ns = fs.n2, toff = 0;
   for (int p = 0; p < fs.npass; ++p) {
     if (fs.n2 / fs.radix[p] > 256) return false;  // a lane keeps <= 4 butterflies of a pass in registers
     ns /= fs.radix[p];
     fs.ns[p] = ns;
-    fs.tstep[p] = fs.n2 / (ns * fs.radix[p]);
+    fs.toff[p] = toff;
+    if (ns > 1) toff += (fs.radix[p] - 1) * ns;
     fs.inv_ns[p] = 1.0f / (float)ns;
   }
   return true;
@@ -454,9 +450,14 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
   void*& tw = st->twiddles[nlon];
   if (!tw) {
     std::vector<float2> host((size_t)n2 + n2 + 1);
-    for (int m = 0; m < n2; ++m) {
-      const double a = -2.0 * M_PI * (double)m / (double)n2;
-      host[m] = make_float2((float)cos(a), (float)sin(a));
+    for (int p = 0; p < fs.npass; ++p) {  // packed per-pass twiddles (n2 - 1 entries, see FusedSpec)
+      const int ns = fs.ns[p], R = fs.radix[p];
+      if (ns <= 1) continue;
+      for (int t = 1; t < R; ++t)
+        for (int k = 0; k < ns; ++k) {
+          const double a = -2.0 * M_PI * (double)k * (double)t / ((double)ns * (double)R);
+          host[fs.toff[p] + (t - 1) * ns + k] = make_float2((float)cos(a), (float)sin(a));
+        }
     }
     for (int k = 0; k <= n2; ++k) {
       const double a = -2.0 * M_PI * (double)k / (double)nlon;
