@@ -19,7 +19,8 @@
 #include "wbx_sortnet_gen.hpp"
 
 #ifndef WBX_ENS_MIN_WAVES
-#define WBX_ENS_MIN_WAVES 1  // 4 (<= 128 VGPRs) spills 132 B and measured 0.63 ms vs 0.37 ms on MI355X: keep 140 VGPRs, 3 waves/SIMD
+#define WBX_ENS_MIN_WAVES 1  // no forced occupancy: 106 VGPRs / 4 waves per SIMD on its own since the fp64 divisions went (before: 140-155
+                             // VGPRs / 3 waves, and forcing 4 spilled 132 B: 0.63 ms vs 0.37 ms)
 #endif
 
 namespace wbx {
@@ -51,6 +52,9 @@ struct EnsOpF32 {
   //   * 2 / 4 interleaved fp64 accumulation chains instead of one: 0.39 ms either way -> not kept.
   // rocprofv3 SQ counters (tools/pmc_ens.sh): WAIT_ANY (memory) 12 %, the VALU pipe is ~saturated: 1453 VALU
   // instructions per 64 points (877 v_min/v_max for the 415-comparator network, ~430 fp64), i.e. VALU-, not HBM-bound.
+  // Instruction diet since then (ISA counts of the inner loop, per 64 points): 1524 -> 1395: reciprocal multiplies for
+  // the five divisions by M-derived constants, packed NaN probe, bare v_min/v_max (no canonicalisation of the loaded
+  // members), statistics accumulated on x - t (one fp64 add per member less): 0.404 -> 0.363 ms.
   // The load-only diagnostic (WBX_ENS_DIAG_LOADONLY) streams the same 52 dword streams at 6.0 TB/s, so what is
   // left is VALU time (~2000 instructions per 64 points) that 3 waves/SIMD only partly overlap with the loads.
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
