@@ -30,8 +30,10 @@ __device__ __forceinline__ T cat_ld(const void* base, int64_t off) {
   return reinterpret_cast<const T*>(base)[off];
 }
 
-// One point: adds its indicator vector (and count lanes) to this thread's LDS column.
-template <typename T>
+// One point: adds its indicator vector (and count lanes) to this thread's LDS column.  MF > 0: the ensemble size is
+// known at compile time (the 50 / 51-member archives): all member loads of a point are issued back to back into
+// registers before the compares (the generic loop keeps 4-8 in flight); MF == 0: any M.
+template <typename T, int MF>
 __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, const int64_t (&ro)[WBX_MAX_INPUTS],
                                           int64_t x, double* col, int stride) {
   const bool masked = a.flags & WBX_FLAG_MASKED, skipna = a.flags & WBX_FLAG_SKIPNA;
@@ -40,10 +42,20 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
   const T tnat = cat_ld<T>(a.in[1], ro[1] + x * a.xstride[1]);
   const double t = (double)tnat;
   const T* pm = reinterpret_cast<const T*>(a.in[0]) + ro[0] + x * a.xstride[0];  // members: pm[m * mstride]
+  T xm[MF > 0 ? MF : 1];
+  if constexpr (MF > 0) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m) xm[m] = ld_stream(pm + (int64_t)m * a.mstride);
+  }
   if (c.func == WBX_CAT_RANK) {
     int r = 0;
+    if constexpr (MF > 0) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) r += (xm[m] < tnat) ? 1 : 0;  // NaN compares false
+    } else {
 #pragma unroll 8
-    for (int m = 0; m < a.M; ++m) r += (ld_stream(pm + (int64_t)m * a.mstride) < tnat) ? 1 : 0;  // NaN compares false
+      for (int m = 0; m < a.M; ++m) r += (ld_stream(pm + (int64_t)m * a.mstride) < tnat) ? 1 : 0;
+    }
     if (valid) col[r * stride] += 1.0;
     if (skipna) {
       for (int k = 0; k < nc; ++k) col[(nc + k) * stride] += valid ? 1.0 : 0.0;
@@ -59,12 +71,22 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
     double thr[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) thr[q] = k0 + q < nc ? c.thr[k0 + q] : INFINITY;
-#pragma unroll 4
-    for (int m = 0; m < a.M; ++m) {
-      const double ae = fabs((double)ld_stream(pm + (int64_t)m * a.mstride) - t);
-      n += (ae == ae) ? 1 : 0;
+    if constexpr (MF > 0) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) cnt[q] += (ae > thr[q]) ? 1 : 0;  // NaN > x is false
+      for (int m = 0; m < MF; ++m) {
+        const double ae = fabs((double)xm[m] - t);
+        n += (ae == ae) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cnt[q] += (ae > thr[q]) ? 1 : 0;  // NaN > x is false
+      }
+    } else {
+#pragma unroll 4
+      for (int m = 0; m < a.M; ++m) {
+        const double ae = fabs((double)ld_stream(pm + (int64_t)m * a.mstride) - t);
+        n += (ae == ae) ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cnt[q] += (ae > thr[q]) ? 1 : 0;  // NaN > x is false
+      }
     }
     const double inv = n > 0 ? 1.0 / (double)n : NAN;  // every member NaN -> NaN
 #pragma unroll
@@ -85,7 +107,7 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
 }
 
 // grid = nkey * nchunk (x summed) or nkey * nxtile * nchunk (x kept); block = 64 threads; dynamic LDS = nacc * 64 * 8 B
-template <typename T>
+template <typename T, int MF>
 __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nacc, int x_kept) {
   extern __shared__ double cols[];  // [nacc][64]
   const int lane = threadIdx.x;
@@ -110,7 +132,7 @@ __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nac
       for (int64_t d = d0; d < d1; ++d) {
         int64_t ro[WBX_MAX_INPUTS];
         row_bases<2>(a, kb, key, d, ro);
-        cat_point<T>(a, c, ro, x, col, 64);
+        cat_point<T, MF>(a, c, ro, x, col, 64);
       }
       for (int i = 0; i < nacc; ++i) a.out[((key * a.nchunk + chunk) * nacc + i) * a.nx + x] = col[i * 64];
     }
@@ -118,7 +140,7 @@ __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nac
     for (int64_t d = d0; d < d1; ++d) {
       int64_t ro[WBX_MAX_INPUTS];
       row_bases<2>(a, kb, key, d, ro);
-      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T>(a, c, ro, x, col, 64);
+      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T, MF>(a, c, ro, x, col, 64);
     }
     __syncthreads();
     for (int i = 0; i < nacc; ++i) {
@@ -170,12 +192,18 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
   const int64_t grid = plan->nkey * plan->nchunk * (plan->x_kept ? a.nxtile : 1);
   WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
   const size_t lds = (size_t)nacc * 64 * sizeof(double);
-  if (dtype == WBX_F32)
-    hipLaunchKernelGGL((s1_cat_kernel<float>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept);
-  else if (dtype == WBX_F64)
-    hipLaunchKernelGGL((s1_cat_kernel<double>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept);
-  else
+#define WBX_LAUNCH_CAT(TT, MFIX) \
+  hipLaunchKernelGGL((s1_cat_kernel<TT, MFIX>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept)
+  if (dtype == WBX_F32) {
+    if (M == 51) WBX_LAUNCH_CAT(float, 51);
+    else if (M == 50) WBX_LAUNCH_CAT(float, 50);
+    else WBX_LAUNCH_CAT(float, 0);
+  } else if (dtype == WBX_F64) {
+    WBX_LAUNCH_CAT(double, 0);
+  } else {
     return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
+  }
+#undef WBX_LAUNCH_CAT
   WBX_HIP(hipGetLastError());
   return 0;
 }
