@@ -534,3 +534,83 @@ def test_full_grid_region_bins_size_independent_properties(ctx, monkeypatch):
   np.testing.assert_allclose(fused_s.transpose(*two_s.dims).values, two_s.values, rtol=1e-11)
   np.testing.assert_allclose(fused_w.transpose(*two_w.dims).values, two_w.values, rtol=1e-12)
   np.testing.assert_allclose(fused2_s.values, 4.0 * fused_s.values, rtol=1e-5)  # fp32 rounding of t + 2e vs t + e
+
+
+@pytest.mark.parametrize('mode', ['plain', 'masked', 'skipna'])
+def test_full_grid_latitude_fastest_ensemble_closed_form(ctx, mode):
+  """IFS-ENS style chunk (lead, number, longitude, latitude): the area weights are folded into the flat
+  one-point-per-lane sweep (s1_xf1_kernel), also under a validity mask / skipna.  Members t + k*d give the same closed
+  forms at every point, whatever the weights and whichever points are masked out or NaN."""
+  import torch
+  m, d, nl = 51, 0.25, 2
+  tt = _torch_field((nl, NLON, NLAT), 6, offset=0.0).round()
+  k = torch.arange(m, device='cuda', dtype=torch.float32)[torch.randperm(m, device='cuda')]
+  pt = tt[:, None] + (k * d)[None, :, None, None]
+  dims, edims = ('lead_time', 'longitude', 'latitude'), ('lead_time', 'number', 'longitude', 'latitude')
+  coords = {'latitude': LAT, 'longitude': LON, 'lead_time': (np.arange(nl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  hole = np.zeros((nl, NLON, NLAT), dtype=bool)
+  hole[:, 100:400, 50:300] = True
+  if mode == 'skipna':
+    tt[torch.from_numpy(hole).cuda()] = float('nan')
+  t = xr.DataArray(tt, dims=dims, coords=coords)
+  if mode == 'masked':
+    t.coords['mask'] = xr.DataArray(~hole, dims=dims, coords=coords)
+  p = {'v': xr.DataArray(pt, dims=edims, coords=coords)}
+  metrics = {'skill': probabilistic.CRPSSkill(), 'spread': probabilistic.CRPSSpread(use_sort=True),
+             'var': probabilistic.EnsembleVariance()}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+  engine.S1_EVENT_LOG = []
+  try:
+    res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, {'v': t})
+    assert engine.S1_EVENT_LOG and all(e.get('flat') for e in engine.S1_EVENT_LOG if e.get('kind') == 'ens')
+  finally:
+    engine.S1_EVENT_LOG = None
+  np.testing.assert_allclose(res['skill.v'].values, d * (m - 1) / 2, rtol=1e-12)
+  np.testing.assert_allclose(res['spread.v'].values, d * (m + 1) / 3, rtol=1e-12)
+  np.testing.assert_allclose(res['var.v'].values, d * d * m * (m + 1) / 12, rtol=1e-10)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_full_grid_rank_histogram_and_exceedance_closed_form(ctx, layout):
+  """51 members t + (k - 20.5) d: exactly 21 members lie below the target at every point, so the rank histogram is the
+  unit vector e_21; |p_k - t| = |k - 20.5| d exceeds a threshold for a known number of members (the kernel instantiated
+  for M = 51)."""
+  import torch
+  m, d = 51, 0.5
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  shp = (NLAT, NLON) if layout == 'lon_fastest' else (NLON, NLAT)
+  tt = _torch_field(shp, 8, offset=0.0).round()
+  k = torch.arange(m, device='cuda', dtype=torch.float32)[torch.randperm(m, device='cuda')]
+  pt = tt[None] + ((k - 20.5) * d)[:, None, None]
+  coords = {'latitude': LAT, 'longitude': LON}
+  p = {'v': xr.DataArray(pt, dims=('number',) + sp, coords=coords)}
+  t = {'v': xr.DataArray(tt, dims=sp, coords=coords)}
+  thr = [0.2, 2.6, 7.0, 100.0]
+  metrics = {'rank': probabilistic.RankHistogram(), 'exc': probabilistic.EnsembleErrorExceedance(thresholds=thr)}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  want = np.zeros(m + 1)
+  want[21] = 1.0
+  np.testing.assert_allclose(np.asarray(res['rank.v'].values).reshape(-1), want, atol=1e-12)
+  frac = [np.mean(np.abs(np.arange(m) - 20.5) * d > x) for x in thr]
+  np.testing.assert_allclose(np.asarray(res['exc.v'].values).reshape(-1), frac, rtol=1e-12)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_full_grid_spectrum_parseval(ctx, layout):
+  """sum_k S_k (Nyquist counted once) == mean over longitude of f^2 for every row (odd row count 3 x 721: the last team ends on a single
+  row), through the fused kernel (lon-fastest) and the transposing slab path (lat-fastest)."""
+  from weatherbenchx_amd import spectra
+  sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  shp = (3,) + ((NLAT, NLON) if layout == 'lon_fastest' else (NLON, NLAT))
+  f = _torch_field(shp, 9, offset=1.0)
+  da = xr.DataArray(f, dims=('lead_time',) + sp, coords={'latitude': LAT, 'longitude': LON,
+                                                           'lead_time': (np.arange(3) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')})
+  stat = spectra.ZonalPowerSpectrum().compute({'v': da}, {'v': da})['v']
+  st = aggregation.Aggregator(reduce_dims=['lead_time']).aggregate_stat_var(stat)
+  got = st.sum_weighted_statistics.transpose('latitude', 'zonal_wavenumber').values  # sum over lead of S_k per latitude
+  lon_ax = 1 + sp.index('longitude')
+  ms = (f.double() ** 2).mean(dim=lon_ax).sum(dim=0).cpu().numpy()  # [latitude]
+  # the Nyquist bin is doubled like every k > 0 (WeatherBench-2 convention): half of it is not part of Parseval's sum
+  np.testing.assert_allclose(got.sum(axis=1) - 0.5 * got[:, -1], ms, rtol=2e-6)
