@@ -614,3 +614,24 @@ def test_full_grid_spectrum_parseval(ctx, layout):
   ms = (f.double() ** 2).mean(dim=lon_ax).sum(dim=0).cpu().numpy()  # [latitude]
   # the Nyquist bin is doubled like every k > 0 (WeatherBench-2 convention): half of it is not part of Parseval's sum
   np.testing.assert_allclose(got.sum(axis=1) - 0.5 * got[:, -1], ms, rtol=2e-6)
+
+
+def test_full_grid_dense_stage2_split_equals_folded_route(ctx, monkeypatch):
+  """Latitude kept through stage 1 with few outputs (8 leads x 5 ensemble lanes over a 100+ MB partial): the dense
+  contraction deals the (Br, chunk) rows of each output to many blocks and adds the pieces (s2_reduce_kernel with
+  nsplit > 1).  The folded route (weights inside stage 1, no stage 2 to speak of) must give the same numbers."""
+  m, nl = 4, 8
+  tt = _torch_field((nl, NLON, NLAT), 12)
+  pt = tt[:, None] + _torch_field((nl, m, NLON, NLAT), 13, offset=0.0)
+  coords = {'latitude': LAT, 'longitude': LON, 'lead_time': (np.arange(nl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  p = {'v': xr.DataArray(pt, dims=('lead_time', 'number', 'longitude', 'latitude'), coords=coords)}
+  t = {'v': xr.DataArray(tt, dims=('lead_time', 'longitude', 'latitude'), coords=coords)}
+  metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = {}
+  for fold in (True, False):
+    monkeypatch.setattr(engine, 'FOLD_X_WEIGHTS', fold)
+    engine.clear_caches()
+    res[fold] = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+  for k in res[True]:
+    np.testing.assert_allclose(res[False][k].values, res[True][k].values, rtol=1e-11)

@@ -18,9 +18,15 @@ constexpr int BG = 8;  // bins per register group
 
 // one block per (A, Bk, lane[, j]); threads stride over the flattened (Br, chunk[, j]) contraction.
 // fixed_j = 0: j is contracted (sum_j).  fixed_j = 1: j is kept and few (< 64): one block per j.
-__global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed_j, const double* __restrict__ partial,
+// nsplit > 1 (long rows only): the (Br, chunk) rows of one output are dealt to nsplit blocks, out is
+// tmp[output][split][bin] and s2_bits_finish_kernel adds the splits -- a handful of outputs (8 leads x 5 ensemble lanes)
+// over a 118 MB partial otherwise ran on 40 of the 256 CUs.
+__global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed_j, int nsplit,
+                                                        const double* __restrict__ partial,
                                                         const double* __restrict__ W, double* __restrict__ out) {
   int64_t b = blockIdx.x;
+  const int split = (int)(b % nsplit);
+  b /= nsplit;
   int64_t jf = 0;
   if (fixed_j) {
     jf = b % p.nj;
@@ -43,17 +49,22 @@ __global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed
     for (int g = 0; g < BG; ++g) acc[g] = 0.0;
     if (!fixed_j && p.nj >= 64) {
       // long rows (x kept in stage 1, summed here): lanes walk j, rows/chunks are plain loops -- no 64-bit divides
-      for (int64_t br = 0; br < p.nBr; ++br) {
+      const int64_t nrc = p.nBr * p.nchunk, per = (nrc + nsplit - 1) / nsplit;
+      const int64_t rc0 = split * per, rc1 = rc0 + per < nrc ? rc0 + per : nrc;
+      int64_t br = rc0 / p.nchunk, ch = rc0 - br * p.nchunk;  // one divide per block, then carried
+      for (int64_t rc = rc0; rc < rc1; ++rc) {
         const double* wrow = wbase + br * p.nj * p.nbin + b0;
-        for (int64_t ch = 0; ch < p.nchunk; ++ch) {
-          const double* prow = pbase + ((br * p.nchunk + ch) * p.nlane + lane) * p.nj;
-          for (int64_t j = threadIdx.x; j < p.nj; j += blockDim.x) {
-            const double v = prow[j];
-            const double* w = wrow + j * p.nbin;
+        const double* prow = pbase + (rc * p.nlane + lane) * p.nj;
+        for (int64_t j = threadIdx.x; j < p.nj; j += blockDim.x) {
+          const double v = prow[j];
+          const double* w = wrow + j * p.nbin;
 #pragma unroll
-            for (int g = 0; g < BG; ++g)
-              if (b0 + g < p.nbin) acc[g] += v * w[g];
-          }
+          for (int g = 0; g < BG; ++g)
+            if (b0 + g < p.nbin) acc[g] += v * w[g];
+        }
+        if (++ch == p.nchunk) {
+          ch = 0;
+          ++br;
         }
       }
     } else {
@@ -79,7 +90,7 @@ __global__ void __launch_bounds__(256) s2_reduce_kernel(wbx_s2_plan p, int fixed
       double s = 0.0;
       for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) s += red[w2][threadIdx.x];
       const int64_t o = fixed_j ? (((A * p.nBk + bk) * p.nlane + lane) * p.nj + jf) : ((A * p.nBk + bk) * p.nlane + lane);
-      out[o * p.nbin + b0 + threadIdx.x] = s;
+      out[(o * nsplit + split) * p.nbin + b0 + threadIdx.x] = s;
     }
     __syncthreads();
   }
@@ -292,8 +303,34 @@ extern "C" int wbx_contract(wbx_ctx* ctx, const wbx_s2_plan* plan, const double*
     WBX_REQUIRE(grid < (int64_t)1 << 31, "stage-2 grid too large");
     const int64_t ncontr = p.nBr * p.nchunk * (fixed_j ? 1 : p.nj);
     const int threads = ncontr >= 256 ? 256 : (ncontr >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(wbx::s2_reduce_kernel, dim3((unsigned)grid), dim3(threads), 0, ctx->stream, p, fixed_j, partial, W,
-                       out);
+    int nsplit = 1;
+    double* dst = out;
+    const int64_t nrc = p.nBr * p.nchunk;
+    if (!fixed_j && p.nj >= 64 && grid < 1024 && nrc * p.nj >= ((int64_t)1 << 16)) {
+      int64_t want = (2048 + grid - 1) / grid;
+      if (want > nrc) want = nrc;
+      nsplit = (int)want;
+      const size_t need = (size_t)grid * nsplit * p.nbin * sizeof(double);
+      if (ctx->s2_scratch_size < need) {
+        if (ctx->s2_scratch) {
+          WBX_HIP(hipStreamSynchronize(ctx->stream));
+          WBX_HIP(hipFree(ctx->s2_scratch));
+          ctx->s2_scratch = nullptr;
+          ctx->s2_scratch_size = 0;
+        }
+        WBX_HIP(hipMalloc(&ctx->s2_scratch, need));
+        ctx->s2_scratch_size = need;
+      }
+      dst = reinterpret_cast<double*>(ctx->s2_scratch);
+    }
+    hipLaunchKernelGGL(wbx::s2_reduce_kernel, dim3((unsigned)(grid * nsplit)), dim3(threads), 0, ctx->stream, p, fixed_j,
+                       nsplit, partial, W, dst);
+    if (nsplit > 1) {
+      WBX_HIP(hipGetLastError());
+      const int64_t n = grid * p.nbin;
+      hipLaunchKernelGGL(wbx::s2_bits_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, grid,
+                         nsplit, (int)p.nbin, dst, out);
+    }
   } else {
     const int threads = p.nj >= 256 ? 256 : (p.nj >= 128 ? 128 : 64);
     const int njtile = (int)((p.nj + threads - 1) / threads);
