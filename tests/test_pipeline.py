@@ -103,14 +103,16 @@ def test_deferred_results_equal_synchronous_results(backend):
   sync_states = [agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
                  for p, t in chunks]
   want = aggregation.AggregationState.sum(sync_states).metric_values(metrics)
+  fresh = [load(init_times[i:i + 1], lead_times) for i in range(len(init_times))]  # new objects: nothing cached on them
   with engine.deferred_results():
     assert engine.deferred_active() is not None
     states = [agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
-              for p, t in chunks]  # every chunk is launched before any result is looked at
+              for p, t in fresh]  # every chunk is launched before any result is looked at
     clone = pickle.loads(pickle.dumps(states[0]))  # pickling waits
     total = aggregation.AggregationState.sum(states)
     got = total.metric_values(metrics)
   assert engine.deferred_active() is None
+  assert not engine._stream_ring  # deterministic reductions stay on the default context's stream
   for k in want:
     xr.assert_allclose(got[k], want[k], rtol=1e-12, atol=0, check_dim_order=False)
   xarray_tree.map_structure(lambda a, b: xr.assert_allclose(a, b, rtol=1e-12, atol=0),
@@ -187,3 +189,34 @@ def test_xarray_tree_map_structure():
     xarray_tree.map_structure(3, ds)
   with pytest.raises(ValueError):
     xarray_tree.map_structure(lambda x: x)
+
+
+def test_deferred_ensemble_reductions_alternate_streams(backend):
+  """Under deferred_results() ensemble / indicator reductions are dealt to two contexts (HIP streams) in turn, so that
+  one kernel's tail overlaps the next launch; the numbers and the fence semantics are those of the one-stream path."""
+  from weatherbenchx_amd import engine, weighting
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(21)
+  lat, lon = np.linspace(-87.5, 87.5, 36), np.arange(72) * 5.0
+  coords = {'latitude': lat, 'longitude': lon}
+
+  def chunk(seed):
+    r = np.random.default_rng(seed)
+    tv = r.normal(size=(3, 36, 72)).astype(np.float32)
+    pv = (tv[:, None] + r.normal(size=(3, 5, 36, 72))).astype(np.float32)
+    names = ('a', 'b', 'c')
+    p = {n: xr.DataArray(pv + i, dims=('lead_time', 'number', 'latitude', 'longitude'), coords=coords) for i, n in enumerate(names)}
+    t = {n: xr.DataArray(tv + i, dims=('lead_time', 'latitude', 'longitude'), coords=coords) for i, n in enumerate(names)}
+    return p, t
+  del rng
+  metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'rank': probabilistic.RankHistogram()}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  launch = lambda p, t: agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+  want = [launch(*chunk(s)).metric_values(metrics) for s in (1, 2, 3)]
+  with engine.deferred_results():
+    states = [launch(*chunk(s)) for s in (1, 2, 3)]  # 3 chunks x 3 variables x 2 statistic families, nothing read yet
+    assert len(engine._stream_ring) == 2 and engine._stream_ring[0] is not engine._stream_ring[1]
+    got = [s.metric_values(metrics) for s in states]
+  for g, w in zip(got, want):
+    for k in w:
+      xr.assert_allclose(g[k], w[k], rtol=1e-12, atol=1e-15)
