@@ -2,7 +2,6 @@
 generic kernel with mask loads vs the same chunk without a mask (LDS plane mode)."""
 import os
 import sys
-import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ import os
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from weatherbenchx_amd import _hip, engine, planner
 from weatherbenchx_amd import xarray_lite as xr
