@@ -25,21 +25,30 @@
 
 namespace wbx {
 
+// waves per block = adjacent x tiles walked side by side (see patch_decode).  Measured on the public-benchmark chunk:
+// 4 waves per block 0.86 / 0.90 ms (latitude- / longitude-fastest) against 0.80 / 0.77 ms for lone waves -- the wider
+// block spreads an XCD's L2 over 4x the weight / membership rows and buys nothing at the DRAM, so 1 it is.
+#ifndef WBX_BINNED_WPB
+#define WBX_BINNED_WPB 1
+#endif
+constexpr int BINNED_WPB = WBX_BINNED_WPB;
+
+
 // MM: 0 none, 1 mask only (one shared count lane), 2 skipna (count lane per value lane), 3 skipna + mask.
 // K = accumulator slots, PD = rows of p, t, c in flight.  WM = how the weights are stored: 0 wt[nBk][nBr][nj] (one 8-byte
 // load per point next to the membership word), 1 wt[nBk][nj] (they depend on x only -- latitude weights on
 // latitude-fastest data: one register per lane for the whole patch), 2 wt[nBk][nBr] (rows only -- latitude weights on
 // longitude-fastest data: resolved 64 rows at a time like the row offsets, broadcast per row).
 template <typename T, int FUNC, int MM, int K, int PD, int WM>
-__global__ void __launch_bounds__(64) det_binned_kernel(S1Args a, BinnedArgs g) {
+__global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, BinnedArgs g) {
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
   constexpr int NA = NL + NC;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   int64_t cell;
   int xt, rs;
-  if (!patch_decode(g, cell, xt, rs)) return;
+  if (!patch_decode<BINNED_WPB>(g, cell, xt, rs)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t A = cell / g.nBk;
   const int64_t R = g.nBr * a.D;
@@ -220,13 +229,13 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   BinnedArgs g;
   if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin)) return rc;
-  const int64_t grid = (g.nblocks + 7) / 8 * 8;
+  const int64_t grid = patch_grid<BINNED_WPB>(g);
   if (wmode == 1)
-    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 1>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g);
+    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 1>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   else if (wmode == 2)
-    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 2>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g);
+    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 2>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   else
-    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 0>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g);
+    hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 0>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   WBX_HIP(hipGetLastError());
   return patch_finish(ctx, g, NA, out);
 }

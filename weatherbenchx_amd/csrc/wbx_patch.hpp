@@ -146,19 +146,35 @@ inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out
 // patch of many cells, so the patch's wt / bits rows (which do not depend on A) are fetched into that XCD's L2 once
 // and hit by the others.  Without this the 16 B / point of wt + bits miss L2 for every cell and cost as much fabric
 // bandwidth as the data.
+// WPB waves per block: the block is WPB ADJACENT x tiles of the same cell and rows, one wave each (xt = WPB * xq + wave).
+// The waves are independent (own slots, own sweeps) but start together and walk the same rows, so a row's WPB x 256 B
+// are requested at about the same time.  (Tried for DRAM page locality with WPB = 4; measured slower than lone waves,
+// see wbx_det_binned.hip -- both patch kernels run WPB = 1.)  grid = patch_grid<WPB>(g).
+template <int WPB>
 __device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs) {
   // 32-bit arithmetic (the launcher checks nblocks < 2^31): a 64-bit divide is a ~100-instruction sequence on this ISA,
   // and a patch is only a few thousand instructions long
-  const uint32_t nblocks = (uint32_t)g.nblocks, ncell = (uint32_t)g.ncell, nxt = (uint32_t)g.nxt;
+  const uint32_t ncell = (uint32_t)g.ncell, nxt = (uint32_t)g.nxt;
+  const uint32_t nxq = (nxt + WPB - 1) / WPB;
+  const uint32_t nblocks = ncell * nxq * (uint32_t)g.nrs;
   const uint32_t per_xcd = (nblocks + 7u) >> 3;
   uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   if (b >= nblocks) return false;
   const uint32_t q = b / ncell;
   cell = (int64_t)(b - q * ncell);
-  const uint32_t q2 = q / nxt;
-  xt = (int)(q - q2 * nxt);
+  const uint32_t q2 = q / nxq;
+  const uint32_t wave = WPB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+  const uint32_t x = (q - q2 * nxq) * WPB + wave;
+  if (x >= nxt) return false;
+  xt = (int)x;
   rs = (int)q2;
   return true;
+}
+
+template <int WPB>
+inline int64_t patch_grid(const BinnedArgs& g) {
+  const int64_t nxq = (g.nxt + WPB - 1) / WPB;
+  return (g.ncell * nxq * g.nrs + 7) / 8 * 8;
 }
 
 }  // namespace wbx

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(64) s2_patch_kernel(const double* __restrict__
   const int lane = threadIdx.x;
   int64_t cell;
   int xt, rs;
-  if (!patch_decode(g, cell, xt, rs)) return;
+  if (!patch_decode<1>(g, cell, xt, rs)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t rbeg = (int64_t)rs * g.rows_per_split;
   const int64_t rend = rbeg + g.rows_per_split < g.nBr ? rbeg + g.rows_per_split : g.nBr;
