@@ -156,13 +156,32 @@ def _move_member_last(p, p_dims, ensemble_dim):
   return np.moveaxis(f64(p), ax, -1), tuple(d for d in p_dims if d != ensemble_dim)
 
 
-def crps_skill(p, p_dims, t, t_dims, ensemble_dim):
-  """probabilistic.py:116-145: mean_m |p_m - t|."""
+def _nanmean_last(x):
+  """xarray's mean(skipna=True): NaNs are left out, an all-NaN slice gives NaN (quietly)."""
+  ok = ~np.isnan(x)
+  n = ok.sum(axis=-1)
+  with np.errstate(invalid='ignore', divide='ignore'):
+    return np.where(ok, x, 0.0).sum(axis=-1) / np.where(n > 0, n, np.nan)
+
+
+def _nanvar_last(x, ddof=1):
+  """xarray's var(ddof=1, skipna=True): over the non-NaN members, NaN where fewer than ddof + 1 are left."""
+  ok = ~np.isnan(x)
+  n = ok.sum(axis=-1)
+  mean = _nanmean_last(x)
+  with np.errstate(invalid='ignore', divide='ignore'):
+    dev2 = np.where(ok, (x - mean[..., None]) ** 2, 0.0).sum(axis=-1)
+    return dev2 / np.where(n - ddof > 0, n - ddof, np.nan)
+
+
+def crps_skill(p, p_dims, t, t_dims, ensemble_dim, skipna_ensemble=False):
+  """probabilistic.py:116-145: mean_m |p_m - t|; skipna_ensemble -> the mean skips NaN members (:143-145)."""
   pm, dims = _move_member_last(p, p_dims, ensemble_dim)
   out_dims = union_dims(dims, t_dims)
   pe = expand_to(pm, dims + (ensemble_dim,), out_dims + (ensemble_dim,))
   te = expand_to(f64(t), t_dims, out_dims)[..., None]
-  return np.abs(pe - te).mean(axis=-1), out_dims
+  ae = np.abs(pe - te)
+  return (_nanmean_last(ae) if skipna_ensemble else ae.mean(axis=-1)), out_dims
 
 
 def rankdata_ordinal(x, axis=-1):
@@ -174,10 +193,21 @@ def rankdata_ordinal(x, axis=-1):
   return np.swapaxes(ranks, axis, -1)
 
 
-def crps_spread(p, p_dims, ensemble_dim, fair=True, use_sort=False):
-  """probabilistic.py:165-247: rank form (:231-240) or pairwise form (:241-247)."""
+def crps_spread(p, p_dims, ensemble_dim, fair=True, use_sort=False, skipna_ensemble=False):
+  """probabilistic.py:165-247: rank form (:231-240) or pairwise form (:241-247).  skipna_ensemble (pairwise form only,
+  :215-216): pairs with a NaN member add nothing to the double sum, and M becomes the per-point count of non-NaN
+  members (:206-207, :243-247)."""
   pm, dims = _move_member_last(p, p_dims, ensemble_dim)
   m = pm.shape[-1]
+  if skipna_ensemble:
+    if use_sort:
+      raise ValueError('skipna_ensemble is not supported with use_sort=True.')
+    n = (~np.isnan(pm)).sum(axis=-1).astype(np.float64)
+    total = np.zeros(pm.shape[:-1])
+    for i in range(m):
+      total += np.nansum(np.abs(pm - pm[..., i:i + 1]), axis=-1)
+    with np.errstate(invalid='ignore', divide='ignore'):
+      return total / (n * (n - int(fair))), dims
   if m < 2:
     raise ValueError('Cannot estimate CRPS spread with n_ensemble < 2.')
   if use_sort:
@@ -189,21 +219,27 @@ def crps_spread(p, p_dims, ensemble_dim, fair=True, use_sort=False):
   return total / (m * (m - int(fair))), dims
 
 
-def ensemble_variance(p, p_dims, ensemble_dim):
-  """probabilistic.py:250-273: var(ddof=1)."""
+def ensemble_variance(p, p_dims, ensemble_dim, skipna_ensemble=False):
+  """probabilistic.py:250-273: var(ddof=1), over the non-NaN members with skipna_ensemble."""
   pm, dims = _move_member_last(p, p_dims, ensemble_dim)
-  return pm.var(axis=-1, ddof=1), dims
+  return (_nanvar_last(pm) if skipna_ensemble else pm.var(axis=-1, ddof=1)), dims
 
 
-def unbiased_ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):
-  """probabilistic.py:276-336: (mean_m p - t)^2 - var/M."""
+def unbiased_ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim, skipna_ensemble=False):
+  """probabilistic.py:276-336: (mean_m p - t)^2 - var/M; skipna_ensemble -> mean, variance and M over the non-NaN
+  members of each point (:304-314)."""
   pm, dims = _move_member_last(p, p_dims, ensemble_dim)
-  m = pm.shape[-1]
   out_dims = union_dims(dims, t_dims)
-  mean = expand_to(pm.mean(axis=-1), dims, out_dims)
-  var = expand_to(pm.var(axis=-1, ddof=1), dims, out_dims)
+  if skipna_ensemble:
+    m = expand_to((~np.isnan(pm)).sum(axis=-1).astype(np.float64), dims, out_dims)
+    mean, var = expand_to(_nanmean_last(pm), dims, out_dims), expand_to(_nanvar_last(pm), dims, out_dims)
+  else:
+    m = pm.shape[-1]
+    mean = expand_to(pm.mean(axis=-1), dims, out_dims)
+    var = expand_to(pm.var(axis=-1, ddof=1), dims, out_dims)
   te = expand_to(f64(t), t_dims, out_dims)
-  return (mean - te) ** 2 - var / m, out_dims
+  with np.errstate(invalid='ignore', divide='ignore'):
+    return (mean - te) ** 2 - var / m, out_dims
 
 
 def ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):

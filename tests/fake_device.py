@@ -78,7 +78,7 @@ def _ens_lanes(plan, devs, ens, flags):
       skill = np.nansum(np.abs(d), axis=-1) / n
       spread = np.nansum(np.abs(members[..., :, None] - members[..., None, :]), axis=(-1, -2)) / (n * (n - fair))
       mean = np.nansum(members, axis=-1) / n
-      var = np.nansum((members - mean[..., None]) ** 2, axis=-1) / (n - 1)
+      var = np.where(n > 0, np.nansum((members - mean[..., None]) ** 2, axis=-1) / (n - 1), np.nan)  # no member: NaN
       md = mean - t
     return [skill, spread, var, md * md - var / n, md * md]
   d = members - t[..., None]

@@ -527,6 +527,40 @@ def test_crps_with_nan_member_equals_dropping_it(backend, m, fair):
   assert 'not supported with use_sort=True' in str(info.value.__cause__)
 
 
+@pytest.mark.parametrize('fair', [True, False])
+def test_skipna_ensemble_with_scattered_nan_members_matches_oracle(backend, fair):
+  """skipna_ensemble=True where the NaNs differ from point to point (per-point member counts, probabilistic.py:206-216,
+  :304-314): skill, pairwise spread, variance and the unbiased mean squared error against the float64 restatement;
+  a point with fewer than two members left is NaN and poisons its aggregate exactly as in the reference."""
+  rng = np.random.default_rng(44)
+  m, nlat, nlon = 6, 19, 36
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * 10.0
+  pv = rng.normal(size=(2, m, nlat, nlon)).astype(np.float32)
+  tv = rng.normal(size=(2, nlat, nlon)).astype(np.float32)
+  pv[rng.random(pv.shape) < 0.15] = np.nan
+  pv[1, :, 3, 4] = np.nan   # a point without any member
+  pv[1, 1:, 5, 6] = np.nan  # a point with a single member
+  pdims, tdims = ('time', 'number', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'v': xr.DataArray(pv, dims=pdims, coords=coords)}
+  t = {'v': xr.DataArray(tv, dims=tdims, coords=coords)}
+  stats = {'skill': probabilistic.CRPSSkill(skipna_ensemble=True),
+           'spread': probabilistic.CRPSSpread(use_sort=False, fair=fair, skipna_ensemble=True),
+           'var': probabilistic.EnsembleVariance(skipna_ensemble=True),
+           'uemse': probabilistic.UnbiasedEnsembleMeanSquaredError(skipna_ensemble=True)}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], skipna=True)
+  got = aggregation.compute_metric_values_for_single_chunk(stats, agg, p, t)
+  w = (O.grid_area_weights(lat), ('latitude',))
+  with np.errstate(invalid='ignore', divide='ignore'):
+    want = {'skill': O.crps_skill(pv, pdims, tv, tdims, 'number', skipna_ensemble=True),
+            'spread': O.crps_spread(pv, pdims, 'number', fair=fair, skipna_ensemble=True),
+            'var': O.ensemble_variance(pv, pdims, 'number', skipna_ensemble=True),
+            'uemse': O.unbiased_ensemble_mean_squared_error(pv, pdims, tv, tdims, 'number', skipna_ensemble=True)}
+    for k, (vals, dims) in want.items():
+      sws, sw, _ = O.aggregate(vals, dims, ['latitude', 'longitude'], weights=[w], skipna=True)
+      np.testing.assert_allclose(got[f'{k}.v'].values, sws / sw, rtol=RTOL, err_msg=k)
+
+
 @pytest.mark.parametrize('m,use_sort,fair', list(itertools.product([4, 5], [False, True], [True, False])))
 def test_crps_ensemble_distance(backend, m, use_sort, fair):
   # metrics_test.py:673-752

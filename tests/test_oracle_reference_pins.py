@@ -198,3 +198,24 @@ def test_rank_histogram_one_hot_table_and_its_mean():
   sws, sw, out_dims = O.aggregate(out, dims, ['batch', 'space'])
   assert out_dims == ('rank',)
   np.testing.assert_allclose(sws / sw, want.mean(axis=(0, 1)))
+
+
+@pytest.mark.parametrize('m,fair', list(itertools.product([4, 5], [True, False])))
+def test_skipna_ensemble_with_an_all_nan_member_equals_dropping_it(m, fair):
+  # metrics_test.py:1199-1274: CRPS / spread-skill with skipna_ensemble=True and one all-NaN member == the ensemble
+  # without that member (pairwise spread: use_sort=True is rejected, probabilistic.py:215-216)
+  rng = np.random.default_rng(30 + m)
+  p = rng.normal(size=(m, 2, 19, 36))
+  t = rng.normal(size=(2, 19, 36))
+  q = p.copy()
+  q[0] = np.nan
+  pd_, td = ('realization', 'time', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+  for fn, kw in ((O.crps_skill, {}), (O.unbiased_ensemble_mean_squared_error, {})):
+    got = fn(q, pd_, t, td, 'realization', skipna_ensemble=True, **kw)[0]
+    np.testing.assert_allclose(got, fn(p[1:], pd_, t, td, 'realization')[0], rtol=1e-12)
+  np.testing.assert_allclose(O.crps_spread(q, pd_, 'realization', fair=fair, skipna_ensemble=True)[0],
+                             O.crps_spread(p[1:], pd_, 'realization', fair=fair)[0], rtol=1e-12)
+  np.testing.assert_allclose(O.ensemble_variance(q, pd_, 'realization', skipna_ensemble=True)[0],
+                             O.ensemble_variance(p[1:], pd_, 'realization')[0], rtol=1e-12)
+  with pytest.raises(ValueError, match='not supported with use_sort=True'):
+    O.crps_spread(q, pd_, 'realization', use_sort=True, skipna_ensemble=True)
