@@ -121,10 +121,13 @@ typedef struct wbx_s1_plan {
   int32_t reserved_;
   const double* x_weights; /* NULL, or DEVICE float64[nx]: every lane of the point at x is multiplied by x_weights[x] inside
                               stage 1 and x is SUMMED there (x_kept = 0) -- for weights that depend on the innermost dim
-                              only and no bins (GridAreaWeighting on latitude-fastest data).  wbx_det_partial, fp32, no
-                              mask / skipna, with plane_rows = R > 0, R % 4 == 0: the R contiguous, 16-B aligned depth
-                              rows are streamed as one flat float4 array (element e takes x_weights[e mod nx]);
-                              depth_chunk % 4 == 0, ndepth % R == 0, nx <= 2045. */
+                              only and no bins (GridAreaWeighting on latitude-fastest data); count lanes (mask / skipna)
+                              take the weight too.  Always with plane_rows = R > 0 (R contiguous depth rows form one span,
+                              ndepth % R == 0) and fp32 inputs.  wbx_det_partial (no flag, or WBX_FLAG_MASKED with a mask
+                              stored like the data): R % 4 == 0, 16-B aligned spans streamed as one flat float4 array
+                              (element e takes x_weights[e mod nx]), depth_chunk % 4 == 0, nx <= 2045.  wbx_ens_partial
+                              (any of FAIR / MASKED / SKIPNA, not SKIPNA_ENS): one point per lane walks the flat index,
+                              any R, nx <= 2048. */
 } wbx_s1_plan;
 
 /* number of fp64 values stage 1 writes: nkey * nchunk * nlanes_total * nj, layout partial[key][chunk][lane][j].
