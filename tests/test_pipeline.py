@@ -220,3 +220,29 @@ def test_deferred_ensemble_reductions_alternate_streams(backend):
   for g, w in zip(got, want):
     for k in w:
       xr.assert_allclose(g[k], w[k], rtol=1e-12, atol=1e-15)
+
+
+def test_ensemble_chunk_loop_with_feeder_and_two_launch_streams(backend):
+  """evaluate_chunks on an ensemble workload with prefetch=1: the feeder's copy stream, the deferred read-back and the
+  two alternating launch streams work together; chunked == one chunk == serial loading."""
+  from weatherbenchx_amd import engine, weighting
+  from weatherbenchx_amd.metrics import probabilistic
+  predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-04T00', lead_start_days=0,
+                                               lead_stop_days=1, random=True, seed=7, ensemble_size=5)
+  targets = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-06T00', random=True, seed=8)
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  load = _loader(predictions, targets)
+  metrics = {'crps': probabilistic.CRPSEnsemble(ensemble_dim='realization', use_sort=True),
+             'ssr': probabilistic.UnbiasedSpreadSkillRatio(ensemble_dim='realization'),
+             'rank': probabilistic.RankHistogram(ensemble_dim='realization')}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  whole = time_chunks.TimeChunks(init_times, lead_times)
+  pieces = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+  want = pipeline.evaluate_chunks(whole, load, metrics, agg)[None].metric_values(metrics)
+  serial = pipeline.evaluate_chunks(pieces, load, metrics, agg)[None].metric_values(metrics)
+  fed = pipeline.evaluate_chunks(pieces, load, metrics, agg, prefetch=1)[None].metric_values(metrics)
+  assert len(engine._stream_ring) == 2  # the chunk loop ran under deferred_results(): ensemble launches alternated
+  for k in want:
+    xr.assert_allclose(serial[k], want[k], rtol=1e-9, atol=1e-12, check_dim_order=False)
+    xr.assert_allclose(fed[k], serial[k], rtol=1e-12, atol=0, check_dim_order=False)
