@@ -99,3 +99,76 @@ def test_random_layouts_and_aggregators(backend, seed):
     assert set(got_s.dims) == set(out_dims), (got_s.dims, out_dims)
     np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_ensemble_layouts_and_aggregators(backend, seed):
+  """The ensemble family on random layouts: the member dim anywhere in the prediction's dim order, targets in another
+  order, random reduce sets, vector weights, boolean bins, masks / skipna -- whatever route the planner picks (x summed,
+  x kept, flat folded weights, membership bits) must reproduce the float64 restatement."""
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(5000 + seed)
+  ndim = int(rng.integers(1, 5))
+  dims = list(rng.permutation([d for d in ALL_DIMS if d != 'tile'])[:ndim])
+  sizes = {d: int(rng.integers(1, 6)) for d in dims}
+  if rng.random() < 0.5:
+    sizes[dims[-1]] = int(rng.choice([4, 64, 65, 130]))
+  m = int(rng.choice([2, 4, 5, 9]))
+  pdims = list(dims)
+  pdims.insert(int(rng.integers(0, ndim + 1)), 'number')
+  psizes = dict(sizes, number=m)
+  tperm = list(rng.permutation(dims))
+  tv = rng.normal(size=[sizes[d] for d in tperm]).astype(np.float32)
+  pv = rng.normal(size=[psizes[d] for d in pdims]).astype(np.float32)
+  mode = rng.choice(['plain', 'masked', 'skipna'])
+  if mode != 'plain' and tv.size > 1:
+    tv.reshape(-1)[int(rng.integers(0, tv.size))] = np.nan
+  t = xr.DataArray(tv, dims=tperm)
+  p = xr.DataArray(pv, dims=pdims)
+  mask_arr = None
+  if mode == 'masked':
+    mask_arr = ~np.isnan(tv) & (rng.random(tv.shape) > 0.2)
+    t.coords['mask'] = xr.DataArray(mask_arr, dims=tperm)
+  reduce_dims = [d for d in dims if rng.random() < 0.6]
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.3:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  bins, oracle_b = [], []
+  if rng.random() < 0.5:
+    bd = list(rng.permutation(dims)[:int(rng.integers(1, min(2, ndim) + 1))])
+    nb = int(rng.choice([2, 6, 9]))
+    bm = rng.random([nb] + [sizes[d] for d in bd]) > 0.4
+    bins.append(RandomBins('bin0', bd, bm))
+    oracle_b.append(('bin0', bm, ('bin0',) + tuple(bd)))
+  use_sort = bool(rng.random() < 0.7)
+  fair = bool(rng.random() < 0.7)
+  stats = {'skill': probabilistic.CRPSSkill(), 'spread': probabilistic.CRPSSpread(use_sort=use_sort, fair=fair),
+           'var': probabilistic.EnsembleVariance(), 'uemse': probabilistic.UnbiasedEnsembleMeanSquaredError()}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, bin_by=bins or None,
+                               masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+  computed = {k: s.compute({'v': p}, {'v': t}) for k, s in stats.items()}
+  state = agg.aggregate_statistics(computed)
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(tperm))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  pd_, td = tuple(pdims), tuple(tperm)
+  want = {'skill': O.crps_skill(pv, pd_, tv, td, 'number'), 'spread': O.crps_spread(pv, pd_, 'number', fair=fair, use_sort=use_sort),
+          'var': O.ensemble_variance(pv, pd_, 'number'), 'uemse': O.unbiased_ensemble_mean_squared_error(pv, pd_, tv, td, 'number')}
+  for k, (vals, vdims) in want.items():
+    got_s, got_w = state.sum_weighted_statistics[k].get('v'), state.sum_weights[k].get('v')
+    full_dims = O.union_dims(vdims, td) if mode == 'masked' else vdims
+    vals_full = np.broadcast_to(O.expand_to(vals, vdims, full_dims), [sizes[d] for d in full_dims])
+    ref = O.aggregate(vals_full, full_dims, reduce_dims, weights=oracle_w, bin_masks=oracle_b, **okw)
+    if ref is None:
+      assert got_s is None, k
+      continue
+    assert got_s is not None, k
+    sws, sw, out_dims = ref
+    assert set(got_s.dims) == set(out_dims), (k, got_s.dims, out_dims)
+    np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
