@@ -172,3 +172,67 @@ def test_random_ensemble_layouts_and_aggregators(backend, seed):
     assert set(got_s.dims) == set(out_dims), (k, got_s.dims, out_dims)
     np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9, err_msg=k)
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_random_indicator_layouts_and_aggregators(backend, seed):
+  """ErrorExceedance / EnsembleErrorExceedance / RankHistogram on random layouts (member dim anywhere, targets in another
+  order), random reduce sets, weights, masks / skipna, NaN members and NaN thresholds, against the oracle."""
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(9000 + seed)
+  ndim = int(rng.integers(1, 4))
+  dims = list(rng.permutation(['lead_time', 'level', 'latitude', 'longitude'])[:ndim])
+  sizes = {d: int(rng.integers(1, 6)) for d in dims}
+  if rng.random() < 0.5:
+    sizes[dims[-1]] = int(rng.choice([64, 65, 130]))
+  m = int(rng.choice([2, 3, 5, 8]))
+  pdims = list(dims)
+  pdims.insert(int(rng.integers(0, ndim + 1)), 'number')
+  psizes = dict(sizes, number=m)
+  tperm = list(rng.permutation(dims))
+  tv = rng.normal(size=[sizes[d] for d in tperm]).astype(np.float32)
+  pv = (rng.normal(size=[psizes[d] for d in pdims]) * 1.5).astype(np.float32)
+  if pv.size > 4:
+    pv.reshape(-1)[int(rng.integers(0, pv.size))] = np.nan  # a NaN member somewhere: skipped by the member mean
+  mode = rng.choice(['plain', 'masked', 'skipna'])
+  if mode != 'plain' and tv.size > 1:
+    tv.reshape(-1)[int(rng.integers(0, tv.size))] = np.nan
+  t = xr.DataArray(tv, dims=tperm)
+  p = xr.DataArray(pv, dims=pdims)
+  mask_arr = None
+  if mode == 'masked':
+    mask_arr = ~np.isnan(tv) & (rng.random(tv.shape) > 0.2)
+    t.coords['mask'] = xr.DataArray(mask_arr, dims=tperm)
+  reduce_dims = [d for d in dims if rng.random() < 0.6]
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.3:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  thresholds = [0.3, float('nan'), 1.5] if rng.random() < 0.5 else [0.1, 0.7, 1.2, 2.5, 4.0]
+  stats = {'exc': probabilistic.EnsembleErrorExceedance(thresholds), 'rank': probabilistic.RankHistogram()}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, masked=(mode == 'masked'),
+                               skipna=(mode == 'skipna'))
+  state = agg.aggregate_statistics({k: s.compute({'v': p}, {'v': t}) for k, s in stats.items()})
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(tperm))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  pd_, td = tuple(pdims), tuple(tperm)
+  with np.errstate(invalid='ignore'):
+    want = {'exc': O.ensemble_error_exceedance(pv, pd_, tv, td, thresholds, 'number'),
+            'rank': O.rank_histogram(pv, pd_, tv, td, 'number')}
+  for k, (vals, vdims) in want.items():
+    got_s, got_w = state.sum_weighted_statistics[k].get('v'), state.sum_weights[k].get('v')
+    ref = O.aggregate(vals, vdims, reduce_dims, weights=oracle_w, **okw)
+    assert ref is not None and got_s is not None, k
+    sws, sw, out_dims = ref
+    assert set(got_s.dims) == set(out_dims), (k, got_s.dims, out_dims)
+    gs = got_s.transpose(*out_dims).values
+    # a cell without any valid point: the reference's sum is 0 and its mean 0 / 0; the product reports NaN for a
+    # NaN-threshold category there already in the sum -- the mean (and every combined state) is NaN either way
+    empty = np.broadcast_to(sw == 0, sws.shape)
+    np.testing.assert_allclose(np.where(empty, np.nan, gs), np.where(empty, np.nan, sws), rtol=1e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
