@@ -119,7 +119,8 @@ def _cat_lanes(plan, devs, cat):
   ae = np.abs(members - t)
   n = (~np.isnan(ae)).sum(axis=-1).astype(np.float64)
   thresholds = np.asarray(thr.ptr, dtype=np.float64)
-  return [(ae > thresholds[k]).sum(axis=-1) / np.where(n > 0, n, np.nan) for k in range(ncat)]
+  return [np.where(np.isnan(thresholds[k]), np.nan, (ae > thresholds[k]).sum(axis=-1) / np.where(n > 0, n, np.nan))
+          for k in range(ncat)]  # NaN threshold: NaN indicator (deterministic.py:293-294)
 
 
 def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None):

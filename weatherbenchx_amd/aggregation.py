@@ -369,11 +369,8 @@ class Aggregator:
     _resolve_now()  # the lanes are stacked on the host
     v = np.stack([np.asarray(a, np.float64) for a in values], axis=0)
     c = np.stack([np.asarray(a, np.float64) for a in counts], axis=0)
-    nan_cat = stat.nan_categories()
-    if nan_cat.any():  # deterministic.py:293-294: NaN thresholds make the statistic NaN (counted out under skipna)
-      v[nan_cat] = 0.0 if skipna else np.nan
-      if skipna:
-        c[nan_cat] = 0.0
+    # NaN thresholds (deterministic.py:293-294) are NaN indicators inside the kernel already: poisoned sums, or counted
+    # out under skipna, exactly where a valid point is involved
     dims_in = (cat_dim,) + tuple(out_dims)
     final_dims = tuple(d for d in stat.dims if d in dims_in) + tuple(bin_dims)
     coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(final_dims) and k != 'mask'}  # pylint: disable=protected-access

@@ -2,7 +2,7 @@
 //
 // Reference semantics restated:
 //   ErrorExceedance (weatherbenchX/metrics/deterministic.py:262-295)
-//       out[.., k] = float(|p - t| > thr_k), NaN where |p - t| is NaN (NaN thresholds are patched in by the host)
+//       out[.., k] = float(|p - t| > thr_k), NaN where |p - t| or thr_k is NaN
 //   EnsembleErrorExceedance (weatherbenchX/metrics/probabilistic.py:836-861)
 //       the mean over members of the above, NaN members skipped (xarray's default skipna), NaN if every member is NaN
 //   RankHistogram (weatherbenchX/metrics/probabilistic.py:1306-1343)
@@ -92,9 +92,12 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       if (k0 + q < nc) {
-        const double v = (double)cnt[q] * inv;
+        // deterministic.py:293-294: a NaN threshold makes the indicator NaN -- at valid points only, so a cell whose
+        // points are all masked out still sums to 0 (aggregation.py:339-352)
+        const bool thr_ok = thr[q] == thr[q];
+        const double v = thr_ok ? (double)cnt[q] * inv : NAN;
         if (skipna) {  // aggregation.py:353-355: NaN statistics are counted out, lane by lane
-          const bool ok = valid && n > 0;
+          const bool ok = valid && n > 0 && thr_ok;
           col[(k0 + q) * stride] += ok ? v : 0.0;
           col[(nc + k0 + q) * stride] += ok ? 1.0 : 0.0;
         } else {       // aggregation.py:339-352: masked-out points contribute 0; a NaN under a valid point poisons

@@ -362,11 +362,6 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
   def ncat(self) -> int:
     return int(self._group.cat['ncat'])
 
-  def nan_categories(self) -> np.ndarray:
-    """Categories whose threshold is NaN: the reference makes the statistic NaN there (deterministic.py:293-294)."""
-    thr = self._group.cat.get('thresholds')
-    return np.zeros(self.ncat, bool) if thr is None else np.isnan(np.asarray(thr, np.float64))
-
   @property
   def data(self):
     if self._data is None:
@@ -374,7 +369,6 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
       values, _, out_dims = grp.reduce((), None, (), use_mask=False, skipna=False)
       arr = np.stack([np.asarray(v, np.float64) for v in values], axis=-1)
       arr = np.transpose(arr, [out_dims.index(d) for d in grp.dims] + [len(out_dims)])
-      arr[..., self.nan_categories()] = np.nan
       self._data = np.ascontiguousarray(arr)
     return self._data
 
