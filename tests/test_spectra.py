@@ -129,3 +129,20 @@ def test_spectra_under_deferred_results(backend):
     got = [s.metric_values(metrics)['spec.v'].values.copy() for s in states]
   for g, w in zip(got, want):
     np.testing.assert_allclose(g, w, rtol=1e-10)  # fp64 atomics: the order of the adds differs from run to run
+
+
+@pytest.mark.parametrize('nlon', [96, 250, 540, 600, 750, 972, 1000, 1458, 2048, 2046])
+def test_row_lengths_exercise_every_first_pass_radix_and_table_layout(backend, nlon):
+  """Row lengths whose half length starts with each radix (4: 600, 1000, 2048; 2: 540, 972; 5: 750; 3: 1458), short rows
+  on one-wave / two-wave teams (96, 250), the longest supported row (2048: 3 mirrored wavenumbers per thread) and a
+  non-smooth length on the library route (2046 = 2 * 3 * 11 * 31): per-row spectra of 5 rows (odd: a lone last row)
+  against numpy's float64 rfft."""
+  rng = np.random.default_rng(nlon)
+  vals = (rng.normal(size=(5, nlon)) + 3.0).astype(np.float32)
+  f = xr.DataArray(vals, dims=('latitude', 'longitude'),
+                   coords={'latitude': np.linspace(-40, 40, 5), 'longitude': np.arange(nlon) * (360.0 / nlon)})
+  stat = spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v']
+  got = np.asarray(stat.values)
+  want = O.zonal_power_spectrum(vals)
+  assert got.shape == (5, nlon // 2 + 1)
+  np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * want.max())
