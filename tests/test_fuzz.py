@@ -232,3 +232,60 @@ def test_random_indicator_layouts_and_aggregators(backend, seed):
     assert set(got_s.dims) == set(out_dims), (k, got_s.dims, out_dims)
     np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9, err_msg=k)
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_random_layouts_through_every_bin_route(monkeypatch, seed):
+  """Host logic only (NumPy plan interpreter): with >= 5 boolean bins the engine may contract membership bits in stage 2
+  or run the one-pass binned route; forcing either must give the oracle's sums on random layouts, reduce sets, weights
+  and masks (which dims end up as key / depth / x differs from case to case)."""
+  import fake_device
+  from weatherbenchx_amd import engine
+  fake_device.install(monkeypatch)
+  rng = np.random.default_rng(7000 + seed)
+  ndim = int(rng.integers(2, 6))
+  dims = list(rng.permutation(ALL_DIMS)[:ndim])
+  sizes = {d: int(rng.integers(1, 7)) for d in dims}
+  sizes[dims[-1]] = int(rng.choice([3, 8, 64, 70]))
+  shape = [sizes[d] for d in dims]
+  pv = rng.normal(size=shape).astype(np.float32)
+  tperm = list(rng.permutation(dims))
+  tv = rng.normal(size=[sizes[d] for d in tperm]).astype(np.float32)
+  mode = rng.choice(['plain', 'masked', 'skipna'])
+  if mode != 'plain':
+    pv[tuple(int(rng.integers(0, s)) for s in shape)] = np.nan
+  p = xr.DataArray(pv, dims=dims)
+  t = xr.DataArray(tv, dims=tperm)
+  mask_arr = None
+  if mode == 'masked':
+    mask_arr = ~np.isnan(pv) & (rng.random(shape) > 0.2)
+    p.coords['mask'] = xr.DataArray(mask_arr, dims=dims)
+  bd = list(rng.permutation(dims)[:int(rng.integers(1, 3))])
+  nb = int(rng.choice([5, 9, 34]))
+  bm = rng.random([nb] + [sizes[d] for d in bd]) > 0.5
+  reduce_dims = sorted(set(bd) | {d for d in dims if rng.random() < 0.5}, key=dims.index)
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.4:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  te = O.expand_to(tv, tuple(tperm), tuple(dims))
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(dims))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  want = O.aggregate(O.squared_error(pv, te), tuple(dims), reduce_dims, weights=oracle_w,
+                     bin_masks=[('bin0', bm, ('bin0',) + tuple(bd))], **okw)
+  sws, sw, out_dims = want
+  for route in ('never', 'always'):
+    monkeypatch.setattr(engine, 'BINNED_MODE', route)
+    engine.clear_caches()
+    agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, bin_by=[RandomBins('bin0', bd, bm)],
+                                 masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+    stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'v': p}, {'v': t})
+    state = agg.aggregate_statistics(stats)
+    got_s, got_w = state.sum_weighted_statistics['SquaredError']['v'], state.sum_weights['SquaredError']['v']
+    np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9, err_msg=route)
+    np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=route)
