@@ -289,3 +289,38 @@ def test_random_layouts_through_every_bin_route(monkeypatch, seed):
     got_s, got_w = state.sum_weighted_statistics['SquaredError']['v'], state.sum_weights['SquaredError']['v']
     np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9, err_msg=route)
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=route)
+
+
+@pytest.mark.parametrize('seed', range(25))
+def test_random_spectrum_frames(monkeypatch, seed):
+  """Host logic only: longitude anywhere in the dim order, random kept dims, vector weights on row dims -- the row
+  weights / group ids handed to the spectrum reduction must reproduce the weighted mean of the per-row spectra."""
+  import fake_device
+  from weatherbenchx_amd import spectra
+  fake_device.install(monkeypatch)
+  rng = np.random.default_rng(11000 + seed)
+  row_dims = list(rng.permutation(['lead_time', 'level', 'latitude'])[:int(rng.integers(1, 4))])
+  dims = list(row_dims)
+  dims.insert(int(rng.integers(0, len(dims) + 1)), 'longitude')
+  sizes = {d: int(rng.integers(1, 5)) for d in row_dims}
+  sizes['longitude'] = int(rng.choice([8, 12, 30]))
+  vals = rng.normal(size=[sizes[d] for d in dims]).astype(np.float32)
+  coords = {'longitude': np.arange(sizes['longitude']) * (360.0 / sizes['longitude'])}
+  if 'latitude' in sizes:
+    coords['latitude'] = np.linspace(-60, 60, sizes['latitude']) if sizes['latitude'] > 1 else np.array([10.0])
+  f = xr.DataArray(vals, dims=dims, coords=coords)
+  reduce_dims = [d for d in row_dims if rng.random() < 0.6] or row_dims[:1]
+  weights, oracle_w = [], []
+  for d in row_dims:
+    if rng.random() < 0.4:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  stat = spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v']
+  state = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None).aggregate_stat_var(stat)
+  lon_ax = dims.index('longitude')
+  per_row = np.moveaxis(O.zonal_power_spectrum(vals, lon_axis=lon_ax), lon_ax, -1)  # rows in `dims` order, then k
+  rd = tuple(d for d in dims if d != 'longitude') + ('zonal_wavenumber',)
+  sws, sw, out_dims = O.aggregate(per_row, rd, reduce_dims, weights=oracle_w)
+  np.testing.assert_allclose(state.sum_weighted_statistics.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9)
+  np.testing.assert_allclose(state.sum_weights.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12)
