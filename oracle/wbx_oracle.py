@@ -156,6 +156,14 @@ def _move_member_last(p, p_dims, ensemble_dim):
   return np.moveaxis(f64(p), ax, -1), tuple(d for d in p_dims if d != ensemble_dim)
 
 
+def _abs_error_per_member(p, p_dims, t, t_dims, ensemble_dim):
+  """|p_m - t| with the member axis last, over the union of the other dims."""
+  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
+  out_dims = union_dims(dims, t_dims)
+  pe = expand_to(pm, dims + (ensemble_dim,), out_dims + (ensemble_dim,))
+  return np.abs(pe - expand_to(f64(t), t_dims, out_dims)[..., None]), out_dims
+
+
 def _nanmean_last(x):
   """xarray's mean(skipna=True): NaNs are left out, an all-NaN slice gives NaN (quietly)."""
   ok = ~np.isnan(x)
@@ -175,7 +183,23 @@ def _nanvar_last(x, ddof=1):
 
 
 def crps_skill(p, p_dims, t, t_dims, ensemble_dim, skipna_ensemble=False):
-  """probabilistic.py:116-145: mean_m |p_m - t|; skipna_ensemble -> the mean skips NaN members (:143-145)."""
+  """probabilistic.py:116-145: mean_m |p_m - t|; skipna_ensemble -> the mean skips NaN members (:143-145).  Targets that
+  carry the ensemble dim too (:133-142): the mean runs over every (prediction member, target member) pair."""
+  if ensemble_dim in t_dims:
+    tm, tdims = _move_member_last(t, t_dims, ensemble_dim)
+    acc, out_dims = None, None
+    cnt = None
+    for j in range(tm.shape[-1]):  # one target member at a time: no M x M' x grid temporary
+      pe, out_dims = _abs_error_per_member(p, p_dims, tm[..., j], tdims, ensemble_dim)
+      if skipna_ensemble:
+        ok = ~np.isnan(pe)
+        acc = np.where(ok, pe, 0.0).sum(axis=-1) + (0.0 if acc is None else acc)
+        cnt = ok.sum(axis=-1) + (0 if cnt is None else cnt)
+      else:
+        acc = pe.sum(axis=-1) + (0.0 if acc is None else acc)
+    n_p = np.shape(p)[p_dims.index(ensemble_dim)]
+    with np.errstate(invalid='ignore', divide='ignore'):
+      return (acc / np.where(cnt > 0, cnt, np.nan) if skipna_ensemble else acc / (n_p * tm.shape[-1])), out_dims
   pm, dims = _move_member_last(p, p_dims, ensemble_dim)
   out_dims = union_dims(dims, t_dims)
   pe = expand_to(pm, dims + (ensemble_dim,), out_dims + (ensemble_dim,))
@@ -352,6 +376,11 @@ def acc(mean_cov, mean_spa, mean_sta):
 
 def crps(mean_skill, mean_spread):
   return mean_skill - 0.5 * mean_spread
+
+
+def crps_ensemble_distance(mean_skill, mean_spread, mean_target_spread):
+  """probabilistic.py:773-782: E|X - Y| - E|X - X'| / 2 - E|Y - Y'| / 2 from the three mean statistics."""
+  return mean_skill - 0.5 * mean_spread - 0.5 * mean_target_spread
 
 
 def unbiased_spread_skill_ratio(mean_var, mean_uemse):

@@ -219,3 +219,28 @@ def test_skipna_ensemble_with_an_all_nan_member_equals_dropping_it(m, fair):
                              O.ensemble_variance(p[1:], pd_, 'realization')[0], rtol=1e-12)
   with pytest.raises(ValueError, match='not supported with use_sort=True'):
     O.crps_spread(q, pd_, 'realization', use_sort=True, skipna_ensemble=True)
+
+
+@pytest.mark.parametrize('m,use_sort,fair', list(itertools.product([4, 5], [False, True], [True, False])))
+def test_crps_ensemble_distance_between_equal_distributions(m, use_sort, fair):
+  # metrics_test.py:662-752: predictions (M members) and targets (M + 1 members) from the same N(0, 1): the fair distance
+  # is ~0 within 5 standard errors; targets without spread (every member the same) reproduce the plain CRPS.
+  rng = np.random.default_rng(100 + m)
+  shape = (3, 19, 36)
+  p = rng.normal(size=shape + (m,))
+  t = rng.normal(size=shape + (m + 1,))
+  pd_ = ('time', 'latitude', 'longitude', 'realization')
+  red = ['time', 'latitude', 'longitude']
+  mean = lambda vals, dims: (lambda r: r[0] / r[1])(O.aggregate(vals, dims, red))
+  spread_p = mean(*O.crps_spread(p, pd_, 'realization', fair=fair, use_sort=use_sort))
+  dist = O.crps_ensemble_distance(mean(*O.crps_skill(p, pd_, t, pd_, 'realization')), spread_p,
+                                  mean(*O.crps_spread(t, pd_, 'realization', fair=fair, use_sort=use_sort)))
+  stderr = 1 / np.sqrt(np.prod([m * n for n in shape]))
+  if fair:
+    np.testing.assert_allclose(dist, 0, atol=5 * stderr)
+  t_flat = np.repeat(t[..., :1], m + 1, axis=-1)  # no spread among the targets
+  no_spread = O.crps_ensemble_distance(mean(*O.crps_skill(p, pd_, t_flat, pd_, 'realization')), spread_p,
+                                       mean(*O.crps_spread(t_flat, pd_, 'realization', fair=fair, use_sort=use_sort)))
+  plain = O.crps(mean(*O.crps_skill(p, pd_, t[..., 0], pd_[:3], 'realization')), spread_p)
+  np.testing.assert_allclose(no_spread, plain, atol=5 * stderr)
+  np.testing.assert_allclose(no_spread, plain, rtol=1e-12)  # identical in fact: the target spread term is exactly 0
