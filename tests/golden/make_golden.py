@@ -70,6 +70,39 @@ def ensembles():
   np.savez_compressed(os.path.join(HERE, 'ensemble_19x36.npz'), **out)
 
 
+def skipna_ensembles():
+  """skipna_ensemble=True with NaNs scattered over members (per-point member counts, probabilistic.py:206-216, :304-314)
+  and the CRPS ensemble distance against ensemble-valued targets (probabilistic.py:691-782), 19x36 grid, M = 6 / 4."""
+  lat = np.linspace(-90, 90, 19)
+  rng = np.random.default_rng(321)
+  t = rng.normal(size=(2, 19, 36)).astype(np.float32)
+  p = (t[:, None] + rng.normal(size=(2, 6, 19, 36))).astype(np.float32)
+  p[rng.random(p.shape) < 0.15] = np.nan
+  p[1, :, 3, 4] = np.nan   # no member left
+  p[1, 1:, 5, 6] = np.nan  # a single member left
+  te = (t[:, None] + rng.normal(size=(2, 4, 19, 36))).astype(np.float32)  # ensemble-valued targets
+  q = np.where(np.isnan(p), 0.0, p).astype(np.float32)                     # NaN-free predictions for the distance
+  pd, td = ('time', 'realization', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+  w = (O.grid_area_weights(lat), ('latitude',))
+  out = {'latitude': lat, 'p': p, 't': t, 'te': te, 'q': q}
+  with np.errstate(invalid='ignore', divide='ignore'):
+    lanes = {'CRPSSkill': O.crps_skill(p, pd, t, td, 'realization', skipna_ensemble=True)[0],
+             'CRPSSpread_fair': O.crps_spread(p, pd, 'realization', fair=True, skipna_ensemble=True)[0],
+             'CRPSSpread_unfair': O.crps_spread(p, pd, 'realization', fair=False, skipna_ensemble=True)[0],
+             'EnsembleVariance': O.ensemble_variance(p, pd, 'realization', skipna_ensemble=True)[0],
+             'UnbiasedEnsembleMeanSquaredError': O.unbiased_ensemble_mean_squared_error(p, pd, t, td, 'realization',
+                                                                                        skipna_ensemble=True)[0]}
+    for k, v in lanes.items():
+      sws, sw, _ = O.aggregate(v, td, ['latitude', 'longitude'], weights=[w], skipna=True)
+      out[f'skipna__{k}__sws'], out[f'skipna__{k}__sw'] = sws, sw
+  mean = lambda v: (lambda r: r[0] / r[1])(O.aggregate(v, td, ['latitude', 'longitude'], weights=[w]))
+  for fair in (True, False):
+    out[f'distance__fair{int(fair)}'] = O.crps_ensemble_distance(
+        mean(O.crps_skill(q, pd, te, pd, 'realization')[0]), mean(O.crps_spread(q, pd, 'realization', fair=fair)[0]),
+        mean(O.crps_spread(te, pd, 'realization', fair=fair)[0]))
+  np.savez_compressed(os.path.join(HERE, 'skipna_ensemble_19x36.npz'), **out)
+
+
 def regions_and_indicators():
   """32x64 grid, 7 regions x land/sea = 14 bins (the public benchmark's binning, run_benchmark_evaluation.py:369-382,
   at test size) with NaN targets under masked=True; ErrorExceedance / EnsembleErrorExceedance / RankHistogram
@@ -124,4 +157,5 @@ if __name__ == '__main__':
   ensembles()
   weights_and_spectrum()
   regions_and_indicators()
+  skipna_ensembles()
   print('golden vectors written to', HERE)
