@@ -1,0 +1,181 @@
+"""Result / upload caches must never serve numbers computed from other inputs: a changed weigh_by / bin_by, an
+aggregator at a recycled address, payloads or coordinates edited in place.  The reference rebuilds everything on every
+call (aggregation.py:297-366), so any cache here has to be invisible."""
+import gc
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation, binning, weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic, probabilistic
+
+LAT = np.linspace(-87.1875, 87.1875, 32)
+LON = np.arange(64) * 5.625
+DIMS = ('lead_time', 'latitude', 'longitude')
+REGIONS_A = {'global': ((-90, 90), (0, 360)), 'nh': ((20, 90), (0, 360))}
+REGIONS_B = {'global': ((-90, 90), (0, 360)), 'sh': ((-90, -20), (0, 360))}
+
+
+def _fields(seed=0):
+  rng = np.random.default_rng(seed)
+  coords = {'latitude': LAT, 'longitude': LON}
+  p = xr.DataArray(rng.normal(size=(3, 32, 64)).astype(np.float32), dims=DIMS, coords=coords)
+  t = xr.DataArray(rng.normal(size=(3, 32, 64)).astype(np.float32), dims=DIMS, coords=coords)
+  return p, t
+
+
+def _oracle_mse(p, t, regions=None, weights=True, mask=None):
+  se = O.squared_error(np.asarray(p.values, np.float64), np.asarray(t.values, np.float64))
+  kw = {}
+  if regions is not None:
+    names, masks = O.region_masks(LAT, LON, regions)
+    kw['bin_masks'] = [('region', masks, ('region', 'latitude', 'longitude'))]
+  if weights:
+    kw['weights'] = [(O.grid_area_weights(LAT), ('latitude',))]
+  if mask is not None:
+    kw.update(mask=mask, mask_dims=DIMS)
+  sws, sw, od = O.aggregate(se, DIMS, ['latitude', 'longitude'], **kw)
+  return sws / sw, od
+
+
+def _mse(agg, p, t):
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'v': p}, {'v': t})
+  return agg.aggregate_statistics(stats).metric_values({'mse': deterministic.MSE()})['mse.v']
+
+
+def test_reassigned_plugins_are_honoured_on_the_same_statistics(backend):
+  p, t = _fields()
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS_A)])
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'v': p}, {'v': t})
+  first = agg.aggregate_statistics(stats).mean_statistics()['SquaredError']['v']
+  want_a, od = _oracle_mse(p, t, REGIONS_A)
+  np.testing.assert_allclose(first.transpose(*od).values, want_a, rtol=1e-9)
+  agg.bin_by = [binning.Regions(REGIONS_B)]  # same shapes, other content: the SAME statistic objects are re-aggregated
+  second = agg.aggregate_statistics(stats).mean_statistics()['SquaredError']['v']
+  want_b, od = _oracle_mse(p, t, REGIONS_B)
+  np.testing.assert_allclose(second.transpose(*od).values, want_b, rtol=1e-9)
+  assert not np.allclose(want_a, want_b)
+  agg.weigh_by = None
+  third = agg.aggregate_statistics(stats).mean_statistics()['SquaredError']['v']
+  want_c, od = _oracle_mse(p, t, REGIONS_B, weights=False)
+  np.testing.assert_allclose(third.transpose(*od).values, want_c, rtol=1e-9)
+  agg.bin_by.append(binning.Regions({'tropics': ((-20, 20), (0, 360))}, bin_dim_name='band'))  # list edited in place
+  fourth = agg.aggregate_statistics(stats).mean_statistics()['SquaredError']['v']
+  assert set(fourth.dims) == {'lead_time', 'region', 'band'}
+
+
+def test_aggregator_at_a_recycled_address_gets_its_own_result(backend):
+  p, t = _fields(1)
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'mse': deterministic.MSE()}, {'v': p}, {'v': t})
+  want = {}
+  for regions in (REGIONS_A, REGIONS_B):
+    want[id(regions)] = _oracle_mse(p, t, regions)
+  seen_ids = set()
+  for _ in range(6):  # CPython hands a freed object's address to the next allocation of the same size
+    for regions in (REGIONS_A, REGIONS_B):
+      agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                                   bin_by=[binning.Regions(regions)])
+      seen_ids.add(id(agg))
+      got = agg.aggregate_statistics(stats).mean_statistics()['SquaredError']['v']
+      w, od = want[id(regions)]
+      np.testing.assert_allclose(got.transpose(*od).values, w, rtol=1e-9)
+      del agg, got
+      gc.collect()
+  del seen_ids  # (whether an address was actually reused is up to the allocator; the results may never depend on it)
+
+
+def test_payload_and_coordinates_edited_in_place(backend):
+  p, t = _fields(2)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], masked=True)
+  np.testing.assert_allclose(_mse(agg, p, t).values, _oracle_mse(p, t)[0], rtol=1e-9)
+  p[0, 0, 0] = 100.0  # through the class's own API: uploads and fused groups are dropped
+  np.testing.assert_allclose(_mse(agg, p, t).values, _oracle_mse(p, t)[0], rtol=1e-9)
+  t[{'lead_time': 1}] = t.isel(lead_time=1) + 3.0  # the targets too (the fused group lives on the predictions)
+  np.testing.assert_allclose(_mse(agg, p, t).values, _oracle_mse(p, t)[0], rtol=1e-9)
+  valid = np.ones((3, 32, 64), bool)
+  valid[:, :8] = False
+  t.coords['mask'] = xr.DataArray(valid, dims=DIMS)  # a mask coordinate added after the first use
+  np.testing.assert_allclose(_mse(agg, p, t).values, _oracle_mse(p, t, mask=valid)[0], rtol=1e-9)
+  del t.coords['mask']
+  np.testing.assert_allclose(_mse(agg, p, t).values, _oracle_mse(p, t)[0], rtol=1e-9)
+
+
+def test_climatology_edited_in_place(backend):
+  rng = np.random.default_rng(3)
+  coords = {'latitude': LAT, 'longitude': LON,
+            'init_time': np.array(['2020-01-01T00', '2020-01-02T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(2) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  dims = ('init_time', 'lead_time', 'latitude', 'longitude')
+  p = xr.DataArray(rng.normal(size=(2, 2, 32, 64)).astype(np.float32), dims=dims, coords=coords)
+  t = xr.DataArray(rng.normal(size=(2, 2, 32, 64)).astype(np.float32), dims=dims, coords=coords)
+  cv = rng.normal(size=(366, 4, 32, 64)).astype(np.float32)
+  cdims = ('dayofyear', 'hour', 'latitude', 'longitude')
+  clim = xr.Dataset({'v': xr.DataArray(cv, dims=cdims, coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'latitude': LAT, 'longitude': LON})})
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'])
+  metrics = {'act': deterministic.PredictionActivity(clim)}
+
+  def want():
+    vt = coords['init_time'][:, None] + coords['lead_time'][None, :]
+    c, _ = O.align_climatology(clim['v'].values, cdims, vt, ('init_time', 'lead_time'))
+    sws, sw, _ = O.aggregate(O.squared_prediction_anomaly(p.values, c), dims, ['init_time', 'latitude', 'longitude'])
+    return np.sqrt(sws / sw)
+  got = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p}, {'v': t})['act.v']
+  np.testing.assert_allclose(got.values, want(), rtol=1e-6)
+  clim['v'][0] = clim['v'].isel(dayofyear=0) + 5.0  # 1 January is what the first init time reads
+  got = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p}, {'v': t})['act.v']
+  np.testing.assert_allclose(got.values, want(), rtol=1e-6)
+
+
+def test_ensemble_statistics_inner_join_labeled_dims(backend):
+  """predictions - targets inner-joins labeled dims (deterministic statistics already did); the ensemble family and the
+  ensemble branch of the indicator statistics must do the same instead of failing."""
+  rng = np.random.default_rng(4)
+  times = np.arange('2020-01-01', '2020-01-05', dtype='datetime64[D]').astype('datetime64[ns]')
+  pv = rng.normal(size=(4, 5, 6)).astype(np.float32)
+  tv = rng.normal(size=(3, 6)).astype(np.float32)
+  p = xr.DataArray(pv, dims=('time', 'number', 'x'), coords={'time': times})
+  t = xr.DataArray(tv, dims=('time', 'x'), coords={'time': times[[0, 2, 3]]})  # one time missing from the targets
+  agg = aggregation.Aggregator(reduce_dims=['x'])
+  metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'rank': probabilistic.RankHistogram()}
+  got = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p}, {'v': t})
+  pj = pv[[0, 2, 3]]
+  pd, td = ('time', 'number', 'x'), ('time', 'x')
+  sk = O.aggregate(O.crps_skill(pj, pd, tv, td, 'number')[0], td, ['x'])
+  sp = O.aggregate(O.crps_spread(pj, pd, 'number', use_sort=True)[0], td, ['x'])
+  assert list(got['crps.v']['time'].values) == list(times[[0, 2, 3]])
+  np.testing.assert_allclose(got['crps.v'].values, O.crps(sk[0] / sk[1], sp[0] / sp[1]), rtol=1e-6)
+  mae = aggregation.compute_metric_values_for_single_chunk(
+      {'mae': deterministic.MAE()}, agg, {'v': p.isel(number=0, drop=True)}, {'v': t})
+  assert mae['mae.v'].shape == (3,)
+
+
+def test_member_only_statistics_ignore_the_targets_mask_and_extra_dims(backend):
+  rng = np.random.default_rng(5)
+  pv = rng.normal(size=(6, 9, 12)).astype(np.float32)
+  tv = rng.normal(size=(2, 9, 12)).astype(np.float32)  # targets carry a dim the predictions lack
+  tv[:, :3] = np.nan
+  p = xr.DataArray(pv, dims=('number', 'latitude', 'longitude'))
+  t = xr.DataArray(tv, dims=('source', 'latitude', 'longitude'))
+  t.coords['mask'] = ~np.isnan(t)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], masked=True)
+  var = probabilistic.EnsembleVariance().compute({'v': p}, {'v': t})['v']
+  assert var.dims == ('latitude', 'longitude') and 'mask' not in var.coords
+  state = agg.aggregate_stat_var(var)
+  np.testing.assert_allclose(state.mean_statistics().values, pv.astype(np.float64).var(axis=0, ddof=1).mean(), rtol=1e-9)
+  skill = probabilistic.CRPSSkill().compute({'v': p}, {'v': t})['v']
+  assert set(skill.dims) == {'source', 'latitude', 'longitude'} and 'mask' in skill.coords
+
+
+def test_lazy_mean_drops_nans_by_default(backend):
+  p, t = _fields(6)
+  p[0, 0, 0] = np.nan
+  se = deterministic.SquaredError().compute({'v': p}, {'v': t})['v']
+  want = np.nanmean((p.values.astype(np.float64) - t.values) ** 2, axis=0)
+  np.testing.assert_allclose(se.mean('lead_time').values, want, rtol=1e-9)           # default: skipna like xarray
+  np.testing.assert_allclose(se.mean('lead_time', skipna=True).values, want, rtol=1e-9)
+  assert np.isnan(se.mean('lead_time', skipna=False).values[0, 0])

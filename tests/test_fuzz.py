@@ -161,9 +161,13 @@ def test_random_ensemble_layouts_and_aggregators(backend, seed):
           'var': O.ensemble_variance(pv, pd_, 'number'), 'uemse': O.unbiased_ensemble_mean_squared_error(pv, pd_, tv, td, 'number')}
   for k, (vals, vdims) in want.items():
     got_s, got_w = state.sum_weighted_statistics[k].get('v'), state.sum_weights[k].get('v')
-    full_dims = O.union_dims(vdims, td) if mode == 'masked' else vdims
+    # spread / variance are statistics of the predictions alone: they carry the predictions' coordinates, so the
+    # targets' `mask` does not reach them and Aggregator(masked=True) leaves them unmasked like the reference
+    # (probabilistic.py:250-273 `predictions.var(...)`, aggregation.py:339-352 `'mask' in stat.coords`)
+    kw_k = {} if (mode == 'masked' and k in ('spread', 'var')) else okw
+    full_dims = O.union_dims(vdims, td) if 'mask' in kw_k else vdims
     vals_full = np.broadcast_to(O.expand_to(vals, vdims, full_dims), [sizes[d] for d in full_dims])
-    ref = O.aggregate(vals_full, full_dims, reduce_dims, weights=oracle_w, bin_masks=oracle_b, **okw)
+    ref = O.aggregate(vals_full, full_dims, reduce_dims, weights=oracle_w, bin_masks=oracle_b, **kw_k)
     if ref is None:
       assert got_s is None, k
       continue

@@ -339,7 +339,8 @@ def test_materialised_statistics_match_oracle(backend):
 
 def test_masked_and_skipna_ensemble_aggregation(backend):
   """masked=True is the public-benchmark default (run_benchmark_evaluation.py:379): the target mask coordinate must
-  reach the ensemble statistics too (aggregation.py:339-357)."""
+  reach the ensemble statistics that look at the targets (aggregation.py:339-357); the spread term only looks at the
+  predictions, carries no mask and stays unmasked, exactly as in the reference."""
   rng = np.random.default_rng(8)
   lat = np.linspace(-80, 80, 9)
   tv = rng.normal(size=(9, 12)).astype(np.float32)
@@ -358,7 +359,9 @@ def test_masked_and_skipna_ensemble_aggregation(backend):
     agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], **kw)
     res = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, {'v': t})
     a = O.aggregate(skill, td, list(td), weights=[w], **okw)
-    b = O.aggregate(spread, td, list(td), weights=[w], **(okw if 'mask' in okw else dict(skipna=True)))
+    # the spread is a statistic of the predictions alone: no `mask` coordinate reaches it, so masked=True averages it
+    # over every point, like the reference (probabilistic.py:196-247, aggregation.py:339-352)
+    b = O.aggregate(spread, td, list(td), weights=[w], **({} if 'mask' in okw else dict(skipna=True)))
     np.testing.assert_allclose(res['crps.v'].values, O.crps(a[0] / a[1], b[0] / b[1]), rtol=RTOL)
   # without either, the NaN targets poison the skill term
   agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'])
@@ -875,7 +878,8 @@ def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
   used = [pl for pl in logs[True] if pl.x_weights is not None]
   assert used and all(not pl.x_kept and pl.plane_rows == nlon for pl in used)
   # deterministic + ensemble plans; skipna keeps the deterministic family on the x-kept kernel (measured faster)
-  assert len({id(pl) for pl in used}) == {'plain': 2, 'masked': 2, 'skipna': 1}[mode]
+  # (masked: the ensemble lanes that look at the targets are masked, the member-only ones are a second, unmasked launch)
+  assert len({id(pl) for pl in used}) == {'plain': 2, 'masked': 3, 'skipna': 1}[mode]
   assert logs[False] and all(pl.x_weights is None and pl.x_kept for pl in logs[False])
   for k, v in results[False].items():
     np.testing.assert_allclose(results[True][k].values, v.values, rtol=1e-9, equal_nan=True)

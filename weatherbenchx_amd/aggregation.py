@@ -191,6 +191,11 @@ def _weight_product(stat: xr.DataArray, weigh_by, bin_by):
   return product, tuple(names)
 
 
+class _Token:
+  """Hashable by identity; kept alive by whatever cache key holds it."""
+  __slots__ = ()
+
+
 @dataclasses.dataclass
 class Aggregator:
   """Weighted / binned reduction over `reduce_dims` (aggregation.py:268-408); see the reference for the
@@ -298,38 +303,64 @@ class Aggregator:
       return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
     return AggregationState(wrap(values[lane]), wrap(counts[lane]))
 
+  def __setattr__(self, name, value):
+    # the cached weight products below belong to the configuration they were built for
+    if not name.startswith('_w_'):
+      self.__dict__.pop('_w_products', None)
+      self.__dict__.pop('_w_dep_hints', None)
+    object.__setattr__(self, name, value)
+
   def _cached_weight_product(self, stat: xr.DataArray):
     """W = prod(weights) * prod(bin masks) is rebuilt by the reference for every (statistic, variable)
     call (aggregation.py:311-330).  For the built-in coordinate-only plugins it is cached per
-    (statistic dims, coordinates of the dims W depends on)."""
+    (plugin objects, statistic dims, coordinates of the dims W depends on); assigning a new `weigh_by` / `bin_by`
+    drops the cache (`__setattr__`), and the plugin objects themselves are part of the key (a list edited in place)."""
     known = (weighting.GridAreaWeighting, binning.Regions, binning.LandSea)
-    if not all(isinstance(m, known) for m in list(self.weigh_by or []) + list(self.bin_by or [])):
+    plugins = tuple(self.weigh_by or ()) + tuple(self.bin_by or ())
+    if not all(isinstance(m, known) for m in plugins):
       return _weight_product(stat, self.weigh_by, self.bin_by)
     cache = self.__dict__.setdefault('_w_products', {})
     hints = self.__dict__.setdefault('_w_dep_hints', {})
-    frame = (stat.dims, stat.shape)
+    # ids stay unique while the cache entry holds the objects (stored next to the product)
+    who = (len(self.weigh_by or ()),) + tuple(id(m) for m in plugins)
+    frame = (who, stat.dims, stat.shape)
+
+    def key_for(dep):
+      return (frame, tuple((d, hash(np.asarray(stat._coords[d][1]).tobytes()) if d in stat._coords else None)  # pylint: disable=protected-access
+                           for d in dep))
     dep = hints.get(frame)
     if dep is not None:
-      key = (frame, tuple((d, hash(np.asarray(stat._coords[d][1]).tobytes()) if d in stat._coords else None)  # pylint: disable=protected-access
-                          for d in dep))
-      if key in cache:
-        return cache[key]
+      hit = cache.get(key_for(dep))
+      if hit is not None:
+        return hit[0]
     wp = _weight_product(stat, self.weigh_by, self.bin_by)
     if wp is None:
       return None
     w_da, bin_dims = wp
     dep = tuple(d for d in (w_da.dims if w_da is not None else ()) if d not in bin_dims)
-    hints[frame] = dep
-    key = (frame, tuple((d, hash(np.asarray(stat._coords[d][1]).tobytes()) if d in stat._coords else None)  # pylint: disable=protected-access
-                        for d in dep))
     if len(cache) > 16:
       cache.clear()
-    cache[key] = wp
+      hints.clear()
+    hints[frame] = dep
+    cache[key_for(dep)] = (wp, plugins)
     return wp
 
+  @staticmethod
+  def _w_token(w_da):
+    """Identity of a weight product for result caches: a token object that lives and dies with `w_da` (an id() could be
+    reused by a later, different W; a content hash of a 721 x 1440 x 34 product would cost more than the reduction)."""
+    if w_da is None:
+      return None
+    tok = w_da.__dict__.get('_wbx_token')
+    if tok is None:
+      tok = w_da.__dict__['_wbx_token'] = _Token()
+    return tok
+
   def _cache_key(self, w_da, bin_dims, use_mask, skipna, extra=()):
-    return (id(self), tuple(sorted(self.reduce_dims)), use_mask, skipna, tuple(bin_dims),
-            None if w_da is None else (w_da.dims, w_da.shape), extra)
+    """Key of a finished fused reduction on its FusedGroup: everything the sums depend on besides the group's inputs.
+    W enters through its token, so an aggregator whose weigh_by / bin_by changed, or another aggregator that happens to
+    sit at a recycled address, can never be served sums computed with a different W."""
+    return (tuple(sorted(self.reduce_dims, key=str)), use_mask, skipna, tuple(bin_dims), self._w_token(w_da), extra)
 
   def _reduce_lazy(self, stat: lazy.LazyStatistic, w_da, bin_dims, use_mask, skipna):
     grp = stat._group  # pylint: disable=protected-access
@@ -358,7 +389,9 @@ class Aggregator:
     scale = 1.0
     for d in mean_dims:  # mean over d == sum over d / n; the count carries the same factor
       scale /= grp.sizes[d]
-    return values, counts, out_dims, grp.coords, stat._lane, scale  # pylint: disable=protected-access
+    names = stat._coord_names  # pylint: disable=protected-access
+    frame_coords = grp.coords if names is None else {k: v for k, v in grp.coords.items() if k in names}
+    return values, counts, out_dims, frame_coords, stat._lane, scale  # pylint: disable=protected-access
 
   def _reduce_categorical(self, stat: 'lazy.LazyCategorical', w_da, bin_dims, use_mask, skipna):
     """Indicator statistics: every category is a lane of ONE launch (wbx_cat_partial); the categories come back as

@@ -208,7 +208,7 @@ def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, 
 def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=None, cat=None) -> FusedGroup:
   """The FusedGroup shared by every statistic built from these very (p, t) objects."""
   table = p.__dict__.setdefault('_wbx_groups', {})
-  key = (kind, id(t), ens['member_dim'] if ens else None, clim_key)
+  key = (kind, id(t), t.__dict__.get('_mutations', 0), ens['member_dim'] if ens else None, clim_key)
   hit = table.get(key)
   if hit is not None and hit[0]() is t:
     return hit[1]
@@ -220,18 +220,22 @@ def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=N
 class LazyStatistic(xr.LazyPickleMixin, xr.DataArray):
   """A per-point statistic that is a DataArray in every respect, evaluated on demand by a HIP kernel."""
 
-  def __init__(self, group: FusedGroup, lane: int, name=None, ens_params=None, mean_dims=()):
+  def __init__(self, group: FusedGroup, lane: int, name=None, ens_params=None, mean_dims=(), coord_names=None):
     # deliberately no super().__init__: the payload does not exist yet
     self._data = None
     self._dims = tuple(d for d in group.dims if d not in mean_dims)
     self.name = name
     self.attrs = {}
     dset = set(self._dims)
-    self._coords = {k: v for k, v in group.coords.items() if set(v[0]) <= dset}
+    # coord_names: statistics of the predictions alone (EnsembleVariance, CRPSSpread) carry the predictions' coordinates
+    # only -- in particular not the targets' `mask` (probabilistic.py:250-273: `predictions.var(...)`)
+    self._coords = {k: v for k, v in group.coords.items()
+                    if set(v[0]) <= dset and (coord_names is None or k in coord_names)}
     self._group = group
     self._lane = lane
     self._ens_params = ens_params
     self._mean_dims = tuple(mean_dims)
+    self._coord_names = coord_names
 
   @property
   def is_lazy(self) -> bool:
@@ -259,10 +263,11 @@ class LazyStatistic(xr.LazyPickleMixin, xr.DataArray):
     """Mean over a dim that nothing else depends on stays lazy (EnsembleAveragedStatistic,
     probabilistic.py:35-69): it becomes one more reduced dim of the fused launch."""
     dims = (dim,) if isinstance(dim, str) else tuple(dim or ())
-    if (self.is_lazy and dims and not skipna and all(d in self._dims for d in dims)
+    # only an explicit skipna=False stays lazy: the default (None) drops NaNs like DataArray.mean / xarray do
+    if (self.is_lazy and dims and skipna is False and all(d in self._dims for d in dims)
         and self._group.kind == 'det'):
       return LazyStatistic(self._group, self._lane, name=self.name, ens_params=self._ens_params,
-                           mean_dims=self._mean_dims + dims)
+                           mean_dims=self._mean_dims + dims, coord_names=self._coord_names)
     return super().mean(dim, skipna=skipna, **kw)
 
 
@@ -324,18 +329,35 @@ def det_statistic(stat_name: str, p, t, climatology_ref: ClimatologyRef | None =
   return LazyStatistic(grp, DET_LANE[stat_name], name=p.name)
 
 
+def _same_mask(p: xr.DataArray, t: xr.DataArray) -> bool:
+  pm, tm = p._coords.get('mask'), t._coords.get('mask')  # pylint: disable=protected-access
+  if tm is None:
+    return True
+  return pm is not None and pm[0] == tm[0] and xr._values_equal(pm[1], tm[1])  # pylint: disable=protected-access
+
+
 def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fair=True,
-                  skipna_ensemble=False) -> xr.DataArray:
+                  skipna_ensemble=False, member_only=False) -> xr.DataArray:
+  """`member_only`: the statistic looks at `p` alone (EnsembleVariance, CRPSSpread); `t` is only the kernel's companion
+  operand.  Its frame and coordinates are then those of `p` -- the reference computes it from the predictions, so a
+  `mask` coordinate or an extra dim of the targets must not leak into it (Aggregator(masked=True) leaves such a statistic
+  unmasked, aggregation.py:339-352).  While `t` has the frame of `p` the (p, t) launch of the other lanes is shared."""
   p, t = xr.as_dataarray(p), xr.as_dataarray(t)
   if ensemble_dim not in p.dims:
     raise ValueError(f'Dimension {ensemble_dim} not found in {p.dims}')
   if ensemble_dim in t.dims:
     raise ValueError(f'targets must not carry {ensemble_dim!r} here (select a member or use target_members())')
+  coord_names = None
+  if member_only:
+    if not (set(t.dims) <= set(p.dims) and _same_mask(p, t)):
+      t = target_members(p, ensemble_dim)[0]  # a companion with exactly the predictions' frame
+    coord_names = frozenset(p._coords)  # pylint: disable=protected-access
+  p, t = _aligned(p, t)
   m = p.sizes[ensemble_dim]
   grp = _group_for('ens', p, t, ens={'member_dim': ensemble_dim, 'M': m})
   params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair),
             'skipna': bool(skipna_ensemble)}
-  return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params)
+  return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params, coord_names=coord_names)
 
 
 class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
@@ -388,8 +410,7 @@ def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, 
       raise ValueError(f'Dimension {ensemble_dim} not found in {p.dims}')
     if ensemble_dim in t.dims:
       raise ValueError(f'targets must not carry {ensemble_dim!r} here')
-  else:
-    p, t = _aligned(p, t)
+  p, t = _aligned(p, t)
   if cat_dim in p.dims or cat_dim in t.dims:
     raise ValueError(f'{cat_dim!r} is already a dimension of the inputs')
   thr = None if thresholds is None else np.asarray(thresholds, np.float64).reshape(-1)

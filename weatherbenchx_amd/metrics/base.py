@@ -153,8 +153,9 @@ class PerVariableStatisticWithClimatology(Statistic):
     # (predictions object, climatology variable).
     cache = predictions.__dict__.setdefault('_wbx_clim_refs', {})
     hit = cache.get(id(climatology))
-    if hit is None or hit[0] is not climatology:
-      hit = (climatology, self._climatology_ref(predictions, climatology))
+    version = climatology.__dict__.get('_mutations', 0)
+    if hit is None or hit[0] is not climatology or hit[2] != version:
+      hit = (climatology, self._climatology_ref(predictions, climatology), version)
       cache[id(climatology)] = hit
     return self._compute_per_variable_with_aligned_climatology(predictions, targets, hit[1])
 

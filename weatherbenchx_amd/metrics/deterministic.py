@@ -19,6 +19,11 @@ def _sqrt(da: xr.DataArray) -> xr.DataArray:
   return np.sqrt(da)
 
 
+def _clim_key(ref):
+  """Identity of the climatology payload a fused group was built on (the payload object and its in-place edits)."""
+  return (id(ref.source.data), ref.source.__dict__.get('_mutations', 0))
+
+
 class Error(base.PerVariableStatistic):
   """predictions - targets (deterministic.py:91-100)."""
 
@@ -117,7 +122,7 @@ class SquaredPredictionAnomaly(base.PerVariableStatisticWithClimatology):
 
   def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
     return lazy.det_statistic('SquaredPredictionAnomaly', predictions, targets, aligned_climatology,
-                              clim_key=id(aligned_climatology.source.data))
+                              clim_key=_clim_key(aligned_climatology))
 
 
 class SquaredTargetAnomaly(base.PerVariableStatisticWithClimatology):
@@ -125,7 +130,7 @@ class SquaredTargetAnomaly(base.PerVariableStatisticWithClimatology):
 
   def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
     return lazy.det_statistic('SquaredTargetAnomaly', predictions, targets, aligned_climatology,
-                              clim_key=id(aligned_climatology.source.data))
+                              clim_key=_clim_key(aligned_climatology))
 
 
 class AnomalyCovariance(base.PerVariableStatisticWithClimatology):
@@ -133,7 +138,7 @@ class AnomalyCovariance(base.PerVariableStatisticWithClimatology):
 
   def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):
     return lazy.det_statistic('AnomalyCovariance', predictions, targets, aligned_climatology,
-                              clim_key=id(aligned_climatology.source.data))
+                              clim_key=_clim_key(aligned_climatology))
 
 
 # Metrics that are the plain mean of a statistic (deterministic.py:305-309).

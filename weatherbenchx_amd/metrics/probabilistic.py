@@ -122,7 +122,7 @@ class CRPSSpread(base.PerVariableStatistic):
     if self._ensemble_dim in other.dims or self._which == 'targets':
       other = lazy.target_members(da, self._ensemble_dim)[0]
     return lazy.ens_statistic('CRPSSpread', da, other, self._ensemble_dim, use_sort=self._use_sort, fair=self._fair,
-                              skipna_ensemble=self._skipna_ensemble)
+                              skipna_ensemble=self._skipna_ensemble, member_only=True)
 
 
 class EnsembleVariance(base.PerVariableStatistic):
@@ -139,7 +139,7 @@ class EnsembleVariance(base.PerVariableStatistic):
   def _compute_per_variable(self, predictions, targets):
     other = targets if self._ensemble_dim not in targets.dims else lazy.target_members(targets, self._ensemble_dim)[0]
     return lazy.ens_statistic('EnsembleVariance', predictions, other, self._ensemble_dim,
-                              skipna_ensemble=self._skipna_ensemble)
+                              skipna_ensemble=self._skipna_ensemble, member_only=True)
 
 
 class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
@@ -169,7 +169,7 @@ class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
         raise ValueError('an ensemble of targets needs at least 2 members (its variance has ddof=1)')
       terms = [lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, tj, self._ensemble_dim)
                for tj in members]
-      terms.append(lazy.ens_statistic('EnsembleVariance', targets, members[0], self._ensemble_dim))
+      terms.append(lazy.ens_statistic('EnsembleVariance', targets, members[0], self._ensemble_dim, member_only=True))
       return lazy.LinearCombination(terms, coeffs=[1.0 / n] * n + [-1.0], name=predictions.name)
     return lazy.ens_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim,
                               skipna_ensemble=self._skipna_ensemble)

@@ -166,6 +166,7 @@ class _Coords(Mapping):
 
   def __delitem__(self, key):
     del self._o._coords[key]
+    self._o._drop_device_caches()
 
   def __iter__(self):
     return iter(self._o._coords)
@@ -323,6 +324,16 @@ class DataArray:
 
   def _set_coord(self, key, value):
     self._coords[key] = _normalise_coord(key, value, self.dims, self.sizes)
+    self._drop_device_caches()
+
+  def _drop_device_caches(self):
+    """Forgets everything the engine cached on this object (uploaded copies, fused groups, packed weights): called by
+    every in-place mutation of the payload or the coordinates, so that later reductions see the new content.  Host
+    payloads are uploaded once per object: writing through `.values[...] = x` bypasses this -- use `da[...] = x`."""
+    for k in [k for k in self.__dict__ if k.startswith('_wbx_')]:
+      del self.__dict__[k]
+    # caches that live on OTHER objects (the fused group of (predictions, targets) sits on the predictions) key on this
+    self.__dict__['_mutations'] = self.__dict__.get('_mutations', 0) + 1
 
   def __getattr__(self, name):
     # only called when normal lookup fails: expose coords / dims as attributes
@@ -456,6 +467,7 @@ class DataArray:
     if isinstance(value, DataArray):
       value = value.data
     self._data[idx] = value
+    self._drop_device_caches()
 
   def isel(self, indexers=None, drop=False, **kw):
     indexers = dict(indexers or {}, **kw)
