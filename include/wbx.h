@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 4
+#define WBX_ABI_VERSION 5
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -168,6 +168,29 @@ int wbx_fence_create(wbx_ctx* ctx, wbx_fence** out);
 int wbx_fence_record(wbx_ctx* ctx, wbx_fence* fence);
 int wbx_fence_wait(wbx_fence* fence);
 int wbx_fence_destroy(wbx_fence* fence);
+/* Work enqueued on `ctx` after this call starts only when `fence` (recorded on ANY context of the same process) has been
+ * reached: hipStreamWaitEvent.  Orders a context's kernels behind another context's copies without blocking the host
+ * (the chunk feeder's upload stream in front of the launch stream, beam_pipeline.py:69-116 -> :161-250). */
+int wbx_ctx_wait_fence(wbx_ctx* ctx, wbx_fence* fence);
+/* Asynchronous upload from page-locked memory (wbx_host_alloc) on the context stream: the staging half of the chunk
+ * feeder's double buffer.  The source must stay untouched until a fence recorded afterwards has been reached. */
+int wbx_memcpy_h2d_async(wbx_ctx* ctx, void* dptr, const void* h_pinned, size_t bytes);
+int wbx_memcpy_d2d(wbx_ctx* ctx, void* dst, const void* src, size_t bytes); /* enqueued on the context stream */
+
+/* ---- accumulators ------------------------------------------------------------------------------------------
+ * The reference combines per-chunk AggregationStates on the host (beam.CombinePerKey(CombiningSum()),
+ * beam_pipeline.py:509-510, beam_utils.py:30-50; AggregationState.sum, aggregation.py:84-110).  Here the stage-2 /
+ * binned / spectrum outputs of a chunk stay in HBM and are added into a persistent float64 accumulator right behind
+ * the kernel that produced them:
+ *     acc[i] = (overwrite ? 0 : acc[i]) + src[i],  i < n          (stream ordered, deterministic, no atomics)
+ * A rank's accumulators live in ONE device buffer that is all-reduced in place over RCCL (torch.distributed on the
+ * device pointer) and read back once per job -- the counterpart of SURVEY 8b's wbx_acc_allreduce / wbx_acc_read. */
+int wbx_acc_add(wbx_ctx* ctx, double* acc, const double* src, int64_t n, int32_t overwrite);
+
+/* valid_out[i] = !isnan(data[i]) (one byte per element, 1 = valid) over n contiguous elements: the `mask` coordinate
+ * of data_loaders/base.py:25-56 (add_nan_mask_to_data) for payloads that are already in HBM -- the mask is built and
+ * consumed (WBX_FLAG_MASKED, input 3) without ever visiting the host.  valid_out must be 4-byte aligned. */
+int wbx_notnan_mask(wbx_ctx* ctx, const void* data, int dtype, int64_t n, uint8_t* valid_out);
 
 /* HIP-event timer on the context stream (bench.py's roofline leg). */
 int wbx_timer_start(wbx_ctx* ctx);

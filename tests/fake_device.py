@@ -16,11 +16,38 @@ class _Buf:
     self.ptr = arr
 
 
+class _Fence:
+  def wait(self):
+    pass
+
+
 class FakeCtx:
   device_id = 0
 
   def upload(self, arr):
     return _Buf(np.array(arr, copy=True))
+
+  def alloc(self, nbytes):
+    return _Buf(np.zeros(max(int(nbytes) // 8, 1)))
+
+  def download(self, ptr, shape, dtype=np.float64):
+    n = int(np.prod(shape, dtype=np.int64))
+    return np.array(np.asarray(ptr).reshape(-1)[:n], dtype=dtype).reshape(shape)
+
+  def download_async(self, ptr, shape):
+    return self.download(ptr, shape)
+
+  def fence(self):
+    return _Fence()
+
+  def synchronize(self):
+    pass
+
+
+def _acc_add(ctx, dst_buf, dst_off, src_ptr, n, overwrite):
+  src = np.asarray(src_ptr, dtype=np.float64).reshape(-1)[:n]
+  with np.errstate(all='ignore'):
+    dst_buf.ptr[dst_off:dst_off + n] = src if overwrite else dst_buf.ptr[dst_off:dst_off + n] + src
 
 
 def _to_device(ctx, da, dtype_code):
@@ -184,7 +211,7 @@ def _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf):
       v = v.reshape(nA, nBk, nBr, plan.ndepth, plan.nx) * wt[None, :, :, None, :]
       out[:, :, l, 0, :] = np.einsum('abrdx,brxn->abn', v, np.broadcast_to(member, (nBk, nBr, nj, nbin)) if nj > 1
                                      else np.broadcast_to(member, (nBk, nBr, 1, nbin)).repeat(plan.nx, axis=2))
-  return out
+  return out, out.shape
 
 
 def _run_map(ctx, kind, dplan, plan, devs, dtype_code, lane, func=0, ens=None):
@@ -211,7 +238,7 @@ def _run_s2(ctx, s2, partial, w_buf):
       out = np.einsum('abrclj,brjn->abln', part, w)[:, :, :, None, :]
     else:
       out = np.einsum('abrclj,brjn->abljn', part, w)
-  return out
+  return np.ascontiguousarray(out), out.shape
 
 
 def install(monkeypatch):
@@ -224,6 +251,7 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
   monkeypatch.setattr(engine, '_run_binned', _run_binned)
+  monkeypatch.setattr(engine, '_acc_add', _acc_add)
   monkeypatch.setattr(engine, 'new_context', lambda: FakeCtx())
 
 

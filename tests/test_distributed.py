@@ -1,13 +1,38 @@
-"""Multi-rank path on CPU: two gloo processes shard the time chunks round-robin, aggregate locally and
-all-reduce ONE packed accumulator buffer; the result must equal the single-process evaluation.
+"""Multi-rank path on CPU: two gloo processes shard the time chunks round-robin, accumulate locally and combine with
+ONE sum all-reduce of one buffer that holds the union of every rank's accumulator slots; whatever survives of
+(init_time, lead_time) -- nothing, one of them, both -- every rank must end up with the single-process result
+(the reference's CombinePerKey + ConcatPerStatisticPerVariable, beam_pipeline.py:253-319, 509-510).
 (The per-chunk device math is the NumPy plan interpreter here; on the GPU box the same code runs over RCCL.)"""
 import os
+import pickle
 import sys
 
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _init(rank, world_size, out_dir):
+  """gloo group over a file store in the test's tmp dir (no TCP port to collide on when tests run in parallel)."""
+  for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+      sys.path.insert(0, p)
+  import torch.distributed as dist
+  import fake_device
+
+  class MP:  # minimal monkeypatch
+    def setattr(self, obj, name, value):
+      setattr(obj, name, value)
+  fake_device.install(MP())
+  dist.init_process_group('gloo', init_method='file://' + os.path.join(out_dir, 'rendezvous'), rank=rank,
+                          world_size=world_size)
+  return dist
+
+
+def _spawn(fn, world_size, tmp_path, *args):
+  import torch.multiprocessing as mp
+  mp.spawn(fn, args=(world_size, str(tmp_path)) + args, nprocs=world_size, join=True)
 
 
 def _ensemble_case(tp):
@@ -29,20 +54,10 @@ def _ensemble_case(tp):
   return times, tp._loader(predictions, targets), metrics, agg
 
 
-def _ensemble_worker(rank, world_size, port, out_dir):
-  sys.path.insert(0, ROOT)
-  sys.path.insert(0, os.path.join(ROOT, 'tests'))
-  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
-  import torch.distributed as dist
-  import fake_device
+def _ensemble_worker(rank, world_size, out_dir):
+  dist = _init(rank, world_size, out_dir)
   import test_pipeline as tp
   from weatherbenchx_amd import pipeline
-
-  class MP:  # minimal monkeypatch
-    def setattr(self, obj, name, value):
-      setattr(obj, name, value)
-  fake_device.install(MP())
-  dist.init_process_group('gloo', rank=rank, world_size=world_size)
   try:
     times, load, metrics, agg = _ensemble_case(tp)
     state = pipeline.evaluate_chunks(times, load, metrics, agg, rank=rank, world_size=world_size, prefetch=1)[None]
@@ -55,12 +70,7 @@ def _ensemble_worker(rank, world_size, port, out_dir):
 def test_two_rank_allreduce_of_an_ensemble_workload(tmp_path, monkeypatch):
   """CRPS, spread/skill and rank histograms over 2 gloo ranks (chunk feeder on, launches alternating over two contexts
   on each rank): every rank ends up with the single-process numbers."""
-  import socket
-  import torch.multiprocessing as mp
-  with socket.socket() as s:
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-  mp.spawn(_ensemble_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  _spawn(_ensemble_worker, 2, tmp_path)
   import fake_device
   import test_pipeline as tp
   from weatherbenchx_amd import pipeline
@@ -74,88 +84,111 @@ def test_two_rank_allreduce_of_an_ensemble_workload(tmp_path, monkeypatch):
       np.testing.assert_allclose(got[k], want[k].values, rtol=1e-12, err_msg=k)
 
 
-def _worker(rank, world_size, port, out_dir):
-  sys.path.insert(0, ROOT)
-  sys.path.insert(0, os.path.join(ROOT, 'tests'))
-  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
-  import torch.distributed as dist
-  import fake_device
-  import test_pipeline as tp
-  from weatherbenchx_amd import aggregation, pipeline, time_chunks
-  from weatherbenchx_amd.metrics import deterministic
+REDUCE_SETS = {'all_time': ['init_time', 'lead_time', 'latitude', 'longitude'],
+               'lead_kept': ['init_time', 'latitude', 'longitude'],       # the benchmark's default: RMSE per lead time
+               'both_kept': ['latitude', 'longitude'],                    # every chunk owns its own offsets
+               'maps_per_lead': ['init_time'],                            # latitude / longitude survive too
+               'init_kept': ['lead_time', 'latitude', 'longitude']}
 
-  class MP:  # minimal monkeypatch
-    def setattr(self, obj, name, value):
-      setattr(obj, name, value)
-  fake_device.install(MP())
-  dist.init_process_group('gloo', rank=rank, world_size=world_size)
+
+def _det_case(tp, reduce_dims, chunk=(1, 1)):
+  from weatherbenchx_amd import aggregation, binning, time_chunks, weighting
+  from weatherbenchx_amd.metrics import deterministic
+  predictions, targets = tp._datasets()
+  init_times = predictions['geopotential']['time'].values
+  lead_times = predictions['geopotential']['prediction_timedelta'].values
+  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=chunk[0], lead_time_chunk_size=chunk[1])
+  metrics = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias(),
+             'wind': deterministic.WindVectorRMSE('geopotential', 'geopotential', 'wind')}  # a linear combination
+  aggs = {'plain': aggregation.Aggregator(reduce_dims=reduce_dims)}
+  if 'latitude' in reduce_dims:
+    aggs['regions'] = aggregation.Aggregator(
+        reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()], masked=True,
+        bin_by=[binning.Regions({'global': ((-90, 90), (0, 360)), 'nh': ((20, 90), (0, 360))})])
+  return times, tp._loader(predictions, targets), metrics, aggs
+
+
+def _dump(states, metrics, path):
+  out = {}
+  for name, st in states.items():
+    out[name] = {'metrics': {k: (v.dims, np.asarray(v.values), {c: np.asarray(v[c].values) for c in v.dims if c in v.coords})
+                             for k, v in st.metric_values(metrics).items()},
+                 'sws': {(s, v): (da.dims, np.asarray(da.values)) for s, per in st.sum_weighted_statistics.items()
+                         for v, da in per.items()},
+                 'sw': {(s, v): (da.dims, np.asarray(da.values)) for s, per in st.sum_weights.items() for v, da in per.items()}}
+  with open(path, 'wb') as f:
+    pickle.dump(out, f)
+
+
+def _det_worker(rank, world_size, out_dir, which, chunk):
+  dist = _init(rank, world_size, out_dir)
+  import test_pipeline as tp
+  from weatherbenchx_amd import pipeline
   try:
-    predictions, targets = tp._datasets()
-    init_times = predictions['geopotential']['time'].values
-    lead_times = predictions['geopotential']['prediction_timedelta'].values
-    times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
-    metrics = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
-    agg = aggregation.Aggregator(reduce_dims=['init_time', 'lead_time', 'latitude', 'longitude'])
-    state = pipeline.evaluate_chunks(times, tp._loader(predictions, targets), metrics, agg, rank=rank,
-                                     world_size=world_size)[None]
-    vals = state.metric_values(metrics)
-    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **{k: v.values for k, v in vals.items()})
+    times, load, metrics, aggs = _det_case(tp, REDUCE_SETS[which], chunk)
+    states = pipeline.evaluate_chunks(times, load, metrics, aggs, rank=rank, world_size=world_size)
+    _dump(states, metrics, os.path.join(out_dir, f'rank{rank}.pkl'))
   finally:
     dist.destroy_process_group()
 
 
-def test_two_rank_allreduce_matches_single_process(tmp_path, monkeypatch):
-  import torch.multiprocessing as mp
-  import socket
-  with socket.socket() as s:
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-  mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-  # single-process reference
+@pytest.mark.parametrize('which,chunk,world', [('all_time', (1, 1), 2), ('lead_kept', (1, 1), 2), ('both_kept', (1, 1), 2),
+                                               ('maps_per_lead', (1, 1), 2), ('init_kept', (1, 2), 2),
+                                               ('lead_kept', (1, 2), 3), ('both_kept', (2, 1), 3)])
+def test_ranks_equal_single_process_whatever_survives(tmp_path, monkeypatch, which, chunk, world):
+  """reduce_dims in {all, [init,lat,lon], [lat,lon], [init], ...} x chunkings x 2-3 ranks (3 ranks over 2 chunks: one
+  rank has nothing to contribute and still returns the complete result)."""
+  _spawn(_det_worker, world, tmp_path, which, chunk)
   import fake_device
   import test_pipeline as tp
-  from weatherbenchx_amd import aggregation, pipeline, time_chunks
-  from weatherbenchx_amd.metrics import deterministic
+  from weatherbenchx_amd import pipeline
   fake_device.install(monkeypatch)
-  predictions, targets = tp._datasets()
-  init_times = predictions['geopotential']['time'].values
-  lead_times = predictions['geopotential']['prediction_timedelta'].values
-  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
-  metrics = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
-  agg = aggregation.Aggregator(reduce_dims=['init_time', 'lead_time', 'latitude', 'longitude'])
-  want = pipeline.evaluate_chunks(times, tp._loader(predictions, targets), metrics, agg)[None].metric_values(metrics)
-  for rank in (0, 1):
-    got = np.load(os.path.join(tmp_path, f'rank{rank}.npz'))
-    assert set(got.files) == set(want)
-    for k in want:
-      np.testing.assert_allclose(got[k], want[k].values, rtol=1e-12)
+  times, load, metrics, aggs = _det_case(tp, REDUCE_SETS[which], chunk)
+  states = pipeline.evaluate_chunks(times, load, metrics, aggs)
+  _dump(states, metrics, os.path.join(tmp_path, 'want.pkl'))
+  want = pickle.load(open(os.path.join(tmp_path, 'want.pkl'), 'rb'))
+  assert any(len(v['metrics']) for v in want.values())
+  for rank in range(world):
+    got = pickle.load(open(os.path.join(tmp_path, f'rank{rank}.pkl'), 'rb'))
+    assert set(got) == set(want)
+    for name in want:
+      for part in ('sws', 'sw'):
+        assert set(got[name][part]) == set(want[name][part])
+        for k, (dims, vals) in want[name][part].items():
+          assert got[name][part][k][0] == dims, (name, part, k)
+          np.testing.assert_allclose(got[name][part][k][1], vals, rtol=1e-12, atol=1e-300, err_msg=f'{name} {part} {k}')
+      assert set(got[name]['metrics']) == set(want[name]['metrics'])
+      for k, (dims, vals, coords) in want[name]['metrics'].items():
+        gd, gv, gc = got[name]['metrics'][k]
+        assert gd == dims
+        np.testing.assert_allclose(gv, vals, rtol=1e-12, equal_nan=True, err_msg=f'{name} {k}')
+        for c in coords:
+          assert np.array_equal(gc[c], coords[c]), (name, k, c)  # time coordinates are concatenated in offset order
 
 
-def test_pack_unpack_round_trip_and_sharding():
+def test_host_states_and_sharding():
+  """all_reduce_state on finished (host) states is the identity without a process group; sharding is round-robin."""
   sys.path.insert(0, ROOT)
-  from weatherbenchx_amd import distributed
+  from weatherbenchx_amd import distributed, engine
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.aggregation import AggregationState
   st = AggregationState({'s': {'a': xr.DataArray(np.arange(6.0).reshape(2, 3), dims=['x', 'y']),
                                'b': xr.DataArray(np.float64(7.0))}},
                         {'s': {'a': xr.DataArray(np.ones((2, 3)), dims=['x', 'y']), 'b': xr.DataArray(np.float64(2.0))}})
-  flat, layout, items = distributed.pack_state(st)
-  assert flat.shape == (14,) and len(layout) == 4
-  back = distributed.unpack_state(flat * 2, items)
-  np.testing.assert_allclose(back.sum_weighted_statistics['s']['a'].values, 2 * np.arange(6.0).reshape(2, 3))
-  np.testing.assert_allclose(back.sum_weights['s']['b'].values, 4.0)
   assert distributed.shard_chunks(list(range(7)), 1, 3) == [1, 4]
   assert distributed.all_reduce_state(st) is st  # no process group: identity
+  back, plan = distributed.resolve_state(st, engine.Accumulation())  # host leaves through the packed buffer
+  assert plan.total == 14 and plan.collectives == 0
+  np.testing.assert_allclose(back.sum_weighted_statistics['s']['a'].values, np.arange(6.0).reshape(2, 3))
+  np.testing.assert_allclose(back.sum_weights['s']['b'].values, 2.0)
+  assert back.sum_weighted_statistics['s']['b'].dims == ()
 
 
-def _ragged_worker(rank, world_size, port, out_dir):
-  sys.path.insert(0, ROOT)
-  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
-  import torch.distributed as dist
+def _ragged_worker(rank, world_size, out_dir):
+  dist = _init(rank, world_size, out_dir)
   from weatherbenchx_amd import distributed
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.aggregation import AggregationState
-  dist.init_process_group('gloo', rank=rank, world_size=world_size)
   try:
     n = 3 + rank  # rank 1 packs one value more
     st = AggregationState({'s': {'v': xr.DataArray(np.ones(n), dims=['x'])}},
@@ -171,11 +204,53 @@ def _ragged_worker(rank, world_size, port, out_dir):
 
 
 def test_ragged_shards_fail_loudly(tmp_path):
-  import socket
-  import torch.multiprocessing as mp
-  with socket.socket() as s:
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-  mp.spawn(_ragged_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  _spawn(_ragged_worker, 2, tmp_path)
   outcomes = [open(os.path.join(tmp_path, f'ragged{r}.txt')).read() for r in (0, 1)]
-  assert all(o != 'no error' for o in outcomes), outcomes
+  assert all(o == 'ValueError' for o in outcomes), outcomes  # the layout exchange catches it before the payload collective
+
+
+def _step_worker(rank, world_size, out_dir):
+  """A bench-like loop: every step accumulates one launch set and all-reduces it; the layout is exchanged once."""
+  dist = _init(rank, world_size, out_dir)
+  from weatherbenchx_amd import aggregation, distributed, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic
+  try:
+    lat, lon = np.linspace(-80, 80, 9), np.arange(12) * 30.0
+    metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+    agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+    plan, sums = None, []
+    for step in range(3):
+      rng = np.random.default_rng(100 * step + rank)
+      p = {'v': xr.DataArray(rng.normal(size=(2, 9, 12)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
+                             coords={'latitude': lat, 'longitude': lon})}
+      t = {'v': xr.DataArray(rng.normal(size=(2, 9, 12)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
+                             coords={'latitude': lat, 'longitude': lon})}
+      acc = engine.Accumulation()
+      with engine.accumulate_results(acc):
+        state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+      state, plan = distributed.resolve_state(state, acc, plan=plan)
+      sums.append(state.metric_values(metrics)['rmse.v'].values)
+    assert plan.collectives == 3  # one sum all-reduce per step, the layout exchange only before the first
+    np.save(os.path.join(out_dir, f'steps{rank}.npy'), np.stack(sums))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_per_step_allreduce_reuses_the_layout(tmp_path):
+  _spawn(_step_worker, 2, tmp_path)
+  a, b = (np.load(os.path.join(tmp_path, f'steps{r}.npy')) for r in (0, 1))
+  np.testing.assert_array_equal(a, b)
+  lat = np.linspace(-80, 80, 9)
+  from oracle import wbx_oracle as O
+  w = O.grid_area_weights(lat)
+  for step in range(3):
+    num = den = 0.0
+    for rank in (0, 1):
+      rng = np.random.default_rng(100 * step + rank)
+      p = rng.normal(size=(2, 9, 12)).astype(np.float32).astype(np.float64)
+      t = rng.normal(size=(2, 9, 12)).astype(np.float32).astype(np.float64)
+      num = num + ((p - t) ** 2 * w[None, :, None]).sum(axis=(1, 2))
+      den = den + (np.ones_like(p) * w[None, :, None]).sum(axis=(1, 2))
+    np.testing.assert_allclose(a[step], np.sqrt(num / den), rtol=1e-9)

@@ -453,14 +453,16 @@ def test_region_binned_paths_on_a_one_degree_grid(ctx, monkeypatch, layout, mode
     assert np.isfinite(got.sel(lead_time=coords['lead_time'][0], level=850).values).all()
 
 
-def test_rccl_all_reduce_of_a_packed_state_single_rank(ctx):
-  """The RCCL leg of distributed.all_reduce_state (backend 'nccl' = RCCL on ROCm) on the one GPU a test box has:
-  pack -> H2D -> fingerprint MIN all-reduce -> payload SUM all-reduce -> D2H -> unpack must be the identity for a
-  one-rank group.  (World size 2 runs on gloo in tests/test_distributed.py; N > 1 on RCCL is the driver's scaling run.)"""
+def test_rccl_all_reduce_of_the_device_accumulators_single_rank(ctx):
+  """The RCCL leg of distributed.reduce_accumulation (backend 'nccl' = RCCL on ROCm) on the one GPU a test box has: the
+  chunks' sums are added into device accumulator slots (wbx_acc_add), the slots are laid out in one device buffer, that
+  buffer is all-reduced IN PLACE through its device pointer (no host hop: torch sees wbx memory through the CUDA array
+  interface) and read back once -- the identity for a one-rank group, and exactly ONE collective per reduction.
+  (World sizes 2-3 run on gloo in tests/test_distributed.py; N > 1 on RCCL is the driver's scaling run.)"""
   import socket
   import torch
   import torch.distributed as dist
-  from weatherbenchx_amd import distributed
+  from weatherbenchx_amd import distributed, pipeline, time_chunks
   if dist.is_initialized():
     pytest.skip('a process group already exists in this process')
   with socket.socket() as s:
@@ -471,18 +473,49 @@ def test_rccl_all_reduce_of_a_packed_state_single_rank(ctx):
                           device_id=torch.device('cuda', 0))
   try:
     rng = np.random.default_rng(0)
+    lat = np.linspace(-80, 80, 16)
     p = xr.DataArray(rng.normal(size=(3, 16, 32)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
-                     coords={'latitude': np.linspace(-80, 80, 16)})
+                     coords={'latitude': lat})
     t = xr.DataArray(rng.normal(size=(3, 16, 32)).astype(np.float32), dims=('lead_time', 'latitude', 'longitude'),
-                     coords={'latitude': np.linspace(-80, 80, 16)})
+                     coords={'latitude': lat})
     metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
     agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
-    with engine.deferred_results():
-      state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t}))
-      reduced = distributed.all_reduce_state(state, force=True)  # waits for the deferred sums first
-    want, got = state.metric_values(metrics), reduced.metric_values(metrics)
-    for k in want:
-      np.testing.assert_array_equal(got[k].values, want[k].values)
+    want = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t}))
+    # the device pointer really is what torch reduces: same address, no copy
+    buf = ctx.upload(np.arange(8.0))
+    view = distributed.device_tensor(buf.ptr, 8, ctx.device_id)
+    assert view.data_ptr() == buf.ptr and view.dtype == torch.float64
+    dist.all_reduce(view)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ctx.download(buf.ptr, (8,)), np.arange(8.0))
+    del view
+    plan = None
+    for step in range(3):  # a per-step all-reduce loop: layout exchanged once, one collective per step
+      acc = engine.Accumulation()
+      with engine.accumulate_results(acc):
+        fresh = lambda a: {'v': xr.DataArray(a.data, dims=a.dims, coords={'latitude': lat})}
+        state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(p), fresh(t)))
+      reduced, plan = distributed.resolve_state(state, acc, plan=plan, force=True)
+      assert plan.collectives == step + 1
+      for k, v in want.metric_values(metrics).items():
+        np.testing.assert_array_equal(reduced.metric_values(metrics)[k].values, v.values)
+    # the chunk loop: accumulate 2 + 2 chunks on the device, one collective at the end
+    predictions, targets = None, None
+    import mock_data
+    predictions = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-03T00', lead_start_days=0,
+                                                 lead_stop_days=1, random=True, seed=0)
+    targets = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', random=True, seed=1)
+    import test_pipeline as tp
+    init_times = predictions['geopotential']['time'].values
+    lead_times = predictions['geopotential']['prediction_timedelta'].values
+    load = tp._loader(predictions, targets)
+    pieces = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+    whole = time_chunks.TimeChunks(init_times, lead_times)
+    agg2 = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+    a = pipeline.evaluate_chunks(pieces, load, metrics, agg2, force_collective=True)[None].metric_values(metrics)
+    b = pipeline.evaluate_chunks(whole, load, metrics, agg2)[None].metric_values(metrics)
+    for k in b:
+      xr.assert_allclose(a[k], b[k], rtol=1e-9, atol=1e-12, check_dim_order=False)
   finally:
     dist.destroy_process_group()
 

@@ -32,7 +32,8 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
     'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_cat_partial', 'wbx_det_map', 'wbx_ens_map',
     'wbx_zonal_spectrum', 'wbx_zonal_spectrum_slabs', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
-    'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy',
+    'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy', 'wbx_ctx_wait_fence', 'wbx_memcpy_h2d_async',
+    'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask',
 )
 
 
@@ -104,6 +105,11 @@ def load_library():
         'wbx_fence_record': [vp, vp],
         'wbx_fence_wait': [vp],
         'wbx_fence_destroy': [vp],
+        'wbx_ctx_wait_fence': [vp, vp],
+        'wbx_memcpy_h2d_async': [vp, vp, vp, C.c_size_t],
+        'wbx_memcpy_d2d': [vp, vp, vp, C.c_size_t],
+        'wbx_acc_add': [vp, vp, vp, i64, i32],
+        'wbx_notnan_mask': [vp, vp, i32, i64, vp],
         'wbx_timer_start': [vp],
         'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
         'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],

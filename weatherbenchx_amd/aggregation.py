@@ -151,13 +151,6 @@ class AggregationState:
     return cls.from_data_tree(tree)
 
 
-def _resolve_now():
-  """Inside engine.deferred_results(): waits for every read-back enqueued so far (host arithmetic follows)."""
-  d = engine.deferred_active()
-  if d is not None:
-    d.mark().wait()
-
-
 def _fenced(state):
   d = engine.deferred_active()
   if d is not None and state is not None:
@@ -191,6 +184,41 @@ def _weight_product(stat: xr.DataArray, weigh_by, bin_by):
   return product, tuple(names)
 
 
+class _PendingLinear(xr.LazyPickleMixin, xr.DataArray):
+  """sum_i coeff_i * term_i of result arrays whose numbers are still on their way (read-back in flight, or living in a
+  device accumulator): the combination is evaluated when `.data` is first read -- AggregationState waits on its fence
+  before it looks -- and an Accumulation records the terms instead (the reduction is linear, so the coefficients can be
+  applied after the chunks have been summed and all-reduced)."""
+
+  def __init__(self, terms, name=None, attrs=None):
+    first = terms[0][1]
+    self._data = None
+    self._dims = first.dims
+    self.name = name
+    self.attrs = dict(attrs or {})
+    self._coords = dict(first._coords)  # pylint: disable=protected-access
+    self._linear_terms = [(float(c), t) for c, t in terms]
+
+  @property
+  def data(self):
+    if self._data is None:
+      total = None
+      for c, t in self._linear_terms:
+        v = np.asarray(t.transpose(*self._dims).values, dtype=np.float64)
+        v = v if c == 1.0 else v * c
+        total = v if total is None else total + v
+      self._data = total
+    return self._data
+
+  @property
+  def shape(self):
+    return self._linear_terms[0][1].transpose(*self._dims).shape
+
+  @property
+  def dtype(self):
+    return np.dtype(np.float64)
+
+
 class _Token:
   """Hashable by identity; kept alive by whatever cache key holds it."""
   __slots__ = ()
@@ -217,8 +245,8 @@ class Aggregator:
   # ---- reference-compatible single-array entry point -------------------------------------------------
   def aggregation_fn(self, stat: xr.DataArray) -> xr.DataArray | None:
     """sum over reduce_dims of stat * weights * bin masks (aggregation.py:297-335)."""
-    state = self._aggregate(xr.as_dataarray(stat), use_mask=False, skipna=False)
-    _resolve_now()  # a bare DataArray cannot carry a fence
+    with engine.synchronous_results():  # a bare DataArray cannot carry a fence
+      state = self._aggregate(xr.as_dataarray(stat), use_mask=False, skipna=False)
     return None if state is None else state.sum_weighted_statistics
 
   def aggregate_stat_var(self, stat: xr.DataArray) -> AggregationState | None:
@@ -256,13 +284,14 @@ class Aggregator:
 
     if isinstance(stat, lazy.LinearCombination) and stat.is_lazy and not use_mask and not skipna:
       parts = [self._aggregate(term, use_mask=False, skipna=False) for term in stat._terms]  # pylint: disable=protected-access
-      _resolve_now()  # the terms are combined on the host
-      coeffs = stat._coeffs  # pylint: disable=protected-access
-      sws = parts[0].sum_weighted_statistics if coeffs[0] == 1.0 else parts[0].sum_weighted_statistics * coeffs[0]
-      for p, c in zip(parts[1:], coeffs[1:]):
-        sws = sws + (p.sum_weighted_statistics if c == 1.0 else p.sum_weighted_statistics * c)
-      if stat._scale != 1.0:  # pylint: disable=protected-access
-        sws = sws * stat._scale  # pylint: disable=protected-access
+      coeffs = [c * stat._scale for c in stat._coeffs]  # pylint: disable=protected-access
+      if engine.deferred_active() is not None:  # combined once the sums have arrived / been accumulated
+        sws = _PendingLinear([(c, p.sum_weighted_statistics) for c, p in zip(coeffs, parts)], name=stat.name)
+        return AggregationState(sws, parts[0].sum_weights)
+      sws = None
+      for p, c in zip(parts, coeffs):
+        term = p.sum_weighted_statistics if c == 1.0 else p.sum_weighted_statistics * c
+        sws = term if sws is None else sws + term
       return AggregationState(sws, parts[0].sum_weights)
 
     if (isinstance(stat, lazy.LazyCategorical) and stat.is_lazy and stat._cat_dim not in reduce_set  # pylint: disable=protected-access
@@ -288,18 +317,18 @@ class Aggregator:
           coords.setdefault(k, v)
 
     pending = engine.deferred_active() is not None
-    if pending and scale != 1.0:
-      _resolve_now()  # scaling reads the sums
-      pending = False
 
     def wrap(arr):
       da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
       da = da.transpose(*final_dims)
-      # deferred: keep the (possibly strided) view of the page-locked buffer the GPU is still writing -- no reads here
+      # deferred: keep the (possibly strided) view of the buffer the GPU is still writing / accumulating -- no reads here
       data = da.data if pending else np.array(da.values, order="C", copy=True)
       return xr.DataArray(data, dims=final_dims, coords=coords, name=stat.name, attrs=stat.attrs, _raw_coords=True)
 
     if scale != 1.0:
+      if pending:  # the factor is applied when the numbers are read (or after the accumulators have been reduced)
+        return AggregationState(_PendingLinear([(scale, wrap(values[lane]))], name=stat.name, attrs=stat.attrs),
+                                _PendingLinear([(scale, wrap(counts[lane]))], name=stat.name, attrs=stat.attrs))
       return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
     return AggregationState(wrap(values[lane]), wrap(counts[lane]))
 
@@ -398,10 +427,8 @@ class Aggregator:
     the statistic's trailing dimension."""
     grp = stat._group  # pylint: disable=protected-access
     cat_dim = stat._cat_dim  # pylint: disable=protected-access
+    # every category is a lane of one launch: `values` / `counts` are (category,) + out_dims views of its output
     values, counts, out_dims = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna)
-    _resolve_now()  # the lanes are stacked on the host
-    v = np.stack([np.asarray(a, np.float64) for a in values], axis=0)
-    c = np.stack([np.asarray(a, np.float64) for a in counts], axis=0)
     # NaN thresholds (deterministic.py:293-294) are NaN indicators inside the kernel already: poisoned sums, or counted
     # out under skipna, exactly where a valid point is involved
     dims_in = (cat_dim,) + tuple(out_dims)
@@ -412,9 +439,13 @@ class Aggregator:
         if set(x[0]) <= set(final_dims):
           coords.setdefault(k, x)
     order = [dims_in.index(d) for d in final_dims]
-    mk = lambda a: xr.DataArray(np.ascontiguousarray(np.transpose(a, order)), dims=final_dims, coords=coords,
-                                name=stat.name, attrs=stat.attrs, _raw_coords=True)
-    return AggregationState(mk(v), mk(c))
+    pending = engine.deferred_active() is not None
+
+    def mk(a):
+      a = np.transpose(np.asarray(a, dtype=np.float64), order)
+      return xr.DataArray(a if pending else np.ascontiguousarray(a), dims=final_dims, coords=coords, name=stat.name,
+                          attrs=stat.attrs, _raw_coords=True)
+    return AggregationState(mk(values), mk(counts))
 
   def _reduce_spectrum(self, stat: 'spectra.LazySpectrum', w_da, bin_dims):
     """Weighted mean of zonal spectra over rows (time, latitude, ...) without materialising per-row spectra:

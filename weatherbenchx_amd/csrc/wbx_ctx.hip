@@ -177,6 +177,12 @@ extern "C" int wbx_fence_wait(wbx_fence* f) {
   return 0;
 }
 
+extern "C" int wbx_ctx_wait_fence(wbx_ctx* ctx, wbx_fence* f) {
+  WBX_REQUIRE(ctx != nullptr && f != nullptr, "NULL argument");
+  WBX_HIP(hipStreamWaitEvent(ctx->stream, f->ev, 0));
+  return 0;
+}
+
 extern "C" int wbx_fence_destroy(wbx_fence* f) {
   if (f) {
     (void)hipEventDestroy(f->ev);

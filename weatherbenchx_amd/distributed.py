@@ -1,18 +1,29 @@
 """Accumulator reduction across GPUs: the counterpart of the Beam combine stage.
 
-The reference sums per-chunk accumulators with `beam.CombinePerKey(CombiningSum())`
-(weatherbenchX/beam_pipeline.py:509-510, weatherbenchX/beam_utils.py:30-50).  Here chunks of
-(init_time x lead_time) are sharded over one process per GPU and, when `init_time`/`lead_time` is reduced,
-every rank's AggregationState is packed into ONE float64 buffer and summed with a single all-reduce
-(RCCL over xGMI with backend 'nccl'; 'gloo' on CPU for tests).  The buffer is KBs..MBs, so the
-collective is latency bound and is issued once per job / step, never per chunk.
+The reference sums per-chunk accumulators with `beam.CombinePerKey(CombiningSum())` and concatenates the pieces that
+belong to different chunk offsets afterwards (weatherbenchX/beam_pipeline.py:121-137, 253-319, 509-510,
+weatherbenchX/beam_utils.py:30-50).  Here chunks of (init_time x lead_time) are sharded over one process per GPU; each
+rank ADDS its chunks' results into device-resident accumulator slots (engine.Accumulation: a slot per
+(aggregator, statistic, variable, surviving chunk offsets)).  At the end of the job
+
+  1. the ranks exchange their slot tables once (a small pickled all-gather: names, sizes, result frames),
+  2. every rank lays the UNION of all slots out in one float64 device buffer -- its own slots copied in, the others zero --
+  3. ONE sum all-reduce of that buffer (RCCL over xGMI on the device pointer with backend 'nccl'; 'gloo' on CPU in tests)
+     both adds the accumulators ranks share (a reduced time dim) and fills in the ones they own alone (a surviving time
+     dim: disjoint offsets -> the reference's concat),
+  4. the buffer is read back once and every result array is rebuilt as a view of it.
+
+The buffer is KBs..MBs, so the collective is latency bound and is issued once per job / step, never per
+chunk.  A `ReductionPlan` returned by the first call lets later calls with an unchanged layout skip step 1 (a bench
+loop that all-reduces every step).
 """
 from __future__ import annotations
 
 import numpy as np
 
+from weatherbenchx_amd import engine
 from weatherbenchx_amd import xarray_lite as xr
-from weatherbenchx_amd.aggregation import AggregationState
+from weatherbenchx_amd.aggregation import AggregationState, combining_sum
 
 
 def _leaves(tree, prefix=()):
@@ -25,59 +36,204 @@ def _leaves(tree, prefix=()):
     raise TypeError(f'unsupported leaf type {type(tree)}')
 
 
-def pack_state(state: AggregationState):
-  """-> (flat float64 vector, layout) with a deterministic (sorted-key) order shared by all ranks."""
-  items = []
-  for which, tree in (('sws', state.sum_weighted_statistics), ('sw', state.sum_weights)):
-    for path, da in _leaves(tree):
-      items.append((which, path, da))
-  flat = np.concatenate([np.asarray(da.values, dtype=np.float64).reshape(-1) for _, _, da in items]) if items \
-      else np.zeros(0)
-  layout = [(which, path, da.dims, da.shape) for which, path, da in items]
-  return flat, layout, items
-
-
-def unpack_state(flat: np.ndarray, items) -> AggregationState:
-  out = {'sws': {}, 'sw': {}}
-  pos = 0
-  for which, path, da in items:
-    n = da.size
-    new = da.copy(data=flat[pos:pos + n].reshape(da.shape))
-    pos += n
-    node = out[which]
-    for k in path[:-1]:
-      node = node.setdefault(k, {})
-    if path:
-      node[path[-1]] = new
-    else:
-      out[which] = new
-  return AggregationState(out['sws'], out['sw'])
-
-
-def all_reduce_state(state: AggregationState, group=None, *, force: bool = False) -> AggregationState:
-  """Sum of every rank's AggregationState (all ranks must hold the same statistics / shapes).  `force` runs the
-  collectives even in a one-rank group (the RCCL plumbing check of tests/test_gpu_cabi.py)."""
-  import torch  # pylint: disable=g-import-not-at-top
-  import torch.distributed as dist  # pylint: disable=g-import-not-at-top
-
-  if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-    return state
-  state.wait()
-  flat, layout, items = pack_state(state)
-  backend = dist.get_backend(group)
-  dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
-  # fixed-size fingerprint first (one MIN all-reduce of [n, -n] gives min and max of the packed length): ranks that
-  # disagree must fail loudly BEFORE the payload collective, which would otherwise crash or hang on ragged sizes.
-  n = float(flat.size + 1000003 * len(layout))
-  fp = torch.tensor([n, -n], dtype=torch.float64, device=dev)
-  dist.all_reduce(fp, op=dist.ReduceOp.MIN, group=group)
-  if float(fp[0]) != -float(fp[1]):
-    raise ValueError('AggregationState layouts differ between ranks; cannot all-reduce')
-  buf = torch.from_numpy(flat).to(dev)
-  dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-  return unpack_state(buf.cpu().numpy(), items)
-
-
 def shard_chunks(chunks: list, rank: int, world_size: int) -> list:
   """Round-robin assignment of time chunks to ranks (chunk i -> rank i mod n)."""
   return [c for i, c in enumerate(chunks) if i % world_size == rank]
+
+
+def _group_info(group):
+  """(world size, backend) of an initialised process group, (1, None) otherwise."""
+  try:
+    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+  except ImportError:
+    return 1, None
+  if not dist.is_available() or not dist.is_initialized():
+    return 1, None
+  return dist.get_world_size(group), dist.get_backend(group)
+
+
+class _DeviceView:
+  """Exposes wbx device memory to torch through the CUDA array interface (zero copy): RCCL then reduces the accumulator
+  buffer in place, no host hop."""
+
+  def __init__(self, ptr: int, n: int):
+    self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': '<f8', 'data': (int(ptr), False), 'version': 2,
+                                     'strides': None}
+
+
+def device_tensor(ptr: int, n: int, device_id: int):
+  import torch  # pylint: disable=g-import-not-at-top
+  return torch.as_tensor(_DeviceView(ptr, n), device=torch.device('cuda', device_id))
+
+
+class ReductionPlan:
+  """The global layout agreed on by the ranks: slot order / offsets and every leaf's views."""
+
+  def __init__(self, local_sig, order, offsets, total, leaves, frames):
+    self.local_sig, self.order, self.offsets, self.total = local_sig, order, offsets, total
+    self.leaves, self.frames = leaves, frames
+    self.collectives = 0  # sum all-reduces issued through this plan (tests / traces)
+
+
+def _key_sort(key):
+  return repr(key)
+
+
+def _local_meta(acc: engine.Accumulation):
+  slots = dict(acc.slot_table())
+  host = {}
+  for path, da in acc.host.items():
+    arr = np.array(da.values, dtype=np.float64, order='C')  # (ascontiguousarray would turn 0-d into 1-d)
+    key = ('host', path)
+    slots[key] = int(arr.size)
+    host[key] = arr
+    strides = tuple(int(s // 8) for s in arr.strides)
+    acc_spec = (key, 0, tuple(int(x) for x in arr.shape), strides, tuple(da.dims), 1.0)
+    lst = acc.specs.setdefault(path, [])
+    if acc_spec not in lst:
+      lst.append(acc_spec)
+      acc.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
+  leaves = {path: list(specs) for path, specs in acc.specs.items()}
+  frames = {(path, spec): acc.frames[(path, i)] for path, specs in leaves.items() for i, spec in enumerate(specs)}
+  return slots, host, leaves, frames
+
+
+def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: bool = True, plan: ReductionPlan | None = None,
+                        force: bool = False):
+  """-> ({path: DataArray}, ReductionPlan): every captured leaf of `acc`, summed over the ranks of `group`.
+
+  `all_reduce=False` resolves the local accumulators only.  `force` runs the collective even in a one-rank group (the
+  RCCL plumbing check on a single GPU).  Pass the returned plan back in while the local layout does not change to skip
+  the layout exchange (ranks whose layout DOES change must all call without a plan again)."""
+  world, backend = _group_info(group)
+  collective = all_reduce and (world > 1 or (force and backend is not None))
+  slots, host, leaves, frames = _local_meta(acc)
+  local_sig = (tuple(sorted(slots.items(), key=lambda kv: _key_sort(kv[0]))),
+               tuple(sorted(((p, tuple(s)) for p, s in leaves.items()), key=lambda kv: _key_sort(kv[0]))))
+  if plan is None or plan.local_sig != local_sig:
+    if plan is not None and collective:
+      raise ValueError('the accumulator layout changed under a cached ReductionPlan: call again without `plan` on '
+                       'every rank')
+    metas = [(slots, leaves, frames)]
+    if collective and world > 1:
+      import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+      gathered = [None] * world
+      dist.all_gather_object(gathered, (slots, leaves, frames), group=group)
+      metas = gathered
+    union: dict = {}
+    for sl, _, _ in metas:
+      for key, n in sl.items():
+        if union.setdefault(key, n) != n:
+          raise ValueError(f'accumulator {key} has {n} values on one rank and {union[key]} on another: the ranks '
+                           'do not run the same statistics / aggregators')
+    order = sorted(union, key=_key_sort)
+    offsets, total = {}, 0
+    for key in order:
+      offsets[key] = total
+      total += union[key]
+    all_leaves: dict = {}
+    all_frames: dict = {}
+    for _, lv, fr in metas:
+      for path, specs in lv.items():
+        have = all_leaves.setdefault(path, [])
+        for spec in specs:
+          if spec not in have:  # the same view of the same slot on several ranks is ONE array after the reduction
+            have.append(spec)
+            all_frames[(path, spec)] = fr[(path, spec)]
+    plan = ReductionPlan(local_sig, order, offsets, total, all_leaves, all_frames)
+
+  # ---- the values: this rank's slots at their global offsets, zero elsewhere, then ONE sum over the ranks --------
+  nccl = collective and backend == 'nccl'
+  if nccl:
+    import torch  # pylint: disable=g-import-not-at-top
+    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+    from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+    import ctypes as C  # pylint: disable=g-import-not-at-top
+    ctx = _hip.default_context()
+    gbuf = ctx.alloc(max(plan.total, 1) * 8)
+    _hip.check(ctx.lib.wbx_memset(ctx.handle, C.c_void_p(gbuf.ptr), 0, max(plan.total, 1) * 8), 'wbx_memset')
+    for c in acc.ctxs.values():  # the adds ran on their launch streams; the copies below run on the default one
+      if c is not ctx:
+        c.synchronize()
+    for key, (blk, off, n, _) in acc.slots.items():
+      if n:
+        _hip.check(ctx.lib.wbx_memcpy_d2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
+                                          C.c_void_p(blk.dev.ptr + 8 * off), n * 8), 'wbx_memcpy_d2d')
+    for key, arr in host.items():
+      if arr.size:
+        _hip.check(ctx.lib.wbx_memcpy_h2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
+                                          arr.ctypes.data_as(C.c_void_p), arr.nbytes), 'wbx_memcpy_h2d')
+    ctx.synchronize()
+    if plan.total:
+      t = device_tensor(gbuf.ptr, plan.total, ctx.device_id)
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # in place, on the device buffer
+      plan.collectives += 1
+      torch.cuda.current_stream(t.device).synchronize()
+      del t
+    flat = ctx.download(gbuf.ptr, (plan.total,), np.float64)
+  else:
+    acc.synchronize()
+    flat = np.zeros(plan.total, dtype=np.float64)
+    for key, arr in acc.download_slots().items():
+      flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr
+    for key, arr in host.items():
+      flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr.reshape(-1)
+    if collective and plan.total:
+      import torch  # pylint: disable=g-import-not-at-top
+      import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+      dist.all_reduce(torch.from_numpy(flat), op=dist.ReduceOp.SUM, group=group)
+      plan.collectives += 1
+
+  # ---- the arrays: views of the reduced buffer ----------------------------------------------------------------
+  out = {}
+  for path, specs in plan.leaves.items():
+    arrays = []
+    for spec in specs:
+      key, rel, shape, strides, dims, coeff = spec
+      base = plan.offsets[key] + rel
+      view = np.lib.stride_tricks.as_strided(flat[base:], shape=shape, strides=tuple(8 * s for s in strides),
+                                             writeable=False)
+      coords, name, attrs = plan.frames[(path, spec)]
+      data = np.array(view, order='C') if coeff == 1.0 else np.array(view, order='C') * coeff
+      arrays.append(xr.DataArray(data, dims=dims, coords=coords, name=name, attrs=attrs, _raw_coords=True))
+    out[path] = arrays[0] if len(arrays) == 1 else combining_sum(arrays)
+  return out, plan
+
+
+def resolve_state(state: AggregationState, acc: engine.Accumulation, group=None, *, all_reduce: bool = True,
+                  plan: ReductionPlan | None = None, force: bool = False):
+  """An AggregationState produced under `engine.accumulate_results(acc)` -> (the same tree with real numbers, summed
+  over the ranks of `group`; ReductionPlan).  Nothing is waited for before the collective: the state's sums never
+  visit the host on their own."""
+  fence = getattr(state, '_fence', None)
+  for which, tree in (('sws', state.sum_weighted_statistics), ('sw', state.sum_weights)):
+    for path, da in _leaves(tree):
+      acc.capture((which,) + tuple(path), da)
+  leaves, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=plan, force=force)
+  if fence is not None:
+    fence.wait()  # (already reached: the reduction synchronised the launch streams) releases the chunk's inputs
+    state._fence = None  # pylint: disable=protected-access
+  trees = {'sws': {}, 'sw': {}}
+  for path, da in leaves.items():
+    which, rest = path[0], path[1:]
+    if not rest:
+      trees[which] = da
+      continue
+    node = trees[which]
+    for k in rest[:-1]:
+      node = node.setdefault(k, {})
+    node[rest[-1]] = da
+  return AggregationState(trees['sws'], trees['sw']), plan
+
+
+def all_reduce_state(state: AggregationState, group=None, *, force: bool = False) -> AggregationState:
+  """Sum of every rank's (already resolved, host-side) AggregationState: the state is packed into an accumulation as
+  host leaves and goes through the same single collective.  Prefer `engine.accumulate_results` + `resolve_state`, which
+  keeps the sums on the device."""
+  world, backend = _group_info(group)
+  if world == 1 and not (force and backend is not None):
+    return state
+  state.wait()
+  acc = engine.Accumulation()
+  out, _ = resolve_state(state, acc, group, force=force)
+  return out

@@ -279,6 +279,10 @@ def _launch_context(kind: str = 'det'):
     return base
   if not _stream_ring or _stream_ring[0] is not base:
     _stream_ring[:] = [base, new_context()]
+  if _accum is not None:
+    # accumulating: the same launch of every chunk must land on the same stream, so that the adds into its
+    # accumulator slot are ordered by that stream
+    return _stream_ring[_accum.launch_turn(len(_stream_ring))]
   d.turn = (d.turn + 1) % len(_stream_ring)
   return _stream_ring[d.turn]
 
@@ -407,24 +411,211 @@ def deferred_active() -> DeferredResults | None:
 
 @contextlib.contextmanager
 def synchronous_results():
-  """Inside an enclosing `deferred_results()` block: read-backs issued here are complete when the call returns (for
-  callers that post-process the numbers on the host right away)."""
-  global _deferred
+  """Inside an enclosing `deferred_results()` / `accumulate_results()` block: results requested here are complete host
+  arrays when the call returns (for callers that post-process the numbers on the host right away)."""
+  global _deferred, _accum
   saved, _deferred = _deferred, None
+  saved_acc, _accum = _accum, None
   try:
     yield
   finally:
-    _deferred = saved
+    _deferred, _accum = saved, saved_acc
 
 
-def _download(ctx, ptr: int, shape) -> np.ndarray:
+def _deliver(ctx, ptr, shape) -> np.ndarray:
+  """Hands a finished device result (float64 `shape` at `ptr`) to the caller: added into the active accumulation
+  (the returned view only carries the layout, see Accumulation), read back asynchronously under deferred_results(),
+  or downloaded right away."""
+  if _accum is not None:
+    if _deferred is not None:
+      _deferred.ctxs[id(ctx)] = ctx
+    return _accum.accumulate(ctx, ptr, shape)
   if _deferred is not None:
     _deferred.ctxs[id(ctx)] = ctx
     return ctx.download_async(ptr, shape)
   return ctx.download(ptr, shape, np.float64)
 
 
-def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
+_download = _deliver  # (name kept for callers outside this module)
+
+
+def _acc_add(ctx, dst_buf, dst_off: int, src_ptr, n: int, overwrite: bool):
+  """acc[dst_off : dst_off + n] (+)= src on the context stream (wbx_acc_add)."""
+  _hip.check(ctx.lib.wbx_acc_add(ctx.handle, C.c_void_p(dst_buf.ptr + 8 * int(dst_off)), C.c_void_p(src_ptr), int(n),
+                                 int(bool(overwrite))), 'wbx_acc_add')
+
+
+class _AccBlock:
+  """A piece of the accumulator arena: device memory plus an (untouched, never read) host array of the same length whose
+  only job is to give numpy views an address -- (offset, shape, strides) of every result view is recovered from it."""
+
+  def __init__(self, ctx, nelem: int):
+    self.ctx = ctx
+    self.dev = ctx.alloc(nelem * 8)
+    self.shadow = np.empty(nelem, dtype=np.float64)
+    self.base = self.shadow.__array_interface__['data'][0]
+    self.cap, self.used = int(nelem), 0
+    self.starts: list = []  # slot offsets in allocation order (ascending)
+    self.keys: list = []
+
+
+class Accumulation:
+  """Device-resident accumulators of a chunk loop (the CombinePerKey(CombiningSum()) stage, beam_pipeline.py:509-510,
+  kept in HBM).
+
+  While it is active (`accumulate_results`), every reduction's device result is ADDED into a slot of this arena instead of
+  being read back; the slot is identified by (label, ordinal of the result under that label), so the same launch of a
+  later chunk with the same label lands on the same slot.  The arrays the Aggregator hands out meanwhile are views of a
+  shadow array: they carry dims / shape / strides but no numbers.  `capture()` records where such a view lives;
+  `distributed.reduce_accumulation` all-reduces the arena across ranks (one collective on the device buffer), reads it
+  back once and rebuilds every captured array on the result."""
+
+  BLOCK_ELEMS = 1 << 20  # 8 MB of accumulators per block; a larger slot gets a block of its own
+
+  def __init__(self):
+    self.blocks: list[_AccBlock] = []
+    self.slots: dict = {}          # key -> (block, offset, n, ctx)
+    self.label = None
+    self._ordinal = 0
+    self._launches = 0
+    self._turns: dict = {}
+    self.multi = False             # some slot has been added to more than once
+    self.host: dict = {}           # path -> DataArray summed on the host (results that never were on the device)
+    self.specs: dict = {}          # path -> [spec, ...]
+    self.frames: dict = {}         # (path, index) -> (coords, name, attrs)
+    self.ctxs: dict = {}
+
+  # -- bookkeeping driven by the chunk loop ---------------------------------------------------------------------
+  def set_label(self, label):
+    """Names what is being aggregated next (aggregator, statistic, variable, chunk offsets that survive): results under
+    the same label accumulate."""
+    self.label, self._ordinal, self._launches = label, 0, 0
+
+  def launch_turn(self, n: int) -> int:
+    key = (self.label, self._launches)
+    self._launches += 1
+    turn = self._turns.get(key)
+    if turn is None:
+      turn = self._turns[key] = len(self._turns) % n
+    return turn
+
+  # -- engine side ------------------------------------------------------------------------------------------------
+  def accumulate(self, ctx, src_ptr, shape) -> np.ndarray:
+    n = int(np.prod(shape, dtype=np.int64))
+    key = (self.label, self._ordinal)
+    self._ordinal += 1
+    slot = self.slots.get(key)
+    if slot is None:
+      blk = next((b for b in self.blocks if b.ctx is ctx and b.cap - b.used >= n), None)
+      if blk is None:
+        blk = _AccBlock(ctx, max(self.BLOCK_ELEMS, n))
+        self.blocks.append(blk)
+      slot = self.slots[key] = (blk, blk.used, n, ctx)
+      blk.starts.append(blk.used)
+      blk.keys.append(key)
+      blk.used += n
+      first = True
+    else:
+      if slot[2] != n:
+        raise ValueError(f'accumulating {key}: this chunk produced {n} values where earlier chunks produced {slot[2]} '
+                         '(chunks under one label must have the same result layout)')
+      if slot[3] is not ctx:
+        raise RuntimeError(f'accumulating {key}: launched on another stream than before')
+      first = False
+      self.multi = True
+    blk, off = slot[0], slot[1]
+    if n:
+      _acc_add(ctx, blk.dev, off, src_ptr, n, first)
+    self.ctxs[id(ctx)] = ctx
+    return blk.shadow[off:off + n].reshape(shape)
+
+  def locate(self, arr):
+    """(slot key, offset inside the slot, shape, element strides) of a view handed out by accumulate(), else None."""
+    if not isinstance(arr, np.ndarray) or arr.dtype != np.float64 or arr.size == 0:
+      return None
+    addr = arr.__array_interface__['data'][0]
+    for blk in self.blocks:
+      if blk.base <= addr < blk.base + 8 * blk.used:
+        pos = (addr - blk.base) // 8
+        import bisect  # pylint: disable=g-import-not-at-top
+        i = bisect.bisect_right(blk.starts, pos) - 1
+        key = blk.keys[i]
+        n = self.slots[key][2]
+        rel = pos - blk.starts[i]
+        strides = tuple(int(st // 8) for st in arr.strides)
+        last = rel + sum((sz - 1) * st for sz, st in zip(arr.shape, strides))
+        if not 0 <= last < n:
+          raise RuntimeError('a result view reaches outside its accumulator slot')
+        return key, int(rel), tuple(int(x) for x in arr.shape), strides
+    return None
+
+  # -- result side ------------------------------------------------------------------------------------------------
+  def capture(self, path, da, coeff: float = 1.0):
+    """Remembers that the leaf `path` of the final result is (the sum over captures of) coeff * this array.  Arrays that
+    are not views of the arena hold finished numbers: they are summed on the host under `path`."""
+    terms = getattr(da, '_wbx_terms', None)
+    if terms is not None:  # a linear combination of pending arrays (aggregation._PendingLinear)
+      for c, term in terms:
+        self.capture(path, term, coeff * c)
+      return
+    loc = self.locate(da.data)
+    if loc is None:
+      val = da if coeff == 1.0 else da * coeff
+      if path in self.host:
+        a, b = xr.align(self.host[path], val, join='outer', fill_value=0)
+        val = a + b
+      self.host[path] = val
+      return
+    spec = loc + (tuple(da.dims), float(coeff))
+    lst = self.specs.setdefault(path, [])
+    if spec not in lst:
+      lst.append(spec)
+      self.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
+
+  def synchronize(self):
+    for ctx in self.ctxs.values():
+      ctx.synchronize()
+
+  def slot_table(self):
+    """[(key, n)] in allocation order."""
+    return [(k, v[2]) for k, v in self.slots.items()]
+
+  def download_slots(self) -> dict:
+    """key -> float64 ndarray (one synchronous read-back per block)."""
+    out = {}
+    for blk in self.blocks:
+      if not blk.used:
+        continue
+      host = blk.ctx.download(blk.dev.ptr, (blk.used,), np.float64)
+      for start, key in zip(blk.starts, blk.keys):
+        out[key] = host[start:start + self.slots[key][2]]
+    return out
+
+
+_accum: Accumulation | None = None
+
+
+@contextlib.contextmanager
+def accumulate_results(acc: Accumulation):
+  """Inside the block (which also is a `deferred_results()` block: nothing is waited for) every reduction adds its device
+  result into `acc`; the states the Aggregator returns carry layout only.  Resolve with
+  `distributed.reduce_accumulation(acc)` / `distributed.resolve_state(state, acc)` after the block."""
+  global _accum
+  prev = _accum
+  with deferred_results() as d:
+    _accum = acc
+    try:
+      yield d
+    finally:
+      _accum = prev
+
+
+def accumulation_active() -> Accumulation | None:
+  return _accum
+
+
+def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf):
+  """-> (device pointer, shape) of out[nA][nBk][lanes][nj_out][nbin]."""
   st = _hip.S2PlanStruct(s2.nA, s2.nBk, s2.nBr, s2.nchunk, s2.nlane, s2.nj, s2.nbin, int(s2.sum_j))
   shape = s2.out_shape()
   n = int(np.prod(shape, dtype=np.int64))
@@ -435,7 +626,7 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf) -> np.ndarray:
   else:
     _hip.check(ctx.lib.wbx_contract(ctx.handle, C.byref(st), C.c_void_p(partial_ptr), C.c_void_p(w_buf.bufs[0].ptr),
                                     C.c_void_p(out.ptr)), 'wbx_contract')
-  return _download(ctx, out.ptr, shape)
+  return out.ptr, shape
 
 
 # 'auto': the fused binned kernel runs when the stage-1 partials would exceed BINNED_PARTIAL_RATIO x the input bytes
@@ -461,8 +652,8 @@ def _binned_eligible(kind, plan: planner.S1Plan, w_buf, devs, nl_total: int, nin
 
 
 def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_code: int, nl_total: int, func: int,
-                w_buf) -> np.ndarray:
-  """wbx_det_binned: out[nA][nBk][lanes][1][nbin] (same shape as the sum_j stage-2 result)."""
+                w_buf):
+  """wbx_det_binned -> (device pointer, shape) of out[nA][nBk][lanes][1][nbin] (like the sum_j stage-2 result)."""
   nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
   nbin = w_buf.shape[-1]
   shape = (nA, nBk, nl_total, 1, nbin)
@@ -485,7 +676,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin,
                          'w_flags': w_flags})
-  return _download(ctx, out.ptr, shape)
+  return out.ptr, shape
 
 
 def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
@@ -516,9 +707,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   kind 'det' / 'ens' / 'cat' (indicator statistics: `cat` = {'func', 'ncat', 'thresholds' (float64 ndarray or None),
   'member_dim' (or None), 'M'}; one value lane per category).
 
-  Returns (values, counts, out_dims): `values[lane]` is an ndarray over out_dims =
-  (A dims..., Bk dims..., [x dim], bin dims...); `counts` is the matching sum of W over valid
-  elements -- per lane when mask/skipna is active, else a single array shared by every lane.
+  Returns (values, counts, out_dims): `values` is ONE array (lanes,) + out_dims, out_dims =
+  (A dims..., Bk dims..., [x dim], bin dims...) -- a view of the kernel's output, so `values[lane]` is a view too;
+  `counts` (same shape) is the matching sum of W over valid elements: per lane under skipna, one lane broadcast to all
+  under a mask alone, else a data-independent constant broadcast to all.
   """
   global _deferred
   ctx = ctx or _launch_context(kind)
@@ -581,22 +773,29 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
   if _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
-    out = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
+    res = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
   else:
     partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args)
-    out = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
+    res = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
+  out = _deliver(ctx, *res)
 
   x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()
   out_dims = plan.a_dims + plan.bk_dims + x_out + tuple(bin_dims)
   lead_shape = [plan.sizes[d] for d in plan.a_dims] + [plan.sizes[d] for d in plan.bk_dims]
   tail_shape = [plan.sizes[d] for d in x_out] + list(bin_shape)
 
-  def lane_array(l):
-    return out[:, :, l].reshape(lead_shape + tail_shape)
+  def lanes_of(first, count):
+    # (count,) + out_dims as a VIEW of out[nA][nBk][lane][nj_out][nbin]: lanes first, then the A / Bk / x / bin axes split
+    # into their dims (splitting axes never copies), so the result can still be filled in later (deferred read-back) or
+    # be located in an accumulator slot
+    v = np.moveaxis(out[:, :, first:first + count], 2, 0).reshape([count] + lead_shape + tail_shape)
+    if v.size and not np.may_share_memory(v, out):
+      raise RuntimeError('internal: lane view of a reduction result was copied')
+    return v
 
-  values = [lane_array(l) for l in range(nl)]
+  values = lanes_of(0, nl)
   if counted:
-    counts = [lane_array(nl)] * nl if shared_count else [lane_array(nl + l) for l in range(nl)]
+    counts = np.broadcast_to(lanes_of(nl, 1), values.shape) if shared_count else lanes_of(nl, nl)
   else:
     # data-independent: (elements folded per partial) * sum of W, computed by the same stage-2 kernel
     ckey = (id(w_buf), s2.nBk, s2.nBr, s2.nj, s2.nbin, s2.sum_j, plan.reduced_count_per_partial())
@@ -605,11 +804,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
       ones = np.full((1, s2.nBk, s2.nBr, 1, 1, s2.nj), float(plan.reduced_count_per_partial()), dtype=np.float64)
       s2c = planner.S2Plan(nA=1, nBk=s2.nBk, nBr=s2.nBr, nchunk=1, nlane=1, nj=s2.nj, nbin=s2.nbin, sum_j=s2.sum_j)
       ones_buf = ctx.upload(ones)
-      saved, _deferred = _deferred, None  # computed once per geometry and cached: read it back synchronously
-      try:
-        cnt = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
-      finally:
-        _deferred = saved
+      cptr, cshape = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
+      cnt = ctx.download(cptr, cshape, np.float64)  # computed once per geometry and cached: read back synchronously
       if len(_count_cache) > 64:
         _count_cache.clear()
       _count_cache[ckey] = (cnt, w_buf)  # keep w_buf alive so its id stays unique
@@ -618,7 +814,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
     cnt = np.broadcast_to(cnt[:, :, 0], (s2.nA,) + cnt[:, :, 0].shape[1:]).reshape(lead_shape + tail_shape)
     if x_weights is not None:  # sum of the folded weights over the reduced elements: (others reduced) * sum_x w[x]
       cnt = cnt * (float(x_weights.sum()) / plan.nx)
-    counts = [cnt] * nl
+    counts = np.broadcast_to(cnt, values.shape)
   return values, counts, out_dims
 
 

@@ -388,8 +388,9 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
   def data(self):
     if self._data is None:
       grp = self._group
-      values, _, out_dims = grp.reduce((), None, (), use_mask=False, skipna=False)
-      arr = np.stack([np.asarray(v, np.float64) for v in values], axis=-1)
+      with engine.synchronous_results():
+        values, _, out_dims = grp.reduce((), None, (), use_mask=False, skipna=False)
+      arr = np.moveaxis(np.asarray(values, np.float64), 0, -1)
       arr = np.transpose(arr, [out_dims.index(d) for d in grp.dims] + [len(out_dims)])
       self._data = np.ascontiguousarray(arr)
     return self._data

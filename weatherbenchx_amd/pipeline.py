@@ -96,74 +96,83 @@ class ChunkFeeder:
       yield item[0], predictions, targets
 
 
-def _consume(chunks, metrics, aggregators, commit):
-  """Launches every chunk; the accumulators of chunk k are combined after chunk k+1 has been enqueued."""
+def _offset_key(offsets, stat_dims, reduce_dims):
+  """(init offset | None, lead offset | None): the chunk offsets of the time dims that survive the aggregation
+  (`_AggregationKey`, beam_pipeline.py:121-137, :221-232)."""
+  keep = lambda d: d in stat_dims and d not in reduce_dims
+  return (offsets.init_time if keep('init_time') else None, offsets.lead_time if keep('lead_time') else None)
+
+
+def _consume(chunks, metrics, aggregators, acc):
+  """Launches every chunk.  A chunk's results are ADDED to the device accumulators of `acc` right behind its kernels
+  (slot = aggregator, statistic, variable, surviving offsets); the host only records where each result lives.  The
+  inputs of chunk k are released once chunk k+1 has been enqueued."""
   previous = []
   for offsets, predictions, targets in chunks:
-    entries = []
+    states = []
     for stat_name, stats in metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets):
       for var_name, stat in stats.items():
         for agg_name, agg in aggregators.items():
+          dims = getattr(stat, 'dims', ())
+          key = _offset_key(offsets, dims, set(agg.reduce_dims))
+          acc.set_label((agg_name, stat_name, str(var_name), key))
           state = agg.aggregate_stat_var(stat)
           if state is None:
             continue
-          dims = state.sum_weighted_statistics.dims
-          key = (offsets.init_time if 'init_time' in dims else None,
-                 offsets.lead_time if 'lead_time' in dims else None)
-          entries.append((state, agg_name, stat_name, var_name, key))
-    commit(previous)
-    previous = entries
-  return previous
+          got = state.sum_weighted_statistics.dims
+          assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
+          for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
+            acc.capture((agg_name, kind, stat_name, str(var_name), key), da)
+          states.append(state)
+    for state in previous:
+      state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
+    previous = states
+  for state in previous:
+    state.wait()
 
 
 def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[str, metrics_base.Metric],
-                    aggregator, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True, prefetch: int = 0):
+                    aggregator, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True, prefetch: int = 0,
+                    group=None, force_collective: bool = False):
   """Returns {aggregator_name: AggregationState} (key None for a single unnamed aggregator).
 
   `load_chunk(init_times, lead_times) -> (predictions, targets)`; chunks are sharded round-robin over ranks.
   `prefetch` > 0 loads and uploads that many chunks ahead on a feeder thread (ChunkFeeder).
+
+  The accumulators stay in HBM for the whole loop (engine.Accumulation).  With `all_reduce` and an initialised
+  torch.distributed group of more than one rank, the ranks' accumulators are combined with ONE sum all-reduce of one
+  device buffer at the end (distributed.reduce_accumulation): accumulators of a reduced time dim add up, those of a
+  surviving `init_time` / `lead_time` are owned by the rank that ran the chunk and are zero elsewhere, so the same
+  collective also assembles the pieces the reference concatenates (beam_pipeline.py:253-319).  Every rank returns the
+  complete result.  `force_collective` issues the collective even in a one-rank group (plumbing tests on one GPU).
   """
   aggregators = {None: aggregator} if isinstance(aggregator, aggregation.Aggregator) else dict(aggregator)
-  # acc[agg][type][stat][var][(init_off, lead_off)] -> DataArray
-  acc = {name: {'sum_weighted_statistics': {}, 'sum_weights': {}} for name in aggregators}
   work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
-
-  def commit(entries):
-    # CombiningSum of one chunk's accumulators (beam_pipeline.py:509-510); waits for that chunk's read-back only
-    for state, agg_name, stat_name, var_name, key in entries:
-      state.wait()
-      for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
-        slot = acc[agg_name][kind].setdefault(stat_name, {}).setdefault(str(var_name), {})
-        slot[key] = da if key not in slot else aggregation.combining_sum([slot[key], da])
-
-  # Software pipeline over chunks: the sums of chunk k are read back asynchronously and combined only after the
-  # kernels of chunk k+1 have been enqueued, so the GPU never waits for the host-side bookkeeping.
-  with engine.deferred_results():
+  acc = engine.Accumulation()
+  # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
+  # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
+  with engine.accumulate_results(acc):
     if prefetch:
       chunks = ChunkFeeder(work, load_chunk, depth=prefetch)
     else:
       chunks = ((offsets, *load_chunk(init_chunk, lead_chunk)) for offsets, (init_chunk, lead_chunk) in work)
     try:
-      previous = _consume(chunks, metrics, aggregators, commit)
+      _consume(chunks, metrics, aggregators, acc)
     finally:
       if prefetch:
         chunks.close()
-    commit(previous)
+  leaves, _ = distributed.reduce_accumulation(acc, group, all_reduce=all_reduce and (world_size > 1 or force_collective),
+                                              force=force_collective)
 
+  # acc[agg][type][stat][var][(init_off, lead_off)] -> DataArray
+  trees = {name: {'sum_weighted_statistics': {}, 'sum_weights': {}} for name in aggregators}
+  for (agg_name, kind, stat_name, var_name, key), da in leaves.items():
+    trees[agg_name][kind].setdefault(stat_name, {}).setdefault(var_name, {})[key] = da
   out = {}
   for agg_name in aggregators:
-    trees = {}
-    for kind in ('sum_weighted_statistics', 'sum_weights'):
-      trees[kind] = {s: {v: _concat_pieces(p) for v, p in per_var.items()} for s, per_var in acc[agg_name][kind].items()}
-    state = aggregation.AggregationState(trees['sum_weighted_statistics'], trees['sum_weights'])
-    if all_reduce and world_size > 1:
-      reduced_all_time = all(('init_time' not in da.dims and 'lead_time' not in da.dims)
-                             for _, da in distributed._leaves(state.sum_weighted_statistics))  # pylint: disable=protected-access
-      if not reduced_all_time:
-        raise NotImplementedError('all-reduce with surviving init_time/lead_time needs an all-gather of disjoint '
-                                  'offsets; run with all_reduce=False and concatenate on the host')
-      state = distributed.all_reduce_state(state)
-    out[agg_name] = state
+    done = {kind: {s: {v: _concat_pieces(p) for v, p in per_var.items()} for s, per_var in trees[agg_name][kind].items()}
+            for kind in ('sum_weighted_statistics', 'sum_weights')}
+    out[agg_name] = aggregation.AggregationState(done['sum_weighted_statistics'], done['sum_weights'])
   return out
 
 

@@ -101,7 +101,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
                                               int(geo.batch), int(offs.size), offs.ctypes.data_as(C.c_void_p), int(nlon),
                                               C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr), int(ngroup), 0,
                                               C.c_void_p(out.ptr)), 'wbx_zonal_spectrum_slabs')
-  return engine._download(ctx, out.ptr, (ngroup, nk))  # pylint: disable=protected-access
+  return engine._deliver(ctx, out.ptr, (ngroup, nk))  # pylint: disable=protected-access
 
 
 class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
