@@ -318,7 +318,7 @@ class Aggregator:
 
     pending = engine.deferred_active() is not None
 
-    def wrap(arr):
+    def wrap(arr):  # (`values[lane, ...]`: the ellipsis keeps a 0-d result a view instead of a scalar copy)
       da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
       da = da.transpose(*final_dims)
       # deferred: keep the (possibly strided) view of the buffer the GPU is still writing / accumulating -- no reads here
@@ -327,10 +327,10 @@ class Aggregator:
 
     if scale != 1.0:
       if pending:  # the factor is applied when the numbers are read (or after the accumulators have been reduced)
-        return AggregationState(_PendingLinear([(scale, wrap(values[lane]))], name=stat.name, attrs=stat.attrs),
-                                _PendingLinear([(scale, wrap(counts[lane]))], name=stat.name, attrs=stat.attrs))
-      return AggregationState(wrap(values[lane] * scale), wrap(counts[lane] * scale))
-    return AggregationState(wrap(values[lane]), wrap(counts[lane]))
+        return AggregationState(_PendingLinear([(scale, wrap(values[lane, ...]))], name=stat.name, attrs=stat.attrs),
+                                _PendingLinear([(scale, wrap(counts[lane, ...]))], name=stat.name, attrs=stat.attrs))
+      return AggregationState(wrap(values[lane, ...] * scale), wrap(counts[lane, ...] * scale))
+    return AggregationState(wrap(values[lane, ...]), wrap(counts[lane, ...]))
 
   def __setattr__(self, name, value):
     # the cached weight products below belong to the configuration they were built for

@@ -446,13 +446,13 @@ def _acc_add(ctx, dst_buf, dst_off: int, src_ptr, n: int, overwrite: bool):
 
 
 class _AccBlock:
-  """A piece of the accumulator arena: device memory plus an (untouched, never read) host array of the same length whose
-  only job is to give numpy views an address -- (offset, shape, strides) of every result view is recovered from it."""
+  """A piece of the accumulator arena: device memory plus a (never read) host array of the same length whose only job
+  is to give numpy views an address -- (offset, shape, strides) of every result view is recovered from it."""
 
   def __init__(self, ctx, nelem: int):
     self.ctx = ctx
     self.dev = ctx.alloc(nelem * 8)
-    self.shadow = np.empty(nelem, dtype=np.float64)
+    self.shadow = np.full(nelem, np.nan, dtype=np.float64)  # NaN: reading a layout-only view by mistake is loud
     self.base = self.shadow.__array_interface__['data'][0]
     self.cap, self.used = int(nelem), 0
     self.starts: list = []  # slot offsets in allocation order (ascending)
@@ -553,7 +553,7 @@ class Accumulation:
   def capture(self, path, da, coeff: float = 1.0):
     """Remembers that the leaf `path` of the final result is (the sum over captures of) coeff * this array.  Arrays that
     are not views of the arena hold finished numbers: they are summed on the host under `path`."""
-    terms = getattr(da, '_wbx_terms', None)
+    terms = getattr(da, '_linear_terms', None)
     if terms is not None:  # a linear combination of pending arrays (aggregation._PendingLinear)
       for c, term in terms:
         self.capture(path, term, coeff * c)
