@@ -1,24 +1,41 @@
 #!/usr/bin/env python3
 """Benchmark of the scoring hot path on MI355X (driver contract: one JSON line on rank 0).
 
-Workload (BASELINE.json configs[1]): area-weighted RMSE / MSE / MAE / bias / ACC / prediction activity on one
-variable block float32[40 init, 10 lead, 5 level, 721 lat, 1440 lon] for predictions and targets plus a
-(dayofyear, hour)-indexed climatology, reduced over (init_time, latitude, longitude) with GridAreaWeighting --
-through the drop-in API (Statistic.compute -> Aggregator.aggregate_statistics -> metric_values), inputs resident
-in HBM.  A "step" is one such pass; the K timed steps are software-pipelined one deep like pipeline.evaluate_chunks
-(the sums of step k are read back asynchronously and turned into metric values after step k+1 has been launched;
-every step is launched and finished inside the timed region).  With --gpus N every rank owns a block of the same size (weak scaling) and
-the packed fp64 accumulators are summed with ONE all-reduce (RCCL) per step.
+`python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment the script launches
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU,
+backend 'nccl' = RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Fewer visible devices than N: one JSON
+line with "skipped" and exit code 0.
+
+Main line (BASELINE.json configs[1]): area-weighted RMSE / MSE / MAE / bias / ACC / prediction activity on one variable
+block float32[40 init, 10 lead, 5 level, 721 lat, 1440 lon] for predictions and targets plus a (dayofyear, hour)-indexed
+climatology, reduced over (init_time, latitude, longitude) with GridAreaWeighting -- through the drop-in API
+(Statistic.compute -> Aggregator.aggregate_statistics -> metric_values), inputs resident in HBM.  A "step" is one such
+pass; the K timed steps are software-pipelined one deep like pipeline.evaluate_chunks (every step is launched and
+finished inside the timed region).  With N ranks every rank owns a block of the same size (weak scaling): the step's
+sums stay in HBM (engine.Accumulation) and are summed over the ranks with ONE all-reduce of the device buffer per step
+(distributed.resolve_state; the layout is exchanged once, before the first step).
 
 value    = (points per step x 6 metrics x N) / wall time per step (max over ranks), evals/s
-roofline = algorithmic bytes (12 B/point: p, t, c read once) / mean stage-1 kernel duration (HIP events on the
-           launch stream, separate pass), against 8.0 TB/s
-cpu_baseline = the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
-           statistics; oracle/wbx_oracle.py) on a 10 init x 5 lead sample (~4 s), rank 0, N=1 only.
+roofline = algorithmic bytes (12 B/point: p, t, c read once) / mean stage-1 kernel duration (HIP events on the launch
+           stream, separate pass), against 8.0 TB/s
+
+Side legs in the same line (N = 1 unless noted):
+  rmse_crps_37L  the north_star's target field: weighted CRPS + spread/skill + ensemble-mean RMSE on ONE
+                 f32[37 level, 51 member, 721, 1440] forecast (7.99 GB) against f32[37, 721, 1440] targets
+  ensemble       configs[2]: 6 variables x f32[8, 51, 721, 1440]
+  public_chunk   the public benchmark's chunk (1 init x 12 lead x 13 level, 34 region x land/sea bins, masked)
+  spectrum       configs[3]: zonal spectra of two f32[8, 37, 721, 1440] fields
+  config5        configs[4] (every N): the full suite streamed as [1 init x 20 lead x 37 level] chunks from a resident
+                 pool through pipeline.evaluate_chunks, 366 inits sharded i mod N, accumulators in HBM, ONE all-reduce
+                 per pass at the end; strong scaling (total work fixed)
+  cpu_baseline   the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
+                 statistics; oracle/wbx_oracle.py) on a bounded sample: one process, and os.cpu_count() worker
+                 processes over time slices (oracle/cpu_workers.py); rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC = 'grid-point·metric evals/s (area-weighted RMSE/MSE/MAE/bias/ACC/activity, 0.25deg 721x1440)'
 
 
 def parse():
@@ -39,134 +57,194 @@ def parse():
   ap.add_argument('--leads', type=int, default=10)
   ap.add_argument('--levels', type=int, default=5)
   ap.add_argument('--layout', choices=['lon_fastest', 'lat_fastest'], default='lon_fastest')
-  ap.add_argument('--no-ens', action='store_true', help='skip the ensemble (configs[2]) side measurement')
+  ap.add_argument('--no-ens', action='store_true', help='skip the single-GPU side legs (ensemble, 37L, public chunk, spectrum)')
   ap.add_argument('--ens-slices', type=int, default=8)
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
+  ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
+  ap.add_argument('--config5-inits', type=int, default=366)
+  ap.add_argument('--cpu-workers', type=int, default=0, help='worker processes of the multi-core CPU baseline (0 = os.cpu_count())')
   ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
   return ap.parse_args()
 
 
-def main():
-  args = parse()
-  import torch
-  import torch.distributed as dist
-  from weatherbenchx_amd import _hip, aggregation, distributed, engine, weighting
+def self_launch(args):
+  """`python bench.py --gpus N` from a bare shell: re-run under torch.distributed.run, one rank per GPU."""
+  from weatherbenchx_amd import _hip
+  ndev = _hip.device_count() if os.path.exists(_hip.lib_path()) else 0
+  if ndev < args.gpus:
+    print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps,
+                      'warmup': args.warmup, 'skipped': True, 'higher_is_better': True,
+                      'reason': f'--gpus {args.gpus} needs {args.gpus} visible devices, this box has {ndev} '
+                                '(one rank per GPU: RCCL refuses two ranks on one device)'}))
+    return 0
+  import socket
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  return subprocess.call(cmd, env=env)
+
+
+class Env:
+  """Everything the legs share: process group, device, grid, generators."""
+
+  def __init__(self, args):
+    import torch
+    import torch.distributed as dist
+    from weatherbenchx_amd import _hip
+    self.args, self.torch, self.dist = args, torch, dist
+    self.world = int(os.environ.get('WORLD_SIZE', '1'))
+    self.rank = int(os.environ.get('RANK', '0'))
+    self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(self.local_rank)
+    self.dev = torch.device('cuda', self.local_rank)
+    if self.world > 1:
+      dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+    self.ctx = _hip.default_context(self.local_rank)
+    self.nlat, self.nlon = (721, 1440) if not args.small else (73, 144)
+    self.lat = np.linspace(-90, 90, self.nlat)
+    self.lon = np.linspace(0, 360, self.nlon, endpoint=False)
+    self.sp = ('latitude', 'longitude') if args.layout == 'lon_fastest' else ('longitude', 'latitude')
+    self.gen = torch.Generator(device=self.dev)
+    self.gen.manual_seed(1234 + self.rank)
+
+  def randn(self, shp, offset=0.0, scale=1.0):
+    t = self.torch.randn(shp, generator=self.gen, device=self.dev, dtype=self.torch.float32)
+    if scale != 1.0:
+      t *= scale
+    if offset != 0.0:
+      t += offset
+    return t
+
+  def sp_shape(self):
+    return tuple({'latitude': self.nlat, 'longitude': self.nlon}[d] for d in self.sp)
+
+  def sync(self):
+    self.torch.cuda.synchronize()
+    self.ctx.synchronize()
+    if self.world > 1:
+      self.dist.barrier()
+      self.torch.cuda.synchronize()
+
+  def max_over_ranks(self, seconds):
+    if self.world == 1:
+      return seconds
+    t = self.torch.tensor([seconds], device=self.dev, dtype=self.torch.float64)
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def fresh(d):
+  """New DataArray objects on the same payloads: nothing (statistics, plan results) is cached across steps."""
   from weatherbenchx_amd import xarray_lite as xr
-  from weatherbenchx_amd.metrics import deterministic, probabilistic, wrappers
+  return {k: xr.DataArray(v.data, dims=v.dims, coords={c: v[c].values for c in v.dims}) for k, v in d.items()}
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-  torch.cuda.set_device(local_rank)
-  dev = torch.device('cuda', local_rank)
-  if world > 1:
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-  ctx = _hip.default_context(local_rank)
 
-  nlat, nlon = (721, 1440) if not args.small else (73, 144)
+def pipelined(launch, finish, n):
+  """n steps, one deep: step k+1 is launched before step k is finished (host bookkeeping overlaps the kernels)."""
+  out, pending = None, None
+  for _ in range(n):
+    cur = launch()
+    if pending is not None:
+      out = finish(pending)
+    pending = cur
+  if pending is not None:
+    out = finish(pending)
+  return out
+
+
+def kernel_roofline(name, ms, nbytes, traffic=None):
+  ach = nbytes / (ms * 1e-3) / 1e9
+  return {'bound': 'hbm', 'kernel': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+          'frac': round(ach / HBM_PEAK_GBS, 4), 'kernel_ms': round(ms, 4), 'algorithmic_bytes_per_launch': int(nbytes),
+          'traffic': traffic}
+
+
+def pmc_traffic(kernel_key, enabled=True):
+  """HBM traffic per launch from the separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on gfx950,
+  + WRITE_SIZE), committed under profiles/ -- PMC collection cannot run inside the timed process."""
+  import glob
+  files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+  if not files or not enabled:
+    return None
+  entry = json.load(open(files[-1])).get(kernel_key.split(' (')[0])
+  return None if not entry else entry.get('traffic_bytes_per_launch')
+
+
+# ---- main line: configs[1] -----------------------------------------------------------------------------------------
+def main_leg(env):
+  from weatherbenchx_amd import aggregation, distributed, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic
+  args = env.args
   ni, nl, nlev = (args.inits, args.leads, args.levels) if not args.small else (4, 3, 2)
-  lat = np.linspace(-90, 90, nlat)
-  lon = np.linspace(0, 360, nlon, endpoint=False)
   init_time = np.datetime64('2020-01-01T00', 'ns') + np.arange(ni) * np.timedelta64(24, 'h')
   lead_time = (np.arange(nl) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
   ndoy = int(ni + (nl * 6) // 24 + 2)
-  coords = {'init_time': init_time, 'lead_time': lead_time, 'level': np.arange(nlev), 'latitude': lat, 'longitude': lon}
-  sp = ('latitude', 'longitude') if args.layout == 'lon_fastest' else ('longitude', 'latitude')
-  dims = ('init_time', 'lead_time', 'level') + sp
-  cdims = ('dayofyear', 'hour', 'level') + sp
+  coords = {'init_time': init_time, 'lead_time': lead_time, 'level': np.arange(nlev), 'latitude': env.lat, 'longitude': env.lon}
+  dims = ('init_time', 'lead_time', 'level') + env.sp
+  cdims = ('dayofyear', 'hour', 'level') + env.sp
   shape = tuple(len(coords[d]) for d in dims)
-  gen = torch.Generator(device=dev)
-  gen.manual_seed(1234 + rank)
-
-  def randn(shp, offset=0.0, scale=1.0):
-    return torch.randn(shp, generator=gen, device=dev, dtype=torch.float32) * scale + offset
-
-  cshape = (ndoy, 4) + shape[2:]
-  clim_t = randn(cshape, 280.0, 10.0)
+  clim_t = env.randn((ndoy, 4) + shape[2:], 280.0, 10.0)
   clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=cdims, coords={
       'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), **{d: coords[d] for d in cdims[2:]}})})
-  p_t = randn(shape, 280.0)
-  t_t = randn(shape, 280.0)
+  p_t, t_t = env.randn(shape, 280.0), env.randn(shape, 280.0)
   p = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}
   t = {'z': xr.DataArray(t_t, dims=dims, coords=coords)}
-  torch.cuda.synchronize()
-
+  env.torch.cuda.synchronize()
   metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(),
              'bias': deterministic.Bias(), 'acc': deterministic.ACC(clim),
              'prediction_activity': deterministic.PredictionActivity(clim)}
-  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
-                               weigh_by=[weighting.GridAreaWeighting()])
-  from weatherbenchx_amd.metrics import base as metrics_base
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  plan_box = [None]
 
-  def fresh(d):
-    # new DataArray objects every step: nothing (statistics, plans results) is cached across steps
-    return {k: xr.DataArray(v.data, dims=v.dims, coords={c: v[c].values for c in v.dims}) for k, v in d.items()}
+  def stats():
+    return metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(p), fresh(t))
 
-  def launch():
-    # Statistic.compute -> Aggregator.aggregate_statistics: enqueues the kernels and the read-back of the sums
-    pp, tt = fresh(p), fresh(t)
-    stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, pp, tt)
-    return agg.aggregate_statistics(stats)
+  if env.world == 1:
+    def launch():  # Statistic.compute -> Aggregator.aggregate_statistics: enqueues the kernels and the read-back
+      return agg.aggregate_statistics(stats())
 
-  def finish(state):
-    # waits for THAT step's sums only, then (all-reduce and) metric values on the host
-    if world > 1:
-      state = distributed.all_reduce_state(state)
-    return state.metric_values(metrics)
+    def finish(state):  # waits for THAT step's sums only, then the metric values on the host
+      return state.metric_values(metrics)
 
-  def step():
-    return finish(launch())
+    def run(n):
+      with engine.deferred_results():
+        return pipelined(launch, finish, n)
+  else:
+    def launch():  # the step's sums stay in HBM ...
+      acc = engine.Accumulation()
+      with engine.accumulate_results(acc):
+        return agg.aggregate_statistics(stats()), acc
 
-  def run(n):
-    """n steps, software-pipelined like pipeline.evaluate_chunks: step k+1 is launched before step k's sums are
-    turned into metric values, so the host-side bookkeeping overlaps the kernels.  Every step is launched AND
-    finished inside the call."""
-    out, pending = None, None
-    with engine.deferred_results():
-      for _ in range(n):
-        state = launch()
-        if pending is not None:
-          out = finish(pending)
-        pending = state
-      if pending is not None:
-        out = finish(pending)
-    return out
+    def finish(pair):  # ... and are summed over the ranks with ONE all-reduce of the device buffer, read back once
+      state, plan_box[0] = distributed.resolve_state(pair[0], pair[1], plan=plan_box[0])
+      return state.metric_values(metrics)
 
-  def sync():
-    torch.cuda.synchronize()
-    ctx.synchronize()
-    if world > 1:
-      dist.barrier()
-      torch.cuda.synchronize()
+    def run(n):
+      return pipelined(launch, finish, n)
 
   out = run(args.warmup)
-  sync()
+  env.sync()
+  c0 = plan_box[0].collectives if plan_box[0] is not None else 0
   t0 = time.perf_counter()
   out = run(args.steps)
-  sync()
-  dt = time.perf_counter() - t0
-  if world > 1:
-    tt_ = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-    dt = float(tt_.item())
+  env.sync()
+  dt = env.max_over_ranks(time.perf_counter() - t0)
   ms_per_step = dt / args.steps * 1e3
   points = int(np.prod(shape, dtype=np.int64))
-  n_metrics = len(metrics)
-  value = points * n_metrics * world / (ms_per_step * 1e-3)
+  value = points * len(metrics) * env.world / (ms_per_step * 1e-3)
 
-  # ---- roofline leg: HIP events around the dominant (stage-1) kernel, separate pass -------------------
-  engine.S1_EVENT_LOG = []
-  engine.S1_EVENT_REPEAT = 10  # 10 back-to-back launches per HIP-event pair
+  # roofline leg: HIP events around the dominant (stage-1) kernel, separate pass, 10 launches per event pair
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 10
   for _ in range(3):
-    step()
+    agg.aggregate_statistics(stats()).metric_values(metrics)
   log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'det']
   engine.S1_EVENT_LOG = None
   k_ms = float(np.mean([e['ms'] for e in log]))
-  alg_bytes = points * 12
-  achieved = alg_bytes / (k_ms * 1e-3) / 1e9
   if log[0].get('flat'):
     kname = 's1_xf_kernel<DetOp<float,DET6>> (latitude weights folded into stage 1, flat float4 sweep)'
   elif log[0].get('x_weighted'):
@@ -177,220 +255,347 @@ def main():
     kname = f"s1_xk_kernel<DetOp<float,DET6>,{log[0]['vec']}>"
   else:
     kname = f"s1_xr_kernel<DetOp<float,DET6>,{log[0]['vec']}>"
-  roofline = {'bound': 'hbm', 'kernel': kname,
-              'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-              'kernel_ms': round(k_ms, 4), 'algorithmic_bytes_per_launch': alg_bytes, 'traffic': None}
-
-  # HBM traffic per launch from the separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on gfx950,
-  # + WRITE_SIZE), committed under profiles/ -- PMC collection cannot run inside the timed process.
-  def pmc_traffic(kernel_key):
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
-    if not files or args.small or (ni, nl, nlev) != (40, 10, 5):
-      return None
-    table = json.load(open(files[-1]))
-    entry = table.get(kernel_key.split(' (')[0])
-    return None if not entry else entry.get('traffic_bytes_per_launch')
-  roofline['traffic'] = pmc_traffic(kname)
+  full = (not args.small) and (ni, nl, nlev) == (40, 10, 5)
+  roofline = kernel_roofline(kname, k_ms, points * 12, pmc_traffic(kname, full))
   roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
   result = {
-      'metric': 'grid-point·metric evals/s (area-weighted RMSE/MSE/MAE/bias/ACC/activity, 0.25deg 721x1440)',
-      'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-      'dtype': 'f64', 'data': 'synthetic',
-      'config': {'workload': f'configs[1]: f32[{ni} init,{nl} lead,{nlev} level,{nlat},{nlon}] p,t + (doy,hour) climatology, '
+      'metric': METRIC, 'value': value, 'unit': 'evals/s', 'n_gpus': env.world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+      'data': 'synthetic',
+      'config': {'workload': f'configs[1]: f32[{ni} init,{nl} lead,{nlev} level,{env.nlat},{env.nlon}] p,t + (doy,hour) climatology, '
                              f'reduce (init_time,latitude,longitude), GridAreaWeighting, {args.layout}',
-                 'points_per_step_per_gpu': points, 'metrics': list(metrics), 'input_dtype': 'f32',
-                 'accumulators': 'f64', 'layout': args.layout,
-                 'host_pipeline': 'deferred read-back, steps overlapped one deep (engine.deferred_results)', 'sharding': f'{world} x (init x lead) blocks, 1 all-reduce/step'},
+                 'points_per_step_per_gpu': points, 'metrics': list(metrics), 'input_dtype': 'f32', 'accumulators': 'f64',
+                 'layout': args.layout,
+                 'host_pipeline': 'steps overlapped one deep; ' + ('deferred read-back (engine.deferred_results)' if env.world == 1 else
+                                  'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
+                 'sharding': f'{env.world} x (init x lead) blocks (one per rank), 1 all-reduce/step',
+                 'rccl_ranks': env.world if env.world > 1 else 0,
+                 'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
       'roofline': roofline,
   }
-
   # sanity: values must be finite and physically plausible (sigma=1 errors -> rmse ~ sqrt(2))
   r = float(np.asarray(out['rmse.z'].values).mean())
   assert np.isfinite(r) and abs(r - np.sqrt(2.0)) < 0.01, r
   result['check'] = {'rmse_mean': r, 'acc_mean': float(np.asarray(out['acc.z'].values).mean())}
+  keep = (p_t, t_t, clim_t, coords, nlev, ni, nl, len(metrics))
+  return result, keep
 
-  # ---- ensemble side measurement (configs[2] shape: 51 members, CRPS + spread/skill) ---------------------
-  if not args.no_ens and world == 1:
-    m = 51
+
+# ---- ensemble legs ---------------------------------------------------------------------------------------------------
+def ensemble_suite():
+  from weatherbenchx_amd.metrics import deterministic, probabilistic, wrappers
+  return {'crps': probabilistic.CRPSEnsemble(use_sort=True),
+          'unbiased_spread_skill': probabilistic.UnbiasedSpreadSkillRatio(),
+          'unbiased_mean_rmse': probabilistic.UnbiasedEnsembleMeanRMSE(),
+          'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
+
+
+def ens_leg(env, lead_dim, nlead, nvar, name, describe):
+  """`nvar` variables x f32[nlead, 51, lat, lon] against f32[nlead, lat, lon]: one fused launch per variable."""
+  from weatherbenchx_amd import aggregation, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  args, m = env.args, 51
+  sp_shape = env.sp_shape()
+  cs = {'latitude': env.lat, 'longitude': env.lon}
+  tv = {f'v{i}': env.randn((nlead,) + sp_shape, 280.0) for i in range(nvar)}
+  pe, te = {}, {}
+  for k, v in tv.items():
+    ens = env.randn((nlead, m) + sp_shape)
+    ens += v[:, None]
+    pe[k] = xr.DataArray(ens, dims=(lead_dim, 'number') + env.sp, coords=cs)
+    te[k] = xr.DataArray(v, dims=(lead_dim,) + env.sp, coords=cs)
+  env.torch.cuda.synchronize()
+  emetrics = ensemble_suite()
+  eagg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+  def launch():
+    return eagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(emetrics, fresh(pe), fresh(te)))
+
+  def run(n):
+    with engine.deferred_results():
+      return pipelined(launch, lambda s: s.metric_values(emetrics), n)
+  run(2)
+  env.sync()
+  t0 = time.perf_counter()
+  eout = run(args.steps)
+  env.sync()
+  e_ms = (time.perf_counter() - t0) / args.steps * 1e3
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 20 if nlead <= 8 else 5
+  for _ in range(3):
+    launch().metric_values(emetrics)
+  elog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+  engine.S1_EVENT_LOG = None
+  epoints = nlead * env.nlat * env.nlon  # per variable launch
+  ek_ms = float(np.mean([e['ms'] for e in elog]))
+  kname = ('s1_xf1_kernel<EnsOpF32<51,true,SORT>> (folded weights, one point per lane)' if elog[0].get('flat')
+           else 's1_xr_kernel<EnsOpF32<51,true,SORT>,1>')
+  out = {'workload': describe, 'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
+         'metrics': list(emetrics),
+         'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4,
+                                     pmc_traffic(kname, nlead == 8 and not args.small)),
+         'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
+                   'spread_skill_v0_mean': float(np.asarray(eout['unbiased_spread_skill.v0'].values).mean())}}
+  del pe, te, tv
+  return name, out
+
+
+# ---- public-benchmark chunk ----------------------------------------------------------------------------------------
+def public_chunk_leg(env):
+  from weatherbenchx_amd import aggregation, binning, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic
+  sys.path.insert(0, os.path.join(ROOT, 'tools'))
+  from wb_regions import REGIONS  # the reference's region table restated as data
+  args = env.args
+  pl, plev = (12, 13) if not args.small else (3, 2)
+  pdims = ('init_time', 'lead_time', 'level') + env.sp
+  cdims = ('dayofyear', 'hour', 'level') + env.sp
+  pcoords = {'init_time': np.array(['2020-01-01T00'], dtype='datetime64[ns]'),
+             'lead_time': (np.arange(pl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]'),
+             'level': np.arange(plev), 'latitude': env.lat, 'longitude': env.lon}
+  pshape = tuple(len(pcoords[d]) for d in pdims)
+  pp_t, pt_t = env.randn(pshape, 280.0), env.randn(pshape, 280.0)
+  pclim = xr.Dataset({'z': xr.DataArray(env.randn((10, 4) + pshape[2:], 280.0, 10.0), dims=cdims, coords={
+      'dayofyear': np.arange(1, 11), 'hour': np.array([0, 6, 12, 18]), **{d: pcoords[d] for d in cdims[2:]}})})
+  land = (np.sin(np.deg2rad(env.lon) * 3)[None, :] * np.cos(np.deg2rad(env.lat) * 2.5)[:, None]) > 0.35
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': env.lat, 'longitude': env.lon})
+  pmetrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'bias': deterministic.Bias(),
+              'acc': deterministic.ACC(pclim), 'prediction_activity': deterministic.PredictionActivity(pclim)}
+  pagg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                                bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+  env.torch.cuda.synchronize()
+
+  def plaunch():
+    return pagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(
+        pmetrics, {'z': xr.DataArray(pp_t, dims=pdims, coords=pcoords)}, {'z': xr.DataArray(pt_t, dims=pdims, coords=pcoords)}))
+
+  def prun(n):
+    with engine.deferred_results():
+      return pipelined(plaunch, lambda s: s.metric_values(pmetrics), n)
+  prun(args.warmup)
+  env.sync()
+  t0 = time.perf_counter()
+  pout = prun(args.steps * 2)
+  env.sync()
+  p_ms = (time.perf_counter() - t0) / (args.steps * 2) * 1e3
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
+  plaunch().wait()
+  plog = list(engine.S1_EVENT_LOG)
+  engine.S1_EVENT_LOG = None
+  ppoints = int(np.prod(pshape))
+  k_ms = float(np.sum([e['ms'] for e in plog]))
+  return {'workload': f'public benchmark chunk: f32[1 init,{pl} lead,{plev} level,{env.nlat},{env.nlon}] p,t + climatology, '
+                      f'rmse/mse/bias/acc/activity, GridAreaWeighting, {len(REGIONS)} regions x land/sea = '
+                      f'{2 * len(REGIONS)} bins, masked=True, {args.layout}',
+          'ms_per_chunk': p_ms, 'value': ppoints * len(pmetrics) / (p_ms * 1e-3), 'unit': 'evals/s',
+          'kernels': [e.get('kind') for e in plog],
+          'roofline': kernel_roofline('wbx_det_binned (atomise + main + finish)', k_ms, ppoints * 12),
+          'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
+
+
+# ---- zonal spectra ----------------------------------------------------------------------------------------------------
+def spectrum_leg(env):
+  from weatherbenchx_amd import aggregation, engine, spectra, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  args = env.args
+  nt_s, nlev_s = (8, 37) if not args.small else (2, 3)
+  sdims = ('lead_time', 'level') + env.sp
+  scoords = {'latitude': env.lat, 'longitude': env.lon}
+  shp = (nt_s, nlev_s) + env.sp_shape()
+  sp_p = {'z': xr.DataArray(env.randn(shp, 280.0), dims=sdims, coords=scoords)}
+  sp_t = {'z': xr.DataArray(env.randn(shp, 280.0), dims=sdims, coords=scoords)}
+  env.torch.cuda.synchronize()
+  smetrics = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+  sagg = aggregation.Aggregator(reduce_dims=['lead_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+  def launch():
+    return sagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(smetrics, fresh(sp_p), fresh(sp_t)))
+
+  def srun(n):  # the spectrum read-back goes through the deferred-result path like the other legs
+    with engine.deferred_results():
+      return pipelined(launch, lambda s: s.metric_values(smetrics), n)
+  srun(3)
+  env.sync()
+  t0 = time.perf_counter()
+  sout = srun(args.steps)
+  env.sync()
+  s_ms = (time.perf_counter() - t0) / args.steps * 1e3
+  spoints = nt_s * nlev_s * env.nlat * env.nlon
+  parseval = float(np.asarray(sout['spectrum_p.z'].values)[0].sum())
+  return {'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{env.nlat},{env.nlon}] each, area-weighted '
+                      'mean over (lead_time, latitude); fused in-LDS mixed-radix FFT + fp64 |F|^2 reduction (one pass over the '
+                      'field); parity unpinned (no reference implementation, SURVEY F3)',
+          'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms,
+          'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
+          'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+          'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
+
+
+# ---- configs[4]: the full suite streamed over (init x lead) chunks, sharded over the ranks ------------------------
+def config5_leg(env):
+  from weatherbenchx_amd import aggregation, pipeline, spectra, time_chunks, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import deterministic
+  args = env.args
+  ninit = args.config5_inits if not args.small else 6
+  nlead, nlev, m = (20, 37, 51) if not args.small else (3, 2, 5)
+  npool = 2
+  lead_time = (np.arange(nlead) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  init_times = np.datetime64('2020-01-01T00', 'ns') + np.arange(ninit) * np.timedelta64(24, 'h')
+  level = np.arange(nlev)
+  zdims = ('init_time', 'lead_time', 'level') + env.sp
+  edims = ('init_time', 'lead_time', 'number') + env.sp
+  tdims = ('init_time', 'lead_time') + env.sp
+  cdims = ('dayofyear', 'hour', 'level') + env.sp
+  sp_shape = env.sp_shape()
+  # resident pool (H2D excluded and stated): chunk i reads buffer i mod npool; the climatology holds every
+  # (dayofyear, hour) slot the 366 inits x 20 leads touch in a ring of 12 days (dayofyear = 1 + (i mod 6) + lead days)
+  pool = []
+  for _ in range(npool):
+    ens = env.randn((1, nlead, m) + sp_shape)
+    t2 = env.randn((1, nlead) + sp_shape, 280.0)
+    ens += t2[:, :, None]
+    pool.append({'z_p': env.randn((1, nlead, nlev) + sp_shape, 280.0), 'z_t': env.randn((1, nlead, nlev) + sp_shape, 280.0),
+                 't2m_p': ens, 't2m_t': t2})
+  ndoy = 12
+  clim = xr.Dataset({'z': xr.DataArray(env.randn((ndoy, 4, nlev) + sp_shape, 280.0, 10.0), dims=cdims, coords={
+      'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), 'level': level,
+      'latitude': env.lat, 'longitude': env.lon})})
+  env.torch.cuda.synchronize()
+  index_of = {int(t.astype('int64')): i for i, t in enumerate(init_times)}
+  ring = np.datetime64('2020-01-01T00', 'ns') + np.arange(6) * np.timedelta64(24, 'h')
+
+  def coords_for(inits):
+    # the chunk keeps its real init_time label for the result; the climatology is addressed through a valid_time
+    # coordinate in the 6-day ring, so that 366 inits fit a 12-day resident climatology
+    i = index_of[int(inits[0].astype('int64'))]
+    return i, {'init_time': inits, 'lead_time': lead_time, 'latitude': env.lat, 'longitude': env.lon,
+               'valid_time': (('init_time', 'lead_time'), ring[i % 6] + lead_time[None, :])}
+
+  def load_det(inits, leads):
+    i, cs = coords_for(inits)
+    buf = pool[i % npool]
+    cz = dict(cs, level=level)
+    return ({'z': xr.DataArray(buf['z_p'], dims=zdims, coords=cz)}, {'z': xr.DataArray(buf['z_t'], dims=zdims, coords=cz)})
+
+  def load_ens(inits, leads):
+    i, cs = coords_for(inits)
+    buf = pool[i % npool]
+    return ({'t2m': xr.DataArray(buf['t2m_p'], dims=edims, coords=cs)}, {'t2m': xr.DataArray(buf['t2m_t'], dims=tdims, coords=cs)})
+
+  det = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias(),
+         'acc': deterministic.ACC(clim), 'prediction_activity': deterministic.PredictionActivity(clim)}
+  spec = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+  ens = ensemble_suite()
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  passes = [('deterministic', load_det, det, area), ('spectra', load_det, spec, zonal), ('ensemble', load_ens, ens, area)]
+
+  def run(times):
+    out = {}
+    for name, load, metrics, agg in passes:
+      state = pipeline.evaluate_chunks(times, load, metrics, agg, rank=env.rank, world_size=env.world)[None]
+      out[name] = state.metric_values(metrics)
+    return out
+  warm = time_chunks.TimeChunks(init_times[:2 * env.world], lead_time, init_time_chunk_size=1)
+  run(warm)
+  env.sync()
+  times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+  t0 = time.perf_counter()
+  out = run(times)
+  env.sync()
+  dt = env.max_over_ranks(time.perf_counter() - t0)
+  grid = env.nlat * env.nlon
+  pz, pt = nlead * nlev * grid, nlead * grid
+  evals_per_chunk = pz * len(det) + pz * len(spec) + pt * len(ens)
+  bytes_per_chunk = pz * 12 + pz * 8 + pt * (m + 1) * 4
+  rm = float(np.asarray(out['deterministic']['rmse.z'].values).mean())
+  return {'workload': f'configs[4]: full suite on {ninit} inits x {nlead} leads, streamed as [1 init x {nlead} lead] chunks from a '
+                      f'resident pool of {npool} (H2D excluded): z f32[{nlead},{nlev},{env.nlat},{env.nlon}] p,t + climatology -> '
+                      f'rmse/mse/mae/bias/acc/activity + zonal spectra of p and t; t2m f32[{nlead},{m},{env.nlat},{env.nlon}] -> '
+                      'crps/spread-skill/unbiased-mean rmse/mean rmse; reduce (init_time, latitude, longitude) -> per (lead, level)',
+          'sharding': f'chunk i -> rank i mod {env.world}; accumulators in HBM; one all-reduce per pass (3 passes) at the end',
+          'scaling': 'strong', 'n_gpus': env.world, 'chunks': ninit, 'time_slices': ninit * nlead, 'seconds': dt,
+          'ms_per_chunk': dt / ninit * 1e3, 'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
+          'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
+          'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),
+          'check': {'rmse_z_mean': rm, 'crps_t2m_mean': float(np.asarray(out['ensemble']['crps.t2m'].values).mean()),
+                    'shape_rmse_z': list(out['deterministic']['rmse.z'].shape)}}
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_leg(env, keep):
+  from oracle import cpu_workers
+  from oracle import wbx_oracle as O
+  args = env.args
+  p_t, t_t, clim_t, _, nlev, ni, nl, n_metrics = keep
+  si, sl = min(10, ni), min(5, nl)  # ~50 of the 400 (init, lead) slices: a few seconds of single-thread NumPy
+  idx = (slice(0, si), slice(0, sl))
+  ph, th = p_t[idx].cpu().numpy(), t_t[idx].cpu().numpy()
+  # an already-aligned climatology of the same shape (the reference's .sel gather is NOT charged to the CPU side)
+  ch = clim_t[:si, :1].expand(si, sl, *clim_t.shape[2:]).contiguous().cpu().numpy()
+  w = O.grid_area_weights(env.lat)
+  if args.layout == 'lat_fastest':
+    ph, th, ch = (np.ascontiguousarray(np.swapaxes(a, -1, -2)) for a in (ph, th, ch))
+  t0 = time.perf_counter()
+  O.reference_structure_deterministic(ph, th, ch, w)
+  cdt = time.perf_counter() - t0
+  spoints = int(np.prod(ph.shape))
+  one = spoints * n_metrics / cdt
+  out = {'value': one, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+         'sample': f'{si} init x {sl} lead x {nlev} level x {env.nlat} x {env.nlon} of the same workload '
+                   f'({spoints} points, {cdt:.1f} s; NumPy elementwise + einsum, single thread)',
+         'host_cpus': os.cpu_count()}
+  nworkers = args.cpu_workers or (os.cpu_count() or 1)
+  try:
+    per = 2 if not args.small else 1  # (init, lead) slices per worker
+    t0 = time.perf_counter()
+    res = cpu_workers.run(nworkers, per, nlev, env.nlat, env.nlon)
+    out['all_cores'] = {'value': res['points'] * n_metrics / res['seconds'], 'unit': 'evals/s', 'cores': nworkers,
+                        'kind': 'port', 'sample': f"{nworkers} worker processes x {per} (init, lead) slices x {nlev} level x "
+                                                  f"{env.nlat} x {env.nlon} ({res['points']} points, {res['seconds']:.2f} s between the "
+                                                  f'start barrier and the last finish; {time.perf_counter() - t0:.1f} s with process start-up)',
+                        'speedup_over_one_core': res['points'] * n_metrics / res['seconds'] / one}
+  except Exception as e:  # pylint: disable=broad-except
+    out['all_cores'] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
+  return out
+
+
+def main():
+  args = parse()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(self_launch(args))
+  if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
+  env = Env(args)
+  result, keep = main_leg(env)
+  if not args.no_ens and env.world == 1:
+    nl37 = 37 if not args.small else 3
+    name, leg = ens_leg(env, 'level', nl37, 1, 'rmse_crps_37L',
+                        f'north_star target: weighted CRPS(rank form, fair) + unbiased spread/skill + unbiased-mean RMSE + '
+                        f'ensemble-mean RMSE on ONE f32[{nl37} level,51 member,{env.nlat},{env.nlon}] forecast vs '
+                        f'f32[{nl37},{env.nlat},{env.nlon}] targets, reduce (latitude, longitude), GridAreaWeighting')
+    result[name] = leg
     ns = args.ens_slices if not args.small else 2
     nvar = 6 if not args.small else 2
-    tv = {f'v{i}': randn((ns, nlat, nlon), 280.0) for i in range(nvar)}
-    pe = {k: xr.DataArray(v[:, None] + randn((ns, m, nlat, nlon)), dims=('lead_time', 'number', 'latitude', 'longitude'),
-                          coords={'latitude': lat, 'longitude': lon}) for k, v in tv.items()}
-    te = {k: xr.DataArray(v, dims=('lead_time', 'latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
-          for k, v in tv.items()}
-    torch.cuda.synchronize()
-    emetrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True),
-                'unbiased_spread_skill': probabilistic.UnbiasedSpreadSkillRatio(),
-                'unbiased_mean_rmse': probabilistic.UnbiasedEnsembleMeanRMSE(),
-                'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
-    eagg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
-
-    def estep():
-      return aggregation.compute_metric_values_for_single_chunk(emetrics, eagg, fresh(pe), fresh(te))
-
-    def erun(n):  # software-pipelined like the main loop: launch step k+1, then turn step k's sums into metric values
-      out_, prev = None, None
-      with engine.deferred_results():
-        for _ in range(n):
-          cur = eagg.aggregate_statistics(
-              metrics_base.compute_unique_statistics_for_all_metrics(emetrics, fresh(pe), fresh(te)))
-          if prev is not None:
-            out_ = prev.metric_values(emetrics)
-          prev = cur
-        out_ = prev.metric_values(emetrics)
-      return out_
-    eout = erun(2)
-    sync()
-    t0 = time.perf_counter()
-    eout = erun(args.steps)
-    sync()
-    e_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    engine.S1_EVENT_LOG = []
-    engine.S1_EVENT_REPEAT = 20
-    for _ in range(3):
-      estep()
-    elog = [e['ms'] for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
-    engine.S1_EVENT_LOG = None
-    epoints = ns * nlat * nlon  # per variable launch
-    ek_ms = float(np.mean(elog))
-    e_bytes = epoints * (m + 1) * 4
-    e_ach = e_bytes / (ek_ms * 1e-3) / 1e9
-    result['ensemble'] = {
-        'workload': f'configs[2]: {nvar} vars x f32[{ns} slices,{m} members,{nlat},{nlon}], CRPS(rank form, fair) + '
-                    'unbiased spread/skill + unbiased-mean RMSE + mean RMSE',
-        'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
-        'roofline': {'bound': 'hbm', 'kernel': 's1_xr_kernel<EnsOpF32<51,true,SORT>,1>', 'achieved': round(e_ach, 1),
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(e_ach / HBM_PEAK_GBS, 4),
-                     'kernel_ms': round(ek_ms, 4), 'algorithmic_bytes_per_launch': e_bytes,
-                     'traffic': pmc_traffic('s1_xr_kernel<EnsOpF32<51,true,SORT>,1>') if ns == 8 else None},
-        'check': {'crps_v0': float(np.asarray(eout['crps.v0'].values).mean())}}
-    del pe, te, tv
-
-    # ---- public-benchmark chunk side measurement: 1 init x 12 leads x 13 levels, 17 regions x land/sea = 34 bins --
-    # (public_benchmark/run_benchmark_evaluation.py:97-131, 369-382): the one-pass binned kernel, pipelined like
-    # pipeline.evaluate_chunks
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    from wb_regions import REGIONS  # the reference's region table restated as data
-    from weatherbenchx_amd import binning
-    pl, plev = (12, 13) if not args.small else (3, 2)
-    pdims = ('init_time', 'lead_time', 'level') + sp
-    pcoords = {'init_time': init_time[:1], 'lead_time': (np.arange(pl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]'),
-               'level': np.arange(plev), 'latitude': lat, 'longitude': lon}
-    pshape = tuple(len(pcoords[d]) for d in pdims)
-    pp_t, pt_t = randn(pshape, 280.0), randn(pshape, 280.0)
-    pclim = xr.Dataset({'z': xr.DataArray(randn((10, 4) + pshape[2:], 280.0, 10.0), dims=cdims, coords={
-        'dayofyear': np.arange(1, 11), 'hour': np.array([0, 6, 12, 18]), **{d: pcoords[d] for d in cdims[2:]}})})
-    land = (np.sin(np.deg2rad(lon) * 3)[None, :] * np.cos(np.deg2rad(lat) * 2.5)[:, None]) > 0.35
-    lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
-    pmetrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'bias': deterministic.Bias(),
-                'acc': deterministic.ACC(pclim), 'prediction_activity': deterministic.PredictionActivity(pclim)}
-    pagg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'],
-                                  weigh_by=[weighting.GridAreaWeighting()],
-                                  bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
-    torch.cuda.synchronize()
-
-    def plaunch():
-      return pagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(
-          pmetrics, {'z': xr.DataArray(pp_t, dims=pdims, coords=pcoords)}, {'z': xr.DataArray(pt_t, dims=pdims, coords=pcoords)}))
-
-    def prun(n):
-      out_, prev = None, None
-      with engine.deferred_results():
-        for _ in range(n):
-          cur = plaunch()
-          if prev is not None:
-            out_ = prev.metric_values(pmetrics)
-          prev = cur
-        out_ = prev.metric_values(pmetrics)
-      return out_
-    prun(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    pout = prun(args.steps * 2)
-    sync()
-    p_ms = (time.perf_counter() - t0) / (args.steps * 2) * 1e3
-    engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
-    plaunch().wait()
-    plog = [e['ms'] for e in engine.S1_EVENT_LOG]
-    engine.S1_EVENT_LOG = None
-    ppoints = int(np.prod(pshape))
-    result['public_chunk'] = {
-        'workload': f'public benchmark chunk: f32[1 init,{pl} lead,{plev} level,{nlat},{nlon}] p,t + climatology, '
-                    f'rmse/mse/bias/acc/activity, GridAreaWeighting, {len(REGIONS)} regions x land/sea = '
-                    f'{2 * len(REGIONS)} bins, masked=True, {args.layout}',
-        'ms_per_chunk': p_ms, 'value': ppoints * len(pmetrics) / (p_ms * 1e-3), 'unit': 'evals/s',
-        'kernel': 'wbx_det_binned (det_binned_kernel + union + finish)', 'kernel_ms': round(float(np.sum(plog)), 4),
-        'algorithmic_GBps': round(ppoints * 12 / (p_ms * 1e-3) / 1e9, 1),
-        'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
-    del pp_t, pt_t, pclim
-
-    # ---- zonal spectra side measurement (configs[3] shape: 37 levels; fused FFT + |F|^2 reduction) ------------------
-    from weatherbenchx_amd import spectra
-    nt_s, nlev_s = (8, 37) if not args.small else (2, 3)
-    sdims = ('lead_time', 'level', 'latitude', 'longitude')
-    scoords = {'latitude': lat, 'longitude': lon}
-    sp_p = {'z': xr.DataArray(randn((nt_s, nlev_s, nlat, nlon), 280.0), dims=sdims, coords=scoords)}
-    sp_t = {'z': xr.DataArray(randn((nt_s, nlev_s, nlat, nlon), 280.0), dims=sdims, coords=scoords)}
-    torch.cuda.synchronize()
-    smetrics = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
-    sagg = aggregation.Aggregator(reduce_dims=['lead_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
-
-    def srun(n):  # pipelined like the other legs: the spectrum read-back goes through the deferred-result path too
-      out_, prev = None, None
-      with engine.deferred_results():
-        for _ in range(n):
-          cur = sagg.aggregate_statistics(
-              metrics_base.compute_unique_statistics_for_all_metrics(smetrics, fresh(sp_p), fresh(sp_t)))
-          if prev is not None:
-            out_ = prev.metric_values(smetrics)
-          prev = cur
-        out_ = prev.metric_values(smetrics)
-      return out_
-    sout = srun(3)
-    sync()
-    t0 = time.perf_counter()
-    sout = srun(args.steps)
-    sync()
-    s_ms = (time.perf_counter() - t0) / args.steps * 1e3
-    spoints = nt_s * nlev_s * nlat * nlon
-    parseval = float(np.asarray(sout['spectrum_p.z'].values)[0].sum())
-    result['spectrum'] = {
-        'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{nlat},{nlon}] each, area-weighted '
-                    'mean over (lead_time, latitude); fused in-LDS mixed-radix FFT + fp64 |F|^2 reduction (one pass over the field); parity unpinned '
-                    '(no reference implementation, SURVEY F3)',
-        'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms,
-        'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
-        'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
-    del sp_p, sp_t
-
-  # ---- CPU baseline (rank 0, N=1): oracle's reference-structure NumPy path on a bounded sample -------------
-  if not args.no_cpu and world == 1 and rank == 0:
-    from oracle import wbx_oracle as O
-    si, sl = min(10, ni), min(5, nl)  # ~50 of the 400 (init, lead) slices: 10-30 s of single-thread NumPy
-    idx = (slice(0, si), slice(0, sl))
-    ph, th = p_t[idx].cpu().numpy(), t_t[idx].cpu().numpy()
-    # an already-aligned climatology of the same shape (the reference's .sel gather is NOT charged to the CPU side)
-    ch = clim_t[:si, :1].expand(si, sl, *clim_t.shape[2:]).contiguous().cpu().numpy()
-    if args.layout == 'lat_fastest':
-      ph, th, ch = (np.ascontiguousarray(np.swapaxes(a, -1, -2)) for a in (ph, th, ch))
-    w = O.grid_area_weights(lat)
-    t0 = time.perf_counter()
-    O.reference_structure_deterministic(ph, th, ch, w)
-    cdt = time.perf_counter() - t0
-    spoints = int(np.prod(ph.shape))
-    result['cpu_baseline'] = {'value': spoints * n_metrics / cdt, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-                              'sample': f'{si} init x {sl} lead x {nlev} level x {nlat} x {nlon} of the same workload '
-                                        f'({spoints} points, {cdt:.1f} s; NumPy elementwise + einsum, single thread)',
-                              'host_cpus': os.cpu_count()}
-  if rank == 0:
+    name, leg = ens_leg(env, 'lead_time', ns, nvar, 'ensemble',
+                        f'configs[2]: {nvar} vars x f32[{ns} slices,51 members,{env.nlat},{env.nlon}], CRPS(rank form, fair) + '
+                        'unbiased spread/skill + unbiased-mean RMSE + mean RMSE')
+    result[name] = leg
+    result['public_chunk'] = public_chunk_leg(env)
+    result['spectrum'] = spectrum_leg(env)
+  if not args.no_config5:
+    result['config5'] = config5_leg(env)
+  if not args.no_cpu and env.world == 1 and env.rank == 0:
+    result['cpu_baseline'] = cpu_leg(env, keep)
+  if env.rank == 0:
     print(json.dumps(result))
-  if world > 1:
-    dist.destroy_process_group()
+  if env.world > 1:
+    env.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -179,3 +179,30 @@ def test_lazy_mean_drops_nans_by_default(backend):
   np.testing.assert_allclose(se.mean('lead_time').values, want, rtol=1e-9)           # default: skipna like xarray
   np.testing.assert_allclose(se.mean('lead_time', skipna=True).values, want, rtol=1e-9)
   assert np.isnan(se.mean('lead_time', skipna=False).values[0, 0])
+
+
+def test_group_grows_from_det3_to_det6_between_aggregations(backend):
+  """A statistic aggregated BEFORE a climatology statistic joins its fused group (the reference's one-at-a-time
+  generator order, beam_pipeline.py:186-197) must not make the later anomaly lanes read the cached 3-lane result."""
+  rng = np.random.default_rng(9)
+  coords = {'latitude': LAT, 'longitude': LON,
+            'init_time': np.array(['2020-01-01T00', '2020-01-02T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(2) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')}
+  dims = ('init_time', 'lead_time', 'latitude', 'longitude')
+  p = {'v': xr.DataArray(rng.normal(size=(2, 2, 32, 64)).astype(np.float32), dims=dims, coords=coords)}
+  t = {'v': xr.DataArray(rng.normal(size=(2, 2, 32, 64)).astype(np.float32), dims=dims, coords=coords)}
+  cdims = ('dayofyear', 'hour', 'latitude', 'longitude')
+  cv = rng.normal(size=(366, 4, 32, 64)).astype(np.float32)
+  clim = xr.Dataset({'v': xr.DataArray(cv, dims=cdims, coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'latitude': LAT, 'longitude': LON})})
+  metrics = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC(clim)}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'])
+  states = {}
+  for stat_name, stats in metrics_base.generate_unique_statistics_for_all_metrics(metrics, p, t):
+    states[stat_name] = agg.aggregate_stat_vars(stats)  # aggregated as they come: SquaredError first, as DET3
+  state = aggregation.AggregationState({k: v.sum_weighted_statistics for k, v in states.items()},
+                                       {k: v.sum_weights for k, v in states.items()})
+  got = state.metric_values(metrics)
+  want = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p['v'].copy()}, {'v': t['v'].copy()})
+  for k in want:
+    np.testing.assert_allclose(got[k].values, want[k].values, rtol=1e-12)

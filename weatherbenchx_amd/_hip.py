@@ -199,11 +199,12 @@ DEVICE_POOL_LIMIT_BYTES = int(os.environ.get('WBX_DEVICE_POOL_BYTES', 32 << 30))
 
 class PinnedBlock:
   """Page-locked host memory from the context's pool, exposed through the array interface: `np.asarray(block)` is a
-  float64 view that keeps the block alive; when the last view dies the memory goes back to the pool."""
+  view (float64 unless `typestr` says otherwise) that keeps the block alive; when the last view dies the memory goes
+  back to the pool."""
 
-  def __init__(self, ctx: 'Context', ptr: int, capacity: int, nbytes: int):
+  def __init__(self, ctx: 'Context', ptr: int, capacity: int, nbytes: int, typestr: str = '<f8', itemsize: int = 8):
     self._ctx, self._ptr, self._capacity = ctx, ptr, capacity
-    self.__array_interface__ = {'shape': (nbytes // 8,), 'typestr': '<f8', 'data': (ptr, False), 'version': 3}
+    self.__array_interface__ = {'shape': (nbytes // itemsize,), 'typestr': typestr, 'data': (ptr, False), 'version': 3}
 
   @property
   def ptr(self) -> int:
@@ -214,6 +215,14 @@ class PinnedBlock:
       self._ctx._pinned_free.setdefault(self._capacity, []).append(self._ptr)  # pylint: disable=protected-access
     except Exception:  # pylint: disable=broad-except
       pass
+
+
+def is_pinned(arr) -> bool:
+  """True for numpy arrays (views included) whose memory came from Context.pinned_empty / the read-back pool."""
+  base = arr
+  while isinstance(base, np.ndarray):
+    base = base.base
+  return isinstance(base, PinnedBlock)
 
 
 class Fence:
@@ -235,6 +244,7 @@ class Fence:
   def __del__(self):
     try:
       if self._h:
+        self.wait()  # (an event must not be destroyed while a stream may still be told to wait on it)
         self._lib.wbx_fence_destroy(self._h)
         self._h = None
     except Exception:  # pylint: disable=broad-except
@@ -307,22 +317,48 @@ class Context:
             'wbx_memcpy_d2h')
     return out
 
+  def _pinned_block(self, nbytes: int, typestr: str = '<f8', itemsize: int = 8) -> PinnedBlock:
+    capacity = max(4096, 1 << (max(nbytes, 1) - 1).bit_length())
+    with self._pool_lock:
+      free = self._pinned_free.get(capacity)
+      hptr = free.pop() if free else None
+    if hptr is None:
+      p = C.c_void_p(0)
+      check(self.lib.wbx_host_alloc(self.handle, capacity, C.byref(p)), 'wbx_host_alloc')
+      hptr = p.value
+    return PinnedBlock(self, hptr, capacity, nbytes, typestr, itemsize)
+
+  def pinned_empty(self, shape, dtype=np.float32) -> np.ndarray:
+    """Uninitialised page-locked array (wbx_host_alloc, pooled): a loader that decodes its chunk straight into it gets
+    a pure-DMA upload (`upload_async`) with no bounce copy through the runtime's staging buffers."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64))
+    block = self._pinned_block(n * dt.itemsize, dt.str, dt.itemsize)
+    return np.asarray(block).reshape(shape)
+
+  def upload_async(self, arr: np.ndarray) -> DeviceBuffer:
+    """Enqueues the upload of a page-locked, C-contiguous array on the context stream and returns at once; the caller
+    orders consumers with a Fence recorded afterwards and keeps `arr` untouched until that fence has been reached."""
+    if not (is_pinned(arr) and arr.flags['C_CONTIGUOUS']):
+      raise ValueError('upload_async needs a C-contiguous array from Context.pinned_empty')
+    buf = self.alloc(arr.nbytes)
+    if arr.nbytes:
+      check(self.lib.wbx_memcpy_h2d_async(self.handle, C.c_void_p(buf.ptr), C.c_void_p(arr.ctypes.data), arr.nbytes),
+            'wbx_memcpy_h2d_async')
+    return buf
+
+  def wait_fence(self, fence: 'Fence'):
+    """Work enqueued on this context from now on starts after `fence` (recorded on any context): no host blocking."""
+    check(self.lib.wbx_ctx_wait_fence(self.handle, fence._h), 'wbx_ctx_wait_fence')  # pylint: disable=protected-access
+
   def download_async(self, ptr: int, shape) -> np.ndarray:
     """Enqueues the read-back of float64 `shape` into pooled page-locked memory and returns the (not yet valid) view;
     the caller orders its reads with a Fence recorded afterwards."""
     n = int(np.prod(shape, dtype=np.int64))
     nbytes = n * 8
-    capacity = max(4096, 1 << (max(nbytes, 1) - 1).bit_length())
-    free = self._pinned_free.get(capacity)
-    if free:
-      hptr = free.pop()
-    else:
-      p = C.c_void_p(0)
-      check(self.lib.wbx_host_alloc(self.handle, capacity, C.byref(p)), 'wbx_host_alloc')
-      hptr = p.value
-    block = PinnedBlock(self, hptr, capacity, nbytes)
+    block = self._pinned_block(nbytes)
     if nbytes:
-      check(self.lib.wbx_memcpy_d2h_async(self.handle, C.c_void_p(hptr), C.c_void_p(ptr), nbytes), 'wbx_memcpy_d2h_async')
+      check(self.lib.wbx_memcpy_d2h_async(self.handle, C.c_void_p(block.ptr), C.c_void_p(ptr), nbytes), 'wbx_memcpy_d2h_async')
     return np.asarray(block).reshape(shape)
 
   def fence(self) -> Fence:

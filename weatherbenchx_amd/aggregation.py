@@ -395,7 +395,10 @@ class Aggregator:
     grp = stat._group  # pylint: disable=protected-access
     mean_dims = stat._mean_dims  # pylint: disable=protected-access
     ens_params = stat._ens_params  # pylint: disable=protected-access
-    extra = (tuple(sorted(ens_params.items())) if ens_params else (), mean_dims)
+    # (the family a deterministic group launches grows from DET3 to DET6 when a climatology statistic joins it: sums
+    # cached before that hold three lanes only)
+    family = grp.inputs_and_func()[1] if grp.kind == 'det' else 0
+    extra = (tuple(sorted(ens_params.items())) if ens_params else (), mean_dims, family)
     key = self._cache_key(w_da, bin_dims, use_mask, skipna, extra)
     hit = grp.cache.get(key)
     if hit is None and grp.kind == 'ens' and stat._lane != lazy.ENS_LANE['CRPSSpread']:  # pylint: disable=protected-access
@@ -408,7 +411,7 @@ class Aggregator:
           break
       if hit is None:
         ens_params = {'algo': _hip.ENS_PAIRWISE if want_skip else _hip.ENS_SORT, 'fair': True, 'skipna': want_skip}
-        key = self._cache_key(w_da, bin_dims, use_mask, skipna, (tuple(sorted(ens_params.items())), mean_dims))
+        key = self._cache_key(w_da, bin_dims, use_mask, skipna, (tuple(sorted(ens_params.items())), mean_dims, family))
         hit = grp.cache.get(key)
     if hit is None:
       hit = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna, ens_params=ens_params,
@@ -500,7 +503,7 @@ class Aggregator:
     """Any DataArray (user-defined statistics, numpy or torch payload): the PASS1 family."""
     mask = stat.coords['mask'] if use_mask else None
     if mask is not None:
-      mask = xr.DataArray(mask.values.astype(bool), dims=mask.dims)
+      mask = xr.DataArray(mask.data if xr._is_torch(mask.data) else mask.values.astype(bool), dims=mask.dims)  # pylint: disable=protected-access
     plain = xr.DataArray(stat.data, dims=stat.dims)
     if not xr._is_float(plain.data):  # pylint: disable=protected-access
       plain = plain.astype(np.float64)

@@ -5,20 +5,29 @@ from typing import Collection, Hashable, Mapping
 
 import numpy as np
 
+from weatherbenchx_amd import engine
 from weatherbenchx_amd import xarray_lite as xr
 
 
 def add_nan_mask_to_data(data: Mapping[Hashable, xr.DataArray],
                          variable_subset: Collection[str] | None = None) -> Mapping[Hashable, xr.DataArray]:
   """Adds the boolean coordinate `mask` (True = valid, i.e. not NaN) to each variable, so that
-  `Aggregator(masked=True)` skips those evaluation units (data_loaders/base.py:25-56).  For device-resident
-  payloads the isnan pass runs where the data lives; the mask itself is a (small-typed) host coordinate."""
+  `Aggregator(masked=True)` skips those evaluation units (data_loaders/base.py:25-56).
+
+  For payloads that are already in HBM the mask is BUILT there (wbx_notnan_mask, one byte per point in the data's own
+  memory layout) and STAYS there: the coordinate holds the device tensor, the masked kernels read it in place
+  (WBX_FLAG_MASKED, input 3) -- no D2H of a byte per point and no re-upload at reduce time.  Host payloads get a host
+  mask as before."""
   out = dict(data)
   for name in out:
     if variable_subset is None or name in variable_subset:
       da = xr.as_dataarray(out[name])
-      valid = ~da.isnull()
+      payload = da.data
+      if xr._is_torch(payload) and payload.is_cuda:  # pylint: disable=protected-access
+        valid = engine.notnan_mask(payload)
+      else:
+        valid = np.asarray((~da.isnull()).values, dtype=bool)
       da = da._replace()  # pylint: disable=protected-access
-      da.coords['mask'] = xr.DataArray(np.asarray(valid.values, dtype=bool), dims=da.dims)
+      da.coords['mask'] = xr.DataArray(valid, dims=da.dims)
       out[name] = da
   return out

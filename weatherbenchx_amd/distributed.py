@@ -98,13 +98,26 @@ def _local_meta(acc: engine.Accumulation):
   return slots, host, leaves, frames
 
 
+_reduce_ctx: dict = {}
+
+
+def _reduction_context():
+  from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+  base = _hip.default_context()
+  hit = _reduce_ctx.get(base.device_id)
+  if hit is None or hit[0] is not base:
+    hit = _reduce_ctx[base.device_id] = (base, engine.new_context())
+  return hit[1]
+
+
 def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: bool = True, plan: ReductionPlan | None = None,
-                        force: bool = False):
+                        force: bool = False, fence=None):
   """-> ({path: DataArray}, ReductionPlan): every captured leaf of `acc`, summed over the ranks of `group`.
 
   `all_reduce=False` resolves the local accumulators only.  `force` runs the collective even in a one-rank group (the
   RCCL plumbing check on a single GPU).  Pass the returned plan back in while the local layout does not change to skip
-  the layout exchange (ranks whose layout DOES change must all call without a plan again)."""
+  the layout exchange (ranks whose layout DOES change must all call without a plan again).  `fence`: wait for this fence
+  (the state's own) instead of draining every launch stream -- a pipelined loop has the next step's kernels in flight."""
   world, backend = _group_info(group)
   collective = all_reduce and (world > 1 or (force and backend is not None))
   slots, host, leaves, frames = _local_meta(acc)
@@ -144,17 +157,19 @@ def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: boo
 
   # ---- the values: this rank's slots at their global offsets, zero elsewhere, then ONE sum over the ranks --------
   nccl = collective and backend == 'nccl'
+  if fence is not None:
+    fence.wait()     # the kernels (and accumulator adds) of exactly this state; later launches keep running
+  else:
+    acc.synchronize()
   if nccl:
     import torch  # pylint: disable=g-import-not-at-top
     import torch.distributed as dist  # pylint: disable=g-import-not-at-top
     from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
     import ctypes as C  # pylint: disable=g-import-not-at-top
-    ctx = _hip.default_context()
-    gbuf = ctx.alloc(max(plan.total, 1) * 8)
-    _hip.check(ctx.lib.wbx_memset(ctx.handle, C.c_void_p(gbuf.ptr), 0, max(plan.total, 1) * 8), 'wbx_memset')
-    for c in acc.ctxs.values():  # the adds ran on their launch streams; the copies below run on the default one
-      if c is not ctx:
-        c.synchronize()
+    ctx = _reduction_context()  # own stream: the copies do not queue behind the next step's kernels
+    nbytes = max(plan.total, 1) * 8
+    gbuf = ctx.alloc(nbytes)
+    _hip.check(ctx.lib.wbx_memset(ctx.handle, C.c_void_p(gbuf.ptr), 0, nbytes), 'wbx_memset')
     for key, (blk, off, n, _) in acc.slots.items():
       if n:
         _hip.check(ctx.lib.wbx_memcpy_d2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
@@ -166,13 +181,12 @@ def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: boo
     ctx.synchronize()
     if plan.total:
       t = device_tensor(gbuf.ptr, plan.total, ctx.device_id)
-      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # in place, on the device buffer
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # in place, on the device buffer: no host hop
       plan.collectives += 1
       torch.cuda.current_stream(t.device).synchronize()
       del t
     flat = ctx.download(gbuf.ptr, (plan.total,), np.float64)
   else:
-    acc.synchronize()
     flat = np.zeros(plan.total, dtype=np.float64)
     for key, arr in acc.download_slots().items():
       flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr
@@ -209,10 +223,8 @@ def resolve_state(state: AggregationState, acc: engine.Accumulation, group=None,
   for which, tree in (('sws', state.sum_weighted_statistics), ('sw', state.sum_weights)):
     for path, da in _leaves(tree):
       acc.capture((which,) + tuple(path), da)
-  leaves, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=plan, force=force)
-  if fence is not None:
-    fence.wait()  # (already reached: the reduction synchronised the launch streams) releases the chunk's inputs
-    state._fence = None  # pylint: disable=protected-access
+  leaves, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=plan, force=force, fence=fence)
+  state._fence = None  # pylint: disable=protected-access  (waited for inside: the chunk's inputs are released)
   trees = {'sws': {}, 'sw': {}}
   for path, da in leaves.items():
     which, rest = path[0], path[1:]

@@ -24,8 +24,17 @@ _is_torch = xr._is_torch  # pylint: disable=protected-access
 class _Dev:
   """A device-resident input: pointer + layout (+ whatever keeps the memory alive)."""
 
-  def __init__(self, ptr, layout, dtype_code, keep, nbytes):
+  def __init__(self, ptr, layout, dtype_code, keep, nbytes, fence=None):
     self.ptr, self.layout, self.dtype_code, self.keep, self.nbytes = ptr, layout, dtype_code, keep, nbytes
+    self.fence = fence  # an asynchronous upload in flight: consumers make their stream wait on it (no host block)
+
+
+def _order_uploads(ctx, devs):
+  """Uploads still in flight on a feeder's copy stream: `ctx`'s stream waits on their events (stream-ordered; the
+  host is not blocked)."""
+  for d in devs:
+    if d is not None and d.fence is not None:
+      ctx.wait_fence(d.fence)
 
 
 def _sync_torch_producers(arrays):
@@ -64,19 +73,57 @@ def _to_device(ctx: _hip.Context, da: xr.DataArray, dtype_code: int) -> _Dev:
     dev = _Dev(int(t.data_ptr()), lay, dtype_code, t, t.numel() * t.element_size())
   else:
     host = xr._to_numpy(data)  # pylint: disable=protected-access
-    host = np.ascontiguousarray(host, dtype=want)
-    buf = ctx.upload(host)
+    fence = None
+    if host.dtype == want and host.flags['C_CONTIGUOUS'] and host.nbytes and _hip.is_pinned(host):
+      # page-locked source (pipeline.pinned_empty): pure DMA on the context stream, nobody waits on the host; the
+      # array is kept (untouched) with the device copy until both are dropped
+      buf = ctx.upload_async(host)
+      fence = ctx.fence()
+      keep = (buf, host)
+    else:
+      host = np.ascontiguousarray(host, dtype=want)
+      buf = keep = ctx.upload(host)
     st = [int(s // host.itemsize) for s in host.strides] if host.ndim else []
     lay = planner.InputLayout(strides=dict(zip(da.dims, st)), itemsize=host.itemsize, base_alignment=256)
-    dev = _Dev(buf.ptr, lay, dtype_code, buf, host.nbytes)
+    dev = _Dev(buf.ptr, lay, dtype_code, keep, host.nbytes, fence)
   cache[dtype_code] = dev
   return dev
+
+
+def notnan_mask(tensor):
+  """bool tensor (True = not NaN) for a float32 / float64 tensor in HBM, in the tensor's own memory layout, written by
+  wbx_notnan_mask; layouts that are not one dense block fall back to torch's elementwise isnan."""
+  import torch  # pylint: disable=g-import-not-at-top
+  code = {torch.float32: _hip.F32, torch.float64: _hip.F64}.get(tensor.dtype)
+  order = sorted(range(tensor.dim()), key=lambda i: (-tensor.stride(i), i))
+  dense, expect = True, 1
+  for i in reversed(order):
+    if tensor.size(i) != 1 and tensor.stride(i) != expect:
+      dense = False
+    expect *= tensor.size(i)
+  if code is None or not dense or tensor.numel() == 0:
+    return ~torch.isnan(tensor)
+  ctx = _hip.default_context(tensor.device.index)
+  torch.cuda.current_stream(tensor.device).synchronize()  # whoever produced the data is done
+  valid = torch.empty_strided(tuple(tensor.shape), tuple(tensor.stride()), dtype=torch.uint8, device=tensor.device)
+  _hip.check(ctx.lib.wbx_notnan_mask(ctx.handle, C.c_void_p(tensor.data_ptr()), code, int(tensor.numel()),
+                                     C.c_void_p(valid.data_ptr())), 'wbx_notnan_mask')
+  ctx.synchronize()  # the mask may be consumed on another launch stream (ensemble statistics alternate over two)
+  return valid.view(torch.bool)
 
 
 def _mask_to_device(ctx, mask: xr.DataArray) -> _Dev:
   cache = mask.__dict__.setdefault('_wbx_dev', {})
   if 'u8' in cache:
     return cache['u8']
+  data = mask.data
+  if _is_torch(data) and data.is_cuda:  # built in HBM (data.add_nan_mask_to_data): consumed in place
+    import torch  # pylint: disable=g-import-not-at-top
+    t = data.view(torch.uint8) if data.dtype == torch.bool else (data != 0).view(torch.uint8)
+    lay = planner.InputLayout(strides=dict(zip(mask.dims, [int(s) for s in t.stride()])), itemsize=1,
+                              base_alignment=256 if t.data_ptr() % 256 == 0 else (16 if t.data_ptr() % 16 == 0 else 4))
+    dev = cache['u8'] = _Dev(int(t.data_ptr()), lay, 'u8', t, t.numel())
+    return dev
   host = np.ascontiguousarray(xr._to_numpy(mask.data).astype(bool).astype(np.uint8))  # pylint: disable=protected-access
   buf = ctx.upload(host)
   st = [int(s) for s in host.strides] if host.ndim else []
@@ -733,6 +780,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   if ens and ens.get('skipna', False):
     flags |= _hip.FLAG_SKIPNA_ENS
   layouts = [d.layout if d is not None else None for d in devs]
+  _order_uploads(ctx, devs)
   if _deferred is not None:
     _deferred.keepalive.append((datas, devs))
   # Weights that depend on the innermost (contiguous) dim ONLY and no bins -- GridAreaWeighting on latitude-fastest
@@ -830,6 +878,7 @@ def materialise(kind: str, inputs: Sequence[xr.DataArray | None], dims: Sequence
   while len(devs) < 4:
     devs.append(None)
   layouts = [d.layout if d is not None else None for d in devs]
+  _order_uploads(ctx, devs)
   flags = _hip.FLAG_FAIR if (ens and ens.get('fair', True)) else 0
   if ens and ens.get('skipna', False):
     flags |= _hip.FLAG_SKIPNA_ENS

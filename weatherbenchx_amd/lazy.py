@@ -146,7 +146,8 @@ class FusedGroup:
   def mask(self) -> xr.DataArray | None:
     if 'mask' in self.coords:
       cd, cv = self.coords['mask']
-      return xr.DataArray(np.asarray(cv), dims=cd)
+      # a mask that was built in HBM (data.add_nan_mask_to_data on device payloads) is consumed there
+      return xr.DataArray(cv if xr._is_torch(cv) else np.asarray(cv), dims=cd)  # pylint: disable=protected-access
     return None
 
   # -- execution ---------------------------------------------------------------------------------

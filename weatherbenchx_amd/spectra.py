@@ -79,6 +79,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
   if engine._common_dtype([data]) != _hip.F32:  # pylint: disable=protected-access
     raise TypeError('zonal spectra take float32 fields (rocFFT single precision); cast the input')
   dev = engine._to_device(ctx, field, _hip.F32)  # pylint: disable=protected-access
+  engine._order_uploads(ctx, [dev])  # pylint: disable=protected-access
   nlon = field.sizes[lon_dim]
   nk = nlon // 2 + 1
   geo = _geometry(field, dev.layout, lon_dim)

@@ -139,6 +139,13 @@ def _reduce(x, op: str, axes: tuple[int, ...], skipna: bool, ddof: int = 0):
 
 
 def _values_equal(a: np.ndarray, b: np.ndarray) -> bool:
+  if a is b:
+    return True
+  if _is_torch(a) or _is_torch(b):  # device-resident coordinates (a validity mask built in HBM)
+    if not (_is_torch(a) and _is_torch(b)) or a.device != b.device:
+      a, b = _to_numpy(a), _to_numpy(b)
+    else:
+      return tuple(a.shape) == tuple(b.shape) and bool(_torch().equal(a, b))
   a, b = np.asarray(a), np.asarray(b)
   if a.shape != b.shape:
     return False
@@ -208,7 +215,8 @@ class _DtAccessor:
 def _normalise_coord(name, value, owner_dims, owner_sizes):
   """-> (dims, np.ndarray)."""
   if isinstance(value, DataArray):
-    dims, vals = value.dims, _to_numpy(value.data)
+    # a device-resident payload stays where it is (data.add_nan_mask_to_data builds the `mask` coordinate in HBM)
+    dims, vals = value.dims, (value.data if _is_torch(value.data) and value.data.is_cuda else _to_numpy(value.data))
   elif isinstance(value, tuple) and len(value) == 2 and (isinstance(value[0], (str, tuple, list))):
     dims = (value[0],) if isinstance(value[0], str) else tuple(value[0])
     vals = _to_numpy(value[1])
@@ -222,7 +230,7 @@ def _normalise_coord(name, value, owner_dims, owner_sizes):
       dims = (name,)
     else:
       raise ValueError(f'cannot infer dims of coordinate {name!r} with shape {vals.shape}')
-  for d, n in zip(dims, vals.shape):
+  for d, n in zip(dims, tuple(vals.shape)):
     if d not in owner_dims:
       raise ValueError(f'coordinate {name!r} has dim {d!r} not on the array {owner_dims}')
     if owner_sizes[d] != n:
@@ -355,6 +363,8 @@ class DataArray:
     state = {k: v for k, v in self.__dict__.items() if not k.startswith('_wbx_')}
     if state.get('_data', 0) is None:  # lazy payloads are materialised by pickling (they reference device state)
       state['_data'] = self.data
+    if any(_is_torch(v[1]) for v in state.get('_coords', {}).values()):
+      state['_coords'] = {k: (cd, _to_numpy(cv) if _is_torch(cv) else cv) for k, (cd, cv) in state['_coords'].items()}
     return state
 
   def __setstate__(self, state):
@@ -510,6 +520,8 @@ class DataArray:
       for d, k in zip(cd, cidx):
         if isinstance(k, np.ndarray) and k.ndim == 0:
           k = int(k)
+        if isinstance(k, np.ndarray) and _is_torch(v):
+          k = _torch().as_tensor(k, device=v.device)
         v = v[(slice(None),) * ax2 + (k,)]
         if not isinstance(k, numbers.Integral):
           ax2 += 1
