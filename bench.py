@@ -299,11 +299,14 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   args, m = env.args, 51
   sp_shape = env.sp_shape()
   cs = {'latitude': env.lat, 'longitude': env.lon}
+  # exchangeable synthetic ensemble: members and the target are independent N(0, 1) draws around a common state, so the
+  # unbiased spread/skill ratio is ~1 (a target that IS the ensemble centre makes the unbiased MSE vanish)
   tv = {f'v{i}': env.randn((nlead,) + sp_shape, 280.0) for i in range(nvar)}
   pe, te = {}, {}
   for k, v in tv.items():
     ens = env.randn((nlead, m) + sp_shape)
     ens += v[:, None]
+    v += env.randn((nlead,) + sp_shape)
     pe[k] = xr.DataArray(ens, dims=(lead_dim, 'number') + env.sp, coords=cs)
     te[k] = xr.DataArray(v, dims=(lead_dim,) + env.sp, coords=cs)
   env.torch.cuda.synchronize()
@@ -459,6 +462,7 @@ def config5_leg(env):
     ens = env.randn((1, nlead, m) + sp_shape)
     t2 = env.randn((1, nlead) + sp_shape, 280.0)
     ens += t2[:, :, None]
+    t2 += env.randn((1, nlead) + sp_shape)
     pool.append({'z_p': env.randn((1, nlead, nlev) + sp_shape, 280.0), 'z_t': env.randn((1, nlead, nlev) + sp_shape, 280.0),
                  't2m_p': ens, 't2m_t': t2})
   ndoy = 12

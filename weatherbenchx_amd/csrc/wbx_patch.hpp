@@ -20,7 +20,14 @@ struct BinnedArgs {
   double* tmp;                       // [cell][patch][NA][nbin], zeroed
   double* tmp_poison;                // [cell][patch][NA]
   unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
+  // "atoms" of a patch = its distinct membership words (regions are boxes: a patch of 64 x ~150 rows sees a handful)
+  uint8_t* aid;                      // [nBk][nBr][nj]: index of the point's word in its patch's list
+  unsigned long long* words;         // [nBk][patch][ATOM_MAX]
+  int32_t* nwords;                   // [nBk][patch]: entries in the list, -1 = more than ATOM_MAX (slot kernel takes it)
+  int32_t atoms;                     // 0: every patch goes to the slot kernel (A/B timing: WBX_BINNED_ATOMS=0)
 };
+
+constexpr int ATOM_MAX = 32;
 
 // OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
 __device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
@@ -66,6 +73,90 @@ static __global__ void __launch_bounds__(256) binned_union_kernel(BinnedArgs g, 
   if (lane == 0 && all) atomicOr(&g.uni[bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt], all);
 }
 
+// One wave per (bk, patch): the list of the patch's distinct membership words ("atoms"), every point's index in it, and
+// the union of the words.  Row splits are aligned to Br (patch_setup), so a (bk, br, x) point belongs to one patch.
+// Rows are fetched RB at a time (the loop is latency bound: one wave, dependent list updates); a lane whose word equals
+// the one it saw in the previous row keeps that index, so the list is searched only where region / land-sea borders
+// are crossed.
+static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, int64_t D, int64_t nx) {
+  constexpr int RB = 16;
+  __shared__ unsigned long long list[ATOM_MAX];
+  const int lane = threadIdx.x;
+  int64_t b = blockIdx.x;
+  const int xt = (int)(b % g.nxt);
+  b /= g.nxt;
+  const int rs = (int)(b % g.nrs);
+  const int64_t bk = b / g.nrs;
+  const int64_t R = g.nBr * D;
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  const int64_t br0 = rbeg / D, br1 = (rend - 1) / D;  // inclusive
+  const bool live = (int64_t)xt * 64 + lane < nx;
+  const int64_t xw = g.nj > 1 ? (live ? (int64_t)xt * 64 + lane : nx - 1) : 0;
+  const bool writer = live && (g.nj > 1 || lane == 0);  // W independent of x: one byte per row, written once
+  int count = 0;
+  bool overflow = false;
+  unsigned long long prev = 0ull;
+  int prev_idx = -1;
+  for (int64_t brb = br0; brb <= br1; brb += RB) {
+    unsigned long long w[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int64_t br = brb + u <= br1 ? brb + u : br1;
+      w[u] = g.bits[(bk * g.nBr + br) * g.nj + xw];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      if (brb + u > br1) break;  // wave-uniform
+      const unsigned long long me = w[u];
+      int idx = (prev_idx >= 0 && me == prev) ? prev_idx : -1;
+      bool pending = live && idx < 0;
+      if (__builtin_amdgcn_ballot_w64(pending)) {
+        for (int k = 0; k < count; ++k)
+          if (pending && list[k] == me) {
+            idx = k;
+            pending = false;
+          }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(pending);
+        while (todo) {
+          const int leader = __builtin_ctzll(todo);
+          const unsigned long long wl = (unsigned long long)readlane64((int64_t)me, leader);
+          int slot = count;
+          if (count < ATOM_MAX) {
+            if (lane == 0) list[count] = wl;
+            ++count;
+          } else {
+            overflow = true;
+            slot = 0;
+          }
+          if (pending && me == wl) {
+            idx = slot;
+            pending = false;
+          }
+          todo = __builtin_amdgcn_ballot_w64(pending);
+        }
+        // (list[] was written by lane 0 and is read by every lane of this one wave: LDS keeps program order)
+      }
+      prev = me;
+      prev_idx = idx;
+      if (writer) g.aid[(bk * g.nBr + brb + u) * g.nj + xw] = (uint8_t)idx;
+    }
+  }
+  const int64_t pidx = bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt;
+  unsigned long long all = 0ull;
+  for (int k = 0; k < count; ++k) all |= list[k];
+  if (overflow) {  // the list is incomplete: take the union the slow way
+    unsigned long long mine = 0ull;
+    for (int64_t br = br0; br <= br1; ++br) mine |= g.bits[(bk * g.nBr + br) * g.nj + xw];
+    all = wave_or64(live ? mine : 0ull);
+  }
+  if (lane < ATOM_MAX) g.words[pidx * ATOM_MAX + lane] = lane < count ? list[lane] : 0ull;
+  if (lane == 0) {
+    g.uni[pidx] = all;
+    g.nwords[pidx] = (overflow || !g.atoms) ? -1 : count;
+  }
+}
+
 // out[cell][lane][bin] = sum over patches of tmp[cell][patch][lane][bin] + poison[cell][patch][lane].
 // One block per (cell, lane): thread (pg, bin) sums every (256 / nbin)-th patch, LDS folds the pg.
 static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, int nacc, int nbin,
@@ -89,10 +180,10 @@ static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, 
 }
 
 
-// Patch geometry, scratch (tmp | uni | poison) and the union pre-kernel.  rows = nBr * D reduced rows of nx points per
+// Patch geometry, scratch (tmp | uni | poison | words | nwords | aid) and the atom pre-kernel (lists + union).  rows = nBr * D reduced rows of nx points per
 // cell; nacc = accumulated lanes.
 inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
-                       int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin) {
+                       int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false) {
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
   g.nBk = nBk;
@@ -107,11 +198,15 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   if (want > (rows + 63) / 64) want = (rows + 63) / 64;
   if (want < 1) want = 1;
   g.rows_per_split = (rows + want - 1) / want;
+  g.rows_per_split = (g.rows_per_split + D - 1) / D * D;  // whole Br rows per split: a (bk, br, x) point has ONE patch
   g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
   const size_t n_uni = (size_t)nBk * npatch;
-  const size_t need = (n_tmp + n_poison + n_uni) * sizeof(double);
+  const size_t n_words = (size_t)nBk * npatch * ATOM_MAX;
+  const size_t n_nwords = ((size_t)nBk * npatch + 1) / 2;                  // int32 pairs, in 8-byte units
+  const size_t n_aid = ((size_t)nBk * nBr * nj + 7) / 8;                   // bytes, in 8-byte units
+  const size_t need = (n_tmp + n_poison + n_uni + n_words + n_nwords + n_aid) * sizeof(double);
   if (ctx->s2_scratch_size < need) {
     if (ctx->s2_scratch) {
       WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -125,11 +220,15 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
   g.uni = reinterpret_cast<unsigned long long*>(g.tmp + n_tmp);
   g.tmp_poison = g.tmp + n_tmp + n_uni;
-  WBX_HIP(hipMemsetAsync(g.tmp, 0, (n_tmp + n_uni) * sizeof(double), ctx->stream));
+  g.words = reinterpret_cast<unsigned long long*>(g.tmp_poison + n_poison);
+  g.nwords = reinterpret_cast<int32_t*>(g.words + n_words);
+  g.aid = reinterpret_cast<uint8_t*>(g.words + n_words + n_nwords);
+  g.atoms = atoms ? 1 : 0;
+  WBX_HIP(hipMemsetAsync(g.tmp, 0, n_tmp * sizeof(double), ctx->stream));
   g.ncell = cells;
   g.nblocks = cells * npatch;
   WBX_REQUIRE((g.nblocks + 7) / 8 * 8 < (int64_t)1 << 31, "patch grid too large");
-  hipLaunchKernelGGL(binned_union_kernel, dim3((unsigned)(nBk * npatch)), dim3(256), 0, ctx->stream, g, D, nx);
+  hipLaunchKernelGGL(binned_atoms_kernel, dim3((unsigned)(nBk * npatch)), dim3(64), 0, ctx->stream, g, D, nx);
   WBX_HIP(hipGetLastError());
   return 0;
 }
