@@ -257,9 +257,17 @@ int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, 
 #define WBX_BINNED_W_ON_X 1
 #define WBX_BINNED_WT_X_ONLY 2
 #define WBX_BINNED_WT_ROW_ONLY 4
+/* `atoms`: NULL, or the tables wbx_binned_atoms wrote for exactly this geometry (plan extents, nA, nBk, nBr, w_on_x) and
+ * these `bits`.  The kernel works on a patch's "atoms" (= its distinct membership words: regions are boxes, so a patch
+ * of 64 x ~150 rows sees a handful) and needs every point's atom index; the tables depend on the bins and the geometry
+ * only, so a chunk loop computes them once.  With NULL they are recomputed inside every call. */
 int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
                    const void* c, const uint8_t* mask, const double* wt, const uint64_t* bits, int64_t nA,
-                   int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, double* out);
+                   int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, const void* atoms, double* out);
+int wbx_binned_atoms_size(const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
+                          int64_t* bytes_out);
+int wbx_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
+                     const uint64_t* bits, void* atoms_out /* device, wbx_binned_atoms_size bytes */);
 
 /* ---- materialisation of per-point statistics --------------------------------
  * Statistic.compute()'s full-resolution result (metrics/base.py:135-158) for callers

@@ -1,0 +1,15 @@
+#!/bin/bash
+# tests, binned kernel timing + per-kernel trace, the read-ceiling microbenchmark
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$PWD
+( timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_3.log
+tail -3 gpurun_out/pytest_3.log
+timeout 300 python tools/kbench_binned_ab.py "atoms,prepared" 2>gpurun_out/binned_3.err | tee gpurun_out/binned_3.json
+for lay in lon_fastest lat_fastest; do
+  ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace_binned_$lay -o r1 -- python $R/tools/kbench_binned.py $lay 6 > /dev/null 2>&1 )
+done
+python profiles/summarize_rocpd.py gpurun_out/trace_binned_*/r1_results.db > gpurun_out/trace_binned_summary.txt 2>&1
+rm -rf gpurun_out/trace_binned_lon_fastest gpurun_out/trace_binned_lat_fastest
+head -40 gpurun_out/trace_binned_summary.txt
+timeout 120 tools/ubench/read_stream | tee gpurun_out/read_stream.json

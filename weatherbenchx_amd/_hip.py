@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_cat_partial', 'wbx_det_map', 'wbx_ens_map',
     'wbx_zonal_spectrum', 'wbx_zonal_spectrum_slabs', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy', 'wbx_ctx_wait_fence', 'wbx_memcpy_h2d_async',
-    'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask',
+    'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
 )
 
 
@@ -117,7 +117,9 @@ def load_library():
         'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp, vp],
         'wbx_contract': [vp, C.POINTER(S2PlanStruct), vp, vp, vp],
         'wbx_contract_bits': [vp, C.POINTER(S2PlanStruct), vp, vp, vp, vp],
-        'wbx_det_binned': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int32, C.c_int32, vp],
+        'wbx_det_binned': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int32, C.c_int32, vp, vp],
+        'wbx_binned_atoms_size': [C.POINTER(S1PlanStruct), i64, i64, i64, C.c_int32, C.POINTER(i64)],
+        'wbx_binned_atoms': [vp, C.POINTER(S1PlanStruct), i64, i64, i64, C.c_int32, vp, vp],
         'wbx_cat_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, i32, i64, vp, vp, vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],

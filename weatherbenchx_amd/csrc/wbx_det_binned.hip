@@ -18,6 +18,7 @@
 // Semantics as aggregation.py:297-366: NaN * 0 = NaN poisons every bin of a lane (`poison`, added to all bins by the
 // second kernel; inside a visited bin the 0.0 / 1.0 membership FMA propagates it), mask / skipna count lanes follow
 // the conventions of wbx_det_partial.
+#include <cstdlib>
 #include <type_traits>
 
 #include "wbx_patch.hpp"
@@ -65,7 +66,8 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
   for (int i = 0; i < WBX_MAX_INPUTS; ++i) xoff[i] = x * a.xstride[i];
 
   const int64_t patch = (int64_t)rs * g.nxt + xt;
-  // union of the patch's bins (binned_union_kernel: it does not depend on A, so it is computed once per launch)
+  if (g.nwords[bk * ((int64_t)g.nrs * g.nxt) + patch] >= 0) return;  // det_atoms_kernel owns this patch
+  // union of the patch's bins (binned_atoms_kernel: it does not depend on A, so it is computed once per launch)
   unsigned long long todo = g.uni[bk * ((int64_t)g.nrs * g.nxt) + patch];
   todo = (unsigned long long)readlane64((int64_t)todo, 0);
   double* const out = g.tmp + (cell * ((int64_t)g.nrs * g.nxt) + patch) * (NA * (int64_t)g.nbin);
@@ -222,14 +224,250 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
   } while (todo);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same reduction by ATOMS instead of bins.  A point belongs to several bins (its region, the hemisphere, 'global',
+// each again as land or sea: ~8 of the 34), so the slot kernel above spends ~8 slots x NA fp64 FMAs per point, most of
+// them with a 0.0 factor -- it is VALU-bound at 30 % of the HBM peak.  But a point belongs to exactly ONE atom (= distinct
+// membership word; binned_atoms_kernel lists a patch's atoms and stores every point's index as one byte), and a lane
+// that walks down its column stays in the same one or two atoms (land / sea of one region pattern) for long runs.  So
+// every lane keeps TWO private accumulator sets keyed by atom id (a 2-entry cache: 2 x NA FMAs per point, whatever the
+// number of bins); when some lane meets a third atom the wave flushes the evicted sets -- lanes grouped by evicted id,
+// one wave sum per (group, statistic) -- into a wave-private [atom][statistic] table in LDS.  At the end of the patch the
+// table is expanded to the patch's bins, out[statistic][bin] = sum over atoms that have the bin's bit, and written in the
+// slot kernel's tmp layout, so the finish kernel and the NaN rule are shared: a non-finite term makes its atom's sum
+// non-finite, `poison` = sum over atoms of (sum * 0) then turns every bin of that statistic into NaN, exactly like the
+// reference's xr.dot (aggregation.py:272-277).  Per point the membership costs 1 byte from L2 instead of 8.
+// Patches with more than ATOM_MAX atoms (arbitrary user masks) stay with the slot kernel.
+template <typename T, int FUNC, int MM, int PD, int WM>
+__global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
+  constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
+  constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
+  constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
+  constexpr int NA = NL + NC;
+  constexpr bool has_mask = MM == 1 || MM == 3;
+  constexpr int NONE = 255;
+  __shared__ double tab[ATOM_MAX * NA];
+  __shared__ unsigned long long wlist[ATOM_MAX];
+  const int lane = threadIdx.x;
+  int64_t cell;
+  int xt, rs;
+  if (!patch_decode<1>(g, cell, xt, rs)) return;
+  const int64_t bk = cell % g.nBk;
+  const int64_t A = cell / g.nBk;
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  const int64_t patch = (int64_t)rs * g.nxt + xt;
+  const int nw = g.nwords[bk * npatch + patch];
+  if (nw < 0) return;  // too many atoms: det_binned_kernel takes this patch
+  for (int i = lane; i < ATOM_MAX * NA; i += 64) tab[i] = 0.0;
+  if (lane < ATOM_MAX) wlist[lane] = g.words[(bk * npatch + patch) * ATOM_MAX + lane];
+  __syncthreads();  // (one wave per block: the barriers only pin the order of the LDS accesses for the compiler)
+  const int64_t R = g.nBr * a.D;
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+
+  // lanes beyond a ragged nx re-read the last element and never accumulate
+  const bool live = (int64_t)xt * 64 + lane < a.nx;
+  const int64_t x = live ? (int64_t)xt * 64 + lane : a.nx - 1;
+  // 32-bit lane offsets (the launcher checked they fit): row base in SGPRs + one VGPR, no 64-bit VALU adds per load
+  uint32_t xo[WBX_MAX_INPUTS];
+#pragma unroll
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i) xo[i] = (uint32_t)(x * a.xstride[i]);
+  const uint32_t xw = g.nj > 1 ? (uint32_t)x : 0u;
+  double w_lane = 1.0;
+  if constexpr (WM == 1) w_lane = g.wt[bk * g.nj + xw];
+
+  int c0 = NONE, c1 = NONE;  // the atoms this lane is accumulating
+  bool last1 = false;        // entry 1 was the one used last
+  double acc0[NA], acc1[NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) acc0[l] = acc1[l] = 0.0;
+
+  // flush entry 0 / 1 (per lane: `second`) of the lanes that ask for it into the LDS table, lanes grouped by atom id
+  auto flush = [&](bool ask, bool second) {
+    const int id = ask ? (second ? c1 : c0) : NONE;
+    const bool go = id != NONE;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(go);
+    while (todo) {
+      const int gid = __builtin_amdgcn_readlane(id, __builtin_ctzll(todo));
+      const bool sel = go && id == gid;
+      double mine = 0.0;
+#pragma unroll
+      for (int l = 0; l < NA; ++l) {
+        const double v = sel ? (second ? acc1[l] : acc0[l]) : 0.0;
+        const double sum = wave_sum(v);
+        if (lane == l) mine = sum;
+      }
+      if (lane < NA) tab[gid * NA + lane] += mine;
+      todo &= ~__builtin_amdgcn_ballot_w64(sel);
+    }
+#pragma unroll
+    for (int l = 0; l < NA; ++l) {
+      if (go && !second) acc0[l] = 0.0;
+      if (go && second) acc1[l] = 0.0;
+    }
+  };
+
+  for (int64_t rb = rbeg; rb < rend; rb += 64) {
+    // lane j resolves row rb + j through the plan's tables; the sweep below broadcasts them one by one
+    const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
+    const int64_t br = rmine / a.D;
+    const int64_t d = rmine - br * a.D;
+    const int64_t key = (A * g.nBk + bk) * g.nBr + br;
+    int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
+    key_bases<NIN>(a, key, kb);
+    row_bases<NIN>(a, kb, key, d, ro);
+    const int64_t wrow_v = (bk * g.nBr + br) * g.nj;
+    double wrow_w = 0.0;
+    if constexpr (WM == 2) wrow_w = g.wt[bk * g.nBr + br];
+    const int nrow = (int)(rend - rb < 64 ? rend - rb : 64);
+
+    T rp[PD], rt[PD], rc[PD];
+    uint8_t rv[PD];
+    auto fetch_ptc = [&](int j, int u) {
+      rp[u] = ld_stream(reinterpret_cast<const T*>(a.in[0]) + readlane64(ro[0], j) + xo[0]);
+      if constexpr (NIN > 1) rt[u] = ld_stream(reinterpret_cast<const T*>(a.in[1]) + readlane64(ro[1], j) + xo[1]);
+      if constexpr (NIN > 2) rc[u] = ld_stream(reinterpret_cast<const T*>(a.in[2]) + readlane64(ro[2], j) + xo[2]);
+      rv[u] = 1;
+      if constexpr (has_mask) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + readlane64(ro[3], j))[xo[3]];
+    };
+    double w_cur, w_nxt = 0.0;
+    int id_cur, id_nxt = 0;
+    auto fetch_aw = [&](int j, double& w, int& id) {
+      const int64_t wi = readlane64(wrow_v, j);
+      id = (g.aid + wi)[xw];
+      if constexpr (WM == 0) w = (g.wt + wi)[xw];
+      if constexpr (WM == 1) w = w_lane;
+      if constexpr (WM == 2) w = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+    };
+    auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
+      const bool ok = live && tv != 0;
+      bool hit0 = id == c0, hit1 = id == c1;
+      const bool miss = ok && !hit0 && !hit1;
+      if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform, rare: region / coast lines
+        // victim: an empty entry first, else the one that was not used last
+        const bool second = c0 == NONE ? false : (c1 == NONE ? true : !last1);
+        flush(miss, second);
+        if (miss && second) c1 = id;
+        if (miss && !second) c0 = id;
+        hit0 = id == c0;
+        hit1 = id == c1;
+      }
+      if (ok) {
+        last1 = hit1;
+        const double p = (double)tp, t = (double)tt, c = (double)tc;
+        double val[NA];
+        if constexpr (FUNC == WBX_PASS1) {
+          val[0] = p;
+        } else {
+          const double e = p - t;
+          val[0] = e;
+          val[1] = fabs(e);
+          val[2] = e * e;
+          if constexpr (FUNC == WBX_DET6) {
+            const double pa = p - c, ta = t - c;
+            val[3] = pa * pa;
+            val[4] = ta * ta;
+            val[5] = pa * ta;
+          }
+        }
+        if constexpr (MM == 1) val[NL] = 1.0;
+        if constexpr (MM >= 2) {
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            const bool fin = !(val[l] != val[l]);
+            val[NL + l] = fin ? 1.0 : 0.0;
+            val[l] = fin ? val[l] : 0.0;
+          }
+        }
+        // the weight goes to the entry the point belongs to, 0 to the other (a NaN term reaches both: harmless, the
+        // poison rule makes every bin of that statistic NaN anyway)
+        const double f0 = hit0 ? w : 0.0, f1 = hit1 ? w : 0.0;
+#pragma unroll
+        for (int l = 0; l < NA; ++l) {
+          acc0[l] = fma(val[l], f0, acc0[l]);
+          acc1[l] = fma(val[l], f1, acc1[l]);
+        }
+      }
+    };
+    // every load is unconditional (clamped row indices), see det_binned_kernel
+    const int last = nrow - 1;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) fetch_ptc(u < last ? u : last, u);
+    fetch_aw(0, w_cur, id_cur);
+    for (int j = 0; j < nrow; j += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int jj = j + u;
+        const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
+        const uint8_t tv = rv[u];
+        fetch_ptc(jj + PD < last ? jj + PD : last, u);
+        fetch_aw(jj + 1 < last ? jj + 1 : last, w_nxt, id_nxt);
+        if (jj < nrow) accumulate(tp, tt, tc, tv, w_cur, id_cur);  // wave-uniform
+        w_cur = w_nxt;
+        id_cur = id_nxt;
+      }
+    }
+  }
+  flush(true, false);
+  flush(true, true);
+  __syncthreads();
+
+  // ---- atoms -> bins: thread (bin of the union, statistic) sums the atoms that carry the bin's bit
+  unsigned long long uni = 0ull;
+  for (int k = 0; k < nw; ++k) uni |= wlist[k];
+  const int npair = __builtin_popcountll(uni) * NA;
+  double* const out = g.tmp + (cell * npatch + patch) * (NA * (int64_t)g.nbin);
+  for (int pr = lane; pr < npair; pr += 64) {
+    const int bi = pr / NA, l = pr - bi * NA;
+    unsigned long long u = uni;
+    for (int q = 0; q < bi; ++q) u &= u - 1ull;
+    const int bit = __builtin_ctzll(u);
+    double s = 0.0;
+    for (int k = 0; k < nw; ++k)
+      if ((wlist[k] >> bit) & 1ull) s += tab[k * NA + l];
+    out[(int64_t)l * g.nbin + bit] = s;
+  }
+  if (lane < NA) {
+    double ps = 0.0;
+    for (int k = 0; k < nw; ++k) ps = fma(tab[k * NA + lane], 0.0, ps);
+    g.tmp_poison[(cell * npatch + patch) * NA + lane] = ps;
+  }
+}
+
+// WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_PD = rows of p, t, c in flight (2 / 4)
+static int atoms_setting(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
 template <typename T, int FUNC, int MM, int K, int PD>
 static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
-                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode) {
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
+  static const int use_atoms = atoms_setting("WBX_BINNED_ATOMS", 1);
+  static const int atoms_pd = atoms_setting("WBX_ATOMS_PD", 4);
+  // the atom kernel addresses a row as (uniform base) + (32-bit lane offset)
+  bool atoms = use_atoms != 0;
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i)
+    if ((plan->nx - 1) * plan->xstride[i] >= ((int64_t)1 << 31) / (int64_t)sizeof(double) || plan->xstride[i] < 0) atoms = false;
   BinnedArgs g;
-  if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin)) return rc;
+  if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin, atoms, atoms ? prepared : nullptr)) return rc;
   const int64_t grid = patch_grid<BINNED_WPB>(g);
+  if (atoms) {
+    const int64_t agrid = patch_grid<1>(g);
+#define WBX_ATOMS_LAUNCH(PDV, WMV) \
+    hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g)
+    if (atoms_pd <= 2) {
+      if (wmode == 1) WBX_ATOMS_LAUNCH(2, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(2, 2); else WBX_ATOMS_LAUNCH(2, 0);
+    } else {
+      if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
+    }
+#undef WBX_ATOMS_LAUNCH
+    WBX_HIP(hipGetLastError());
+  }
+  // the slot kernel takes the patches the atom kernel declined (more than ATOM_MAX distinct membership words); its
+  // waves return at once everywhere else
   if (wmode == 1)
     hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 1>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   else if (wmode == 2)
@@ -242,45 +480,72 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
 
 template <typename T, int FUNC, int MM>
 static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
-                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode) {
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   // Slots: 2 * NA * K accumulator VGPRs + ~70 working registers must stay <= 168 for 3 waves / SIMD.  Measured on the
   // public-benchmark chunk (DET6, 34 bins): K = 6 / 8 / 12 -> 0.92 / 0.85 / 0.95 ms; 2 rows of p, t, c in flight are
   // enough (4: 1.01 ms, the extra registers cost a wave).
   constexpr int K = NA <= 1 ? 32 : (NA <= 2 ? 24 : (NA <= 3 ? 16 : (NA <= 4 ? 12 : (NA <= 6 ? 8 : (NA <= 7 ? 6 : 3)))));
-  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
 }
 
 template <typename T, int FUNC>
 static int binned_mm(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits, int64_t nA,
-                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode) {
+                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
   if ((plan->flags & WBX_FLAG_SKIPNA) && (plan->flags & WBX_FLAG_MASKED))
-    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
-  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
-  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
-  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
 }
 
 template <typename T>
 static int binned_func(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, S1Args& a, const double* wt,
-                       const uint64_t* bits, int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode) {
+                       const uint64_t* bits, int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
   switch (func) {
     case WBX_DET3:
-      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
     case WBX_DET6:
-      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
     case WBX_PASS1:
-      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
   }
   return fail(WBX_ERR_INVALID, "unknown deterministic family %d", func);
 }
 
 }  // namespace wbx
 
+extern "C" int wbx_binned_atoms_size(const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
+                                     int64_t* bytes_out) {
+  using namespace wbx;
+  if (int rc = check_plan(plan)) return rc;
+  WBX_REQUIRE(bytes_out != nullptr, "bytes_out is NULL");
+  WBX_REQUIRE(nA >= 1 && nBk >= 1 && nBr >= 1 && plan->nx >= 1 && plan->ndepth >= 1, "empty geometry");
+  BinnedArgs g;
+  patch_geometry(g, nA * nBk, nBk, nBr, (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1, plan->ndepth, plan->nx);
+  *bytes_out = (int64_t)atoms_carve(g, nullptr);
+  return 0;
+}
+
+extern "C" int wbx_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr,
+                                int32_t w_on_x, const uint64_t* bits, void* atoms_out) {
+  using namespace wbx;
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (int rc = check_plan(plan)) return rc;
+  WBX_REQUIRE(bits != nullptr && atoms_out != nullptr, "NULL pointer");
+  WBX_REQUIRE(nA >= 1 && nBk >= 1 && nBr >= 1 && plan->nx >= 1 && plan->ndepth >= 1, "empty geometry");
+  WBX_HIP(hipSetDevice(ctx->device));
+  static const int use_atoms = atoms_setting("WBX_BINNED_ATOMS", 1);
+  BinnedArgs g;
+  patch_geometry(g, nA * nBk, nBk, nBr, (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1, plan->ndepth, plan->nx);
+  atoms_carve(g, atoms_out);
+  return atoms_launch(ctx, g, bits, plan->ndepth, plan->nx, use_atoms != 0);
+}
+
 extern "C" int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
                               const void* c, const uint8_t* mask, const double* wt, const uint64_t* bits, int64_t nA,
-                              int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, double* out) {
+                              int64_t nBk, int64_t nBr, int32_t w_on_x, int32_t nbin, const void* prepared, double* out) {
   using namespace wbx;
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (int rc = check_plan(plan)) return rc;
@@ -309,7 +574,7 @@ extern "C" int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, i
   WBX_REQUIRE((w_on_x & ~7) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
   const int64_t nj = (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1;
   const int wmode = (w_on_x & WBX_BINNED_WT_X_ONLY) ? 1 : ((w_on_x & WBX_BINNED_WT_ROW_ONLY) ? 2 : 0);
-  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
-  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode);
+  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
   return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
 }

@@ -135,7 +135,7 @@ static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, i
           }
           todo = __builtin_amdgcn_ballot_w64(pending);
         }
-        // (list[] was written by lane 0 and is read by every lane of this one wave: LDS keeps program order)
+        __syncthreads();  // list[] was written by lane 0 and is read by every lane (one wave per block: free)
       }
       prev = me;
       prev_idx = idx;
@@ -143,6 +143,7 @@ static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, i
     }
   }
   const int64_t pidx = bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt;
+  __syncthreads();
   unsigned long long all = 0ull;
   for (int k = 0; k < count; ++k) all |= list[k];
   if (overflow) {  // the list is incomplete: take the union the slow way
@@ -180,16 +181,11 @@ static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, 
 }
 
 
-// Patch geometry, scratch (tmp | uni | poison | words | nwords | aid) and the atom pre-kernel (lists + union).  rows = nBr * D reduced rows of nx points per
-// cell; nacc = accumulated lanes.
-inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
-                       int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false) {
-  g.wt = wt;
-  g.bits = reinterpret_cast<const unsigned long long*>(bits);
+// Patch geometry: rows = nBr * D reduced rows of nx points per cell, cut into nrs row splits x nxt tiles of 64 x.
+inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nBr, int64_t nj, int64_t D, int64_t nx) {
   g.nBk = nBk;
   g.nBr = nBr;
   g.nj = nj;
-  g.nbin = nbin;
   const int64_t rows = nBr * D;
   g.nxt = (int)((nx + 63) / 64);
   // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
@@ -200,13 +196,48 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   g.rows_per_split = (rows + want - 1) / want;
   g.rows_per_split = (g.rows_per_split + D - 1) / D * D;  // whole Br rows per split: a (bk, br, x) point has ONE patch
   g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
+  g.ncell = cells;
+  g.nblocks = cells * (int64_t)g.nrs * g.nxt;
+}
+
+// The atom tables of a geometry: uni | words | nwords | aid, each padded to 8 bytes.  They depend on the membership
+// bits and the geometry only -- not on the data -- so a caller that runs many chunks with the same bins computes them
+// once (wbx_binned_atoms) and hands them to every wbx_det_binned call.
+inline size_t atoms_carve(BinnedArgs& g, void* base) {
+  const size_t npatch = (size_t)g.nrs * g.nxt;
+  const size_t n_uni = (size_t)g.nBk * npatch;
+  const size_t n_words = (size_t)g.nBk * npatch * ATOM_MAX;
+  const size_t n_nwords = ((size_t)g.nBk * npatch + 1) / 2;          // int32 pairs, in 8-byte units
+  const size_t n_aid = ((size_t)g.nBk * g.nBr * g.nj + 7) / 8;       // bytes, in 8-byte units
+  if (base) {
+    g.uni = reinterpret_cast<unsigned long long*>(base);
+    g.words = g.uni + n_uni;
+    g.nwords = reinterpret_cast<int32_t*>(g.words + n_words);
+    g.aid = reinterpret_cast<uint8_t*>(g.words + n_words + n_nwords);
+  }
+  return (n_uni + n_words + n_nwords + n_aid) * 8;
+}
+
+inline int atoms_launch(wbx_ctx* ctx, BinnedArgs& g, const uint64_t* bits, int64_t D, int64_t nx, bool atoms) {
+  g.bits = reinterpret_cast<const unsigned long long*>(bits);
+  g.atoms = atoms ? 1 : 0;
+  hipLaunchKernelGGL(binned_atoms_kernel, dim3((unsigned)(g.nBk * g.nrs * g.nxt)), dim3(64), 0, ctx->stream, g, D, nx);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+// Scratch (tmp | poison [| atom tables]) and, unless the caller brought prepared atom tables, the atom pre-kernel.
+// nacc = accumulated lanes.
+inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
+                       int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false,
+                       const void* prepared = nullptr) {
+  g.wt = wt;
+  g.bits = reinterpret_cast<const unsigned long long*>(bits);
+  g.nbin = nbin;
+  patch_geometry(g, cells, nBk, nBr, nj, D, nx);
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
-  const size_t n_uni = (size_t)nBk * npatch;
-  const size_t n_words = (size_t)nBk * npatch * ATOM_MAX;
-  const size_t n_nwords = ((size_t)nBk * npatch + 1) / 2;                  // int32 pairs, in 8-byte units
-  const size_t n_aid = ((size_t)nBk * nBr * nj + 7) / 8;                   // bytes, in 8-byte units
-  const size_t need = (n_tmp + n_poison + n_uni + n_words + n_nwords + n_aid) * sizeof(double);
+  const size_t need = (n_tmp + n_poison) * sizeof(double) + (prepared ? 0 : atoms_carve(g, nullptr));
   if (ctx->s2_scratch_size < need) {
     if (ctx->s2_scratch) {
       WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -218,19 +249,16 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
     ctx->s2_scratch_size = need;
   }
   g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
-  g.uni = reinterpret_cast<unsigned long long*>(g.tmp + n_tmp);
-  g.tmp_poison = g.tmp + n_tmp + n_uni;
-  g.words = reinterpret_cast<unsigned long long*>(g.tmp_poison + n_poison);
-  g.nwords = reinterpret_cast<int32_t*>(g.words + n_words);
-  g.aid = reinterpret_cast<uint8_t*>(g.words + n_words + n_nwords);
-  g.atoms = atoms ? 1 : 0;
+  g.tmp_poison = g.tmp + n_tmp;
   WBX_HIP(hipMemsetAsync(g.tmp, 0, n_tmp * sizeof(double), ctx->stream));
-  g.ncell = cells;
-  g.nblocks = cells * npatch;
   WBX_REQUIRE((g.nblocks + 7) / 8 * 8 < (int64_t)1 << 31, "patch grid too large");
-  hipLaunchKernelGGL(binned_atoms_kernel, dim3((unsigned)(nBk * npatch)), dim3(64), 0, ctx->stream, g, D, nx);
-  WBX_HIP(hipGetLastError());
-  return 0;
+  if (prepared) {
+    atoms_carve(g, const_cast<void*>(prepared));
+    g.atoms = 1;
+    return 0;
+  }
+  atoms_carve(g, g.tmp_poison + n_poison);
+  return atoms_launch(ctx, g, bits, D, nx, atoms);
 }
 
 inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out) {

@@ -192,6 +192,7 @@ class _WOnDevice:
   def __init__(self, kind, bufs, shape, bin_shape):
     self.kind, self.bufs, self.shape, self.bin_shape = kind, bufs, shape, bin_shape
     self.factored = None  # (WBX_BINNED_WT_* flag, device buffer) when the weights of a 'bits' operand separate
+    self.atoms = {}       # launch geometry -> device buffer of wbx_binned_atoms tables
 
 
 BITS_MIN_BINS = 5  # below this the dense contraction is just as cheap
@@ -682,6 +683,7 @@ def _run_s2(ctx, s2: planner.S2Plan, partial_ptr: int, w_buf):
 # plus ~0.52 ms per GB of partials (written by stage 1, read back by the stage-2 patch kernel) -> break-even where
 # the partials are ~45 % of the inputs (about 10 inits per chunk for the 6-lane family).
 BINNED_MODE = 'auto'
+PREPARED_ATOMS = True  # False: wbx_det_binned recomputes the atom tables in every call (A/B timing and tests)
 FOLD_X_WEIGHTS = True  # False: keep x for stage 2 (plane mode / x-kept kernels), for A/B timing and tests
 BINNED_PARTIAL_RATIO = 0.45
 
@@ -711,6 +713,20 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   if w_buf.factored is not None and SEPARABLE_BINNED_WEIGHTS:
     w_flags |= w_buf.factored[0]
     wt_buf = w_buf.factored[1]
+  # the atom tables (a patch's distinct membership words + every point's index) depend on the bins and the launch
+  # geometry only: computed once per (W, geometry) and kept with the device copy of W
+  akey = (id(ctx), nA, nBk, nBr, plan.ndepth, plan.nx, w_flags & _hip.BINNED_W_ON_X)
+  atoms = w_buf.atoms.get(akey) if PREPARED_ATOMS else None
+  if atoms is None and PREPARED_ATOMS:
+    nbytes = C.c_int64(0)
+    _hip.check(ctx.lib.wbx_binned_atoms_size(C.byref(dplan.struct), nA, nBk, nBr, w_flags & _hip.BINNED_W_ON_X,
+                                             C.byref(nbytes)), 'wbx_binned_atoms_size')
+    atoms = ctx.alloc(int(nbytes.value))
+    _hip.check(ctx.lib.wbx_binned_atoms(ctx.handle, C.byref(dplan.struct), nA, nBk, nBr, w_flags & _hip.BINNED_W_ON_X,
+                                        C.c_void_p(w_buf.bufs[1].ptr), C.c_void_p(atoms.ptr)), 'wbx_binned_atoms')
+    if len(w_buf.atoms) > 8:
+      w_buf.atoms.clear()
+    w_buf.atoms[akey] = atoms
   reps = 1
   if S1_EVENT_LOG is not None:
     reps = max(1, int(S1_EVENT_REPEAT))
@@ -719,6 +735,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
     _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
                                       ptr(devs[2]), ptr(devs[3]), C.c_void_p(wt_buf.ptr),
                                       C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags, nbin,
+                                      C.c_void_p(atoms.ptr) if atoms is not None else None,
                                       C.c_void_p(out.ptr)), 'wbx_det_binned')
   if S1_EVENT_LOG is not None:
     S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin,
