@@ -56,6 +56,31 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Sum over the 64 lanes with DPP row operations (no LDS crossbar round trips, unlike the ds_bpermute shuffles above):
+// the total is valid in LANE 63 ONLY.  All lanes must be active.  Same step pattern as wave_or32 (wbx_patch.hpp).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_moved(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);  // rows masked off receive +0.0
+}
+
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_moved<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_moved<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_moved<0x124, 0xf>(v);  // row_ror:4
+  v += dpp_moved<0x128, 0xf>(v);  // row_ror:8  -> every lane holds its row's sum
+  v += dpp_moved<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+  v += dpp_moved<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+  return v;
+}
+
+// The wave total as a wave-uniform value (SGPRs).
+__device__ __forceinline__ double wave_sum_uniform(double v) {
+  const double t = wave_sum_lane63(v);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 63), __builtin_amdgcn_readlane(__double2loint(t), 63));
+}
+
 }  // namespace wbx
 
 #define WBX_HIP(expr)                                                                   \

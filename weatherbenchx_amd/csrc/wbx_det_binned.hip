@@ -231,8 +231,9 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
 // membership word; binned_atoms_kernel lists a patch's atoms and stores every point's index as one byte), and a lane
 // that walks down its column stays in the same one or two atoms (land / sea of one region pattern) for long runs.  So
 // every lane keeps TWO private accumulator sets keyed by atom id (a 2-entry cache: 2 x NA FMAs per point, whatever the
-// number of bins); when some lane meets a third atom the wave flushes the evicted sets -- lanes grouped by evicted id,
-// one wave sum per (group, statistic) -- into a wave-private [atom][statistic] table in LDS.  At the end of the patch the
+// number of bins); when some lane with both entries taken meets a third atom -- a region edge, the same row for most
+// lanes -- the wave flushes ALL sets, lanes grouped by atom id, one DPP wave sum per (group, statistic), into a
+// wave-private [atom][statistic] table in LDS and starts over with empty caches.  At the end of the patch the
 // table is expanded to the patch's bins, out[statistic][bin] = sum over atoms that have the bin's bit, and written in the
 // slot kernel's tmp layout, so the finish kernel and the NaN rule are shared: a non-finite term makes its atom's sum
 // non-finite, `poison` = sum over atoms of (sum * 0) then turns every bin of that statistic into NaN, exactly like the
@@ -277,34 +278,35 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   if constexpr (WM == 1) w_lane = g.wt[bk * g.nj + xw];
 
   int c0 = NONE, c1 = NONE;  // the atoms this lane is accumulating
-  bool last1 = false;        // entry 1 was the one used last
   double acc0[NA], acc1[NA];
 #pragma unroll
   for (int l = 0; l < NA; ++l) acc0[l] = acc1[l] = 0.0;
 
-  // flush entry 0 / 1 (per lane: `second`) of the lanes that ask for it into the LDS table, lanes grouped by atom id
-  auto flush = [&](bool ask, bool second) {
-    const int id = ask ? (second ? c1 : c0) : NONE;
-    const bool go = id != NONE;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(go);
-    while (todo) {
-      const int gid = __builtin_amdgcn_readlane(id, __builtin_ctzll(todo));
-      const bool sel = go && id == gid;
-      double mine = 0.0;
+  // Flush BOTH entries of EVERY lane into the LDS table and empty the caches: lanes are grouped by atom id, one DPP wave
+  // sum per (group, statistic).  Evicting lane by lane was measured 1.3x slower overall: after a region edge every lane
+  // drops its stale entries at a different row (when it next crosses a coast), and each of those rows paid a flush.
+  auto flush_all = [&]() {
 #pragma unroll
-      for (int l = 0; l < NA; ++l) {
-        const double v = sel ? (second ? acc1[l] : acc0[l]) : 0.0;
-        const double sum = wave_sum(v);
-        if (lane == l) mine = sum;
+    for (int e = 0; e < 2; ++e) {
+      const int id = e ? c1 : c0;
+      const bool go = id != NONE;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(go);
+      while (todo) {
+        const int gid = __builtin_amdgcn_readlane(id, __builtin_ctzll(todo));
+        const bool sel = go && id == gid;
+        double mine = 0.0;
+#pragma unroll
+        for (int l = 0; l < NA; ++l) {
+          const double sum = wave_sum_uniform(sel ? (e ? acc1[l] : acc0[l]) : 0.0);
+          if (lane == l) mine = sum;
+        }
+        if (lane < NA) tab[gid * NA + lane] += mine;
+        todo &= ~__builtin_amdgcn_ballot_w64(sel);
       }
-      if (lane < NA) tab[gid * NA + lane] += mine;
-      todo &= ~__builtin_amdgcn_ballot_w64(sel);
     }
 #pragma unroll
-    for (int l = 0; l < NA; ++l) {
-      if (go && !second) acc0[l] = 0.0;
-      if (go && second) acc1[l] = 0.0;
-    }
+    for (int l = 0; l < NA; ++l) acc0[l] = acc1[l] = 0.0;
+    c0 = c1 = NONE;
   };
 
   for (int64_t rb = rbeg; rb < rend; rb += 64) {
@@ -321,39 +323,42 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
     if constexpr (WM == 2) wrow_w = g.wt[bk * g.nBr + br];
     const int nrow = (int)(rend - rb < 64 ? rend - rb : 64);
 
+    // EVERYTHING a row needs (p, t, c, mask, atom id, weight) is requested together, PD rows ahead.  The memory counter
+    // retires in issue order: an operand fetched "one row ahead" (as the slot kernel does with its membership words)
+    // sits behind the data loads of PD - 1 later rows in the queue, so waiting for it drains all of them and the real
+    // prefetch depth collapses to one row.
     T rp[PD], rt[PD], rc[PD];
-    uint8_t rv[PD];
-    auto fetch_ptc = [&](int j, int u) {
+    uint8_t rv[PD], rid[PD];
+    double rw[PD];
+    auto fetch = [&](int j, int u) {
       rp[u] = ld_stream(reinterpret_cast<const T*>(a.in[0]) + readlane64(ro[0], j) + xo[0]);
       if constexpr (NIN > 1) rt[u] = ld_stream(reinterpret_cast<const T*>(a.in[1]) + readlane64(ro[1], j) + xo[1]);
       if constexpr (NIN > 2) rc[u] = ld_stream(reinterpret_cast<const T*>(a.in[2]) + readlane64(ro[2], j) + xo[2]);
       rv[u] = 1;
       if constexpr (has_mask) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + readlane64(ro[3], j))[xo[3]];
-    };
-    double w_cur, w_nxt = 0.0;
-    int id_cur, id_nxt = 0;
-    auto fetch_aw = [&](int j, double& w, int& id) {
       const int64_t wi = readlane64(wrow_v, j);
-      id = (g.aid + wi)[xw];
-      if constexpr (WM == 0) w = (g.wt + wi)[xw];
-      if constexpr (WM == 1) w = w_lane;
-      if constexpr (WM == 2) w = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+      rid[u] = (g.aid + wi)[xw];
+      if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
+      if constexpr (WM == 1) rw[u] = w_lane;
+      if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
     };
     auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
       const bool ok = live && tv != 0;
       bool hit0 = id == c0, hit1 = id == c1;
       const bool miss = ok && !hit0 && !hit1;
-      if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform, rare: region / coast lines
-        // victim: an empty entry first, else the one that was not used last
-        const bool second = c0 == NONE ? false : (c1 == NONE ? true : !last1);
-        flush(miss, second);
-        if (miss && second) c1 = id;
-        if (miss && !second) c0 = id;
+      if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform: a lane meets an atom it is not accumulating
+        // a lane with both entries taken meets a third atom (a region edge: the same row for most lanes): start over
+        bool place = miss;
+        if (__builtin_amdgcn_ballot_w64(miss && c0 != NONE && c1 != NONE)) {
+          flush_all();
+          place = ok;  // every entry is empty now: the lanes that had a hit re-enter their atom too
+        }
+        if (place && c0 == NONE) c0 = id;
+        else if (place) c1 = id;
         hit0 = id == c0;
         hit1 = id == c1;
       }
       if (ok) {
-        last1 = hit1;
         const double p = (double)tp, t = (double)tt, c = (double)tc;
         double val[NA];
         if constexpr (FUNC == WBX_PASS1) {
@@ -392,24 +397,21 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
     // every load is unconditional (clamped row indices), see det_binned_kernel
     const int last = nrow - 1;
 #pragma unroll
-    for (int u = 0; u < PD; ++u) fetch_ptc(u < last ? u : last, u);
-    fetch_aw(0, w_cur, id_cur);
+    for (int u = 0; u < PD; ++u) fetch(u < last ? u : last, u);
     for (int j = 0; j < nrow; j += PD) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
         const int jj = j + u;
         const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
         const uint8_t tv = rv[u];
-        fetch_ptc(jj + PD < last ? jj + PD : last, u);
-        fetch_aw(jj + 1 < last ? jj + 1 : last, w_nxt, id_nxt);
-        if (jj < nrow) accumulate(tp, tt, tc, tv, w_cur, id_cur);  // wave-uniform
-        w_cur = w_nxt;
-        id_cur = id_nxt;
+        const double tw = rw[u];
+        const int tid = rid[u];
+        fetch(jj + PD < last ? jj + PD : last, u);
+        if (jj < nrow) accumulate(tp, tt, tc, tv, tw, tid);  // wave-uniform
       }
     }
   }
-  flush(true, false);
-  flush(true, true);
+  flush_all();
   __syncthreads();
 
   // ---- atoms -> bins: thread (bin of the union, statistic) sums the atoms that carry the bin's bit
@@ -434,7 +436,7 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   }
 }
 
-// WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_PD = rows of p, t, c in flight (2 / 4)
+// WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_PD = rows in flight per wave (2 / 4 / 8)
 static int atoms_setting(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -460,6 +462,8 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g)
     if (atoms_pd <= 2) {
       if (wmode == 1) WBX_ATOMS_LAUNCH(2, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(2, 2); else WBX_ATOMS_LAUNCH(2, 0);
+    } else if (atoms_pd >= 8) {
+      if (wmode == 1) WBX_ATOMS_LAUNCH(8, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(8, 2); else WBX_ATOMS_LAUNCH(8, 0);
     } else {
       if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
     }
