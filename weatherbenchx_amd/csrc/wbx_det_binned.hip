@@ -286,8 +286,8 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   // sum per (group, statistic).  Evicting lane by lane was measured 1.3x slower overall: after a region edge every lane
   // drops its stale entries at a different row (when it next crosses a coast), and each of those rows paid a flush.
   auto flush_all = [&]() {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {  // (not unrolled: this code is inlined at every row position of the sweeps)
       const int id = e ? c1 : c0;
       const bool go = id != NONE;
       unsigned long long todo = __builtin_amdgcn_ballot_w64(go);
@@ -309,8 +309,62 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
     c0 = c1 = NONE;
   };
 
+  // One row of the patch: hit / miss bookkeeping of the lane's two accumulator sets, then 2 x NA FMAs.
+  auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
+    const bool ok = live && tv != 0;
+    bool hit0 = id == c0, hit1 = id == c1;
+    const bool miss = ok && !hit0 && !hit1;
+    if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform: a lane meets an atom it is not accumulating
+      // a lane with both entries taken meets a third atom (a region edge: the same row for most lanes): start over
+      bool place = miss;
+      if (__builtin_amdgcn_ballot_w64(miss && c0 != NONE && c1 != NONE)) {
+        flush_all();
+        place = ok;  // every entry is empty now: the lanes that had a hit re-enter their atom too
+      }
+      if (place && c0 == NONE) c0 = id;
+      else if (place) c1 = id;
+      hit0 = id == c0;
+      hit1 = id == c1;
+    }
+    if (ok) {
+      const double p = (double)tp, t = (double)tt, c = (double)tc;
+      double val[NA];
+      if constexpr (FUNC == WBX_PASS1) {
+        val[0] = p;
+      } else {
+        const double e = p - t;
+        val[0] = e;
+        val[1] = fabs(e);
+        val[2] = e * e;
+        if constexpr (FUNC == WBX_DET6) {
+          const double pa = p - c, ta = t - c;
+          val[3] = pa * pa;
+          val[4] = ta * ta;
+          val[5] = pa * ta;
+        }
+      }
+      if constexpr (MM == 1) val[NL] = 1.0;
+      if constexpr (MM >= 2) {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          const bool fin = !(val[l] != val[l]);
+          val[NL + l] = fin ? 1.0 : 0.0;
+          val[l] = fin ? val[l] : 0.0;
+        }
+      }
+      // the weight goes to the entry the point belongs to, 0 to the other (a NaN term reaches both: harmless, the
+      // poison rule makes every bin of that statistic NaN anyway)
+      const double f0 = hit0 ? w : 0.0, f1 = hit1 ? w : 0.0;
+#pragma unroll
+      for (int l = 0; l < NA; ++l) {
+        acc0[l] = fma(val[l], f0, acc0[l]);
+        acc1[l] = fma(val[l], f1, acc1[l]);
+      }
+    }
+  };
+
   for (int64_t rb = rbeg; rb < rend; rb += 64) {
-    // lane j resolves row rb + j through the plan's tables; the sweep below broadcasts them one by one
+    // lane j resolves row rb + j through the plan's tables (key / depth offsets, the climatology gather)
     const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
     const int64_t br = rmine / a.D;
     const int64_t d = rmine - br * a.D;
@@ -322,94 +376,79 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
     double wrow_w = 0.0;
     if constexpr (WM == 2) wrow_w = g.wt[bk * g.nBr + br];
     const int nrow = (int)(rend - rb < 64 ? rend - rb : 64);
+    const int last = nrow - 1;
+
+    // Usually the rows of a batch are evenly spaced in every input (a patch walks one dim of the chunk): then row j is
+    // base + j * step in SCALAR registers and every load is `global_load v, v_lane_offset, s[row]` -- no broadcast of
+    // lane j's offsets (12 v_readlane per row) and no 64-bit vector address arithmetic, in a kernel that is VALU-bound.
+    int64_t step[WBX_MAX_INPUTS + 1];
+    bool even = true;
+    {
+      const int up = lane + 1 < nrow ? lane + 1 : lane;  // (the last row compares with itself: difference 0, ignored)
+#pragma unroll
+      for (int i = 0; i <= WBX_MAX_INPUTS; ++i) {
+        const bool used = i == WBX_MAX_INPUTS || i < NIN || (i == 3 && has_mask);
+        if (!used) {
+          step[i] = 0;
+          continue;
+        }
+        const int64_t mine = i == WBX_MAX_INPUTS ? wrow_v : ro[i];
+        const int64_t next = (int64_t)(((uint64_t)(uint32_t)__shfl((int)((uint64_t)mine >> 32), up, 64) << 32) |
+                                       (uint32_t)__shfl((int)(uint32_t)(uint64_t)mine, up, 64));
+        step[i] = readlane64(next - mine, 0);
+        even = even && !__builtin_amdgcn_ballot_w64(lane + 1 < nrow && next - mine != step[i]);
+      }
+    }
 
     // EVERYTHING a row needs (p, t, c, mask, atom id, weight) is requested together, PD rows ahead.  The memory counter
     // retires in issue order: an operand fetched "one row ahead" (as the slot kernel does with its membership words)
     // sits behind the data loads of PD - 1 later rows in the queue, so waiting for it drains all of them and the real
     // prefetch depth collapses to one row.
-    T rp[PD], rt[PD], rc[PD];
-    uint8_t rv[PD], rid[PD];
-    double rw[PD];
-    auto fetch = [&](int j, int u) {
-      rp[u] = ld_stream(reinterpret_cast<const T*>(a.in[0]) + readlane64(ro[0], j) + xo[0]);
-      if constexpr (NIN > 1) rt[u] = ld_stream(reinterpret_cast<const T*>(a.in[1]) + readlane64(ro[1], j) + xo[1]);
-      if constexpr (NIN > 2) rc[u] = ld_stream(reinterpret_cast<const T*>(a.in[2]) + readlane64(ro[2], j) + xo[2]);
-      rv[u] = 1;
-      if constexpr (has_mask) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + readlane64(ro[3], j))[xo[3]];
-      const int64_t wi = readlane64(wrow_v, j);
-      rid[u] = (g.aid + wi)[xw];
-      if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
-      if constexpr (WM == 1) rw[u] = w_lane;
-      if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
-    };
-    auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
-      const bool ok = live && tv != 0;
-      bool hit0 = id == c0, hit1 = id == c1;
-      const bool miss = ok && !hit0 && !hit1;
-      if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform: a lane meets an atom it is not accumulating
-        // a lane with both entries taken meets a third atom (a region edge: the same row for most lanes): start over
-        bool place = miss;
-        if (__builtin_amdgcn_ballot_w64(miss && c0 != NONE && c1 != NONE)) {
-          flush_all();
-          place = ok;  // every entry is empty now: the lanes that had a hit re-enter their atom too
-        }
-        if (place && c0 == NONE) c0 = id;
-        else if (place) c1 = id;
-        hit0 = id == c0;
-        hit1 = id == c1;
-      }
-      if (ok) {
-        const double p = (double)tp, t = (double)tt, c = (double)tc;
-        double val[NA];
-        if constexpr (FUNC == WBX_PASS1) {
-          val[0] = p;
-        } else {
-          const double e = p - t;
-          val[0] = e;
-          val[1] = fabs(e);
-          val[2] = e * e;
-          if constexpr (FUNC == WBX_DET6) {
-            const double pa = p - c, ta = t - c;
-            val[3] = pa * pa;
-            val[4] = ta * ta;
-            val[5] = pa * ta;
-          }
-        }
-        if constexpr (MM == 1) val[NL] = 1.0;
-        if constexpr (MM >= 2) {
+    auto sweep = [&](auto even_tag, auto depth_tag) {
+      constexpr bool EVEN = decltype(even_tag)::value;
+      constexpr int RD = decltype(depth_tag)::value;
+      T rp[RD], rt[RD], rc[RD];
+      uint8_t rv[RD], rid[RD];
+      double rw[RD];
+      int64_t base[WBX_MAX_INPUTS + 1];
 #pragma unroll
-          for (int l = 0; l < NL; ++l) {
-            const bool fin = !(val[l] != val[l]);
-            val[NL + l] = fin ? 1.0 : 0.0;
-            val[l] = fin ? val[l] : 0.0;
-          }
-        }
-        // the weight goes to the entry the point belongs to, 0 to the other (a NaN term reaches both: harmless, the
-        // poison rule makes every bin of that statistic NaN anyway)
-        const double f0 = hit0 ? w : 0.0, f1 = hit1 ? w : 0.0;
+      for (int i = 0; i <= WBX_MAX_INPUTS; ++i) base[i] = EVEN ? readlane64(i == WBX_MAX_INPUTS ? wrow_v : ro[i], 0) : 0;
+      auto row_of = [&](int i, int j) -> int64_t {
+        if constexpr (EVEN) return base[i] + (int64_t)j * step[i];
+        return readlane64(i == WBX_MAX_INPUTS ? wrow_v : ro[i], j);
+      };
+      auto fetch = [&](int j, int u) {
+        rp[u] = ld_stream((reinterpret_cast<const T*>(a.in[0]) + row_of(0, j)) + xo[0]);
+        if constexpr (NIN > 1) rt[u] = ld_stream((reinterpret_cast<const T*>(a.in[1]) + row_of(1, j)) + xo[1]);
+        if constexpr (NIN > 2) rc[u] = ld_stream((reinterpret_cast<const T*>(a.in[2]) + row_of(2, j)) + xo[2]);
+        rv[u] = 1;
+        if constexpr (has_mask) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
+        const int64_t wi = row_of(WBX_MAX_INPUTS, j);
+        rid[u] = (g.aid + wi)[xw];
+        if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
+        if constexpr (WM == 1) rw[u] = w_lane;
+        if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+      };
+      // every load is unconditional (clamped row indices), see det_binned_kernel
 #pragma unroll
-        for (int l = 0; l < NA; ++l) {
-          acc0[l] = fma(val[l], f0, acc0[l]);
-          acc1[l] = fma(val[l], f1, acc1[l]);
+      for (int u = 0; u < RD; ++u) fetch(u < last ? u : last, u);
+      for (int j = 0; j < nrow; j += RD) {
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+          const int jj = j + u;
+          const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
+          const uint8_t tv = rv[u];
+          const double tw = rw[u];
+          const int tid = rid[u];
+          fetch(jj + RD < last ? jj + RD : last, u);
+          if (jj < nrow) accumulate(tp, tt, tc, tv, tw, tid);  // wave-uniform
         }
       }
     };
-    // every load is unconditional (clamped row indices), see det_binned_kernel
-    const int last = nrow - 1;
-#pragma unroll
-    for (int u = 0; u < PD; ++u) fetch(u < last ? u : last, u);
-    for (int j = 0; j < nrow; j += PD) {
-#pragma unroll
-      for (int u = 0; u < PD; ++u) {
-        const int jj = j + u;
-        const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
-        const uint8_t tv = rv[u];
-        const double tw = rw[u];
-        const int tid = rid[u];
-        fetch(jj + PD < last ? jj + PD : last, u);
-        if (jj < nrow) accumulate(tp, tt, tc, tv, tw, tid);  // wave-uniform
-      }
-    }
+    if (even)
+      sweep(std::true_type{}, std::integral_constant<int, PD>{});
+    else
+      sweep(std::false_type{}, std::integral_constant<int, 2>{});  // (gathers that jump between rows, several inits)
   }
   flush_all();
   __syncthreads();
@@ -458,6 +497,10 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   const int64_t grid = patch_grid<BINNED_WPB>(g);
   if (atoms) {
     const int64_t agrid = patch_grid<1>(g);
+    static const int order_env = atoms_setting("WBX_PATCH_ORDER", -1);
+    BinnedArgs ga = g;
+    ga.order = order_env >= 0 ? order_env : ((plan->nx * (int64_t)sizeof(T)) % 128 != 0 ? 1 : 0);
+#define g ga
 #define WBX_ATOMS_LAUNCH(PDV, WMV) \
     hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g)
     if (atoms_pd <= 2) {
@@ -468,6 +511,7 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
       if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
     }
 #undef WBX_ATOMS_LAUNCH
+#undef g
     WBX_HIP(hipGetLastError());
   }
   // the slot kernel takes the patches the atom kernel declined (more than ATOM_MAX distinct membership words); its

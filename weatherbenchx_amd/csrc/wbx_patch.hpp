@@ -25,6 +25,7 @@ struct BinnedArgs {
   unsigned long long* words;         // [nBk][patch][ATOM_MAX]
   int32_t* nwords;                   // [nBk][patch]: entries in the list, -1 = more than ATOM_MAX (slot kernel takes it)
   int32_t atoms;                     // 0: every patch goes to the slot kernel (A/B timing: WBX_BINNED_ATOMS=0)
+  int32_t order;                     // block order: 0 cell fastest, 1 x tile fastest (see patch_decode)
 };
 
 constexpr int ATOM_MAX = 32;
@@ -198,6 +199,7 @@ inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nB
   g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
   g.ncell = cells;
   g.nblocks = cells * (int64_t)g.nrs * g.nxt;
+  g.order = 0;
 }
 
 // The atom tables of a geometry: uni | words | nwords | aid, each padded to 8 bytes.  They depend on the membership
@@ -287,10 +289,25 @@ __device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell,
   const uint32_t per_xcd = (nblocks + 7u) >> 3;
   uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   if (b >= nblocks) return false;
+  const uint32_t wave = WPB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+  if (g.order == 1) {
+    // x tile fastest: the tiles of one (cell, row range) run side by side on one XCD.  Rows that are not a multiple of
+    // the 128-byte line long (721 floats) make neighbouring tiles share their boundary lines; with the cell-fastest
+    // order the neighbour comes ~20 MB of streamed data later and fetches the line again (measured: 1.53x the
+    // algorithmic bytes on latitude-fastest chunks).  The atom kernel reads 1 byte of membership per point, so it does
+    // not need the cell-fastest order for its W operand any more.
+    const uint32_t q = b / nxq;
+    const uint32_t x = (b - q * nxq) * WPB + wave;
+    const uint32_t q2 = q / ncell;
+    cell = (int64_t)(q - q2 * ncell);
+    if (x >= nxt) return false;
+    xt = (int)x;
+    rs = (int)q2;
+    return true;
+  }
   const uint32_t q = b / ncell;
   cell = (int64_t)(b - q * ncell);
   const uint32_t q2 = q / nxq;
-  const uint32_t wave = WPB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
   const uint32_t x = (q - q2 * nxq) * WPB + wave;
   if (x >= nxt) return false;
   xt = (int)x;
