@@ -615,10 +615,32 @@ def test_unbiased_mse_with_an_ensemble_of_targets(backend, np_members, nt_member
   stats = metrics_base.compute_unique_statistics_for_all_metrics({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, p, t)
   (name, per_var), = stats.items()
   np.testing.assert_allclose(per_var['v'].values, stat, rtol=1e-5, atol=1e-6)
-  with pytest.raises(ValueError, match='Failed to compute statistic') as info:
-    metrics_base.compute_unique_statistics_for_all_metrics(
-        {'u': probabilistic.UnbiasedEnsembleMeanRMSE(skipna_ensemble=True)}, p, t)
-  assert isinstance(info.value.__cause__, NotImplementedError)
+  # skipna_ensemble=True with NaN members on BOTH sides (probabilistic.py:304-333, 133-145): per-point member counts,
+  # evaluated un-fused and reduced through the generic kernels
+  pn, tn = pv.copy(), tv.copy()
+  pn[0, :, 2:4] = np.nan   # a prediction member missing over a band
+  tn[:, 1, 5:7] = np.nan   # a target member missing over another band
+  pn[1, 0, 0, 0] = np.nan
+  pq = {'v': xr.DataArray(pn, dims=('number', 'lead_time', 'latitude', 'longitude'), coords={'latitude': lat})}
+  tq = {'v': xr.DataArray(tn, dims=('lead_time', 'number', 'latitude', 'longitude'), coords={'latitude': lat})}
+  got = aggregation.compute_metric_values_for_single_chunk(
+      {'u': probabilistic.UnbiasedEnsembleMeanRMSE(skipna_ensemble=True)}, agg, pq, tq)
+  p64, t64 = pn.astype(np.float64), tn.astype(np.float64)
+  with np.errstate(invalid='ignore'):
+    stat = ((np.nanmean(p64, 0) - np.nanmean(t64, 1)) ** 2 - np.nanvar(p64, 0, ddof=1) / (~np.isnan(p64)).sum(0)
+            - np.nanvar(t64, 1, ddof=1) / (~np.isnan(t64)).sum(1))
+  want = np.sqrt((stat * w).sum(axis=(1, 2)) / (np.broadcast_to(w, stat.shape).sum(axis=(1, 2))))
+  np.testing.assert_allclose(got['u.v'].values, want, rtol=RTOL)
+  # CRPSSkill: mean over the non-NaN (prediction member, target member) pairs of each point
+  skill = probabilistic.CRPSSkill(skipna_ensemble=True).compute(pq, tq)['v']
+  tt = np.moveaxis(t64, 1, 0)                                     # [N, lead, lat, lon]
+  pairs = np.abs(p64[:, None] - tt[None])                          # [M, N, lead, lat, lon]
+  with np.errstate(invalid='ignore'):
+    want_skill = np.nanmean(pairs.reshape(-1, *pairs.shape[2:]), axis=0)
+  np.testing.assert_allclose(skill.transpose('lead_time', 'latitude', 'longitude').values, want_skill, rtol=1e-6)
+  assert np.isclose(O.crps_skill(pn, ('number', 'lead_time', 'latitude', 'longitude'), tn,
+                                 ('lead_time', 'number', 'latitude', 'longitude'), 'number', skipna_ensemble=True)[0],
+                    want_skill, rtol=1e-12).all()  # the oracle agrees with the brute force
 
 
 @pytest.mark.parametrize('nlon,expect_rows', [(24, 8), (25, 5), (29, 0)])
@@ -896,3 +918,32 @@ def test_latitude_weights_folded_into_stage_one(backend, monkeypatch, mode):
     sk = O.aggregate(O.crps_skill(ev, edims, tv, dims, 'number')[0], dims, ['latitude', 'longitude'], weights=[w])
     sp = O.aggregate(O.crps_spread(ev, edims, 'number', use_sort=True)[0], dims, ['latitude', 'longitude'], weights=[w])
     np.testing.assert_allclose(results[True]['crps.v'].values, O.crps(sk[0] / sk[1], sp[0] / sp[1]), rtol=RTOL)
+
+
+def test_error_exceedance_with_thresholds_that_vary_with_data_dims(backend):
+  """deterministic.py:262-295 with a thresholds DataArray that carries a data dim (one threshold set per level): the
+  comparison broadcasts like `abs_error > thresholds`; NaN errors and NaN thresholds stay NaN."""
+  rng = np.random.default_rng(17)
+  lat = np.linspace(-80, 80, 9)
+  pv = rng.normal(size=(3, 2, 9, 12)).astype(np.float32)
+  tv = rng.normal(size=(3, 2, 9, 12)).astype(np.float32)
+  tv[0, 0, 0, 0] = np.nan
+  dims = ('lead_time', 'level', 'latitude', 'longitude')
+  coords = {'level': np.array([500, 850]), 'latitude': lat}
+  thr = xr.DataArray(np.array([[0.5, 1.0, np.nan], [1.0, 2.0, 3.0]]), dims=('level', 'error_exceedance_thresholds'),
+                     coords={'level': np.array([500, 850]), 'error_exceedance_thresholds': np.array([0, 1, 2])})
+  stat = deterministic.ErrorExceedance(thr).compute({'v': xr.DataArray(pv, dims=dims, coords=coords)},
+                                                   {'v': xr.DataArray(tv, dims=dims, coords=coords)})['v']
+  ae = np.abs(pv.astype(np.float64) - tv.astype(np.float64))[..., None]
+  th = thr.values[None, :, None, None, :]
+  with np.errstate(invalid='ignore'):
+    want = np.where(np.isnan(ae) | np.isnan(th), np.nan, (ae > th).astype(np.float64))
+  np.testing.assert_array_equal(stat.transpose(*dims, 'error_exceedance_thresholds').values, want)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], skipna=True)
+  state = agg.aggregate_stat_var(stat)
+  got = state.mean_statistics().transpose('lead_time', 'level', 'error_exceedance_thresholds').values
+  w = O.grid_area_weights(lat)[None, None, :, None, None]
+  ok = ~np.isnan(want)
+  with np.errstate(invalid='ignore'):
+    ref = (np.where(ok, want, 0) * w).sum(axis=(2, 3)) / (ok * w).sum(axis=(2, 3))
+  np.testing.assert_allclose(got, ref, rtol=RTOL, equal_nan=True)

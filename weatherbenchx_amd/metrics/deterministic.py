@@ -97,7 +97,7 @@ def _threshold_array(thresholds, name):
     thresholds = thresholds[name]
   if isinstance(thresholds, xr.DataArray):
     if thresholds.ndim != 1:
-      raise NotImplementedError('thresholds that depend on data dimensions are not fused; pass a 1-D DataArray')
+      return None  # thresholds that vary with data dims: evaluated un-fused (ErrorExceedance._compute_per_variable)
     dim = thresholds.dims[0]
     coord = thresholds.coords[dim].values if dim in thresholds.coords else None
     return np.asarray(thresholds.values, np.float64), dim, coord
@@ -113,7 +113,15 @@ class ErrorExceedance(base.PerVariableStatistic):
     self._thresholds = thresholds
 
   def _compute_per_variable(self, predictions, targets):
-    values, dim, coord = _threshold_array(self._thresholds, predictions.name)
+    spec = _threshold_array(self._thresholds, predictions.name)
+    if spec is None:
+      # thresholds with data dims (per level, per latitude ...): the comparison broadcasts like the reference's
+      # `abs_error > thresholds`, evaluated on the labeled arrays; NaN errors and NaN thresholds stay NaN
+      thresholds = self._thresholds[predictions.name] if isinstance(self._thresholds, (xr.Dataset, dict)) else self._thresholds
+      abs_error = abs(predictions - targets)
+      out = (abs_error > thresholds).astype(np.float64)
+      return out.where(abs_error.notnull()).where(thresholds.notnull()).rename(predictions.name)
+    values, dim, coord = spec
     return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, dim, coord, thresholds=values)
 
 

@@ -5,7 +5,8 @@ Per-point arithmetic lives in csrc/wbx_ens_impl.hpp (one lane owns one grid poin
 VGPRs: sorting-network rank form for `use_sort=True`, pairwise form for `use_sort=False`).
 `skipna_ensemble=True` and float64 / M > 64 members run on the generic (memory re-reading, fp64 pair form) kernel;
 targets that carry the ensemble dim are handled member by member (CRPSSkill, UnbiasedEnsembleMeanSquaredError,
-`which='targets'`); only their combination with skipna_ensemble=True raises NotImplementedError.
+`which='targets'`); their combination with skipna_ensemble=True (per-point counts on both sides: not linear in the
+target member) is evaluated un-fused on the labeled arrays and reduced through the generic (PASS1) kernels.
 """
 from __future__ import annotations
 
@@ -80,7 +81,19 @@ class CRPSSkill(base.PerVariableStatistic):
       # mean over both ensemble dims of |p_i - t_j| (probabilistic.py:134-145) = mean over target members of the
       # per-member skill: linear, so one fused launch per target member
       if self._skipna_ensemble:
-        raise NotImplementedError('skipna_ensemble with ensemble-valued targets is not supported')
+        # NaN members on either side: the mean runs over the non-NaN (prediction member, target member) pairs of each
+        # point, which is not linear in the target member any more -- evaluated un-fused on the labeled arrays, one
+        # target member at a time (no M x N x grid temporary), exactly as written in the reference
+        pseudo = f'{self._ensemble_dim}_PSEUDO_FOR_TARGETS'
+        total = count = None
+        for tj in lazy.target_members(targets, self._ensemble_dim):
+          ae = abs(predictions - tj)
+          ok = ae.notnull()
+          part, n = ae.where(ok, 0.0).sum(self._ensemble_dim, skipna=False), ok.sum(self._ensemble_dim)
+          total = part if total is None else total + part
+          count = n if count is None else count + n
+        del pseudo
+        return (total / count.where(count > 0)).rename(predictions.name)
       members = lazy.target_members(targets, self._ensemble_dim)
       terms = [lazy.ens_statistic('CRPSSkill', predictions, tj, self._ensemble_dim) for tj in members]
       return lazy.LinearCombination(terms, scale=1.0 / len(terms), name=predictions.name)
@@ -162,7 +175,11 @@ class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
       # this is  mean_j UEMSE(p, t_j) - var_t : N fused launches against single target members plus the variance
       # lane of one launch over the target ensemble -- linear, so the accumulators are combined after the reduction.
       if self._skipna_ensemble:
-        raise NotImplementedError('skipna_ensemble with ensemble-valued targets is not supported')
+        # per-point member counts on both sides (probabilistic.py:304-333): un-fused, on the labeled arrays
+        dim = self._ensemble_dim
+        bias = lambda x: x.var(dim=dim, ddof=1, skipna=True) / x.count(dim)
+        out = (predictions.mean(dim=dim, skipna=True) - targets.mean(dim=dim, skipna=True)) ** 2
+        return (out - bias(predictions) - bias(targets)).rename(predictions.name)
       members = lazy.target_members(targets, self._ensemble_dim)
       n = len(members)
       if n < 2:
