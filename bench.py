@@ -63,6 +63,8 @@ def parse():
   ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
   ap.add_argument('--config5-inits', type=int, default=366)
   ap.add_argument('--cpu-workers', type=int, default=0, help='worker processes of the multi-core CPU baseline (0 = os.cpu_count())')
+  ap.add_argument('--legs', default='all', help='comma list of main,rmse_crps_37L,ensemble,public_chunk,spectrum,config5,cpu '
+                  '(profiling passes: one kernel shape per trace); default all')
   ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
   return ap.parse_args()
 
@@ -395,7 +397,11 @@ def public_chunk_leg(env):
                       f'{2 * len(REGIONS)} bins, masked=True, {args.layout}',
           'ms_per_chunk': p_ms, 'value': ppoints * len(pmetrics) / (p_ms * 1e-3), 'unit': 'evals/s',
           'kernels': [e.get('kind') for e in plog],
-          'roofline': kernel_roofline('wbx_det_binned (atomise + main + finish)', k_ms, ppoints * 12),
+          'roofline': dict(kernel_roofline('wbx_det_binned (memset + det_atoms_kernel + slot kernel for overflow patches + finish)',
+                                           k_ms, ppoints * 12,
+                                           pmc_traffic(f"det_atoms_kernel<float,DET6,MM=0,PD=4,WM={2 if args.layout == 'lon_fastest' else 1}>",
+                                                       not args.small and args.layout == 'lat_fastest')),
+                           traffic_note='PMC pass of tools/kbench_binned.py (latitude-fastest chunk), main kernel only'),
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
 
 
@@ -576,25 +582,33 @@ def main():
   if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
   env = Env(args)
-  result, keep = main_leg(env)
+  legs = None if args.legs == 'all' else set(args.legs.split(','))
+  want = lambda name: legs is None or name in legs
+  result, keep = ({'metric': METRIC, 'value': None, 'note': 'main leg not selected (--legs)'}, None)
+  if want('main'):
+    result, keep = main_leg(env)
   if not args.no_ens and env.world == 1:
-    nl37 = 37 if not args.small else 3
-    name, leg = ens_leg(env, 'level', nl37, 1, 'rmse_crps_37L',
-                        f'north_star target: weighted CRPS(rank form, fair) + unbiased spread/skill + unbiased-mean RMSE + '
-                        f'ensemble-mean RMSE on ONE f32[{nl37} level,51 member,{env.nlat},{env.nlon}] forecast vs '
-                        f'f32[{nl37},{env.nlat},{env.nlon}] targets, reduce (latitude, longitude), GridAreaWeighting')
-    result[name] = leg
-    ns = args.ens_slices if not args.small else 2
-    nvar = 6 if not args.small else 2
-    name, leg = ens_leg(env, 'lead_time', ns, nvar, 'ensemble',
-                        f'configs[2]: {nvar} vars x f32[{ns} slices,51 members,{env.nlat},{env.nlon}], CRPS(rank form, fair) + '
-                        'unbiased spread/skill + unbiased-mean RMSE + mean RMSE')
-    result[name] = leg
-    result['public_chunk'] = public_chunk_leg(env)
-    result['spectrum'] = spectrum_leg(env)
-  if not args.no_config5:
+    if want('rmse_crps_37L'):
+      nl37 = 37 if not args.small else 3
+      name, leg = ens_leg(env, 'level', nl37, 1, 'rmse_crps_37L',
+                          f'north_star target: weighted CRPS(rank form, fair) + unbiased spread/skill + unbiased-mean RMSE + '
+                          f'ensemble-mean RMSE on ONE f32[{nl37} level,51 member,{env.nlat},{env.nlon}] forecast vs '
+                          f'f32[{nl37},{env.nlat},{env.nlon}] targets, reduce (latitude, longitude), GridAreaWeighting')
+      result[name] = leg
+    if want('ensemble'):
+      ns = args.ens_slices if not args.small else 2
+      nvar = 6 if not args.small else 2
+      name, leg = ens_leg(env, 'lead_time', ns, nvar, 'ensemble',
+                          f'configs[2]: {nvar} vars x f32[{ns} slices,51 members,{env.nlat},{env.nlon}], CRPS(rank form, fair) + '
+                          'unbiased spread/skill + unbiased-mean RMSE + mean RMSE')
+      result[name] = leg
+    if want('public_chunk'):
+      result['public_chunk'] = public_chunk_leg(env)
+    if want('spectrum'):
+      result['spectrum'] = spectrum_leg(env)
+  if not args.no_config5 and want('config5'):
     result['config5'] = config5_leg(env)
-  if not args.no_cpu and env.world == 1 and env.rank == 0:
+  if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu') and keep is not None:
     result['cpu_baseline'] = cpu_leg(env, keep)
   if env.rank == 0:
     print(json.dumps(result))

@@ -46,6 +46,9 @@ def bench_key(name: str) -> str:
   m = re.match(r's1_xf_kernel<(.*?) ?>$', n)
   if m:
     return f's1_xf_kernel<{m.group(1)}>'
+  m = re.match(r'det_atoms_kernel<float, 1, (\d), (\d+), (\d)>', n)
+  if m:
+    return f'det_atoms_kernel<float,DET6,MM={m.group(1)},PD={m.group(2)},WM={m.group(3)}>'
   m = re.match(r'det_binned_kernel<float, 1, (\d), (\d+), (\d), (\d)>', n)
   if m:
     return f'det_binned_kernel<float,DET6,MM={m.group(1)},K={m.group(2)},PD={m.group(3)},WM={m.group(4)}>'
@@ -66,4 +69,7 @@ traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pm
                     'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
                     '(gfx950 reports half of wide coalesced reads)')
 json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
+for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt'):
+  if os.path.exists(os.path.join(src, extra)):
+    shutil.copy(os.path.join(src, extra), out(extra))
 print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])

@@ -27,6 +27,7 @@ struct FftState {
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, FftPlan> plans;  // (nlon, lon_stride, row_stride, batch)
   void* scratch = nullptr;  // complex tile
   std::map<int, void*> twiddles;  // nlon -> device float2[n/2] + float2[n/2 + 1] of the fused path
+  std::map<std::vector<int64_t>, void*> slab_offsets;  // slab offset lists of latitude-fastest fields, on the device
   std::map<std::pair<const void*, size_t>, int> occupancy;  // (fused kernel, dynamic LDS bytes) -> resident blocks per CU
   size_t scratch_size = 0;
   bool setup = false;
@@ -45,6 +46,7 @@ void spectrum_release(wbx_ctx* ctx) {
   for (auto& kv : st->plans) destroy_plan(kv.second);
   if (st->scratch) (void)hipFree(st->scratch);
   for (auto& kv : st->twiddles) (void)hipFree(kv.second);
+  for (auto& kv : st->slab_offsets) (void)hipFree(kv.second);
   if (st->setup) rocfft_cleanup();
   delete st;
   ctx->fft_state = nullptr;
@@ -637,11 +639,15 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
     // latitude-fastest fields (rows adjacent, longitude strided): transpose row tiles into a contiguous scratch, then the
     // fused kernel -- 3 passes over the field instead of one strided rocFFT batch per slab (configs[3], 296 slabs of
     // 721 rows: 27.6 ms -> see DESIGN.md)
-    int64_t tile = ((int64_t)256 << 20) / ((int64_t)nlon * 4);
+    // (Scratch tiles small enough to stay in the 256 MB Infinity Cache between the transpose and the FFT were measured
+    // SLOWER: 16 / 32 / 64 / 128 / 256 MB -> 8.1 / 6.1 / 4.1 / 3.3 / 3.0 ms per configs[3] step; the short launches do
+    // not fill the chip.)  WBX_SPECTRUM_TILE_MB: A/B timing.
+    static const int tile_mb = getenv("WBX_SPECTRUM_TILE_MB") ? atoi(getenv("WBX_SPECTRUM_TILE_MB")) : 256;
+    int64_t tile = ((int64_t)(tile_mb > 0 ? tile_mb : 256) << 20) / ((int64_t)nlon * 4);
     tile -= tile & 1;
     if (tile < 2) tile = 2;
     if (tile > nrows) tile = nrows;
-    const size_t need = (size_t)tile * nlon * sizeof(float) + (size_t)(nslab > 1 ? nslab : 1) * sizeof(int64_t);
+    const size_t need = (size_t)tile * nlon * sizeof(float);
     if (st->scratch_size < need) {
       if (st->scratch) {
         WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -655,9 +661,23 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
     float* rows = reinterpret_cast<float*>(st->scratch);
     int64_t* d_off = nullptr;
     if (nslab > 1 || (h_slab_offsets && h_slab_offsets[0] != 0)) {
-      d_off = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(st->scratch) + (size_t)tile * nlon * sizeof(float));
-      WBX_HIP(hipMemcpyAsync(d_off, h_slab_offsets, (size_t)nslab * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-      WBX_HIP(hipStreamSynchronize(ctx->stream));  // the host array may go away after the call
+      // the slab offsets of a chunk layout repeat from chunk to chunk: kept on the device per content, so that the steady
+      // state has no host-blocking copy in front of the kernels
+      std::vector<int64_t> key(h_slab_offsets, h_slab_offsets + nslab);
+      auto it = st->slab_offsets.find(key);
+      if (it == st->slab_offsets.end()) {
+        if (st->slab_offsets.size() > 16) {
+          WBX_HIP(hipStreamSynchronize(ctx->stream));
+          for (auto& kv : st->slab_offsets) (void)hipFree(kv.second);
+          st->slab_offsets.clear();
+        }
+        void* d = nullptr;
+        WBX_HIP(hipMalloc(&d, (size_t)nslab * sizeof(int64_t)));
+        WBX_HIP(hipMemcpyAsync(d, h_slab_offsets, (size_t)nslab * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        WBX_HIP(hipStreamSynchronize(ctx->stream));  // the host array may go away after the call
+        it = st->slab_offsets.emplace(std::move(key), d).first;
+      }
+      d_off = reinterpret_cast<int64_t*>(it->second);
     }
     for (int64_t r0 = 0; r0 < nrows; r0 += tile) {
       const int64_t n = r0 + tile <= nrows ? tile : nrows - r0;
