@@ -16,7 +16,7 @@ for f in sorted(glob.glob('$OUT/*/*counter_collection.csv')):
   for row in csv.DictReader(open(f)):
     agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
   for k, c in agg.items():
-    if 'binned_kernel' in k or 'atoms_kernel' in k:
+    if 'binned_kernel' in k or 'atoms_kernel' in k or 'atoms4_kernel' in k:
       print(k, {n: (len(v), sum(v) / len(v)) for n, v in c.items()})
 PY
 # memory-side counters (their own pass): texture-address / data busy, L2 hit rate, stalls
@@ -29,7 +29,7 @@ for f in sorted(glob.glob('$OUT/d/*counter_collection.csv')):
   for row in csv.DictReader(open(f)):
     agg[row['Kernel_Name'][:60]][row['Counter_Name']].append(float(row['Counter_Value']))
   for k, c in agg.items():
-    if 'binned_kernel' in k or 'atoms_kernel' in k:
+    if 'binned_kernel' in k or 'atoms_kernel' in k or 'atoms4_kernel' in k:
       print(k, {n: (len(v), sum(v) / len(v)) for n, v in c.items()})
 PY
 tail -3 $OUT/d.log
