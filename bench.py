@@ -63,6 +63,9 @@ def parse():
   ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
   ap.add_argument('--config5-inits', type=int, default=366)
   ap.add_argument('--cpu-workers', type=int, default=0, help='worker processes of the multi-core CPU baseline (0 = os.cpu_count())')
+  ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                  help='torch.distributed backend for N > 1; gloo combines through the host and lets several ranks share '
+                       'one device (a plumbing check of the N > 1 path on a 1-GPU box, not a measurement)')
   ap.add_argument('--legs', default='all', help='comma list of main,rmse_crps_37L,ensemble,public_chunk,spectrum,config5,cpu '
                   '(profiling passes: one kernel shape per trace); default all')
   ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
@@ -73,7 +76,7 @@ def self_launch(args):
   """`python bench.py --gpus N` from a bare shell: re-run under torch.distributed.run, one rank per GPU."""
   from weatherbenchx_amd import _hip
   ndev = _hip.device_count() if os.path.exists(_hip.lib_path()) else 0
-  if ndev < args.gpus:
+  if ndev < args.gpus and not (args.backend == 'gloo' and ndev >= 1):
     print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'evals/s', 'n_gpus': args.gpus, 'steps': args.steps,
                       'warmup': args.warmup, 'skipped': True, 'higher_is_better': True,
                       'reason': f'--gpus {args.gpus} needs {args.gpus} visible devices, this box has {ndev} '
@@ -100,11 +103,15 @@ class Env:
     self.world = int(os.environ.get('WORLD_SIZE', '1'))
     self.rank = int(os.environ.get('RANK', '0'))
     self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(self.local_rank)
-    self.dev = torch.device('cuda', self.local_rank)
+    self.device_index = self.local_rank % max(torch.cuda.device_count(), 1)  # (gloo plumbing runs may share a device)
+    torch.cuda.set_device(self.device_index)
+    self.dev = torch.device('cuda', self.device_index)
     if self.world > 1:
-      dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
-    self.ctx = _hip.default_context(self.local_rank)
+      if args.backend == 'nccl':
+        dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+      else:
+        dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+    self.ctx = _hip.default_context(self.device_index)
     self.nlat, self.nlon = (721, 1440) if not args.small else (73, 144)
     self.lat = np.linspace(-90, 90, self.nlat)
     self.lon = np.linspace(0, 360, self.nlon, endpoint=False)
@@ -133,7 +140,7 @@ class Env:
   def max_over_ranks(self, seconds):
     if self.world == 1:
       return seconds
-    t = self.torch.tensor([seconds], device=self.dev, dtype=self.torch.float64)
+    t = self.torch.tensor([seconds], device=self.dev if self.args.backend == 'nccl' else 'cpu', dtype=self.torch.float64)
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -272,7 +279,7 @@ def main_leg(env):
                  'host_pipeline': 'steps overlapped one deep; ' + ('deferred read-back (engine.deferred_results)' if env.world == 1 else
                                   'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
                  'sharding': f'{env.world} x (init x lead) blocks (one per rank), 1 all-reduce/step',
-                 'rccl_ranks': env.world if env.world > 1 else 0,
+                 'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0, 'backend': args.backend if env.world > 1 else None,
                  'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
       'roofline': roofline,
   }

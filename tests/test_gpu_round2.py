@@ -312,3 +312,50 @@ def test_gpu_state_through_file_to_the_bootstrap_consumer(ctx, tmp_path):
   resampled = back.dot(xr.DataArray(counts, dims=['replicate', 'init_time']), dim='init_time').metric_values(metrics)
   want = np.sqrt((counts.astype(np.float64) @ se_s) / (counts.astype(np.float64) @ se_w))
   np.testing.assert_allclose(resampled['rmse.z'].transpose('replicate', 'lead_time').values, want, rtol=RTOL)
+
+
+def _run_bench(*flags, timeout=600):
+  import json
+  import subprocess
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+  res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags), capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+  assert res.returncode == 0, res.stderr[-3000:]
+  lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, res.stdout[-2000:]  # exactly ONE JSON line
+  return json.loads(lines[0])
+
+
+def test_bench_contract_small(ctx):
+  """bench.py keeps the driver's contract (one JSON line with value / roofline / config.workload, every leg present) --
+  at debugging sizes, so that a broken leg shows up here and not in the round-end run."""
+  out = _run_bench('--small', '--steps', '2', '--warmup', '1', '--cpu-workers', '2')
+  for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'rmse_crps_37L', 'ensemble',
+              'public_chunk', 'spectrum', 'config5'):
+    assert key in out, key
+  assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0 and 'workload' in out['config']
+  assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(out['roofline'])
+  assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(out['cpu_baseline']) and out['cpu_baseline']['cores'] == 1
+  assert out['cpu_baseline']['all_cores']['cores'] == 2
+  assert out['config5']['scaling'] == 'strong' and out['config5']['chunks'] == 6
+  assert abs(out['check']['rmse_mean'] - 2 ** 0.5) < 0.01
+
+
+def test_bench_two_ranks_from_a_bare_shell(ctx):
+  """`python bench.py --gpus 2` from a bare shell launches itself under torch.distributed.run.  On a 1-GPU box the RCCL
+  run is skipped with a clear JSON line (rc 0); with --backend gloo the two ranks share the device and the whole N > 1
+  path -- per-step device accumulators + one all-reduce, config5 sharded i mod 2 with one reduce per pass -- runs for
+  real (the collective goes through the host: a plumbing check, not a measurement)."""
+  import torch
+  if torch.cuda.device_count() < 2:
+    skipped = _run_bench('--gpus', '2', '--small', '--steps', '2', '--warmup', '1')
+    assert skipped.get('skipped') is True and skipped['n_gpus'] == 2 and 'devices' in skipped['reason']
+  out = _run_bench('--gpus', '2', '--backend', 'gloo', '--small', '--steps', '2', '--warmup', '1', '--legs', 'main,config5')
+  assert out['n_gpus'] == 2 and out['config']['collectives_per_step'] == 1.0 and out['config']['backend'] == 'gloo'
+  assert abs(out['check']['rmse_mean'] - 2 ** 0.5) < 0.01
+  one = _run_bench('--small', '--steps', '2', '--warmup', '1', '--legs', 'config5')
+  # the sharded, all-reduced result of the streamed suite equals the one-rank result
+  assert out['config5']['n_gpus'] == 2 and out['config5']['check']['shape_rmse_z'] == one['config5']['check']['shape_rmse_z']
+  np.testing.assert_allclose(out['config5']['check']['rmse_z_mean'], one['config5']['check']['rmse_z_mean'], rtol=1e-12)
+  np.testing.assert_allclose(out['config5']['check']['crps_t2m_mean'], one['config5']['check']['crps_t2m_mean'], rtol=1e-12)
