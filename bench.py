@@ -119,8 +119,8 @@ class Env:
     self.gen = torch.Generator(device=self.dev)
     self.gen.manual_seed(1234 + self.rank)
 
-  def randn(self, shp, offset=0.0, scale=1.0):
-    t = self.torch.randn(shp, generator=self.gen, device=self.dev, dtype=self.torch.float32)
+  def randn(self, shp, offset=0.0, scale=1.0, gen=None):
+    t = self.torch.randn(shp, generator=gen or self.gen, device=self.dev, dtype=self.torch.float32)
     if scale != 1.0:
       t *= scale
     if offset != 0.0:
@@ -470,16 +470,20 @@ def config5_leg(env):
   sp_shape = env.sp_shape()
   # resident pool (H2D excluded and stated): chunk i reads buffer i mod npool; the climatology holds every
   # (dayofyear, hour) slot the 366 inits x 20 leads touch in a ring of 12 days (dayofyear = 1 + (i mod 6) + lead days)
+  # (its own generator, the same on every rank: chunk i holds the same numbers whichever rank runs it, so the result does
+  # not depend on N)
+  gen5 = env.torch.Generator(device=env.dev)
+  gen5.manual_seed(4242)
   pool = []
   for _ in range(npool):
-    ens = env.randn((1, nlead, m) + sp_shape)
-    t2 = env.randn((1, nlead) + sp_shape, 280.0)
+    ens = env.randn((1, nlead, m) + sp_shape, gen=gen5)
+    t2 = env.randn((1, nlead) + sp_shape, 280.0, gen=gen5)
     ens += t2[:, :, None]
-    t2 += env.randn((1, nlead) + sp_shape)
-    pool.append({'z_p': env.randn((1, nlead, nlev) + sp_shape, 280.0), 'z_t': env.randn((1, nlead, nlev) + sp_shape, 280.0),
-                 't2m_p': ens, 't2m_t': t2})
+    t2 += env.randn((1, nlead) + sp_shape, gen=gen5)
+    pool.append({'z_p': env.randn((1, nlead, nlev) + sp_shape, 280.0, gen=gen5),
+                 'z_t': env.randn((1, nlead, nlev) + sp_shape, 280.0, gen=gen5), 't2m_p': ens, 't2m_t': t2})
   ndoy = 12
-  clim = xr.Dataset({'z': xr.DataArray(env.randn((ndoy, 4, nlev) + sp_shape, 280.0, 10.0), dims=cdims, coords={
+  clim = xr.Dataset({'z': xr.DataArray(env.randn((ndoy, 4, nlev) + sp_shape, 280.0, 10.0, gen=gen5), dims=cdims, coords={
       'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), 'level': level,
       'latitude': env.lat, 'longitude': env.lon})})
   env.torch.cuda.synchronize()
