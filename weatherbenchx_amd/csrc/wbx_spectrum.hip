@@ -422,6 +422,45 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
   flush(cur);
 }
 
+#include "wbx_zspec1440.hpp"
+
+// Launches zspec1440_kernel: as many one-wave teams per block as the LDS holds (12: tables + 12 x 11.4 KB), one block per
+// CU, and -- every team takes the same time -- a grid of exactly `rounds` resident sets.
+static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t row_stride, int64_t nrows,
+                       const int32_t* group, const double* scale, double* power_out) {
+  void*& tab = st->twiddles[-Z14_N];
+  if (!tab) {
+    std::vector<float2> host;
+    zspec1440_tables(host);
+    WBX_HIP(hipMalloc(&tab, host.size() * sizeof(float2)));
+    WBX_HIP(hipMemcpyAsync(tab, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  static const int teams_env = getenv("WBX_SPECTRUM_1440_TEAMS") ? atoi(getenv("WBX_SPECTRUM_1440_TEAMS")) : 12;
+  const int nteam = teams_env < 1 ? 1 : (teams_env > 12 ? 12 : teams_env);
+  const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)nteam * Z14_BUF * sizeof(v4);
+  const void* fn = reinterpret_cast<const void*>(&zspec1440_kernel);
+  int& per_cu = st->occupancy[std::make_pair(fn, lds)];
+  if (per_cu == 0) {
+    if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * nteam, lds));
+    if (per_cu <= 0) per_cu = 1;
+  }
+  int rounds = 1;
+  if (const char* e = getenv("WBX_SPECTRUM_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : 1;
+  if (getenv("WBX_SPECTRUM_DEBUG")) fprintf(stderr, "zspec1440: teams/block=%d lds=%zu blocks/CU=%d\n", nteam, lds, per_cu);
+  int64_t teams = (int64_t)per_cu * ctx->num_cus * nteam * rounds;
+  if (teams > (nrows + 1) / 2) teams = (nrows + 1) / 2;
+  int rows_per_team = (int)((nrows + teams - 1) / teams);
+  rows_per_team += rows_per_team & 1;  // whole pairs
+  teams = (nrows + rows_per_team - 1) / rows_per_team;
+  const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
+  hipLaunchKernelGGL(zspec1440_kernel, dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows,
+                     rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 static bool fused_factor(int n, FusedSpec& fs) {
   if (n < 4 || (n & 1) || n > 2048) return false;
   int m = n / 2;
@@ -449,6 +488,9 @@ static bool fused_factor(int n, FusedSpec& fs) {
 static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const float* field, int64_t row_stride,
                         int64_t nrows, const int32_t* group, const double* scale, double* power_out) {
   const int nlon = fs.n, n2 = fs.n2;
+  static const bool use_1440 = getenv("WBX_SPECTRUM_1440") == nullptr || atoi(getenv("WBX_SPECTRUM_1440")) != 0;
+  if (nlon == Z14_N && use_1440 && !getenv("WBX_SPECTRUM_TEAM"))  // (WBX_SPECTRUM_TEAM pins the generic kernel's team size)
+    return launch_1440(ctx, st, field, row_stride, nrows, group, scale, power_out);
   void*& tw = st->twiddles[nlon];
   if (!tw) {
     std::vector<float2> host((size_t)n2 + n2 + 1);

@@ -1,0 +1,203 @@
+// Zonal spectrum of 1440-point rows (0.25 degree grids): ONE WAVE per row pair, 720 = 12 x 5 x 12.
+//
+// The generic fused kernel (zspec_fused_kernel) runs five Stockham passes (4, 4, 5, 3, 3) over a 256-thread team: five
+// LDS round trips, a block barrier between the read and the write half of every pass, 60-94 % of the lanes busy, and the
+// butterfly addresses / twiddle indices recomputed per pass (SQ counters of configs[3]: 1150 VALU + 630 SALU + 172 LDS
+// instructions per row pair, every unit ~45 % busy, 2500 cycles per pair and CU).  Here the length-720 complex transform
+// of the packed row (z[m] = x[2m] + i x[2m+1]) is split as
+//     m = 60 a + b          pass 1: lane b (60 of 64 lanes) takes z[60 a + b], a = 0..11, straight from global memory
+//                                   (consecutive lanes = consecutive points), a 12-point DFT in registers, then the
+//                                   twiddle W720^(b k1)
+//     b = 12 c + d          pass 2: butterfly (k1, d) -- 144 of them, 3 per lane on 48 lanes -- a 5-point DFT over c,
+//                                   then W60^(d q)
+//     k = k1 + 12 q + 60 s  pass 3: lane L = k1 + 12 q (60 lanes) a 12-point DFT over d: Z[L + 60 s], s = 0..11
+// so a row crosses the LDS three times (two transposes between the passes and one mirror exchange for the Hermitian
+// unpack) instead of five, the 12-point DFTs are prime-factor (3 x 4) butterflies without internal twiddles, every LDS
+// address and twiddle index of a lane is a loop-invariant register or an immediate offset, and there is no barrier: a
+// wave's LDS instructions execute in order.  As in the generic kernel two rows share every instruction (C2 = the same
+// point of rows A and B in one packed-fp32 register pair), the next pair's 24 loads are issued as soon as pass 1 has
+// consumed the current ones, and |X_k|^2 * scale is accumulated in fp64 registers (lane L owns k = L + 60 s) and flushed
+// with fp64 atomics when the row group changes.
+//
+// Included by wbx_spectrum.hip (inside namespace wbx, after C2 / butterfly<R>).
+#pragma once
+
+constexpr int Z14_N = 1440, Z14_N2 = 720, Z14_LANES = 60, Z14_LANES5 = 48;
+constexpr int Z14_S1 = 61;                 // row stride of the first transpose (odd: the strided side is the READ)
+constexpr int Z14_BUF = 12 * Z14_S1;       // v4 elements of LDS per wave (>= 720)
+constexpr int Z14_TW1 = 11 * 60, Z14_TW2 = 4 * 12, Z14_TWR = 720;  // float2 entries: W720^(b k1) | W60^(d q) | W1440^k
+constexpr int Z14_TABLES = Z14_TW1 + Z14_TW2 + Z14_TWR;
+
+// 12-point DFT, Good-Thomas: input n = (4 n1 + 3 n2) mod 12, output k = (4 k1 + 9 k2) mod 12; four 3-point and three
+// 4-point butterflies, no twiddles in between.
+__device__ __forceinline__ void dft12(C2 (&v)[12]) {
+  C2 t[3][4];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {
+    C2 u[3] = {v[(3 * n2) % 12], v[(4 + 3 * n2) % 12], v[(8 + 3 * n2) % 12]};
+    butterfly<3>(u);
+    t[0][n2] = u[0];
+    t[1][n2] = u[1];
+    t[2][n2] = u[2];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1) {
+    butterfly<4>(t[k1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) v[(4 * k1 + 9 * k2) % 12] = t[k1][k2];
+  }
+}
+
+// blockDim.x = 64 * (teams per block); dynamic LDS = Z14_TABLES * 8 + teams * Z14_BUF * 16 bytes.
+__global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
+                                                        int rows_per_team, const float2* __restrict__ tables_g,
+                                                        const int32_t* __restrict__ group,
+                                                        const double* __restrict__ scale, double* __restrict__ power) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
+  float2* const tw2 = tw1 + Z14_TW1;
+  float2* const twr = tw2 + Z14_TW2;
+  const int lane = (int)(threadIdx.x & 63);
+  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nteam = (int)(blockDim.x >> 6);
+  v4* const buf = reinterpret_cast<v4*>(twr + Z14_TWR) + team * Z14_BUF;
+  for (int i = threadIdx.x; i < Z14_TABLES; i += blockDim.x) tw1[i] = tables_g[i];
+  __syncthreads();
+  const int64_t w = (int64_t)blockIdx.x * nteam + team;
+  const int64_t r0 = w * rows_per_team;
+  const int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
+  if (r0 >= r1) return;  // only wave-level ordering below
+  constexpr int nk = Z14_N2 + 1;
+  // lanes 60..63 (passes 1, 3) and 48..63 (pass 2) shadow the last working lane: same addresses, same values, no branch
+  const int L = lane < Z14_LANES ? lane : Z14_LANES - 1;
+  const int l5 = lane < Z14_LANES5 ? lane : Z14_LANES5 - 1;
+  const int k1_5 = l5 % 12, d0_5 = l5 / 12;  // pass 2, butterfly i = 0..2: (k1, d) = (k1_5, d0_5 + 4 i)
+  const v4* const rd5 = buf + k1_5 * Z14_S1 + d0_5;  // + 4 i + 12 c
+  v4* const wr5 = buf + d0_5 * 60 + k1_5;            // + 240 i + 12 q
+  const float2* const tw5 = tw2 + d0_5;              // + 4 i + 12 (q - 1)
+  const int mir0 = L == 0 ? 0 : Z14_N2 - L;          // mirror of k = L + 60 s is mir0 - 60 s (s = 0: 0 for L = 0)
+  const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
+
+  double acc[12], acc_ny = 0.0;  // k = L + 60 s; lane 0 also owns the Nyquist wavenumber k = 720
+#pragma unroll
+  for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+  int32_t cur = group[r0];
+  auto flush = [&](int32_t next) {
+    if (lane < Z14_LANES) {
+      double* const out = power + (int64_t)cur * nk + L;
+#pragma unroll
+      for (int s = 0; s < 12; ++s) unsafeAtomicAdd(out + 60 * s, (s == 0 && L == 0) ? acc[s] : 2.0 * acc[s]);
+      if (L == 0) unsafeAtomicAdd(out + Z14_N2, 2.0 * acc_ny);  // S_k = |F_k|^2 * (k == 0 ? 1 : 2), include/wbx.h
+    }
+#pragma unroll
+    for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+    acc_ny = 0.0;
+    cur = next;
+  };
+
+  v2 pa[12], pb[12];  // the pair's pass-1 inputs, fetched one pair ahead
+  auto fetch = [&](int64_t r) {
+    const bool two = r + 1 < r1;
+    const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride) + L;
+    const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride) + L;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      pa[a] = __builtin_nontemporal_load(rowa + 60 * a);
+      pb[a] = __builtin_nontemporal_load(rowb + 60 * a);
+    }
+  };
+  fetch(r0);
+  for (int64_t r = r0; r < r1; r += 2) {
+    const bool two = r + 1 < r1;  // a missing second row is a row of zeros with scale 0
+    const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
+    const double sca = scale[r] * quarter_inv_nn, scb = two ? scale[r + 1] * quarter_inv_nn : 0.0;
+    C2 v[12];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) v[a] = {{pa[a].x, two ? pb[a].x : 0.f}, {pa[a].y, two ? pb[a].y : 0.f}};
+    if (r + 2 < r1) fetch(r + 2);
+
+    // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
+    dft12(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
+#pragma unroll
+    for (int k1 = 0; k1 < 12; ++k1) st_c2(buf + k1 * Z14_S1 + L, v[k1]);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass 2: 5-point DFT over c, twiddle W60^(d q), transpose 2: buf[d * 60 + k1 + 12 q]
+    C2 u[3][5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) u[i][c] = ld_c2(rd5 + 4 * i + 12 * c);
+    }
+    __builtin_amdgcn_wave_barrier();  // every read of the first layout precedes the writes of the second
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      butterfly<5>(u[i]);
+#pragma unroll
+      for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], tw5[4 * i + 12 * (q - 1)]);
+#pragma unroll
+      for (int q = 0; q < 5; ++q) st_c2(wr5 + 240 * i + 12 * q, u[i][q]);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass 3: 12-point DFT over d: v[s] = Z[L + 60 s]
+#pragma unroll
+    for (int d = 0; d < 12; ++d) v[d] = ld_c2(buf + d * 60 + L);
+    __builtin_amdgcn_wave_barrier();
+    dft12(v);
+
+    // ---- mirror exchange: Z[k] goes to buf[k], the partner Z[720 - k] comes back
+#pragma unroll
+    for (int s = 0; s < 12; ++s) st_c2(buf + L + 60 * s, v[s]);
+    __builtin_amdgcn_wave_barrier();
+    if (ga != cur) flush(ga);       // wave-uniform
+    const bool split = gb != ga;    // the pair straddles a group boundary (rare): row B goes out through its own atomics
+    // Hermitian unpack: X_k = E_k + W^k O_k, W = exp(-2 pi i / 1440), 2 E_k = Z_k + conj Z_{720-k},
+    // 2 O_k = -i (Z_k - conj Z_{720-k});  X_720 = conj(E_0 - O_0).  |X|^2 in packed fp32 (as the transform), fp64 sums.
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+      const C2 zk = v[s];
+      const C2 zc = ld_c2(s == 0 ? buf + mir0 : buf + (Z14_N2 - 60 * s) - L);
+      const C2 e = {zk.re + zc.re, zk.im - zc.im};
+      const C2 o = {zk.im + zc.im, zc.re - zk.re};
+      const C2 wo = ctw(o, twr[L + 60 * s]);
+      const C2 x = cadd(e, wo);
+      const v2 p = x.re * x.re + x.im * x.im;  // (row A, row B)
+      if (split) {
+        acc[s] = fma((double)p.x, sca, acc[s]);
+        if (lane < Z14_LANES)
+          unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
+      } else {
+        acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+      }
+      if (s == 0) {
+        const C2 xm = csub(e, wo);
+        const v2 pm = xm.re * xm.re + xm.im * xm.im;
+        if (split) {
+          acc_ny = fma((double)pm.x, sca, acc_ny);
+          if (lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
+        } else {
+          acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair
+  }
+  flush(cur);
+}
+
+// host side: W720^(b k1) at (k1 - 1) * 60 + b | W60^(d q) at (q - 1) * 12 + d | W1440^k, k < 720
+static void zspec1440_tables(std::vector<float2>& host) {
+  host.resize(Z14_TABLES);
+  auto unit = [](double num, double den) {
+    const double a = -2.0 * M_PI * num / den;
+    return make_float2((float)cos(a), (float)sin(a));
+  };
+  for (int k1 = 1; k1 < 12; ++k1)
+    for (int b = 0; b < 60; ++b) host[(k1 - 1) * 60 + b] = unit((double)((b * k1) % 720), 720.0);
+  for (int q = 1; q < 5; ++q)
+    for (int d = 0; d < 12; ++d) host[Z14_TW1 + (q - 1) * 12 + d] = unit((double)((d * q) % 60), 60.0);
+  for (int k = 0; k < Z14_TWR; ++k) host[Z14_TW1 + Z14_TW2 + k] = unit((double)k, 1440.0);
+}
