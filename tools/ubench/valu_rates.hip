@@ -8,8 +8,10 @@
 
 template <int OP>
 __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
-  float a[8]; double d[8];
-  for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; }
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  float a[8]; double d[8]; v2 p[8];
+  for (int i = 0; i < 8; ++i) { a[i] = seed + threadIdx.x * 1e-3f + i; d[i] = a[i]; p[i] = (v2){a[i], a[i] + 0.5f}; }
+  const v2 c1 = {1.0001f, 0.9999f}, c2 = {0.5f, 0.25f};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -21,9 +23,13 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, float seed) {
       if (OP == 5) d[i] = d[i] + (double)a[i];                  // v_cvt_f64_f32 + v_add_f64
       if (OP == 6) d[i] = d[i] * 1.0001;                        // v_mul_f64
       if (OP == 7) d[i] = d[i] + fabs(d[(i + 1) & 7]);          // v_add_f64 with |.| modifier
+      if (OP == 8) p[i] = __builtin_elementwise_fma(p[i], c1, c2);  // v_pk_fma_f32
+      if (OP == 9) p[i] = p[i] + c1;                            // v_pk_add_f32
+      if (OP == 10) p[i] = p[i] * c1;                           // v_pk_mul_f32
+      if (OP == 11) { a[i] = fmaf(a[i], 1.0001f, 0.5f); d[i] = fma(d[i], 1.0001, 0.5); }  // f32 + f64 interleaved
     }
   }
-  float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + (float)d[i];
+  float s = 0; for (int i = 0; i < 8; ++i) s += a[i] + (float)d[i] + p[i].x + p[i].y;
   if (s == 12345.678f) out[0] = s;
 }
 
@@ -49,5 +55,7 @@ int main() {
   run<0>("v_add_f32", 1, out); run<1>("v_fma_f32", 1, out); run<2>("v_add_f32+v_min_f32", 2, out);
   run<3>("v_add_f64", 1, out); run<4>("v_fma_f64", 1, out); run<5>("v_cvt_f64_f32+v_add_f64", 2, out);
   run<6>("v_mul_f64", 1, out); run<7>("v_add_f64 |src|", 1, out);
+  run<8>("v_pk_fma_f32", 1, out); run<9>("v_pk_add_f32", 1, out); run<10>("v_pk_mul_f32", 1, out);
+  run<11>("v_fma_f32+v_fma_f64", 2, out);
   return 0;
 }

@@ -439,7 +439,9 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   static const int teams_env = getenv("WBX_SPECTRUM_1440_TEAMS") ? atoi(getenv("WBX_SPECTRUM_1440_TEAMS")) : 12;
   const int nteam = teams_env < 1 ? 1 : (teams_env > 12 ? 12 : teams_env);
   const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)nteam * Z14_BUF * sizeof(v4);
-  const void* fn = reinterpret_cast<const void*>(&zspec1440_kernel);
+  // WBX_SPECTRUM_PROF=<file>: the phase-stamped instantiation; the eight counters are appended to the file per launch
+  static const char* prof_path = getenv("WBX_SPECTRUM_PROF");
+  const void* fn = prof_path ? reinterpret_cast<const void*>(&zspec1440_kernel<true, 0>) : reinterpret_cast<const void*>(&zspec1440_kernel<false, 0>);
   int& per_cu = st->occupancy[std::make_pair(fn, lds)];
   if (per_cu == 0) {
     if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -455,8 +457,45 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   rows_per_team += rows_per_team & 1;  // whole pairs
   teams = (nrows + rows_per_team - 1) / rows_per_team;
   const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
-  hipLaunchKernelGGL(zspec1440_kernel, dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows,
-                     rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out);
+  if (prof_path) {
+    static unsigned long long* prof = nullptr;  // (diagnostic path: one device, never freed)
+    unsigned long long host[26];
+    if (!prof) WBX_HIP(hipMalloc(reinterpret_cast<void**>(&prof), sizeof(host)));
+    const bool timing_only = prof_path[0] == '-';  // "-": the stamped kernel back to back, no read-back (event timing)
+    if (!timing_only) {
+      for (int i = 0; i < 26; ++i) host[i] = i == 11 ? ~0ull : 0ull;
+      WBX_HIP(hipMemcpyAsync(prof, host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
+      WBX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    hipLaunchKernelGGL((zspec1440_kernel<true, 0>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows,
+                       rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+    WBX_HIP(hipGetLastError());
+    if (timing_only) return 0;
+    WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+    if (FILE* f = fopen(prof_path, "a")) {
+      for (int i = 0; i < 26; ++i) fprintf(f, "%llu%c", host[i], i == 25 ? '\n' : ' ');
+      fclose(f);
+    }
+    return 0;
+  }
+  static const int knock = getenv("WBX_SPECTRUM_KNOCK") ? atoi(getenv("WBX_SPECTRUM_KNOCK")) : 0;  // diagnostic, wrong results
+#define WBX_Z14_LAUNCH(KN)                                                                                                 \
+  hipLaunchKernelGGL((zspec1440_kernel<false, KN>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, \
+                     rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out,                         \
+                     static_cast<unsigned long long*>(nullptr))
+  switch (knock) {
+    case 1: WBX_Z14_LAUNCH(1); break;
+    case 2: WBX_Z14_LAUNCH(2); break;
+    case 6: WBX_Z14_LAUNCH(6); break;
+    case 7: WBX_Z14_LAUNCH(7); break;
+    case 8: WBX_Z14_LAUNCH(8); break;
+    case 14: WBX_Z14_LAUNCH(14); break;
+    case 15: WBX_Z14_LAUNCH(15); break;
+    case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
+    default: WBX_Z14_LAUNCH(0); break;
+  }
+#undef WBX_Z14_LAUNCH
   WBX_HIP(hipGetLastError());
   return 0;
 }

@@ -48,12 +48,29 @@ __device__ __forceinline__ void dft12(C2 (&v)[12]) {
   }
 }
 
+// (KNOCK & 2: the value is computed -- pinned by an empty asm -- but not stored)
+template <bool DROP>
+__device__ __forceinline__ void z14_store(v4* p, C2 a) {
+  if constexpr (DROP)
+    asm volatile("" ::"v"(a.re.x), "v"(a.re.y), "v"(a.im.x), "v"(a.im.y));
+  else
+    st_c2(p, a);
+}
+
 // blockDim.x = 64 * (teams per block); dynamic LDS = Z14_TABLES * 8 + teams * Z14_BUF * 16 bytes.
+// PROF (tools/spec_phase_profile.py): wave 0 of every block adds the cycles it spent in each phase of a pair to prof[0..7], in its prologue to prof[8] and in its closing flush to prof[9]
+// (s_memtime stamps; the stamps after a transpose first wait for the LDS, which the production kernel does not).
+// KNOCK (diagnostic, wrong results; tools/kbench_spectrum_raw.py): 1 = every pair re-reads the team's first rows (L2 hits,
+// no HBM stream), 2 = the LDS stores of the three exchanges are dropped, 4 = their loads too, 8 = no unpack arithmetic.
+template <bool PROF, int KNOCK, bool ROTATE = true>
 __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
                                                         int rows_per_team, const float2* __restrict__ tables_g,
                                                         const int32_t* __restrict__ group,
-                                                        const double* __restrict__ scale, double* __restrict__ power) {
+                                                        const double* __restrict__ scale, double* __restrict__ power,
+                                                        unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const unsigned long long t_start = PROF ? __builtin_readcyclecounter() : 0ull;
+  const unsigned long long w_start = PROF ? wall_clock64() : 0ull;  // 100 MHz
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
   float2* const tw2 = tw1 + Z14_TW1;
   float2* const twr = tw2 + Z14_TW2;
@@ -98,8 +115,9 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   v2 pa[12], pb[12];  // the pair's pass-1 inputs, fetched one pair ahead
   auto fetch = [&](int64_t r) {
     const bool two = r + 1 < r1;
-    const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride) + L;
-    const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride) + L;
+    const int64_t ra = (KNOCK & 1) ? r0 : r;
+    const v2* rowa = reinterpret_cast<const v2*>(field + ra * row_stride) + L;
+    const v2* rowb = reinterpret_cast<const v2*>(field + (two ? ra + 1 : ra) * row_stride) + L;
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
       pa[a] = __builtin_nontemporal_load(rowa + 60 * a);
@@ -107,13 +125,37 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     }
   };
   fetch(r0);
+  unsigned long long stamp[8], spent[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (PROF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    spent[8] = __builtin_readcyclecounter() - t_start;  // tables, first rows
+  }
+  auto mark = [&](int i, bool drain) {
+    if constexpr (PROF) {
+      if (drain) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp[i] = __builtin_readcyclecounter();
+    }
+  };
+  // The instruction arbiter serves the oldest wave of a SIMD first: with equal shares of rows the three waves of a SIMD
+  // finished after 175 / 226 / 275 us (configs[3]) and the SIMD ran its last 100 us under-occupied.  Rotating the user
+  // priority pair by pair gives every wave the same share of the issue slots.
+  int turn = team >> 2;  // waves t, t + 4, t + 8 of a block share a SIMD
   for (int64_t r = r0; r < r1; r += 2) {
+    if constexpr (ROTATE) {
+      turn = turn == 2 ? 0 : turn + 1;
+      if (turn == 0) __builtin_amdgcn_s_setprio(0);
+      else if (turn == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(2);
+    }
+    mark(0, false);
     const bool two = r + 1 < r1;  // a missing second row is a row of zeros with scale 0
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const double sca = scale[r] * quarter_inv_nn, scb = two ? scale[r + 1] * quarter_inv_nn : 0.0;
     C2 v[12];
 #pragma unroll
     for (int a = 0; a < 12; ++a) v[a] = {{pa[a].x, two ? pb[a].x : 0.f}, {pa[a].y, two ? pb[a].y : 0.f}};
+    if constexpr (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mark(1, false);  // 0 -> 1: scalar bookkeeping + the wait for the prefetched rows
     if (r + 2 < r1) fetch(r + 2);
 
     // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
@@ -121,37 +163,45 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 #pragma unroll
     for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
 #pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1) st_c2(buf + k1 * Z14_S1 + L, v[k1]);
+    for (int k1 = 0; k1 < 12; ++k1)
+      z14_store<(KNOCK & 2) != 0>(buf + k1 * Z14_S1 + L, v[k1]);
     __builtin_amdgcn_wave_barrier();
+    mark(2, false);  // 1 -> 2: pass 1 (prefetch issue, DFT 12, twiddles from the LDS, 12 stores issued)
 
     // ---- pass 2: 5-point DFT over c, twiddle W60^(d q), transpose 2: buf[d * 60 + k1 + 12 q]
     C2 u[3][5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
-      for (int c = 0; c < 5; ++c) u[i][c] = ld_c2(rd5 + 4 * i + 12 * c);
+      for (int c = 0; c < 5; ++c) u[i][c] = (KNOCK & 4) ? v[(5 * i + c) % 12] : ld_c2(rd5 + 4 * i + 12 * c);
     }
     __builtin_amdgcn_wave_barrier();  // every read of the first layout precedes the writes of the second
+    mark(3, true);  // 2 -> 3: transpose 1 round trip (stores drain, 15 loads return)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       butterfly<5>(u[i]);
 #pragma unroll
       for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], tw5[4 * i + 12 * (q - 1)]);
 #pragma unroll
-      for (int q = 0; q < 5; ++q) st_c2(wr5 + 240 * i + 12 * q, u[i][q]);
+      for (int q = 0; q < 5; ++q)
+        z14_store<(KNOCK & 2) != 0>(wr5 + 240 * i + 12 * q, u[i][q]);
     }
     __builtin_amdgcn_wave_barrier();
+    mark(4, false);  // 3 -> 4: pass 2
 
     // ---- pass 3: 12-point DFT over d: v[s] = Z[L + 60 s]
 #pragma unroll
-    for (int d = 0; d < 12; ++d) v[d] = ld_c2(buf + d * 60 + L);
+    for (int d = 0; d < 12; ++d) v[d] = (KNOCK & 4) ? u[d % 3][d % 5] : ld_c2(buf + d * 60 + L);
     __builtin_amdgcn_wave_barrier();
+    mark(5, true);  // 4 -> 5: transpose 2 round trip
     dft12(v);
 
     // ---- mirror exchange: Z[k] goes to buf[k], the partner Z[720 - k] comes back
 #pragma unroll
-    for (int s = 0; s < 12; ++s) st_c2(buf + L + 60 * s, v[s]);
+    for (int s = 0; s < 12; ++s)
+      z14_store<(KNOCK & 2) != 0>(buf + L + 60 * s, v[s]);
     __builtin_amdgcn_wave_barrier();
+    mark(6, false);  // 5 -> 6: pass 3
     if (ga != cur) flush(ga);       // wave-uniform
     const bool split = gb != ga;    // the pair straddles a group boundary (rare): row B goes out through its own atomics
     // Hermitian unpack: X_k = E_k + W^k O_k, W = exp(-2 pi i / 1440), 2 E_k = Z_k + conj Z_{720-k},
@@ -159,18 +209,19 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 #pragma unroll
     for (int s = 0; s < 12; ++s) {
       const C2 zk = v[s];
-      const C2 zc = ld_c2(s == 0 ? buf + mir0 : buf + (Z14_N2 - 60 * s) - L);
+      const C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + mir0 : buf + (Z14_N2 - 60 * s) - L);
       const C2 e = {zk.re + zc.re, zk.im - zc.im};
       const C2 o = {zk.im + zc.im, zc.re - zk.re};
-      const C2 wo = ctw(o, twr[L + 60 * s]);
+      const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[L + 60 * s]);
       const C2 x = cadd(e, wo);
-      const v2 p = x.re * x.re + x.im * x.im;  // (row A, row B)
+      const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;  // (row A, row B)
       if (split) {
         acc[s] = fma((double)p.x, sca, acc[s]);
         if (lane < Z14_LANES)
           unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
       } else {
-        acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+        if constexpr (KNOCK & 8) acc[s] += (double)(p.x + p.y);
+        else acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
       }
       if (s == 0) {
         const C2 xm = csub(e, wo);
@@ -184,8 +235,29 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
       }
     }
     __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair
+    mark(7, true);  // 6 -> 7: mirror exchange + unpack + fp64 sums
+    if constexpr (PROF) {
+#pragma unroll
+      for (int i = 1; i < 8; ++i) spent[i] += stamp[i] - stamp[i - 1];
+      spent[0] += 1;
+    }
   }
+  const unsigned long long t_flush = PROF ? __builtin_readcyclecounter() : 0ull;
   flush(cur);
+  if constexpr (PROF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    spent[9] = __builtin_readcyclecounter() - t_flush;  // the closing atomics
+    if (team == 0 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 10; ++i) atomicAdd(prof + i, spent[i]);
+      const unsigned long long w_end = wall_clock64();
+      atomicAdd(prof + 10, w_end - w_start);  // lifetime of the wave
+      atomicMin(prof + 11, w_start);
+      atomicMax(prof + 12, w_end);
+      atomicMax(prof + 13, w_start);  // the last block to start
+    }
+    if (lane == 0) atomicAdd(prof + 14 + team, wall_clock64() - w_start);  // lifetime by team (= launch order on its SIMD)
+  }
 }
 
 // host side: W720^(b k1) at (k1 - 1) * 60 + b | W60^(d q) at (q - 1) * 12 + d | W1440^k, k < 720
