@@ -146,3 +146,44 @@ def test_row_lengths_exercise_every_first_pass_radix_and_table_layout(backend, n
   want = O.zonal_power_spectrum(vals)
   assert got.shape == (5, nlon // 2 + 1)
   np.testing.assert_allclose(got, want, rtol=2e-4, atol=1e-6 * want.max())
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('nlat,mean', [(7, 0.0), (10, 0.0), (7, 280.0), (50, 280.0)])
+def test_1440_point_rows_one_wave_kernel(backend, layout, nlat, mean):
+  """0.25 degree rows (csrc/wbx_zspec1440.hpp: one wave per row pair, 720 = 12 x 5 x 12; latitude-fastest fields through
+  the block-staged variant, 24 adjacent rows per step): groups of 7 rows (every other pair straddles a group boundary, the
+  lone last row), of 10, and of 50 (three runs of rows per slab, the last team of a run with a lone row) against the
+  float64 numpy.fft oracle.  The fp32 transform's error is relative to the largest coefficient of the row, |dF_k| <~ eps
+  (|F_k| + |F|_max): S_k is held to 2e-5 S_k + 4e-7 sqrt(S_max S_k), for white noise and for a mean of 280 (a steep spectrum,
+  S_0 = 78400 against 1e-3 per wave)."""
+  rng = np.random.default_rng(nlat)
+  nlon = 1440
+  lat, lon = np.linspace(-80, 80, nlat), np.arange(nlon) * 0.25
+  dims = ('lead_time', 'level', 'latitude', 'longitude') if layout == 'lon_fastest' else \
+      ('lead_time', 'level', 'longitude', 'latitude')
+  shape = {'lead_time': 3, 'level': 3, 'latitude': nlat, 'longitude': nlon}
+  vals = (rng.normal(size=[shape[d] for d in dims]) + mean).astype(np.float32)
+  f = _field(vals, dims, lat=lat, lon=lon)
+  metrics = {'spec': spectra.ZonalPowerSpectrum()}
+  agg = aggregation.Aggregator(reduce_dims=['lead_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  res = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': f}, {'v': f})).metric_values(metrics)
+  lon_ax = dims.index('longitude')
+  per_row = np.moveaxis(O.zonal_power_spectrum(vals, lon_axis=lon_ax), lon_ax, -1)
+  rd = tuple(d for d in dims if d != 'longitude')
+  wv = O.expand_to(O.grid_area_weights(lat), ('latitude',), rd)[..., None]
+  red = tuple(rd.index(d) for d in ('lead_time', 'latitude'))
+  want = (per_row * wv).sum(axis=red) / (wv * np.ones_like(per_row)).sum(axis=red)
+  got = res['spec.v'].transpose('level', 'zonal_wavenumber').values
+
+  def check(g, w):
+    # |dF_k| <~ eps (|F_k| + |F|_max): dS_k <= 2e-5 S_k + 4e-7 sqrt(S_max S_k)
+    bound = 2e-5 * w + 4e-7 * np.sqrt(w.max(axis=-1, keepdims=True) * w)
+    worst = float(np.max(np.abs(g - w) / bound))
+    assert worst <= 1.0, worst
+    if mean != 0.0:
+      np.testing.assert_allclose(g[..., 0], w[..., 0], rtol=1e-6)
+  check(got, want)
+  # per-row spectra (no reduction): rows as their own groups
+  stat = spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v'].transpose(*rd, 'zonal_wavenumber')
+  check(np.asarray(stat.values), per_row)

@@ -9,6 +9,7 @@ import torch
 from weatherbenchx_amd import _hip
 
 nt, nlev, nlat, nlon = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), 37, 721, 1440
+layout = sys.argv[2] if len(sys.argv) > 2 else 'lon_fastest'
 ctx = _hip.default_context(0)
 lib = ctx.lib
 nrows = nt * nlev * nlat
@@ -20,7 +21,15 @@ power = torch.zeros((nlev, nlon // 2 + 1), device='cuda', dtype=torch.float64)
 torch.cuda.synchronize()
 
 
+import ctypes
+slab_off = (np.arange(nt * nlev, dtype=np.int64) * nlat * nlon)
+
+
 def launch(f):
+  if layout == 'lat_fastest':  # [slab][lon][lat]: rows adjacent, longitude strided by nlat
+    _hip.check(lib.wbx_zonal_spectrum_slabs(ctx.handle, f.data_ptr(), nlat, 1, nlat, nt * nlev, slab_off.ctypes.data_as(ctypes.c_void_p),
+                                            nlon, group.data_ptr(), scale.data_ptr(), nlev, 0, power.data_ptr()), 'spectrum')
+    return
   _hip.check(lib.wbx_zonal_spectrum(ctx.handle, f.data_ptr(), 1, nlon, nrows, nlon, group.data_ptr(), scale.data_ptr(), nlev, 0,
                                     power.data_ptr()), 'spectrum')
 

@@ -500,6 +500,73 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   return 0;
 }
 
+// Launches zspec1440_latfast_kernel over nslab slabs of rps adjacent rows (row_stride 1, longitude strided).
+static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, int64_t lon_stride, const int64_t* d_slab_off,
+                               int64_t rps, int64_t nslab, const int32_t* group, const double* scale, double* power_out) {
+  void*& tab = st->twiddles[-Z14_N];
+  if (!tab) {
+    std::vector<float2> host;
+    zspec1440_tables(host);
+    WBX_HIP(hipMalloc(&tab, host.size() * sizeof(float2)));
+    WBX_HIP(hipMemcpyAsync(tab, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)Z14_TEAMS * Z14_BUFL * sizeof(v4) + (size_t)(Z14_N2 + 2) * sizeof(double);
+  static const char* prof_path = getenv("WBX_SPECTRUM_PROF");
+  const void* fn = prof_path ? reinterpret_cast<const void*>(&zspec1440_latfast_kernel<true, 0>) : reinterpret_cast<const void*>(&zspec1440_latfast_kernel<false, 0>);
+  int& per_cu = st->occupancy[std::make_pair(fn, lds)];
+  if (per_cu == 0) {
+    WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * Z14_TEAMS, lds));
+    if (per_cu <= 0) per_cu = 1;
+  }
+  int nlocal = per_cu * ctx->num_cus / 8;  // blocks per XCD
+  if (nlocal < 1) nlocal = 1;
+  // runs per slab: <= 24 rows each; a whole number of XCD sets when that does not shred the runs (721 rows: 31 -> 32)
+  int64_t runs = (rps + Z14_RUN - 1) / Z14_RUN;
+  const int64_t rounded = (runs + nlocal - 1) / nlocal * nlocal;
+  if (rps / rounded >= Z14_RUN / 2) runs = rounded;
+  const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
+  if (per_xcd < nlocal) nlocal = (int)per_xcd;
+  if (prof_path) {
+    static unsigned long long* prof = nullptr;  // (diagnostic path, see launch_1440)
+    unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!prof) WBX_HIP(hipMalloc(reinterpret_cast<void**>(&prof), sizeof(host)));
+    WBX_HIP(hipMemcpyAsync(prof, host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+    if (getenv("WBX_SPECTRUM_KNOCK") && atoi(getenv("WBX_SPECTRUM_KNOCK")) == 3)
+      hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 3>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
+                         lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+    else
+      hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
+                         lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+    WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+    if (FILE* f = fopen(prof_path, "a")) {
+      fprintf(f, "latfast");
+      for (int i = 0; i < 6; ++i) fprintf(f, " %llu", host[i]);
+      fprintf(f, "\n");
+      fclose(f);
+    }
+    return 0;
+  }
+  static const int knock = getenv("WBX_SPECTRUM_KNOCK") ? atoi(getenv("WBX_SPECTRUM_KNOCK")) : 0;  // diagnostic, wrong results
+#define WBX_Z14LF_LAUNCH(KN)                                                                                               \
+  hipLaunchKernelGGL((zspec1440_latfast_kernel<false, KN>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,  \
+                     lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),                    \
+                     reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr))
+  if (knock == 1) WBX_Z14LF_LAUNCH(1);
+  else if (knock == 2) WBX_Z14LF_LAUNCH(2);
+  else if (knock == 3) WBX_Z14LF_LAUNCH(3);
+
+  else WBX_Z14LF_LAUNCH(0);
+#undef WBX_Z14LF_LAUNCH
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 static bool fused_factor(int n, FusedSpec& fs) {
   if (n < 4 || (n & 1) || n > 2048) return false;
   int m = n / 2;
@@ -728,18 +795,6 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
     tile -= tile & 1;
     if (tile < 2) tile = 2;
     if (tile > nrows) tile = nrows;
-    const size_t need = (size_t)tile * nlon * sizeof(float);
-    if (st->scratch_size < need) {
-      if (st->scratch) {
-        WBX_HIP(hipStreamSynchronize(ctx->stream));
-        WBX_HIP(hipFree(st->scratch));
-        st->scratch = nullptr;
-        st->scratch_size = 0;
-      }
-      WBX_HIP(hipMalloc(&st->scratch, need));
-      st->scratch_size = need;
-    }
-    float* rows = reinterpret_cast<float*>(st->scratch);
     int64_t* d_off = nullptr;
     if (nslab > 1 || (h_slab_offsets && h_slab_offsets[0] != 0)) {
       // the slab offsets of a chunk layout repeat from chunk to chunk: kept on the device per content, so that the steady
@@ -760,6 +815,22 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
       }
       d_off = reinterpret_cast<int64_t*>(it->second);
     }
+    static const bool use_latfast = (getenv("WBX_SPECTRUM_1440") == nullptr || atoi(getenv("WBX_SPECTRUM_1440")) != 0) &&
+                                    (getenv("WBX_SPECTRUM_LATFAST") == nullptr || atoi(getenv("WBX_SPECTRUM_LATFAST")) != 0);
+    if (nlon == Z14_N && use_latfast && !getenv("WBX_SPECTRUM_TEAM"))
+      return launch_1440_latfast(ctx, st, field, lon_stride, d_off, rps, nslab, group, scale, power_out);
+    const size_t need = (size_t)tile * nlon * sizeof(float);
+    if (st->scratch_size < need) {
+      if (st->scratch) {
+        WBX_HIP(hipStreamSynchronize(ctx->stream));
+        WBX_HIP(hipFree(st->scratch));
+        st->scratch = nullptr;
+        st->scratch_size = 0;
+      }
+      WBX_HIP(hipMalloc(&st->scratch, need));
+      st->scratch_size = need;
+    }
+    float* rows = reinterpret_cast<float*>(st->scratch);
     for (int64_t r0 = 0; r0 < nrows; r0 += tile) {
       const int64_t n = r0 + tile <= nrows ? tile : nrows - r0;
       dim3 grid((unsigned)((nlon + 63) / 64), (unsigned)((n + 63) / 64));

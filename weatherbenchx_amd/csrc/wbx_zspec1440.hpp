@@ -260,6 +260,306 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Latitude-fastest fields (the public ERA5 / WeatherBench layout [.., longitude, latitude]): element (lon j, row r) of a
+// slab sits at slab + j * lon_stride + r, so the two rows of a pair are ADJACENT floats and one 8-byte load delivers
+// (A[j], B[j]) -- exactly one half (re or im, rows A and B) of the packed point m = j / 2.  A block takes a run of <= 24
+// adjacent rows of one slab = one row pair per team: its 768 threads read the 1440 x (<= 96 byte) segments with
+// consecutive threads on consecutive pairs of a longitude, one step ahead into registers, and store them into the
+// teams' LDS buffers (element j of team t's buffer = the 8 bytes of longitude j: already the pass-1 layout); the teams
+// then run the same three passes with pass 1 reading the LDS instead of global memory.  One pass over the field, no
+// transposed scratch (the generic route: transpose_rows_kernel + fused kernel = three passes).
+// The 96-byte segments do not line up with the 128-byte lines, so a line is shared with the neighbouring runs of rows:
+// the runs of one slab are spread over the blocks of ONE XCD in the same step (blockIdx & 7 = XCD, slab o -> XCD o mod 8),
+// which all move at the same pace, so the line's other users find it in that XCD's L2.
+struct Z14Lane {
+  int lane, L;
+  const v4* rd5;
+  v4* wr5;
+  const float2* tw5;
+  int mir0;
+};
+
+// passes 1-3 on v (pass-1 inputs), the mirror exchange and the Hermitian unpack; adds scale * |X_k|^2 into acc / acc_ny
+// (row B straight into `power` when the pair straddles two groups)
+// `between(i)`, i = 0..3, runs after pass 1 / pass 2 / pass 3 / the unpack have issued their work (the latitude-fastest
+// kernel spreads the next run's global loads over them)
+template <typename Between>
+__device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* __restrict__ buf, const Z14Lane& c, const float2* __restrict__ tw1,
+                                         const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
+                                         double (&acc)[12], double& acc_ny, double* __restrict__ power, Between&& between) {
+  constexpr int nk = Z14_N2 + 1;
+  const int L = c.L;
+  dft12(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
+#pragma unroll
+  for (int k1 = 0; k1 < 12; ++k1) st_c2(buf + k1 * Z14_S1 + L, v[k1]);
+  __builtin_amdgcn_wave_barrier();
+  between(0);
+  C2 u[3][5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) u[i][cc] = ld_c2(c.rd5 + 4 * i + 12 * cc);
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    butterfly<5>(u[i]);
+#pragma unroll
+    for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], c.tw5[4 * i + 12 * (q - 1)]);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) st_c2(c.wr5 + 240 * i + 12 * q, u[i][q]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  between(1);
+#pragma unroll
+  for (int d = 0; d < 12; ++d) v[d] = ld_c2(buf + d * 60 + L);
+  __builtin_amdgcn_wave_barrier();
+  dft12(v);
+#pragma unroll
+  for (int s = 0; s < 12; ++s) st_c2(buf + L + 60 * s, v[s]);
+  __builtin_amdgcn_wave_barrier();
+  between(2);
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const C2 zk = v[s];
+    const C2 zc = ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+    const C2 e = {zk.re + zc.re, zk.im - zc.im};
+    const C2 o = {zk.im + zc.im, zc.re - zk.re};
+    const C2 wo = ctw(o, twr[L + 60 * s]);
+    const C2 x = cadd(e, wo);
+    const v2 p = x.re * x.re + x.im * x.im;  // (row A, row B)
+    if (split) {
+      acc[s] = fma((double)p.x, sca, acc[s]);
+      if (c.lane < Z14_LANES)
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
+    } else {
+      acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+    }
+    if (s == 0) {
+      const C2 xm = csub(e, wo);
+      const v2 pm = xm.re * xm.re + xm.im * xm.im;
+      if (split) {
+        acc_ny = fma((double)pm.x, sca, acc_ny);
+        if (c.lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
+      } else {
+        acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  between(3);
+}
+
+constexpr int Z14_TEAMS = 12;                 // teams (row pairs) of a latitude-fastest block
+constexpr int Z14_RUN = 2 * Z14_TEAMS;        // rows of a run
+constexpr int Z14_BUFL = 733;                 // v4 elements between the team buffers (odd: the staging stores of one
+                                              // longitude go to 12 buffers at once)
+constexpr int Z14_STAGE = (Z14_N * Z14_TEAMS + 64 * Z14_TEAMS - 1) / (64 * Z14_TEAMS);  // 8-byte items per thread: 23
+
+typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
+
+// grid = 8 * (blocks per XCD); runs_per_slab >= ceil(rps / 24) and rps = run_base * runs_per_slab + run_rem; row i of slab o is
+// row o * rps + i of group / scale
+// PROF: wave 0 of every block adds its cycles per step to prof[1..6] (wait at the first barrier | staging stores + second
+// barrier | issue of the next run's loads | pass-1 loads from the LDS | the three passes and the unpack), steps to prof[0].
+// KNOCK (diagnostic, wrong results): 1 = no global loads, 2 = no passes (the staged data is only summed)
+template <bool PROF, int KNOCK = 0>
+__global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
+    const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
+    int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g, const int32_t* __restrict__ group,
+    const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
+  float2* const tw2 = tw1 + Z14_TW1;
+  float2* const twr = tw2 + Z14_TW2;
+  v4* const bufs = reinterpret_cast<v4*>(twr + Z14_TWR);
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 6);
+  v4* const buf = bufs + team * Z14_BUFL;
+  for (int i = tid; i < Z14_TABLES; i += 64 * Z14_TEAMS) tw1[i] = tables_g[i];
+  constexpr int nk = Z14_N2 + 1;
+  Z14Lane c;
+  c.lane = lane;
+  c.L = lane < Z14_LANES ? lane : Z14_LANES - 1;
+  const int l5 = lane < Z14_LANES5 ? lane : Z14_LANES5 - 1;
+  const int k1_5 = l5 % 12, d0_5 = l5 / 12;
+  c.rd5 = buf + k1_5 * Z14_S1 + d0_5;
+  c.wr5 = buf + d0_5 * 60 + k1_5;
+  c.tw5 = tw2 + d0_5;
+  c.mir0 = c.L == 0 ? 0 : Z14_N2 - c.L;
+  const int L = c.L;
+  const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);
+
+  // the block's steps: XCD x owns the slabs x, x + 8, ...; its (slab, run) pairs, slab-major, are dealt out to its blocks
+  // round-robin -- with 32 runs per slab and 32 blocks per XCD every step of the XCD is one whole slab
+  const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3), nlocal = (int)(gridDim.x >> 3);
+  // (no integer division in here: a 64-bit divide is a ~1000-cycle routine on this ISA; the host sends rows = base * runs + rem)
+  int64_t o = xcd;
+  int run = local;
+  auto normalise = [&](int64_t& oo, int& rr) {
+    while (rr >= runs_per_slab) {
+      rr -= runs_per_slab;
+      oo += 8;
+    }
+  };
+  normalise(o, run);
+  auto run_rows = [&](int rr, int64_t& rbeg, int64_t& rend) {  // the first `rem` runs of a slab are one row longer
+    rbeg = (int64_t)rr * run_base + (rr < run_rem ? rr : run_rem);
+    rend = rbeg + run_base + (rr < run_rem ? 1 : 0);
+  };
+  // loader role: thread -> (team t_ld, longitudes j0 + 64 n); its 8 bytes of longitude j belong at element j of that team's buffer
+  const int t_ld = tid % Z14_TEAMS, j0 = tid / Z14_TEAMS;
+  v2* const stage_dst = reinterpret_cast<v2*>(bufs + t_ld * Z14_BUFL) + j0;
+  v2 held[Z14_STAGE];
+  if constexpr (KNOCK & 1) {
+#pragma unroll
+    for (int n = 0; n < Z14_STAGE; ++n) held[n] = (v2){1.f, 2.f};
+  }
+  // part p of the run's loads: items [6 p, 6 p + 6) (p = 3: the rest).  All twelve waves of the block leave the barrier
+  // together; 23 loads each at once is 7 us of texture-addresser time in front of the passes, spread over the passes they
+  // run under the other waves' arithmetic.
+  auto load_part = [&](int64_t oo, int rr, int part) {
+    if constexpr (KNOCK & 1) return;
+    int64_t rbeg, rend;
+    run_rows(rr, rbeg, rend);
+    const int64_t ra = rbeg + 2 * t_ld;
+    const float* src = field + (slab_off ? slab_off[oo] : 0) + ra + (int64_t)j0 * lon_stride;
+    if (ra + 1 < rend) {
+#pragma unroll
+      for (int n = 0; n < Z14_STAGE; ++n)
+        if ((n / 6 == part || (part == 3 && n >= 18)) && (n < Z14_STAGE - 1 || j0 + 64 * n < Z14_N))
+          held[n] = *reinterpret_cast<const v2u*>(src + (int64_t)(64 * n) * lon_stride);
+    } else if (ra < rend) {  // a lone last row: nothing may be read behind it
+#pragma unroll
+      for (int n = 0; n < Z14_STAGE; ++n)
+        if ((n / 6 == part || (part == 3 && n >= 18)) && (n < Z14_STAGE - 1 || j0 + 64 * n < Z14_N))
+          held[n] = (v2){src[(int64_t)(64 * n) * lon_stride], 0.f};
+    }
+  };
+  auto load_run = [&](int64_t oo, int rr) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) load_part(oo, rr, part);
+  };
+  // Sums: fp64 registers per team (k = L + 60 s) while its rows stay in one group; when the group changes they are added to
+  // the BLOCK's [721] table in the LDS (ds_add_f64), and the table goes out with one global atomic per wavenumber when the
+  // block's group changes.  (A run of rows belongs to one slab = normally one group, but consecutive steps of a block are
+  // different slabs: twelve teams sending 721 atomics each per step cost more than the transform -- 0.93 against 0.41 ms.)
+  double* const blk = reinterpret_cast<double*>(bufs + Z14_TEAMS * Z14_BUFL);
+  for (int k = tid; k < nk; k += 64 * Z14_TEAMS) blk[k] = 0.0;
+  int32_t blk_group = -1;  // block-uniform
+  double acc[12], acc_ny = 0.0;
+#pragma unroll
+  for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+  int32_t cur = -1;
+  auto dump = [&](int32_t next) {  // the team's sums of group `cur` -> the block's table, or straight out if that holds another group
+    if (cur >= 0 && lane < Z14_LANES) {
+      if (cur == blk_group) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) unsafeAtomicAdd(blk + L + 60 * s, acc[s]);
+        if (L == 0) unsafeAtomicAdd(blk + Z14_N2, acc_ny);
+      } else {
+        double* const out = power + (int64_t)cur * nk + L;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) unsafeAtomicAdd(out + 60 * s, (s == 0 && L == 0) ? acc[s] : 2.0 * acc[s]);
+        if (L == 0) unsafeAtomicAdd(out + Z14_N2, 2.0 * acc_ny);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+    acc_ny = 0.0;
+    cur = next;
+  };
+  auto flush_block = [&](int32_t next) {  // every thread of the block; the callers put barriers around it
+    if (blk_group >= 0) {
+      for (int k = tid; k < nk; k += 64 * Z14_TEAMS) {
+        const double sum = blk[k];
+        if (sum != 0.0) unsafeAtomicAdd(power + (int64_t)blk_group * nk + k, k == 0 ? sum : 2.0 * sum);  // S_k, include/wbx.h
+        blk[k] = 0.0;
+      }
+    }
+    blk_group = next;
+  };
+  if (o < nslab) load_run(o, run);
+  unsigned long long stamp[6], spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto mark = [&](int i) {
+    if constexpr (PROF) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp[i] = __builtin_readcyclecounter();
+    }
+  };
+  while (o < nslab) {  // block-uniform
+    mark(0);
+    __syncthreads();  // every team is done with its buffer (and, the first time, the tables are in place)
+    mark(1);
+    int64_t rbeg, rend;
+    run_rows(run, rbeg, rend);
+    const int64_t row0 = o * rps;
+    const int64_t ra = rbeg + 2 * team;
+    const bool active = ra < rend, two = ra + 1 < rend;  // team-uniform
+    int32_t ga = cur, gb = cur;
+    double sca = 0.0, scb = 0.0;
+    if (active) {
+      ga = group[row0 + ra];
+      gb = two ? group[row0 + ra + 1] : ga;
+      sca = scale[row0 + ra] * quarter_inv_nn;
+      scb = two ? scale[row0 + ra + 1] * quarter_inv_nn : 0.0;
+      if (ga != cur) dump(ga);  // (the table still belongs to the previous step's group: it is flushed behind the next barrier)
+    }
+#pragma unroll
+    for (int n = 0; n < Z14_STAGE; ++n)
+      if (n < Z14_STAGE - 1 || j0 + 64 * n < Z14_N) stage_dst[64 * n] = held[n];
+    __syncthreads();
+    mark(2);
+    const int32_t g0 = group[row0 + rbeg];
+    if (g0 != blk_group) flush_block(g0);  // block-uniform; the teams touch the table again behind the next barrier
+    int64_t on = o;
+    int rn = run + nlocal;
+    normalise(on, rn);
+    const bool more = on < nslab;
+    mark(3);
+    if (active) {
+      C2 v[12];
+#pragma unroll
+      for (int a = 0; a < 12; ++a) v[a] = ld_c2(buf + 60 * a + L);
+      __builtin_amdgcn_wave_barrier();
+      mark(4);
+      if constexpr (KNOCK & 2) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) acc[a] += (double)(v[a].re.x + v[a].im.y) * sca;
+        if (more) load_run(on, rn);
+      } else {
+        z14_pair(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int part) {
+          if (more) load_part(on, rn, part);
+        });
+      }
+      mark(5);
+      if constexpr (PROF) {
+#pragma unroll
+        for (int i = 1; i < 6; ++i) spent[i] += stamp[i] - stamp[i - 1];
+        spent[0] += 1;
+      }
+    } else if (more) {
+      load_run(on, rn);  // (a team without rows in this run still loads its share of the next one)
+    }
+    o = on;
+    run = rn;
+  }
+  if constexpr (PROF) {
+    if (team == 0 && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) atomicAdd(prof + i, spent[i]);
+    }
+  }
+  __syncthreads();
+  dump(-1);
+  __syncthreads();
+  flush_block(-1);
+}
+
 // host side: W720^(b k1) at (k1 - 1) * 60 + b | W60^(d q) at (q - 1) * 12 + d | W1440^k, k < 720
 static void zspec1440_tables(std::vector<float2>& host) {
   host.resize(Z14_TABLES);
