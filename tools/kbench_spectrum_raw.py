@@ -23,6 +23,10 @@ torch.cuda.synchronize()
 
 import ctypes
 slab_off = (np.arange(nt * nlev, dtype=np.int64) * nlat * nlon)
+if len(sys.argv) > 3 and sys.argv[3] == 'sorted':  # the slabs of one group (level) next to each other, as spectra.py lists them
+  order = np.argsort(np.arange(nt * nlev) % nlev, kind='stable')
+  slab_off = np.ascontiguousarray(slab_off[order])
+  group = torch.from_numpy(np.repeat((np.arange(nt * nlev) % nlev)[order], nlat).astype(np.int32)).cuda()
 
 
 def launch(f):

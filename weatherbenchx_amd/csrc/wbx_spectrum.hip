@@ -536,11 +536,11 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     WBX_HIP(hipStreamSynchronize(ctx->stream));
     if (getenv("WBX_SPECTRUM_KNOCK") && atoi(getenv("WBX_SPECTRUM_KNOCK")) == 3)
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 3>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
-                         lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),
                          reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
     else
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
-                         lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),
                          reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
     WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -555,11 +555,12 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   static const int knock = getenv("WBX_SPECTRUM_KNOCK") ? atoi(getenv("WBX_SPECTRUM_KNOCK")) : 0;  // diagnostic, wrong results
 #define WBX_Z14LF_LAUNCH(KN)                                                                                               \
   hipLaunchKernelGGL((zspec1440_latfast_kernel<false, KN>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,  \
-                     lon_stride, d_slab_off, rps, nslab, (int)runs, (int)(rps / runs), (int)(rps % runs),                    \
+                     lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),                    \
                      reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr))
   if (knock == 1) WBX_Z14LF_LAUNCH(1);
   else if (knock == 2) WBX_Z14LF_LAUNCH(2);
   else if (knock == 3) WBX_Z14LF_LAUNCH(3);
+  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, false>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
 
   else WBX_Z14LF_LAUNCH(0);
 #undef WBX_Z14LF_LAUNCH

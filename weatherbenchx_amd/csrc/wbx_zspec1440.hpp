@@ -366,10 +366,10 @@ typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
 // PROF: wave 0 of every block adds its cycles per step to prof[1..6] (wait at the first barrier | staging stores + second
 // barrier | issue of the next run's loads | pass-1 loads from the LDS | the three passes and the unpack), steps to prof[0].
 // KNOCK (diagnostic, wrong results): 1 = no global loads, 2 = no passes (the staged data is only summed)
-template <bool PROF, int KNOCK = 0>
+template <bool PROF, int KNOCK = 0, bool SPREAD = true>
 __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
-    int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g, const int32_t* __restrict__ group,
+    int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g, const int32_t* __restrict__ group,
     const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
@@ -394,16 +394,18 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
   const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);
 
-  // the block's steps: XCD x owns the slabs x, x + 8, ...; its (slab, run) pairs, slab-major, are dealt out to its blocks
-  // round-robin -- with 32 runs per slab and 32 blocks per XCD every step of the XCD is one whole slab
+  // the block's steps: XCD x owns a contiguous eighth of the slabs (callers list the slabs of one group next to each other:
+  // a block then changes group -- and empties its table of sums -- only every few steps); its (slab, run) pairs, slab-major,
+  // are dealt out to its blocks round-robin: with 32 runs per slab and 32 blocks per XCD every step of the XCD is one whole slab
   const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3), nlocal = (int)(gridDim.x >> 3);
   // (no integer division in here: a 64-bit divide is a ~1000-cycle routine on this ISA; the host sends rows = base * runs + rem)
-  int64_t o = xcd;
+  const int64_t o_end = (xcd + 1) * slabs_per_xcd < nslab ? (xcd + 1) * slabs_per_xcd : nslab;
+  int64_t o = xcd * slabs_per_xcd;
   int run = local;
   auto normalise = [&](int64_t& oo, int& rr) {
     while (rr >= runs_per_slab) {
       rr -= runs_per_slab;
-      oo += 8;
+      oo += 1;
     }
   };
   normalise(o, run);
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     }
     blk_group = next;
   };
-  if (o < nslab) load_run(o, run);
+  if (o < o_end) load_run(o, run);
   unsigned long long stamp[6], spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto mark = [&](int i) {
     if constexpr (PROF) {
@@ -491,7 +493,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
       stamp[i] = __builtin_readcyclecounter();
     }
   };
-  while (o < nslab) {  // block-uniform
+  while (o < o_end) {  // block-uniform
     mark(0);
     __syncthreads();  // every team is done with its buffer (and, the first time, the tables are in place)
     mark(1);
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     int64_t on = o;
     int rn = run + nlocal;
     normalise(on, rn);
-    const bool more = on < nslab;
+    const bool more = on < o_end;
     mark(3);
     if (active) {
       C2 v[12];
@@ -532,8 +534,15 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
         for (int a = 0; a < 12; ++a) acc[a] += (double)(v[a].re.x + v[a].im.y) * sca;
         if (more) load_run(on, rn);
       } else {
+        if constexpr (!SPREAD) {
+          if (more) load_run(on, rn);
+        } else {
+          if (more) load_part(on, rn, 0);
+        }
         z14_pair(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int part) {
-          if (more) load_part(on, rn, part);
+          if constexpr (SPREAD) {
+            if (more && part < 3) load_part(on, rn, part + 1);  // (nothing behind the unpack: the next step starts by storing them)
+          }
         });
       }
       mark(5);

@@ -90,14 +90,23 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
     sc = np.ascontiguousarray(scale, dtype=np.float64)
     if geo.permutation is not None:  # slabs walk the rows in another order than C order
       g, sc = g[geo.permutation], sc[geo.permutation]
-    bufs = (ctx.upload(g), ctx.upload(sc), geo)
+    offs = np.ascontiguousarray(geo.outer_offsets, dtype=np.int64)
+    if offs.size > 1 and g.size == offs.size * geo.batch:
+      # the slabs of one output group next to each other (a stable sort on each slab's first group): the kernels keep their
+      # fp64 sums in registers / LDS while the group stays, and [lead, level] slabs in storage order change it every slab
+      order = np.argsort(g.reshape(offs.size, geo.batch)[:, 0], kind='stable')
+      if np.any(order != np.arange(offs.size)):
+        offs = np.ascontiguousarray(offs[order])
+        g = np.ascontiguousarray(g.reshape(offs.size, geo.batch)[order].reshape(-1))
+        sc = np.ascontiguousarray(sc.reshape(offs.size, geo.batch)[order].reshape(-1))
+    bufs = (ctx.upload(g), ctx.upload(sc), geo, offs)
     if cache is not None:
       cache[ckey] = bufs
   g_dev, s_dev = bufs[0], bufs[1]
   out = engine._scratch(ctx, 'spectrum', max(ngroup * nk, 1) * 8)  # pylint: disable=protected-access
   # one call for every slab (lead x level slabs of adjacent latitude rows for latitude-fastest fields); group / scale are
   # already in slab-major row order (geo.permutation)
-  offs = np.ascontiguousarray(geo.outer_offsets, dtype=np.int64)
+  offs = bufs[3]
   _hip.check(ctx.lib.wbx_zonal_spectrum_slabs(ctx.handle, C.c_void_p(dev.ptr), int(geo.lon_stride), int(geo.row_stride),
                                               int(geo.batch), int(offs.size), offs.ctypes.data_as(C.c_void_p), int(nlon),
                                               C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr), int(ngroup), 0,
