@@ -436,18 +436,31 @@ def spectrum_leg(env):
       return pipelined(launch, lambda s: s.metric_values(smetrics), n)
   srun(3)
   env.sync()
+  nsteps = args.steps * 5  # (a step is ~0.6 ms: the pipeline's fill and drain would be a tenth of ten steps)
   t0 = time.perf_counter()
-  sout = srun(args.steps)
+  sout = srun(nsteps)
   env.sync()
-  s_ms = (time.perf_counter() - t0) / args.steps * 1e3
+  s_ms = (time.perf_counter() - t0) / nsteps * 1e3
   spoints = nt_s * nlev_s * env.nlat * env.nlon
   parseval = float(np.asarray(sout['spectrum_p.z'].values)[0].sum())
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 10  # the kernel alone: HIP events, 10 launches per pair
+  for _ in range(2):
+    launch().metric_values(smetrics)
+  slog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'spectrum']
+  engine.S1_EVENT_LOG = None
+  sk_ms = float(np.mean([e['ms'] for e in slog]))
+  if env.nlon == 1440:
+    kname = ('zspec1440_kernel (one wave per row pair, 720 = 12 x 5 x 12)' if args.layout == 'lon_fastest' else
+             'zspec1440_latfast_kernel (24 adjacent rows per block step, staged through the LDS)')
+  else:
+    kname = 'zspec_fused_kernel'
   return {'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{env.nlat},{env.nlon}] each, area-weighted '
-                      'mean over (lead_time, latitude); fused in-LDS mixed-radix FFT + fp64 |F|^2 reduction (one pass over the '
-                      'field); parity unpinned (no reference implementation, SURVEY F3)',
-          'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms,
+                      f'mean over (lead_time, latitude), {args.layout}; fused in-LDS FFT + fp64 |F|^2 reduction (one pass over '
+                      'the field); parity unpinned (no reference implementation, SURVEY F3)',
+          'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms, 'steps': nsteps,
           'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
           'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+          'roofline': kernel_roofline(kname + ' (+ 6 us memset of the output), one field', sk_ms, spoints * 4),
           'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
 
 
