@@ -460,7 +460,8 @@ def spectrum_leg(env):
           'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms, 'steps': nsteps,
           'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
           'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-          'roofline': kernel_roofline(kname + ' (+ 6 us memset of the output), one field', sk_ms, spoints * 4),
+          'roofline': kernel_roofline(kname + ' (+ 6 us memset of the output), one field', sk_ms, spoints * 4,
+                                      pmc_traffic(kname, not args.small)),
           'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
 
 

@@ -46,12 +46,16 @@ def bench_key(name: str) -> str:
   m = re.match(r's1_xf_kernel<(.*?) ?>$', n)
   if m:
     return f's1_xf_kernel<{m.group(1)}>'
-  m = re.match(r'det_atoms_kernel<float, 1, (\d), (\d+), (\d)>', n)
+  m = re.match(r'det_atoms_kernel<float, 1, (\d), (\d+), (\d)(?:, (?:true|false))?>', n)
   if m:
     return f'det_atoms_kernel<float,DET6,MM={m.group(1)},PD={m.group(2)},WM={m.group(3)}>'
   m = re.match(r'det_binned_kernel<float, 1, (\d), (\d+), (\d), (\d)>', n)
   if m:
     return f'det_binned_kernel<float,DET6,MM={m.group(1)},K={m.group(2)},PD={m.group(3)},WM={m.group(4)}>'
+  if n.startswith('zspec1440_latfast_kernel'):
+    return 'zspec1440_latfast_kernel'
+  if n.startswith('zspec1440_kernel'):
+    return 'zspec1440_kernel'
   m = re.match(r'zspec_fused_kernel<(\d), (\d+), (\d)>', n)
   if m:
     return f'zspec_fused_kernel<{m.group(1)},{m.group(2)},{m.group(3)}> (zonal spectrum, n=1440)'
@@ -69,7 +73,8 @@ traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pm
                     'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
                     '(gfx950 reports half of wide coalesced reads)')
 json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
-for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt'):
+for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt',
+              'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt'):
   if os.path.exists(os.path.join(src, extra)):
     shutil.copy(os.path.join(src, extra), out(extra))
 print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])
