@@ -522,10 +522,12 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   }
   int nlocal = per_cu * ctx->num_cus / 8;  // blocks per XCD
   if (nlocal < 1) nlocal = 1;
-  // runs per slab: <= 24 rows each; a whole number of XCD sets when that does not shred the runs (721 rows: 31 -> 32)
-  int64_t runs = (rps + Z14_RUN - 1) / Z14_RUN;
-  const int64_t rounded = (runs + nlocal - 1) / nlocal * nlocal;
-  if (rps / rounded >= Z14_RUN / 2) runs = rounded;
+  // runs per slab: 22 rows = 11 of the 12 teams.  Measured on configs[3] (721 rows per slab, 32 blocks per XCD), ms per
+  // field for 31 / 32 / 33 / 34 / 36 / 40 / 48 runs: 0.396 / 0.418 / 0.389 / 0.425 / 0.393 / 0.421 / 0.512 -- 32 runs, where
+  // the 32 blocks of an XCD walk the same longitudes of ONE slab in lockstep, is the slowest of the neighbours (FETCH 1.06 x
+  // algorithmic against 1.09 x for 33: the shared lines are found in L2 either way)
+  int64_t runs = (rps + 21) / 22;
+  if (const char* e = getenv("WBX_SPECTRUM_LF_RUNS")) runs = atoi(e) >= (rps + Z14_RUN - 1) / Z14_RUN ? atoi(e) : runs;  // A/B timing
   const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
   if (per_xcd < nlocal) nlocal = (int)per_xcd;
   if (prof_path) {

@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
 
   // the block's steps: XCD x owns a contiguous eighth of the slabs (callers list the slabs of one group next to each other:
   // a block then changes group -- and empties its table of sums -- only every few steps); its (slab, run) pairs, slab-major,
-  // are dealt out to its blocks round-robin: with 32 runs per slab and 32 blocks per XCD every step of the XCD is one whole slab
+  // are dealt out to its blocks round-robin, so the blocks of an XCD work on one or two neighbouring slabs at any time
   const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3), nlocal = (int)(gridDim.x >> 3);
   // (no integer division in here: a 64-bit divide is a ~1000-cycle routine on this ISA; the host sends rows = base * runs + rem)
   const int64_t o_end = (xcd + 1) * slabs_per_xcd < nslab ? (xcd + 1) * slabs_per_xcd : nslab;
