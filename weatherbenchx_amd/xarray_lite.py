@@ -28,8 +28,15 @@ import numpy as np
 
 # --------------------------------------------------------------------------------------------------
 # backend helpers (numpy / torch duck typing)
+_TORCH_TYPE: dict = {np.ndarray: False}  # type -> is it a torch type (asked ~90 times per aggregation step)
+
+
 def _is_torch(x) -> bool:
-  return type(x).__module__.split('.')[0] == 'torch'
+  t = type(x)
+  r = _TORCH_TYPE.get(t)
+  if r is None:
+    r = _TORCH_TYPE[t] = t.__module__.split('.')[0] == 'torch'
+  return r
 
 
 def _torch():
@@ -45,7 +52,7 @@ def _to_numpy(x) -> np.ndarray:
 
 
 def _shape(x):
-  return tuple(int(s) for s in x.shape)
+  return tuple(x.shape)  # (numpy shapes and torch.Size both hold Python ints)
 
 
 def _transpose(x, axes):
