@@ -1,3 +1,6 @@
+#!/bin/bash
+# Phase profile of zspec1440_latfast_kernel (s_memtime stamps of wave 0 of every block, cycles per step of <= 12 row pairs):
+# usage (GPU box): bash tools/spec_latfast_phase_profile.sh
 rm -f /tmp/lf.txt; WBX_SPECTRUM_PROF=/tmp/lf.txt timeout 200 python tools/kbench_spectrum_raw.py 8 lat_fastest > /dev/null 2>&1; python - <<'PY'
 rows=[list(map(int,l.split()[1:])) for l in open('/tmp/lf.txt') if l.startswith('latfast')]
 import numpy as np

@@ -48,6 +48,27 @@ __device__ __forceinline__ void dft12(C2 (&v)[12]) {
   }
 }
 
+struct Z14Lane {  // what a lane keeps for the whole launch: every LDS address / twiddle index is this + an immediate
+  int lane, L;        // L = the lane's butterfly in passes 1 and 3 (lanes 60..63 shadow lane 59: same addresses, same values)
+  const v4* rd5;      // pass 2 (lanes 48..63 shadow lane 47), butterfly i = 0..2: loads at + 4 i + 12 c
+  v4* wr5;            //         stores at + 240 i + 12 q
+  const float2* tw5;  //         twiddles at + 4 i + 12 (q - 1)
+  int mir0;           // mirror of k = L + 60 s is mir0 - 60 s (s = 0: 0 for L = 0)
+};
+
+__device__ __forceinline__ Z14Lane z14_lane(int lane, v4* buf, const float2* tw2) {
+  Z14Lane c;
+  c.lane = lane;
+  c.L = lane < Z14_LANES ? lane : Z14_LANES - 1;
+  const int l5 = lane < Z14_LANES5 ? lane : Z14_LANES5 - 1;
+  const int k1_5 = l5 % 12, d0_5 = l5 / 12;  // butterfly i of pass 2: (k1, d) = (k1_5, d0_5 + 4 i)
+  c.rd5 = buf + k1_5 * Z14_S1 + d0_5;
+  c.wr5 = buf + d0_5 * 60 + k1_5;
+  c.tw5 = tw2 + d0_5;
+  c.mir0 = c.L == 0 ? 0 : Z14_N2 - c.L;
+  return c;
+}
+
 // (KNOCK & 2: the value is computed -- pinned by an empty asm -- but not stored)
 template <bool DROP>
 __device__ __forceinline__ void z14_store(v4* p, C2 a) {
@@ -55,6 +76,92 @@ __device__ __forceinline__ void z14_store(v4* p, C2 a) {
     asm volatile("" ::"v"(a.re.x), "v"(a.re.y), "v"(a.im.x), "v"(a.im.y));
   else
     st_c2(p, a);
+}
+
+// One row pair: passes 1-3 on v (the pass-1 inputs), the mirror exchange and the Hermitian unpack; adds scale * |X_k|^2
+// into acc / acc_ny (row B straight into `power` when the pair straddles two groups).
+// at(i) is called at six points: 0 pass 1 has issued its stores | 1 pass 2 has its loads | 2 pass 2 has issued its stores |
+// 3 pass 3 has its loads | 4 the mirror stores are issued | 5 done.  The longitude-fastest kernel stamps the clock there
+// (PROF), the latitude-fastest one issues a part of the next run's global loads at 0, 2, 4.
+// KNOCK (diagnostic instantiations, wrong results): 2 = the exchange stores are dropped, 4 = their loads too (register
+// values are passed on), 8 = no unpack arithmetic.
+template <int KNOCK, typename At>
+__device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* __restrict__ buf, const Z14Lane& c, const float2* __restrict__ tw1,
+                                         const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
+                                         double (&acc)[12], double& acc_ny, double* __restrict__ power, At&& at) {
+  constexpr int nk = Z14_N2 + 1;
+  constexpr bool DROP = (KNOCK & 2) != 0;
+  const int L = c.L;
+  // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
+  dft12(v);
+#pragma unroll
+  for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
+#pragma unroll
+  for (int k1 = 0; k1 < 12; ++k1) z14_store<DROP>(buf + k1 * Z14_S1 + L, v[k1]);
+  __builtin_amdgcn_wave_barrier();
+  at(0);
+  // ---- pass 2: 5-point DFT over c, twiddle W60^(d q), transpose 2: buf[d * 60 + k1 + 12 q]
+  C2 u[3][5];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) u[i][cc] = (KNOCK & 4) ? v[(5 * i + cc) % 12] : ld_c2(c.rd5 + 4 * i + 12 * cc);
+  }
+  __builtin_amdgcn_wave_barrier();  // every load of the first layout precedes the stores of the second
+  at(1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    butterfly<5>(u[i]);
+#pragma unroll
+    for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], c.tw5[4 * i + 12 * (q - 1)]);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) z14_store<DROP>(c.wr5 + 240 * i + 12 * q, u[i][q]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  at(2);
+  // ---- pass 3: 12-point DFT over d: v[s] = Z[L + 60 s]
+#pragma unroll
+  for (int d = 0; d < 12; ++d) v[d] = (KNOCK & 4) ? u[d % 3][d % 5] : ld_c2(buf + d * 60 + L);
+  __builtin_amdgcn_wave_barrier();
+  at(3);
+  dft12(v);
+  // ---- mirror exchange: Z[k] goes to buf[k], the partner Z[720 - k] comes back
+#pragma unroll
+  for (int s = 0; s < 12; ++s) z14_store<DROP>(buf + L + 60 * s, v[s]);
+  __builtin_amdgcn_wave_barrier();
+  at(4);
+  // Hermitian unpack: X_k = E_k + W^k O_k, W = exp(-2 pi i / 1440), 2 E_k = Z_k + conj Z_{720-k},
+  // 2 O_k = -i (Z_k - conj Z_{720-k});  X_720 = conj(E_0 - O_0).  |X|^2 in packed fp32 (as the transform), fp64 sums.
+#pragma unroll
+  for (int s = 0; s < 12; ++s) {
+    const C2 zk = v[s];
+    const C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+    const C2 e = {zk.re + zc.re, zk.im - zc.im};
+    const C2 o = {zk.im + zc.im, zc.re - zk.re};
+    const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[L + 60 * s]);
+    const C2 x = cadd(e, wo);
+    const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;  // (row A, row B)
+    if (split) {
+      acc[s] = fma((double)p.x, sca, acc[s]);
+      if (c.lane < Z14_LANES)
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
+    } else {
+      if constexpr (KNOCK & 8) acc[s] += (double)(p.x + p.y);
+      else acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+    }
+    if (s == 0) {
+      const C2 xm = csub(e, wo);
+      const v2 pm = xm.re * xm.re + xm.im * xm.im;
+      if (split) {
+        acc_ny = fma((double)pm.x, sca, acc_ny);
+        if (c.lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
+      } else {
+        acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair
+  at(5);
 }
 
 // blockDim.x = 64 * (teams per block); dynamic LDS = Z14_TABLES * 8 + teams * Z14_BUF * 16 bytes.
@@ -85,14 +192,8 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   const int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
   if (r0 >= r1) return;  // only wave-level ordering below
   constexpr int nk = Z14_N2 + 1;
-  // lanes 60..63 (passes 1, 3) and 48..63 (pass 2) shadow the last working lane: same addresses, same values, no branch
-  const int L = lane < Z14_LANES ? lane : Z14_LANES - 1;
-  const int l5 = lane < Z14_LANES5 ? lane : Z14_LANES5 - 1;
-  const int k1_5 = l5 % 12, d0_5 = l5 / 12;  // pass 2, butterfly i = 0..2: (k1, d) = (k1_5, d0_5 + 4 i)
-  const v4* const rd5 = buf + k1_5 * Z14_S1 + d0_5;  // + 4 i + 12 c
-  v4* const wr5 = buf + d0_5 * 60 + k1_5;            // + 240 i + 12 q
-  const float2* const tw5 = tw2 + d0_5;              // + 4 i + 12 (q - 1)
-  const int mir0 = L == 0 ? 0 : Z14_N2 - L;          // mirror of k = L + 60 s is mir0 - 60 s (s = 0: 0 for L = 0)
+  const Z14Lane c = z14_lane(lane, buf, tw2);
+  const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
 
   double acc[12], acc_ny = 0.0;  // k = L + 60 s; lane 0 also owns the Nyquist wavenumber k = 720
@@ -158,84 +259,11 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     mark(1, false);  // 0 -> 1: scalar bookkeeping + the wait for the prefetched rows
     if (r + 2 < r1) fetch(r + 2);
 
-    // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
-    dft12(v);
-#pragma unroll
-    for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
-#pragma unroll
-    for (int k1 = 0; k1 < 12; ++k1)
-      z14_store<(KNOCK & 2) != 0>(buf + k1 * Z14_S1 + L, v[k1]);
-    __builtin_amdgcn_wave_barrier();
-    mark(2, false);  // 1 -> 2: pass 1 (prefetch issue, DFT 12, twiddles from the LDS, 12 stores issued)
-
-    // ---- pass 2: 5-point DFT over c, twiddle W60^(d q), transpose 2: buf[d * 60 + k1 + 12 q]
-    C2 u[3][5];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-      for (int c = 0; c < 5; ++c) u[i][c] = (KNOCK & 4) ? v[(5 * i + c) % 12] : ld_c2(rd5 + 4 * i + 12 * c);
-    }
-    __builtin_amdgcn_wave_barrier();  // every read of the first layout precedes the writes of the second
-    mark(3, true);  // 2 -> 3: transpose 1 round trip (stores drain, 15 loads return)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      butterfly<5>(u[i]);
-#pragma unroll
-      for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], tw5[4 * i + 12 * (q - 1)]);
-#pragma unroll
-      for (int q = 0; q < 5; ++q)
-        z14_store<(KNOCK & 2) != 0>(wr5 + 240 * i + 12 * q, u[i][q]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    mark(4, false);  // 3 -> 4: pass 2
-
-    // ---- pass 3: 12-point DFT over d: v[s] = Z[L + 60 s]
-#pragma unroll
-    for (int d = 0; d < 12; ++d) v[d] = (KNOCK & 4) ? u[d % 3][d % 5] : ld_c2(buf + d * 60 + L);
-    __builtin_amdgcn_wave_barrier();
-    mark(5, true);  // 4 -> 5: transpose 2 round trip
-    dft12(v);
-
-    // ---- mirror exchange: Z[k] goes to buf[k], the partner Z[720 - k] comes back
-#pragma unroll
-    for (int s = 0; s < 12; ++s)
-      z14_store<(KNOCK & 2) != 0>(buf + L + 60 * s, v[s]);
-    __builtin_amdgcn_wave_barrier();
-    mark(6, false);  // 5 -> 6: pass 3
-    if (ga != cur) flush(ga);       // wave-uniform
-    const bool split = gb != ga;    // the pair straddles a group boundary (rare): row B goes out through its own atomics
-    // Hermitian unpack: X_k = E_k + W^k O_k, W = exp(-2 pi i / 1440), 2 E_k = Z_k + conj Z_{720-k},
-    // 2 O_k = -i (Z_k - conj Z_{720-k});  X_720 = conj(E_0 - O_0).  |X|^2 in packed fp32 (as the transform), fp64 sums.
-#pragma unroll
-    for (int s = 0; s < 12; ++s) {
-      const C2 zk = v[s];
-      const C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + mir0 : buf + (Z14_N2 - 60 * s) - L);
-      const C2 e = {zk.re + zc.re, zk.im - zc.im};
-      const C2 o = {zk.im + zc.im, zc.re - zk.re};
-      const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[L + 60 * s]);
-      const C2 x = cadd(e, wo);
-      const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;  // (row A, row B)
-      if (split) {
-        acc[s] = fma((double)p.x, sca, acc[s]);
-        if (lane < Z14_LANES)
-          unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
-      } else {
-        if constexpr (KNOCK & 8) acc[s] += (double)(p.x + p.y);
-        else acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
-      }
-      if (s == 0) {
-        const C2 xm = csub(e, wo);
-        const v2 pm = xm.re * xm.re + xm.im * xm.im;
-        if (split) {
-          acc_ny = fma((double)pm.x, sca, acc_ny);
-          if (lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
-        } else {
-          acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // buf is overwritten by the next pair
-    mark(7, true);  // 6 -> 7: mirror exchange + unpack + fp64 sums
+    if (ga != cur) flush(ga);  // wave-uniform
+    // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
+    // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
+    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power,
+                           [&](int i) { mark(i + 2, i == 1 || i == 3 || i == 5); });
     if constexpr (PROF) {
 #pragma unroll
       for (int i = 1; i < 8; ++i) spent[i] += stamp[i] - stamp[i - 1];
@@ -272,87 +300,6 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 // The 96-byte segments do not line up with the 128-byte lines, so a line is shared with the neighbouring runs of rows:
 // the runs of one slab are spread over the blocks of ONE XCD in the same step (blockIdx & 7 = XCD, slab o -> XCD o mod 8),
 // which all move at the same pace, so the line's other users find it in that XCD's L2.
-struct Z14Lane {
-  int lane, L;
-  const v4* rd5;
-  v4* wr5;
-  const float2* tw5;
-  int mir0;
-};
-
-// passes 1-3 on v (pass-1 inputs), the mirror exchange and the Hermitian unpack; adds scale * |X_k|^2 into acc / acc_ny
-// (row B straight into `power` when the pair straddles two groups)
-// `between(i)`, i = 0..3, runs after pass 1 / pass 2 / pass 3 / the unpack have issued their work (the latitude-fastest
-// kernel spreads the next run's global loads over them)
-template <typename Between>
-__device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* __restrict__ buf, const Z14Lane& c, const float2* __restrict__ tw1,
-                                         const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
-                                         double (&acc)[12], double& acc_ny, double* __restrict__ power, Between&& between) {
-  constexpr int nk = Z14_N2 + 1;
-  const int L = c.L;
-  dft12(v);
-#pragma unroll
-  for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
-#pragma unroll
-  for (int k1 = 0; k1 < 12; ++k1) st_c2(buf + k1 * Z14_S1 + L, v[k1]);
-  __builtin_amdgcn_wave_barrier();
-  between(0);
-  C2 u[3][5];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-#pragma unroll
-    for (int cc = 0; cc < 5; ++cc) u[i][cc] = ld_c2(c.rd5 + 4 * i + 12 * cc);
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    butterfly<5>(u[i]);
-#pragma unroll
-    for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], c.tw5[4 * i + 12 * (q - 1)]);
-#pragma unroll
-    for (int q = 0; q < 5; ++q) st_c2(c.wr5 + 240 * i + 12 * q, u[i][q]);
-  }
-  __builtin_amdgcn_wave_barrier();
-  between(1);
-#pragma unroll
-  for (int d = 0; d < 12; ++d) v[d] = ld_c2(buf + d * 60 + L);
-  __builtin_amdgcn_wave_barrier();
-  dft12(v);
-#pragma unroll
-  for (int s = 0; s < 12; ++s) st_c2(buf + L + 60 * s, v[s]);
-  __builtin_amdgcn_wave_barrier();
-  between(2);
-#pragma unroll
-  for (int s = 0; s < 12; ++s) {
-    const C2 zk = v[s];
-    const C2 zc = ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
-    const C2 e = {zk.re + zc.re, zk.im - zc.im};
-    const C2 o = {zk.im + zc.im, zc.re - zk.re};
-    const C2 wo = ctw(o, twr[L + 60 * s]);
-    const C2 x = cadd(e, wo);
-    const v2 p = x.re * x.re + x.im * x.im;  // (row A, row B)
-    if (split) {
-      acc[s] = fma((double)p.x, sca, acc[s]);
-      if (c.lane < Z14_LANES)
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
-    } else {
-      acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
-    }
-    if (s == 0) {
-      const C2 xm = csub(e, wo);
-      const v2 pm = xm.re * xm.re + xm.im * xm.im;
-      if (split) {
-        acc_ny = fma((double)pm.x, sca, acc_ny);
-        if (c.lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
-      } else {
-        acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  between(3);
-}
-
 constexpr int Z14_TEAMS = 12;                 // teams (row pairs) of a latitude-fastest block
 constexpr int Z14_RUN = 2 * Z14_TEAMS;        // rows of a run
 constexpr int Z14_BUFL = 733;                 // v4 elements between the team buffers (odd: the staging stores of one
@@ -382,15 +329,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
   v4* const buf = bufs + team * Z14_BUFL;
   for (int i = tid; i < Z14_TABLES; i += 64 * Z14_TEAMS) tw1[i] = tables_g[i];
   constexpr int nk = Z14_N2 + 1;
-  Z14Lane c;
-  c.lane = lane;
-  c.L = lane < Z14_LANES ? lane : Z14_LANES - 1;
-  const int l5 = lane < Z14_LANES5 ? lane : Z14_LANES5 - 1;
-  const int k1_5 = l5 % 12, d0_5 = l5 / 12;
-  c.rd5 = buf + k1_5 * Z14_S1 + d0_5;
-  c.wr5 = buf + d0_5 * 60 + k1_5;
-  c.tw5 = tw2 + d0_5;
-  c.mir0 = c.L == 0 ? 0 : Z14_N2 - c.L;
+  const Z14Lane c = z14_lane(lane, buf, tw2);
   const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);
 
@@ -539,9 +478,9 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
         } else {
           if (more) load_part(on, rn, 0);
         }
-        z14_pair(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int part) {
-          if constexpr (SPREAD) {
-            if (more && part < 3) load_part(on, rn, part + 1);  // (nothing behind the unpack: the next step starts by storing them)
+        z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int i) {
+          if constexpr (SPREAD) {  // parts 1..3 behind the stores of passes 1, 2, 3 (nothing behind the unpack: the next step
+            if (more && !(i & 1) && i < 6) load_part(on, rn, i / 2 + 1);  // starts by storing them)
           }
         });
       }
