@@ -338,6 +338,15 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   for _ in range(3):
     launch().metric_values(emetrics)
   elog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+  # the north_star's pairwise |x_i - x_j| form (use_sort=False: the 1275 pairs of a point tiled in registers),
+  # timed on the same launch shape beside the rank form
+  from weatherbenchx_amd.metrics import probabilistic as _prob
+  pmet = {'crps_pairwise': _prob.CRPSEnsemble(use_sort=False)}
+  k0 = next(iter(pe))
+  engine.S1_EVENT_LOG = []
+  for _ in range(2):
+    eagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(pmet, fresh({k0: pe[k0]}), fresh({k0: te[k0]}))).metric_values(pmet)
+  plog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
   engine.S1_EVENT_LOG = None
   epoints = nlead * env.nlat * env.nlon  # per variable launch
   ek_ms = float(np.mean([e['ms'] for e in elog]))
@@ -347,6 +356,8 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
          'metrics': list(emetrics),
          'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4,
                                      pmc_traffic(kname, nlead == 8 and not args.small)),
+         'pairwise_form': (kernel_roofline('EnsOpF32<51,true,PAIRWISE> (use_sort=False)', float(np.mean([e['ms'] for e in plog])),
+                                           epoints * (m + 1) * 4) if plog else None),
          'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
                    'spread_skill_v0_mean': float(np.asarray(eout['unbiased_spread_skill.v0'].values).mean())}}
   del pe, te, tv
