@@ -187,3 +187,38 @@ def test_1440_point_rows_one_wave_kernel(backend, layout, nlat, mean):
   # per-row spectra (no reduction): rows as their own groups
   stat = spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v'].transpose(*rd, 'zonal_wavenumber')
   check(np.asarray(stat.values), per_row)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_1440_point_rows_random_shapes_and_reductions(backend, seed):
+  """Randomised: 1-3 leads x 1-4 levels x 1-60 latitudes of 1440-point rows in either layout, any subset of
+  (lead_time, level, latitude) reduced (rows as their own groups, groups per level, one group for everything), with and
+  without area weights -- the row-pair / run / slab bookkeeping of both 1440-point kernels against the float64 oracle."""
+  rng = np.random.default_rng(1000 + seed)
+  nlon = 1440
+  shape = {'lead_time': int(rng.integers(1, 4)), 'level': int(rng.integers(1, 5)), 'latitude': int(rng.integers(1, 61)),
+           'longitude': nlon}
+  layout = ('lon_fastest', 'lat_fastest')[seed % 2]
+  dims = ('lead_time', 'level', 'latitude', 'longitude') if layout == 'lon_fastest' else \
+      ('lead_time', 'level', 'longitude', 'latitude')
+  lat = np.linspace(-85, 85, shape['latitude']) if shape['latitude'] > 1 else np.array([10.0])
+  vals = (rng.normal(size=[shape[d] for d in dims]) * rng.uniform(0.5, 3.0) + rng.uniform(-5, 5)).astype(np.float32)
+  f = _field(vals, dims, lat=lat, lon=np.arange(nlon) * 0.25)
+  row_dims = ('lead_time', 'level', 'latitude')
+  reduce_dims = [d for d in row_dims if rng.random() < 0.5]
+  weighted = bool(rng.random() < 0.5) and shape['latitude'] > 1
+  metrics = {'spec': spectra.ZonalPowerSpectrum()}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()] if weighted else [])
+  res = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': f}, {'v': f})).metric_values(metrics)
+  lon_ax = dims.index('longitude')
+  per_row = np.moveaxis(O.zonal_power_spectrum(vals, lon_axis=lon_ax), lon_ax, -1)
+  rd = tuple(d for d in dims if d != 'longitude')
+  w = O.grid_area_weights(lat) if weighted else np.ones(shape['latitude'])
+  wv = O.expand_to(w, ('latitude',), rd)[..., None]
+  red = tuple(rd.index(d) for d in reduce_dims)
+  want = (per_row * wv).sum(axis=red) / (wv * np.ones_like(per_row)).sum(axis=red)
+  kept = [d for d in rd if d not in reduce_dims]
+  got = res['spec.v'].transpose(*kept, 'zonal_wavenumber').values
+  bound = 2e-5 * want + 4e-7 * np.sqrt(want.max(axis=-1, keepdims=True) * want)
+  worst = float(np.max(np.abs(got - want) / bound))
+  assert got.shape == want.shape and worst <= 1.0, (shape, layout, reduce_dims, weighted, worst)
