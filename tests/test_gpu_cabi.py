@@ -668,3 +668,52 @@ def test_full_grid_dense_stage2_split_equals_folded_route(ctx, monkeypatch):
     res[fold] = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
   for k in res[True]:
     np.testing.assert_allclose(res[False][k].values, res[True][k].values, rtol=1e-11)
+
+
+@pytest.mark.parametrize('entry', ['rows', 'slabs'])
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_zonal_spectrum_entry_points_raw_1440(ctx, layout, entry):
+  """wbx_zonal_spectrum / wbx_zonal_spectrum_slabs called with raw pointers (include/wbx.h) on 1440-point rows: 3 slabs of
+  37 rows (odd: a lone last row per slab / run) in either layout, two groups per slab with unequal row scales, against
+  numpy.fft in float64; `accumulate = 1` adds a second pass onto the first."""
+  import torch
+  nslab, rps, nlon = 3, 37, 1440
+  rng = np.random.default_rng(5)
+  if entry == 'rows':
+    nslab = 1
+  vals = (rng.normal(size=(nslab, rps, nlon)) + 2.0).astype(np.float32)  # [slab][row][lon]
+  if layout == 'lon_fastest':
+    dev = torch.from_numpy(vals).cuda()
+    lon_stride, row_stride = 1, nlon
+    offs = np.arange(nslab, dtype=np.int64) * rps * nlon
+  else:
+    dev = torch.from_numpy(np.ascontiguousarray(vals.transpose(0, 2, 1))).cuda()  # [slab][lon][row]
+    lon_stride, row_stride = rps, 1
+    offs = np.arange(nslab, dtype=np.int64) * rps * nlon
+  ngroup = 2 * nslab
+  group = (np.arange(nslab)[:, None] * 2 + (np.arange(rps)[None, :] >= 20)).astype(np.int32).reshape(-1)
+  scale = rng.uniform(0.5, 2.0, size=nslab * rps)
+  g_dev, s_dev = torch.from_numpy(group).cuda(), torch.from_numpy(scale).cuda()
+  out = torch.full((ngroup, nlon // 2 + 1), 7.0, device='cuda', dtype=torch.float64)  # accumulate = 0 must overwrite it
+  torch.cuda.synchronize()
+  lib = ctx.lib
+
+  def call(accumulate):
+    if entry == 'rows':
+      _hip.check(lib.wbx_zonal_spectrum(ctx.handle, dev.data_ptr(), lon_stride, row_stride, rps, nlon, g_dev.data_ptr(),
+                                        s_dev.data_ptr(), ngroup, accumulate, out.data_ptr()), 'wbx_zonal_spectrum')
+    else:
+      _hip.check(lib.wbx_zonal_spectrum_slabs(ctx.handle, dev.data_ptr(), lon_stride, row_stride, rps, nslab,
+                                              offs.ctypes.data_as(C.c_void_p), nlon, g_dev.data_ptr(), s_dev.data_ptr(), ngroup,
+                                              accumulate, out.data_ptr()), 'wbx_zonal_spectrum_slabs')
+  call(0)
+  ctx.synchronize()
+  per_row = O.zonal_power_spectrum(vals.reshape(-1, nlon)) * scale[:, None]
+  want = np.zeros((ngroup, nlon // 2 + 1))
+  np.add.at(want, group, per_row)
+  got = out.cpu().numpy()
+  bound = 2e-5 * want + 4e-7 * np.sqrt(want.max(axis=-1, keepdims=True) * want)
+  assert float(np.max(np.abs(got - want) / bound)) <= 1.0
+  call(1)
+  ctx.synchronize()
+  np.testing.assert_allclose(out.cpu().numpy(), 2 * got, rtol=1e-12)

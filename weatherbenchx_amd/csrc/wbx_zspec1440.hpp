@@ -85,8 +85,10 @@ __device__ __forceinline__ void z14_store(v4* p, C2 a) {
 // (PROF), the latitude-fastest one issues a part of the next run's global loads at 0, 2, 4.
 // KNOCK (diagnostic instantiations, wrong results): 2 = the exchange stores are dropped, 4 = their loads too (register
 // values are passed on), 8 = no unpack arithmetic.
+// (`buf` must NOT be __restrict__: c.rd5 / c.wr5 point into it -- with the qualifier the compiler moved pass-2 loads above
+// the pass-1 stores.)
 template <int KNOCK, typename At>
-__device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* __restrict__ buf, const Z14Lane& c, const float2* __restrict__ tw1,
+__device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
                                          double (&acc)[12], double& acc_ny, double* __restrict__ power, At&& at) {
   constexpr int nk = Z14_N2 + 1;
