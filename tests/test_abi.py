@@ -55,3 +55,15 @@ def test_product_code_never_imports_the_oracle():
       if f.endswith('.py'):
         src = open(os.path.join(dirpath, f)).read()
         assert 'from oracle' not in src and 'import oracle' not in src, f'{f} imports the oracle'
+
+
+def test_makefile_lists_every_header_as_a_dependency():
+  """A header missing from HDRS is edited without the objects being rebuilt (that is how a broken kernel once shipped
+  behind green tests: the tests had run against the previous build)."""
+  import glob
+  import re
+  csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'weatherbenchx_amd', 'csrc')
+  text = open(os.path.join(csrc, 'Makefile')).read()
+  hdrs = set(re.search(r'^HDRS := (.*)$', text, re.M).group(1).split())
+  for h in glob.glob(os.path.join(csrc, '*.hpp')):
+    assert os.path.basename(h) in hdrs, h
