@@ -562,7 +562,8 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   if (knock == 1) WBX_Z14LF_LAUNCH(1);
   else if (knock == 2) WBX_Z14LF_LAUNCH(2);
   else if (knock == 3) WBX_Z14LF_LAUNCH(3);
-  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, false>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
+  else if (knock == 9) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 1>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // a quarter of the loads in front of pass 1, none behind the unpack
+  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
 
   else WBX_Z14LF_LAUNCH(0);
 #undef WBX_Z14LF_LAUNCH

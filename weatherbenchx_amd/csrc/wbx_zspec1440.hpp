@@ -315,7 +315,7 @@ typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
 // PROF: wave 0 of every block adds its cycles per step to prof[1..6] (wait at the first barrier | staging stores + second
 // barrier | issue of the next run's loads | pass-1 loads from the LDS | the three passes and the unpack), steps to prof[0].
 // KNOCK (diagnostic, wrong results): 1 = no global loads, 2 = no passes (the staged data is only summed)
-template <bool PROF, int KNOCK = 0, bool SPREAD = true>
+template <bool PROF, int KNOCK = 0, int SPREAD = 2>
 __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
     int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g, const int32_t* __restrict__ group,
@@ -475,14 +475,19 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
         for (int a = 0; a < 12; ++a) acc[a] += (double)(v[a].re.x + v[a].im.y) * sca;
         if (more) load_run(on, rn);
       } else {
-        if constexpr (!SPREAD) {
+        // SPREAD: where the next run's loads are issued -- 0 one burst in front of the passes, 1 a quarter in front and one
+        // behind the stores of each pass, 2 a quarter behind each pass's stores and the last behind the unpack (production);
+        // configs[3]: 0.498 / 0.390 / 0.382 ms per field
+        if constexpr (SPREAD == 0) {
           if (more) load_run(on, rn);
-        } else {
+        } else if constexpr (SPREAD == 1) {
           if (more) load_part(on, rn, 0);
         }
         z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int i) {
-          if constexpr (SPREAD) {  // parts 1..3 behind the stores of passes 1, 2, 3 (nothing behind the unpack: the next step
-            if (more && !(i & 1) && i < 6) load_part(on, rn, i / 2 + 1);  // starts by storing them)
+          if constexpr (SPREAD == 1) {
+            if (more && !(i & 1) && i < 6) load_part(on, rn, i / 2 + 1);
+          } else if constexpr (SPREAD == 2) {
+            if (more && (!(i & 1) || i == 5)) load_part(on, rn, i == 5 ? 3 : i / 2);
           }
         });
       }
