@@ -492,6 +492,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
     case 8: WBX_Z14_LAUNCH(8); break;
     case 14: WBX_Z14_LAUNCH(14); break;
     case 15: WBX_Z14_LAUNCH(15); break;
+    case 17: hipLaunchKernelGGL((zspec1440_kernel<false, 0, true, true>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // loads in front of pass 1
     case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
     default: WBX_Z14_LAUNCH(0); break;
   }
