@@ -303,13 +303,15 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 // slab sits at slab + j * lon_stride + r, so the two rows of a pair are ADJACENT floats and one 8-byte load delivers
 // (A[j], B[j]) -- exactly one half (re or im, rows A and B) of the packed point m = j / 2.  A block takes a run of <= 24
 // adjacent rows of one slab = one row pair per team: its 768 threads read the 1440 x (<= 96 byte) segments with
-// consecutive threads on consecutive pairs of a longitude, one step ahead into registers, and store them into the
-// teams' LDS buffers (element j of team t's buffer = the 8 bytes of longitude j: already the pass-1 layout); the teams
-// then run the same three passes with pass 1 reading the LDS instead of global memory.  One pass over the field, no
-// transposed scratch (the generic route: transpose_rows_kernel + fused kernel = three passes).
+// consecutive threads on consecutive pairs of a longitude, one step ahead into registers (a quarter of the loads behind
+// each pass's stores and behind the unpack: all twelve waves leave a barrier together, and one burst of 23 loads per
+// thread is 9 K cycles of texture-addresser time in front of the passes), and store them into the teams' LDS buffers at
+// the start of the next step (element j of team t's buffer = the 8 bytes of longitude j: already the pass-1 layout);
+// the teams then run the same three passes with pass 1 reading the LDS instead of global memory.  One pass over the
+// field, no transposed scratch (the generic route: transpose_rows_kernel + fused kernel = three passes).
 // The 96-byte segments do not line up with the 128-byte lines, so a line is shared with the neighbouring runs of rows:
-// the runs of one slab are spread over the blocks of ONE XCD in the same step (blockIdx & 7 = XCD, slab o -> XCD o mod 8),
-// which all move at the same pace, so the line's other users find it in that XCD's L2.
+// the runs of a slab go to the blocks of ONE XCD (blockIdx & 7; an XCD owns a contiguous eighth of the slabs) at about
+// the same time, so the line's other users find it in that XCD's L2 (FETCH_SIZE x 2 = 1.06-1.10 x the field).
 constexpr int Z14_TEAMS = 12;                 // teams (row pairs) of a latitude-fastest block
 constexpr int Z14_RUN = 2 * Z14_TEAMS;        // rows of a run
 constexpr int Z14_BUFL = 733;                 // v4 elements between the team buffers (odd: the staging stores of one
@@ -318,16 +320,16 @@ constexpr int Z14_STAGE = (Z14_N * Z14_TEAMS + 64 * Z14_TEAMS - 1) / (64 * Z14_T
 
 typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
 
-// grid = 8 * (blocks per XCD); runs_per_slab >= ceil(rps / 24) and rps = run_base * runs_per_slab + run_rem; row i of slab o is
-// row o * rps + i of group / scale
+// grid = 8 * (blocks per XCD); runs_per_slab >= ceil(rps / 24) and rps = run_base * runs_per_slab + run_rem; row i of slab o
+// is row o * rps + i of group / scale
 // PROF: wave 0 of every block adds its cycles per step to prof[1..6] (wait at the first barrier | staging stores + second
 // barrier | issue of the next run's loads | pass-1 loads from the LDS | the three passes and the unpack), steps to prof[0].
 // KNOCK (diagnostic, wrong results): 1 = no global loads, 2 = no passes (the staged data is only summed)
 template <bool PROF, int KNOCK = 0, int SPREAD = 2>
 __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
-    int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g, const int32_t* __restrict__ group,
-    const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
+    int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g,
+    const int32_t* __restrict__ group, const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
   float2* const tw2 = tw1 + Z14_TW1;
