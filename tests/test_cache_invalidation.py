@@ -206,3 +206,32 @@ def test_group_grows_from_det3_to_det6_between_aggregations(backend):
   want = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p['v'].copy()}, {'v': t['v'].copy()})
   for k in want:
     np.testing.assert_allclose(got[k].values, want[k].values, rtol=1e-12)
+
+
+def test_climatology_index_tables_follow_the_time_labels(backend):
+  """The (dayofyear, hour) index tables are reused between chunks with the same time labels (metrics/base.py): a chunk with
+  other init times, the same shapes and the same climatology object must read other climatology slots."""
+  rng = np.random.default_rng(4)
+  lead = (np.arange(2) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  dims = ('init_time', 'lead_time', 'latitude', 'longitude')
+  cdims = ('dayofyear', 'hour', 'latitude', 'longitude')
+  cv = rng.normal(size=(366, 4, 32, 64)).astype(np.float32)
+  clim = xr.Dataset({'v': xr.DataArray(cv, dims=cdims, coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'latitude': LAT, 'longitude': LON})})
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'])
+  metrics = {'act': deterministic.PredictionActivity(clim)}
+  pv = rng.normal(size=(2, 2, 32, 64)).astype(np.float32)
+
+  def run(first_day):
+    init = np.array([f'2020-01-{first_day:02d}T00', f'2020-01-{first_day + 1:02d}T00'], dtype='datetime64[ns]')
+    coords = {'latitude': LAT, 'longitude': LON, 'init_time': init, 'lead_time': lead}
+    p = xr.DataArray(pv, dims=dims, coords=coords)
+    got = aggregation.compute_metric_values_for_single_chunk(metrics, agg, {'v': p}, {'v': p})['act.v']
+    vt = init[:, None] + lead[None, :]
+    c, _ = O.align_climatology(clim['v'].values, cdims, vt, ('init_time', 'lead_time'))
+    sws, sw, _ = O.aggregate(O.squared_prediction_anomaly(pv, c), dims, ['init_time', 'latitude', 'longitude'])
+    np.testing.assert_allclose(got.values, np.sqrt(sws / sw), rtol=1e-6)
+  run(1)
+  run(1)   # served from the table cache
+  run(11)  # other labels, same shapes
+  run(1)

@@ -318,12 +318,13 @@ class Aggregator:
 
     pending = engine.deferred_active() is not None
 
+    perm = tuple(out_dims.index(d) for d in final_dims)
+
     def wrap(arr):  # (`values[lane, ...]`: the ellipsis keeps a 0-d result a view instead of a scalar copy)
-      da = xr.DataArray(np.asarray(arr, dtype=np.float64), dims=out_dims)
-      da = da.transpose(*final_dims)
+      view = np.asarray(arr, dtype=np.float64).transpose(perm)
       # deferred: keep the (possibly strided) view of the buffer the GPU is still writing / accumulating -- no reads here
-      data = da.data if pending else np.array(da.values, order="C", copy=True)
-      return xr.DataArray(data, dims=final_dims, coords=coords, name=stat.name, attrs=stat.attrs, _raw_coords=True)
+      data = view if pending else np.array(view, order="C", copy=True)
+      return xr.DataArray._assemble(data, final_dims, coords, name=stat.name, attrs=stat.attrs)  # pylint: disable=protected-access
 
     if scale != 1.0:
       if pending:  # the factor is applied when the numbers are read (or after the accumulators have been reduced)

@@ -395,6 +395,18 @@ class DataArray:
     return self.values.item()
 
   # ---- construction helpers ----------------------------------------------------------------------
+  @classmethod
+  def _assemble(cls, data, dims, raw_coords, name=None, attrs=None):
+    """Internal constructor for results whose pieces are already consistent: `data` has len(dims) axes and every entry
+    of `raw_coords` is a (dims, values) pair over a subset of `dims` (no validation, no coordinate normalisation)."""
+    out = cls.__new__(cls)
+    out._data = data
+    out._dims = tuple(dims)
+    out.name = name
+    out.attrs = dict(attrs) if attrs else {}
+    out._coords = dict(raw_coords)
+    return out
+
   def _replace(self, data=None, dims=None, coords=None, name='__keep__'):
     out = DataArray.__new__(DataArray)
     out._data = self.data if data is None else data
