@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   }
 }
 
-// WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_PD = rows in flight per wave (2 / 4); WBX_ATOMS_NT=0/1 pins the non-temporal hint
+// WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_NT=0/1 pins the non-temporal hint
 static int atoms_setting(const char* name, int dflt) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : dflt;
@@ -495,7 +495,6 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   static const int use_atoms = atoms_setting("WBX_BINNED_ATOMS", 1);
-  static const int atoms_pd = atoms_setting("WBX_ATOMS_PD", 4);
   // the atom kernel addresses a row as (uniform base) + (32-bit lane offset)
   bool atoms = use_atoms != 0;
   for (int i = 0; i < WBX_MAX_INPUTS; ++i)
@@ -519,11 +518,9 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
       if (nt) WBX_ATOMS_LAUNCH_NT(PDV, WMV, true);                    \
       else WBX_ATOMS_LAUNCH_NT(PDV, WMV, false);                      \
     } while (0)
-    if (atoms_pd <= 2) {
-      if (wmode == 1) WBX_ATOMS_LAUNCH(2, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(2, 2); else WBX_ATOMS_LAUNCH(2, 0);
-    } else {
-      if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
-    }
+    // (4 rows in flight per wave; 2 / 4 / 8 were measured 0.61 / 0.59 / 0.63 ms and the variants dropped: they doubled the
+    // 144 instantiations of this kernel and the build time of this file)
+    if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
 #undef WBX_ATOMS_LAUNCH_NT
 #undef WBX_ATOMS_LAUNCH
 #undef g
