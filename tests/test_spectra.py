@@ -222,3 +222,22 @@ def test_1440_point_rows_random_shapes_and_reductions(backend, seed):
   bound = 2e-5 * want + 4e-7 * np.sqrt(want.max(axis=-1, keepdims=True) * want)
   worst = float(np.max(np.abs(got - want) / bound))
   assert got.shape == want.shape and worst <= 1.0, (shape, layout, reduce_dims, weighted, worst)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_1440_point_rows_nan_stays_in_its_row(backend, layout):
+  """A NaN anywhere in a row makes that row's whole spectrum NaN (as numpy.fft does) and nothing else: the two rows of a
+  pair share every packed instruction, their values must not mix."""
+  rng = np.random.default_rng(7)
+  nlat, nlon = 9, 1440
+  vals = rng.normal(size=(nlat, nlon)).astype(np.float32)
+  vals[2, 77] = np.nan   # row 2 = row A of the pair (2, 3)
+  vals[5, 1439] = np.nan  # row 5 = row B of the pair (4, 5)
+  dims = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+  arr = vals if layout == 'lon_fastest' else np.ascontiguousarray(vals.T)
+  f = _field(arr, dims, lat=np.linspace(-80, 80, nlat), lon=np.arange(nlon) * 0.25)
+  s = np.asarray(spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v'].transpose('latitude', 'zonal_wavenumber').values)
+  bad = np.isnan(s).all(axis=1)
+  assert list(np.nonzero(bad)[0]) == [2, 5] and not np.isnan(s[~bad]).any()
+  want = O.zonal_power_spectrum(vals[~bad])
+  np.testing.assert_allclose(s[~bad], want, rtol=2e-4, atol=1e-6 * want.max())
