@@ -241,3 +241,24 @@ def test_1440_point_rows_nan_stays_in_its_row(backend, layout):
   assert list(np.nonzero(bad)[0]) == [2, 5] and not np.isnan(s[~bad]).any()
   want = O.zonal_power_spectrum(vals[~bad])
   np.testing.assert_allclose(s[~bad], want, rtol=2e-4, atol=1e-6 * want.max())
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_1440_point_rows_agree_with_the_rocfft_route(backend, monkeypatch, layout):
+  """An independent implementation of the same definition: the batched R2C rocFFT route (WBX_SPECTRUM_PATH=rocfft) against
+  the one-wave kernels on the same 1440-point field; both are single precision, so they agree to the fp32 bound of either."""
+  rng = np.random.default_rng(11)
+  shape = {'lead_time': 2, 'level': 2, 'latitude': 13, 'longitude': 1440}
+  dims = ('lead_time', 'level', 'latitude', 'longitude') if layout == 'lon_fastest' else \
+      ('lead_time', 'level', 'longitude', 'latitude')
+  vals = (rng.normal(size=[shape[d] for d in dims]) + 1.0).astype(np.float32)
+  f = _field(vals, dims, lat=np.linspace(-80, 80, 13), lon=np.arange(1440) * 0.25)
+  rd = tuple(d for d in dims if d != 'longitude')
+
+  def run():
+    return np.asarray(spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v'].transpose(*rd, 'zonal_wavenumber').values)
+  fused = run()
+  monkeypatch.setenv('WBX_SPECTRUM_PATH', 'rocfft')
+  library = run()
+  bound = 4e-5 * library + 8e-7 * np.sqrt(library.max(axis=-1, keepdims=True) * library)
+  assert float(np.max(np.abs(fused - library) / bound)) <= 1.0
