@@ -171,14 +171,14 @@ def kernel_roofline(name, ms, nbytes, traffic=None):
           'traffic': traffic}
 
 
-def pmc_traffic(kernel_key, enabled=True):
+def pmc_traffic(kernel_key, enabled=True, variant=None):
   """HBM traffic per launch from the separate rocprofv3 --pmc passes of this same command (FETCH_SIZE x2 on gfx950,
   + WRITE_SIZE), committed under profiles/ -- PMC collection cannot run inside the timed process."""
   import glob
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
   if not files or not enabled:
     return None
-  entry = json.load(open(files[-1])).get(kernel_key.split(' (')[0])
+  entry = json.load(open(files[-1])).get(kernel_key.split(' (')[0] + (f'@{variant}' if variant else ''))
   return None if not entry else entry.get('traffic_bytes_per_launch')
 
 
@@ -355,7 +355,7 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   out = {'workload': describe, 'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
          'metrics': list(emetrics),
          'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4,
-                                     pmc_traffic(kname, nlead == 8 and not args.small)),
+                                     pmc_traffic(kname, nlead in (8, 37) and not args.small, '37L' if name == 'rmse_crps_37L' else None)),
          'pairwise_form': (kernel_roofline('EnsOpF32<51,true,PAIRWISE> (use_sort=False)', float(np.mean([e['ms'] for e in plog])),
                                            epoints * (m + 1) * 4) if plog else None),
          'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
@@ -418,8 +418,8 @@ def public_chunk_leg(env):
           'roofline': dict(kernel_roofline('wbx_det_binned (memset + det_atoms_kernel + slot kernel for overflow patches + finish)',
                                            k_ms, ppoints * 12,
                                            pmc_traffic(f"det_atoms_kernel<float,DET6,MM=0,PD=4,WM={2 if args.layout == 'lon_fastest' else 1}>",
-                                                       not args.small and args.layout == 'lat_fastest')),
-                           traffic_note='PMC pass of tools/kbench_binned.py (latitude-fastest chunk), main kernel only'),
+                                                       not args.small)),
+                           traffic_note='PMC pass of the main kernel only (bench.py public_chunk leg / tools/kbench_binned.py)'),
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
 
 

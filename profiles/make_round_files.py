@@ -37,6 +37,9 @@ with open(out('kernel_stats.csv'), 'w', newline='') as f:
 
 def bench_key(name: str) -> str:
   """rocprofv3's demangled name -> the label bench.py prints (template arguments spelled out)."""
+  if '@' in name:  # launch-size variant of a kernel (tools/profile_round.sh): the suffix rides along
+    base, suffix = name.rsplit('@', 1)
+    return bench_key(base) + '@' + suffix
   n = name.replace('wbx::', '')
   n = re.sub(r'DetOp<float, 1, \d>', 'DetOp<float,DET6>', n)
   n = re.sub(r'EnsOpF32<51, true, 0>', 'EnsOpF32<51,true,SORT>', n)

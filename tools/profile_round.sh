@@ -22,6 +22,8 @@ timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o r1 -- p
 timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o r1 -- python $R/bench.py --steps 2 --warmup 1 --legs main,ensemble,public_chunk,spectrum > /dev/null 2>&1
 timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_lat -o r1 -- python $R/bench.py --layout lat_fastest --steps 2 --warmup 1 --legs main > /dev/null 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_public_chunk -o r1 -- python $R/tools/kbench_binned.py lat_fastest 3 > /dev/null 2>&1
+timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_37L -o r1 -- python $R/bench.py --steps 2 --warmup 1 --legs rmse_crps_37L > /dev/null 2>&1
+timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_37L -o r1 -- python $R/bench.py --steps 2 --warmup 1 --legs rmse_crps_37L > /dev/null 2>&1
 timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_spectrum_lat -o r1 -- python $R/bench.py --layout lat_fastest --steps 2 --warmup 1 --legs spectrum > /dev/null 2>&1
 timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_spectrum_lat -o r1 -- python $R/bench.py --layout lat_fastest --steps 2 --warmup 1 --legs spectrum > /dev/null 2>&1
 DBS=$(ls $O/*/r1_results.db 2>/dev/null)
@@ -38,8 +40,9 @@ for db in sorted(glob.glob('$O/pmc_*/r1_results.db')):
     out.setdefault('_errors', []).append(f'{db}: {e}')
     continue
   for k, c, n, v in rows:
-    e = out.setdefault(k.replace('void ', '').split('(')[0], {})
     run = db.split('/')[-2]
+    suffix = '@37L' if run.endswith('_37L') else ''  # (the north_star field: same kernel, its own launch size)
+    e = out.setdefault(k.replace('void ', '').split('(')[0] + suffix, {})
     if c == 'FETCH_SIZE':
       e.update({'FETCH_SIZE_KiB_avg': v, 'launches': n, 'hbm_read_bytes': v * 1024 * 2, 'fetch_run': run})
     elif c == 'WRITE_SIZE':
