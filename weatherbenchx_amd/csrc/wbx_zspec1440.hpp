@@ -16,8 +16,8 @@
 // address and twiddle index of a lane is a loop-invariant register or an immediate offset, and there is no barrier: a
 // wave's LDS instructions execute in order.  As in the generic kernel two rows share every instruction (C2 = the same
 // point of rows A and B in one packed-fp32 register pair), the next pair's 24 loads are issued behind pass 1's stores,
-// and |X_k|^2 * scale is accumulated in fp64 registers (lane L owns k = L + 60 s) and flushed
-// with fp64 atomics when the row group changes.
+// and |X_k|^2 * scale is accumulated in fp64 registers (lane L owns k = L + 60 s, s < 6, and their mirrors 720 - k: one
+// Hermitian unpack yields both) and flushed with fp64 atomics when the row group changes.
 //
 // Included by wbx_spectrum.hip (inside namespace wbx, after C2 / butterfly<R>).
 #pragma once
@@ -54,6 +54,7 @@ struct Z14Lane {  // what a lane keeps for the whole launch: every LDS address /
   v4* wr5;            //         stores at + 240 i + 12 q
   const float2* tw5;  //         twiddles at + 4 i + 12 (q - 1)
   int mir0;           // mirror of k = L + 60 s is mir0 - 60 s (s = 0: 0 for L = 0)
+  int k0;             // the lane's first wavenumber in the unpack: L, or 360 on lane 60 (see z14_pair)
 };
 
 __device__ __forceinline__ Z14Lane z14_lane(int lane, v4* buf, const float2* tw2) {
@@ -66,6 +67,7 @@ __device__ __forceinline__ Z14Lane z14_lane(int lane, v4* buf, const float2* tw2
   c.wr5 = buf + d0_5 * 60 + k1_5;
   c.tw5 = tw2 + d0_5;
   c.mir0 = c.L == 0 ? 0 : Z14_N2 - c.L;
+  c.k0 = lane == Z14_LANES ? Z14_N2 / 2 : c.L;
   return c;
 }
 
@@ -78,8 +80,25 @@ __device__ __forceinline__ void z14_store(v4* p, C2 a) {
     st_c2(p, a);
 }
 
+// A lane's twelve sums go to k = L + 60 s (acc) and 720 - L - 60 s (accm), s < 6; lane 60 owns k = 360 (acc[0]).
+// weight = true applies S_k = |F_k|^2 * (k == 0 ? 1 : 2) (include/wbx.h); the block table of the latitude-fastest kernel
+// takes the raw sums.
+template <bool WEIGHT>
+__device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const double (&acc)[6], const double (&accm)[6]) {
+  if (c.lane < Z14_LANES) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      unsafeAtomicAdd(out + c.L + 60 * s, (!WEIGHT || (s == 0 && c.L == 0)) ? acc[s] : 2.0 * acc[s]);
+      unsafeAtomicAdd(out + Z14_N2 - c.L - 60 * s, WEIGHT ? 2.0 * accm[s] : accm[s]);
+    }
+  } else if (c.lane == Z14_LANES) {
+    unsafeAtomicAdd(out + Z14_N2 / 2, WEIGHT ? 2.0 * acc[0] : acc[0]);
+  }
+}
+
 // One row pair: passes 1-3 on v (the pass-1 inputs), the mirror exchange and the Hermitian unpack; adds scale * |X_k|^2
-// into acc / acc_ny (row B straight into `power` when the pair straddles two groups).
+// into acc (k = L + 60 s, s < 6; lane 60: k = 360 in slot 0) and accm (720 - k) -- row B straight into `power` when the pair
+// straddles two groups.
 // at(i) is called at six points: 0 pass 1 has issued its stores | 1 pass 2 has its loads | 2 pass 2 has issued its stores |
 // 3 pass 3 has its loads | 4 the mirror stores are issued | 5 done.  The longitude-fastest kernel stamps the clock there
 // (PROF), the latitude-fastest one issues a part of the next run's global loads at 0, 2, 4.
@@ -90,7 +109,7 @@ __device__ __forceinline__ void z14_store(v4* p, C2 a) {
 template <int KNOCK, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
-                                         double (&acc)[12], double& acc_ny, double* __restrict__ power, At&& at) {
+                                         double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at) {
   constexpr int nk = Z14_N2 + 1;
   constexpr bool DROP = (KNOCK & 2) != 0;
   const int L = c.L;
@@ -133,32 +152,45 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
   __builtin_amdgcn_wave_barrier();
   at(4);
   // Hermitian unpack: X_k = E_k + W^k O_k, W = exp(-2 pi i / 1440), 2 E_k = Z_k + conj Z_{720-k},
-  // 2 O_k = -i (Z_k - conj Z_{720-k});  X_720 = conj(E_0 - O_0).  |X|^2 in packed fp32 (as the transform), fp64 sums.
+  // 2 O_k = -i (Z_k - conj Z_{720-k}), and the mirror from the same two points: X_{720-k} = conj(E_k - W^k O_k).  A lane
+  // therefore takes only the FIRST six of its wavenumbers, k = L + 60 s (s < 6), with their mirrors 720 - k -- which are
+  // the last six wavenumbers of lane 60 - L (of lane 0 itself, and the Nyquist wavenumber 720 for k = 0): half the mirror
+  // loads, twiddle loads and twiddle products of taking all twelve.  Only k = 360 (its own mirror, lane 0's s = 6) is
+  // left over: the otherwise idle lane 60 takes it in its s = 0 slot.  |X|^2 in packed fp32 (as the transform), fp64 sums.
+  const bool self360 = c.lane == Z14_LANES;
+  const C2 z360 = ld_c2(buf + Z14_N2 / 2);
 #pragma unroll
-  for (int s = 0; s < 12; ++s) {
-    const C2 zk = v[s];
-    const C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+  for (int s = 0; s < 6; ++s) {
+    C2 zk = v[s];
+    C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+    if (s == 0) {
+      zk.re = self360 ? z360.re : zk.re;
+      zk.im = self360 ? z360.im : zk.im;
+      zc.re = self360 ? z360.re : zc.re;
+      zc.im = self360 ? z360.im : zc.im;
+    }
     const C2 e = {zk.re + zc.re, zk.im - zc.im};
     const C2 o = {zk.im + zc.im, zc.re - zk.re};
-    const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[L + 60 * s]);
-    const C2 x = cadd(e, wo);
-    const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;  // (row A, row B)
+    const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[s == 0 ? c.k0 : L + 60 * s]);
+    const C2 x = cadd(e, wo), xm = csub(e, wo);
+    const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;      // (row A, row B) of k
+    const v2 pm = (KNOCK & 8) ? xm.re : xm.re * xm.re + xm.im * xm.im;  // ... of 720 - k
     if (split) {
       acc[s] = fma((double)p.x, sca, acc[s]);
-      if (c.lane < Z14_LANES)
+      accm[s] = fma((double)pm.x, sca, accm[s]);
+      if (c.lane < Z14_LANES) {
         unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 - L - 60 * s], (double)pm.y * scb * 2.0);
+      } else if (self360 && s == 0) {
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 / 2], (double)p.y * scb * 2.0);
+      }
     } else {
-      if constexpr (KNOCK & 8) acc[s] += (double)(p.x + p.y);
-      else acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
-    }
-    if (s == 0) {
-      const C2 xm = csub(e, wo);
-      const v2 pm = xm.re * xm.re + xm.im * xm.im;
-      if (split) {
-        acc_ny = fma((double)pm.x, sca, acc_ny);
-        if (c.lane == 0) unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2], (double)pm.y * scb * 2.0);
+      if constexpr (KNOCK & 8) {
+        acc[s] += (double)(p.x + p.y);
+        accm[s] += (double)(pm.x + pm.y);
       } else {
-        acc_ny = fma((double)pm.x, sca, fma((double)pm.y, scb, acc_ny));
+        acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+        accm[s] = fma((double)pm.x, sca, fma((double)pm.y, scb, accm[s]));
       }
     }
   }
@@ -199,20 +231,14 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
 
-  double acc[12], acc_ny = 0.0;  // k = L + 60 s; lane 0 also owns the Nyquist wavenumber k = 720
+  double acc[6], accm[6];  // sums of k = L + 60 s and of 720 - k (z14_send)
 #pragma unroll
-  for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+  for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
   int32_t cur = group[r0];
   auto flush = [&](int32_t next) {
-    if (lane < Z14_LANES) {
-      double* const out = power + (int64_t)cur * nk + L;
+    z14_send<true>(power + (int64_t)cur * nk, c, acc, accm);
 #pragma unroll
-      for (int s = 0; s < 12; ++s) unsafeAtomicAdd(out + 60 * s, (s == 0 && L == 0) ? acc[s] : 2.0 * acc[s]);
-      if (L == 0) unsafeAtomicAdd(out + Z14_N2, 2.0 * acc_ny);  // S_k = |F_k|^2 * (k == 0 ? 1 : 2), include/wbx.h
-    }
-#pragma unroll
-    for (int s = 0; s < 12; ++s) acc[s] = 0.0;
-    acc_ny = 0.0;
+    for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
     cur = next;
   };
 
@@ -267,7 +293,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     if (ga != cur) flush(ga);  // wave-uniform
     // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
     // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
-    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power,
+    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, power,
                            [&](int i) {
                              mark(i + 2, i == 1 || i == 3 || i == 5);
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads
@@ -404,26 +430,19 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
   double* const blk = reinterpret_cast<double*>(bufs + Z14_TEAMS * Z14_BUFL);
   for (int k = tid; k < nk; k += 64 * Z14_TEAMS) blk[k] = 0.0;
   int32_t blk_group = -1;  // block-uniform
-  double acc[12], acc_ny = 0.0;
+  double acc[6], accm[6];
 #pragma unroll
-  for (int s = 0; s < 12; ++s) acc[s] = 0.0;
+  for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
   int32_t cur = -1;
   auto dump = [&](int32_t next) {  // the team's sums of group `cur` -> the block's table, or straight out if that holds another group
-    if (cur >= 0 && lane < Z14_LANES) {
-      if (cur == blk_group) {
-#pragma unroll
-        for (int s = 0; s < 12; ++s) unsafeAtomicAdd(blk + L + 60 * s, acc[s]);
-        if (L == 0) unsafeAtomicAdd(blk + Z14_N2, acc_ny);
-      } else {
-        double* const out = power + (int64_t)cur * nk + L;
-#pragma unroll
-        for (int s = 0; s < 12; ++s) unsafeAtomicAdd(out + 60 * s, (s == 0 && L == 0) ? acc[s] : 2.0 * acc[s]);
-        if (L == 0) unsafeAtomicAdd(out + Z14_N2, 2.0 * acc_ny);
-      }
+    if (cur >= 0) {
+      if (cur == blk_group)
+        z14_send<false>(blk, c, acc, accm);
+      else
+        z14_send<true>(power + (int64_t)cur * nk, c, acc, accm);
     }
 #pragma unroll
-    for (int s = 0; s < 12; ++s) acc[s] = 0.0;
-    acc_ny = 0.0;
+    for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
     cur = next;
   };
   auto flush_block = [&](int32_t next) {  // every thread of the block; the callers put barriers around it
@@ -482,7 +501,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
       mark(4);
       if constexpr (KNOCK & 2) {
 #pragma unroll
-        for (int a = 0; a < 12; ++a) acc[a] += (double)(v[a].re.x + v[a].im.y) * sca;
+        for (int a = 0; a < 6; ++a) acc[a] += (double)(v[a].re.x + v[a + 6].im.y) * sca;
         if (more) load_run(on, rn);
       } else {
         // SPREAD: where the next run's loads are issued -- 0 one burst in front of the passes, 1 a quarter in front and one
@@ -493,7 +512,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
         } else if constexpr (SPREAD == 1) {
           if (more) load_part(on, rn, 0);
         }
-        z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, acc_ny, power, [&](int i) {
+        z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, power, [&](int i) {
           if constexpr (SPREAD == 1) {
             if (more && !(i & 1) && i < 6) load_part(on, rn, i / 2 + 1);
           } else if constexpr (SPREAD == 2) {
