@@ -76,7 +76,7 @@ traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pm
                     'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
                     '(gfx950 reports half of wide coalesced reads)')
 json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
-for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt',
+for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt', 'pmc_spectrum_lat_fastest.txt',
               'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt'):
   if os.path.exists(os.path.join(src, extra)):
     shutil.copy(os.path.join(src, extra), out(extra))

@@ -58,6 +58,7 @@ for d in trace_bench trace_bench_lat trace_rmse_crps_37L trace_config5 trace_pub
 ( cd $R/tools/ubench && for u in valu_rates lds_rates load_patterns clock_rate; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $u.hip -o $u 2>/dev/null; echo "== $u"; timeout 120 ./$u; done ) > $O/ubench.txt 2>&1
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
 ( cd $R && bash tools/pmc_spectrum.sh ) > $O/pmc_spectrum.txt 2>&1
+( cd $R && bash tools/pmc_spec_latfast.sh ) > $O/pmc_spectrum_lat_fastest.txt 2>&1
 ( cd $R && python tools/spec_phase_profile.py 2>&1 | grep -v amdgpu.ids ) > $O/spectrum_phase_profile.txt 2>&1
 ( cd $R && for l in lon_fastest lat_fastest; do python tools/kbench_spectrum_raw.py 8 $l sorted 2>&1 | grep -v amdgpu.ids | sed "s/^/$l /"; done ) > $O/spectrum_raw.txt 2>&1
 ( cd $R && bash tools/pmc_binned.sh lon_fastest | grep -v rocprofv3 ) > $O/pmc_binned_lon_fastest.txt 2>&1
