@@ -424,6 +424,18 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
 
 #include "wbx_zspec1440.hpp"
 
+// WBX_SPECTRUM_KNOCK selects diagnostic instantiations whose RESULTS ARE WRONG by design (timing only): said once, loudly.
+static int spectrum_knock() {
+  static const int knock = [] {
+    const char* e = getenv("WBX_SPECTRUM_KNOCK");
+    const int k = e ? atoi(e) : 0;
+    if (k != 0)
+      fprintf(stderr, "libwbx_hip: WBX_SPECTRUM_KNOCK=%d -- diagnostic spectrum kernels are in use, their results are not valid\n", k);
+    return k;
+  }();
+  return knock;
+}
+
 // Launches zspec1440_kernel: as many one-wave teams per block as the LDS holds (12: tables + 12 x 11.4 KB), one block per
 // CU, and -- every team takes the same time -- a grid of exactly `rounds` resident sets.
 static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t row_stride, int64_t nrows,
@@ -479,7 +491,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
     }
     return 0;
   }
-  static const int knock = getenv("WBX_SPECTRUM_KNOCK") ? atoi(getenv("WBX_SPECTRUM_KNOCK")) : 0;  // diagnostic, wrong results
+  const int knock = spectrum_knock();  // diagnostic, wrong results
 #define WBX_Z14_LAUNCH(KN)                                                                                                 \
   hipLaunchKernelGGL((zspec1440_kernel<false, KN>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, \
                      rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out,                         \
@@ -537,7 +549,7 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     if (!prof) WBX_HIP(hipMalloc(reinterpret_cast<void**>(&prof), sizeof(host)));
     WBX_HIP(hipMemcpyAsync(prof, host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
     WBX_HIP(hipStreamSynchronize(ctx->stream));
-    if (getenv("WBX_SPECTRUM_KNOCK") && atoi(getenv("WBX_SPECTRUM_KNOCK")) == 3)
+    if (spectrum_knock() == 3)
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 3>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
                          lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),
                          reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
@@ -555,7 +567,7 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     }
     return 0;
   }
-  static const int knock = getenv("WBX_SPECTRUM_KNOCK") ? atoi(getenv("WBX_SPECTRUM_KNOCK")) : 0;  // diagnostic, wrong results
+  const int knock = spectrum_knock();  // diagnostic, wrong results
 #define WBX_Z14LF_LAUNCH(KN)                                                                                               \
   hipLaunchKernelGGL((zspec1440_latfast_kernel<false, KN>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,  \
                      lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),                    \
