@@ -611,10 +611,30 @@ def cpu_leg(env, keep):
   return out
 
 
+_JSON_FD = None
+
+
+def _claim_stdout():
+  """stdout carries the ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for everything that prints on
+  its own (RCCL's version banner, gloo's rank messages, torch warnings written from C++), and the line goes out through a
+  private duplicate of the original descriptor."""
+  global _JSON_FD
+  if _JSON_FD is None:
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(result):
+  sys.stdout.flush()
+  os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(result) + '\n').encode())
+
+
 def main():
   args = parse()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-    sys.exit(self_launch(args))
+    sys.exit(self_launch(args))  # (the ranks inherit this process's stdout: rank 0 writes the line)
+  _claim_stdout()
   if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}")
   env = Env(args)
@@ -647,7 +667,7 @@ def main():
   if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu') and keep is not None:
     result['cpu_baseline'] = cpu_leg(env, keep)
   if env.rank == 0:
-    print(json.dumps(result))
+    _emit(result)
   if env.world > 1:
     env.dist.destroy_process_group()
 

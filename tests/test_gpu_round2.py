@@ -321,8 +321,9 @@ def _run_bench(*flags, timeout=600):
   res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags), capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
   assert res.returncode == 0, res.stderr[-3000:]
-  lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
-  assert len(lines) == 1, res.stdout[-2000:]  # exactly ONE JSON line
+  lines = [l for l in res.stdout.splitlines() if l.strip()]
+  # stdout is ONE JSON line and nothing else (library banners -- RCCL's version block, gloo's rank messages -- go to stderr)
+  assert len(lines) == 1 and lines[0].startswith('{'), res.stdout[-2000:]
   return json.loads(lines[0])
 
 
