@@ -393,11 +393,9 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
   // loader role: thread -> (team t_ld, longitudes j0 + 64 n); its 8 bytes of longitude j belong at element j of that team's buffer
   const int t_ld = tid % Z14_TEAMS, j0 = tid / Z14_TEAMS;
   v2* const stage_dst = reinterpret_cast<v2*>(bufs + t_ld * Z14_BUFL) + j0;
-  v2 held[Z14_STAGE];
-  if constexpr (KNOCK & 1) {
+  v2 held[Z14_STAGE];  // rows a short last run does not have stay at their previous (first: zero) value; nobody reads them
 #pragma unroll
-    for (int n = 0; n < Z14_STAGE; ++n) held[n] = (v2){1.f, 2.f};
-  }
+  for (int n = 0; n < Z14_STAGE; ++n) held[n] = (KNOCK & 1) ? (v2){1.f, 2.f} : (v2){0.f, 0.f};
   // part p of the run's loads: items [6 p, 6 p + 6) (p = 3: the rest).  All twelve waves of the block leave the barrier
   // together; 23 loads each at once is 7 us of texture-addresser time in front of the passes, spread over the passes they
   // run under the other waves' arithmetic.
