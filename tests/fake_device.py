@@ -247,6 +247,7 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_to_device', _to_device)
   monkeypatch.setattr(engine, '_mask_to_device', _mask_to_device)
   monkeypatch.setattr(engine, '_device_plan', lambda c, plan: plan)
+  monkeypatch.setattr(engine, '_swap_gather_table', lambda c, dplan, plan_v: plan_v)
   monkeypatch.setattr(engine, '_run_s1', _run_s1)
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)

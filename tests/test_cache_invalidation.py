@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import wbx_oracle as O
-from weatherbenchx_amd import aggregation, binning, weighting
+from weatherbenchx_amd import aggregation, binning, engine, planner, weighting
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base as metrics_base
 from weatherbenchx_amd.metrics import deterministic, probabilistic
@@ -208,7 +208,7 @@ def test_group_grows_from_det3_to_det6_between_aggregations(backend):
     np.testing.assert_allclose(got[k].values, want[k].values, rtol=1e-12)
 
 
-def test_climatology_index_tables_follow_the_time_labels(backend):
+def test_climatology_index_tables_follow_the_time_labels(backend, monkeypatch):
   """The (dayofyear, hour) index tables are reused between chunks with the same time labels (metrics/base.py): a chunk with
   other init times, the same shapes and the same climatology object must read other climatology slots."""
   rng = np.random.default_rng(4)
@@ -231,7 +231,14 @@ def test_climatology_index_tables_follow_the_time_labels(backend):
     c, _ = O.align_climatology(clim['v'].values, cdims, vt, ('init_time', 'lead_time'))
     sws, sw, _ = O.aggregate(O.squared_prediction_anomaly(pv, c), dims, ['init_time', 'latitude', 'longitude'])
     np.testing.assert_allclose(got.values, np.sqrt(sws / sw), rtol=1e-6)
+  builds = []
+  build = planner.build_s1_plan
+  monkeypatch.setattr(planner, 'build_s1_plan', lambda *a, **k: builds.append(1) or build(*a, **k))
+  engine._fast_plan_cache.clear()  # pylint: disable=protected-access
   run(1)
   run(1)   # served from the table cache
-  run(11)  # other labels, same shapes
+  run(11)  # other labels, same shapes: the cached plan with the climatology gather table swapped, not a new plan
   run(1)
+  run(21)
+  run(11)
+  assert len(builds) == 1, builds

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import dataclasses
 from typing import Sequence
 
 import numpy as np
@@ -163,6 +164,24 @@ class _PlanOnDevice:
     self.keep.append(buf)
     return buf.ptr
 
+  def with_gather_table(self, ctx, gtab: np.ndarray) -> '_PlanOnDevice':
+    """The same plan with another climatology gather table (same shape): every other table is shared.  The table is a few
+    hundred bytes; it goes up through page-locked memory on the context stream, so the host does not wait for the kernels
+    already enqueued (a blocking upload here would drain the chunk pipeline once per chunk)."""
+    other = object.__new__(_PlanOnDevice)
+    other.struct = type(self.struct).from_buffer_copy(self.struct)
+    gtab = np.ascontiguousarray(gtab, dtype=np.int64)
+    if hasattr(ctx, 'upload_async'):
+      src = ctx.pinned_empty(gtab.shape, np.int64)
+      src[...] = gtab
+      buf = ctx.upload_async(src)
+      other.keep = [self, src, buf]  # (src stays untouched for as long as this variant lives)
+    else:
+      buf = ctx.upload(gtab)
+      other.keep = [self, buf]
+    other.struct.gather_tab = buf.ptr
+    return other
+
 
 def _plan_signature(plan: planner.S1Plan):
   def h(t):
@@ -254,13 +273,24 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
 
 
 def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None):
-  """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads."""
+  """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads.
+
+  The climatology gather table is the one table that follows the chunk's time labels (every chunk of a streamed evaluation
+  has its own valid times): the signature holds its dims / shape / 16-byte alignment class only, and a chunk with new labels
+  gets the cached plan with that table swapped (`_PlanOnDevice.with_gather_table`) -- rebuilding and uploading the per-key
+  tables of a 20 lead x 37 level x 721 latitude chunk (533 540 keys) took 11-20 ms per chunk against 1.5 ms of kernels."""
+  gsig = gbytes = None
+  if gather is not None:
+    gtable = np.ascontiguousarray(gather.table, dtype=np.int64)
+    gsig = (tuple(gather.dims), gtable.shape, not bool(np.any(gtable % 4)))  # (vec = 4 needs every offset 16-B aligned)
+    gbytes = gtable.tobytes()
+    if not SWAP_GATHER_TABLES:
+      gsig += (gbytes,)
   sig = (id(ctx), kind, tuple(dims), tuple(sizes[d] for d in dims),
          None if x_weights is None else hash(x_weights.tobytes()),
          tuple(None if l is None else (tuple(sorted(l.strides.items(), key=str)), l.itemsize, l.base_alignment % 16 == 0)
                for l in layouts),
-         tuple(sorted(reduce_dims, key=str)), tuple(sorted(wdep, key=str)), flags,
-         None if gather is None else (tuple(gather.dims), gather.table.shape, hash(gather.table.tobytes())))
+         tuple(sorted(reduce_dims, key=str)), tuple(sorted(wdep, key=str)), flags, gsig)
   hit = _fast_plan_cache.get(sig)
   if hit is None:
     plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
@@ -271,11 +301,29 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
       plan.x_weights = np.ascontiguousarray(x_weights, dtype=np.float64)
     if len(_fast_plan_cache) > 64:
       _fast_plan_cache.clear()
-    hit = (plan, _device_plan(ctx, plan))
+    hit = (plan, _device_plan(ctx, plan), {'built': gbytes})  # + variants of the plan by gather table contents
     _fast_plan_cache[sig] = hit
-  return hit
+  plan, dplan, variants = hit
+  if gather is None or gbytes == variants['built']:
+    return plan, dplan
+  var = variants.get(gbytes)
+  if var is None:
+    gtab = planner.gather_table(plan.key_dims, plan.depth_dims, gather)
+    if len(variants) > GATHER_VARIANTS_MAX:  # (dropped device tables return to the context's pool: reuse is stream ordered)
+      built = variants['built']
+      variants.clear()
+      variants['built'] = built
+    plan_v = dataclasses.replace(plan, gather_tab=gtab)
+    var = variants[gbytes] = (plan_v, _swap_gather_table(ctx, dplan, plan_v))
+  return var
 
 
+def _swap_gather_table(ctx, dplan: _PlanOnDevice, plan_v: planner.S1Plan) -> _PlanOnDevice:
+  return dplan.with_gather_table(ctx, plan_v.gather_tab)
+
+
+SWAP_GATHER_TABLES = True  # False: a plan per gather table, as before (A/B timing: tools/bench_new_labels.py)
+GATHER_VARIANTS_MAX = 512  # climatology gather tables kept per cached plan (one per distinct set of time labels)
 _fast_plan_cache: dict = {}
 _thr_cache: dict = {}
 _count_cache: dict = {}

@@ -120,6 +120,17 @@ def _gather_index(dims: Sequence, sizes: dict, gdims: Sequence) -> tuple[np.ndar
   return np.ascontiguousarray(idx.reshape(-1).astype(np.int32)), n
 
 
+def gather_table(key_dims: Sequence, depth_dims: Sequence, gather: GatherSpec) -> np.ndarray:
+  """`gather.table` flattened to [gather-key combos][gather-depth combos], the order stage 1 indexes it in.  It is the
+  only table of a plan that follows the chunk's TIME LABELS (climatology alignment, deterministic.py:167-220): the engine
+  swaps it into a cached plan instead of rebuilding the plan for every chunk."""
+  kd = [d for d in key_dims if d in gather.dims]
+  dd = [d for d in depth_dims if d in gather.dims]
+  tab = np.asarray(gather.table, dtype=np.int64)
+  tab = np.transpose(tab, [gather.dims.index(d) for d in kd + dd])
+  return np.ascontiguousarray(tab.reshape(-1))
+
+
 def choose_x_dim(dims: Sequence, sizes: dict, layout: InputLayout, exclude=()):
   """The contiguous-most dim of the predictions (stride 1 preferred)."""
   cands = [d for d in dims if d not in exclude and sizes[d] > 1 and layout.stride(d) != 0]
@@ -184,12 +195,7 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
       raise ValueError(f'gather dim {x_dim!r} is the innermost dim; align the climatology on the host instead')
     gk, ngk = _gather_index(key_dims, sizes, gather.dims)
     gd, ngd = _gather_index(depth_dims, sizes, gather.dims)
-    # table reordered to [gather-key combos][gather-depth combos]
-    kd = [d for d in key_dims if d in gather.dims]
-    dd = [d for d in depth_dims if d in gather.dims]
-    tab = np.asarray(gather.table, dtype=np.int64)
-    tab = np.transpose(tab, [gather.dims.index(d) for d in kd + dd])
-    gtab = np.ascontiguousarray(tab.reshape(ngk * ngd))
+    gtab = gather_table(key_dims, depth_dims, gather)
 
   # launch geometry
   block_threads = 256
