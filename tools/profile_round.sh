@@ -55,12 +55,14 @@ PY
 for d in trace_bench trace_bench_lat trace_rmse_crps_37L trace_config5 trace_public_chunk trace_ens_regions trace_spectrum_lat; do cp $O/$d/r1_kernel_stats.csv $O/${d}_kernel_stats.csv 2>/dev/null; done
 # 4. the same-box read ceiling, and the SQ / memory-side counters of the ensemble and binned kernels (own --pmc passes)
 ( cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 read_stream.hip -o read_stream 2>/dev/null; timeout 120 ./read_stream ) > $O/read_stream.json 2>&1
-( cd $R/tools/ubench && for u in valu_rates lds_rates load_patterns clock_rate; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $u.hip -o $u 2>/dev/null; echo "== $u"; timeout 120 ./$u; done ) > $O/ubench.txt 2>&1
+( cd $R/tools/ubench && for u in valu_rates valu_ops lds_rates load_patterns clock_rate; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $u.hip -o $u 2>/dev/null; echo "== $u"; timeout 120 ./$u; done ) > $O/ubench.txt 2>&1
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
 ( cd $R && bash tools/pmc_spectrum.sh ) > $O/pmc_spectrum.txt 2>&1
 ( cd $R && bash tools/pmc_spec_latfast.sh ) > $O/pmc_spectrum_lat_fastest.txt 2>&1
 ( cd $R && python tools/spec_phase_profile.py 2>&1 | grep -v amdgpu.ids ) > $O/spectrum_phase_profile.txt 2>&1
 ( cd $R && for l in lon_fastest lat_fastest; do python tools/kbench_spectrum_raw.py 8 $l sorted 2>&1 | grep -v amdgpu.ids | sed "s/^/$l /"; done ) > $O/spectrum_raw.txt 2>&1
+( cd $R && python tools/config5_host_split.py 150 2>&1 | grep -v amdgpu.ids | tail -7 ) > $O/config5_host_split.txt 2>&1
+( cd $R && python tools/bench_new_labels.py 2>&1 | grep -v amdgpu.ids | tail -2 ) > $O/new_time_labels.txt 2>&1
 ( cd $R && bash tools/pmc_binned.sh lon_fastest | grep -v rocprofv3 ) > $O/pmc_binned_lon_fastest.txt 2>&1
 ( cd $R && bash tools/pmc_binned.sh lat_fastest | grep -v rocprofv3 ) > $O/pmc_binned_lat_fastest.txt 2>&1
 rm -rf $R/gpurun_out/pmc_ens $R/gpurun_out/pmc_spec $R/gpurun_out/pmc_binned_lon_fastest $R/gpurun_out/pmc_binned_lat_fastest
