@@ -309,10 +309,13 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
   var = variants.get(gbytes)
   if var is None:
     gtab = planner.gather_table(plan.key_dims, plan.depth_dims, gather)
-    if len(variants) > GATHER_VARIANTS_MAX:  # (dropped device tables return to the context's pool: reuse is stream ordered)
+    if len(variants) > GATHER_VARIANTS_MAX:
+      # start a new generation; the old one is kept (unused) until the next turnover, so that the page-locked source of a
+      # table whose upload is still queued on the stream is not handed out again under it
+      retired = {k: v for k, v in variants.items() if k not in ('built', 'retired')}
       built = variants['built']
       variants.clear()
-      variants['built'] = built
+      variants['built'], variants['retired'] = built, retired
     plan_v = dataclasses.replace(plan, gather_tab=gtab)
     var = variants[gbytes] = (plan_v, _swap_gather_table(ctx, dplan, plan_v))
   return var
