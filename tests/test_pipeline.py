@@ -62,6 +62,32 @@ def test_chunked_equals_single_chunk(backend, reduce_dims):
                             (state.sum_weighted_statistics, state.sum_weights))
 
 
+@pytest.mark.parametrize('reduce_dims', [['init_time', 'latitude'], ['init_time', 'lead_time', 'latitude'], ['latitude']])
+def test_chunked_spectra_equal_single_chunk(backend, reduce_dims):
+  """Zonal spectra through the chunk loop: the power sums are accumulated in HBM, the (data-independent) sums of row
+  weights are one cached array met once per chunk -- both must add up to the single-chunk state."""
+  from weatherbenchx_amd import spectra, weighting  # pylint: disable=g-import-not-at-top
+  predictions, targets = _datasets()
+  keep = lambda ds: xr.Dataset({'2m_temperature': ds['2m_temperature'].astype(np.float32)})
+  predictions, targets = keep(predictions), keep(targets)
+  init_times = predictions['2m_temperature']['time'].values
+  lead_times = predictions['2m_temperature']['prediction_timedelta'].values
+  times = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1)
+  load = _loader(predictions, targets)
+  metrics = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()])
+  p, t = load(init_times, lead_times)
+  direct = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t))
+  for _ in range(2):  # (the second loop meets the cached weight sums of the first)
+    state = pipeline.evaluate_chunks(times, load, metrics, agg)[None]
+    xarray_tree.map_structure(lambda a, b: xr.assert_allclose(a, b, rtol=1e-9, atol=1e-9, check_dim_order=False),
+                              (direct.sum_weighted_statistics, direct.sum_weights),
+                              (state.sum_weighted_statistics, state.sum_weights))
+    want, got = direct.metric_values(metrics), state.metric_values(metrics)
+    for k in want:
+      xr.assert_allclose(want[k], got[k], rtol=1e-9, check_dim_order=False)
+
+
 def test_multiple_named_aggregators(backend):
   predictions, targets = _datasets()
   init_times = predictions['geopotential']['time'].values

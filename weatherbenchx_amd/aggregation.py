@@ -491,14 +491,25 @@ class Aggregator:
       v = vals[0].reshape(list(vals[0].shape) + bshape)
     else:
       v = np.stack(vals, axis=-1).reshape(list(vals[0].shape) + bshape)
-    c = np.stack(cnts, axis=-1).reshape(list(vals[0].shape) + bshape)
+    # the stacked sums of row weights are data independent too: one read-only array per (weights, frame) while results are
+    # being accumulated in HBM (the chunk loop then counts how often it met that very array instead of copying and adding
+    # 4 MB per statistic and chunk, engine.Accumulation.capture); a private copy otherwise
+    fkey = ('stacked', tuple(row_dims), tuple(sizes[d] for d in row_dims), tuple(kept), tuple(bin_dims), tuple(vals[0].shape))
+    fstore = w.__dict__.setdefault('_wbx_spectrum_counts', {})
+    c = fstore.get(fkey)
+    if c is None:
+      c = np.array(np.stack(cnts, axis=-1).reshape(list(vals[0].shape) + bshape), dtype=np.float64)
+      c.flags.writeable = False
+      fstore[fkey] = c
+    if engine.accumulation_active() is None:
+      c = c.copy()
     coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(out_dims)}  # pylint: disable=protected-access
     if w_da is not None:
       for k, x in w_da._coords.items():  # pylint: disable=protected-access
         if set(x[0]) <= set(out_dims):
           coords.setdefault(k, x)
     mk = lambda a: xr.DataArray(a, dims=out_dims, coords=coords, name=stat.name, _raw_coords=True)
-    return AggregationState(mk(np.asarray(v, dtype=np.float64)), mk(np.array(c, dtype=np.float64)))
+    return AggregationState(mk(np.asarray(v, dtype=np.float64)), mk(c))
 
   def _reduce_materialised(self, stat: xr.DataArray, w_da, bin_dims, use_mask, skipna):
     """Any DataArray (user-defined statistics, numpy or torch payload): the PASS1 family."""

@@ -579,7 +579,8 @@ class Accumulation:
     self._launches = 0
     self._turns: dict = {}
     self.multi = False             # some slot has been added to more than once
-    self.host: dict = {}           # path -> DataArray summed on the host (results that never were on the device)
+    self._host_sum: dict = {}      # path -> DataArray summed on the host (results that never were on the device)
+    self._host_const: dict = {}    # path -> [[read-only constant DataArray, multiplicity], ...]
     self.specs: dict = {}          # path -> [spec, ...]
     self.frames: dict = {}         # (path, index) -> (coords, name, attrs)
     self.ctxs: dict = {}
@@ -659,17 +660,39 @@ class Accumulation:
       return
     loc = self.locate(da.data)
     if loc is None:
-      val = da if coeff == 1.0 else da * coeff
-      if path in self.host:
-        a, b = xr.align(self.host[path], val, join='outer', fill_value=0)
-        val = a + b
-      self.host[path] = val
+      data = da.data
+      if isinstance(data, np.ndarray) and not data.flags.writeable and data.flags.owndata:
+        # a cached constant (data-independent sums of weights handed out read-only): met again under the same path with the
+        # same frame it only bumps a multiplicity, folded into the host sums when they are read (`host`)
+        for term in self._host_const.setdefault(path, []):
+          if term[0].data is data and term[0].dims == da.dims and _same_coords(term[0], da):
+            term[1] += coeff
+            return
+        self._host_const[path].append([da, float(coeff)])
+        return
+      self._host_add(self._host_sum, path, da if coeff == 1.0 else da * coeff)
       return
     spec = loc + (tuple(da.dims), float(coeff))
     lst = self.specs.setdefault(path, [])
     if spec not in lst:
       lst.append(spec)
       self.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
+
+  @staticmethod
+  def _host_add(table, path, val):
+    if path in table:
+      a, b = xr.align(table[path], val, join='outer', fill_value=0)
+      val = a + b
+    table[path] = val
+
+  @property
+  def host(self) -> dict:
+    """path -> DataArray: the results that never were on the device, summed over the captures."""
+    out = dict(self._host_sum)
+    for path, terms in self._host_const.items():
+      for da, mult in terms:
+        self._host_add(out, path, da if mult == 1.0 else da * mult)
+    return out
 
   def synchronize(self):
     for ctx in self.ctxs.values():
@@ -689,6 +712,17 @@ class Accumulation:
       for start, key in zip(blk.starts, blk.keys):
         out[key] = host[start:start + self.slots[key][2]]
     return out
+
+
+def _same_coords(a: xr.DataArray, b: xr.DataArray) -> bool:
+  ca, cb = a._coords, b._coords  # pylint: disable=protected-access
+  if ca.keys() != cb.keys():
+    return False
+  for k, (dims, vals) in ca.items():
+    odims, ovals = cb[k]
+    if dims != odims or (vals is not ovals and not np.array_equal(np.asarray(vals), np.asarray(ovals))):
+      return False
+  return True
 
 
 _accum: Accumulation | None = None
