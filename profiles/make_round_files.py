@@ -77,7 +77,7 @@ traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pm
                     '(gfx950 reports half of wide coalesced reads)')
 json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
 for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt', 'pmc_spectrum_lat_fastest.txt',
-              'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt', 'config5_host_split.txt', 'new_time_labels.txt'):
+              'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt', 'config5_host_split.txt', 'new_time_labels.txt', 'kbench_ens.txt'):
   if os.path.exists(os.path.join(src, extra)):
     shutil.copy(os.path.join(src, extra), out(extra))
 print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])

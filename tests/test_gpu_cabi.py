@@ -201,6 +201,40 @@ def test_full_grid_ensemble_closed_form(ctx, use_sort):
   np.testing.assert_allclose(res['crps.v'].values, d * (m - 1) / 2 - 0.5 * d * (m + 1) / 3, rtol=1e-6)
 
 
+def test_lds_tiled_pair_form_diagnostic_agrees_with_the_register_pair_form(ctx):
+  """The north_star's LDS-tiled pairwise CRPS spread exists as a diagnostic instantiation (algo 98, tools/kbench.py times it
+  next to the register-tiled pair form `use_sort=False` runs): same 1275 terms per point, other association of the fp32 row
+  sums -> the partial sums agree to fp32 round-off of the rows, the other lanes exactly."""
+  import torch
+  m, ns = 51, 2
+  g = torch.Generator(device='cuda')
+  g.manual_seed(11)
+  tt = torch.randn((ns, NLAT, NLON), generator=g, device='cuda') * 3.7 + 1.3
+  pt = tt[:, None] + torch.randn((ns, m, NLAT, NLON), generator=g, device='cuda') * 2.9
+  torch.cuda.synchronize()  # (engine._run_s1 is called directly: nothing orders torch's stream in front of the launch stream)
+  p = xr.DataArray(pt, dims=('lead_time', 'number', 'latitude', 'longitude'))
+  t = xr.DataArray(tt, dims=('lead_time', 'latitude', 'longitude'))
+  devs = [engine._to_device(ctx, p, _hip.F32), engine._to_device(ctx, t, _hip.F32), None, None]
+  lays = [d.layout if d else None for d in devs]
+  sizes = {'lead_time': ns, 'latitude': NLAT, 'longitude': NLON}
+  plan = planner.build_s1_plan(('lead_time', 'latitude', 'longitude'), sizes, lays, ['latitude', 'longitude'],
+                               wdep_dims=['latitude'], allow_vec4=False, flags=_hip.FLAG_FAIR)
+  plan.block_threads = 64
+  dplan = engine._device_plan(ctx, plan)
+  got = {}
+  for algo in (_hip.ENS_PAIRWISE, 98):
+    part = engine._run_s1(ctx, 'ens', dplan, plan, devs, _hip.F32, 5, ens=(m, devs[0].layout.stride('number'), algo))
+    got[algo] = ctx.download(part.ptr, (plan.nkey * plan.nchunk, 5)).copy()
+  a, b = got[_hip.ENS_PAIRWISE], got[98]
+  assert np.isfinite(a).all() and a[:, 1].min() > 0
+  np.testing.assert_allclose(b[:, 1], a[:, 1], rtol=5e-7)
+  np.testing.assert_array_equal(b[:, [0, 2, 3, 4]], a[:, [0, 2, 3, 4]])
+  plan.block_threads = 256  # the tile is sized for one-wave blocks: anything else is refused, not mis-run
+  with pytest.raises(_hip.WbxError):
+    engine._run_s1(ctx, 'ens', engine._device_plan(ctx, plan), plan, devs, _hip.F32, 5,
+                   ens=(m, devs[0].layout.stride('number'), 98))
+
+
 def test_oracle_parity_on_a_full_grid_slice(ctx):
   """One 721x1440 field pair + 5 members: every fused lane against the float64 oracle."""
   rng = np.random.default_rng(7)

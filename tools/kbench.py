@@ -40,10 +40,24 @@ def ens():
     plan = planner.build_s1_plan(('lead_time', 'latitude', 'longitude'), sizes, lays, ['latitude', 'longitude'],
                                  wdep_dims=['latitude'], allow_vec4=False, flags=_hip.FLAG_FAIR)
     plan.block_threads = bt
-    for name, algo in (('sort', 0), ('pairwise', 1), ('loadonly', 99)):
+    for name, algo in (('sort', 0), ('pairwise', 1), ('pairwise through LDS tiles', 98), ('loadonly', 99)):
+      if algo == 98 and bt != 64:
+        continue  # (the LDS-tiled diagnostic is built for one-wave blocks)
       ms = time_s1('ens', plan, devs, 5, ens=(m, devs[0].layout.stride('number'), algo))
       print(f'ens M=51 block={bt:3d} nkey={plan.nkey} nchunk={plan.nchunk} {name:9s} {ms:7.4f} ms  '
             f'{nbytes / ms / 1e6:7.1f} GB/s  {nbytes / ms / 1e6 / 80:5.1f}% of 8 TB/s')
+
+
+  # the LDS-tiled diagnostic forms the same 1275 terms: its partial sums must agree with the register pair form's
+  plan.block_threads = 64
+  dplan = engine._device_plan(ctx, plan)
+  got = {}
+  for algo in (1, 98):
+    part = engine._run_s1(ctx, 'ens', dplan, plan, devs, _hip.F32, 5, ens=(m, devs[0].layout.stride('number'), algo))
+    got[algo] = ctx.download(part.ptr, (plan.nkey * plan.nchunk, 5)).copy()
+  err = np.max(np.abs(got[98] - got[1]) / np.maximum(np.abs(got[1]), 1e-30))
+  print(f'LDS-tiled pair form against the register pair form: max relative difference of the partial sums {err:.2e}')
+  assert err < 1e-6, err
 
 
 def det():

@@ -61,6 +61,7 @@ for d in trace_bench trace_bench_lat trace_rmse_crps_37L trace_config5 trace_pub
 ( cd $R && bash tools/pmc_spec_latfast.sh ) > $O/pmc_spectrum_lat_fastest.txt 2>&1
 ( cd $R && python tools/spec_phase_profile.py 2>&1 | grep -v amdgpu.ids ) > $O/spectrum_phase_profile.txt 2>&1
 ( cd $R && for l in lon_fastest lat_fastest; do python tools/kbench_spectrum_raw.py 8 $l sorted 2>&1 | grep -v amdgpu.ids | sed "s/^/$l /"; done ) > $O/spectrum_raw.txt 2>&1
+( cd $R && python tools/kbench.py ens 2>&1 | grep -v amdgpu.ids ) > $O/kbench_ens.txt 2>&1
 ( cd $R && python tools/config5_host_split.py 150 2>&1 | grep -v amdgpu.ids | tail -7 ) > $O/config5_host_split.txt 2>&1
 ( cd $R && python tools/bench_new_labels.py 2>&1 | grep -v amdgpu.ids | tail -2 ) > $O/new_time_labels.txt 2>&1
 ( cd $R && bash tools/pmc_binned.sh lon_fastest | grep -v rocprofv3 ) > $O/pmc_binned_lon_fastest.txt 2>&1

@@ -72,7 +72,8 @@ static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, i
   WBX_REQUIRE(plan->vec == 1, "ensemble kernels use vec=1");
   if (plan->flags & WBX_FLAG_MASKED) WBX_REQUIRE(mask != nullptr, "WBX_FLAG_MASKED set but mask is NULL");
   WBX_REQUIRE(M >= 1, "ensemble size must be >= 1 (got %d)", M);
-  WBX_REQUIRE(algo == WBX_ENS_SORT || algo == WBX_ENS_PAIRWISE || (algo == WBX_ENS_DIAG_LOADONLY && (M == 50 || M == 51)),
+  WBX_REQUIRE(algo == WBX_ENS_SORT || algo == WBX_ENS_PAIRWISE || (algo == WBX_ENS_DIAG_LOADONLY && (M == 50 || M == 51)) ||
+                  (algo == WBX_ENS_DIAG_PAIRWISE_LDS && M == 51),
               "unknown ensemble algorithm %d", algo);
   const bool empty = plan->nkey * plan->ndepth * plan->nx == 0;
   WBX_REQUIRE(empty || (p != nullptr && t != nullptr), "predictions/targets pointer is NULL");

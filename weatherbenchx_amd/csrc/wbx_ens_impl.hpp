@@ -27,6 +27,12 @@ namespace wbx {
 
 // not part of the ABI enum: stage-1 memory-pattern diagnostic used by tools/kbench.py (lane 0 = sum_m p - t)
 constexpr int WBX_ENS_DIAG_LOADONLY = 99;
+// not part of the ABI enum either: the north_star's "LDS-tiled pairwise" form, built to be MEASURED (tools/kbench.py) next to
+// the register-tiled pair form that `use_sort=False` runs: a point's members are parked in the LDS (one column per lane: bank =
+// lane, conflict free, no barrier -- a lane reads back only what it wrote) after the member sums have consumed them, and the
+// 1275 |x_i - x_j| terms are formed on register blocks of 17 members read back from there (34 live member registers instead of
+// 51).  M == 51 only.
+constexpr int WBX_ENS_DIAG_PAIRWISE_LDS = 98;
 
 // MP: register bucket (compile time).  EXACT: M == MP known at compile time.
 template <int MP, bool EXACT, int ALGO>
@@ -98,7 +104,7 @@ struct EnsOpF32 {
           pair_total += (double)row;
         }
       }
-    } else {
+    } else if constexpr (ALGO == WBX_ENS_SORT) {
       {  // two members per instruction (v_pk_fma_f32): x * 0 + p is NaN iff x is NaN or +-inf
         typedef float pk2 __attribute__((ext_vector_type(2)));
         pk2 pz = {0.f, 0.f};
@@ -162,6 +168,43 @@ struct EnsOpF32 {
       spread = dot * spread_scale;
     } else {
       spread = pair_total * spread_scale;
+    }
+    if constexpr (ALGO == WBX_ENS_DIAG_PAIRWISE_LDS) {
+      static_assert(EXACT && MP % 17 == 0, "the LDS-tiled diagnostic is instantiated for M = 51");
+      constexpr int B = 17, NB = MP / B;
+      __shared__ float tile[MP][64];  // one-wave blocks (the launcher checks): 13 KB each, 12 blocks = 3 waves per SIMD on a CU
+      float* col = &tile[0][threadIdx.x];
+#pragma unroll
+      for (int m = 0; m < MP; ++m) col[m * 64] = xm[m];
+      asm volatile("" ::: "memory");  // the members are read back from the LDS, not forwarded from the registers
+      double total = 0.0;
+#pragma unroll
+      for (int bi = 0; bi < NB; ++bi) {
+        float xi[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) xi[k] = col[(bi * B + k) * 64];
+#pragma unroll
+        for (int k = 1; k < B; ++k) {
+          float row = 0.f;
+#pragma unroll
+          for (int l = 0; l < k; ++l) row += fabsf(xi[k] - xi[l]);
+          total += (double)row;
+        }
+#pragma unroll
+        for (int bj = 0; bj < bi; ++bj) {
+          float xj[B];
+#pragma unroll
+          for (int l = 0; l < B; ++l) xj[l] = col[(bj * B + l) * 64];
+#pragma unroll
+          for (int k = 0; k < B; ++k) {
+            float row = 0.f;
+#pragma unroll
+            for (int l = 0; l < B; ++l) row += fabsf(xi[k] - xj[l]);
+            total += (double)row;
+          }
+        }
+      }
+      spread = total * spread_scale;
     }
     val[0] = sabs * inv_m;
     val[1] = spread;
@@ -244,6 +287,15 @@ int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo
   if (algo == WBX_ENS_DIAG_LOADONLY) {
     if (!EXACT || map) return fail(WBX_ERR_INVALID, "the load-only diagnostic exists for the exact-M partial kernels only");
     return launch_partial<EnsOpF32<MP, EXACT, WBX_ENS_DIAG_LOADONLY>, 1>(ctx, plan, a);
+  }
+  if (algo == WBX_ENS_DIAG_PAIRWISE_LDS) {
+    if constexpr (EXACT && MP == 51) {
+      if (map || plan->x_weights != nullptr || (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) || plan->block_threads != 64)
+        return fail(WBX_ERR_INVALID, "the LDS-tiled pair-form diagnostic exists for the plain partial kernels with one-wave blocks only");
+      return launch_partial<EnsOpF32<MP, EXACT, WBX_ENS_DIAG_PAIRWISE_LDS>, 1>(ctx, plan, a);
+    } else {
+      return fail(WBX_ERR_INVALID, "the LDS-tiled pair-form diagnostic exists for M = 51 only");
+    }
   }
   return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_PAIRWISE>>(ctx, plan, a, map);
 }
