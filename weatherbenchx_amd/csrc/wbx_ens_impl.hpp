@@ -17,10 +17,18 @@
 
 #include "wbx_s1.hpp"
 #include "wbx_sortnet_gen.hpp"
+#include "wbx_sortnet3_gen.hpp"
 
 #ifndef WBX_ENS_MIN_WAVES
 #define WBX_ENS_MIN_WAVES 1  // no forced occupancy: 106 VGPRs / 4 waves per SIMD on its own since the fp64 divisions went (before: 140-155
                              // VGPRs / 3 waves, and forcing 4 spilled 132 B: 0.63 ms vs 0.37 ms)
+#endif
+
+#ifndef WBX_ENS_MIN_WAVES_PLAIN
+#define WBX_ENS_MIN_WAVES_PLAIN WBX_ENS_MIN_WAVES  // the unmasked op alone (the masked / skipna wrappers keep WBX_ENS_MIN_WAVES)
+#endif
+#ifndef WBX_ENS_SORTNET3
+#define WBX_ENS_SORTNET3 1  // 0: Batcher's compare-exchange network for every size (A/B timing: make EXTRA=-DWBX_ENS_SORTNET3=0)
 #endif
 
 namespace wbx {
@@ -40,7 +48,7 @@ struct EnsOpF32 {
   static constexpr int NIN = 2;
   static constexpr int NLANE = WBX_ENS_LANES;
   static constexpr int NACC = WBX_ENS_LANES;
-  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = WBX_ENS_MIN_WAVES;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = WBX_ENS_MIN_WAVES_PLAIN;
 
   // One grid point's inputs in VGPRs.  load() only issues the (coalesced-across-lanes) member loads; compute() is
   // pure register work, so the skeleton can keep the NEXT point's loads in flight while this one is reduced.
@@ -116,21 +124,42 @@ struct EnsOpF32 {
         if ((MP & 1) && (EXACT || MP - 1 < M)) pz.x = fmaf(xm[MP - 1], 0.f, pz.x);
         poison = pz.x + pz.y;
       }
-      SortNet<MP>::sort(
-          xm,
-          // the bare instructions: fminf / fmaxf make the compiler canonicalise every loaded member first (one extra
-          // v_max_f32 x, x each) to quiet signalling NaNs, which v_min / v_max in IEEE mode do themselves; NaN members
-          // are caught by the probe above, not by the network
-          [](float u, float v) {
-            float r;
-            asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
-            return r;
-          },
-          [](float u, float v) {
-            float r;
-            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
-            return r;
-          });
+      // the bare instructions: fminf / fmaxf make the compiler canonicalise every loaded member first (one extra
+      // v_max_f32 x, x each) to quiet signalling NaNs, which v_min / v_max in IEEE mode do themselves; NaN members
+      // are caught by the probe above, not by the network
+      auto mn = [](float u, float v) {
+        float r;
+        asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
+        return r;
+      };
+      auto mx = [](float u, float v) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
+        return r;
+      };
+      if constexpr (WBX_ENS_SORTNET3 && EXACT && (MP == 50 || MP == 51)) {
+        // the exact IFS-ENS sizes: merge sort of compare-exchanges and 3-sorters (gen_sortnet3.py): v_min3 / v_med3 / v_max3
+        // cost what v_min / v_max do, so M = 51 sorts in 630 instructions instead of the 830 of Batcher's 415 comparators
+        SortNet3<MP>::sort(
+            xm, mn, mx,
+            [](float u, float v, float w) {
+              float r;
+              asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(v), "v"(w));
+              return r;
+            },
+            [](float u, float v, float w) {
+              float r;
+              asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(v), "v"(w));
+              return r;
+            },
+            [](float u, float v, float w) {
+              float r;
+              asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(v), "v"(w));
+              return r;
+            });
+      } else {
+        SortNet<MP>::sort(xm, mn, mx);
+      }
     }
 
     // Everything is accumulated on e = x - shift (variance and spread are shift invariant).  shift = the target when it
@@ -237,7 +266,7 @@ struct EnsMasked {
   static constexpr int NIN = Core::NIN;
   static constexpr int NLANE = Core::NLANE;
   static constexpr int NACC = Core::NLANE + (SKIPNA ? Core::NLANE : 1);  // same count-lane convention as DetOp
-  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = Core::MIN_WAVES;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = WBX_ENS_MIN_WAVES;
 
   __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
                                                 double (&val)[NLANE]) {
