@@ -273,6 +273,30 @@ def test_acc_with_climatology_gather_matches_oracle(backend, layout):
   np.testing.assert_allclose(res['rmse.z'].transpose(*out_dims).values, O.rmse(means['se']), rtol=RTOL)
 
 
+@pytest.mark.parametrize('m', [2, 3, 4, 6, 8, 9, 13, 16, 17, 24, 31, 32, 33, 49, 50, 51, 52, 63, 64])
+def test_rank_form_spread_for_every_register_bucket(backend, m):
+  """The rank form sorts a point's members with a network of compare-exchanges and 3-sorters per register bucket (4 / 8 / 16 /
+  32 / 64 padded with +inf, exact 50 / 51: csrc/gen_sortnet3.py).  Heavy ties, reversed and already sorted members, huge and
+  tiny magnitudes next to each other: the spread must be the float64 oracle's for every ensemble size around the bucket edges."""
+  rng = np.random.default_rng(100 + m)
+  nlat, nlon = 8, 48
+  lat, lon = np.linspace(-78.75, 78.75, nlat), np.arange(nlon) * 7.5
+  pv = np.empty((m, nlat, nlon), np.float32)
+  pv[:, 0] = rng.integers(0, 3, size=(m, nlon))                      # many equal members
+  pv[:, 1] = np.sort(rng.normal(size=(m, nlon)), axis=0)             # already sorted
+  pv[:, 2] = np.sort(rng.normal(size=(m, nlon)), axis=0)[::-1]       # reversed
+  pv[:, 3] = rng.normal(size=(m, nlon)) * 10.0 ** rng.integers(-20, 20, size=(m, nlon))  # mixed magnitudes
+  pv[:, 4] = np.where(rng.random((m, nlon)) < 0.5, -0.0, 0.0)        # signed zeros
+  pv[:, 5:] = rng.normal(size=(m, nlat - 5, nlon)) + 280.0
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'v': xr.DataArray(pv, dims=('number', 'latitude', 'longitude'), coords=coords)}
+  t = {'v': xr.DataArray(pv[0].copy(), dims=('latitude', 'longitude'), coords=coords)}
+  agg = aggregation.Aggregator(reduce_dims=['longitude'])
+  got = aggregation.compute_metric_values_for_single_chunk({'spread': probabilistic.CRPSSpread(use_sort=True)}, agg, p, t)
+  want, _ = O.crps_spread(pv, ('number', 'latitude', 'longitude'), 'number', fair=True, use_sort=True)
+  np.testing.assert_allclose(got['spread.v'].values, want.mean(axis=-1), rtol=1e-12, atol=1e-300)
+
+
 @pytest.mark.parametrize('member_layout', ['member_slow', 'member_fast'])
 @pytest.mark.parametrize('m,dtype', [(5, np.float32), (51, np.float32), (7, np.float64), (70, np.float32)])
 @pytest.mark.parametrize('use_sort', [True, False])

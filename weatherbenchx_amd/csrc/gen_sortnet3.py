@@ -23,7 +23,7 @@ import itertools
 import random
 import sys
 
-SIZES = [50, 51]
+SIZES = [4, 8, 16, 32, 50, 51, 64]
 
 # (op, wires...): ('ce', lo, hi) or ('s3', lo, mid, hi); found by the exhaustive search described above
 LEAVES = {

@@ -137,9 +137,9 @@ struct EnsOpF32 {
         asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(u), "v"(v));
         return r;
       };
-      if constexpr (WBX_ENS_SORTNET3 && EXACT && (MP == 50 || MP == 51)) {
-        // the exact IFS-ENS sizes: merge sort of compare-exchanges and 3-sorters (gen_sortnet3.py): v_min3 / v_med3 / v_max3
-        // cost what v_min / v_max do, so M = 51 sorts in 630 instructions instead of the 830 of Batcher's 415 comparators
+      if constexpr (WBX_ENS_SORTNET3) {
+        // merge sort of compare-exchanges and 3-sorters (gen_sortnet3.py): v_min3 / v_med3 / v_max3 cost what v_min / v_max
+        // do, so M = 51 sorts in 606 instructions instead of the 830 of Batcher's 415 comparators (32: 301 / 382, 64: 850 / 1086)
         SortNet3<MP>::sort(
             xm, mn, mx,
             [](float u, float v, float w) {
