@@ -8,7 +8,8 @@
 //   UnbiasedEnsembleMeanSquaredError :276-336   (mean_m p - t)^2 - var/M
 //   EnsembleMean + SquaredError (wrappers.py:116-148, deterministic.py:115-123)   (mean_m p - t)^2
 //
-// fp32 members are sorted exactly with a v_min/v_max network in VGPRs; every sum is fp64 on the
+// fp32 members are sorted exactly with a network of compare-exchanges (v_min / v_max) and 3-sorters (v_min3 / v_med3 /
+// v_max3) in VGPRs (gen_sortnet3.py); every sum is fp64 on the
 // widened values, so each per-point value matches the float64 restatement to ~1e-15 (rank form)
 // or ~1e-7 (pair form: the |x_i - x_j| row sums are fp32, their total fp64).
 // Members beyond the runtime M (padded buckets) are +inf for the network and skipped in the sums.
@@ -71,6 +72,9 @@ struct EnsOpF32 {
   // members), statistics accumulated on x - t (one fp64 add per member less): 0.404 -> 0.363 ms.
   // The load-only diagnostic (WBX_ENS_DIAG_LOADONLY) streams the same 52 dword streams at 6.0 TB/s, so what is
   // left is VALU time (~2000 instructions per 64 points) that 3 waves/SIMD only partly overlap with the loads.
+  // (r2) The network itself: Batcher's 415 compare-exchanges (830 instructions) -> 54 compare-exchanges + 166 3-sorters (606):
+  // 0.349 -> 0.316 ms on one box (tools/gpu_ens_ab.sh), 133 VGPRs / 3 waves per SIMD; forcing 4 waves (5 spilled registers)
+  // changes nothing.
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
     const int M = EXACT ? MP : a.M;
     const float* pp = reinterpret_cast<const float*>(a.in[0]) + ro[0] + x * a.xstride[0];
