@@ -9,11 +9,14 @@
 //       out[.., r] = float(#{m : p_m < t} == r), r = 0..M; comparisons with NaN are False, the result is never NaN
 //
 // The category index is data dependent, so the per-thread accumulators cannot live in registers: each thread owns one
-// column col[cat][thread] of fp64 counters in LDS (conflict-free: the bank depends on the thread only).  One wave per
+// column col[cat][thread] of counters in LDS (conflict-free: the bank depends on the thread only) -- fp64 for the exceedance
+// fractions, uint32 for the rank histogram, whose sums are plain counts (r2: 52 categories x 64 threads x 8 B = 26.6 KB per
+// one-wave block held a CU to six waves; with 4-byte counters and ds_add_u32 it is twelve).  One wave per
 // block; same plan / partial layout as the other stage-1 kernels (partial[key][chunk][lane][j]), so stage 2 -- weights,
 // bins, the patch contraction -- is shared.  Count lanes follow wbx_det_partial: one shared lane for WBX_FLAG_MASKED,
 // one per category for WBX_FLAG_SKIPNA.
 #include <cmath>
+#include <type_traits>
 
 #include "wbx_s1.hpp"
 
@@ -33,9 +36,10 @@ __device__ __forceinline__ T cat_ld(const void* base, int64_t off) {
 // One point: adds its indicator vector (and count lanes) to this thread's LDS column.  MF > 0: the ensemble size is
 // known at compile time (the 50 / 51-member archives): all member loads of a point are issued back to back into
 // registers before the compares (the generic loop keeps 4-8 in flight); MF == 0: any M.
-template <typename T, int MF>
+template <typename T, int MF, typename C>
 __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, const int64_t (&ro)[WBX_MAX_INPUTS],
-                                          int64_t x, double* col, int stride) {
+                                          int64_t x, C* col, int stride) {
+  constexpr bool RANK = std::is_same<C, uint32_t>::value;  // the column type says which family this instantiation serves
   const bool masked = a.flags & WBX_FLAG_MASKED, skipna = a.flags & WBX_FLAG_SKIPNA;
   const bool valid = masked ? cat_ld<uint8_t>(a.in[3], ro[3] + x * a.xstride[3]) != 0 : true;
   const int nc = c.ncat;
@@ -47,7 +51,7 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
 #pragma unroll
     for (int m = 0; m < MF; ++m) xm[m] = ld_stream(pm + (int64_t)m * a.mstride);
   }
-  if (c.func == WBX_CAT_RANK) {
+  if constexpr (RANK) {
     int r = 0;
     if constexpr (MF > 0) {
 #pragma unroll
@@ -56,14 +60,14 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
 #pragma unroll 8
       for (int m = 0; m < a.M; ++m) r += (ld_stream(pm + (int64_t)m * a.mstride) < tnat) ? 1 : 0;
     }
-    if (valid) col[r * stride] += 1.0;
+    if (valid) col[r * stride] += 1u;
     if (skipna) {
-      for (int k = 0; k < nc; ++k) col[(nc + k) * stride] += valid ? 1.0 : 0.0;
+      for (int k = 0; k < nc; ++k) col[(nc + k) * stride] += valid ? 1u : 0u;
     } else if (masked) {
-      col[nc * stride] += valid ? 1.0 : 0.0;
+      col[nc * stride] += valid ? 1u : 0u;
     }
     return;
-  }
+  } else {
   // exceedance: per threshold the fraction of (non-NaN) members whose absolute error exceeds it; M = 1 without ensemble
   for (int k0 = 0; k0 < nc; k0 += 8) {
     int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -107,14 +111,16 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
     }
   }
   if (masked && !skipna) col[nc * stride] += valid ? 1.0 : 0.0;
+  }
 }
 
 // grid = nkey * nchunk (x summed) or nkey * nxtile * nchunk (x kept); block = 64 threads; dynamic LDS = nacc * 64 * 8 B
-template <typename T, int MF>
+template <typename T, int MF, typename C>
 __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nacc, int x_kept) {
-  extern __shared__ double cols[];  // [nacc][64]
+  extern __shared__ double cols_raw[];  // [nacc][64] of C
+  C* const cols = reinterpret_cast<C*>(cols_raw);
   const int lane = threadIdx.x;
-  for (int i = 0; i < nacc; ++i) cols[i * 64 + lane] = 0.0;
+  for (int i = 0; i < nacc; ++i) cols[i * 64 + lane] = C(0);
   int64_t b = blockIdx.x;
   const int chunk = (int)(b % a.nchunk);
   b /= a.nchunk;
@@ -128,26 +134,26 @@ __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nac
   const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
   int64_t kb[WBX_MAX_INPUTS];
   key_bases<2>(a, key, kb);
-  double* col = cols + lane;
+  C* col = cols + lane;
   if (x_kept) {
     const int64_t x = (int64_t)xt * 64 + lane;
     if (x < a.nx) {
       for (int64_t d = d0; d < d1; ++d) {
         int64_t ro[WBX_MAX_INPUTS];
         row_bases<2>(a, kb, key, d, ro);
-        cat_point<T, MF>(a, c, ro, x, col, 64);
+        cat_point<T, MF, C>(a, c, ro, x, col, 64);
       }
-      for (int i = 0; i < nacc; ++i) a.out[((key * a.nchunk + chunk) * nacc + i) * a.nx + x] = col[i * 64];
+      for (int i = 0; i < nacc; ++i) a.out[((key * a.nchunk + chunk) * nacc + i) * a.nx + x] = (double)col[i * 64];
     }
   } else {
     for (int64_t d = d0; d < d1; ++d) {
       int64_t ro[WBX_MAX_INPUTS];
       row_bases<2>(a, kb, key, d, ro);
-      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T, MF>(a, c, ro, x, col, 64);
+      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T, MF, C>(a, c, ro, x, col, 64);
     }
     __syncthreads();
     for (int i = 0; i < nacc; ++i) {
-      const double s = wave_sum(cols[i * 64 + lane]);
+      const double s = wave_sum((double)cols[i * 64 + lane]);
       if (lane == 0) a.out[(key * a.nchunk + chunk) * nacc + i] = s;
     }
   }
@@ -166,7 +172,11 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
   WBX_REQUIRE(M >= 1, "M must be >= 1");
   if (func == WBX_CAT_RANK) WBX_REQUIRE(ncat == M + 1, "rank histogram needs ncat == M + 1");
   const int nacc = ncat + ((plan->flags & WBX_FLAG_SKIPNA) ? ncat : ((plan->flags & WBX_FLAG_MASKED) ? 1 : 0));
-  WBX_REQUIRE((size_t)nacc * 64 * sizeof(double) <= 64 * 1024, "too many categories for the LDS columns (%d lanes)", nacc);
+  const bool rank = func == WBX_CAT_RANK;
+  const size_t counter = rank ? sizeof(uint32_t) : sizeof(double);
+  WBX_REQUIRE((size_t)nacc * 64 * counter <= 64 * 1024, "too many categories for the LDS columns (%d lanes)", nacc);
+  if (rank)  // a thread's counters are uint32: it meets at most depth_chunk * ceil(nx / 64) points
+    WBX_REQUIRE((double)plan->depth_chunk * (double)((plan->nx + 63) / 64) < 4.0e9, "rank histogram: more than 2^32 points per thread");
   if (plan->nkey == 0) return 0;
   WBX_REQUIRE(partial_out != nullptr, "partial_out is NULL");
   WBX_HIP(hipSetDevice(ctx->device));
@@ -194,9 +204,16 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
   a.nxtile = (int)((plan->nx + 63) / 64);
   const int64_t grid = plan->nkey * plan->nchunk * (plan->x_kept ? a.nxtile : 1);
   WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
-  const size_t lds = (size_t)nacc * 64 * sizeof(double);
-#define WBX_LAUNCH_CAT(TT, MFIX) \
-  hipLaunchKernelGGL((s1_cat_kernel<TT, MFIX>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept)
+  const size_t lds = (size_t)nacc * 64 * counter;
+#define WBX_LAUNCH_CAT(TT, MFIX)                                                                                              \
+  do {                                                                                                                        \
+    if (rank)                                                                                                                 \
+      hipLaunchKernelGGL((s1_cat_kernel<TT, MFIX, uint32_t>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc,   \
+                         (int)plan->x_kept);                                                                                  \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((s1_cat_kernel<TT, MFIX, double>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc,     \
+                         (int)plan->x_kept);                                                                                  \
+  } while (0)
   if (dtype == WBX_F32) {
     if (M == 51) WBX_LAUNCH_CAT(float, 51);
     else if (M == 50) WBX_LAUNCH_CAT(float, 50);
