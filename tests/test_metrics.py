@@ -287,7 +287,9 @@ def test_rank_form_spread_for_every_register_bucket(backend, m):
   pv[:, 2] = np.sort(rng.normal(size=(m, nlon)), axis=0)[::-1]       # reversed
   pv[:, 3] = rng.normal(size=(m, nlon)) * 10.0 ** rng.integers(-20, 20, size=(m, nlon))  # mixed magnitudes
   pv[:, 4] = np.where(rng.random((m, nlon)) < 0.5, -0.0, 0.0)        # signed zeros
-  pv[:, 5:] = rng.normal(size=(m, nlat - 5, nlon)) + 280.0
+  pv[:, 5] = (rng.integers(-4000, 4000, size=(m, nlon)) * np.float64(1.4e-45)).astype(np.float32)  # fp32 denormals, not flushed
+  assert 0 < np.abs(pv[:, 5]).max() < 1.2e-38
+  pv[:, 6:] = rng.normal(size=(m, nlat - 6, nlon)) + 280.0
   coords = {'latitude': lat, 'longitude': lon}
   p = {'v': xr.DataArray(pv, dims=('number', 'latitude', 'longitude'), coords=coords)}
   t = {'v': xr.DataArray(pv[0].copy(), dims=('latitude', 'longitude'), coords=coords)}
