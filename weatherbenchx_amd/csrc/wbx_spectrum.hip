@@ -438,6 +438,10 @@ static int spectrum_knock() {
 
 // Launches zspec1440_kernel: as many one-wave teams per block as the LDS holds (12: tables + 12 x 11.4 KB), one block per
 // CU, and -- every team takes the same time -- a grid of exactly `rounds` resident sets.
+#ifndef WBX_SPECTRUM_SKEW_DEFAULT
+#define WBX_SPECTRUM_SKEW_DEFAULT 100  // per mille of a team's rows (WBX_SPECTRUM_SKEW overrides; 0 / 40 / 70 / 100 / 130 / 200 / 250: 0.249 / 0.245 / 0.242 / 0.239 / 0.241 / 0.242 / 0.248 ms)
+#endif
+
 static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t row_stride, int64_t nrows,
                        const int32_t* group, const double* scale, double* power_out) {
   void*& tab = st->twiddles[-Z14_N];
@@ -469,6 +473,11 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   rows_per_team += rows_per_team & 1;  // whole pairs
   teams = (nrows + rows_per_team - 1) / rows_per_team;
   const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);
+  // rows the oldest four waves of a block take more / the youngest four less (whole pairs), see the kernel
+  static const int skew_permille = getenv("WBX_SPECTRUM_SKEW") ? atoi(getenv("WBX_SPECTRUM_SKEW")) : WBX_SPECTRUM_SKEW_DEFAULT;
+  int skew = 0;
+  if (nteam == 12 && rows_per_team >= 16) skew = 2 * (int)(((int64_t)rows_per_team * skew_permille + 1000) / 2000);
+  if (skew >= rows_per_team) skew = 0;
   if (prof_path) {
     static unsigned long long* prof = nullptr;  // (diagnostic path: one device, never freed)
     unsigned long long host[26];
@@ -480,7 +489,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
       WBX_HIP(hipStreamSynchronize(ctx->stream));
     }
     hipLaunchKernelGGL((zspec1440_kernel<true, 0>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows,
-                       rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+                       rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
     WBX_HIP(hipGetLastError());
     if (timing_only) return 0;
     WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -494,7 +503,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   const int knock = spectrum_knock();  // diagnostic, wrong results
 #define WBX_Z14_LAUNCH(KN)                                                                                                 \
   hipLaunchKernelGGL((zspec1440_kernel<false, KN>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, \
-                     rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out,                         \
+                     rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out,                   \
                      static_cast<unsigned long long*>(nullptr))
   switch (knock) {
     case 1: WBX_Z14_LAUNCH(1); break;
@@ -504,8 +513,8 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
     case 8: WBX_Z14_LAUNCH(8); break;
     case 14: WBX_Z14_LAUNCH(14); break;
     case 15: WBX_Z14_LAUNCH(15); break;
-    case 17: hipLaunchKernelGGL((zspec1440_kernel<false, 0, true, true>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // loads in front of pass 1
-    case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
+    case 17: hipLaunchKernelGGL((zspec1440_kernel<false, 0, true, true>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // loads in front of pass 1
+    case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
     default: WBX_Z14_LAUNCH(0); break;
   }
 #undef WBX_Z14_LAUNCH

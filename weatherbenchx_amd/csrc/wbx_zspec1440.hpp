@@ -206,7 +206,7 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
 // FETCH_EARLY (A/B): the next pair's 24 loads in front of pass 1 instead of behind its stores (0.285 vs 0.275 ms per field)
 template <bool PROF, int KNOCK, bool ROTATE = true, bool FETCH_EARLY = false>
 __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
-                                                        int rows_per_team, const float2* __restrict__ tables_g,
+                                                        int rows_per_team, int skew, const float2* __restrict__ tables_g,
                                                         const int32_t* __restrict__ group,
                                                         const double* __restrict__ scale, double* __restrict__ power,
                                                         unsigned long long* __restrict__ prof) {
@@ -222,9 +222,15 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   v4* const buf = reinterpret_cast<v4*>(twr + Z14_TWR) + team * Z14_BUF;
   for (int i = threadIdx.x; i < Z14_TABLES; i += blockDim.x) tw1[i] = tables_g[i];
   __syncthreads();
-  const int64_t w = (int64_t)blockIdx.x * nteam + team;
-  const int64_t r0 = w * rows_per_team;
-  const int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
+  // A block's 12 * rows_per_team rows are dealt to its teams in launch order.  The instruction arbiter serves the OLDEST wave
+  // of a SIMD first (teams 0-3 before 4-7 before 8-11: lifetimes 196 / 217 / 231 us with equal shares, even with the priority
+  // rotation below), so with `skew` > 0 (twelve-team blocks only) the first four teams take `skew` rows more and the last four
+  // `skew` rows less: the waves of a SIMD finish together and the kernel's tail shrinks.
+  const int g = team >> 2;
+  const int64_t lead = g == 0 ? (int64_t)team * skew : (g == 1 ? 4 * (int64_t)skew : (int64_t)(12 - team) * skew);
+  const int64_t r0 = ((int64_t)blockIdx.x * nteam + team) * rows_per_team + lead;
+  const int64_t mine = rows_per_team + (int64_t)skew * (1 - g);
+  const int64_t r1 = r0 + mine < nrows ? r0 + mine : nrows;
   if (r0 >= r1) return;  // only wave-level ordering below
   constexpr int nk = Z14_N2 + 1;
   const Z14Lane c = z14_lane(lane, buf, tw2);
