@@ -575,6 +575,7 @@ def config5_leg(env):
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),
           'check': {'rmse_z_mean': rm, 'crps_t2m_mean': float(np.asarray(out['ensemble']['crps.t2m'].values).mean()),
+                    'spectrum_p_z_mean': float(np.asarray(out['spectra']['spectrum_p.z'].values).mean()),
                     'shape_rmse_z': list(out['deterministic']['rmse.z'].shape)}}
 
 

@@ -360,3 +360,6 @@ def test_bench_two_ranks_from_a_bare_shell(ctx):
   assert out['config5']['n_gpus'] == 2 and out['config5']['check']['shape_rmse_z'] == one['config5']['check']['shape_rmse_z']
   np.testing.assert_allclose(out['config5']['check']['rmse_z_mean'], one['config5']['check']['rmse_z_mean'], rtol=1e-12)
   np.testing.assert_allclose(out['config5']['check']['crps_t2m_mean'], one['config5']['check']['crps_t2m_mean'], rtol=1e-12)
+  # (the spectra's sums of row weights never touch the device: every rank counts how often it met the cached array)
+  np.testing.assert_allclose(out['config5']['check']['spectrum_p_z_mean'], one['config5']['check']['spectrum_p_z_mean'], rtol=1e-9)
+  assert out['config5']['check']['spectrum_p_z_mean'] > 0
