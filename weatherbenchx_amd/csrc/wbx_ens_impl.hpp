@@ -74,7 +74,8 @@ struct EnsOpF32 {
   // left is VALU time (~2000 instructions per 64 points) that 3 waves/SIMD only partly overlap with the loads.
   // (r2) The network itself: Batcher's 415 compare-exchanges (830 instructions) -> 54 compare-exchanges + 166 3-sorters (606):
   // 0.349 -> 0.316 ms on one box (tools/gpu_ens_ab.sh), 133 VGPRs / 3 waves per SIMD; forcing 4 waves (5 spilled registers)
-  // changes nothing.
+  // changes nothing.  A wave-uniform row base + one 32-bit VGPR offset for all 52 streams (to drop the 53 v_lshl_add_u64 per
+  // point): the compiler reassociates the sum back into 64-bit VGPR addresses, 107 VGPRs, 0.329 against 0.312 ms -- not kept.
   __device__ __forceinline__ static void load(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r) {
     const int M = EXACT ? MP : a.M;
     const float* pp = reinterpret_cast<const float*>(a.in[0]) + ro[0] + x * a.xstride[0];
