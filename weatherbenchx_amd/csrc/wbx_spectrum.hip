@@ -523,6 +523,10 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
 }
 
 // Launches zspec1440_latfast_kernel over nslab slabs of rps adjacent rows (row_stride 1, longitude strided).
+#ifndef WBX_SPECTRUM_LF_PRIO_DEFAULT
+#define WBX_SPECTRUM_LF_PRIO_DEFAULT 1  // (0 / 1 / 2: 0.3673 / 0.3630 / 0.3674 ms back to back on one box) user priority of a block's waves by age (WBX_SPECTRUM_LF_PRIO overrides), see the kernel
+#endif
+
 static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, int64_t lon_stride, const int64_t* d_slab_off,
                                int64_t rps, int64_t nslab, const int32_t* group, const double* scale, double* power_out) {
   void*& tab = st->twiddles[-Z14_N];
@@ -550,6 +554,7 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   // algorithmic against 1.09 x for 33: the shared lines are found in L2 either way)
   int64_t runs = (rps + 21) / 22;
   if (const char* e = getenv("WBX_SPECTRUM_LF_RUNS")) runs = atoi(e) >= (rps + Z14_RUN - 1) / Z14_RUN ? atoi(e) : runs;  // A/B timing
+  static const int lf_prio = getenv("WBX_SPECTRUM_LF_PRIO") ? atoi(getenv("WBX_SPECTRUM_LF_PRIO")) : WBX_SPECTRUM_LF_PRIO_DEFAULT;
   const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
   if (per_xcd < nlocal) nlocal = (int)per_xcd;
   if (prof_path) {
@@ -560,11 +565,11 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     WBX_HIP(hipStreamSynchronize(ctx->stream));
     if (spectrum_knock() == 3)
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 3>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
-                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,
                          reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
     else
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
-                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),
+                         lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,
                          reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
     WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -579,13 +584,13 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   const int knock = spectrum_knock();  // diagnostic, wrong results
 #define WBX_Z14LF_LAUNCH(KN)                                                                                               \
   hipLaunchKernelGGL((zspec1440_latfast_kernel<false, KN>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,  \
-                     lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs),                    \
+                     lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,           \
                      reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr))
   if (knock == 1) WBX_Z14LF_LAUNCH(1);
   else if (knock == 2) WBX_Z14LF_LAUNCH(2);
   else if (knock == 3) WBX_Z14LF_LAUNCH(3);
-  else if (knock == 9) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 1>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // a quarter of the loads in front of pass 1, none behind the unpack
-  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
+  else if (knock == 9) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 1>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // a quarter of the loads in front of pass 1, none behind the unpack
+  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
 
   else WBX_Z14LF_LAUNCH(0);
 #undef WBX_Z14LF_LAUNCH

@@ -360,7 +360,7 @@ typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
 template <bool PROF, int KNOCK = 0, int SPREAD = 2>
 __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
-    int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, const float2* __restrict__ tables_g,
+    int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, int prio, const float2* __restrict__ tables_g,
     const int32_t* __restrict__ group, const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
@@ -370,6 +370,14 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int team = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // every step ends in a block barrier, and the arbiter serves the oldest wave of a SIMD first: with `prio` = 1 the younger
+  // waves of a SIMD (teams 4-7, 8-11) get the higher user priority, so that the three reach the barrier together (2: the reverse)
+  if (prio != 0) {
+    const int rank = prio == 1 ? team >> 2 : 2 - (team >> 2);
+    if (rank == 0) __builtin_amdgcn_s_setprio(0);
+    else if (rank == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+  }
   v4* const buf = bufs + team * Z14_BUFL;
   for (int i = tid; i < Z14_TABLES; i += 64 * Z14_TEAMS) tw1[i] = tables_g[i];
   constexpr int nk = Z14_N2 + 1;
