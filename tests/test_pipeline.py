@@ -88,6 +88,26 @@ def test_chunked_spectra_equal_single_chunk(backend, reduce_dims):
       xr.assert_allclose(want[k], got[k], rtol=1e-9, check_dim_order=False)
 
 
+def test_host_side_constants_are_counted_per_frame():
+  """`engine.Accumulation.capture` counts how often it met one cached read-only array under a path instead of adding it up
+  chunk by chunk -- but only for the same frame: the same numbers under other coordinates are another term (outer join), a
+  writable array is summed as before."""
+  from weatherbenchx_amd import engine  # pylint: disable=g-import-not-at-top
+  const = np.array(np.arange(6, dtype=np.float64).reshape(2, 3))  # (owns its memory, like the cached weight sums)
+  const.flags.writeable = False
+  mk = lambda lead: xr.DataArray(const, dims=('lead_time', 'k'), coords={'lead_time': np.asarray(lead), 'k': np.arange(3)})
+  acc = engine.Accumulation()
+  for _ in range(5):
+    acc.capture('p', mk([0, 6]))
+  acc.capture('p', mk([12, 18]))  # same array, other labels
+  acc.capture('p', xr.DataArray(np.ones((2, 3)), dims=('lead_time', 'k'), coords={'lead_time': np.asarray([0, 6]), 'k': np.arange(3)}))
+  got = acc.host['p']
+  assert list(got['lead_time'].values) == [0, 6, 12, 18]
+  np.testing.assert_array_equal(got.sel(lead_time=[0, 6]).values, 5 * const + 1)
+  np.testing.assert_array_equal(got.sel(lead_time=[12, 18]).values, const)
+  assert len(acc._host_const['p']) == 2 and acc._host_const['p'][0][1] == 5.0  # pylint: disable=protected-access
+
+
 def test_multiple_named_aggregators(backend):
   predictions, targets = _datasets()
   init_times = predictions['geopotential']['time'].values
