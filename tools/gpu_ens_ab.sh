@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the ensemble kernel: the library as built against a second build (WBX_LIBRARY_PATH).  usage: gpu_ens_ab.sh <other.so>
 cd "$(dirname "$0")/.."
-other=${1:-weatherbenchx_amd/libwbx_hip_batcher.so}
+other=${1:-weatherbenchx_amd/libwbx_hip_batcher.so}  # make -C weatherbenchx_amd/csrc ab-batcher
 for round in 1 2; do
   for lib in default "$other"; do
     if [ "$lib" = default ]; then unset WBX_LIBRARY_PATH; else export WBX_LIBRARY_PATH=$PWD/$lib; fi
