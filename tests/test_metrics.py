@@ -296,7 +296,9 @@ def test_rank_form_spread_for_every_register_bucket(backend, m):
   agg = aggregation.Aggregator(reduce_dims=['longitude'])
   got = aggregation.compute_metric_values_for_single_chunk({'spread': probabilistic.CRPSSpread(use_sort=True)}, agg, p, t)
   want, _ = O.crps_spread(pv, ('number', 'latitude', 'longitude'), 'number', fair=True, use_sort=True)
-  np.testing.assert_allclose(got['spread.v'].values, want.mean(axis=-1), rtol=1e-12, atol=1e-300)
+  # M = 50 / 51 run the fp32 chain sums (wbx_ens_impl.hpp stats32: worst case 9 * 2^-24 per point, north_star 1e-6); the other
+  # buckets and the out-of-range escape (mixed magnitudes, denormals) are fp64 sums
+  np.testing.assert_allclose(got['spread.v'].values, want.mean(axis=-1), rtol=1e-6 if m in (50, 51) else 1e-12, atol=1e-300)
 
 
 @pytest.mark.parametrize('member_layout', ['member_slow', 'member_fast'])

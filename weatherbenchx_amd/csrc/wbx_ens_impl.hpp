@@ -15,6 +15,7 @@
 // Members beyond the runtime M (padded buckets) are +inf for the network and skipped in the sums.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 
 #include "wbx_s1.hpp"
 #include "wbx_sortnet_gen.hpp"
@@ -32,6 +33,13 @@
 #define WBX_ENS_SORTNET3 1  // 0: Batcher's compare-exchange network for every size (A/B timing: make EXTRA=-DWBX_ENS_SORTNET3=0)
 #endif
 
+#ifndef WBX_ENS_NOFALLBACK
+#define WBX_ENS_NOFALLBACK 0  // diagnostic builds only
+#endif
+#ifndef WBX_ENS_STATS32
+#define WBX_ENS_STATS32 1  // 0: fp64 sums in the exact-M rank-form kernels too (A/B timing / exactness checks: make EXTRA=-DWBX_ENS_STATS32=0)
+#endif
+
 namespace wbx {
 
 // not part of the ABI enum: stage-1 memory-pattern diagnostic used by tools/kbench.py (lane 0 = sum_m p - t)
@@ -42,6 +50,67 @@ constexpr int WBX_ENS_DIAG_LOADONLY = 99;
 // 1275 |x_i - x_j| terms are formed on register blocks of 17 members read back from there (34 live member registers instead of
 // 51).  M == 51 only.
 constexpr int WBX_ENS_DIAG_PAIRWISE_LDS = 98;
+
+// Generic op: members are re-read from memory (L1/L2-served) instead of living in VGPRs.
+// Always uses the O(M^2) pair form in fp64 -- algebraically identical to the rank form
+// (probabilistic.py:214-247) -- so it serves M > 64 and float64 inputs (the reference's
+// mock test data is float64, test_utils.py:36-48).
+template <typename T>
+struct EnsOpGeneric {
+  static constexpr int NIN = 2;
+  static constexpr int NLANE = WBX_ENS_LANES;
+  static constexpr int NACC = WBX_ENS_LANES;
+  static constexpr int XR_UNROLL = 1, XK_UNROLL = 1, MIN_WAVES = 1;
+
+  __device__ __forceinline__ static void values(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                                double (&val)[NLANE]) {
+    const int M = a.M;
+    const T* pp = reinterpret_cast<const T*>(a.in[0]) + ro[0] + x * a.xstride[0];
+    const double td = (double)(reinterpret_cast<const T*>(a.in[1])[ro[1] + x * a.xstride[1]]);
+    // skipna_ensemble (probabilistic.py:139-145, 206-216, 271-273, 303-336): NaN members are missing members; the
+    // ensemble size becomes the per-point count of non-NaN values.
+    const bool skip = a.flags & WBX_FLAG_SKIPNA_ENS;
+    double se = 0.0, sq = 0.0, sabs = 0.0, pair_total = 0.0, x0 = 0.0;
+    int n = 0;
+    for (int i = 0; i < M; ++i) {
+      const double xi = (double)pp[(int64_t)i * a.mstride];
+      if (skip && xi != xi) continue;
+      if (n == 0) x0 = xi;  // member-only lanes use e = x - x0 and stay finite for a NaN target
+      ++n;
+      const double e = xi - x0;
+      se += e;
+      sq = fma(e, e, sq);
+      sabs += fabs(xi - td);
+      double row = 0.0;
+      for (int j = 0; j < i; ++j) {
+        const double xj = (double)pp[(int64_t)j * a.mstride];
+        if (skip && xj != xj) continue;
+        row += fabs(xi - xj);
+      }
+      pair_total += row;
+    }
+    const double dM = (double)n;
+    const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
+    const double mean_e = se / dM;
+    const double mean_d = (x0 - td) + mean_e;
+    const double var = (sq - se * mean_e) / (dM - 1.0);
+    val[0] = sabs / dM;
+    val[1] = 2.0 * pair_total / (dM * (dM - fair));
+    val[2] = var;
+    val[3] = mean_d * mean_d - var / dM;
+    val[4] = mean_d * mean_d;
+  }
+
+  template <int V, bool XK>
+  __device__ __forceinline__ static void accum(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x,
+                                               double (&acc)[XK ? V : 1][NACC]) {
+    static_assert(V == 1, "ensemble op is one point per lane");
+    double val[NLANE];
+    values(a, ro, x, val);
+#pragma unroll
+    for (int l = 0; l < NLANE; ++l) acc[0][l] += val[l];
+  }
+};
 
 // MP: register bucket (compile time).  EXACT: M == MP known at compile time.
 template <int MP, bool EXACT, int ALGO>
@@ -56,6 +125,7 @@ struct EnsOpF32 {
   struct Regs {
     float xm[MP];
     float t;
+    float poison;  // NaN iff a member is NaN / inf (set by compute())
   };
   // (Register double-buffering of the next point was tried on MI355X: 255 VGPRs, 2 waves/SIMD, 0.49 ms vs 0.39 ms -- dropped.)
 
@@ -88,10 +158,11 @@ struct EnsOpF32 {
                                                 double (&val)[NLANE]) {
     Regs r;
     load(a, ro, x, r);
-    compute(a, r, val);
+    finish(a, ro, x, r, val);
   }
 
-  __device__ __forceinline__ static void compute(const S1Args& a, Regs& r, double (&val)[NLANE]) {
+  // -> true: the point has to be redone by the generic fp64 op (see finish())
+  __device__ __forceinline__ static bool compute(const S1Args& a, Regs& r, double (&val)[NLANE]) {
     const int M = EXACT ? MP : a.M;
     const double td = (double)r.t;
     float(&xm)[MP] = r.xm;
@@ -103,7 +174,7 @@ struct EnsOpF32 {
         if (EXACT || m < M) s += xm[m];
       val[0] = (double)s - td;
       val[1] = val[2] = val[3] = val[4] = 0.0;
-      return;
+      return false;
     }
     double pair_total = 0.0;
     float poison = 0.f;  // NaN iff any member is NaN/inf (v_min/v_max would silently drop a NaN)
@@ -167,6 +238,47 @@ struct EnsOpF32 {
       }
     }
 
+    bool redo = false;
+    if constexpr (EXACT && ALGO == WBX_ENS_SORT && WBX_ENS_STATS32) {
+      // the hot instantiations (M = 50 / 51, rank form): fp32 chain sums on median-centred members (stats32), unless a lane
+      // of the wave holds a point whose magnitudes could overflow / underflow an fp32 square or sum.  Then the CALLER redoes
+      // the point with the generic fp64 op (members re-read from memory, a rolled loop: no registers of the hot path are
+      // spent on the escape; a second set of unrolled fp64 sums here cost 20-40 VGPRs and a wave per SIMD).  Wave-uniform;
+      // never taken on physical fields.  The comparisons are false for NaN: a NaN target goes the same way.
+      const float range = xm[MP - 1] - xm[0];
+      const float big = fmaxf(fmaxf(fabsf(xm[0]), fabsf(xm[MP - 1])), fabsf(r.t));
+      const bool fast_ok = (range == 0.f || (range >= 0x1p-50f && range <= 0x1p60f)) && big <= 0x1p100f;
+      redo = !WBX_ENS_NOFALLBACK && __builtin_amdgcn_ballot_w64(!fast_ok) != 0;
+      if (!redo) stats32(a, xm, r.t, val);
+    } else {
+      stats64(a, xm, td, pair_total, val);
+    }
+    r.poison = poison;
+    if (!redo) apply_poison(r, val);
+    return redo;
+  }
+
+  __device__ __forceinline__ static void apply_poison(const Regs& r, double (&val)[NLANE]) {
+    if constexpr (ALGO == WBX_ENS_SORT) {
+      if (r.poison != r.poison) {  // reference: a NaN member makes every ensemble statistic NaN
+#pragma unroll
+        for (int l = 0; l < NLANE; ++l) val[l] = (double)r.poison;
+      }
+    }
+  }
+
+  // compute() + the escape, for callers that know where the point lives
+  __device__ __forceinline__ static void finish(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r,
+                                                double (&val)[NLANE]) {
+    if (compute(a, r, val)) {
+      EnsOpGeneric<float>::values(a, ro, x, val);
+      apply_poison(r, val);
+    }
+  }
+
+  __device__ __forceinline__ static void stats64(const S1Args& a, float (&xm)[MP], const double td, const double pair_total,
+                                                 double (&val)[NLANE]) {
+    const int M = EXACT ? MP : a.M;
     // Everything is accumulated on e = x - shift (variance and spread are shift invariant).  shift = the target when it
     // is finite, so |x - t| is |e| itself (one fp64 add per member less than a separate x0 shift); with a NaN / infinite
     // target the shift falls back to the first register member, so that the member-only quantities (spread, variance)
@@ -245,12 +357,67 @@ struct EnsOpF32 {
     val[2] = var;
     val[3] = mean_d * mean_d - var * inv_m;
     val[4] = mean_d * mean_d;
-    if constexpr (ALGO == WBX_ENS_SORT) {
-      if (poison != poison) {  // reference: a NaN member makes every ensemble statistic NaN
+  }
+
+  // The fp32 chain sums of the exact-M rank form (M = MP known at compile time, xm ascending).
+  //
+  // Per member the fp64 sums above cost six fp64-class instructions (convert, x - t, and the four accumulations) at 2.1 ns
+  // per wave instruction; plain fp32 adds / FMAs issue at 1.18 ns (tools/ubench/valu_rates).  Here everything per member is
+  // fp32, arranged so that no sum cancels and every chain is short:
+  //   * centre c = the sorted median x_(MP/2).  e_i = fl(x_i - c): one rounding, |error| <= u |e_i|, u = 2^-24, and exact
+  //     whenever x_i and c are within a factor two of each other (Sterbenz): temperatures, geopotential, pressure ...
+  //   * spread:  sum_i (2i - M - 1) x_(i) = sum_{i < M/2} (M - 1 - 2i) (x_(M-1-i) - x_(i)): every term is a non-negative
+  //     difference times a positive integer <= 50, so the relative error of the sum is bounded by the chain length: no term
+  //     can cancel another.
+  //   * skill:   sum_i |x_i - t|, terms non-negative.
+  //   * sum e^2: terms non-negative.  With the median as centre sum e^2 / M <= 2 var_pop (|mean - median| <= sigma), so
+  //     var = (sum e^2 - (sum e)^2 / M) / (M - 1) loses at most a factor ~2-3 to the subtraction, whatever the bias to the
+  //     target is (the fp64 path's shift is the target: exact in fp64, hopeless in fp32 when |bias| >> spread).
+  //   * sum e:   accumulated as pairs e_i + e_(M-1-i), which have opposite signs around the median: partial sums stay small.
+  // K = 8 interleaved chains per sum (<= 8 terms each), chains added in pairs in fp32, the four pair sums widened and added
+  // in fp64; the rest of the point (mean, variance, squares) is fp64 as before.  Worst-case relative error of each
+  // non-negative sum: (1 rounding of the term + 7 chain adds + 1 pair add) u = 9 u = 5.4e-7; typical (random rounding) ~2 u;
+  // measured against the float64 oracle in tests/test_metrics.py and tests/test_gpu_round3.py.  The north_star tolerance
+  // is 1e-6 on the aggregated value (a weighted mean of >= 10^3 such points, whose errors do not add coherently).
+  __device__ __forceinline__ static void stats32(const S1Args& a, float (&xm)[MP], const float t, double (&val)[NLANE]) {
+    static_assert(EXACT, "fp32 chain sums are instantiated for the exact-M buckets");
+    constexpr int K = 8, MID = MP / 2, NPAIR = MP / 2;
+    const float c = xm[MID];
+    float se[K], sq[K], sa[K], dt[K];
 #pragma unroll
-        for (int l = 0; l < NLANE; ++l) val[l] = (double)poison;
-      }
+    for (int k = 0; k < K; ++k) se[k] = sq[k] = sa[k] = dt[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      const int j = MP - 1 - i, k = i % K;
+      const float ei = xm[i] - c, ej = xm[j] - c;
+      se[k] += ei + ej;
+      sq[k] = fmaf(ei, ei, sq[k]);
+      sq[k] = fmaf(ej, ej, sq[k]);
+      sa[k] += fabsf(xm[i] - t);
+      sa[k] += fabsf(xm[j] - t);
+      dt[k] = fmaf((float)(MP - 1 - 2 * i), xm[j] - xm[i], dt[k]);
     }
+    if constexpr (MP & 1) {
+      sa[NPAIR % K] += fabsf(c - t);  // the median itself: e = 0, rank weight 0
+    } else {
+      // even M: x_(MID) is the upper median and already went through the loop as j = MID of the pair i = MID - 1
+    }
+    auto fold = [](const float (&v)[K]) {
+      return ((double)(v[0] + v[4]) + (double)(v[1] + v[5])) + ((double)(v[2] + v[6]) + (double)(v[3] + v[7]));
+    };
+    const double dse = fold(se), dsq = fold(sq), dsa = fold(sa), ddt = fold(dt);
+    constexpr double dM = (double)MP;
+    const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
+    constexpr double inv_m = 1.0 / dM, inv_m1 = 1.0 / (dM - 1.0);
+    const double spread_scale = 2.0 / (dM * (dM - fair));
+    const double mean_e = dse * inv_m;
+    const double mean_d = ((double)c - (double)t) + mean_e;  // mean_m p - t
+    const double var = (dsq - dse * mean_e) * inv_m1;         // ddof = 1
+    val[0] = dsa * inv_m;
+    val[1] = ddt * spread_scale;
+    val[2] = var;
+    val[3] = mean_d * mean_d - var * inv_m;
+    val[4] = mean_d * mean_d;
   }
 
   template <int V, bool XK>
@@ -301,6 +468,194 @@ struct EnsMasked {
   }
 };
 
+
+// ---------------------------------------------------------------------------------------------
+// The x-summed sweep of the unmasked fp32 ensemble ops with the NEXT tile's members in flight while this one is reduced.
+//
+// s1_xr_kernel reduces a 64-point tile as  [52 loads] -> wait -> [~1100 VALU instructions]: a wave's own loads and arithmetic
+// never overlap, and three waves per SIMD (133 VGPRs) cover only part of the ~5 us a tile's loads take at this bandwidth
+// (load-only 0.256 ms, arithmetic ~0.25 ms, kernel 0.31 ms per 1.73 GB: the two add up to 80 % instead of overlapping).
+// Register double-buffering needs 255 VGPRs (tried in round 1: slower).  Here the next tile goes through the LDS instead:
+//   * `global_load_lds_dword` (LDS-DMA) writes a member's 64 dwords straight into the wave's staging buffer
+//     stage[member][lane] -- no VGPR is held while the load is in flight;
+//   * the address is  SGPR base (row + member * stride, scalar adds) + one shared 32-bit VGPR offset (x):  no 64-bit vector
+//     address arithmetic at all (the 68 v_lshl_add_u64 per tile of the register version);
+//   * per tile: wait vmcnt(0) -> 50 members from the LDS into VGPRs (ds_read2st64_b32, bank = lane) -> wait lgkmcnt(0) ->
+//     issue the next tile's 50 LDS-DMA loads -> sort + sums of this tile.
+// LDS is allocated in 1280-byte granules on gfx950: 50 members x 256 B = 12 800 B = exactly ten, so twelve one-wave blocks
+// (3 per SIMD) fit the 160 KB of a CU; the 51st member and the target ride in two VGPRs loaded one tile ahead.
+// One wave per block; rows (depth) and x tiles of the block's (key, chunk) form one tile sequence.
+// A wave-uniform pointer the compiler also KNOWS to be uniform (SGPR pair): row offsets come out of tables through vector
+// loads once an asm statement clobbers memory.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
+// FLAT: the latitude-fastest flavour (s1_xf1_kernel's geometry): the block's rows are runs of a contiguous plane walked by a
+// flat element index e, lanes starting on a 64-element boundary of the plane, every point weighted with xw[e mod nx]
+// (fp64, fetched one tile ahead like the target).  Otherwise a segment is one depth row, e = x.
+#ifndef WBX_ENS_PIPE_NLDS
+#define WBX_ENS_PIPE_NLDS 50   // members staged through the LDS (x 256 B per one-wave block)
+#endif
+#ifndef WBX_ENS_PIPE_WAVES
+#define WBX_ENS_PIPE_WAVES 3   // waves per SIMD the register budget is cut for (12 800-byte blocks: 12 per CU)
+#endif
+template <int MP, bool EXACT, int ALGO, bool FLAT>
+__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a, int R) {
+  using Op = EnsOpF32<MP, EXACT, ALGO>;
+  constexpr int NA = Op::NACC;
+  constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
+  constexpr int NREG = MP - NLDS;          // members prefetched into VGPRs
+  __shared__ float stage[NLDS][64];
+  const int lane = threadIdx.x;
+  const int M = EXACT ? MP : a.M;
+  const int64_t b = blockIdx.x;
+  const int64_t key = b / a.nchunk;
+  const int chunk = (int)(b - key * a.nchunk);
+  const int64_t d0 = (int64_t)chunk * a.dchunk;
+  const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+  const int nx = (int)a.nx;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&stage[0][0];
+  const int64_t mstride_b = a.mstride * 4;
+
+  int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
+  key_bases<2>(a, key, kb);
+  double acc[NA];
+#pragma unroll
+  for (int l = 0; l < NA; ++l) acc[l] = 0.0;
+
+  // the current segment: elements [e0, e1) of the row / plane at `ro`, tiles of 64 from ea; d = the depth row behind it
+  int64_t d = d0, e0 = 0, e1 = 0, et = 0;
+  int wi = 0;  // FLAT: this lane's weight index (e mod nx) at tile et
+  auto open_segment = [&]() {  // d < d1
+    if constexpr (FLAT) {
+      const int64_t plane = d / R, j0 = d - plane * R;
+      const int64_t nj = d1 - d < R - j0 ? d1 - d : R - j0;
+      row_bases<2>(a, kb, key, plane * R, ro);
+      e0 = j0 * nx;
+      e1 = (j0 + nj) * nx;
+      et = e0 & ~(int64_t)63;
+      wi = (int)((et + lane) % nx);
+      d += nj;
+    } else {
+      row_bases<2>(a, kb, key, d, ro);
+      e0 = 0;
+      e1 = nx;
+      et = 0;
+      d += 1;
+    }
+  };
+
+  float xn[NREG > 0 ? NREG : 1], tn = 0.f;
+  double wn = 1.0;
+  auto issue = [&]() {  // the tile at et of the open segment
+    int64_t e = et + lane;
+    e = e < e0 ? e0 : (e < e1 ? e : e1 - 1);  // lanes outside the segment re-read its edge (counted out below): no EXEC games
+    const uint32_t voff = (uint32_t)e * (uint32_t)a.xstride[0] * 4u;
+    const char* um = uniform_ptr(reinterpret_cast<const char*>(a.in[0]) + ro[0] * 4);
+#pragma unroll
+    for (int m = 0; m < NLDS; ++m) {
+      if (EXACT || m < M)
+        asm volatile("s_add_u32 m0, %2, %3\n\tglobal_load_lds_dword %0, %1 nt" ::"v"(voff), "s"(um), "s"(lds0), "i"(m * 256)
+                     : "memory", "scc", "m0");
+      um += mstride_b;
+      asm volatile("" : "+s"(um));  // one s_add_u32 / s_addc_u32 per member, not a table of 50 hoisted products
+    }
+    const float* pr = reinterpret_cast<const float*>(a.in[0]) + ro[0] + e * a.xstride[0];
+#pragma unroll
+    for (int m = NLDS; m < MP; ++m) xn[m - NLDS] = (EXACT || m < M) ? ld_stream(pr + (int64_t)m * a.mstride) : INFINITY;
+    tn = ld_stream(reinterpret_cast<const float*>(a.in[1]) + ro[1] + e * a.xstride[1]);
+    if constexpr (FLAT) wn = a.xw[wi];
+  };
+
+  bool more = d < d1;
+  if (more) {
+    open_segment();
+    issue();
+  }
+  while (more) {
+    typename Op::Regs r;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < NLDS; ++m) r.xm[m] = (EXACT || m < M) ? stage[m][lane] : INFINITY;
+#pragma unroll
+    for (int m = NLDS; m < MP; ++m) r.xm[m] = xn[m - NLDS];
+    r.t = tn;
+    const double w = wn;
+    const int64_t ecur = et + lane;
+    const bool valid = ecur >= e0 && ecur < e1;
+    const int64_t xcur = ecur < e0 ? e0 : (ecur < e1 ? ecur : e1 - 1);
+    int64_t rocur[WBX_MAX_INPUTS];
+#pragma unroll
+    for (int i = 0; i < WBX_MAX_INPUTS; ++i) rocur[i] = ro[i];
+    et += 64;
+    if constexpr (FLAT) {
+      wi += 64;
+      if (nx >= 64) {
+        wi = wi >= nx ? wi - nx : wi;
+      } else {
+        wi %= nx;
+      }
+    }
+    if (et >= e1) {
+      more = d < d1;
+      if (more) open_segment();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile has left the staging buffer
+    if (more) issue();
+    double val[Op::NLANE];
+    Op::finish(a, rocur, xcur, r, val);
+#pragma unroll
+    for (int l = 0; l < NA; ++l) {
+      if constexpr (FLAT) {
+        acc[l] = valid ? fma(val[l], w, acc[l]) : acc[l];
+      } else {
+        acc[l] += valid ? val[l] : 0.0;
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NA; ++l) {
+    const double v = wave_sum(acc[l]);
+    if (lane == l) a.out[(key * a.nchunk + chunk) * NA + l] = v;
+  }
+}
+
+#pragma clang diagnostic pop
+
+// Eligibility of the pipelined sweep: plain (no mask / skipna wrappers), x summed, offsets inside a segment within 32 bits;
+// one-wave blocks for the row flavour (the flat flavour keeps the plan's chunking and launches one wave per chunk).
+inline bool ens_pipe_ok(const wbx_s1_plan* plan, const S1Args& a) {
+  static const bool off = getenv("WBX_ENS_PIPE") && atoi(getenv("WBX_ENS_PIPE")) == 0;  // A/B against s1_xr_kernel / s1_xf1_kernel
+  if (off) return false;
+  if (plan->x_kept) return false;
+  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA | WBX_FLAG_SKIPNA_ENS)) return false;
+  if (plan->nx <= 0 || plan->ndepth <= 0 || plan->nkey <= 0) return false;
+  if (a.xstride[0] < 0 || a.xstride[1] < 0) return false;
+  if (plan->x_weights != nullptr) {  // flat flavour: launch_flat_weighted1's requirements
+    if (plan->plane_rows <= 0 || plan->ndepth % plan->plane_rows != 0 || a.xstride[0] != 1 || a.xstride[1] != 1) return false;
+    return (double)plan->nx * (double)plan->plane_rows * 4.0 < 4294967296.0;
+  }
+  if (plan->block_threads != 64) return false;
+  return (double)plan->nx * (double)a.xstride[0] * 4.0 < 4294967296.0;
+}
+
+template <int MP, bool EXACT, int ALGO>
+int launch_ens_pipe(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
+  const int64_t grid = plan->nkey * plan->nchunk;
+  WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
+  if (plan->x_weights != nullptr)
+    hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, plan->plane_rows);
+  else
+    hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, 1);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 template <class Op>
 int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
   if (map) return launch_map<Op>(ctx, plan, a);
@@ -317,6 +672,8 @@ int launch_ens_op(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, bool map) {
 
 template <int MP, bool EXACT>
 int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo, bool map) {
+  // (the pair form stays on s1_xr_kernel: pipelined it takes 168 VGPRs + scratch, and it is a diagnostic since round 3)
+  if (!map && algo == WBX_ENS_SORT && ens_pipe_ok(plan, a)) return launch_ens_pipe<MP, EXACT, WBX_ENS_SORT>(ctx, plan, a);
   if (algo == WBX_ENS_SORT) return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_SORT>>(ctx, plan, a, map);
   if (algo == WBX_ENS_DIAG_LOADONLY) {
     if (!EXACT || map) return fail(WBX_ERR_INVALID, "the load-only diagnostic exists for the exact-M partial kernels only");

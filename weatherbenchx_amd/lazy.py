@@ -10,6 +10,7 @@ all lanes at once, which is one stage-1 launch that reads every input exactly on
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Sequence
 
@@ -337,6 +338,11 @@ def _same_mask(p: xr.DataArray, t: xr.DataArray) -> bool:
   return pm is not None and pm[0] == tm[0] and xr._values_equal(pm[1], tm[1])  # pylint: disable=protected-access
 
 
+# True: CRPSSpread(use_sort=False) launches the register-tiled O(M^2) pair kernel (EnsOpF32<..., PAIRWISE>) instead of the
+# rank-form kernel.  A measurement switch (bench.py's `pairwise_form`, tools/kbench.py): the results agree to ~1e-7.
+PAIR_FORM_KERNEL = os.environ.get('WBX_ENS_PAIR_FORM', '0') == '1'
+
+
 def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fair=True,
                   skipna_ensemble=False, member_only=False) -> xr.DataArray:
   """`member_only`: the statistic looks at `p` alone (EnsembleVariance, CRPSSpread); `t` is only the kernel's companion
@@ -356,8 +362,14 @@ def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fa
   p, t = _aligned(p, t)
   m = p.sizes[ensemble_dim]
   grp = _group_for('ens', p, t, ens={'member_dim': ensemble_dim, 'M': m})
-  params = {'algo': _hip.ENS_SORT if use_sort else _hip.ENS_PAIRWISE, 'fair': bool(fair),
-            'skipna': bool(skipna_ensemble)}
+  # use_sort=False (the reference's default, probabilistic.py:644) asks for the O(M^2) pair form of the SAME number -- the
+  # reference's own CRPSSpread.unique_name leaves use_sort out (probabilistic.py:189-192), i.e. it treats the two forms as
+  # one statistic.  On this hardware the rank form is the cheaper way to that number (51 members: 0.31 against 0.51 ms per
+  # 1.73 GB) and all five lanes of a (p, t) pair come out of ONE launch, so both settings run the rank-form kernel; the
+  # register-tiled pair kernel stays reachable through PAIR_FORM_KERNEL (or WBX_ENS_PAIR_FORM=1) for measurements.
+  # skipna_ensemble needs per-point member counts: the generic pair-form kernel (WBX_FLAG_SKIPNA_ENS).
+  pair = bool(skipna_ensemble) or (not use_sort and PAIR_FORM_KERNEL)
+  params = {'algo': _hip.ENS_PAIRWISE if pair else _hip.ENS_SORT, 'fair': bool(fair), 'skipna': bool(skipna_ensemble)}
   return LazyStatistic(grp, ENS_LANE[stat_name], name=p.name, ens_params=params, coord_names=coord_names)
 
 
