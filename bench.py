@@ -6,31 +6,34 @@ itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --ma
 backend 'nccl' = RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Fewer visible devices than N: one JSON
 line with "skipped" and exit code 0.
 
-Main line (BASELINE.json configs[1]): area-weighted RMSE / MSE / MAE / bias / ACC / prediction activity on one variable
-block float32[40 init, 10 lead, 5 level, 721 lat, 1440 lon] for predictions and targets plus a (dayofyear, hour)-indexed
-climatology, reduced over (init_time, latitude, longitude) with GridAreaWeighting -- through the drop-in API
-(Statistic.compute -> Aggregator.aggregate_statistics -> metric_values), inputs resident in HBM.  A "step" is one such
-pass; the K timed steps are software-pipelined one deep like pipeline.evaluate_chunks (every step is launched and
-finished inside the timed region).  With N ranks every rank owns a block of the same size (weak scaling): the step's
-sums stay in HBM (engine.Accumulation) and are summed over the ranks with ONE all-reduce of the device buffer per step
-(distributed.resolve_state; the layout is exchanged once, before the first step).
+Main line = the configuration BASELINE.json's metric and north_star name: area-weighted CRPS (fair) + unbiased spread/skill +
+unbiased ensemble-mean RMSE + ensemble-mean RMSE on ONE forecast field float32[1 init, 37 level, 51 member, 721, 1440]
+(7.99 GB) against float32[1, 37, 721, 1440] targets, reduced over (init_time, latitude, longitude) with GridAreaWeighting --
+through the drop-in API (Statistic.compute -> Aggregator.aggregate_statistics -> metric_values), inputs resident in HBM.
+A "step" is one such pass; the K timed steps are software-pipelined one deep like pipeline.evaluate_chunks (every step is
+launched and finished inside the timed region).  With N ranks every rank owns one such field = one (init, lead) time slice
+(weak scaling): the step's sums stay in HBM (engine.Accumulation) and are summed over the ranks with ONE all-reduce of the
+device buffer per step (distributed.resolve_state; the layout is exchanged once, before the first step).
 
-value    = (points per step x 6 metrics x N) / wall time per step (max over ranks), evals/s
-roofline = algorithmic bytes (12 B/point: p, t, c read once) / mean stage-1 kernel duration (HIP events on the launch
-           stream, separate pass), against 8.0 TB/s
+value    = (grid points per step x 4 metrics x N) / wall time per step (max over ranks), evals/s; ensemble members are not
+           extra points
+roofline = algorithmic bytes (208 B/point: 51 members + the target, read once) / mean duration of the ensemble kernel
+           (HIP events on the launch stream, separate pass), against 8.0 TB/s
 
 Side legs in the same line (N = 1 unless noted):
-  rmse_crps_37L  the north_star's target field: weighted CRPS + spread/skill + ensemble-mean RMSE on ONE
-                 f32[37 level, 51 member, 721, 1440] forecast (7.99 GB) against f32[37, 721, 1440] targets
-  ensemble       configs[2]: 6 variables x f32[8, 51, 721, 1440]
+  configs1       BASELINE.json configs[1]: RMSE / MSE / MAE / bias / ACC / activity on f32[40 init, 10 lead, 5 level, 721, 1440]
+                 p, t + (dayofyear, hour) climatology (the main line of rounds 1-2)
+  ensemble       configs[2]: 6 variables x f32[8, 51, 721, 1440]; `pairwise_form`: the O(M^2) pair kernel alone
   public_chunk   the public benchmark's chunk (1 init x 12 lead x 13 level, 34 region x land/sea bins, masked)
   spectrum       configs[3]: zonal spectra of two f32[8, 37, 721, 1440] fields
+  lat_fastest    the main line, configs1 and spectrum again on latitude-fastest arrays (the layout of the public archives)
   config5        configs[4] (every N): the full suite streamed as [1 init x 20 lead x 37 level] chunks from a resident
                  pool through pipeline.evaluate_chunks, 366 inits sharded i mod N, accumulators in HBM, ONE all-reduce
-                 per pass at the end; strong scaling (total work fixed)
+                 at the end; strong scaling (total work fixed)
   cpu_baseline   the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
-                 statistics; oracle/wbx_oracle.py) on a bounded sample: one process, and os.cpu_count() worker
-                 processes over time slices (oracle/cpu_workers.py); rank 0, N = 1 only.
+                 statistics; oracle/wbx_oracle.py) on bounded samples: the ensemble suite (the main line's workload) and the
+                 deterministic suite (configs1), each on one process and on os.cpu_count() worker processes
+                 (oracle/cpu_workers.py); rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -45,7 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-METRIC = 'grid-point·metric evals/s (area-weighted RMSE/MSE/MAE/bias/ACC/activity, 0.25deg 721x1440)'
+METRIC = 'grid-point·metric evals/s (0.25° 721×1440×37L) at 1/2/4/8 GPUs; % HBM roofline'  # BASELINE.json's string
 
 
 def parse():
@@ -57,7 +60,7 @@ def parse():
   ap.add_argument('--leads', type=int, default=10)
   ap.add_argument('--levels', type=int, default=5)
   ap.add_argument('--layout', choices=['lon_fastest', 'lat_fastest'], default='lon_fastest')
-  ap.add_argument('--no-ens', action='store_true', help='skip the single-GPU side legs (ensemble, 37L, public chunk, spectrum)')
+  ap.add_argument('--no-ens', action='store_true', help='skip the single-GPU side legs (configs1, ensemble, public chunk, spectrum, lat_fastest)')
   ap.add_argument('--ens-slices', type=int, default=8)
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
@@ -66,7 +69,7 @@ def parse():
   ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                   help='torch.distributed backend for N > 1; gloo combines through the host and lets several ranks share '
                        'one device (a plumbing check of the N > 1 path on a 1-GPU box, not a measurement)')
-  ap.add_argument('--legs', default='all', help='comma list of main,rmse_crps_37L,ensemble,public_chunk,spectrum,config5,cpu '
+  ap.add_argument('--legs', default='all', help='comma list of main,configs1,ensemble,public_chunk,spectrum,lat_fastest,config5,cpu '
                   '(profiling passes: one kernel shape per trace); default all')
   ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
   return ap.parse_args()
@@ -115,9 +118,13 @@ class Env:
     self.nlat, self.nlon = (721, 1440) if not args.small else (73, 144)
     self.lat = np.linspace(-90, 90, self.nlat)
     self.lon = np.linspace(0, 360, self.nlon, endpoint=False)
-    self.sp = ('latitude', 'longitude') if args.layout == 'lon_fastest' else ('longitude', 'latitude')
+    self.set_layout(args.layout)
     self.gen = torch.Generator(device=self.dev)
     self.gen.manual_seed(1234 + self.rank)
+
+  def set_layout(self, layout):
+    self.layout = layout
+    self.sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
 
   def randn(self, shp, offset=0.0, scale=1.0, gen=None):
     t = self.torch.randn(shp, generator=gen or self.gen, device=self.dev, dtype=self.torch.float32)
@@ -182,36 +189,46 @@ def pmc_traffic(kernel_key, enabled=True, variant=None):
   return None if not entry else entry.get('traffic_bytes_per_launch')
 
 
-# ---- main line: configs[1] -----------------------------------------------------------------------------------------
+# ---- main line: the north_star field ---------------------------------------------------------------------------------------
+def ens_kernel_name(e, m=51):
+  """The kernel wbx_ens_partial launches for this event (the dispatch rule of csrc/wbx_ens_impl.hpp restated)."""
+  if e.get('algo') == 1:
+    return f's1_xr_kernel<EnsOpF32<{m},true,PAIRWISE>,1> (register-tiled O(M^2) pair form)'
+  piped = (os.environ.get('WBX_ENS_PIPE', '1') != '0' and e.get('block') == 64 and not e.get('x_kept') and not e.get('x_weighted')
+           and not (e.get('flags', 0) & 11))
+  if piped:
+    return f'ens_pipe_kernel<{m},true,SORT> (rank form, next tile through LDS-DMA, fp32 chain sums)'
+  if e.get('flat'):
+    return f's1_xf1_kernel<EnsOpF32<{m},true,SORT>> (rank form, folded latitude weights, flat sweep, one point per lane)'
+  return f"s1_{'xk' if e.get('x_kept') else 'xr'}_kernel<EnsOpF32<{m},true,SORT>,1>"
+
+
 def main_leg(env):
+  """ONE f32[1 init, 37 level, 51 member, lat, lon] forecast per rank against f32[1, 37, lat, lon] targets."""
   from weatherbenchx_amd import aggregation, distributed, engine, weighting
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.metrics import base as metrics_base
-  from weatherbenchx_amd.metrics import deterministic
-  args = env.args
-  ni, nl, nlev = (args.inits, args.leads, args.levels) if not args.small else (4, 3, 2)
-  init_time = np.datetime64('2020-01-01T00', 'ns') + np.arange(ni) * np.timedelta64(24, 'h')
-  lead_time = (np.arange(nl) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
-  ndoy = int(ni + (nl * 6) // 24 + 2)
-  coords = {'init_time': init_time, 'lead_time': lead_time, 'level': np.arange(nlev), 'latitude': env.lat, 'longitude': env.lon}
-  dims = ('init_time', 'lead_time', 'level') + env.sp
-  cdims = ('dayofyear', 'hour', 'level') + env.sp
-  shape = tuple(len(coords[d]) for d in dims)
-  clim_t = env.randn((ndoy, 4) + shape[2:], 280.0, 10.0)
-  clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=cdims, coords={
-      'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), **{d: coords[d] for d in cdims[2:]}})})
-  p_t, t_t = env.randn(shape, 280.0), env.randn(shape, 280.0)
-  p = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}
-  t = {'z': xr.DataArray(t_t, dims=dims, coords=coords)}
+  args, m = env.args, 51
+  nlev = 37 if not args.small else 3
+  sp_shape = env.sp_shape()
+  # every rank's field is another (init, lead) time slice: its own init_time label, the sums combine over init_time
+  init_time = np.array([np.datetime64('2020-01-01T00', 'ns') + env.rank * np.timedelta64(24, 'h')])
+  cs = {'init_time': init_time, 'level': np.arange(nlev), 'latitude': env.lat, 'longitude': env.lon}
+  # exchangeable synthetic ensemble: members and the target are independent N(0, 1) draws around a common state, so the
+  # unbiased spread/skill ratio is ~1 (a target that IS the ensemble centre makes the unbiased MSE vanish)
+  tv = env.randn((1, nlev) + sp_shape, 280.0)
+  ens = env.randn((1, nlev, m) + sp_shape)
+  ens += tv[:, :, None]
+  tv += env.randn((1, nlev) + sp_shape)
+  pe = {'t': xr.DataArray(ens, dims=('init_time', 'level', 'number') + env.sp, coords=cs)}
+  te = {'t': xr.DataArray(tv, dims=('init_time', 'level') + env.sp, coords=cs)}
   env.torch.cuda.synchronize()
-  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(),
-             'bias': deterministic.Bias(), 'acc': deterministic.ACC(clim),
-             'prediction_activity': deterministic.PredictionActivity(clim)}
+  metrics = ensemble_suite()
   agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
   plan_box = [None]
 
   def stats():
-    return metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(p), fresh(t))
+    return metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(pe), fresh(te))
 
   if env.world == 1:
     def launch():  # Statistic.compute -> Aggregator.aggregate_statistics: enqueues the kernels and the read-back
@@ -244,8 +261,100 @@ def main_leg(env):
   env.sync()
   dt = env.max_over_ranks(time.perf_counter() - t0)
   ms_per_step = dt / args.steps * 1e3
-  points = int(np.prod(shape, dtype=np.int64))
+  points = nlev * env.nlat * env.nlon
   value = points * len(metrics) * env.world / (ms_per_step * 1e-3)
+
+  # roofline leg: HIP events around the ensemble kernel, separate pass, 5 launches per event pair
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
+  for _ in range(4):
+    agg.aggregate_statistics(stats()).metric_values(metrics)
+  log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+  engine.S1_EVENT_LOG = None
+  ms_list = sorted(e['ms'] for e in log)
+  k_ms = float(np.median(ms_list))
+  kname = ens_kernel_name(log[0], m)
+  roofline = kernel_roofline(kname, k_ms, points * (m + 1) * 4, pmc_traffic('ens_pipe_kernel', nlev == 37 and not args.small, env.layout))
+  roofline['kernel_ms_min_max'] = [round(ms_list[0], 4), round(ms_list[-1], 4)]
+  roofline['launches_per_step'] = len(log) // 4
+  roofline['bytes_per_point'] = (m + 1) * 4
+  roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; replayed, not measured in this run)'
+
+  result = {
+      'metric': METRIC, 'value': value, 'unit': 'evals/s', 'n_gpus': env.world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+      'data': 'synthetic',
+      'config': {'workload': f'north_star: area-weighted CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + ensemble-mean RMSE on ONE '
+                             f'f32[1 init,{nlev} level,{m} member,{env.nlat},{env.nlon}] forecast per GPU vs f32[1,{nlev},{env.nlat},{env.nlon}] '
+                             f'targets, reduce (init_time,latitude,longitude), GridAreaWeighting, {env.layout}',
+                 'points_per_step_per_gpu': points, 'members': m, 'metrics': list(metrics), 'input_dtype': 'f32',
+                 'arithmetic': 'sorting network + fp32 chain sums per point (worst case 9 x 2^-24 relative, wbx_ens_impl.hpp), '
+                               'fp64 sums across points',
+                 'accumulators': 'f64', 'layout': env.layout,
+                 'host_pipeline': 'steps overlapped one deep; ' + ('deferred read-back (engine.deferred_results)' if env.world == 1 else
+                                  'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
+                 'sharding': f'{env.world} x one (init, lead) field per rank, 1 all-reduce/step',
+                 'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0, 'backend': args.backend if env.world > 1 else None,
+                 'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
+      'roofline': roofline,
+  }
+  # sanity: an exchangeable ensemble of N(0,1) draws: CRPS = 2/sqrt(pi) * (1 - ... ) ~ 0.5642 x sigma_eff, spread/skill ~ 1
+  crps = float(np.asarray(out['crps.t'].values).mean())
+  ssr = float(np.asarray(out['unbiased_spread_skill.t'].values).mean())
+  assert np.isfinite(crps) and abs(crps - 0.5642) < 0.01 and abs(ssr - 1.0) < 0.01, (crps, ssr)
+  result['check'] = {'crps_mean': crps, 'unbiased_spread_skill_mean': ssr,
+                     'mean_rmse': float(np.asarray(out['mean_rmse.t'].values).mean())}
+  del pe, te, ens, tv
+  return result
+
+
+# ---- configs[1]: the deterministic suite (main line of rounds 1-2), N = 1 ----------------------------------------------------
+def configs1_leg(env):
+  from weatherbenchx_amd import aggregation, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic
+  args = env.args
+  ni, nl, nlev = (args.inits, args.leads, args.levels) if not args.small else (4, 3, 2)
+  init_time = np.datetime64('2020-01-01T00', 'ns') + np.arange(ni) * np.timedelta64(24, 'h')
+  lead_time = (np.arange(nl) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  ndoy = int(ni + (nl * 6) // 24 + 2)
+  coords = {'init_time': init_time, 'lead_time': lead_time, 'level': np.arange(nlev), 'latitude': env.lat, 'longitude': env.lon}
+  dims = ('init_time', 'lead_time', 'level') + env.sp
+  cdims = ('dayofyear', 'hour', 'level') + env.sp
+  shape = tuple(len(coords[d]) for d in dims)
+  clim_t = env.randn((ndoy, 4) + shape[2:], 280.0, 10.0)
+  clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=cdims, coords={
+      'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), **{d: coords[d] for d in cdims[2:]}})})
+  p_t, t_t = env.randn(shape, 280.0), env.randn(shape, 280.0)
+  p = {'z': xr.DataArray(p_t, dims=dims, coords=coords)}
+  t = {'z': xr.DataArray(t_t, dims=dims, coords=coords)}
+  env.torch.cuda.synchronize()
+  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(),
+             'bias': deterministic.Bias(), 'acc': deterministic.ACC(clim),
+             'prediction_activity': deterministic.PredictionActivity(clim)}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  def stats():
+    return metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(p), fresh(t))
+
+  def launch():  # Statistic.compute -> Aggregator.aggregate_statistics: enqueues the kernels and the read-back
+    return agg.aggregate_statistics(stats())
+
+  def finish(state):  # waits for THAT step's sums only, then the metric values on the host
+    return state.metric_values(metrics)
+
+  def run(n):
+    with engine.deferred_results():
+      return pipelined(launch, finish, n)
+
+  out = run(args.warmup)
+  env.sync()
+  t0 = time.perf_counter()
+  out = run(args.steps)
+  env.sync()
+  dt = time.perf_counter() - t0
+  ms_per_step = dt / args.steps * 1e3
+  points = int(np.prod(shape, dtype=np.int64))
+  value = points * len(metrics) / (ms_per_step * 1e-3)
 
   # roofline leg: HIP events around the dominant (stage-1) kernel, separate pass, 10 launches per event pair
   engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 10
@@ -269,18 +378,9 @@ def main_leg(env):
   roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
   result = {
-      'metric': METRIC, 'value': value, 'unit': 'evals/s', 'n_gpus': env.world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
-      'data': 'synthetic',
-      'config': {'workload': f'configs[1]: f32[{ni} init,{nl} lead,{nlev} level,{env.nlat},{env.nlon}] p,t + (doy,hour) climatology, '
-                             f'reduce (init_time,latitude,longitude), GridAreaWeighting, {args.layout}',
-                 'points_per_step_per_gpu': points, 'metrics': list(metrics), 'input_dtype': 'f32', 'accumulators': 'f64',
-                 'layout': args.layout,
-                 'host_pipeline': 'steps overlapped one deep; ' + ('deferred read-back (engine.deferred_results)' if env.world == 1 else
-                                  'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
-                 'sharding': f'{env.world} x (init x lead) blocks (one per rank), 1 all-reduce/step',
-                 'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0, 'backend': args.backend if env.world > 1 else None,
-                 'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
+      'workload': f'configs[1]: f32[{ni} init,{nl} lead,{nlev} level,{env.nlat},{env.nlon}] p,t + (doy,hour) climatology, '
+                  f'rmse/mse/mae/bias/acc/activity, reduce (init_time,latitude,longitude), GridAreaWeighting, {env.layout}',
+      'value': value, 'unit': 'evals/s', 'ms_per_step': ms_per_step, 'points_per_step': points, 'metrics': list(metrics),
       'roofline': roofline,
   }
   # sanity: values must be finite and physically plausible (sigma=1 errors -> rmse ~ sqrt(2))
@@ -338,26 +438,46 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   for _ in range(3):
     launch().metric_values(emetrics)
   elog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
-  # the north_star's pairwise |x_i - x_j| form (use_sort=False: the 1275 pairs of a point tiled in registers),
-  # timed on the same launch shape beside the rank form
+  # (a) the reference-DEFAULT CRPSEnsemble() (use_sort=False, probabilistic.py:644) through the API: launches per variable
+  # and their cost -- it shares the rank-form launch since round 3 (lazy.ens_statistic); (b) the north_star's pairwise
+  # |x_i - x_j| form as a kernel: lazy.PAIR_FORM_KERNEL routes use_sort=False to the register-tiled O(M^2) pair kernel, and
+  # only events of THAT algorithm are counted (round 2 averaged rank- and pair-form launches here).
+  from weatherbenchx_amd import lazy as _lazy
   from weatherbenchx_amd.metrics import probabilistic as _prob
-  pmet = {'crps_pairwise': _prob.CRPSEnsemble(use_sort=False)}
+  pmet = {'crps_default': _prob.CRPSEnsemble()}
   k0 = next(iter(pe))
+
+  def default_crps():
+    return eagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(
+        pmet, fresh({k0: pe[k0]}), fresh({k0: te[k0]}))).metric_values(pmet)
   engine.S1_EVENT_LOG = []
   for _ in range(2):
-    eagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(pmet, fresh({k0: pe[k0]}), fresh({k0: te[k0]}))).metric_values(pmet)
-  plog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+    dout = default_crps()
+  dlog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+  engine.S1_EVENT_LOG = []
+  was = _lazy.PAIR_FORM_KERNEL
+  _lazy.PAIR_FORM_KERNEL = True
+  try:
+    for _ in range(2):
+      pout = default_crps()
+  finally:
+    _lazy.PAIR_FORM_KERNEL = was
+  plog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens' and e.get('algo') == 1]
   engine.S1_EVENT_LOG = None
   epoints = nlead * env.nlat * env.nlon  # per variable launch
-  ek_ms = float(np.mean([e['ms'] for e in elog]))
-  kname = ('s1_xf1_kernel<EnsOpF32<51,true,SORT>> (folded weights, one point per lane)' if elog[0].get('flat')
-           else 's1_xr_kernel<EnsOpF32<51,true,SORT>,1>')
+  ek_ms = float(np.median([e['ms'] for e in elog]))
+  kname = ens_kernel_name(elog[0], m)
   out = {'workload': describe, 'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
          'metrics': list(emetrics),
-         'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4,
-                                     pmc_traffic(kname, nlead in (8, 37) and not args.small, '37L' if name == 'rmse_crps_37L' else None)),
-         'pairwise_form': (kernel_roofline('EnsOpF32<51,true,PAIRWISE> (use_sort=False)', float(np.mean([e['ms'] for e in plog])),
-                                           epoints * (m + 1) * 4) if plog else None),
+         'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4, pmc_traffic('ens_pipe_kernel', nlead == 8 and not args.small, 'configs2')),
+         'default_crps_ensemble': {'what': 'CRPSEnsemble() with the reference defaults (use_sort=False) on one variable through the API',
+                                   'ensemble_launches_per_variable': len(dlog) // 2,
+                                   'kernel_ms_per_variable': round(float(np.sum([e['ms'] for e in dlog]) / 2), 4),
+                                   'frac_of_hbm_peak': round(epoints * (m + 1) * 4 / (float(np.sum([e['ms'] for e in dlog]) / 2) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   'crps': float(np.asarray(dout[f'crps_default.{k0}'].values).mean())},
+         'pairwise_form': (dict(kernel_roofline(ens_kernel_name(plog[0], m) + ' via lazy.PAIR_FORM_KERNEL', float(np.median([e['ms'] for e in plog])),
+                                                epoints * (m + 1) * 4),
+                                crps=float(np.asarray(pout[f'crps_default.{k0}'].values).mean())) if plog else None),
          'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
                    'spread_skill_v0_mean': float(np.asarray(eout['unbiased_spread_skill.v0'].values).mean())}}
   del pe, te, tv
@@ -412,12 +532,12 @@ def public_chunk_leg(env):
   k_ms = float(np.sum([e['ms'] for e in plog]))
   return {'workload': f'public benchmark chunk: f32[1 init,{pl} lead,{plev} level,{env.nlat},{env.nlon}] p,t + climatology, '
                       f'rmse/mse/bias/acc/activity, GridAreaWeighting, {len(REGIONS)} regions x land/sea = '
-                      f'{2 * len(REGIONS)} bins, masked=True, {args.layout}',
+                      f'{2 * len(REGIONS)} bins, masked=True, {env.layout}',
           'ms_per_chunk': p_ms, 'value': ppoints * len(pmetrics) / (p_ms * 1e-3), 'unit': 'evals/s',
           'kernels': [e.get('kind') for e in plog],
           'roofline': dict(kernel_roofline('wbx_det_binned (memset + det_atoms_kernel + slot kernel for overflow patches + finish)',
                                            k_ms, ppoints * 12,
-                                           pmc_traffic(f"det_atoms_kernel<float,DET6,MM=0,PD=4,WM={2 if args.layout == 'lon_fastest' else 1}>",
+                                           pmc_traffic(f"det_atoms_kernel<float,DET6,MM=0,PD=4,WM={2 if env.layout == 'lon_fastest' else 1}>",
                                                        not args.small)),
                            traffic_note='PMC pass of the main kernel only (bench.py public_chunk leg / tools/kbench_binned.py)'),
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
@@ -461,12 +581,12 @@ def spectrum_leg(env):
   engine.S1_EVENT_LOG = None
   sk_ms = float(np.mean([e['ms'] for e in slog]))
   if env.nlon == 1440:
-    kname = ('zspec1440_kernel (one wave per row pair, 720 = 12 x 5 x 12)' if args.layout == 'lon_fastest' else
+    kname = ('zspec1440_kernel (one wave per row pair, 720 = 12 x 5 x 12)' if env.layout == 'lon_fastest' else
              'zspec1440_latfast_kernel (24 adjacent rows per block step, staged through the LDS)')
   else:
     kname = 'zspec_fused_kernel'
   return {'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{env.nlat},{env.nlon}] each, area-weighted '
-                      f'mean over (lead_time, latitude), {args.layout}; fused in-LDS FFT + fp64 |F|^2 reduction (one pass over '
+                      f'mean over (lead_time, latitude), {env.layout}; fused in-LDS FFT + fp64 |F|^2 reduction (one pass over '
                       'the field); parity unpinned (no reference implementation, SURVEY F3)',
           'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms, 'steps': nsteps,
           'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
@@ -581,39 +701,78 @@ def config5_leg(env):
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------
 def cpu_leg(env, keep):
+  """The oracle's reference-structure NumPy path on bounded samples, on this box's host cores: the ensemble suite of the main
+  line first (top-level `value`), the deterministic suite of configs1 beside it; each on one process and on all cores."""
   from oracle import cpu_workers
   from oracle import wbx_oracle as O
   args = env.args
-  p_t, t_t, clim_t, _, nlev, ni, nl, n_metrics = keep
-  si, sl = min(10, ni), min(5, nl)  # ~50 of the 400 (init, lead) slices: a few seconds of single-thread NumPy
-  idx = (slice(0, si), slice(0, sl))
-  ph, th = p_t[idx].cpu().numpy(), t_t[idx].cpu().numpy()
-  # an already-aligned climatology of the same shape (the reference's .sel gather is NOT charged to the CPU side)
-  ch = clim_t[:si, :1].expand(si, sl, *clim_t.shape[2:]).contiguous().cpu().numpy()
-  w = O.grid_area_weights(env.lat)
-  if args.layout == 'lat_fastest':
-    ph, th, ch = (np.ascontiguousarray(np.swapaxes(a, -1, -2)) for a in (ph, th, ch))
-  t0 = time.perf_counter()
-  O.reference_structure_deterministic(ph, th, ch, w)
-  cdt = time.perf_counter() - t0
-  spoints = int(np.prod(ph.shape))
-  one = spoints * n_metrics / cdt
-  out = {'value': one, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-         'sample': f'{si} init x {sl} lead x {nlev} level x {env.nlat} x {env.nlon} of the same workload '
-                   f'({spoints} points, {cdt:.1f} s; NumPy elementwise + einsum, single thread)',
-         'host_cpus': os.cpu_count()}
   nworkers = args.cpu_workers or (os.cpu_count() or 1)
+  w = O.grid_area_weights(env.lat)
+  out = {}
+
+  # -- ensemble suite: CRPS (rank form, fair) + variance + unbiased MSE + ensemble-mean SE on f32[51, lat, lon] fields
+  m, nfield = 51, (8 if not args.small else 1)
+  rng = np.random.default_rng(7)
+  tv = rng.standard_normal((nfield, env.nlat, env.nlon), dtype=np.float32) + 280
+  pv = tv[:, None] + rng.standard_normal((nfield, m, env.nlat, env.nlon), dtype=np.float32)
+  tv = tv + rng.standard_normal((nfield, env.nlat, env.nlon), dtype=np.float32)
+  t0 = time.perf_counter()
+  crps = [float(r['CRPSSkill'] - 0.5 * r['CRPSSpread']) for r in (O.reference_structure_ensemble(pv[k], tv[k], w) for k in range(nfield))]
+  cdt = time.perf_counter() - t0
+  epoints = nfield * env.nlat * env.nlon
+  n_emetrics = 4
+  one = epoints * n_emetrics / cdt
+  ens = {'value': one, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+         'sample': f'{nfield} of the 37 levels: f32[{m},{env.nlat},{env.nlon}] fields of the main line\'s workload ({epoints} points, '
+                   f'{cdt:.1f} s; NumPy argsort ranks + elementwise + einsum, single thread; 4 metrics)',
+         'check_crps': float(np.mean(crps))}
+  del pv, tv
   try:
-    per = 2 if not args.small else 1  # (init, lead) slices per worker
+    band, per = (90, 2) if not args.small else (env.nlat, 1)  # a worker's field is a 90-latitude band: ~0.3 GB per process
     t0 = time.perf_counter()
-    res = cpu_workers.run(nworkers, per, nlev, env.nlat, env.nlon)
-    out['all_cores'] = {'value': res['points'] * n_metrics / res['seconds'], 'unit': 'evals/s', 'cores': nworkers,
-                        'kind': 'port', 'sample': f"{nworkers} worker processes x {per} (init, lead) slices x {nlev} level x "
-                                                  f"{env.nlat} x {env.nlon} ({res['points']} points, {res['seconds']:.2f} s between the "
-                                                  f'start barrier and the last finish; {time.perf_counter() - t0:.1f} s with process start-up)',
-                        'speedup_over_one_core': res['points'] * n_metrics / res['seconds'] / one}
+    res = cpu_workers.run(nworkers, per, m, band, env.nlon, kind='ensemble')
+    ens['all_cores'] = {'value': res['points'] * n_emetrics / res['seconds'], 'unit': 'evals/s', 'cores': nworkers, 'kind': 'port',
+                        'sample': f"{nworkers} worker processes x {per} bands of f32[{m},{band},{env.nlon}] ({res['points']} points, "
+                                  f"{res['seconds']:.2f} s between the start barrier and the last finish; "
+                                  f'{time.perf_counter() - t0:.1f} s with process start-up)',
+                        'speedup_over_one_core': res['points'] * n_emetrics / res['seconds'] / one}
   except Exception as e:  # pylint: disable=broad-except
-    out['all_cores'] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
+    ens['all_cores'] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
+  out.update({k: v for k, v in ens.items() if k != 'all_cores'})
+  out['workload'] = 'ensemble suite of the main line (CRPS + unbiased spread/skill + unbiased-mean RMSE + ensemble-mean RMSE)'
+  out['host_cpus'] = os.cpu_count()
+  out['ensemble'] = ens
+
+  # -- deterministic suite (configs1)
+  if keep is not None:
+    p_t, t_t, clim_t, _, nlev, ni, nl, n_metrics = keep
+    si, sl = min(10, ni), min(5, nl)  # ~50 of the 400 (init, lead) slices: a few seconds of single-thread NumPy
+    idx = (slice(0, si), slice(0, sl))
+    ph, th = p_t[idx].cpu().numpy(), t_t[idx].cpu().numpy()
+    # an already-aligned climatology of the same shape (the reference's .sel gather is NOT charged to the CPU side)
+    ch = clim_t[:si, :1].expand(si, sl, *clim_t.shape[2:]).contiguous().cpu().numpy()
+    if env.layout == 'lat_fastest':
+      ph, th, ch = (np.ascontiguousarray(np.swapaxes(a, -1, -2)) for a in (ph, th, ch))
+    t0 = time.perf_counter()
+    O.reference_structure_deterministic(ph, th, ch, w)
+    cdt = time.perf_counter() - t0
+    spoints = int(np.prod(ph.shape))
+    done = spoints * n_metrics / cdt
+    det = {'value': done, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{si} init x {sl} lead x {nlev} level x {env.nlat} x {env.nlon} of configs1 '
+                     f'({spoints} points, {cdt:.1f} s; NumPy elementwise + einsum, single thread; {n_metrics} metrics)'}
+    try:
+      per = 2 if not args.small else 1  # (init, lead) slices per worker
+      t0 = time.perf_counter()
+      res = cpu_workers.run(nworkers, per, nlev, env.nlat, env.nlon)
+      det['all_cores'] = {'value': res['points'] * n_metrics / res['seconds'], 'unit': 'evals/s', 'cores': nworkers,
+                          'kind': 'port', 'sample': f"{nworkers} worker processes x {per} (init, lead) slices x {nlev} level x "
+                                                    f"{env.nlat} x {env.nlon} ({res['points']} points, {res['seconds']:.2f} s between the "
+                                                    f'start barrier and the last finish; {time.perf_counter() - t0:.1f} s with process start-up)',
+                          'speedup_over_one_core': res['points'] * n_metrics / res['seconds'] / done}
+    except Exception as e:  # pylint: disable=broad-except
+      det['all_cores'] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
+    out['deterministic'] = det
   return out
 
 
@@ -646,31 +805,38 @@ def main():
   env = Env(args)
   legs = None if args.legs == 'all' else set(args.legs.split(','))
   want = lambda name: legs is None or name in legs
-  result, keep = ({'metric': METRIC, 'value': None, 'note': 'main leg not selected (--legs)'}, None)
+  result, keep = {'metric': METRIC, 'value': None, 'note': 'main leg not selected (--legs)'}, None
   if want('main'):
-    result, keep = main_leg(env)
+    result = main_leg(env)
   if not args.no_ens and env.world == 1:
-    if want('rmse_crps_37L'):
-      nl37 = 37 if not args.small else 3
-      name, leg = ens_leg(env, 'level', nl37, 1, 'rmse_crps_37L',
-                          f'north_star target: weighted CRPS(rank form, fair) + unbiased spread/skill + unbiased-mean RMSE + '
-                          f'ensemble-mean RMSE on ONE f32[{nl37} level,51 member,{env.nlat},{env.nlon}] forecast vs '
-                          f'f32[{nl37},{env.nlat},{env.nlon}] targets, reduce (latitude, longitude), GridAreaWeighting')
-      result[name] = leg
+    if want('configs1'):
+      result['configs1'], keep = configs1_leg(env)
     if want('ensemble'):
       ns = args.ens_slices if not args.small else 2
       nvar = 6 if not args.small else 2
       name, leg = ens_leg(env, 'lead_time', ns, nvar, 'ensemble',
                           f'configs[2]: {nvar} vars x f32[{ns} slices,51 members,{env.nlat},{env.nlon}], CRPS(rank form, fair) + '
-                          'unbiased spread/skill + unbiased-mean RMSE + mean RMSE')
+                          f'unbiased spread/skill + unbiased-mean RMSE + mean RMSE, {env.layout}')
       result[name] = leg
     if want('public_chunk'):
       result['public_chunk'] = public_chunk_leg(env)
     if want('spectrum'):
       result['spectrum'] = spectrum_leg(env)
+    if want('lat_fastest') and args.layout == 'lon_fastest':
+      # the layout of the public archives (data_loaders/xarray_loaders.py:185-188): the same legs on [.., longitude, latitude]
+      env.set_layout('lat_fastest')
+      lf = {'note': 'the main line, configs1 and the spectrum leg again on latitude-fastest arrays (N = 1)'}
+      m = main_leg(env)
+      lf['main'] = {k: m[k] for k in ('value', 'unit', 'ms_per_step', 'roofline', 'check')}
+      lf['main']['workload'] = m['config']['workload']
+      c1, _ = configs1_leg(env)
+      lf['configs1'] = c1
+      lf['spectrum'] = spectrum_leg(env)
+      result['lat_fastest'] = lf
+      env.set_layout('lon_fastest')
   if not args.no_config5 and want('config5'):
     result['config5'] = config5_leg(env)
-  if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu') and keep is not None:
+  if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu'):
     result['cpu_baseline'] = cpu_leg(env, keep)
   if env.rank == 0:
     _emit(result)

@@ -332,15 +332,32 @@ def test_bench_contract_small(ctx):
   at debugging sizes, so that a broken leg shows up here and not in the round-end run."""
   out = _run_bench('--small', '--steps', '2', '--warmup', '1', '--cpu-workers', '2')
   for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
-              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'rmse_crps_37L', 'ensemble',
-              'public_chunk', 'spectrum', 'config5'):
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'configs1', 'ensemble',
+              'public_chunk', 'spectrum', 'lat_fastest', 'config5'):
     assert key in out, key
-  assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0 and 'workload' in out['config']
-  assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(out['roofline'])
-  assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(out['cpu_baseline']) and out['cpu_baseline']['cores'] == 1
-  assert out['cpu_baseline']['all_cores']['cores'] == 2
+  import json
+  baseline = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+  assert out['metric'] == baseline['metric']  # the driver line quotes BASELINE.json's metric string itself
+  assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0
+  # the main line is the north_star field: one 51-member forecast per GPU, the ensemble kernel's roofline beside it
+  assert 'north_star' in out['config']['workload'] and '51 member' in out['config']['workload']
+  assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(out['roofline']) and 'ens_pipe_kernel' in out['roofline']['kernel']
+  assert out['roofline']['launches_per_step'] == 1  # all four metrics of a variable out of ONE ensemble launch
+  cpu = out['cpu_baseline']
+  assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(cpu) and cpu['cores'] == 1
+  for suite in ('ensemble', 'deterministic'):  # the main line's workload and configs1, one core and all cores each
+    assert {'value', 'unit', 'cores', 'kind', 'sample', 'all_cores'} <= set(cpu[suite]), suite
+    assert cpu[suite]['all_cores']['cores'] == 2 and cpu[suite]['all_cores']['value'] > 0
+  assert cpu['value'] == cpu['ensemble']['value']
+  # the reference-default CRPSEnsemble() (use_sort=False) is ONE ensemble launch per variable; the pair-form kernel is
+  # timed on its own events
+  assert out['ensemble']['default_crps_ensemble']['ensemble_launches_per_variable'] == 1
+  assert 'PAIRWISE' in out['ensemble']['pairwise_form']['kernel']
+  np.testing.assert_allclose(out['ensemble']['pairwise_form']['crps'], out['ensemble']['default_crps_ensemble']['crps'], rtol=1e-6)
+  assert {'main', 'configs1', 'spectrum'} <= set(out['lat_fastest'])
+  assert 'lat_fastest' in out['lat_fastest']['main']['workload']
   assert out['config5']['scaling'] == 'strong' and out['config5']['chunks'] == 6
-  assert abs(out['check']['rmse_mean'] - 2 ** 0.5) < 0.01
+  assert abs(out['check']['crps_mean'] - 0.5642) < 0.01 and abs(out['configs1']['check']['rmse_mean'] - 2 ** 0.5) < 0.01
 
 
 def test_bench_two_ranks_from_a_bare_shell(ctx):
@@ -354,7 +371,7 @@ def test_bench_two_ranks_from_a_bare_shell(ctx):
     assert skipped.get('skipped') is True and skipped['n_gpus'] == 2 and 'devices' in skipped['reason']
   out = _run_bench('--gpus', '2', '--backend', 'gloo', '--small', '--steps', '2', '--warmup', '1', '--legs', 'main,config5')
   assert out['n_gpus'] == 2 and out['config']['collectives_per_step'] == 1.0 and out['config']['backend'] == 'gloo'
-  assert abs(out['check']['rmse_mean'] - 2 ** 0.5) < 0.01
+  assert abs(out['check']['crps_mean'] - 0.5642) < 0.01
   one = _run_bench('--small', '--steps', '2', '--warmup', '1', '--legs', 'config5')
   # the sharded, all-reduced result of the streamed suite equals the one-rank result
   assert out['config5']['n_gpus'] == 2 and out['config5']['check']['shape_rmse_z'] == one['config5']['check']['shape_rmse_z']

@@ -162,6 +162,10 @@ struct EnsOpF32 {
   }
 
   // -> true: the point has to be redone by the generic fp64 op (see finish())
+  // FAST32: the fp32 chain sums (stats32) -- the pipelined kernel only.  In s1_xr / s1_xk / s1_xf1 (no prefetch, 64-bit vector
+  // addresses) they measured SLOWER than the fp64 sums (37-level field, same box: 1.57 against 1.40 ms on longitude-fastest,
+  // 1.73 against 1.44 ms on latitude-fastest data: 162 instead of 133 VGPRs), while ens_pipe_kernel gains 9 % (1.39 -> 1.27 ms).
+  template <bool FAST32 = false>
   __device__ __forceinline__ static bool compute(const S1Args& a, Regs& r, double (&val)[NLANE]) {
     const int M = EXACT ? MP : a.M;
     const double td = (double)r.t;
@@ -239,7 +243,7 @@ struct EnsOpF32 {
     }
 
     bool redo = false;
-    if constexpr (EXACT && ALGO == WBX_ENS_SORT && WBX_ENS_STATS32) {
+    if constexpr (FAST32 && EXACT && ALGO == WBX_ENS_SORT && WBX_ENS_STATS32) {
       // the hot instantiations (M = 50 / 51, rank form): fp32 chain sums on median-centred members (stats32), unless a lane
       // of the wave holds a point whose magnitudes could overflow / underflow an fp32 square or sum.  Then the CALLER redoes
       // the point with the generic fp64 op (members re-read from memory, a rolled loop: no registers of the hot path are
@@ -249,12 +253,13 @@ struct EnsOpF32 {
       const float big = fmaxf(fmaxf(fabsf(xm[0]), fabsf(xm[MP - 1])), fabsf(r.t));
       const bool fast_ok = (range == 0.f || (range >= 0x1p-50f && range <= 0x1p60f)) && big <= 0x1p100f;
       redo = !WBX_ENS_NOFALLBACK && __builtin_amdgcn_ballot_w64(!fast_ok) != 0;
-      if (!redo) stats32(a, xm, r.t, val);
+      if (!redo) stats32(a, xm, r.t, poison, val);
+      r.poison = poison;
     } else {
       stats64(a, xm, td, pair_total, val);
+      r.poison = poison;
+      apply_poison(r, val);
     }
-    r.poison = poison;
-    if (!redo) apply_poison(r, val);
     return redo;
   }
 
@@ -268,9 +273,10 @@ struct EnsOpF32 {
   }
 
   // compute() + the escape, for callers that know where the point lives
+  template <bool FAST32 = false>
   __device__ __forceinline__ static void finish(const S1Args& a, const int64_t (&ro)[WBX_MAX_INPUTS], int64_t x, Regs& r,
                                                 double (&val)[NLANE]) {
-    if (compute(a, r, val)) {
+    if (compute<FAST32>(a, r, val)) {
       EnsOpGeneric<float>::values(a, ro, x, val);
       apply_poison(r, val);
     }
@@ -379,13 +385,15 @@ struct EnsOpF32 {
   // non-negative sum: (1 rounding of the term + 7 chain adds + 1 pair add) u = 9 u = 5.4e-7; typical (random rounding) ~2 u;
   // measured against the float64 oracle in tests/test_metrics.py and tests/test_gpu_round3.py.  The north_star tolerance
   // is 1e-6 on the aggregated value (a weighted mean of >= 10^3 such points, whose errors do not add coherently).
-  __device__ __forceinline__ static void stats32(const S1Args& a, float (&xm)[MP], const float t, double (&val)[NLANE]) {
+  // `poison` (0, or NaN when a member is NaN / inf) enters the first chain of every sum: all five values turn NaN with it.
+  __device__ __forceinline__ static void stats32(const S1Args& a, float (&xm)[MP], const float t, const float poison,
+                                                 double (&val)[NLANE]) {
     static_assert(EXACT, "fp32 chain sums are instantiated for the exact-M buckets");
     constexpr int K = 8, MID = MP / 2, NPAIR = MP / 2;
     const float c = xm[MID];
     float se[K], sq[K], sa[K], dt[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) se[k] = sq[k] = sa[k] = dt[k] = 0.f;
+    for (int k = 0; k < K; ++k) se[k] = sq[k] = sa[k] = dt[k] = k == 0 ? poison : 0.f;
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) {
       const int j = MP - 1 - i, k = i % K;
@@ -495,17 +503,17 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
-// FLAT: the latitude-fastest flavour (s1_xf1_kernel's geometry): the block's rows are runs of a contiguous plane walked by a
-// flat element index e, lanes starting on a 64-element boundary of the plane, every point weighted with xw[e mod nx]
-// (fp64, fetched one tile ahead like the target).  Otherwise a segment is one depth row, e = x.
+// (A flat flavour of this kernel for latitude-fastest planes with folded weights -- s1_xf1_kernel's geometry, the weight
+// fetched one tile ahead -- was built and measured in round 3: 1.48-1.52 ms for the 37-level field against 1.44 ms for
+// s1_xf1_kernel with fp64 sums on the same box; not kept.)
 #ifndef WBX_ENS_PIPE_NLDS
 #define WBX_ENS_PIPE_NLDS 50   // members staged through the LDS (x 256 B per one-wave block)
 #endif
 #ifndef WBX_ENS_PIPE_WAVES
 #define WBX_ENS_PIPE_WAVES 3   // waves per SIMD the register budget is cut for (12 800-byte blocks: 12 per CU)
 #endif
-template <int MP, bool EXACT, int ALGO, bool FLAT>
-__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a, int R) {
+template <int MP, bool EXACT, int ALGO>
+__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a) {
   using Op = EnsOpF32<MP, EXACT, ALGO>;
   constexpr int NA = Op::NACC;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
@@ -528,30 +536,17 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
   for (int l = 0; l < NA; ++l) acc[l] = 0.0;
 
-  // the current segment: elements [e0, e1) of the row / plane at `ro`, tiles of 64 from ea; d = the depth row behind it
+  // the current segment: elements [e0, e1) of the depth row at `ro`, tiles of 64 from et; d = the next depth row
   int64_t d = d0, e0 = 0, e1 = 0, et = 0;
-  int wi = 0;  // FLAT: this lane's weight index (e mod nx) at tile et
   auto open_segment = [&]() {  // d < d1
-    if constexpr (FLAT) {
-      const int64_t plane = d / R, j0 = d - plane * R;
-      const int64_t nj = d1 - d < R - j0 ? d1 - d : R - j0;
-      row_bases<2>(a, kb, key, plane * R, ro);
-      e0 = j0 * nx;
-      e1 = (j0 + nj) * nx;
-      et = e0 & ~(int64_t)63;
-      wi = (int)((et + lane) % nx);
-      d += nj;
-    } else {
-      row_bases<2>(a, kb, key, d, ro);
-      e0 = 0;
-      e1 = nx;
-      et = 0;
-      d += 1;
-    }
+    row_bases<2>(a, kb, key, d, ro);
+    e0 = 0;
+    e1 = nx;
+    et = 0;
+    d += 1;
   };
 
   float xn[NREG > 0 ? NREG : 1], tn = 0.f;
-  double wn = 1.0;
   auto issue = [&]() {  // the tile at et of the open segment
     int64_t e = et + lane;
     e = e < e0 ? e0 : (e < e1 ? e : e1 - 1);  // lanes outside the segment re-read its edge (counted out below): no EXEC games
@@ -569,7 +564,6 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
     for (int m = NLDS; m < MP; ++m) xn[m - NLDS] = (EXACT || m < M) ? ld_stream(pr + (int64_t)m * a.mstride) : INFINITY;
     tn = ld_stream(reinterpret_cast<const float*>(a.in[1]) + ro[1] + e * a.xstride[1]);
-    if constexpr (FLAT) wn = a.xw[wi];
   };
 
   bool more = d < d1;
@@ -585,22 +579,14 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
     for (int m = NLDS; m < MP; ++m) r.xm[m] = xn[m - NLDS];
     r.t = tn;
-    const double w = wn;
     const int64_t ecur = et + lane;
     const bool valid = ecur >= e0 && ecur < e1;
     const int64_t xcur = ecur < e0 ? e0 : (ecur < e1 ? ecur : e1 - 1);
     int64_t rocur[WBX_MAX_INPUTS];
 #pragma unroll
     for (int i = 0; i < WBX_MAX_INPUTS; ++i) rocur[i] = ro[i];
+    const bool full = et + 64 <= e1;  // every lane of this tile holds a point of the row (wave-uniform)
     et += 64;
-    if constexpr (FLAT) {
-      wi += 64;
-      if (nx >= 64) {
-        wi = wi >= nx ? wi - nx : wi;
-      } else {
-        wi %= nx;
-      }
-    }
     if (et >= e1) {
       more = d < d1;
       if (more) open_segment();
@@ -608,14 +594,13 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile has left the staging buffer
     if (more) issue();
     double val[Op::NLANE];
-    Op::finish(a, rocur, xcur, r, val);
+    Op::template finish<true>(a, rocur, xcur, r, val);
+    if (full) {
 #pragma unroll
-    for (int l = 0; l < NA; ++l) {
-      if constexpr (FLAT) {
-        acc[l] = valid ? fma(val[l], w, acc[l]) : acc[l];
-      } else {
-        acc[l] += valid ? val[l] : 0.0;
-      }
+      for (int l = 0; l < NA; ++l) acc[l] += val[l];
+    } else {
+#pragma unroll
+      for (int l = 0; l < NA; ++l) acc[l] += valid ? val[l] : 0.0;
     }
   }
 #pragma unroll
@@ -627,20 +612,15 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 
 #pragma clang diagnostic pop
 
-// Eligibility of the pipelined sweep: plain (no mask / skipna wrappers), x summed, offsets inside a segment within 32 bits;
-// one-wave blocks for the row flavour (the flat flavour keeps the plan's chunking and launches one wave per chunk).
+// Eligibility of the pipelined sweep: plain (no mask / skipna wrappers), x summed without folded weights, one-wave blocks,
+// offsets inside a row within 32 bits.
 inline bool ens_pipe_ok(const wbx_s1_plan* plan, const S1Args& a) {
-  static const bool off = getenv("WBX_ENS_PIPE") && atoi(getenv("WBX_ENS_PIPE")) == 0;  // A/B against s1_xr_kernel / s1_xf1_kernel
+  static const bool off = getenv("WBX_ENS_PIPE") && atoi(getenv("WBX_ENS_PIPE")) == 0;  // A/B against s1_xr_kernel
   if (off) return false;
-  if (plan->x_kept) return false;
+  if (plan->x_kept || plan->x_weights != nullptr || plan->block_threads != 64) return false;
   if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA | WBX_FLAG_SKIPNA_ENS)) return false;
   if (plan->nx <= 0 || plan->ndepth <= 0 || plan->nkey <= 0) return false;
   if (a.xstride[0] < 0 || a.xstride[1] < 0) return false;
-  if (plan->x_weights != nullptr) {  // flat flavour: launch_flat_weighted1's requirements
-    if (plan->plane_rows <= 0 || plan->ndepth % plan->plane_rows != 0 || a.xstride[0] != 1 || a.xstride[1] != 1) return false;
-    return (double)plan->nx * (double)plan->plane_rows * 4.0 < 4294967296.0;
-  }
-  if (plan->block_threads != 64) return false;
   return (double)plan->nx * (double)a.xstride[0] * 4.0 < 4294967296.0;
 }
 
@@ -648,10 +628,7 @@ template <int MP, bool EXACT, int ALGO>
 int launch_ens_pipe(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   const int64_t grid = plan->nkey * plan->nchunk;
   WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
-  if (plan->x_weights != nullptr)
-    hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, plan->plane_rows);
-  else
-    hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, 1);
+  hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
   WBX_HIP(hipGetLastError());
   return 0;
 }

@@ -422,7 +422,8 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
     S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop() / reps, 'reps': reps, 'vec': plan.vec,
                          'x_kept': plan.x_kept, 'plane_rows': plan.plane_rows, 'x_weighted': plan.x_weights is not None,
                          'flat': plan.x_weights is not None and plan.plane_rows > 0, 'grid': plan.nkey * plan.nchunk,
-                         'block': plan.block_threads})
+                         'block': plan.block_threads, 'algo': int(ens[2]) if kind == 'ens' else None,
+                         'flags': int(plan.flags)})
   return out
 
 
