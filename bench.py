@@ -596,6 +596,11 @@ def spectrum_leg(env):
           'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
 
 
+def distributed_shard(times, env):
+  from weatherbenchx_amd import distributed
+  return distributed.shard_chunks(list(times.iter_with_chunk_offsets()), env.rank, env.world)
+
+
 # ---- configs[4]: the full suite streamed over (init x lead) chunks, sharded over the ranks ------------------------
 def config5_leg(env):
   from weatherbenchx_amd import aggregation, pipeline, spectra, time_chunks, weighting
@@ -660,17 +665,25 @@ def config5_leg(env):
   area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
   zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
   passes = [('deterministic', load_det, det, area), ('spectra', load_det, spec, zonal), ('ensemble', load_ens, ens, area)]
-
-  pass_s = {}
+  metrics_of = {name: m for name, _, m, _ in passes}
+  # ONE job: the chunks of the three evaluations run interleaved, all their accumulators live in one engine.Accumulation and
+  # cross the ranks in ONE all-reduce at the end (pipeline.evaluate_passes; beam_pipeline.py:509-510 combines every key of
+  # the job in one CombinePerKey).  WBX_COLLECTIVE=cabi: through the library's own RCCL entry point (wbx_acc_allreduce).
+  comm = None
+  if env.world > 1 and args.backend == 'nccl' and os.environ.get('WBX_COLLECTIVE', 'torch') == 'cabi':
+    from weatherbenchx_amd import distributed
+    comm = distributed.CabiCommunicator.from_torch_group()
+  stats = {}
 
   def run(times):
-    out = {}
-    for name, load, metrics, agg in passes:
-      tp = time.perf_counter()
-      state = pipeline.evaluate_chunks(times, load, metrics, agg, rank=env.rank, world_size=env.world)[None]
-      out[name] = state.metric_values(metrics)  # reads the pass's sums back: the pass is complete here
-      pass_s[name] = time.perf_counter() - tp
-    return out
+    states = pipeline.evaluate_passes(times, passes, rank=env.rank, world_size=env.world, comm=comm, stats=stats)
+    return {name: states[name][None].metric_values(metrics_of[name]) for name in metrics_of}  # (the sums are on the host here)
+
+  def run_one(times, which):  # a single pass, for the per-pass timings below
+    name, load, metrics, agg = next(p for p in passes if p[0] == which)
+    tp = time.perf_counter()
+    pipeline.evaluate_chunks(times, load, metrics, agg, rank=env.rank, world_size=env.world, all_reduce=False)[None].metric_values(metrics)
+    return time.perf_counter() - tp
   warm = time_chunks.TimeChunks(init_times[:2 * env.world], lead_time, init_time_chunk_size=1)
   run(warm)
   env.sync()
@@ -678,7 +691,13 @@ def config5_leg(env):
   t0 = time.perf_counter()
   out = run(times)
   env.sync()
-  dt = env.max_over_ranks(time.perf_counter() - t0)
+  rank_s = time.perf_counter() - t0
+  dt = env.max_over_ranks(rank_s)
+  # per-pass pace of this rank (outside the timed region, a sixth of the chunks, no collective)
+  sub = time_chunks.TimeChunks(init_times[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
+  nsub = len(distributed_shard(sub, env))
+  pass_s = {name: run_one(sub, name) / max(nsub, 1) * 1e3 for name in metrics_of}
+  env.sync()
   grid = env.nlat * env.nlon
   pz, pt = nlead * nlev * grid, nlead * grid
   evals_per_chunk = pz * len(det) + pz * len(spec) + pt * len(ens)
@@ -688,9 +707,15 @@ def config5_leg(env):
                       f'resident pool of {npool} (H2D excluded): z f32[{nlead},{nlev},{env.nlat},{env.nlon}] p,t + climatology -> '
                       f'rmse/mse/mae/bias/acc/activity + zonal spectra of p and t; t2m f32[{nlead},{m},{env.nlat},{env.nlon}] -> '
                       'crps/spread-skill/unbiased-mean rmse/mean rmse; reduce (init_time, latitude, longitude) -> per (lead, level)',
-          'sharding': f'chunk i -> rank i mod {env.world}; accumulators in HBM; one all-reduce per pass (3 passes) at the end',
+          'sharding': f'chunk i -> rank i mod {env.world}; the three evaluations interleaved chunk by chunk (pipeline.evaluate_passes), '
+                      'every accumulator in HBM, ONE all-reduce for the whole job at the end',
+          'collectives': stats.get('collectives'), 'accumulator_values': stats.get('accumulator_values'),
+          'collective_backend': ('wbx_acc_allreduce (C ABI, RCCL)' if comm is not None else ('torch.distributed ' + args.backend)) if env.world > 1 else None,
+          'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0,
           'scaling': 'strong', 'n_gpus': env.world, 'chunks': ninit, 'time_slices': ninit * nlead, 'seconds': dt,
-          'ms_per_chunk': dt / ninit * 1e3, 'ms_per_chunk_by_pass_rank0': {k: round(v / (ninit / env.world) * 1e3, 3) for k, v in pass_s.items()},
+          'seconds_rank0': rank_s, 'ms_per_chunk': dt / ninit * 1e3, 'ms_per_chunk_rank0': rank_s / max(len(distributed_shard(times, env)), 1) * 1e3,
+          'ms_per_chunk_by_pass_rank0': {k: round(v, 3) for k, v in pass_s.items()},
+          'ms_per_chunk_by_pass_note': 'each evaluation alone on a sixth of the chunks, outside the timed region',
           'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),

@@ -33,14 +33,15 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 5
+#define WBX_ABI_VERSION 6
 
 typedef enum wbx_status {
   WBX_OK = 0,
   WBX_ERR_INVALID = -1,    /* bad argument / unsupported combination */
   WBX_ERR_HIP = -2,        /* a HIP runtime call failed              */
   WBX_ERR_NO_DEVICE = -3,  /* no gfx950 device visible               */
-  WBX_ERR_FFT = -4         /* rocFFT failure                         */
+  WBX_ERR_FFT = -4,        /* rocFFT failure                         */
+  WBX_ERR_RCCL = -5        /* RCCL missing or a collective failed    */
 } wbx_status;
 
 typedef struct wbx_ctx wbx_ctx; /* opaque: device id, stream, timers, scratch */
@@ -183,9 +184,32 @@ int wbx_memcpy_d2d(wbx_ctx* ctx, void* dst, const void* src, size_t bytes); /* e
  * binned / spectrum outputs of a chunk stay in HBM and are added into a persistent float64 accumulator right behind
  * the kernel that produced them:
  *     acc[i] = (overwrite ? 0 : acc[i]) + src[i],  i < n          (stream ordered, deterministic, no atomics)
- * A rank's accumulators live in ONE device buffer that is all-reduced in place over RCCL (torch.distributed on the
- * device pointer) and read back once per job -- the counterpart of SURVEY 8b's wbx_acc_allreduce / wbx_acc_read. */
+ * A rank's accumulators live in ONE device buffer that is all-reduced in place over RCCL and read back once per job. */
 int wbx_acc_add(wbx_ctx* ctx, double* acc, const double* src, int64_t n, int32_t overwrite);
+
+/* ---- accumulators across ranks (one process per GPU) ----------------------------------------------------------
+ * The combine stage of the reference -- beam.CombinePerKey(CombiningSum()) over every (statistic, variable, offsets)
+ * key of the job, beam_pipeline.py:509-519, beam_utils.py:30-50 -- as ONE collective on device memory:
+ *     wbx_acc_allreduce:  acc[i] <- sum over ranks of acc[i], i < n      (ncclAllReduce(sum, double) in place, RCCL / xGMI,
+ *                         enqueued on the context's stream: ordered behind the kernels and wbx_acc_add calls before it)
+ *     wbx_acc_read:       the buffer on the host (waits for the stream)
+ *     wbx_acc_reset:      acc[i] <- 0 (stream ordered)
+ * Every rank lays its accumulators out identically (the caller's contract: same statistics and aggregators on every rank,
+ * chunks of (init_time x lead_time) dealt round-robin); a slot only one rank wrote is zero on the others, so the
+ * same sum also assembles results that keep init_time / lead_time (the reference's ConcatPerStatisticPerVariable,
+ * beam_pipeline.py:253-319).
+ * A communicator joins `nranks` processes: rank 0 calls wbx_comm_unique_id, hands the WBX_COMM_ID_BYTES bytes to the other
+ * ranks by any means (a file, MPI, a torch.distributed store ...), and every rank calls wbx_comm_create on its own context.
+ * RCCL is loaded on first use (librccl.so.1; WBX_RCCL_PATH overrides); without it these calls return WBX_ERR_RCCL. */
+#define WBX_COMM_ID_BYTES 128
+typedef struct wbx_comm wbx_comm; /* opaque: one RCCL communicator (rank, size, device) */
+int wbx_comm_unique_id(void* id_out /* WBX_COMM_ID_BYTES */);
+int wbx_comm_create(wbx_ctx* ctx, const void* unique_id, int32_t nranks, int32_t rank, wbx_comm** out);
+int wbx_comm_destroy(wbx_comm* comm);
+int wbx_comm_info(const wbx_comm* comm, int32_t* nranks_out, int32_t* rank_out, int64_t* collectives_out);
+int wbx_acc_allreduce(wbx_ctx* ctx, wbx_comm* comm, double* acc, int64_t n);
+int wbx_acc_read(wbx_ctx* ctx, const double* acc, int64_t n, double* host_out);
+int wbx_acc_reset(wbx_ctx* ctx, double* acc, int64_t n);
 
 /* valid_out[i] = !isnan(data[i]) (one byte per element, 1 = valid) over n contiguous elements: the `mask` coordinate
  * of data_loaders/base.py:25-56 (add_nan_mask_to_data) for payloads that are already in HBM -- the mask is built and

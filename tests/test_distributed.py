@@ -254,3 +254,100 @@ def test_per_step_allreduce_reuses_the_layout(tmp_path):
       num = num + ((p - t) ** 2 * w[None, :, None]).sum(axis=(1, 2))
       den = den + (np.ones_like(p) * w[None, :, None]).sum(axis=(1, 2))
     np.testing.assert_allclose(a[step], np.sqrt(num / den), rtol=1e-9)
+
+
+def _passes_case(tp):
+  """Two evaluations of one job with different loaders, metrics and aggregators: deterministic per lead time, and an ensemble
+  suite reduced over everything (bench.py's configs[4] in miniature)."""
+  _, load_e, metrics_e, agg_e = _ensemble_case(tp)
+  times_d, load_d, metrics_d, aggs_d = _det_case(tp, REDUCE_SETS['lead_kept'])
+  # one chunking for the job: the deterministic case's times (a subset of the ensemble data's: both loaders serve them)
+  return times_d, [('deterministic', load_d, metrics_d, aggs_d), ('ensemble', load_e, metrics_e, agg_e)]
+
+
+def _passes_worker(rank, world_size, out_dir):
+  dist = _init(rank, world_size, out_dir)
+  import test_pipeline as tp
+  from weatherbenchx_amd import pipeline
+  try:
+    times, passes = _passes_case(tp)
+    stats = {}
+    out = pipeline.evaluate_passes(times, passes, rank=rank, world_size=world_size, stats=stats)
+    assert stats['collectives'] == 1, stats  # ONE sum all-reduce for every pass, aggregator, statistic and variable of the job
+    res = {}
+    for name, _, metrics, _ in passes:
+      for agg_name, st in out[name].items():
+        res.update({f'{name}/{agg_name}/{k}': v.values for k, v in st.metric_values(metrics).items()})
+    np.savez(os.path.join(out_dir, f'passes{rank}.npz'), **res)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_several_passes_share_one_collective(tmp_path, monkeypatch):
+  """pipeline.evaluate_passes: the accumulators of every pass live in one Accumulation and cross the ranks in ONE
+  all-reduce (the reference's single CombinePerKey over all keys, beam_pipeline.py:509-510); the result of every pass
+  equals evaluating that pass alone in one process."""
+  _spawn(_passes_worker, 2, tmp_path)
+  import fake_device
+  import test_pipeline as tp
+  from weatherbenchx_amd import pipeline
+  fake_device.install(monkeypatch)
+  times, passes = _passes_case(tp)
+  want = {}
+  for name, load, metrics, aggs in passes:
+    states = pipeline.evaluate_chunks(times, load, metrics, aggs)
+    for agg_name, st in states.items():
+      want.update({f'{name}/{agg_name}/{k}': v.values for k, v in st.metric_values(metrics).items()})
+  assert len(want) > 6
+  for rank in (0, 1):
+    got = np.load(os.path.join(tmp_path, f'passes{rank}.npz'))
+    assert set(got.files) == set(want)
+    for k in want:
+      np.testing.assert_allclose(got[k], want[k], rtol=1e-12, equal_nan=True, err_msg=k)
+
+
+def _stale_worker(rank, world_size, out_dir):
+  """Step 2 changes the latitude labels on rank 1 ONLY (same shapes, so the slot layout is unchanged): under the cached plan
+  rank 1's arrays would come back with the first step's coordinates and -- had rank 1 re-planned alone -- rank 0 would sit in
+  the payload all-reduce while rank 1 sits in the layout exchange.  The stale flag rides in the payload buffer: both re-plan."""
+  dist = _init(rank, world_size, out_dir)
+  from weatherbenchx_amd import aggregation, distributed, engine
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic
+  try:
+    lon = np.arange(12) * 30.0
+    metrics = {'mse': deterministic.MSE()}
+    agg = aggregation.Aggregator(reduce_dims=['longitude'])
+    plan, rows = None, []
+    for step in range(3):
+      lat = np.linspace(-80, 80, 9) + (1.0 if (step == 1 and rank == 1) else 0.0)
+      rng = np.random.default_rng(7 * step + rank)
+      mk = lambda: xr.DataArray(rng.normal(size=(9, 12)).astype(np.float32), dims=('latitude', 'longitude'),
+                                coords={'latitude': lat, 'longitude': lon})
+      acc = engine.Accumulation()
+      with engine.accumulate_results(acc):
+        state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': mk()}, {'v': mk()}))
+      state, plan = distributed.resolve_state(state, acc, plan=plan)
+      out = state.metric_values(metrics)['mse.v']
+      rows.append((out['latitude'].values.copy(), out.values.copy(), plan.collectives))
+    with open(os.path.join(out_dir, f'stale{rank}.pkl'), 'wb') as f:
+      pickle.dump(rows, f)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_changed_labels_under_a_cached_plan_replan_on_every_rank(tmp_path):
+  _spawn(_stale_worker, 2, tmp_path)
+  r0, r1 = (pickle.load(open(os.path.join(tmp_path, f'stale{r}.pkl'), 'rb')) for r in (0, 1))
+  base = np.linspace(-80, 80, 9)
+  for step in range(3):
+    np.testing.assert_array_equal(r0[step][1], r1[step][1])  # the same sums on both ranks, nobody hung
+    assert np.all(np.isfinite(r0[step][1]))
+  np.testing.assert_array_equal(r0[0][0], base)
+  # step 1: a fresh plan on BOTH ranks (collectives: 1 for step 0, then the flagged round + the re-planned round)
+  assert r0[1][2] == r1[1][2] == 3
+  # the plan of step 1 holds rank 0's labels first (leaf frames: first rank that has the leaf); what matters is that it is
+  # the CURRENT step's frame, and that step 2 (labels back to the base grid) re-plans again instead of replaying step 1
+  np.testing.assert_array_equal(r0[2][0], base)
+  np.testing.assert_array_equal(r1[2][0], base)

@@ -22,6 +22,7 @@ DET_INPUTS = {DET3: 2, DET6: 3, PASS1: 1}
 CAT_EXCEED, CAT_RANK = 0, 1
 ENS_LANES = 5
 ENS_SORT, ENS_PAIRWISE = 0, 1
+COMM_ID_BYTES = 128
 FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR, FLAG_SKIPNA_ENS = 1, 2, 4, 8
 BINNED_W_ON_X, BINNED_WT_X_ONLY, BINNED_WT_ROW_ONLY = 1, 2, 4  # wbx_det_binned `w_on_x` flags (WBX_BINNED_*)
 
@@ -34,6 +35,8 @@ EXPORTED_SYMBOLS = (
     'wbx_zonal_spectrum', 'wbx_zonal_spectrum_slabs', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy', 'wbx_ctx_wait_fence', 'wbx_memcpy_h2d_async',
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
+    'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
+    'wbx_acc_reset',
 )
 
 
@@ -110,6 +113,13 @@ def load_library():
         'wbx_memcpy_d2d': [vp, vp, vp, C.c_size_t],
         'wbx_acc_add': [vp, vp, vp, i64, i32],
         'wbx_notnan_mask': [vp, vp, i32, i64, vp],
+        'wbx_comm_unique_id': [vp],
+        'wbx_comm_create': [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)],
+        'wbx_comm_destroy': [vp],
+        'wbx_comm_info': [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(i64)],
+        'wbx_acc_allreduce': [vp, vp, vp, i64],
+        'wbx_acc_read': [vp, vp, i64, vp],
+        'wbx_acc_reset': [vp, vp, i64],
         'wbx_timer_start': [vp],
         'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
         'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],

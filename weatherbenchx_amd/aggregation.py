@@ -258,18 +258,23 @@ class Aggregator:
     return _fenced(self._stat_vars(stats))
 
   def aggregate_statistics(self, statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> AggregationState:
-    # look ahead: the spread lane is the only ensemble lane that depends on (algorithm, fair).  Whatever lane of a (p, t)
-    # group comes first launches the kernel for ALL five lanes, so it has to launch the variant the group's CRPSSpread
-    # statistic will ask for -- otherwise CRPSEnsemble reads the ensemble twice (skill first, spread with other parameters
-    # second: round 2's 0.82 ms per 1.73 GB for the reference-default CRPSEnsemble()).
+    self.note_statistics(statistics)
+    per_stat = {name: self._stat_vars(stats) for name, stats in statistics.items()}
+    return _fenced(AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
+                                    {k: v.sum_weights for k, v in per_stat.items()}))
+
+  @staticmethod
+  def note_statistics(statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> None:
+    """Look ahead over the statistics that are about to be aggregated: the spread lane is the only ensemble lane that
+    depends on (algorithm, fair).  Whatever lane of a (p, t) group comes first launches the kernel for ALL five lanes, so it
+    has to launch the variant the group's CRPSSpread statistic will ask for -- otherwise CRPSEnsemble reads the ensemble
+    twice (skill first, spread with other parameters second: round 2's 0.82 ms per 1.73 GB for the reference-default
+    CRPSEnsemble()).  Called by aggregate_statistics and by the chunk loop (pipeline._consume)."""
     for stats in statistics.values():
       for s in stats.values():
         if isinstance(s, lazy.LazyStatistic) and s.is_lazy and s._group.kind == 'ens' \
             and s._lane == lazy.ENS_LANE['CRPSSpread'] and s._ens_params:  # pylint: disable=protected-access
           s._group.spread_params = dict(s._ens_params)  # pylint: disable=protected-access
-    per_stat = {name: self._stat_vars(stats) for name, stats in statistics.items()}
-    return _fenced(AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
-                                    {k: v.sum_weights for k, v in per_stat.items()}))
 
   def _stat_var(self, stat: xr.DataArray) -> AggregationState | None:
     stat = xr.as_dataarray(stat)

@@ -80,22 +80,94 @@ def _key_sort(key):
 
 
 def _local_meta(acc: engine.Accumulation):
+  """(slot sizes, host arrays, leaf specs, frames) of this rank -- read only: host leaves (results that never were on the
+  device) get their specs and frames in LOCAL dicts, so resolving an accumulation twice, or after a host leaf changed its
+  shape, can never leave a stale spec behind."""
   slots = dict(acc.slot_table())
   host = {}
+  leaves = {path: list(specs) for path, specs in acc.specs.items()}
+  frames = {(path, spec): acc.frames[(path, i)] for path, specs in leaves.items() for i, spec in enumerate(specs)}
   for path, da in acc.host.items():
     arr = np.array(da.values, dtype=np.float64, order='C')  # (ascontiguousarray would turn 0-d into 1-d)
     key = ('host', path)
     slots[key] = int(arr.size)
     host[key] = arr
     strides = tuple(int(s // 8) for s in arr.strides)
-    acc_spec = (key, 0, tuple(int(x) for x in arr.shape), strides, tuple(da.dims), 1.0)
-    lst = acc.specs.setdefault(path, [])
-    if acc_spec not in lst:
-      lst.append(acc_spec)
-      acc.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
-  leaves = {path: list(specs) for path, specs in acc.specs.items()}
-  frames = {(path, spec): acc.frames[(path, i)] for path, specs in leaves.items() for i, spec in enumerate(specs)}
+    spec = (key, 0, tuple(int(x) for x in arr.shape), strides, tuple(da.dims), 1.0)
+    lst = leaves.setdefault(path, [])
+    lst[:] = [sp for sp in lst if sp[0] != key]  # one spec per host leaf: the current one
+    lst.append(spec)
+    frames[(path, spec)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
   return slots, host, leaves, frames
+
+
+def _frames_digest(frames) -> int:
+  """A cheap hash of every result frame's coordinates (labels of surviving dims, names): a cached ReductionPlan is only
+  reused while the arrays it would hand out carry the labels of THIS step (another latitude slice, other time labels ->
+  re-plan)."""
+  import zlib  # pylint: disable=g-import-not-at-top
+  h = 0
+  for key in sorted(frames, key=repr):
+    coords, name, _ = frames[key]
+    h = zlib.crc32(repr((key[0], name)).encode(), h)
+    for cname in sorted(coords, key=str):
+      dims, values = coords[cname]
+      v = np.ascontiguousarray(np.asarray(values))
+      h = zlib.crc32(repr((cname, tuple(dims), v.shape, str(v.dtype))).encode(), h)
+      h = zlib.crc32(v.tobytes() if v.dtype != object else repr(v.tolist()).encode(), h)
+  return h
+
+
+class CabiCommunicator:
+  """An RCCL communicator owned by libwbx_hip.so (wbx_comm_create): the payload collective of reduce_accumulation then is
+  wbx_acc_allreduce on the library's own stream -- what a C / cgo / JNI host of the library would call; torch is not
+  involved in moving the sums.  `CabiCommunicator.from_torch_group()` bootstraps it inside a torch.distributed job (the 128
+  byte id travels through the group's object broadcast); a host without torch passes the id around itself."""
+
+  def __init__(self, ctx, unique_id: bytes, nranks: int, rank: int):
+    import ctypes as C  # pylint: disable=g-import-not-at-top
+    from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+    if len(unique_id) != _hip.COMM_ID_BYTES:
+      raise ValueError(f'unique_id must be {_hip.COMM_ID_BYTES} bytes')
+    self.ctx, self.nranks, self.rank = ctx, int(nranks), int(rank)
+    handle = C.c_void_p()
+    buf = C.create_string_buffer(bytes(unique_id), _hip.COMM_ID_BYTES)
+    _hip.check(ctx.lib.wbx_comm_create(ctx.handle, buf, self.nranks, self.rank, C.byref(handle)), 'wbx_comm_create')
+    self.handle = handle
+
+  @staticmethod
+  def new_unique_id() -> bytes:
+    import ctypes as C  # pylint: disable=g-import-not-at-top
+    from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+    buf = C.create_string_buffer(_hip.COMM_ID_BYTES)
+    _hip.check(_hip.load_library().wbx_comm_unique_id(buf), 'wbx_comm_unique_id')
+    return buf.raw
+
+  @classmethod
+  def from_torch_group(cls, group=None, ctx=None):
+    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [cls.new_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return cls(ctx if ctx is not None else _reduction_context(), box[0], world, rank)
+
+  @property
+  def collectives(self) -> int:
+    import ctypes as C  # pylint: disable=g-import-not-at-top
+    n = C.c_int64()
+    self.ctx.lib.wbx_comm_info(self.handle, None, None, C.byref(n))
+    return int(n.value)
+
+  def close(self):
+    if self.handle is not None:
+      self.ctx.lib.wbx_comm_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
 
 _reduce_ctx: dict = {}
@@ -110,93 +182,125 @@ def _reduction_context():
   return hit[1]
 
 
+def _build_plan(local_sig, slots, leaves, frames, group, exchange: bool, world: int) -> ReductionPlan:
+  metas = [(slots, leaves, frames)]
+  if exchange:
+    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (slots, leaves, frames), group=group)
+    metas = gathered
+  union: dict = {}
+  for sl, _, _ in metas:
+    for key, n in sl.items():
+      if union.setdefault(key, n) != n:
+        raise ValueError(f'accumulator {key} has {n} values on one rank and {union[key]} on another: the ranks '
+                         'do not run the same statistics / aggregators')
+  order = sorted(union, key=_key_sort)
+  offsets, total = {}, 0
+  for key in order:
+    offsets[key] = total
+    total += union[key]
+  all_leaves: dict = {}
+  all_frames: dict = {}
+  for _, lv, fr in metas:
+    for path, specs in lv.items():
+      have = all_leaves.setdefault(path, [])
+      for spec in specs:
+        if spec not in have:  # the same view of the same slot on several ranks is ONE array after the reduction
+          have.append(spec)
+          all_frames[(path, spec)] = fr[(path, spec)]
+  return ReductionPlan(local_sig, order, offsets, total, all_leaves, all_frames)
+
+
 def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: bool = True, plan: ReductionPlan | None = None,
-                        force: bool = False, fence=None):
+                        force: bool = False, fence=None, comm: CabiCommunicator | None = None):
   """-> ({path: DataArray}, ReductionPlan): every captured leaf of `acc`, summed over the ranks of `group`.
 
   `all_reduce=False` resolves the local accumulators only.  `force` runs the collective even in a one-rank group (the
   RCCL plumbing check on a single GPU).  Pass the returned plan back in while the local layout does not change to skip
-  the layout exchange (ranks whose layout DOES change must all call without a plan again).  `fence`: wait for this fence
-  (the state's own) instead of draining every launch stream -- a pipelined loop has the next step's kernels in flight."""
+  the layout exchange.  The payload buffer carries ONE extra element, "my layout or my result labels changed under the
+  cached plan": it is summed with the payload, so a rank that has to re-plan makes EVERY rank re-plan after that collective
+  (its own payload is zeros for that round) -- nobody is left waiting in a collective the others never enter, and the steady
+  state stays at exactly one collective per call.  `fence`: wait for this fence (the state's own) instead of
+  draining every launch stream -- a pipelined loop has the next step's kernels in flight.  `comm`: the payload collective goes
+  through the library's own RCCL communicator (wbx_acc_allreduce) instead of torch.distributed; the layout exchange (once
+  per job) still needs a torch group when there is more than one rank."""
   world, backend = _group_info(group)
-  collective = all_reduce and (world > 1 or (force and backend is not None))
+  if comm is not None:
+    if backend is not None and comm.nranks != world:
+      raise ValueError(f'the C-ABI communicator has {comm.nranks} ranks, the torch group {world}')
+    world = comm.nranks if backend is None else world
+  collective = all_reduce and (world > 1 or (force and (backend is not None or comm is not None)))
   slots, host, leaves, frames = _local_meta(acc)
   local_sig = (tuple(sorted(slots.items(), key=lambda kv: _key_sort(kv[0]))),
-               tuple(sorted(((p, tuple(s)) for p, s in leaves.items()), key=lambda kv: _key_sort(kv[0]))))
-  if plan is None or plan.local_sig != local_sig:
-    if plan is not None and collective:
-      raise ValueError('the accumulator layout changed under a cached ReductionPlan: call again without `plan` on '
-                       'every rank')
-    metas = [(slots, leaves, frames)]
-    if collective and world > 1:
-      import torch.distributed as dist  # pylint: disable=g-import-not-at-top
-      gathered = [None] * world
-      dist.all_gather_object(gathered, (slots, leaves, frames), group=group)
-      metas = gathered
-    union: dict = {}
-    for sl, _, _ in metas:
-      for key, n in sl.items():
-        if union.setdefault(key, n) != n:
-          raise ValueError(f'accumulator {key} has {n} values on one rank and {union[key]} on another: the ranks '
-                           'do not run the same statistics / aggregators')
-    order = sorted(union, key=_key_sort)
-    offsets, total = {}, 0
-    for key in order:
-      offsets[key] = total
-      total += union[key]
-    all_leaves: dict = {}
-    all_frames: dict = {}
-    for _, lv, fr in metas:
-      for path, specs in lv.items():
-        have = all_leaves.setdefault(path, [])
-        for spec in specs:
-          if spec not in have:  # the same view of the same slot on several ranks is ONE array after the reduction
-            have.append(spec)
-            all_frames[(path, spec)] = fr[(path, spec)]
-    plan = ReductionPlan(local_sig, order, offsets, total, all_leaves, all_frames)
+               tuple(sorted(((p, tuple(s)) for p, s in leaves.items()), key=lambda kv: _key_sort(kv[0]))),
+               _frames_digest(frames))
+  exchange = collective and world > 1
+  if exchange and backend is None:
+    raise ValueError('more than one rank needs an initialised torch.distributed group for the layout exchange')
+  stale = plan is not None and plan.local_sig != local_sig
+  if plan is None or (stale and not exchange):
+    plan, stale = _build_plan(local_sig, slots, leaves, frames, group, exchange, world), False
 
   # ---- the values: this rank's slots at their global offsets, zero elsewhere, then ONE sum over the ranks --------
-  nccl = collective and backend == 'nccl'
+  device_path = collective and (backend == 'nccl' or comm is not None)
   if fence is not None:
     fence.wait()     # the kernels (and accumulator adds) of exactly this state; later launches keep running
   else:
     acc.synchronize()
-  if nccl:
-    import torch  # pylint: disable=g-import-not-at-top
-    import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+  ntot = plan.total + 1  # [payload ..., number of ranks whose cached plan went stale]
+  if device_path:
     from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
     import ctypes as C  # pylint: disable=g-import-not-at-top
-    ctx = _reduction_context()  # own stream: the copies do not queue behind the next step's kernels
-    nbytes = max(plan.total, 1) * 8
-    gbuf = ctx.alloc(nbytes)
-    _hip.check(ctx.lib.wbx_memset(ctx.handle, C.c_void_p(gbuf.ptr), 0, nbytes), 'wbx_memset')
-    for key, (blk, off, n, _) in acc.slots.items():
-      if n:
-        _hip.check(ctx.lib.wbx_memcpy_d2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
-                                          C.c_void_p(blk.dev.ptr + 8 * off), n * 8), 'wbx_memcpy_d2d')
-    for key, arr in host.items():
-      if arr.size:
-        _hip.check(ctx.lib.wbx_memcpy_h2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
-                                          arr.ctypes.data_as(C.c_void_p), arr.nbytes), 'wbx_memcpy_h2d')
-    ctx.synchronize()
-    if plan.total:
-      t = device_tensor(gbuf.ptr, plan.total, ctx.device_id)
+    ctx = comm.ctx if comm is not None else _reduction_context()  # own stream: the copies do not queue behind the next step's kernels
+    gbuf = ctx.alloc(ntot * 8)
+    _hip.check(ctx.lib.wbx_memset(ctx.handle, C.c_void_p(gbuf.ptr), 0, ntot * 8), 'wbx_memset')
+    if stale:
+      one = np.ones(1, dtype=np.float64)
+      _hip.check(ctx.lib.wbx_memcpy_h2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.total), one.ctypes.data_as(C.c_void_p), 8),
+                 'wbx_memcpy_h2d')
+    else:
+      for key, (blk, off, n, _) in acc.slots.items():
+        if n:
+          _hip.check(ctx.lib.wbx_memcpy_d2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
+                                            C.c_void_p(blk.dev.ptr + 8 * off), n * 8), 'wbx_memcpy_d2d')
+      for key, arr in host.items():
+        if arr.size:
+          _hip.check(ctx.lib.wbx_memcpy_h2d(ctx.handle, C.c_void_p(gbuf.ptr + 8 * plan.offsets[key]),
+                                            arr.ctypes.data_as(C.c_void_p), arr.nbytes), 'wbx_memcpy_h2d')
+    if comm is not None:  # all of it is enqueued on the library's stream: copies -> ncclAllReduce -> read-back
+      flat = np.empty(ntot, dtype=np.float64)
+      _hip.check(ctx.lib.wbx_acc_allreduce(ctx.handle, comm.handle, C.c_void_p(gbuf.ptr), ntot), 'wbx_acc_allreduce')
+      _hip.check(ctx.lib.wbx_acc_read(ctx.handle, C.c_void_p(gbuf.ptr), ntot, flat.ctypes.data_as(C.c_void_p)), 'wbx_acc_read')
+    else:
+      import torch  # pylint: disable=g-import-not-at-top
+      import torch.distributed as dist  # pylint: disable=g-import-not-at-top
+      ctx.synchronize()
+      t = device_tensor(gbuf.ptr, ntot, ctx.device_id)
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)  # in place, on the device buffer: no host hop
-      plan.collectives += 1
       torch.cuda.current_stream(t.device).synchronize()
       del t
-    flat = ctx.download(gbuf.ptr, (plan.total,), np.float64)
+      flat = ctx.download(gbuf.ptr, (ntot,), np.float64)
+    plan.collectives += 1
   else:
-    flat = np.zeros(plan.total, dtype=np.float64)
-    for key, arr in acc.download_slots().items():
-      flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr
-    for key, arr in host.items():
-      flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr.reshape(-1)
-    if collective and plan.total:
+    flat = np.zeros(ntot, dtype=np.float64)
+    if stale:
+      flat[plan.total] = 1.0
+    else:
+      for key, arr in acc.download_slots().items():
+        flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr
+      for key, arr in host.items():
+        flat[plan.offsets[key]:plan.offsets[key] + arr.size] = arr.reshape(-1)
+    if collective:
       import torch  # pylint: disable=g-import-not-at-top
       import torch.distributed as dist  # pylint: disable=g-import-not-at-top
       dist.all_reduce(torch.from_numpy(flat), op=dist.ReduceOp.SUM, group=group)
       plan.collectives += 1
+  if flat[plan.total] != 0.0:  # somebody's layout / labels changed: every rank re-plans, then the payload moves again
+    before = plan.collectives
+    out, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=None, force=force, fence=None, comm=comm)
+    plan.collectives += before
+    return out, plan
 
   # ---- the arrays: views of the reduced buffer ----------------------------------------------------------------
   out = {}
@@ -215,7 +319,7 @@ def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: boo
 
 
 def resolve_state(state: AggregationState, acc: engine.Accumulation, group=None, *, all_reduce: bool = True,
-                  plan: ReductionPlan | None = None, force: bool = False):
+                  plan: ReductionPlan | None = None, force: bool = False, comm: CabiCommunicator | None = None):
   """An AggregationState produced under `engine.accumulate_results(acc)` -> (the same tree with real numbers, summed
   over the ranks of `group`; ReductionPlan).  Nothing is waited for before the collective: the state's sums never
   visit the host on their own."""
@@ -223,7 +327,7 @@ def resolve_state(state: AggregationState, acc: engine.Accumulation, group=None,
   for which, tree in (('sws', state.sum_weighted_statistics), ('sw', state.sum_weights)):
     for path, da in _leaves(tree):
       acc.capture((which,) + tuple(path), da)
-  leaves, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=plan, force=force, fence=fence)
+  leaves, plan = reduce_accumulation(acc, group, all_reduce=all_reduce, plan=plan, force=force, fence=fence, comm=comm)
   state._fence = None  # pylint: disable=protected-access  (waited for inside: the chunk's inputs are released)
   trees = {'sws': {}, 'sw': {}}
   for path, da in leaves.items():

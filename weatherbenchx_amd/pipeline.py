@@ -114,31 +114,40 @@ def _offset_key(offsets, stat_dims, reduce_dims):
   return (offsets.init_time if keep('init_time') else None, offsets.lead_time if keep('lead_time') else None)
 
 
-def _consume(chunks, metrics, aggregators, acc):
-  """Launches every chunk.  A chunk's results are ADDED to the device accumulators of `acc` right behind its kernels
-  (slot = aggregator, statistic, variable, surviving offsets); the host only records where each result lives.  The
-  inputs of chunk k are released once chunk k+1 has been enqueued."""
+def _load_stream(work, load_chunk):
+  for offsets, (init_chunk, lead_chunk) in work:
+    yield (offsets, *load_chunk(init_chunk, lead_chunk))
+
+
+def _consume(chunk_streams, passes, acc):
+  """Launches every chunk of every pass.  `chunk_streams[i]` yields (offsets, predictions, targets) for pass i; the streams
+  advance in lockstep, so chunk k of every pass is enqueued before chunk k + 1 of any.  A chunk's results are ADDED to the
+  device accumulators of `acc` right behind its kernels (slot = pass, aggregator, statistic, variable, surviving offsets);
+  the host only records where each result lives.  The inputs of chunk k are released once chunk k+1 has been enqueued."""
   previous = []
-  for offsets, predictions, targets in chunks:
+  for group in zip(*chunk_streams):
     states = []
-    # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
-    # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates them
-    # one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
-    unique = list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
-    for stat_name, stats in unique:
-      for var_name, stat in stats.items():
-        for agg_name, agg in aggregators.items():
-          dims = getattr(stat, 'dims', ())
-          key = _offset_key(offsets, dims, set(agg.reduce_dims))
-          acc.set_label((agg_name, stat_name, str(var_name), key))
-          state = agg.aggregate_stat_var(stat)
-          if state is None:
-            continue
-          got = state.sum_weighted_statistics.dims
-          assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
-          for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
-            acc.capture((agg_name, kind, stat_name, str(var_name), key), da)
-          states.append(state)
+    for (pass_name, metrics, aggregators), (offsets, predictions, targets) in zip(passes, group):
+      # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
+      # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates
+      # them one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
+      unique = list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
+      # (the spread lane of an ensemble group decides which kernel variant serves all its lanes: Aggregator.note_statistics)
+      aggregation.Aggregator.note_statistics(dict(unique))
+      for stat_name, stats in unique:
+        for var_name, stat in stats.items():
+          for agg_name, agg in aggregators.items():
+            dims = getattr(stat, 'dims', ())
+            key = _offset_key(offsets, dims, set(agg.reduce_dims))
+            acc.set_label((pass_name, agg_name, stat_name, str(var_name), key))
+            state = agg.aggregate_stat_var(stat)
+            if state is None:
+              continue
+            got = state.sum_weighted_statistics.dims
+            assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
+            for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
+              acc.capture((pass_name, agg_name, kind, stat_name, str(var_name), key), da)
+            states.append(state)
     for state in previous:
       state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
     previous = states
@@ -146,9 +155,66 @@ def _consume(chunks, metrics, aggregators, acc):
     state.wait()
 
 
+def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True,
+                    prefetch: int = 0, group=None, force_collective: bool = False, comm=None, stats: dict | None = None):
+  """Several evaluations over the same time chunks -- `passes` = [(name, load_chunk, metrics, aggregator | {name: aggregator}),
+  ...], e.g. a deterministic suite, zonal spectra under another aggregator and an ensemble suite from another loader -- as
+  ONE job: the chunks of all passes run interleaved (chunk k of every pass before chunk k + 1), every accumulator of every
+  pass lives in one engine.Accumulation, and the ranks combine EVERYTHING with ONE sum all-reduce of one device buffer at the
+  end, like the reference's single CombinePerKey over all keys of the job (beam_pipeline.py:509-510).
+
+  Returns {pass name: {aggregator name: AggregationState}} (aggregator key None for a single unnamed aggregator).
+  `comm`: a distributed.CabiCommunicator -- the collective then goes through the library's own RCCL entry point
+  (wbx_acc_allreduce) instead of torch.distributed.  `stats`, if given, receives {'collectives': n, 'accumulator_values': n}."""
+  norm = []
+  for name, load_chunk, metrics, aggregator in passes:
+    aggs = {None: aggregator} if isinstance(aggregator, aggregation.Aggregator) else dict(aggregator)
+    norm.append((name, load_chunk, metrics, aggs))
+  if len({n for n, *_ in norm}) != len(norm):
+    raise ValueError('pass names must be unique')
+  work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
+  acc = engine.Accumulation()
+  # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
+  # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
+  feeders = []
+  with engine.accumulate_results(acc):
+    streams = []
+    for _, load_chunk, _, _ in norm:
+      if prefetch:
+        feeder = ChunkFeeder(work, load_chunk, depth=prefetch)
+        feeders.append(feeder)
+        streams.append(iter(feeder))
+      else:
+        streams.append(_load_stream(work, load_chunk))
+    try:
+      _consume(streams, [(n, m, a) for n, _, m, a in norm], acc)
+    finally:
+      for feeder in feeders:
+        feeder.close()
+  leaves, plan = distributed.reduce_accumulation(acc, group, all_reduce=all_reduce and (world_size > 1 or force_collective),
+                                                 force=force_collective, comm=comm)
+  if stats is not None:
+    stats['collectives'] = plan.collectives
+    stats['accumulator_values'] = plan.total
+
+  # acc[pass][agg][type][stat][var][(init_off, lead_off)] -> DataArray
+  trees = {n: {a: {'sum_weighted_statistics': {}, 'sum_weights': {}} for a in aggs} for n, _, _, aggs in norm}
+  for (pass_name, agg_name, kind, stat_name, var_name, key), da in leaves.items():
+    trees[pass_name][agg_name][kind].setdefault(stat_name, {}).setdefault(var_name, {})[key] = da
+  out = {}
+  for pass_name, _, _, aggs in norm:
+    out[pass_name] = {}
+    for agg_name in aggs:
+      done = {kind: {s: {v: _concat_pieces(p) for v, p in per_var.items()}
+                     for s, per_var in trees[pass_name][agg_name][kind].items()}
+              for kind in ('sum_weighted_statistics', 'sum_weights')}
+      out[pass_name][agg_name] = aggregation.AggregationState(done['sum_weighted_statistics'], done['sum_weights'])
+  return out
+
+
 def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[str, metrics_base.Metric],
                     aggregator, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True, prefetch: int = 0,
-                    group=None, force_collective: bool = False):
+                    group=None, force_collective: bool = False, comm=None):
   """Returns {aggregator_name: AggregationState} (key None for a single unnamed aggregator).
 
   `load_chunk(init_times, lead_times) -> (predictions, targets)`; chunks are sharded round-robin over ranks.
@@ -160,35 +226,11 @@ def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[s
   surviving `init_time` / `lead_time` are owned by the rank that ran the chunk and are zero elsewhere, so the same
   collective also assembles the pieces the reference concatenates (beam_pipeline.py:253-319).  Every rank returns the
   complete result.  `force_collective` issues the collective even in a one-rank group (plumbing tests on one GPU).
+  Several (loader, metrics, aggregator) evaluations of one job: `evaluate_passes` (still one collective).
   """
-  aggregators = {None: aggregator} if isinstance(aggregator, aggregation.Aggregator) else dict(aggregator)
-  work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
-  acc = engine.Accumulation()
-  # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
-  # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
-  with engine.accumulate_results(acc):
-    if prefetch:
-      chunks = ChunkFeeder(work, load_chunk, depth=prefetch)
-    else:
-      chunks = ((offsets, *load_chunk(init_chunk, lead_chunk)) for offsets, (init_chunk, lead_chunk) in work)
-    try:
-      _consume(chunks, metrics, aggregators, acc)
-    finally:
-      if prefetch:
-        chunks.close()
-  leaves, _ = distributed.reduce_accumulation(acc, group, all_reduce=all_reduce and (world_size > 1 or force_collective),
-                                              force=force_collective)
-
-  # acc[agg][type][stat][var][(init_off, lead_off)] -> DataArray
-  trees = {name: {'sum_weighted_statistics': {}, 'sum_weights': {}} for name in aggregators}
-  for (agg_name, kind, stat_name, var_name, key), da in leaves.items():
-    trees[agg_name][kind].setdefault(stat_name, {}).setdefault(var_name, {})[key] = da
-  out = {}
-  for agg_name in aggregators:
-    done = {kind: {s: {v: _concat_pieces(p) for v, p in per_var.items()} for s, per_var in trees[agg_name][kind].items()}
-            for kind in ('sum_weighted_statistics', 'sum_weights')}
-    out[agg_name] = aggregation.AggregationState(done['sum_weighted_statistics'], done['sum_weights'])
-  return out
+  out = evaluate_passes(times, [('', load_chunk, metrics, aggregator)], rank=rank, world_size=world_size, all_reduce=all_reduce,
+                        prefetch=prefetch, group=group, force_collective=force_collective, comm=comm)
+  return out['']
 
 
 def resolve_out_path(out_path, agg_name):
