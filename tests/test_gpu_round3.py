@@ -142,12 +142,13 @@ def test_magnitudes_the_fp32_sums_cannot_hold_take_the_fp64_escape(ctx):
   nlat, nlon, m = 6, 1440, 51
   pv = np.empty((m, nlat, nlon), np.float32)
   tv = np.empty((nlat, nlon), np.float32)
-  pv[:, 0] = rng.normal(size=(m, nlon)) * 10.0 ** rng.integers(-30, 25, size=(m, nlon))   # range far above 2^60 in most points
+  pv[:, 0] = rng.normal(size=(m, nlon)) * 10.0 ** rng.integers(-30, 36, size=(m, nlon))   # mixed magnitudes up to 1e36
+  pv[0, 0] = 3e22                                                                            # ... range above 2^60 in EVERY point
   tv[0] = pv[3, 0]
   pv[:, 1] = (rng.integers(-4000, 4000, size=(m, nlon)) * np.float64(1.4e-45)).astype(np.float32)  # denormals: range < 2^-50
   tv[1] = 0.0
   pv[:, 2] = rng.normal(size=(m, nlon)) + 280
-  tv[2] = 1e30                                                                               # |target| > 2^100
+  tv[2] = 1e32                                                                               # |target| > 2^100
   pv[:, 3] = rng.normal(size=(m, nlon)) * 1e-18                                              # squares underflow fp32 normals
   tv[3] = pv[7, 3]
   pv[:, 4] = 5.0                                                                             # zero range: stays fast, exact
@@ -255,6 +256,7 @@ def test_configs4_composite_against_the_oracle(ctx):
   zt = [_randn((1, nlead, nlev, NLAT, NLON), 200 + i, 280.0, 3.0) for i in range(ninit)]
   et = [_randn((1, nlead, NLAT, NLON), 300 + i, 280.0) for i in range(2)]      # the ensemble pool: 2 buffers, reused cyclically
   ep = [_randn((1, nlead, m, NLAT, NLON), 400 + i) + et[i][:, :, None] for i in range(2)]
+  et = [et[i] + _randn((1, nlead, NLAT, NLON), 500 + i) for i in range(2)]     # (target and members exchangeable: spread/skill ~ 1)
   torch.cuda.synchronize()
   index_of = {int(t.astype('int64')): i for i, t in enumerate(init_times)}
 
@@ -322,6 +324,7 @@ def test_configs4_composite_against_the_oracle(ctx):
       var += mean(lanes['EnsembleVariance'])
       ue += mean(lanes['UnbiasedEnsembleMeanSquaredError'])
     np.testing.assert_allclose(evals['crps.t2m'].values[lead], (skill - 0.5 * spread) / ninit, rtol=RTOL)
+    assert abs(np.sqrt(var / ue) - 1.0) < 0.01
     np.testing.assert_allclose(evals['ssr.t2m'].values[lead], np.sqrt(var / ue), rtol=RTOL)
 
 
