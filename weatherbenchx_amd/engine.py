@@ -11,6 +11,7 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 import dataclasses
+import os
 from typing import Sequence
 
 import numpy as np
@@ -367,7 +368,7 @@ def stage_inputs(ctx, arrays: Sequence[xr.DataArray]):
 # (two of them side by side only share the bandwidth; configs[1] measured 3.8 -> 4.0 ms).  Every reduction still runs
 # start to end on ONE stream, scratch buffers are per context, cached operands are uploaded synchronously, and the
 # state's fence covers every context that got work.
-ALTERNATE_STREAMS = True
+ALTERNATE_STREAMS = os.environ.get('WBX_ALTERNATE_STREAMS', '1') != '0'
 _stream_ring: list = []
 
 
