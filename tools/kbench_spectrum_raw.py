@@ -1,6 +1,10 @@
 """wbx_zonal_spectrum through the C ABI alone, HIP events on the launch stream: N back-to-back launches per event pair, with
 and without idle gaps between the pairs (is the kernel slower in a sustained loop than in isolation?)."""
 import os
+# the knock-out / phase-stamped kernels live in the diagnostic build only (make -C weatherbenchx_amd/csrc diag)
+_diag = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'weatherbenchx_amd', 'libwbx_hip_diag.so')
+if os.path.exists(_diag):
+  os.environ.setdefault('WBX_LIBRARY_PATH', _diag)
 import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

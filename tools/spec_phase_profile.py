@@ -1,6 +1,10 @@
 """Phase profile of the 1440-point spectrum kernel: runs configs[3]'s field through the s_memtime-stamped instantiation
 (WBX_SPECTRUM_PROF) and prints the average shader-clock cycles wave 0 of each block spends per row pair and phase."""
 import os
+# the knock-out / phase-stamped kernels live in the diagnostic build only (make -C weatherbenchx_amd/csrc diag)
+_diag = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'weatherbenchx_amd', 'libwbx_hip_diag.so')
+if os.path.exists(_diag):
+  os.environ.setdefault('WBX_LIBRARY_PATH', _diag)
 import sys
 import tempfile
 path = os.path.join(tempfile.gettempdir(), 'wbx_spec_prof.txt')

@@ -229,12 +229,24 @@ class PinnedBlock:
       pass
 
 
-def is_pinned(arr) -> bool:
-  """True for numpy arrays (views included) whose memory came from Context.pinned_empty / the read-back pool."""
+def _pinned_block_of(arr):
   base = arr
   while isinstance(base, np.ndarray):
     base = base.base
-  return isinstance(base, PinnedBlock)
+  return base if isinstance(base, PinnedBlock) else None
+
+
+def is_pinned(arr) -> bool:
+  """True for numpy arrays (views included) whose memory came from Context.pinned_empty / the read-back pool."""
+  return _pinned_block_of(arr) is not None
+
+
+def is_loader_pinned(arr) -> bool:
+  """True only for arrays handed out by Context.pinned_empty (pipeline.pinned_empty) -- the arrays whose contract says
+  "filled once, then left alone": those may be uploaded asynchronously.  Views of the read-back pool (results of earlier
+  reductions) are page-locked too but are recycled by the pool, so they take the synchronous path."""
+  block = _pinned_block_of(arr)
+  return block is not None and getattr(block, 'for_loader', False)
 
 
 class Fence:
@@ -346,6 +358,7 @@ class Context:
     dt = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64))
     block = self._pinned_block(n * dt.itemsize, dt.str, dt.itemsize)
+    block.for_loader = True  # (see is_loader_pinned)
     return np.asarray(block).reshape(shape)
 
   def upload_async(self, arr: np.ndarray) -> DeviceBuffer:

@@ -424,17 +424,42 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
 
 #include "wbx_zspec1440.hpp"
 
-// WBX_SPECTRUM_KNOCK selects diagnostic instantiations whose RESULTS ARE WRONG by design (timing only): said once, loudly.
+// Diagnostic instantiations -- WBX_SPECTRUM_KNOCK: kernels whose RESULTS ARE WRONG by design (timing only);
+// WBX_SPECTRUM_PROF=<file>: the phase-stamped kernels, counters appended to a file -- exist only in a library built with
+// -DWBX_DIAGNOSTICS (`make diag`: libwbx_hip_diag.so, what tools/kbench_spectrum_raw.py and tools/spec_phase_profile.py load
+// through WBX_LIBRARY_PATH).  The shipped library ignores both variables and says so once: a stray environment variable in a
+// production job must not be able to corrupt spectra or write files.
+#ifdef WBX_DIAGNOSTICS
 static int spectrum_knock() {
   static const int knock = [] {
     const char* e = getenv("WBX_SPECTRUM_KNOCK");
     const int k = e ? atoi(e) : 0;
     if (k != 0)
-      fprintf(stderr, "libwbx_hip: WBX_SPECTRUM_KNOCK=%d -- diagnostic spectrum kernels are in use, their results are not valid\n", k);
+      fprintf(stderr, "libwbx_hip (diagnostic build): WBX_SPECTRUM_KNOCK=%d -- diagnostic spectrum kernels are in use, their results are not valid\n", k);
     return k;
   }();
   return knock;
 }
+static const char* spectrum_prof_path() {
+  static const char* path = getenv("WBX_SPECTRUM_PROF");
+  return path;
+}
+#else
+static void spectrum_diag_ignored() {
+  static const bool said = [] {
+    if (getenv("WBX_SPECTRUM_KNOCK") || getenv("WBX_SPECTRUM_PROF"))
+      fprintf(stderr, "libwbx_hip: WBX_SPECTRUM_KNOCK / WBX_SPECTRUM_PROF are ignored: this library was built without -DWBX_DIAGNOSTICS (make diag)\n");
+    return true;
+  }();
+  (void)said;
+}
+static constexpr int spectrum_knock_value = 0;
+static int spectrum_knock() {
+  spectrum_diag_ignored();
+  return 0;
+}
+static const char* spectrum_prof_path() { return nullptr; }
+#endif
 
 // Launches zspec1440_kernel: as many one-wave teams per block as the LDS holds (12: tables + 12 x 11.4 KB), one block per
 // CU, and -- every team takes the same time -- a grid of exactly `rounds` resident sets.
@@ -456,7 +481,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   const int nteam = teams_env < 1 ? 1 : (teams_env > 12 ? 12 : teams_env);
   const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)nteam * Z14_BUF * sizeof(v4);
   // WBX_SPECTRUM_PROF=<file>: the phase-stamped instantiation; the eight counters are appended to the file per launch
-  static const char* prof_path = getenv("WBX_SPECTRUM_PROF");
+  const char* prof_path = spectrum_prof_path();
   const void* fn = prof_path ? reinterpret_cast<const void*>(&zspec1440_kernel<true, 0>) : reinterpret_cast<const void*>(&zspec1440_kernel<false, 0>);
   int& per_cu = st->occupancy[std::make_pair(fn, lds)];
   if (per_cu == 0) {
@@ -538,7 +563,7 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     WBX_HIP(hipStreamSynchronize(ctx->stream));
   }
   const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)Z14_TEAMS * Z14_BUFL * sizeof(v4) + (size_t)(Z14_N2 + 2) * sizeof(double);
-  static const char* prof_path = getenv("WBX_SPECTRUM_PROF");
+  const char* prof_path = spectrum_prof_path();
   const void* fn = prof_path ? reinterpret_cast<const void*>(&zspec1440_latfast_kernel<true, 0>) : reinterpret_cast<const void*>(&zspec1440_latfast_kernel<false, 0>);
   int& per_cu = st->occupancy[std::make_pair(fn, lds)];
   if (per_cu == 0) {

@@ -76,12 +76,21 @@ def _to_device(ctx: _hip.Context, da: xr.DataArray, dtype_code: int) -> _Dev:
   else:
     host = xr._to_numpy(data)  # pylint: disable=protected-access
     fence = None
-    if host.dtype == want and host.flags['C_CONTIGUOUS'] and host.nbytes and _hip.is_pinned(host):
-      # page-locked source (pipeline.pinned_empty): pure DMA on the context stream, nobody waits on the host; the
-      # array is kept (untouched) with the device copy until both are dropped
+    if host.dtype == want and host.flags['C_CONTIGUOUS'] and host.nbytes and _hip.is_loader_pinned(host):
+      # page-locked source from pipeline.pinned_empty: pure DMA on the context stream, nobody waits on the host; the
+      # array is kept with the device copy until both are dropped.  Contract (pinned_empty's docstring): a chunk's arrays
+      # are filled once and then left alone -- the next chunk takes fresh ones.  The array is frozen here so that a loader
+      # that re-uses it as its own double buffer fails loudly instead of racing the in-flight DMA; any other
+      # page-locked memory (views of the read-back pool) goes through the synchronous copy below.
       buf = ctx.upload_async(host)
       fence = ctx.fence()
       keep = (buf, host)
+      try:
+        host.flags.writeable = False
+        if isinstance(data, np.ndarray):
+          data.flags.writeable = False
+      except ValueError:
+        pass
     else:
       host = np.ascontiguousarray(host, dtype=want)
       buf = keep = ctx.upload(host)
@@ -331,6 +340,27 @@ GATHER_VARIANTS_MAX = 512  # climatology gather tables kept per cached plan (one
 _fast_plan_cache: dict = {}
 _thr_cache: dict = {}
 _count_cache: dict = {}
+# id(root array) -> root array: read-only host arrays that hold data-INDEPENDENT results (sums of weights per geometry).  A view
+# of one of them means the same numbers every time it is met, whatever view object carries it.
+_const_roots: dict = {}
+
+
+def register_constant(arr: np.ndarray) -> np.ndarray:
+  arr.flags.writeable = False
+  _const_roots[id(arr)] = arr
+  return arr
+
+
+def _constant_view_key(a):
+  """(root id, address, shape, strides) when `a` is a view of a registered constant, else None."""
+  if not isinstance(a, np.ndarray) or a.flags.writeable:
+    return None
+  root = a
+  while isinstance(root, np.ndarray) and root.base is not None:
+    root = root.base
+  if not isinstance(root, np.ndarray) or _const_roots.get(id(root)) is not root:
+    return None
+  return (id(root), a.__array_interface__['data'][0], a.shape, a.strides)
 _scratch_bufs: dict = {}
 
 
@@ -393,6 +423,7 @@ def clear_caches():
   _w_cache.clear()
   _fast_plan_cache.clear()
   _count_cache.clear()
+  _const_roots.clear()
   _scratch_bufs.clear()
   _thr_cache.clear()
 
@@ -663,14 +694,17 @@ class Accumulation:
     loc = self.locate(da.data)
     if loc is None:
       data = da.data
-      if isinstance(data, np.ndarray) and not data.flags.writeable and data.flags.owndata:
-        # a cached constant (data-independent sums of weights handed out read-only): met again under the same path with the
-        # same frame it only bumps a multiplicity, folded into the host sums when they are read (`host`)
+      ckey = _constant_view_key(data)
+      if ckey is not None or (isinstance(data, np.ndarray) and not data.flags.writeable and data.flags.owndata):
+        # a cached constant (data-independent sums of weights handed out read-only, or ANY view of a registered one): met
+        # again under the same path with the same frame it only bumps a multiplicity, folded into the host sums when they
+        # are read (`host`)
         for term in self._host_const.setdefault(path, []):
-          if term[0].data is data and term[0].dims == da.dims and _same_coords(term[0], da):
+          same = term[2] == ckey if ckey is not None else term[0].data is data
+          if same and term[0].dims == da.dims and _same_coords(term[0], da):
             term[1] += coeff
             return
-        self._host_const[path].append([da, float(coeff)])
+        self._host_const[path].append([da, float(coeff), ckey])
         return
       self._host_add(self._host_sum, path, da if coeff == 1.0 else da * coeff)
       return
@@ -692,7 +726,7 @@ class Accumulation:
     """path -> DataArray: the results that never were on the device, summed over the captures."""
     out = dict(self._host_sum)
     for path, terms in self._host_const.items():
-      for da, mult in terms:
+      for da, mult, _ in terms:
         self._host_add(out, path, da if mult == 1.0 else da * mult)
     return out
 
@@ -958,14 +992,23 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
       ones_buf = ctx.upload(ones)
       cptr, cshape = _run_s2(ctx, s2c, ones_buf.ptr, w_buf)  # [1][nBk][1][nj_out][nbin]
       cnt = ctx.download(cptr, cshape, np.float64)  # computed once per geometry and cached: read back synchronously
+      cnt = np.array(cnt, dtype=np.float64)  # (own memory: the read-back pool recycles its blocks)
       if len(_count_cache) > 64:
         _count_cache.clear()
-      _count_cache[ckey] = (cnt, w_buf)  # keep w_buf alive so its id stays unique
+        _const_roots.clear()
+      scaled = {}
+      _count_cache[ckey] = (cnt, w_buf, scaled)  # keep w_buf alive so its id stays unique
+      register_constant(cnt)
     else:
-      cnt = cnt[0]
-    cnt = np.broadcast_to(cnt[:, :, 0], (s2.nA,) + cnt[:, :, 0].shape[1:]).reshape(lead_shape + tail_shape)
+      cnt, scaled = cnt[0], cnt[2]
     if x_weights is not None:  # sum of the folded weights over the reduced elements: (others reduced) * sum_x w[x]
-      cnt = cnt * (float(x_weights.sum()) / plan.nx)
+      factor = float(x_weights.sum()) / plan.nx
+      if factor not in scaled:
+        scaled[factor] = register_constant(cnt * factor)
+      cnt = scaled[factor]
+    # every view handed out below is a view of ONE registered read-only array: Accumulation.capture recognises it by its
+    # root and only counts how often it met it -- no outer-join / full-size add per statistic, aggregator and chunk
+    cnt = np.broadcast_to(cnt[:, :, 0], (s2.nA,) + cnt[:, :, 0].shape[1:]).reshape(lead_shape + tail_shape)
     counts = np.broadcast_to(cnt, values.shape)
   return values, counts, out_dims
 

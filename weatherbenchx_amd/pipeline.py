@@ -28,7 +28,10 @@ def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
   the kernels of the previous chunk and the loader's work on the next one); the launch stream waits on the copy's
   event, the host never does.  Every chunk takes fresh arrays: a block returns to the pool when the chunk's DataArrays
   are dropped, i.e. after its kernels have run, so an array is never overwritten while it is being read (the pool is
-  the double buffer).  Arrays from anywhere else are uploaded through the runtime's pageable path (measured 55 GB/s)."""
+  the double buffer).  CONTRACT: fill the array, hand it over, leave it alone -- the upload returns before the DMA has read
+  it, and the array is made read-only at that point, so a loader that keeps one array as its own double buffer gets a
+  ValueError on its next write instead of corrupting the chunk in flight.  Arrays from anywhere else are uploaded through
+  the runtime's pageable path (measured 55 GB/s), synchronously."""
   from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
   return _hip.default_context().pinned_empty(shape, dtype)
 
