@@ -694,10 +694,12 @@ def config5_leg(env):
     states = pipeline.evaluate_passes(times, passes, rank=env.rank, world_size=env.world, comm=comm, stats=stats)
     return {name: states[name][None].metric_values(metrics_of[name]) for name in metrics_of}  # (the sums are on the host here)
 
-  def run_one(times, which):  # a single pass, for the per-pass timings below
-    name, load, metrics, agg = next(p for p in passes if p[0] == which)
+  def run_some(times, names):  # a subset of the evaluations as their own job, for the per-evaluation timings below
+    some = [p for p in passes if p[0] in names]
     tp = time.perf_counter()
-    pipeline.evaluate_chunks(times, load, metrics, agg, rank=env.rank, world_size=env.world, all_reduce=False)[None].metric_values(metrics)
+    st = pipeline.evaluate_passes(times, some, rank=env.rank, world_size=env.world, all_reduce=False)
+    for name, _, metrics, _ in some:
+      st[name][None].metric_values(metrics)
     return time.perf_counter() - tp
   warm = time_chunks.TimeChunks(init_times[:2 * env.world], lead_time, init_time_chunk_size=1)
   run(warm)
@@ -711,12 +713,20 @@ def config5_leg(env):
   # per-pass pace of this rank (outside the timed region, a sixth of the chunks, no collective)
   sub = time_chunks.TimeChunks(init_times[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
   nsub = len(distributed_shard(sub, env))
-  pass_s = {name: run_one(sub, name) / max(nsub, 1) * 1e3 for name in metrics_of}
+  from weatherbenchx_amd import engine as _engine
+  fused = _engine.FUSE_DET_SPECTRA and env.layout == 'lon_fastest' and env.nlon == 1440
+  pass_s = {'z: deterministic + spectra of p and t' + (' (ONE sweep: wbx_det_spectrum)' if fused else ' (separate launches)'):
+                run_some(sub, ('deterministic', 'spectra')) / max(nsub, 1) * 1e3,
+            'deterministic alone': run_some(sub, ('deterministic',)) / max(nsub, 1) * 1e3,
+            'spectra alone': run_some(sub, ('spectra',)) / max(nsub, 1) * 1e3,
+            'ensemble': run_some(sub, ('ensemble',)) / max(nsub, 1) * 1e3}
   env.sync()
   grid = env.nlat * env.nlon
   pz, pt = nlead * nlev * grid, nlead * grid
   evals_per_chunk = pz * len(det) + pz * len(spec) + pt * len(ens)
-  bytes_per_chunk = pz * 12 + pz * 8 + pt * (m + 1) * 4
+  # one sweep over p, t, c serves the deterministic lanes AND both spectra (12 B/point); as separate launches p and t are read
+  # again by the spectra (20 B/point of traffic for the same 12 B/point of algorithmic input -- the fraction below counts 12)
+  bytes_per_chunk = pz * 12 + pt * (m + 1) * 4
   rm = float(np.asarray(out['deterministic']['rmse.z'].values).mean())
   return {'workload': f'configs[4]: full suite on {ninit} inits x {nlead} leads, streamed as [1 init x {nlead} lead] chunks from a '
                       f'resident pool of {npool} (H2D excluded): z f32[{nlead},{nlev},{env.nlat},{env.nlon}] p,t + climatology -> '
@@ -730,7 +740,8 @@ def config5_leg(env):
           'scaling': 'strong', 'n_gpus': env.world, 'chunks': ninit, 'time_slices': ninit * nlead, 'seconds': dt,
           'seconds_rank0': rank_s, 'ms_per_chunk': dt / ninit * 1e3, 'ms_per_chunk_rank0': rank_s / max(len(distributed_shard(times, env)), 1) * 1e3,
           'ms_per_chunk_by_pass_rank0': {k: round(v, 3) for k, v in pass_s.items()},
-          'ms_per_chunk_by_pass_note': 'each evaluation alone on a sixth of the chunks, outside the timed region',
+          'ms_per_chunk_by_pass_note': 'subsets of the evaluations as their own jobs on a sixth of the chunks, outside the timed region',
+          'z_bytes_per_point': 12, 'fused_det_spectra': bool(fused),
           'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),

@@ -328,6 +328,22 @@ int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_strid
                              const int32_t* group, const double* scale, int32_t ngroup, int32_t accumulate,
                              double* power_out);
 
+/* ---- spectra + deterministic lanes in one sweep ---------------------------------------------------------------------
+ * configs[3] / configs[4]: "spectra of p and t + the full deterministic suite in the same sweep".  One launch
+ * reads every row of p, t (and c for WBX_DET6) ONCE -- 12 B/point instead of 20 for wbx_det_partial + two wbx_zonal_spectrum
+ * launches -- and produces
+ *   partial_out[key][lane]      exactly what wbx_det_partial writes for this plan (nchunk = 1): the unweighted per-row sums of
+ *                               e, |e|, e^2 (, (p-c)^2, (t-c)^2, (p-c)(t-c)); wbx_contract consumes it unchanged
+ *   power_p / power_t[g][k]     what wbx_zonal_spectrum returns for the rows of p resp. t: sum over the rows of group g of
+ *                               scale[row] * S_k(row), k = 0 .. 720; zeroed here first
+ * `plan` is the deterministic plan of (p, t[, c]) with x = longitude (nx = 1440, unit x strides, even row offsets), summed,
+ * ndepth = 1, nchunk = 1, no mask: a row of the spectra = a key of the plan, group / scale are indexed by key.
+ * Spectrum accuracy: as wbx_zonal_spectrum (fp32 transform, |dS_k| <= 2e-5 S_k + 4e-7 sqrt(S_max S_k)); the deterministic lanes
+ * are fp64 sums of the widened inputs like wbx_det_partial (1e-12).  Parity unpinned for the spectra. */
+int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3 | WBX_DET6 */, int dtype /* WBX_F32 */,
+                     const void* p, const void* t, const void* c, const int32_t* group, const double* scale, int64_t ngroup,
+                     double* partial_out, double* power_p, double* power_t);
+
 #ifdef __cplusplus
 }
 #endif

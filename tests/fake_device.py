@@ -150,7 +150,7 @@ def _cat_lanes(plan, devs, cat):
           for k in range(ncat)]  # NaN threshold: NaN indicator (deterministic.py:293-294)
 
 
-def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None):
+def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None, inputs=None):  # pylint: disable=unused-argument
   with np.errstate(all='ignore'):
     if kind == 'det':
       nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]

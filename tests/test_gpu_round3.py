@@ -274,15 +274,23 @@ def test_configs4_composite_against_the_oracle(ctx):
     return ({'t2m': xr.DataArray(ep[i], dims=('init_time', 'lead_time', 'number') + sp, coords=coords_for(inits))},
             {'t2m': xr.DataArray(et[i], dims=('init_time', 'lead_time') + sp, coords=coords_for(inits))})
   det = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC(clim), 'bias': deterministic.Bias()}
-  spec = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions')}
+  spec = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
   ens = {'crps': probabilistic.CRPSEnsemble(), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
   area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
   zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
   times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
   stats = {}
-  out = pipeline.evaluate_passes(times, [('deterministic', load_det, det, area), ('spectra', load_det, spec, zonal),
-                                         ('ensemble', load_ens, ens, area)], stats=stats)
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 1
+  try:
+    out = pipeline.evaluate_passes(times, [('deterministic', load_det, det, area), ('spectra', load_det, spec, zonal),
+                                           ('ensemble', load_ens, ens, area)], stats=stats)
+    kinds = [e['kind'] for e in engine.S1_EVENT_LOG]
+  finally:
+    engine.S1_EVENT_LOG = None
   assert stats['collectives'] == 0  # one rank: nothing to combine
+  # the two evaluations of z share their loader: every chunk is ONE sweep over p, t, c for the deterministic lanes AND both
+  # spectra (wbx_det_spectrum) -- no separate spectrum launch, no separate deterministic launch
+  assert kinds.count('det_spectrum') == ninit and 'spectrum' not in kinds and 'det' not in kinds, kinds
   dvals = out['deterministic'][None].metric_values(det)
   svals = out['spectra'][None].metric_values(spec)
   evals = out['ensemble'][None].metric_values(ens)
@@ -291,7 +299,7 @@ def test_configs4_composite_against_the_oracle(ctx):
   wn = w / w.sum()
   for lead, lev in ((0, 0), (7, 20), (19, 36)):
     num = {k: 0.0 for k in ('se', 'e', 'cov', 'spa', 'sta')}
-    power = 0.0
+    power = power_t = 0.0
     for i in range(ninit):
       p64 = zp[i][0, lead, lev].cpu().numpy().astype(np.float64)
       t64 = zt[i][0, lead, lev].cpu().numpy().astype(np.float64)
@@ -305,13 +313,14 @@ def test_configs4_composite_against_the_oracle(ctx):
       num['spa'] += ((p64 - c64) ** 2 * wn[:, None]).sum() / NLON
       num['sta'] += ((t64 - c64) ** 2 * wn[:, None]).sum() / NLON
       power = power + (O.zonal_power_spectrum(p64) * wn[:, None]).sum(axis=0)
+      power_t = power_t + (O.zonal_power_spectrum(t64) * wn[:, None]).sum(axis=0)
     np.testing.assert_allclose(dvals['rmse.z'].values[lead, lev], np.sqrt(num['se'] / ninit), rtol=RTOL)
     np.testing.assert_allclose(dvals['bias.z'].values[lead, lev], num['e'] / ninit, rtol=RTOL, atol=1e-9)
     np.testing.assert_allclose(dvals['acc.z'].values[lead, lev], num['cov'] / np.sqrt(num['spa'] * num['sta']), rtol=RTOL)
-    got = np.asarray(svals['spectrum_p.z'].values)[lead, lev]
-    ref = power / ninit
-    # (the spectrum's own bound: the FFT is fp32, include/wbx.h "zonal spectrum")
-    assert np.all(np.abs(got - ref) <= 2e-5 * ref + 4e-7 * np.sqrt(ref.max() * ref))
+    for name, ref in (('spectrum_p.z', power / ninit), ('spectrum_t.z', power_t / ninit)):
+      got = np.asarray(svals[name].values)[lead, lev]
+      # (the spectrum's own bound: the FFT is fp32, include/wbx.h "zonal spectrum")
+      assert np.all(np.abs(got - ref) <= 2e-5 * ref + 4e-7 * np.sqrt(ref.max() * ref)), name
   for lead in (3,):
     skill = spread = var = ue = 0.0
     for i in range(ninit):
@@ -388,3 +397,118 @@ def test_chunk_loop_combines_through_the_cabi_collective(ctx):
   w = O.grid_area_weights(lat)
   want = np.sqrt((((pv.astype(np.float64) - tv) ** 2) * w[None, None, :, None]).sum(axis=(0, 2, 3)) / (w.sum() * nlon * ninit))
   np.testing.assert_allclose(plain['rmse.v'].values, want, rtol=RTOL)
+
+
+# ---- spectra + deterministic lanes in one sweep ---------------------------------------------------------------------------
+@pytest.mark.parametrize('func', ['DET6', 'DET3'])
+def test_det_spectrum_entry_point_against_the_oracle(ctx, func):
+  """wbx_det_spectrum with raw pointers: rows of 1440 points of p, t and a climatology addressed through a gather table (other
+  time labels per lead), ragged row count (not a multiple of the teams).  The partial buffer must be exactly wbx_det_partial's,
+  the per-row sums the float64 formulas of the oracle, both spectra numpy.fft's within the transform's bound."""
+  from weatherbenchx_amd import planner
+  rng = np.random.default_rng(3)
+  nlead, nlev, nlat, nlon = 3, 2, 37, 1440
+  dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+  shape = (1, nlead, nlev, nlat, nlon)
+  pv = (rng.normal(size=shape) * 3 + 280).astype(np.float32)
+  tv = (rng.normal(size=shape) * 3 + 280).astype(np.float32)
+  nslot = 5
+  cv = (rng.normal(size=(nslot, nlev, nlat, nlon)) * 10 + 280).astype(np.float32)
+  slot_of_lead = np.array([4, 0, 2])
+  p, t = xr.DataArray(pv, dims=dims), xr.DataArray(tv, dims=dims)
+  c = xr.DataArray(cv, dims=('slot', 'level', 'latitude', 'longitude'))
+  devs = [engine._to_device(ctx, a, _hip.F32) for a in (p, t, c)] + [None]
+  lays = [d.layout for d in devs[:3]] + [None]
+  sizes = dict(zip(dims, shape))
+  table = (slot_of_lead * devs[2].layout.stride('slot')).reshape(1, nlead).astype(np.int64)
+  gather = planner.GatherSpec(dims=('init_time', 'lead_time'), table=table) if func == 'DET6' else None
+  if func == 'DET3':
+    lays[2] = None
+  plan = planner.build_s1_plan(dims, sizes, lays, ['init_time', 'latitude', 'longitude'], wdep_dims=['latitude'], gather=gather)
+  assert plan.ndepth == 1 and plan.nchunk == 1 and plan.nkey == nlead * nlev * nlat and plan.key_dims == ('lead_time', 'level', 'latitude')
+  dplan = engine._device_plan(ctx, plan)
+  code = getattr(_hip, func)
+  nl = _hip.DET_LANES[code]
+  nrows, ngroup, nk = plan.nkey, nlead * nlev, nlon // 2 + 1
+  w = np.cos(np.deg2rad(np.linspace(-88, 88, nlat)))
+  group = np.repeat(np.arange(ngroup, dtype=np.int32), nlat)
+  scale = np.tile(w, ngroup)
+  g_dev, s_dev = ctx.upload(group), ctx.upload(scale)
+  part_a, part_b = ctx.alloc(nrows * nl * 8), ctx.alloc(nrows * nl * 8)
+  pw_p, pw_t = ctx.alloc(ngroup * nk * 8), ctx.alloc(ngroup * nk * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  cdev = devs[2] if func == 'DET6' else None
+  _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), code, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev), None,
+                                     ptr(part_a)), 'wbx_det_partial')
+  _hip.check(ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), code, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
+                                      ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)), 'wbx_det_spectrum')
+  ctx.synchronize()
+  a = ctx.download(part_a.ptr, (nrows, nl)).copy()
+  b = ctx.download(part_b.ptr, (nrows, nl)).copy()
+  np.testing.assert_allclose(b, a, rtol=1e-13, atol=1e-9)
+  p64, t64 = pv.astype(np.float64)[0], tv.astype(np.float64)[0]
+  c64 = cv.astype(np.float64)[slot_of_lead]
+  want = [O.error(p64, t64), O.absolute_error(p64, t64), O.squared_error(p64, t64)]
+  if func == 'DET6':
+    want += [O.squared_prediction_anomaly(p64, c64), O.squared_target_anomaly(t64, c64), O.anomaly_covariance(p64, t64, c64)]
+  for lane, wv in enumerate(want):
+    np.testing.assert_allclose(b[:, lane], wv.sum(axis=-1).reshape(-1), rtol=1e-11, atol=1e-6, err_msg=f'lane {lane}')
+  for buf, f64 in ((pw_p, p64), (pw_t, t64)):
+    got = ctx.download(buf.ptr, (ngroup, nk)).copy()
+    ref = (O.zonal_power_spectrum(f64) * w[None, None, :, None]).sum(axis=2).reshape(ngroup, nk)
+    assert np.all(np.abs(got - ref) <= 2e-5 * ref + 4e-7 * np.sqrt(ref.max(axis=1, keepdims=True) * ref))
+  # misuse is refused, not mis-run
+  assert ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), _hip.PASS1, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
+                                  ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)) == -1
+
+
+def test_fused_and_separate_launches_agree_through_the_chunk_loop(ctx, monkeypatch):
+  """Two evaluations over the same loader (RMSE / ACC per (lead, level); zonal spectra of predictions and targets): with the
+  fused launch and with engine.FUSE_DET_SPECTRA off -- the deterministic values bit for bit, the spectra to the last few ulps
+  (same transform, other row pairing)."""
+  rng = np.random.default_rng(8)
+  nlat, nlon, ninit, nlead, nlev = 25, 1440, 3, 2, 3
+  lat, lon = np.linspace(-84, 84, nlat), np.arange(nlon) * 0.25
+  init_times = np.datetime64('2021-06-01T00', 'ns') + np.arange(ninit) * np.timedelta64(24, 'h')
+  lead_time = (np.arange(nlead) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')
+  level = np.array([500, 700, 850])
+  pv = (rng.normal(size=(ninit, nlead, nlev, nlat, nlon)) * 2 + 270).astype(np.float32)
+  tv = (rng.normal(size=(ninit, nlead, nlev, nlat, nlon)) * 2 + 270).astype(np.float32)
+  clim = xr.Dataset({'z': xr.DataArray((rng.normal(size=(8, 2, nlev, nlat, nlon)) * 5 + 270).astype(np.float32),
+                                       dims=('dayofyear', 'hour', 'level', 'latitude', 'longitude'),
+                                       coords={'dayofyear': np.arange(152, 160), 'hour': np.array([0, 12]), 'level': level,
+                                               'latitude': lat, 'longitude': lon})})
+
+  def load(inits, leads):
+    i = [int(np.where(init_times == x)[0][0]) for x in inits]
+    cs = {'init_time': inits, 'lead_time': lead_time, 'level': level, 'latitude': lat, 'longitude': lon}
+    dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+    return {'z': xr.DataArray(pv[i], dims=dims, coords=cs)}, {'z': xr.DataArray(tv[i], dims=dims, coords=cs)}
+  det = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC(clim), 'mae': deterministic.MAE()}
+  spec = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalEnergySpectrum('targets')}
+  spec_same = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalPowerSpectrum('targets')}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+
+  def run(spec_metrics, fuse):
+    monkeypatch.setattr(engine, 'FUSE_DET_SPECTRA', fuse)
+    engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 1
+    try:
+      out = pipeline.evaluate_passes(times, [('det', load, det, area), ('spec', load, spec_metrics, zonal)])
+      kinds = [e['kind'] for e in engine.S1_EVENT_LOG]
+    finally:
+      engine.S1_EVENT_LOG = None
+    return out['det'][None].metric_values(det), out['spec'][None].metric_values(spec_metrics), kinds
+  d1, s1, k1 = run(spec_same, True)
+  d0, s0, k0 = run(spec_same, False)
+  assert k1.count('det_spectrum') == ninit and 'spectrum' not in k1
+  assert 'det_spectrum' not in k0 and k0.count('spectrum') == 2 * ninit
+  for k in d0:
+    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in s0:
+    np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
+  # spectra with different row scales (power vs energy) do not share a (group, scale) table: no fusion, same numbers
+  d2, s2, k2 = run(spec, True)
+  assert 'det_spectrum' not in k2
+  np.testing.assert_array_equal(d2['rmse.z'].values, d0['rmse.z'].values)

@@ -42,6 +42,14 @@ __device__ __forceinline__ T ld_stream(const T* p) {
   return __builtin_nontemporal_load(p);
 }
 
+// A wave-uniform pointer the compiler also KNOWS to be uniform (SGPR pair): row offsets come out of tables through vector
+// loads once an asm statement clobbers memory.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
 // Broadcast of lane j's 64-bit value to the whole wave (result in SGPRs).
 __device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
   const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);

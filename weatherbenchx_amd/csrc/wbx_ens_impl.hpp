@@ -493,14 +493,6 @@ struct EnsMasked {
 // LDS is allocated in 1280-byte granules on gfx950: 50 members x 256 B = 12 800 B = exactly ten, so twelve one-wave blocks
 // (3 per SIMD) fit the 160 KB of a CU; the 51st member and the target ride in two VGPRs loaded one tile ahead.
 // One wave per block; rows (depth) and x tiles of the block's (key, chunk) form one tile sequence.
-// A wave-uniform pointer the compiler also KNOWS to be uniform (SGPR pair): row offsets come out of tables through vector
-// loads once an asm statement clobbers memory.
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-  const uint64_t v = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (const char*)(((uint64_t)hi << 32) | lo);
-}
-
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
 // (A flat flavour of this kernel for latitude-fastest planes with folded weights -- s1_xf1_kernel's geometry, the weight

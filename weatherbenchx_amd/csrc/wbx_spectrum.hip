@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "wbx_common.hpp"
+#include "wbx_s1.hpp"
 
 namespace wbx {
 
@@ -423,6 +424,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
 }
 
 #include "wbx_zspec1440.hpp"
+#include "wbx_zspec_det.hpp"
 
 // Diagnostic instantiations -- WBX_SPECTRUM_KNOCK: kernels whose RESULTS ARE WRONG by design (timing only);
 // WBX_SPECTRUM_PROF=<file>: the phase-stamped kernels, counters appended to a file -- exist only in a library built with
@@ -453,7 +455,6 @@ static void spectrum_diag_ignored() {
   }();
   (void)said;
 }
-static constexpr int spectrum_knock_value = 0;
 static int spectrum_knock() {
   spectrum_diag_ignored();
   return 0;
@@ -797,7 +798,85 @@ static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t 
   return 0;
 }
 
+// ---- spectra of (p, t) + the deterministic lanes of the same rows in one sweep (wbx_zspec_det.hpp) --------------------------
+static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, bool has_c, const void* p, const void* t,
+                           const void* c, const int32_t* group, const double* scale, double* partial_out, double* power_p,
+                           double* power_t) {
+  void*& tab = st->twiddles[-Z14_N];
+  if (!tab) {
+    std::vector<float2> host;
+    zspec1440_tables(host);
+    WBX_HIP(hipMalloc(&tab, host.size() * sizeof(float2)));
+    WBX_HIP(hipMemcpyAsync(tab, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  S1Args a;
+  fill_args(plan, a);
+  a.in[0] = p;
+  a.in[1] = t;
+  a.in[2] = c;
+  a.out = partial_out;
+  const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)ZD_TEAMS * Z14_BUF * sizeof(v4) +
+                     ((has_c && !WBX_ZD_C_IN_REGISTERS) ? (size_t)ZD_TEAMS * 24 * 64 * sizeof(float) : 0);  // + the climatology staging slots
+  const void* fn = has_c ? reinterpret_cast<const void*>(&zspec1440_det_kernel<true>) : reinterpret_cast<const void*>(&zspec1440_det_kernel<false>);
+  int& per_cu = st->occupancy[std::make_pair(fn, lds)];
+  if (per_cu == 0) {
+    if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64 * ZD_TEAMS, lds));
+    if (per_cu <= 0) per_cu = 1;
+  }
+  const int64_t nrows = plan->nkey;
+  int64_t teams = (int64_t)per_cu * ctx->num_cus * ZD_TEAMS;  // one resident set: every team takes the same time
+  int64_t rows_per_team = (nrows + teams - 1) / teams;
+  if (rows_per_team < 1) rows_per_team = 1;
+  const int64_t blocks = (nrows + rows_per_team * ZD_TEAMS - 1) / (rows_per_team * ZD_TEAMS);
+  WBX_REQUIRE(blocks < (int64_t)1 << 31 && rows_per_team < (int64_t)1 << 31, "launch too large");
+  if (has_c)
+    hipLaunchKernelGGL((zspec1440_det_kernel<true>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_p, power_t);
+  else
+    hipLaunchKernelGGL((zspec1440_det_kernel<false>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_p, power_t);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace wbx
+
+extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                                const void* c, const int32_t* group, const double* scale, int64_t ngroup, double* partial_out,
+                                double* power_p, double* power_t) {
+  using namespace wbx;
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (int rc = check_plan(plan)) return rc;
+  WBX_REQUIRE(func == WBX_DET3 || func == WBX_DET6, "wbx_det_spectrum takes WBX_DET3 or WBX_DET6 (got %d)", func);
+  WBX_REQUIRE(dtype == WBX_F32, "wbx_det_spectrum takes float32 fields");
+  WBX_REQUIRE(plan->nx == Z14_N && !plan->x_kept && plan->ndepth == 1 && plan->nchunk == 1,
+              "wbx_det_spectrum needs rows of %d points summed along x, one depth row and one chunk per key", Z14_N);
+  WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) && plan->x_weights == nullptr, "no masks / folded weights here");
+  const int nin = func == WBX_DET6 ? 3 : 2;
+  for (int i = 0; i < nin; ++i) {
+    WBX_REQUIRE(plan->xstride[i] == 1, "input %d is not contiguous along x", i);
+  }
+  WBX_REQUIRE(ngroup >= 1, "ngroup must be >= 1");
+  if (plan->nkey == 0) return 0;
+  WBX_REQUIRE(p && t && (func == WBX_DET3 || c) && group && scale && partial_out && power_p && power_t, "NULL pointer");
+  WBX_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(c)) % 8 == 0,
+              "fields must be 8-byte aligned (row offsets must be even: the caller's plan)");
+  WBX_HIP(hipSetDevice(ctx->device));
+  auto* st = reinterpret_cast<FftState*>(ctx->fft_state);
+  if (!st) {
+    st = new FftState();
+    ctx->fft_state = st;
+    WBX_FFT(rocfft_setup());  // (the state is shared with wbx_zonal_spectrum, which may take the rocFFT route later)
+    st->setup = true;
+  }
+  constexpr int nk = Z14_N2 + 1;
+  WBX_HIP(hipMemsetAsync(power_p, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+  WBX_HIP(hipMemsetAsync(power_t, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+  return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, partial_out, power_p, power_t);
+}
+
 
 static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride, int64_t rps,
                                int64_t nslab, const int64_t* h_slab_offsets, int32_t nlon, const int32_t* group,

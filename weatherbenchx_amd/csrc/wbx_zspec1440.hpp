@@ -106,10 +106,13 @@ __device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const do
 // values are passed on), 8 = no unpack arithmetic.
 // (`buf` must NOT be __restrict__: c.rd5 / c.wr5 point into it -- with the qualifier the compiler moved pass-2 loads above
 // the pass-1 stores.)
-template <int KNOCK, typename At>
+// PT (wbx_zspec_det.hpp): rows A and B are the predictions' and the targets' row of ONE location; B's sums go to their own
+// accumulators accb / accmb instead of joining A's (no `split` then).
+template <int KNOCK, bool PT = false, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
-                                         double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at) {
+                                         double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at,
+                                         double (&accb)[6], double (&accmb)[6]) {
   constexpr int nk = Z14_N2 + 1;
   constexpr bool DROP = (KNOCK & 2) != 0;
   const int L = c.L;
@@ -175,7 +178,12 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     const C2 x = cadd(e, wo), xm = csub(e, wo);
     const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;      // (row A, row B) of k
     const v2 pm = (KNOCK & 8) ? xm.re : xm.re * xm.re + xm.im * xm.im;  // ... of 720 - k
-    if (split) {
+    if constexpr (PT) {
+      acc[s] = fma((double)p.x, sca, acc[s]);
+      accm[s] = fma((double)pm.x, sca, accm[s]);
+      accb[s] = fma((double)p.y, scb, accb[s]);
+      accmb[s] = fma((double)pm.y, scb, accmb[s]);
+    } else if (split) {
       acc[s] = fma((double)p.x, sca, acc[s]);
       accm[s] = fma((double)pm.x, sca, accm[s]);
       if (c.lane < Z14_LANES) {
@@ -305,7 +313,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads
                                if (i == 0 && r + 2 < r1) fetch(r + 2);
                              }
-                           });
+                           }, acc, accm);
     if constexpr (PROF) {
 #pragma unroll
       for (int i = 1; i < 8; ++i) spent[i] += stamp[i] - stamp[i - 1];
@@ -530,7 +538,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
           } else if constexpr (SPREAD == 2) {
             if (more && (!(i & 1) || i == 5)) load_part(on, rn, i == 5 ? 3 : i / 2);
           }
-        });
+        }, acc, accm);
       }
       mark(5);
       if constexpr (PROF) {

@@ -1,0 +1,190 @@
+// Zonal spectra of predictions AND targets plus the deterministic lanes of the same (p, t[, c]) rows in ONE sweep.
+//
+// configs[3] / configs[4] ask for "spectra of p and t + the full deterministic suite in the same sweep" (SURVEY 8d).  As
+// separate launches the z fields cross the HBM twice: wbx_det_partial reads p, t, c (12 B/point), the two spectrum launches
+// read p and t again (8 B/point).  zspec1440_kernel already transforms TWO rows per wave (every quantity is a (row A, row B)
+// pair of packed fp32): here the pair is (p[row], t[row]) instead of two consecutive rows of one field, so
+//   * the 48 floats a lane holds of the pair in front of pass 1 are exactly the p and t values of its 24 points: with the
+//     climatology row fetched alongside (one more 8-byte load per 2 points) the DET6 lanes e, |e|, e^2, (p-c)^2, (t-c)^2,
+//     (p-c)(t-c) are accumulated there in fp64 -- the same arithmetic as DetOp (wbx_det.hip) -- folded over the wave with DPP
+//     row operations and written as the row's entry of the stage-1 partial buffer (one key = one row: stage 2 is unchanged);
+//   * the spectra of row A go to the predictions' accumulators, those of row B to the targets' (z14_pair<.., PT = true>).
+// Algorithmic bytes: 12 B/point (8 without a climatology) for BOTH families.
+// Registers: +24 (climatology prefetch) +24 (second set of spectrum sums) +12 (deterministic sums) on a kernel that sat at
+// 168: eight one-wave teams per block = two waves per SIMD and up to 256 VGPRs (the spectrum kernel's throughput is flat
+// from 8 to 12 teams per CU: 0.311 vs 0.291 ms per field).  What it took to fit (round 3, configs[4] chunk
+// = 533 540 rows, `tools/kbench_det_spectrum.py`; the three separate launches: 2.59 ms):
+//   * first version: 287 VGPRs needed, 31 spilled -- among them ten of the 24 PREFETCH loads, each stored to scratch behind a
+//     full `s_waitcnt vmcnt(0)`: 3.75 ms.  The six deterministic sums are serial fma chains over a lane's 24 points, so the
+//     compiler widened all 72 inputs and formed all 48 anomalies up front (~100 fp64 temporaries) to feed the chains;
+//     scheduling barriers do not help (the hoisting happens on the IR).  An opaque asm redefinition of a point pair's inputs
+//     AND of the running sums makes pair i start when pair i - 1 is done: 214 VGPRs, no scratch, 1.87 ms = 4.95 TB/s = 62 % of
+//     the HBM peak on 12 B/point.
+//   * the climatology row staged through the LDS instead of 24 registers (24 `global_load_lds_dword` per row into a 6 KB slot
+//     per team, read back with ds_read2st64_b32; WBX_ZD_C_IN_REGISTERS = 0): 192 VGPRs, 1.98 ms -- twice the vector-memory
+//     instructions for the same bytes; kept as the A/B build (`make ab-zdlds`).
+//   * without a climatology (DET3): 190 VGPRs, 1.44-1.51 ms (the two spectra alone: 1.22-1.26 ms).
+//
+// Rows = the keys of the deterministic plan (wbx_s1_plan with x = longitude summed, nx = 1440, unit x strides, ndepth = 1,
+// nchunk = 1), addressed through the plan's own offset / gather tables; `group` / `scale` are per key.
+// Included by wbx_spectrum.hip (inside namespace wbx, after wbx_zspec1440.hpp).
+#pragma once
+
+constexpr int ZD_TEAMS = 8;
+#ifndef WBX_ZD_C_IN_REGISTERS
+#define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
+#endif
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
+template <bool HAS_C>
+__global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, int64_t nrows, int rows_per_team,
+                                                                      const float2* __restrict__ tables_g,
+                                                                      const int32_t* __restrict__ group,
+                                                                      const double* __restrict__ scale,
+                                                                      double* __restrict__ power_p, double* __restrict__ power_t) {
+  constexpr int NA = HAS_C ? 6 : 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
+  float2* const tw2 = tw1 + Z14_TW1;
+  float2* const twr = tw2 + Z14_TW2;
+  const int lane = (int)(threadIdx.x & 63);
+  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nteam = (int)(blockDim.x >> 6);
+  v4* const buf = reinterpret_cast<v4*>(twr + Z14_TWR) + team * Z14_BUF;
+  // the climatology staging slots behind the teams' transform buffers: [team][24 dwords of a lane][64 lanes]
+  float* const cbuf = reinterpret_cast<float*>(reinterpret_cast<v4*>(twr + Z14_TWR) + nteam * Z14_BUF) + team * (24 * 64);
+  const uint32_t cbuf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)cbuf;
+  for (int i = threadIdx.x; i < Z14_TABLES; i += blockDim.x) tw1[i] = tables_g[i];
+  __syncthreads();
+  const int64_t r0 = ((int64_t)blockIdx.x * nteam + team) * rows_per_team;
+  const int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
+  if (r0 >= r1) return;  // only wave-level ordering below
+  constexpr int nk = Z14_N2 + 1;
+  const Z14Lane c = z14_lane(lane, buf, tw2);
+  const int L = c.L;
+  const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
+
+  double accp[6], accmp[6], acct[6], accmt[6];  // sums of k = L + 60 s and of 720 - k, predictions / targets
+#pragma unroll
+  for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
+  int32_t cur = group[r0];
+  auto flush = [&](int32_t next) {
+    z14_send<true>(power_p + (int64_t)cur * nk, c, accp, accmp);
+    z14_send<true>(power_t + (int64_t)cur * nk, c, acct, accmt);
+#pragma unroll
+    for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
+    cur = next;
+  };
+
+  v2 pa[12], pb[12];  // the row's p and t values of this lane's 12 packed points, fetched one row ahead (c: through cbuf)
+  v2 pc[WBX_ZD_C_IN_REGISTERS ? 12 : 1];
+  const uint32_t voff_c = (uint32_t)L * 8u;  // this lane's first packed point, bytes into the row
+  // A row's three base pointers come out of the plan's offset / gather tables.  They are resolved one row ahead at the TOP of a
+  // row -- where few registers are live -- and parked in SGPR pairs: the asm statements below clobber memory, so the table
+  // lookups are vector loads, and resolving them inside fetch() (in the middle of the transform, at the register peak) made the
+  // allocator spill ten of the 24 prefetch loads right behind a full vmcnt(0) wait each.
+  auto resolve = [&](int64_t r, const char*& up, const char*& ut, const char*& uc) {
+    int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
+    key_bases<HAS_C ? 3 : 2>(a, r, kb);
+    row_bases<HAS_C ? 3 : 2>(a, kb, r, 0, ro);
+    up = uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[0]) + ro[0]));
+    ut = uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[1]) + ro[1]));
+    uc = HAS_C ? uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[2]) + ro[2])) : nullptr;
+  };
+  // The next row's loads are spread over the transform so that they never sit on top of its register peak (pass 2 holds 60
+  // registers of butterflies): p and the climatology's LDS-DMA (no registers) behind pass 1's stores, t behind pass 2's.
+  auto fetch_p = [&](const char* up, const char* uc) {
+    const v2* rowp = reinterpret_cast<const v2*>(up) + L;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pa[i] = __builtin_nontemporal_load(rowp + 60 * i);
+    if constexpr (HAS_C && WBX_ZD_C_IN_REGISTERS) {
+      const v2* rowc = reinterpret_cast<const v2*>(uc) + L;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pc[i] = __builtin_nontemporal_load(rowc + 60 * i);
+    } else if constexpr (HAS_C) {
+      const char* um = uc;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // dword (2 i + h) of the lane: point 60 i + L, component h
+          asm volatile("s_add_u32 m0, %2, %3\n\tglobal_load_lds_dword %0, %1 nt" ::"v"(voff_c), "s"(um), "s"(cbuf_lds), "i"((2 * i + h) * 256)
+                       : "memory", "scc", "m0");
+          um += h == 0 ? 4 : 476;  // -> the next dword of the pair, then 60 packed points on
+          asm volatile("" : "+s"(um));
+        }
+      }
+    }
+  };
+  auto fetch_t = [&](const char* ut) {
+    const v2* rowt = reinterpret_cast<const v2*>(ut) + L;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pb[i] = __builtin_nontemporal_load(rowt + 60 * i);
+  };
+  const char *np = nullptr, *nt = nullptr, *nc = nullptr;
+  resolve(r0, np, nt, nc);
+  fetch_p(np, nc);
+  fetch_t(nt);
+  int turn = team >> 2;  // waves t and t + 4 of a block share a SIMD: the user priority alternates row by row (see zspec1440_kernel)
+  for (int64_t r = r0; r < r1; ++r) {
+    turn ^= 1;
+    if (turn == 0) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(1);
+    const int32_t g = group[r];
+    const double sc = scale[r] * quarter_inv_nn;
+    if (r + 1 < r1) resolve(r + 1, np, nt, nc);
+    if constexpr (HAS_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's LDS-DMA has landed in cbuf
+    // ---- the deterministic lanes of this row, on the raw values (lanes 60..63 shadow lane 59: counted out)
+    __builtin_amdgcn_sched_barrier(0);
+    double d[NA];
+#pragma unroll
+    for (int l = 0; l < NA; ++l) d[l] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      // The six sums are serial fma chains over the lane's 24 points, so the compiler widens all 72 inputs and forms all 48
+      // anomalies up front to have independent work for the chains' latency: ~100 fp64 temporaries (v160..v253 in the ISA), 287
+      // VGPRs, the prefetch loads spilled behind vmcnt(0) waits.  An opaque redefinition of the point pair's inputs AND of the
+      // running sums right where they are used makes point pair i start when pair i - 1 is done; the other wave of the SIMD
+      // covers the chains' latency.
+      if constexpr (HAS_C && WBX_ZD_C_IN_REGISTERS)
+        asm volatile("" : "+v"(pa[i]), "+v"(pb[i]), "+v"(pc[i]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+      else if constexpr (HAS_C)
+        asm volatile("" : "+v"(pa[i]), "+v"(pb[i]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+      else
+        asm volatile("" : "+v"(pa[i]), "+v"(pb[i]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double p = (double)(h ? pa[i].y : pa[i].x), t = (double)(h ? pb[i].y : pb[i].x);
+        const double e = p - t;
+        d[0] += e;
+        d[1] += fabs(e);
+        d[2] = fma(e, e, d[2]);
+        if constexpr (HAS_C) {
+          const double cv = WBX_ZD_C_IN_REGISTERS ? (double)(h ? pc[i].y : pc[i].x) : (double)cbuf[(2 * i + h) * 64 + lane];
+          const double ap = p - cv, at = t - cv;
+          d[3] = fma(ap, ap, d[3]);
+          d[4] = fma(at, at, d[4]);
+          d[5] = fma(ap, at, d[5]);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < NA; ++l) {
+      const double tot = wave_sum_uniform(lane < Z14_LANES ? d[l] : 0.0);
+      if (lane == 0) a.out[r * NA + l] = tot;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the row's deterministic sums are done before the transform starts: their temporaries die here
+    C2 v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = {{pa[i].x, pb[i].x}, {pa[i].y, pb[i].y}};
+    if (g != cur) flush(g);  // wave-uniform
+    z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
+      if (r + 1 < r1) {
+        if (i == 0) fetch_p(np, nc);
+        if (i == 2) fetch_t(nt);
+      }
+    }, acct, accmt);
+  }
+  flush(cur);
+}
+#pragma clang diagnostic pop

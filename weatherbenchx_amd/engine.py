@@ -428,10 +428,98 @@ def clear_caches():
   _thr_cache.clear()
 
 
+# Spectra of p and t in the sweep of the deterministic launch (wbx_det_spectrum, csrc/wbx_zspec_det.hpp): the chunk loop
+# registers a request per deterministic (p, t) pair whose zonal spectra are about to be aggregated too (pipeline._plan_fusion);
+# the stage-1 launch of that pair then computes both spectra alongside its own lanes and leaves them with the source arrays,
+# where spectra._run_spectrum finds them instead of launching.  Nothing is registered -> nothing changes.
+_fusion_requests: dict = {}   # id(predictions DataArray) -> {'p', 't', 'entry', 'ngroup'}
+FUSE_DET_SPECTRA = os.environ.get('WBX_FUSE_DET_SPECTRA', '1') != '0'
+
+
+def request_det_spectra(p_da, t_da, entry, ngroup: int):
+  """`entry`: spectra.LazySpectrum.rows_entry(...) of BOTH fields' spectra (group / scale per row of the fields' row dims)."""
+  if FUSE_DET_SPECTRA:
+    _fusion_requests[id(p_da)] = {'p': p_da, 't': t_da, 'entry': entry, 'ngroup': int(ngroup)}
+
+
+def clear_det_spectra_requests():
+  _fusion_requests.clear()
+
+
+def _fused_rows(plan: planner.S1Plan, entry):
+  """Key k of the deterministic plan = which row of the spectra's row numbering (C order over entry['row_dims'])?  None when the
+  plan's rows are not exactly the fields' rows (a reduced dim that is summed inside stage 1 with more than one element, ...)."""
+  row_dims, row_shape = entry['row_dims'], entry['row_shape']
+  key_dims = plan.key_dims
+  if plan.ndepth != 1 or set(key_dims) | set(plan.depth_dims) != set(row_dims):
+    return None
+  idx = np.zeros((), dtype=np.int64)
+  strides = {}
+  mult = 1
+  for d, n in zip(reversed(row_dims), reversed(row_shape)):
+    strides[d] = mult
+    mult *= n
+  for d in key_dims:
+    idx = idx[..., None] + np.arange(plan.sizes[d], dtype=np.int64) * strides[d]
+  return np.ascontiguousarray(np.asarray(idx).reshape(-1))
+
+
+def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
+  """The fused launch when a request for these very inputs is pending and the plan qualifies: -> True (partial written to
+  `out`, both spectra parked with their source arrays), else False (the caller launches wbx_det_partial as usual)."""
+  if not _fusion_requests or inputs is None:
+    return False
+  req = _fusion_requests.get(id(inputs[0]))
+  if req is None or req['p'] is not inputs[0] or req['t'] is not inputs[1]:
+    return False
+  nin = _hip.DET_INPUTS[func]
+  if (func not in (_hip.DET3, _hip.DET6) or dtype_code != _hip.F32 or plan.nx != 1440 or plan.x_kept or plan.ndepth != 1
+      or plan.nchunk != 1 or plan.flags or plan.x_weights is not None or any(plan.xstride[i] != 1 for i in range(nin))
+      or plan.x_dim is None or ctx is not _hip.default_context()):
+    return False
+  entry, ngroup = req['entry'], req['ngroup']
+  fkey = ('fused', tuple(plan.key_dims), tuple(plan.sizes[d] for d in plan.key_dims))
+  bufs = entry['dev'].get(fkey)
+  if bufs is None:
+    rows = _fused_rows(plan, entry)
+    if rows is None or rows.size != plan.nkey:
+      entry['dev'][fkey] = bufs = False
+    else:
+      g = np.ascontiguousarray(np.asarray(entry['group'])[rows], dtype=np.int32)
+      sc = np.ascontiguousarray(np.asarray(entry['scale'])[rows], dtype=np.float64)
+      entry['dev'][fkey] = bufs = (ctx.upload(g), ctx.upload(sc))
+  if bufs is False:
+    return False
+  del _fusion_requests[id(inputs[0])]
+  nk = 721
+  pw_p = _scratch(ctx, 'fused_spectrum_p', max(ngroup * nk, 1) * 8)
+  pw_t = _scratch(ctx, 'fused_spectrum_t', max(ngroup * nk, 1) * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+
+  def call():
+    _hip.check(ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                        ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
+                                        int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)),
+               'wbx_det_spectrum')
+  if S1_EVENT_LOG is not None:
+    reps = max(1, int(S1_EVENT_REPEAT))
+    ctx.timer_start()
+    for _ in range(reps):
+      call()
+    S1_EVENT_LOG.append({'kind': 'det_spectrum', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'rows': int(plan.nkey), 'func': int(func)})
+  else:
+    call()
+  for da, buf in ((req['p'], pw_p), (req['t'], pw_t)):
+    da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'ngroup': ngroup, 'cache': entry['dev']}
+  return True
+
+
 def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Sequence[_Dev | None], dtype_code: int,
-            nlanes_total: int, func: int = 0, ens=None, cat=None) -> _hip.DeviceBuffer:
+            nlanes_total: int, func: int = 0, ens=None, cat=None, inputs=None) -> _hip.DeviceBuffer:
   n = int(np.prod(plan.partial_shape(nlanes_total), dtype=np.int64))
   out = _scratch(ctx, 'partial', n * 8)
+  if kind == 'det' and _fusion_requests and _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
+    return out
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   reps = 1
   if S1_EVENT_LOG is not None:  # bench.py's roofline leg: HIP events on the launch stream
@@ -961,7 +1049,7 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   if _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
     res = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
   else:
-    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args)
+    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args, inputs=inputs)
     res = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
   out = _deliver(ctx, *res)
 

@@ -117,9 +117,64 @@ def _offset_key(offsets, stat_dims, reduce_dims):
   return (offsets.init_time if keep('init_time') else None, offsets.lead_time if keep('lead_time') else None)
 
 
-def _load_stream(work, load_chunk):
-  for offsets, (init_chunk, lead_chunk) in work:
-    yield (offsets, *load_chunk(init_chunk, lead_chunk))
+class _SharedLoads:
+  """Passes that were given the SAME `load_chunk` callable share the loaded chunk: the loader runs once per chunk and every
+  such pass sees the same DataArray objects -- which is also what lets statistics of different passes over the same fields
+  fuse (_plan_fusion).  The streams advance in lockstep, so only the latest chunk of a loader is kept."""
+
+  def __init__(self):
+    self._last = {}
+
+  def stream(self, work, load_chunk):
+    for k, (offsets, (init_chunk, lead_chunk)) in enumerate(work):
+      hit = self._last.get(id(load_chunk))
+      if hit is None or hit[0] != k or hit[1] is not load_chunk:
+        hit = self._last[id(load_chunk)] = (k, load_chunk, load_chunk(init_chunk, lead_chunk))
+      yield (offsets, *hit[2])
+
+
+def _plan_fusion(group_stats):
+  """Look ahead over ALL statistics of a chunk (every pass): a deterministic (p, t[, climatology]) group whose two fields also
+  have their zonal spectra aggregated in this chunk -- the same DataArray objects, i.e. passes that share a loader -- gets a
+  request for the fused launch (engine.request_det_spectra): its stage-1 kernel then produces both spectra in the same sweep
+  (12 B/point for both families instead of 20; csrc/wbx_zspec_det.hpp).  Only the common, simple frame is fused: one
+  aggregator for the two spectra, no bins, weights that do not depend on longitude / wavenumber; the deterministic side decides
+  at launch time whether its plan qualifies.  Everything else runs as separate launches, as before."""
+  from weatherbenchx_amd import lazy  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd import spectra  # pylint: disable=g-import-not-at-top
+  engine.clear_det_spectra_requests()
+  by_source, groups = {}, {}
+  for unique, aggregators in group_stats:
+    for _, stats in unique:
+      for stat in stats.values():
+        if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy:
+          by_source.setdefault(id(stat._source), []).append((stat, aggregators))  # pylint: disable=protected-access
+        elif isinstance(stat, lazy.LazyStatistic) and stat.is_lazy and stat._group.kind == 'det':  # pylint: disable=protected-access
+          groups[id(stat._group)] = stat._group  # pylint: disable=protected-access
+  for grp in groups.values():
+    sp, st = by_source.get(id(grp.p)), by_source.get(id(grp.t))
+    if not sp or not st or len(sp) != 1 or len(st) != 1:
+      continue
+    (spec_p, aggs_p), (spec_t, aggs_t) = sp[0], st[0]
+    if aggs_p is not aggs_t or len(aggs_p) != 1:
+      continue
+    agg = next(iter(aggs_p.values()))
+    entries = []
+    for spec in (spec_p, spec_t):
+      if spec._k_dim in set(agg.reduce_dims) or not set(agg.reduce_dims) <= set(spec.dims):  # pylint: disable=protected-access
+        break
+      wp = agg._cached_weight_product(spec)  # pylint: disable=protected-access
+      if wp is None:
+        break
+      w_da, bin_dims = wp
+      if bin_dims or (w_da is not None and (spec._k_dim in w_da.dims or spec._lon_dim in w_da.dims)):  # pylint: disable=protected-access
+        break
+      row_dims = [d for d in spec.dims if d != spec._k_dim]  # pylint: disable=protected-access
+      kept = [d for d in row_dims if d not in set(agg.reduce_dims)]
+      w = w_da if w_da is not None else xr.DataArray(np.float64(1.0))
+      entries.append(spec.rows_entry(w, kept)[:2])
+    if len(entries) == 2 and entries[0][0] is entries[1][0]:  # one (group, scale) table for both spectra
+      engine.request_det_spectra(grp.p, grp.t, entries[0][0], entries[0][1])
 
 
 def _consume(chunk_streams, passes, acc):
@@ -130,11 +185,14 @@ def _consume(chunk_streams, passes, acc):
   previous = []
   for group in zip(*chunk_streams):
     states = []
-    for (pass_name, metrics, aggregators), (offsets, predictions, targets) in zip(passes, group):
-      # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
-      # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates
-      # them one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
-      unique = list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
+    # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
+    # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates
+    # them one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
+    uniques = [list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
+               for (_, metrics, _), (_, predictions, targets) in zip(passes, group)]
+    if len(passes) > 1:
+      _plan_fusion([(u, aggs) for u, (_, _, aggs) in zip(uniques, passes)])
+    for (pass_name, metrics, aggregators), (offsets, predictions, targets), unique in zip(passes, group, uniques):
       # (the spread lane of an ensemble group decides which kernel variant serves all its lanes: Aggregator.note_statistics)
       aggregation.Aggregator.note_statistics(dict(unique))
       for stat_name, stats in unique:
@@ -151,6 +209,7 @@ def _consume(chunk_streams, passes, acc):
             for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
               acc.capture((pass_name, agg_name, kind, stat_name, str(var_name), key), da)
             states.append(state)
+    engine.clear_det_spectra_requests()
     for state in previous:
       state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
     previous = states
@@ -180,6 +239,7 @@ def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: 
   # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
   # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
   feeders = []
+  shared = _SharedLoads()
   with engine.accumulate_results(acc):
     streams = []
     for _, load_chunk, _, _ in norm:
@@ -188,7 +248,7 @@ def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: 
         feeders.append(feeder)
         streams.append(iter(feeder))
       else:
-        streams.append(_load_stream(work, load_chunk))
+        streams.append(shared.stream(work, load_chunk))
     try:
       _consume(streams, [(n, m, a) for n, _, m, a in norm], acc)
     finally:

@@ -74,6 +74,10 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
   """power[ngroup][nk]; rows = all non-longitude dims in the field's own order.  `cache` (owned by the caller,
   e.g. the aggregator's weight object) keeps the uploaded group/scale arrays between chunks."""
   ctx = _hip.default_context()
+  fused = field.__dict__.pop('_wbx_fused_spectrum', None)
+  if fused is not None and cache is not None and fused['cache'] is cache and fused['ngroup'] == ngroup and fused['ctx'] is ctx:
+    # engine.fuse_det_spectra: the deterministic launch over this very field already produced its spectrum (wbx_det_spectrum)
+    return engine._deliver(ctx, fused['ptr'], (ngroup, field.sizes[lon_dim] // 2 + 1))  # pylint: disable=protected-access
   data = field.data
   engine._sync_torch_producers([data])  # pylint: disable=protected-access
   if engine._common_dtype([data]) != _hip.F32:  # pylint: disable=protected-access
@@ -159,13 +163,14 @@ class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
     lat = self._source[self._lat_dim]
     return lat.copy(data=2 * np.pi * EARTH_RADIUS_M * np.cos(np.deg2rad(np.asarray(lat.values, dtype=np.float64))))
 
-  def reduce_rows(self, row_weight: xr.DataArray, kept_dims) -> np.ndarray:
-    """sum over the non-kept row dims of weight * spectrum -> array over (kept_dims..., k)."""
+  def rows_entry(self, row_weight: xr.DataArray, kept_dims):
+    """-> (entry, ngroup, kept, sizes): the per-row output group and scale of `sum over the non-kept row dims of weight *
+    spectrum` -- data independent, built once per (weight object, frame) and kept with the weight object (`entry['dev']`
+    holds the device copies)."""
     row_dims = [d for d in self._source.dims if d != self._lon_dim]
     sizes = {d: self._source.sizes[d] for d in row_dims}
     kept = [d for d in row_dims if d in kept_dims]
     ngroup = int(np.prod([sizes[d] for d in kept], dtype=np.int64)) if kept else 1
-    # group / scale per row are data independent: built once per (weight object, frame) and kept on the device
     store = row_weight.__dict__.setdefault('_wbx_spectrum', {})
     fkey = (tuple(row_dims), tuple(sizes[d] for d in row_dims), tuple(kept), self._circumference)
     entry = store.get(fkey)
@@ -180,10 +185,16 @@ class LazySpectrum(xr.LazyPickleMixin, xr.DataArray):
         mult *= sizes[d]
       for d in row_dims:
         g = g[..., None] + np.arange(sizes[d], dtype=np.int64) * mults.get(d, 0)
-      entry = {'group': np.broadcast_to(g, shape).reshape(-1), 'scale': scale, 'dev': {}}
+      entry = {'group': np.broadcast_to(g, shape).reshape(-1), 'scale': scale, 'dev': {}, 'row_dims': tuple(row_dims),
+               'row_shape': tuple(shape)}
       if len(store) > 8:
         store.clear()
       store[fkey] = entry
+    return entry, ngroup, kept, sizes
+
+  def reduce_rows(self, row_weight: xr.DataArray, kept_dims) -> np.ndarray:
+    """sum over the non-kept row dims of weight * spectrum -> array over (kept_dims..., k)."""
+    entry, ngroup, kept, sizes = self.rows_entry(row_weight, kept_dims)
     out = _run_spectrum(self._source, self._lon_dim, entry['group'], entry['scale'], ngroup, cache=entry['dev'])
     return out.reshape([sizes[d] for d in kept] + [self._nk]), tuple(kept) + (self._k_dim,)
 
