@@ -558,6 +558,72 @@ def public_chunk_leg(env):
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
 
 
+# ---- configs[3] as BASELINE.json words it: spectra + the full deterministic suite in the same sweep -------------------------
+def configs3_composite(env, nlead, nlev):
+  """z f32[1 init, nlead, nlev, lat, lon] p, t + climatology -> RMSE / MSE / MAE / bias / ACC / activity per (lead, level) AND the
+  zonal spectra of p and t per (lead, level), as two evaluations that share their loader through pipeline.evaluate_passes:
+  on longitude-fastest 1440-point rows ONE kernel (wbx_det_spectrum) reads p, t, c once for both."""
+  from weatherbenchx_amd import aggregation, engine, pipeline, spectra, time_chunks, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import deterministic
+  args = env.args
+  nchunk = max(8, args.steps * 2) if not args.small else 4
+  lead_time = (np.arange(nlead) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  init_times = np.datetime64('2020-01-01T00', 'ns') + np.arange(nchunk) * np.timedelta64(24, 'h')
+  level = np.arange(nlev)
+  zdims = ('init_time', 'lead_time', 'level') + env.sp
+  cdims = ('dayofyear', 'hour', 'level') + env.sp
+  sp_shape = env.sp_shape()
+  pool = [(env.randn((1, nlead, nlev) + sp_shape, 280.0), env.randn((1, nlead, nlev) + sp_shape, 280.0)) for _ in range(2)]
+  ndoy = 8
+  clim = xr.Dataset({'z': xr.DataArray(env.randn((ndoy, 4, nlev) + sp_shape, 280.0, 10.0), dims=cdims, coords={
+      'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), 'level': level, 'latitude': env.lat, 'longitude': env.lon})})
+  env.torch.cuda.synchronize()
+  index_of = {int(t.astype('int64')): i for i, t in enumerate(init_times)}
+  ring = np.datetime64('2020-01-01T00', 'ns') + np.arange(4) * np.timedelta64(24, 'h')
+
+  def load(inits, leads):
+    i = index_of[int(inits[0].astype('int64'))]
+    cs = {'init_time': inits, 'lead_time': lead_time, 'level': level, 'latitude': env.lat, 'longitude': env.lon,
+          'valid_time': (('init_time', 'lead_time'), ring[i % 4] + lead_time[None, :])}
+    return {'z': xr.DataArray(pool[i % 2][0], dims=zdims, coords=cs)}, {'z': xr.DataArray(pool[i % 2][1], dims=zdims, coords=cs)}
+  det = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias(),
+         'acc': deterministic.ACC(clim), 'prediction_activity': deterministic.PredictionActivity(clim)}
+  spec = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  passes = [('deterministic', load, det, area), ('spectra', load, spec, zonal)]
+
+  def run(times):
+    st = pipeline.evaluate_passes(times, passes)
+    return st['deterministic'][None].metric_values(det), st['spectra'][None].metric_values(spec)
+  run(time_chunks.TimeChunks(init_times[:3], lead_time, init_time_chunk_size=1))
+  env.sync()
+  t0 = time.perf_counter()
+  dvals, svals = run(time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1))
+  env.sync()
+  ms = (time.perf_counter() - t0) / nchunk * 1e3
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
+  run(time_chunks.TimeChunks(init_times[:2], lead_time, init_time_chunk_size=1))
+  log = list(engine.S1_EVENT_LOG)
+  engine.S1_EVENT_LOG = None
+  points = nlead * nlev * env.nlat * env.nlon
+  fused = [e for e in log if e['kind'] == 'det_spectrum']
+  out = {'workload': f'configs[3]: z f32[1,{nlead},{nlev},{env.nlat},{env.nlon}] p, t + climatology per chunk -> rmse/mse/mae/bias/acc/'
+                     f'activity AND zonal power spectra of p and t per (lead, level), {env.layout}; two evaluations sharing a loader '
+                     '(pipeline.evaluate_passes)',
+         'chunks': nchunk, 'ms_per_chunk': ms, 'value': points * (len(det) + len(spec)) / (ms * 1e-3), 'unit': 'evals/s',
+         'algorithmic_bytes_per_point': 12, 'frac_of_hbm_peak': round(points * 12 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+         'launches_per_chunk': {k: sum(1 for e in log if e['kind'] == k) // 2 for k in sorted({e['kind'] for e in log})},
+         'check': {'rmse_mean': float(np.asarray(dvals['rmse.z'].values).mean()),
+                   'sum_k_S_k': float(np.asarray(svals['spectrum_p.z'].values)[0, 0].sum()), 'expected': 280.0 ** 2 + 1.0}}
+  if fused:
+    out['roofline'] = kernel_roofline('zspec1440_det_kernel<true> (spectra of p and t + DET6 lanes, one sweep; + 2 x 5 us memsets)',
+                                      float(np.median([e['ms'] for e in fused])), points * 12)
+  del pool
+  return out
+
+
 # ---- zonal spectra ----------------------------------------------------------------------------------------------------
 def spectrum_leg(env):
   from weatherbenchx_amd import aggregation, engine, spectra, weighting
@@ -600,7 +666,9 @@ def spectrum_leg(env):
              'zspec1440_latfast_kernel (24 adjacent rows per block step, staged through the LDS)')
   else:
     kname = 'zspec_fused_kernel'
-  return {'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{env.nlat},{env.nlon}] each, area-weighted '
+  both = configs3_composite(env, nt_s, nlev_s)
+  return {'with_deterministic_suite': both,
+          'workload': f'configs[3]: zonal power spectra of p and t, f32[{nt_s},{nlev_s},{env.nlat},{env.nlon}] each, area-weighted '
                       f'mean over (lead_time, latitude), {env.layout}; fused in-LDS FFT + fp64 |F|^2 reduction (one pass over '
                       'the field); parity unpinned (no reference implementation, SURVEY F3)',
           'value': spoints * 2 / (s_ms * 1e-3), 'unit': 'field-points/s', 'ms_per_step': s_ms, 'steps': nsteps,
