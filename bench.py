@@ -287,7 +287,7 @@ def main_leg(env):
   ms_list = sorted(e['ms'] for e in log)
   k_ms = float(np.median(ms_list))
   kname = ens_kernel_name(log[0], m)
-  roofline = kernel_roofline(kname, k_ms, points * (m + 1) * 4, pmc_traffic('ens_pipe_kernel', nlev == 37 and not args.small, env.layout))
+  roofline = kernel_roofline(kname, k_ms, points * (m + 1) * 4, pmc_traffic(kname.split('<')[0], nlev == 37 and not args.small, f'main@{env.layout}'))
   roofline['kernel_ms_min_max'] = [round(ms_list[0], 4), round(ms_list[-1], 4)]
   roofline['launches_per_step'] = len(log) // 4
   roofline['bytes_per_point'] = (m + 1) * 4
@@ -389,7 +389,7 @@ def configs1_leg(env):
   else:
     kname = f"s1_xr_kernel<DetOp<float,DET6>,{log[0]['vec']}>"
   full = (not args.small) and (ni, nl, nlev) == (40, 10, 5)
-  roofline = kernel_roofline(kname, k_ms, points * 12, pmc_traffic(kname, full))
+  roofline = kernel_roofline(kname, k_ms, points * 12, pmc_traffic(kname, full, f'configs1@{env.layout}'))
   roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 
   result = {
@@ -484,7 +484,7 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   kname = ens_kernel_name(elog[0], m)
   out = {'workload': describe, 'value': epoints * nvar * len(emetrics) / (e_ms * 1e-3), 'unit': 'evals/s', 'ms_per_step': e_ms,
          'metrics': list(emetrics),
-         'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4, pmc_traffic('ens_pipe_kernel', nlead == 8 and not args.small, 'configs2')),
+         'roofline': kernel_roofline(kname, ek_ms, epoints * (m + 1) * 4, pmc_traffic(kname.split('<')[0], nlead == 8 and not args.small, f'ensemble@{env.layout}')),
          'default_crps_ensemble': {'what': 'CRPSEnsemble() with the reference defaults (use_sort=False) on one variable through the API',
                                    'ensemble_launches_per_variable': len(dlog) // 2,
                                    'kernel_ms_per_variable': round(float(np.sum([e['ms'] for e in dlog]) / 2), 4),
@@ -553,7 +553,7 @@ def public_chunk_leg(env):
           'roofline': dict(kernel_roofline('wbx_det_binned (memset + det_atoms_kernel + slot kernel for overflow patches + finish)',
                                            k_ms, ppoints * 12,
                                            pmc_traffic(f"det_atoms_kernel<float,DET6,MM=0,PD=4,WM={2 if env.layout == 'lon_fastest' else 1}>",
-                                                       not args.small)),
+                                                       not args.small, f'public_chunk@{env.layout}')),
                            traffic_note='PMC pass of the main kernel only (bench.py public_chunk leg / tools/kbench_binned.py)'),
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
 
@@ -619,7 +619,8 @@ def configs3_composite(env, nlead, nlev):
                    'sum_k_S_k': float(np.asarray(svals['spectrum_p.z'].values)[0, 0].sum()), 'expected': 280.0 ** 2 + 1.0}}
   if fused:
     out['roofline'] = kernel_roofline('zspec1440_det_kernel<true> (spectra of p and t + DET6 lanes, one sweep; + 2 x 5 us memsets)',
-                                      float(np.median([e['ms'] for e in fused])), points * 12)
+                                      float(np.median([e['ms'] for e in fused])), points * 12,
+                                      pmc_traffic('zspec1440_det_kernel', not args.small, f'spectrum@{env.layout}'))
   del pool
   return out
 
@@ -675,7 +676,7 @@ def spectrum_leg(env):
           'algorithmic_GBps': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9, 1),
           'frac_of_hbm_peak': round(spoints * 2 * 4 / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
           'roofline': kernel_roofline(kname + ' (+ 6 us memset of the output), one field', sk_ms, spoints * 4,
-                                      pmc_traffic(kname, not args.small)),
+                                      pmc_traffic(kname, not args.small, f'spectrum@{env.layout}')),
           'check': {'sum_k_S_k': parseval, 'expected': 280.0 ** 2 + 1.0}}
 
 

@@ -281,6 +281,8 @@ int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, 
 #define WBX_BINNED_W_ON_X 1
 #define WBX_BINNED_WT_X_ONLY 2
 #define WBX_BINNED_WT_ROW_ONLY 4
+#define WBX_BINNED_MASK_ON_W 8 /* the validity mask (WBX_FLAG_MASKED) depends on the Bk / Br / x dims only (a (latitude, longitude)
+                                  mask under Regions bins): its byte is folded into the atom-id byte, one load less per point */
 /* `atoms`: NULL, or the tables wbx_binned_atoms wrote for exactly this geometry (plan extents, nA, nBk, nBr, w_on_x) and
  * these `bits`.  The kernel works on a patch's "atoms" (= its distinct membership words: regions are boxes, so a patch
  * of 64 x ~150 rows sees a handful) and needs every point's atom index; the tables depend on the bins and the geometry

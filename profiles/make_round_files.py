@@ -26,12 +26,12 @@ for line in text.split('\n'):
   if line.startswith('== '):
     run = line[3:].split('/')[0]
     continue
-  m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', line)
+  m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', line)
   if m and run and run.startswith('trace_'):
     rows.append([run] + list(m.groups()))
 with open(out('kernel_stats.csv'), 'w', newline='') as f:
   w = csv.writer(f)
-  w.writerow(['run', 'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct'])
+  w.writerow(['run', 'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'median_us'])
   w.writerows(rows)
 
 
@@ -41,6 +41,12 @@ def bench_key(name: str) -> str:
     base, suffix = name.rsplit('@', 1)
     return bench_key(base) + '@' + suffix
   n = name.replace('wbx::', '')
+  if n.startswith('ens_pipe_kernel<51'):
+    return 'ens_pipe_kernel'
+  if n.startswith('s1_xf1_kernel<EnsOpF32<51'):
+    return 's1_xf1_kernel'
+  if n.startswith('zspec1440_det_kernel'):
+    return 'zspec1440_det_kernel'
   n = re.sub(r'DetOp<float, 1, \d>', 'DetOp<float,DET6>', n)
   n = re.sub(r'EnsOpF32<51, true, 0>', 'EnsOpF32<51,true,SORT>', n)
   m = re.match(r's1_xr_kernel<(.*?), (\d), (?:false|true)>', n)

@@ -8,6 +8,6 @@ python - <<'PY'
 import sqlite3, glob
 for db in sorted(glob.glob('gpurun_out/pmc_ens/*/r_results.db')):
     con = sqlite3.connect(db); c = con.cursor()
-    rows = c.execute("select substr(kernel_name,1,60), counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%EnsOpF32<51%' and workgroup_size=64 group by 1,2").fetchall()
+    rows = c.execute("select substr(kernel_name,1,60), counter_name, count(*), avg(value), avg(duration) from counters_collection where (kernel_name like '%ens_pipe_kernel<51%' or kernel_name like '%EnsOpF32<51%') and workgroup_size=64 group by 1,2").fetchall()
     for r in rows: print(db.split('/')[-2], r)
 PY

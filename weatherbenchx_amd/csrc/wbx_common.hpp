@@ -20,6 +20,8 @@ struct wbx_ctx {
   void* fft_state = nullptr;
   void* s2_scratch = nullptr;  // split partials of wbx_contract_bits
   size_t s2_scratch_size = 0;
+  void* aidm_scratch = nullptr;  // wbx_det_binned: atom ids with the validity mask folded in (one byte per point)
+  size_t aidm_scratch_size = 0;
 };
 
 namespace wbx {

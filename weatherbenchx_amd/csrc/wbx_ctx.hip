@@ -65,6 +65,7 @@ extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   wbx::spectrum_release(ctx);
   if (ctx->s2_scratch) (void)hipFree(ctx->s2_scratch);
+  if (ctx->aidm_scratch) (void)hipFree(ctx->aidm_scratch);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

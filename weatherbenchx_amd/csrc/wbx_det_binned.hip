@@ -242,7 +242,11 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
 // NT: the operands are fetched with the non-temporal hint (see ld_stream).  Off for rows that are not a whole number of
 // 128-byte lines (721 floats): neighbouring x tiles share their boundary lines, and a streamed line is gone from L2 before
 // the neighbour asks for it -- measured on the latitude-fastest public chunk: 1.53x -> 1.08x the algorithmic bytes, 8 % faster.
-template <typename T, int FUNC, int MM, int PD, int WM, bool NT>
+// MERGED (MM == 1 with a mask that depends on the W dims only -- a (latitude, longitude) validity mask like the atom ids
+// themselves): the mask byte and the atom-id byte of a point are ONE byte, 255 = masked out (aid_merge_kernel, a 1 MB
+// pre-pass per launch).  The kernel is bound by the texture addresser -- a wave64 load costs it 16 cycles whatever its width,
+// and a row was five of them (p, t, c, mask, atom id): four now.
+template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = false>
 __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
@@ -314,7 +318,7 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
 
   // One row of the patch: hit / miss bookkeeping of the lane's two accumulator sets, then 2 x NA FMAs.
   auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
-    const bool ok = live && tv != 0;
+    const bool ok = MERGED ? (live && id != NONE) : (live && tv != 0);
     bool hit0 = id == c0, hit1 = id == c1;
     const bool miss = ok && !hit0 && !hit1;
     if (__builtin_amdgcn_ballot_w64(miss)) {  // wave-uniform: a lane meets an atom it is not accumulating
@@ -430,9 +434,9 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (NIN > 1) rt[u] = operand(1, j);
         if constexpr (NIN > 2) rc[u] = operand(2, j);
         rv[u] = 1;
-        if constexpr (has_mask) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
+        if constexpr (has_mask && !MERGED) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
         const int64_t wi = row_of(WBX_MAX_INPUTS, j);
-        rid[u] = (g.aid + wi)[xw];
+        rid[u] = ((MERGED ? g.aidm : g.aid) + wi)[xw];
         if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
         if constexpr (WM == 1) rw[u] = w_lane;
         if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
@@ -483,6 +487,20 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   }
 }
 
+// aidm[bk][br][x] = mask(bk, br, x) ? aid[bk][br][x] : 255, for a mask that does not depend on A or the depth dims (the caller
+// says so: WBX_BINNED_MASK_ON_W): addressed through the plan's tables at A = 0, depth row 0.
+static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedArgs g, uint8_t* __restrict__ aidm) {
+  const int64_t row = blockIdx.x;  // (bk, br)
+  const int64_t bk = row / g.nBr, br = row - bk * g.nBr;
+  const int64_t key = bk * g.nBr + br;  // A = 0
+  const int64_t base = (a.key_off[3] ? a.key_off[3][key] : 0) + (a.depth_off[3] ? a.depth_off[3][0] : 0);
+  const uint8_t* m = reinterpret_cast<const uint8_t*>(a.in[3]) + base;
+  for (int64_t x = threadIdx.x; x < g.nj; x += blockDim.x) {
+    const int64_t i = row * g.nj + x;
+    aidm[i] = m[x * a.xstride[3]] != 0 ? g.aid[i] : (uint8_t)255;
+  }
+}
+
 // WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_NT=0/1 pins the non-temporal hint
 static int atoms_setting(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -491,10 +509,12 @@ static int atoms_setting(const char* name, int dflt) {
 
 template <typename T, int FUNC, int MM, int K, int PD>
 static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
-                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared,
+                         bool mask_on_w) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   static const int use_atoms = atoms_setting("WBX_BINNED_ATOMS", 1);
+  static const int use_merged = atoms_setting("WBX_BINNED_MERGED_MASK", 1);  // A/B timing
   // the atom kernel addresses a row as (uniform base) + (32-bit lane offset)
   bool atoms = use_atoms != 0;
   for (int i = 0; i < WBX_MAX_INPUTS; ++i)
@@ -510,9 +530,38 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     const bool nt = nt_env >= 0 ? nt_env != 0 : !ragged_lines;
     BinnedArgs ga = g;
     ga.order = order_env >= 0 ? order_env : (ragged_lines ? 1 : 0);
+    bool merged = false;
+    if constexpr (MM == 1) {
+      if (mask_on_w && use_merged != 0 && nj == plan->nx && nj > 1) {  // the mask lives on the atom ids' own index space
+        const size_t need = (size_t)(nBk * nBr * nj);
+        if (ctx->aidm_scratch_size < need) {
+          if (ctx->aidm_scratch) {
+            WBX_HIP(hipStreamSynchronize(ctx->stream));
+            WBX_HIP(hipFree(ctx->aidm_scratch));
+            ctx->aidm_scratch = nullptr;
+            ctx->aidm_scratch_size = 0;
+          }
+          WBX_HIP(hipMalloc(&ctx->aidm_scratch, need));
+          ctx->aidm_scratch_size = need;
+        }
+        hipLaunchKernelGGL(aid_merge_kernel, dim3((unsigned)(nBk * nBr)), dim3(256), 0, ctx->stream, a, ga,
+                           reinterpret_cast<uint8_t*>(ctx->aidm_scratch));
+        WBX_HIP(hipGetLastError());
+        ga.aidm = reinterpret_cast<const uint8_t*>(ctx->aidm_scratch);
+        merged = true;
+      }
+    }
 #define g ga
-#define WBX_ATOMS_LAUNCH_NT(PDV, WMV, NTV) \
-    hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g)
+#define WBX_ATOMS_LAUNCH_NT(PDV, WMV, NTV)                                                                                                   \
+    do {                                                                                                                                       \
+      if constexpr (MM == 1) {                                                                                                                 \
+        if (merged) {                                                                                                                          \
+          hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV, true>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g);   \
+          break;                                                                                                                               \
+        }                                                                                                                                      \
+      }                                                                                                                                        \
+      hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g);             \
+    } while (0)
 #define WBX_ATOMS_LAUNCH(PDV, WMV)                                  \
     do {                                                              \
       if (nt) WBX_ATOMS_LAUNCH_NT(PDV, WMV, true);                    \
@@ -540,36 +589,37 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
 
 template <typename T, int FUNC, int MM>
 static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
-                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   // Slots: 2 * NA * K accumulator VGPRs + ~70 working registers must stay <= 168 for 3 waves / SIMD.  Measured on the
   // public-benchmark chunk (DET6, 34 bins): K = 6 / 8 / 12 -> 0.92 / 0.85 / 0.95 ms; 2 rows of p, t, c in flight are
   // enough (4: 1.01 ms, the extra registers cost a wave).
   constexpr int K = NA <= 1 ? 32 : (NA <= 2 ? 24 : (NA <= 3 ? 16 : (NA <= 4 ? 12 : (NA <= 6 ? 8 : (NA <= 7 ? 6 : 3)))));
-  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
 }
 
 template <typename T, int FUNC>
 static int binned_mm(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits, int64_t nA,
-                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
+                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w) {
   if ((plan->flags & WBX_FLAG_SKIPNA) && (plan->flags & WBX_FLAG_MASKED))
-    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
-  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
-  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
-  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
 }
 
 template <typename T>
 static int binned_func(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, S1Args& a, const double* wt,
-                       const uint64_t* bits, int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared) {
+                       const uint64_t* bits, int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared,
+                       bool mask_on_w) {
   switch (func) {
     case WBX_DET3:
-      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
     case WBX_DET6:
-      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
     case WBX_PASS1:
-      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
   }
   return fail(WBX_ERR_INVALID, "unknown deterministic family %d", func);
 }
@@ -631,10 +681,11 @@ extern "C" int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, i
   a.in[1] = t;
   a.in[2] = c;
   a.in[3] = mask;
-  WBX_REQUIRE((w_on_x & ~7) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
+  WBX_REQUIRE((w_on_x & ~15) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
+  const bool mask_on_w = (w_on_x & WBX_BINNED_MASK_ON_W) != 0 && (plan->flags & WBX_FLAG_MASKED);
   const int64_t nj = (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1;
   const int wmode = (w_on_x & WBX_BINNED_WT_X_ONLY) ? 1 : ((w_on_x & WBX_BINNED_WT_ROW_ONLY) ? 2 : 0);
-  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
-  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared);
+  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
   return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
 }

@@ -22,6 +22,7 @@ struct BinnedArgs {
   unsigned long long* uni;           // [nBk][patch]: union of the patch's membership words
   // "atoms" of a patch = its distinct membership words (regions are boxes: a patch of 64 x ~150 rows sees a handful)
   uint8_t* aid;                      // [nBk][nBr][nj]: index of the point's word in its patch's list
+  const uint8_t* aidm;               // the same with masked-out points set to 255 (det_atoms_kernel<.., MERGED>), or NULL
   unsigned long long* words;         // [nBk][patch][ATOM_MAX]
   int32_t* nwords;                   // [nBk][patch]: entries in the list, -1 = more than ATOM_MAX (slot kernel takes it)
   int32_t atoms;                     // 0: every patch goes to the slot kernel (A/B timing: WBX_BINNED_ATOMS=0)
@@ -236,6 +237,7 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
   g.nbin = nbin;
+  g.aidm = nullptr;
   patch_geometry(g, cells, nBk, nBr, nj, D, nx);
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
