@@ -56,6 +56,7 @@ def parse():
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--main-streams', type=int, default=1, choices=(1, 2), help='HIP streams the steps of the main line are dealt to')
   ap.add_argument('--prewarm-ms', type=float, default=150.0,
                   help='untimed steps of the main loop before the W warm-up steps, until the device has been under load this long')
   ap.add_argument('--inits', type=int, default=40)
@@ -206,7 +207,22 @@ def ens_kernel_name(e, m=51):
 
 
 def main_leg(env):
-  """ONE f32[1 init, 37 level, 51 member, lat, lon] forecast per rank against f32[1, 37, lat, lon] targets."""
+  """ONE f32[1 init, 37 level, 51 member, lat, lon] forecast per rank against f32[1, 37, lat, lon] targets.
+
+  One launch per step, every step on the SAME stream (`--main-streams 1`): a step's kernel then runs alone on the chip, so
+  the duration between its two timing marks is the launch's own and is what rocprofv3 reports for it.  (Dealing steps to
+  two streams, as the chunk loops do for ensemble kernels, lets the tail of one launch overlap the head of the next --
+  about 3 % per step here -- but two overlapping launches each read as ~2 ms in any per-kernel timing.)"""
+  from weatherbenchx_amd import engine
+  saved = engine.ALTERNATE_STREAMS
+  engine.ALTERNATE_STREAMS = env.args.main_streams == 2
+  try:
+    return _main_leg(env)
+  finally:
+    engine.ALTERNATE_STREAMS = saved
+
+
+def _main_leg(env):
   from weatherbenchx_amd import aggregation, distributed, engine, weighting
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.metrics import base as metrics_base
@@ -270,26 +286,28 @@ def main_leg(env):
   out = run(args.warmup)
   env.sync()
   c0 = plan_box[0].collectives if plan_box[0] is not None else 0
+  # every launch of the timed region sits between two timing marks on its launch stream (wbx_mark: two event records per
+  # launch, nothing waits); they are read after the region's closing synchronisation
+  engine.S1_EVENT_LOG, engine.S1_EVENT_MARKS = [], True
   t0 = time.perf_counter()
   out = run(args.steps)
   env.sync()
   dt = env.max_over_ranks(time.perf_counter() - t0)
+  log = engine.resolve_event_marks([e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens'])
+  engine.S1_EVENT_LOG, engine.S1_EVENT_MARKS = None, False
   ms_per_step = dt / args.steps * 1e3
   points = nlev * env.nlat * env.nlon
   value = points * len(metrics) * env.world / (ms_per_step * 1e-3)
 
-  # roofline leg: HIP events around the ensemble kernel, separate pass, 5 launches per event pair
-  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 5
-  for _ in range(4):
-    agg.aggregate_statistics(stats()).metric_values(metrics)
-  log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
-  engine.S1_EVENT_LOG = None
   ms_list = sorted(e['ms'] for e in log)
-  k_ms = float(np.median(ms_list))
+  k_ms = float(np.mean(ms_list))  # the average launch duration over the K timed steps (rank 0)
   kname = ens_kernel_name(log[0], m)
   roofline = kernel_roofline(kname, k_ms, points * (m + 1) * 4, pmc_traffic(kname.split('<')[0], nlev == 37 and not args.small, f'main@{env.layout}'))
+  roofline['kernel_ms_source'] = (f'HIP events around each of the {len(log)} launches of the timed region on their launch stream '
+                                  '(wbx_mark), mean; the rocprofv3 --kernel-trace median of the same command is in profiles/')
+  roofline['kernel_ms_median'] = round(float(np.median(ms_list)), 4)
   roofline['kernel_ms_min_max'] = [round(ms_list[0], 4), round(ms_list[-1], 4)]
-  roofline['launches_per_step'] = len(log) // 4
+  roofline['launches_per_step'] = len(log) // max(args.steps, 1)
   roofline['bytes_per_point'] = (m + 1) * 4
   roofline['traffic_source'] = 'profiles/r*_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; replayed, not measured in this run)'
 
@@ -305,6 +323,7 @@ def main_leg(env):
                                'fp64 sums across points',
                  'accumulators': 'f64', 'layout': env.layout,
                  'prewarm': f'{prewarm_steps} untimed steps ({args.prewarm_ms:.0f} ms under load) before the {args.warmup} warm-up steps',
+                 'streams': args.main_streams,
                  'host_pipeline': 'steps overlapped one deep; ' + ('deferred read-back (engine.deferred_results)' if env.world == 1 else
                                   'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
                  'sharding': f'{env.world} x one (init, lead) field per rank, 1 all-reduce/step',

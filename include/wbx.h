@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 6
+#define WBX_ABI_VERSION 7
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -219,6 +219,13 @@ int wbx_notnan_mask(wbx_ctx* ctx, const void* data, int dtype, int64_t n, uint8_
 /* HIP-event timer on the context stream (bench.py's roofline leg). */
 int wbx_timer_start(wbx_ctx* ctx);
 int wbx_timer_stop(wbx_ctx* ctx, float* ms_out); /* synchronises on the stop event */
+/* Timing marks that do NOT synchronise: wbx_mark records a timing event on the context stream and returns its index;
+ * wbx_mark_elapsed waits for mark i1 and returns the time between two marks of this context; wbx_marks_reset recycles
+ * the events.  bench.py brackets every launch of its timed region with a pair of marks and reads them after the
+ * region's closing synchronisation, so the durations it reports are those of the timed launches themselves. */
+int wbx_mark(wbx_ctx* ctx, int* index_out);
+int wbx_mark_elapsed(wbx_ctx* ctx, int i0, int i1, float* ms_out);
+int wbx_marks_reset(wbx_ctx* ctx);
 
 /* ---- stage 1: deterministic ----------------------------------------------
  * Replaces Statistic.compute + the stat-side einsum of Aggregator.aggregate_stat_var

@@ -4,7 +4,7 @@
   rNN_kernel_stats.csv                               the kernel-trace tables as one CSV (run, kernel, calls, ...)
   rNN_pmc_traffic.json                               HBM bytes per launch per kernel (FETCH_SIZE x2 + WRITE_SIZE), keyed
                                                      by the names bench.py uses for its roofline entries
-usage: python profiles/make_round_files.py gpurun_out/prof r01"""
+usage: python profiles/make_round_files.py gpurun_out/prof r01 [--traffic-only]"""
 import csv
 import json
 import os
@@ -15,24 +15,70 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 here = os.path.dirname(os.path.abspath(__file__))
 out = lambda name: os.path.join(here, f'{tag}_{name}')
-shutil.copy(os.path.join(src, 'bench_n1.json'), out('bench_n1.json'))
-shutil.copy(os.path.join(src, 'bench_n1_lat_fastest.json'), out('bench_n1_lat_fastest.json'))
-text = open(os.path.join(src, 'summary.txt')).read()
-text = re.sub(r'== \S*/prof/', '== ', text)  # scratch path of the GPU box
-open(out('rocprofv3_summary.txt'), 'w').write(text)
+def write_tables():
+  shutil.copy(os.path.join(src, 'bench_n1.json'), out('bench_n1.json'))
+  shutil.copy(os.path.join(src, 'bench_n1_lat_fastest.json'), out('bench_n1_lat_fastest.json'))
+  text = open(os.path.join(src, 'summary.txt')).read()
+  text = re.sub(r'== \S*/prof/', '== ', text)  # scratch path of the GPU box
+  open(out('rocprofv3_summary.txt'), 'w').write(text)
 
-rows, run = [], None
-for line in text.split('\n'):
-  if line.startswith('== '):
-    run = line[3:].split('/')[0]
-    continue
-  m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', line)
-  if m and run and run.startswith('trace_'):
-    rows.append([run] + list(m.groups()))
-with open(out('kernel_stats.csv'), 'w', newline='') as f:
-  w = csv.writer(f)
-  w.writerow(['run', 'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'median_us'])
-  w.writerows(rows)
+  rows, run = [], None
+  for line in text.split('\n'):
+    if line.startswith('== '):
+      run = line[3:].split('/')[0]
+      continue
+    m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)$', line)
+    if m and run and run.startswith('trace_'):
+      rows.append([run] + list(m.groups()))
+  with open(out('kernel_stats.csv'), 'w', newline='') as f:
+    w = csv.writer(f)
+    w.writerow(['run', 'kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'median_us'])
+    w.writerows(rows)
+  compare_events(rows)
+
+
+
+def roofline_entries(node, path=''):
+  """(where, roofline dict) for every roofline object of a bench.py line."""
+  if isinstance(node, dict):
+    if 'kernel' in node and 'kernel_ms' in node:
+      yield path, node
+    for k, v in node.items():
+      yield from roofline_entries(v, f'{path}.{k}' if path else k)
+
+
+def compare_events(rows):
+  """rNN_events_vs_rocprof.txt: every traced bench.py process printed its own line, so the HIP-event duration of a kernel
+  and rocprofv3's durations of the same launches come from ONE process."""
+  lines = [f'{"traced run":20s} {"roofline entry":38s} {"kernel":26s} {"HIP events ms":>13s} {"rocprof median":>14s} {"avg":>9s} {"min":>9s} '
+           f'{"calls":>6s} {"events/median":>13s}']
+  for run in sorted({r[0] for r in rows}):
+    path = os.path.join(src, run + '.json')
+    if not os.path.exists(path):
+      continue
+    text = [l for l in open(path).read().split('\n') if l.startswith('{')]
+    if not text:
+      continue
+    for where, roof in roofline_entries(json.loads(text[-1])):
+      if where.startswith('lat_fastest'):
+        continue
+      token = re.split(r'[<( ]', roof['kernel'])[0]
+      if token == 'wbx_det_binned':
+        token = 'det_atoms_kernel'
+      pair = 'true, 1>' if 'PAIRWISE' in roof['kernel'] else None
+      match = [r for r in rows if r[0] == run and ('wbx::' + token + '<' in r[1] or 'wbx::' + token + '(' in r[1])
+               and (pair is None or pair in r[1]) and (pair is not None or 'true, 1>' not in r[1])]
+      if not match:
+        continue
+      r = max(match, key=lambda r: float(r[3]))
+      med, avg, mn = float(r[8]) / 1e3, float(r[4]) / 1e3, float(r[5]) / 1e3
+      lines.append(f'{run[6:]:20s} {(where or "(main line)")[:38]:38s} {token[:26]:26s} {roof["kernel_ms"]:13.4f} {med:14.4f} {avg:9.4f} {mn:9.4f} '
+                   f'{r[2]:>6s} {roof["kernel_ms"] / med:13.3f}')
+  lines.append('')
+  lines.append('HIP events: bench.py (main line: mean over the launches of the timed region, wbx_mark; side legs: N back-to-back launches per '
+               'event pair in a separate pass).  rocprofv3 --kernel-trace: all launches of that kernel in the process, warm-up and '
+               'first launches included -- hence the median.  The public-chunk entry of bench.py also holds the memset and the finish kernel.')
+  open(out('events_vs_rocprof.txt'), 'w').write('\n'.join(lines) + '\n')
 
 
 def bench_key(name: str) -> str:
@@ -55,7 +101,7 @@ def bench_key(name: str) -> str:
   m = re.match(r's1_xf_kernel<(.*?) ?>$', n)
   if m:
     return f's1_xf_kernel<{m.group(1)}>'
-  m = re.match(r'det_atoms_kernel<float, 1, (\d), (\d+), (\d)(?:, (?:true|false))?>', n)
+  m = re.match(r'det_atoms_kernel<float, 1, (\d), (\d+), (\d)(?:, (?:true|false))*>', n)
   if m:
     return f'det_atoms_kernel<float,DET6,MM={m.group(1)},PD={m.group(2)},WM={m.group(3)}>'
   m = re.match(r'det_binned_kernel<float, 1, (\d), (\d+), (\d), (\d)>', n)
@@ -71,19 +117,25 @@ def bench_key(name: str) -> str:
   return n
 
 
-raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
-traffic = {}
-for name, e in raw.items():
-  if not isinstance(e, dict) or 'hbm_read_bytes' not in e:
-    continue
-  traffic[bench_key(name)] = dict(e, rocprof_name=name)
-traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python '
-                    'bench.py --steps 2 --warmup 1 --no-cpu` (+ --layout lat_fastest, + tools/kbench_binned.py for the '
-                    'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
-                    '(gfx950 reports half of wide coalesced reads)')
-json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
-for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt', 'pmc_spectrum_lat_fastest.txt',
-              'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt', 'config5_host_split.txt', 'new_time_labels.txt', 'kbench_ens.txt'):
-  if os.path.exists(os.path.join(src, extra)):
-    shutil.copy(os.path.join(src, extra), out(extra))
-print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])
+def write_traffic():
+  raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
+  traffic = {}
+  for name, e in raw.items():
+    if not isinstance(e, dict) or 'hbm_read_bytes' not in e:
+      continue
+    traffic[bench_key(name)] = dict(e, rocprof_name=name)
+  traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python '
+                      'bench.py --steps 2 --warmup 1 --no-cpu` (+ --layout lat_fastest, + tools/kbench_binned.py for the '
+                      'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '
+                      '(gfx950 reports half of wide coalesced reads)')
+  json.dump(traffic, open(out('pmc_traffic.json'), 'w'), indent=1)
+
+
+write_traffic()
+if '--traffic-only' not in sys.argv[3:]:  # tools/profile_round.sh writes the traffic file first: bench.py replays it
+  write_tables()
+  for extra in ('read_stream.json', 'pmc_ens.txt', 'pmc_binned_lon_fastest.txt', 'pmc_binned_lat_fastest.txt', 'pmc_spectrum.txt', 'pmc_spectrum_lat_fastest.txt',
+                'spectrum_phase_profile.txt', 'spectrum_raw.txt', 'ubench.txt', 'config5_host_split.txt', 'new_time_labels.txt', 'kbench_ens.txt'):
+    if os.path.exists(os.path.join(src, extra)):
+      shutil.copy(os.path.join(src, extra), out(extra))
+  print('wrote', [f for f in sorted(os.listdir(here)) if f.startswith(tag + '_')])

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
   assert declared == set(_hip.EXPORTED_SYMBOLS)
   for name in declared:
     assert hasattr(lib, name), f'{name} declared in include/wbx.h but not exported'
-  assert _hip.load_library().wbx_abi_version() == 6
+  assert _hip.load_library().wbx_abi_version() == 7
 
 
 def test_struct_layout_matches_header():

@@ -30,7 +30,7 @@ BINNED_W_ON_X, BINNED_WT_X_ONLY, BINNED_WT_ROW_ONLY, BINNED_MASK_ON_W = 1, 2, 4,
 EXPORTED_SYMBOLS = (
     'wbx_abi_version', 'wbx_last_error', 'wbx_device_count', 'wbx_ctx_create', 'wbx_ctx_destroy',
     'wbx_ctx_synchronize', 'wbx_ctx_device_name', 'wbx_malloc', 'wbx_free', 'wbx_memcpy_h2d',
-    'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_s1_partial_len',
+    'wbx_memcpy_d2h', 'wbx_memset', 'wbx_timer_start', 'wbx_timer_stop', 'wbx_mark', 'wbx_mark_elapsed', 'wbx_marks_reset', 'wbx_s1_partial_len',
     'wbx_det_partial', 'wbx_ens_partial', 'wbx_contract', 'wbx_contract_bits', 'wbx_det_binned', 'wbx_cat_partial', 'wbx_det_map', 'wbx_ens_map',
     'wbx_zonal_spectrum', 'wbx_zonal_spectrum_slabs', 'wbx_host_alloc', 'wbx_host_free', 'wbx_memcpy_d2h_async', 'wbx_fence_create',
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy', 'wbx_ctx_wait_fence', 'wbx_memcpy_h2d_async',
@@ -122,6 +122,9 @@ def load_library():
         'wbx_acc_reset': [vp, vp, i64],
         'wbx_timer_start': [vp],
         'wbx_timer_stop': [vp, C.POINTER(C.c_float)],
+        'wbx_mark': [vp, C.POINTER(i32)],
+        'wbx_mark_elapsed': [vp, i32, i32, C.POINTER(C.c_float)],
+        'wbx_marks_reset': [vp],
         'wbx_s1_partial_len': [C.POINTER(S1PlanStruct), i32, C.POINTER(i64)],
         'wbx_det_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp],
         'wbx_ens_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp, vp],
@@ -397,6 +400,20 @@ class Context:
     ms = C.c_float(0)
     check(self.lib.wbx_timer_stop(self.handle, C.byref(ms)), 'wbx_timer_stop')
     return float(ms.value)
+
+  def mark(self) -> int:
+    """A timing event on this context's stream; nothing waits (read with mark_elapsed once the work is known to be done)."""
+    i = C.c_int(0)
+    check(self.lib.wbx_mark(self.handle, C.byref(i)), 'wbx_mark')
+    return int(i.value)
+
+  def mark_elapsed(self, i0: int, i1: int) -> float:
+    ms = C.c_float(0)
+    check(self.lib.wbx_mark_elapsed(self.handle, int(i0), int(i1), C.byref(ms)), 'wbx_mark_elapsed')
+    return float(ms.value)
+
+  def marks_reset(self):
+    check(self.lib.wbx_marks_reset(self.handle), 'wbx_marks_reset')
 
 
 _default_ctx: dict[int, Context] = {}

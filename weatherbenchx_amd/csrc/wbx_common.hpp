@@ -22,6 +22,8 @@ struct wbx_ctx {
   size_t s2_scratch_size = 0;
   void* aidm_scratch = nullptr;  // wbx_det_binned: atom ids with the validity mask folded in (one byte per point)
   size_t aidm_scratch_size = 0;
+  hipEvent_t* marks = nullptr;  // wbx_mark: timing events, created on demand and recycled by wbx_marks_reset
+  int marks_used = 0, marks_made = 0, marks_cap = 0;
 };
 
 namespace wbx {
@@ -41,7 +43,11 @@ inline int fail(int code, const char* fmt, ...) {
 // L2 / Infinity Cache.  Measured on the configs[1] kernel: 6.12 -> 6.45 TB/s (76.5 % -> 80.6 % of the HBM peak).
 template <typename T>
 __device__ __forceinline__ T ld_stream(const T* p) {
+#ifdef WBX_LD_STREAM_PLAIN  // A/B build (make ab-plainld): the same loads without the hint
+  return *p;
+#else
   return __builtin_nontemporal_load(p);
+#endif
 }
 
 // A wave-uniform pointer the compiler also KNOWS to be uniform (SGPR pair): row offsets come out of tables through vector

@@ -1,4 +1,6 @@
 // Context, memory helpers and HIP-event timers of libwbx_hip.so (see include/wbx.h).
+#include <cstdlib>
+
 #include "wbx_common.hpp"
 
 namespace wbx {
@@ -68,6 +70,8 @@ extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
   if (ctx->aidm_scratch) (void)hipFree(ctx->aidm_scratch);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  for (int i = 0; i < ctx->marks_made; ++i) (void)hipEventDestroy(ctx->marks[i]);
+  free(ctx->marks);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -203,6 +207,39 @@ extern "C" int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes) {
 extern "C" int wbx_timer_start(wbx_ctx* ctx) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   WBX_HIP(hipEventRecord(ctx->ev_start, ctx->stream));
+  return 0;
+}
+
+extern "C" int wbx_mark(wbx_ctx* ctx, int* index_out) {
+  WBX_REQUIRE(ctx != nullptr && index_out != nullptr, "bad arguments");
+  if (ctx->marks_used == ctx->marks_cap) {
+    const int cap = ctx->marks_cap ? 2 * ctx->marks_cap : 256;
+    hipEvent_t* grown = static_cast<hipEvent_t*>(realloc(ctx->marks, sizeof(hipEvent_t) * cap));
+    WBX_REQUIRE(grown != nullptr, "out of memory for %d timing marks", cap);
+    ctx->marks = grown;
+    ctx->marks_cap = cap;
+  }
+  if (ctx->marks_used == ctx->marks_made) {
+    WBX_HIP(hipEventCreate(&ctx->marks[ctx->marks_made]));
+    ++ctx->marks_made;
+  }
+  WBX_HIP(hipEventRecord(ctx->marks[ctx->marks_used], ctx->stream));
+  *index_out = ctx->marks_used++;
+  return 0;
+}
+
+extern "C" int wbx_mark_elapsed(wbx_ctx* ctx, int i0, int i1, float* ms_out) {
+  WBX_REQUIRE(ctx != nullptr && ms_out != nullptr, "bad arguments");
+  WBX_REQUIRE(i0 >= 0 && i1 >= 0 && i0 < ctx->marks_used && i1 < ctx->marks_used, "marks %d, %d out of range (%d recorded)", i0, i1,
+              ctx->marks_used);
+  WBX_HIP(hipEventSynchronize(ctx->marks[i1]));
+  WBX_HIP(hipEventElapsedTime(ms_out, ctx->marks[i0], ctx->marks[i1]));
+  return 0;
+}
+
+extern "C" int wbx_marks_reset(wbx_ctx* ctx) {
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  ctx->marks_used = 0;
   return 0;
 }
 

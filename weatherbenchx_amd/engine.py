@@ -501,14 +501,7 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
                                         ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
                                         int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)),
                'wbx_det_spectrum')
-  if S1_EVENT_LOG is not None:
-    reps = max(1, int(S1_EVENT_REPEAT))
-    ctx.timer_start()
-    for _ in range(reps):
-      call()
-    S1_EVENT_LOG.append({'kind': 'det_spectrum', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'rows': int(plan.nkey), 'func': int(func)})
-  else:
-    call()
+  timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func))
   for da, buf in ((req['p'], pw_p), (req['t'], pw_t)):
     da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'ngroup': ngroup, 'cache': entry['dev']}
   return True
@@ -521,11 +514,8 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
   if kind == 'det' and _fusion_requests and _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
     return out
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
-  reps = 1
-  if S1_EVENT_LOG is not None:  # bench.py's roofline leg: HIP events on the launch stream
-    reps = max(1, int(S1_EVENT_REPEAT))
-    ctx.timer_start()
-  for _ in range(reps):  # idempotent: every repetition overwrites the same partial buffer
+
+  def call():  # idempotent: a repetition overwrites the same partial buffer
     if kind == 'det':
       _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]),
                                          ptr(devs[1]), ptr(devs[2]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_det_partial')
@@ -538,12 +528,13 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
       m, mstride, algo = ens
       _hip.check(ctx.lib.wbx_ens_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride),
                                          int(algo), ptr(devs[0]), ptr(devs[1]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_ens_partial')
-  if S1_EVENT_LOG is not None:
-    S1_EVENT_LOG.append({'kind': kind, 'ms': ctx.timer_stop() / reps, 'reps': reps, 'vec': plan.vec,
-                         'x_kept': plan.x_kept, 'plane_rows': plan.plane_rows, 'x_weighted': plan.x_weights is not None,
-                         'flat': plan.x_weights is not None and plan.plane_rows > 0, 'grid': plan.nkey * plan.nchunk,
-                         'block': plan.block_threads, 'algo': int(ens[2]) if kind == 'ens' else None,
-                         'flags': int(plan.flags)})
+  if S1_EVENT_LOG is None:
+    call()
+  else:
+    timed_launch(ctx, call, kind=kind, vec=plan.vec, x_kept=plan.x_kept, plane_rows=plan.plane_rows,
+                 x_weighted=plan.x_weights is not None, flat=plan.x_weights is not None and plan.plane_rows > 0,
+                 grid=plan.nkey * plan.nchunk, block=plan.block_threads, algo=int(ens[2]) if kind == 'ens' else None,
+                 flags=int(plan.flags))
   return out
 
 
@@ -551,6 +542,38 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
 S1_EVENT_LOG = None
 # launches per event pair in that mode (amortises the ~60 us event/dispatch overhead of a single launch)
 S1_EVENT_REPEAT = 1
+# True: the launches are bracketed by timing MARKS instead (wbx_mark: nothing waits, one launch per pair), so a pipelined
+# loop runs exactly as it does untimed; `resolve_event_marks(log)` fills in the durations once the loop has been waited for.
+S1_EVENT_MARKS = False
+
+
+def timed_launch(ctx, call, **entry):
+  """Runs `call` (one launch on ctx's stream); with S1_EVENT_LOG set, brackets it with HIP events and logs `entry`."""
+  if S1_EVENT_LOG is None:
+    call()
+  elif S1_EVENT_MARKS:
+    i0 = ctx.mark()
+    call()
+    S1_EVENT_LOG.append(dict(entry, ms=None, reps=1, marks=(ctx, i0, ctx.mark())))
+  else:
+    reps = max(1, int(S1_EVENT_REPEAT))
+    ctx.timer_start()
+    for _ in range(reps):
+      call()
+    S1_EVENT_LOG.append(dict(entry, ms=ctx.timer_stop() / reps, reps=reps))
+
+
+def resolve_event_marks(log):
+  """Durations of the entries logged under S1_EVENT_MARKS (waits for each entry's closing mark); recycles the marks."""
+  ctxs = {}
+  for e in log:
+    if e.get('marks') is not None:
+      ctx, i0, i1 = e.pop('marks')
+      e['ms'] = ctx.mark_elapsed(i0, i1)
+      ctxs[id(ctx)] = ctx
+  for ctx in ctxs.values():
+    ctx.marks_reset()
+  return log
 
 
 def _run_map(ctx, kind: str, dplan, plan: planner.S1Plan, devs, dtype_code: int, lane: int, func: int = 0,
@@ -941,19 +964,13 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
     if len(w_buf.atoms) > 8:
       w_buf.atoms.clear()
     w_buf.atoms[akey] = atoms
-  reps = 1
-  if S1_EVENT_LOG is not None:
-    reps = max(1, int(S1_EVENT_REPEAT))
-    ctx.timer_start()
-  for _ in range(reps):
+  def call():
     _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
                                       ptr(devs[2]), ptr(devs[3]), C.c_void_p(wt_buf.ptr),
                                       C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags, nbin,
                                       C.c_void_p(atoms.ptr) if atoms is not None else None,
                                       C.c_void_p(out.ptr)), 'wbx_det_binned')
-  if S1_EVENT_LOG is not None:
-    S1_EVENT_LOG.append({'kind': 'det_binned', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'nbin': nbin,
-                         'w_flags': w_flags})
+  timed_launch(ctx, call, kind='det_binned', nbin=nbin, w_flags=w_flags)
   return out.ptr, shape
 
 

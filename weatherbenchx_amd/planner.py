@@ -15,12 +15,16 @@ weatherbenchX/aggregation.py:297-335, for arbitrary loader dim orders
 from __future__ import annotations
 
 import dataclasses
+import os
 from typing import Sequence
 
 import numpy as np
 
 MAX_INPUTS = 4
 TARGET_BLOCKS = 4096  # >> 256 CUs * resident blocks, so the tail is short
+# geometry of the flat one-point-per-lane sweep (s1_xf1_kernel): threads per block, fewest elements per block
+FLAT1_THREADS = int(os.environ.get('WBX_FLAT1_THREADS', '256'))
+FLAT1_MIN_ELEMENTS = int(os.environ.get('WBX_FLAT1_MIN_ELEMENTS', '2816'))
 
 
 @dataclasses.dataclass
@@ -290,8 +294,8 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
         plane_rows, vec = sizes[inner], 1
         # measured on 8 x 51 x 1440 x 721 (threads, rows per block): (64, 1..2) 0.48 ms, (128, 2..4) 0.41-0.43,
         # (256, 4..8) 0.407, (256, 15) 0.415; the x-kept kernel on the same data 0.452, longitude-fastest data 0.397
-        block_threads = 256
-        depth_chunk = min(max(depth_chunk, -(-2816 // nx)), ndepth)
+        block_threads = FLAT1_THREADS
+        depth_chunk = min(max(depth_chunk, -(-FLAT1_MIN_ELEMENTS // nx)), ndepth)
         nchunk = -(-ndepth // depth_chunk)
   elif fold_x and not x_kept and not map_mode and not (flags & 2) and x_dim is not None and depth_dims and nx + 3 <= 2048:
     inner = depth_dims[-1]

@@ -117,15 +117,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
                                                 int(geo.batch), int(offs.size), offs.ctypes.data_as(C.c_void_p), int(nlon),
                                                 C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr), int(ngroup), 0,
                                                 C.c_void_p(out.ptr)), 'wbx_zonal_spectrum_slabs')
-  if engine.S1_EVENT_LOG is not None:  # bench.py's roofline leg: HIP events on the launch stream
-    reps = max(1, int(engine.S1_EVENT_REPEAT))
-    ctx.timer_start()
-    for _ in range(reps):
-      call()
-    engine.S1_EVENT_LOG.append({'kind': 'spectrum', 'ms': ctx.timer_stop() / reps, 'reps': reps, 'rows': int(offs.size * geo.batch),
-                                'nlon': int(nlon), 'lon_stride': int(geo.lon_stride)})
-  else:
-    call()
+  engine.timed_launch(ctx, call, kind='spectrum', rows=int(offs.size * geo.batch), nlon=int(nlon), lon_stride=int(geo.lon_stride))
   return engine._deliver(ctx, out.ptr, (ngroup, nk))  # pylint: disable=protected-access
 
 
