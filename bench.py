@@ -197,8 +197,11 @@ def ens_kernel_name(e, m=51):
   """The kernel wbx_ens_partial launches for this event (the dispatch rule of csrc/wbx_ens_impl.hpp restated)."""
   if e.get('algo') == 1:
     return f's1_xr_kernel<EnsOpF32<{m},true,PAIRWISE>,1> (register-tiled O(M^2) pair form)'
-  piped = (os.environ.get('WBX_ENS_PIPE', '1') != '0' and e.get('block') == 64 and not e.get('x_kept') and not e.get('x_weighted')
-           and not (e.get('flags', 0) & 11))
+  piped = (os.environ.get('WBX_ENS_PIPE', '1') != '0' and e.get('block') == 64 and not e.get('x_kept') and not (e.get('flags', 0) & 11)
+           and (e.get('flat') or not e.get('x_weighted')))
+  if piped and e.get('flat'):
+    return (f'ens_pipe_kernel<{m},true,SORT,FLAT> (rank form, contiguous planes with folded latitude weights, next tile through '
+            'LDS-DMA, fp32 chain sums)')
   if piped:
     return f'ens_pipe_kernel<{m},true,SORT> (rank form, next tile through LDS-DMA, fp32 chain sums)'
   if e.get('flat'):

@@ -512,3 +512,61 @@ def test_fused_and_separate_launches_agree_through_the_chunk_loop(ctx, monkeypat
   d2, s2, k2 = run(spec, True)
   assert 'det_spectrum' not in k2
   np.testing.assert_array_equal(d2['rmse.z'].values, d0['rmse.z'].values)
+
+
+# ---- the pipelined sweep over latitude-fastest planes (ens_pipe_kernel<.., FLAT>) ----------------------------------------------
+@pytest.mark.parametrize('nlat,nlon,m', [(721, 96, 51), (97, 40, 51), (33, 50, 50), (181, 64, 16)])
+def test_latitude_fastest_planes_through_the_pipelined_sweep(ctx, nlat, nlon, m, monkeypatch):
+  """Area-weighted ensemble suite on [init, level, member, longitude, latitude] arrays (the public IFS-ENS layout): the
+  latitude weights are folded into stage 1 and the planes are walked flat by one-wave blocks.  Rows of 721 / 97 / 33 / 181
+  floats put every chunk boundary inside a 64-element tile (the lanes in front of it are dropped), two inits make two planes
+  per key, a NaN member sits right in front of a chunk boundary and the weight index wraps inside a tile (nlat = 33 < 64).
+  Against the float64 oracle per (level), and against the 256-thread flat sweep (s1_xf1_kernel) the same library runs when the
+  engine does not ask for one-wave blocks."""
+  rng = np.random.default_rng(nlat * 1000 + nlon)
+  ninit, nlev = 2, 3
+  lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  tv = (rng.normal(size=(ninit, nlev, nlon, nlat)) + 280).astype(np.float32)
+  pv = (tv[:, :, None] + rng.normal(size=(ninit, nlev, m, nlon, nlat))).astype(np.float32)
+  tv = (tv + rng.normal(size=tv.shape)).astype(np.float32)
+  pv[1, 2, 7, nlon // 2, nlat - 1] = np.nan  # the last point of a row: whatever chunk ends there ends on it
+  pd, td = ('init_time', 'level', 'number', 'longitude', 'latitude'), ('init_time', 'level', 'longitude', 'latitude')
+  coords = {'init_time': np.array(['2020-01-01', '2020-01-02'], dtype='datetime64[ns]'), 'level': np.arange(nlev),
+            'latitude': lat, 'longitude': lon}
+  import torch
+  p = {'v': xr.DataArray(torch.from_numpy(pv).cuda(), dims=pd, coords=coords)}
+  t = {'v': xr.DataArray(torch.from_numpy(tv).cuda(), dims=td, coords=coords)}
+  metrics = _suite()
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+
+  def run(one_wave):
+    monkeypatch.setattr(engine, 'ENS_PIPE', one_wave)
+    engine.clear_caches()
+    engine.S1_EVENT_LOG = []
+    try:
+      fresh = lambda d: {k: xr.DataArray(v.data, dims=v.dims, coords={c: v[c].values for c in v.dims}) for k, v in d.items()}
+      out = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, fresh(p), fresh(t))).metric_values(metrics)
+      log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
+    finally:
+      engine.S1_EVENT_LOG = None
+    return {k: np.asarray(out[f'{k}.v'].values) for k in metrics}, log
+
+  got, log = run(True)
+  assert len(log) == 1 and log[0]['flat'] and log[0]['block'] == 64, log
+  ref, rlog = run(False)
+  assert len(rlog) == 1 and rlog[0]['flat'] and rlog[0]['block'] == 256, rlog
+  wt = O.grid_area_weights(lat)
+  p64, t64 = pv.astype(np.float64), tv.astype(np.float64)
+  lanes = {'skill': O.crps_skill(p64, pd, t64, td, 'number')[0], 'spread': O.crps_spread(p64, pd, 'number', fair=True, use_sort=True)[0],
+           'var': O.ensemble_variance(p64, pd, 'number')[0],
+           'uemse': O.unbiased_ensemble_mean_squared_error(p64, pd, t64, td, 'number')[0],
+           'emse': O.ensemble_mean_squared_error(p64, pd, t64, td, 'number')[0]}
+  mean = {k: (v * wt).sum(axis=(0, 2, 3)) / (wt.sum() * ninit * nlon) for k, v in lanes.items()}  # NaN at level 2, like xr.dot
+  want = {'crps': mean['skill'] - 0.5 * mean['spread'],
+          'unbiased_spread_skill': np.sqrt(mean['var'] / mean['uemse']),
+          'unbiased_mean_rmse': np.sqrt(mean['uemse']), 'mean_rmse': np.sqrt(mean['emse'])}
+  for k in metrics:
+    assert got[k].shape == (nlev,)
+    assert np.isnan(got[k][2]) and np.isnan(want[k][2]) and np.isnan(ref[k][2]), k  # the NaN member poisons its level only
+    np.testing.assert_allclose(got[k][:2], want[k][:2], rtol=RTOL, err_msg=k)
+    np.testing.assert_allclose(got[k][:2], ref[k][:2], rtol=RTOL, err_msg=k + ' (256-thread sweep)')

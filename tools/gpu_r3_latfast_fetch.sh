@@ -10,14 +10,19 @@ one() {  # name, layout, env assignments...
   env "$@" timeout 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $O/${name}_ea -o r -- $B --layout $layout --steps 3 --warmup 1 --prewarm-ms 0 > /dev/null 2>&1
   env "$@" timeout 200 $B --layout $layout --steps 20 --warmup 5 > $O/$name.json 2> $O/$name.err
 }
-one lat_default lat_fastest WBX_X=0
-one lat_threads64 lat_fastest WBX_FLAT1_THREADS=64
-one lat_bigchunks lat_fastest WBX_FLAT1_MIN_ELEMENTS=30000
-one lat_plainld lat_fastest WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_plainld.so
-one lon_default lon_fastest WBX_X=0
+for v in ${VARIANTS:-lat_default lat_threads64 lat_threads128 lat_bigchunks lat_plainld lon_default}; do
+  case $v in
+    lat_default) one $v lat_fastest WBX_X=0;;
+    lat_threads64) one $v lat_fastest WBX_FLAT1_THREADS=64;;
+    lat_threads128) one $v lat_fastest WBX_FLAT1_THREADS=128;;
+    lat_bigchunks) one $v lat_fastest WBX_FLAT1_MIN_ELEMENTS=30000;;
+    lat_plainld) one $v lat_fastest WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_plainld.so;;
+    lon_default) one $v lon_fastest WBX_X=0;;
+  esac
+done
 python - <<PY
 import glob, json, sqlite3
-for name in ('lat_default', 'lat_threads64', 'lat_bigchunks', 'lat_plainld', 'lon_default'):
+for name in '${VARIANTS:-lat_default lat_threads64 lat_threads128 lat_bigchunks lat_plainld lon_default}'.split():
   line = name + ':'
   try:
     r = json.loads([l for l in open('$O/%s.json' % name).read().split('\n') if l.startswith('{')][-1])

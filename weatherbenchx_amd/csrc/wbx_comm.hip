@@ -119,7 +119,7 @@ extern "C" int wbx_comm_destroy(wbx_comm* comm) {
   if (comm == nullptr) return 0;
   Rccl* R = rccl();
   if (R && comm->comm) {
-    hipSetDevice(comm->device);
+    (void)hipSetDevice(comm->device);
     R->comm_destroy(comm->comm);
   }
   delete comm;

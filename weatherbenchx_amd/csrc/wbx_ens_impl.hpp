@@ -495,17 +495,21 @@ struct EnsMasked {
 // One wave per block; rows (depth) and x tiles of the block's (key, chunk) form one tile sequence.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
-// (A flat flavour of this kernel for latitude-fastest planes with folded weights -- s1_xf1_kernel's geometry, the weight
-// fetched one tile ahead -- was built and measured in round 3: 1.48-1.52 ms for the 37-level field against 1.44 ms for
-// s1_xf1_kernel with fp64 sums on the same box; not kept.)
+// FLAT: the same sweep over contiguous latitude-fastest planes with the latitude weights folded in (s1_xf1_kernel's
+// geometry, plan->x_weights): a chunk's rows are one run [e0, e1) of the plane, walked in 64-element tiles that start on a
+// 64-element boundary of the PLANE (whole cache lines; the lanes of the first tile in front of e0 are dropped, never moved
+// to another tile: a wave whose lanes sit in two 256-byte pieces fetches three or four lines per load).  A lane's weight
+// w[e mod nx] comes from the fp64 table in global memory (5.7 KB, cache resident), fetched one tile ahead like the target.
+// (A first version of this flavour lost to s1_xf1_kernel in round 3 -- 1.48-1.52 against 1.44 ms for the 37-level field --
+// because both started their lanes one trip ahead instead of dropping them: 12 % more line requests, see wbx_s1.hpp.)
 #ifndef WBX_ENS_PIPE_NLDS
 #define WBX_ENS_PIPE_NLDS 50   // members staged through the LDS (x 256 B per one-wave block)
 #endif
 #ifndef WBX_ENS_PIPE_WAVES
 #define WBX_ENS_PIPE_WAVES 3   // waves per SIMD the register budget is cut for (12 800-byte blocks: 12 per CU)
 #endif
-template <int MP, bool EXACT, int ALGO>
-__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a) {
+template <int MP, bool EXACT, int ALGO, bool FLAT>
+__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a, int R) {
   using Op = EnsOpF32<MP, EXACT, ALGO>;
   constexpr int NA = Op::NACC;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
@@ -528,17 +532,33 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
   for (int l = 0; l < NA; ++l) acc[l] = 0.0;
 
-  // the current segment: elements [e0, e1) of the depth row at `ro`, tiles of 64 from et; d = the next depth row
+  // the current segment: elements [e0, e1) of the depth row (FLAT: of the plane) at `ro`, tiles of 64 from et; d = the next
+  // depth row
   int64_t d = d0, e0 = 0, e1 = 0, et = 0;
+  int wm = 0;  // FLAT: this lane's weight index in the tile at et
+  const int wstep = 64 % nx;
   auto open_segment = [&]() {  // d < d1
-    row_bases<2>(a, kb, key, d, ro);
-    e0 = 0;
-    e1 = nx;
-    et = 0;
-    d += 1;
+    if constexpr (FLAT) {
+      const int64_t plane = d / R;
+      const int64_t j0 = d - plane * R;
+      const int64_t nj = d1 - d < R - j0 ? d1 - d : R - j0;
+      row_bases<2>(a, kb, key, plane * R, ro);
+      e0 = j0 * nx;
+      e1 = (j0 + nj) * nx;
+      et = e0 & ~(int64_t)63;
+      wm = (int)((et + lane) % nx);
+      d += nj;
+    } else {
+      row_bases<2>(a, kb, key, d, ro);
+      e0 = 0;
+      e1 = nx;
+      et = 0;
+      d += 1;
+    }
   };
 
   float xn[NREG > 0 ? NREG : 1], tn = 0.f;
+  double wn = 0.0;
   auto issue = [&]() {  // the tile at et of the open segment
     int64_t e = et + lane;
     e = e < e0 ? e0 : (e < e1 ? e : e1 - 1);  // lanes outside the segment re-read its edge (counted out below): no EXEC games
@@ -556,6 +576,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
     for (int m = NLDS; m < MP; ++m) xn[m - NLDS] = (EXACT || m < M) ? ld_stream(pr + (int64_t)m * a.mstride) : INFINITY;
     tn = ld_stream(reinterpret_cast<const float*>(a.in[1]) + ro[1] + e * a.xstride[1]);
+    if constexpr (FLAT) wn = a.xw[wm];
   };
 
   bool more = d < d1;
@@ -571,23 +592,35 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 #pragma unroll
     for (int m = NLDS; m < MP; ++m) r.xm[m] = xn[m - NLDS];
     r.t = tn;
+    const double wcur = wn;
     const int64_t ecur = et + lane;
     const bool valid = ecur >= e0 && ecur < e1;
     const int64_t xcur = ecur < e0 ? e0 : (ecur < e1 ? ecur : e1 - 1);
     int64_t rocur[WBX_MAX_INPUTS];
 #pragma unroll
     for (int i = 0; i < WBX_MAX_INPUTS; ++i) rocur[i] = ro[i];
-    const bool full = et + 64 <= e1;  // every lane of this tile holds a point of the row (wave-uniform)
+    const bool full = et >= e0 && et + 64 <= e1;  // every lane of this tile holds a point of the segment (wave-uniform)
     et += 64;
     if (et >= e1) {
       more = d < d1;
       if (more) open_segment();
+    } else if constexpr (FLAT) {
+      wm += wstep;
+      wm = wm >= nx ? wm - nx : wm;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile has left the staging buffer
     if (more) issue();
     double val[Op::NLANE];
     Op::template finish<true>(a, rocur, xcur, r, val);
-    if (full) {
+    if constexpr (FLAT) {
+      if (full) {
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc[l] = fma(val[l], wcur, acc[l]);
+      } else {
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc[l] = fma(valid ? val[l] : 0.0, wcur, acc[l]);
+      }
+    } else if (full) {
 #pragma unroll
       for (int l = 0; l < NA; ++l) acc[l] += val[l];
     } else {
@@ -616,11 +649,24 @@ inline bool ens_pipe_ok(const wbx_s1_plan* plan, const S1Args& a) {
   return (double)plan->nx * (double)a.xstride[0] * 4.0 < 4294967296.0;
 }
 
-template <int MP, bool EXACT, int ALGO>
+// ... and of its FLAT flavour: latitude weights folded into stage 1 over whole contiguous planes (what launch_flat_weighted1
+// asks for), one-wave blocks (the planner's 'point64' geometry), offsets inside a plane within 32 bits.
+inline bool ens_pipe_flat_ok(const wbx_s1_plan* plan, const S1Args& a) {
+  static const bool off = getenv("WBX_ENS_PIPE") && atoi(getenv("WBX_ENS_PIPE")) == 0;
+  if (off) return false;
+  if (plan->x_kept || plan->x_weights == nullptr || plan->block_threads != 64 || plan->plane_rows <= 0) return false;
+  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA | WBX_FLAG_SKIPNA_ENS)) return false;
+  if (plan->nx <= 0 || plan->nx > WBX_XW_MAX || plan->ndepth <= 0 || plan->nkey <= 0 || plan->ndepth % plan->plane_rows != 0) return false;
+  if (a.xstride[0] != 1 || a.xstride[1] != 1) return false;
+  return (double)plan->nx * (double)plan->plane_rows * 4.0 < 4294967296.0;
+}
+
+template <int MP, bool EXACT, int ALGO, bool FLAT = false>
 int launch_ens_pipe(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a) {
   const int64_t grid = plan->nkey * plan->nchunk;
   WBX_REQUIRE(grid < (int64_t)1 << 31, "grid too large (%lld blocks)", (long long)grid);
-  hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a);
+  hipLaunchKernelGGL((ens_pipe_kernel<MP, EXACT, ALGO, FLAT>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a,
+                     FLAT ? plan->plane_rows : 0);
   WBX_HIP(hipGetLastError());
   return 0;
 }
@@ -643,6 +689,7 @@ template <int MP, bool EXACT>
 int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo, bool map) {
   // (the pair form stays on s1_xr_kernel: pipelined it takes 168 VGPRs + scratch, and it is a diagnostic since round 3)
   if (!map && algo == WBX_ENS_SORT && ens_pipe_ok(plan, a)) return launch_ens_pipe<MP, EXACT, WBX_ENS_SORT>(ctx, plan, a);
+  if (!map && algo == WBX_ENS_SORT && ens_pipe_flat_ok(plan, a)) return launch_ens_pipe<MP, EXACT, WBX_ENS_SORT, true>(ctx, plan, a);
   if (algo == WBX_ENS_SORT) return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_SORT>>(ctx, plan, a, map);
   if (algo == WBX_ENS_DIAG_LOADONLY) {
     if (!EXACT || map) return fail(WBX_ERR_INVALID, "the load-only diagnostic exists for the exact-M partial kernels only");

@@ -497,22 +497,24 @@ __global__ void __launch_bounds__(256, Op::MIN_WAVES) s1_xf1_kernel(S1Args a, in
     row_bases<Op::NIN>(a, kb, key, plane * R, ro);
     const int64_t e0 = j0 * nx, e1 = (j0 + nj) * nx;
     // lanes start on a 64-element boundary of the plane (planes are normally 128-B aligned, rows of 721 are not), so
-    // every wave load covers whole cache lines; the lanes in front of e0 sit the first trip out
+    // every wave load covers whole cache lines.  The lanes in front of e0 are DROPPED in the first trip -- they must not run
+    // one trip ahead of the others instead: a wave whose lanes sit in two different 256-byte pieces touches three or four
+    // lines per load, every trip (round 2 did that: FETCH_SIZE 1.11 x the algorithmic bytes with 256-thread blocks, whose
+    // first wave is the split one, 1.44 x with one-wave blocks; tools/ubench/flat_fetch.hip counts the line requests).
     int64_t e = (e0 & ~(int64_t)63) + tid;
-    int m = (int)((e - e0 + nx) % nx);
-    if (e < e0) {
-      e += nt;
-      m += step;
-      m = m >= nx ? m - nx : m;
-    }
+    int m = (int)((e - e0) % nx);  // the weight index of e (a lane in front of e0 counts back from the row's end)
+    m = m < 0 ? m + nx : m;
     for (; e < e1; e += nt) {
+      // (branch-free: the masked lanes read their own element -- it lies in the same plane, in the previous chunk -- and
+      // drop the values; a divergent `if` around the body costs 200 instead of 117 VGPRs)
       double one[1][NA];
 #pragma unroll
       for (int l = 0; l < NA; ++l) one[0][l] = 0.0;
       Op::template accum<1, false>(a, ro, e, one);
       const double w = wbx_xw_lds[m];
+      const bool mine = e >= e0;
 #pragma unroll
-      for (int l = 0; l < NA; ++l) acc[l] = fma(one[0][l], w, acc[l]);
+      for (int l = 0; l < NA; ++l) acc[l] = fma(mine ? one[0][l] : 0.0, w, acc[l]);
       m += step;
       m = m >= nx ? m - nx : m;
     }

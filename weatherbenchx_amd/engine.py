@@ -282,7 +282,7 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
   return store[sig]
 
 
-def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None):
+def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None, one_wave=False):
   """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads.
 
   The climatology gather table is the one table that follows the chunk's time labels (every chunk of a streamed evaluation
@@ -296,7 +296,7 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
     gbytes = gtable.tobytes()
     if not SWAP_GATHER_TABLES:
       gsig += (gbytes,)
-  sig = (id(ctx), kind, tuple(dims), tuple(sizes[d] for d in dims),
+  sig = (id(ctx), kind, bool(one_wave), tuple(dims), tuple(sizes[d] for d in dims),
          None if x_weights is None else hash(x_weights.tobytes()),
          tuple(None if l is None else (tuple(sorted(l.strides.items(), key=str)), l.itemsize, l.base_alignment % 16 == 0)
                for l in layouts),
@@ -305,7 +305,8 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
   if hit is None:
     plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
                                  allow_vec4=(kind == 'det' and x_weights is None),
-                                 fold_x=False if x_weights is None else (True if kind == 'det' else 'point'))
+                                 fold_x=False if x_weights is None else
+                                 (True if kind == 'det' else ('point64' if one_wave else 'point')))
     if x_weights is not None and plan.plane_rows > 0:
       assert not plan.x_kept and plan.vec == 1 and plan.nx == x_weights.size
       plan.x_weights = np.ascontiguousarray(x_weights, dtype=np.float64)
@@ -399,6 +400,7 @@ def stage_inputs(ctx, arrays: Sequence[xr.DataArray]):
 # start to end on ONE stream, scratch buffers are per context, cached operands are uploaded synchronously, and the
 # state's fence covers every context that got work.
 ALTERNATE_STREAMS = os.environ.get('WBX_ALTERNATE_STREAMS', '1') != '0'
+ENS_PIPE = os.environ.get('WBX_ENS_PIPE', '1') != '0'  # the library reads the same variable (csrc/wbx_ens_impl.hpp)
 _stream_ring: list = []
 
 
@@ -1041,7 +1043,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
     x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
     if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:
       xw = np.ascontiguousarray(w_da.values, dtype=np.float64)
-      hit = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, set(), gather, flags, xw)
+      # the rank-form fp32 ensemble ops without mask / skipna run the pipelined one-wave sweep (ens_pipe_kernel<.., FLAT>)
+      one_wave = (ENS_PIPE and kind == 'ens' and dtype_code == _hip.F32 and ens['algo'] == 0 and ens['M'] <= 64
+                  and not (flags & (_hip.FLAG_MASKED | _hip.FLAG_SKIPNA | _hip.FLAG_SKIPNA_ENS)))
+      hit = _planned(ctx, kind, dims, sizes, layouts, reduce_dims, set(), gather, flags, xw, one_wave=one_wave)
       if hit[0].plane_rows > 0 and dtype_code == _hip.F32:  # the flat float4 sweep applies (contiguous aligned planes)
         x_weights, wdep, w_da = xw, set(), None
       else:

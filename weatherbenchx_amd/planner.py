@@ -25,6 +25,9 @@ TARGET_BLOCKS = 4096  # >> 256 CUs * resident blocks, so the tail is short
 # geometry of the flat one-point-per-lane sweep (s1_xf1_kernel): threads per block, fewest elements per block
 FLAT1_THREADS = int(os.environ.get('WBX_FLAT1_THREADS', '256'))
 FLAT1_MIN_ELEMENTS = int(os.environ.get('WBX_FLAT1_MIN_ELEMENTS', '2816'))
+# ... and of its one-wave flavour (ens_pipe_kernel<.., FLAT>): elements per block, unless that leaves fewer blocks than this
+FLAT64_MIN_ELEMENTS = int(os.environ.get('WBX_FLAT64_MIN_ELEMENTS', '2816'))
+FLAT64_MIN_BLOCKS = int(os.environ.get('WBX_FLAT64_MIN_BLOCKS', '18432'))
 
 
 @dataclasses.dataclass
@@ -150,7 +153,7 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
                   fold_x: bool = False) -> S1Plan:
   """Plans stage 1.  `layouts[i]` is None for unused inputs.  `map_mode` keeps every dim (nchunk=1).  `fold_x`: the
   caller folds weights on the innermost dim into stage 1 (S1Plan.x_weights), so x is summed here; when the inner depth
-  rows are contiguous the flat float4 sweep is planned (plane_rows = their count, see s1_xf_kernel); fold_x='point' plans
+  rows are contiguous the flat float4 sweep is planned (plane_rows = their count, see s1_xf_kernel); fold_x='point' / 'point64' plans
   the one-point-per-lane flavour of it (s1_xf1_kernel, ensemble statistics)."""
   dims = tuple(dims)
   sizes = {d: int(sizes[d]) for d in dims}
@@ -281,7 +284,7 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
       depth_chunk = -(-depth_chunk // plane_rows) * plane_rows
       nchunk = -(-ndepth // depth_chunk)
 
-  if fold_x == 'point':
+  if fold_x in ('point', 'point64'):
     # one point per lane (ensemble kernels): the generic chunking stands, rows only have to be one contiguous run
     if not x_kept and not (flags & ~7) and x_dim is not None and depth_dims and nx <= 2048 and gather is None:
       inner = depth_dims[-1]
@@ -296,6 +299,13 @@ def build_s1_plan(dims: Sequence, sizes: dict, layouts: Sequence[InputLayout | N
         # (256, 4..8) 0.407, (256, 15) 0.415; the x-kept kernel on the same data 0.452, longitude-fastest data 0.397
         block_threads = FLAT1_THREADS
         depth_chunk = min(max(depth_chunk, -(-FLAT1_MIN_ELEMENTS // nx)), ndepth)
+        if fold_x == 'point64':
+          # one-wave blocks for the pipelined ensemble sweep (ens_pipe_kernel<.., FLAT>): a chunk's first and last tile
+          # are shared with its neighbours (a 64-element piece each, fetched by both), so chunks are a few rows long, but
+          # short enough for >= ~6 rounds of the 3072 resident waves
+          block_threads = 64
+          rows = max(1, -(-FLAT64_MIN_ELEMENTS // nx))
+          depth_chunk = int(min(max(1, min(rows, (nkey * ndepth) // FLAT64_MIN_BLOCKS)), ndepth))
         nchunk = -(-ndepth // depth_chunk)
   elif fold_x and not x_kept and not map_mode and not (flags & 2) and x_dim is not None and depth_dims and nx + 3 <= 2048:
     inner = depth_dims[-1]
