@@ -390,6 +390,12 @@ class Context:
       check(self.lib.wbx_memcpy_d2h_async(self.handle, C.c_void_p(block.ptr), C.c_void_p(ptr), nbytes), 'wbx_memcpy_d2h_async')
     return np.asarray(block).reshape(shape)
 
+  def pinned_result(self, shape) -> np.ndarray:
+    """Pooled page-locked float64 array a kernel writes its result into directly (device-visible: wbx_host_alloc);
+    the caller orders its reads with a Fence recorded after that kernel."""
+    n = int(np.prod(shape, dtype=np.int64))
+    return np.asarray(self._pinned_block(n * 8)).reshape(shape)
+
   def fence(self) -> Fence:
     return Fence(self)
 

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
     for (int64_t rb = rbeg; rb < rend; rb += 64) {
       // lane j resolves row rb + j through the plan's tables; the sweep below broadcasts them one by one
       const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
-      const int64_t br = rmine / a.D;
+      const int64_t br = rmine < ((int64_t)1 << 31) && a.D < ((int64_t)1 << 31) ? (int64_t)((uint32_t)rmine / (uint32_t)a.D) : rmine / a.D;
       const int64_t d = rmine - br * a.D;
       const int64_t key = (A * g.nBk + bk) * g.nBr + br;
       int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
@@ -247,7 +247,11 @@ __global__ void __launch_bounds__(64 * BINNED_WPB) det_binned_kernel(S1Args a, B
 // pre-pass per launch).  The kernel is bound by the texture addresser -- a wave64 load costs it 16 cycles whatever its width,
 // and a row was five of them (p, t, c, mask, atom id): four now.
 template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = false>
-__global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
+#ifndef WBX_ATOMS_WAVES
+#define WBX_ATOMS_WAVES 4  // waves per SIMD the register budget is cut for (111 VGPRs as it falls)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WBX_ATOMS_WAVES, WBX_ATOMS_WAVES)))
+det_atoms_kernel(S1Args a, BinnedArgs g) {
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
@@ -265,7 +269,11 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const int64_t patch = (int64_t)rs * g.nxt + xt;
   const int nw = g.nwords[bk * npatch + patch];
-  if (nw < 0) return;  // too many atoms: det_binned_kernel takes this patch
+  double* const out = g.tmp + (cell * npatch + patch) * (NA * (int64_t)g.nbin);
+  if (nw < 0) {  // too many atoms: det_binned_kernel takes this patch (it adds into zeros: nobody memsets tmp in this mode)
+    for (int pr = lane; pr < NA * g.nbin; pr += 64) out[pr] = 0.0;
+    return;
+  }
   for (int i = lane; i < ATOM_MAX * NA; i += 64) tab[i] = 0.0;
   if (lane < ATOM_MAX) wlist[lane] = g.words[(bk * npatch + patch) * ATOM_MAX + lane];
   __syncthreads();  // (one wave per block: the barriers only pin the order of the LDS accesses for the compiler)
@@ -292,7 +300,13 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   // Flush BOTH entries of EVERY lane into the LDS table and empty the caches: lanes are grouped by atom id, one DPP wave
   // sum per (group, statistic).  Evicting lane by lane was measured 1.3x slower overall: after a region edge every lane
   // drops its stale entries at a different row (when it next crosses a coast), and each of those rows paid a flush.
-  auto flush_all = [&]() {
+  auto flush_all = [&](bool at_end = true) {
+#ifdef WBX_DIAG_NOFLUSH  // timing diagnostic (wrong sums): what do the flushes in the middle of a sweep cost?
+    if (!at_end) {
+      c0 = c1 = NONE;
+      return;
+    }
+#endif
 #pragma unroll 1
     for (int e = 0; e < 2; ++e) {  // (not unrolled: this code is inlined at every row position of the sweeps)
       const int id = e ? c1 : c0;
@@ -325,7 +339,7 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
       // a lane with both entries taken meets a third atom (a region edge: the same row for most lanes): start over
       bool place = miss;
       if (__builtin_amdgcn_ballot_w64(miss && c0 != NONE && c1 != NONE)) {
-        flush_all();
+        flush_all(false);
         place = ok;  // every entry is empty now: the lanes that had a hit re-enter their atom too
       }
       if (place && c0 == NONE) c0 = id;
@@ -373,7 +387,8 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   for (int64_t rb = rbeg; rb < rend; rb += 64) {
     // lane j resolves row rb + j through the plan's tables (key / depth offsets, the climatology gather)
     const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
-    const int64_t br = rmine / a.D;
+    // (a 64-bit divide is a ~250-instruction sequence, paid per 64 rows: the row count fits 31 bits on every real chunk)
+    const int64_t br = R < ((int64_t)1 << 31) ? (int64_t)((uint32_t)rmine / (uint32_t)a.D) : rmine / a.D;
     const int64_t d = rmine - br * a.D;
     const int64_t key = (A * g.nBk + bk) * g.nBr + br;
     int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
@@ -479,17 +494,14 @@ __global__ void __launch_bounds__(64) det_atoms_kernel(S1Args a, BinnedArgs g) {
   // ---- atoms -> bins: thread (bin of the union, statistic) sums the atoms that carry the bin's bit
   unsigned long long uni = 0ull;
   for (int k = 0; k < nw; ++k) uni |= wlist[k];
-  const int npair = __builtin_popcountll(uni) * NA;
-  double* const out = g.tmp + (cell * npatch + patch) * (NA * (int64_t)g.nbin);
-  for (int pr = lane; pr < npair; pr += 64) {
-    const int bi = pr / NA, l = pr - bi * NA;
-    unsigned long long u = uni;
-    for (int q = 0; q < bi; ++q) u &= u - 1ull;
-    const int bit = __builtin_ctzll(u);
+  // every (statistic, bin) of the patch is written, zeros for the bins outside the union: det_binned_finish sums plain rows
+  for (int pr = lane; pr < NA * g.nbin; pr += 64) {
+    const int l = pr / g.nbin, bit = pr - l * g.nbin;
     double s = 0.0;
-    for (int k = 0; k < nw; ++k)
-      if ((wlist[k] >> bit) & 1ull) s += tab[k * NA + l];
-    out[(int64_t)l * g.nbin + bit] = s;
+    if ((uni >> bit) & 1ull)
+      for (int k = 0; k < nw; ++k)
+        if ((wlist[k] >> bit) & 1ull) s += tab[k * NA + l];
+    out[pr] = s;
   }
   if (lane < NA) {
     double ps = 0.0;
@@ -531,7 +543,8 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   for (int i = 0; i < WBX_MAX_INPUTS; ++i)
     if ((plan->nx - 1) * plan->xstride[i] >= ((int64_t)1 << 31) / (int64_t)sizeof(double) || plan->xstride[i] < 0) atoms = false;
   BinnedArgs g;
-  if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin, atoms, atoms ? prepared : nullptr)) return rc;
+  if (int rc = patch_setup(ctx, g, wt, bits, nA * nBk, nBk, nBr, nj, plan->ndepth, plan->nx, NA, nbin, atoms, atoms ? prepared : nullptr, atoms))
+    return rc;
   const int64_t grid = patch_grid<BINNED_WPB>(g);
   if (atoms) {
     const int64_t agrid = patch_grid<1>(g);

@@ -2,6 +2,7 @@
 // full-map partials): per-wave patches of the (row, x) plane, the union of a patch's bins, slot dealing, the final sum
 // over patches.  See the header comment of wbx_det_binned.hip for the design.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -192,7 +193,8 @@ inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nB
   g.nxt = (int)((nx + 63) / 64);
   // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
   // (the lane fold at the end of a patch costs about as much as 10 rows)
-  int64_t want = (16384 + cells * g.nxt - 1) / (cells * g.nxt);
+  static const int64_t target = getenv("WBX_BINNED_TARGET_WAVES") ? atol(getenv("WBX_BINNED_TARGET_WAVES")) : 8192;
+  int64_t want = (target + cells * g.nxt - 1) / (cells * g.nxt);
   if (want > (rows + 63) / 64) want = (rows + 63) / 64;
   if (want < 1) want = 1;
   g.rows_per_split = (rows + want - 1) / want;
@@ -233,7 +235,7 @@ inline int atoms_launch(wbx_ctx* ctx, BinnedArgs& g, const uint64_t* bits, int64
 // nacc = accumulated lanes.
 inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
                        int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false,
-                       const void* prepared = nullptr) {
+                       const void* prepared = nullptr, bool tmp_written_by_kernels = false) {
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
   g.nbin = nbin;
@@ -254,7 +256,9 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   }
   g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
   g.tmp_poison = g.tmp + n_tmp;
-  WBX_HIP(hipMemsetAsync(g.tmp, 0, n_tmp * sizeof(double), ctx->stream));
+  // (det_atoms_kernel writes every bin of every patch itself -- zeros for the patches it leaves to the slot kernel --, so
+  // the 29 MB memset of a public-benchmark chunk, 12 us + a dependency gap in front of a 0.39 ms kernel, is not needed there)
+  if (!tmp_written_by_kernels) WBX_HIP(hipMemsetAsync(g.tmp, 0, n_tmp * sizeof(double), ctx->stream));
   WBX_REQUIRE((g.nblocks + 7) / 8 * 8 < (int64_t)1 << 31, "patch grid too large");
   if (prepared) {
     atoms_carve(g, const_cast<void*>(prepared));

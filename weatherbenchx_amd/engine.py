@@ -667,10 +667,36 @@ def synchronous_results():
     _deferred, _accum = saved, saved_acc
 
 
+# Under deferred_results() (and no accumulation) a reduction whose LAST kernel writes every element of its result exactly
+# once writes it straight into page-locked host memory: the separate device-to-host copy -- a blit kernel behind ~12 us
+# of dependency latency, 5 % of a public-benchmark chunk -- disappears.
+DIRECT_RESULTS = os.environ.get('WBX_DIRECT_RESULTS', '1') != '0'
+
+
+class _HostResult:
+  """A result that its kernel has been told to write into page-locked host memory (`view`, valid after the state's fence)."""
+
+  def __init__(self, view):
+    self.view = view
+
+
+def _result_target(ctx, shape, scratch_name):
+  """(pointer the kernel writes its float64 `shape` result to, what to hand to _deliver)."""
+  n = int(np.prod(shape, dtype=np.int64))
+  if DIRECT_RESULTS and _deferred is not None and _accum is None and n:
+    view = ctx.pinned_result(shape)
+    return view.ctypes.data, _HostResult(view)
+  out = _scratch(ctx, scratch_name, n * 8)
+  return out.ptr, out.ptr
+
+
 def _deliver(ctx, ptr, shape) -> np.ndarray:
   """Hands a finished device result (float64 `shape` at `ptr`) to the caller: added into the active accumulation
   (the returned view only carries the layout, see Accumulation), read back asynchronously under deferred_results(),
   or downloaded right away."""
+  if isinstance(ptr, _HostResult):  # already on its way into page-locked memory (_result_target)
+    _deferred.ctxs[id(ctx)] = ctx
+    return ptr.view
   if _accum is not None:
     if _deferred is not None:
       _deferred.ctxs[id(ctx)] = ctx
@@ -940,7 +966,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
   nbin = w_buf.shape[-1]
   shape = (nA, nBk, nl_total, 1, nbin)
-  out = _scratch(ctx, 's2out', int(np.prod(shape, dtype=np.int64)) * 8)
+  out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   w_flags = _hip.BINNED_W_ON_X if (plan.x_kept and plan.nj > 1) else 0
   wt_buf = w_buf.bufs[0]
@@ -971,9 +997,9 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
                                       ptr(devs[2]), ptr(devs[3]), C.c_void_p(wt_buf.ptr),
                                       C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags, nbin,
                                       C.c_void_p(atoms.ptr) if atoms is not None else None,
-                                      C.c_void_p(out.ptr)), 'wbx_det_binned')
+                                      C.c_void_p(out_ptr)), 'wbx_det_binned')
   timed_launch(ctx, call, kind='det_binned', nbin=nbin, w_flags=w_flags)
-  return out.ptr, shape
+  return handle, shape
 
 
 def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
