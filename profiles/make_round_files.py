@@ -95,6 +95,7 @@ def bench_key(name: str) -> str:
     return 'zspec1440_det_kernel'
   n = re.sub(r'DetOp<float, 1, \d>', 'DetOp<float,DET6>', n)
   n = re.sub(r'EnsOpF32<51, true, 0>', 'EnsOpF32<51,true,SORT>', n)
+  n = re.sub(r'EnsOpF32<51, true, 1>', 'EnsOpF32<51,true,PAIRWISE>', n)
   m = re.match(r's1_xr_kernel<(.*?), (\d), (?:false|true)>', n)
   if m:
     return f's1_xr_kernel<{m.group(1)},{m.group(2)}>'

@@ -193,7 +193,12 @@ inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nB
   g.nxt = (int)((nx + 63) / 64);
   // row splits: enough waves to fill the chip several times over, but >= 64 rows per patch where the data allows it
   // (the lane fold at the end of a patch costs about as much as 10 rows)
-  static const int64_t target = getenv("WBX_BINNED_TARGET_WAVES") ? atol(getenv("WBX_BINNED_TARGET_WAVES")) : 8192;
+  // (measured on the public-benchmark chunk: 3 splits of 241 rows 0.39 ms, 5 of 145 rows 0.41-0.42 ms on 1440-point rows --
+  // every patch and every 64-row batch pays a setup; rows that are not whole 128-byte lines (721 points) keep the shorter
+  // patches: their neighbouring x tiles share boundary lines, which only hit in L2 while the tiles walk the same rows at
+  // about the same time -- 5 splits of 288 rows fetched 1.21 x the algorithmic bytes, 9 of 160 rows 1.11 x)
+  static const int64_t target_env = getenv("WBX_BINNED_TARGET_WAVES") ? atol(getenv("WBX_BINNED_TARGET_WAVES")) : 0;
+  const int64_t target = target_env > 0 ? target_env : (nx % 32 == 0 ? 8192 : 16384);
   int64_t want = (target + cells * g.nxt - 1) / (cells * g.nxt);
   if (want > (rows + 63) / 64) want = (rows + 63) / 64;
   if (want < 1) want = 1;
