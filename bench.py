@@ -316,7 +316,7 @@ def _main_leg(env):
 
   result = {
       'metric': METRIC, 'value': value, 'unit': 'evals/s', 'n_gpus': env.world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+      'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32+f64',
       'data': 'synthetic',
       'config': {'workload': f'north_star: area-weighted CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + ensemble-mean RMSE on ONE '
                              f'f32[1 init,{nlev} level,{m} member,{env.nlat},{env.nlon}] forecast per GPU vs f32[1,{nlev},{env.nlat},{env.nlon}] '
