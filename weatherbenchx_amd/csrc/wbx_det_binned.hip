@@ -380,13 +380,16 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
           val[l] = fin ? val[l] : 0.0;
         }
       }
-      // the weight goes to the entry the point belongs to, 0 to the other (a NaN term reaches both: harmless, the
-      // poison rule makes every bin of that statistic NaN anyway)
-      const double f0 = hit0 ? w : 0.0, f1 = hit1 ? w : 0.0;
+      // each entry's FMAs run under its own lane mask (EXEC = the lanes whose point belongs to that entry) with the weight
+      // as it is -- a scalar register for row weights: no `hit ? w : 0` selects (four v_cndmask + two v_mov per row), and a
+      // row in which no lane uses an entry skips that entry's FMAs
+      if (hit0) {
 #pragma unroll
-      for (int l = 0; l < NA; ++l) {
-        acc0[l] = fma(val[l], f0, acc0[l]);
-        acc1[l] = fma(val[l], f1, acc1[l]);
+        for (int l = 0; l < NA; ++l) acc0[l] = fma(val[l], w, acc0[l]);
+      }
+      if (hit1) {
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc1[l] = fma(val[l], w, acc1[l]);
       }
     }
   };
