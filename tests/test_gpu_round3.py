@@ -515,12 +515,14 @@ def test_fused_and_separate_launches_agree_through_the_chunk_loop(ctx, monkeypat
 
 
 # ---- the pipelined sweep over latitude-fastest planes (ens_pipe_kernel<.., FLAT>) ----------------------------------------------
-@pytest.mark.parametrize('nlat,nlon,m', [(721, 96, 51), (97, 40, 51), (33, 50, 50), (181, 64, 16)])
+@pytest.mark.parametrize('nlat,nlon,m', [(721, 96, 51), (97, 40, 51), (33, 50, 50), (181, 64, 16), (97, 40, 13), (65, 48, 60),
+                                         (97, 24, 4), (129, 40, 32)])
 def test_latitude_fastest_planes_through_the_pipelined_sweep(ctx, nlat, nlon, m, monkeypatch):
   """Area-weighted ensemble suite on [init, level, member, longitude, latitude] arrays (the public IFS-ENS layout): the
   latitude weights are folded into stage 1 and the planes are walked flat by one-wave blocks.  Rows of 721 / 97 / 33 / 181
   floats put every chunk boundary inside a 64-element tile (the lanes in front of it are dropped), two inits make two planes
-  per key, a NaN member sits right in front of a chunk boundary and the weight index wraps inside a tile (nlat = 33 < 64).
+  per key, a NaN member sits right in front of a chunk boundary and the weight index wraps inside a tile (nlat = 33 < 64);
+  M = 13 and 60 run the padded buckets (16, 64), M = 4 and 32 the small exact ones.
   Against the float64 oracle per (level), and against the 256-thread flat sweep (s1_xf1_kernel) the same library runs when the
   engine does not ask for one-wave blocks."""
   rng = np.random.default_rng(nlat * 1000 + nlon)
@@ -529,7 +531,7 @@ def test_latitude_fastest_planes_through_the_pipelined_sweep(ctx, nlat, nlon, m,
   tv = (rng.normal(size=(ninit, nlev, nlon, nlat)) + 280).astype(np.float32)
   pv = (tv[:, :, None] + rng.normal(size=(ninit, nlev, m, nlon, nlat))).astype(np.float32)
   tv = (tv + rng.normal(size=tv.shape)).astype(np.float32)
-  pv[1, 2, 7, nlon // 2, nlat - 1] = np.nan  # the last point of a row: whatever chunk ends there ends on it
+  pv[1, 2, min(7, m - 1), nlon // 2, nlat - 1] = np.nan  # the last point of a row: whatever chunk ends there ends on it
   pd, td = ('init_time', 'level', 'number', 'longitude', 'latitude'), ('init_time', 'level', 'longitude', 'latitude')
   coords = {'init_time': np.array(['2020-01-01', '2020-01-02'], dtype='datetime64[ns]'), 'level': np.arange(nlev),
             'latitude': lat, 'longitude': lon}
