@@ -452,9 +452,9 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (EVEN) return cur[i];
         return readlane64(i == WBX_MAX_INPUTS ? wrow_v : ro[i], j);
       };
-      auto fetched = [&](int j) {  // row j has just been asked for
+      auto fetched = [&](int j, auto inside_tag) {  // row j has just been asked for
         if constexpr (EVEN) {
-          const bool more = j < last;
+          const bool more = decltype(inside_tag)::value || j < last;  // inside: row j + 1 exists, no test
 #pragma unroll
           for (int i = 0; i <= WBX_MAX_INPUTS; ++i) cur[i] += more ? step[i] : 0;
         }
@@ -464,7 +464,7 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (NT) return ld_stream(q);
         return *q;
       };
-      auto fetch = [&](int j, int u) {
+      auto fetch = [&](int j, int u, auto inside_tag) {
         rp[u] = operand(0, j);
         if constexpr (NIN > 1) rt[u] = operand(1, j);
         if constexpr (NIN > 2) rc[u] = operand(2, j);
@@ -475,12 +475,30 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
         if constexpr (WM == 1) rw[u] = w_lane;
         if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
-        fetched(j);
+        fetched(j, inside_tag);
       };
       // every load is unconditional (clamped row indices), see det_binned_kernel
 #pragma unroll
-      for (int u = 0; u < RD; ++u) fetch(u < last ? u : last, u);
-      for (int j = 0; j < nrow; j += RD) {
+      for (int u = 0; u < RD; ++u) fetch(u < last ? u : last, u, std::false_type{});
+      int j = 0;
+      if constexpr (EVEN) {
+        // The rows whose prefetch (RD rows ahead) and its successor both exist need no clamping and no `row < nrow` test: the
+        // scalar unit is what this kernel has too much work for (32 scalar instructions + 5.5 branches per row against 4 + 1.3
+        // in its load + arithmetic skeleton, tools/gpu_r3_binned_vs_skeleton.sh), and the clamp was 6 of them and a branch.
+        const int nmain = nrow > RD + 1 ? ((nrow - RD - 1) / RD) * RD : 0;
+        for (; j < nmain; j += RD) {
+#pragma unroll
+          for (int u = 0; u < RD; ++u) {
+            const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
+            const uint8_t tv = rv[u];
+            const double tw = rw[u];
+            const int tid = rid[u];
+            fetch(j + u + RD, u, std::true_type{});  // j + u + RD + 1 <= last
+            accumulate(tp, tt, tc, tv, tw, tid);
+          }
+        }
+      }
+      for (; j < nrow; j += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
           const int jj = j + u;
@@ -488,7 +506,7 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
           const uint8_t tv = rv[u];
           const double tw = rw[u];
           const int tid = rid[u];
-          fetch(jj + RD < last ? jj + RD : last, u);
+          fetch(jj + RD < last ? jj + RD : last, u, std::false_type{});
           if (jj < nrow) accumulate(tp, tt, tc, tv, tw, tid);  // wave-uniform
         }
       }
