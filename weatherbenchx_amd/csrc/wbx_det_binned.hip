@@ -439,9 +439,11 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
     auto sweep = [&](auto even_tag, auto depth_tag) {
       constexpr bool EVEN = decltype(even_tag)::value;
       constexpr int RD = decltype(depth_tag)::value;
-      T rp[RD], rt[RD], rc[RD];
-      uint8_t rv[RD], rid[RD];
-      double rw[RD];
+      struct Slots {  // the rows in flight
+        T p[RD], t[RD], c[RD];
+        uint8_t v[RD], id[RD];
+        double w[RD];
+      };
       // EVEN: the row offsets of the NEXT fetch, stepped by scalar additions.  Fetches ask for rows 0, 1, 2, ... in order and
       // stay on the last row once they reach it, so `base + j * step` (a 64-bit scalar multiplication per input and row:
       // 24 of the 41 scalar instructions a row cost in round 2; public chunk 0.443 -> 0.415 ms) is never needed.
@@ -464,22 +466,23 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (NT) return ld_stream(q);
         return *q;
       };
-      auto fetch = [&](int j, int u, auto inside_tag) {
-        rp[u] = operand(0, j);
-        if constexpr (NIN > 1) rt[u] = operand(1, j);
-        if constexpr (NIN > 2) rc[u] = operand(2, j);
-        rv[u] = 1;
-        if constexpr (has_mask && !MERGED) rv[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
+      auto fetch = [&](Slots& S, int j, int u, auto inside_tag) {
+        S.p[u] = operand(0, j);
+        if constexpr (NIN > 1) S.t[u] = operand(1, j);
+        if constexpr (NIN > 2) S.c[u] = operand(2, j);
+        S.v[u] = 1;
+        if constexpr (has_mask && !MERGED) S.v[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
         const int64_t wi = row_of(WBX_MAX_INPUTS, j);
-        rid[u] = ((MERGED ? g.aidm : g.aid) + wi)[xw];
-        if constexpr (WM == 0) rw[u] = (g.wt + wi)[xw];
-        if constexpr (WM == 1) rw[u] = w_lane;
-        if constexpr (WM == 2) rw[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+        S.id[u] = ((MERGED ? g.aidm : g.aid) + wi)[xw];
+        if constexpr (WM == 0) S.w[u] = (g.wt + wi)[xw];
+        if constexpr (WM == 1) S.w[u] = w_lane;
+        if constexpr (WM == 2) S.w[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
         fetched(j, inside_tag);
       };
       // every load is unconditional (clamped row indices), see det_binned_kernel
+      Slots A;
 #pragma unroll
-      for (int u = 0; u < RD; ++u) fetch(u < last ? u : last, u, std::false_type{});
+      for (int u = 0; u < RD; ++u) fetch(A, u < last ? u : last, u, std::false_type{});
       int j = 0;
       if constexpr (EVEN) {
         // The rows whose prefetch (RD rows ahead) and its successor both exist need no clamping and no `row < nrow` test: the
@@ -489,24 +492,27 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         for (; j < nmain; j += RD) {
 #pragma unroll
           for (int u = 0; u < RD; ++u) {
-            const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
-            const uint8_t tv = rv[u];
-            const double tw = rw[u];
-            const int tid = rid[u];
-            fetch(j + u + RD, u, std::true_type{});  // j + u + RD + 1 <= last
+            const T tp = A.p[u], tt = NIN > 1 ? A.t[u] : T(0), tc = NIN > 2 ? A.c[u] : T(0);
+            const uint8_t tv = A.v[u];
+            const double tw = A.w[u];
+            const int tid = A.id[u];
+            // (consumed first, asked for again second: the load then lands in the registers it replaces -- the other order made
+            // the compiler rotate the slots with v_mov at the back edge, behind an `s_waitcnt vmcnt(1)` that drained the queue)
             accumulate(tp, tt, tc, tv, tw, tid);
+            fetch(A, j + u + RD, u, std::true_type{});  // j + u + RD + 1 <= last
           }
         }
       }
+      Slots B = A;  // (the tail's own copy: its loop-carried registers are not tied to the loop above)
       for (; j < nrow; j += RD) {
 #pragma unroll
         for (int u = 0; u < RD; ++u) {
           const int jj = j + u;
-          const T tp = rp[u], tt = NIN > 1 ? rt[u] : T(0), tc = NIN > 2 ? rc[u] : T(0);
-          const uint8_t tv = rv[u];
-          const double tw = rw[u];
-          const int tid = rid[u];
-          fetch(jj + RD < last ? jj + RD : last, u, std::false_type{});
+          const T tp = B.p[u], tt = NIN > 1 ? B.t[u] : T(0), tc = NIN > 2 ? B.c[u] : T(0);
+          const uint8_t tv = B.v[u];
+          const double tw = B.w[u];
+          const int tid = B.id[u];
+          fetch(B, jj + RD < last ? jj + RD : last, u, std::false_type{});
           if (jj < nrow) accumulate(tp, tt, tc, tv, tw, tid);  // wave-uniform
         }
       }
