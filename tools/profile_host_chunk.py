@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side profile of bench.py's public-chunk loop: cProfile around the timed loop only (the kernels run asynchronously, so
-what is listed is what the Python side of a chunk costs).  usage: python tools/profile_host_chunk.py [lon_fastest|lat_fastest]"""
+what is listed is what the Python side of a chunk costs).  usage: python tools/profile_host_chunk.py [lon_fastest|lat_fastest] [--small]"""
 import cProfile
 import os
 import pstats
@@ -9,8 +9,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ['bench.py', '--legs', 'public_chunk', '--no-cpu', '--no-config5', '--steps', '300', '--warmup', '20',
-            '--layout', sys.argv[1] if len(sys.argv) > 1 else 'lon_fastest']
+sys.argv = (['bench.py'] + (['--small'] if '--small' in sys.argv else []) +  # --small: tiny grids = the Python cost alone
+            ['--legs', 'public_chunk', '--no-cpu', '--no-config5', '--steps', '300', '--warmup', '20',
+             '--layout', 'lat_fastest' if 'lat_fastest' in sys.argv else 'lon_fastest'])
 import bench  # noqa: E402
 
 prof = cProfile.Profile()

@@ -77,7 +77,15 @@ class AggregationState:
 
   def mean_statistics(self) -> Any:
     self.wait()
-    return xarray_tree.map_structure(lambda num, den: num / den, self.sum_weighted_statistics, self.sum_weights)
+
+    def mean(num, den):
+      # numerator and denominator of one reduction sit on the identical frame: one numpy division, no joins
+      if (type(num) is xr.DataArray and type(den) is xr.DataArray and isinstance(num._data, np.ndarray)  # pylint: disable=protected-access,unidiomatic-typecheck
+          and isinstance(den._data, np.ndarray) and num._data.shape == den._data.shape and xr._same_frame(num, den)):  # pylint: disable=protected-access
+        return num._replace(data=np.true_divide(num._data, den._data))  # pylint: disable=protected-access
+      return num / den
+    with np.errstate(all='ignore'):
+      return xarray_tree.map_structure(mean, self.sum_weighted_statistics, self.sum_weights)
 
   def metric_values(self, metrics: Mapping[str, metrics_base.Metric]) -> xr.Dataset:
     """Dataset of `<metric>.<variable>` values (aggregation.py:122-148)."""
@@ -259,7 +267,13 @@ class Aggregator:
 
   def aggregate_statistics(self, statistics: Mapping[str, Mapping[Hashable, xr.DataArray]]) -> AggregationState:
     self.note_statistics(statistics)
-    per_stat = {name: self._stat_vars(stats) for name, stats in statistics.items()}
+    # (the statistics of one call usually sit on the same frame -- the very same coordinate arrays: their weight product
+    # is looked up once per call by identity instead of once per statistic by content hash)
+    self.__dict__['_w_call_memo'] = {}
+    try:
+      per_stat = {name: self._stat_vars(stats) for name, stats in statistics.items()}
+    finally:
+      self.__dict__.pop('_w_call_memo', None)
     return _fenced(AggregationState({k: v.sum_weighted_statistics for k, v in per_stat.items()},
                                     {k: v.sum_weights for k, v in per_stat.items()}))
 
@@ -362,7 +376,16 @@ class Aggregator:
     known = (weighting.GridAreaWeighting, binning.Regions, binning.LandSea)
     plugins = tuple(self.weigh_by or ()) + tuple(self.bin_by or ())
     if not all(isinstance(m, known) for m in plugins):
-      return _weight_product(stat, self.weigh_by, self.bin_by)
+      return _weight_product(stat, self.weigh_by, self.bin_by)  # (a user plugin may look at the statistic's values)
+    memo = self.__dict__.get('_w_call_memo')  # set for the duration of one aggregate_statistics call
+    if memo is None:
+      return self._weight_product_by_content(stat, plugins)
+    mkey = (stat.dims, stat.shape, tuple((k, id(v[1])) for k, v in stat._coords.items()))  # pylint: disable=protected-access
+    if mkey not in memo:
+      memo[mkey] = self._weight_product_by_content(stat, plugins)
+    return memo[mkey]
+
+  def _weight_product_by_content(self, stat: xr.DataArray, plugins):
     cache = self.__dict__.setdefault('_w_products', {})
     hints = self.__dict__.setdefault('_w_dep_hints', {})
     # ids stay unique while the cache entry holds the objects (stored next to the product)

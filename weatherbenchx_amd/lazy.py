@@ -319,7 +319,10 @@ def det_statistic(stat_name: str, p, t, climatology_ref: ClimatologyRef | None =
   p, t = xr.as_dataarray(p), xr.as_dataarray(t)
   if isinstance(p, LazyEnsembleMean) and p.is_lazy and stat_name == 'SquaredError':
     return ens_statistic('EnsembleMeanSquaredError', p._source, t, p._ensemble_dim)  # pylint: disable=protected-access
-  p, t = _aligned(p, t)
+  table = p.__dict__.get('_wbx_groups')
+  if not (table and any(k[0] == 'det' and k[1] == id(t) and k[2] == t.__dict__.get('_mutations', 0) and v[0]() is t
+                        for k, v in table.items())):
+    p, t = _aligned(p, t)  # (a group of these very objects exists: an earlier statistic has checked their frames)
   # one group per (p, t): Error/AbsoluteError/SquaredError and the anomaly statistics of the FIRST
   # climatology share a launch; a second, different climatology gets its own group.
   grp = _group_for('det', p, t)
