@@ -246,3 +246,34 @@ def test_climatology_index_tables_follow_the_time_labels(backend, monkeypatch):
   for day in (3, 5, 7, 9, 3, 13, 15, 5, 1):
     run(day)
   assert len(builds) == 1, builds
+
+
+def test_a_fused_group_dies_with_its_statistics_without_the_cyclic_collector():
+  """The arrays keep a table of the fused groups built on them so that statistics of the same (p, t) share one launch; that
+  table must not keep the groups alive (round 3: a strong p -> table -> group -> p cycle held a chunk's cached result
+  buffers -- pooled page-locked / device memory -- until the garbage collector ran, and chunk loops allocated fresh memory
+  job after job).  With the collector off, dropping the statistics must free the group at once."""
+  import gc
+  import weakref
+  from weatherbenchx_amd import lazy
+  rng = np.random.default_rng(0)
+  coords = {'latitude': np.linspace(-80, 80, 5), 'longitude': np.arange(8) * 45.0}
+  p = xr.DataArray(rng.normal(size=(5, 8)).astype(np.float32), dims=('latitude', 'longitude'), coords=coords)
+  t = xr.DataArray(rng.normal(size=(5, 8)).astype(np.float32), dims=('latitude', 'longitude'), coords=coords)
+  gc.collect()
+  gc.disable()
+  try:
+    a = lazy.det_statistic('SquaredError', p, t)
+    b = lazy.det_statistic('Error', p, t)
+    assert a._group is b._group  # pylint: disable=protected-access
+    ref = weakref.ref(a._group)  # pylint: disable=protected-access
+    del a
+    assert ref() is not None  # b still uses it
+    c = lazy.det_statistic('AbsoluteError', p, t)
+    assert c._group is ref()  # pylint: disable=protected-access
+    del b, c
+    assert ref() is None, 'the group outlived its statistics: a reference cycle through the array'
+    d = lazy.det_statistic('SquaredError', p, t)  # a fresh group on the same arrays
+    assert d._group is not None  # pylint: disable=protected-access
+  finally:
+    gc.enable()
