@@ -277,3 +277,36 @@ def test_a_fused_group_dies_with_its_statistics_without_the_cyclic_collector():
     assert d._group is not None  # pylint: disable=protected-access
   finally:
     gc.enable()
+
+
+def test_a_warm_evaluation_step_leaves_nothing_for_the_cyclic_collector(backend):
+  """Deterministic + ensemble statistics through an aggregator with deferred read-back, fresh arrays every step (what a
+  chunk loop does): once warm, a step must not leave reference cycles behind -- result buffers come from pools, and a
+  buffer caught in a cycle returns to its pool only when the collector runs."""
+  rng = np.random.default_rng(3)
+  coords = {'latitude': LAT, 'longitude': LON}
+  p, t = _fields(3)
+  ep = xr.DataArray(rng.normal(size=(5, 32, 64)).astype(np.float32), dims=('number', 'latitude', 'longitude'), coords=coords)
+  et = xr.DataArray(rng.normal(size=(32, 64)).astype(np.float32), dims=('latitude', 'longitude'), coords=coords)
+  det = {'mse': deterministic.MSE(), 'bias': deterministic.Bias()}
+  ens = {'crps': probabilistic.CRPSEnsemble(), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS_A)])
+  fresh = lambda a: xr.DataArray(a.data, dims=a.dims, coords={c: a[c].values for c in a.dims})
+
+  def step():
+    with engine.deferred_results():
+      a = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(det, {'v': fresh(p)}, {'v': fresh(t)}))
+      b = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(ens, {'v': fresh(ep)}, {'v': fresh(et)}))
+      return float(a.metric_values(det)['mse.v'].values.sum()) + float(b.metric_values(ens)['crps.v'].values.sum())
+
+  for _ in range(3):
+    step()
+  gc.collect()
+  gc.disable()
+  try:
+    for _ in range(3):
+      step()
+    assert gc.collect() == 0, 'a warm step left reference cycles behind'
+  finally:
+    gc.enable()
