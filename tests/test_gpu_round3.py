@@ -572,3 +572,4 @@ def test_latitude_fastest_planes_through_the_pipelined_sweep(ctx, nlat, nlon, m,
     assert np.isnan(got[k][2]) and np.isnan(want[k][2]) and np.isnan(ref[k][2]), k  # the NaN member poisons its level only
     np.testing.assert_allclose(got[k][:2], want[k][:2], rtol=RTOL, err_msg=k)
     np.testing.assert_allclose(got[k][:2], ref[k][:2], rtol=RTOL, err_msg=k + ' (256-thread sweep)')
+

@@ -1,6 +1,6 @@
 """Times wbx_det_binned on the public-benchmark chunk (HIP events, 10 launches per pair) for both layouts and two
 land-sea masks (smooth continents / random points); prints one JSON line.  The kernel variant comes from the
-environment: WBX_BINNED_ATOMS=0|1, WBX_ATOMS_NT=0|1.  usage: python tools/kbench_binned_ab.py [tag]"""
+environment: WBX_BINNED_ATOMS=0|1, WBX_ATOMS_NT=0|1, WBX_LIBRARY_PATH (A/B builds), WBX_KBENCH_LAYOUTS=lat_fastest.  usage: python tools/kbench_binned_ab.py [tag]"""
 import json
 import os
 import sys
@@ -18,7 +18,7 @@ lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
 out = {'tag': sys.argv[1] if len(sys.argv) > 1 else '', 'atoms': os.environ.get('WBX_BINNED_ATOMS', '1'),
        'nt': os.environ.get('WBX_ATOMS_NT', 'auto')}
 engine.BINNED_MODE = 'always'
-for layout in ('lon_fastest', 'lat_fastest'):
+for layout in os.environ.get('WBX_KBENCH_LAYOUTS', 'lon_fastest,lat_fastest').split(','):
   sp = ('longitude', 'latitude') if layout == 'lat_fastest' else ('latitude', 'longitude')
   dims = ('init_time', 'lead_time', 'level') + sp
   coords = {'init_time': np.array(['2020-01-01T00'], dtype='datetime64[ns]'),

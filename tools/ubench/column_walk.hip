@@ -7,7 +7,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
-constexpr int NX = 1440, NROW = 721, RR = 103;  // 7 row ranges per plane
+// -DCW_RAGGED: the latitude-fastest chunk instead (rows of 721 floats: not a whole number of 128-byte lines, so a wave load
+// touches three lines and neighbouring tiles share their boundary lines): 1440 rows of 721 points, 9 row ranges per plane,
+// with / without the non-temporal hint and with / without the XCD-contiguous block order of patch_decode (wbx_patch.hpp).
+#ifdef CW_RAGGED
+constexpr int NX = 721, NROW = 1440, RR = 160, NRANGE = 9;
+#else
+constexpr int NX = 1440, NROW = 721, RR = 103, NRANGE = 7;  // 7 row ranges per plane
+#endif
+template <bool NT, typename Q>
+__device__ __forceinline__ Q ld(const Q* q) {
+  if constexpr (NT) return __builtin_nontemporal_load(q);
+  else return *q;
+}
 
 template <int V>
 struct Vec;
@@ -17,15 +29,21 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 template <>
 struct Vec<2> { using F = float2v; using B = uint16_t; };
 
-template <int V, int PD, int WAVES>
+template <int V, int PD, int WAVES, bool NT = true, bool XCD = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WAVES))) walk_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ c,
-                                                  const uint8_t* __restrict__ aid, int ntile, double* out) {
+                                                  const uint8_t* __restrict__ aid, int ntile, int nplane, double* out) {
   using F = typename Vec<V>::F;
   using B = typename Vec<V>::B;
   const int lane = threadIdx.x;
   int b = blockIdx.x;
+  if constexpr (XCD) {  // blocks that follow each other in b run on ONE XCD (blockIdx.x round-robins over the eight)
+    const int per_xcd = (gridDim.x + 7) >> 3;
+    b = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (b >= (int)gridDim.x) return;
+  }
   const int tile = b % ntile; b /= ntile;
-  const int rr = b % 7; const int plane = b / 7;
+  const int rr = b % NRANGE; const int plane = b / NRANGE;
+  if (plane >= nplane) return;  // (the grid is rounded up to a multiple of 8)
   const int x = tile * 64 * V + lane * V;
   if (x >= NX) return;
   const int r0 = rr * RR, r1 = r0 + RR < NROW ? r0 + RR : NROW;
@@ -35,9 +53,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WAVE
   F fp[PD], ft[PD], fc[PD]; B fa[PD];
   auto load = [&](int r, int s) {
     const size_t o = base + (size_t)(r < r1 ? r : r1 - 1) * NX + x;
-    fp[s] = __builtin_nontemporal_load(reinterpret_cast<const F*>(p + o));
-    ft[s] = __builtin_nontemporal_load(reinterpret_cast<const F*>(t + o));
-    fc[s] = __builtin_nontemporal_load(reinterpret_cast<const F*>(c + o));  // a climatology plane per (lead, level): 12 B/point from HBM
+    fp[s] = ld<NT>(reinterpret_cast<const F*>(p + o));
+    ft[s] = ld<NT>(reinterpret_cast<const F*>(t + o));
+    fc[s] = ld<NT>(reinterpret_cast<const F*>(c + o));  // a climatology plane per (lead, level): 12 B/point from HBM
     fa[s] = *reinterpret_cast<const B*>(aid + (o % ((size_t)NROW * NX)));
   };
 #pragma unroll
@@ -67,11 +85,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, WAVE
   if (s == 1234.5) out[0] = s;
 }
 
-template <int V, int PD, int WAVES = 8>
+template <int V, int PD, int WAVES = 8, bool NT = true, bool XCD = false>
 void run(const char* name, const float* p, const float* t, const float* c, const uint8_t* aid, int nplane, double* out) {
   const int ntile = (NX + 64 * V - 1) / (64 * V);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  auto launch = [&] { hipLaunchKernelGGL((walk_kernel<V, PD, WAVES>), dim3(nplane * 7 * ntile), dim3(64), 0, 0, p, t, c, aid, ntile, out); };
+  auto launch = [&] { hipLaunchKernelGGL((walk_kernel<V, PD, WAVES, NT, XCD>), dim3((nplane * NRANGE * ntile + 7) / 8 * 8), dim3(64), 0, 0, p, t, c, aid, ntile, nplane, out); };
   launch(); (void)hipDeviceSynchronize();
   (void)hipEventRecord(a); for (int i = 0; i < 10; ++i) launch(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
   float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= 10;
@@ -86,6 +104,17 @@ int main() {
   (void)hipMalloc(&p, n * 4 + 64); (void)hipMalloc(&t, n * 4 + 64); (void)hipMalloc(&c, n * 4 + 64);
   (void)hipMalloc(&aid, (size_t)NROW * NX + 64); (void)hipMalloc(&out, 8);
   (void)hipMemset(p, 0, n * 4); (void)hipMemset(t, 0, n * 4); (void)hipMemset(c, 0, n * 4); (void)hipMemset(aid, 3, (size_t)NROW * NX);
+#ifdef CW_RAGGED
+  run<1, 4, 4, true, false>("721: nt loads, launch order", p, t, c, aid, nplane, out);
+  run<1, 4, 4, false, false>("721: plain loads, launch order", p, t, c, aid, nplane, out);
+  run<1, 4, 4, true, true>("721: nt loads, XCD-contiguous", p, t, c, aid, nplane, out);
+  run<1, 4, 4, false, true>("721: plain loads, XCD-contiguous", p, t, c, aid, nplane, out);
+  run<1, 8, 4, false, true>("721: plain, XCD, 8 rows ahead", p, t, c, aid, nplane, out);
+  run<1, 4, 6, false, true>("721: plain, XCD, <= 6 waves/SIMD", p, t, c, aid, nplane, out);
+  run<2, 4, 4, false, true>("721: plain, XCD, 2 columns/lane", p, t, c, aid, nplane, out);
+  run<2, 4, 4, true, true>("721: nt, XCD, 2 columns/lane", p, t, c, aid, nplane, out);
+  return 0;
+#endif
   run<1, 4>("1 column per lane, 4 rows ahead", p, t, c, aid, nplane, out);
   run<1, 8>("1 column per lane, 8 rows ahead", p, t, c, aid, nplane, out);
   run<2, 2>("2 columns per lane, 2 rows ahead", p, t, c, aid, nplane, out);

@@ -250,20 +250,33 @@ template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = f
 #ifndef WBX_ATOMS_WAVES
 #define WBX_ATOMS_WAVES 4  // waves per SIMD the register budget is cut for (111 VGPRs as it falls)
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WBX_ATOMS_WAVES, WBX_ATOMS_WAVES)))
+// On such rows (!NT) a block is FOUR waves on adjacent x tiles of one row range, meeting at a barrier every 64 rows: the line
+// two tiles share is asked for by both within a few rows and from one CU.  Same-box A/B on the latitude-fastest public chunk,
+// 1 / 2 / 3 / 4 / 6 / 12 waves per block (`make ab-wpb1 ...`, tools/gpu_r3_ragged_wpb.sh): 0.449 / 0.427 (one box: 0.434 /)
+// 0.427 / 0.440 / 0.428 / 0.493 / 0.465 ms -- 4 is 4-5 % faster than 1 on both boxes, 4 without the barrier 3.7 %; 6 and 12
+// leave wave slots of the CU empty (16 per CU at 111 VGPRs).
+#ifndef WBX_ATOMS_RAGGED_WPB
+#define WBX_ATOMS_RAGGED_WPB 4
+#endif
+__global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ATOMS_RAGGED_WPB))
+__attribute__((amdgpu_waves_per_eu(WBX_ATOMS_WAVES, WBX_ATOMS_WAVES)))
 det_atoms_kernel(S1Args a, BinnedArgs g) {
+  constexpr int W = NT ? 1 : WBX_ATOMS_RAGGED_WPB;
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NC = MM == 1 ? 1 : (MM >= 2 ? NL : 0);
   constexpr int NA = NL + NC;
   constexpr bool has_mask = MM == 1 || MM == 3;
   constexpr int NONE = 255;
-  __shared__ double tab[ATOM_MAX * NA];
-  __shared__ unsigned long long wlist[ATOM_MAX];
-  const int lane = threadIdx.x;
+  __shared__ double tab_all[W][ATOM_MAX * NA];
+  __shared__ unsigned long long wlist_all[W][ATOM_MAX];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = W > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  double* const tab = tab_all[wave_in_block];
+  unsigned long long* const wlist = wlist_all[wave_in_block];
   int64_t cell;
   int xt, rs;
-  if (!patch_decode<1>(g, cell, xt, rs)) return;
+  if (!patch_decode<W>(g, cell, xt, rs)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t A = cell / g.nBk;
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
@@ -395,6 +408,11 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
   };
 
   for (int64_t rb = rbeg; rb < rend; rb += 64) {
+    // W > 1: the waves of a block walk ADJACENT x tiles of the same rows and meet here every 64 rows, so a boundary line two
+    // tiles share is asked for by both within a few rows of each other (waves that have left the kernel do not count)
+#ifndef WBX_ATOMS_RAGGED_NOBARRIER  // (A/B: side by side on one CU, free-running)
+    if constexpr (W > 1) __builtin_amdgcn_s_barrier();
+#endif
     // lane j resolves row rb + j through the plan's tables (key / depth offsets, the climatology gather)
     const int64_t rmine = rb + lane < rend ? rb + lane : rend - 1;
     // (a 64-bit divide is a ~250-instruction sequence, paid per 64 rows: the row count fits 31 bits on every real chunk)
@@ -581,7 +599,8 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     return rc;
   const int64_t grid = patch_grid<BINNED_WPB>(g);
   if (atoms) {
-    const int64_t agrid = patch_grid<1>(g);
+    constexpr int RW = WBX_ATOMS_RAGGED_WPB;
+    const int64_t agrid1 = patch_grid<1>(g), agridw = patch_grid<RW>(g);
     static const int order_env = atoms_setting("WBX_PATCH_ORDER", -1);
     static const int nt_env = atoms_setting("WBX_ATOMS_NT", -1);
     const bool ragged_lines = (plan->nx * (int64_t)sizeof(T)) % 128 != 0;
@@ -614,11 +633,13 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     do {                                                                                                                                       \
       if constexpr (MM == 1) {                                                                                                                 \
         if (merged) {                                                                                                                          \
-          hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV, true>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g);   \
+          hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV, true>), dim3((unsigned)(NTV ? agrid1 : agridw)),                  \
+                             dim3(64 * (NTV ? 1 : RW)), 0, ctx->stream, a, g);                                                                \
           break;                                                                                                                               \
         }                                                                                                                                      \
       }                                                                                                                                        \
-      hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV>), dim3((unsigned)agrid), dim3(64), 0, ctx->stream, a, g);             \
+      hipLaunchKernelGGL((det_atoms_kernel<T, FUNC, MM, PDV, WMV, NTV>), dim3((unsigned)(NTV ? agrid1 : agridw)),                            \
+                         dim3(64 * (NTV ? 1 : RW)), 0, ctx->stream, a, g);                                                                    \
     } while (0)
 #define WBX_ATOMS_LAUNCH(PDV, WMV)                                  \
     do {                                                              \
