@@ -70,6 +70,8 @@ for d in $O/trace_*; do cp $d/r1_kernel_stats.csv $O/$(basename $d)_kernel_stats
 import sqlite3
 for k, c, n, v in sqlite3.connect('$O/ff$shift/r_results.db').execute(\"select substr(kernel_name, 1, 44), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%_kernel<%' group by 1, 2\"): print('   shift $shift', k, c, n, '%.0f' % v)"; done; rm -rf $O/ff0 $O/ff16 ) > $O/flat_fetch.txt 2>&1
 ( cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 column_walk.hip -o /tmp/column_walk 2>/dev/null && /tmp/column_walk ) > $O/column_walk.txt 2>&1
+( cd $R && bash tools/gpu_r3_ragged_walk.sh ) > $O/ragged_walk.txt 2>&1
+( cd $R && bash tools/gpu_r3_ragged_wpb.sh ) > $O/ragged_wpb.txt 2>&1
 ( cd $R && python tools/kbench_det_spectrum.py; echo "== climatology row through the LDS (make ab-zdlds)"; WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_zdlds.so python tools/kbench_det_spectrum.py ) > $O/kbench_det_spectrum.txt 2>&1
 ( cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 read_stream.hip -o read_stream 2>/dev/null; timeout 120 ./read_stream ) > $O/read_stream.json 2>&1
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
@@ -77,7 +79,7 @@ for k, c, n, v in sqlite3.connect('$O/ff$shift/r_results.db').execute(\"select s
 # 5. only the summaries travel back (gpurun merges at most 64 MiB): the raw rocprofv3 databases stay on the box
 python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r03} >> $O/make_round_files.log 2>&1
 mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r03}_* $R/gpurun_out/round/
-for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk; do cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r03}_$f.txt; done
+for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r03}_$f.txt; done
 rm -rf $O/trace_* $O/pmc_fetch_* $O/pmc_write_* $R/gpurun_out/pmc_ens $R/gpurun_out/pmc_spec
 find $O -maxdepth 1 -type d -name "*" | sed -n 2,100p | xargs -r rm -rf
 du -sh $R/gpurun_out
