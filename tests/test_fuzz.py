@@ -1,6 +1,8 @@
 """Randomised planner / Aggregator checks against the oracle: random dim orders, sizes, reduce sets, weights on
 random dims, boolean bins on random dims, masks and skipna -- every combination the two-stage reduction has to
 map onto (key, depth, x).  Runs on the NumPy plan interpreter (CPU) and on the HIP library (GPU)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,9 @@ from weatherbenchx_amd import weighting
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base as metrics_base
 from weatherbenchx_amd.metrics import deterministic
+
+# more seeds per family for a soak run: WBX_FUZZ_SCALE=10 python -m pytest tests/test_fuzz.py [-m gpu]
+FUZZ_SCALE = int(os.environ.get('WBX_FUZZ_SCALE', '1'))
 
 ALL_DIMS = ['init_time', 'lead_time', 'level', 'latitude', 'longitude', 'tile']
 
@@ -38,7 +43,7 @@ class RandomBins(binning.Binning):
     return xr.DataArray(self.mask, dims=(self.bin_dim_name,) + tuple(self.dims))
 
 
-@pytest.mark.parametrize('seed', range(80))
+@pytest.mark.parametrize('seed', range(80 * FUZZ_SCALE))
 def test_random_layouts_and_aggregators(backend, seed):
   rng = np.random.default_rng(1000 + seed)
   ndim = int(rng.integers(1, 6))
@@ -101,7 +106,7 @@ def test_random_layouts_and_aggregators(backend, seed):
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(40 * FUZZ_SCALE))
 def test_random_ensemble_layouts_and_aggregators(backend, seed):
   """The ensemble family on random layouts: the member dim anywhere in the prediction's dim order, targets in another
   order, random reduce sets, vector weights, boolean bins, masks / skipna -- whatever route the planner picks (x summed,
@@ -178,7 +183,7 @@ def test_random_ensemble_layouts_and_aggregators(backend, seed):
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
 
 
-@pytest.mark.parametrize('seed', range(30))
+@pytest.mark.parametrize('seed', range(30 * FUZZ_SCALE))
 def test_random_indicator_layouts_and_aggregators(backend, seed):
   """ErrorExceedance / EnsembleErrorExceedance / RankHistogram on random layouts (member dim anywhere, targets in another
   order), random reduce sets, weights, masks / skipna, NaN members and NaN thresholds, against the oracle."""
@@ -238,7 +243,7 @@ def test_random_indicator_layouts_and_aggregators(backend, seed):
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(40 * FUZZ_SCALE))
 def test_random_layouts_through_every_bin_route(monkeypatch, seed):
   """Host logic only (NumPy plan interpreter): with >= 5 boolean bins the engine may contract membership bits in stage 2
   or run the one-pass binned route; forcing either must give the oracle's sums on random layouts, reduce sets, weights
@@ -295,7 +300,79 @@ def test_random_layouts_through_every_bin_route(monkeypatch, seed):
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=route)
 
 
-@pytest.mark.parametrize('seed', range(25))
+@pytest.mark.parametrize('seed', range(36 * FUZZ_SCALE))
+def test_random_medium_layouts_through_every_bin_route(backend, monkeypatch, seed):
+  """The same on BOTH backends and at sizes where the one-pass binned kernels run several x tiles, several 64-row batches and
+  row splits per patch (x up to 257 points -- whole and ragged 128-byte lines --, up to ~600 reduced rows, a depth dim under
+  the bin dims or not), with few distinct membership words per patch (band-like bins: the atom kernel) or many (random
+  bins: the slot kernel), DET3 lanes (MSE + bias + MAE) and float32 / float64 inputs: forced binned route, forced two-stage
+  route, float64 oracle."""
+  from weatherbenchx_amd import engine
+  rng = np.random.default_rng(13000 + seed)
+  ndim = int(rng.integers(2, 5))
+  dims = list(rng.permutation(ALL_DIMS)[:ndim])
+  sizes = {d: int(rng.integers(1, 6)) for d in dims}
+  sizes[dims[-1]] = int(rng.choice([3, 64, 70, 96, 130, 200, 257]))
+  sizes[dims[int(rng.integers(0, ndim - 1))]] = int(rng.choice([7, 33, 64, 90, 150]))
+  shape = [sizes[d] for d in dims]
+  dtype = np.float32 if rng.random() < 0.75 else np.float64
+  pv = rng.normal(size=shape).astype(dtype)
+  tperm = list(rng.permutation(dims))
+  tv = rng.normal(size=[sizes[d] for d in tperm]).astype(dtype)
+  mode = rng.choice(['plain', 'masked', 'skipna'])
+  if mode != 'plain':
+    pv[rng.random(shape) < 0.02] = np.nan
+  p = xr.DataArray(pv, dims=dims)
+  t = xr.DataArray(tv, dims=tperm)
+  mask_arr = None
+  if mode == 'masked':
+    mask_arr = ~np.isnan(pv) & (rng.random(shape) > 0.2)
+    p.coords['mask'] = xr.DataArray(mask_arr, dims=dims)
+  bd = list(rng.permutation(dims)[:int(rng.integers(1, 3))])
+  nb = int(rng.choice([5, 9, 34, 40, 64]))
+  bshape = [sizes[d] for d in bd]
+  if rng.random() < 0.6:  # bands along the first bin dim, one global bin, a two-valued pattern on the rest: few words per patch
+    first = (np.arange(bshape[0]) * nb // max(bshape[0], 1))[None, :] == np.arange(nb)[:, None]
+    bm = np.broadcast_to(first.reshape([nb, bshape[0]] + [1] * (len(bd) - 1)), [nb] + bshape).copy()
+    bm[0] = True
+    if len(bd) > 1:
+      bm[1:] &= (rng.random(bshape) > 0.3)
+  else:
+    bm = rng.random([nb] + bshape) > 0.5
+  reduce_dims = sorted(set(bd) | {d for d in dims if rng.random() < 0.4}, key=dims.index)
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.4:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  te = O.expand_to(tv, tuple(tperm), tuple(dims))
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(dims))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  metrics = {'mse': deterministic.MSE(), 'bias': deterministic.Bias(), 'mae': deterministic.MAE()}
+  pd64, td64 = pv.astype(np.float64), te.astype(np.float64)
+  lanes = {'SquaredError': O.squared_error(pv, te), 'Error': pd64 - td64, 'AbsoluteError': np.abs(pd64 - td64)}
+  for route in ('always', 'never'):
+    monkeypatch.setattr(engine, 'BINNED_MODE', route)
+    engine.clear_caches()
+    agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, bin_by=[RandomBins('bin0', bd, bm)],
+                                 masked=(mode == 'masked'), skipna=(mode == 'skipna'))
+    stats = metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t})
+    state = agg.aggregate_statistics(stats)
+    for name, vals in lanes.items():
+      sws, sw, out_dims = O.aggregate(vals, tuple(dims), reduce_dims, weights=oracle_w,
+                                      bin_masks=[('bin0', bm, ('bin0',) + tuple(bd))], **okw)
+      got_s, got_w = state.sum_weighted_statistics[name]['v'], state.sum_weights[name]['v']
+      scale = np.nanmax(np.abs(sws)) if np.isfinite(sws).any() else 1.0
+      np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9 * max(scale, 1.0),
+                                 err_msg=f'{route} {name}')
+      np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=f'{route} {name}')
+
+
+@pytest.mark.parametrize('seed', range(25 * FUZZ_SCALE))
 def test_random_spectrum_frames(monkeypatch, seed):
   """Host logic only: longitude anywhere in the dim order, random kept dims, vector weights on row dims -- the row
   weights / group ids handed to the spectrum reduction must reproduce the weighted mean of the per-row spectra."""
