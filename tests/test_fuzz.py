@@ -183,6 +183,77 @@ def test_random_ensemble_layouts_and_aggregators(backend, seed):
     np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
 
 
+@pytest.mark.parametrize('seed', range(24 * FUZZ_SCALE))
+def test_random_medium_ensemble_layouts(backend, seed):
+  """The ensemble family at sizes and member counts where the register-sorting kernels run several tiles per block and the
+  pipelined sweeps their look-ahead (2-64 members incl. the padded buckets 3 / 17 / 50 / 51, x up to 257 points, a few
+  hundred rows, the member dim anywhere in the dim order, either spatial dim fastest): skill, spread (rank and pair form,
+  fair or not), variance and unbiased ensemble-mean MSE against the float64 oracle."""
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(15000 + seed)
+  ndim = int(rng.integers(2, 5))
+  dims = list(rng.permutation([d for d in ALL_DIMS if d != 'tile'])[:ndim])
+  sizes = {d: int(rng.integers(1, 4)) for d in dims}
+  sizes[dims[-1]] = int(rng.choice([64, 70, 130, 257]))
+  sizes[dims[int(rng.integers(0, ndim - 1))]] = int(rng.choice([7, 33, 90]))
+  use_sort = bool(rng.random() < 0.7)
+  m = int(rng.choice([2, 3, 8, 16, 17, 32, 50, 51, 64] if use_sort else [2, 3, 8, 16, 17]))
+  pdims = list(dims)
+  pdims.insert(int(rng.integers(0, ndim + 1)), 'number')
+  psizes = dict(sizes, number=m)
+  tperm = list(rng.permutation(dims))
+  offset, spread = float(rng.choice([0.0, 280.0])), float(rng.choice([1.0, 30.0]))
+  tv = (rng.normal(size=[sizes[d] for d in tperm]) * spread + offset).astype(np.float32)
+  pv = (rng.normal(size=[psizes[d] for d in pdims]) * spread + offset).astype(np.float32)
+  mode = rng.choice(['plain', 'plain', 'masked', 'skipna'])
+  if mode != 'plain':
+    tv[rng.random(tv.shape) < 0.02] = np.nan
+  t = xr.DataArray(tv, dims=tperm)
+  p = xr.DataArray(pv, dims=pdims)
+  mask_arr = None
+  if mode == 'masked':
+    mask_arr = ~np.isnan(tv) & (rng.random(tv.shape) > 0.2)
+    t.coords['mask'] = xr.DataArray(mask_arr, dims=tperm)
+  reduce_dims = [d for d in dims if rng.random() < 0.6]
+  weights, oracle_w = [], []
+  for d in dims:
+    if rng.random() < 0.4:
+      v = rng.random(sizes[d]) + 0.5
+      weights.append(VectorWeighting(d, v))
+      oracle_w.append((v, (d,)))
+  fair = bool(rng.random() < 0.7)
+  stats = {'skill': probabilistic.CRPSSkill(), 'spread': probabilistic.CRPSSpread(use_sort=use_sort, fair=fair),
+           'var': probabilistic.EnsembleVariance(), 'uemse': probabilistic.UnbiasedEnsembleMeanSquaredError()}
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=weights or None, masked=(mode == 'masked'),
+                               skipna=(mode == 'skipna'))
+  computed = {k: s.compute({'v': p}, {'v': t}) for k, s in stats.items()}
+  state = agg.aggregate_statistics(computed)
+  okw = {}
+  if mode == 'masked':
+    okw = dict(mask=mask_arr, mask_dims=tuple(tperm))
+  elif mode == 'skipna':
+    okw = dict(skipna=True)
+  pd_, td = tuple(pdims), tuple(tperm)
+  want = {'skill': O.crps_skill(pv, pd_, tv, td, 'number'), 'spread': O.crps_spread(pv, pd_, 'number', fair=fair, use_sort=use_sort),
+          'var': O.ensemble_variance(pv, pd_, 'number'), 'uemse': O.unbiased_ensemble_mean_squared_error(pv, pd_, tv, td, 'number')}
+  for k, (vals, vdims) in want.items():
+    got_s, got_w = state.sum_weighted_statistics[k].get('v'), state.sum_weights[k].get('v')
+    kw_k = {} if (mode == 'masked' and k in ('spread', 'var')) else okw  # (see the small-size test above)
+    full_dims = O.union_dims(vdims, td) if 'mask' in kw_k else vdims
+    vals_full = np.broadcast_to(O.expand_to(vals, vdims, full_dims), [sizes[d] for d in full_dims])
+    ref = O.aggregate(vals_full, full_dims, reduce_dims, weights=oracle_w, **kw_k)
+    if ref is None:
+      assert got_s is None, k
+      continue
+    assert got_s is not None, k
+    sws, sw, out_dims = ref
+    assert set(got_s.dims) == set(out_dims), (k, got_s.dims, out_dims)
+    # uemse = (mean - t)^2 - var / M is a difference of like-sized terms: 1e-6 of the terms, not of the difference
+    atol = 1e-6 * float(np.nanmax(np.abs(sw))) * spread * spread if k == 'uemse' else 1e-9
+    np.testing.assert_allclose(got_s.transpose(*out_dims).values, sws, rtol=1e-6, atol=atol, err_msg=k)
+    np.testing.assert_allclose(got_w.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12, err_msg=k)
+
+
 @pytest.mark.parametrize('seed', range(30 * FUZZ_SCALE))
 def test_random_indicator_layouts_and_aggregators(backend, seed):
   """ErrorExceedance / EnsembleErrorExceedance / RankHistogram on random layouts (member dim anywhere, targets in another
