@@ -289,7 +289,8 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
   }
   for (int i = lane; i < ATOM_MAX * NA; i += 64) tab[i] = 0.0;
   if (lane < ATOM_MAX) wlist[lane] = g.words[(bk * npatch + patch) * ATOM_MAX + lane];
-  __syncthreads();  // (one wave per block: the barriers only pin the order of the LDS accesses for the compiler)
+  __syncthreads();  // (a wave only touches its own table: the barriers pin the order of its LDS accesses for the compiler;
+                    //  with W > 1 every wave still in the kernel passes each of them exactly once)
   const int64_t R = g.nBr * a.D;
   const int64_t rbeg = (int64_t)rs * g.rows_per_split;
   const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
