@@ -1,6 +1,7 @@
 """Measured error of the 1440-point spectrum kernels against the float64 numpy.fft oracle (per row: median / 99.9th percentile
 / maximum relative error and the maximum of |dS_k| / sqrt(S_max S_k); aggregated over 200 rows), white noise and a mean of
-280, both layouts -- where the bound stated in tests/test_spectra.py comes from.  usage (GPU box): python tools/spectrum_error.py"""
+280, both layouts -- where the bound stated in tests/test_spectra.py comes from.  A checker like the tests next to it (it calls
+the oracle), not collected by pytest.  usage (GPU box): python tests/measure_spectrum_error.py"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
