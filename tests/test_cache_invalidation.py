@@ -317,3 +317,24 @@ def test_a_warm_evaluation_step_leaves_nothing_for_the_cyclic_collector(backend)
     gc.set_debug(0)
     gc.garbage.clear()
     gc.enable()
+
+
+def test_values_of_an_uploaded_payload_is_a_read_only_view(backend):
+  """A write through `.values[...]` cannot reach the device copy cached on the object: while such a copy
+  exists the array is handed out read-only, so the write raises instead of leaving later reductions on the old numbers; the
+  payload itself stays writeable for its owner, and `da[...] = x` (which drops the caches) keeps working."""
+  p, t = _fields(7)
+  own = p.data
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  p.values[0, 0, 0] = 1.5  # nothing cached yet: the plain payload
+  first = _mse(agg, p, t)
+  np.testing.assert_allclose(first.values, _oracle_mse(p, t)[0], rtol=1e-6)
+  with pytest.raises(ValueError, match='read-only'):
+    p.values[0] = 0.0
+  assert own.flags.writeable and p.values.base is not None
+  np.testing.assert_array_equal(p.values, own)
+  p[0] = 0.0  # the supported mutation: caches dropped, the array is writeable again
+  assert p.values.flags.writeable
+  second = _mse(agg, p, t)
+  np.testing.assert_allclose(second.values, _oracle_mse(p, t)[0], rtol=1e-6)
+  assert not np.allclose(first.values, second.values)

@@ -296,7 +296,14 @@ class DataArray:
 
   @property
   def values(self) -> np.ndarray:
-    return _to_numpy(self.data)
+    out = _to_numpy(self.data)
+    if isinstance(out, np.ndarray) and out.flags.writeable and any(k.startswith('_wbx_') for k in self.__dict__):
+      # an uploaded copy of this payload (or a result computed from it) is cached on the object: a write through
+      # `.values[...] = x` would leave it stale without anybody noticing, so the array is handed out as a read-only VIEW
+      # (the caller's own array is not frozen) and the write fails loudly; `da[...] = x` is the mutation that drops the caches
+      out = out.view()
+      out.flags.writeable = False
+    return out
 
   @property
   def dims(self) -> tuple:
@@ -344,7 +351,9 @@ class DataArray:
   def _drop_device_caches(self):
     """Forgets everything the engine cached on this object (uploaded copies, fused groups, packed weights): called by
     every in-place mutation of the payload or the coordinates, so that later reductions see the new content.  Host
-    payloads are uploaded once per object: writing through `.values[...] = x` bypasses this -- use `da[...] = x`."""
+    payloads are uploaded once per object: while an uploaded copy exists `.values` is a read-only view, so
+    `.values[...] = x` raises instead of leaving the copy stale -- use `da[...] = x` (an alias of the payload taken BEFORE the
+    upload can still be written behind the object's back)."""
     for k in [k for k in self.__dict__ if k.startswith('_wbx_')]:
       del self.__dict__[k]
     # caches that live on OTHER objects (the fused group of (predictions, targets) sits on the predictions) key on this
