@@ -322,7 +322,15 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
  *   power_out[group[r]][k] (+)= scale[r] * S_k(row r)
  * group[nrows] (int32 in [0, ngroup)) and scale[nrows] (float64, e.g. area weight / count) are device arrays;
  * power_out is float64[ngroup][nlon/2 + 1]; accumulate = 0 overwrites it, 1 adds to it (fp64 atomics, so the
- * summation order -- not the value beyond ~1e-16 relative -- may differ between runs). */
+ * summation order -- not the value beyond ~1e-16 relative -- may differ between runs).
+ * Accuracy (the one family that is not held to north_star's 1e-6 per value: the transform itself is fp32, only |F|^2 and the
+ * sums over rows are fp64).  1440-point rows (0.25 degree grids, both layouts): a row is shifted by an estimate of its mean
+ * before the transform and F_0 is restored in fp64, so the error does not scale with the field's mean --
+ * |dS_k| <= 2e-6 S_k + 1e-6 sqrt(S'_max S_k), S'_max = max_{k >= 1} S_k, and S_0 to 1e-6, per row against float64 numpy.fft
+ * (tests/test_spectra.py::bound_1440); measured on N(0, 1) and N(280, 1) rows: median 1.4e-7, and 1e-7 for every wavenumber
+ * after a mean over 200 rows (profiles/r03_spectrum_demean_ab.txt; without the shift the N(280, 1) rows came out at 1e-5
+ * in the median and 6e-5 after that mean).  Other row lengths (generic fused kernel, rocFFT route) transform the rows as they are:
+ * |dS_k| <= 2e-5 S_k + 4e-7 sqrt(S_max S_k) with S_max including the mean. */
 int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride, int64_t nrows,
                        int32_t nlon, const int32_t* group, const double* scale, int32_t ngroup,
                        int32_t accumulate, double* power_out);
@@ -347,7 +355,7 @@ int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_strid
  *                               scale[row] * S_k(row), k = 0 .. 720; zeroed here first
  * `plan` is the deterministic plan of (p, t[, c]) with x = longitude (nx = 1440, unit x strides, even row offsets), summed,
  * ndepth = 1, nchunk = 1, no mask: a row of the spectra = a key of the plan, group / scale are indexed by key.
- * Spectrum accuracy: as wbx_zonal_spectrum (fp32 transform, |dS_k| <= 2e-5 S_k + 4e-7 sqrt(S_max S_k)); the deterministic lanes
+ * Spectrum accuracy: as wbx_zonal_spectrum on 1440-point rows (fp32 transform of the mean-shifted rows); the deterministic lanes
  * are fp64 sums of the widened inputs like wbx_det_partial (1e-12).  Parity unpinned for the spectra. */
 int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3 | WBX_DET6 */, int dtype /* WBX_F32 */,
                      const void* p, const void* t, const void* c, const int32_t* group, const double* scale, int64_t ngroup,

@@ -746,8 +746,8 @@ def test_zonal_spectrum_entry_points_raw_1440(ctx, layout, entry):
   want = np.zeros((ngroup, nlon // 2 + 1))
   np.add.at(want, group, per_row)
   got = out.cpu().numpy()
-  bound = 2e-5 * want + 4e-7 * np.sqrt(want.max(axis=-1, keepdims=True) * want)
-  assert float(np.max(np.abs(got - want) / bound)) <= 1.0
+  from test_spectra import bound_1440
+  assert float(np.max(np.abs(got - want) / bound_1440(want))) <= 1.0
   call(1)
   ctx.synchronize()
   np.testing.assert_allclose(out.cpu().numpy(), 2 * got, rtol=1e-12)

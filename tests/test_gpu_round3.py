@@ -17,6 +17,7 @@ from weatherbenchx_amd import engine
 from weatherbenchx_amd import lazy
 from weatherbenchx_amd import pipeline
 from weatherbenchx_amd import spectra
+from test_spectra import bound_1440
 from weatherbenchx_amd import time_chunks
 from weatherbenchx_amd import weighting
 from weatherbenchx_amd import xarray_lite as xr
@@ -320,7 +321,7 @@ def test_configs4_composite_against_the_oracle(ctx):
     for name, ref in (('spectrum_p.z', power / ninit), ('spectrum_t.z', power_t / ninit)):
       got = np.asarray(svals[name].values)[lead, lev]
       # (the spectrum's own bound: the FFT is fp32, include/wbx.h "zonal spectrum")
-      assert np.all(np.abs(got - ref) <= 2e-5 * ref + 4e-7 * np.sqrt(ref.max() * ref)), name
+      assert np.all(np.abs(got - ref) <= bound_1440(ref)), name
   for lead in (3,):
     skill = spread = var = ue = 0.0
     for i in range(ninit):
@@ -456,7 +457,7 @@ def test_det_spectrum_entry_point_against_the_oracle(ctx, func):
   for buf, f64 in ((pw_p, p64), (pw_t, t64)):
     got = ctx.download(buf.ptr, (ngroup, nk)).copy()
     ref = (O.zonal_power_spectrum(f64) * w[None, None, :, None]).sum(axis=2).reshape(ngroup, nk)
-    assert np.all(np.abs(got - ref) <= 2e-5 * ref + 4e-7 * np.sqrt(ref.max(axis=1, keepdims=True) * ref))
+    assert np.all(np.abs(got - ref) <= bound_1440(ref))
   # misuse is refused, not mis-run
   assert ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), _hip.PASS1, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
                                   ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)) == -1

@@ -28,6 +28,57 @@ constexpr int Z14_BUF = 12 * Z14_S1;       // v4 elements of LDS per wave (>= 72
 constexpr int Z14_TW1 = 11 * 60, Z14_TW2 = 4 * 12, Z14_TWR = 720;  // float2 entries: W720^(b k1) | W60^(d q) | W1440^k
 constexpr int Z14_TABLES = Z14_TW1 + Z14_TW2 + Z14_TWR;
 
+// The transform is fp32: every output carries ~eps |F|_max of its row, and on a physical field |F|_max is the mean (F_0 = n x
+// mean: T ~ 280 K against anomalies of a few K, geopotential 5e4 against 1e2..1e3), so the wavenumbers above it were held to
+// eps x mean / anomaly instead of eps (measured on N(280, 1) rows: median relative error of S_k 1.0e-5 per row, up to 48 % on
+// single coefficients, against 1.4e-7 on N(0, 1) rows).  With WBX_SPECTRUM_DEMEAN a row is shifted by m = an estimate of its
+// mean (fp32; any m is valid, it only has to be close) before the transform (z14_demean) -- x - m is exact in fp32 for x
+// within a factor two of m -- which changes nothing but F_0 (n is even: the Nyquist term keeps its value), and
+// F_0 = F'_0 + n m is put back in fp64 where |X_0|^2 is formed (z14_pair).
+#ifndef WBX_SPECTRUM_DEMEAN
+#define WBX_SPECTRUM_DEMEAN 1
+#endif
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_moved_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+__device__ __forceinline__ float wave_sum_uniform_f32(float v) {  // all 64 lanes active; steps as wave_sum_lane63 (wbx_common.hpp)
+  v += dpp_moved_f32<0xB1, 0xf>(v);
+  v += dpp_moved_f32<0x4E, 0xf>(v);
+  v += dpp_moved_f32<0x124, 0xf>(v);
+  v += dpp_moved_f32<0x128, 0xf>(v);
+  v += dpp_moved_f32<0x142, 0xa>(v);
+  v += dpp_moved_f32<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// -> (m_A, m_B) of the rows A and B whose pass-1 inputs v holds; subtracted from v in place.  Every instruction here is
+// paid three times per SIMD (its waves run the passes in step), so the estimate takes what is cheap: the real parts of every
+// other pass-1 input (x[120 a + 2 b], a even: 5 packed additions) of all 64 lanes -- lanes 60..63 shadow lane 59, whose
+// samples therefore count five times: a slightly noisier mean, no select -- i.e. 360 evenly spread longitudes of the row.
+// FEW (the latitude-fastest kernel, whose pass-1 inputs are LDS loads still in flight here): only v[0] and v[6] -- two
+// antipodal arcs of 32 degrees, 128 samples -- so that the reduction runs under the latency of the other ten loads.
+template <bool FEW = false>
+__device__ __forceinline__ v2 z14_demean(C2 (&v)[12]) {
+  if constexpr (!WBX_SPECTRUM_DEMEAN) return (v2){0.f, 0.f};
+  v2 s = v[0].re + v[6].re;
+  if constexpr (!FEW) {
+#pragma unroll
+    for (int a = 2; a < 12; a += 2)
+      if (a != 6) s += v[a].re;
+  }
+  constexpr float inv = FEW ? 1.0f / 128.0f : 1.0f / 384.0f;
+  const v2 m = {wave_sum_uniform_f32(s.x) * inv, wave_sum_uniform_f32(s.y) * inv};
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    v[a].re -= m;
+    v[a].im -= m;
+  }
+  return m;
+}
+
 // 12-point DFT, Good-Thomas: input n = (4 n1 + 3 n2) mod 12, output k = (4 k1 + 9 k2) mod 12; four 3-point and three
 // 4-point butterflies, no twiddles in between.
 __device__ __forceinline__ void dft12(C2 (&v)[12]) {
@@ -112,7 +163,7 @@ template <int KNOCK, bool PT = false, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
                                          double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at,
-                                         double (&accb)[6], double (&accmb)[6]) {
+                                         double (&accb)[6], double (&accmb)[6], v2 msh = (v2){0.f, 0.f}) {
   constexpr int nk = Z14_N2 + 1;
   constexpr bool DROP = (KNOCK & 2) != 0;
   const int L = c.L;
@@ -178,26 +229,36 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     const C2 x = cadd(e, wo), xm = csub(e, wo);
     const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;      // (row A, row B) of k
     const v2 pm = (KNOCK & 8) ? xm.re : xm.re * xm.re + xm.im * xm.im;  // ... of 720 - k
+    double pxd = (double)p.x, pyd = (double)p.y;
+    if constexpr (WBX_SPECTRUM_DEMEAN && !(KNOCK & 8)) {
+      // k = 0 (lane 0, s = 0): x.re = 2 F'_0 of the shifted rows and x.im = 0 exactly; F_0 = F'_0 + n m (2 F_0 here: E and O
+      // are used without their factor 1/2), formed and squared in fp64 -- the mean is not squeezed through fp32 again
+      if (s == 0 && c.lane == 0) {
+        const double fa = (double)x.re.x + 2.0 * Z14_N * (double)msh.x, fb = (double)x.re.y + 2.0 * Z14_N * (double)msh.y;
+        pxd = fa * fa;
+        pyd = fb * fb;
+      }
+    }
     if constexpr (PT) {
-      acc[s] = fma((double)p.x, sca, acc[s]);
+      acc[s] = fma(pxd, sca, acc[s]);
       accm[s] = fma((double)pm.x, sca, accm[s]);
-      accb[s] = fma((double)p.y, scb, accb[s]);
+      accb[s] = fma(pyd, scb, accb[s]);
       accmb[s] = fma((double)pm.y, scb, accmb[s]);
     } else if (split) {
-      acc[s] = fma((double)p.x, sca, acc[s]);
+      acc[s] = fma(pxd, sca, acc[s]);
       accm[s] = fma((double)pm.x, sca, accm[s]);
       if (c.lane < Z14_LANES) {
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], (double)p.y * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], pyd * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
         unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 - L - 60 * s], (double)pm.y * scb * 2.0);
       } else if (self360 && s == 0) {
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 / 2], (double)p.y * scb * 2.0);
+        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 / 2], pyd * scb * 2.0);
       }
     } else {
       if constexpr (KNOCK & 8) {
         acc[s] += (double)(p.x + p.y);
         accm[s] += (double)(pm.x + pm.y);
       } else {
-        acc[s] = fma((double)p.x, sca, fma((double)p.y, scb, acc[s]));
+        acc[s] = fma(pxd, sca, fma(pyd, scb, acc[s]));
         accm[s] = fma((double)pm.x, sca, fma((double)pm.y, scb, accm[s]));
       }
     }
@@ -298,6 +359,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     C2 v[12];
 #pragma unroll
     for (int a = 0; a < 12; ++a) v[a] = {{pa[a].x, two ? pb[a].x : 0.f}, {pa[a].y, two ? pb[a].y : 0.f}};
+    const v2 msh = z14_demean(v);
     if constexpr (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mark(1, false);  // 0 -> 1: scalar bookkeeping + the wait for the prefetched rows
     if constexpr (FETCH_EARLY) {
@@ -313,7 +375,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads
                                if (i == 0 && r + 2 < r1) fetch(r + 2);
                              }
-                           }, acc, accm);
+                           }, acc, accm, msh);
     if constexpr (PROF) {
 #pragma unroll
       for (int i = 1; i < 8; ++i) spent[i] += stamp[i] - stamp[i - 1];
@@ -516,9 +578,10 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     if (active) {
       C2 v[12];
 #pragma unroll
-      for (int a = 0; a < 12; ++a) v[a] = ld_c2(buf + 60 * a + L);
+      for (int a = 0; a < 12; ++a) v[(6 * a) % 12 + a / 2] = ld_c2(buf + 60 * ((6 * a) % 12 + a / 2) + L);  // 0, 6, 1, 7, ..: z14_demean
       __builtin_amdgcn_wave_barrier();
       mark(4);
+      const v2 msh = (KNOCK & 2) ? (v2){0.f, 0.f} : z14_demean<true>(v);
       if constexpr (KNOCK & 2) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) acc[a] += (double)(v[a].re.x + v[a + 6].im.y) * sca;
@@ -538,7 +601,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
           } else if constexpr (SPREAD == 2) {
             if (more && (!(i & 1) || i == 5)) load_part(on, rn, i == 5 ? 3 : i / 2);
           }
-        }, acc, accm);
+        }, acc, accm, msh);
       }
       mark(5);
       if constexpr (PROF) {

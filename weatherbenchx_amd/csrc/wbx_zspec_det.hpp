@@ -177,13 +177,14 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     C2 v[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) v[i] = {{pa[i].x, pb[i].x}, {pa[i].y, pb[i].y}};
+    const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
     z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
       if (r + 1 < r1) {
         if (i == 0) fetch_p(np, nc);
         if (i == 2) fetch_t(nt);
       }
-    }, acct, accmt);
+    }, acct, accmt, msh);
   }
   flush(cur);
 }
