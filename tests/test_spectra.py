@@ -234,6 +234,29 @@ def test_1440_point_rows_random_shapes_and_reductions(backend, seed):
 
 
 @pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('nlon,nlat,mean', [(64, 32, 0.0), (64, 32, 280.0), (240, 121, 0.0), (240, 121, 280.0), (256, 9, 5.0e4)])
+def test_short_rows_are_shifted_by_their_mean_too(backend, layout, nlon, nlat, mean):
+  """The other grids of the public configs (64 x 32 and 240 x 121; 256 = the longest row of a one-wave team) go through the
+  generic fused kernel, whose one-wave teams shift a row by the mean of its even points in front of the fp32 transform like
+  the 1440-point kernels (csrc/wbx_spectrum.hip, team_pass): the same bound against the float64 oracle whatever the mean --
+  N(280, 1) like a temperature field, N(5e4, 1) like geopotential --, odd row counts (a lone last row), both layouts."""
+  rng = np.random.default_rng(nlon + nlat)
+  lat, lon = np.linspace(-85, 85, nlat), np.arange(nlon) * (360.0 / nlon)
+  dims = ('lead_time', 'latitude', 'longitude') if layout == 'lon_fastest' else ('lead_time', 'longitude', 'latitude')
+  shape = {'lead_time': 3, 'latitude': nlat, 'longitude': nlon}
+  vals = (rng.normal(size=[shape[d] for d in dims]) + mean).astype(np.float32)
+  f = _field(vals, dims, lat=lat, lon=lon)
+  lon_ax = dims.index('longitude')
+  per_row = np.moveaxis(O.zonal_power_spectrum(vals, lon_axis=lon_ax), lon_ax, -1)
+  stat = spectra.ZonalPowerSpectrum().compute({'v': f}, {'v': f})['v'].transpose('lead_time', 'latitude', 'zonal_wavenumber')
+  got = np.asarray(stat.values)
+  worst = float(np.max(np.abs(got - per_row) / bound_1440(per_row)))
+  assert worst <= 1.0, worst
+  if mean != 0.0:  # (S_0 of a zero-mean row is one more small coefficient)
+    np.testing.assert_allclose(got[..., 0], per_row[..., 0], rtol=1e-6)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
 def test_1440_point_rows_nan_stays_in_its_row(backend, layout):
   """A NaN anywhere in a row makes that row's whole spectrum NaN (as numpy.fft does) and nothing else: the two rows of a
   pair share every packed instruction, their values must not mix."""

@@ -166,6 +166,29 @@ __device__ __forceinline__ C2 ld_c2(const v4* p) {
 }
 __device__ __forceinline__ void st_c2(v4* p, C2 a) { *p = (v4){a.re.x, a.re.y, a.im.x, a.im.y}; }
 
+// WBX_SPECTRUM_DEMEAN (what it is for: wbx_zspec1440.hpp): rows are shifted by an estimate of their mean in front of the fp32
+// transform and F_0 is restored in fp64 -- the 1440-point kernels, and the one-wave teams (G == 64: rows of up to 256 points,
+// i.e. the 64- and 240-point grids of the public configs) of the generic kernel below, where the team's mean is one DPP
+// reduction; teams of two or four waves (257..2048-point rows other than 1440) transform the rows as they are.
+#ifndef WBX_SPECTRUM_DEMEAN
+#define WBX_SPECTRUM_DEMEAN 1
+#endif
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_moved_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+
+__device__ __forceinline__ float wave_sum_uniform_f32(float v) {  // all 64 lanes active; steps as wave_sum_lane63 (wbx_common.hpp)
+  v += dpp_moved_f32<0xB1, 0xf>(v);
+  v += dpp_moved_f32<0x4E, 0xf>(v);
+  v += dpp_moved_f32<0x124, 0xf>(v);
+  v += dpp_moved_f32<0x128, 0xf>(v);
+  v += dpp_moved_f32<0x142, 0xa>(v);
+  v += dpp_moved_f32<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int R>
 __device__ __forceinline__ void butterfly(C2 (&v)[R]) {
   if constexpr (R == 2) {
@@ -219,15 +242,20 @@ __device__ __forceinline__ void team_sync() {
 // a read, and an N-way bank conflict multiplies that), so the strided side is the read.  ns shrinks from n2 / R to 1.
 // FIRST (ns == nb): the inputs k + t * nb are taken straight from the two rows in global memory (coalesced), the raw
 // rows never visit the LDS.  All LDS reads precede all writes.
+// FIRST on a one-wave team (G == 64) with WBX_SPECTRUM_DEMEAN: the rows are shifted by the mean of their even points (the
+// real parts of the packed row: every one of them is in some lane's registers here) before the first butterfly; the shift
+// comes back in *msh for the k = 0 term of the unpack.
 template <int R, int NB, int G, bool FIRST>
 __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns, int toff,
                                           float inv_ns, int tid, const v2* __restrict__ rowa,
-                                          const v2* __restrict__ rowb, bool two) {
+                                          const v2* __restrict__ rowb, bool two, v2* msh) {
   const int nb = n2 / R;  // exp(-2 pi i t k / (ns R)) = tw[toff + (t - 1) ns + k]
   C2 v[NB][R];
+  int kk[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int j = tid + G * i;
+    kk[i] = j;
     if (j < nb) {
       int k = j, base = j;
       if constexpr (!FIRST) {
@@ -235,6 +263,7 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
         k = j - q * ns;
         base = (j - k) * R + k;
       }
+      kk[i] = k;
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         if constexpr (FIRST) {
@@ -245,6 +274,36 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
           v[i][t] = ld_c2(buf + base + t * ns);
         }
       }
+    }
+  }
+  if constexpr (FIRST && G == 64 && WBX_SPECTRUM_DEMEAN) {
+    v2 sum = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (tid + G * i < nb) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) sum += v[i][t].re;
+      }
+    }
+    const float inv_n2 = 1.0f / (float)n2;
+    const v2 m = {wave_sum_uniform_f32(sum.x) * inv_n2, wave_sum_uniform_f32(sum.y) * inv_n2};
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (tid + G * i < nb) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          v[i][t].re -= m;
+          v[i][t].im -= m;
+        }
+      }
+    }
+    *msh = m;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int j = tid + G * i;
+    if (j < nb) {
+      const int k = kk[i];
       butterfly<R>(v[i]);
       if (ns > 1) {
         const float2* twk = tw + toff + k;
@@ -267,33 +326,33 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
 
 template <int R, int G, bool FIRST>
 __device__ __forceinline__ void team_pass_any(v4* buf, const float2* tw, int n2, int ns, int toff, float inv_ns, int tid,
-                                              const v2* rowa, const v2* rowb, bool two) {
+                                              const v2* rowa, const v2* rowb, bool two, v2* msh) {
   // fused_factor() admits at most 256 butterflies per pass
   constexpr int NBMAX = 256 / G;
   const int nbl = (n2 / R + G - 1) / G;  // butterflies per thread
   if constexpr (NBMAX >= 4) {
-    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
-    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 3) return team_pass<R, 4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
+    if (nbl > 2) return team_pass<R, 3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
   }
   if constexpr (NBMAX >= 2) {
-    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    if (nbl > 1) return team_pass<R, 2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
   }
-  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+  team_pass<R, 1, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
 }
 
 template <int G, bool FIRST>
 __device__ __forceinline__ void team_pass_radix(const FusedSpec& fs, int p, v4* buf, const float2* tw, int tid,
-                                                const v2* rowa, const v2* rowb, bool two) {
+                                                const v2* rowa, const v2* rowb, bool two, v2* msh = nullptr) {
   const int rdx = fs.radix[p], n2 = fs.n2, ns = fs.ns[p], toff = fs.toff[p];
   const float inv_ns = fs.inv_ns[p];
   if (rdx == 4)
-    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<4, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
   else if (rdx == 2)
-    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<2, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
   else if (rdx == 3)
-    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<3, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
   else
-    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two);
+    team_pass_any<5, G, FIRST>(buf, tw, n2, ns, toff, inv_ns, tid, rowa, rowb, two, msh);
 }
 
 // tw_pass = the packed per-pass twiddles (n2 - 1 entries, FusedSpec::toff);  tw_real[k] = exp(-2 pi i k / n), k <= n2 / 2 (only those are copied to the LDS).  KPT >= ceil((n2 / 2 + 1) / G).
@@ -365,6 +424,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
     const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
+    v2 msh = {0.f, 0.f};  // the shift of rows A and B (one-wave teams, WBX_SPECTRUM_DEMEAN), team-uniform
     if constexpr (R0 > 0) {
       C2 v[RP];
 #pragma unroll
@@ -381,7 +441,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
       }
       team_sync<G>();
     } else {
-      team_pass_radix<G, true>(fs, 0, buf, tw_pass, tid, rowa, rowb, two);
+      team_pass_radix<G, true>(fs, 0, buf, tw_pass, tid, rowa, rowb, two, &msh);
     }
     for (int p = 1; p < fs.npass; ++p) team_pass_radix<G, false>(fs, p, buf, tw_pass, tid, rowa, rowb, two);
     // Hermitian unpack of the half-length transform Z: X_k = E_k + W^k O_k with W = exp(-2 pi i / n),
@@ -404,16 +464,24 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
         const C2 wo = ctw(o, tw_real[k]);
         const C2 x = cadd(e, wo), xm = csub(e, wo);
         const v2 p = x.re * x.re + x.im * x.im, pm = xm.re * xm.re + xm.im * xm.im;  // (row A, row B)
+        double pxd = (double)p.x, pyd = (double)p.y;
+        if constexpr (G == 64 && R0 == 0 && WBX_SPECTRUM_DEMEAN) {
+          if (k == 0) {  // x.re = F'_0 of the shifted rows, x.im = 0: F_0 = F'_0 + n m, formed and squared in fp64
+            const double fa = (double)x.re.x + (double)fs.n * (double)msh.x, fb = (double)x.re.y + (double)fs.n * (double)msh.y;
+            pxd = fa * fa;
+            pyd = fb * fb;
+          }
+        }
         const bool mirror = km != k;
         if (split) {
-          acc[i] = fma((double)p.x, sca, acc[i]);
-          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], (double)p.y * scb * (k == 0 ? 1.0 : 2.0));
+          acc[i] = fma(pxd, sca, acc[i]);
+          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], pyd * scb * (k == 0 ? 1.0 : 2.0));
           if (mirror) {
             accm[i] = fma((double)pm.x, sca, accm[i]);
             unsafeAtomicAdd(&power[(int64_t)gb * nk + km], (double)pm.y * scb * 2.0);
           }
         } else {
-          acc[i] = fma((double)p.x, sca, fma((double)p.y, scb, acc[i]));
+          acc[i] = fma(pxd, sca, fma(pyd, scb, acc[i]));
           if (mirror) accm[i] = fma((double)pm.x, sca, fma((double)pm.y, scb, accm[i]));
         }
       }

@@ -35,24 +35,7 @@ constexpr int Z14_TABLES = Z14_TW1 + Z14_TW2 + Z14_TWR;
 // mean (fp32; any m is valid, it only has to be close) before the transform (z14_demean) -- x - m is exact in fp32 for x
 // within a factor two of m -- which changes nothing but F_0 (n is even: the Nyquist term keeps its value), and
 // F_0 = F'_0 + n m is put back in fp64 where |X_0|^2 is formed (z14_pair).
-#ifndef WBX_SPECTRUM_DEMEAN
-#define WBX_SPECTRUM_DEMEAN 1
-#endif
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_moved_f32(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
-}
-
-__device__ __forceinline__ float wave_sum_uniform_f32(float v) {  // all 64 lanes active; steps as wave_sum_lane63 (wbx_common.hpp)
-  v += dpp_moved_f32<0xB1, 0xf>(v);
-  v += dpp_moved_f32<0x4E, 0xf>(v);
-  v += dpp_moved_f32<0x124, 0xf>(v);
-  v += dpp_moved_f32<0x128, 0xf>(v);
-  v += dpp_moved_f32<0x142, 0xa>(v);
-  v += dpp_moved_f32<0x143, 0xc>(v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
+// (the macro and the DPP reduction: wbx_spectrum.hip, in front of the generic kernel, whose one-wave teams use them too)
 
 // -> (m_A, m_B) of the rows A and B whose pass-1 inputs v holds; subtracted from v in place.  Every instruction here is
 // paid three times per SIMD (its waves run the passes in step), so the estimate takes what is cheap: the real parts of every
