@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 7
+#define WBX_ABI_VERSION 8
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -301,6 +301,34 @@ int wbx_binned_atoms_size(const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int6
                           int64_t* bytes_out);
 int wbx_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
                      const uint64_t* bits, void* atoms_out /* device, wbx_binned_atoms_size bytes */);
+
+/* ---- fused binned reduction of the ensemble family ---------------------------------------------------------------
+ * The public benchmark's probabilistic configuration (public_benchmark/run_benchmark_evaluation.py:341-354, 365-382): CRPS /
+ * spread-skill / ensemble-mean RMSE under Regions x land-sea bins, GridAreaWeighting and masked=True.  Replaces
+ * probabilistic.py:116-336 + wrappers.py:116-148 + the two xr.dot of aggregation.py:337-366 for every ensemble statistic of a
+ * (predictions, targets) pair: the M members of a point are read ONCE (no full-map partial is written), sorted in registers,
+ * and the five lanes go straight into the bins.
+ *   out[nA][nBk][6][nbin]: lanes 0-4 = the WBX_ENS_LANES of wbx_ens_partial, weighted and binned like wbx_det_binned does;
+ *                          lane 5 = the sum of the weights of the valid points of the bin (the count lane, with and without mask).
+ * plan / nA / nBk / nBr / bits / nbin / w_on_x as for wbx_det_binned, with these restrictions (WBX_ERR_INVALID otherwise; the
+ * two-stage route wbx_ens_partial + wbx_contract_bits covers the rest):
+ *   dtype WBX_F32, algo WBX_ENS_SORT (the pair form gives the same number), 2 <= M <= 64, plan->flags within FAIR | MASKED;
+ *   weights factored: WBX_BINNED_WT_X_ONLY (wt[nBk][nx]) or WBX_BINNED_WT_ROW_ONLY (wt[nBk][nBr]), or wt = NULL (ones);
+ *   a mask (WBX_FLAG_MASKED) must live on the W dims: WBX_BINNED_MASK_ON_W together with WBX_BINNED_W_ON_X.
+ * `atoms`: NULL, or the tables wbx_ens_binned_atoms wrote for this geometry and these bits (its patches are shorter than
+ * wbx_det_binned's, so the tables are its own).  *overflow_out = number of patches with more than 32 distinct membership
+ * words (bins that are not boxes): when it is not zero use the two-stage route -- wbx_ens_binned would return NaN for the
+ * cells of those patches.  wbx_ens_binned_atoms synchronises when overflow_out is not NULL.
+ * Accuracy: as wbx_ens_partial (fp32 chain sums per point for M = 50 / 51, fp64 from the point's values on); lane 3 is formed
+ * per (patch, bin) as lane 4 - lane 2 / M from the fp64 sums (the identity holds at every point). */
+int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride, int algo, const void* p,
+                   const void* t, const uint8_t* mask, const double* wt, const uint64_t* bits, int64_t nA, int64_t nBk,
+                   int64_t nBr, int32_t w_on_x, int32_t nbin, const void* atoms, double* out);
+int wbx_ens_binned_atoms_size(const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
+                              int64_t* bytes_out);
+int wbx_ens_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x,
+                         const uint64_t* bits, void* atoms_out /* device, wbx_ens_binned_atoms_size bytes */,
+                         int64_t* overflow_out /* host, or NULL */);
 
 /* ---- materialisation of per-point statistics --------------------------------
  * Statistic.compute()'s full-resolution result (metrics/base.py:135-158) for callers

@@ -214,6 +214,40 @@ def _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf):
   return out, out.shape
 
 
+def _ens_binned_atoms(ctx, dplan, plan, w_buf, w_flags):
+  """The interpreter needs no atom tables; a patch never overflows here."""
+  return object()
+
+
+def _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, route):
+  """wbx_ens_binned: the five ensemble lanes + the count lane, weights (factored form) and membership applied per point."""
+  w_flags, _ = route
+  nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
+  nbin = w_buf.shape[-1]
+  nj = plan.nj if plan.x_kept else 1
+  if engine.S1_EVENT_LOG is not None:
+    engine.S1_EVENT_LOG.append({'kind': 'ens_binned', 'nbin': nbin, 'w_flags': w_flags, 'flags': int(plan.flags), 'ms': 0.0})
+  with np.errstate(all='ignore'):
+    lanes = _ens_lanes(plan, devs, ens_args, plan.flags)
+    valid = np.ones(lanes[0].shape, dtype=bool)
+    if plan.flags & _hip.FLAG_MASKED:
+      assert w_flags & _hip.BINNED_MASK_ON_W
+      valid = devs[3].ptr[_offsets(plan, 3)] != 0
+    lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
+    flag, buf = w_buf.factored
+    assert flag == (w_flags & (_hip.BINNED_WT_X_ONLY | _hip.BINNED_WT_ROW_ONLY))
+    fac = np.asarray(buf.ptr)
+    wt = np.broadcast_to(fac.reshape(nBk, 1, nj) if flag == _hip.BINNED_WT_X_ONLY else fac.reshape(nBk, nBr, 1), (nBk, nBr, nj))
+    bits = np.asarray(w_buf.bufs[1].ptr).reshape(nBk, nBr, nj)
+    member = ((bits[..., None] >> np.arange(nbin, dtype=np.uint64)) & np.uint64(1)).astype(np.float64)
+    member = np.broadcast_to(member, (nBk, nBr, nj, nbin)) if nj > 1 else np.broadcast_to(member, (nBk, nBr, 1, nbin)).repeat(plan.nx, axis=2)
+    out = np.empty((nA, nBk, engine.ENS_BINNED_LANES, 1, nbin))
+    for l, v in enumerate(lanes):
+      v = v.reshape(nA, nBk, nBr, plan.ndepth, plan.nx) * wt[None, :, :, None, :]
+      out[:, :, l, 0, :] = np.einsum('abrdx,brxn->abn', v, member)
+  return out, out.shape
+
+
 def _run_map(ctx, kind, dplan, plan, devs, dtype_code, lane, func=0, ens=None):
   with np.errstate(all='ignore'):
     if kind == 'det':
@@ -252,6 +286,8 @@ def install(monkeypatch):
   monkeypatch.setattr(engine, '_run_map', _run_map)
   monkeypatch.setattr(engine, '_run_s2', _run_s2)
   monkeypatch.setattr(engine, '_run_binned', _run_binned)
+  monkeypatch.setattr(engine, '_run_ens_binned', _run_ens_binned)
+  monkeypatch.setattr(engine, '_ens_binned_atoms', _ens_binned_atoms)
   monkeypatch.setattr(engine, '_acc_add', _acc_add)
   monkeypatch.setattr(engine, 'new_context', lambda: FakeCtx())
 

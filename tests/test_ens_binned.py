@@ -1,0 +1,182 @@
+"""The ensemble family under Regions x land/sea bins, GridAreaWeighting and masked=True -- the public benchmark's
+probabilistic configuration (public_benchmark/run_benchmark_evaluation.py:341-354, 365-382) -- through the drop-in API on
+both backends: ONE wbx_ens_binned launch per (variable, mask setting), every bin of every lane against the oracle.
+Tolerance: rtol 1e-6 (north_star)."""
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import probabilistic
+from weatherbenchx_amd.metrics import wrappers
+
+RTOL = 1e-6
+REGIONS = {'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'nh': ((20, 90), (0, 360)),
+           'sh': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)), 'namerica': ((25, 60), (240, 285)),
+           'nowhere': ((100, 101), (0, 360))}
+
+LAYOUTS = {
+    'lon_fastest': (('lead_time', 'number', 'latitude', 'longitude'), ('lead_time', 'latitude', 'longitude')),
+    'lat_fastest': (('lead_time', 'number', 'longitude', 'latitude'), ('lead_time', 'longitude', 'latitude')),
+    # the recorded IFS-ENS chunk (docs/source/how_to/metric_wrappers.ipynb:955-964): member-slow, latitude fastest
+    'ifs': (('init_time', 'number', 'lead_time', 'longitude', 'latitude'), ('init_time', 'lead_time', 'longitude', 'latitude')),
+}
+
+
+def lane_statistics():
+  return {'CRPSSkill': probabilistic.CRPSSkill(), 'CRPSSpread': probabilistic.CRPSSpread(use_sort=True),
+          'EnsembleVariance': probabilistic.EnsembleVariance(),
+          'UnbiasedEnsembleMeanSquaredError': probabilistic.UnbiasedEnsembleMeanSquaredError(),
+          'EnsembleMeanSquaredError': wrappers.WrappedStatistic(deterministic.SquaredError(),
+                                                                wrappers.EnsembleMean(which='predictions'))}
+
+
+def oracle_lanes(pv, pd, tv, td):
+  return {'CRPSSkill': O.crps_skill(pv, pd, tv, td, 'number'),
+          'CRPSSpread': O.crps_spread(pv, pd, 'number', fair=True, use_sort=True),
+          'EnsembleVariance': O.ensemble_variance(pv, pd, 'number'),
+          'UnbiasedEnsembleMeanSquaredError': O.unbiased_ensemble_mean_squared_error(pv, pd, tv, td, 'number'),
+          'EnsembleMeanSquaredError': O.ensemble_mean_squared_error(pv, pd, tv, td, 'number')}
+
+
+def make_case(layout, m, nlat, nlon, nlead, seed, *, offset=280.0, mask=None, nan_at=None, ninit=2):
+  """(predictions, targets, raw arrays) in `layout`; `mask`: bool[lat, lon] validity attached to the targets as the `mask`
+  coordinate (data_loaders/base.py:25-56)."""
+  pd, td = LAYOUTS[layout]
+  rng = np.random.default_rng(seed)
+  lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  sizes = {'lead_time': nlead, 'number': m, 'latitude': nlat, 'longitude': nlon, 'init_time': ninit}
+  tv = (rng.normal(size=[sizes[d] for d in td]) + offset).astype(np.float32)
+  pv = (np.expand_dims(tv, pd.index('number')) + rng.normal(size=[sizes[d] for d in pd])).astype(np.float32)
+  tv = (tv + rng.normal(size=tv.shape)).astype(np.float32)
+  if nan_at is not None:
+    pv[nan_at] = np.nan
+  coords = {'latitude': lat, 'longitude': lon, 'lead_time': (np.arange(nlead) * 12).astype('timedelta64[h]').astype('timedelta64[ns]'),
+            'init_time': np.datetime64('2020-01-01T00', 'ns') + np.arange(ninit) * np.timedelta64(1, 'D')}
+  p = xr.DataArray(pv, dims=pd, coords={k: v for k, v in coords.items() if k in pd})
+  t = xr.DataArray(tv, dims=td, coords={k: v for k, v in coords.items() if k in td})
+  if mask is not None:
+    sp = tuple(d for d in td if d in ('latitude', 'longitude'))
+    mv = mask if sp == ('latitude', 'longitude') else np.ascontiguousarray(mask.T)
+    t = t.assign_coords(mask=xr.DataArray(mv, dims=sp, coords={'latitude': lat, 'longitude': lon}))
+  return p, t, pv, tv, lat, lon
+
+
+def check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=None, rtol=RTOL, regions=None):
+  pd, td = LAYOUTS[layout]
+  regions = REGIONS if regions is None else regions
+  names, masks = O.region_masks(lat, lon, regions, land_sea_mask=land)
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  w = (O.grid_area_weights(lat), ('latitude',))
+  want = oracle_lanes(pv, pd, tv, td)
+  for name, (lane, ldims) in want.items():
+    member_only = name in ('CRPSSpread', 'EnsembleVariance')  # statistics of the predictions alone carry no mask
+    use = None if (mask is None or member_only) else mask
+    sws, sw, out_dims = O.aggregate(lane, ldims, reduce_dims, weights=[w], bin_masks=bm, mask=use,
+                                    mask_dims=('latitude', 'longitude') if use is not None else None)
+    key = stats[name].unique_name
+    got_s, got_w = state.sum_weighted_statistics[key]['v'], state.sum_weights[key]['v']
+    assert list(got_s['region'].values) == names
+    gs, gw = np.asarray(got_s.transpose(*out_dims).values), np.asarray(got_w.transpose(*out_dims).values)
+    np.testing.assert_allclose(gw, sw, rtol=1e-12, atol=1e-12, err_msg=f'{layout} {name} sum_weights')
+    scale = np.abs(sws).max() if np.isfinite(sws).all() else 1.0
+    np.testing.assert_allclose(gs, sws, rtol=rtol, atol=rtol * 1e-3 * scale, err_msg=f'{layout} {name} sum_weighted_statistics')
+    if 'nowhere' in names:
+      assert (gw[..., names.index('nowhere')] == 0).all()
+
+
+def run(stats, agg, p, t):
+  engine.S1_EVENT_LOG = []
+  try:
+    state = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(stats, {'v': p}, {'v': t}))
+    state.wait() if hasattr(state, 'wait') else None
+    log = list(engine.S1_EVENT_LOG)
+  finally:
+    engine.S1_EVENT_LOG = None
+  return state, log
+
+
+@pytest.mark.parametrize('layout', sorted(LAYOUTS))
+@pytest.mark.parametrize('m', [5, 51])
+def test_every_bin_of_every_lane_one_launch(backend, layout, m):
+  nlat, nlon = 37, 72
+  rng = np.random.default_rng(7)
+  land = rng.random((nlat, nlon)) > 0.6
+  p, t, pv, tv, lat, lon = make_case(layout, m, nlat, nlon, 3, seed=m)
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+  stats = lane_statistics()
+  state, log = run(stats, agg, p, t)
+  kinds = [e['kind'] for e in log]
+  assert kinds == ['ens_binned'], kinds  # ONE pass over the members, no partial, no second stage
+  check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, reduce_dims)
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+def test_validity_mask_on_latitude_longitude(backend, layout):
+  """masked=True with a (latitude, longitude) `mask` coordinate on the targets: skill / unbiased MSE / mean MSE are masked
+  (masked-out points contribute 0 whatever they hold -- NaN members there must not poison anything, aggregation.py:339-352),
+  spread and variance are statistics of the predictions alone and stay unmasked: two launches, both on wbx_ens_binned."""
+  nlat, nlon, m = 37, 72, 8
+  rng = np.random.default_rng(11)
+  land = rng.random((nlat, nlon)) > 0.5
+  valid = rng.random((nlat, nlon)) > 0.3
+  p, t, pv, tv, lat, lon = make_case(layout, m, nlat, nlon, 2, seed=3, mask=valid)
+  # a NaN target where the mask says invalid: the masked lanes ignore it
+  lat_i, lon_i = np.argwhere(~valid)[5]
+  sp = LAYOUTS[layout][1]
+  idx = tuple(1 if d == 'lead_time' else (lat_i if d == 'latitude' else lon_i) for d in sp)
+  tv[idx] = np.nan
+  t = xr.DataArray(tv, dims=t.dims, coords={k: t.coords[k].values for k in t.dims}).assign_coords(mask=t.coords['mask'])
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+  stats = lane_statistics()
+  state, log = run(stats, agg, p, t)
+  assert sorted((e['kind'], e['flags'] & 1) for e in log) == [('ens_binned', 0), ('ens_binned', 1)], log
+  check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, ['latitude', 'longitude'], mask=valid)
+
+
+def test_nan_member_poisons_every_bin_of_its_lead_time_only(backend):
+  """skipna=False: a NaN anywhere in the reduced set makes EVERY bin of that output cell NaN -- also the bins the point is
+  not in (NaN * 0, aggregation.py:272-277) -- and leaves the other cells alone."""
+  nlat, nlon, m = 24, 128, 16
+  pd = LAYOUTS['lon_fastest'][0]
+  nan_at = tuple({'lead_time': 1, 'number': 3, 'latitude': 20, 'longitude': 100}[d] for d in pd)
+  p, t, pv, tv, lat, lon = make_case('lon_fastest', m, nlat, nlon, 3, seed=5, nan_at=nan_at)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS)])
+  stats = lane_statistics()
+  state, _ = run(stats, agg, p, t)
+  for name, s in stats.items():
+    got = np.asarray(state.sum_weighted_statistics[s.unique_name]['v'].transpose('lead_time', 'region').values)
+    assert np.isnan(got[1]).all(), name
+    assert np.isfinite(got[[0, 2]]).all(), name
+  check_against_oracle(state, stats, pv, tv, 'lon_fastest', lat, lon, None, ['latitude', 'longitude'])
+
+
+def test_routes_that_stay_two_stage(backend):
+  """skipna aggregation, skipna_ensemble and float64 members are not wbx_ens_binned's: same numbers through the two-stage
+  route (x-kept ensemble kernel + wbx_contract_bits)."""
+  nlat, nlon, m = 19, 36, 5
+  p, t, pv, tv, lat, lon = make_case('lon_fastest', m, nlat, nlon, 2, seed=2)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS)], skipna=True)
+  stats = {'CRPSSkill': probabilistic.CRPSSkill()}
+  state, log = run(stats, agg, p, t)
+  assert not any(e['kind'] == 'ens_binned' for e in log)
+  pd, td = LAYOUTS['lon_fastest']
+  names, masks = O.region_masks(lat, lon, REGIONS)
+  lane, ldims = O.crps_skill(pv, pd, tv, td, 'number')
+  sws, sw, out_dims = O.aggregate(lane, ldims, ['latitude', 'longitude'], weights=[(O.grid_area_weights(lat), ('latitude',))],
+                                  bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))], skipna=True)
+  got = state.sum_weighted_statistics['CRPSSkill_number']['v'].transpose(*out_dims).values
+  np.testing.assert_allclose(np.asarray(got), sws, rtol=RTOL)

@@ -1,0 +1,179 @@
+"""Round-4 GPU parity tests at the sizes that run: the one-pass binned + masked ensemble kernel (wbx_ens_binned) on the
+public benchmark's probabilistic configuration -- M = 51, 721 x 1440, Regions(17) x land/sea = 34 bins, GridAreaWeighting,
+masked=True with a (latitude, longitude) validity mask -- every bin of all five lanes against the float64 oracle, both
+layouts and the recorded IFS-ENS layout.  Tolerance: rtol 1e-6 (north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import planner
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+import test_ens_binned as EB
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+NLAT, NLON = 721, 1440
+# the 17 evaluation regions of public_benchmark/run_benchmark_evaluation.py:110-131 (coordinates are data)
+REGIONS17 = {
+    'global': ((-90, 90), (0, 360)), 'tropics': ((-20, 20), (0, 360)), 'northern-hemisphere': ((20, 90), (0, 360)),
+    'southern-hemisphere': ((-90, -20), (0, 360)), 'europe': ((35, 75), (-12.5, 42.5)),
+    'north-america': ((25, 60), (360 - 120, 360 - 75)), 'north-atlantic': ((25, 65), (360 - 70, 360 - 10)),
+    'north-pacific': ((25, 60), (145, 360 - 130)), 'east-asia': ((25, 60), (102.5, 150)),
+    'ausnz': ((-45, -12.5), (120, 175)), 'arctic': ((60, 90), (0, 360)), 'antarctic': ((-90, -60), (0, 360)),
+    'northern-africa': ((5, 32.5), (-12.5, 37.5)), 'southern-africa': ((-30, 5), (12.5, 37.5)),
+    'south-america': ((-40, 5), (-75, -45)), 'west-asia': ((15, 60), (42.5, 102.5)),
+    'south-east-asia': ((-12.5, 25), (95, 125)),
+}
+
+
+@pytest.fixture(scope='module')
+def ctx():
+  assert _hip.is_available(), 'gpu tests need libwbx_hip.so and a HIP device'
+  return _hip.default_context(0)
+
+
+def _land(lat, lon):
+  """A coast-like land mask: blobs a few degrees wide, so patches see land / sea alternate the way real coasts do."""
+  return (np.sin(np.deg2rad(lon) * 3)[None, :] * np.cos(np.deg2rad(lat) * 2.5)[:, None]
+          + 0.3 * np.sin(np.deg2rad(lon) * 17)[None, :] * np.sin(np.deg2rad(lat) * 13)[:, None]) > 0.35
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest', 'ifs'])
+@pytest.mark.parametrize('m', [51, 50])
+def test_public_probabilistic_chunk_every_bin_every_lane(ctx, layout, m):
+  """M = 51 (and the 50 perturbed members of IFS-ENS) on the full 0.25 degree grid, 34 bins, masked=True with a (latitude,
+  longitude) validity mask: the masked statistics in ONE wbx_ens_binned launch, the statistics of the predictions alone
+  (spread, variance: no mask coordinate) in a second one -- and nothing else."""
+  if m == 50 and layout != 'ifs':
+    pytest.skip('M = 50 runs on the layout it comes in')
+  lat, lon = np.linspace(-90, 90, NLAT), np.linspace(0, 360, NLON, endpoint=False)
+  land = _land(lat, lon)
+  valid = ~((np.abs(lat)[:, None] > 80) & (np.cos(np.deg2rad(lon) * 5)[None, :] > 0.2))  # a NaN-mask-like hole near the poles
+  p, t, pv, tv, lat, lon = EB.make_case(layout, m, NLAT, NLON, 1, seed=100 + m, mask=valid, ninit=1)
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS17, land_sea_mask=lsm)], masked=True)
+  stats = EB.lane_statistics()
+  state, log = EB.run(stats, agg, p, t)
+  assert sorted((e['kind'], e['flags'] & 1) for e in log) == [('ens_binned', 0), ('ens_binned', 1)], log
+  EB.check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=valid, regions=REGIONS17)
+
+
+def test_two_stage_route_gives_the_same_numbers(ctx, monkeypatch):
+  """A/B of the routes on one chunk: wbx_ens_binned against the x-kept ensemble kernel + wbx_contract_bits."""
+  lat, lon = np.linspace(-90, 90, 181), np.linspace(0, 360, 360, endpoint=False)
+  land = _land(lat, lon)
+  p, t, pv, tv, lat, lon = EB.make_case('lat_fastest', 51, 181, 360, 2, seed=4)
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS17, land_sea_mask=lsm)])
+  stats = EB.lane_statistics()
+  one, log1 = EB.run(stats, agg, p, t)
+  monkeypatch.setattr(engine, 'ENS_BINNED', False)
+  engine.clear_caches()
+  p2 = xr.DataArray(pv, dims=p.dims, coords={k: p.coords[k].values for k in p.dims if k != 'number'})
+  t2 = xr.DataArray(tv, dims=t.dims, coords={k: t.coords[k].values for k in t.dims})
+  two, log2 = EB.run(stats, agg, p2, t2)
+  assert [e['kind'] for e in log1] == ['ens_binned'] and 'ens_binned' not in [e['kind'] for e in log2]
+  for name, s in stats.items():
+    a = np.asarray(one.sum_weighted_statistics[s.unique_name]['v'].values)
+    b = np.asarray(two.sum_weighted_statistics[s.unique_name]['v'].values)
+    np.testing.assert_allclose(a, b, rtol=RTOL, atol=1e-9 * np.abs(b).max(), err_msg=name)
+
+
+def _raw_call(ctx, plan, dplan, m, mstride, p_buf, t_buf, mask_buf, wt_buf, bits_buf, nA, nBk, nBr, w_flags, nbin, atoms, out):
+  return ctx.lib.wbx_ens_binned(ctx.handle, C.byref(dplan.struct), _hip.F32, m, mstride, _hip.ENS_SORT, C.c_void_p(p_buf.ptr),
+                                C.c_void_p(t_buf.ptr), C.c_void_p(mask_buf.ptr) if mask_buf is not None else None,
+                                C.c_void_p(wt_buf.ptr) if wt_buf is not None else None, C.c_void_p(bits_buf.ptr), nA, nBk, nBr,
+                                w_flags, nbin, C.c_void_p(atoms.ptr) if atoms is not None else None, C.c_void_p(out.ptr))
+
+
+def test_raw_c_abi_call_and_its_error_returns(ctx):
+  """wbx_ens_binned through raw pointers (what a binding would do): result == oracle with and without prepared atom tables;
+  the combinations it does not take come back as WBX_ERR_INVALID with a message, and bins that are no boxes (more than 32
+  distinct membership words in a patch) are reported by wbx_ens_binned_atoms and turn the cell NaN instead of wrong."""
+  rng = np.random.default_rng(1)
+  nlead, m, nlat, nlon, nbin = 2, 8, 40, 200, 9
+  tv = rng.normal(size=(nlead, nlat, nlon)).astype(np.float32)
+  pv = (tv[:, None] + rng.normal(size=(nlead, m, nlat, nlon))).astype(np.float32)
+  dims = ('lead_time', 'latitude', 'longitude')
+  sizes = {'lead_time': nlead, 'latitude': nlat, 'longitude': nlon}
+  lay_p = planner.InputLayout(strides={'lead_time': m * nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_t = planner.InputLayout(strides={'lead_time': nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  plan = planner.build_s1_plan(dims, sizes, [lay_p, lay_t, None, None], ('latitude', 'longitude'),
+                               wdep_dims={'latitude', 'longitude'}, flags=_hip.FLAG_FAIR, allow_vec4=False)
+  assert plan.a_dims == ('lead_time',) and plan.br_dims == ('latitude',) and plan.x_dim == 'longitude'
+  dplan = engine._PlanOnDevice(ctx, plan)  # pylint: disable=protected-access
+  member = rng.random((nlat, nlon, nbin)) < 0.4
+  member[:20, :, 0] = True
+  member[:, :, nbin - 1] = False
+  # box-like bins: a handful of distinct words per patch
+  boxy = np.zeros((nlat, nlon, nbin), bool)
+  for b in range(nbin - 1):
+    boxy[(b * 4) % nlat:(b * 4) % nlat + 18, (b * 23) % nlon:(b * 23) % nlon + 90, b] = True
+  wrow = rng.random(nlat) + 0.5
+  bufs = {'p': ctx.upload(pv), 't': ctx.upload(tv), 'w': ctx.upload(wrow)}
+  w_flags = _hip.BINNED_W_ON_X | _hip.BINNED_WT_ROW_ONLY
+  nA, nBk, nBr = nlead, 1, nlat
+  lanes = EB.oracle_lanes(pv, ('lead_time', 'number', 'latitude', 'longitude'), tv, dims)
+  order = ['CRPSSkill', 'CRPSSpread', 'EnsembleVariance', 'UnbiasedEnsembleMeanSquaredError', 'EnsembleMeanSquaredError']
+
+  def pack(mem):
+    bits = np.zeros((nlat, nlon), np.uint64)
+    for b in range(nbin):
+      bits |= mem[..., b].astype(np.uint64) << np.uint64(b)
+    return bits
+
+  def tables(bits_buf):
+    nbytes, overflow = C.c_int64(0), C.c_int64(-1)
+    _hip.check(ctx.lib.wbx_ens_binned_atoms_size(C.byref(dplan.struct), nA, nBk, nBr, _hip.BINNED_W_ON_X, C.byref(nbytes)), 'size')
+    atoms = ctx.alloc(int(nbytes.value))
+    _hip.check(ctx.lib.wbx_ens_binned_atoms(ctx.handle, C.byref(dplan.struct), nA, nBk, nBr, _hip.BINNED_W_ON_X,
+                                            C.c_void_p(bits_buf.ptr), C.c_void_p(atoms.ptr), C.byref(overflow)), 'atoms')
+    return atoms, int(overflow.value)
+
+  out = ctx.alloc(nA * nBk * 6 * nbin * 8)
+  bits_buf = ctx.upload(pack(boxy))
+  atoms, overflow = tables(bits_buf)
+  assert overflow == 0
+  for prepared in (atoms, None):
+    _hip.check(_raw_call(ctx, plan, dplan, m, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], bits_buf, nA, nBk, nBr, w_flags,
+                         nbin, prepared, out), 'wbx_ens_binned')
+    got = ctx.download(out.ptr, (nA, nBk, 6, nbin), np.float64)
+    for l, name in enumerate(order):
+      want = np.einsum('ayx,y,yxb->ab', lanes[name][0], wrow, boxy.astype(np.float64))
+      np.testing.assert_allclose(got[:, 0, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(got[:, 0, 5], np.broadcast_to(np.einsum('y,yxb->b', wrow, boxy.astype(np.float64)), (nA, nbin)), rtol=1e-12)
+    assert (got[:, 0, :, nbin - 1] == 0).all()
+  # random membership: patches with more than 32 distinct words are counted, and their cells come back NaN
+  rbits = ctx.upload(pack(member))
+  atoms_r, overflow_r = tables(rbits)
+  assert overflow_r > 0
+  _hip.check(_raw_call(ctx, plan, dplan, m, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], rbits, nA, nBk, nBr, w_flags, nbin,
+                       atoms_r, out), 'wbx_ens_binned')
+  assert np.isnan(ctx.download(out.ptr, (nA, nBk, 6, nbin), np.float64)).all()
+  # what it does not take
+  def refused(rc, text):
+    assert rc == -1 and text in ctx.lib.wbx_last_error().decode(), (rc, ctx.lib.wbx_last_error())
+  refused(_raw_call(ctx, plan, dplan, 65, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], bits_buf, nA, nBk, nBr, w_flags, nbin,
+                    atoms, out), '2..64 members')
+  refused(_raw_call(ctx, plan, dplan, m, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], bits_buf, nA, nBk, nBr,
+                    _hip.BINNED_W_ON_X, nbin, atoms, out), 'factored weights')
+  import dataclasses
+  plan_m = dataclasses.replace(plan, flags=plan.flags | _hip.FLAG_MASKED)
+  dplan_m = engine._PlanOnDevice(ctx, plan_m)  # pylint: disable=protected-access
+  mask_buf = ctx.upload(np.ones((nlat, nlon), np.uint8))
+  refused(_raw_call(ctx, plan_m, dplan_m, m, nlat * nlon, bufs['p'], bufs['t'], mask_buf, bufs['w'], bits_buf, nA, nBk, nBr, w_flags,
+                    nbin, atoms, out), 'lives on the W dims')
+  plan_s = dataclasses.replace(plan, flags=plan.flags | _hip.FLAG_SKIPNA)
+  dplan_s = engine._PlanOnDevice(ctx, plan_s)  # pylint: disable=protected-access
+  refused(_raw_call(ctx, plan_s, dplan_s, m, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], bits_buf, nA, nBk, nBr, w_flags,
+                    nbin, atoms, out), 'skipna')

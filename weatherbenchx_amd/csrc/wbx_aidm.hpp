@@ -1,0 +1,43 @@
+// A validity mask that lives on the W dims folded into the atom-id bytes of the patch kernels (det_atoms_kernel<.., MERGED>,
+// ens_atoms_kernel): one byte per point carries both, 255 = masked out.
+#pragma once
+#include "wbx_patch.hpp"
+#include "wbx_s1.hpp"
+
+namespace wbx {
+
+// aidm[bk][br][x] = mask(bk, br, x) ? aid[bk][br][x] : 255, for a mask that does not depend on A or the depth dims (the caller
+// says so: WBX_BINNED_MASK_ON_W): addressed through the plan's tables at A = 0, depth row 0.
+static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedArgs g, uint8_t* __restrict__ aidm) {
+  const int64_t row = blockIdx.x;  // (bk, br)
+  const int64_t bk = row / g.nBr, br = row - bk * g.nBr;
+  const int64_t key = bk * g.nBr + br;  // A = 0
+  const int64_t base = (a.key_off[3] ? a.key_off[3][key] : 0) + (a.depth_off[3] ? a.depth_off[3][0] : 0);
+  const uint8_t* m = reinterpret_cast<const uint8_t*>(a.in[3]) + base;
+  for (int64_t x = threadIdx.x; x < g.nj; x += blockDim.x) {
+    const int64_t i = row * g.nj + x;
+    aidm[i] = m[x * a.xstride[3]] != 0 ? g.aid[i] : (uint8_t)255;
+  }
+}
+
+// Launches the merge into the context's scratch (grown on demand) and points g.aidm at it.
+inline int merge_mask_into_atom_ids(wbx_ctx* ctx, const S1Args& a, BinnedArgs& g) {
+  const size_t need = (size_t)(g.nBk * g.nBr * g.nj);
+  if (ctx->aidm_scratch_size < need) {
+    if (ctx->aidm_scratch) {
+      WBX_HIP(hipStreamSynchronize(ctx->stream));
+      WBX_HIP(hipFree(ctx->aidm_scratch));
+      ctx->aidm_scratch = nullptr;
+      ctx->aidm_scratch_size = 0;
+    }
+    WBX_HIP(hipMalloc(&ctx->aidm_scratch, need));
+    ctx->aidm_scratch_size = need;
+  }
+  hipLaunchKernelGGL(aid_merge_kernel, dim3((unsigned)(g.nBk * g.nBr)), dim3(256), 0, ctx->stream, a, g,
+                     reinterpret_cast<uint8_t*>(ctx->aidm_scratch));
+  WBX_HIP(hipGetLastError());
+  g.aidm = reinterpret_cast<const uint8_t*>(ctx->aidm_scratch);
+  return 0;
+}
+
+}  // namespace wbx

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "wbx_aidm.hpp"
 #include "wbx_patch.hpp"
 #include "wbx_s1.hpp"
 
@@ -563,20 +564,6 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
   }
 }
 
-// aidm[bk][br][x] = mask(bk, br, x) ? aid[bk][br][x] : 255, for a mask that does not depend on A or the depth dims (the caller
-// says so: WBX_BINNED_MASK_ON_W): addressed through the plan's tables at A = 0, depth row 0.
-static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedArgs g, uint8_t* __restrict__ aidm) {
-  const int64_t row = blockIdx.x;  // (bk, br)
-  const int64_t bk = row / g.nBr, br = row - bk * g.nBr;
-  const int64_t key = bk * g.nBr + br;  // A = 0
-  const int64_t base = (a.key_off[3] ? a.key_off[3][key] : 0) + (a.depth_off[3] ? a.depth_off[3][0] : 0);
-  const uint8_t* m = reinterpret_cast<const uint8_t*>(a.in[3]) + base;
-  for (int64_t x = threadIdx.x; x < g.nj; x += blockDim.x) {
-    const int64_t i = row * g.nj + x;
-    aidm[i] = m[x * a.xstride[3]] != 0 ? g.aid[i] : (uint8_t)255;
-  }
-}
-
 // WBX_BINNED_ATOMS=0 sends every patch to the slot kernel (A/B timing); WBX_ATOMS_NT=0/1 pins the non-temporal hint
 static int atoms_setting(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -611,21 +598,7 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     bool merged = false;
     if constexpr (MM == 1) {
       if (mask_on_w && use_merged != 0 && nj == plan->nx && nj > 1) {  // the mask lives on the atom ids' own index space
-        const size_t need = (size_t)(nBk * nBr * nj);
-        if (ctx->aidm_scratch_size < need) {
-          if (ctx->aidm_scratch) {
-            WBX_HIP(hipStreamSynchronize(ctx->stream));
-            WBX_HIP(hipFree(ctx->aidm_scratch));
-            ctx->aidm_scratch = nullptr;
-            ctx->aidm_scratch_size = 0;
-          }
-          WBX_HIP(hipMalloc(&ctx->aidm_scratch, need));
-          ctx->aidm_scratch_size = need;
-        }
-        hipLaunchKernelGGL(aid_merge_kernel, dim3((unsigned)(nBk * nBr)), dim3(256), 0, ctx->stream, a, ga,
-                           reinterpret_cast<uint8_t*>(ctx->aidm_scratch));
-        WBX_HIP(hipGetLastError());
-        ga.aidm = reinterpret_cast<const uint8_t*>(ctx->aidm_scratch);
+        if (int rc = merge_mask_into_atom_ids(ctx, a, ga)) return rc;
         merged = true;
       }
     }

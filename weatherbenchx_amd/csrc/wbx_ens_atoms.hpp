@@ -1,0 +1,393 @@
+// The ensemble family with weights, boolean bin masks and a validity mask in ONE pass over the members: the public
+// benchmark's probabilistic configuration -- CRPS / spread-skill / ensemble-mean RMSE per region x land/sea (34 bins),
+// GridAreaWeighting, masked=True (public_benchmark/run_benchmark_evaluation.py:341-354, 365-382; aggregation.py:297-366).
+//
+// The two-stage route (wbx_ens_partial with x kept + wbx_contract_bits) writes a full-map partial of 5 lanes x 8 B per point
+// and reads it back: 43 % of the HBM peak where the un-binned sweep reaches 73 %.  Here the pipelined member sweep of
+// ens_pipe_kernel (the next tile's members travel HBM -> LDS by LDS-DMA while this tile is sorted in VGPRs) is combined with
+// the atom scheme of det_atoms_kernel (wbx_det_binned.hip):
+//   * one WAVE owns one patch = (cell (A, Bk), 64 consecutive x, a short range of the nBr * D reduced rows); a tile of the
+//     sweep is one ROW of the patch, so a lane stays on its x column and walks down the rows;
+//   * a point belongs to exactly one atom (= distinct 64-bit membership word of the patch; the index comes as one byte per
+//     point from binned_atoms_kernel, with the validity mask folded in as 255).  A lane keeps TWO private accumulator sets
+//     keyed by atom id (land / sea of one region pattern alternate for long runs): 2 x 5 fp64 FMAs per point, whatever the
+//     number of bins -- against ~1100 instructions for the sort and the member sums of that point;
+//   * when a lane with both sets taken meets a third atom the wave flushes ALL sets, lanes grouped by atom id, one DPP wave sum
+//     per (group, statistic), into the patch's [atom][statistic] table.  That table lives in GLOBAL memory (1.3 KB per patch,
+//     cache resident, touched by this wave only): the LDS is the staging buffer -- twelve one-wave blocks of 12.8 KB fill a
+//     CU's 160 KB -- and the register file is what the kernel is short of.  The bookkeeping of a row runs right after the
+//     staged members have been copied into VGPRs and BEFORE the next row's loads are issued, so a flush waits for nothing but
+//     its own accesses;
+//   * four value lanes are accumulated, not five: lane 3 = (mean - t)^2 - var / M = lane 4 - lane 2 / M at every point, and
+//     the weighted sums are linear, so it is formed once per (patch, bin) from the sums of lanes 2 and 4 (a NaN in either
+//     poisons it exactly like a NaN of its own).  The fifth accumulator is the count lane (sum of weights of the valid points);
+//   * at the end of the patch the table is expanded to the patch's bins in det_atoms_kernel's tmp layout: det_binned_finish and
+//     the NaN rule (poison = sum over atoms of sum * 0: a non-finite term anywhere turns every bin of that statistic NaN, like
+//     the reference's xr.dot, aggregation.py:272-277) are shared.
+// Weights come factored (WBX_BINNED_WT_X_ONLY / _ROW_ONLY: GridAreaWeighting on latitude- / longitude-fastest chunks):
+// w = w_x[x] * w_row[row], one of the two factors being 1 (exact).  The mask must live on the W dims (WBX_BINNED_MASK_ON_W).
+// Everything else (dense weights, time-dependent masks, skipna, skipna_ensemble, float64 members, M > 64) stays on the
+// two-stage route.
+#pragma once
+#include "wbx_aidm.hpp"
+#include "wbx_ens_impl.hpp"
+#include "wbx_patch.hpp"
+
+namespace wbx {
+
+constexpr int ENS_ATOMS_NQ = 5;    // accumulated per atom: skill, spread, variance, squared error of the mean, count
+constexpr int ENS_ATOMS_NOUT = 6;  // written per (patch, bin): the five ensemble lanes + the count lane
+
+#ifndef WBX_ENS_ATOMS_ROWS
+#define WBX_ENS_ATOMS_ROWS 16  // rows (= 64-point tiles) per patch; WBX_ENS_ATOMS_ROWS in the environment overrides
+#endif
+
+// a pointer that went through an opaque asm statement or an integer has lost its address space: say "global" again, or the
+// loads come out as flat_load (which also counts on lgkmcnt)
+template <typename T>
+using global_ptr = const __attribute__((address_space(1))) T*;
+
+// read-only tables (the plan's offset tables, the row weights) addressed with wave-uniform indices: through the constant
+// address space these are scalar loads (s_load, SGPR results, counted on lgkmcnt) -- plain global loads are vector loads even
+// when every lane asks for the same element
+template <typename T>
+using const_ptr = const __attribute__((address_space(4))) T*;
+
+// what a NULL table stands for (all zeros / all ones): selecting one of these instead of branching around a load keeps the
+// row lookups of the sweep free of control flow (the compiler waits for outstanding scalar loads wherever two paths join)
+static __constant__ int64_t wbx_zero_i64[1] = {0};
+static __constant__ double wbx_one_f64[1] = {1.0};
+
+struct EnsAtomsArgs {
+  const double* wx;    // [nBk][nj] or NULL (all ones)
+  const double* wrow;  // [nBk][nBr] or NULL (all ones)
+  double* tab;         // [cell][patch][ATOM_MAX][NQ]: the patches' atom tables (written before they are read: no memset)
+  int32_t masked;      // the atom ids are g.aidm (255 = masked out)
+  int64_t br_per_split;  // g.rows_per_split / D
+};
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
+template <int MP, bool EXACT, bool NT>
+__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+  using Op = EnsOpF32<MP, EXACT, WBX_ENS_SORT>;
+  constexpr int NQ = ENS_ATOMS_NQ, NOUT = ENS_ATOMS_NOUT;
+  constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
+  constexpr int NREG = MP - NLDS;                                        // members prefetched into VGPRs
+  constexpr int NST = NLDS < 8 ? 8 : NLDS;                               // (the end of the patch borrows 1.5 KB of it)
+  constexpr int NONE = 255;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NST * 256];
+  float(*stage)[64] = reinterpret_cast<float(*)[64]>(lds_raw);
+  const int lane = threadIdx.x;
+  const int M = EXACT ? MP : a.M;
+  int64_t cell;
+  int xt, rs;
+  if (!patch_decode<1>(g, cell, xt, rs)) return;
+  const int64_t bk = cell % g.nBk;
+  const int64_t A = cell / g.nBk;
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  const int64_t patch = (int64_t)rs * g.nxt + xt;
+  const int nw = g.nwords[bk * npatch + patch];
+  double* const out = g.tmp + (cell * npatch + patch) * (NOUT * (int64_t)g.nbin);
+  double* const tab = e.tab + (cell * npatch + patch) * (ATOM_MAX * NQ);
+  if (nw < 0) {
+    // more than ATOM_MAX distinct membership words in one patch (arbitrary user masks): this kernel has no slot fallback.
+    // The host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller that
+    // did not gets NaN in every bin of the cell instead of silently wrong sums.
+    for (int pr = lane; pr < NOUT * g.nbin; pr += 64) out[pr] = __builtin_nan("");
+    if (lane < NOUT) g.tmp_poison[(cell * npatch + patch) * NOUT + lane] = 0.0;
+    return;
+  }
+  const int64_t R = g.nBr * a.D;
+  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
+  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+
+  // lanes beyond a ragged nx re-read the last element and never accumulate
+  const bool live = (int64_t)xt * 64 + lane < a.nx;
+  const uint32_t x = live ? (uint32_t)xt * 64u + (uint32_t)lane : (uint32_t)a.nx - 1u;
+  const uint32_t xw = g.nj > 1 ? x : 0u;
+  const double w_lane = e.wx ? e.wx[bk * g.nj + xw] : 1.0;
+  const uint8_t* const ids = e.masked ? g.aidm : g.aid;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)&stage[0][0];
+  const int64_t mstride_b = a.mstride * 4;
+  const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+
+  int c0 = NONE, c1 = NONE;  // the atoms this lane is accumulating
+  double acc0[NQ], acc1[NQ];
+#pragma unroll
+  for (int l = 0; l < NQ; ++l) acc0[l] = acc1[l] = 0.0;
+  uint32_t touched = 0u;  // atoms whose table row has been written (wave-uniform): the first flush of an atom stores
+
+  // Flush BOTH sets of EVERY lane into the patch's table and empty them: lanes grouped by atom id, one DPP wave sum per
+  // (group, statistic); lane l < NQ owns column l of the table (the only lane that ever reads or writes it).
+  auto flush_all = [&]() {
+#pragma unroll 1
+    for (int s = 0; s < 2; ++s) {
+      const int id = s ? c1 : c0;
+      const bool go = id != NONE;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(go);
+      while (todo) {
+        const int gid = __builtin_amdgcn_readlane(id, __builtin_ctzll(todo));
+        const bool sel = go && id == gid;
+        double mine = 0.0;
+#pragma unroll
+        for (int l = 0; l < NQ; ++l) {
+          const double sum = wave_sum_uniform(sel ? (s ? acc1[l] : acc0[l]) : 0.0);
+          if (lane == l) mine = sum;
+        }
+        if (lane < NQ) {
+          double* q = tab + gid * NQ + lane;
+          *q = ((touched >> gid) & 1u) ? *q + mine : mine;
+        }
+        touched |= 1u << gid;
+        todo &= ~__builtin_amdgcn_ballot_w64(sel);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < NQ; ++l) acc0[l] = acc1[l] = 0.0;
+    c0 = c1 = NONE;
+  };
+
+  // ---- rows.  Everything about a row is wave-uniform and lives in SCALAR registers: the offsets of row i + 2 are looked up
+  // in the plan's tables (scalar loads) right after the loads of row i + 1 have been issued, and arrive while row i is sorted.
+  // (A first version resolved 64 rows at a time lane-parallel like det_atoms_kernel: eight vector registers this kernel does
+  // not have.)  Row r of the cell = (br, d) = (r / D, r mod D), stepped without a division.
+  const int nrows = (int)(rend - rbeg);  // (the launcher checked that the row counts fit 31 bits)
+  const int nD = (int)a.D;
+  int br_a = (int)((int64_t)rs * e.br_per_split);  // (row splits are whole Br rows: rbeg = br_a * D)
+  int d_a = 0;
+  const int br_last = (int)((rend - 1) / a.D);
+  const int64_t key0 = (A * g.nBk + bk) * g.nBr, wrow0 = bk * g.nBr;
+  int64_t ra0k = 0, ra0d = 0, ra1k = 0, ra1d = 0, wra = 0;  // the row looked up ahead (the table entries as they were loaded:
+  double wwa = 1.0;                                          // adding them here would wait for the loads on the spot)
+  // Unconditional (past the patch's last row it looks the last row up again): under a branch the scalar loads would be
+  // waited for at the join, in front of the sort.
+  const const_ptr<int64_t> zero = (const_ptr<int64_t>)wbx_zero_i64;
+  const const_ptr<int64_t> tk0 = a.key_off[0] ? (const_ptr<int64_t>)a.key_off[0] : zero, td0 = a.depth_off[0] ? (const_ptr<int64_t>)a.depth_off[0] : zero;
+  const const_ptr<int64_t> tk1 = a.key_off[1] ? (const_ptr<int64_t>)a.key_off[1] : zero, td1 = a.depth_off[1] ? (const_ptr<int64_t>)a.depth_off[1] : zero;
+  const const_ptr<double> twr = e.wrow ? (const_ptr<double>)e.wrow : (const_ptr<double>)wbx_one_f64;
+  const int64_t mk0 = a.key_off[0] ? -1 : 0, md0 = a.depth_off[0] ? -1 : 0, mk1 = a.key_off[1] ? -1 : 0, md1 = a.depth_off[1] ? -1 : 0,
+                mwr = e.wrow ? -1 : 0;  // index masks: a stand-in table has one element
+  auto resolve_ahead = [&]() {
+    const int64_t key = key0 + br_a;
+    ra0k = tk0[key & mk0];
+    ra0d = td0[(int64_t)d_a & md0];
+    ra1k = tk1[key & mk1];
+    ra1d = td1[(int64_t)d_a & md1];
+    wra = (wrow0 + br_a) * g.nj;
+    wwa = twr[(wrow0 + br_a) & mwr];
+    const bool wrap = d_a + 1 == nD;
+    d_a = wrap ? 0 : d_a + 1;
+    br_a = (wrap && br_a < br_last) ? br_a + 1 : br_a;
+  };
+
+  // the tile (row) in flight
+  float xn[NREG > 0 ? NREG : 1], tn = 0.f;
+  int idn = NONE;
+  int64_t ron0 = 0, ron1 = 0;
+  double wrn = 1.0;
+  const uint32_t sx0 = (uint32_t)a.xstride[0] * 4u, sx1 = (uint32_t)a.xstride[1] * 4u, sxw = g.nj > 1 ? 1u : 0u;
+  auto issue = [&]() {  // the row that was looked up ahead
+    ron0 = ra0k + ra0d;
+    ron1 = ra1k + ra1d;
+    wrn = wwa;
+    // 32-bit BYTE offsets of the lane (the launcher checked they fit), formed here from x: every load of the sweep is
+    //  SGPR row base + one VGPR offset.  Kept as loop-invariant registers they were three more than the kernel has, hoisted
+    // zero extensions of them are 64-bit pairs, and the instruction selector only folds  base + zext(offset)  into one load
+    // when it sees the extension in the same block: hence the opaque statement.
+    uint32_t o0 = x * sx0, o1 = x * sx1, ow = x * sxw;
+    asm volatile("" : "+v"(o0), "+v"(o1), "+v"(ow));
+    // (opaque SGPR row pointers: left alone, the compiler re-associates  (base + row) + lane offset  into a hoisted 64-bit
+    //  VECTOR pointer per operand plus a scalar)
+    const float* tr = reinterpret_cast<const float*>(a.in[1]) + ron1;
+    asm volatile("" : "+s"(tr));
+    const global_ptr<float> tq = (global_ptr<float>)((global_ptr<char>)tr + o1);
+    tn = NT ? __builtin_nontemporal_load(tq) : *tq;
+    const uint8_t* ir = ids + wra;
+    asm volatile("" : "+s"(ir));
+    idn = ((global_ptr<uint8_t>)ir)[ow];
+    const char* um = uniform_ptr(reinterpret_cast<const char*>(a.in[0]) + ron0 * 4);
+#pragma unroll
+    for (int m = 0; m < NLDS; ++m) {
+      if (EXACT || m < M) {
+        if constexpr (NT)
+          asm volatile("s_add_u32 m0, %2, %3\n\tglobal_load_lds_dword %0, %1 nt" ::"v"(o0), "s"(um), "s"(lds0), "i"(m * 256)
+                       : "memory", "scc", "m0");
+        else
+          asm volatile("s_add_u32 m0, %2, %3\n\tglobal_load_lds_dword %0, %1" ::"v"(o0), "s"(um), "s"(lds0), "i"(m * 256)
+                       : "memory", "scc", "m0");
+      }
+      um += mstride_b;
+      asm volatile("" : "+s"(um));  // one s_add_u32 / s_addc_u32 per member, not a table of 50 hoisted products
+    }
+#pragma unroll
+    for (int m = NLDS; m < MP; ++m) {  // the members beyond the staging buffer ride in registers
+      const global_ptr<float> pr = (global_ptr<float>)((global_ptr<char>)um + o0);
+      if constexpr (NT)
+        xn[m - NLDS] = (EXACT || m < M) ? __builtin_nontemporal_load(pr) : INFINITY;
+      else
+        xn[m - NLDS] = (EXACT || m < M) ? *pr : INFINITY;
+      um += mstride_b;
+      asm volatile("" : "+s"(um));
+    }
+  };
+
+  if (nrows > 0) {
+    resolve_ahead();
+    issue();
+    resolve_ahead();
+  }
+  for (int i = 0; i < nrows; ++i) {
+    typename Op::Regs r;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < NLDS; ++m) r.xm[m] = (EXACT || m < M) ? stage[m][lane] : INFINITY;
+#pragma unroll
+    for (int m = NLDS; m < MP; ++m) r.xm[m] = xn[m - NLDS];
+    r.t = tn;
+    const int id = idn;
+    const double w = w_lane * wrn;
+    int64_t rocur[WBX_MAX_INPUTS];
+    rocur[0] = ron0;
+    rocur[1] = ron1;
+    rocur[2] = rocur[3] = 0;
+
+    // ---- hit / miss bookkeeping of the lane's two accumulator sets (wave masks in scalar registers, see det_atoms_kernel);
+    // no load of the next row is in flight here
+    const unsigned long long m_ok = live_mask & __builtin_amdgcn_ballot_w64(id != NONE);
+    unsigned long long n0 = __builtin_amdgcn_ballot_w64(id != c0), n1 = __builtin_amdgcn_ballot_w64(id != c1);
+    if (m_ok & n0 & n1) {  // wave-uniform: a lane meets an atom it is not accumulating
+      const bool ok = __builtin_amdgcn_inverse_ballot_w64(m_ok);
+      const bool miss = __builtin_amdgcn_inverse_ballot_w64(m_ok & n0 & n1);
+      bool place = miss;
+      if (__builtin_amdgcn_ballot_w64(miss && c0 != NONE && c1 != NONE)) {
+        flush_all();
+        place = ok;  // every set is empty now: the lanes that had a hit re-enter their atom too
+      }
+      if (place && c0 == NONE) c0 = id;
+      else if (place) c1 = id;
+      n0 = __builtin_amdgcn_ballot_w64(id != c0);
+      n1 = __builtin_amdgcn_ballot_w64(id != c1);
+    }
+    const unsigned long long h0 = m_ok & ~n0, h1 = m_ok & ~n1;
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile has left the staging buffer
+    if (i + 1 < nrows) issue();
+    resolve_ahead();
+
+    double val[Op::NLANE];
+    Op::template finish<true>(a, rocur, (int64_t)x, r, val);
+    const double q[4] = {val[0], val[1], val[2], val[4]};
+    if (__builtin_amdgcn_inverse_ballot_w64(h0)) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc0[l] = fma(q[l], w, acc0[l]);
+      acc0[4] += w;
+    }
+    if (__builtin_amdgcn_inverse_ballot_w64(h1)) {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc1[l] = fma(q[l], w, acc1[l]);
+      acc1[4] += w;
+    }
+  }
+  flush_all();
+
+  // ---- atoms -> bins.  Lane l < NQ hands its column of the table (its own writes) to the wave through the LDS: the staging
+  // buffer is idle now.  ltab[k][l], l = accumulated statistic; wl[k] = membership word of atom k.
+  double* const ltab = reinterpret_cast<double*>(lds_raw);
+  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lds_raw + ATOM_MAX * NQ * sizeof(double));
+  __syncthreads();
+  if (lane < NQ)
+    for (int k = 0; k < nw; ++k) ltab[k * NQ + lane] = ((touched >> k) & 1u) ? tab[k * NQ + lane] : 0.0;
+  if (lane < ATOM_MAX) wl[lane] = g.words[(bk * npatch + patch) * ATOM_MAX + lane];
+  __syncthreads();
+  const double inv_m = 1.0 / (double)M;
+  // output lane -> accumulated statistics: 0 skill, 1 spread, 2 variance, 3 = (4) - (2) / M, 4 squared error of the mean, 5 count
+  auto term = [&](int k, int l) -> double {
+    const double* row = ltab + k * NQ;
+    if (l < 3) return row[l];
+    if (l == 3) return row[3] - row[2] * inv_m;
+    return row[l - 1];
+  };
+  unsigned long long uni = 0ull;
+  for (int k = 0; k < nw; ++k) uni |= wl[k];
+  // every (statistic, bin) of the patch is written, zeros for the bins outside the union: det_binned_finish sums plain rows
+  for (int pr = lane; pr < NOUT * g.nbin; pr += 64) {
+    const int l = pr / g.nbin, bit = pr - l * g.nbin;
+    double s = 0.0;
+    if ((uni >> bit) & 1ull)
+      for (int k = 0; k < nw; ++k)
+        if ((wl[k] >> bit) & 1ull) s += term(k, l);
+    out[pr] = s;
+  }
+  if (lane < NOUT) {
+    double ps = 0.0;
+    for (int k = 0; k < nw; ++k) ps = fma(term(k, lane), 0.0, ps);
+    g.tmp_poison[(cell * npatch + patch) * NOUT + lane] = ps;
+  }
+}
+#pragma clang diagnostic pop
+
+// What wbx_ens_binned was called with, besides the plan and the inputs in S1Args.
+struct EnsBinnedCall {
+  const double* wt;      // factored weights (see w_on_x) or NULL
+  const uint64_t* bits;  // [nBk][nBr][nj]
+  int64_t nA, nBk, nBr, nj;
+  int32_t nbin, w_on_x;
+  const void* prepared;  // atom tables of wbx_ens_binned_atoms, or NULL (computed inside the call)
+  double* out;           // [nA][nBk][ENS_ATOMS_NOUT][nbin]
+};
+
+inline int64_t ens_atoms_rows() {
+  static const int64_t rows = getenv("WBX_ENS_ATOMS_ROWS") && atol(getenv("WBX_ENS_ATOMS_ROWS")) > 0 ? atol(getenv("WBX_ENS_ATOMS_ROWS")) : WBX_ENS_ATOMS_ROWS;
+  return rows;
+}
+
+template <int MP, bool EXACT>
+int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const EnsBinnedCall& c) {
+  BinnedArgs g;
+  double* tab = nullptr;
+  const int64_t cells = c.nA * c.nBk;
+  // (the table scratch is sized for the geometry patch_setup is about to choose: same call as inside it)
+  BinnedArgs probe;
+  patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows());
+  probe.nbin = c.nbin;
+  const size_t n_tab = (size_t)probe.nblocks * ATOM_MAX * ENS_ATOMS_NQ, n_part = patch_finish2_scratch(probe, ENS_ATOMS_NOUT);
+  if (int rc = patch_setup(ctx, g, nullptr, c.bits, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ENS_ATOMS_NOUT, c.nbin, true,
+                           c.prepared, true, ens_atoms_rows(), n_tab + n_part, &tab))
+    return rc;
+  EnsAtomsArgs e;
+  e.wx = (c.w_on_x & WBX_BINNED_WT_X_ONLY) ? c.wt : nullptr;
+  e.wrow = (c.w_on_x & WBX_BINNED_WT_ROW_ONLY) ? c.wt : nullptr;
+  e.tab = tab;
+  e.masked = 0;
+  e.br_per_split = g.rows_per_split / plan->ndepth;
+  if (plan->flags & WBX_FLAG_MASKED) {
+    if (int rc = merge_mask_into_atom_ids(ctx, a, g)) return rc;
+    e.masked = 1;
+  }
+  static const int nt_env = getenv("WBX_ENS_ATOMS_NT") ? atoi(getenv("WBX_ENS_ATOMS_NT")) : -1;
+  static const int order_env = getenv("WBX_PATCH_ORDER") ? atoi(getenv("WBX_PATCH_ORDER")) : -1;
+  // rows that are not whole 128-byte lines (721 latitudes): neighbouring x tiles share their boundary lines -- x tile fastest
+  // block order and no non-temporal hint, so that the second request of a line finds it in L2 (see det_atoms_kernel)
+  const bool ragged_lines = (plan->nx * plan->xstride[0] * 4) % 128 != 0 || plan->xstride[0] != 1;
+  const bool nt = nt_env >= 0 ? nt_env != 0 : !ragged_lines;
+  g.order = order_env >= 0 ? order_env : (ragged_lines ? 1 : 0);
+  const int64_t grid = patch_grid<1>(g);
+  if (nt)
+    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
+  else
+    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
+  WBX_HIP(hipGetLastError());
+  return patch_finish2(ctx, g, ENS_ATOMS_NOUT, tab + n_tab, c.out);
+}
+
+// one translation unit per bucket (parallel build)
+int launch_ens_atoms_m4(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m8(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m16(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m32(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m64(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m50(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+int launch_ens_atoms_m51(wbx_ctx*, const wbx_s1_plan*, S1Args&, const EnsBinnedCall&);
+
+}  // namespace wbx

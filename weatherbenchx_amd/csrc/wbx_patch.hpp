@@ -185,7 +185,10 @@ static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, 
 
 
 // Patch geometry: rows = nBr * D reduced rows of nx points per cell, cut into nrs row splits x nxt tiles of 64 x.
-inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nBr, int64_t nj, int64_t D, int64_t nx) {
+// rows_hint > 0: patches of about that many rows instead (the ensemble atom kernel, wbx_ens_atoms.hpp: a row of a patch is a
+// 64-point tile of ~2.4 us there, so its patches are short).
+inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nBr, int64_t nj, int64_t D, int64_t nx,
+                           int64_t rows_hint = 0) {
   g.nBk = nBk;
   g.nBr = nBr;
   g.nj = nj;
@@ -202,6 +205,7 @@ inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nB
   int64_t want = (target + cells * g.nxt - 1) / (cells * g.nxt);
   if (want > (rows + 63) / 64) want = (rows + 63) / 64;
   if (want < 1) want = 1;
+  if (rows_hint > 0) want = (rows + rows_hint - 1) / rows_hint;
   g.rows_per_split = (rows + want - 1) / want;
   g.rows_per_split = (g.rows_per_split + D - 1) / D * D;  // whole Br rows per split: a (bk, br, x) point has ONE patch
   g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
@@ -238,17 +242,19 @@ inline int atoms_launch(wbx_ctx* ctx, BinnedArgs& g, const uint64_t* bits, int64
 
 // Scratch (tmp | poison [| atom tables]) and, unless the caller brought prepared atom tables, the atom pre-kernel.
 // nacc = accumulated lanes.
+// extra_doubles > 0: that many more doubles of scratch per patch launch, handed back through extra_out (not initialised).
 inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
                        int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false,
-                       const void* prepared = nullptr, bool tmp_written_by_kernels = false) {
+                       const void* prepared = nullptr, bool tmp_written_by_kernels = false, int64_t rows_hint = 0,
+                       size_t extra_doubles = 0, double** extra_out = nullptr) {
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
   g.nbin = nbin;
   g.aidm = nullptr;
-  patch_geometry(g, cells, nBk, nBr, nj, D, nx);
+  patch_geometry(g, cells, nBk, nBr, nj, D, nx, rows_hint);
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
-  const size_t need = (n_tmp + n_poison) * sizeof(double) + (prepared ? 0 : atoms_carve(g, nullptr));
+  const size_t need = (n_tmp + n_poison + extra_doubles) * sizeof(double) + (prepared ? 0 : atoms_carve(g, nullptr));
   if (ctx->s2_scratch_size < need) {
     if (ctx->s2_scratch) {
       WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -261,6 +267,7 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   }
   g.tmp = reinterpret_cast<double*>(ctx->s2_scratch);
   g.tmp_poison = g.tmp + n_tmp;
+  if (extra_out) *extra_out = g.tmp_poison + n_poison;
   // (det_atoms_kernel writes every bin of every patch itself -- zeros for the patches it leaves to the slot kernel --, so
   // the 29 MB memset of a public-benchmark chunk, 12 us + a dependency gap in front of a 0.39 ms kernel, is not needed there)
   if (!tmp_written_by_kernels) WBX_HIP(hipMemsetAsync(g.tmp, 0, n_tmp * sizeof(double), ctx->stream));
@@ -270,8 +277,54 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
     g.atoms = 1;
     return 0;
   }
-  atoms_carve(g, g.tmp_poison + n_poison);
+  atoms_carve(g, g.tmp_poison + n_poison + extra_doubles);
   return atoms_launch(ctx, g, bits, D, nx, atoms);
+}
+
+// The same sum in two levels, for launches with many short patches (the ensemble atom kernel: ~1000 patches per cell, where
+// one block per (cell, lane) walked 1.6 KB strides for 46 us behind a 0.32 ms kernel): level 1, one block per (cell, group of
+// G consecutive patches), thread = element e of the patch's [nacc][nbin] result -- every read is a contiguous row --; level 2,
+// one block per cell adds the groups.  Fixed order, no atomics.
+static __global__ void __launch_bounds__(256) patch_finish_groups(int64_t npatch, int nacc, int nbin, int G, int ngroup,
+                                                                  const double* __restrict__ tmp, const double* __restrict__ poison,
+                                                                  double* __restrict__ part) {
+  const int64_t cell = blockIdx.x / ngroup;
+  const int grp = (int)(blockIdx.x % ngroup);
+  const int ne = nacc * nbin;
+  const int64_t k0 = (int64_t)grp * G, k1 = k0 + G < npatch ? k0 + G : npatch;
+  for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+    const int l = e / nbin;
+    double s = 0.0;
+    for (int64_t k = k0; k < k1; ++k) s += tmp[(cell * npatch + k) * ne + e] + poison[(cell * npatch + k) * nacc + l];
+    part[(cell * ngroup + grp) * ne + e] = s;
+  }
+}
+
+static __global__ void __launch_bounds__(256) patch_finish_cells(int ne, int ngroup, const double* __restrict__ part,
+                                                                 double* __restrict__ out) {
+  const int64_t cell = blockIdx.x;
+  for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+    double s = 0.0;
+    for (int q = 0; q < ngroup; ++q) s += part[(cell * ngroup + q) * ne + e];
+    out[cell * ne + e] = s;  // out[cell][lane][bin]
+  }
+}
+
+constexpr int PATCH_FINISH_GROUP = 16;  // patches per level-1 block
+inline size_t patch_finish2_scratch(const BinnedArgs& g, int nacc) {  // doubles
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  return (size_t)(g.ncell * ((npatch + PATCH_FINISH_GROUP - 1) / PATCH_FINISH_GROUP) * nacc * g.nbin);
+}
+
+inline int patch_finish2(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* part, double* out) {
+  const int64_t npatch = (int64_t)g.nrs * g.nxt;
+  const int ngroup = (int)((npatch + PATCH_FINISH_GROUP - 1) / PATCH_FINISH_GROUP);
+  hipLaunchKernelGGL(patch_finish_groups, dim3((unsigned)(g.ncell * ngroup)), dim3(256), 0, ctx->stream, npatch, nacc, (int)g.nbin,
+                     PATCH_FINISH_GROUP, ngroup, g.tmp, g.tmp_poison, part);
+  WBX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(patch_finish_cells, dim3((unsigned)g.ncell), dim3(256), 0, ctx->stream, nacc * (int)g.nbin, ngroup, part, out);
+  WBX_HIP(hipGetLastError());
+  return 0;
 }
 
 inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out) {

@@ -1002,6 +1002,91 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   return handle, shape
 
 
+# The ensemble family with weights, bins and mask in ONE pass (wbx_ens_binned, csrc/wbx_ens_atoms.hpp) whenever it applies:
+# rank form, float32, 2..64 members, boolean bin masks, separable weights, a validity mask that lives on the W dims, no
+# skipna.  False: the two-stage route (x-kept ensemble kernel + wbx_contract_bits), for A/B timing and tests.
+ENS_BINNED = os.environ.get('WBX_ENS_BINNED', '1') != '0'
+ENS_BINNED_LANES = 6  # the five ensemble lanes + the count lane, always
+
+
+def _mask_on_w_only(plan: planner.S1Plan, mask_dev) -> bool:
+  return all(mask_dev.layout.stride(d) == 0 for d in tuple(plan.a_dims) + tuple(plan.depth_dims))
+
+
+def _ens_binned_flags(plan: planner.S1Plan, w_buf, devs):
+  """WBX_BINNED_* flags of a wbx_ens_binned call, or None when the weights / the mask rule it out."""
+  w_flags = _hip.BINNED_W_ON_X if (plan.x_kept and plan.nj > 1) else 0
+  if w_buf.factored is None or not SEPARABLE_BINNED_WEIGHTS:
+    return None
+  w_flags |= w_buf.factored[0]
+  if (w_flags & _hip.BINNED_WT_X_ONLY) and not (w_flags & _hip.BINNED_W_ON_X):
+    return None
+  if devs[3] is not None:
+    if not (w_flags & _hip.BINNED_W_ON_X) or not _mask_on_w_only(plan, devs[3]):
+      return None
+    w_flags |= _hip.BINNED_MASK_ON_W
+  return w_flags
+
+
+def _ens_binned_atoms(ctx, dplan, plan: planner.S1Plan, w_buf, w_flags):
+  """The atom tables of (bins, launch geometry) for wbx_ens_binned, computed once and kept with the device copy of W; None
+  when some patch holds more distinct membership words than the kernel's table takes (arbitrary user masks)."""
+  nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
+  akey = ('ens', ctx.device_id, nA, nBk, nBr, plan.ndepth, plan.nx, w_flags & _hip.BINNED_W_ON_X)
+  hit = w_buf.atoms.get(akey)
+  if hit is None:
+    nbytes = C.c_int64(0)
+    _hip.check(ctx.lib.wbx_ens_binned_atoms_size(C.byref(dplan.struct), nA, nBk, nBr, w_flags & _hip.BINNED_W_ON_X,
+                                                 C.byref(nbytes)), 'wbx_ens_binned_atoms_size')
+    atoms = ctx.alloc(int(nbytes.value))
+    overflow = C.c_int64(0)
+    _hip.check(ctx.lib.wbx_ens_binned_atoms(ctx.handle, C.byref(dplan.struct), nA, nBk, nBr, w_flags & _hip.BINNED_W_ON_X,
+                                            C.c_void_p(w_buf.bufs[1].ptr), C.c_void_p(atoms.ptr), C.byref(overflow)),
+               'wbx_ens_binned_atoms')
+    if len(w_buf.atoms) > 8:
+      w_buf.atoms.clear()
+    hit = w_buf.atoms[akey] = (atoms, int(overflow.value))
+  return hit[0] if hit[1] == 0 else None
+
+
+def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype_code, flags, ens):
+  """(w_flags, atoms) when this reduction runs on wbx_ens_binned, else None."""
+  if kind != 'ens' or not ENS_BINNED or w_buf.kind != 'bits' or dtype_code != _hip.F32:
+    return None
+  if ens['algo'] != _hip.ENS_SORT or not 2 <= ens['M'] <= 64 or (flags & (_hip.FLAG_SKIPNA | _hip.FLAG_SKIPNA_ENS)):
+    return None
+  if plan.x_kept and not plan.sum_j:  # x survives into the output: the two-stage path keeps it
+    return None
+  if plan.nkey * plan.ndepth * plan.nx == 0 or plan.xstride[0] < 0 or plan.xstride[1] < 0 or plan.nx * plan.xstride[0] * 4 >= 1 << 32:
+    return None
+  w_flags = _ens_binned_flags(plan, w_buf, devs)
+  if w_flags is None:
+    return None
+  atoms = _ens_binned_atoms(ctx, dplan, plan, w_buf, w_flags)
+  if atoms is None:
+    return None
+  return w_flags, atoms
+
+
+def _run_ens_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_code: int, ens_args, w_buf, route):
+  """wbx_ens_binned -> (device pointer, shape) of out[nA][nBk][6][1][nbin]: lanes 0-4 the ensemble family, lane 5 the sum of
+  the weights of the valid points (the count lane)."""
+  w_flags, atoms = route
+  nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
+  nbin = w_buf.shape[-1]
+  shape = (nA, nBk, ENS_BINNED_LANES, 1, nbin)
+  out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  m, mstride, algo = ens_args
+
+  def call():
+    _hip.check(ctx.lib.wbx_ens_binned(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(algo), ptr(devs[0]),
+                                      ptr(devs[1]), ptr(devs[3]), C.c_void_p(w_buf.factored[1].ptr), C.c_void_p(w_buf.bufs[1].ptr),
+                                      nA, nBk, nBr, w_flags, nbin, C.c_void_p(atoms.ptr), C.c_void_p(out_ptr)), 'wbx_ens_binned')
+  timed_launch(ctx, call, kind='ens_binned', nbin=nbin, w_flags=w_flags, flags=int(plan.flags))
+  return handle, shape
+
+
 def dense_w(plan: planner.S1Plan, w_da: xr.DataArray | None, bin_dims: Sequence) -> tuple[np.ndarray, tuple]:
   """W as float64 [nBk][nBr][nj][nbin] from the labeled product of weights and bin masks."""
   bin_dims = tuple(bin_dims)
@@ -1099,7 +1184,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
-  if _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
+  ens_route = _ens_binned_route(ctx, kind, plan, dplan, w_buf, devs, dtype_code, flags, ens) if kind == 'ens' else None
+  if ens_route is not None:
+    res = _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, ens_route)
+  elif _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
     res = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
   else:
     partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args, inputs=inputs)
