@@ -72,7 +72,7 @@ def parse():
   ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                   help='torch.distributed backend for N > 1; gloo combines through the host and lets several ranks share '
                        'one device (a plumbing check of the N > 1 path on a 1-GPU box, not a measurement)')
-  ap.add_argument('--legs', default='all', help='comma list of main,configs1,ensemble,public_chunk,spectrum,lat_fastest,config5,cpu '
+  ap.add_argument('--legs', default='all', help='comma list of main,configs1,ensemble,public_chunk,public_chunk_ens,spectrum,lat_fastest,config5,cpu '
                   '(profiling passes: one kernel shape per trace); default all')
   ap.add_argument('--small', action='store_true', help='tiny sizes (debugging only; not a valid measurement)')
   return ap.parse_args()
@@ -581,6 +581,115 @@ def public_chunk_leg(env):
           'check': {'acc_first': float(np.asarray(pout['acc.z'].values).reshape(-1)[0])}}
 
 
+# ---- public-benchmark chunk, probabilistic configuration --------------------------------------------------------------
+def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
+  """The reference's probabilistic evaluation (public_benchmark/run_benchmark_evaluation.py:341-354, 365-382): the ensemble
+  suite under Regions(17) x land/sea = 34 bins, GridAreaWeighting, masked=True, on one f32[1 init, 8 lead, 51 member, lat, lon]
+  chunk.  Without a `mask` coordinate on the variable (most variables) the whole suite is ONE wbx_ens_binned launch --
+  asserted.  `with_mask`: the targets carry a (latitude, longitude) `mask` coordinate; the reference then masks skill /
+  unbiased MSE / mean MSE and leaves the statistics of the predictions alone (spread, variance: no mask coordinate,
+  probabilistic.py:165-273) unmasked, so there are two launches, each one pass over the members -- asserted.  The roofline is
+  that of a launch.  `ifs_layout`: the recorded IFS-ENS dim order (init, number, lead, longitude, latitude),
+  docs/source/how_to/metric_wrappers.ipynb:955-964."""
+  from weatherbenchx_amd import aggregation, binning, engine, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  sys.path.insert(0, os.path.join(ROOT, 'tools'))
+  from wb_regions import REGIONS  # the reference's region table restated as data
+  args, m = env.args, 51
+  nl = 8 if not args.small else 2
+  sp_shape = env.sp_shape()
+  coords = {'init_time': np.array(['2020-01-01T00'], dtype='datetime64[ns]'),
+            'lead_time': (np.arange(nl) * 12).astype('timedelta64[h]').astype('timedelta64[ns]'), 'latitude': env.lat, 'longitude': env.lon}
+  if ifs_layout:
+    pdims, tdims = ('init_time', 'number', 'lead_time') + env.sp, ('init_time', 'lead_time') + env.sp
+    tv = env.randn((1, nl) + sp_shape, 280.0)
+    ens = env.randn((1, m, nl) + sp_shape)
+    ens += tv[:, None]
+  else:
+    pdims, tdims = ('init_time', 'lead_time', 'number') + env.sp, ('init_time', 'lead_time') + env.sp
+    tv = env.randn((1, nl) + sp_shape, 280.0)
+    ens = env.randn((1, nl, m) + sp_shape)
+    ens += tv[:, :, None]
+  tv += env.randn((1, nl) + sp_shape)
+  land = (np.sin(np.deg2rad(env.lon) * 3)[None, :] * np.cos(np.deg2rad(env.lat) * 2.5)[:, None]
+          + 0.3 * np.sin(np.deg2rad(env.lon) * 17)[None, :] * np.sin(np.deg2rad(env.lat) * 13)[:, None]) > 0.35
+  valid = ~((np.abs(env.lat)[:, None] > 80) & (np.cos(np.deg2rad(env.lon) * 5)[None, :] > 0.2))  # a NaN-mask-like hole at the poles
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': env.lat, 'longitude': env.lon})
+  mv = valid if env.sp == ('latitude', 'longitude') else np.ascontiguousarray(valid.T)
+  mask_da = xr.DataArray(env.torch.as_tensor(mv, device=env.dev), dims=env.sp, coords={'latitude': env.lat, 'longitude': env.lon})
+  metrics = ensemble_suite()
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+  env.torch.cuda.synchronize()
+
+  def launch():
+    p = xr.DataArray(ens, dims=pdims, coords={k: v for k, v in coords.items() if k in pdims})
+    t = xr.DataArray(tv, dims=tdims, coords={k: v for k, v in coords.items() if k in tdims})
+    if with_mask:
+      t = t.assign_coords(mask=mask_da)
+    return agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t}))
+
+  def run(n):
+    with engine.deferred_results():
+      return pipelined(launch, lambda s: s.metric_values(metrics), n)
+  run(max(args.warmup, 2))
+  env.sync()
+  t0 = time.perf_counter()
+  out = run(args.steps * 2)
+  env.sync()
+  ms_chunk = (time.perf_counter() - t0) / (args.steps * 2) * 1e3
+  # the launches of one chunk, each alone on its stream between HIP events (synchronising)
+  saved = engine.ALTERNATE_STREAMS
+  engine.ALTERNATE_STREAMS = False
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 10
+  try:
+    launch().wait()
+    log = list(engine.S1_EVENT_LOG)
+  finally:
+    engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT, engine.ALTERNATE_STREAMS = None, 1, saved
+  kinds = sorted((e['kind'], e.get('flags', 0) & 1) for e in log)
+  # one pass over the members (per mask setting), nothing else
+  assert kinds == ([('ens_binned', 0), ('ens_binned', 1)] if with_mask else [('ens_binned', 0)]), kinds
+  points = nl * env.nlat * env.nlon
+  k_ms = float(np.mean([e['ms'] for e in log]))
+  name = f"ens_atoms_kernel<{m},true,{'NT' if env.layout == 'lon_fastest' else 'L2-shared lines'}> behind wbx_ens_binned"
+  roof = kernel_roofline(name, k_ms, points * (m + 1) * 4,
+                         pmc_traffic('ens_atoms_kernel', not args.small, f"public_chunk_ens{'_ifs' if ifs_layout else ''}@{env.layout}"))
+  roof['kernel_ms_source'] = 'HIP events around 10 back-to-back repetitions of each launch of a chunk, mean per launch (one stream)'
+  roof['launch_includes'] = ('aid_merge (mask folded into the atom ids, masked launch only) + ens_atoms_kernel with its in-kernel '
+                             'sums over patches: no second-stage or finish kernel')
+  # a sampled check against the oracle, outside the timed region: one lead time, every bin of CRPS
+  from oracle import wbx_oracle as O
+  lead = nl - 1
+  sel_p = ens[0, :, lead] if ifs_layout else ens[0, lead]
+  pv = sel_p.cpu().numpy()
+  tvh = tv[0, lead].cpu().numpy()
+  od_p, od_t = ('number',) + env.sp, env.sp
+  skill, sd = O.crps_skill(pv, od_p, tvh, od_t, 'number')
+  spread, _ = O.crps_spread(pv, od_p, 'number', fair=True, use_sort=True)
+  names, masks = O.region_masks(env.lat, env.lon, REGIONS, land_sea_mask=land)
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  w = (O.grid_area_weights(env.lat), ('latitude',))
+  a = O.aggregate(skill, sd, ['latitude', 'longitude'], weights=[w], bin_masks=bm, mask=valid if with_mask else None,
+                  mask_dims=('latitude', 'longitude') if with_mask else None)
+  b = O.aggregate(spread, sd, ['latitude', 'longitude'], weights=[w], bin_masks=bm)
+  want = O.crps(a[0] / a[1], b[0] / b[1])
+  got = np.asarray(out['crps.v'].transpose('lead_time', 'region').values)[lead]
+  ok = np.isfinite(want)
+  err = float(np.max(np.abs(got[ok] / want[ok] - 1.0)))
+  assert list(out['crps.v']['region'].values) == names and err < 1e-6, err
+  del ens, tv
+  return {'workload': f"public benchmark chunk, probabilistic: f32[1 init,{nl} lead,{m} member,{env.nlat},{env.nlon}] "
+                      f"({'init,number,lead' if ifs_layout else 'init,lead,number'} order) vs f32[1,{nl},{env.nlat},{env.nlon}] "
+                      f"{'with a (latitude,longitude) mask coordinate' if with_mask else 'without a mask coordinate'}, CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + mean RMSE, '
+                      f'GridAreaWeighting, {len(REGIONS)} regions x land/sea = {2 * len(REGIONS)} bins, masked=True, {env.layout}',
+          'ms_per_chunk': ms_chunk, 'value': points * len(metrics) / (ms_chunk * 1e-3), 'unit': 'evals/s',
+          'launches_per_chunk': len(log), 'kernels': [e['kind'] for e in log],
+          'ms_per_launch': [round(e['ms'], 4) for e in log], 'roofline': roof,
+          'check': {'crps_global': float(got[0]), 'max_rel_err_vs_oracle_crps_all_bins_one_lead': err}}
+
+
 # ---- configs[3] as BASELINE.json words it: spectra + the full deterministic suite in the same sweep -------------------------
 def configs3_composite(env, nlead, nlev):
   """z f32[1 init, nlead, nlev, lat, lon] p, t + climatology -> RMSE / MSE / MAE / bias / ACC / activity per (lead, level) AND the
@@ -970,6 +1079,9 @@ def main():
       result[name] = leg
     if want('public_chunk'):
       result['public_chunk'] = public_chunk_leg(env)
+    if want('public_chunk_ens'):
+      result['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False)
+      result['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
     if want('spectrum'):
       result['spectrum'] = spectrum_leg(env)
     if want('lat_fastest') and args.layout == 'lon_fastest':
@@ -982,6 +1094,10 @@ def main():
       c1, _ = configs1_leg(env)
       lf['configs1'] = c1
       lf['spectrum'] = spectrum_leg(env)
+      if want('public_chunk_ens'):
+        lf['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False)
+        lf['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
+        lf['public_chunk_ens_ifs_layout'] = public_chunk_ens_leg(env, ifs_layout=True, with_mask=False)
       result['lat_fastest'] = lf
       env.set_layout('lon_fastest')
   if not args.no_config5 and want('config5'):

@@ -338,3 +338,14 @@ def test_values_of_an_uploaded_payload_is_a_read_only_view(backend):
   second = _mse(agg, p, t)
   np.testing.assert_allclose(second.values, _oracle_mse(p, t)[0], rtol=1e-6)
   assert not np.allclose(first.values, second.values)
+
+
+def test_a_statistic_without_an_upload_does_not_freeze_unrelated_objects(backend):
+  """Only an uploaded copy (or a fused group reading the payload) makes `.values` read-only: weight products and tokens
+  cached on coordinate / weight objects do not."""
+  from weatherbenchx_amd import weighting
+  lat = np.linspace(-80, 80, 9)
+  w = weighting.GridAreaWeighting().weights(xr.DataArray(np.zeros((9, 4), np.float32), dims=('latitude', 'longitude'),
+                                                         coords={'latitude': lat, 'longitude': np.arange(4) * 90.0}))
+  w.__dict__['_wbx_token'] = object()  # what the aggregator parks on a weight product
+  assert w.values.flags.writeable

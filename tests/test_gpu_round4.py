@@ -177,3 +177,85 @@ def test_raw_c_abi_call_and_its_error_returns(ctx):
   dplan_s = engine._PlanOnDevice(ctx, plan_s)  # pylint: disable=protected-access
   refused(_raw_call(ctx, plan_s, dplan_s, m, nlat * nlon, bufs['p'], bufs['t'], None, bufs['w'], bits_buf, nA, nBk, nBr, w_flags,
                     nbin, atoms, out), 'skipna')
+
+
+# ---- spectra fused into the deterministic launch: several variables, pass order, prefetch -------------------------
+def _two_variable_case():
+  from weatherbenchx_amd import time_chunks
+  rng = np.random.default_rng(18)
+  nlat, nlon, ninit, nlead, nlev = 19, 1440, 3, 2, 2
+  lat, lon = np.linspace(-81, 81, nlat), np.arange(nlon) * 0.25
+  init_times = np.datetime64('2021-06-01T00', 'ns') + np.arange(ninit) * np.timedelta64(24, 'h')
+  lead_time = (np.arange(nlead) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')
+  level = np.array([500, 850])
+  shape = (ninit, nlead, nlev, nlat, nlon)
+  data = {v: ((rng.normal(size=shape) * (2 + i) + 270 + 10 * i).astype(np.float32), (rng.normal(size=shape) * 2 + 270 + 10 * i).astype(np.float32))
+          for i, v in enumerate(('z', 't'))}
+  calls = []
+
+  def load(inits, leads):
+    calls.append(1)
+    i = [int(np.where(init_times == x)[0][0]) for x in inits]
+    cs = {'init_time': inits, 'lead_time': lead_time, 'level': level, 'latitude': lat, 'longitude': lon}
+    dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+    return ({v: xr.DataArray(data[v][0][i], dims=dims, coords=cs) for v in data}, {v: xr.DataArray(data[v][1][i], dims=dims, coords=cs) for v in data})
+  times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+  return times, load, calls, ninit
+
+
+def _run_passes(order, fuse, monkeypatch, prefetch=0):
+  from weatherbenchx_amd import pipeline, spectra
+  from weatherbenchx_amd.metrics import deterministic
+  times, load, calls, ninit = _two_variable_case()
+  det = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  spec = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalPowerSpectrum('targets')}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  passes = {'det': ('det', load, det, area), 'spec': ('spec', load, spec, zonal)}
+  monkeypatch.setattr(engine, 'FUSE_DET_SPECTRA', fuse)
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 1
+  try:
+    out = pipeline.evaluate_passes(times, [passes[n] for n in order], prefetch=prefetch)
+    kinds = [e['kind'] for e in engine.S1_EVENT_LOG]
+  finally:
+    engine.S1_EVENT_LOG = None
+  return out['det'][None].metric_values(det), out['spec'][None].metric_values(spec), kinds, len(calls), ninit
+
+
+def test_fused_spectra_of_two_variables_do_not_share_a_buffer(ctx, monkeypatch):
+  """Two variables on the 1440-point grid through one loader: every deterministic launch of a chunk runs before the spectra
+  pass reads the first fused spectrum, so each launch needs its own result buffers (round 3 parked a pointer into ONE scratch
+  slot per context: every variable then accumulated the last variable's spectrum)."""
+  d1, s1, k1, _, ninit = _run_passes(('det', 'spec'), True, monkeypatch)
+  d0, s0, k0, _, _ = _run_passes(('det', 'spec'), False, monkeypatch)
+  assert k1.count('det_spectrum') == 2 * ninit and 'spectrum' not in k1
+  assert 'det_spectrum' not in k0 and k0.count('spectrum') == 4 * ninit
+  assert not np.allclose(s0['sp.z'].values, s0['sp.t'].values, rtol=1e-3)  # the variables really differ
+  for k in d0:
+    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in s0:
+    np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
+
+
+def test_spectra_pass_in_front_of_the_deterministic_pass_does_not_fuse(ctx, monkeypatch):
+  """The fused launch only pays when the deterministic pass comes first; the other order runs separate launches, leaves
+  nothing parked on the arrays and gives the same numbers."""
+  d1, s1, k1, _, ninit = _run_passes(('spec', 'det'), True, monkeypatch)
+  d0, s0, _, _, _ = _run_passes(('det', 'spec'), False, monkeypatch)
+  assert 'det_spectrum' not in k1 and k1.count('spectrum') == 4 * ninit
+  assert not engine._fusion_parks and not engine._fusion_requests  # pylint: disable=protected-access
+  for k in d0:
+    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in s0:
+    np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
+
+
+def test_passes_share_one_feeder_per_loader(ctx, monkeypatch):
+  """prefetch > 0: ONE chunk feeder per loader, so the loader runs once per chunk and the passes still fuse."""
+  d1, s1, k1, ncalls, ninit = _run_passes(('det', 'spec'), True, monkeypatch, prefetch=1)
+  d0, s0, _, _, _ = _run_passes(('det', 'spec'), False, monkeypatch)
+  assert ncalls == ninit and k1.count('det_spectrum') == 2 * ninit
+  for k in d0:
+    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in s0:
+    np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)

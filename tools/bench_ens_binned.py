@@ -19,6 +19,7 @@ from wb_regions import REGIONS
 args = sys.argv[1:]
 layout = next((a for a in args if a in ('lon_fastest', 'lat_fastest', 'ifs')), 'lon_fastest')
 with_mask = 'mask' in args
+no_bins = 'nobins' in args  # the un-binned pipelined kernel on the same members, for reference
 nl = int(next((a[3:] for a in args if a.startswith('nl=')), 8))
 m = int(next((a[2:] for a in args if a.startswith('m=')), 51))
 nlat, nlon = 721, 1440
@@ -49,7 +50,7 @@ metrics = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'ssr': probabilist
            'unbiased_mean_rmse': probabilistic.UnbiasedEnsembleMeanRMSE(),
            'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
 agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
-                             bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+                             bin_by=None if no_bins else [binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
 nbytes = nl * nlat * nlon * (m + 1) * 4
 
 
@@ -82,7 +83,7 @@ kinds = sorted({e['kind'] for e in log})
 per_kind = {k: float(np.mean([e['ms'] for e in log if e['kind'] == k])) for k in kinds}
 launches = {k: sum(e['kind'] == k for e in log) / n for k in kinds}
 kernel_ms = sum(per_kind[k] * launches[k] for k in kinds)
-print(json.dumps({'layout': layout, 'mask': with_mask, 'M': m, 'leads': nl, 'GB': round(nbytes / 1e9, 3),
+print(json.dumps({'layout': layout, 'bins': 0 if no_bins else 34, 'lib': os.path.basename(os.environ.get('WBX_LIBRARY_PATH', 'libwbx_hip.so')), 'mask': with_mask, 'M': m, 'leads': nl, 'GB': round(nbytes / 1e9, 3),
                   'ms_per_chunk': round(ms_chunk, 4), 'launches_per_chunk': launches, 'ms_per_launch': {k: round(v, 4) for k, v in per_kind.items()},
                   'kernel_ms_per_chunk': round(kernel_ms, 4),
                   'frac_of_hbm_peak_per_launch': {k: round(nbytes / (v * 1e-3) / 8e12, 4) for k, v in per_kind.items()},

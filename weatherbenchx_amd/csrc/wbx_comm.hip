@@ -36,10 +36,15 @@ struct Rccl {
   char why[256] = {0};
 };
 
-static Rccl* rccl() {
+static Rccl& rccl_state() {
   static Rccl r;
+  return r;
+}
+
+static Rccl* rccl() {
+  Rccl& r = rccl_state();
   static std::once_flag once;
-  std::call_once(once, [] {
+  std::call_once(once, [&r] {
     const char* names[] = {getenv("WBX_RCCL_PATH"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
       if (n == nullptr || *n == 0) continue;
@@ -55,6 +60,7 @@ static Rccl* rccl() {
     r.error_string = reinterpret_cast<fn_error_string>(dlsym(r.handle, "ncclGetErrorString"));
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.error_string) {
       snprintf(r.why, sizeof(r.why), "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+      dlclose(r.handle);
       r.handle = nullptr;
     }
   });
@@ -62,9 +68,11 @@ static Rccl* rccl() {
 }
 
 static const char* rccl_why() {
-  static Rccl* dummy = rccl();
-  (void)dummy;
-  return "librccl.so.1 could not be loaded (set WBX_RCCL_PATH)";
+  (void)rccl();
+  static char msg[384];
+  const char* why = rccl_state().why;
+  snprintf(msg, sizeof(msg), "librccl.so.1 could not be loaded (set WBX_RCCL_PATH)%s%s", *why ? ": " : "", why);
+  return msg;
 }
 
 }  // namespace wbx

@@ -68,6 +68,7 @@ extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
   wbx::spectrum_release(ctx);
   if (ctx->s2_scratch) (void)hipFree(ctx->s2_scratch);
   if (ctx->aidm_scratch) (void)hipFree(ctx->aidm_scratch);
+  if (ctx->patch_counters) (void)hipFree(ctx->patch_counters);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   for (int i = 0; i < ctx->marks_made; ++i) (void)hipEventDestroy(ctx->marks[i]);

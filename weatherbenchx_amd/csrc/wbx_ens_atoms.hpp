@@ -38,6 +38,9 @@ namespace wbx {
 constexpr int ENS_ATOMS_NQ = 5;    // accumulated per atom: skill, spread, variance, squared error of the mean, count
 constexpr int ENS_ATOMS_NOUT = 6;  // written per (patch, bin): the five ensemble lanes + the count lane
 
+#ifndef WBX_EA_KNOCK
+#define WBX_EA_KNOCK 0  // diagnostic builds only (make ab-eak1 / ab-eak2)
+#endif
 #ifndef WBX_ENS_ATOMS_ROWS
 #define WBX_ENS_ATOMS_ROWS 16  // rows (= 64-point tiles) per patch; WBX_ENS_ATOMS_ROWS in the environment overrides
 #endif
@@ -58,13 +61,61 @@ using const_ptr = const __attribute__((address_space(4))) T*;
 static __constant__ int64_t wbx_zero_i64[1] = {0};
 static __constant__ double wbx_one_f64[1] = {1.0};
 
+// The sum over a cell's patches happens INSIDE the kernel, in three levels, each done by whichever wave finishes last:
+//   level 1: the last wave of a group of G1 consecutive patches expands the group's atom tables to bins -> part1[cell][group]
+//   level 2: the last level-1 finisher of G2 consecutive groups adds their records                      -> part2[cell][group2]
+//   level 3: the last level-2 finisher of the cell adds those                                            -> out[cell]
+// ("last" = an atomic counter per set, reset by the wave that sees it full; every sum runs in index order, so the result does
+// not depend on who does it: deterministic, and no atomics on any VALUE).  As separate kernels behind the sweep the same sums
+// cost two launches, two dependency gaps and a 14 MB round trip of per-patch bin tables: 0.48 ms per call around a 0.35 ms kernel.
+constexpr int ENS_ATOMS_G1 = 8;    // patches per level-1 group (their tables fit the idle staging buffer: 8 x 1536 B)
+constexpr int ENS_ATOMS_G2 = 16;   // level-1 records per level-2 group
+
+// What one wave publishes for another (atom tables, flags, records) is written and read with device-scope relaxed atomics:
+// they go to / come from the point where the eight XCDs' L2 caches agree (sc1), so no cache-wide write-back or invalidation is
+// needed to hand data from a wave on one XCD to a wave on another -- __threadfence() in front of every patch's arrival (a
+// release at agent scope writes the XCD's whole L2 back) took the kernel from 0.35 to 0.83 ms.  Order: a wave's stores, then
+// s_waitcnt vmcnt(0) (they are acknowledged), then its arrival (an atomic add); the wave that sees the set complete reads after
+// that.
+template <typename T>
+__device__ __forceinline__ void st_dev(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T ld_dev(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a load that other XCDs' stores are visible to, as a plain (not atomic) instruction: buffer_load ... sc1
+__device__ __forceinline__ double ld_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_offset) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)byte_offset, 0, 1 << 4);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
+
 struct EnsAtomsArgs {
   const double* wx;    // [nBk][nj] or NULL (all ones)
   const double* wrow;  // [nBk][nBr] or NULL (all ones)
-  double* tab;         // [cell][patch][ATOM_MAX][NQ]: the patches' atom tables (written before they are read: no memset)
+  double* tab;         // [cell][patch][ATOM_MAX][NQ]: the patches' atom tables (rows k < nwords cleared by their own wave)
+  double* part1;       // [cell][ng1][NOUT][64]
+  double* part2;       // [cell][ng2][NP]
+  uint32_t* counters;  // [cell][ng1] | [cell][ng2] | [cell], zero before the first launch and after every launch
+  double* out;         // [cell][NOUT][nbin]
+  int32_t ng1, ng2;
   int32_t masked;      // the atom ids are g.aidm (255 = masked out)
   int64_t br_per_split;  // g.rows_per_split / D
+  unsigned long long* prof;  // diagnostic builds (WBX_EA_PROF): eight time stamps per patch, else NULL
 };
+
+#ifndef WBX_EA_PROF
+#define WBX_EA_PROF 0  // make ab-eaprof: phase stamps of every wave, dumped to $WBX_EA_PROF_DUMP after each launch
+#endif
+#if WBX_EA_PROF
+#define WBX_EA_STAMP(slot) \
+  do { if (lane == 0) e.prof[(cell * npatch + patch) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define WBX_EA_STAMP(slot) do {} while (0)
+#endif
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
@@ -74,7 +125,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   constexpr int NQ = ENS_ATOMS_NQ, NOUT = ENS_ATOMS_NOUT;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
   constexpr int NREG = MP - NLDS;                                        // members prefetched into VGPRs
-  constexpr int NST = NLDS < 8 ? 8 : NLDS;                               // (the end of the patch borrows 1.5 KB of it)
+  constexpr int NST = NLDS < 48 ? 48 : NLDS;                             // (the level-1 finisher borrows 12 KB of it)
   constexpr int NONE = 255;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NST * 256];
   float(*stage)[64] = reinterpret_cast<float(*)[64]>(lds_raw);
@@ -88,16 +139,11 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const int64_t patch = (int64_t)rs * g.nxt + xt;
   const int nw = g.nwords[bk * npatch + patch];
-  double* const out = g.tmp + (cell * npatch + patch) * (NOUT * (int64_t)g.nbin);
+  WBX_EA_STAMP(0);
   double* const tab = e.tab + (cell * npatch + patch) * (ATOM_MAX * NQ);
-  if (nw < 0) {
-    // more than ATOM_MAX distinct membership words in one patch (arbitrary user masks): this kernel has no slot fallback.
-    // The host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller that
-    // did not gets NaN in every bin of the cell instead of silently wrong sums.
-    for (int pr = lane; pr < NOUT * g.nbin; pr += 64) out[pr] = __builtin_nan("");
-    if (lane < NOUT) g.tmp_poison[(cell * npatch + patch) * NOUT + lane] = 0.0;
-    return;
-  }
+  // nw < 0: more than ATOM_MAX distinct membership words in one patch (arbitrary user masks).  This kernel has no slot
+  // fallback: the host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller
+  // that did not gets NaN in every bin of the cell instead of silently wrong sums.
   const int64_t R = g.nBr * a.D;
   const int64_t rbeg = (int64_t)rs * g.rows_per_split;
   const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
@@ -117,6 +163,10 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
 #pragma unroll
   for (int l = 0; l < NQ; ++l) acc0[l] = acc1[l] = 0.0;
   uint32_t touched = 0u;  // atoms whose table row has been written (wave-uniform): the first flush of an atom stores
+  // ... and the rows no flush ever writes must read as zeros for the wave that sums the group: lane l < NQ clears its column
+  // (the lane that writes it later: same lane, same address, in order), fire and forget
+  if (lane < NQ)
+    for (int k = 0; k < nw; ++k) st_dev(tab + k * NQ + lane, 0.0);
 
   // Flush BOTH sets of EVERY lane into the patch's table and empty them: lanes grouped by atom id, one DPP wave sum per
   // (group, statistic); lane l < NQ owns column l of the table (the only lane that ever reads or writes it).
@@ -137,7 +187,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
         }
         if (lane < NQ) {
           double* q = tab + gid * NQ + lane;
-          *q = ((touched >> gid) & 1u) ? *q + mine : mine;
+          st_dev(q, ((touched >> gid) & 1u) ? ld_dev(q) + mine : mine);
         }
         touched |= 1u << gid;
         todo &= ~__builtin_amdgcn_ballot_w64(sel);
@@ -152,7 +202,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   // in the plan's tables (scalar loads) right after the loads of row i + 1 have been issued, and arrive while row i is sorted.
   // (A first version resolved 64 rows at a time lane-parallel like det_atoms_kernel: eight vector registers this kernel does
   // not have.)  Row r of the cell = (br, d) = (r / D, r mod D), stepped without a division.
-  const int nrows = (int)(rend - rbeg);  // (the launcher checked that the row counts fit 31 bits)
+  const int nrows = nw < 0 ? 0 : (int)(rend - rbeg);  // (the launcher checked that the row counts fit 31 bits)
   const int nD = (int)a.D;
   int br_a = (int)((int64_t)rs * e.br_per_split);  // (row splits are whole Br rows: rbeg = br_a * D)
   int d_a = 0;
@@ -256,7 +306,12 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
     // no load of the next row is in flight here
     const unsigned long long m_ok = live_mask & __builtin_amdgcn_ballot_w64(id != NONE);
     unsigned long long n0 = __builtin_amdgcn_ballot_w64(id != c0), n1 = __builtin_amdgcn_ballot_w64(id != c1);
-    if (m_ok & n0 & n1) {  // wave-uniform: a lane meets an atom it is not accumulating
+#if WBX_EA_KNOCK >= 1  // timing diagnostic (wrong sums): every point goes to set 0 as atom 0, no hit / miss bookkeeping
+    c0 = 0;
+    n0 = 0ull;
+    n1 = ~0ull;
+#endif
+    if (WBX_EA_KNOCK == 0 && (m_ok & n0 & n1)) {  // wave-uniform: a lane meets an atom it is not accumulating
       const bool ok = __builtin_amdgcn_inverse_ballot_w64(m_ok);
       const bool miss = __builtin_amdgcn_inverse_ballot_w64(m_ok & n0 & n1);
       bool place = miss;
@@ -289,41 +344,134 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
       acc1[4] += w;
     }
   }
+  WBX_EA_STAMP(1);
   flush_all();
+  WBX_EA_STAMP(2);
+#if WBX_EA_KNOCK >= 2  // timing diagnostic: no sums over patches
+  return;
+#endif
 
-  // ---- atoms -> bins.  Lane l < NQ hands its column of the table (its own writes) to the wave through the LDS: the staging
-  // buffer is idle now.  ltab[k][l], l = accumulated statistic; wl[k] = membership word of atom k.
-  double* const ltab = reinterpret_cast<double*>(lds_raw);
-  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lds_raw + ATOM_MAX * NQ * sizeof(double));
-  __syncthreads();
-  if (lane < NQ)
-    for (int k = 0; k < nw; ++k) ltab[k * NQ + lane] = ((touched >> k) & 1u) ? tab[k * NQ + lane] : 0.0;
-  if (lane < ATOM_MAX) wl[lane] = g.words[(bk * npatch + patch) * ATOM_MAX + lane];
-  __syncthreads();
-  const double inv_m = 1.0 / (double)M;
-  // output lane -> accumulated statistics: 0 skill, 1 spread, 2 variance, 3 = (4) - (2) / M, 4 squared error of the mean, 5 count
-  auto term = [&](int k, int l) -> double {
-    const double* row = ltab + k * NQ;
-    if (l < 3) return row[l];
-    if (l == 3) return row[3] - row[2] * inv_m;
-    return row[l - 1];
+  // ---- the patch is done: publish its table, then the sums over patches (see EnsAtomsArgs).  A record is [NOUT][64]: lane =
+  // bin, so every lane of the wave adds the same six statistics and only the membership factor differs.
+  constexpr int NP = NOUT * 64;
+  // -> true for the wave that completes the set (exactly one): everything the others wrote before their arrival is visible to it
+  auto last_of = [&](uint32_t* counter, uint32_t total) -> bool {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's table / record has arrived where every XCD sees it
+    uint32_t seen = 0;
+    if (lane == 0) seen = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+    if (seen != total - 1) return false;
+    if (lane == 0) st_dev(counter, 0u);  // ready for the next launch
+    return true;
   };
-  unsigned long long uni = 0ull;
-  for (int k = 0; k < nw; ++k) uni |= wl[k];
-  // every (statistic, bin) of the patch is written, zeros for the bins outside the union: det_binned_finish sums plain rows
-  for (int pr = lane; pr < NOUT * g.nbin; pr += 64) {
-    const int l = pr / g.nbin, bit = pr - l * g.nbin;
-    double s = 0.0;
-    if ((uni >> bit) & 1ull)
-      for (int k = 0; k < nw; ++k)
-        if ((wl[k] >> bit) & 1ull) s += term(k, l);
-    out[pr] = s;
+  // sum of n consecutive records at src (index order); sc1 BUFFER loads: the compiler keeps a batch of them in flight, where
+  // it waits for every atomic load on its own (16 records = 96 loads one after the other took 18 us of the kernel's tail)
+  auto add_records = [&](const double* src, int n, double (&sum)[NOUT]) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int l = 0; l < NOUT; ++l) sum[l] = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < n; ++q) {
+#pragma unroll
+      for (int l = 0; l < NOUT; ++l) sum[l] += ld_sc1(rs, (uint32_t)((q * NP + l * 64 + lane) * 8));
+    }
+  };
+  auto put_record = [&](double* dst, const double (&sum)[NOUT]) {
+#pragma unroll
+    for (int l = 0; l < NOUT; ++l) st_dev(dst + l * 64 + lane, sum[l]);
+  };
+
+  const int g1 = (int)(patch / ENS_ATOMS_G1);
+  const int k0 = g1 * ENS_ATOMS_G1;
+  const int gn = npatch - k0 < ENS_ATOMS_G1 ? (int)(npatch - k0) : ENS_ATOMS_G1;
+  uint32_t* const cnt1 = e.counters + cell * e.ng1 + g1;
+  const bool last1 = last_of(cnt1, (uint32_t)gn);
+  WBX_EA_STAMP(3);
+  if (!last1) return;
+
+  // ---- level 1: atoms -> bins for the gn patches of the group.  Their tables and membership words go through the idle
+  // staging buffer: ltab[p][k][l], wl[p][k]; every load of the group is asked for before any of them is used.
+  double* const ltab = reinterpret_cast<double*>(lds_raw);
+  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lds_raw + ENS_ATOMS_G1 * ATOM_MAX * NQ * sizeof(double));
+  int nwv[ENS_ATOMS_G1];
+#pragma unroll
+  for (int p = 0; p < ENS_ATOMS_G1; ++p) nwv[p] = p < gn ? ((const_ptr<int32_t>)g.nwords)[bk * npatch + k0 + p] : 0;
+  bool overflowed = false;
+  {
+    constexpr int NJ = (ATOM_MAX * NQ + 63) / 64;
+    double v[ENS_ATOMS_G1][NJ];
+    unsigned long long wv[ENS_ATOMS_G1];
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(e.tab + (cell * npatch + k0) * (ATOM_MAX * NQ), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < ENS_ATOMS_G1; ++p) {
+      overflowed = overflowed || nwv[p] < 0;
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int i = lane + 64 * jj;  // (rows past the patch's atoms -- never cleared -- are not used below)
+        v[p][jj] = ld_sc1(rs, (uint32_t)((p * (ATOM_MAX * NQ) + (i < ATOM_MAX * NQ && p < gn ? i : 0)) * 8));
+      }
+      wv[p] = (p < gn && lane < ATOM_MAX) ? g.words[(bk * npatch + k0 + p) * ATOM_MAX + lane] : 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < ENS_ATOMS_G1; ++p) {
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        if (lane + 64 * jj < ATOM_MAX * NQ) ltab[p * (ATOM_MAX * NQ) + lane + 64 * jj] = v[p][jj];
+      if (lane < ATOM_MAX) wl[p * ATOM_MAX + lane] = wv[p];
+    }
+    __syncthreads();
   }
-  if (lane < NOUT) {
-    double ps = 0.0;
-    for (int k = 0; k < nw; ++k) ps = fma(term(k, lane), 0.0, ps);
-    g.tmp_poison[(cell * npatch + patch) * NOUT + lane] = ps;
+  const double inv_m = 1.0 / (double)M;
+  double sum[NOUT];
+#pragma unroll
+  for (int l = 0; l < NOUT; ++l) sum[l] = 0.0;
+#pragma unroll
+  for (int p = 0; p < ENS_ATOMS_G1; ++p) {
+    for (int k = 0; k < nwv[p]; ++k) {
+      const double* row = ltab + (p * ATOM_MAX + k) * NQ;
+      // membership of the lane's bin as 0.0 / 1.0: NaN * 0 = NaN, so a non-finite sum reaches every bin of its statistic
+      // like in the reference's xr.dot (aggregation.py:272-277)
+      const double f = ((wl[p * ATOM_MAX + k] >> lane) & 1ull) ? 1.0 : 0.0;
+      // output lanes: 0 skill, 1 spread, 2 variance, 3 = (4) - (2) / M, 4 squared error of the mean, 5 count
+      const double t0 = row[0], t1 = row[1], t2 = row[2], t4 = row[3], t5 = row[4];
+      sum[0] = fma(t0, f, sum[0]);
+      sum[1] = fma(t1, f, sum[1]);
+      sum[2] = fma(t2, f, sum[2]);
+      sum[3] = fma(t4 - t2 * inv_m, f, sum[3]);
+      sum[4] = fma(t4, f, sum[4]);
+      sum[5] = fma(t5, f, sum[5]);
+    }
   }
+  if (overflowed) {
+#pragma unroll
+    for (int l = 0; l < NOUT; ++l) sum[l] = __builtin_nan("");
+  }
+  put_record(e.part1 + (cell * e.ng1 + g1) * NP, sum);
+  WBX_EA_STAMP(4);
+
+  // ---- level 2
+  const int g2 = g1 / ENS_ATOMS_G2;
+  const int q0 = g2 * ENS_ATOMS_G2;
+  const int qn = e.ng1 - q0 < ENS_ATOMS_G2 ? e.ng1 - q0 : ENS_ATOMS_G2;
+  uint32_t* const cnt2 = e.counters + (int64_t)g.ncell * e.ng1 + cell * e.ng2 + g2;
+  const bool last2 = last_of(cnt2, (uint32_t)qn);
+  WBX_EA_STAMP(5);
+  if (!last2) return;
+  add_records(e.part1 + (cell * e.ng1 + q0) * NP, qn, sum);
+  put_record(e.part2 + (cell * e.ng2 + g2) * NP, sum);
+  WBX_EA_STAMP(6);
+
+  // ---- level 3: the cell's result
+  uint32_t* const cnt3 = e.counters + (int64_t)g.ncell * (e.ng1 + e.ng2) + cell;
+  if (!last_of(cnt3, (uint32_t)e.ng2)) return;
+  add_records(e.part2 + cell * e.ng2 * NP, e.ng2, sum);
+  if (lane < g.nbin) {
+#pragma unroll
+    for (int l = 0; l < NOUT; ++l) e.out[(cell * NOUT + l) * g.nbin + lane] = sum[l];
+  }
+  WBX_EA_STAMP(7);
 }
 #pragma clang diagnostic pop
 
@@ -342,23 +490,50 @@ inline int64_t ens_atoms_rows() {
   return rows;
 }
 
+// Counters of the in-kernel sums (EnsAtomsArgs): zero when allocated, and every launch leaves them zero.
+inline int ens_atoms_counters(wbx_ctx* ctx, size_t n, uint32_t** out) {
+  if (ctx->patch_counters_size < n) {
+    if (ctx->patch_counters) {
+      WBX_HIP(hipStreamSynchronize(ctx->stream));
+      WBX_HIP(hipFree(ctx->patch_counters));
+      ctx->patch_counters = nullptr;
+      ctx->patch_counters_size = 0;
+    }
+    const size_t cap = n < 4096 ? 4096 : n * 2;
+    WBX_HIP(hipMalloc(&ctx->patch_counters, cap * sizeof(uint32_t)));
+    WBX_HIP(hipMemsetAsync(ctx->patch_counters, 0, cap * sizeof(uint32_t), ctx->stream));
+    ctx->patch_counters_size = cap;
+  }
+  *out = reinterpret_cast<uint32_t*>(ctx->patch_counters);
+  return 0;
+}
+
 template <int MP, bool EXACT>
 int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const EnsBinnedCall& c) {
   BinnedArgs g;
-  double* tab = nullptr;
+  double* extra = nullptr;
   const int64_t cells = c.nA * c.nBk;
-  // (the table scratch is sized for the geometry patch_setup is about to choose: same call as inside it)
+  // (the scratch is sized for the geometry patch_setup is about to choose: same call as inside it)
   BinnedArgs probe;
   patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows());
-  probe.nbin = c.nbin;
-  const size_t n_tab = (size_t)probe.nblocks * ATOM_MAX * ENS_ATOMS_NQ, n_part = patch_finish2_scratch(probe, ENS_ATOMS_NOUT);
-  if (int rc = patch_setup(ctx, g, nullptr, c.bits, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ENS_ATOMS_NOUT, c.nbin, true,
-                           c.prepared, true, ens_atoms_rows(), n_tab + n_part, &tab))
+  const int64_t npatch = (int64_t)probe.nrs * probe.nxt;
+  const int ng1 = (int)((npatch + ENS_ATOMS_G1 - 1) / ENS_ATOMS_G1), ng2 = (ng1 + ENS_ATOMS_G2 - 1) / ENS_ATOMS_G2;
+  const size_t NP = (size_t)ENS_ATOMS_NOUT * 64;
+  const size_t n_tab = (size_t)probe.nblocks * ATOM_MAX * ENS_ATOMS_NQ, n_p1 = (size_t)cells * ng1 * NP, n_p2 = (size_t)cells * ng2 * NP;
+  // (nacc = 0: no per-patch bin tables -- the sums over patches happen inside the kernel)
+  if (int rc = patch_setup(ctx, g, nullptr, c.bits, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, 0, c.nbin, true, c.prepared,
+                           true, ens_atoms_rows(), n_tab + n_p1 + n_p2, &extra))
     return rc;
   EnsAtomsArgs e;
   e.wx = (c.w_on_x & WBX_BINNED_WT_X_ONLY) ? c.wt : nullptr;
   e.wrow = (c.w_on_x & WBX_BINNED_WT_ROW_ONLY) ? c.wt : nullptr;
-  e.tab = tab;
+  e.tab = extra;
+  e.part1 = extra + n_tab;
+  e.part2 = e.part1 + n_p1;
+  e.out = c.out;
+  e.ng1 = ng1;
+  e.ng2 = ng2;
+  if (int rc = ens_atoms_counters(ctx, (size_t)cells * (ng1 + ng2 + 1), &e.counters)) return rc;
   e.masked = 0;
   e.br_per_split = g.rows_per_split / plan->ndepth;
   if (plan->flags & WBX_FLAG_MASKED) {
@@ -373,12 +548,35 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const bool nt = nt_env >= 0 ? nt_env != 0 : !ragged_lines;
   g.order = order_env >= 0 ? order_env : (ragged_lines ? 1 : 0);
   const int64_t grid = patch_grid<1>(g);
+  e.prof = nullptr;
+#if WBX_EA_PROF
+  const size_t prof_bytes = (size_t)g.nblocks * 8 * sizeof(unsigned long long);
+  WBX_HIP(hipMalloc(reinterpret_cast<void**>(&e.prof), prof_bytes));
+  WBX_HIP(hipMemsetAsync(e.prof, 0, prof_bytes, ctx->stream));
+#endif
   if (nt)
     hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
   else
     hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
   WBX_HIP(hipGetLastError());
-  return patch_finish2(ctx, g, ENS_ATOMS_NOUT, tab + n_tab, c.out);
+#if WBX_EA_PROF
+  {
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long* host = (unsigned long long*)malloc(prof_bytes);
+    WBX_HIP(hipMemcpy(host, e.prof, prof_bytes, hipMemcpyDeviceToHost));
+    if (const char* path = getenv("WBX_EA_PROF_DUMP")) {
+      if (FILE* f = fopen(path, "wb")) {
+        const long long hdr[4] = {(long long)g.ncell, (long long)g.nrs, (long long)g.nxt, 8};
+        fwrite(hdr, sizeof(hdr), 1, f);
+        fwrite(host, 1, prof_bytes, f);
+        fclose(f);
+      }
+    }
+    free(host);
+    WBX_HIP(hipFree(e.prof));
+  }
+#endif
+  return 0;
 }
 
 // one translation unit per bucket (parallel build)

@@ -281,52 +281,6 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   return atoms_launch(ctx, g, bits, D, nx, atoms);
 }
 
-// The same sum in two levels, for launches with many short patches (the ensemble atom kernel: ~1000 patches per cell, where
-// one block per (cell, lane) walked 1.6 KB strides for 46 us behind a 0.32 ms kernel): level 1, one block per (cell, group of
-// G consecutive patches), thread = element e of the patch's [nacc][nbin] result -- every read is a contiguous row --; level 2,
-// one block per cell adds the groups.  Fixed order, no atomics.
-static __global__ void __launch_bounds__(256) patch_finish_groups(int64_t npatch, int nacc, int nbin, int G, int ngroup,
-                                                                  const double* __restrict__ tmp, const double* __restrict__ poison,
-                                                                  double* __restrict__ part) {
-  const int64_t cell = blockIdx.x / ngroup;
-  const int grp = (int)(blockIdx.x % ngroup);
-  const int ne = nacc * nbin;
-  const int64_t k0 = (int64_t)grp * G, k1 = k0 + G < npatch ? k0 + G : npatch;
-  for (int e = threadIdx.x; e < ne; e += blockDim.x) {
-    const int l = e / nbin;
-    double s = 0.0;
-    for (int64_t k = k0; k < k1; ++k) s += tmp[(cell * npatch + k) * ne + e] + poison[(cell * npatch + k) * nacc + l];
-    part[(cell * ngroup + grp) * ne + e] = s;
-  }
-}
-
-static __global__ void __launch_bounds__(256) patch_finish_cells(int ne, int ngroup, const double* __restrict__ part,
-                                                                 double* __restrict__ out) {
-  const int64_t cell = blockIdx.x;
-  for (int e = threadIdx.x; e < ne; e += blockDim.x) {
-    double s = 0.0;
-    for (int q = 0; q < ngroup; ++q) s += part[(cell * ngroup + q) * ne + e];
-    out[cell * ne + e] = s;  // out[cell][lane][bin]
-  }
-}
-
-constexpr int PATCH_FINISH_GROUP = 16;  // patches per level-1 block
-inline size_t patch_finish2_scratch(const BinnedArgs& g, int nacc) {  // doubles
-  const int64_t npatch = (int64_t)g.nrs * g.nxt;
-  return (size_t)(g.ncell * ((npatch + PATCH_FINISH_GROUP - 1) / PATCH_FINISH_GROUP) * nacc * g.nbin);
-}
-
-inline int patch_finish2(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* part, double* out) {
-  const int64_t npatch = (int64_t)g.nrs * g.nxt;
-  const int ngroup = (int)((npatch + PATCH_FINISH_GROUP - 1) / PATCH_FINISH_GROUP);
-  hipLaunchKernelGGL(patch_finish_groups, dim3((unsigned)(g.ncell * ngroup)), dim3(256), 0, ctx->stream, npatch, nacc, (int)g.nbin,
-                     PATCH_FINISH_GROUP, ngroup, g.tmp, g.tmp_poison, part);
-  WBX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(patch_finish_cells, dim3((unsigned)g.ncell), dim3(256), 0, ctx->stream, nacc * (int)g.nbin, ngroup, part, out);
-  WBX_HIP(hipGetLastError());
-  return 0;
-}
-
 inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out) {
   hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)(g.ncell * nacc)), dim3(256), 0, ctx->stream,
                      (int64_t)g.nrs * g.nxt, nacc, (int)g.nbin, g.tmp, g.tmp_poison, out);

@@ -29,6 +29,27 @@ class _Dev:
   def __init__(self, ptr, layout, dtype_code, keep, nbytes, fence=None):
     self.ptr, self.layout, self.dtype_code, self.keep, self.nbytes = ptr, layout, dtype_code, keep, nbytes
     self.fence = fence  # an asynchronous upload in flight: consumers make their stream wait on it (no host block)
+    self.frozen = []    # host arrays made read-only while the DMA reads them (thaw() gives them back)
+
+  def thaw(self):
+    """The upload has been waited for and the device copy is being dropped: the loader may write its arrays again."""
+    if self.frozen:
+      if self.fence is not None:
+        self.fence.wait()
+      for arr in self.frozen:
+        try:
+          arr.flags.writeable = True
+        except ValueError:
+          pass
+      self.frozen = []
+
+  def __del__(self):
+    # the DataArray that carried this copy is gone (a chunk that has been aggregated): its page-locked source is the
+    # loader's to refill -- the DMA that read it is waited for first
+    try:
+      self.thaw()
+    except Exception:  # pylint: disable=broad-except
+      pass
 
 
 def _order_uploads(ctx, devs):
@@ -85,18 +106,22 @@ def _to_device(ctx: _hip.Context, da: xr.DataArray, dtype_code: int) -> _Dev:
       buf = ctx.upload_async(host)
       fence = ctx.fence()
       keep = (buf, host)
-      try:
-        host.flags.writeable = False
-        if isinstance(data, np.ndarray):
-          data.flags.writeable = False
-      except ValueError:
-        pass
+      froze = []
+      for arr in (host, data):
+        if isinstance(arr, np.ndarray) and arr.flags.writeable:
+          try:
+            arr.flags.writeable = False
+            froze.append(arr)
+          except ValueError:
+            pass
     else:
       host = np.ascontiguousarray(host, dtype=want)
       buf = keep = ctx.upload(host)
     st = [int(s // host.itemsize) for s in host.strides] if host.ndim else []
     lay = planner.InputLayout(strides=dict(zip(da.dims, st)), itemsize=host.itemsize, base_alignment=256)
     dev = _Dev(buf.ptr, lay, dtype_code, keep, host.nbytes, fence)
+    if fence is not None:
+      dev.frozen = froze
   cache[dtype_code] = dev
   return dev
 
@@ -435,6 +460,7 @@ def clear_caches():
 # the stage-1 launch of that pair then computes both spectra alongside its own lanes and leaves them with the source arrays,
 # where spectra._run_spectrum finds them instead of launching.  Nothing is registered -> nothing changes.
 _fusion_requests: dict = {}   # id(predictions DataArray) -> {'p', 't', 'entry', 'ngroup'}
+_fusion_parks: list = []      # arrays that carry a fused spectrum nobody has asked for yet
 FUSE_DET_SPECTRA = os.environ.get('WBX_FUSE_DET_SPECTRA', '1') != '0'
 
 
@@ -445,7 +471,12 @@ def request_det_spectra(p_da, t_da, entry, ngroup: int):
 
 
 def clear_det_spectra_requests():
+  """End of a chunk: requests that no deterministic launch picked up, and spectra that were computed but never asked for
+  (their buffers go back to the pool; a later, unrelated aggregation of the same array must not find them)."""
   _fusion_requests.clear()
+  for da in _fusion_parks:
+    da.__dict__.pop('_wbx_fused_spectrum', None)
+  _fusion_parks.clear()
 
 
 def _fused_rows(plan: planner.S1Plan, entry):
@@ -494,8 +525,10 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
     return False
   del _fusion_requests[id(inputs[0])]
   nk = 721
-  pw_p = _scratch(ctx, 'fused_spectrum_p', max(ngroup * nk, 1) * 8)
-  pw_t = _scratch(ctx, 'fused_spectrum_t', max(ngroup * nk, 1) * 8)
+  # this launch's OWN result buffers (pooled device blocks): several variables of a chunk are launched before the spectra
+  # pass reads the first of them, so one scratch slot per context would hand every variable the last variable's spectra
+  pw_p = ctx.alloc(max(ngroup * nk, 1) * 8)
+  pw_t = ctx.alloc(max(ngroup * nk, 1) * 8)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
 
   def call():
@@ -505,7 +538,9 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
                'wbx_det_spectrum')
   timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func))
   for da, buf in ((req['p'], pw_p), (req['t'], pw_t)):
-    da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'ngroup': ngroup, 'cache': entry['dev']}
+    # (the buffer object rides along: it is released -- stream ordered behind its consumer -- when the entry is dropped)
+    da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'buf': buf, 'ngroup': ngroup, 'cache': entry['dev']}
+    _fusion_parks.append(da)
   return True
 
 

@@ -132,6 +132,23 @@ class _SharedLoads:
         hit = self._last[id(load_chunk)] = (k, load_chunk, load_chunk(init_chunk, lead_chunk))
       yield (offsets, *hit[2])
 
+  def tee(self, load_chunk, source):
+    """The same for a chunk FEEDER: `source` (one iterator per loader, handed to every pass of that loader) is advanced by
+    whichever pass asks for chunk k first; the others get that very item."""
+    key = ('feeder', id(load_chunk))
+    self._last.setdefault(key, [-1, None, source])
+    k = 0
+    while True:
+      state = self._last[key]
+      if state[0] < k:
+        try:
+          state[1] = next(state[2])
+        except StopIteration:
+          return
+        state[0] = k
+      yield state[1]
+      k += 1
+
 
 def _plan_fusion(group_stats):
   """Look ahead over ALL statistics of a chunk (every pass): a deterministic (p, t[, climatology]) group whose two fields also
@@ -143,20 +160,25 @@ def _plan_fusion(group_stats):
   from weatherbenchx_amd import lazy  # pylint: disable=g-import-not-at-top
   from weatherbenchx_amd import spectra  # pylint: disable=g-import-not-at-top
   engine.clear_det_spectra_requests()
-  by_source, groups = {}, {}
-  for unique, aggregators in group_stats:
+  by_source, groups, first_pass = {}, {}, {}
+  for ipass, (unique, aggregators) in enumerate(group_stats):
     for _, stats in unique:
       for stat in stats.values():
         if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy:
-          by_source.setdefault(id(stat._source), []).append((stat, aggregators))  # pylint: disable=protected-access
+          by_source.setdefault(id(stat._source), []).append((stat, aggregators, ipass))  # pylint: disable=protected-access
         elif isinstance(stat, lazy.LazyStatistic) and stat.is_lazy and stat._group.kind == 'det':  # pylint: disable=protected-access
           groups[id(stat._group)] = stat._group  # pylint: disable=protected-access
+          first_pass.setdefault(id(stat._group), ipass)  # pylint: disable=protected-access
   for grp in groups.values():
     sp, st = by_source.get(id(grp.p)), by_source.get(id(grp.t))
     if not sp or not st or len(sp) != 1 or len(st) != 1:
       continue
-    (spec_p, aggs_p), (spec_t, aggs_t) = sp[0], st[0]
+    (spec_p, aggs_p, pass_p), (spec_t, aggs_t, pass_t) = sp[0], st[0]
     if aggs_p is not aggs_t or len(aggs_p) != 1:
+      continue
+    # the deterministic launch has to come FIRST: a spectra pass in front of it launches its own transforms, and the fused
+    # launch afterwards would be the slower kernel for nothing (and leave two spectra nobody asks for)
+    if not first_pass[id(grp)] < min(pass_p, pass_t):
       continue
     agg = next(iter(aggs_p.values()))
     entries = []
@@ -238,21 +260,23 @@ def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: 
   acc = engine.Accumulation()
   # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
   # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
-  feeders = []
+  feeders = {}
   shared = _SharedLoads()
   with engine.accumulate_results(acc):
     streams = []
     for _, load_chunk, _, _ in norm:
       if prefetch:
-        feeder = ChunkFeeder(work, load_chunk, depth=prefetch)
-        feeders.append(feeder)
-        streams.append(iter(feeder))
+        # ONE feeder per loader: passes that share a loader share its chunks (and can fuse), exactly as without prefetch
+        if id(load_chunk) not in feeders:
+          feeders[id(load_chunk)] = ChunkFeeder(work, load_chunk, depth=prefetch)
+          feeders[id(load_chunk)].source = iter(feeders[id(load_chunk)])
+        streams.append(shared.tee(load_chunk, feeders[id(load_chunk)].source))
       else:
         streams.append(shared.stream(work, load_chunk))
     try:
       _consume(streams, [(n, m, a) for n, _, m, a in norm], acc)
     finally:
-      for feeder in feeders:
+      for feeder in feeders.values():
         feeder.close()
   leaves, plan = distributed.reduce_accumulation(acc, group, all_reduce=all_reduce and (world_size > 1 or force_collective),
                                                  force=force_collective, comm=comm)

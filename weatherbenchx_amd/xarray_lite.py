@@ -297,8 +297,9 @@ class DataArray:
   @property
   def values(self) -> np.ndarray:
     out = _to_numpy(self.data)
-    if isinstance(out, np.ndarray) and out.flags.writeable and any(k.startswith('_wbx_') for k in self.__dict__):
-      # an uploaded copy of this payload (or a result computed from it) is cached on the object: a write through
+    if isinstance(out, np.ndarray) and out.flags.writeable and (self.__dict__.get('_wbx_dev') or self.__dict__.get('_wbx_groups')):
+      # an uploaded copy of this payload, or a fused group whose (lazy or finished) statistics read it, is cached on the
+      # object -- other engine caches (weight products, tokens) do not depend on the payload --: a write through
       # `.values[...] = x` would leave it stale without anybody noticing, so the array is handed out as a read-only VIEW
       # (the caller's own array is not frozen) and the write fails loudly; `da[...] = x` is the mutation that drops the caches
       out = out.view()
@@ -354,6 +355,10 @@ class DataArray:
     payloads are uploaded once per object: while an uploaded copy exists `.values` is a read-only view, so
     `.values[...] = x` raises instead of leaving the copy stale -- use `da[...] = x` (an alias of the payload taken BEFORE the
     upload can still be written behind the object's back)."""
+    for dev in (self.__dict__.get('_wbx_dev') or {}).values():
+      thaw = getattr(dev, 'thaw', None)  # a loader's page-locked array frozen for the duration of its asynchronous upload
+      if thaw is not None:
+        thaw()
     for k in [k for k in self.__dict__ if k.startswith('_wbx_')]:
       del self.__dict__[k]
     # caches that live on OTHER objects (the fused group of (predictions, targets) sits on the predictions) key on this
