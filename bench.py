@@ -682,7 +682,7 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   del ens, tv
   return {'workload': f"public benchmark chunk, probabilistic: f32[1 init,{nl} lead,{m} member,{env.nlat},{env.nlon}] "
                       f"({'init,number,lead' if ifs_layout else 'init,lead,number'} order) vs f32[1,{nl},{env.nlat},{env.nlon}] "
-                      f"{'with a (latitude,longitude) mask coordinate' if with_mask else 'without a mask coordinate'}, CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + mean RMSE, '
+                      f"{'with a (latitude,longitude) mask coordinate' if with_mask else 'without a mask coordinate'}, CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + mean RMSE, "
                       f'GridAreaWeighting, {len(REGIONS)} regions x land/sea = {2 * len(REGIONS)} bins, masked=True, {env.layout}',
           'ms_per_chunk': ms_chunk, 'value': points * len(metrics) / (ms_chunk * 1e-3), 'unit': 'evals/s',
           'launches_per_chunk': len(log), 'kernels': [e['kind'] for e in log],
