@@ -209,6 +209,24 @@ def ens_kernel_name(e, m=51):
   return f"s1_{'xk' if e.get('x_kept') else 'xr'}_kernel<EnsOpF32<{m},true,SORT>,1>"
 
 
+def oracle_level_check(env, ens_level, t_level, got):
+  """One [51, spatial] level of the timed field on the host through the oracle (float64, reference structure): the four
+  metrics of the suite with GridAreaWeighting over (latitude, longitude) -> max relative error of `got` (asserted < 1e-6)."""
+  from oracle import wbx_oracle as O
+  pv, tvh = ens_level.cpu().numpy(), t_level.cpu().numpy()
+  pd, td = ('number',) + env.sp, env.sp
+  w = [(O.grid_area_weights(env.lat), ('latitude',))]
+  mean = lambda lane: (lambda a: float(a[0] / a[1]))(O.aggregate(lane[0], lane[1], ['latitude', 'longitude'], weights=w))
+  skill, spread = mean(O.crps_skill(pv, pd, tvh, td, 'number')), mean(O.crps_spread(pv, pd, 'number', fair=True, use_sort=True))
+  var, uemse = mean(O.ensemble_variance(pv, pd, 'number')), mean(O.unbiased_ensemble_mean_squared_error(pv, pd, tvh, td, 'number'))
+  emse = mean(O.ensemble_mean_squared_error(pv, pd, tvh, td, 'number'))
+  want = {'crps': O.crps(skill, spread), 'unbiased_spread_skill': float(np.sqrt(var / uemse)), 'unbiased_mean_rmse': float(np.sqrt(uemse)),
+          'mean_rmse': float(np.sqrt(emse))}
+  err = {k: abs(float(got[k]) / want[k] - 1.0) for k in want}
+  assert max(err.values()) < 1e-6, (err, got, want)
+  return {'oracle_max_rel_err': max(err.values()), 'oracle_rel_err': err}
+
+
 def main_leg(env):
   """ONE f32[1 init, 37 level, 51 member, lat, lon] forecast per rank against f32[1, 37, lat, lon] targets.
 
@@ -334,12 +352,16 @@ def _main_leg(env):
                  'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
       'roofline': roofline,
   }
-  # sanity: an exchangeable ensemble of N(0,1) draws: CRPS = 2/sqrt(pi) * (1 - ... ) ~ 0.5642 x sigma_eff, spread/skill ~ 1
+  # outside the timed region: one sampled level of the timed field against the float64 oracle, every metric of the suite
+  # (the kernel's per-level sums are independent: a level checks the kernel, the planes' addressing and the weights)
   crps = float(np.asarray(out['crps.t'].values).mean())
   ssr = float(np.asarray(out['unbiased_spread_skill.t'].values).mean())
-  assert np.isfinite(crps) and abs(crps - 0.5642) < 0.01 and abs(ssr - 1.0) < 0.01, (crps, ssr)
-  result['check'] = {'crps_mean': crps, 'unbiased_spread_skill_mean': ssr,
-                     'mean_rmse': float(np.asarray(out['mean_rmse.t'].values).mean())}
+  result['check'] = {'crps_mean': crps, 'unbiased_spread_skill_mean': ssr, 'mean_rmse': float(np.asarray(out['mean_rmse.t'].values).mean())}
+  if env.world == 1:
+    result['check'].update(oracle_level_check(env, ens[0, nlev // 2], tv[0, nlev // 2],
+                                              {k: np.asarray(out[f'{k}.t'].values).reshape(-1)[nlev // 2] for k in metrics}), level=nlev // 2)
+  else:  # (N > 1: the sums combine every rank's field; an exchangeable N(0, 1) ensemble has CRPS ~ 0.5642, spread/skill ~ 1)
+    assert np.isfinite(crps) and abs(crps - 0.5642) < 0.01 and abs(ssr - 1.0) < 0.01, (crps, ssr)
   del pe, te, ens, tv
   return result
 

@@ -71,7 +71,16 @@ typedef enum wbx_det_func { WBX_DET3 = 0, WBX_DET6 = 1, WBX_PASS1 = 2 } wbx_det_
  *  2 EnsembleVariance     var_m(p, ddof=1)
  *  3 UnbiasedEnsembleMeanSquaredError  (mean_m p - t)^2 - var/M
  *  4 SquaredError of the ensemble mean (mean_m p - t)^2   (EnsembleMean + SquaredError)
- */
+ * Accuracy per point against the float64 restatement of the float32 members (tests/test_gpu_round4.py holds these on outputs
+ * of 64 points -- one tile -- and on whole fields; geopotential-like 5.5e4 +- 30, spread = 0.05 x error, a target at the
+ * ensemble mean): the rank-form fp32 kernels for M = 50 / 51 (ens_pipe_kernel, ens_atoms_kernel) sum e = x - median in fp32
+ * chains of <= 8 terms, every chain of non-negative terms:
+ *   lanes 0, 1, 4   relative: <= 9 x 2^-24 = 5.4e-7 worst case, ~1e-7 typical
+ *   lane 2          relative to S = sum e^2 / (M - 1) <= 3 var: |d var| <= 5.4e-7 S (the subtraction (sum e)^2 / M is fp64)
+ *   lane 3          a DIFFERENCE, so its bound is absolute, in units of the two terms it is the difference of:
+ *                   |d lane3| <= 1e-6 (lane 4 + lane 2 / M); relative 1e-6 wherever lane 3 is not itself a cancellation
+ * Every other ensemble kernel (padded buckets, masked / skipna wrappers, pair form, generic) sums in fp64 on the widened
+ * members: ~1e-15 (pair form: ~1e-7, its |x_i - x_j| row sums are fp32). */
 #define WBX_ENS_LANES 5
 typedef enum wbx_ens_algo {
   WBX_ENS_SORT = 0,     /* rank / sorting-network form, probabilistic.py:214-240 (use_sort=True)  */
