@@ -151,6 +151,8 @@ def _cat_lanes(plan, devs, cat):
 
 
 def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None, inputs=None):  # pylint: disable=unused-argument
+  if engine.S1_EVENT_LOG is not None:
+    engine.S1_EVENT_LOG.append({'kind': kind, 'flags': int(plan.flags), 'ms': 0.0, 'x_kept': plan.x_kept, 'block': plan.block_threads})
   with np.errstate(all='ignore'):
     if kind == 'det':
       nin = {_hip.DET3: 2, _hip.DET6: 3, _hip.PASS1: 1}[func]

@@ -1,0 +1,130 @@
+"""Foreign labeled arrays -- a real xr.DataArray, or anything exposing .dims / .coords / .values / .name / .attrs -- through the
+plugin API (metrics/base.py:184-197, aggregation.py:411-435): accepted, and FUSED like native arrays: every statistic of a
+(predictions, targets) pair shares one conversion, so RMSE + MSE + MAE + bias + ACC are one stage-1 launch and three uploads,
+the CRPS suite one launch."""
+import numpy as np
+import pytest
+
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import probabilistic
+
+
+class _Coord:
+  def __init__(self, dims, values):
+    self.dims, self.values = dims, values
+
+
+class Foreign:
+  """The smallest thing that quacks like an xr.DataArray: no arithmetic, no .data, no methods."""
+
+  def __init__(self, values, dims, coords, name=None):
+    self._values = values
+    self.dims = tuple(dims)
+    self.coords = {k: _Coord((k,), np.asarray(v)) for k, v in coords.items()}
+    self.name = name
+    self.attrs = {}
+
+  @property
+  def values(self):
+    return self._values
+
+
+def _case(seed=0):
+  rng = np.random.default_rng(seed)
+  nlat, nlon = 19, 36
+  lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  init = np.datetime64('2020-01-01T00', 'ns') + np.arange(2) * np.timedelta64(1, 'D')
+  lead = (np.arange(3) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  dims = ('init_time', 'lead_time', 'latitude', 'longitude')
+  coords = {'init_time': init, 'lead_time': lead, 'latitude': lat, 'longitude': lon}
+  pv = (rng.normal(size=(2, 3, nlat, nlon)) + 280).astype(np.float32)
+  tv = (rng.normal(size=(2, 3, nlat, nlon)) + 280).astype(np.float32)
+  cv = (rng.normal(size=(366, 4, nlat, nlon)) * 5 + 280).astype(np.float32)
+  clim = xr.Dataset({'z': xr.DataArray(cv, dims=('dayofyear', 'hour', 'latitude', 'longitude'), coords={
+      'dayofyear': np.arange(1, 367), 'hour': np.array([0, 6, 12, 18]), 'latitude': lat, 'longitude': lon})})
+  ev = (tv[:, :, None] + rng.normal(size=(2, 3, 7, nlat, nlon))).astype(np.float32)
+  edims = ('init_time', 'lead_time', 'number', 'latitude', 'longitude')
+  return dims, coords, pv, tv, clim, ev, edims
+
+
+def _count_uploads(monkeypatch):
+  made = []
+  real = engine._to_device  # pylint: disable=protected-access
+
+  def spy(ctx, da, dtype_code):
+    before = set(da.__dict__.get('_wbx_dev', {})) | set(da.__dict__.get('_wbx_dev_fake', {}))
+    dev = real(ctx, da, dtype_code)
+    after = set(da.__dict__.get('_wbx_dev', {})) | set(da.__dict__.get('_wbx_dev_fake', {}))
+    if after - before:
+      made.append(da)
+    return dev
+  monkeypatch.setattr(engine, '_to_device', spy)
+  return made
+
+
+def _run(metrics, agg, p, t):
+  engine.S1_EVENT_LOG = []
+  try:
+    out = aggregation.compute_metric_values_for_single_chunk(metrics, agg, p, t)
+    log = [e for e in engine.S1_EVENT_LOG if e['kind'] in ('det', 'ens', 'det_binned', 'ens_binned')]
+  finally:
+    engine.S1_EVENT_LOG = None
+  return out, log
+
+
+def test_deterministic_suite_of_a_foreign_pair_is_one_launch_three_uploads(backend, monkeypatch):
+  dims, coords, pv, tv, clim, _, _ = _case()
+  metrics = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias(),
+             'acc': deterministic.ACC(clim)}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  uploads = _count_uploads(monkeypatch)
+  got, log = _run(metrics, agg, {'z': Foreign(pv, dims, coords)}, {'z': Foreign(tv, dims, coords)})
+  assert len(log) == 1 and log[0]['kind'] == 'det', log
+  assert len(uploads) == 3, len(uploads)  # predictions, targets, climatology: once each
+  want, _ = _run(metrics, agg, {'z': xr.DataArray(pv, dims=dims, coords=coords)}, {'z': xr.DataArray(tv, dims=dims, coords=coords)})
+  for k in metrics:
+    np.testing.assert_array_equal(np.asarray(got[f'{k}.z'].values), np.asarray(want[f'{k}.z'].values), err_msg=k)
+
+
+def test_crps_suite_of_a_foreign_pair_is_one_launch(backend, monkeypatch):
+  dims, coords, _, tv, _, ev, edims = _case(1)
+  metrics = {'crps': probabilistic.CRPSEnsemble(), 'ssr': probabilistic.UnbiasedSpreadSkillRatio(),
+             'uemrmse': probabilistic.UnbiasedEnsembleMeanRMSE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  uploads = _count_uploads(monkeypatch)
+  got, log = _run(metrics, agg, {'v': Foreign(ev, edims, coords)}, {'v': Foreign(tv, dims, coords)})
+  assert len(log) == 1 and log[0]['kind'] == 'ens', log
+  assert len(uploads) == 2, len(uploads)
+  want, _ = _run(metrics, agg, {'v': xr.DataArray(ev, dims=edims, coords=coords)}, {'v': xr.DataArray(tv, dims=dims, coords=coords)})
+  for k in metrics:
+    np.testing.assert_array_equal(np.asarray(got[f'{k}.v'].values), np.asarray(want[f'{k}.v'].values), err_msg=k)
+
+
+def test_statistics_computed_one_call_at_a_time_still_share_the_conversion(backend, monkeypatch):
+  """`stat.compute(p, t)` called per statistic (the reference's own loop, metrics/base.py:252-269): while the first statistic
+  is alive the second finds the same conversion of the same foreign objects; a NEW foreign object over other values is never
+  served the old one."""
+  dims, coords, pv, tv, _, _, _ = _case(2)
+  p, t = {'z': Foreign(pv, dims, coords)}, {'z': Foreign(tv, dims, coords)}
+  se = deterministic.SquaredError().compute(p, t)
+  ae = deterministic.AbsoluteError().compute(p, t)
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'])
+  uploads = _count_uploads(monkeypatch)
+  engine.S1_EVENT_LOG = []
+  try:
+    state = agg.aggregate_statistics({'se': se, 'ae': ae})
+    log = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'det']
+  finally:
+    engine.S1_EVENT_LOG = None
+  assert len(log) == 1 and len(uploads) == 2, (log, len(uploads))
+  np.testing.assert_allclose(np.asarray(state.mean_statistics()['ae']['z'].values), np.abs(pv.astype(np.float64) - tv).mean(axis=(0, 2, 3)), rtol=1e-12)
+  del se, ae, state
+  p2 = {'z': Foreign(pv + 1, dims, coords)}
+  se2 = deterministic.SquaredError().compute(p2, t)
+  got = agg.aggregate_statistics({'se': se2}).mean_statistics()['se']['z'].values
+  np.testing.assert_allclose(np.asarray(got), ((pv.astype(np.float64) + 1 - tv) ** 2).mean(axis=(0, 2, 3)), rtol=1e-6)

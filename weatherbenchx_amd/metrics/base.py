@@ -77,6 +77,15 @@ class PerVariableStatistic(Statistic):
     ...
 
 
+def _converted(mapping):
+  """{name: DataArray} with foreign labeled arrays converted (kept by the caller for the duration of its loop); anything that is
+  not a plain mapping of arrays (a Dataset, a user object) is passed through untouched."""
+  if isinstance(mapping, dict) and not all(isinstance(v, xr.DataArray) for v in mapping.values()):
+    return {k: (xr.as_dataarray(v) if (hasattr(v, 'dims') and hasattr(v, 'coords') and hasattr(v, 'values')) else v)
+            for k, v in mapping.items()}
+  return mapping
+
+
 def _named(da, name):
   da = xr.as_dataarray(da)
   if da.name is None:
@@ -107,6 +116,9 @@ NoOpMetric = lambda statistic: statistic  # pylint: disable=invalid-name
 
 def generate_unique_statistics_for_all_metrics(metrics, predictions, targets) -> Iterator[tuple[str, Mapping]]:
   """Yields (unique_name, values) once per distinct statistic (base.py:252-269)."""
+  # foreign labeled arrays (a real xr.DataArray ...) are converted ONCE here: every statistic of a (predictions, targets) pair
+  # then meets the same DataArray objects, and with them the same fused group and the same uploaded copies
+  predictions, targets = _converted(predictions), _converted(targets)
   unique = {}
   for metric in metrics.values():
     for stat in metric.statistics.values():

@@ -77,6 +77,8 @@ class ChunkFeeder:
       for item in self._work:
         _, (init_chunk, lead_chunk) = item
         predictions, targets = self._load(init_chunk, lead_chunk)
+        # (foreign labeled arrays are converted HERE and handed on converted: the staged device copy hangs on the DataArray)
+        predictions, targets = metrics_base._converted(predictions), metrics_base._converted(targets)  # pylint: disable=protected-access
         for name in predictions.keys():
           if name in targets.keys():
             engine.stage_inputs(self._ctx, [xr.as_dataarray(predictions[name]), xr.as_dataarray(targets[name])])

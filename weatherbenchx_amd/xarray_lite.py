@@ -843,11 +843,37 @@ def _host_or_same(x):
   return _to_numpy(x) if _is_torch(x) else x
 
 
+# Conversions of foreign labeled arrays (a real xr.DataArray, anything with .dims / .coords / .values): id(object) ->
+# (weak reference to the object, weak reference to its DataArray).  Everything the engine caches -- the uploaded copy, the fused
+# group of a (predictions, targets) pair -- hangs on the DataArray OBJECT, so every statistic computed from one foreign array
+# has to see the SAME conversion: RMSE + MAE + bias + ACC of a foreign (p, t) pair are then one launch and two uploads like
+# for native arrays (they were three launches and six uploads).  The entry holds the conversion WEAKLY: it lives exactly as long
+# as some statistic (its fused group) still refers to it; the next chunk's arrays are new objects and convert afresh.
+_foreign_conversions: dict = {}
+
+
+def _foreign_payload_key(x):
+  data = getattr(x, 'data', None)
+  if isinstance(data, np.ndarray):
+    return (id(data), data.__array_interface__['data'][0], data.shape, data.dtype.str)
+  if _is_torch(data):
+    return (id(data), int(data.data_ptr()), tuple(data.shape), str(data.dtype))
+  return None
+
+
 def as_dataarray(x) -> DataArray:
   """Accepts DataArray, anything xarray-like (.dims/.coords/.values) or array-likes."""
   if isinstance(x, DataArray):
     return x
   if hasattr(x, 'dims') and hasattr(x, 'coords') and hasattr(x, 'values'):
+    import weakref  # pylint: disable=g-import-not-at-top
+    hit = _foreign_conversions.get(id(x))
+    if hit is not None:
+      owner, conv, key = hit[0](), hit[1](), hit[2]
+      # (same object -- not a recycled id --, same payload buffer, same frame)
+      if owner is x and conv is not None and key == (_foreign_payload_key(x), tuple(x.dims)):
+        return conv
+      del _foreign_conversions[id(x)]
     coords = {}
     for k in x.coords:
       c = x.coords[k]
@@ -855,8 +881,15 @@ def as_dataarray(x) -> DataArray:
     data = getattr(x, 'data', None)
     if data is None or not (isinstance(data, np.ndarray) or _is_torch(data)):
       data = np.asarray(x.values)
-    return DataArray(data, dims=tuple(x.dims), coords=coords, name=getattr(x, 'name', None),
+    conv = DataArray(data, dims=tuple(x.dims), coords=coords, name=getattr(x, 'name', None),
                      attrs=getattr(x, 'attrs', None), _raw_coords=True)
+    try:
+      ident = id(x)
+      owner = weakref.ref(x, lambda _, ident=ident: _foreign_conversions.pop(ident, None))
+      _foreign_conversions[ident] = (owner, weakref.ref(conv), (_foreign_payload_key(x), tuple(x.dims)))
+    except TypeError:  # an object that cannot be weakly referenced: converted per call, as before
+      pass
+    return conv
   return DataArray(x)
 
 
