@@ -67,6 +67,9 @@ def test_makefile_lists_every_header_as_a_dependency():
   csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'weatherbenchx_amd', 'csrc')
   text = open(os.path.join(csrc, 'Makefile')).read()
   hdrs = set(re.search(r'^HDRS := (.*)$', text, re.M).group(1).split())
+  for m in re.finditer(r'^\w+_HDRS := (.*)$', text, re.M):  # headers of one family of objects (ENS_HDRS: the ensemble units)
+    hdrs |= set(m.group(1).split())
+    assert re.search(r'^build/.*: .*\$\(' + m.group(0).split()[0] + r'\)', text, re.M), m.group(0)  # ... and somebody depends on them
   for m in re.finditer(r'^build/\S+\.o: (.*)$', text, re.M):  # headers with one user sit on that object's own line
     hdrs |= {w for w in m.group(1).split() if w.endswith('.hpp')}
   for h in glob.glob(os.path.join(csrc, '*.hpp')):
