@@ -188,8 +188,28 @@ def pmc_traffic(kernel_key, enabled=True, variant=None):
   files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
   if not files or not enabled:
     return None
-  entry = json.load(open(files[-1])).get(kernel_key.split(' (')[0] + (f'@{variant}' if variant else ''))
-  return None if not entry else entry.get('traffic_bytes_per_launch')
+  table = json.load(open(files[-1]))
+  entry = table.get(kernel_key.split(' (')[0] + (f'@{variant}' if variant else ''))
+  if not entry:
+    return None
+  # a figure measured on ANOTHER build of the library says nothing about this one (round 4: every entry carries the md5 of the
+  # .so it was collected with; files of earlier rounds carry none and are not replayed against a newer library)
+  stamp = entry.get('library_md5') or table.get('_library_md5')
+  if stamp != _library_md5():
+    return None
+  return entry.get('traffic_bytes_per_launch')
+
+
+_LIB_MD5 = []
+
+
+def _library_md5():
+  if not _LIB_MD5:
+    import hashlib
+    from weatherbenchx_amd import _hip
+    path = _hip.lib_path()
+    _LIB_MD5.append(hashlib.md5(open(path, 'rb').read()).hexdigest() if os.path.exists(path) else None)
+  return _LIB_MD5[0]
 
 
 # ---- main line: the north_star field ---------------------------------------------------------------------------------------

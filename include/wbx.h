@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 8
+#define WBX_ABI_VERSION 9
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -250,6 +250,18 @@ int wbx_ens_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M,
                     int64_t member_stride, int algo /*wbx_ens_algo*/, const void* p,
                     const void* t, const uint8_t* mask, double* partial_out);
 
+/* Ensemble-valued predictions AND targets (CRPSEnsembleDistance-style evaluations) with per-point member counts on both sides:
+ * skipna_ensemble=True of probabilistic.py:133-145 (CRPSSkill over the non-NaN (prediction member, target member) pairs) and
+ * :304-336 (UnbiasedEnsembleMeanSquaredError with both ensembles' own counts).  t has a member axis of length N and element
+ * stride `target_member_stride`, like p's M / `member_stride`.  Lanes (partial layout, count lanes and flags as wbx_ens_partial):
+ *   0  sum over valid pairs |p_i - t_j| / (n_p n_t)                    NaN without a valid pair
+ *   1  (mean p - mean t)^2 - var(p) / n_p - var(t) / n_t  (ddof = 1)   NaN with fewer than two valid members on a side
+ * WBX_FLAG_SKIPNA_ENS: NaN members are missing members; without it a NaN member makes both lanes NaN.  From-memory fp64
+ * arithmetic for any M, N (O(M N) per point): a correctness path for a rare configuration, no roofline claim. */
+#define WBX_ENS2_LANES 2
+int wbx_ens2_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t member_stride, int N,
+                     int64_t target_member_stride, const void* p, const void* t, const uint8_t* mask, double* partial_out);
+
 /* ---- stage 2: weighted / binned contraction --------------------------------
  * partial is viewed as [nA][nBk][nBr][nchunk][nlane][nj];  W as [nBk][nBr][nj][nbin].
  *   sum_j = 1: out[nA][nBk][nlane][nbin]      = sum_{Br,chunk,j} partial * W
@@ -283,6 +295,14 @@ typedef enum wbx_cat_func { WBX_CAT_EXCEED = 0, WBX_CAT_RANK = 1 } wbx_cat_func;
 int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int ncat, int M,
                     int64_t member_stride, const void* p, const void* t, const double* thresholds,
                     const uint8_t* mask, double* partial_out);
+/* WBX_CAT_EXCEED against thresholds that depend on the statistic's own dims (one set per level, per latitude ...:
+ * deterministic.py:262-295 compares |p - t| with any DataArray that broadcasts).  `threshold_field` is a DEVICE float64 array
+ * addressed as input 2 of the plan: threshold k of the point (key, depth, x) is
+ *     threshold_field[key_off[2][key] + depth_off[2][depth] + x * xstride[2] + k * category_stride]
+ * (zero strides along the dims it does not depend on).  NaN thresholds give NaN indicators, exactly as above. */
+int wbx_cat_exceed_field(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int ncat, int M, int64_t member_stride,
+                         const void* p, const void* t, const double* threshold_field, int64_t category_stride,
+                         const uint8_t* mask, double* partial_out);
 
 /* ---- fused binned reduction (small depth, many boolean bins) -------------------------------------------------
  * Statistic, weight and bin membership in ONE pass over p, t, c -- for chunks where little is reduced before the

@@ -87,6 +87,8 @@ def bench_key(name: str) -> str:
     base, suffix = name.rsplit('@', 1)
     return bench_key(base) + '@' + suffix
   n = name.replace('wbx::', '')
+  if n.startswith('ens_atoms_kernel<51'):
+    return 'ens_atoms_kernel'
   if n.startswith('ens_pipe_kernel<51'):
     return 'ens_pipe_kernel'
   if n.startswith('s1_xf1_kernel<EnsOpF32<51'):
@@ -118,13 +120,21 @@ def bench_key(name: str) -> str:
   return n
 
 
+def library_md5():
+  import hashlib
+  path = os.path.join(os.path.dirname(here), 'weatherbenchx_amd', 'libwbx_hip.so')
+  return hashlib.md5(open(path, 'rb').read()).hexdigest() if os.path.exists(path) else None
+
+
 def write_traffic():
+  lib_md5 = library_md5()
   raw = json.load(open(os.path.join(src, 'pmc_raw.json')))
   traffic = {}
   for name, e in raw.items():
     if not isinstance(e, dict) or 'hbm_read_bytes' not in e:
       continue
-    traffic[bench_key(name)] = dict(e, rocprof_name=name)
+    traffic[bench_key(name)] = dict(e, rocprof_name=name, library_md5=lib_md5)
+  traffic['_library_md5'] = lib_md5  # bench.py drops a replayed traffic figure that was measured on another build
   traffic['_note'] = ('tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python '
                       'bench.py --steps 2 --warmup 1 --no-cpu` (+ --layout lat_fastest, + tools/kbench_binned.py for the '
                       'public-benchmark chunk); FETCH_SIZE is KiB and doubled per /opt/skills/guides/MI355X_MICROARCH.md '

@@ -135,8 +135,30 @@ def _chunked(plan, arr):
   return out
 
 
+def _ens2_lanes(plan, devs, ens, flags):
+  m, mstride, n_t, tstride = ens
+  off_p, off_t = _offsets(plan, 0), _offsets(plan, 1)
+  pm = np.stack([devs[0].ptr[off_p + k * mstride] for k in range(m)], axis=-1).astype(np.float64)
+  tm = np.stack([devs[1].ptr[off_t + k * tstride] for k in range(n_t)], axis=-1).astype(np.float64)
+  with np.errstate(all='ignore'):
+    if flags & _hip.FLAG_SKIPNA_ENS:
+      d = np.abs(pm[..., :, None] - tm[..., None, :])
+      npair = (~np.isnan(d)).sum(axis=(-1, -2)).astype(np.float64)
+      skill = np.where(npair > 0, np.nansum(d, axis=(-1, -2)) / npair, np.nan)
+      cnt = lambda x: (~np.isnan(x)).sum(axis=-1).astype(np.float64)
+      mean = lambda x: np.where(cnt(x) > 0, np.nansum(x, axis=-1) / cnt(x), np.nan)
+      var = lambda x: np.where(cnt(x) > 1, np.nansum((x - mean(x)[..., None]) ** 2, axis=-1) / (cnt(x) - 1), np.nan)
+      uemse = (mean(pm) - mean(tm)) ** 2 - var(pm) / cnt(pm) - var(tm) / cnt(tm)
+    else:
+      skill = np.abs(pm[..., :, None] - tm[..., None, :]).mean(axis=(-1, -2))
+      pv = pm.var(axis=-1, ddof=1) if m > 1 else np.full(skill.shape, np.nan)
+      tv = tm.var(axis=-1, ddof=1) if n_t > 1 else np.full(skill.shape, np.nan)
+      uemse = (pm.mean(axis=-1) - tm.mean(axis=-1)) ** 2 - pv / m - tv / n_t
+  return [skill, uemse]
+
+
 def _cat_lanes(plan, devs, cat):
-  cfunc, ncat, m, mstride, thr = cat
+  cfunc, ncat, m, mstride, thr, cstride = cat
   off_p = _offsets(plan, 0)
   members = np.stack([devs[0].ptr[off_p + k * mstride] for k in range(m)], axis=-1).astype(np.float64)
   t = devs[1].ptr[_offsets(plan, 1)].astype(np.float64)[..., None]
@@ -145,6 +167,10 @@ def _cat_lanes(plan, devs, cat):
     return [(r == k).astype(np.float64) for k in range(ncat)]
   ae = np.abs(members - t)
   n = (~np.isnan(ae)).sum(axis=-1).astype(np.float64)
+  if cstride is not None:  # a threshold field: threshold k of every point through input 2's offsets
+    off = _offsets(plan, 2)
+    fields = [np.asarray(devs[2].ptr, dtype=np.float64)[off + k * cstride] for k in range(ncat)]
+    return [np.where(np.isnan(f), np.nan, (ae > f[..., None]).sum(axis=-1) / np.where(n > 0, n, np.nan)) for f in fields]
   thresholds = np.asarray(thr.ptr, dtype=np.float64)
   return [np.where(np.isnan(thresholds[k]), np.nan, (ae > thresholds[k]).sum(axis=-1) / np.where(n > 0, n, np.nan))
           for k in range(ncat)]  # NaN threshold: NaN indicator (deterministic.py:293-294)
@@ -160,6 +186,8 @@ def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=
       lanes = _det_lanes(func, vals)
     elif kind == 'cat':
       lanes = _cat_lanes(plan, devs, cat)
+    elif kind == 'ens2':
+      lanes = _ens2_lanes(plan, devs, ens, plan.flags)
     else:
       lanes = _ens_lanes(plan, devs, ens, plan.flags)
     counted = bool(plan.flags & 3)

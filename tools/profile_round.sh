@@ -17,15 +17,17 @@ timeout 300 $T -d $O/trace_configs1_lat -o r1 -- $B --steps 10 --warmup 3 --legs
 timeout 300 $T -d $O/trace_ensemble -o r1 -- $B --steps 10 --warmup 3 --legs ensemble --no-cpu --no-config5 > $O/trace_ensemble.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk --no-cpu --no-config5 > $O/trace_public_chunk.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_lat.json 2> /dev/null
+timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
+timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 > $O/trace_spectrum.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum_lat -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 --layout lat_fastest > $O/trace_spectrum_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_config5 -o r1 -- $B --legs config5 --no-cpu --config5-inits 48 > $O/trace_config5.json 2> /dev/null
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
-for leg in main configs1 ensemble public_chunk spectrum; do
+for leg in main configs1 ensemble public_chunk public_chunk_ens spectrum; do
   timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
   timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
 done
-for leg in main configs1 public_chunk spectrum; do
+for leg in main configs1 public_chunk public_chunk_ens spectrum; do
   timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_${leg}_lat -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 --layout lat_fastest > /dev/null 2>&1
 done
 DBS=$(ls $O/*/r1_results.db 2>/dev/null)
@@ -59,7 +61,7 @@ json.dump(out, open('$O/pmc_raw.json', 'w'), indent=1)
 PY
 # 1. the bench lines, without any profiler attached (the driver's own settings: --steps 20 --warmup 5). They come AFTER the
 # counter passes: bench.py replays profiles/rNN_pmc_traffic.json into roofline.traffic, so that file is written first.
-python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r03} --traffic-only > $O/make_round_files.log 2>&1
+python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r04} --traffic-only > $O/make_round_files.log 2>&1
 timeout 900 $B --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
 timeout 400 $B --steps 20 --warmup 5 --layout lat_fastest --no-cpu > $O/bench_n1_lat_fastest.json 2>> $O/bench_n1.err
 for d in $O/trace_*; do cp $d/r1_kernel_stats.csv $O/$(basename $d)_kernel_stats.csv 2>/dev/null; done
@@ -77,9 +79,9 @@ for k, c, n, v in sqlite3.connect('$O/ff$shift/r_results.db').execute(\"select s
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
 ( cd $R && for s in "10 3" "20 5" "50 20" "200 50"; do set -- $s; python bench.py --legs main --no-cpu --no-config5 --steps $1 --warmup $2 --prewarm-ms 0 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('no prewarm, steps $1 warmup $2: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'])"; done; python bench.py --legs main --no-cpu --no-config5 --steps 20 --warmup 5 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('prewarm 150 ms, steps 20 warmup 5: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'], r['config']['prewarm'])" ) > $O/steady_state.txt 2>&1
 # 5. only the summaries travel back (gpurun merges at most 64 MiB): the raw rocprofv3 databases stay on the box
-python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r03} >> $O/make_round_files.log 2>&1
-mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r03}_* $R/gpurun_out/round/
-for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r03}_$f.txt; done
+python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r04} >> $O/make_round_files.log 2>&1
+mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r04}_* $R/gpurun_out/round/
+for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r04}_$f.txt; done
 rm -rf $O/trace_* $O/pmc_fetch_* $O/pmc_write_* $R/gpurun_out/pmc_ens $R/gpurun_out/pmc_spec
 find $O -maxdepth 1 -type d -name "*" | sed -n 2,100p | xargs -r rm -rf
 du -sh $R/gpurun_out

@@ -21,6 +21,7 @@ DET_LANES = {DET3: 3, DET6: 6, PASS1: 1}
 DET_INPUTS = {DET3: 2, DET6: 3, PASS1: 1}
 CAT_EXCEED, CAT_RANK = 0, 1
 ENS_LANES = 5
+ENS2_LANES = 2  # wbx_ens2_partial: skill over (prediction, target) member pairs, unbiased MSE with both ensembles' counts
 ENS_SORT, ENS_PAIRWISE = 0, 1
 COMM_ID_BYTES = 128
 FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR, FLAG_SKIPNA_ENS = 1, 2, 4, 8
@@ -37,6 +38,7 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
     'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
+    'wbx_ens2_partial', 'wbx_cat_exceed_field',
 )
 
 
@@ -136,6 +138,8 @@ def load_library():
         'wbx_ens_binned': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, vp, vp, vp, vp, vp, i64, i64, i64, C.c_int32, C.c_int32, vp, vp],
         'wbx_ens_binned_atoms_size': [C.POINTER(S1PlanStruct), i64, i64, i64, C.c_int32, C.POINTER(i64)],
         'wbx_ens_binned_atoms': [vp, C.POINTER(S1PlanStruct), i64, i64, i64, C.c_int32, vp, vp, C.POINTER(i64)],
+        'wbx_ens2_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i64, vp, vp, vp, vp],
+        'wbx_cat_exceed_field': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, i64, vp, vp, vp, i64, vp, vp],
         'wbx_cat_partial': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, i32, i64, vp, vp, vp, vp, vp],
         'wbx_det_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i32, vp, vp, vp, vp],
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],

@@ -23,7 +23,8 @@
 namespace wbx {
 
 struct CatArgs {
-  const double* thr;  // [ncat] thresholds (exceedance families)
+  const double* thr;  // [ncat] thresholds (exceedance families), or (FIELD) the threshold field: input 2 of the plan
+  int64_t cstride;    // FIELD: element stride of the category axis of the threshold field
   int32_t ncat;       // value lanes
   int32_t func;
 };
@@ -36,7 +37,9 @@ __device__ __forceinline__ T cat_ld(const void* base, int64_t off) {
 // One point: adds its indicator vector (and count lanes) to this thread's LDS column.  MF > 0: the ensemble size is
 // known at compile time (the 50 / 51-member archives): all member loads of a point are issued back to back into
 // registers before the compares (the generic loop keeps 4-8 in flight); MF == 0: any M.
-template <typename T, int MF, typename C>
+// FIELD: the thresholds depend on the statistic's own dims (per level, per latitude ...: deterministic.py:262-295 compares
+// against any DataArray that broadcasts): threshold k of the point is thr[ro[2] + x * xstride[2] + k * cstride], float64.
+template <typename T, int MF, typename C, bool FIELD = false>
 __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, const int64_t (&ro)[WBX_MAX_INPUTS],
                                           int64_t x, C* col, int stride) {
   constexpr bool RANK = std::is_same<C, uint32_t>::value;  // the column type says which family this instantiation serves
@@ -74,7 +77,12 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
     int n = 0;
     double thr[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) thr[q] = k0 + q < nc ? c.thr[k0 + q] : INFINITY;
+    for (int q = 0; q < 8; ++q) {
+      if constexpr (FIELD)
+        thr[q] = k0 + q < nc ? c.thr[ro[2] + x * a.xstride[2] + (int64_t)(k0 + q) * c.cstride] : INFINITY;
+      else
+        thr[q] = k0 + q < nc ? c.thr[k0 + q] : INFINITY;
+    }
     if constexpr (MF > 0) {
 #pragma unroll
       for (int m = 0; m < MF; ++m) {
@@ -115,8 +123,9 @@ __device__ __forceinline__ void cat_point(const S1Args& a, const CatArgs& c, con
 }
 
 // grid = nkey * nchunk (x summed) or nkey * nxtile * nchunk (x kept); block = 64 threads; dynamic LDS = nacc * 64 * 8 B
-template <typename T, int MF, typename C>
+template <typename T, int MF, typename C, bool FIELD = false>
 __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nacc, int x_kept) {
+  constexpr int NIN = FIELD ? 3 : 2;
   extern __shared__ double cols_raw[];  // [nacc][64] of C
   C* const cols = reinterpret_cast<C*>(cols_raw);
   const int lane = threadIdx.x;
@@ -133,23 +142,23 @@ __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nac
   const int64_t d0 = (int64_t)chunk * a.dchunk;
   const int64_t d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
   int64_t kb[WBX_MAX_INPUTS];
-  key_bases<2>(a, key, kb);
+  key_bases<NIN>(a, key, kb);
   C* col = cols + lane;
   if (x_kept) {
     const int64_t x = (int64_t)xt * 64 + lane;
     if (x < a.nx) {
       for (int64_t d = d0; d < d1; ++d) {
         int64_t ro[WBX_MAX_INPUTS];
-        row_bases<2>(a, kb, key, d, ro);
-        cat_point<T, MF, C>(a, c, ro, x, col, 64);
+        row_bases<NIN>(a, kb, key, d, ro);
+        cat_point<T, MF, C, FIELD>(a, c, ro, x, col, 64);
       }
       for (int i = 0; i < nacc; ++i) a.out[((key * a.nchunk + chunk) * nacc + i) * a.nx + x] = (double)col[i * 64];
     }
   } else {
     for (int64_t d = d0; d < d1; ++d) {
       int64_t ro[WBX_MAX_INPUTS];
-      row_bases<2>(a, kb, key, d, ro);
-      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T, MF, C>(a, c, ro, x, col, 64);
+      row_bases<NIN>(a, kb, key, d, ro);
+      for (int64_t x = lane; x < a.nx; x += 64) cat_point<T, MF, C, FIELD>(a, c, ro, x, col, 64);
     }
     __syncthreads();
     for (int i = 0; i < nacc; ++i) {
@@ -161,10 +170,9 @@ __global__ void __launch_bounds__(64) s1_cat_kernel(S1Args a, CatArgs c, int nac
 
 }  // namespace wbx
 
-extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int ncat, int M,
-                               int64_t member_stride, const void* p, const void* t, const double* thresholds,
-                               const uint8_t* mask, double* partial_out) {
-  using namespace wbx;
+namespace wbx {
+static int cat_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int ncat, int M, int64_t member_stride, const void* p,
+                      const void* t, const double* thresholds, bool field, int64_t cat_stride, const uint8_t* mask, double* partial_out) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (int rc = check_plan(plan)) return rc;
   WBX_REQUIRE(func == WBX_CAT_EXCEED || func == WBX_CAT_RANK, "unknown categorical family %d", func);
@@ -199,6 +207,7 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
   a.out = partial_out;
   CatArgs c;
   c.thr = thresholds;
+  c.cstride = cat_stride;
   c.ncat = ncat;
   c.func = func;
   a.nxtile = (int)((plan->nx + 63) / 64);
@@ -214,6 +223,16 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
       hipLaunchKernelGGL((s1_cat_kernel<TT, MFIX, double>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc,     \
                          (int)plan->x_kept);                                                                                  \
   } while (0)
+  if (field) {  // thresholds that depend on the statistic's dims: any M through the generic member loop
+    if (dtype == WBX_F32)
+      hipLaunchKernelGGL((s1_cat_kernel<float, 0, double, true>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept);
+    else if (dtype == WBX_F64)
+      hipLaunchKernelGGL((s1_cat_kernel<double, 0, double, true>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, a, c, nacc, (int)plan->x_kept);
+    else
+      return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
+    WBX_HIP(hipGetLastError());
+    return 0;
+  }
   if (dtype == WBX_F32) {
     if (M == 51) WBX_LAUNCH_CAT(float, 51);
     else if (M == 50) WBX_LAUNCH_CAT(float, 50);
@@ -226,4 +245,18 @@ extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, 
 #undef WBX_LAUNCH_CAT
   WBX_HIP(hipGetLastError());
   return 0;
+}
+}  // namespace wbx
+
+extern "C" int wbx_cat_partial(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, int ncat, int M,
+                               int64_t member_stride, const void* p, const void* t, const double* thresholds,
+                               const uint8_t* mask, double* partial_out) {
+  return wbx::cat_common(ctx, plan, func, dtype, ncat, M, member_stride, p, t, thresholds, false, 0, mask, partial_out);
+}
+
+extern "C" int wbx_cat_exceed_field(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int ncat, int M, int64_t member_stride,
+                                    const void* p, const void* t, const double* threshold_field, int64_t category_stride,
+                                    const uint8_t* mask, double* partial_out) {
+  return wbx::cat_common(ctx, plan, WBX_CAT_EXCEED, dtype, ncat, M, member_stride, p, t, threshold_field, true, category_stride, mask,
+                         partial_out);
 }

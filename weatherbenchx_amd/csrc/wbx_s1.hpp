@@ -38,8 +38,9 @@ struct S1Args {
   // ensemble
   int32_t M;
   int64_t mstride;
-  // map kernels
+  // map kernels (wbx_ens2_partial: the target ensemble size)
   int32_t lane;
+  int64_t ngd_t;  // wbx_ens2_partial: element stride between target members
 };
 
 // Row base offsets (elements) of every input for (key, depth row).

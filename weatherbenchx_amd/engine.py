@@ -556,8 +556,17 @@ def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Se
     if kind == 'det':
       _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]),
                                          ptr(devs[1]), ptr(devs[2]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_det_partial')
+    elif kind == 'cat' and cat[5] is not None:  # thresholds that depend on the statistic's dims: input 2 of the plan
+      cfunc, ncat, m, mstride, _, cstride = cat
+      _hip.check(ctx.lib.wbx_cat_exceed_field(ctx.handle, C.byref(dplan.struct), dtype_code, int(ncat), int(m), int(mstride),
+                                              ptr(devs[0]), ptr(devs[1]), ptr(devs[2]), int(cstride), ptr(devs[3]),
+                                              C.c_void_p(out.ptr)), 'wbx_cat_exceed_field')
+    elif kind == 'ens2':
+      m, mstride, n_t, tstride = ens
+      _hip.check(ctx.lib.wbx_ens2_partial(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(n_t), int(tstride),
+                                          ptr(devs[0]), ptr(devs[1]), ptr(devs[3]), C.c_void_p(out.ptr)), 'wbx_ens2_partial')
     elif kind == 'cat':
-      cfunc, ncat, m, mstride, thr = cat
+      cfunc, ncat, m, mstride, thr, _ = cat
       _hip.check(ctx.lib.wbx_cat_partial(ctx.handle, C.byref(dplan.struct), int(cfunc), dtype_code, int(ncat), int(m),
                                          int(mstride), ptr(devs[0]), ptr(devs[1]), ptr(thr), ptr(devs[3]),
                                          C.c_void_p(out.ptr)), 'wbx_cat_partial')
@@ -1165,6 +1174,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   devs = [(_to_device(ctx, i, dtype_code) if i is not None else None) for i in inputs]
   while len(devs) < 4:
     devs.append(None)
+  thr_field = cat.get('thr_field') if cat else None
+  if thr_field is not None:  # float64 whatever the inputs are: it is the kernel's own operand, not a statistic input
+    _sync_torch_producers([thr_field.data])
+    devs[2] = _to_device(ctx, thr_field, _hip.F64)
   flags = 0
   if mask is not None:
     flags |= _hip.FLAG_MASKED
@@ -1198,16 +1211,19 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
       else:
         hit = None
   plan, dplan = hit if hit is not None else _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags)
-  nl = _hip.DET_LANES[func] if kind == 'det' else (int(cat['ncat']) if kind == 'cat' else _hip.ENS_LANES)
+  nl = _hip.DET_LANES[func] if kind == 'det' else (int(cat['ncat']) if kind == 'cat' else
+                                                   (_hip.ENS2_LANES if kind == 'ens2' else _hip.ENS_LANES))
   counted = bool(flags & 3)
   shared_count = counted and not (flags & _hip.FLAG_SKIPNA)  # mask only: one count lane for every statistic
   nl_total = nl + 1 if shared_count else nl * (2 if counted else 1)
   ens_args = cat_args = None
   if kind == 'ens':
     ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['algo'])
+  if kind == 'ens2':
+    ens_args = (ens['M'], devs[0].layout.stride(member_dim), ens['N'], devs[1].layout.stride(member_dim))
   if kind == 'cat':
     thr = None
-    if cat.get('thresholds') is not None:
+    if cat.get('thresholds') is not None and thr_field is None:
       tkey = (ctx.device_id, np.asarray(cat['thresholds'], np.float64).tobytes())
       thr = _thr_cache.get(tkey)
       if thr is None:
@@ -1215,7 +1231,8 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
           _thr_cache.clear()
         thr = _thr_cache[tkey] = ctx.upload(np.asarray(cat['thresholds'], np.float64))
     cat_args = (cat['func'], nl, cat.get('M', 1) if member_dim else 1,
-                devs[0].layout.stride(member_dim) if member_dim else 0, thr)
+                devs[0].layout.stride(member_dim) if member_dim else 0, thr,
+                None if thr_field is None else devs[2].layout.stride(cat['cat_dim']))
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])

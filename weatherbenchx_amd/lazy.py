@@ -153,7 +153,7 @@ class FusedGroup:
 
   # -- execution ---------------------------------------------------------------------------------
   def inputs_and_func(self):
-    if self.kind in ('ens', 'cat'):
+    if self.kind in ('ens', 'cat', 'ens2'):
       return [self.p, self.t], 0
     if self.clim is not None:
       return [self.p, self.t, self.clim.source], _hip.DET6
@@ -165,6 +165,9 @@ class FusedGroup:
     ens = None
     if self.kind == 'ens':
       ens = dict(self.ens, **(ens_params or {}))
+    if self.kind == 'ens2':
+      return engine.reduce_statistics('ens2', inputs, self.dims, self.sizes, tuple(reduce_dims) + tuple(extra_reduce),
+                                      w_da, bin_dims, mask=mask, skipna=skipna, ens=self.ens)
     if self.kind == 'cat':
       return engine.reduce_statistics('cat', inputs, self.dims, self.sizes, tuple(reduce_dims) + tuple(extra_reduce),
                                       w_da, bin_dims, mask=mask, skipna=skipna, cat=self.cat)
@@ -172,6 +175,11 @@ class FusedGroup:
                                bin_dims, func=func, mask=mask, skipna=skipna, clim=self.clim, ens=ens)
 
   def materialise(self, lane: int, ens_params=None) -> np.ndarray:
+    if self.kind == 'ens2':  # stage 1 with every dim kept IS the per-point statistic
+      with engine.synchronous_results():
+        values, _, out_dims = self.reduce((), None, (), use_mask=False, skipna=False)
+      arr = np.asarray(values, np.float64)[lane]
+      return np.ascontiguousarray(np.transpose(arr, [out_dims.index(d) for d in self.dims]))
     inputs, func = self.inputs_and_func()
     ens = dict(self.ens, **(ens_params or {})) if self.kind == 'ens' else None
     gather, inputs = _gather_spec(self.clim, inputs, self.dims)
@@ -428,7 +436,28 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
     return np.dtype(np.float64)
 
 
-def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, ensemble_dim=None) -> xr.DataArray:
+ENS2_LANE = {'CRPSSkill': 0, 'UnbiasedEnsembleMeanSquaredError': 1}
+
+
+def ens2_statistic(stat_name: str, p, t, ensemble_dim: str, *, skipna_ensemble: bool) -> xr.DataArray:
+  """Statistics of an ensemble of predictions against an ensemble of TARGETS with per-point member counts on both sides
+  (wbx_ens2_partial): both lanes of a (p, t) pair come out of one launch."""
+  p, t = xr.as_dataarray(p), xr.as_dataarray(t)
+  for da in (p, t):
+    if ensemble_dim not in da.dims:
+      raise ValueError(f'Dimension {ensemble_dim} not found in {da.dims}')
+  try:  # frames without the member axes (the two ensembles have their own sizes and member labels)
+    _stat_frame([p.isel({ensemble_dim: 0}, drop=True), t.isel({ensemble_dim: 0}, drop=True)])
+  except _NeedsAlignment:
+    p0, t0 = xr.align(p.isel({ensemble_dim: 0}, drop=True), t.isel({ensemble_dim: 0}, drop=True), join='inner')
+    p = p.sel({d: p0[d].values for d in p0.dims if d in p0.coords})
+    t = t.sel({d: t0[d].values for d in t0.dims if d in t0.coords})
+  ens = {'member_dim': ensemble_dim, 'M': p.sizes[ensemble_dim], 'N': t.sizes[ensemble_dim], 'skipna': bool(skipna_ensemble)}
+  grp = _group_for('ens2', p, t, ens=ens, clim_key=('ens2', bool(skipna_ensemble)))
+  return LazyStatistic(grp, ENS2_LANE[stat_name], name=p.name)
+
+
+def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, ensemble_dim=None, threshold_field=None) -> xr.DataArray:
   p, t = xr.as_dataarray(p), xr.as_dataarray(t)
   if ensemble_dim is not None:
     if ensemble_dim not in p.dims:
@@ -439,10 +468,24 @@ def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, 
   if cat_dim in p.dims or cat_dim in t.dims:
     raise ValueError(f'{cat_dim!r} is already a dimension of the inputs')
   thr = None if thresholds is None else np.asarray(thresholds, np.float64).reshape(-1)
-  ncat = (p.sizes[ensemble_dim] + 1) if func == _hip.CAT_RANK else int(thr.size)
+  if threshold_field is not None:
+    # thresholds that depend on the statistic's dims (wbx_cat_exceed_field): a float64 DataArray over (some of) the frame's dims
+    # + `cat_dim`, consumed in place through its strides
+    threshold_field = xr.as_dataarray(threshold_field)
+    extra = [d for d in threshold_field.dims if d != cat_dim and d not in p.dims and d not in t.dims]
+    if extra or cat_dim not in threshold_field.dims:
+      raise ValueError(f'thresholds over {threshold_field.dims} do not broadcast against the statistic (extra dims {extra})')
+    for d in threshold_field.dims:  # same labels on the shared dims (the reference's comparison aligns on them)
+      ref = p if d in p.dims else t
+      if d != cat_dim and d in threshold_field.coords and d in ref.coords and not xr._values_equal(threshold_field.coords[d].values, ref.coords[d].values):  # pylint: disable=protected-access
+        raise ValueError(f'thresholds and inputs carry different {d!r} coordinates: select the common labels first')
+    if not xr._is_float(threshold_field.data) or str(threshold_field.dtype) != 'float64':  # pylint: disable=protected-access
+      threshold_field = threshold_field.astype(np.float64)
+    thr = None
+  ncat = (p.sizes[ensemble_dim] + 1) if func == _hip.CAT_RANK else (int(thr.size) if thr is not None else threshold_field.sizes[cat_dim])
   cat = {'func': int(func), 'ncat': ncat, 'thresholds': thr, 'member_dim': ensemble_dim,
-         'M': p.sizes[ensemble_dim] if ensemble_dim else 1}
-  key = ('cat', int(func), cat_dim, None if thr is None else thr.tobytes())
+         'M': p.sizes[ensemble_dim] if ensemble_dim else 1, 'thr_field': threshold_field, 'cat_dim': cat_dim}
+  key = ('cat', int(func), cat_dim, None if thr is None else thr.tobytes(), None if threshold_field is None else id(threshold_field))
   grp = _group_for('cat', p, t, ens=None, clim_key=(key, ensemble_dim), cat=cat)
   return LazyCategorical(grp, cat_dim, cat_coord, name=p.name)
 

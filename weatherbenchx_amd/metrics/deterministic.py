@@ -115,12 +115,15 @@ class ErrorExceedance(base.PerVariableStatistic):
   def _compute_per_variable(self, predictions, targets):
     spec = _threshold_array(self._thresholds, predictions.name)
     if spec is None:
-      # thresholds with data dims (per level, per latitude ...): the comparison broadcasts like the reference's
-      # `abs_error > thresholds`, evaluated on the labeled arrays; NaN errors and NaN thresholds stay NaN
+      # thresholds with data dims (per level, per latitude ...): the kernel reads threshold k of a point through the field's
+      # own strides (wbx_cat_exceed_field); the new dimension is the one the inputs do not have
       thresholds = self._thresholds[predictions.name] if isinstance(self._thresholds, (xr.Dataset, dict)) else self._thresholds
-      abs_error = abs(predictions - targets)
-      out = (abs_error > thresholds).astype(np.float64)
-      return out.where(abs_error.notnull()).where(thresholds.notnull()).rename(predictions.name)
+      thresholds = xr.as_dataarray(thresholds)
+      new = [d for d in thresholds.dims if d not in predictions.dims and d not in targets.dims]
+      if len(new) != 1:
+        raise ValueError(f'thresholds over {thresholds.dims} must add exactly one dimension to the inputs (got {new})')
+      coord = thresholds.coords[new[0]].values if new[0] in thresholds.coords else None
+      return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, new[0], coord, threshold_field=thresholds)
     values, dim, coord = spec
     return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, dim, coord, thresholds=values)
 

@@ -82,18 +82,8 @@ class CRPSSkill(base.PerVariableStatistic):
       # per-member skill: linear, so one fused launch per target member
       if self._skipna_ensemble:
         # NaN members on either side: the mean runs over the non-NaN (prediction member, target member) pairs of each
-        # point, which is not linear in the target member any more -- evaluated un-fused on the labeled arrays, one
-        # target member at a time (no M x N x grid temporary), exactly as written in the reference
-        pseudo = f'{self._ensemble_dim}_PSEUDO_FOR_TARGETS'
-        total = count = None
-        for tj in lazy.target_members(targets, self._ensemble_dim):
-          ae = abs(predictions - tj)
-          ok = ae.notnull()
-          part, n = ae.where(ok, 0.0).sum(self._ensemble_dim, skipna=False), ok.sum(self._ensemble_dim)
-          total = part if total is None else total + part
-          count = n if count is None else count + n
-        del pseudo
-        return (total / count.where(count > 0)).rename(predictions.name)
+        # point, which is not linear in the target member any more: the pair kernel with per-point counts (wbx_ens2_partial)
+        return lazy.ens2_statistic('CRPSSkill', predictions, targets, self._ensemble_dim, skipna_ensemble=True)
       members = lazy.target_members(targets, self._ensemble_dim)
       terms = [lazy.ens_statistic('CRPSSkill', predictions, tj, self._ensemble_dim) for tj in members]
       return lazy.LinearCombination(terms, scale=1.0 / len(terms), name=predictions.name)
@@ -175,11 +165,8 @@ class UnbiasedEnsembleMeanSquaredError(base.PerVariableStatistic):
       # this is  mean_j UEMSE(p, t_j) - var_t : N fused launches against single target members plus the variance
       # lane of one launch over the target ensemble -- linear, so the accumulators are combined after the reduction.
       if self._skipna_ensemble:
-        # per-point member counts on both sides (probabilistic.py:304-333): un-fused, on the labeled arrays
-        dim = self._ensemble_dim
-        bias = lambda x: x.var(dim=dim, ddof=1, skipna=True) / x.count(dim)
-        out = (predictions.mean(dim=dim, skipna=True) - targets.mean(dim=dim, skipna=True)) ** 2
-        return (out - bias(predictions) - bias(targets)).rename(predictions.name)
+        # per-point member counts on both sides (probabilistic.py:304-333): lane 1 of the same launch (wbx_ens2_partial)
+        return lazy.ens2_statistic('UnbiasedEnsembleMeanSquaredError', predictions, targets, self._ensemble_dim, skipna_ensemble=True)
       members = lazy.target_members(targets, self._ensemble_dim)
       n = len(members)
       if n < 2:
