@@ -1,0 +1,92 @@
+"""File-backed loaders (weatherbenchx_amd/loaders.py): `.npy` memory maps and NetCDF-3 files read chunk by chunk into
+(page-locked) buffers, predictions as (init, lead) blocks, targets gathered at valid_time = init + lead -- the semantics of
+PredictionsFromXarray / TargetsFromXarray (data_loaders/xarray_loaders.py:176-316) -- and a chunked evaluation over them
+against the oracle on the whole arrays."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import loaders
+from weatherbenchx_amd import pipeline
+from weatherbenchx_amd import time_chunks
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd.metrics import deterministic
+
+RTOL = 1e-6
+
+
+def _write(tmp_path, fmt, nlat=19, nlon=36):
+  rng = np.random.default_rng(5)
+  ninit, nlead, nlev = 5, 3, 2
+  init_times = np.datetime64('2020-01-01T00', 'ns') + np.arange(ninit) * np.timedelta64(12, 'h')
+  lead_times = (np.arange(nlead) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')
+  times = np.datetime64('2020-01-01T00', 'ns') + np.arange(ninit + nlead) * np.timedelta64(12, 'h')
+  lat, lon, level = np.linspace(-90, 90, nlat), np.arange(nlon) * (360.0 / nlon), np.array([500, 850])
+  pv = (rng.normal(size=(ninit, nlead, nlev, nlon, nlat)) + 280).astype(np.float32)   # latitude fastest, like the archives
+  tv = (rng.normal(size=(times.size, nlev, nlon, nlat)) + 280).astype(np.float32)
+  tv[3, 1, 4, 5] = np.nan
+  dims, coords = ('level', 'longitude', 'latitude'), {'level': level, 'longitude': lon, 'latitude': lat}
+  if fmt == 'npy':
+    pp, tp = os.path.join(tmp_path, 'p.npy'), os.path.join(tmp_path, 't.npy')
+    np.save(pp, pv)
+    np.save(tp, tv)
+    src_p, src_t = {'z': pp}, {'z': tp}
+  else:
+    from scipy.io import netcdf_file
+    pp, tp = os.path.join(tmp_path, 'p.nc'), os.path.join(tmp_path, 't.nc')
+    for path, arr, names in ((pp, pv, ('init_time', 'lead_time') + dims), (tp, tv, ('time',) + dims)):
+      f = netcdf_file(path, 'w', version=2)
+      for n, s in zip(names, arr.shape):
+        f.createDimension(n, s)
+      v = f.createVariable('z', np.float32, names)
+      v[:] = arr
+      f.close()
+    src_p, src_t = {'z': (pp, 'z')}, {'z': (tp, 'z')}
+  return src_p, src_t, init_times, lead_times, times, dims, coords, pv, tv
+
+
+@pytest.mark.parametrize('fmt', ['npy', 'nc'])
+def test_chunks_from_files_have_the_reference_frames(tmp_path, fmt):
+  src_p, src_t, init_times, lead_times, times, dims, coords, pv, tv = _write(str(tmp_path), fmt)
+  lp = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=False)
+  lt = loaders.TargetsFromFiles(src_t, times, dims, coords, pinned=False, add_nan_mask=True)
+  p = lp.load_chunk(init_times[[3, 1]], lead_times[1:])['z']
+  assert p.dims == ('init_time', 'lead_time') + dims
+  np.testing.assert_array_equal(p.values, pv[[3, 1]][:, 1:])
+  np.testing.assert_array_equal(p['init_time'].values, init_times[[3, 1]])
+  t = lt.load_chunk(init_times[[3, 1]], lead_times[1:])['z']
+  assert t.dims == ('init_time', 'lead_time') + dims
+  for a, i in enumerate((3, 1)):
+    for b, l in enumerate((1, 2)):
+      np.testing.assert_array_equal(t.values[a, b], tv[i + l])       # valid_time = init + lead (12 h steps)
+  np.testing.assert_array_equal(t.coords['valid_time'].values, init_times[[3, 1]][:, None] + lead_times[1:][None, :])
+  np.testing.assert_array_equal(np.asarray(t.coords['mask'].values), ~np.isnan(t.values))  # data_loaders/base.py:25-56
+  assert p.values.dtype == np.float32 and p.values.dtype.isnative
+  with pytest.raises(KeyError):
+    lp.load_chunk(np.array(['2031-01-01'], dtype='datetime64[ns]'), lead_times)
+  with pytest.raises(ValueError, match='slice'):
+    lt.load_chunk(init_times[:1], slice(None))
+  assert lp.timings['chunks'] == 1 and lp.timings['bytes'] == p.values.nbytes
+
+
+@pytest.mark.parametrize('fmt', ['npy', 'nc'])
+def test_chunked_evaluation_from_files_against_the_oracle(backend, tmp_path, fmt):
+  src_p, src_t, init_times, lead_times, times, dims, coords, pv, tv = _write(str(tmp_path), fmt)
+  lp = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=backend == 'hip')
+  lt = loaders.TargetsFromFiles(src_t, times, dims, coords, pinned=backend == 'hip', add_nan_mask=True)
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], masked=True)
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=2, lead_time_chunk_size=2)
+  got = pipeline.evaluate_chunks(tc, loaders.load_chunk_fn(lp, lt), metrics, agg, prefetch=1 if backend == 'hip' else 0)[None].metric_values(metrics)
+  valid_idx = (np.arange(init_times.size)[:, None] + np.arange(lead_times.size)[None, :])  # 12 h init step == 12 h lead step
+  tfull = tv[valid_idx]
+  fdims = ('init_time', 'lead_time') + dims
+  w = (O.grid_area_weights(coords['latitude']), ('latitude',))
+  ok = ~np.isnan(tfull)
+  for name, lane in (('rmse', O.squared_error(pv, tfull)), ('mae', O.absolute_error(pv, tfull))):
+    sws, sw, od = O.aggregate(lane, fdims, ['init_time', 'latitude', 'longitude'], weights=[w], mask=ok, mask_dims=fdims)
+    want = np.sqrt(sws / sw) if name == 'rmse' else sws / sw
+    np.testing.assert_allclose(np.asarray(got[f'{name}.z'].transpose(*od).values), want, rtol=RTOL, err_msg=name)

@@ -1,0 +1,193 @@
+"""File-backed chunk loaders under the chunk feeder (counterpart of weatherbenchX/data_loaders/base.py:58-170 and
+weatherbenchX/data_loaders/xarray_loaders.py:143-316, whose zarr / xarray backends are not installable here).
+
+A loader maps (init_times, lead_times) to {variable: DataArray} exactly like the reference's `DataLoader.load_chunk`:
+  * `PredictionsFromFiles`  fields indexed [init_time, lead_time, ...]: the chunk is the (init, lead) block
+                            (PredictionsFromXarray, xarray_loaders.py:176-221);
+  * `TargetsFromFiles`      fields indexed by ONE time axis: the chunk is gathered at valid_time = init_time + lead_time and
+                            carries init_time / lead_time dims plus a 2-D `valid_time` coordinate
+                            (TargetsFromXarray, xarray_loaders.py:224-316).
+Storage: `.npy` files (numpy memory maps) or NetCDF-3 (scipy.io.netcdf_file with mmap, the format io.py writes).  A chunk is
+read -- decoded, if the file is big-endian -- STRAIGHT into page-locked memory (`pipeline.pinned_empty`), so the feeder's
+upload is pure DMA on its copy stream (`wbx_memcpy_h2d_async`) and overlaps both the kernels of the previous chunk and this
+loader's reads of the next one; the pool of page-locked blocks is the double buffer.  `add_nan_mask` attaches the `mask`
+coordinate of data_loaders/base.py:25-56.  `timings` accumulates what the reads cost (bytes, seconds): disk / page-cache rate.
+"""
+from __future__ import annotations
+
+import time
+from typing import Mapping, Sequence
+
+import numpy as np
+
+from weatherbenchx_amd import xarray_lite as xr
+
+
+class _FileSource:
+  """One variable in a file: an array-like that supports numpy fancy indexing along its leading axes."""
+
+  def __init__(self, path: str, variable: str | None = None):
+    self.path, self.variable = path, variable
+    self._arr = None
+
+  def array(self):
+    if self._arr is None:
+      if self.path.endswith('.npy'):
+        self._arr = np.load(self.path, mmap_mode='r')
+      else:
+        from scipy.io import netcdf_file  # pylint: disable=g-import-not-at-top
+        self._file = netcdf_file(self.path, 'r', mmap=True)  # (kept open: the variable is a view of its map)
+        self._arr = self._file.variables[self.variable].data
+    return self._arr
+
+  def __getstate__(self):  # loaders travel to worker processes (the reference pickles its DoFns): reopen there
+    return {'path': self.path, 'variable': self.variable, '_arr': None}
+
+
+def _strip_pool(state):
+  state = dict(state)
+  state['_pool'] = None
+  return state
+
+
+class FileLoader:
+  """Base of the file-backed loaders.  `sources` = {variable: path.npy | (path.nc, name)}; `dims` = the stored dim order of
+  every variable (after the time axes), e.g. ('level', 'longitude', 'latitude'); `coords` = {dim: values}."""
+
+  def __init__(self, sources: Mapping[str, object], dims: Sequence[str], coords: Mapping[str, np.ndarray], *, add_nan_mask: bool = False,
+               pinned: bool = True, threads: int = 4):
+    self._sources = {k: (_FileSource(v) if isinstance(v, str) else _FileSource(*v)) for k, v in sources.items()}
+    self._dims = tuple(dims)
+    self._coords = {k: np.asarray(v) for k, v in coords.items()}
+    self._add_nan_mask = add_nan_mask
+    self._pinned = pinned
+    self._threads = max(1, int(threads))  # a chunk's gather is split over this many threads (numpy's copies release the GIL)
+    self._pool = None
+    self.timings = {'bytes': 0, 'seconds': 0.0, 'chunks': 0}
+
+  def _buffer(self, shape, dtype):
+    if self._pinned:
+      from weatherbenchx_amd import pipeline  # pylint: disable=g-import-not-at-top
+      try:
+        return pipeline.pinned_empty(shape, dtype)
+      except Exception:  # pylint: disable=broad-except  (no device in this process: plain memory, pageable upload later)
+        pass
+    return np.empty(shape, dtype)
+
+  def _gather(self, arr, index, out):
+    """out[...] = arr[index] along the leading axis, gathered STRAIGHT into `out` (no temporary), timed.  The indices have
+    been validated (`_positions`), so `mode='clip'` only switches numpy's buffered copy off."""
+    t0 = time.perf_counter()
+
+    def part(lo, hi):
+      if arr.dtype.isnative:
+        np.take(arr, index[lo:hi], axis=0, out=out[lo:hi], mode='clip')
+      else:  # a big-endian file (NetCDF-3): decoded on the way
+        for a in range(lo, hi):
+          np.copyto(out[a], arr[int(index[a])])
+    n = len(index)
+    # one memcpy thread moves ~24 GB/s out of the page cache (tools/bench_feeder_files.py), PCIe takes ~50: split the rows
+    if self._threads > 1 and n > 1 and out.nbytes >= (8 << 20):
+      if self._pool is None:
+        from concurrent.futures import ThreadPoolExecutor  # pylint: disable=g-import-not-at-top
+        self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix='wbx-loader')
+      cuts = np.linspace(0, n, min(self._threads, n) + 1).astype(int)
+      list(self._pool.map(lambda ab: part(*ab), zip(cuts[:-1], cuts[1:])))
+    else:
+      part(0, n)
+    self.timings['seconds'] += time.perf_counter() - t0
+    self.timings['bytes'] += out.nbytes
+
+  def __getstate__(self):
+    return _strip_pool(self.__dict__)
+
+  def _finish(self, out):
+    self.timings['chunks'] += 1
+    if self._add_nan_mask:
+      from weatherbenchx_amd import data as wdata  # pylint: disable=g-import-not-at-top
+      out = wdata.add_nan_mask_to_data(out)
+    return out
+
+
+class PredictionsFromFiles(FileLoader):
+  """Forecast fields stored [init_time, lead_time, *dims]."""
+
+  def __init__(self, sources, init_times, lead_times, dims, coords, **kw):
+    super().__init__(sources, dims, coords, **kw)
+    self._init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    self._lead_times = np.asarray(lead_times, dtype='timedelta64[ns]')
+
+  def load_chunk(self, init_times, lead_times=None):
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    ii = _positions(self._init_times, init_times, 'init_time')
+    if lead_times is None or isinstance(lead_times, slice):
+      li = np.arange(self._lead_times.size)[lead_times if lead_times is not None else slice(None)]
+    else:
+      li = _positions(self._lead_times, np.asarray(lead_times, dtype='timedelta64[ns]'), 'lead_time')
+    out = {}
+    for name, src in self._sources.items():
+      arr = src.array()
+      buf = self._buffer((ii.size, li.size) + tuple(arr.shape[2:]), np.dtype(arr.dtype).newbyteorder('='))
+      for a, i in enumerate(ii):
+        self._gather(arr[int(i)], li, buf[a])
+      coords = dict(self._coords, init_time=self._init_times[ii], lead_time=self._lead_times[li])
+      out[name] = xr.DataArray(buf, dims=('init_time', 'lead_time') + self._dims, coords={k: v for k, v in coords.items() if k in ('init_time', 'lead_time') + self._dims},
+                               name=name)
+    return self._finish(out)
+
+
+class TargetsFromFiles(FileLoader):
+  """Analysis / observation fields stored [time, *dims]; a chunk is gathered at valid_time = init_time + lead_time."""
+
+  def __init__(self, sources, times, dims, coords, **kw):
+    super().__init__(sources, dims, coords, **kw)
+    self._times = np.asarray(times, dtype='datetime64[ns]')
+
+  def load_chunk(self, init_times, lead_times=None):
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    if isinstance(lead_times, slice):
+      raise ValueError('Lead time slice not supported for target data loaders.')  # xarray_loaders.py:288-289
+    if lead_times is None:  # the init times ARE the valid times (xarray_loaders.py:290-297)
+      ti = _positions(self._times, init_times, 'valid_time')
+      out = {}
+      for name, src in self._sources.items():
+        arr = src.array()
+        buf = self._buffer((ti.size,) + tuple(arr.shape[1:]), np.dtype(arr.dtype).newbyteorder('='))
+        self._gather(arr, ti, buf)
+        out[name] = xr.DataArray(buf, dims=('init_time',) + self._dims,
+                                 coords={k: v for k, v in dict(self._coords, init_time=init_times).items() if k in ('init_time',) + self._dims}, name=name)
+      return self._finish(out)
+    lead_times = np.asarray(lead_times, dtype='timedelta64[ns]')
+    valid = init_times[:, None] + lead_times[None, :]
+    ti = _positions(self._times, valid.reshape(-1), 'valid_time')
+    out = {}
+    for name, src in self._sources.items():
+      arr = src.array()
+      shape = (init_times.size, lead_times.size) + tuple(arr.shape[1:])
+      buf = self._buffer(shape, np.dtype(arr.dtype).newbyteorder('='))
+      self._gather(arr, ti, buf.reshape((ti.size,) + tuple(arr.shape[1:])))
+      coords = {k: v for k, v in dict(self._coords, init_time=init_times, lead_time=lead_times).items() if k in ('init_time', 'lead_time') + self._dims}
+      da = xr.DataArray(buf, dims=('init_time', 'lead_time') + self._dims, coords=coords, name=name)
+      out[name] = da.assign_coords(valid_time=xr.DataArray(valid, dims=('init_time', 'lead_time')))
+    return self._finish(out)
+
+
+def _positions(axis: np.ndarray, wanted: np.ndarray, what: str) -> np.ndarray:
+  """Exact label lookup (`.sel` of the reference): KeyError for a label the file does not hold."""
+  order = np.argsort(axis, kind='stable')
+  pos = np.searchsorted(axis[order], wanted)
+  pos = np.clip(pos, 0, axis.size - 1)
+  hit = order[pos]
+  if not np.array_equal(axis[hit], wanted):
+    missing = wanted[axis[hit] != wanted]
+    raise KeyError(f'{what} labels not in the file: {missing[:4]}')
+  return hit
+
+
+def load_chunk_fn(predictions: FileLoader, targets: FileLoader):
+  """(init_chunk, lead_chunk) -> (predictions, targets) for pipeline.evaluate_chunks / evaluate_passes: the two
+  `load_chunk` calls of LoadPredictionsAndTargets (beam_pipeline.py:69-116)."""
+  def load(init_chunk, lead_chunk):
+    return predictions.load_chunk(init_chunk, lead_chunk), targets.load_chunk(init_chunk, lead_chunk)
+  load.loaders = (predictions, targets)
+  return load
