@@ -627,11 +627,10 @@ def public_chunk_leg(env):
 def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   """The reference's probabilistic evaluation (public_benchmark/run_benchmark_evaluation.py:341-354, 365-382): the ensemble
   suite under Regions(17) x land/sea = 34 bins, GridAreaWeighting, masked=True, on one f32[1 init, 8 lead, 51 member, lat, lon]
-  chunk.  Without a `mask` coordinate on the variable (most variables) the whole suite is ONE wbx_ens_binned launch --
-  asserted.  `with_mask`: the targets carry a (latitude, longitude) `mask` coordinate; the reference then masks skill /
-  unbiased MSE / mean MSE and leaves the statistics of the predictions alone (spread, variance: no mask coordinate,
-  probabilistic.py:165-273) unmasked, so there are two launches, each one pass over the members -- asserted.  The roofline is
-  that of a launch.  `ifs_layout`: the recorded IFS-ENS dim order (init, number, lead, longitude, latitude),
+  chunk.  The whole suite is ONE wbx_ens_binned launch per variable -- asserted -- also when (`with_mask`) the targets carry a
+  (latitude, longitude) `mask` coordinate: the reference then masks skill / unbiased MSE / mean MSE and leaves the statistics
+  of the predictions alone (spread, variance: no mask coordinate, probabilistic.py:165-273) unmasked, and the kernel yields both
+  sets from one pass (masked-out points are accumulated under their atom's twin).  The roofline is that of the launch.  `ifs_layout`: the recorded IFS-ENS dim order (init, number, lead, longitude, latitude),
   docs/source/how_to/metric_wrappers.ipynb:955-964."""
   from weatherbenchx_amd import aggregation, binning, engine, weighting
   from weatherbenchx_amd import xarray_lite as xr
@@ -692,7 +691,7 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
     engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT, engine.ALTERNATE_STREAMS = None, 1, saved
   kinds = sorted((e['kind'], e.get('flags', 0) & 1) for e in log)
   # one pass over the members (per mask setting), nothing else
-  assert kinds == ([('ens_binned', 0), ('ens_binned', 1)] if with_mask else [('ens_binned', 0)]), kinds
+  assert kinds == [('ens_binned', 1 if with_mask else 0)], kinds
   points = nl * env.nlat * env.nlon
   k_ms = float(np.mean([e['ms'] for e in log]))
   name = f"ens_atoms_kernel<{m},true,{'NT' if env.layout == 'lon_fastest' else 'L2-shared lines'}> behind wbx_ens_binned"

@@ -317,6 +317,8 @@ int wbx_cat_exceed_field(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int n
 #define WBX_BINNED_W_ON_X 1
 #define WBX_BINNED_WT_X_ONLY 2
 #define WBX_BINNED_WT_ROW_ONLY 4
+#define WBX_BINNED_TWIN_MASK 16 /* wbx_ens_binned with WBX_FLAG_MASKED: 12 output lanes instead of 6 -- lanes 0-5 with the mask applied,
+                                   lanes 6-11 the same statistics over ALL points (mask ignored) from the same pass over the members */
 #define WBX_BINNED_MASK_ON_W 8 /* the validity mask (WBX_FLAG_MASKED) depends on the Bk / Br / x dims only (a (latitude, longitude)
                                   mask under Regions bins): its byte is folded into the atom-id byte, one load less per point */
 /* `atoms`: NULL, or the tables wbx_binned_atoms wrote for exactly this geometry (plan extents, nA, nBk, nBr, w_on_x) and
@@ -344,6 +346,10 @@ int wbx_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t 
  *   dtype WBX_F32, algo WBX_ENS_SORT (the pair form gives the same number), 2 <= M <= 64, plan->flags within FAIR | MASKED;
  *   weights factored: WBX_BINNED_WT_X_ONLY (wt[nBk][nx]) or WBX_BINNED_WT_ROW_ONLY (wt[nBk][nBr]), or wt = NULL (ones);
  *   a mask (WBX_FLAG_MASKED) must live on the W dims: WBX_BINNED_MASK_ON_W together with WBX_BINNED_W_ON_X.
+ * WBX_BINNED_TWIN_MASK (with a mask): out[nA][nBk][12][nbin] -- lanes 0-5 as above with the mask applied, lanes 6-11 the same six over
+ * ALL points.  The reference masks the skill / unbiased-MSE / mean-MSE statistics of a variable whose targets carry a `mask`
+ * coordinate but not its spread / variance (statistics of the predictions alone, probabilistic.py:165-273, aggregation.py:339-352):
+ * both sets come out of ONE pass (masked-out points are accumulated under their atom's twin).
  * `atoms`: NULL, or the tables wbx_ens_binned_atoms wrote for this geometry and these bits (its patches are shorter than
  * wbx_det_binned's, so the tables are its own).  *overflow_out = number of patches with more than 32 distinct membership
  * words (bins that are not boxes): when it is not zero use the two-stage route -- wbx_ens_binned would return NaN for the

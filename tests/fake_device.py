@@ -263,7 +263,10 @@ def _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, route):
     if plan.flags & _hip.FLAG_MASKED:
       assert w_flags & _hip.BINNED_MASK_ON_W
       valid = devs[3].ptr[_offsets(plan, 3)] != 0
+    every = lanes + [np.ones(lanes[0].shape)]
     lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
+    if w_flags & _hip.BINNED_TWIN_MASK:  # lanes 6-11: the same statistics over all points
+      lanes = lanes + every
     flag, buf = w_buf.factored
     assert flag == (w_flags & (_hip.BINNED_WT_X_ONLY | _hip.BINNED_WT_ROW_ONLY))
     fac = np.asarray(buf.ptr)
@@ -271,7 +274,7 @@ def _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, route):
     bits = np.asarray(w_buf.bufs[1].ptr).reshape(nBk, nBr, nj)
     member = ((bits[..., None] >> np.arange(nbin, dtype=np.uint64)) & np.uint64(1)).astype(np.float64)
     member = np.broadcast_to(member, (nBk, nBr, nj, nbin)) if nj > 1 else np.broadcast_to(member, (nBk, nBr, 1, nbin)).repeat(plan.nx, axis=2)
-    out = np.empty((nA, nBk, engine.ENS_BINNED_LANES, 1, nbin))
+    out = np.empty((nA, nBk, len(lanes), 1, nbin))
     for l, v in enumerate(lanes):
       v = v.reshape(nA, nBk, nBr, plan.ndepth, plan.nx) * wt[None, :, :, None, :]
       out[:, :, l, 0, :] = np.einsum('abrdx,brxn->abn', v, member)

@@ -10,6 +10,7 @@ bin dims in `bin_by` order (unpinned by the reference, SURVEY F11: compare by na
 from __future__ import annotations
 
 import dataclasses
+import weakref
 from typing import Any, Callable, Collection, Hashable, Iterable, Mapping, Sequence
 
 import numpy as np
@@ -284,11 +285,24 @@ class Aggregator:
     has to launch the variant the group's CRPSSpread statistic will ask for -- otherwise CRPSEnsemble reads the ensemble
     twice (skill first, spread with other parameters second: round 2's 0.82 ms per 1.73 GB for the reference-default
     CRPSEnsemble()).  Called by aggregate_statistics and by the chunk loop (pipeline._consume)."""
+    by_p = {}
     for stats in statistics.values():
       for s in stats.values():
-        if isinstance(s, lazy.LazyStatistic) and s.is_lazy and s._group.kind == 'ens' \
-            and s._lane == lazy.ENS_LANE['CRPSSpread'] and s._ens_params:  # pylint: disable=protected-access
-          s._group.spread_params = dict(s._ens_params)  # pylint: disable=protected-access
+        if isinstance(s, lazy.LazyStatistic) and s.is_lazy and s._group.kind == 'ens':  # pylint: disable=protected-access
+          by_p.setdefault(id(s._group.p), set()).add(s._group)  # pylint: disable=protected-access
+          if s._lane == lazy.ENS_LANE['CRPSSpread'] and s._ens_params:  # pylint: disable=protected-access
+            s._group.spread_params = dict(s._ens_params)  # pylint: disable=protected-access
+    # Statistics of the predictions alone (spread, variance) live in a group of their own -- no mask coordinate -- next to the
+    # group of the same predictions against the masked targets.  One launch can serve both (engine.ENS_TWIN_MASK): the unmasked
+    # group learns who its masked sibling is, so that whichever statistic comes first runs that one launch.
+    for groups in by_p.values():
+      masked = [g for g in groups if 'mask' in g.coords]
+      if len(masked) == 1:
+        for g in groups:
+          if g is not masked[0] and 'mask' not in g.coords:
+            g.twin_sibling = weakref.ref(masked[0])
+            if getattr(g, 'spread_params', None) and not getattr(masked[0], 'spread_params', None):
+              masked[0].spread_params = dict(g.spread_params)
 
   def _stat_var(self, stat: xr.DataArray) -> AggregationState | None:
     stat = xr.as_dataarray(stat)
@@ -455,6 +469,15 @@ class Aggregator:
         key = self._cache_key(w_da, bin_dims, use_mask, skipna, (tuple(sorted(ens_params.items())), mean_dims, family))
         hit = grp.cache.get(key)
     if hit is None:
+      sib = getattr(grp, 'twin_sibling', None)
+      sib = sib() if sib is not None else None
+      if sib is not None and grp.kind == 'ens' and not use_mask and self.masked and not skipna and engine.ENS_TWIN_MASK:
+        # the masked sibling's launch also yields this group's (unmasked) sums: run it first if it has not run yet
+        sparams = dict(getattr(sib, 'spread_params', None) or ens_params or {'algo': _hip.ENS_SORT, 'fair': True, 'skipna': False})
+        skey = self._cache_key(w_da, bin_dims, True, skipna, (tuple(sorted(sparams.items())), mean_dims, 0))
+        if skey not in sib.cache and not sparams.get('skipna'):
+          sib.cache[skey] = sib.reduce(self.reduce_dims, w_da, bin_dims, use_mask=True, skipna=skipna, ens_params=sparams,
+                                       extra_reduce=mean_dims)
       hit = grp.reduce(self.reduce_dims, w_da, bin_dims, use_mask=use_mask, skipna=skipna, ens_params=ens_params,
                        extra_reduce=mean_dims)
       grp.cache[key] = hit

@@ -8,7 +8,8 @@ namespace wbx {
 
 // aidm[bk][br][x] = mask(bk, br, x) ? aid[bk][br][x] : 255, for a mask that does not depend on A or the depth dims (the caller
 // says so: WBX_BINNED_MASK_ON_W): addressed through the plan's tables at A = 0, depth row 0.
-static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedArgs g, uint8_t* __restrict__ aidm) {
+// twin: masked-out points keep their atom as its TWIN (id | 0x80) instead of 255 (ens_atoms_kernel's twin mode).
+static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedArgs g, uint8_t* __restrict__ aidm, int twin) {
   const int64_t row = blockIdx.x;  // (bk, br)
   const int64_t bk = row / g.nBr, br = row - bk * g.nBr;
   const int64_t key = bk * g.nBr + br;  // A = 0
@@ -16,12 +17,12 @@ static __global__ void __launch_bounds__(256) aid_merge_kernel(S1Args a, BinnedA
   const uint8_t* m = reinterpret_cast<const uint8_t*>(a.in[3]) + base;
   for (int64_t x = threadIdx.x; x < g.nj; x += blockDim.x) {
     const int64_t i = row * g.nj + x;
-    aidm[i] = m[x * a.xstride[3]] != 0 ? g.aid[i] : (uint8_t)255;
+    aidm[i] = m[x * a.xstride[3]] != 0 ? g.aid[i] : (twin ? (uint8_t)(g.aid[i] | 0x80) : (uint8_t)255);
   }
 }
 
 // Launches the merge into the context's scratch (grown on demand) and points g.aidm at it.
-inline int merge_mask_into_atom_ids(wbx_ctx* ctx, const S1Args& a, BinnedArgs& g) {
+inline int merge_mask_into_atom_ids(wbx_ctx* ctx, const S1Args& a, BinnedArgs& g, bool twin = false) {
   const size_t need = (size_t)(g.nBk * g.nBr * g.nj);
   if (ctx->aidm_scratch_size < need) {
     if (ctx->aidm_scratch) {
@@ -34,7 +35,7 @@ inline int merge_mask_into_atom_ids(wbx_ctx* ctx, const S1Args& a, BinnedArgs& g
     ctx->aidm_scratch_size = need;
   }
   hipLaunchKernelGGL(aid_merge_kernel, dim3((unsigned)(g.nBk * g.nBr)), dim3(256), 0, ctx->stream, a, g,
-                     reinterpret_cast<uint8_t*>(ctx->aidm_scratch));
+                     reinterpret_cast<uint8_t*>(ctx->aidm_scratch), twin ? 1 : 0);
   WBX_HIP(hipGetLastError());
   g.aidm = reinterpret_cast<const uint8_t*>(ctx->aidm_scratch);
   return 0;

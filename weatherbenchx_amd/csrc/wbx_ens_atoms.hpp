@@ -36,7 +36,9 @@
 namespace wbx {
 
 constexpr int ENS_ATOMS_NQ = 5;    // accumulated per atom: skill, spread, variance, squared error of the mean, count
-constexpr int ENS_ATOMS_NOUT = 6;  // written per (patch, bin): the five ensemble lanes + the count lane
+constexpr int ENS_ATOMS_NOUT = 6;  // written per (cell, bin): the five ensemble lanes + the count lane ...
+constexpr int ENS_ATOMS_NOUT2 = 12;  // ... and, in twin mode, the same six again over ALL points (mask ignored)
+constexpr int ENS_ATOMS_ROWS2 = 2 * ATOM_MAX;  // table rows per patch: an atom and its twin (the masked-out points of the atom)
 
 #ifndef WBX_EA_KNOCK
 #define WBX_EA_KNOCK 0  // diagnostic builds only (make ab-eak1 / ab-eak2)
@@ -68,7 +70,7 @@ static __constant__ double wbx_one_f64[1] = {1.0};
 // ("last" = an atomic counter per set, reset by the wave that sees it full; every sum runs in index order, so the result does
 // not depend on who does it: deterministic, and no atomics on any VALUE).  As separate kernels behind the sweep the same sums
 // cost two launches, two dependency gaps and a 14 MB round trip of per-patch bin tables: 0.48 ms per call around a 0.35 ms kernel.
-constexpr int ENS_ATOMS_G1 = 8;    // patches per level-1 group (their tables fit the idle staging buffer: 8 x 1536 B)
+constexpr int ENS_ATOMS_G1 = 4;    // patches per level-1 group (their tables fit the idle staging buffer: 4 x (2560 + 256) B)
 constexpr int ENS_ATOMS_G2 = 16;   // level-1 records per level-2 group
 
 // What one wave publishes for another (atom tables, flags, records) is written and read with device-scope relaxed atomics:
@@ -102,7 +104,10 @@ struct EnsAtomsArgs {
   uint32_t* counters;  // [cell][ng1] | [cell][ng2] | [cell], zero before the first launch and after every launch
   double* out;         // [cell][NOUT][nbin]
   int32_t ng1, ng2;
-  int32_t masked;      // the atom ids are g.aidm (255 = masked out)
+  int32_t masked;      // 0: no mask; 1: the atom ids are g.aidm, 255 = masked out; 2 (twin): g.aidm, id | 0x80 = masked out -- such
+                       // points are accumulated under the atom's TWIN, so that one launch yields the masked sums (atoms only) AND
+                       // the unmasked ones (atoms + twins): the reference masks skill / unbiased MSE / mean MSE of a variable
+                       // whose targets carry a mask but not its spread / variance (statistics of the predictions alone)
   int64_t br_per_split;  // g.rows_per_split / D
   unsigned long long* prof;  // diagnostic builds (WBX_EA_PROF): eight time stamps per patch, else NULL
 };
@@ -140,7 +145,9 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   const int64_t patch = (int64_t)rs * g.nxt + xt;
   const int nw = g.nwords[bk * npatch + patch];
   WBX_EA_STAMP(0);
-  double* const tab = e.tab + (cell * npatch + patch) * (ATOM_MAX * NQ);
+  constexpr int TR = ENS_ATOMS_ROWS2;  // table rows per patch (the twin half is only touched in twin mode)
+  const bool twin = e.masked == 2;
+  double* const tab = e.tab + (cell * npatch + patch) * (TR * NQ);
   // nw < 0: more than ATOM_MAX distinct membership words in one patch (arbitrary user masks).  This kernel has no slot
   // fallback: the host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller
   // that did not gets NaN in every bin of the cell instead of silently wrong sums.
@@ -162,11 +169,14 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   double acc0[NQ], acc1[NQ];
 #pragma unroll
   for (int l = 0; l < NQ; ++l) acc0[l] = acc1[l] = 0.0;
-  uint32_t touched = 0u;  // atoms whose table row has been written (wave-uniform): the first flush of an atom stores
+  unsigned long long touched = 0ull;  // table rows that have been written (wave-uniform): the first flush of a row stores
   // ... and the rows no flush ever writes must read as zeros for the wave that sums the group: lane l < NQ clears its column
   // (the lane that writes it later: same lane, same address, in order), fire and forget
   if (lane < NQ)
-    for (int k = 0; k < nw; ++k) st_dev(tab + k * NQ + lane, 0.0);
+    for (int k = 0; k < nw; ++k) {
+      st_dev(tab + k * NQ + lane, 0.0);
+      if (twin) st_dev(tab + (ATOM_MAX + k) * NQ + lane, 0.0);
+    }
 
   // Flush BOTH sets of EVERY lane into the patch's table and empty them: lanes grouped by atom id, one DPP wave sum per
   // (group, statistic); lane l < NQ owns column l of the table (the only lane that ever reads or writes it).
@@ -185,11 +195,12 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
           const double sum = wave_sum_uniform(sel ? (s ? acc1[l] : acc0[l]) : 0.0);
           if (lane == l) mine = sum;
         }
+        const int row = (gid & (ATOM_MAX - 1)) + ((gid >> 7) ? ATOM_MAX : 0);  // ids 128 + k are the twins
         if (lane < NQ) {
-          double* q = tab + gid * NQ + lane;
-          st_dev(q, ((touched >> gid) & 1u) ? ld_dev(q) + mine : mine);
+          double* q = tab + row * NQ + lane;
+          st_dev(q, ((touched >> row) & 1ull) ? ld_dev(q) + mine : mine);
         }
-        touched |= 1u << gid;
+        touched |= 1ull << row;
         todo &= ~__builtin_amdgcn_ballot_w64(sel);
       }
     }
@@ -353,7 +364,9 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
 
   // ---- the patch is done: publish its table, then the sums over patches (see EnsAtomsArgs).  A record is [NOUT][64]: lane =
   // bin, so every lane of the wave adds the same six statistics and only the membership factor differs.
-  constexpr int NP = NOUT * 64;
+  constexpr int NOUT2 = ENS_ATOMS_NOUT2;
+  const int nout = twin ? NOUT2 : NOUT;
+  const int NP = nout * 64;
   // -> true for the wave that completes the set (exactly one): everything the others wrote before their arrival is visible to it
   auto last_of = [&](uint32_t* counter, uint32_t total) -> bool {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's table / record has arrived where every XCD sees it
@@ -366,19 +379,21 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   };
   // sum of n consecutive records at src (index order); sc1 BUFFER loads: the compiler keeps a batch of them in flight, where
   // it waits for every atomic load on its own (16 records = 96 loads one after the other took 18 us of the kernel's tail)
-  auto add_records = [&](const double* src, int n, double (&sum)[NOUT]) {
+  auto add_records = [&](const double* src, int n, double (&sum)[NOUT2]) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int l = 0; l < NOUT; ++l) sum[l] = 0.0;
-#pragma unroll 8
+    for (int l = 0; l < NOUT2; ++l) sum[l] = 0.0;
+#pragma unroll 4
     for (int q = 0; q < n; ++q) {
 #pragma unroll
-      for (int l = 0; l < NOUT; ++l) sum[l] += ld_sc1(rs, (uint32_t)((q * NP + l * 64 + lane) * 8));
+      for (int l = 0; l < NOUT2; ++l)
+        if (l < NOUT || twin) sum[l] += ld_sc1(rs, (uint32_t)((q * NP + l * 64 + lane) * 8));
     }
   };
-  auto put_record = [&](double* dst, const double (&sum)[NOUT]) {
+  auto put_record = [&](double* dst, const double (&sum)[NOUT2]) {
 #pragma unroll
-    for (int l = 0; l < NOUT; ++l) st_dev(dst + l * 64 + lane, sum[l]);
+    for (int l = 0; l < NOUT2; ++l)
+      if (l < NOUT || twin) st_dev(dst + l * 64 + lane, sum[l]);
   };
 
   const int g1 = (int)(patch / ENS_ATOMS_G1);
@@ -390,26 +405,26 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   if (!last1) return;
 
   // ---- level 1: atoms -> bins for the gn patches of the group.  Their tables and membership words go through the idle
-  // staging buffer: ltab[p][k][l], wl[p][k]; every load of the group is asked for before any of them is used.
+  // staging buffer: ltab[p][row][l], wl[p][k]; every load of the group is asked for before any of them is used.
   double* const ltab = reinterpret_cast<double*>(lds_raw);
-  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lds_raw + ENS_ATOMS_G1 * ATOM_MAX * NQ * sizeof(double));
+  unsigned long long* const wl = reinterpret_cast<unsigned long long*>(lds_raw + ENS_ATOMS_G1 * TR * NQ * sizeof(double));
   int nwv[ENS_ATOMS_G1];
 #pragma unroll
   for (int p = 0; p < ENS_ATOMS_G1; ++p) nwv[p] = p < gn ? ((const_ptr<int32_t>)g.nwords)[bk * npatch + k0 + p] : 0;
   bool overflowed = false;
   {
-    constexpr int NJ = (ATOM_MAX * NQ + 63) / 64;
+    constexpr int NJ = (TR * NQ + 63) / 64;
     double v[ENS_ATOMS_G1][NJ];
     unsigned long long wv[ENS_ATOMS_G1];
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(e.tab + (cell * npatch + k0) * (ATOM_MAX * NQ), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.tab + (cell * npatch + k0) * (TR * NQ), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int p = 0; p < ENS_ATOMS_G1; ++p) {
       overflowed = overflowed || nwv[p] < 0;
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int i = lane + 64 * jj;  // (rows past the patch's atoms -- never cleared -- are not used below)
-        v[p][jj] = ld_sc1(rs, (uint32_t)((p * (ATOM_MAX * NQ) + (i < ATOM_MAX * NQ && p < gn ? i : 0)) * 8));
+        const bool mine = i < TR * NQ && p < gn && (twin || i < ATOM_MAX * NQ);
+        v[p][jj] = ld_sc1(rs, (uint32_t)((p * (TR * NQ) + (mine ? i : 0)) * 8));
       }
       wv[p] = (p < gn && lane < ATOM_MAX) ? g.words[(bk * npatch + k0 + p) * ATOM_MAX + lane] : 0ull;
     }
@@ -418,35 +433,45 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
     for (int p = 0; p < ENS_ATOMS_G1; ++p) {
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj)
-        if (lane + 64 * jj < ATOM_MAX * NQ) ltab[p * (ATOM_MAX * NQ) + lane + 64 * jj] = v[p][jj];
+        if (lane + 64 * jj < TR * NQ) ltab[p * (TR * NQ) + lane + 64 * jj] = v[p][jj];
       if (lane < ATOM_MAX) wl[p * ATOM_MAX + lane] = wv[p];
     }
     __syncthreads();
   }
   const double inv_m = 1.0 / (double)M;
-  double sum[NOUT];
+  double sum[NOUT2];
 #pragma unroll
-  for (int l = 0; l < NOUT; ++l) sum[l] = 0.0;
+  for (int l = 0; l < NOUT2; ++l) sum[l] = 0.0;
 #pragma unroll
   for (int p = 0; p < ENS_ATOMS_G1; ++p) {
     for (int k = 0; k < nwv[p]; ++k) {
-      const double* row = ltab + (p * ATOM_MAX + k) * NQ;
+      const double* row = ltab + (p * TR + k) * NQ;
       // membership of the lane's bin as 0.0 / 1.0: NaN * 0 = NaN, so a non-finite sum reaches every bin of its statistic
       // like in the reference's xr.dot (aggregation.py:272-277)
       const double f = ((wl[p * ATOM_MAX + k] >> lane) & 1ull) ? 1.0 : 0.0;
       // output lanes: 0 skill, 1 spread, 2 variance, 3 = (4) - (2) / M, 4 squared error of the mean, 5 count
-      const double t0 = row[0], t1 = row[1], t2 = row[2], t4 = row[3], t5 = row[4];
+      double t0 = row[0], t1 = row[1], t2 = row[2], t4 = row[3], t5 = row[4];
       sum[0] = fma(t0, f, sum[0]);
       sum[1] = fma(t1, f, sum[1]);
       sum[2] = fma(t2, f, sum[2]);
       sum[3] = fma(t4 - t2 * inv_m, f, sum[3]);
       sum[4] = fma(t4, f, sum[4]);
       sum[5] = fma(t5, f, sum[5]);
+      if (twin) {  // the same over ALL points of the atom: its own rows + those of its twin (what the mask left out)
+        const double* rt = row + ATOM_MAX * NQ;
+        t0 += rt[0], t1 += rt[1], t2 += rt[2], t4 += rt[3], t5 += rt[4];
+        sum[6] = fma(t0, f, sum[6]);
+        sum[7] = fma(t1, f, sum[7]);
+        sum[8] = fma(t2, f, sum[8]);
+        sum[9] = fma(t4 - t2 * inv_m, f, sum[9]);
+        sum[10] = fma(t4, f, sum[10]);
+        sum[11] = fma(t5, f, sum[11]);
+      }
     }
   }
   if (overflowed) {
 #pragma unroll
-    for (int l = 0; l < NOUT; ++l) sum[l] = __builtin_nan("");
+    for (int l = 0; l < NOUT2; ++l) sum[l] = __builtin_nan("");
   }
   put_record(e.part1 + (cell * e.ng1 + g1) * NP, sum);
   WBX_EA_STAMP(4);
@@ -469,7 +494,8 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   add_records(e.part2 + cell * e.ng2 * NP, e.ng2, sum);
   if (lane < g.nbin) {
 #pragma unroll
-    for (int l = 0; l < NOUT; ++l) e.out[(cell * NOUT + l) * g.nbin + lane] = sum[l];
+    for (int l = 0; l < NOUT2; ++l)
+      if (l < nout) e.out[(cell * nout + l) * g.nbin + lane] = sum[l];
   }
   WBX_EA_STAMP(7);
 }
@@ -482,7 +508,7 @@ struct EnsBinnedCall {
   int64_t nA, nBk, nBr, nj;
   int32_t nbin, w_on_x;
   const void* prepared;  // atom tables of wbx_ens_binned_atoms, or NULL (computed inside the call)
-  double* out;           // [nA][nBk][ENS_ATOMS_NOUT][nbin]
+  double* out;           // [nA][nBk][ENS_ATOMS_NOUT (twin mode: NOUT2)][nbin]
 };
 
 inline int64_t ens_atoms_rows() {
@@ -518,8 +544,9 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows());
   const int64_t npatch = (int64_t)probe.nrs * probe.nxt;
   const int ng1 = (int)((npatch + ENS_ATOMS_G1 - 1) / ENS_ATOMS_G1), ng2 = (ng1 + ENS_ATOMS_G2 - 1) / ENS_ATOMS_G2;
-  const size_t NP = (size_t)ENS_ATOMS_NOUT * 64;
-  const size_t n_tab = (size_t)probe.nblocks * ATOM_MAX * ENS_ATOMS_NQ, n_p1 = (size_t)cells * ng1 * NP, n_p2 = (size_t)cells * ng2 * NP;
+  const bool twin = (plan->flags & WBX_FLAG_MASKED) && (c.w_on_x & WBX_BINNED_TWIN_MASK);
+  const size_t NP = (size_t)(twin ? ENS_ATOMS_NOUT2 : ENS_ATOMS_NOUT) * 64;
+  const size_t n_tab = (size_t)probe.nblocks * ENS_ATOMS_ROWS2 * ENS_ATOMS_NQ, n_p1 = (size_t)cells * ng1 * NP, n_p2 = (size_t)cells * ng2 * NP;
   // (nacc = 0: no per-patch bin tables -- the sums over patches happen inside the kernel)
   if (int rc = patch_setup(ctx, g, nullptr, c.bits, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, 0, c.nbin, true, c.prepared,
                            true, ens_atoms_rows(), n_tab + n_p1 + n_p2, &extra))
@@ -537,8 +564,8 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   e.masked = 0;
   e.br_per_split = g.rows_per_split / plan->ndepth;
   if (plan->flags & WBX_FLAG_MASKED) {
-    if (int rc = merge_mask_into_atom_ids(ctx, a, g)) return rc;
-    e.masked = 1;
+    if (int rc = merge_mask_into_atom_ids(ctx, a, g, twin)) return rc;
+    e.masked = twin ? 2 : 1;
   }
   static const int nt_env = getenv("WBX_ENS_ATOMS_NT") ? atoi(getenv("WBX_ENS_ATOMS_NT")) : -1;
   static const int order_env = getenv("WBX_PATCH_ORDER") ? atoi(getenv("WBX_PATCH_ORDER")) : -1;

@@ -1051,6 +1051,11 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
 # skipna.  False: the two-stage route (x-kept ensemble kernel + wbx_contract_bits), for A/B timing and tests.
 ENS_BINNED = os.environ.get('WBX_ENS_BINNED', '1') != '0'
 ENS_BINNED_LANES = 6  # the five ensemble lanes + the count lane, always
+# With a mask, ONE launch yields the masked sums (lanes 0-5) and the sums over all points (lanes 6-11): the reference masks the
+# skill / unbiased-MSE / mean-MSE statistics of such a variable but not its spread / variance (statistics of the predictions
+# alone), which would otherwise be a second pass over the members.  The unmasked half is left with the predictions array
+# ('_wbx_twin') for the member-only group of the same predictions to pick up.  False: one launch per mask setting (A/B, tests).
+ENS_TWIN_MASK = os.environ.get('WBX_ENS_TWIN_MASK', '1') != '0'
 
 
 def _mask_on_w_only(plan: planner.S1Plan, mask_dev) -> bool:
@@ -1069,6 +1074,8 @@ def _ens_binned_flags(plan: planner.S1Plan, w_buf, devs):
     if not (w_flags & _hip.BINNED_W_ON_X) or not _mask_on_w_only(plan, devs[3]):
       return None
     w_flags |= _hip.BINNED_MASK_ON_W
+    if ENS_TWIN_MASK:
+      w_flags |= _hip.BINNED_TWIN_MASK
   return w_flags
 
 
@@ -1112,13 +1119,35 @@ def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype
   return w_flags, atoms
 
 
+def _twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens):
+  return (tuple(dims), tuple(sizes[d] for d in dims), tuple(sorted(reduce_dims, key=str)), id(w_da), tuple(bin_dims),
+          ens['member_dim'], ens['M'], ens['algo'], bool(ens.get('fair', True)))
+
+
+def _twin_store(p_da, ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, result):
+  p_da.__dict__.setdefault('_wbx_twin', {})[_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens)] = (result, ctx, w_da)
+
+
+def _twin_lookup(p_da, dims, sizes, reduce_dims, w_da, bin_dims, ens):
+  """The unmasked half of a twin launch over these very predictions (same frame, reduction, weights / bins object and ensemble
+  parameters), or None.  Only the statistics of the predictions ALONE are served from it (spread, variance: their group's
+  companion target is a member of the predictions, lazy.ens_statistic(member_only=True)) -- the caller's lane picks them."""
+  hit = p_da.__dict__.get('_wbx_twin', {}).get(_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens))
+  if hit is None:
+    return None
+  result, ctx, _ = hit
+  if _deferred is not None:  # the reader's fence has to cover the launch that produced it
+    _deferred.ctxs[id(ctx)] = ctx
+  return result
+
+
 def _run_ens_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_code: int, ens_args, w_buf, route):
   """wbx_ens_binned -> (device pointer, shape) of out[nA][nBk][6][1][nbin]: lanes 0-4 the ensemble family, lane 5 the sum of
   the weights of the valid points (the count lane)."""
   w_flags, atoms = route
   nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
   nbin = w_buf.shape[-1]
-  shape = (nA, nBk, ENS_BINNED_LANES, 1, nbin)
+  shape = (nA, nBk, ENS_BINNED_LANES * (2 if (w_flags & _hip.BINNED_TWIN_MASK) else 1), 1, nbin)
   out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   m, mstride, algo = ens_args
@@ -1165,6 +1194,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   under a mask alone, else a data-independent constant broadcast to all.
   """
   global _deferred
+  if kind == 'ens' and mask is None and not skipna and inputs[0] is not None:
+    twin = _twin_lookup(inputs[0], dims, sizes, reduce_dims, w_da, bin_dims, ens)
+    if twin is not None:
+      return twin
   ctx = ctx or _launch_context(kind)
   wdep = set(w_da.dims) - set(bin_dims) if w_da is not None else set()
   member_dim = ens['member_dim'] if ens else (cat.get('member_dim') if cat else None)
@@ -1260,6 +1293,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
       raise RuntimeError('internal: lane view of a reduction result was copied')
     return v
 
+  if ens_route is not None and (ens_route[0] & _hip.BINNED_TWIN_MASK):
+    # lanes 6-11: the same statistics over ALL points, for the statistics of these predictions that carry no mask
+    _twin_store(inputs[0], ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, (lanes_of(ENS_BINNED_LANES, nl),
+                np.broadcast_to(lanes_of(2 * ENS_BINNED_LANES - 1, 1), lanes_of(0, nl).shape), out_dims))
   values = lanes_of(0, nl)
   if counted:
     counts = np.broadcast_to(lanes_of(nl, 1), values.shape) if shared_count else lanes_of(nl, nl)
