@@ -798,9 +798,10 @@ def configs3_composite(env, nlead, nlev):
          'check': {'rmse_mean': float(np.asarray(dvals['rmse.z'].values).mean()),
                    'sum_k_S_k': float(np.asarray(svals['spectrum_p.z'].values)[0, 0].sum()), 'expected': 280.0 ** 2 + 1.0}}
   if fused:
-    out['roofline'] = kernel_roofline('zspec1440_det_kernel<true> (spectra of p and t + DET6 lanes, one sweep; + 2 x 5 us memsets)',
+    kname = 'zspec1440_det_latfast_kernel' if fused[0].get('slab_rows') else 'zspec1440_det_kernel'
+    out['roofline'] = kernel_roofline(kname + '<true> (spectra of p and t + DET6 lanes, one sweep; + 2 x 5 us memsets)',
                                       float(np.median([e['ms'] for e in fused])), points * 12,
-                                      pmc_traffic('zspec1440_det_kernel', not args.small, f'spectrum@{env.layout}'))
+                                      pmc_traffic(kname, not args.small, f'spectrum@{env.layout}'))
   del pool
   return out
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 9
+#define WBX_ABI_VERSION 10
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -425,6 +425,17 @@ int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_strid
 int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3 | WBX_DET6 */, int dtype /* WBX_F32 */,
                      const void* p, const void* t, const void* c, const int32_t* group, const double* scale, int64_t ngroup,
                      double* partial_out, double* power_p, double* power_t);
+
+/* The same for LATITUDE-FASTEST fields (the layout of the public ERA5 / WeatherBench archives, [.., longitude, latitude];
+ * weatherbenchX/data_loaders/xarray_loaders.py:185-188 hands such chunks on as they are stored): `plan` is the deterministic
+ * plan of (p, t[, c]) with x = longitude (nx = 1440, summed, ndepth = 1, nchunk = 1, no mask) whose keys are nkey /
+ * rows_per_slab slabs of `rows_per_slab` rows each: key o * rows_per_slab + r is row r of slab o, and the rows of a slab are
+ * ADJACENT elements of every input (row r + 1 = row r + 1 element; plan->xstride[i] = the longitude stride of input i,
+ * >= rows_per_slab).  Outputs and accuracy as wbx_det_spectrum; the deterministic sums of a row are formed in a fixed order
+ * (no atomics). */
+int wbx_det_spectrum_slabs(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3 | WBX_DET6 */, int dtype /* WBX_F32 */,
+                           const void* p, const void* t, const void* c, int64_t rows_per_slab, const int32_t* group,
+                           const double* scale, int64_t ngroup, double* partial_out, double* power_p, double* power_t);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,8 @@ def bench_key(name: str) -> str:
     return 'ens_pipe_kernel'
   if n.startswith('s1_xf1_kernel<EnsOpF32<51'):
     return 's1_xf1_kernel'
+  if n.startswith('zspec1440_det_latfast_kernel'):
+    return 'zspec1440_det_latfast_kernel'
   if n.startswith('zspec1440_det_kernel'):
     return 'zspec1440_det_kernel'
   n = re.sub(r'DetOp<float, 1, \d>', 'DetOp<float,DET6>', n)

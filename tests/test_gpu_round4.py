@@ -408,3 +408,140 @@ def test_crps_ensemble_with_few_points_per_output_cell(ctx):
   crps = got['CRPSSkill'] - 0.5 * got['CRPSSpread']
   np.testing.assert_allclose(crps, want, rtol=RTOL)
   assert np.abs(crps / want - 1).max() < 5e-7
+
+
+# ---- spectra + deterministic lanes in one sweep over LATITUDE-FASTEST fields (wbx_det_spectrum_slabs) ------------------------
+@pytest.mark.parametrize('func,nlat', [('DET6', 37), ('DET3', 37), ('DET6', 8), ('DET6', 721)])
+def test_det_spectrum_slabs_entry_point_against_the_oracle(ctx, func, nlat):
+  """wbx_det_spectrum_slabs with raw pointers on [.., longitude, latitude] fields (the archives' layout,
+  data_loaders/xarray_loaders.py:185-188): the plan's x is the STRIDED longitude, a slab = the `nlat` adjacent rows of one
+  (lead, level); 37 rows = runs of 8 + a short one with a lone last row, 8 rows = one run, 721 = the real grid.  The partial
+  buffer against wbx_det_partial on the same plan and against the float64 oracle, both spectra against numpy.fft within
+  the transform's bound; the climatology through a gather table (another slot per lead)."""
+  from test_spectra import bound_1440
+  rng = np.random.default_rng(5)
+  nlead, nlev, nlon = (3, 2, 1440) if nlat < 721 else (2, 1, 1440)
+  dims = ('init_time', 'lead_time', 'level', 'longitude', 'latitude')
+  shape = (1, nlead, nlev, nlon, nlat)
+  pv = (rng.normal(size=shape) * 3 + 280).astype(np.float32)
+  tv = (rng.normal(size=shape) * 3 + 280).astype(np.float32)
+  nslot = 5
+  cv = (rng.normal(size=(nslot, nlev, nlon, nlat)) * 10 + 280).astype(np.float32)
+  slot_of_lead = np.array([4, 0, 2])[:nlead]
+  p, t = xr.DataArray(pv, dims=dims), xr.DataArray(tv, dims=dims)
+  c = xr.DataArray(cv, dims=('slot', 'level', 'longitude', 'latitude'))
+  devs = [engine._to_device(ctx, a, _hip.F32) for a in (p, t, c)] + [None]
+  lays = [d.layout for d in devs[:3]] + [None]
+  sizes = dict(zip(dims, shape))
+  table = (slot_of_lead * devs[2].layout.stride('slot')).reshape(1, nlead).astype(np.int64)
+  gather = planner.GatherSpec(dims=('init_time', 'lead_time'), table=table) if func == 'DET6' else None
+  if func == 'DET3':
+    lays[2] = None
+  plan = planner.build_s1_plan(dims, sizes, lays, ['init_time', 'latitude', 'longitude'], wdep_dims=['latitude'], gather=gather,
+                               force_x_dim='longitude', allow_vec4=False)
+  assert plan.ndepth == 1 and plan.nchunk == 1 and plan.nkey == nlead * nlev * nlat and plan.key_dims == ('lead_time', 'level', 'latitude')
+  assert plan.xstride[0] == nlat and not plan.x_kept
+  dplan = engine._device_plan(ctx, plan)
+  code = getattr(_hip, func)
+  nl = _hip.DET_LANES[code]
+  nrows, ngroup, nk = plan.nkey, nlead * nlev, nlon // 2 + 1
+  w = np.cos(np.deg2rad(np.linspace(-88, 88, nlat)))
+  group = np.repeat(np.arange(ngroup, dtype=np.int32), nlat)
+  scale = np.tile(w, ngroup)
+  g_dev, s_dev = ctx.upload(group), ctx.upload(scale)
+  part_a, part_b = ctx.alloc(nrows * nl * 8), ctx.alloc(nrows * nl * 8)
+  pw_p, pw_t = ctx.alloc(ngroup * nk * 8), ctx.alloc(ngroup * nk * 8)
+  ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
+  cdev = devs[2] if func == 'DET6' else None
+  _hip.check(ctx.lib.wbx_det_partial(ctx.handle, C.byref(dplan.struct), code, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev), None,
+                                     ptr(part_a)), 'wbx_det_partial')
+  for _ in range(2):  # (twice: the second launch must not see anything of the first)
+    _hip.check(ctx.lib.wbx_det_spectrum_slabs(ctx.handle, C.byref(dplan.struct), code, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
+                                              nlat, ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)),
+               'wbx_det_spectrum_slabs')
+  ctx.synchronize()
+  a = ctx.download(part_a.ptr, (nrows, nl)).copy()
+  b = ctx.download(part_b.ptr, (nrows, nl)).copy()
+  np.testing.assert_allclose(b, a, rtol=1e-13, atol=1e-9)
+  p64, t64 = np.swapaxes(pv.astype(np.float64)[0], -1, -2), np.swapaxes(tv.astype(np.float64)[0], -1, -2)  # [lead, level, lat, lon]
+  c64 = np.swapaxes(cv.astype(np.float64)[slot_of_lead], -1, -2)
+  want = [O.error(p64, t64), O.absolute_error(p64, t64), O.squared_error(p64, t64)]
+  if func == 'DET6':
+    want += [O.squared_prediction_anomaly(p64, c64), O.squared_target_anomaly(t64, c64), O.anomaly_covariance(p64, t64, c64)]
+  for lane, wv in enumerate(want):
+    np.testing.assert_allclose(b[:, lane], wv.sum(axis=-1).reshape(-1), rtol=1e-11, atol=1e-6, err_msg=f'lane {lane}')
+  for buf, f64 in ((pw_p, p64), (pw_t, t64)):
+    got = ctx.download(buf.ptr, (ngroup, nk)).copy()
+    ref = (O.zonal_power_spectrum(f64) * w[None, None, :, None]).sum(axis=2).reshape(ngroup, nk)
+    assert np.all(np.abs(got - ref) <= bound_1440(ref))
+  # misuse is refused, not mis-run: a slab length that does not divide the keys, a statistic family without spectra
+  assert ctx.lib.wbx_det_spectrum_slabs(ctx.handle, C.byref(dplan.struct), code, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
+                                        nlat + 1, ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)) == -1
+  assert ctx.lib.wbx_det_spectrum_slabs(ctx.handle, C.byref(dplan.struct), _hip.PASS1, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(cdev),
+                                        nlat, ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw_p), ptr(pw_t)) == -1
+
+
+def test_latitude_fastest_chunks_fuse_spectra_into_the_deterministic_sweep(ctx, monkeypatch):
+  """The chunk loop on latitude-fastest arrays with engine.FUSE_DET_SPECTRA_LATFAST: RMSE / ACC / MAE per (lead, level) under
+  the area aggregator and the zonal spectra of predictions and targets under another -- ONE launch per chunk (det_spectrum
+  with slab_rows = nlat), results equal
+  to the separate launches (deterministic: same fp64 formulas, other summation order; spectra: same transform) and to the
+  same data stored longitude-fastest."""
+  from weatherbenchx_amd import pipeline, spectra, time_chunks
+  from weatherbenchx_amd.metrics import deterministic
+  rng = np.random.default_rng(18)
+  nlat, nlon, ninit, nlead, nlev = 27, 1440, 3, 2, 3
+  lat, lon = np.linspace(-84, 84, nlat), np.arange(nlon) * 0.25
+  init_times = np.datetime64('2021-06-01T00', 'ns') + np.arange(ninit) * np.timedelta64(24, 'h')
+  lead_time = (np.arange(nlead) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')
+  level = np.array([500, 700, 850])
+  pv = (rng.normal(size=(ninit, nlead, nlev, nlon, nlat)) * 2 + 270).astype(np.float32)
+  tv = (rng.normal(size=(ninit, nlead, nlev, nlon, nlat)) * 2 + 270).astype(np.float32)
+  cvals = (rng.normal(size=(8, 2, nlev, nlon, nlat)) * 5 + 270).astype(np.float32)
+
+  def clim_of(latfast):
+    dims = ('dayofyear', 'hour', 'level') + (('longitude', 'latitude') if latfast else ('latitude', 'longitude'))
+    vals = cvals if latfast else np.ascontiguousarray(np.swapaxes(cvals, -1, -2))
+    return xr.Dataset({'z': xr.DataArray(vals, dims=dims, coords={'dayofyear': np.arange(152, 160), 'hour': np.array([0, 12]),
+                                                                 'level': level, 'latitude': lat, 'longitude': lon})})
+
+  def loader(latfast):
+    def load(inits, leads):
+      i = [int(np.where(init_times == x)[0][0]) for x in inits]
+      cs = {'init_time': inits, 'lead_time': lead_time, 'level': level, 'latitude': lat, 'longitude': lon}
+      dims = ('init_time', 'lead_time', 'level') + (('longitude', 'latitude') if latfast else ('latitude', 'longitude'))
+      a, b = (pv[i], tv[i]) if latfast else (np.ascontiguousarray(np.swapaxes(pv[i], -1, -2)), np.ascontiguousarray(np.swapaxes(tv[i], -1, -2)))
+      return {'z': xr.DataArray(a, dims=dims, coords=cs)}, {'z': xr.DataArray(b, dims=dims, coords=cs)}
+    return load
+  spec = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalPowerSpectrum('targets')}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+
+  def run(latfast, fuse):
+    det = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC(clim_of(latfast)), 'mae': deterministic.MAE()}
+    monkeypatch.setattr(engine, 'FUSE_DET_SPECTRA', fuse)
+    monkeypatch.setattr(engine, 'FUSE_DET_SPECTRA_LATFAST', fuse)  # (opt-in: measured slower than the launches it replaces)
+    engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 1
+    try:
+      load = loader(latfast)
+      out = pipeline.evaluate_passes(times, [('det', load, det, area), ('spec', load, spec, zonal)])
+      log = list(engine.S1_EVENT_LOG)
+    finally:
+      engine.S1_EVENT_LOG = None
+    return out['det'][None].metric_values(det), out['spec'][None].metric_values(spec), log
+  d1, s1, l1 = run(True, True)
+  d0, s0, l0 = run(True, False)
+  d2, s2, l2 = run(False, True)
+  k1, k0 = [e['kind'] for e in l1], [e['kind'] for e in l0]
+  assert k1.count('det_spectrum') == ninit and 'spectrum' not in k1 and 'det' not in k1, k1
+  assert all(e['slab_rows'] == nlat for e in l1 if e['kind'] == 'det_spectrum')
+  assert all(e.get('slab_rows', 0) == 0 for e in l2 if e['kind'] == 'det_spectrum')
+  assert 'det_spectrum' not in k0 and k0.count('spectrum') == 2 * ninit
+  for k in d0:
+    np.testing.assert_allclose(d1[k].values, d0[k].values, rtol=1e-12, err_msg=k)
+    np.testing.assert_allclose(d1[k].values, d2[k].values, rtol=1e-12, err_msg=k)
+  for k in s0:
+    # (same transform; the mean shift is estimated from other samples of the row: fp32 rounding of another shifted row)
+    np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=2e-6, err_msg=k)
+    np.testing.assert_allclose(s1[k].values, s2[k].values, rtol=2e-6, err_msg=k)

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Counters of the latitude-fastest fused det + spectra kernel (zspec1440_det_latfast_kernel) on the configs[3] composite;
+# each pass is a separate, bounded rocprofv3 --pmc run (never combined with other trace domains).
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+OUT=$REPO/gpurun_out/pmc_zl
+rm -rf $OUT; mkdir -p $OUT
+export WBX_BENCH_COMPOSITE_RUNS=2
+run() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$PASS -o pmc --output-format csv -- python $REPO/bench.py --legs spectrum --no-cpu --no-config5 --steps 2 --warmup 1 --layout lat_fastest --prewarm-ms 0 > $OUT/$PASS.log 2>&1; }
+PASS=a run FETCH_SIZE
+PASS=d run TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE
+PASS=f run TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum
+if [ "$1" = full ]; then
+PASS=b run SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY
+PASS=c run SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY
+fi
+python - <<PY
+import csv, collections, glob
+for f in sorted(glob.glob('$OUT/*/*counter_collection.csv')):
+  agg = collections.defaultdict(lambda: collections.defaultdict(list))
+  for row in csv.DictReader(open(f)):
+    agg[row['Kernel_Name'][:48]][row['Counter_Name']].append(float(row['Counter_Value']))
+  for k, c in agg.items():
+    if 'zspec1440' in k:
+      print(f.split('/')[-3], k, {n: (len(v), round(sum(v) / len(v), 1)) for n, v in c.items()})
+for f in sorted(glob.glob('$OUT/a/*kernel_trace.csv')):
+  dur = collections.defaultdict(list)
+  for row in csv.DictReader(open(f)):
+    dur[row['Kernel_Name'][:60]].append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+  for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:6]:
+    v = sorted(v)
+    print('trace', k, 'n', len(v), 'avg_us', round(sum(v) / len(v), 1), 'median_us', round(v[len(v) // 2], 1))
+PY
+tail -2 $OUT/f.log

@@ -67,7 +67,9 @@ timeout 400 $B --steps 20 --warmup 5 --layout lat_fastest --no-cpu > $O/bench_n1
 for d in $O/trace_*; do cp $d/r1_kernel_stats.csv $O/$(basename $d)_kernel_stats.csv 2>/dev/null; done
 # 4. same-box A/B and ceilings: the ensemble kernel variants, the fused spectra + deterministic kernel, the read stream
 ( cd $R && python tools/kbench.py ens ) > $O/kbench_ens.txt 2>&1
-( cd $R && for layout in lon_fastest lat_fastest; do for v in default stats64; do if [ $v = default ]; then unset WBX_LIBRARY_PATH; else export WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_$v.so; fi; for pipe in 1 0; do echo "== $layout library $v WBX_ENS_PIPE=$pipe"; WBX_ENS_PIPE=$pipe python bench.py --legs main --no-cpu --no-config5 --steps 20 --warmup 5 --layout $layout 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('ms_per_step', round(r['ms_per_step'], 4), 'kernel', r['roofline']['kernel'].split(' (')[0], 'kernel_ms', r['roofline']['kernel_ms'], r['roofline']['kernel_ms_min_max'], 'frac', r['roofline']['frac'])"; done; done; done; unset WBX_LIBRARY_PATH ) > $O/ens_pipe_ab.txt 2>&1
+( cd $R && for layout in lon_fastest lat_fastest; do for v in default $( [ -f $R/weatherbenchx_amd/libwbx_hip_stats64.so ] && echo stats64 ); do if [ $v = default ]; then unset WBX_LIBRARY_PATH; else export WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_$v.so; fi; for pipe in 1 0; do echo "== $layout library $v WBX_ENS_PIPE=$pipe"; WBX_ENS_PIPE=$pipe python bench.py --legs main --no-cpu --no-config5 --steps 20 --warmup 5 --layout $layout 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('ms_per_step', round(r['ms_per_step'], 4), 'kernel', r['roofline']['kernel'].split(' (')[0], 'kernel_ms', r['roofline']['kernel_ms'], r['roofline']['kernel_ms_min_max'], 'frac', r['roofline']['frac'])"; done; done; done; unset WBX_LIBRARY_PATH ) > $O/ens_pipe_ab.txt 2>&1
+# (kernels these five exercise did not change since r03: WBX_ROUND_FULL=1 re-measures them, make ab-zdlds first)
+if [ "${WBX_ROUND_FULL:-0}" = 1 ]; then
 ( cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 flat_fetch.hip -o /tmp/flat_fetch 2>/dev/null && cd /tmp && for shift in 0 16; do /tmp/flat_fetch $shift; timeout 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_REQ_sum --kernel-trace -d $O/ff$shift -o r -- /tmp/flat_fetch $shift > /dev/null 2>&1; python -c "
 import sqlite3
 for k, c, n, v in sqlite3.connect('$O/ff$shift/r_results.db').execute(\"select substr(kernel_name, 1, 44), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%_kernel<%' group by 1, 2\"): print('   shift $shift', k, c, n, '%.0f' % v)"; done; rm -rf $O/ff0 $O/ff16 ) > $O/flat_fetch.txt 2>&1
@@ -75,13 +77,14 @@ for k, c, n, v in sqlite3.connect('$O/ff$shift/r_results.db').execute(\"select s
 ( cd $R && bash tools/gpu_r3_ragged_walk.sh ) > $O/ragged_walk.txt 2>&1
 ( cd $R && bash tools/gpu_r3_ragged_wpb.sh ) > $O/ragged_wpb.txt 2>&1
 ( cd $R && python tools/kbench_det_spectrum.py; echo "== climatology row through the LDS (make ab-zdlds)"; WBX_LIBRARY_PATH=$R/weatherbenchx_amd/libwbx_hip_zdlds.so python tools/kbench_det_spectrum.py ) > $O/kbench_det_spectrum.txt 2>&1
+fi
 ( cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 read_stream.hip -o read_stream 2>/dev/null; timeout 120 ./read_stream ) > $O/read_stream.json 2>&1
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
 ( cd $R && for s in "10 3" "20 5" "50 20" "200 50"; do set -- $s; python bench.py --legs main --no-cpu --no-config5 --steps $1 --warmup $2 --prewarm-ms 0 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('no prewarm, steps $1 warmup $2: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'])"; done; python bench.py --legs main --no-cpu --no-config5 --steps 20 --warmup 5 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('prewarm 150 ms, steps 20 warmup 5: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'], r['config']['prewarm'])" ) > $O/steady_state.txt 2>&1
 # 5. only the summaries travel back (gpurun merges at most 64 MiB): the raw rocprofv3 databases stay on the box
 python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r04} >> $O/make_round_files.log 2>&1
 mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r04}_* $R/gpurun_out/round/
-for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r04}_$f.txt; done
+for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do [ -f $O/$f.txt ] && cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r04}_$f.txt; done
 rm -rf $O/trace_* $O/pmc_fetch_* $O/pmc_write_* $R/gpurun_out/pmc_ens $R/gpurun_out/pmc_spec
 find $O -maxdepth 1 -type d -name "*" | sed -n 2,100p | xargs -r rm -rf
 du -sh $R/gpurun_out

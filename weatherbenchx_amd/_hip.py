@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = (
     'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy', 'wbx_ctx_wait_fence', 'wbx_memcpy_h2d_async',
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
-    'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
+    'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_det_spectrum_slabs', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
     'wbx_ens2_partial', 'wbx_cat_exceed_field',
 )
 
@@ -145,6 +145,7 @@ def load_library():
         'wbx_ens_map': [vp, C.POINTER(S1PlanStruct), i32, i32, i64, i32, i32, vp, vp, vp],
         'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
         'wbx_det_spectrum': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp],
+        'wbx_det_spectrum_slabs': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
         'wbx_zonal_spectrum_slabs': [vp, vp, i64, i64, i64, i64, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
     for name, argtypes in protos.items():

@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
 
 #include "wbx_zspec1440.hpp"
 #include "wbx_zspec_det.hpp"
+#include "wbx_zspec_det_latfast.hpp"
 
 // Diagnostic instantiations -- WBX_SPECTRUM_KNOCK: kernels whose RESULTS ARE WRONG by design (timing only);
 // WBX_SPECTRUM_PROF=<file>: the phase-stamped kernels, counters appended to a file -- exist only in a library built with
@@ -909,6 +910,78 @@ static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, 
   return 0;
 }
 
+// ---- the same for latitude-fastest fields (wbx_zspec_det_latfast.hpp) -------------------------------------------------------
+static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, bool has_c, const void* p, const void* t,
+                                   const void* c, int64_t rps, const int32_t* group, const double* scale, double* partial_out,
+                                   double* power_p, double* power_t) {
+  void*& tab = st->twiddles[-Z14_N];
+  if (!tab) {
+    std::vector<float2> host;
+    zspec1440_tables(host);
+    WBX_HIP(hipMalloc(&tab, host.size() * sizeof(float2)));
+    WBX_HIP(hipMemcpyAsync(tab, host.data(), host.size() * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  S1Args a;
+  fill_args(plan, a);
+  a.in[0] = p;
+  a.in[1] = t;
+  a.in[2] = c;
+  a.out = partial_out;
+  const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)ZL_TEAMS * WBX_ZL_BUFL * sizeof(v4) +
+                     (size_t)2 * (Z14_N2 + 2) * sizeof(double) + (size_t)ZL_GROUPS * 4 * 2 * 6 * sizeof(double);
+  const void* fn = has_c ? reinterpret_cast<const void*>(&zspec1440_det_latfast_kernel<true>)
+                         : reinterpret_cast<const void*>(&zspec1440_det_latfast_kernel<false>);
+  int& per_cu = st->occupancy[std::make_pair(fn, lds)];
+  if (per_cu == 0) {
+    WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WBX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, ZL_THREADS, lds));
+    if (per_cu <= 0) per_cu = 1;
+  }
+  const int64_t nslab = plan->nkey / rps;
+  int nlocal = per_cu * ctx->num_cus / 8;  // blocks per XCD
+  if (nlocal < 1) nlocal = 1;
+  // Runs of exactly eight rows from the start of the slab (the last one short): a slab of a [.., 1440, nlat] array starts on a
+  // 128-byte line (1440 = 32 x 45), so a run's 32-byte segment never straddles two lines.  The L1 keeps ~64 line requests in
+  // flight whatever part of a line is used (pmc: TCP_PENDING_STALL 58 % of the cycles, 5.2 x the algorithmic bytes requested
+  // from L2 with runs of 7-8 rows at arbitrary offsets): every line a CU asks for twice is bandwidth lost.
+  // WBX_SPECTRUM_ZL_EVEN=1: runs of equal length instead (A/B timing)
+  int64_t runs = (rps + ZL_TEAMS - 1) / ZL_TEAMS;
+  static const bool even_runs = getenv("WBX_SPECTRUM_ZL_EVEN") && atoi(getenv("WBX_SPECTRUM_ZL_EVEN"));
+  const int run_base = even_runs ? (int)(rps / runs) : ZL_TEAMS, run_rem = even_runs ? (int)(rps % runs) : 0;
+  const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
+  if (per_xcd < nlocal) nlocal = (int)per_xcd;
+  WBX_REQUIRE(runs < (int64_t)1 << 30, "launch too large");
+  static const int knock = getenv("WBX_ZL_KNOCK") ? atoi(getenv("WBX_ZL_KNOCK")) : 0;  // diagnostic, wrong results
+#define WBX_ZL_LAUNCH(KN)                                                                                                      \
+  hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true, KN>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab, \
+                     (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group, \
+                     scale, power_p, power_t)
+  if (has_c && knock) {
+    switch (knock) {
+      case 1: WBX_ZL_LAUNCH(1); break;
+      case 2: WBX_ZL_LAUNCH(2); break;
+      case 3: WBX_ZL_LAUNCH(3); break;
+      case 4: WBX_ZL_LAUNCH(4); break;
+      case 8: WBX_ZL_LAUNCH(8); break;
+      default: WBX_ZL_LAUNCH(11); break;
+    }
+    WBX_HIP(hipGetLastError());
+    return 0;
+  }
+#undef WBX_ZL_LAUNCH
+  if (has_c)
+    hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab,
+                       (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group,
+                       scale, power_p, power_t);
+  else
+    hipLaunchKernelGGL((zspec1440_det_latfast_kernel<false>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab,
+                       (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group,
+                       scale, power_p, power_t);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace wbx
 
 extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
@@ -943,6 +1016,43 @@ extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func,
   WBX_HIP(hipMemsetAsync(power_p, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
   WBX_HIP(hipMemsetAsync(power_t, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
   return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, partial_out, power_p, power_t);
+}
+
+
+extern "C" int wbx_det_spectrum_slabs(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                                      const void* c, int64_t rows_per_slab, const int32_t* group, const double* scale,
+                                      int64_t ngroup, double* partial_out, double* power_p, double* power_t) {
+  using namespace wbx;
+  WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
+  if (int rc = check_plan(plan)) return rc;
+  WBX_REQUIRE(func == WBX_DET3 || func == WBX_DET6, "wbx_det_spectrum_slabs takes WBX_DET3 or WBX_DET6 (got %d)", func);
+  WBX_REQUIRE(dtype == WBX_F32, "wbx_det_spectrum_slabs takes float32 fields");
+  WBX_REQUIRE(plan->nx == Z14_N && !plan->x_kept && plan->ndepth == 1 && plan->nchunk == 1,
+              "wbx_det_spectrum_slabs needs rows of %d points summed along x, one depth row and one chunk per key", Z14_N);
+  WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) && plan->x_weights == nullptr, "no masks / folded weights here");
+  WBX_REQUIRE(rows_per_slab >= 1 && plan->nkey % rows_per_slab == 0, "nkey = %lld is not a whole number of slabs of %lld rows",
+              (long long)plan->nkey, (long long)rows_per_slab);
+  const int nin = func == WBX_DET6 ? 3 : 2;
+  for (int i = 0; i < nin; ++i) {
+    WBX_REQUIRE(plan->xstride[i] >= rows_per_slab, "input %d: the longitude stride %lld is smaller than a slab's %lld adjacent rows", i,
+                (long long)plan->xstride[i], (long long)rows_per_slab);
+  }
+  WBX_REQUIRE(ngroup >= 1, "ngroup must be >= 1");
+  if (plan->nkey == 0) return 0;
+  WBX_REQUIRE(p && t && (func == WBX_DET3 || c) && group && scale && partial_out && power_p && power_t, "NULL pointer");
+  WBX_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(c)) % 4 == 0, "fields must be 4-byte aligned");
+  WBX_HIP(hipSetDevice(ctx->device));
+  auto* st = reinterpret_cast<FftState*>(ctx->fft_state);
+  if (!st) {
+    st = new FftState();
+    ctx->fft_state = st;
+    WBX_FFT(rocfft_setup());  // (the state is shared with wbx_zonal_spectrum, which may take the rocFFT route later)
+    st->setup = true;
+  }
+  constexpr int nk = Z14_N2 + 1;
+  WBX_HIP(hipMemsetAsync(power_p, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+  WBX_HIP(hipMemsetAsync(power_t, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+  return launch_1440_det_latfast(ctx, st, plan, func == WBX_DET6, p, t, c, rows_per_slab, group, scale, partial_out, power_p, power_t);
 }
 
 

@@ -307,7 +307,7 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
   return store[sig]
 
 
-def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None, one_wave=False):
+def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None, one_wave=False, force_x=None):
   """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads.
 
   The climatology gather table is the one table that follows the chunk's time labels (every chunk of a streamed evaluation
@@ -321,7 +321,7 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
     gbytes = gtable.tobytes()
     if not SWAP_GATHER_TABLES:
       gsig += (gbytes,)
-  sig = (id(ctx), kind, bool(one_wave), tuple(dims), tuple(sizes[d] for d in dims),
+  sig = (id(ctx), kind, bool(one_wave), force_x, tuple(dims), tuple(sizes[d] for d in dims),
          None if x_weights is None else hash(x_weights.tobytes()),
          tuple(None if l is None else (tuple(sorted(l.strides.items(), key=str)), l.itemsize, l.base_alignment % 16 == 0)
                for l in layouts),
@@ -329,7 +329,7 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
   hit = _fast_plan_cache.get(sig)
   if hit is None:
     plan = planner.build_s1_plan(dims, sizes, layouts, reduce_dims, wdep_dims=wdep, gather=gather, flags=flags,
-                                 allow_vec4=(kind == 'det' and x_weights is None),
+                                 allow_vec4=(kind == 'det' and x_weights is None and force_x is None), force_x_dim=force_x,
                                  fold_x=False if x_weights is None else
                                  (True if kind == 'det' else ('point64' if one_wave else 'point')))
     if x_weights is not None and plan.plane_rows > 0:
@@ -462,6 +462,11 @@ def clear_caches():
 _fusion_requests: dict = {}   # id(predictions DataArray) -> {'p', 't', 'entry', 'ngroup'}
 _fusion_parks: list = []      # arrays that carry a fused spectrum nobody has asked for yet
 FUSE_DET_SPECTRA = os.environ.get('WBX_FUSE_DET_SPECTRA', '1') != '0'
+# The same fusion on latitude-fastest fields (wbx_det_spectrum_slabs, csrc/wbx_zspec_det_latfast.hpp) is correct but NOT faster
+# than the three launches it replaces (configs[3] chunk on MI355X: 1.70 ms against 1.55 ms -- runs of eight adjacent rows use a
+# quarter of every 128-byte line a CU asks its L2 for, and the L1 keeps only so many line requests in flight):
+# opt-in (WBX_FUSE_DET_SPECTRA_LATFAST=1), the default stays the flat deterministic sweep + one staged-run launch per field.
+FUSE_DET_SPECTRA_LATFAST = os.environ.get('WBX_FUSE_DET_SPECTRA_LATFAST', '0') == '1'
 
 
 def request_det_spectra(p_da, t_da, entry, ngroup: int):
@@ -497,6 +502,53 @@ def _fused_rows(plan: planner.S1Plan, entry):
   return np.ascontiguousarray(np.asarray(idx).reshape(-1))
 
 
+def _fused_slab_rows(plan: planner.S1Plan, entry, nin: int):
+  """Latitude-fastest fields under a plan whose x is the (strided) longitude: rows per slab when the keys are whole slabs of
+  ADJACENT rows in every input (wbx_det_spectrum_slabs), else None.  Cached with the spectra's row tables."""
+  ckey = ('slabs', tuple(plan.key_dims), tuple(plan.sizes[d] for d in plan.key_dims), tuple(plan.xstride[:nin]))
+  hit = entry['dev'].get(ckey)
+  if hit is None:
+    hit = False
+    rows = _fused_rows(plan, entry)
+    if rows is not None and rows.size == plan.nkey and plan.key_dims and plan.nchunk == 1 and not plan.x_kept:
+      rps = int(plan.sizes[plan.key_dims[-1]])
+      ok = rps >= 1 and all(plan.xstride[i] >= rps for i in range(nin))
+      for i in range(nin):
+        ko = plan.key_off[i]
+        ok = ok and ko is not None and (rps == 1 or bool(np.all(np.diff(np.asarray(ko).reshape(-1, rps), axis=1) == 1)))
+      if ok and plan.gather_key is not None and rps > 1:  # the climatology slice must not change inside a slab
+        ok = bool(np.all(np.diff(np.asarray(plan.gather_key).reshape(-1, rps), axis=1) == 0))
+      if ok:
+        hit = rps
+    entry['dev'][ckey] = hit
+  return hit or None
+
+
+def _fusion_latfast_plan(ctx, inputs, dims, sizes, layouts, reduce_dims, wdep, gather, func, dtype_code):
+  """A pending request for the spectra of these (p, t) on fields whose LONGITUDE is strided (latitude-fastest archives): the
+  deterministic plan with x = longitude -- rows = the spectra's rows -- when wbx_det_spectrum_slabs can run it, else None (the
+  planner's own choice stays: x = the contiguous dim)."""
+  if not FUSE_DET_SPECTRA_LATFAST:
+    return None
+  req = _fusion_requests.get(id(inputs[0]))
+  if req is None or req['p'] is not inputs[0] or req['t'] is not inputs[1] or layouts[0] is None:
+    return None
+  lon = [d for d in dims if d not in req['entry']['row_dims']]
+  if len(lon) != 1 or func not in (_hip.DET3, _hip.DET6) or dtype_code != _hip.F32 or ctx is not _hip.default_context():
+    return None
+  lon = lon[0]
+  if (sizes[lon] != 1440 or lon not in set(reduce_dims) or lon in wdep or layouts[0].stride(lon) == 1
+      or (gather is not None and lon in gather.dims)):
+    return None
+  nin = _hip.DET_INPUTS[func]
+  if any(layouts[i] is None for i in range(nin)):
+    return None
+  plan, dplan = _planned(ctx, 'det', dims, sizes, layouts, reduce_dims, wdep, gather, 0, force_x=lon)
+  if plan.ndepth != 1 or _fused_slab_rows(plan, req['entry'], nin) is None:
+    return None
+  return plan, dplan
+
+
 def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
   """The fused launch when a request for these very inputs is pending and the plan qualifies: -> True (partial written to
   `out`, both spectra parked with their source arrays), else False (the caller launches wbx_det_partial as usual)."""
@@ -507,10 +559,14 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
     return False
   nin = _hip.DET_INPUTS[func]
   if (func not in (_hip.DET3, _hip.DET6) or dtype_code != _hip.F32 or plan.nx != 1440 or plan.x_kept or plan.ndepth != 1
-      or plan.nchunk != 1 or plan.flags or plan.x_weights is not None or any(plan.xstride[i] != 1 for i in range(nin))
-      or plan.x_dim is None or ctx is not _hip.default_context()):
+      or plan.nchunk != 1 or plan.flags or plan.x_weights is not None or plan.x_dim is None or ctx is not _hip.default_context()):
     return False
   entry, ngroup = req['entry'], req['ngroup']
+  rps = None
+  if any(plan.xstride[i] != 1 for i in range(nin)):  # latitude-fastest fields: slabs of adjacent rows, longitude strided
+    rps = _fused_slab_rows(plan, entry, nin)
+    if rps is None:
+      return False
   fkey = ('fused', tuple(plan.key_dims), tuple(plan.sizes[d] for d in plan.key_dims))
   bufs = entry['dev'].get(fkey)
   if bufs is None:
@@ -532,11 +588,17 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
 
   def call():
-    _hip.check(ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
-                                        ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
-                                        int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)),
-               'wbx_det_spectrum')
-  timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func))
+    if rps is None:
+      _hip.check(ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                          ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
+                                          int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)),
+                 'wbx_det_spectrum')
+    else:
+      _hip.check(ctx.lib.wbx_det_spectrum_slabs(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                                ptr(devs[2]) if nin > 2 else None, int(rps), C.c_void_p(bufs[0].ptr),
+                                                C.c_void_p(bufs[1].ptr), int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr),
+                                                C.c_void_p(pw_t.ptr)), 'wbx_det_spectrum_slabs')
+  timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func), slab_rows=int(rps or 0))
   for da, buf in ((req['p'], pw_p), (req['t'], pw_t)):
     # (the buffer object rides along: it is released -- stream ordered behind its consumer -- when the entry is dropped)
     da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'buf': buf, 'ngroup': ngroup, 'cache': entry['dev']}
@@ -1230,8 +1292,11 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   # kept as nx partials per key for stage 2.
   x_weights = None
   hit = None
+  if kind == 'det' and _fusion_requests and not flags and not bin_dims and inputs[0] is not None:
+    # spectra of these very fields are about to be asked for and longitude is strided: rows = the spectra's rows
+    hit = _fusion_latfast_plan(ctx, inputs, dims, sizes, layouts, reduce_dims, wdep, gather, func, dtype_code)
   fold_ok = (kind == 'det' and not (flags & ~_hip.FLAG_MASKED)) or (kind == 'ens' and not (flags & _hip.FLAG_SKIPNA_ENS))
-  if FOLD_X_WEIGHTS and fold_ok and w_da is not None and not bin_dims and len(w_da.dims) == 1:
+  if hit is None and FOLD_X_WEIGHTS and fold_ok and w_da is not None and not bin_dims and len(w_da.dims) == 1:
     x_dim = planner.choose_x_dim(dims, sizes, layouts[0])
     if x_dim is not None and w_da.dims[0] == x_dim and x_dim in set(reduce_dims) and 1 < sizes[x_dim] <= 2045:
       xw = np.ascontiguousarray(w_da.values, dtype=np.float64)
