@@ -60,7 +60,7 @@ namespace wbx {
 static int ens_binned_geometry(const wbx_s1_plan* plan, int64_t nA, int64_t nBk, int64_t nBr, int32_t w_on_x, BinnedArgs& g) {
   if (int rc = check_plan(plan)) return rc;
   WBX_REQUIRE(nA >= 1 && nBk >= 1 && nBr >= 1 && plan->nx >= 1 && plan->ndepth >= 1, "empty geometry");
-  patch_geometry(g, nA * nBk, nBk, nBr, (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1, plan->ndepth, plan->nx, ens_atoms_rows());
+  patch_geometry(g, nA * nBk, nBk, nBr, (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1, plan->ndepth, plan->nx, ens_atoms_rows(), ens_atoms_taper());
   return 0;
 }
 

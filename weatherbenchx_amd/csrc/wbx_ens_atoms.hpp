@@ -151,9 +151,18 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   // nw < 0: more than ATOM_MAX distinct membership words in one patch (arbitrary user masks).  This kernel has no slot
   // fallback: the host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller
   // that did not gets NaN in every bin of the cell instead of silently wrong sums.
-  const int64_t R = g.nBr * a.D;
-  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
-  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  int64_t rbeg, rend;
+  int br_first = 0;
+  if (g.taper) {  // (scalar loads: the table sits next to the atom tables)
+    const const_ptr<int32_t> tab = (const_ptr<int32_t>)g.split_tab;
+    br_first = tab[rs];
+    rbeg = (int64_t)br_first * a.D;
+    rend = (int64_t)tab[rs + 1] * a.D;
+  } else {
+    const int64_t R = g.nBr * a.D;
+    rbeg = (int64_t)rs * g.rows_per_split;
+    rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  }
 
   // lanes beyond a ragged nx re-read the last element and never accumulate
   const bool live = (int64_t)xt * 64 + lane < a.nx;
@@ -215,7 +224,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
   // not have.)  Row r of the cell = (br, d) = (r / D, r mod D), stepped without a division.
   const int nrows = nw < 0 ? 0 : (int)(rend - rbeg);  // (the launcher checked that the row counts fit 31 bits)
   const int nD = (int)a.D;
-  int br_a = (int)((int64_t)rs * e.br_per_split);  // (row splits are whole Br rows: rbeg = br_a * D)
+  int br_a = g.taper ? br_first : (int)((int64_t)rs * e.br_per_split);  // (row splits are whole Br rows: rbeg = br_a * D)
   int d_a = 0;
   const int br_last = (int)((rend - 1) / a.D);
   const int64_t key0 = (A * g.nBk + bk) * g.nBr, wrow0 = bk * g.nBr;
@@ -511,6 +520,12 @@ struct EnsBinnedCall {
   double* out;           // [nA][nBk][ENS_ATOMS_NOUT (twin mode: NOUT2)][nbin]
 };
 
+// WBX_ENS_ATOMS_TAPER=0: uniform row splits (A/B timing); default: the tapered table of patch_taper
+inline bool ens_atoms_taper() {
+  static const bool on = !(getenv("WBX_ENS_ATOMS_TAPER") && atoi(getenv("WBX_ENS_ATOMS_TAPER")) == 0);
+  return on;
+}
+
 inline int64_t ens_atoms_rows() {
   static const int64_t rows = getenv("WBX_ENS_ATOMS_ROWS") && atol(getenv("WBX_ENS_ATOMS_ROWS")) > 0 ? atol(getenv("WBX_ENS_ATOMS_ROWS")) : WBX_ENS_ATOMS_ROWS;
   return rows;
@@ -541,7 +556,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const int64_t cells = c.nA * c.nBk;
   // (the scratch is sized for the geometry patch_setup is about to choose: same call as inside it)
   BinnedArgs probe;
-  patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows());
+  patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows(), ens_atoms_taper());
   const int64_t npatch = (int64_t)probe.nrs * probe.nxt;
   const int ng1 = (int)((npatch + ENS_ATOMS_G1 - 1) / ENS_ATOMS_G1), ng2 = (ng1 + ENS_ATOMS_G2 - 1) / ENS_ATOMS_G2;
   const bool twin = (plan->flags & WBX_FLAG_MASKED) && (c.w_on_x & WBX_BINNED_TWIN_MASK);
@@ -549,7 +564,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const size_t n_tab = (size_t)probe.nblocks * ENS_ATOMS_ROWS2 * ENS_ATOMS_NQ, n_p1 = (size_t)cells * ng1 * NP, n_p2 = (size_t)cells * ng2 * NP;
   // (nacc = 0: no per-patch bin tables -- the sums over patches happen inside the kernel)
   if (int rc = patch_setup(ctx, g, nullptr, c.bits, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, 0, c.nbin, true, c.prepared,
-                           true, ens_atoms_rows(), n_tab + n_p1 + n_p2, &extra))
+                           true, ens_atoms_rows(), n_tab + n_p1 + n_p2, &extra, ens_atoms_taper()))
     return rc;
   EnsAtomsArgs e;
   e.wx = (c.w_on_x & WBX_BINNED_WT_X_ONLY) ? c.wt : nullptr;

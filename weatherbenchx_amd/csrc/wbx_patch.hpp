@@ -6,10 +6,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "wbx_common.hpp"
 
 namespace wbx {
+
+constexpr int WBX_SPLIT_MAX = 255;
 
 struct BinnedArgs {
   const double* wt;                  // [nBk][nBr][nj]
@@ -28,9 +31,27 @@ struct BinnedArgs {
   int32_t* nwords;                   // [nBk][patch]: entries in the list, -1 = more than ATOM_MAX (slot kernel takes it)
   int32_t atoms;                     // 0: every patch goes to the slot kernel (A/B timing: WBX_BINNED_ATOMS=0)
   int32_t order;                     // block order: 0 cell fastest, 1 x tile fastest (see patch_decode)
+  // Tapered row splits (patch_taper; the ensemble atom kernel): split rs = Br rows [split_br[rs], split_br[rs + 1]) instead of
+  // rs * rows_per_split ..: an XCD walks a contiguous eighth of the splits in order (patch_decode), and the last splits of each
+  // eighth are half and quarter size, so that its 384 wave slots run dry within a short patch instead of a long one
+  int32_t taper;
+  int32_t* split_tab;                // the same table in device memory, next to the atom tables (written by binned_atoms_kernel):
+  int32_t split_br[WBX_SPLIT_MAX + 1];  // the main kernel reads it with scalar loads
 };
 
 constexpr int ATOM_MAX = 32;
+
+// Rows [rbeg, rend) of row split rs (rows = Br rows x D depth rows).
+__device__ __forceinline__ void patch_rows(const BinnedArgs& g, int rs, int64_t D, int64_t& rbeg, int64_t& rend) {
+  if (g.taper) {
+    rbeg = (int64_t)g.split_br[rs] * D;
+    rend = (int64_t)g.split_br[rs + 1] * D;
+  } else {
+    const int64_t R = g.nBr * D;
+    rbeg = (int64_t)rs * g.rows_per_split;
+    rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  }
+}
 
 // OR of a 32-bit value over the 64 lanes (all lanes must be active); the result is wave-uniform (SGPR).
 __device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
@@ -90,9 +111,8 @@ static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, i
   b /= g.nxt;
   const int rs = (int)(b % g.nrs);
   const int64_t bk = b / g.nrs;
-  const int64_t R = g.nBr * D;
-  const int64_t rbeg = (int64_t)rs * g.rows_per_split;
-  const int64_t rend = rbeg + g.rows_per_split < R ? rbeg + g.rows_per_split : R;
+  int64_t rbeg, rend;
+  patch_rows(g, rs, D, rbeg, rend);
   const int64_t br0 = rbeg / D, br1 = (rend - 1) / D;  // inclusive
   const bool live = (int64_t)xt * 64 + lane < nx;
   const int64_t xw = g.nj > 1 ? (live ? (int64_t)xt * 64 + lane : nx - 1) : 0;
@@ -146,6 +166,8 @@ static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, i
     }
   }
   const int64_t pidx = bk * ((int64_t)g.nrs * g.nxt) + (int64_t)rs * g.nxt + xt;
+  if (g.taper && blockIdx.x == 0)
+    for (int i = lane; i <= g.nrs; i += 64) g.split_tab[i] = g.split_br[i];
   __syncthreads();
   unsigned long long all = 0ull;
   for (int k = 0; k < count; ++k) all |= list[k];
@@ -187,8 +209,43 @@ static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, 
 // Patch geometry: rows = nBr * D reduced rows of nx points per cell, cut into nrs row splits x nxt tiles of 64 x.
 // rows_hint > 0: patches of about that many rows instead (the ensemble atom kernel, wbx_ens_atoms.hpp: a row of a patch is a
 // 64-point tile of ~2.4 us there, so its patches are short).
+// The tapered split table: the Br rows are dealt to eight segments (one per XCD, see BinnedArgs::split_br) with the SAME number
+// of splits each -- patches of `s0` Br rows for the first ~70 % of a segment, then half, then quarter size.  -> false when the
+// table would not fit (the caller keeps uniform splits).
+inline bool patch_taper(BinnedArgs& g, int64_t nBr, int64_t s0) {
+  if (s0 < 4 || nBr < 8 * 2 * s0) return false;
+  const int64_t longest = (nBr + 7) / 8;
+  std::vector<int64_t> sizes;  // of the longest segment
+  int64_t done = 0;
+  const int64_t half = s0 / 2, quarter = s0 / 4;
+  while ((done + s0) * 10 <= longest * 7) sizes.push_back(s0), done += s0;
+  while ((done + half) * 10 <= longest * 9) sizes.push_back(half), done += half;
+  while (done + quarter <= longest) sizes.push_back(quarter), done += quarter;
+  if (done < longest) sizes.push_back(longest - done);
+  if (sizes.empty() || sizes[0] < 2) return false;
+  const int64_t per = (int64_t)sizes.size();
+  if (per * 8 > WBX_SPLIT_MAX) return false;
+  int64_t at = 0;
+  for (int seg = 0; seg < 8; ++seg) {
+    int64_t len = nBr / 8 + (seg < nBr % 8 ? 1 : 0);
+    int64_t shave = longest - len;  // 0 or 1 (or more when nBr % 8 == 0 ... never: longest = ceil)
+    for (int64_t i = 0; i < per; ++i) {
+      int64_t n = sizes[(size_t)i];
+      if (i == 0) n -= shave;
+      g.split_br[seg * per + i] = (int32_t)at;
+      at += n;
+    }
+  }
+  g.split_br[8 * per] = (int32_t)at;
+  if (at != nBr) return false;
+  g.nrs = (int)(8 * per);
+  g.taper = 1;
+  return true;
+}
+
 inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nBr, int64_t nj, int64_t D, int64_t nx,
-                           int64_t rows_hint = 0) {
+                           int64_t rows_hint = 0, bool taper = false) {
+  g.taper = 0;
   g.nBk = nBk;
   g.nBr = nBr;
   g.nj = nj;
@@ -209,6 +266,7 @@ inline void patch_geometry(BinnedArgs& g, int64_t cells, int64_t nBk, int64_t nB
   g.rows_per_split = (rows + want - 1) / want;
   g.rows_per_split = (g.rows_per_split + D - 1) / D * D;  // whole Br rows per split: a (bk, br, x) point has ONE patch
   g.nrs = (int)((rows + g.rows_per_split - 1) / g.rows_per_split);
+  if (taper && rows_hint > 0) patch_taper(g, nBr, g.rows_per_split / D);
   g.ncell = cells;
   g.nblocks = cells * (int64_t)g.nrs * g.nxt;
   g.order = 0;
@@ -223,13 +281,15 @@ inline size_t atoms_carve(BinnedArgs& g, void* base) {
   const size_t n_words = (size_t)g.nBk * npatch * ATOM_MAX;
   const size_t n_nwords = ((size_t)g.nBk * npatch + 1) / 2;          // int32 pairs, in 8-byte units
   const size_t n_aid = ((size_t)g.nBk * g.nBr * g.nj + 7) / 8;       // bytes, in 8-byte units
+  const size_t n_split = g.taper ? (WBX_SPLIT_MAX + 2) / 2 : 0;      // int32 pairs
   if (base) {
     g.uni = reinterpret_cast<unsigned long long*>(base);
     g.words = g.uni + n_uni;
     g.nwords = reinterpret_cast<int32_t*>(g.words + n_words);
     g.aid = reinterpret_cast<uint8_t*>(g.words + n_words + n_nwords);
+    g.split_tab = g.taper ? reinterpret_cast<int32_t*>(g.words + n_words + n_nwords + n_aid) : nullptr;
   }
-  return (n_uni + n_words + n_nwords + n_aid) * 8;
+  return (n_uni + n_words + n_nwords + n_aid + n_split) * 8;
 }
 
 inline int atoms_launch(wbx_ctx* ctx, BinnedArgs& g, const uint64_t* bits, int64_t D, int64_t nx, bool atoms) {
@@ -246,12 +306,12 @@ inline int atoms_launch(wbx_ctx* ctx, BinnedArgs& g, const uint64_t* bits, int64
 inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint64_t* bits, int64_t cells, int64_t nBk,
                        int64_t nBr, int64_t nj, int64_t D, int64_t nx, int nacc, int nbin, bool atoms = false,
                        const void* prepared = nullptr, bool tmp_written_by_kernels = false, int64_t rows_hint = 0,
-                       size_t extra_doubles = 0, double** extra_out = nullptr) {
+                       size_t extra_doubles = 0, double** extra_out = nullptr, bool taper = false) {
   g.wt = wt;
   g.bits = reinterpret_cast<const unsigned long long*>(bits);
   g.nbin = nbin;
   g.aidm = nullptr;
-  patch_geometry(g, cells, nBk, nBr, nj, D, nx, rows_hint);
+  patch_geometry(g, cells, nBk, nBr, nj, D, nx, rows_hint, taper);
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
   const size_t n_tmp = (size_t)cells * npatch * nacc * nbin, n_poison = (size_t)cells * npatch * nacc;
   const size_t need = (n_tmp + n_poison + extra_doubles) * sizeof(double) + (prepared ? 0 : atoms_carve(g, nullptr));
