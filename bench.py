@@ -215,6 +215,8 @@ def _library_md5():
 # ---- main line: the north_star field ---------------------------------------------------------------------------------------
 def ens_kernel_name(e, m=51):
   """The kernel wbx_ens_partial launches for this event (the dispatch rule of csrc/wbx_ens_impl.hpp restated)."""
+  if e.get('flags', 0) & 8:  # WBX_FLAG_SKIPNA_ENS: per-point member counts, the generic operator
+    return f"s1_{'xk' if e.get('x_kept') else 'xr'}_kernel<EnsOp<float>,1> (generic pair form over the valid members, fp64)"
   if e.get('algo') == 1:
     return f's1_xr_kernel<EnsOpF32<{m},true,PAIRWISE>,1> (register-tiled O(M^2) pair form)'
   piped = (os.environ.get('WBX_ENS_PIPE', '1') != '0' and e.get('block') == 64 and not e.get('x_kept') and not (e.get('flags', 0) & 11)
@@ -542,6 +544,14 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
   finally:
     _lazy.PAIR_FORM_KERNEL = was
   plog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens' and e.get('algo') == 1]
+  # (c) skipna_ensemble=True (probabilistic.py:133-145: NaN members are left out point by point) only exists in pair form with
+  # per-point member counts: the generic from-memory kernel (WBX_FLAG_SKIPNA_ENS), timed here on the same variable
+  smet = {'crps_skipna': _prob.CRPSEnsemble(skipna_ensemble=True)}
+  engine.S1_EVENT_LOG = []
+  for _ in range(2):
+    sout = eagg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(
+        smet, fresh({k0: pe[k0]}), fresh({k0: te[k0]}))).metric_values(smet)
+  slog = [e for e in engine.S1_EVENT_LOG if e['kind'] == 'ens']
   engine.S1_EVENT_LOG = None
   epoints = nlead * env.nlat * env.nlon  # per variable launch
   ek_ms = float(np.median([e['ms'] for e in elog]))
@@ -558,6 +568,12 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
                                                 epoints * (m + 1) * 4,
                                                 pmc_traffic(ens_kernel_name(plog[0], m), nlead == 8 and not args.small, f'ensemble@{env.layout}')),
                                 crps=float(np.asarray(pout[f'crps_default.{k0}'].values).mean())) if plog else None),
+         'skipna_ensemble': ({'what': 'CRPSEnsemble(skipna_ensemble=True) on one variable through the API: the generic pair-form kernel with '
+                                      'per-point member counts (fp64 from memory, WBX_FLAG_SKIPNA_ENS)',
+                              'launches_per_variable': len(slog) // 2,
+                              'roofline': kernel_roofline(ens_kernel_name(slog[0], m), float(np.sum([e['ms'] for e in slog]) / 2),
+                                                          epoints * (m + 1) * 4, None),
+                              'crps': float(np.asarray(sout[f'crps_skipna.{k0}'].values).mean())} if slog else None),
          'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
                    'spread_skill_v0_mean': float(np.asarray(eout['unbiased_spread_skill.v0'].values).mean())}}
   del pe, te, tv

@@ -378,7 +378,10 @@ def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fa
     if not (set(t.dims) <= set(p.dims) and _same_mask(p, t)):
       t = first_member(p, ensemble_dim)  # a companion with exactly the predictions' frame
     coord_names = frozenset(p._coords)  # pylint: disable=protected-access
-  p, t = _aligned(p, t)
+  table = p.__dict__.get('_wbx_groups')
+  if not (table and any(k[0] == 'ens' and k[1] == id(t) and k[2] == t.__dict__.get('_mutations', 0) and k[3] == ensemble_dim
+                        and v[0]() is t and v[1]() is not None for k, v in table.items())):
+    p, t = _aligned(p, t)  # (a group of these very objects exists: an earlier statistic has checked their frames)
   m = p.sizes[ensemble_dim]
   grp = _group_for('ens', p, t, ens={'member_dim': ensemble_dim, 'M': m})
   # use_sort=False (the reference's default, probabilistic.py:644) asks for the O(M^2) pair form of the SAME number -- the
