@@ -545,3 +545,62 @@ def test_latitude_fastest_chunks_fuse_spectra_into_the_deterministic_sweep(ctx, 
     # (same transform; the mean shift is estimated from other samples of the row: fp32 rounding of another shifted row)
     np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=2e-6, err_msg=k)
     np.testing.assert_allclose(s1[k].values, s2[k].values, rtol=2e-6, err_msg=k)
+
+
+# ---- skipna_ensemble: the register-resident rank form over the valid members (WBX_ENS_SKIPNA_SORT) ---------------------------
+@pytest.mark.parametrize('m', [51, 50, 13, 33, 3])
+def test_skipna_ensemble_register_kernel_against_the_oracle(ctx, m):
+  """skipna_ensemble=True on float32 ensembles (probabilistic.py:139-145, 206-216, 303-336): per-point member counts from 0 to
+  M -- points without a member, with one, with two, with all -- an infinite member, a NaN and an infinite target; every lane
+  per POINT (the map path) and under a (latitude, longitude) reduction with skipna, against the float64 restatement."""
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(100 + m)
+  nlat, nlon = 24, 160
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * (360.0 / nlon)
+  pv = (rng.normal(size=(2, m, nlat, nlon)) * 3 + 280).astype(np.float32)
+  tv = (rng.normal(size=(2, nlat, nlon)) * 3 + 280).astype(np.float32)
+  pv[rng.random(pv.shape) < 0.2] = np.nan
+  pv[0, :, 3, 4] = np.nan                 # no member
+  pv[0, 1:, 5, 6] = np.nan                # one member
+  pv[0, 2:, 5, 7] = np.nan                # two members
+  pv[1, :, 7, 8] = rng.normal(size=m)     # all members
+  pv[1, m // 2, 9, 10] = np.inf           # an infinite member: the generic operator's point
+  tv[1, 11, 12] = np.nan
+  tv[1, 11, 13] = np.inf
+  pdims, tdims = ('time', 'number', 'latitude', 'longitude'), ('time', 'latitude', 'longitude')
+  coords = {'latitude': lat, 'longitude': lon}
+  p = {'v': xr.DataArray(pv, dims=pdims, coords=coords)}
+  t = {'v': xr.DataArray(tv, dims=tdims, coords=coords)}
+  stats = {'skill': probabilistic.CRPSSkill(skipna_ensemble=True),
+           'spread': probabilistic.CRPSSpread(use_sort=False, fair=True, skipna_ensemble=True),
+           'var': probabilistic.EnsembleVariance(skipna_ensemble=True),
+           'uemse': probabilistic.UnbiasedEnsembleMeanSquaredError(skipna_ensemble=True)}
+  with np.errstate(all='ignore'):
+    want = {'skill': O.crps_skill(pv, pdims, tv, tdims, 'number', skipna_ensemble=True),
+            'spread': O.crps_spread(pv, pdims, 'number', fair=True, skipna_ensemble=True),
+            'var': O.ensemble_variance(pv, pdims, 'number', skipna_ensemble=True),
+            'uemse': O.unbiased_ensemble_mean_squared_error(pv, pdims, tv, tdims, 'number', skipna_ensemble=True)}
+  engine.S1_EVENT_LOG, engine.S1_EVENT_REPEAT = [], 1
+  try:
+    for k, s in stats.items():
+      got = np.asarray(s.compute(p, t)['v'].values)  # per point: wbx_ens_map
+      ref, rdims = want[k]
+      ref = np.asarray(ref)
+      assert got.shape == ref.shape, (k, got.shape, ref.shape)
+      with np.errstate(all='ignore'):
+        # a difference of two nearly equal numbers (unbiased MSE of a point with two members close to the target) is held
+        # absolutely to the size of its terms
+        scale = np.nan_to_num(np.abs(ref), nan=0.0, posinf=0.0) + (np.nan_to_num(want['var'][0], nan=0.0, posinf=0.0) if k == 'uemse' else 0.0)
+      ok = np.isclose(got, ref, rtol=RTOL, atol=0.0, equal_nan=True) | (np.abs(got - ref) <= RTOL * scale)
+      assert ok.all(), (k, np.argwhere(~ok)[:5], got[~ok][:5], ref[~ok][:5])
+    agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], skipna=True)
+    red = aggregation.compute_metric_values_for_single_chunk(stats, agg, p, t)
+    log = list(engine.S1_EVENT_LOG)
+  finally:
+    engine.S1_EVENT_LOG = None
+  assert any(e['kind'] == 'ens' and e['flags'] & _hip.FLAG_SKIPNA_ENS for e in log)
+  w = (O.grid_area_weights(lat), ('latitude',))
+  with np.errstate(all='ignore'):
+    for k, (vals, dims) in want.items():
+      sws, sw, _ = O.aggregate(vals, dims, ['latitude', 'longitude'], weights=[w], skipna=True)
+      np.testing.assert_allclose(red[f'{k}.v'].values, sws / sw, rtol=RTOL, err_msg=k)

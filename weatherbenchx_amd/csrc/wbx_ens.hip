@@ -29,8 +29,14 @@ static int ens_common(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, i
   a.mstride = member_stride;
   a.lane = lane;
   if (dtype == WBX_F64) return launch_ens_op<EnsOpGeneric<double>>(ctx, plan, a, map);
-  if (plan->flags & WBX_FLAG_SKIPNA_ENS) return launch_ens_op<EnsOpGeneric<float>>(ctx, plan, a, map);
   WBX_REQUIRE(dtype == WBX_F32, "unknown dtype %d", dtype);
+  if (plan->flags & WBX_FLAG_SKIPNA_ENS) {
+    // per-point ensemble sizes: the register-resident rank form over the valid members (WBX_ENS_SKIPNA_SORT, wbx_ens_impl.hpp);
+    // WBX_ENS_SKIPNA_GENERIC=1 pins the generic from-memory operator (A/B timing, tests)
+    static const bool generic = getenv("WBX_ENS_SKIPNA_GENERIC") && atoi(getenv("WBX_ENS_SKIPNA_GENERIC")) != 0;
+    if (generic || M > 64) return launch_ens_op<EnsOpGeneric<float>>(ctx, plan, a, map);
+    algo = WBX_ENS_SKIPNA_SORT;
+  }
   if (M == 51) return launch_ens_m51(ctx, plan, a, algo, map);
   if (M == 50) return launch_ens_m50(ctx, plan, a, algo, map);
   if (M <= 4) return launch_ens_m4(ctx, plan, a, algo, map);

@@ -50,6 +50,14 @@ constexpr int WBX_ENS_DIAG_LOADONLY = 99;
 // 1275 |x_i - x_j| terms are formed on register blocks of 17 members read back from there (34 live member registers instead of
 // 51).  M == 51 only.
 constexpr int WBX_ENS_DIAG_PAIRWISE_LDS = 98;
+// not part of the ABI enum: what WBX_FLAG_SKIPNA_ENS runs for float32 ensembles of up to 64 members (r4).  skipna_ensemble
+// (probabilistic.py:139-145, 206-216, 271-273, 303-336) makes the ensemble size a per-point count, which the generic operator
+// below serves with an O(M^2) loop over members re-read from memory: 10.7 ms per 1.73 GB variable = 2 % of the HBM peak
+// (profiles/r04_bench_n1.json, ensemble.skipna_ensemble).  Here the members sit in registers like in the rank-form kernels: a
+// NaN member becomes +inf, the same sorting network moves the n valid members to the front, and the rank form runs over the
+// first n of them with per-lane n (coefficients 2 i - (n - 1), divisions by n-derived numbers per point).  A point that holds
+// an infinite member goes to the generic operator (EnsOpF32::finish), so +inf can stand for "missing".
+constexpr int WBX_ENS_SKIPNA_SORT = 97;
 
 // Generic op: members are re-read from memory (L1/L2-served) instead of living in VGPRs.
 // Always uses the O(M^2) pair form in fp64 -- algebraically identical to the rank form
@@ -182,6 +190,20 @@ struct EnsOpF32 {
     }
     double pair_total = 0.0;
     float poison = 0.f;  // NaN iff any member is NaN/inf (v_min/v_max would silently drop a NaN)
+    int nvalid = 0;      // (WBX_ENS_SKIPNA_SORT) members that are not NaN
+    bool weird = false;  // ... and whether one of them is infinite
+    if constexpr (ALGO == WBX_ENS_SKIPNA_SORT) {
+#pragma unroll
+      for (int m = 0; m < MP; ++m) {
+        if (EXACT || m < M) {
+          const float x = xm[m];
+          const bool missing = x != x;
+          weird = weird || fabsf(x) == INFINITY;
+          nvalid += missing ? 0 : 1;
+          xm[m] = missing ? INFINITY : x;
+        }
+      }
+    }
     if constexpr (ALGO == WBX_ENS_PAIRWISE) {
 #pragma unroll
       for (int i = 1; i < MP; ++i) {
@@ -192,8 +214,8 @@ struct EnsOpF32 {
           pair_total += (double)row;
         }
       }
-    } else if constexpr (ALGO == WBX_ENS_SORT) {
-      {  // two members per instruction (v_pk_fma_f32): x * 0 + p is NaN iff x is NaN or +-inf
+    } else if constexpr (ALGO == WBX_ENS_SORT || ALGO == WBX_ENS_SKIPNA_SORT) {
+      if constexpr (ALGO == WBX_ENS_SORT) {  // two members per instruction (v_pk_fma_f32): x * 0 + p is NaN iff x is NaN or +-inf
         typedef float pk2 __attribute__((ext_vector_type(2)));
         pk2 pz = {0.f, 0.f};
 #pragma unroll
@@ -243,6 +265,11 @@ struct EnsOpF32 {
     }
 
     bool redo = false;
+    if constexpr (ALGO == WBX_ENS_SKIPNA_SORT) {
+      stats_skipna(a, xm, nvalid, td, val);
+      r.poison = 0.f;
+      return weird;  // per lane: the caller redoes such a point with the generic operator
+    }
     if constexpr (FAST32 && EXACT && ALGO == WBX_ENS_SORT && WBX_ENS_STATS32) {
       // the hot instantiations (M = 50 / 51, rank form): fp32 chain sums on median-centred members (stats32), unless a lane
       // of the wave holds a point whose magnitudes could overflow / underflow an fp32 square or sum.  Then the CALLER redoes
@@ -280,6 +307,39 @@ struct EnsOpF32 {
       EnsOpGeneric<float>::values(a, ro, x, val);
       apply_poison(r, val);
     }
+  }
+
+  // The rank form over the first n (sorted, valid) members, n per lane; the formulas of EnsOpGeneric::values on e = x - shift.
+  // sum_{i<j} |x_i - x_j| = sum_i (2 i - (n - 1)) x_(i): the coefficients add up to 0 over i < n, so the shift drops out.
+  __device__ __forceinline__ static void stats_skipna(const S1Args& a, const float (&xm)[MP], const int n, const double td,
+                                                      double (&val)[NLANE]) {
+    const int M = EXACT ? MP : a.M;
+    const double x0 = n > 0 ? (double)xm[0] : 0.0;
+    const bool tfin = (td - td) == 0.0;
+    const double shift = tfin ? td : x0;
+    const double x0t = shift - td;  // 0 for a finite target, else NaN / -+inf
+    const double dM = (double)n;
+    double se = 0.0, sq = 0.0, sabs = 0.0, dot = 0.0;
+#pragma unroll
+    for (int m = 0; m < MP; ++m) {
+      if (EXACT || m < M) {
+        const double e = m < n ? (double)xm[m] - shift : 0.0;
+        se += e;
+        sq = fma(e, e, sq);
+        sabs += fabs(e);
+        dot = fma((double)(2 * m + 1) - dM, e, dot);
+      }
+    }
+    sabs += n > 0 ? fabs(x0t) : 0.0;  // mean |x - t| is NaN / inf with the target
+    const double fair = (a.flags & WBX_FLAG_FAIR) ? 1.0 : 0.0;
+    const double mean_e = se / dM;
+    const double mean_d = x0t + mean_e;
+    const double var = (sq - se * mean_e) / (dM - 1.0);
+    val[0] = sabs / dM;
+    val[1] = 2.0 * dot / (dM * (dM - fair));
+    val[2] = var;
+    val[3] = mean_d * mean_d - var / dM;
+    val[4] = mean_d * mean_d;
   }
 
   __device__ __forceinline__ static void stats64(const S1Args& a, float (&xm)[MP], const double td, const double pair_total,
@@ -704,6 +764,7 @@ int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo
       return fail(WBX_ERR_INVALID, "the LDS-tiled pair-form diagnostic exists for M = 51 only");
     }
   }
+  if (algo == WBX_ENS_SKIPNA_SORT) return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_SKIPNA_SORT>>(ctx, plan, a, map);
   return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_PAIRWISE>>(ctx, plan, a, map);
 }
 
