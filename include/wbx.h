@@ -91,7 +91,9 @@ typedef enum wbx_ens_algo {
 #define WBX_FLAG_SKIPNA 2u /* NaN statistic values are dropped and counted out: aggregation.py:353-355 */
 #define WBX_FLAG_FAIR   4u /* ensemble: fair CRPS spread (divide by M(M-1)):   probabilistic.py:239,247 */
 #define WBX_FLAG_SKIPNA_ENS 8u /* ensemble: NaN members are missing members (skipna_ensemble=True), per-point
-                                  ensemble size = count of non-NaN members: probabilistic.py:143-145,206-216,303-336 */
+                                  ensemble size = count of non-NaN members: probabilistic.py:143-145,206-216,303-336.
+                                  float32, M <= 64: members in registers, NaN -> +inf, sorted, rank form over the first n
+                                  (either `algo`: the same number); otherwise the pair form over members re-read from memory */
 
 #define WBX_MAX_INPUTS 4 /* 0 = predictions, 1 = targets, 2 = climatology, 3 = mask(uint8) */
 
