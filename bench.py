@@ -984,7 +984,7 @@ def config5_leg(env):
   sub = time_chunks.TimeChunks(init_times[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
   nsub = len(distributed_shard(sub, env))
   from weatherbenchx_amd import engine as _engine
-  fused = _engine.FUSE_DET_SPECTRA and env.layout == 'lon_fastest' and env.nlon == 1440
+  fused = _engine.FUSE_DET_SPECTRA and env.nlon == 1440 and (env.layout == 'lon_fastest' or _engine.FUSE_DET_SPECTRA_LATFAST)
   pass_s = {'z: deterministic + spectra of p and t' + (' (ONE sweep: wbx_det_spectrum)' if fused else ' (separate launches)'):
                 run_some(sub, ('deterministic', 'spectra')) / max(nsub, 1) * 1e3,
             'deterministic alone': run_some(sub, ('deterministic',)) / max(nsub, 1) * 1e3,
@@ -1011,7 +1011,7 @@ def config5_leg(env):
           'seconds_rank0': rank_s, 'ms_per_chunk': dt / ninit * 1e3, 'ms_per_chunk_rank0': rank_s / max(len(distributed_shard(times, env)), 1) * 1e3,
           'ms_per_chunk_by_pass_rank0': {k: round(v, 3) for k, v in pass_s.items()},
           'ms_per_chunk_by_pass_note': 'subsets of the evaluations as their own jobs on a sixth of the chunks, outside the timed region',
-          'z_bytes_per_point': 12, 'fused_det_spectra': bool(fused),
+          'z_bytes_per_point': 12, 'z_traffic_bytes_per_point': 12 if fused else 20, 'fused_det_spectra': bool(fused),
           'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),
