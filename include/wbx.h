@@ -394,9 +394,10 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
  * |dS_k| <= 2e-6 S_k + 1e-6 sqrt(S'_max S_k), S'_max = max_{k >= 1} S_k, and S_0 to 1e-6, per row against float64 numpy.fft
  * (tests/test_spectra.py::bound_1440); measured on N(0, 1) and N(280, 1) rows: median 1.4e-7, and 1e-7 for every wavenumber
  * after a mean over 200 rows (profiles/r03_spectrum_demean_ab.txt; without the shift the N(280, 1) rows came out at 1e-5
- * in the median and 6e-5 after that mean).  Rows of up to 256 points (the generic fused kernel's one-wave teams: the 64- and
- * 240-point grids of the public configs) are shifted the same way and held to the same bound.  Longer rows other than 1440
- * points (teams of two or four waves) and the rocFFT route transform the rows as they are: |dS_k| <= 2e-5 S_k + 4e-7
+ * in the median and 6e-5 after that mean).  Every other length the generic fused kernel takes (even, 2/3/5-smooth half length,
+ * <= 2048 points: the 64- and 240-point grids of the public configs on one-wave teams, 360 / 720 / 1024 points on teams of two
+ * or four waves) is shifted the same way and held to the same bound.  The rocFFT route (odd lengths, prime factors > 5)
+ * transforms the rows as they are: |dS_k| <= 2e-5 S_k + 4e-7
  * sqrt(S_max S_k) with S_max including the mean. */
 int wbx_zonal_spectrum(wbx_ctx* ctx, const float* field, int64_t lon_stride, int64_t row_stride, int64_t nrows,
                        int32_t nlon, const int32_t* group, const double* scale, int32_t ngroup,

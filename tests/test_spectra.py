@@ -234,12 +234,16 @@ def test_1440_point_rows_random_shapes_and_reductions(backend, seed):
 
 
 @pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
-@pytest.mark.parametrize('nlon,nlat,mean', [(64, 32, 0.0), (64, 32, 280.0), (240, 121, 0.0), (240, 121, 280.0), (256, 9, 5.0e4)])
+@pytest.mark.parametrize('nlon,nlat,mean', [(64, 32, 0.0), (64, 32, 280.0), (240, 121, 0.0), (240, 121, 280.0), (256, 9, 5.0e4),
+                                            (360, 181, 280.0), (360, 33, 0.0), (512, 7, 5.0e4), (720, 37, 280.0), (1024, 5, 5.0e4),
+                                            (2048, 3, 280.0)])
 def test_short_rows_are_shifted_by_their_mean_too(backend, layout, nlon, nlat, mean):
-  """The other grids of the public configs (64 x 32 and 240 x 121; 256 = the longest row of a one-wave team) go through the
-  generic fused kernel, whose one-wave teams shift a row by the mean of its even points in front of the fp32 transform like
-  the 1440-point kernels (csrc/wbx_spectrum.hip, team_pass): the same bound against the float64 oracle whatever the mean --
-  N(280, 1) like a temperature field, N(5e4, 1) like geopotential --, odd row counts (a lone last row), both layouts."""
+  """The other grids of the public configs (64 x 32 and 240 x 121; 256 = the longest row of a one-wave team) and the lengths
+  that run on teams of two or four waves (1 degree = 360, 0.5 degree = 720, 512 / 1024 / 2048: first pass with and without
+  the register prefetch) go through the generic fused kernel, which shifts a row by the mean of its even points in front of
+  the fp32 transform like the 1440-point kernels (csrc/wbx_spectrum.hip, team_pass / team_total_f32): the same bound against
+  the float64 oracle whatever the mean -- N(280, 1) like a temperature field, N(5e4, 1) like geopotential --, odd row counts
+  (a lone last row), both layouts."""
   rng = np.random.default_rng(nlon + nlat)
   lat, lon = np.linspace(-85, 85, nlat), np.arange(nlon) * (360.0 / nlon)
   dims = ('lead_time', 'latitude', 'longitude') if layout == 'lon_fastest' else ('lead_time', 'longitude', 'latitude')

@@ -234,6 +234,30 @@ __device__ __forceinline__ void team_sync() {
     __syncthreads();
 }
 
+// Sum of a per-thread (row A, row B) pair over the team; every thread gets it.  Teams of 2 / 4 waves exchange their wave sums
+// through the first bytes of the team's transform buffer, which is idle between the last read of the previous row pair (a
+// team_sync closes it) and the first pass's stores: two more block barriers per row pair.  All threads of the team must call.
+template <int G>
+__device__ __forceinline__ v2 team_total_f32(v2 s, v4* buf, int tid) {
+  const v2 w = {wave_sum_uniform_f32(s.x), wave_sum_uniform_f32(s.y)};
+  if constexpr (G == 64) {
+    return w;
+  } else {
+    float2* sc = reinterpret_cast<float2*>(buf);
+    if ((tid & 63) == 0) sc[tid >> 6] = make_float2(w.x, w.y);
+    __syncthreads();
+    v2 tot = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < G / 64; ++i) {
+      const float2 q = sc[i];
+      tot.x += q.x;
+      tot.y += q.y;
+    }
+    __syncthreads();  // ... before anybody stores the first pass's outputs over them
+    return tot;
+  }
+}
+
 // One in-place pass of radix R over the team's n2 points (two rows each); thread t owns butterflies t, t + G, ... (at
 // most NB of them).  The passes are the TRANSPOSED Stockham flow graph (the DFT matrix is symmetric, so running the
 // transposed passes in reverse order is the same transform): butterfly j = q * ns + k gathers its inputs at stride ns,
@@ -242,9 +266,9 @@ __device__ __forceinline__ void team_sync() {
 // a read, and an N-way bank conflict multiplies that), so the strided side is the read.  ns shrinks from n2 / R to 1.
 // FIRST (ns == nb): the inputs k + t * nb are taken straight from the two rows in global memory (coalesced), the raw
 // rows never visit the LDS.  All LDS reads precede all writes.
-// FIRST on a one-wave team (G == 64) with WBX_SPECTRUM_DEMEAN: the rows are shifted by the mean of their even points (the
-// real parts of the packed row: every one of them is in some lane's registers here) before the first butterfly; the shift
-// comes back in *msh for the k = 0 term of the unpack.
+// FIRST with WBX_SPECTRUM_DEMEAN: the rows are shifted by the mean of their even points (the real parts of the packed row:
+// every one of them is in some thread's registers here; teams of 2 / 4 waves add their wave sums through the LDS,
+// team_total_f32) before the first butterfly; the shift comes back in *msh for the k = 0 term of the unpack.
 template <int R, int NB, int G, bool FIRST>
 __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __restrict__ tw, int n2, int ns, int toff,
                                           float inv_ns, int tid, const v2* __restrict__ rowa,
@@ -276,7 +300,7 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
       }
     }
   }
-  if constexpr (FIRST && G == 64 && WBX_SPECTRUM_DEMEAN) {
+  if constexpr (FIRST && WBX_SPECTRUM_DEMEAN) {
     v2 sum = {0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -286,7 +310,7 @@ __device__ __forceinline__ void team_pass(v4* __restrict__ buf, const float2* __
       }
     }
     const float inv_n2 = 1.0f / (float)n2;
-    const v2 m = {wave_sum_uniform_f32(sum.x) * inv_n2, wave_sum_uniform_f32(sum.y) * inv_n2};
+    const v2 m = team_total_f32<G>(sum, buf, tid) * inv_n2;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       if (tid + G * i < nb) {
@@ -424,12 +448,25 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
     const v2* rowa = reinterpret_cast<const v2*>(field + r * row_stride);
     const v2* rowb = reinterpret_cast<const v2*>(field + (two ? r + 1 : r) * row_stride);
-    v2 msh = {0.f, 0.f};  // the shift of rows A and B (one-wave teams, WBX_SPECTRUM_DEMEAN), team-uniform
+    v2 msh = {0.f, 0.f};  // the shift of rows A and B (WBX_SPECTRUM_DEMEAN), team-uniform
     if constexpr (R0 > 0) {
       C2 v[RP];
 #pragma unroll
       for (int t = 0; t < RP; ++t) v[t] = {{pa[t].x, two ? pb[t].x : 0.f}, {pa[t].y, two ? pb[t].y : 0.f}};
       if (r + 2 < r1) fetch(r + 2);
+      if constexpr (WBX_SPECTRUM_DEMEAN) {  // the rows shifted by the mean of their even points, as in team_pass
+        v2 sum = {0.f, 0.f};
+        if (tid < nb0) {
+#pragma unroll
+          for (int t = 0; t < RP; ++t) sum += v[t].re;
+        }
+        msh = team_total_f32<G>(sum, buf, tid) * (1.0f / (float)n2);
+#pragma unroll
+        for (int t = 0; t < RP; ++t) {
+          v[t].re -= msh;
+          v[t].im -= msh;
+        }
+      }
       if (tid < nb0) {
         butterfly<RP>(v);
         if (nb0 > 1) {  // ns == nb0, k == tid; the first pass's twiddles open the packed table
@@ -465,7 +502,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
         const C2 x = cadd(e, wo), xm = csub(e, wo);
         const v2 p = x.re * x.re + x.im * x.im, pm = xm.re * xm.re + xm.im * xm.im;  // (row A, row B)
         double pxd = (double)p.x, pyd = (double)p.y;
-        if constexpr (G == 64 && R0 == 0 && WBX_SPECTRUM_DEMEAN) {
+        if constexpr (WBX_SPECTRUM_DEMEAN) {
           if (k == 0) {  // x.re = F'_0 of the shifted rows, x.im = 0: F_0 = F'_0 + n m, formed and squared in fp64
             const double fa = (double)x.re.x + (double)fs.n * (double)msh.x, fb = (double)x.re.y + (double)fs.n * (double)msh.y;
             pxd = fa * fa;
