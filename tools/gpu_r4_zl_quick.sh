@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: the latitude-fastest fused det + spectra kernel: parity of the entry point, then the configs[3] composite (lat-fastest)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+export WBX_FUSE_DET_SPECTRA_LATFAST=1
 timeout 600 python -m pytest tests/test_gpu_round4.py -m gpu -x -q -k "slabs or latitude_fastest_chunks" 2>&1 | tail -3
 for env in "$@" ""; do
   [ -z "$env" ] && [ $# -gt 0 ] && break

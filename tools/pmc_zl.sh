@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/pmc_zl
 rm -rf $OUT; mkdir -p $OUT
-export WBX_BENCH_COMPOSITE_RUNS=2
+export WBX_BENCH_COMPOSITE_RUNS=2 WBX_FUSE_DET_SPECTRA_LATFAST=1
 run() { timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$PASS -o pmc --output-format csv -- python $REPO/bench.py --legs spectrum --no-cpu --no-config5 --steps 2 --warmup 1 --layout lat_fastest --prewarm-ms 0 > $OUT/$PASS.log 2>&1; }
 PASS=a run FETCH_SIZE
 PASS=d run TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE

@@ -989,6 +989,7 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
   const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
   if (per_xcd < nlocal) nlocal = (int)per_xcd;
   WBX_REQUIRE(runs < (int64_t)1 << 30, "launch too large");
+#ifdef WBX_DIAGNOSTICS  // (knock-out instantiations, wrong results by design: `make diag` only, like WBX_SPECTRUM_KNOCK)
   static const int knock = getenv("WBX_ZL_KNOCK") ? atoi(getenv("WBX_ZL_KNOCK")) : 0;  // diagnostic, wrong results
 #define WBX_ZL_LAUNCH(KN)                                                                                                      \
   hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true, KN>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab, \
@@ -1007,6 +1008,7 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
     return 0;
   }
 #undef WBX_ZL_LAUNCH
+#endif
   if (has_c)
     hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab,
                        (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group,
