@@ -21,11 +21,14 @@ print(f'last level-2 arrival             : {np.nanmax(us[:, 5]):8.1f}')
 print(f'last level-2 done                : {np.nanmax(us[:, 6]):8.1f}')
 print(f'last cell written                : {np.nanmax(us[:, 7]):8.1f}')
 d = lambda a, b: us[:, b] - us[:, a]
-for name, a, b in (('sweep', 0, 1), ('flush', 1, 2), ('arrive1 (store ack + atomic)', 2, 3), ('level 1', 3, 4), ('arrive2', 4, 5), ('level 2', 5, 6),
+for name, a, b in (('prologue (decode, table pointers, pre-zero)', 0, 8), ('row lookups + first issue', 8, 9), ('first row in flight', 9, 10),
+                   ('first row -> second row landed', 10, 11), ('sweep', 0, 1), ('flush', 1, 2), ('arrive1 (store ack + atomic)', 2, 3), ('level 1', 3, 4), ('arrive2', 4, 5), ('level 2', 5, 6),
                    ('arrive3 + level 3', 6, 7)):
   x = d(a, b)
   x = x[~np.isnan(x)]
-  print(f'{name:32s} n {x.size:6d}  median {np.median(x):8.2f}  mean {x.mean():8.2f}  p95 {np.percentile(x, 95):8.2f}  max {x.max():8.2f} us')
+  if b >= ns:
+    continue
+  print(f'{name:44s} n {x.size:6d}  median {np.median(x):8.2f}  mean {x.mean():8.2f}  p95 {np.percentile(x, 95):8.2f}  max {x.max():8.2f} us')
 # waves in flight over time
 st, en = us[ok, 0], np.nanmax(us[ok], axis=1)
 for q in np.linspace(0, np.nanmax(us), 12):

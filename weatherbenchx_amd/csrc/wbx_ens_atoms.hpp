@@ -117,7 +117,7 @@ struct EnsAtomsArgs {
 #endif
 #if WBX_EA_PROF
 #define WBX_EA_STAMP(slot) \
-  do { if (lane == 0) e.prof[(cell * npatch + patch) * 8 + (slot)] = wall_clock64(); } while (0)
+  do { if (lane == 0) e.prof[(cell * npatch + patch) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define WBX_EA_STAMP(slot) do {} while (0)
 #endif
@@ -302,14 +302,20 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
     }
   };
 
+  WBX_EA_STAMP(8);  // prologue done
   if (nrows > 0) {
     resolve_ahead();
     issue();
     resolve_ahead();
   }
+  WBX_EA_STAMP(9);  // first row asked for
   for (int i = 0; i < nrows; ++i) {
     typename Op::Regs r;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if WBX_EA_PROF
+    if (i == 0) WBX_EA_STAMP(10);  // first row has landed
+    if (i == 1) WBX_EA_STAMP(11);  // ... the second
+#endif
 #pragma unroll
     for (int m = 0; m < NLDS; ++m) r.xm[m] = (EXACT || m < M) ? stage[m][lane] : INFINITY;
 #pragma unroll
@@ -592,7 +598,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const int64_t grid = patch_grid<1>(g);
   e.prof = nullptr;
 #if WBX_EA_PROF
-  const size_t prof_bytes = (size_t)g.nblocks * 8 * sizeof(unsigned long long);
+  const size_t prof_bytes = (size_t)g.nblocks * 16 * sizeof(unsigned long long);
   WBX_HIP(hipMalloc(reinterpret_cast<void**>(&e.prof), prof_bytes));
   WBX_HIP(hipMemsetAsync(e.prof, 0, prof_bytes, ctx->stream));
 #endif
@@ -608,7 +614,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
     WBX_HIP(hipMemcpy(host, e.prof, prof_bytes, hipMemcpyDeviceToHost));
     if (const char* path = getenv("WBX_EA_PROF_DUMP")) {
       if (FILE* f = fopen(path, "wb")) {
-        const long long hdr[4] = {(long long)g.ncell, (long long)g.nrs, (long long)g.nxt, 8};
+        const long long hdr[4] = {(long long)g.ncell, (long long)g.nrs, (long long)g.nxt, 16};
         fwrite(hdr, sizeof(hdr), 1, f);
         fwrite(host, 1, prof_bytes, f);
         fclose(f);
