@@ -67,6 +67,8 @@ def parse():
   ap.add_argument('--ens-slices', type=int, default=8)
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
+  ap.add_argument('--pce-mask', choices=['both', '0', '1'], default='both',
+                  help='public_chunk_ens: run without / with the mask coordinate only (profiling: one kind of launch per traced process)')
   ap.add_argument('--config5-inits', type=int, default=366)
   ap.add_argument('--cpu-workers', type=int, default=0, help='worker processes of the multi-core CPU baseline (0 = os.cpu_count())')
   ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
@@ -1142,8 +1144,9 @@ def main():
     if want('public_chunk'):
       result['public_chunk'] = public_chunk_leg(env)
     if want('public_chunk_ens'):
-      result['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False)
-      result['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
+      result['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False) if args.pce_mask != '1' else {}
+      if args.pce_mask != '0':
+        result['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
     if want('spectrum'):
       result['spectrum'] = spectrum_leg(env)
     if want('lat_fastest') and args.layout == 'lon_fastest':

@@ -17,18 +17,22 @@ timeout 300 $T -d $O/trace_configs1_lat -o r1 -- $B --steps 10 --warmup 3 --legs
 timeout 300 $T -d $O/trace_ensemble -o r1 -- $B --steps 10 --warmup 3 --legs ensemble --no-cpu --no-config5 > $O/trace_ensemble.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk --no-cpu --no-config5 > $O/trace_public_chunk.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
+# (one kind of launch per traced process: the launch with a mask coordinate writes twelve lanes instead of six and folds the mask
+#  into the atom ids first -- its kernel of the same name is ~12 % longer, and one average over both says nothing)
+timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
+timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
+timeout 300 $T -d $O/trace_public_chunk_ens_mask -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 > $O/trace_public_chunk_ens_mask.json 2> /dev/null
+timeout 300 $T -d $O/trace_public_chunk_ens_mask_lat -o r1 -- $B --steps 10 --warmup 3 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_mask_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 > $O/trace_spectrum.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum_lat -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 --layout lat_fastest > $O/trace_spectrum_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_config5 -o r1 -- $B --legs config5 --no-cpu --config5-inits 48 > $O/trace_config5.json 2> /dev/null
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 for leg in main configs1 ensemble public_chunk public_chunk_ens spectrum; do
-  timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
-  timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
+  timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
+  timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
 done
 for leg in main configs1 public_chunk public_chunk_ens spectrum; do
-  timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_${leg}_lat -o r1 -- $B --steps 2 --warmup 1 --legs $leg --no-cpu --no-config5 --prewarm-ms 0 --layout lat_fastest > /dev/null 2>&1
+  timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_${leg}_lat -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 --layout lat_fastest > /dev/null 2>&1
 done
 DBS=$(ls $O/*/r1_results.db 2>/dev/null)
 python $R/profiles/summarize_rocpd.py $DBS > $O/summary.txt 2> $O/summary.err
