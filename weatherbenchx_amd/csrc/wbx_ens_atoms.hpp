@@ -88,6 +88,14 @@ __device__ __forceinline__ T ld_dev(const T* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the wave's LDS stores above are complete (and visible to its own loads below): what __syncthreads() gave a one-wave block,
+// without the block barrier that the waves of a wider block -- each on its own way through the finish levels -- must not meet at
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // a load that other XCDs' stores are visible to, as a plain (not atomic) instruction: buffer_load ... sc1
 __device__ __forceinline__ double ld_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_offset) {
   typedef unsigned int u2 __attribute__((ext_vector_type(2)));
@@ -124,21 +132,33 @@ struct EnsAtomsArgs {
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
+// WPB waves per block: WPB ADJACENT x tiles of one (cell, row split), one wave each -- independent (no barrier), but they start
+// together and walk the same rows, so the 128-byte lines two tiles of a 721-point row share are asked for within a row or two
+// of each other and the second request finds them in the CU's L1 / the XCD's L2 (alone, the neighbouring tile is another wave
+// somewhere on the XCD, up to a patch length away in time, and the line has left the L2 by then: FETCH_SIZE 1.28 x the
+// algorithmic bytes on the latitude-fastest public chunk).  Used with !NT (rows that are not whole lines), like det_atoms_kernel.
+#ifndef WBX_ENS_ATOMS_RAGGED_WPB
+#define WBX_ENS_ATOMS_RAGGED_WPB 4
+#endif
 template <int MP, bool EXACT, bool NT>
-__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+__global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB), WBX_ENS_PIPE_WAVES)
+ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+  constexpr int WPB = NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB;
   using Op = EnsOpF32<MP, EXACT, WBX_ENS_SORT>;
   constexpr int NQ = ENS_ATOMS_NQ, NOUT = ENS_ATOMS_NOUT;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
   constexpr int NREG = MP - NLDS;                                        // members prefetched into VGPRs
   constexpr int NST = NLDS < 48 ? 48 : NLDS;                             // (the level-1 finisher borrows 12 KB of it)
   constexpr int NONE = 255;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[NST * 256];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB][NST * 256];
+  const int wave_in_block = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  unsigned char* const lds_raw = lds_all[wave_in_block];  // (every wave works in its own slice: no block-level sync anywhere)
   float(*stage)[64] = reinterpret_cast<float(*)[64]>(lds_raw);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int M = EXACT ? MP : a.M;
   int64_t cell;
   int xt, rs;
-  if (!patch_decode<1>(g, cell, xt, rs)) return;
+  if (!patch_decode<WPB>(g, cell, xt, rs)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t A = cell / g.nBk;
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
@@ -443,7 +463,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
       }
       wv[p] = (p < gn && lane < ATOM_MAX) ? g.words[(bk * npatch + k0 + p) * ATOM_MAX + lane] : 0ull;
     }
-    __syncthreads();
+    wave_lds_order();
 #pragma unroll
     for (int p = 0; p < ENS_ATOMS_G1; ++p) {
 #pragma unroll
@@ -451,7 +471,7 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_atoms_kernel(S1Arg
         if (lane + 64 * jj < TR * NQ) ltab[p * (TR * NQ) + lane + 64 * jj] = v[p][jj];
       if (lane < ATOM_MAX) wl[p * ATOM_MAX + lane] = wv[p];
     }
-    __syncthreads();
+    wave_lds_order();
   }
   const double inv_m = 1.0 / (double)M;
   double sum[NOUT2];
@@ -595,7 +615,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const bool ragged_lines = (plan->nx * plan->xstride[0] * 4) % 128 != 0 || plan->xstride[0] != 1;
   const bool nt = nt_env >= 0 ? nt_env != 0 : !ragged_lines;
   g.order = order_env >= 0 ? order_env : (ragged_lines ? 1 : 0);
-  const int64_t grid = patch_grid<1>(g);
+  const int64_t grid = nt ? patch_grid<1>(g) : patch_grid<WBX_ENS_ATOMS_RAGGED_WPB>(g);
   e.prof = nullptr;
 #if WBX_EA_PROF
   const size_t prof_bytes = (size_t)g.nblocks * 16 * sizeof(unsigned long long);
@@ -605,7 +625,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   if (nt)
     hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
   else
-    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
+    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64 * WBX_ENS_ATOMS_RAGGED_WPB), 0, ctx->stream, a, g, e);
   WBX_HIP(hipGetLastError());
 #if WBX_EA_PROF
   {
