@@ -17,12 +17,14 @@ timeout 300 $T -d $O/trace_configs1_lat -o r1 -- $B --steps 10 --warmup 3 --legs
 timeout 300 $T -d $O/trace_ensemble -o r1 -- $B --steps 10 --warmup 3 --legs ensemble --no-cpu --no-config5 > $O/trace_ensemble.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 > $O/trace_public_chunk.json 2> /dev/null
 timeout 300 $T -d $O/trace_public_chunk_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_lat.json 2> /dev/null
+# (WBX_ALTERNATE_STREAMS=0: the chunk loop deals ensemble launches to two streams, so consecutive kernels overlap by a few tens of
+#  microseconds and each one's traced duration is longer than its share of the GPU -- on one stream the trace shows the kernel alone)
 # (one kind of launch per traced process: the launch with a mask coordinate writes twelve lanes instead of six and folds the mask
 #  into the atom ids first -- its kernel of the same name is ~12 % longer, and one average over both says nothing)
-timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_ens_mask -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 > $O/trace_public_chunk_ens_mask.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_ens_mask_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_mask_lat.json 2> /dev/null
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 > $O/trace_public_chunk_ens_mask.json 2> /dev/null
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_mask_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 > $O/trace_spectrum.json 2> /dev/null
 timeout 300 $T -d $O/trace_spectrum_lat -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 --layout lat_fastest > $O/trace_spectrum_lat.json 2> /dev/null
 timeout 300 $T -d $O/trace_config5 -o r1 -- $B --legs config5 --no-cpu --config5-inits 48 > $O/trace_config5.json 2> /dev/null
