@@ -476,3 +476,31 @@ def test_random_spectrum_frames(monkeypatch, seed):
   sws, sw, out_dims = O.aggregate(per_row, rd, reduce_dims, weights=oracle_w)
   np.testing.assert_allclose(state.sum_weighted_statistics.transpose(*out_dims).values, sws, rtol=1e-6, atol=1e-9)
   np.testing.assert_allclose(state.sum_weights.transpose(*out_dims).values, sw, rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
+def test_random_ensemble_grids_under_region_bins(backend, seed):
+  """The one-pass binned ensemble kernel (wbx_ens_binned) on random grids: latitude / longitude counts that are and are not
+  multiples of 32 and 64 (whole-line rows on one-wave blocks, ragged rows on four-wave blocks), enough rows for the tapered
+  row splits and too few for them, 2-51 members, the three recorded dim orders, with and without a (latitude, longitude) mask
+  coordinate (twin atoms), random land / sea patterns: every bin of all five lanes against the float64 oracle, one launch."""
+  import test_ens_binned as EB
+  from weatherbenchx_amd import binning, weighting
+  rng = np.random.default_rng(31000 + seed)
+  layout = str(rng.choice(sorted(EB.LAYOUTS)))
+  m = int(rng.choice([2, 5, 16, 33, 50, 51]))
+  nlat = int(rng.choice([19, 33, 64, 91, 181]))
+  nlon = int(rng.choice([36, 64, 90, 128, 145, 256]))
+  nlead = int(rng.integers(1, 4))
+  land = rng.random((nlat, nlon)) > rng.uniform(0.2, 0.8)
+  with_mask = bool(rng.random() < 0.5)
+  valid = (rng.random((nlat, nlon)) > 0.25) if with_mask else None
+  p, t, pv, tv, lat, lon = EB.make_case(layout, m, nlat, nlon, nlead, seed=seed, mask=valid, ninit=int(rng.integers(1, 3)))
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(EB.REGIONS, land_sea_mask=lsm)], masked=True)
+  stats = EB.lane_statistics()
+  state, log = EB.run(stats, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], (layout, m, nlat, nlon, log)
+  EB.check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=valid)
