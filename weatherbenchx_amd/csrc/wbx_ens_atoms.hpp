@@ -29,6 +29,7 @@
 // Everything else (dense weights, time-dependent masks, skipna, skipna_ensemble, float64 members, M > 64) stays on the
 // two-stage route.
 #pragma once
+#include <type_traits>
 #include "wbx_aidm.hpp"
 #include "wbx_ens_impl.hpp"
 #include "wbx_patch.hpp"
@@ -414,16 +415,25 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   };
   // sum of n consecutive records at src (index order); sc1 BUFFER loads: the compiler keeps a batch of them in flight, where
   // it waits for every atomic load on its own (16 records = 96 loads one after the other took 18 us of the kernel's tail)
-  auto add_records = [&](const double* src, int n, double (&sum)[NOUT2]) {
+  // (the number of lanes is a compile-time constant of each flavour: under the run-time `twin` test the loads of the upper six
+  //  lanes were issued and waited for one by one -- 192 of them in a level-2 sum: 28-100 us of a masked launch's tail,
+  //  tools/gpu_r4_ens_prof_mask.sh)
+  auto add_records_n = [&](auto nl_tag, const double* src, int n, double (&sum)[NOUT2]) {
+    constexpr int NL = decltype(nl_tag)::value;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int l = 0; l < NOUT2; ++l) sum[l] = 0.0;
 #pragma unroll 4
     for (int q = 0; q < n; ++q) {
 #pragma unroll
-      for (int l = 0; l < NOUT2; ++l)
-        if (l < NOUT || twin) sum[l] += ld_sc1(rs, (uint32_t)((q * NP + l * 64 + lane) * 8));
+      for (int l = 0; l < NL; ++l) sum[l] += ld_sc1(rs, (uint32_t)((q * NP + l * 64 + lane) * 8));
     }
+  };
+  auto add_records = [&](const double* src, int n, double (&sum)[NOUT2]) {
+    if (twin)
+      add_records_n(std::integral_constant<int, NOUT2>{}, src, n, sum);
+    else
+      add_records_n(std::integral_constant<int, NOUT>{}, src, n, sum);
   };
   auto put_record = [&](double* dst, const double (&sum)[NOUT2]) {
 #pragma unroll
