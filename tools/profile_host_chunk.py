@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.argv = (['bench.py'] + (['--small'] if '--small' in sys.argv else []) +  # --small: tiny grids = the Python cost alone
             ['--legs', os.environ.get('WBX_PROFILE_LEG', 'public_chunk'), '--no-cpu', '--no-config5', '--steps', '300', '--warmup', '20',
-             '--layout', 'lat_fastest' if 'lat_fastest' in sys.argv else 'lon_fastest'])
+             '--layout', 'lat_fastest' if 'lat_fastest' in sys.argv else 'lon_fastest'] + os.environ.get('WBX_PROFILE_ARGS', '').split())
 import bench  # noqa: E402
 
 prof = cProfile.Profile()

@@ -27,8 +27,37 @@ ENS_LANE = {'CRPSSkill': 0, 'CRPSSpread': 1, 'EnsembleVariance': 2, 'UnbiasedEns
             'EnsembleMeanSquaredError': 4}
 
 
+_frame_memo: list = [None]  # (weakref p, weakref t, mutations, frame without drop_dims): the last (p, t) frame that was computed
+
+
 def _stat_frame(arrays: Sequence[xr.DataArray], drop_dims=()):
   """dims / sizes / coords of the broadcast of `arrays` (what `a - b` would carry), without computing it."""
+  if len(arrays) == 2:
+    # `_aligned(p, t)` checks the frame of a pair and the FusedGroup built right after asks for it again (minus the member
+    # dim): one walk over the coordinates serves both
+    memo = _frame_memo[0]
+    a, b = arrays
+    muts = (a.__dict__.get('_mutations', 0), b.__dict__.get('_mutations', 0))
+    if memo is not None and memo[0]() is a and memo[1]() is b and memo[2] == muts:
+      dims, sizes, coords = memo[3]
+    elif drop_dims:
+      return _stat_frame_walk(arrays, drop_dims)  # (nobody has looked at the whole frame of this pair: it may not even exist)
+    else:
+      dims, sizes, coords = _stat_frame_walk(arrays)
+      _frame_memo[0] = (weakref.ref(a), weakref.ref(b), muts, (dims, sizes, coords))
+    if not drop_dims:
+      return dims, dict(sizes), dict(coords)
+    drop = set(drop_dims)
+    if drop & set(dims):
+      # a dropped dim changes which coordinates collide: walk again with it (the member dim is on p only: not the case here)
+      if any(d in b.dims for d in drop) or any(d in a.dims and d in b.dims for d in drop):
+        return _stat_frame_walk(arrays, drop_dims)
+    return (tuple(d for d in dims if d not in drop), {d: n for d, n in sizes.items() if d not in drop},
+            {k: v for k, v in coords.items() if not (set(v[0]) & drop)})
+  return _stat_frame_walk(arrays, drop_dims)
+
+
+def _stat_frame_walk(arrays: Sequence[xr.DataArray], drop_dims=()):
   dims, sizes = [], {}
   for a in arrays:
     for d, n in a.sizes.items():
@@ -499,7 +528,12 @@ def first_member(p: xr.DataArray, ensemble_dim: str) -> xr.DataArray:
   probabilistic configuration with a mask.)"""
   cache = p.__dict__.setdefault('_wbx_member0', {})
   if ensemble_dim not in cache:
-    cache[ensemble_dim] = p.isel({ensemble_dim: 0}, drop=True)
+    # (the general isel walks every axis and every coordinate: ~40 us per chunk of the masked public configuration; a view of
+    #  member 0 needs one slice and the coordinates that do not live on the member dim)
+    ax = p.dims.index(ensemble_dim)
+    data = p.data[(slice(None),) * ax + (0,)]
+    coords = {k: v for k, v in p._coords.items() if ensemble_dim not in v[0]}  # pylint: disable=protected-access
+    cache[ensemble_dim] = xr.DataArray._assemble(data, p.dims[:ax] + p.dims[ax + 1:], coords, name=p.name, attrs=p.attrs)  # pylint: disable=protected-access
   return cache[ensemble_dim]
 
 
