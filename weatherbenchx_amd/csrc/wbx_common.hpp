@@ -22,6 +22,7 @@ struct wbx_ctx {
   size_t s2_scratch_size = 0;
   void* aidm_scratch = nullptr;  // wbx_det_binned: atom ids with the validity mask folded in (one byte per point)
   size_t aidm_scratch_size = 0;
+  void* atoms_clean = nullptr;  // std::set<const void*>*: prepared atom tables (wbx_binned_atoms) without an overflowing patch
   void* patch_counters = nullptr;  // wbx_ens_binned: arrival counters of its in-kernel sums over patches (uint32, kept zero)
   size_t patch_counters_size = 0;
   hipEvent_t* marks = nullptr;  // wbx_mark: timing events, created on demand and recycled by wbx_marks_reset

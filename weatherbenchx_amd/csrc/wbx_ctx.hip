@@ -1,6 +1,8 @@
 // Context, memory helpers and HIP-event timers of libwbx_hip.so (see include/wbx.h).
 #include <cstdlib>
 
+#include <set>
+
 #include "wbx_common.hpp"
 
 namespace wbx {
@@ -69,6 +71,7 @@ extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
   if (ctx->s2_scratch) (void)hipFree(ctx->s2_scratch);
   if (ctx->aidm_scratch) (void)hipFree(ctx->aidm_scratch);
   if (ctx->patch_counters) (void)hipFree(ctx->patch_counters);
+  delete static_cast<std::set<const void*>*>(ctx->atoms_clean);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   for (int i = 0; i < ctx->marks_made; ++i) (void)hipEventDestroy(ctx->marks[i]);
