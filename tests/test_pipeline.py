@@ -292,3 +292,39 @@ def test_ensemble_chunk_loop_with_feeder_and_two_launch_streams(backend):
   for k in want:
     xr.assert_allclose(serial[k], want[k], rtol=1e-9, atol=1e-12, check_dim_order=False)
     xr.assert_allclose(fed[k], serial[k], rtol=1e-12, atol=0, check_dim_order=False)
+
+
+def test_slab_detection_for_the_latitude_fastest_fused_sweep():
+  """engine._fused_slab_rows: a plan whose x is the strided longitude qualifies for wbx_det_spectrum_slabs only when its keys
+  are whole slabs of ADJACENT rows in every input and the climatology slice does not change inside a slab (host logic, no
+  device)."""
+  from weatherbenchx_amd import engine, planner
+  nlead, nlev, nlon, nlat = 2, 3, 1440, 11
+  dims = ('init_time', 'lead_time', 'level', 'longitude', 'latitude')
+  sizes = dict(zip(dims, (1, nlead, nlev, nlon, nlat)))
+
+  def layout(order, shape):
+    strides, acc = {}, 1
+    for d, n in zip(reversed(order), reversed(shape)):
+      strides[d] = acc
+      acc *= n
+    return planner.InputLayout(strides=strides, itemsize=4, base_alignment=256)
+  lay = layout(dims, [sizes[d] for d in dims])
+  clay = layout(('slot', 'level', 'longitude', 'latitude'), [4, nlev, nlon, nlat])
+  table = (np.array([[3, 1]]) * clay.strides['slot']).astype(np.int64)
+  gather = planner.GatherSpec(dims=('init_time', 'lead_time'), table=table)
+  entry = {'row_dims': ('init_time', 'lead_time', 'level', 'latitude'), 'row_shape': (1, nlead, nlev, nlat), 'dev': {}}
+  plan = planner.build_s1_plan(dims, sizes, [lay, lay, clay, None], ['init_time', 'latitude', 'longitude'], wdep_dims=['latitude'],
+                               gather=gather, force_x_dim='longitude', allow_vec4=False)
+  assert plan.nx == nlon and plan.xstride[0] == nlat and plan.key_dims == ('lead_time', 'level', 'latitude')
+  assert engine._fused_slab_rows(plan, entry, 3) == nlat
+  # targets stored longitude-fastest: their rows of a slab are 1440 elements apart -> no slabs
+  tlay = layout(('init_time', 'lead_time', 'level', 'latitude', 'longitude'), [1, nlead, nlev, nlat, nlon])
+  plan2 = planner.build_s1_plan(dims, sizes, [lay, tlay, clay, None], ['init_time', 'latitude', 'longitude'], wdep_dims=['latitude'],
+                                gather=gather, force_x_dim='longitude', allow_vec4=False)
+  entry2 = dict(entry, dev={})
+  assert engine._fused_slab_rows(plan2, entry2, 3) is None
+  # a reduction that keeps longitude rows apart from the spectra's rows (level summed inside stage 1): not the fields' rows
+  plan3 = planner.build_s1_plan(dims, sizes, [lay, lay, clay, None], ['init_time', 'level', 'latitude', 'longitude'], wdep_dims=['latitude'],
+                                gather=gather, force_x_dim='longitude', allow_vec4=False)
+  assert engine._fused_slab_rows(plan3, dict(entry, dev={}), 3) is None
