@@ -778,3 +778,8 @@ int launch_ens_m50(wbx_ctx*, const wbx_s1_plan*, S1Args&, int, bool);
 int launch_ens_m51(wbx_ctx*, const wbx_s1_plan*, S1Args&, int, bool);
 
 }  // namespace wbx
+
+// Measured and not kept (r4), EnsOpF32::stats32: the two members of a pair (x_(i), x_(M-1-i)) in one register pair -- x - c, the
+// sum of e and the sum of e^2 as v_pk_add_f32 / v_pk_fma_f32 -- is 83 vector instructions less per point (1320 -> 1237 in
+// ens_pipe_kernel<51>, no extra moves) and 1 % SLOWER on the same box (north_star kernel 1.244 -> 1.258 ms, three alternating
+// runs of bench.py): a packed fp32 instruction takes two issue passes here, so nothing is saved and the chains get longer.
