@@ -189,3 +189,11 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   flush(cur);
 }
 #pragma clang diagnostic pop
+
+// Measured and not kept (r4): the row's work split between two kinds of waves -- a block of eight transform teams that never
+// touch global memory plus four loader waves (three waves per SIMD, 160 VGPRs) that stream p, t, c into registers, form the
+// deterministic sums and hand the (p, t) pairs to the teams through their LDS buffers (one flag word per team, s_sleep polling,
+// the next row of both its teams ready in a loader's registers).  Correct, and SLOWER on the same box: 1.07-1.08 ms per
+// configs[3] chunk against 0.91-0.93 ms for one wave per row (configs[4]: 3.23 against 2.86 ms per chunk) -- the teams pay
+// twelve more 16-byte LDS writes and reads per row and the hand-over, and the loaders' fp64 chains take vector-ALU slots from
+// the transforms instead of filling idle ones.
