@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the scoring hot path on MI355X (driver contract: one JSON line on rank 0).
 
+Output: stdout carries ONE compact JSON line (< 6 KB: headline + `roofline` + `cpu_baseline` + `legs`, a table of one short
+record per side leg); the full result of every leg goes to `bench_full.json` beside this script (also `gpurun_out/`) and to
+stderr.  `compact_line()` builds the line; tests/test_bench_line.py holds its size.
+
 `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment the script launches
 itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU,
 backend 'nccl' = RCCL); under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Fewer visible devices than N: one JSON
@@ -1113,9 +1117,124 @@ def _claim_stdout():
     os.dup2(2, 1)
 
 
+LINE_LIMIT = 6000  # bytes; the driver's parser lost the 20.9 KB line of round 4 (BENCH_r04.json: parsed null), 8 KB is its tail
+
+
+def _short(s, n):
+  s = str(s)
+  return s if len(s) <= n else s[:n - 1] + '…'
+
+
+def _sig(v, digits=5):
+  return float(f'{float(v):.{digits}g}') if isinstance(v, (int, float)) and not isinstance(v, bool) else v
+
+
+def _leg_record(leg):
+  """One short record of a side leg: wall time per step / chunk, the kernel and its roofline fraction, counter traffic over
+  algorithmic bytes, and the largest error against the oracle the leg measured (outside its timed region)."""
+  roof = leg.get('roofline') if isinstance(leg.get('roofline'), dict) else (leg if 'frac' in leg and 'kernel_ms' in leg else {})
+  rec = {}
+  for k in ('ms_per_step', 'ms_per_chunk'):
+    if isinstance(leg.get(k), (int, float)):
+      rec['ms'] = _sig(leg[k], 4)
+  if roof:
+    rec['kernel'] = _short(str(roof.get('kernel', '')).split(' (')[0], 44)
+    rec['kernel_ms'], rec['frac'] = _sig(roof.get('kernel_ms'), 4), _sig(roof.get('frac'), 4)
+    if roof.get('traffic') and roof.get('algorithmic_bytes_per_launch'):
+      rec['traffic_ratio'] = round(roof['traffic'] / roof['algorithmic_bytes_per_launch'], 3)
+  elif isinstance(leg.get('frac_of_hbm_peak', leg.get('frac_of_hbm_peak_per_gpu')), (int, float)):
+    rec['frac'] = _sig(leg.get('frac_of_hbm_peak', leg.get('frac_of_hbm_peak_per_gpu')), 4)
+  if isinstance(leg.get('value'), (int, float)):
+    rec['value'] = _sig(leg['value'], 4)
+  errs = [v for k, v in (leg.get('check') or {}).items() if 'err' in k and isinstance(v, (int, float))]
+  if errs:
+    rec['oracle_err'] = _sig(max(errs), 2)
+  return rec
+
+
+_NOT_LEGS = ('roofline', 'check', 'config', 'cpu_baseline', 'legs')
+_LEG_ALIASES = {'with_mask_coordinate': 'mask', 'with_nan_mask': 'nanmask', 'with_deterministic_suite': 'det', 'public_chunk_ens': 'pce',
+                'public_chunk_ens_ifs_layout': 'pce_ifs', 'public_chunk': 'pc', 'lat_fastest': 'lat', 'default_crps_ensemble': 'default',
+                'pairwise_form': 'pair', 'skipna_ensemble': 'skipna'}
+
+
+def _collect_legs(node, prefix, out):
+  for k, v in node.items():
+    if not isinstance(v, dict) or k in _NOT_LEGS:
+      continue
+    name = (prefix + '.' if prefix else '') + _LEG_ALIASES.get(k, k)
+    rec = _leg_record(v)
+    if rec:
+      out[name] = rec
+    _collect_legs(v, name, out)
+
+
+def compact_line(result, full_path=None):
+  """The ONE line the driver parses: headline + roofline + cpu_baseline + a table of one short record per side leg.  Everything
+  else (workload prose, per-leg roofline objects, checks) is in `bench_full.json` beside this script (path in the line)."""
+  keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+          'dtype', 'data', 'skipped', 'reason', 'note')
+  line = {k: result[k] for k in keep if k in result}
+  cfg = result.get('config') or {}
+  if cfg:
+    line['config'] = {'workload': _short(cfg.get('workload', ''), 330)}
+    line['config'].update({k: cfg[k] for k in ('points_per_step_per_gpu', 'members', 'metrics', 'layout', 'accumulators', 'sharding',
+                                               'collectives_per_step', 'rccl_ranks') if k in cfg})
+  roof = result.get('roofline') or {}
+  if roof:
+    line['roofline'] = {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel_ms', 'kernel_ms_median',
+                                             'algorithmic_bytes_per_launch', 'bytes_per_point', 'launches_per_step') if k in roof}
+    line['roofline']['kernel'] = _short(roof.get('kernel', ''), 90)
+    line['roofline']['kernel_ms_source'] = 'HIP events around every timed launch on its launch stream, mean'
+    line['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE(x2 gfx950)+WRITE_SIZE, separate passes (profiles/), same library md5'
+  cpu = result.get('cpu_baseline') or {}
+  if cpu:
+    line['cpu_baseline'] = {k: (_short(cpu[k], 200) if k == 'sample' else cpu[k]) for k in ('value', 'unit', 'cores', 'kind', 'sample') if k in cpu}
+    for fam in ('ensemble', 'deterministic'):
+      ac = (cpu.get(fam) or {}).get('all_cores') or {}
+      one = (cpu.get(fam) or {}).get('value')
+      if fam == 'ensemble' and ac:
+        line['cpu_baseline']['all_cores'] = {'value': _sig(ac.get('value')), 'cores': ac.get('cores')}
+      elif one is not None:
+        line['cpu_baseline'][fam] = {'value': _sig(one), 'cores': 1, 'all_cores_value': _sig(ac.get('value')), 'all_cores': ac.get('cores')}
+  chk = result.get('check') or {}
+  if chk:
+    line['check'] = {k: _sig(chk[k], 6) for k in ('crps_mean', 'unbiased_spread_skill_mean', 'oracle_max_rel_err') if k in chk}
+  legs = {}
+  _collect_legs(result, '', legs)
+  if legs:
+    line['legs'] = legs
+  if full_path:
+    line['full'] = full_path
+  text = json.dumps(line, separators=(',', ':'))
+  # a line that outgrows the limit sheds detail in a fixed order instead of failing the parse: leg kernel names, then leg values
+  for drop in ('kernel', 'value', 'kernel_ms'):
+    if len(text.encode()) <= LINE_LIMIT:
+      break
+    for rec in legs.values():
+      rec.pop(drop, None)
+    text = json.dumps(line, separators=(',', ':'))
+  assert len(text.encode()) < 8192, len(text.encode())
+  return text
+
+
 def _emit(result):
+  """Full result -> bench_full.json (+ gpurun_out/ when present, + stderr); the compact line -> stdout."""
+  full = json.dumps(result)
+  name = 'bench_full.json' if result.get('n_gpus', 1) == 1 else f"bench_full_n{result.get('n_gpus')}.json"
+  written = None
+  for d in (ROOT, os.path.join(ROOT, 'gpurun_out')):
+    try:
+      if os.path.isdir(d):
+        with open(os.path.join(d, name), 'w') as f:
+          f.write(full + '\n')
+        written = written or name
+    except OSError:
+      pass
+  sys.stderr.write(full + '\n')
+  sys.stderr.flush()
   sys.stdout.flush()
-  os.write(_JSON_FD if _JSON_FD is not None else 1, (json.dumps(result) + '\n').encode())
+  os.write(_JSON_FD if _JSON_FD is not None else 1, (compact_line(result, written) + '\n').encode())
 
 
 def main():
