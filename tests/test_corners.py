@@ -4,6 +4,7 @@ on HIP kernels now -- asserted from the launch log on both backends, results aga
     a (predictions, targets) pair in ONE launch;
   * ErrorExceedance against thresholds that vary with the statistic's dims (deterministic.py:262-295): wbx_cat_exceed_field."""
 import numpy as np
+import pytest
 
 from oracle import wbx_oracle as O
 from weatherbenchx_amd import aggregation
@@ -108,3 +109,51 @@ def test_no_elementwise_payload_arithmetic_left_under_metrics():
     code = re.sub(r'''""".*?"""''', '', text, flags=re.S)
     code = '\n'.join(line.split('#')[0] for line in code.split('\n'))
     assert not re.search(r'abs\(predictions - |abs_error|\.notnull\(\)|predictions - targets|> thresholds', code), name
+
+
+@pytest.mark.parametrize('kind', ['scalar', 'level_latitude', 'two_new_dims'])
+def test_error_exceedance_thresholds_that_add_no_or_several_dims(backend, kind):
+  """ADVICE r4: the reference takes ANY broadcastable thresholds array (`abs_error > thresholds`, deterministic.py:283-295) -- a
+  0-D threshold, per-(level, latitude) thresholds with no category dim, thresholds that add two dims.  All of them run the
+  threshold-field kernel in one launch; the per-point values (Statistic.compute's contract) and the aggregated means agree
+  with the labeled-array formula."""
+  rng = np.random.default_rng(3)
+  dims = ('lead_time', 'level', 'latitude', 'longitude')
+  lat = np.linspace(-80, 80, 9)
+  pv = rng.normal(size=(3, 2, 9, 12)).astype(np.float32)
+  tv = rng.normal(size=(3, 2, 9, 12)).astype(np.float32)
+  tv[2, 1, 4, 4] = np.nan
+  coords = {'level': np.array([500, 850]), 'latitude': lat}
+  if kind == 'scalar':
+    thr, th, new = xr.DataArray(np.float64(0.7)), np.float64(0.7), ()
+  elif kind == 'level_latitude':
+    tvals = np.abs(rng.normal(size=(9, 2))) + 0.2
+    tvals[4, 0] = np.nan
+    thr = xr.DataArray(tvals, dims=('latitude', 'level'), coords=coords)
+    th, new = tvals.T[None, :, :, None], ()
+  else:
+    tvals = np.abs(rng.normal(size=(2, 3, 4))) + 0.2
+    tvals[1, 2, 3] = np.nan
+    thr = xr.DataArray(tvals, dims=('level', 'quantile', 'season'), coords={'level': coords['level'], 'quantile': [0.1, 0.5, 0.9],
+                                                                            'season': np.arange(4)})
+    th, new = tvals[None, :, None, None, :, :], ('quantile', 'season')
+  ae = np.abs(pv.astype(np.float64) - tv.astype(np.float64))
+  ae = ae.reshape(ae.shape + (1,) * len(new))
+  with np.errstate(invalid='ignore'):
+    want = np.where(np.isnan(ae) | np.isnan(th), np.nan, (ae > th).astype(np.float64))
+  p, t = {'v': xr.DataArray(pv, dims=dims, coords=coords)}, {'v': xr.DataArray(tv, dims=dims, coords=coords)}
+  stat = deterministic.ErrorExceedance(thr).compute(p, t)['v']
+  assert tuple(stat.dims) == dims + new and tuple(stat.shape) == want.shape
+  for d in new:
+    np.testing.assert_array_equal(stat.coords[d].values, thr.coords[d].values)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], skipna=True)
+  got, log = _logged(lambda: agg.aggregate_stat_var(deterministic.ErrorExceedance(thr).compute(p, t)['v']).mean_statistics())
+  assert log == ['cat'], log
+  assert tuple(got.dims) == ('lead_time', 'level') + new
+  w = O.grid_area_weights(lat).reshape((1, 1, 9, 1) + (1,) * len(new))
+  ok = ~np.isnan(want)
+  ref = (np.where(ok, want, 0) * w).sum(axis=(2, 3)) / (ok * w).sum(axis=(2, 3))
+  np.testing.assert_allclose(np.asarray(got.values), ref, rtol=RTOL)
+  vals, log = _logged(lambda: np.asarray(stat.values))
+  assert log == ['cat'], log
+  np.testing.assert_array_equal(vals, want)

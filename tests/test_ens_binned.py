@@ -190,3 +190,44 @@ def test_routes_that_stay_two_stage(backend):
                                   bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))], skipna=True)
   got = state.sum_weighted_statistics['CRPSSkill_number']['v'].transpose(*out_dims).values
   np.testing.assert_allclose(np.asarray(got), sws, rtol=RTOL)
+
+
+def test_twin_sums_never_serve_another_target(backend):
+  """the unmasked half a masked launch leaves with the predictions ('_wbx_twin') belongs to the member-only
+  statistics (spread, variance).  A second evaluation of the SAME predictions object against other, unmasked targets has lanes
+  that depend on those targets (skill, unbiased MSE, mean MSE): it must launch its own pass, not read the twin of the first."""
+  nlat, nlon, m = 19, 36, 6
+  rng = np.random.default_rng(4)
+  valid = rng.random((nlat, nlon)) > 0.3
+  p, t1, pv, tv1, lat, lon = make_case('lon_fastest', m, nlat, nlon, 2, seed=8, mask=valid)
+  tv2 = (tv1 + rng.normal(size=tv1.shape) * 3 + 5).astype(np.float32)
+  t2 = xr.DataArray(tv2, dims=t1.dims, coords={k: t1.coords[k].values for k in t1.dims})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS)], masked=True)
+  stats = lane_statistics()
+  state1, log1 = run(stats, agg, p, t1)
+  assert [(e['kind'], e['flags'] & 1) for e in log1] == [('ens_binned', 1)], log1
+  check_against_oracle(state1, stats, pv, tv1, 'lon_fastest', lat, lon, None, ['latitude', 'longitude'], mask=valid)
+  only_t = {k: stats[k] for k in ('CRPSSkill', 'UnbiasedEnsembleMeanSquaredError', 'EnsembleMeanSquaredError')}
+  state2, log2 = run(only_t, agg, p, t2)  # the same predictions OBJECT
+  assert [(e['kind'], e['flags'] & 1) for e in log2] == [('ens_binned', 0)], log2  # its own launch
+  pd, td = LAYOUTS['lon_fastest']
+  names, masks = O.region_masks(lat, lon, REGIONS)
+  w = (O.grid_area_weights(lat), ('latitude',))
+  for name, (lane, ldims) in oracle_lanes(pv, pd, tv2, td).items():
+    if name not in only_t:
+      continue
+    sws, _, out_dims = O.aggregate(lane, ldims, ['latitude', 'longitude'], weights=[w],
+                                   bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))])
+    got = np.asarray(state2.sum_weighted_statistics[stats[name].unique_name]['v'].transpose(*out_dims).values)
+    np.testing.assert_allclose(got, sws, rtol=RTOL, err_msg=name)
+  # ... while spread / variance of these predictions still come from the twin of the first launch: no launch at all
+  mo = {k: stats[k] for k in ('CRPSSpread', 'EnsembleVariance')}
+  state3, log3 = run(mo, agg, p, t2)
+  assert [e['kind'] for e in log3 if e['kind'].startswith('ens')] in ([], ['ens_binned']), log3
+  for name in mo:
+    lane, ldims = oracle_lanes(pv, pd, tv2, td)[name]
+    sws, _, out_dims = O.aggregate(lane, ldims, ['latitude', 'longitude'], weights=[w],
+                                   bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))])
+    got = np.asarray(state3.sum_weighted_statistics[stats[name].unique_name]['v'].transpose(*out_dims).values)
+    np.testing.assert_allclose(got, sws, rtol=RTOL, err_msg=name)

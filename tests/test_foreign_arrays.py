@@ -128,3 +128,24 @@ def test_statistics_computed_one_call_at_a_time_still_share_the_conversion(backe
   se2 = deterministic.SquaredError().compute(p2, t)
   got = agg.aggregate_statistics({'se': se2}).mean_statistics()['se']['z'].values
   np.testing.assert_allclose(np.asarray(got), ((pv.astype(np.float64) + 1 - tv) ** 2).mean(axis=(0, 2, 3)), rtol=1e-6)
+
+
+def test_replaced_coordinate_of_a_foreign_array_is_seen_by_the_next_statistic(backend):
+  """the conversion memo is keyed on the coordinate variables too -- `x.coords['latitude'] = ...` on the SAME object
+  while an earlier lazy statistic keeps the first conversion alive must not serve stale coordinates (GridAreaWeighting reads
+  the latitudes of the statistic it is given)."""
+  dims, coords, pv, tv, _, _, _ = _case(3)
+  p, t = Foreign(pv, dims, coords, 'z'), Foreign(tv, dims, coords, 'z')
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  keep = deterministic.SquaredError().compute({'z': p}, {'z': t})['z']  # lazy, pending: holds the first conversion
+  first = agg.aggregate_stat_var(keep).mean_statistics().values
+  lat2 = np.linspace(-60, 60, coords['latitude'].size)
+  for f in (p, t):
+    f.coords['latitude'] = _Coord(('latitude',), lat2)
+  second = agg.aggregate_stat_var(deterministic.SquaredError().compute({'z': p}, {'z': t})['z']).mean_statistics()
+  np.testing.assert_array_equal(second['latitude'].values if 'latitude' in second.dims else lat2, lat2)
+  native = agg.aggregate_stat_var(deterministic.SquaredError().compute(
+      {'z': xr.DataArray(pv, dims=dims, coords=dict(coords, latitude=lat2))},
+      {'z': xr.DataArray(tv, dims=dims, coords=dict(coords, latitude=lat2))})['z']).mean_statistics().values
+  np.testing.assert_allclose(np.asarray(second.values), np.asarray(native), rtol=1e-12)
+  assert not np.allclose(np.asarray(first), np.asarray(native), rtol=1e-6)  # (the weights did change)

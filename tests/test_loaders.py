@@ -90,3 +90,21 @@ def test_chunked_evaluation_from_files_against_the_oracle(backend, tmp_path, fmt
     sws, sw, od = O.aggregate(lane, fdims, ['init_time', 'latitude', 'longitude'], weights=[w], mask=ok, mask_dims=fdims)
     want = np.sqrt(sws / sw) if name == 'rmse' else sws / sw
     np.testing.assert_allclose(np.asarray(got[f'{name}.z'].transpose(*od).values), want, rtol=RTOL, err_msg=name)
+
+
+def test_lead_time_slice_is_selected_by_label_with_inclusive_bounds(tmp_path):
+  """`TimeChunks` hands lead-time INTERVALS over as slices of timedelta64 (time_chunks.py:54-61, 97-108) and the
+  reference resolves them with `.sel(lead_time=slice)` -- by label, both ends included (xarray_loaders.py:199-200)."""
+  src_p, _, init_times, lead_times, _, dims, coords, pv, _ = _write(str(tmp_path), 'npy')
+  lp = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=False)
+  tc = time_chunks.TimeChunks(init_times, slice(np.timedelta64(12, 'h'), np.timedelta64(24, 'h')), init_time_chunk_size=2)
+  init_chunk, lead_chunk = next(iter(tc))
+  assert isinstance(lead_chunk, slice)
+  p = lp.load_chunk(init_chunk, lead_chunk)['z']
+  np.testing.assert_array_equal(p['lead_time'].values, lead_times[1:3])  # 12 h and 24 h: the stop label is part of the slice
+  np.testing.assert_array_equal(p.values, pv[:2, 1:3])
+  p = lp.load_chunk(init_chunk, slice(None, np.timedelta64(13, 'h')))['z']  # open start, a stop between two labels
+  np.testing.assert_array_equal(p['lead_time'].values, lead_times[:2])
+  p = lp.load_chunk(init_chunk, slice(np.timedelta64(1, 'h'), None))['z']
+  np.testing.assert_array_equal(p['lead_time'].values, lead_times[1:])
+  assert lp.load_chunk(init_chunk, slice(np.timedelta64(100, 'h'), None))['z'].shape[1] == 0

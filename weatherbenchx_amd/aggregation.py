@@ -336,8 +336,8 @@ class Aggregator:
         sws = term if sws is None else sws + term
       return AggregationState(sws, parts[0].sum_weights)
 
-    if (isinstance(stat, lazy.LazyCategorical) and stat.is_lazy and stat._cat_dim not in reduce_set  # pylint: disable=protected-access
-        and (w_da is None or stat._cat_dim not in w_da.dims)):  # pylint: disable=protected-access
+    if (isinstance(stat, lazy.LazyCategorical) and stat.is_lazy and not set(stat.cat_dims) & reduce_set
+        and (w_da is None or not set(stat.cat_dims) & set(w_da.dims))):
       return self._reduce_categorical(stat, w_da, bin_dims, use_mask, skipna)
 
     if isinstance(stat, spectra.LazySpectrum) and stat.is_lazy and not use_mask and not skipna:
@@ -499,18 +499,22 @@ class Aggregator:
     # NaN thresholds (deterministic.py:293-294) are NaN indicators inside the kernel already: poisoned sums, or counted
     # out under skipna, exactly where a valid point is involved
     dims_in = (cat_dim,) + tuple(out_dims)
-    final_dims = tuple(d for d in stat.dims if d in dims_in) + tuple(bin_dims)
+    kernel_dims = tuple(d for d in tuple(grp.dims) + (cat_dim,) if d in dims_in) + tuple(bin_dims)
+    cat_axis = kernel_dims.index(cat_dim)
+    # (a threshold field that adds no dim, or several: the category axis is dropped / split into them -- views either way)
+    final_dims = kernel_dims[:cat_axis] + tuple(stat.cat_dims) + kernel_dims[cat_axis + 1:]
     coords = {k: x for k, x in stat._coords.items() if set(x[0]) <= set(final_dims) and k != 'mask'}  # pylint: disable=protected-access
     if w_da is not None:
       for k, x in w_da._coords.items():  # pylint: disable=protected-access
         if set(x[0]) <= set(final_dims):
           coords.setdefault(k, x)
-    order = [dims_in.index(d) for d in final_dims]
+    order = [dims_in.index(d) for d in kernel_dims]
     pending = engine.deferred_active() is not None
 
     def mk(a):
       a = np.transpose(np.asarray(a, dtype=np.float64), order)
-      return xr.DataArray(a if pending else np.ascontiguousarray(a), dims=final_dims, coords=coords, name=stat.name,
+      a = stat.split_categories(a if pending else np.ascontiguousarray(a), cat_axis)
+      return xr.DataArray(a, dims=final_dims, coords=coords, name=stat.name,
                           attrs=stat.attrs, _raw_coords=True)
     return AggregationState(mk(values), mk(counts))
 

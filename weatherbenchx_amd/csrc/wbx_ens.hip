@@ -139,8 +139,9 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
     WBX_REQUIRE((w_on_x & WBX_BINNED_MASK_ON_W) && (w_on_x & WBX_BINNED_W_ON_X),
                 "wbx_ens_binned takes a validity mask that lives on the W dims only (WBX_BINNED_MASK_ON_W with WBX_BINNED_W_ON_X)");
   }
-  WBX_REQUIRE(plan->xstride[0] >= 0 && plan->xstride[1] >= 0 && (double)plan->nx * (double)plan->xstride[0] * 4.0 < 4294967296.0,
-              "x offsets of the members must be non-negative and fit 32 bits");
+  WBX_REQUIRE(plan->xstride[0] >= 0 && plan->xstride[1] >= 0 && (double)plan->nx * (double)plan->xstride[0] * 4.0 < 4294967296.0 &&
+                  (double)plan->nx * (double)plan->xstride[1] * 4.0 < 4294967296.0,
+              "x offsets of the members and of the targets must be non-negative and fit 32 bits");
   S1Args a;
   fill_args(plan, a);
   a.in[0] = p;

@@ -1170,7 +1170,9 @@ def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype
     return None
   if plan.x_kept and not plan.sum_j:  # x survives into the output: the two-stage path keeps it
     return None
-  if plan.nkey * plan.ndepth * plan.nx == 0 or plan.xstride[0] < 0 or plan.xstride[1] < 0 or plan.nx * plan.xstride[0] * 4 >= 1 << 32:
+  if plan.nkey * plan.ndepth * plan.nx == 0 or plan.xstride[0] < 0 or plan.xstride[1] < 0:
+    return None
+  if plan.nx * plan.xstride[0] * 4 >= 1 << 32 or plan.nx * plan.xstride[1] * 4 >= 1 << 32:  # 32-bit x byte offsets, both inputs
     return None
   w_flags = _ens_binned_flags(plan, w_buf, devs)
   if w_flags is None:
@@ -1256,7 +1258,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   under a mask alone, else a data-independent constant broadcast to all.
   """
   global _deferred
-  if kind == 'ens' and mask is None and not skipna and inputs[0] is not None:
+  if (kind == 'ens' and mask is None and not skipna and inputs[0] is not None
+      and inputs[1] is inputs[0].__dict__.get('_wbx_member0', {}).get(ens['member_dim'])):
+    # the member-only group alone (lazy.ens_statistic(member_only=True): its companion operand is lazy.first_member(p)) --
+    # lanes 0, 3, 4 of a twin depend on the targets it was launched with, so a group with targets of its own never reads it
     twin = _twin_lookup(inputs[0], dims, sizes, reduce_dims, w_da, bin_dims, ens)
     if twin is not None:
       return twin

@@ -427,16 +427,23 @@ def ens_statistic(stat_name: str, p, t, ensemble_dim: str, *, use_sort=False, fa
 class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
   """An indicator statistic (ErrorExceedance, EnsembleErrorExceedance, RankHistogram): the frame of (p, t) plus ONE new
   trailing dimension of categories.  The Aggregator reduces all categories in one launch (wbx_cat_partial); reading
-  `.data` evaluates the same kernel without reducing anything."""
+  `.data` evaluates the same kernel without reducing anything.
 
-  def __init__(self, group: FusedGroup, cat_dim: str, cat_coord, name=None):
+  `split` = (dims, shape, coords): the kernel's category axis stands for these trailing dims -- none (a threshold field that
+  adds no dimension: one category, squeezed out) or several (a field that adds two or more: stacked for the kernel)."""
+
+  def __init__(self, group: FusedGroup, cat_dim: str, cat_coord, name=None, split=None):
     self._data = None
-    self._dims = tuple(group.dims) + (cat_dim,)
+    self._split = None if split is None else (tuple(split[0]), tuple(int(n) for n in split[1]), dict(split[2]))
+    self._dims = tuple(group.dims) + ((cat_dim,) if split is None else self._split[0])
     self.name = name
     self.attrs = {}
     self._coords = dict(group.coords)
-    if cat_coord is not None:
+    if cat_coord is not None and split is None:
       self._coords[cat_dim] = ((cat_dim,), np.asarray(cat_coord))
+    if split is not None:
+      for d, c in self._split[2].items():
+        self._coords[d] = ((d,), np.asarray(c))
     self._group = group
     self._cat_dim = cat_dim
 
@@ -449,6 +456,20 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
     return int(self._group.cat['ncat'])
 
   @property
+  def cat_dims(self) -> tuple:
+    """The statistic's dims that the kernel's category axis stands for."""
+    return (self._cat_dim,) if self._split is None else self._split[0]
+
+  def split_categories(self, a: np.ndarray, axis: int) -> np.ndarray:
+    """`a` with its category axis replaced by the dims it stands for -- always a view (an axis is split or dropped)."""
+    if self._split is None:
+      return a
+    v = a.reshape(a.shape[:axis] + self._split[1] + a.shape[axis + 1:])
+    if a.size and not np.may_share_memory(v, a):
+      raise RuntimeError('internal: category split copied a pending result')
+    return v
+
+  @property
   def data(self):
     if self._data is None:
       grp = self._group
@@ -456,12 +477,12 @@ class LazyCategorical(xr.LazyPickleMixin, xr.DataArray):
         values, _, out_dims = grp.reduce((), None, (), use_mask=False, skipna=False)
       arr = np.moveaxis(np.asarray(values, np.float64), 0, -1)
       arr = np.transpose(arr, [out_dims.index(d) for d in grp.dims] + [len(out_dims)])
-      self._data = np.ascontiguousarray(arr)
+      self._data = self.split_categories(np.ascontiguousarray(arr), arr.ndim - 1)
     return self._data
 
   @property
   def shape(self):
-    return tuple(self._group.sizes[d] for d in self._group.dims) + (self.ncat,)
+    return tuple(self._group.sizes[d] for d in self._group.dims) + ((self.ncat,) if self._split is None else self._split[1])
 
   @property
   def dtype(self):
@@ -489,7 +510,8 @@ def ens2_statistic(stat_name: str, p, t, ensemble_dim: str, *, skipna_ensemble: 
   return LazyStatistic(grp, ENS2_LANE[stat_name], name=p.name)
 
 
-def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, ensemble_dim=None, threshold_field=None) -> xr.DataArray:
+def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, ensemble_dim=None, threshold_field=None,
+                  split=None) -> xr.DataArray:
   p, t = xr.as_dataarray(p), xr.as_dataarray(t)
   if ensemble_dim is not None:
     if ensemble_dim not in p.dims:
@@ -519,7 +541,7 @@ def cat_statistic(func: int, p, t, cat_dim: str, cat_coord, *, thresholds=None, 
          'M': p.sizes[ensemble_dim] if ensemble_dim else 1, 'thr_field': threshold_field, 'cat_dim': cat_dim}
   key = ('cat', int(func), cat_dim, None if thr is None else thr.tobytes(), None if threshold_field is None else id(threshold_field))
   grp = _group_for('cat', p, t, ens=None, clim_key=(key, ensemble_dim), cat=cat)
-  return LazyCategorical(grp, cat_dim, cat_coord, name=p.name)
+  return LazyCategorical(grp, cat_dim, cat_coord, name=p.name, split=split)
 
 
 def first_member(p: xr.DataArray, ensemble_dim: str) -> xr.DataArray:

@@ -120,8 +120,18 @@ class PredictionsFromFiles(FileLoader):
   def load_chunk(self, init_times, lead_times=None):
     init_times = np.asarray(init_times, dtype='datetime64[ns]')
     ii = _positions(self._init_times, init_times, 'init_time')
-    if lead_times is None or isinstance(lead_times, slice):
-      li = np.arange(self._lead_times.size)[lead_times if lead_times is not None else slice(None)]
+    if lead_times is None:
+      li = np.arange(self._lead_times.size)
+    elif isinstance(lead_times, slice):
+      # `.sel(lead_time=slice(start, stop))` (xarray_loaders.py:199-200): by LABEL, both bounds inclusive, None = open; the
+      # step is not used (time_chunks.py:54-56)
+      lo, hi = (None if b is None else np.asarray(b, dtype='timedelta64[ns]') for b in (lead_times.start, lead_times.stop))
+      keep = np.ones(self._lead_times.size, dtype=bool)
+      if lo is not None:
+        keep &= self._lead_times >= lo
+      if hi is not None:
+        keep &= self._lead_times <= hi
+      li = np.nonzero(keep)[0]
     else:
       li = _positions(self._lead_times, np.asarray(lead_times, dtype='timedelta64[ns]'), 'lead_time')
     out = {}

@@ -105,6 +105,9 @@ def _threshold_array(thresholds, name):
   return values, 'error_exceedance_thresholds', values
 
 
+_STACKED_THRESHOLDS = '_wbx_stacked_thresholds'  # the kernel's category axis when the thresholds add 0 or >= 2 dims
+
+
 class ErrorExceedance(base.PerVariableStatistic):
   """float(|p - t| > threshold) along a new thresholds dimension, NaN where the error or the threshold is NaN
   (deterministic.py:262-295).  All thresholds are lanes of one fused launch (csrc/wbx_cat.hip)."""
@@ -120,10 +123,21 @@ class ErrorExceedance(base.PerVariableStatistic):
       thresholds = self._thresholds[predictions.name] if isinstance(self._thresholds, (xr.Dataset, dict)) else self._thresholds
       thresholds = xr.as_dataarray(thresholds)
       new = [d for d in thresholds.dims if d not in predictions.dims and d not in targets.dims]
-      if len(new) != 1:
-        raise ValueError(f'thresholds over {thresholds.dims} must add exactly one dimension to the inputs (got {new})')
-      coord = thresholds.coords[new[0]].values if new[0] in thresholds.coords else None
-      return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, new[0], coord, threshold_field=thresholds)
+      if len(new) == 1:
+        coord = thresholds.coords[new[0]].values if new[0] in thresholds.coords else None
+        return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, new[0], coord, threshold_field=thresholds)
+      # any other broadcastable field, like the reference's `abs_error > thresholds` (deterministic.py:283-295): no new dim (a
+      # scalar, per-level / per-latitude thresholds) = ONE category that is squeezed out of the result; two or more new dims are
+      # stacked into the kernel's category axis and split again in the result.  Same kernel, same launch count.
+      shared = [d for d in thresholds.dims if d not in new]
+      stacked = thresholds.transpose(*shared, *new)
+      shape_new = tuple(stacked.sizes[d] for d in new)
+      values = np.ascontiguousarray(np.asarray(stacked.values, np.float64)).reshape(
+          tuple(stacked.sizes[d] for d in shared) + (int(np.prod(shape_new, dtype=np.int64)),))
+      field = xr.DataArray(values, dims=tuple(shared) + (_STACKED_THRESHOLDS,),
+                           coords={d: stacked.coords[d].values for d in shared if d in stacked.coords})
+      split = (new, shape_new, {d: stacked.coords[d].values for d in new if d in stacked.coords})
+      return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, _STACKED_THRESHOLDS, None, threshold_field=field, split=split)
     values, dim, coord = spec
     return lazy.cat_statistic(_hip.CAT_EXCEED, predictions, targets, dim, coord, thresholds=values)
 

@@ -861,6 +861,20 @@ def _foreign_payload_key(x):
   return None
 
 
+def _foreign_coords_key(x):
+  """A cheap fingerprint of a foreign array's coordinate variables: names, dims and the identity / address of their value
+  buffers.  `x.coords['latitude'] = ...` or `x = x.assign_coords(...)` on the same object gives another key; values
+  rewritten IN PLACE in a coordinate's own buffer do not -- like for the payload, the memo assumes buffers are not rewritten
+  while a lazy statistic of the array is still pending."""
+  key = []
+  for k in x.coords:
+    c = x.coords[k]
+    v = getattr(c, 'values', None)
+    addr = v.__array_interface__['data'][0] if isinstance(v, np.ndarray) else id(v)
+    key.append((k, tuple(c.dims), addr, getattr(v, 'shape', None), str(getattr(v, 'dtype', ''))))
+  return tuple(key)
+
+
 def as_dataarray(x) -> DataArray:
   """Accepts DataArray, anything xarray-like (.dims/.coords/.values) or array-likes."""
   if isinstance(x, DataArray):
@@ -871,7 +885,7 @@ def as_dataarray(x) -> DataArray:
     if hit is not None:
       owner, conv, key = hit[0](), hit[1](), hit[2]
       # (same object -- not a recycled id --, same payload buffer, same frame)
-      if owner is x and conv is not None and key == (_foreign_payload_key(x), tuple(x.dims)):
+      if owner is x and conv is not None and key == (_foreign_payload_key(x), tuple(x.dims), _foreign_coords_key(x)):
         return conv
       del _foreign_conversions[id(x)]
     coords = {}
@@ -886,7 +900,7 @@ def as_dataarray(x) -> DataArray:
     try:
       ident = id(x)
       owner = weakref.ref(x, lambda _, ident=ident: _foreign_conversions.pop(ident, None))
-      _foreign_conversions[ident] = (owner, weakref.ref(conv), (_foreign_payload_key(x), tuple(x.dims)))
+      _foreign_conversions[ident] = (owner, weakref.ref(conv), (_foreign_payload_key(x), tuple(x.dims), _foreign_coords_key(x)))
     except TypeError:  # an object that cannot be weakly referenced: converted per call, as before
       pass
     return conv
