@@ -71,7 +71,7 @@ def parse():
   ap.add_argument('--ens-slices', type=int, default=8)
   ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline leg')
   ap.add_argument('--no-config5', action='store_true', help='skip the streamed full-suite leg')
-  ap.add_argument('--pce-mask', choices=['both', '0', '1'], default='both',
+  ap.add_argument('--pce-mask', choices=['both', '0', '1', 'nan'], default='both',
                   help='public_chunk_ens: run without / with the mask coordinate only (profiling: one kind of launch per traced process)')
   ap.add_argument('--config5-inits', type=int, default=366)
   ap.add_argument('--cpu-workers', type=int, default=0, help='worker processes of the multi-core CPU baseline (0 = os.cpu_count())')
@@ -659,6 +659,7 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   sets from one pass (masked-out points are accumulated under their atom's twin).  The roofline is that of the launch.  `ifs_layout`: the recorded IFS-ENS dim order (init, number, lead, longitude, latitude),
   docs/source/how_to/metric_wrappers.ipynb:955-964."""
   from weatherbenchx_amd import aggregation, binning, engine, weighting
+  from weatherbenchx_amd import data as wdata
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.metrics import base as metrics_base
   sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -682,9 +683,21 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   land = (np.sin(np.deg2rad(env.lon) * 3)[None, :] * np.cos(np.deg2rad(env.lat) * 2.5)[:, None]
           + 0.3 * np.sin(np.deg2rad(env.lon) * 17)[None, :] * np.sin(np.deg2rad(env.lat) * 13)[:, None]) > 0.35
   valid = ~((np.abs(env.lat)[:, None] > 80) & (np.cos(np.deg2rad(env.lon) * 5)[None, :] > 0.2))  # a NaN-mask-like hole at the poles
+  nan_mask = with_mask == 'nan'
+  if nan_mask:
+    # what the reference's loaders do (data_loaders/base.py:25-56): NaN targets + `mask = ~isnan(targets)` over EVERY dim of
+    # the targets -- here a polar hole that grows with the lead time, so the mask has a lead_time stride
+    holes = np.stack([(np.abs(env.lat)[:, None] > 80 - 2 * l) & (np.cos(np.deg2rad(env.lon) * (5 + l))[None, :] > 0.2) for l in range(nl)])
+    hv = holes if env.sp == ('latitude', 'longitude') else np.ascontiguousarray(np.swapaxes(holes, 1, 2))
+    tv[0][env.torch.as_tensor(hv, device=env.dev)] = float('nan')
+    nan_valid = ~holes
   lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': env.lat, 'longitude': env.lon})
   mv = valid if env.sp == ('latitude', 'longitude') else np.ascontiguousarray(valid.T)
   mask_da = xr.DataArray(env.torch.as_tensor(mv, device=env.dev), dims=env.sp, coords={'latitude': env.lat, 'longitude': env.lon})
+  nan_mask_da = None
+  if nan_mask:  # the loader's step (add_nan_mask_to_data builds the mask in HBM with wbx_notnan_mask): once per chunk, not timed
+    nan_mask_da = wdata.add_nan_mask_to_data({'v': xr.DataArray(tv, dims=tdims, coords={k: v for k, v in coords.items() if k in tdims})})['v'].coords['mask']
+    assert tuple(nan_mask_da.dims) == tdims
   metrics = ensemble_suite()
   agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
                                bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
@@ -693,7 +706,9 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   def launch():
     p = xr.DataArray(ens, dims=pdims, coords={k: v for k, v in coords.items() if k in pdims})
     t = xr.DataArray(tv, dims=tdims, coords={k: v for k, v in coords.items() if k in tdims})
-    if with_mask:
+    if nan_mask:
+      t = t.assign_coords(mask=nan_mask_da)
+    elif with_mask:
       t = t.assign_coords(mask=mask_da)
     return agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': p}, {'v': t}))
 
@@ -718,14 +733,20 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   kinds = sorted((e['kind'], e.get('flags', 0) & 1) for e in log)
   # one pass over the members (per mask setting), nothing else
   assert kinds == [('ens_binned', 1 if with_mask else 0)], kinds
+  if nan_mask:  # the per-point route: the mask is NOT on the W dims only
+    from weatherbenchx_amd import _hip as _h
+    assert not (log[0]['w_flags'] & _h.BINNED_MASK_ON_W), log
   points = nl * env.nlat * env.nlon
   k_ms = float(np.mean([e['ms'] for e in log]))
   name = f"ens_atoms_kernel<{m},true,{'NT' if env.layout == 'lon_fastest' else 'L2-shared lines'}> behind wbx_ens_binned"
-  roof = kernel_roofline(name, k_ms, points * (m + 1) * 4,
-                         pmc_traffic('ens_atoms_kernel', not args.small, f"public_chunk_ens{'_ifs' if ifs_layout else ''}@{env.layout}"))
+  roof = kernel_roofline(name, k_ms, points * ((m + 1) * 4 + (1 if nan_mask else 0)),
+                         pmc_traffic('ens_atoms_kernel', not args.small,
+                                     f"public_chunk_ens{'_ifs' if ifs_layout else ''}{'_nanmask' if nan_mask else ''}@{env.layout}"))
   roof['kernel_ms_source'] = 'HIP events around 10 back-to-back repetitions of each launch of a chunk, mean per launch (one stream)'
-  roof['launch_includes'] = ('aid_merge (mask folded into the atom ids, masked launch only) + ens_atoms_kernel with its in-kernel '
-                             'sums over patches: no second-stage or finish kernel')
+  roof['launch_includes'] = ('aid_merge (mask folded into the atom ids, masked launch only; per point of the chunk for the NaN mask) + '
+                             'ens_atoms_kernel with its in-kernel sums over patches: no second-stage or finish kernel')
+  if nan_mask:
+    roof['bytes_per_point'] = (m + 1) * 4 + 1
   # a sampled check against the oracle, outside the timed region: one lead time, every bin of CRPS
   from oracle import wbx_oracle as O
   lead = nl - 1
@@ -738,7 +759,8 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   names, masks = O.region_masks(env.lat, env.lon, REGIONS, land_sea_mask=land)
   bm = [('region', masks, ('region', 'latitude', 'longitude'))]
   w = (O.grid_area_weights(env.lat), ('latitude',))
-  a = O.aggregate(skill, sd, ['latitude', 'longitude'], weights=[w], bin_masks=bm, mask=valid if with_mask else None,
+  use_valid = (nan_valid[lead] if nan_mask else valid) if with_mask else None
+  a = O.aggregate(skill, sd, ['latitude', 'longitude'], weights=[w], bin_masks=bm, mask=use_valid,
                   mask_dims=('latitude', 'longitude') if with_mask else None)
   b = O.aggregate(spread, sd, ['latitude', 'longitude'], weights=[w], bin_masks=bm)
   want = O.crps(a[0] / a[1], b[0] / b[1])
@@ -749,7 +771,7 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
   del ens, tv
   return {'workload': f"public benchmark chunk, probabilistic: f32[1 init,{nl} lead,{m} member,{env.nlat},{env.nlon}] "
                       f"({'init,number,lead' if ifs_layout else 'init,lead,number'} order) vs f32[1,{nl},{env.nlat},{env.nlon}] "
-                      f"{'with a (latitude,longitude) mask coordinate' if with_mask else 'without a mask coordinate'}, CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + mean RMSE, "
+                      f"{('with NaN targets + add_nan_mask_to_data (per-point mask, another hole per lead)' if nan_mask else 'with a (latitude,longitude) mask coordinate') if with_mask else 'without a mask coordinate'}, CRPS(fair) + unbiased spread/skill + unbiased-mean RMSE + mean RMSE, "
                       f'GridAreaWeighting, {len(REGIONS)} regions x land/sea = {2 * len(REGIONS)} bins, masked=True, {env.layout}',
           'ms_per_chunk': ms_chunk, 'value': points * len(metrics) / (ms_chunk * 1e-3), 'unit': 'evals/s',
           'launches_per_chunk': len(log), 'kernels': [e['kind'] for e in log],
@@ -1263,9 +1285,11 @@ def main():
     if want('public_chunk'):
       result['public_chunk'] = public_chunk_leg(env)
     if want('public_chunk_ens'):
-      result['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False) if args.pce_mask != '1' else {}
-      if args.pce_mask != '0':
+      result['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False) if args.pce_mask in ('both', '0') else {}
+      if args.pce_mask in ('both', '1'):
         result['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
+      if args.pce_mask in ('both', 'nan'):
+        result['public_chunk_ens']['with_nan_mask'] = public_chunk_ens_leg(env, with_mask='nan')
     if want('spectrum'):
       result['spectrum'] = spectrum_leg(env)
     if want('lat_fastest') and args.layout == 'lon_fastest':
@@ -1281,6 +1305,7 @@ def main():
       if want('public_chunk_ens'):
         lf['public_chunk_ens'] = public_chunk_ens_leg(env, with_mask=False)
         lf['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
+        lf['public_chunk_ens']['with_nan_mask'] = public_chunk_ens_leg(env, with_mask='nan')
         lf['public_chunk_ens_ifs_layout'] = public_chunk_ens_leg(env, ifs_layout=True, with_mask=False)
       result['lat_fastest'] = lf
       env.set_layout('lon_fastest')

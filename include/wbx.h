@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 10
+#define WBX_ABI_VERSION 11
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -322,7 +322,8 @@ int wbx_cat_exceed_field(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int n
 #define WBX_BINNED_TWIN_MASK 16 /* wbx_ens_binned with WBX_FLAG_MASKED: 12 output lanes instead of 6 -- lanes 0-5 with the mask applied,
                                    lanes 6-11 the same statistics over ALL points (mask ignored) from the same pass over the members */
 #define WBX_BINNED_MASK_ON_W 8 /* the validity mask (WBX_FLAG_MASKED) depends on the Bk / Br / x dims only (a (latitude, longitude)
-                                  mask under Regions bins): its byte is folded into the atom-id byte, one load less per point */
+                                  mask under Regions bins): its byte is folded into the atom-id byte, one load less per point.
+                                  wbx_ens_binned without this flag: a per-point mask (strides along any dim), see there */
 /* `atoms`: NULL, or the tables wbx_binned_atoms wrote for exactly this geometry (plan extents, nA, nBk, nBr, w_on_x) and
  * these `bits`.  The kernel works on a patch's "atoms" (= its distinct membership words: regions are boxes, so a patch
  * of 64 x ~150 rows sees a handful) and needs every point's atom index; the tables depend on the bins and the geometry
@@ -345,13 +346,27 @@ int wbx_binned_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, int64_t nA, int64_t 
  *                          lane 5 = the sum of the weights of the valid points of the bin (the count lane, with and without mask).
  * plan / nA / nBk / nBr / bits / nbin / w_on_x as for wbx_det_binned, with these restrictions (WBX_ERR_INVALID otherwise; the
  * two-stage route wbx_ens_partial + wbx_contract_bits covers the rest):
- *   dtype WBX_F32, algo WBX_ENS_SORT (the pair form gives the same number), 2 <= M <= 64, plan->flags within FAIR | MASKED;
+ *   dtype WBX_F32, algo WBX_ENS_SORT (the pair form gives the same number), 2 <= M <= 64, plan->flags within
+ *   FAIR | MASKED | SKIPNA;
  *   weights factored: WBX_BINNED_WT_X_ONLY (wt[nBk][nx]) or WBX_BINNED_WT_ROW_ONLY (wt[nBk][nBr]), or wt = NULL (ones);
- *   a mask (WBX_FLAG_MASKED) must live on the W dims: WBX_BINNED_MASK_ON_W together with WBX_BINNED_W_ON_X.
+ *   a mask (WBX_FLAG_MASKED) needs WBX_BINNED_W_ON_X.  It is addressed as input 3 of the plan (key_off[3] / depth_off[3] /
+ *   xstride[3], one byte per element).  With WBX_BINNED_MASK_ON_W the caller says that it depends on the Bk / Br / x dims only (a
+ *   (latitude, longitude) mask: zero strides along A and the depth dims).  WITHOUT that flag (ABI 11) it may have strides along
+ *   any dim -- the per-point mask data_loaders/base.py:25-56 (add_nan_mask_to_data) builds: `mask = ~isnan(data)` over every dim
+ *   of the data, which Aggregator(masked=True) consumes (aggregation.py:339-352).  Same single pass over the members; one more
+ *   byte per point is read (209 instead of 208 for 51 members).
  * WBX_BINNED_TWIN_MASK (with a mask): out[nA][nBk][12][nbin] -- lanes 0-5 as above with the mask applied, lanes 6-11 the same six over
  * ALL points.  The reference masks the skill / unbiased-MSE / mean-MSE statistics of a variable whose targets carry a `mask`
  * coordinate but not its spread / variance (statistics of the predictions alone, probabilistic.py:165-273, aggregation.py:339-352):
  * both sets come out of ONE pass (masked-out points are accumulated under their atom's twin).
+ * WBX_FLAG_SKIPNA (ABI 11; Aggregator(skipna=True), aggregation.py:343-344, 353-355: `mask & ~stat.isnull()` statistic by
+ * statistic): out[nA][nBk][10][nbin] = the five value lanes with their NaN points left out, then five count lanes = the sum of the
+ * weights of the points each statistic was valid at (the layout of wbx_ens_partial + wbx_contract_bits under SKIPNA).  Skill,
+ * unbiased MSE and MSE of the mean are NaN where the target or a member is; spread and variance where a member is (an infinite
+ * member counts as NaN here, as in every rank-form kernel of this library).  With WBX_BINNED_TWIN_MASK: out[nA][nBk][20][nbin] --
+ * the ten over the valid points of the mask, then the ten over all points; of the first ten the spread / variance lanes (1, 2)
+ * and of the second ten the target lanes (0, 3, 4) are NaN: they are not among the sums the pass forms, and the reference's
+ * statistics never ask for them (a statistic of the predictions alone carries no mask).
  * `atoms`: NULL, or the tables wbx_ens_binned_atoms wrote for this geometry and these bits (its patches are shorter than
  * wbx_det_binned's, so the tables are its own).  *overflow_out = number of patches with more than 32 distinct membership
  * words (bins that are not boxes): when it is not zero use the two-stage route -- wbx_ens_binned would return NaN for the

@@ -260,13 +260,30 @@ def _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, route):
   with np.errstate(all='ignore'):
     lanes = _ens_lanes(plan, devs, ens_args, plan.flags)
     valid = np.ones(lanes[0].shape, dtype=bool)
-    if plan.flags & _hip.FLAG_MASKED:
-      assert w_flags & _hip.BINNED_MASK_ON_W
+    if plan.flags & _hip.FLAG_MASKED:  # any strides (ABI 11): WBX_BINNED_MASK_ON_W only says that A / depth strides are zero
       valid = devs[3].ptr[_offsets(plan, 3)] != 0
-    every = lanes + [np.ones(lanes[0].shape)]
-    lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
-    if w_flags & _hip.BINNED_TWIN_MASK:  # lanes 6-11: the same statistics over all points
-      lanes = lanes + every
+      if w_flags & _hip.BINNED_MASK_ON_W:
+        assert all(devs[3].layout.stride(d) == 0 for d in tuple(plan.a_dims) + tuple(plan.depth_dims))
+    twin_out = bool(w_flags & _hip.BINNED_TWIN_MASK)
+    if plan.flags & _hip.FLAG_SKIPNA:
+      # [five values | their five counts] (wbx.h): a statistic's NaN points are left out of its sum and its count.  In twin mode
+      # the kernel does not form the masked spread / variance nor the unmasked target statistics: NaN, as documented.
+      nan = np.full(lanes[0].shape, np.nan)
+      def ten(ok_points, dead):
+        ok = [ok_points & ~np.isnan(l) for l in lanes]
+        vals = [np.where(o, l, 0.0) for o, l in zip(ok, lanes)]
+        cnts = [o.astype(np.float64) for o in ok]
+        if dead:
+          src = 0 if 1 in dead else 1  # (the count lanes of the dead statistics repeat a live one)
+          vals = [nan if i in dead else v for i, v in enumerate(vals)]
+          cnts = [cnts[src] if i in dead else c for i, c in enumerate(cnts)]
+        return vals + cnts
+      lanes = ten(valid, (1, 2) if twin_out else ()) + (ten(np.ones_like(valid), (0, 3, 4)) if twin_out else [])
+    else:
+      every = lanes + [np.ones(lanes[0].shape)]
+      lanes = [np.where(valid, l, 0.0) for l in lanes] + [np.broadcast_to(valid, lanes[0].shape).astype(np.float64)]
+      if twin_out:  # lanes 6-11: the same statistics over all points
+        lanes = lanes + every
     flag, buf = w_buf.factored
     assert flag == (w_flags & (_hip.BINNED_WT_X_ONLY | _hip.BINNED_WT_ROW_ONLY))
     fac = np.asarray(buf.ptr)

@@ -174,22 +174,132 @@ def test_nan_member_poisons_every_bin_of_its_lead_time_only(backend):
 
 
 def test_routes_that_stay_two_stage(backend):
-  """skipna aggregation, skipna_ensemble and float64 members are not wbx_ens_binned's: same numbers through the two-stage
+  """skipna_ensemble (per-point member counts) and float64 members are not wbx_ens_binned's: same numbers through the two-stage
   route (x-kept ensemble kernel + wbx_contract_bits)."""
   nlat, nlon, m = 19, 36, 5
   p, t, pv, tv, lat, lon = make_case('lon_fastest', m, nlat, nlon, 2, seed=2)
   agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
-                               bin_by=[binning.Regions(REGIONS)], skipna=True)
-  stats = {'CRPSSkill': probabilistic.CRPSSkill()}
+                               bin_by=[binning.Regions(REGIONS)])
+  stats = {'CRPSSkill': probabilistic.CRPSSkill(skipna_ensemble=True)}
   state, log = run(stats, agg, p, t)
   assert not any(e['kind'] == 'ens_binned' for e in log)
   pd, td = LAYOUTS['lon_fastest']
   names, masks = O.region_masks(lat, lon, REGIONS)
   lane, ldims = O.crps_skill(pv, pd, tv, td, 'number')
   sws, sw, out_dims = O.aggregate(lane, ldims, ['latitude', 'longitude'], weights=[(O.grid_area_weights(lat), ('latitude',))],
-                                  bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))], skipna=True)
+                                  bin_masks=[('region', masks, ('region', 'latitude', 'longitude'))])
+  got = state.sum_weighted_statistics[stats['CRPSSkill'].unique_name]['v'].transpose(*out_dims).values
+  np.testing.assert_allclose(np.asarray(got), sws, rtol=RTOL)
+  p64 = xr.DataArray(pv.astype(np.float64), dims=p.dims, coords={k: p.coords[k].values for k in p.dims if k != 'number'})
+  t64 = xr.DataArray(tv.astype(np.float64), dims=t.dims, coords={k: t.coords[k].values for k in t.dims})
+  state, log = run({'CRPSSkill': probabilistic.CRPSSkill()}, agg, p64, t64)
+  assert not any(e['kind'] == 'ens_binned' for e in log)
   got = state.sum_weighted_statistics['CRPSSkill_number']['v'].transpose(*out_dims).values
   np.testing.assert_allclose(np.asarray(got), sws, rtol=RTOL)
+
+
+def _check_lanes(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, *, mask=None, mask_dims=None, skipna=False,
+                 masked_member_only=False, rtol=RTOL):
+  """Every bin of every lane AND of its weights against the oracle.  `mask` applies to the statistics that look at the targets
+  (the member-only ones carry no mask coordinate: probabilistic.py:165-273) unless `masked_member_only`."""
+  pd, td = LAYOUTS[layout]
+  names, masks = O.region_masks(lat, lon, REGIONS, land_sea_mask=land)
+  bm = [('region', masks, ('region', 'latitude', 'longitude'))]
+  w = (O.grid_area_weights(lat), ('latitude',))
+  for name, (lane, ldims) in oracle_lanes(pv, pd, tv, td).items():
+    member_only = name in ('CRPSSpread', 'EnsembleVariance')
+    use = mask if (mask is not None and (masked_member_only or not member_only)) else None
+    sws, sw, out_dims = O.aggregate(lane, ldims, reduce_dims, weights=[w], bin_masks=bm, mask=use,
+                                    mask_dims=mask_dims if use is not None else None, skipna=skipna)
+    key = stats[name].unique_name
+    gs = np.asarray(state.sum_weighted_statistics[key]['v'].transpose(*out_dims).values)
+    gw = np.asarray(state.sum_weights[key]['v'].transpose(*out_dims).values)
+    np.testing.assert_allclose(gw, sw, rtol=1e-12, atol=1e-12, err_msg=f'{layout} {name} sum_weights')
+    scale = np.abs(sws).max() if np.isfinite(sws).all() else 1.0
+    np.testing.assert_allclose(gs, sws, rtol=rtol, atol=rtol * 1e-3 * scale, err_msg=f'{layout} {name} sum_weighted_statistics')
+
+
+@pytest.mark.parametrize('layout', sorted(LAYOUTS))
+def test_nan_mask_with_time_strides_is_one_launch(backend, layout):
+  """What the reference's loaders build (data_loaders/base.py:25-56, add_nan_mask_to_data): targets with NaNs and
+  `mask = ~isnan(targets)` over EVERY dim of the targets -- another hole per lead time -- consumed by Aggregator(masked=True)
+  (aggregation.py:339-352; public_benchmark/run_benchmark_evaluation.py:379-381).  Still ONE wbx_ens_binned launch for the five
+  lanes (round 4 fell back to the two-stage route for any mask with a time / level stride)."""
+  from weatherbenchx_amd import data as wdata
+  nlat, nlon, m = 37, 72, 9
+  rng = np.random.default_rng(21)
+  land = rng.random((nlat, nlon)) > 0.55
+  p, t, pv, tv, lat, lon = make_case(layout, m, nlat, nlon, 3, seed=6)
+  tv[rng.random(tv.shape) < 0.2] = np.nan  # (another pattern at every (init, lead))
+  t = wdata.add_nan_mask_to_data({'v': xr.DataArray(tv, dims=t.dims, coords={k: t.coords[k].values for k in t.dims})})['v']
+  assert tuple(t.coords['mask'].dims) == tuple(t.dims)
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=True)
+  stats = lane_statistics()
+  state, log = run(stats, agg, p, t)
+  assert [(e['kind'], e['flags'] & 1) for e in log] == [('ens_binned', 1)], log
+  _check_lanes(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=~np.isnan(tv), mask_dims=LAYOUTS[layout][1])
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('masked', [False, True])
+def test_skipna_aggregation_is_one_launch(backend, layout, masked):
+  """Aggregator(skipna=True) (aggregation.py:343-344, 353-355): every statistic leaves ITS OWN NaN points out of its sum and its
+  weights -- skill / unbiased MSE / MSE of the mean where the target or a member is NaN, spread / variance where a member is.
+  One wbx_ens_binned launch (NaN-target points go to their atom's twin).  With `masked`: a (latitude, longitude) mask coordinate
+  on the targets on top, both sets from the same launch."""
+  nlat, nlon, m = 37, 72, 7
+  rng = np.random.default_rng(33)
+  land = rng.random((nlat, nlon)) > 0.5
+  valid = rng.random((nlat, nlon)) > 0.25
+  p, t, pv, tv, lat, lon = make_case(layout, m, nlat, nlon, 3, seed=9, mask=valid if masked else None)
+  tv[rng.random(tv.shape) < 0.15] = np.nan
+  pv[rng.random(pv.shape) < 0.01] = np.nan
+  pd, td = LAYOUTS[layout]
+  p = xr.DataArray(pv, dims=pd, coords={k: p.coords[k].values for k in pd if k != 'number'})
+  t2 = xr.DataArray(tv, dims=td, coords={k: t.coords[k].values for k in td})
+  t = t2.assign_coords(mask=t.coords['mask']) if masked else t2
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS, land_sea_mask=lsm)], masked=masked, skipna=True)
+  stats = lane_statistics()
+  state, log = run(stats, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], log
+  _check_lanes(state, stats, pv, tv, layout, lat, lon, land, ['latitude', 'longitude'], mask=valid if masked else None,
+               mask_dims=('latitude', 'longitude'), skipna=True)
+  # the member-only statistics first: the launch they trigger is the same one
+  engine.clear_caches()
+  order = ('EnsembleVariance', 'CRPSSpread', 'CRPSSkill', 'UnbiasedEnsembleMeanSquaredError', 'EnsembleMeanSquaredError')
+  p = xr.DataArray(pv, dims=pd, coords={k: p.coords[k].values for k in pd if k != 'number'})
+  state, log = run({k: stats[k] for k in order}, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], log
+  _check_lanes(state, stats, pv, tv, layout, lat, lon, land, ['latitude', 'longitude'], mask=valid if masked else None,
+               mask_dims=('latitude', 'longitude'), skipna=True)
+
+
+def test_skipna_with_the_same_mask_on_predictions_and_targets(backend):
+  """Predictions that carry the targets' mask coordinate: spread / variance are then statistics of the masked group itself
+  (lazy.ens_statistic: no member-only companion), i.e. lanes 1, 2 of the launch WITHOUT a twin output -- mask AND valid members,
+  whatever the target."""
+  nlat, nlon, m = 19, 36, 5
+  rng = np.random.default_rng(12)
+  valid = rng.random((nlat, nlon)) > 0.3
+  p, t, pv, tv, lat, lon = make_case('lon_fastest', m, nlat, nlon, 2, seed=4, mask=valid)
+  tv[rng.random(tv.shape) < 0.2] = np.nan
+  pv[rng.random(pv.shape) < 0.02] = np.nan
+  pd, td = LAYOUTS['lon_fastest']
+  mask_da = t.coords['mask']
+  p = xr.DataArray(pv, dims=pd, coords={k: p.coords[k].values for k in pd if k != 'number'}).assign_coords(mask=mask_da)
+  t = xr.DataArray(tv, dims=td, coords={k: t.coords[k].values for k in td}).assign_coords(mask=mask_da)
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(REGIONS)], masked=True, skipna=True)
+  stats = lane_statistics()
+  state, log = run(stats, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], log
+  _check_lanes(state, stats, pv, tv, 'lon_fastest', lat, lon, None, ['latitude', 'longitude'], mask=valid,
+               mask_dims=('latitude', 'longitude'), skipna=True, masked_member_only=True)
 
 
 def test_twin_sums_never_serve_another_target(backend):

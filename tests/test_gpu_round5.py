@@ -1,0 +1,187 @@
+"""Round-5 GPU parity tests at the sizes that run: wbx_ens_binned under the masks the reference itself builds -- the per-point
+NaN mask of add_nan_mask_to_data (data_loaders/base.py:25-56), another hole at every lead time -- and under
+Aggregator(skipna=True) (aggregation.py:339-357), at M = 51 on the full 0.25 degree grid with the public benchmark's 34 bins:
+every bin of all five lanes and of their weights against the float64 oracle, ONE launch.  Tolerance: rtol 1e-6 (north_star)."""
+import ctypes as C
+import dataclasses
+
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import _hip
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import data as wdata
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import planner
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+import test_ens_binned as EB
+import test_gpu_round4 as R4
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+NLAT, NLON = 721, 1440
+
+
+@pytest.fixture(scope='module')
+def ctx():
+  assert _hip.is_available(), 'gpu tests need libwbx_hip.so and a HIP device'
+  return _hip.default_context(0)
+
+
+def _holes(tv, td, lat, lon, rng):
+  """NaN targets the way observations / a regional analysis leave them: a block of latitudes that moves with the lead time, a
+  longitude band that differs per lead, and scattered single points."""
+  sizes = dict(zip(td, tv.shape))
+  la = np.abs(lat)[:, None] * np.ones(lon.size)[None, :]
+  for l in range(sizes['lead_time']):
+    hole = (la > 70 - 6 * l) & (np.cos(np.deg2rad(lon) * (3 + l))[None, :] > 0.3)
+    hole |= rng.random(hole.shape) < 0.002
+    sp = tuple(d for d in td if d in ('latitude', 'longitude'))
+    hv = hole if sp == ('latitude', 'longitude') else hole.T
+    idx = tuple(l if d == 'lead_time' else slice(None) for d in td)
+    tv[idx][np.broadcast_to(hv, tv[idx].shape)] = np.nan
+  return tv
+
+
+def _check(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, **kw):
+  saved = EB.REGIONS
+  EB.REGIONS = R4.REGIONS17
+  try:
+    EB._check_lanes(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, **kw)  # pylint: disable=protected-access
+  finally:
+    EB.REGIONS = saved
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest', 'ifs'])
+def test_nan_mask_per_lead_time_full_grid_one_launch(ctx, layout):
+  """M = 51, 721 x 1440, 34 bins, `mask = ~isnan(targets)` with another hole at every lead time, masked=True:
+  the masked statistics AND spread / variance of the predictions alone out of ONE wbx_ens_binned launch."""
+  lat, lon = np.linspace(-90, 90, NLAT), np.linspace(0, 360, NLON, endpoint=False)
+  land = R4._land(lat, lon)  # pylint: disable=protected-access
+  rng = np.random.default_rng(5)
+  p, t, pv, tv, lat, lon = EB.make_case(layout, 51, NLAT, NLON, 2, seed=77, ninit=1)
+  tv = _holes(tv, t.dims, lat, lon, rng)
+  t = wdata.add_nan_mask_to_data({'v': xr.DataArray(tv, dims=t.dims, coords={k: t.coords[k].values for k in t.dims})})['v']
+  assert tuple(t.coords['mask'].dims) == tuple(t.dims)
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(R4.REGIONS17, land_sea_mask=lsm)], masked=True)
+  stats = EB.lane_statistics()
+  state, log = EB.run(stats, agg, p, t)
+  assert [(e['kind'], e['flags'] & 1) for e in log] == [('ens_binned', 1)], log
+  assert not (log[0]['w_flags'] & _hip.BINNED_MASK_ON_W)  # the per-point route
+  _check(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=~np.isnan(tv), mask_dims=EB.LAYOUTS[layout][1])
+
+
+@pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
+@pytest.mark.parametrize('masked', [False, True])
+def test_skipna_full_grid_one_launch(ctx, layout, masked):
+  """Aggregator(skipna=True) at M = 51 on the full grid: NaN targets (holes that move with the lead time) and NaN members
+  (scattered), with and without a (latitude, longitude) mask coordinate on top; every bin of the five lanes and of the five
+  per-statistic weight sums."""
+  lat, lon = np.linspace(-90, 90, NLAT), np.linspace(0, 360, NLON, endpoint=False)
+  land = R4._land(lat, lon)  # pylint: disable=protected-access
+  valid = ~((np.abs(lat)[:, None] > 80) & (np.cos(np.deg2rad(lon) * 5)[None, :] > 0.2))
+  rng = np.random.default_rng(6)
+  p, t, pv, tv, lat, lon = EB.make_case(layout, 51, NLAT, NLON, 2, seed=78, mask=valid if masked else None)
+  tv = _holes(tv, t.dims, lat, lon, rng)
+  pv[rng.random(pv.shape) < 2e-4] = np.nan  # ~1 % of the points lose a member
+  pd, td = EB.LAYOUTS[layout]
+  p = xr.DataArray(pv, dims=pd, coords={k: p.coords[k].values for k in pd if k != 'number'})
+  t2 = xr.DataArray(tv, dims=td, coords={k: t.coords[k].values for k in td})
+  t = t2.assign_coords(mask=t.coords['mask']) if masked else t2
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(R4.REGIONS17, land_sea_mask=lsm)], masked=masked, skipna=True)
+  stats = EB.lane_statistics()
+  state, log = EB.run(stats, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], log
+  _check(state, stats, pv, tv, layout, lat, lon, land, ['latitude', 'longitude'], mask=valid if masked else None,
+         mask_dims=('latitude', 'longitude'), skipna=True)
+
+
+def test_raw_c_abi_point_mask_and_skipna(ctx):
+  """wbx_ens_binned through raw pointers with a mask that has a stride along A (no WBX_BINNED_MASK_ON_W) and with
+  WBX_FLAG_SKIPNA: the 6- / 12- / 10- / 20-lane outputs against NumPy."""
+  rng = np.random.default_rng(2)
+  nlead, m, nlat, nlon, nbin = 3, 8, 40, 200, 9
+  tv = rng.normal(size=(nlead, nlat, nlon)).astype(np.float32)
+  pv = (tv[:, None] + rng.normal(size=(nlead, m, nlat, nlon))).astype(np.float32)
+  mask = rng.random((nlead, nlat, nlon)) > 0.3
+  tv_nan = tv.copy()
+  tv_nan[rng.random(tv.shape) < 0.1] = np.nan
+  pv_nan = pv.copy()
+  pv_nan[rng.random(pv.shape) < 0.01] = np.nan
+  dims = ('lead_time', 'latitude', 'longitude')
+  sizes = {'lead_time': nlead, 'latitude': nlat, 'longitude': nlon}
+  lay_p = planner.InputLayout(strides={'lead_time': m * nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_t = planner.InputLayout(strides={'lead_time': nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_m = planner.InputLayout(strides={'lead_time': nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=1, base_alignment=256)
+  boxy = np.zeros((nlat, nlon, nbin), bool)
+  for b in range(nbin - 1):
+    boxy[(b * 4) % nlat:(b * 4) % nlat + 18, (b * 23) % nlon:(b * 23) % nlon + 90, b] = True
+  bits = np.zeros((nlat, nlon), np.uint64)
+  for b in range(nbin):
+    bits |= boxy[..., b].astype(np.uint64) << np.uint64(b)
+  wrow = rng.random(nlat) + 0.5
+  w_flags = _hip.BINNED_W_ON_X | _hip.BINNED_WT_ROW_ONLY
+  order = ['CRPSSkill', 'CRPSSpread', 'EnsembleVariance', 'UnbiasedEnsembleMeanSquaredError', 'EnsembleMeanSquaredError']
+  bits_buf, w_buf, m_buf = ctx.upload(bits), ctx.upload(wrow), ctx.upload(mask.astype(np.uint8))
+  member = boxy.astype(np.float64)
+
+  def run(pvals, tvals, flags, wf, nl):
+    plan = planner.build_s1_plan(dims, sizes, [lay_p, lay_t, None, lay_m if flags & _hip.FLAG_MASKED else None],
+                                 ('latitude', 'longitude'), wdep_dims={'latitude', 'longitude'}, flags=_hip.FLAG_FAIR | flags,
+                                 allow_vec4=False)
+    dplan = engine._PlanOnDevice(ctx, plan)  # pylint: disable=protected-access
+    out = ctx.alloc(nlead * nl * nbin * 8)
+    pb, tb = ctx.upload(pvals), ctx.upload(tvals)
+    _hip.check(R4._raw_call(ctx, plan, dplan, m, nlat * nlon, pb, tb, m_buf if flags & _hip.FLAG_MASKED else None, w_buf, bits_buf,  # pylint: disable=protected-access
+                            nlead, 1, nlat, wf, nbin, None, out), 'wbx_ens_binned')
+    return ctx.download(out.ptr, (nlead, nl, nbin), np.float64)
+
+  def sums(lane, ok):
+    with np.errstate(invalid='ignore'):
+      return np.einsum('ayx,y,yxb->ab', np.where(ok, lane, 0.0), wrow, member), np.einsum('ayx,y,yxb->ab', ok.astype(np.float64), wrow, member)
+
+  pdims = ('lead_time', 'number', 'latitude', 'longitude')
+  # (1) a mask with a stride along A, no skipna: 6 lanes, and 12 with the twin flag
+  lanes = EB.oracle_lanes(pv, pdims, tv, dims)
+  for wf, nl in ((w_flags, 6), (w_flags | _hip.BINNED_TWIN_MASK, 12)):
+    got = run(pv, tv, _hip.FLAG_MASKED, wf, nl)
+    for l, name in enumerate(order):
+      want, cnt = sums(lanes[name][0], mask)
+      np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+      np.testing.assert_allclose(got[:, 5], cnt, rtol=1e-12)
+      if nl == 12:
+        want, cnt = sums(lanes[name][0], np.ones_like(mask))
+        np.testing.assert_allclose(got[:, 6 + l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(got[:, 11], cnt, rtol=1e-12)
+  # (2) skipna, with NaN targets and NaN members: 10 lanes; with mask + twin: 20
+  lanes = EB.oracle_lanes(pv_nan, pdims, tv_nan, dims)
+  got = run(pv_nan, tv_nan, _hip.FLAG_SKIPNA, w_flags, 10)
+  for l, name in enumerate(order):
+    want, cnt = sums(lanes[name][0], ~np.isnan(lanes[name][0]))
+    np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(got[:, 5 + l], cnt, rtol=1e-12, err_msg=name)
+  got = run(pv_nan, tv_nan, _hip.FLAG_SKIPNA | _hip.FLAG_MASKED, w_flags, 10)
+  for l, name in enumerate(order):
+    want, cnt = sums(lanes[name][0], mask & ~np.isnan(lanes[name][0]))
+    np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(got[:, 5 + l], cnt, rtol=1e-12, err_msg=name)
+  got = run(pv_nan, tv_nan, _hip.FLAG_SKIPNA | _hip.FLAG_MASKED, w_flags | _hip.BINNED_TWIN_MASK, 20)
+  for l, name in enumerate(order):
+    if l in (1, 2):
+      assert np.isnan(got[:, l]).all()
+      want, cnt = sums(lanes[name][0], ~np.isnan(lanes[name][0]))
+      np.testing.assert_allclose(got[:, 10 + l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+      np.testing.assert_allclose(got[:, 15 + l], cnt, rtol=1e-12, err_msg=name)
+    else:
+      assert np.isnan(got[:, 10 + l]).all()
+      want, cnt = sums(lanes[name][0], mask & ~np.isnan(lanes[name][0]))
+      np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+      np.testing.assert_allclose(got[:, 5 + l], cnt, rtol=1e-12, err_msg=name)

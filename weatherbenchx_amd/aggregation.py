@@ -471,7 +471,7 @@ class Aggregator:
     if hit is None:
       sib = getattr(grp, 'twin_sibling', None)
       sib = sib() if sib is not None else None
-      if sib is not None and grp.kind == 'ens' and not use_mask and self.masked and not skipna and engine.ENS_TWIN_MASK:
+      if sib is not None and grp.kind == 'ens' and not use_mask and self.masked and engine.ENS_TWIN_MASK:
         # the masked sibling's launch also yields this group's (unmasked) sums: run it first if it has not run yet
         sparams = dict(getattr(sib, 'spread_params', None) or ens_params or {'algo': _hip.ENS_SORT, 'fair': True, 'skipna': False})
         skey = self._cache_key(w_da, bin_dims, True, skipna, (tuple(sorted(sparams.items())), mean_dims, 0))

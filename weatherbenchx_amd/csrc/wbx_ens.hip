@@ -117,7 +117,7 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
   WBX_REQUIRE(dtype == WBX_F32, "wbx_ens_binned takes float32 members (got dtype %d)", dtype);
   WBX_REQUIRE(algo == WBX_ENS_SORT, "wbx_ens_binned runs the rank form (WBX_ENS_SORT) only");
   WBX_REQUIRE(M >= 2 && M <= 64, "wbx_ens_binned handles 2..64 members (got %d)", M);
-  WBX_REQUIRE(!(plan->flags & (WBX_FLAG_SKIPNA | WBX_FLAG_SKIPNA_ENS)), "wbx_ens_binned does not take skipna / skipna_ensemble");
+  WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA_ENS), "wbx_ens_binned does not take skipna_ensemble (per-point member counts)");
   WBX_REQUIRE(nbin >= 1 && nbin <= 64, "wbx_ens_binned handles 1..64 bins (got %d)", nbin);
   WBX_REQUIRE(nA >= 0 && nBk >= 0 && nBr >= 0 && nA * nBk * nBr == plan->nkey, "nA*nBk*nBr must equal plan->nkey");
   WBX_REQUIRE((w_on_x & ~31) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
@@ -125,7 +125,8 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
               "wbx_ens_binned takes factored weights only (WBX_BINNED_WT_X_ONLY / WBX_BINNED_WT_ROW_ONLY), or wt = NULL");
   WBX_REQUIRE(!(w_on_x & WBX_BINNED_WT_X_ONLY) || (w_on_x & WBX_BINNED_W_ON_X), "WBX_BINNED_WT_X_ONLY needs WBX_BINNED_W_ON_X");
   const bool twin_out = (plan->flags & WBX_FLAG_MASKED) && (w_on_x & WBX_BINNED_TWIN_MASK);
-  const int64_t nout = nA * nBk * (twin_out ? ENS_ATOMS_NOUT2 : ENS_ATOMS_NOUT) * nbin;
+  const bool skipna = (plan->flags & WBX_FLAG_SKIPNA) != 0;
+  const int64_t nout = nA * nBk * (skipna ? (twin_out ? 20 : 10) : (twin_out ? ENS_ATOMS_NOUT2 : ENS_ATOMS_NOUT)) * nbin;
   if (nout == 0) return 0;
   WBX_REQUIRE(out != nullptr, "out is NULL");
   WBX_HIP(hipSetDevice(ctx->device));
@@ -136,8 +137,8 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
   WBX_REQUIRE(p != nullptr && t != nullptr && bits != nullptr, "p/t/bits is NULL");
   if (plan->flags & WBX_FLAG_MASKED) {
     WBX_REQUIRE(mask != nullptr, "WBX_FLAG_MASKED set but mask is NULL");
-    WBX_REQUIRE((w_on_x & WBX_BINNED_MASK_ON_W) && (w_on_x & WBX_BINNED_W_ON_X),
-                "wbx_ens_binned takes a validity mask that lives on the W dims only (WBX_BINNED_MASK_ON_W with WBX_BINNED_W_ON_X)");
+    WBX_REQUIRE(w_on_x & WBX_BINNED_W_ON_X, "wbx_ens_binned with a validity mask needs W indexed per x (WBX_BINNED_W_ON_X)");
+    WBX_REQUIRE(plan->xstride[3] >= 0, "the mask's x stride must be non-negative");
   }
   WBX_REQUIRE(plan->xstride[0] >= 0 && plan->xstride[1] >= 0 && (double)plan->nx * (double)plan->xstride[0] * 4.0 < 4294967296.0 &&
                   (double)plan->nx * (double)plan->xstride[1] * 4.0 < 4294967296.0,

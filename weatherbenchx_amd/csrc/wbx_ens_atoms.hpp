@@ -25,9 +25,19 @@
 //     the NaN rule (poison = sum over atoms of sum * 0: a non-finite term anywhere turns every bin of that statistic NaN, like
 //     the reference's xr.dot, aggregation.py:272-277) are shared.
 // Weights come factored (WBX_BINNED_WT_X_ONLY / _ROW_ONLY: GridAreaWeighting on latitude- / longitude-fastest chunks):
-// w = w_x[x] * w_row[row], one of the two factors being 1 (exact).  The mask must live on the W dims (WBX_BINNED_MASK_ON_W).
-// Everything else (dense weights, time-dependent masks, skipna, skipna_ensemble, float64 members, M > 64) stays on the
-// two-stage route.
+// w = w_x[x] * w_row[row], one of the two factors being 1 (exact).
+// Masks (r5).  A mask that lives on the W dims (WBX_BINNED_MASK_ON_W) is folded into the [bk][br][x] atom-id bytes; a mask with
+// strides along A / the depth dims -- what add_nan_mask_to_data builds, data_loaders/base.py:25-56 -- into one id byte per POINT of
+// the chunk (aid_merge_points_kernel), and the sweep reads its id byte from row (cell, r) instead of (bk, br): same kernel, same
+// instruction count, 209 instead of 208 bytes per point.
+// Aggregator(skipna=True) (r5, aggregation.py:339-357: NaN statistics are left out value by value and counted out of that
+// statistic's weights): flavour SKIPNA.  The statistics that look at the targets (skill, unbiased MSE, MSE of the mean) are NaN
+// where the target or a member is, the statistics of the predictions alone (spread, variance) only where a member is.  A point
+// with a NaN member gets weight 0 and values 0 (it is in no sum and no count); a point with a NaN TARGET is accumulated under its
+// atom's TWIN with skill = squared error = 0: the atom rows then hold the sums and the count of the target statistics, atom +
+// twin rows those of the member-only statistics, and lane 3 = lane 4 - lane 2 / M is formed from the atom rows alone.  No extra
+// accumulators (the kernel has three registers to spare).
+// Everything else (dense weights, skipna_ensemble, float64 members, M > 64) stays on the two-stage route.
 #pragma once
 #include <type_traits>
 #include "wbx_aidm.hpp"
@@ -117,6 +127,11 @@ struct EnsAtomsArgs {
                        // points are accumulated under the atom's TWIN, so that one launch yields the masked sums (atoms only) AND
                        // the unmasked ones (atoms + twins): the reference masks skill / unbiased MSE / mean MSE of a variable
                        // whose targets carry a mask but not its spread / variance (statistics of the predictions alone)
+  int32_t twin_rows;   // the twin half of the atom tables is in use: masked == 2, or the SKIPNA flavour (NaN targets)
+  int32_t out_mode;    // 0: out[cell][6][nbin]; 1 (twin): [12]; 2 (SKIPNA): [10] = five values + their five counts; 3 (SKIPNA +
+                       // twin): [20] = the masked ten, then the ten over all points (see wbx.h)
+  int64_t id_cell_rows;  // 0: the id bytes are [bk][br][nj] (bins / a mask on the W dims); R = nBr * D: one id byte per point,
+                         // [cell][r][nj] (a mask with strides along A / the depth dims)
   int64_t br_per_split;  // g.rows_per_split / D
   unsigned long long* prof;  // diagnostic builds (WBX_EA_PROF): eight time stamps per patch, else NULL
 };
@@ -141,7 +156,7 @@ struct EnsAtomsArgs {
 #ifndef WBX_ENS_ATOMS_RAGGED_WPB
 #define WBX_ENS_ATOMS_RAGGED_WPB 4
 #endif
-template <int MP, bool EXACT, bool NT>
+template <int MP, bool EXACT, bool NT, bool SKIPNA = false>
 __global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB), WBX_ENS_PIPE_WAVES)
 ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   constexpr int WPB = NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB;
@@ -167,7 +182,7 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   const int nw = g.nwords[bk * npatch + patch];
   WBX_EA_STAMP(0);
   constexpr int TR = ENS_ATOMS_ROWS2;  // table rows per patch (the twin half is only touched in twin mode)
-  const bool twin = e.masked == 2;
+  const bool twin = SKIPNA || e.twin_rows != 0;
   double* const tab = e.tab + (cell * npatch + patch) * (TR * NQ);
   // nw < 0: more than ATOM_MAX distinct membership words in one patch (arbitrary user masks).  This kernel has no slot
   // fallback: the host checks the tables before it chooses this route (wbx_ens_binned_atoms reports such patches); a caller
@@ -249,6 +264,9 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   int d_a = 0;
   const int br_last = (int)((rend - 1) / a.D);
   const int64_t key0 = (A * g.nBk + bk) * g.nBr, wrow0 = bk * g.nBr;
+  // id bytes: row (bk, br) of the [bk][br][nj] table, or row (cell, r = br * D + d) of the per-point table
+  const int64_t idrow0 = e.id_cell_rows ? cell * e.id_cell_rows : wrow0;
+  const int32_t idbr = e.id_cell_rows ? nD : 1, idd = e.id_cell_rows ? 1 : 0;
   int64_t ra0k = 0, ra0d = 0, ra1k = 0, ra1d = 0, wra = 0;  // the row looked up ahead (the table entries as they were loaded:
   double wwa = 1.0;                                          // adding them here would wait for the loads on the spot)
   // Unconditional (past the patch's last row it looks the last row up again): under a branch the scalar loads would be
@@ -265,7 +283,8 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
     ra0d = td0[(int64_t)d_a & md0];
     ra1k = tk1[key & mk1];
     ra1d = td1[(int64_t)d_a & md1];
-    wra = (wrow0 + br_a) * g.nj;
+    wra = (idrow0 + (int64_t)__builtin_amdgcn_readfirstlane(br_a * idbr + d_a * idd)) * g.nj;  // (32-bit; the compiler keeps
+                                                                                           //  d_a on the VALU: say that it is uniform)
     wwa = twr[(wrow0 + br_a) & mwr];
     const bool wrap = d_a + 1 == nD;
     d_a = wrap ? 0 : d_a + 1;
@@ -342,8 +361,9 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
 #pragma unroll
     for (int m = NLDS; m < MP; ++m) r.xm[m] = xn[m - NLDS];
     r.t = tn;
-    const int id = idn;
-    const double w = w_lane * wrn;
+    int id = idn;
+    if constexpr (SKIPNA) id = (tn != tn && id != NONE) ? (id | 0x80) : id;  // a NaN target: the point goes to its atom's twin
+    double w = w_lane * wrn;
     int64_t rocur[WBX_MAX_INPUTS];
     rocur[0] = ron0;
     rocur[1] = ron1;
@@ -379,7 +399,17 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
 
     double val[Op::NLANE];
     Op::template finish<true>(a, rocur, (int64_t)x, r, val);
-    const double q[4] = {val[0], val[1], val[2], val[4]};
+    double q[4] = {val[0], val[1], val[2], val[4]};
+    if constexpr (SKIPNA) {
+      // spread is NaN iff a member is NaN / infinite (it never looks at the target): such a point is in no sum and no count;
+      // a twin point (NaN target, or masked out) adds to the member-only statistics alone
+      const bool bad = q[1] != q[1], tw = (id & 0x80) != 0;
+      w = bad ? 0.0 : w;
+      q[0] = (bad || tw) ? 0.0 : q[0];
+      q[3] = (bad || tw) ? 0.0 : q[3];
+      q[1] = bad ? 0.0 : q[1];
+      q[2] = bad ? 0.0 : q[2];
+    }
     if (__builtin_amdgcn_inverse_ballot_w64(h0)) {
 #pragma unroll
       for (int l = 0; l < 4; ++l) acc0[l] = fma(q[l], w, acc0[l]);
@@ -401,8 +431,7 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   // ---- the patch is done: publish its table, then the sums over patches (see EnsAtomsArgs).  A record is [NOUT][64]: lane =
   // bin, so every lane of the wave adds the same six statistics and only the membership factor differs.
   constexpr int NOUT2 = ENS_ATOMS_NOUT2;
-  const int nout = twin ? NOUT2 : NOUT;
-  const int NP = nout * 64;
+  const int NP = (twin ? NOUT2 : NOUT) * 64;  // lanes of a record between the levels
   // -> true for the wave that completes the set (exactly one): everything the others wrote before their arrival is visible to it
   auto last_of = [&](uint32_t* counter, uint32_t total) -> bool {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's table / record has arrived where every XCD sees it
@@ -538,9 +567,30 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   if (!last_of(cnt3, (uint32_t)e.ng2)) return;
   add_records(e.part2 + cell * e.ng2 * NP, e.ng2, sum);
   if (lane < g.nbin) {
+    if constexpr (!SKIPNA) {
+      const int nout = twin ? NOUT2 : NOUT;
 #pragma unroll
-    for (int l = 0; l < NOUT2; ++l)
-      if (l < nout) e.out[(cell * nout + l) * g.nbin + lane] = sum[l];
+      for (int l = 0; l < NOUT2; ++l)
+        if (l < nout) e.out[(cell * nout + l) * g.nbin + lane] = sum[l];
+    } else {
+      // five values, then their five counts (the layout of every skipna reduction in this library); sums 0-5 are over the atom
+      // rows (targets valid), 6-11 over atom + twin rows
+      const double nan = __builtin_nan("");
+      if (e.out_mode == 2) {
+        // no twin output: the member-only statistics of THIS group are the sums over atoms + twins (NaN-target points included)
+        const double v[10] = {sum[0], sum[7], sum[8], sum[3], sum[4], sum[5], sum[11], sum[11], sum[5], sum[5]};
+#pragma unroll
+        for (int l = 0; l < 10; ++l) e.out[(cell * 10 + l) * g.nbin + lane] = v[l];
+      } else {
+        // twin output: the twins also hold the masked-out points, so the masked spread / variance (valid mask AND valid members,
+        // whatever the target) is not among the sums: NaN, and nobody asks for it -- the member-only statistics of such a variable
+        // carry no mask and read the second ten; there the target statistics over all points are not formed either
+        const double v[20] = {sum[0], nan, nan, sum[3], sum[4], sum[5], sum[5], sum[5], sum[5], sum[5],
+                              nan, sum[7], sum[8], nan, nan, sum[11], sum[11], sum[11], sum[11], sum[11]};
+#pragma unroll
+        for (int l = 0; l < 20; ++l) e.out[(cell * 20 + l) * g.nbin + lane] = v[l];
+      }
+    }
   }
   WBX_EA_STAMP(7);
 }
@@ -595,7 +645,9 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   patch_geometry(probe, cells, c.nBk, c.nBr, c.nj, plan->ndepth, plan->nx, ens_atoms_rows(), ens_atoms_taper());
   const int64_t npatch = (int64_t)probe.nrs * probe.nxt;
   const int ng1 = (int)((npatch + ENS_ATOMS_G1 - 1) / ENS_ATOMS_G1), ng2 = (ng1 + ENS_ATOMS_G2 - 1) / ENS_ATOMS_G2;
-  const bool twin = (plan->flags & WBX_FLAG_MASKED) && (c.w_on_x & WBX_BINNED_TWIN_MASK);
+  const bool masked = (plan->flags & WBX_FLAG_MASKED) != 0, skipna = (plan->flags & WBX_FLAG_SKIPNA) != 0;
+  const bool twin_out = masked && (c.w_on_x & WBX_BINNED_TWIN_MASK);  // the caller wants the sums over all points too
+  const bool twin = twin_out || skipna;                                // the twin half of the atom tables is in use
   const size_t NP = (size_t)(twin ? ENS_ATOMS_NOUT2 : ENS_ATOMS_NOUT) * 64;
   const size_t n_tab = (size_t)probe.nblocks * ENS_ATOMS_ROWS2 * ENS_ATOMS_NQ, n_p1 = (size_t)cells * ng1 * NP, n_p2 = (size_t)cells * ng2 * NP;
   // (nacc = 0: no per-patch bin tables -- the sums over patches happen inside the kernel)
@@ -613,10 +665,18 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   e.ng2 = ng2;
   if (int rc = ens_atoms_counters(ctx, (size_t)cells * (ng1 + ng2 + 1), &e.counters)) return rc;
   e.masked = 0;
+  e.twin_rows = twin ? 1 : 0;
+  e.out_mode = skipna ? (twin_out ? 3 : 2) : (twin_out ? 1 : 0);
+  e.id_cell_rows = 0;
   e.br_per_split = g.rows_per_split / plan->ndepth;
-  if (plan->flags & WBX_FLAG_MASKED) {
-    if (int rc = merge_mask_into_atom_ids(ctx, a, g, twin)) return rc;
-    e.masked = twin ? 2 : 1;
+  if (masked) {
+    if (c.w_on_x & WBX_BINNED_MASK_ON_W) {
+      if (int rc = merge_mask_into_atom_ids(ctx, a, g, twin_out)) return rc;
+    } else {  // strides along A / the depth dims: one id byte per point of the chunk
+      if (int rc = merge_point_mask_into_atom_ids(ctx, a, g, plan->ndepth, twin_out)) return rc;
+      e.id_cell_rows = c.nBr * plan->ndepth;
+    }
+    e.masked = twin_out ? 2 : 1;
   }
   static const int nt_env = getenv("WBX_ENS_ATOMS_NT") ? atoi(getenv("WBX_ENS_ATOMS_NT")) : -1;
   static const int order_env = getenv("WBX_PATCH_ORDER") ? atoi(getenv("WBX_PATCH_ORDER")) : -1;
@@ -632,8 +692,12 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   WBX_HIP(hipMalloc(reinterpret_cast<void**>(&e.prof), prof_bytes));
   WBX_HIP(hipMemsetAsync(e.prof, 0, prof_bytes, ctx->stream));
 #endif
-  if (nt)
+  if (nt && skipna)
+    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
+  else if (nt)
     hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
+  else if (skipna)
+    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false, true>), dim3((unsigned)grid), dim3(64 * WBX_ENS_ATOMS_RAGGED_WPB), 0, ctx->stream, a, g, e);
   else
     hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64 * WBX_ENS_ATOMS_RAGGED_WPB), 0, ctx->stream, a, g, e);
   WBX_HIP(hipGetLastError());

@@ -1109,8 +1109,9 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
 
 
 # The ensemble family with weights, bins and mask in ONE pass (wbx_ens_binned, csrc/wbx_ens_atoms.hpp) whenever it applies:
-# rank form, float32, 2..64 members, boolean bin masks, separable weights, a validity mask that lives on the W dims, no
-# skipna.  False: the two-stage route (x-kept ensemble kernel + wbx_contract_bits), for A/B timing and tests.
+# rank form, float32, 2..64 members, boolean bin masks, separable weights; (r5) any validity mask -- also the per-point one
+# add_nan_mask_to_data builds, with strides along time / level -- and Aggregator(skipna=True).  False: the two-stage route
+# (x-kept ensemble kernel + wbx_contract_bits), for A/B timing and tests.
 ENS_BINNED = os.environ.get('WBX_ENS_BINNED', '1') != '0'
 ENS_BINNED_LANES = 6  # the five ensemble lanes + the count lane, always
 # With a mask, ONE launch yields the masked sums (lanes 0-5) and the sums over all points (lanes 6-11): the reference masks the
@@ -1124,7 +1125,7 @@ def _mask_on_w_only(plan: planner.S1Plan, mask_dev) -> bool:
   return all(mask_dev.layout.stride(d) == 0 for d in tuple(plan.a_dims) + tuple(plan.depth_dims))
 
 
-def _ens_binned_flags(plan: planner.S1Plan, w_buf, devs):
+def _ens_binned_flags(plan: planner.S1Plan, w_buf, devs, twin_ok=True):
   """WBX_BINNED_* flags of a wbx_ens_binned call, or None when the weights / the mask rule it out."""
   w_flags = _hip.BINNED_W_ON_X if (plan.x_kept and plan.nj > 1) else 0
   if w_buf.factored is None or not SEPARABLE_BINNED_WEIGHTS:
@@ -1133,10 +1134,11 @@ def _ens_binned_flags(plan: planner.S1Plan, w_buf, devs):
   if (w_flags & _hip.BINNED_WT_X_ONLY) and not (w_flags & _hip.BINNED_W_ON_X):
     return None
   if devs[3] is not None:
-    if not (w_flags & _hip.BINNED_W_ON_X) or not _mask_on_w_only(plan, devs[3]):
+    if not (w_flags & _hip.BINNED_W_ON_X) or plan.xstride[3] < 0:
       return None
-    w_flags |= _hip.BINNED_MASK_ON_W
-    if ENS_TWIN_MASK:
+    if _mask_on_w_only(plan, devs[3]):  # folded into the [bk][br][x] atom ids; else one id byte per point of the chunk
+      w_flags |= _hip.BINNED_MASK_ON_W
+    if ENS_TWIN_MASK and twin_ok:
       w_flags |= _hip.BINNED_TWIN_MASK
   return w_flags
 
@@ -1162,11 +1164,11 @@ def _ens_binned_atoms(ctx, dplan, plan: planner.S1Plan, w_buf, w_flags):
   return hit[0] if hit[1] == 0 else None
 
 
-def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype_code, flags, ens):
+def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype_code, flags, ens, twin_ok=True):
   """(w_flags, atoms) when this reduction runs on wbx_ens_binned, else None."""
   if kind != 'ens' or not ENS_BINNED or w_buf.kind != 'bits' or dtype_code != _hip.F32:
     return None
-  if ens['algo'] != _hip.ENS_SORT or not 2 <= ens['M'] <= 64 or (flags & (_hip.FLAG_SKIPNA | _hip.FLAG_SKIPNA_ENS)):
+  if ens['algo'] != _hip.ENS_SORT or not 2 <= ens['M'] <= 64 or (flags & _hip.FLAG_SKIPNA_ENS):
     return None
   if plan.x_kept and not plan.sum_j:  # x survives into the output: the two-stage path keeps it
     return None
@@ -1174,7 +1176,7 @@ def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype
     return None
   if plan.nx * plan.xstride[0] * 4 >= 1 << 32 or plan.nx * plan.xstride[1] * 4 >= 1 << 32:  # 32-bit x byte offsets, both inputs
     return None
-  w_flags = _ens_binned_flags(plan, w_buf, devs)
+  w_flags = _ens_binned_flags(plan, w_buf, devs, twin_ok)
   if w_flags is None:
     return None
   atoms = _ens_binned_atoms(ctx, dplan, plan, w_buf, w_flags)
@@ -1183,20 +1185,20 @@ def _ens_binned_route(ctx, kind, plan: planner.S1Plan, dplan, w_buf, devs, dtype
   return w_flags, atoms
 
 
-def _twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens):
+def _twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens, skipna=False):
   return (tuple(dims), tuple(sizes[d] for d in dims), tuple(sorted(reduce_dims, key=str)), id(w_da), tuple(bin_dims),
-          ens['member_dim'], ens['M'], ens['algo'], bool(ens.get('fair', True)))
+          ens['member_dim'], ens['M'], ens['algo'], bool(ens.get('fair', True)), bool(skipna))
 
 
-def _twin_store(p_da, ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, result):
-  p_da.__dict__.setdefault('_wbx_twin', {})[_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens)] = (result, ctx, w_da)
+def _twin_store(p_da, ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, result, skipna=False):
+  p_da.__dict__.setdefault('_wbx_twin', {})[_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens, skipna)] = (result, ctx, w_da)
 
 
-def _twin_lookup(p_da, dims, sizes, reduce_dims, w_da, bin_dims, ens):
+def _twin_lookup(p_da, dims, sizes, reduce_dims, w_da, bin_dims, ens, skipna=False):
   """The unmasked half of a twin launch over these very predictions (same frame, reduction, weights / bins object and ensemble
   parameters), or None.  Only the statistics of the predictions ALONE are served from it (spread, variance: their group's
   companion target is a member of the predictions, lazy.ens_statistic(member_only=True)) -- the caller's lane picks them."""
-  hit = p_da.__dict__.get('_wbx_twin', {}).get(_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens))
+  hit = p_da.__dict__.get('_wbx_twin', {}).get(_twin_key(dims, sizes, reduce_dims, w_da, bin_dims, ens, skipna))
   if hit is None:
     return None
   result, ctx, _ = hit
@@ -1211,7 +1213,9 @@ def _run_ens_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype
   w_flags, atoms = route
   nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
   nbin = w_buf.shape[-1]
-  shape = (nA, nBk, ENS_BINNED_LANES * (2 if (w_flags & _hip.BINNED_TWIN_MASK) else 1), 1, nbin)
+  # six lanes (five values + the shared count), under skipna ten (five values + their five counts); twice that in twin mode
+  per_set = 2 * _hip.ENS_LANES if (plan.flags & _hip.FLAG_SKIPNA) else ENS_BINNED_LANES
+  shape = (nA, nBk, per_set * (2 if (w_flags & _hip.BINNED_TWIN_MASK) else 1), 1, nbin)
   out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   m, mstride, algo = ens_args
@@ -1258,11 +1262,11 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   under a mask alone, else a data-independent constant broadcast to all.
   """
   global _deferred
-  if (kind == 'ens' and mask is None and not skipna and inputs[0] is not None
+  if (kind == 'ens' and mask is None and inputs[0] is not None
       and inputs[1] is inputs[0].__dict__.get('_wbx_member0', {}).get(ens['member_dim'])):
     # the member-only group alone (lazy.ens_statistic(member_only=True): its companion operand is lazy.first_member(p)) --
     # lanes 0, 3, 4 of a twin depend on the targets it was launched with, so a group with targets of its own never reads it
-    twin = _twin_lookup(inputs[0], dims, sizes, reduce_dims, w_da, bin_dims, ens)
+    twin = _twin_lookup(inputs[0], dims, sizes, reduce_dims, w_da, bin_dims, ens, skipna)
     if twin is not None:
       return twin
   ctx = ctx or _launch_context(kind)
@@ -1339,7 +1343,11 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
-  ens_route = _ens_binned_route(ctx, kind, plan, dplan, w_buf, devs, dtype_code, flags, ens) if kind == 'ens' else None
+  # Under skipna a twin launch does not form the masked spread / variance (wbx.h): fine while those are statistics of a
+  # member-only group that reads the twin -- i.e. unless the predictions carry a mask coordinate themselves, in which case
+  # lazy.ens_statistic keeps them in THIS group (lanes 1, 2) and no twin output is asked for.
+  twin_ok = not (skipna and inputs[0] is not None and 'mask' in inputs[0].coords)
+  ens_route = _ens_binned_route(ctx, kind, plan, dplan, w_buf, devs, dtype_code, flags, ens, twin_ok) if kind == 'ens' else None
   if ens_route is not None:
     res = _run_ens_binned(ctx, dplan, plan, devs, dtype_code, ens_args, w_buf, ens_route)
   elif _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
@@ -1364,9 +1372,13 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
     return v
 
   if ens_route is not None and (ens_route[0] & _hip.BINNED_TWIN_MASK):
-    # lanes 6-11: the same statistics over ALL points, for the statistics of these predictions that carry no mask
-    _twin_store(inputs[0], ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, (lanes_of(ENS_BINNED_LANES, nl),
-                np.broadcast_to(lanes_of(2 * ENS_BINNED_LANES - 1, 1), lanes_of(0, nl).shape), out_dims))
+    # the second set: the same statistics over ALL points, for the statistics of these predictions that carry no mask
+    if flags & _hip.FLAG_SKIPNA:  # [5 values | 5 counts] twice
+      _twin_store(inputs[0], ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens,
+                  (lanes_of(2 * nl, nl), lanes_of(3 * nl, nl), out_dims), skipna=True)
+    else:
+      _twin_store(inputs[0], ctx, dims, sizes, reduce_dims, w_da, bin_dims, ens, (lanes_of(ENS_BINNED_LANES, nl),
+                  np.broadcast_to(lanes_of(2 * ENS_BINNED_LANES - 1, 1), lanes_of(0, nl).shape), out_dims))
   values = lanes_of(0, nl)
   if counted:
     counts = np.broadcast_to(lanes_of(nl, 1), values.shape) if shared_count else lanes_of(nl, nl)
