@@ -249,21 +249,36 @@ def ensemble_variance(p, p_dims, ensemble_dim, skipna_ensemble=False):
   return (_nanvar_last(pm) if skipna_ensemble else pm.var(axis=-1, ddof=1)), dims
 
 
-def unbiased_ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim, skipna_ensemble=False):
-  """probabilistic.py:276-336: (mean_m p - t)^2 - var/M; skipna_ensemble -> mean, variance and M over the non-NaN
-  members of each point (:304-314)."""
-  pm, dims = _move_member_last(p, p_dims, ensemble_dim)
-  out_dims = union_dims(dims, t_dims)
+def _ensemble_moments(x, x_dims, ensemble_dim, skipna_ensemble):
+  """(mean, var(ddof=1) / n, dims without the member dim) -- probabilistic.py:304-314 for the predictions, :320-330 for
+  ensemble-valued targets: with skipna_ensemble mean, variance and n run over the non-NaN members of each point."""
+  xm, dims = _move_member_last(x, x_dims, ensemble_dim)
   if skipna_ensemble:
-    m = expand_to((~np.isnan(pm)).sum(axis=-1).astype(np.float64), dims, out_dims)
-    mean, var = expand_to(_nanmean_last(pm), dims, out_dims), expand_to(_nanvar_last(pm), dims, out_dims)
+    n = (~np.isnan(xm)).sum(axis=-1).astype(np.float64)
+    mean, var = _nanmean_last(xm), _nanvar_last(xm)
   else:
-    m = pm.shape[-1]
-    mean = expand_to(pm.mean(axis=-1), dims, out_dims)
-    var = expand_to(pm.var(axis=-1, ddof=1), dims, out_dims)
-  te = expand_to(f64(t), t_dims, out_dims)
+    n = xm.shape[-1]
+    with np.errstate(invalid='ignore', divide='ignore'):
+      mean, var = xm.mean(axis=-1), (xm.var(axis=-1, ddof=1) if xm.shape[-1] > 1 else np.full(xm.shape[:-1], np.nan))
   with np.errstate(invalid='ignore', divide='ignore'):
-    return (mean - te) ** 2 - var / m, out_dims
+    return mean, var / n, dims
+
+
+def unbiased_ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim, skipna_ensemble=False):
+  """probabilistic.py:276-336: (mean_m p - t)^2 - var_p / M; skipna_ensemble -> mean, variance and M over the non-NaN
+  members of each point (:304-314).  Targets that carry the ensemble dim too (:320-330): t becomes the mean of the target
+  members and their own bias var_t / N is subtracted as well, (mean p - mean t)^2 - var_p / M - var_t / N (:334-336)."""
+  p_mean, p_bias, dims = _ensemble_moments(p, p_dims, ensemble_dim, skipna_ensemble)
+  if ensemble_dim in t_dims:
+    t_mean, t_bias, tdims = _ensemble_moments(t, t_dims, ensemble_dim, skipna_ensemble)
+  else:
+    t_mean, t_bias, tdims = f64(t), None, tuple(t_dims)
+  out_dims = union_dims(dims, tdims)
+  with np.errstate(invalid='ignore', divide='ignore'):
+    out = (expand_to(p_mean, dims, out_dims) - expand_to(t_mean, tdims, out_dims)) ** 2 - expand_to(p_bias, dims, out_dims)
+    if t_bias is not None:
+      out = out - expand_to(t_bias, tdims, out_dims)
+  return out, out_dims
 
 
 def ensemble_mean_squared_error(p, p_dims, t, t_dims, ensemble_dim):

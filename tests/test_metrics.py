@@ -635,7 +635,9 @@ def test_unbiased_mse_with_an_ensemble_of_targets(backend, np_members, nt_member
   agg = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
   got = aggregation.compute_metric_values_for_single_chunk({'u': probabilistic.UnbiasedEnsembleMeanRMSE()}, agg, p, t)
   p64, t64 = pv.astype(np.float64), tv.astype(np.float64)
-  stat = ((p64.mean(0) - t64.mean(1)) ** 2 - p64.var(0, ddof=1) / np_members - t64.var(1, ddof=1) / nt_members)
+  pdims, tdims = ('number', 'lead_time', 'latitude', 'longitude'), ('lead_time', 'number', 'latitude', 'longitude')
+  stat, sdims = O.unbiased_ensemble_mean_squared_error(pv, pdims, tv, tdims, 'number')  # (pinned: test_oracle_reference_pins.py)
+  assert sdims == ('lead_time', 'latitude', 'longitude')
   w = O.grid_area_weights(lat)[None, :, None]
   want = np.sqrt((stat * w).sum(axis=(1, 2)) / (np.broadcast_to(w, stat.shape).sum(axis=(1, 2))))
   np.testing.assert_allclose(got['u.v'].values, want, rtol=RTOL)
@@ -654,9 +656,7 @@ def test_unbiased_mse_with_an_ensemble_of_targets(backend, np_members, nt_member
   got = aggregation.compute_metric_values_for_single_chunk(
       {'u': probabilistic.UnbiasedEnsembleMeanRMSE(skipna_ensemble=True)}, agg, pq, tq)
   p64, t64 = pn.astype(np.float64), tn.astype(np.float64)
-  with np.errstate(invalid='ignore'):
-    stat = ((np.nanmean(p64, 0) - np.nanmean(t64, 1)) ** 2 - np.nanvar(p64, 0, ddof=1) / (~np.isnan(p64)).sum(0)
-            - np.nanvar(t64, 1, ddof=1) / (~np.isnan(t64)).sum(1))
+  stat, _ = O.unbiased_ensemble_mean_squared_error(pn, pdims, tn, tdims, 'number', skipna_ensemble=True)
   want = np.sqrt((stat * w).sum(axis=(1, 2)) / (np.broadcast_to(w, stat.shape).sum(axis=(1, 2))))
   np.testing.assert_allclose(got['u.v'].values, want, rtol=RTOL)
   # CRPSSkill: mean over the non-NaN (prediction member, target member) pairs of each point

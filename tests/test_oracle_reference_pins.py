@@ -244,3 +244,52 @@ def test_crps_ensemble_distance_between_equal_distributions(m, use_sort, fair):
   plain = O.crps(mean(*O.crps_skill(p, pd_, t[..., 0], pd_[:3], 'realization')), spread_p)
   np.testing.assert_allclose(no_spread, plain, atol=5 * stderr)
   np.testing.assert_allclose(no_spread, plain, rtol=1e-12)  # identical in fact: the target spread term is exactly 0
+
+
+@pytest.mark.parametrize('m,n', [(5, 3), (4, 2), (2, 6)])
+def test_unbiased_mse_against_an_ensemble_of_targets(m, n):
+  # probabilistic.py:320-336 -- the reference's own tests never hand UnbiasedEnsembleMeanSquaredError ensemble-valued targets
+  # (metrics_test.py:947-981 uses deterministic targets), so the restatement is pinned on what the reference lines say:
+  # (a) the literal formula (mean p - mean t)^2 - var_p / M - var_t / N with ddof = 1;
+  # (b) targets whose N members are all the same have var_t = 0: the value against the single field (:331-333);
+  # (c) it is UNBIASED: for iid p ~ N(2, 1), t ~ N(0, 1) the mean over many points is (2 - 0)^2 within 5 standard errors,
+  #     whatever M and N (the biased (mean p - mean t)^2 has expectation 4 + 1 / M + 1 / N);
+  # (d) skipna_ensemble with an all-NaN member on each side equals dropping those members (:304-314, :320-330).
+  rng = np.random.default_rng(7 * m + n)
+  shape = (4, 19, 36)
+  p = rng.normal(size=(m,) + shape) + 2.0
+  t = rng.normal(size=shape[:1] + (n,) + shape[1:])
+  pd_, td = ('realization', 'time', 'latitude', 'longitude'), ('time', 'realization', 'latitude', 'longitude')
+  got, dims = O.unbiased_ensemble_mean_squared_error(p, pd_, t, td, 'realization')
+  assert dims == ('time', 'latitude', 'longitude')
+  want = (p.mean(0) - t.mean(1)) ** 2 - p.var(0, ddof=1) / m - t.var(1, ddof=1) / n
+  np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
+  flat = np.repeat(t[:, :1], n, axis=1)
+  np.testing.assert_allclose(O.unbiased_ensemble_mean_squared_error(p, pd_, flat, td, 'realization')[0],
+                             O.unbiased_ensemble_mean_squared_error(p, pd_, t[:, 0], ('time', 'latitude', 'longitude'), 'realization')[0],
+                             rtol=1e-12, atol=1e-14)
+  # Var of the statistic per point is at most ~ (4 * 4 * (1/M + 1/N) + 2 (1/M + 1/N)^2 + ...): bound it by 20 (1/M + 1/N) + 4
+  stderr = np.sqrt((20 * (1 / m + 1 / n) + 4) / got.size)
+  assert abs(got.mean() - 4.0) < 5 * stderr
+  biased = ((p.mean(0) - t.mean(1)) ** 2).mean()
+  assert abs(biased - (4.0 + 1 / m + 1 / n)) < 5 * stderr
+  if m > 2 and n > 2:
+    q, u = p.copy(), t.copy()
+    q[0], u[:, 0] = np.nan, np.nan
+    np.testing.assert_allclose(O.unbiased_ensemble_mean_squared_error(q, pd_, u, td, 'realization', skipna_ensemble=True)[0],
+                               O.unbiased_ensemble_mean_squared_error(p[1:], pd_, t[:, 1:], td, 'realization')[0], rtol=1e-12)
+
+
+def test_crps_target_spread_is_the_spread_statistic_of_the_targets():
+  # probabilistic.py:749-771: CRPSEnsembleDistance's third statistic is CRPSSpread(which='targets') -- the same estimator on
+  # the target ensemble (:165-247 with `which`), so a distance of an ensemble to ITSELF is E|X - X'| (1 - 1/2 - 1/2) = 0
+  # up to the fair / conventional normalisation of the skill term: with fair=False skill == spread exactly.
+  rng = np.random.default_rng(9)
+  p = rng.normal(size=(3, 5, 7, 6))
+  pd_ = ('time', 'latitude', 'longitude', 'realization')
+  red = ['time', 'latitude', 'longitude']
+  mean = lambda vals, dims: (lambda r: r[0] / r[1])(O.aggregate(vals, dims, red))
+  skill = mean(*O.crps_skill(p, pd_, p, pd_, 'realization'))
+  spread = mean(*O.crps_spread(p, pd_, 'realization', fair=False))
+  np.testing.assert_allclose(skill, spread, rtol=1e-12)
+  np.testing.assert_allclose(O.crps_ensemble_distance(skill, spread, spread), 0.0, atol=1e-14)
