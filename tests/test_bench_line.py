@@ -91,3 +91,26 @@ def test_small_bench_prints_one_parsable_line():
     assert k in line, k
   assert line['roofline']['frac'] > 0 and line['cpu_baseline']['value'] > 0
   assert json.load(open(os.path.join(ROOT, line['full'])))['value'] == line['value']
+
+
+def test_gpus_8_launch_command_is_the_drivers(monkeypatch):
+  """`python bench.py --gpus 8` from a bare shell on an 8-GPU node re-launches itself exactly as the driver would:
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...`,
+  one rank per GPU, with HSA_ENABLE_IPC_MODE_LEGACY=0 in the ranks' environment (dmabuf IPC for RCCL)."""
+  import argparse
+  import bench
+  from weatherbenchx_amd import _hip
+  seen = {}
+  monkeypatch.setattr(_hip, 'device_count', lambda: 8)
+  monkeypatch.setattr(bench.os.path, 'exists', lambda p: True)
+  monkeypatch.setattr(bench.subprocess, 'call', lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+  monkeypatch.setattr(bench.sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'])
+  monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+  rc = bench.self_launch(argparse.Namespace(gpus=8, steps=7, warmup=2, backend='nccl'))
+  assert rc == 0
+  cmd = seen['cmd']
+  assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nnodes=1' in cmd and '--nproc-per-node=8' in cmd
+  assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+  script = cmd.index(os.path.join(ROOT, 'bench.py'))
+  assert cmd[script + 1:] == ['--gpus', '8', '--steps', '7', '--warmup', '2']
+  assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'

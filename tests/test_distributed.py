@@ -351,3 +351,124 @@ def test_changed_labels_under_a_cached_plan_replan_on_every_rank(tmp_path):
   # the CURRENT step's frame, and that step 2 (labels back to the base grid) re-plans again instead of replaying step 1
   np.testing.assert_array_equal(r0[2][0], base)
   np.testing.assert_array_equal(r1[2][0], base)
+
+
+# ---- configs[4] at world size 8: 366 one-init chunks -> 46 / 45 per rank, init_time reduced AND preserved -----------------------
+C5_NINIT, C5_NLEAD, C5_NLEV, C5_NLAT, C5_NLON, C5_M = 366, 4, 2, 6, 16, 3
+
+
+def _config5_accumulator_values(nlead, nlev, nlon, ninit=0):
+  """Values of the job's ONE collective (bench.py config5_leg): per (lead, level) sums + weights of the six deterministic
+  statistics, per (lead, level, wavenumber) of the two spectra, per lead of the five ensemble statistics; `ninit` > 0: plus the
+  slots of the aggregator that preserves init_time -- per (init, lead, level) the six lanes of the deterministic launch it shares
+  with the first evaluation (a launch's result buffer is accumulated whole) and their count lane."""
+  return 6 * 2 * nlead * nlev + 2 * 2 * nlead * nlev * (nlon // 2 + 1) + 5 * 2 * nlead + 7 * ninit * nlead * nlev
+
+
+def _config5_case():
+  """bench.py's configs[4] leg in miniature: three evaluations over ONE chunking of 366 inits (1 init x all leads per chunk), plus
+  a fourth aggregator that keeps init_time (its slots exist on one rank each and are concatenated by the same sum)."""
+  from weatherbenchx_amd import aggregation, spectra, time_chunks, weighting
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import deterministic, probabilistic, wrappers
+  lat, lon, level = np.linspace(-75, 75, C5_NLAT), np.arange(C5_NLON) * (360.0 / C5_NLON), np.arange(C5_NLEV)
+  lead_time = (np.arange(C5_NLEAD) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  init_times = np.datetime64('2020-01-01T00', 'ns') + np.arange(C5_NINIT) * np.timedelta64(24, 'h')
+  index_of = {int(t.astype('int64')): i for i, t in enumerate(init_times)}
+  ndoy = 369
+  rng = np.random.default_rng(1)
+  clim = xr.Dataset({'z': xr.DataArray((rng.normal(size=(ndoy, 4, C5_NLEV, C5_NLAT, C5_NLON)) * 3 + 280).astype(np.float32),
+                                       dims=('dayofyear', 'hour', 'level', 'latitude', 'longitude'),
+                                       coords={'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), 'level': level,
+                                               'latitude': lat, 'longitude': lon})})
+
+  def fields(i):  # chunk i holds the same numbers whichever rank runs it
+    g = np.random.default_rng(1000 + i)
+    zp = (g.normal(size=(1, C5_NLEAD, C5_NLEV, C5_NLAT, C5_NLON)) + 280).astype(np.float32)
+    zt = (g.normal(size=(1, C5_NLEAD, C5_NLEV, C5_NLAT, C5_NLON)) + 280).astype(np.float32)
+    tt = (g.normal(size=(1, C5_NLEAD, C5_NLAT, C5_NLON)) + 280).astype(np.float32)
+    ep = (tt[:, :, None] + g.normal(size=(1, C5_NLEAD, C5_M, C5_NLAT, C5_NLON))).astype(np.float32)
+    return zp, zt, ep, tt
+
+  def load_det(inits, leads):
+    i = index_of[int(inits[0].astype('int64'))]
+    zp, zt, _, _ = fields(i)
+    cs = {'init_time': inits, 'lead_time': lead_time, 'level': level, 'latitude': lat, 'longitude': lon}
+    dims = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+    return {'z': xr.DataArray(zp, dims=dims, coords=cs)}, {'z': xr.DataArray(zt, dims=dims, coords=cs)}
+
+  def load_ens(inits, leads):
+    i = index_of[int(inits[0].astype('int64'))]
+    _, _, ep, tt = fields(i)
+    cs = {'init_time': inits, 'lead_time': lead_time, 'latitude': lat, 'longitude': lon}
+    return ({'t2m': xr.DataArray(ep, dims=('init_time', 'lead_time', 'number', 'latitude', 'longitude'), coords=cs)},
+            {'t2m': xr.DataArray(tt, dims=('init_time', 'lead_time', 'latitude', 'longitude'), coords=cs)})
+
+  det = {'rmse': deterministic.RMSE(), 'mse': deterministic.MSE(), 'mae': deterministic.MAE(), 'bias': deterministic.Bias(),
+         'acc': deterministic.ACC(clim), 'prediction_activity': deterministic.PredictionActivity(clim)}
+  spec = {'spectrum_p': spectra.ZonalPowerSpectrum('predictions'), 'spectrum_t': spectra.ZonalPowerSpectrum('targets')}
+  ens = {'crps': probabilistic.CRPSEnsemble(use_sort=True), 'unbiased_spread_skill': probabilistic.UnbiasedSpreadSkillRatio(),
+         'unbiased_mean_rmse': probabilistic.UnbiasedEnsembleMeanRMSE(),
+         'mean_rmse': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.EnsembleMean(which='predictions')])}
+  per_init = {'rmse': deterministic.RMSE()}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  keep_init = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  passes = [('deterministic', load_det, det, area), ('spectra', load_det, spec, zonal), ('ensemble', load_ens, ens, area),
+            ('per_init', load_det, per_init, keep_init)]
+  times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+  return times, passes
+
+
+def _config5_worker(rank, world_size, out_dir):
+  dist = _init(rank, world_size, out_dir)
+  from weatherbenchx_amd import distributed, pipeline
+  try:
+    times, passes = _config5_case()
+    mine = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
+    stats = {}
+    out = pipeline.evaluate_passes(times, passes, rank=rank, world_size=world_size, stats=stats)
+    res = {}
+    for name, _, metrics, _ in passes:
+      res.update({f'{name}/{k}': np.asarray(v.values) for k, v in out[name][None].metric_values(metrics).items()})
+    res['_init_time_of_per_init'] = out['per_init'][None].metric_values(passes[3][2])['rmse.z']['init_time'].values.astype('int64')
+    np.savez(os.path.join(out_dir, f'c5_{rank}.npz'), _chunks=len(mine), _collectives=stats['collectives'],
+             _values=stats['accumulator_values'], **res)
+  finally:
+    dist.destroy_process_group()
+
+
+def test_config5_sharding_over_eight_ranks(tmp_path, monkeypatch):
+  """the configs[4] partitioning at world size 8 with a ragged split -- 366 chunks -> 46 on six ranks, 45 on two
+  (time_chunks.py:177-202: chunk i -> rank i mod 8) -- init_time both reduced (sums add up: CombinePerKey(CombiningSum()),
+  beam_pipeline.py:509-510) and preserved (every slot lives on one rank; the same sum concatenates them): ONE collective per job
+  on every rank, a buffer of exactly the job's accumulator values, and every rank holds the single-process result."""
+  world = 8
+  _spawn(_config5_worker, world, tmp_path)
+  import fake_device
+  from weatherbenchx_amd import pipeline
+  fake_device.install(monkeypatch)
+  times, passes = _config5_case()
+  want = {}
+  for name, load, metrics, agg in passes:
+    st = pipeline.evaluate_chunks(times, load, metrics, agg)[None]
+    vals = st.metric_values(metrics)
+    want.update({f'{name}/{k}': np.asarray(v.values) for k, v in vals.items()})
+    if name == 'per_init':
+      assert vals['rmse.z'].shape[:1] == (C5_NINIT,) and vals['rmse.z'].dims[0] == 'init_time'
+      want_init = vals['rmse.z']['init_time'].values.astype('int64')
+  expect_values = _config5_accumulator_values(C5_NLEAD, C5_NLEV, C5_NLON, C5_NINIT)
+  counts = []
+  for rank in range(world):
+    got = np.load(os.path.join(tmp_path, f'c5_{rank}.npz'))
+    counts.append(int(got['_chunks']))
+    assert int(got['_collectives']) == 1, (rank, got['_collectives'])
+    assert int(got['_values']) == expect_values, (rank, int(got['_values']), expect_values)
+    np.testing.assert_array_equal(got['_init_time_of_per_init'], want_init)  # concatenated in label order on every rank
+    assert set(want) <= set(got.files)
+    for k in want:
+      np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=1e-300, equal_nan=True, err_msg=f'rank {rank} {k}')
+  assert sorted(counts, reverse=True) == [46] * 6 + [45] * 2 and sum(counts) == C5_NINIT
+  # the same formula at BASELINE.json's configs[4] size: 20 leads x 37 levels x 721 wavenumbers -> the 2.14 M doubles (17 MB)
+  # bench.py's config5 leg reports as `accumulator_values`
+  assert _config5_accumulator_values(20, 37, 1440) == 2143240

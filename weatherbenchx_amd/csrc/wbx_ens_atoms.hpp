@@ -156,9 +156,13 @@ struct EnsAtomsArgs {
 #ifndef WBX_ENS_ATOMS_RAGGED_WPB
 #define WBX_ENS_ATOMS_RAGGED_WPB 4
 #endif
-template <int MP, bool EXACT, bool NT, bool SKIPNA = false>
+// MODE 0: the id bytes are [bk][br][x] (bins, or bins + a mask on the W dims) -- the round-4 kernel, nothing added to its loop;
+//      1: one id byte per point of the chunk (a mask with strides along A / the depth dims);
+//      2: Aggregator(skipna=True), either kind of id table (run-time)
+template <int MP, bool EXACT, bool NT, int MODE = 0>
 __global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB), WBX_ENS_PIPE_WAVES)
 ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+  constexpr bool SKIPNA = MODE == 2;
   constexpr int WPB = NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB;
   using Op = EnsOpF32<MP, EXACT, WBX_ENS_SORT>;
   constexpr int NQ = ENS_ATOMS_NQ, NOUT = ENS_ATOMS_NOUT;
@@ -265,8 +269,11 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   const int br_last = (int)((rend - 1) / a.D);
   const int64_t key0 = (A * g.nBk + bk) * g.nBr, wrow0 = bk * g.nBr;
   // id bytes: row (bk, br) of the [bk][br][nj] table, or row (cell, r = br * D + d) of the per-point table
-  const int64_t idrow0 = e.id_cell_rows ? cell * e.id_cell_rows : wrow0;
-  const int32_t idbr = e.id_cell_rows ? nD : 1, idd = e.id_cell_rows ? 1 : 0;
+  // (the per-point rows of a patch are consecutive: a row counter that runs with the look-ahead, clamped like it)
+  const bool point_ids = MODE == 1 || (MODE == 2 && e.id_cell_rows != 0);
+  const int64_t idrow0 = point_ids ? cell * e.id_cell_rows : wrow0;
+  int r_a = (int)rbeg;
+  const int r_last = (int)(rend - 1);
   int64_t ra0k = 0, ra0d = 0, ra1k = 0, ra1d = 0, wra = 0;  // the row looked up ahead (the table entries as they were loaded:
   double wwa = 1.0;                                          // adding them here would wait for the loads on the spot)
   // Unconditional (past the patch's last row it looks the last row up again): under a branch the scalar loads would be
@@ -283,8 +290,12 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
     ra0d = td0[(int64_t)d_a & md0];
     ra1k = tk1[key & mk1];
     ra1d = td1[(int64_t)d_a & md1];
-    wra = (idrow0 + (int64_t)__builtin_amdgcn_readfirstlane(br_a * idbr + d_a * idd)) * g.nj;  // (32-bit; the compiler keeps
-                                                                                           //  d_a on the VALU: say that it is uniform)
+    if constexpr (MODE == 0) {
+      wra = (wrow0 + br_a) * g.nj;
+    } else {
+      wra = (idrow0 + (int64_t)__builtin_amdgcn_readfirstlane(point_ids ? r_a : br_a)) * g.nj;  // (the compiler keeps r_a on the VALU)
+      r_a = r_a < r_last ? r_a + 1 : r_a;
+    }
     wwa = twr[(wrow0 + br_a) & mwr];
     const bool wrap = d_a + 1 == nD;
     d_a = wrap ? 0 : d_a + 1;
@@ -692,14 +703,19 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   WBX_HIP(hipMalloc(reinterpret_cast<void**>(&e.prof), prof_bytes));
   WBX_HIP(hipMemsetAsync(e.prof, 0, prof_bytes, ctx->stream));
 #endif
-  if (nt && skipna)
-    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
-  else if (nt)
-    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, a, g, e);
-  else if (skipna)
-    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false, true>), dim3((unsigned)grid), dim3(64 * WBX_ENS_ATOMS_RAGGED_WPB), 0, ctx->stream, a, g, e);
-  else
-    hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, false>), dim3((unsigned)grid), dim3(64 * WBX_ENS_ATOMS_RAGGED_WPB), 0, ctx->stream, a, g, e);
+  const int mode = skipna ? 2 : (e.id_cell_rows ? 1 : 0);
+  const dim3 block(nt ? 64 : 64 * WBX_ENS_ATOMS_RAGGED_WPB);
+#define WBX_EA_LAUNCH(NTV, MODEV) hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, NTV, MODEV>), dim3((unsigned)grid), block, 0, ctx->stream, a, g, e)
+  if (nt) {
+    if (mode == 0) WBX_EA_LAUNCH(true, 0);
+    else if (mode == 1) WBX_EA_LAUNCH(true, 1);
+    else WBX_EA_LAUNCH(true, 2);
+  } else {
+    if (mode == 0) WBX_EA_LAUNCH(false, 0);
+    else if (mode == 1) WBX_EA_LAUNCH(false, 1);
+    else WBX_EA_LAUNCH(false, 2);
+  }
+#undef WBX_EA_LAUNCH
   WBX_HIP(hipGetLastError());
 #if WBX_EA_PROF
   {
