@@ -455,6 +455,42 @@ int wbx_det_spectrum_slabs(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WB
                            const void* p, const void* t, const void* c, int64_t rows_per_slab, const int32_t* group,
                            const double* scale, int64_t ngroup, double* partial_out, double* power_p, double* power_t);
 
+/* ---- replayable chunk records (ABI 11) ---------------------------------------------------------------------------
+ * The body of the reference's per-chunk stage (beam_pipeline.py:161-250: statistics of one chunk -> aggregation states ->
+ * CombinePerKey) is, in steady state, the SAME sequence of calls into this library chunk after chunk: same plans, same
+ * weights / bins / atom tables, same scratch and accumulator slots; only the inputs' device pointers (and, for statistics
+ * against a climatology, the plan variant that carries the chunk's gather table) change.  A caller that has watched one such
+ * chunk -- every call with its arguments as 64-bit patterns -- replays the following chunks with ONE call: the host side of
+ * a chunk is then a few microseconds whatever the number of metrics, variables and aggregators (a public-benchmark chunk is
+ * ~0.35 ms of kernel against 0.3-0.45 ms of Python bookkeeping through the per-call path).
+ *   calls[i]   = {fn, nargs, args[]}: entry point WBX_FN_* with its arguments in declaration order, each as the 64-bit pattern
+ *                of the value (pointers as addresses, integers sign-extended);
+ *   relocs[j]  = {call, arg, slot, offset}: before the calls run, calls[call].args[arg] = slots[slot] + offset -- the
+ *                arguments that follow the chunk (input pointers, a plan variant);
+ *   slots[]    = this chunk's values.
+ * The calls run in order, each on the context it names, exactly as if the caller had made them one by one; the first failure
+ * stops the replay and is returned (wbx_last_error says which call).  Only entry points that enqueue work and neither allocate
+ * nor synchronise can be part of a record (WBX_ERR_INVALID otherwise): */
+typedef enum wbx_fn {
+  WBX_FN_DET_PARTIAL = 1, WBX_FN_ENS_PARTIAL = 2, WBX_FN_ENS2_PARTIAL = 3, WBX_FN_CAT_PARTIAL = 4, WBX_FN_CAT_EXCEED_FIELD = 5,
+  WBX_FN_CONTRACT = 6, WBX_FN_CONTRACT_BITS = 7, WBX_FN_DET_BINNED = 8, WBX_FN_ENS_BINNED = 9, WBX_FN_ZONAL_SPECTRUM = 10,
+  WBX_FN_ZONAL_SPECTRUM_SLABS = 11, WBX_FN_DET_SPECTRUM = 12, WBX_FN_DET_SPECTRUM_SLABS = 13, WBX_FN_ACC_ADD = 14,
+  WBX_FN_MEMSET = 15, WBX_FN_MEMCPY_D2D = 16, WBX_FN_CTX_WAIT_FENCE = 17, WBX_FN_FENCE_RECORD = 18
+} wbx_fn;
+#define WBX_CALL_MAX_ARGS 20
+typedef struct wbx_call {
+  int32_t fn;     /* wbx_fn */
+  int32_t nargs;  /* must equal the entry point's parameter count */
+  uint64_t args[WBX_CALL_MAX_ARGS];
+} wbx_call;
+typedef struct wbx_reloc {
+  int32_t call, arg, slot, reserved_;
+  int64_t offset; /* bytes */
+} wbx_reloc;
+/* `calls` is patched in place (it belongs to the caller and is rewritten by every replay). */
+int wbx_chunk_replay(wbx_call* calls, int32_t ncalls, const wbx_reloc* relocs, int32_t nrelocs, const uint64_t* slots,
+                     int32_t nslots);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,8 +38,55 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
     'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_det_spectrum_slabs', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
-    'wbx_ens2_partial', 'wbx_cat_exceed_field',
+    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay',
 )
+
+# wbx_fn (include/wbx.h): the entry points a chunk record may hold
+FN_IDS = {'wbx_det_partial': 1, 'wbx_ens_partial': 2, 'wbx_ens2_partial': 3, 'wbx_cat_partial': 4, 'wbx_cat_exceed_field': 5,
+          'wbx_contract': 6, 'wbx_contract_bits': 7, 'wbx_det_binned': 8, 'wbx_ens_binned': 9, 'wbx_zonal_spectrum': 10,
+          'wbx_zonal_spectrum_slabs': 11, 'wbx_det_spectrum': 12, 'wbx_det_spectrum_slabs': 13, 'wbx_acc_add': 14,
+          'wbx_memset': 15, 'wbx_memcpy_d2d': 16, 'wbx_ctx_wait_fence': 17, 'wbx_fence_record': 18}
+CALL_MAX_ARGS = 20
+# pure queries: they touch neither a stream nor memory, a record simply leaves them out
+QUERY_FNS = frozenset({'wbx_s1_partial_len', 'wbx_binned_atoms_size', 'wbx_ens_binned_atoms_size', 'wbx_last_error',
+                       'wbx_abi_version', 'wbx_device_count', 'wbx_comm_info'})
+
+
+class CallStruct(C.Structure):  # wbx_call
+  _fields_ = [('fn', C.c_int32), ('nargs', C.c_int32), ('args', C.c_uint64 * CALL_MAX_ARGS)]
+
+
+class RelocStruct(C.Structure):  # wbx_reloc
+  _fields_ = [('call', C.c_int32), ('arg', C.c_int32), ('slot', C.c_int32), ('reserved_', C.c_int32), ('offset', C.c_int64)]
+
+
+# The chunk recorder of the calling thread's chunk loop (engine.ChunkRecorder), or None.  While one is set, every call the
+# recording thread makes into the library is noted with its arguments, and every device block it takes from a context's pool is
+# pinned to the recording (the recorded pointer must stay the record's own).
+RECORDER = None
+PROTOS: dict = {}
+
+
+class _RecordingLib:
+  """The loaded library behind one level of indirection: `lib.wbx_xyz(...)` calls straight through and, while a chunk is being
+  recorded on this thread, leaves a note (name, arguments) with the recorder."""
+
+  def __init__(self, lib):
+    self.__dict__['_lib'] = lib
+
+  def __getattr__(self, name):
+    fn = getattr(self._lib, name)
+    if name not in PROTOS:
+      return fn
+
+    def call(*args, _fn=fn, _name=name):
+      rec = RECORDER
+      if rec is not None and rec.thread == threading.get_ident():
+        rec.note(_name, args)
+      return _fn(*args)
+    self.__dict__[name] = call
+    return call
+
 
 
 class WbxUnavailableError(RuntimeError):
@@ -148,12 +195,14 @@ def load_library():
         'wbx_det_spectrum_slabs': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
         'wbx_zonal_spectrum_slabs': [vp, vp, i64, i64, i64, i64, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
+    protos['wbx_chunk_replay'] = [vp, i32, vp, i32, vp, i32]
     for name, argtypes in protos.items():
       fn = getattr(lib, name)
       fn.argtypes = argtypes
       fn.restype = i32
-    _lib = lib
-    return lib
+    PROTOS.update(protos)
+    _lib = _RecordingLib(lib)
+    return _lib
 
 
 def check(rc: int, what: str = ''):
@@ -191,6 +240,9 @@ class DeviceBuffer:
       ptr = free.pop() if free else 0
       if ptr:
         ctx._dev_cached -= self.nbytes  # pylint: disable=protected-access
+    rec = RECORDER
+    if rec is not None and rec.thread == threading.get_ident():
+      rec.pinned.append(self)  # (a block handed out while a chunk is being recorded stays with the record)
     if not ptr:
       p = C.c_void_p(0)
       rc = ctx.lib.wbx_malloc(ctx.handle, self.nbytes, C.byref(p))
@@ -287,11 +339,19 @@ class Fence:
       pass
 
 
+ALL_CONTEXTS = None  # weakref.WeakSet of every live Context (replay.py maps the handles in a recording back to them)
+
+
 class Context:
   """One device + one HIP stream (wbx_ctx).  `torch_stream=True` adopts torch's current stream so
   launches order with tensors produced by torch on that stream."""
 
   def __init__(self, device_id: int = 0, stream_ptr: int | None = None):
+    global ALL_CONTEXTS
+    if ALL_CONTEXTS is None:
+      import weakref  # pylint: disable=g-import-not-at-top
+      ALL_CONTEXTS = weakref.WeakSet()
+    ALL_CONTEXTS.add(self)
     self.lib = load_library()
     h = C.c_void_p(0)
     check(self.lib.wbx_ctx_create(int(device_id), C.c_void_p(stream_ptr or 0), C.byref(h)), 'wbx_ctx_create')

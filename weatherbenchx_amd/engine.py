@@ -18,6 +18,7 @@ import numpy as np
 
 from weatherbenchx_amd import _hip
 from weatherbenchx_amd import planner
+from weatherbenchx_amd import replay
 from weatherbenchx_amd import xarray_lite as xr
 
 _is_torch = xr._is_torch  # pylint: disable=protected-access
@@ -308,6 +309,16 @@ def _device_w(ctx, plan: planner.S1Plan, w_da, bin_dims):
 
 
 def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None, one_wave=False, force_x=None):
+  """_planned_inner + a note for the chunk recorder: a plan that carries a gather table follows the chunk's time labels."""
+  hit = _planned_inner(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights, one_wave, force_x)
+  rec = replay.active()
+  if rec is not None and gather is not None:
+    rec.note_gather(hit[1], lambda g: _planned_inner(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, g, flags, x_weights,
+                                                     one_wave, force_x)[1])
+  return hit
+
+
+def _planned_inner(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, x_weights=None, one_wave=False, force_x=None):
   """(plan, device plan) through a cheap signature, so steady-state chunks skip table building and uploads.
 
   The climatology gather table is the one table that follows the chunk's time labels (every chunk of a streamed evaluation
@@ -353,7 +364,14 @@ def _planned(ctx, kind, dims, sizes, layouts, reduce_dims, wdep, gather, flags, 
       variants.clear()
       variants['built'], variants['retired'] = built, retired
     plan_v = dataclasses.replace(plan, gather_tab=gtab)
-    var = variants[gbytes] = (plan_v, _swap_gather_table(ctx, dplan, plan_v))
+    rec = replay.active()
+    if rec is not None:  # (the table's upload is this chunk's own business: a replay makes its own, replay.ChunkRecord)
+      rec.paused += 1
+    try:
+      var = variants[gbytes] = (plan_v, _swap_gather_table(ctx, dplan, plan_v))
+    finally:
+      if rec is not None:
+        rec.paused -= 1
   return var
 
 
@@ -444,7 +462,13 @@ def _launch_context(kind: str = 'det'):
   return _stream_ring[d.turn]
 
 
+def known_contexts():
+  """Every live context of this process (the default ones, the second launch stream, feeders' copy streams)."""
+  return list(_hip.ALL_CONTEXTS or ())
+
+
 def clear_caches():
+  replay.invalidate_all()
   _stream_ring.clear()
   _plan_cache.clear()
   _w_cache.clear()
@@ -580,6 +604,7 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
   if bufs is False:
     return False
   del _fusion_requests[id(inputs[0])]
+  replay.keep(bufs, dplan, devs[2] if nin > 2 else None)
   nk = 721
   # this launch's OWN result buffers (pooled device blocks): several variables of a chunk are launched before the spectra
   # pass reads the first of them, so one scratch slot per context would hand every variable the last variable's spectra
@@ -862,6 +887,7 @@ class Accumulation:
     self.specs: dict = {}          # path -> [spec, ...]
     self.frames: dict = {}         # (path, index) -> (coords, name, attrs)
     self.ctxs: dict = {}
+    self._recorder = None          # replay.ChunkRecorder while a chunk of this loop is being recorded
 
   # -- bookkeeping driven by the chunk loop ---------------------------------------------------------------------
   def set_label(self, label):
@@ -893,6 +919,8 @@ class Accumulation:
       blk.keys.append(key)
       blk.used += n
       first = True
+      if self._recorder is not None:
+        self._recorder.refuse('an accumulator slot was created in the chunk (its first add overwrites)')
     else:
       if slot[2] != n:
         raise ValueError(f'accumulating {key}: this chunk produced {n} values where earlier chunks produced {slot[2]} '
@@ -944,18 +972,26 @@ class Accumulation:
         # a cached constant (data-independent sums of weights handed out read-only, or ANY view of a registered one): met
         # again under the same path with the same frame it only bumps a multiplicity, folded into the host sums when they
         # are read (`host`)
-        for term in self._host_const.setdefault(path, []):
+        for index, term in enumerate(self._host_const.setdefault(path, [])):
           same = term[2] == ckey if ckey is not None else term[0].data is data
           if same and term[0].dims == da.dims and _same_coords(term[0], da):
             term[1] += coeff
+            if self._recorder is not None:
+              self._recorder.bumps.append((path, index, float(coeff)))
             return
         self._host_const[path].append([da, float(coeff), ckey])
+        if self._recorder is not None:
+          self._recorder.refuse('a constant term was met for the first time in the chunk')
         return
       self._host_add(self._host_sum, path, da if coeff == 1.0 else da * coeff)
+      if self._recorder is not None:
+        self._recorder.refuse('a result was summed on the host in the chunk')
       return
     spec = loc + (tuple(da.dims), float(coeff))
     lst = self.specs.setdefault(path, [])
     if spec not in lst:
+      if self._recorder is not None:
+        self._recorder.refuse('a result layout was met for the first time in the chunk')
       lst.append(spec)
       self.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
 
@@ -1341,6 +1377,12 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
                 devs[0].layout.stride(member_dim) if member_dim else 0, thr,
                 None if thr_field is None else devs[2].layout.stride(cat['cat_dim']))
   w_buf = _device_w(ctx, plan, w_da, bin_dims)
+  # (a chunk that is being recorded: the record keeps what the launches below point at -- plan tables, weights / bins / atom
+  #  tables, inputs that do not follow the chunk such as the climatology, threshold tables)
+  # (input 2 only where it is the SAME array chunk after chunk: the climatology behind a gather table, a threshold field -- an
+  #  aligned climatology materialised per chunk is left unaccounted for, and such a chunk is not recorded)
+  replay.keep(dplan, w_buf, cat_args[4] if cat_args else None,
+              devs[2] if (devs[2] is not None and (gather is not None or thr_field is not None)) else None)
   bin_shape = w_buf.bin_shape
   s2 = planner.build_s2_plan(plan, nl_total, w_buf.shape[-1])
   # Under skipna a twin launch does not form the masked spread / variance (wbx.h): fine while those are statistics of a

@@ -19,6 +19,7 @@ import numpy as np
 from weatherbenchx_amd import _hip
 from weatherbenchx_amd import engine
 from weatherbenchx_amd import planner
+from weatherbenchx_amd import replay
 from weatherbenchx_amd import xarray_lite as xr
 
 DET_LANE = {'Error': 0, 'AbsoluteError': 1, 'SquaredError': 2, 'SquaredPredictionAnomaly': 3,
@@ -215,22 +216,46 @@ class FusedGroup:
     return engine.materialise(self.kind, inputs, self.dims, self.sizes, lane, func=func, gather=gather, ens=ens)
 
 
-def _gather_spec(clim: ClimatologyRef | None, inputs, dims):
-  """Element-offset gather table for the climatology input, from its device layout."""
-  if clim is None:
-    return None, inputs
+def gather_from_ref(clim: ClimatologyRef, dtype_code: int) -> planner.GatherSpec:
+  """Element-offset gather table of an aligned climatology from its device layout (the climatology itself is uploaded once and
+  cached on its DataArray)."""
   ctx = _hip.default_context()
-  datas = [i.data for i in inputs]
-  dtype_code = engine._common_dtype(datas)  # pylint: disable=protected-access
   dev = engine._to_device(ctx, clim.source, dtype_code)  # pylint: disable=protected-access
   table = np.zeros(tuple(np.asarray(next(iter(clim.positions.values()))).shape), dtype=np.int64)
   for d, pos in clim.positions.items():
     table = table + np.asarray(pos, dtype=np.int64) * dev.layout.stride(d)
-  return planner.GatherSpec(dims=tuple(clim.over_dims), table=table), inputs
+  return planner.GatherSpec(dims=tuple(clim.over_dims), table=table)
+
+
+def _gather_spec(clim: ClimatologyRef | None, inputs, dims):
+  """Element-offset gather table for the climatology input, from its device layout."""
+  if clim is None:
+    return None, inputs
+  datas = [i.data for i in inputs]
+  dtype_code = engine._common_dtype(datas)  # pylint: disable=protected-access
+  return gather_from_ref(clim, dtype_code), inputs
+
+
+def _regather(p_new, g):
+  """replay.ChunkRecord: the plan variant of a recorded launch for the chunk whose predictions are `p_new` -- the climatology
+  positions of ITS time labels (metrics/base.py: `_climatology_ref`, cached per label set), the gather table from them, the
+  cached plan with that table swapped in."""
+  from weatherbenchx_amd.metrics import base as metrics_base  # pylint: disable=g-import-not-at-top
+  try:
+    ref = metrics_base.PerVariableStatisticWithClimatology._climatology_ref(p_new, g['source'])  # pylint: disable=protected-access
+    if tuple(ref.over_dims) != tuple(g['over_dims']):
+      return None
+    return g['replan'](gather_from_ref(ref, g['dtype_code']))
+  except (ValueError, KeyError):
+    return None
 
 
 def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, *, func, mask, skipna, clim, ens):
   gather, inputs = _gather_spec(clim, inputs, dims)
+  rec = replay.active() if clim is not None else None
+  if rec is not None:  # a chunk that is being recorded: what its gather plans have to be rebuilt from for the next chunk
+    rec.gather_context = {'source': clim.source, 'p': inputs[0], 'over_dims': tuple(clim.over_dims),
+                          'dtype_code': engine._common_dtype([i.data for i in inputs]), 'regather': _regather}  # pylint: disable=protected-access
   try:
     return engine.reduce_statistics(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, func=func, mask=mask,
                                     skipna=skipna, gather=gather, ens=ens)
@@ -242,6 +267,9 @@ def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, 
     inputs = list(inputs[:2]) + [aligned]
     return engine.reduce_statistics(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, func=func, mask=mask,
                                     skipna=skipna, gather=None, ens=ens)
+  finally:
+    if rec is not None:
+      rec.gather_context = None
 
 
 def _group_for(kind: str, p: xr.DataArray, t: xr.DataArray, ens=None, clim_key=None, cat=None) -> FusedGroup:

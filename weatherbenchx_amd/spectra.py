@@ -18,6 +18,7 @@ import numpy as np
 
 from weatherbenchx_amd import _hip
 from weatherbenchx_amd import engine
+from weatherbenchx_amd import replay
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base
 
@@ -107,6 +108,7 @@ def _run_spectrum(field: xr.DataArray, lon_dim: str, group: np.ndarray, scale: n
     if cache is not None:
       cache[ckey] = bufs
   g_dev, s_dev = bufs[0], bufs[1]
+  replay.keep(bufs)  # (a chunk that is being recorded: the row tables -- device and host -- belong to the record)
   out = engine._scratch(ctx, 'spectrum', max(ngroup * nk, 1) * 8)  # pylint: disable=protected-access
   # one call for every slab (lead x level slabs of adjacent latitude rows for latitude-fastest fields); group / scale are
   # already in slab-major row order (geo.permutation)
