@@ -362,7 +362,10 @@ def _config5_accumulator_values(nlead, nlev, nlon, ninit=0):
   statistics, per (lead, level, wavenumber) of the two spectra, per lead of the five ensemble statistics; `ninit` > 0: plus the
   slots of the aggregator that preserves init_time -- per (init, lead, level) the six lanes of the deterministic launch it shares
   with the first evaluation (a launch's result buffer is accumulated whole) and their count lane."""
-  return 6 * 2 * nlead * nlev + 2 * 2 * nlead * nlev * (nlon // 2 + 1) + 5 * 2 * nlead + 7 * ninit * nlead * nlev
+  base = 6 * 2 * nlead * nlev + 2 * 2 * nlead * nlev * (nlon // 2 + 1) + 5 * 2 * nlead + 7 * ninit * nlead * nlev
+  # (r5) consecutive chunks deal their ensemble launches to the two launch streams the other way round, and every stream adds
+  # into slots of its own (engine.Accumulation.next_chunk): the five ensemble lanes exist once more
+  return base + 5 * nlead
 
 
 def _config5_case():
@@ -471,4 +474,4 @@ def test_config5_sharding_over_eight_ranks(tmp_path, monkeypatch):
   assert sorted(counts, reverse=True) == [46] * 6 + [45] * 2 and sum(counts) == C5_NINIT
   # the same formula at BASELINE.json's configs[4] size: 20 leads x 37 levels x 721 wavenumbers -> the 2.14 M doubles (17 MB)
   # bench.py's config5 leg reports as `accumulator_values`
-  assert _config5_accumulator_values(20, 37, 1440) == 2143240
+  assert _config5_accumulator_values(20, 37, 1440) == 2143240 + 100

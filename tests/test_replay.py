@@ -66,6 +66,7 @@ def test_replay_entry_point_refuses_what_it_cannot_run():
 def test_fn_ids_match_the_header():
   import os
   import re
+  _hip.load_library()
   header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wbx.h')).read()
   enum = dict(re.findall(r'WBX_FN_([A-Z0-9_]+) = (\d+)', header))
   assert {f'wbx_{k.lower()}': int(v) for k, v in enum.items()} == _hip.FN_IDS
@@ -218,6 +219,12 @@ def _states_equal(a, b):
           np.testing.assert_array_equal(np.asarray(x.values), np.asarray(y.values), err_msg=f'{name} {stat} {var}')  # bit for bit
 
 
+def _replays(n):
+  """Chunks of a loop alternate between two signatures (which launch stream an ensemble launch takes, engine.ALTERNATE_CHUNKS):
+  of each kind the first builds, the second is recorded, the rest are replayed."""
+  return max(0, (n + 1) // 2 - 2) + max(0, n // 2 - 2)
+
+
 def _on_off(job, monkeypatch, nchunks, expect_replays):
   engine.clear_caches()
   replay.reset_stats()
@@ -240,39 +247,39 @@ def test_deterministic_loop_with_climatology_bins_and_mask_replays(monkeypatch, 
   """RMSE / MAE / bias / ACC / activity, two aggregators (34-bin style regions with a per-point mask; plain area mean), a
   climatology whose gather table follows every chunk's time labels: chunk 1 builds, chunk 2 is recorded, chunks 3.. are replayed;
   the accumulators equal the ordinary path's bit for bit."""
-  n = 7
-  _on_off(lambda: _det_job(n, layout=layout), monkeypatch, n, n - 2)
+  n = 9
+  _on_off(lambda: _det_job(n, layout=layout), monkeypatch, n, _replays(n))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('with_mask', [False, True, 'nan'])
 @pytest.mark.parametrize('layout', ['lon_fastest', 'lat_fastest'])
 def test_ensemble_loop_replays(monkeypatch, with_mask, layout):
-  n = 6
-  _on_off(lambda: _ens_job(n, with_mask, layout), monkeypatch, n, n - 2)
+  n = 8
+  _on_off(lambda: _ens_job(n, with_mask, layout), monkeypatch, n, _replays(n))
 
 
 @pytest.mark.gpu
 def test_ensemble_skipna_loop_replays(monkeypatch):
-  n = 5
-  _on_off(lambda: _ens_job(n, True, skipna=True), monkeypatch, n, n - 2)
+  n = 7
+  _on_off(lambda: _ens_job(n, True, skipna=True), monkeypatch, n, _replays(n))
 
 
 @pytest.mark.gpu
 def test_changed_chunk_shape_takes_the_ordinary_path_again(monkeypatch):
-  """Chunks 0-3 have three lead times, chunks 4-8 two (other arrays, other plans): the first record does not apply to them; they
+  """Chunks 0-5 have three lead times, chunks 6-11 two (other arrays, other plans): the first records do not apply to them; they
   build, record and replay their own."""
-  n = 9
+  n = 12
   # (lead_time survives nowhere: both shapes add into the same per-(level, region) accumulators ... of different lead counts --
   #  reduce lead_time too so that the sums are comparable)
   def job():
-    times, load, metrics, aggs = _det_job(n, change_at=4)
+    times, load, metrics, aggs = _det_job(n, change_at=6)
     aggs = {'plain': aggregation.Aggregator(reduce_dims=['init_time', 'lead_time', 'latitude', 'longitude'],
                                             weigh_by=[weighting.GridAreaWeighting()])}
     metrics = {k: metrics[k] for k in ('rmse', 'mae', 'bias')}
     return times, load, metrics, aggs
-  _, stats = _on_off(job, monkeypatch, n, (4 - 2) + (5 - 2))
-  assert stats['recorded'] == 2
+  _, stats = _on_off(job, monkeypatch, n, 2 * _replays(6))
+  assert stats['recorded'] == 4
 
 
 @pytest.mark.gpu
@@ -280,7 +287,7 @@ def test_passes_with_spectra_fused_into_the_deterministic_sweep_replay(monkeypat
   """configs[4] in miniature on 1440-point rows: deterministic suite + zonal spectra of p and t (ONE fused sweep) + an ensemble
   suite from another loader, as one job."""
   torch = _torch()
-  n, nlat, nlon, nlead, nlev, m = 6, 31, 1440, 2, 2, 5
+  n, nlat, nlon, nlead, nlev, m = 8, 31, 1440, 2, 2, 5
   g = torch.Generator(device='cuda')
   g.manual_seed(8)
   lat, lon = np.linspace(-75, 75, nlat), np.linspace(0, 360, nlon, endpoint=False)
@@ -329,7 +336,7 @@ def test_passes_with_spectra_fused_into_the_deterministic_sweep_replay(monkeypat
   engine.clear_caches()
   monkeypatch.setattr(replay, 'ENABLED', False)
   off = run()
-  assert stats['replayed'] == n - 2, stats
+  assert stats['replayed'] == _replays(n), stats
   # the deterministic lanes and the ensemble sums are order-fixed: bit for bit; the spectra's accumulate path adds with fp64
   # atomics (the one order-dependent sum of the library): equal to rounding
   for name in ('deterministic', 'ensemble'):

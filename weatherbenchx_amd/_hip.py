@@ -50,6 +50,9 @@ CALL_MAX_ARGS = 20
 # pure queries: they touch neither a stream nor memory, a record simply leaves them out
 QUERY_FNS = frozenset({'wbx_s1_partial_len', 'wbx_binned_atoms_size', 'wbx_ens_binned_atoms_size', 'wbx_last_error',
                        'wbx_abi_version', 'wbx_device_count', 'wbx_comm_info'})
+# the fences a chunk leaves behind for the HOST (when may its inputs be let go of): a replayed chunk records its own
+# (replay.ChunkRecord.replay); waiting for / dropping fences of earlier chunks is the loop's business, not the chunk's
+HOST_FENCE_FNS = frozenset({'wbx_fence_create', 'wbx_fence_record', 'wbx_fence_wait', 'wbx_fence_destroy'})
 
 
 class CallStruct(C.Structure):  # wbx_call

@@ -443,6 +443,9 @@ def stage_inputs(ctx, arrays: Sequence[xr.DataArray]):
 # start to end on ONE stream, scratch buffers are per context, cached operands are uploaded synchronously, and the
 # state's fence covers every context that got work.
 ALTERNATE_STREAMS = os.environ.get('WBX_ALTERNATE_STREAMS', '1') != '0'
+# ... and, accumulating (chunk loops), consecutive chunks the other way round (Accumulation.next_chunk); 0: every launch of a
+# label on one stream, as in round 4 (A/B timing)
+ALTERNATE_CHUNKS = os.environ.get('WBX_ALTERNATE_CHUNKS', '1') != '0'
 ENS_PIPE = os.environ.get('WBX_ENS_PIPE', '1') != '0'  # the library reads the same variable (csrc/wbx_ens_impl.hpp)
 _stream_ring: list = []
 
@@ -455,8 +458,8 @@ def _launch_context(kind: str = 'det'):
   if not _stream_ring or _stream_ring[0] is not base:
     _stream_ring[:] = [base, new_context()]
   if _accum is not None:
-    # accumulating: the same launch of every chunk must land on the same stream, so that the adds into its
-    # accumulator slot are ordered by that stream
+    # accumulating: the adds into an accumulator slot are ordered by ONE stream, so every stream has slots of its own
+    # (Accumulation.accumulate) and a launch of chunk k + 1 may run on the other stream than the same launch of chunk k
     return _stream_ring[_accum.launch_turn(len(_stream_ring))]
   d.turn = (d.turn + 1) % len(_stream_ring)
   return _stream_ring[d.turn]
@@ -880,6 +883,7 @@ class Accumulation:
     self.label = None
     self._ordinal = 0
     self._launches = 0
+    self.chunk_index = 0
     self._turns: dict = {}
     self.multi = False             # some slot has been added to more than once
     self._host_sum: dict = {}      # path -> DataArray summed on the host (results that never were on the device)
@@ -895,18 +899,27 @@ class Accumulation:
     the same label accumulate."""
     self.label, self._ordinal, self._launches = label, 0, 0
 
+  def next_chunk(self):
+    """The chunk loop moves on (pipeline._consume).  Consecutive chunks deal their ensemble launches to the launch streams the
+    other way round: chunk k + 1's kernel then starts in the tail of chunk k's -- the last, partly empty round of blocks, ~80 us of
+    a 0.32 ms ens_atoms_kernel -- instead of behind it and behind its accumulator add.  Each stream adds into slots of its own."""
+    self.chunk_index += 1
+
   def launch_turn(self, n: int) -> int:
     key = (self.label, self._launches)
     self._launches += 1
     turn = self._turns.get(key)
     if turn is None:
       turn = self._turns[key] = len(self._turns) % n
-    return turn
+    return (turn + (self.chunk_index if ALTERNATE_CHUNKS else 0)) % n
 
   # -- engine side ------------------------------------------------------------------------------------------------
   def accumulate(self, ctx, src_ptr, shape) -> np.ndarray:
     n = int(np.prod(shape, dtype=np.int64))
     key = (self.label, self._ordinal)
+    turn = next((i for i, c in enumerate(_stream_ring) if c is ctx), 0)
+    if turn:
+      key += (turn,)  # this launch stream's own slot for the result: its adds are ordered by its stream alone
     self._ordinal += 1
     slot = self.slots.get(key)
     if slot is None:

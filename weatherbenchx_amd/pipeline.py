@@ -283,6 +283,7 @@ class _Replayer:
       per = tuple((role[1], role[2], _array_signature(da)) for role, da in arrays.items() if role[0] == ipass)
       aligned = all(_time_aligned(arrays[(ipass, 'p', n)], arrays[(ipass, 't', n)]) for n in names[0] if n in names[1])
       sig.append((keeps, names, per, aligned))
+    sig.append(self.acc.chunk_index % 2 if engine.ALTERNATE_CHUNKS else 0)  # (which launch stream an ensemble launch takes)
     return tuple(sig)
 
   def try_replay(self, group):
@@ -324,6 +325,7 @@ def _consume(chunk_streams, passes, acc):
   previous = []
   replayer = _Replayer(passes, acc)
   for group in zip(*chunk_streams):
+    acc.next_chunk()
     # steady state: a chunk like one that has been recorded is ONE call into the library (replay.py; wbx_chunk_replay)
     done = replayer.try_replay(group)
     if done is not None:

@@ -80,7 +80,7 @@ def _ranges_of(obj, out, seen, depth=0):
   """(address, nbytes) of every device block / host array reachable from `obj` (plans, weights, atom tables, scratch ...)."""
   if obj is None or depth > 6 or id(obj) in seen:
     return
-  seen.add(id(obj))
+  seen[id(obj)] = obj  # (holds the object: the id of a temporary container must not come round again during the walk)
   if isinstance(obj, _hip.DeviceBuffer):
     out.append((int(obj.ptr), int(obj.nbytes)))
     return
@@ -210,7 +210,7 @@ class ChunkRecorder:
     keepalive = []
     calls = []
     for name, args in self.log:
-      if name in _hip.QUERY_FNS:
+      if name in _hip.QUERY_FNS or name in _hip.HOST_FENCE_FNS:
         continue
       fn = _hip.FN_IDS.get(name)
       if fn is None:
@@ -248,7 +248,7 @@ class ChunkRecorder:
       return slot_of[tag]
 
     # memory the record owns or keeps alive
-    owned, seen = [], set()
+    owned, seen = [], {}
     from weatherbenchx_amd import engine  # pylint: disable=g-import-not-at-top
     _ranges_of(self.kept, owned, seen)
     _ranges_of(self.pinned, owned, seen)
