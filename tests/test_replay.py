@@ -221,7 +221,7 @@ def _states_equal(a, b):
 
 def _replays(n):
   """Chunks of a loop alternate between two signatures (which launch stream an ensemble launch takes, engine.ALTERNATE_CHUNKS):
-  of each kind the first builds, the second is recorded, the rest are replayed."""
+  of each kind the first builds (plans, tables, accumulator slots), the second is recorded, the rest are replayed."""
   return max(0, (n + 1) // 2 - 2) + max(0, n // 2 - 2)
 
 
@@ -237,7 +237,9 @@ def _on_off(job, monkeypatch, nchunks, expect_replays):
   times, load, metrics, aggs = job()
   off = pipeline.evaluate_chunks(times, load, metrics, aggs)
   _states_equal(on, off)
-  assert stats['recorded'] >= 1 and stats['replayed'] == expect_replays, stats
+  # (a recording that met an allocation -- a pool filling up behind an earlier record's pinned blocks -- is tried again on the
+  #  next chunk of its kind: up to two replays fewer)
+  assert stats['recorded'] >= 1 and expect_replays - 2 <= stats['replayed'] <= expect_replays and stats['replayed'] >= 1, stats
   return on, stats
 
 
@@ -267,19 +269,19 @@ def test_ensemble_skipna_loop_replays(monkeypatch):
 
 @pytest.mark.gpu
 def test_changed_chunk_shape_takes_the_ordinary_path_again(monkeypatch):
-  """Chunks 0-5 have three lead times, chunks 6-11 two (other arrays, other plans): the first records do not apply to them; they
+  """Chunks 0-7 have three lead times, chunks 8-15 two (other arrays, other plans): the first records do not apply to them; they
   build, record and replay their own."""
-  n = 12
+  n = 16
   # (lead_time survives nowhere: both shapes add into the same per-(level, region) accumulators ... of different lead counts --
   #  reduce lead_time too so that the sums are comparable)
   def job():
-    times, load, metrics, aggs = _det_job(n, change_at=6)
+    times, load, metrics, aggs = _det_job(n, change_at=8)
     aggs = {'plain': aggregation.Aggregator(reduce_dims=['init_time', 'lead_time', 'latitude', 'longitude'],
                                             weigh_by=[weighting.GridAreaWeighting()])}
     metrics = {k: metrics[k] for k in ('rmse', 'mae', 'bias')}
     return times, load, metrics, aggs
-  _, stats = _on_off(job, monkeypatch, n, 2 * _replays(6))
-  assert stats['recorded'] == 4
+  _, stats = _on_off(job, monkeypatch, n, 2 * _replays(8))
+  assert stats['recorded'] >= 3
 
 
 @pytest.mark.gpu
@@ -287,7 +289,7 @@ def test_passes_with_spectra_fused_into_the_deterministic_sweep_replay(monkeypat
   """configs[4] in miniature on 1440-point rows: deterministic suite + zonal spectra of p and t (ONE fused sweep) + an ensemble
   suite from another loader, as one job."""
   torch = _torch()
-  n, nlat, nlon, nlead, nlev, m = 8, 31, 1440, 2, 2, 5
+  n, nlat, nlon, nlead, nlev, m = 10, 31, 1440, 2, 2, 5
   g = torch.Generator(device='cuda')
   g.manual_seed(8)
   lat, lon = np.linspace(-75, 75, nlat), np.linspace(0, 360, nlon, endpoint=False)
@@ -336,7 +338,7 @@ def test_passes_with_spectra_fused_into_the_deterministic_sweep_replay(monkeypat
   engine.clear_caches()
   monkeypatch.setattr(replay, 'ENABLED', False)
   off = run()
-  assert stats['replayed'] == _replays(n), stats
+  assert _replays(n) - 2 <= stats['replayed'] <= _replays(n) and stats['replayed'] >= 1, stats
   # the deterministic lanes and the ensemble sums are order-fixed: bit for bit; the spectra's accumulate path adds with fp64
   # atomics (the one order-dependent sum of the library): equal to rounding
   for name in ('deterministic', 'ensemble'):

@@ -443,8 +443,11 @@ def stage_inputs(ctx, arrays: Sequence[xr.DataArray]):
 # start to end on ONE stream, scratch buffers are per context, cached operands are uploaded synchronously, and the
 # state's fence covers every context that got work.
 ALTERNATE_STREAMS = os.environ.get('WBX_ALTERNATE_STREAMS', '1') != '0'
-# ... and, accumulating (chunk loops), consecutive chunks the other way round (Accumulation.next_chunk); 0: every launch of a
-# label on one stream, as in round 4 (A/B timing)
+# ... and, accumulating (chunk loops), consecutive chunks the other way round (Accumulation.next_chunk): chunk k + 1's kernel
+# starts in the tail of chunk k's.  Public probabilistic chunk with chunk records on and two chunks in flight
+# (tools/bench_replay.py, profiles/r05_replay.txt): 0.312 against 0.322 ms per chunk on one stream (mask coordinate 0.330 /
+# 0.340, NaN mask 0.334 / 0.349; kernel alone 0.312 / 0.327 / 0.333).  (With ONE chunk in flight the pair ran dry for ~50 us
+# while the host caught up and the same switch lost 5 %.)  0: every launch of a label on one stream (A/B timing).
 ALTERNATE_CHUNKS = os.environ.get('WBX_ALTERNATE_CHUNKS', '1') != '0'
 ENS_PIPE = os.environ.get('WBX_ENS_PIPE', '1') != '0'  # the library reads the same variable (csrc/wbx_ens_impl.hpp)
 _stream_ring: list = []

@@ -202,14 +202,26 @@ def _plan_fusion(group_stats):
       engine.request_det_spectra(grp.p, grp.t, entries[0][0], entries[0][1])
 
 
+_token_memo: dict = {}  # id(values array) -> (the array, its token): loaders hand the same latitude / longitude objects on
+
+
 def _coord_token(values):
   """Identity of a coordinate's values that survives a loader handing out fresh (equal) arrays: content for small ones."""
+  hit = _token_memo.get(id(values))
+  if hit is not None and hit[0] is values:
+    return hit[1]
   if xr._is_torch(values):  # pylint: disable=protected-access
     return ('torch', int(values.data_ptr()), tuple(values.shape))
   a = np.asarray(values)
   if a.size <= 4096:
-    return (a.dtype.str, a.shape, hash(a.tobytes()))
-  return (a.dtype.str, a.shape, int(a.__array_interface__['data'][0]))
+    token = (a.dtype.str, a.shape, hash(a.tobytes()))
+  else:
+    token = (a.dtype.str, a.shape, int(a.__array_interface__['data'][0]))
+  if isinstance(values, np.ndarray) and not values.flags.writeable:  # (only arrays nobody can rewrite in place)
+    if len(_token_memo) > 256:
+      _token_memo.clear()
+    _token_memo[id(values)] = (values, token)
+  return token
 
 
 def _array_signature(da):
@@ -243,6 +255,12 @@ def _time_aligned(p, t) -> bool:
       if a.shape != b.shape or not np.array_equal(a, b):
         return False
   return True
+
+
+# Chunks enqueued ahead of the one the GPU is working on: with 1 the host waits for chunk k - 1 before it enqueues chunk k + 1, and
+# a launch stream runs dry for the ~50 us the host needs to get there whenever a chunk is shorter than expected; 2 keeps a chunk in
+# hand (one more chunk's inputs are held in HBM).
+CHUNKS_IN_FLIGHT = 2
 
 
 # Weightings / binnings whose factors do not depend on a chunk's time labels (a record made on one chunk holds for the next)
@@ -305,15 +323,20 @@ class _Replayer:
       self.records[sig] = False  # (its inputs cannot be addressed the way the recorded ones were: ordinary path from now on)
       return None
     n = self.seen[sig] = self.seen.get(sig, 0) + 1
-    if rec is None and n == 2:
+    if rec is None and n >= 2:
       self.recorder = replay.ChunkRecorder(arrays, self.acc)
       self.sig = sig
     return None
 
+  RECORDING_ATTEMPTS = 3  # (a chunk that still allocates -- pools filling up behind a record's pinned blocks -- is tried again)
+
   def finish(self, failed=False):
     if self.recorder is not None:
       rec = None if failed else self.recorder.finish()
-      self.records[self.sig] = rec if rec is not None else False
+      if rec is not None:
+        self.records[self.sig] = rec
+      elif failed or self.seen.get(self.sig, 0) > self.RECORDING_ATTEMPTS:
+        self.records[self.sig] = False
       self.recorder = None
 
 
@@ -322,16 +345,21 @@ def _consume(chunk_streams, passes, acc):
   advance in lockstep, so chunk k of every pass is enqueued before chunk k + 1 of any.  A chunk's results are ADDED to the
   device accumulators of `acc` right behind its kernels (slot = pass, aggregator, statistic, variable, surviving offsets);
   the host only records where each result lives.  The inputs of chunk k are released once chunk k+1 has been enqueued."""
-  previous = []
+  import collections  # pylint: disable=g-import-not-at-top
+  in_flight = collections.deque()  # the states of the last CHUNKS_IN_FLIGHT chunks: their inputs are held until their kernels ran
+
+  def retire(states):
+    in_flight.append(states)
+    while len(in_flight) > CHUNKS_IN_FLIGHT:
+      for state in in_flight.popleft():
+        state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
   replayer = _Replayer(passes, acc)
   for group in zip(*chunk_streams):
     acc.next_chunk()
     # steady state: a chunk like one that has been recorded is ONE call into the library (replay.py; wbx_chunk_replay)
     done = replayer.try_replay(group)
     if done is not None:
-      for state in previous:
-        state.wait()
-      previous = done
+      retire(done)
       continue
     if replayer.recorder is not None:
       with replayer.recorder:
@@ -343,11 +371,10 @@ def _consume(chunk_streams, passes, acc):
       replayer.finish()
     else:
       states = _run_chunk(group, passes, acc)
-    for state in previous:
-      state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
-    previous = states
-  for state in previous:
-    state.wait()
+    retire(states)
+  while in_flight:
+    for state in in_flight.popleft():
+      state.wait()
 
 
 def _run_chunk(group, passes, acc):
