@@ -324,7 +324,15 @@ def _run_bench(*flags, timeout=600):
   lines = [l for l in res.stdout.splitlines() if l.strip()]
   # stdout is ONE JSON line and nothing else (library banners -- RCCL's version block, gloo's rank messages -- go to stderr)
   assert len(lines) == 1 and lines[0].startswith('{'), res.stdout[-2000:]
-  return json.loads(lines[0])
+  line = json.loads(lines[0])
+  if 'full' not in line:  # (a "skipped" line)
+    return line
+  # (r5) the line is the compact one the driver parses (< 8 KB: headline + roofline + cpu_baseline + one record per leg); every
+  # leg's full result sits in the file it names, beside bench.py
+  assert len(lines[0]) < 8192 and ({'roofline', 'config'} <= set(line) or 'note' in line)  # ('note': --legs without the main leg)
+  full = json.load(open(os.path.join(ROOT, line['full'])))
+  assert full['value'] == line['value'] and full.get('ms_per_step') == line.get('ms_per_step')
+  return full
 
 
 def test_bench_contract_small(ctx):

@@ -185,3 +185,58 @@ def test_raw_c_abi_point_mask_and_skipna(ctx):
       want, cnt = sums(lanes[name][0], mask & ~np.isnan(lanes[name][0]))
       np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
       np.testing.assert_allclose(got[:, 5 + l], cnt, rtol=1e-12, err_msg=name)
+
+
+def test_cross_xcd_hand_off_stress(ctx):
+  """the in-kernel sums over a cell's patches hand atom tables and records from the wave that wrote them to
+  the wave that arrives last -- relaxed agent-scope stores + `s_waitcnt vmcnt(0)` + a relaxed counter on the writer, plain
+  `buffer_load ... sc1` on the reader (csrc/wbx_ens_atoms.hpp).  Geometry that makes every hand-off cross XCDs and leaves no
+  slack: 2048 cells of 64 x 32 points -- one x tile, a few short row splits -- in cell-fastest block order, so the patches of a
+  cell are dealt to DIFFERENT XCDs (workgroup i runs on XCD i mod 8 and an XCD walks a contiguous eighth of the patch list) and
+  finish within microseconds of each other.  1000 launches, each compared BIT FOR BIT with the first (a stale or torn read of a
+  published table changes the sums), and the first against float64 NumPy."""
+  rng = np.random.default_rng(11)
+  ncell, m, nlat, nlon, nbin = 2048, 8, 32, 64, 6
+  tv = rng.normal(size=(ncell, nlat, nlon)).astype(np.float32)
+  pv = (tv[:, None] + rng.normal(size=(ncell, m, nlat, nlon))).astype(np.float32)
+  mask = rng.random((nlat, nlon)) > 0.2
+  dims = ('lead_time', 'latitude', 'longitude')
+  sizes = {'lead_time': ncell, 'latitude': nlat, 'longitude': nlon}
+  lay_p = planner.InputLayout(strides={'lead_time': m * nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_t = planner.InputLayout(strides={'lead_time': nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_m = planner.InputLayout(strides={'lead_time': 0, 'latitude': nlon, 'longitude': 1}, itemsize=1, base_alignment=256)
+  boxy = np.zeros((nlat, nlon, nbin), bool)
+  for b in range(nbin):
+    boxy[(b * 5) % nlat:(b * 5) % nlat + 14, (b * 11) % nlon:(b * 11) % nlon + 30, b] = True
+  boxy[..., 0] = True
+  bits = np.zeros((nlat, nlon), np.uint64)
+  for b in range(nbin):
+    bits |= boxy[..., b].astype(np.uint64) << np.uint64(b)
+  wrow = rng.random(nlat) + 0.5
+  bits_buf, w_buf, m_buf = ctx.upload(bits), ctx.upload(wrow), ctx.upload(mask.astype(np.uint8))
+  pb, tb = ctx.upload(pv), ctx.upload(tv)
+  pdims = ('lead_time', 'number', 'latitude', 'longitude')
+  lanes = EB.oracle_lanes(pv, pdims, tv, dims)
+  order = ['CRPSSkill', 'CRPSSpread', 'EnsembleVariance', 'UnbiasedEnsembleMeanSquaredError', 'EnsembleMeanSquaredError']
+  for flags, wf, nl in ((0, _hip.BINNED_W_ON_X | _hip.BINNED_WT_ROW_ONLY, 6),
+                        (_hip.FLAG_MASKED, _hip.BINNED_W_ON_X | _hip.BINNED_WT_ROW_ONLY | _hip.BINNED_MASK_ON_W | _hip.BINNED_TWIN_MASK, 12)):
+    plan = planner.build_s1_plan(dims, sizes, [lay_p, lay_t, None, lay_m if flags else None], ('latitude', 'longitude'),
+                                 wdep_dims={'latitude', 'longitude'}, flags=_hip.FLAG_FAIR | flags, allow_vec4=False)
+    dplan = engine._PlanOnDevice(ctx, plan)  # pylint: disable=protected-access
+    ring = [ctx.alloc(ncell * nl * nbin * 8) for _ in range(50)]
+    first = None
+    for rep in range(20):
+      for out in ring:
+        _hip.check(R4._raw_call(ctx, plan, dplan, m, nlat * nlon, pb, tb, m_buf if flags else None, w_buf, bits_buf,  # pylint: disable=protected-access
+                                ncell, 1, nlat, wf, nbin, None, out), 'wbx_ens_binned')
+      for k, out in enumerate(ring):
+        got = ctx.download(out.ptr, (ncell, nl, nbin), np.float64)
+        if first is None:
+          first = got
+          valid = mask if flags else np.ones_like(mask)
+          for l, name in enumerate(order):
+            want = np.einsum('ayx,y,yxb->ab', np.where(valid, lanes[name][0], 0.0), wrow, boxy.astype(np.float64))
+            np.testing.assert_allclose(got[:, l], want, rtol=RTOL, atol=1e-9, err_msg=name)
+        else:
+          bad = np.argwhere(got.view(np.uint64) != first.view(np.uint64))
+          assert bad.size == 0, f'launch {rep * 50 + k} (flags {flags}) differs from the first at (cell, lane, bin) {bad[:5].tolist()}'
