@@ -568,8 +568,14 @@ struct EnsMasked {
 #ifndef WBX_ENS_PIPE_WAVES
 #define WBX_ENS_PIPE_WAVES 3   // waves per SIMD the register budget is cut for (12 800-byte blocks: 12 per CU)
 #endif
+// (the skipna_ensemble flavour -- per-lane member counts, fp64 sums over the valid members -- needs ~200 registers: two waves per
+//  SIMD; cut for three it spilled 29 registers)
+#ifndef WBX_ENS_PIPE_SKIPNA_WAVES
+#define WBX_ENS_PIPE_SKIPNA_WAVES 2
+#endif
 template <int MP, bool EXACT, int ALGO, bool FLAT>
-__global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args a, int R) {
+__global__ void __launch_bounds__(64, ALGO == WBX_ENS_SKIPNA_SORT ? WBX_ENS_PIPE_SKIPNA_WAVES : WBX_ENS_PIPE_WAVES)
+ens_pipe_kernel(S1Args a, int R) {
   using Op = EnsOpF32<MP, EXACT, ALGO>;
   constexpr int NA = Op::NACC;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
@@ -699,11 +705,13 @@ __global__ void __launch_bounds__(64, WBX_ENS_PIPE_WAVES) ens_pipe_kernel(S1Args
 
 // Eligibility of the pipelined sweep: plain (no mask / skipna wrappers), x summed without folded weights, one-wave blocks,
 // offsets inside a row within 32 bits.
-inline bool ens_pipe_ok(const wbx_s1_plan* plan, const S1Args& a) {
+// `skipna_ens`: the per-point member counts of skipna_ensemble (EnsOpF32<.., SKIPNA_SORT>) ride the same sweep (r5).
+inline bool ens_pipe_ok(const wbx_s1_plan* plan, const S1Args& a, bool skipna_ens = false) {
   static const bool off = getenv("WBX_ENS_PIPE") && atoi(getenv("WBX_ENS_PIPE")) == 0;  // A/B against s1_xr_kernel
-  if (off) return false;
+  static const bool off_skipna = getenv("WBX_ENS_PIPE_SKIPNA") && atoi(getenv("WBX_ENS_PIPE_SKIPNA")) == 0;
+  if (off || (skipna_ens && off_skipna)) return false;
   if (plan->x_kept || plan->x_weights != nullptr || plan->block_threads != 64) return false;
-  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA | WBX_FLAG_SKIPNA_ENS)) return false;
+  if (plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA | (skipna_ens ? 0u : (unsigned)WBX_FLAG_SKIPNA_ENS))) return false;
   if (plan->nx <= 0 || plan->ndepth <= 0 || plan->nkey <= 0) return false;
   if (a.xstride[0] < 0 || a.xstride[1] < 0) return false;
   return (double)plan->nx * (double)a.xstride[0] * 4.0 < 4294967296.0;
@@ -764,6 +772,7 @@ int launch_ens_bucket(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, int algo
       return fail(WBX_ERR_INVALID, "the LDS-tiled pair-form diagnostic exists for M = 51 only");
     }
   }
+  if (!map && algo == WBX_ENS_SKIPNA_SORT && ens_pipe_ok(plan, a, true)) return launch_ens_pipe<MP, EXACT, WBX_ENS_SKIPNA_SORT>(ctx, plan, a);
   if (algo == WBX_ENS_SKIPNA_SORT) return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_SKIPNA_SORT>>(ctx, plan, a, map);
   return launch_ens_op<EnsOpF32<MP, EXACT, WBX_ENS_PAIRWISE>>(ctx, plan, a, map);
 }
