@@ -1265,11 +1265,12 @@ def compact_line(result, full_path=None):
   if cfg:
     line['config'] = {'workload': _short(cfg.get('workload', ''), 330)}
     line['config'].update({k: cfg[k] for k in ('points_per_step_per_gpu', 'members', 'metrics', 'layout', 'accumulators', 'sharding',
-                                               'collectives_per_step', 'rccl_ranks') if k in cfg})
+                                               'collectives_per_step', 'rccl_ranks', 'prewarm') if k in cfg})
   roof = result.get('roofline') or {}
   if roof:
     line['roofline'] = {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel_ms', 'kernel_ms_median',
-                                             'algorithmic_bytes_per_launch', 'bytes_per_point', 'launches_per_step') if k in roof}
+                                             'kernel_ms_min_max', 'algorithmic_bytes_per_launch', 'bytes_per_point',
+                                             'launches_per_step') if k in roof}
     line['roofline']['kernel'] = _short(roof.get('kernel', ''), 90)
     line['roofline']['kernel_ms_source'] = 'HIP events around every timed launch on its launch stream, mean'
     line['roofline']['traffic_source'] = 'rocprofv3 --pmc FETCH_SIZE(x2 gfx950)+WRITE_SIZE, separate passes (profiles/), same library md5'

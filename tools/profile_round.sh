@@ -10,28 +10,35 @@ B="python $R/bench.py"
 # 2. kernel traces, one leg per trace; each traced process also prints its own JSON line, so its HIP-event durations and
 # rocprofv3's durations of the SAME launches sit side by side in rNN_events_vs_rocprof.txt
 T="rocprofv3 --kernel-trace --stats"
-timeout 300 $T -d $O/trace_main -o r1 -- $B --steps 20 --warmup 5 --legs main --no-cpu --no-config5 > $O/trace_main.json 2> /dev/null
-timeout 300 $T -d $O/trace_main_lat -o r1 -- $B --steps 20 --warmup 5 --legs main --no-cpu --no-config5 --layout lat_fastest > $O/trace_main_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_configs1 -o r1 -- $B --steps 10 --warmup 3 --legs configs1 --no-cpu --no-config5 > $O/trace_configs1.json 2> /dev/null
-timeout 300 $T -d $O/trace_configs1_lat -o r1 -- $B --steps 10 --warmup 3 --legs configs1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_configs1_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_ensemble -o r1 -- $B --steps 10 --warmup 3 --legs ensemble --no-cpu --no-config5 > $O/trace_ensemble.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 > $O/trace_public_chunk.json 2> /dev/null
-timeout 300 $T -d $O/trace_public_chunk_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_lat.json 2> /dev/null
+timeout 300 $T -d $O/trace_main -o r1 -- $B --steps 20 --warmup 5 --legs main --no-cpu --no-config5 > $O/trace_main.line 2> /dev/null; cp $R/bench_full.json $O/trace_main.json
+timeout 300 $T -d $O/trace_main_lat -o r1 -- $B --steps 20 --warmup 5 --legs main --no-cpu --no-config5 --layout lat_fastest > $O/trace_main_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_main_lat.json
+timeout 300 $T -d $O/trace_configs1 -o r1 -- $B --steps 10 --warmup 3 --legs configs1 --no-cpu --no-config5 > $O/trace_configs1.line 2> /dev/null; cp $R/bench_full.json $O/trace_configs1.json
+timeout 300 $T -d $O/trace_configs1_lat -o r1 -- $B --steps 10 --warmup 3 --legs configs1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_configs1_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_configs1_lat.json
+timeout 300 $T -d $O/trace_ensemble -o r1 -- $B --steps 10 --warmup 3 --legs ensemble --no-cpu --no-config5 > $O/trace_ensemble.line 2> /dev/null; cp $R/bench_full.json $O/trace_ensemble.json
+timeout 300 $T -d $O/trace_public_chunk -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 > $O/trace_public_chunk.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk.json
+timeout 300 $T -d $O/trace_public_chunk_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_lat.json
 # (WBX_ALTERNATE_STREAMS=0: the chunk loop deals ensemble launches to two streams, so consecutive kernels overlap by a few tens of
 #  microseconds and each one's traced duration is longer than its share of the GPU -- on one stream the trace shows the kernel alone)
 # (one kind of launch per traced process: the launch with a mask coordinate writes twelve lanes instead of six and folds the mask
 #  into the atom ids first -- its kernel of the same name is ~12 % longer, and one average over both says nothing)
-WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 > $O/trace_public_chunk_ens.json 2> /dev/null
-WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.json 2> /dev/null
-WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 > $O/trace_public_chunk_ens_mask.json 2> /dev/null
-WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_mask_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_spectrum -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 > $O/trace_spectrum.json 2> /dev/null
-timeout 300 $T -d $O/trace_spectrum_lat -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 --layout lat_fastest > $O/trace_spectrum_lat.json 2> /dev/null
-timeout 300 $T -d $O/trace_config5 -o r1 -- $B --legs config5 --no-cpu --config5-inits 48 > $O/trace_config5.json 2> /dev/null
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 > $O/trace_public_chunk_ens.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens.json
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 0 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens_lat.json
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 > $O/trace_public_chunk_ens_mask.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens_mask.json
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_mask_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask 1 --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_mask_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens_mask_lat.json
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_nanmask -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask nan --no-cpu --no-config5 > $O/trace_public_chunk_ens_nanmask.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens_nanmask.json
+WBX_ALTERNATE_STREAMS=0 timeout 300 $T -d $O/trace_public_chunk_ens_nanmask_lat -o r1 -- $B --steps 40 --warmup 5 --legs public_chunk_ens --pce-mask nan --no-cpu --no-config5 --layout lat_fastest > $O/trace_public_chunk_ens_nanmask_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_public_chunk_ens_nanmask_lat.json
+timeout 300 $T -d $O/trace_spectrum -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 > $O/trace_spectrum.line 2> /dev/null; cp $R/bench_full.json $O/trace_spectrum.json
+timeout 300 $T -d $O/trace_spectrum_lat -o r1 -- $B --steps 10 --warmup 3 --legs spectrum --no-cpu --no-config5 --layout lat_fastest > $O/trace_spectrum_lat.line 2> /dev/null; cp $R/bench_full.json $O/trace_spectrum_lat.json
+timeout 300 $T -d $O/trace_config5 -o r1 -- $B --legs config5 --no-cpu --config5-inits 48 > $O/trace_config5.line 2> /dev/null; cp $R/bench_full.json $O/trace_config5.json
 # 3. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
 for leg in main configs1 ensemble public_chunk public_chunk_ens spectrum; do
   timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
   timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_$leg -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 > /dev/null 2>&1
+done
+for lay in lon_fastest lat_fastest; do
+  sfx=$([ $lay = lat_fastest ] && echo _lat || echo "")
+  timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_public_chunk_ens_nanmask$sfx -o r1 -- $B --steps 2 --warmup 1 --legs public_chunk_ens --pce-mask nan --no-cpu --no-config5 --prewarm-ms 0 --layout $lay > /dev/null 2>&1
+  timeout 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write_public_chunk_ens_nanmask$sfx -o r1 -- $B --steps 2 --warmup 1 --legs public_chunk_ens --pce-mask nan --no-cpu --no-config5 --prewarm-ms 0 --layout $lay > /dev/null 2>&1
 done
 for leg in main configs1 public_chunk public_chunk_ens spectrum; do
   timeout 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch_${leg}_lat -o r1 -- $B --steps 2 --warmup 1 --legs $leg --pce-mask 0 --no-cpu --no-config5 --prewarm-ms 0 --layout lat_fastest > /dev/null 2>&1
@@ -67,9 +74,9 @@ json.dump(out, open('$O/pmc_raw.json', 'w'), indent=1)
 PY
 # 1. the bench lines, without any profiler attached (the driver's own settings: --steps 20 --warmup 5). They come AFTER the
 # counter passes: bench.py replays profiles/rNN_pmc_traffic.json into roofline.traffic, so that file is written first.
-python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r04} --traffic-only > $O/make_round_files.log 2>&1
-timeout 900 $B --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
-timeout 400 $B --steps 20 --warmup 5 --layout lat_fastest --no-cpu > $O/bench_n1_lat_fastest.json 2>> $O/bench_n1.err
+python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r05} --traffic-only > $O/make_round_files.log 2>&1
+timeout 900 $B --steps 20 --warmup 5 > $O/bench_n1.line 2> $O/bench_n1.err; cp $R/bench_full.json $O/bench_n1.json
+timeout 600 $B --steps 20 --warmup 5 --layout lat_fastest --no-cpu > $O/bench_n1_lat_fastest.line 2>> $O/bench_n1.err; cp $R/bench_full.json $O/bench_n1_lat_fastest.json
 for d in $O/trace_*; do cp $d/r1_kernel_stats.csv $O/$(basename $d)_kernel_stats.csv 2>/dev/null; done
 # 4. same-box A/B and ceilings: the ensemble kernel variants, the fused spectra + deterministic kernel, the read stream
 ( cd $R && python tools/kbench.py ens ) > $O/kbench_ens.txt 2>&1
@@ -88,9 +95,9 @@ fi
 ( cd $R && bash tools/pmc_ens.sh ) > $O/pmc_ens.txt 2>&1
 ( cd $R && for s in "10 3" "20 5" "50 20" "200 50"; do set -- $s; python bench.py --legs main --no-cpu --no-config5 --steps $1 --warmup $2 --prewarm-ms 0 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('no prewarm, steps $1 warmup $2: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'])"; done; python bench.py --legs main --no-cpu --no-config5 --steps 20 --warmup 5 2>/dev/null | python -c "import sys, json; r = json.loads(sys.stdin.read()); print('prewarm 150 ms, steps 20 warmup 5: ms_per_step', round(r['ms_per_step'], 4), 'kernel_ms', r['roofline']['kernel_ms'], r['config']['prewarm'])" ) > $O/steady_state.txt 2>&1
 # 5. only the summaries travel back (gpurun merges at most 64 MiB): the raw rocprofv3 databases stay on the box
-python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r04} >> $O/make_round_files.log 2>&1
-mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r04}_* $R/gpurun_out/round/
-for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do [ -f $O/$f.txt ] && cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r04}_$f.txt; done
+python $R/profiles/make_round_files.py $O ${WBX_ROUND_TAG:-r05} >> $O/make_round_files.log 2>&1
+mkdir -p $R/gpurun_out/round && cp $R/profiles/${WBX_ROUND_TAG:-r05}_* $R/gpurun_out/round/
+for f in steady_state ens_pipe_ab kbench_det_spectrum flat_fetch column_walk ragged_walk ragged_wpb; do [ -f $O/$f.txt ] && cp $O/$f.txt $R/gpurun_out/round/${WBX_ROUND_TAG:-r05}_$f.txt; done
 rm -rf $O/trace_* $O/pmc_fetch_* $O/pmc_write_* $R/gpurun_out/pmc_ens $R/gpurun_out/pmc_spec
 find $O -maxdepth 1 -type d -name "*" | sed -n 2,100p | xargs -r rm -rf
 du -sh $R/gpurun_out
