@@ -240,3 +240,106 @@ def test_cross_xcd_hand_off_stress(ctx):
         else:
           bad = np.argwhere(got.view(np.uint64) != first.view(np.uint64))
           assert bad.size == 0, f'launch {rep * 50 + k} (flags {flags}) differs from the first at (cell, lane, bin) {bad[:5].tolist()}'
+
+
+@pytest.mark.parametrize('case', ['1440_lon', '1440_lat', '1440_lon_rows', '240_g64', '512_g256', '1000_rocfft', '1440_rocfft'])
+def test_spectra_are_bit_reproducible(ctx, case, monkeypatch):
+  """the spectra's sums over rows no longer depend on the order in which teams arrive (rounds 1-4 added them
+  with fp64 atomics: 9-14 % of the outputs differed in the last bits from run to run).  Every route -- the one-wave 1440-point
+  kernel, its latitude-fastest (block-staged) variant, the generic in-LDS kernel with one-wave and whole-block teams, the rocFFT
+  route -- twenty times on the same field: bit-identical outputs (groups of 721 rows: an odd count, so pairs straddle group
+  boundaries; `_rows`: every row its own group), and the float64 numpy.fft oracle for the first."""
+  from weatherbenchx_amd import spectra
+  from weatherbenchx_amd.metrics import base as metrics_base
+  import torch
+  nlon = {'1440': 1440, '240': 240, '512': 512, '1000': 1000}[case.split('_')[0]]
+  nlat, nlead, nlev = (721, 3, 4) if nlon == 1440 else (91, 3, 5)
+  if 'rocfft' in case:
+    monkeypatch.setenv('WBX_SPECTRUM_PATH', 'rocfft')
+    nlat, nlead, nlev = 61, 2, 3
+  lat, lon = np.linspace(-90, 90, nlat), np.arange(nlon) * (360.0 / nlon)
+  dims = ('lead_time', 'level', 'longitude', 'latitude') if case == '1440_lat' else ('lead_time', 'level', 'latitude', 'longitude')
+  shape = {'lead_time': nlead, 'level': nlev, 'latitude': nlat, 'longitude': nlon}
+  g = torch.Generator(device='cuda')
+  g.manual_seed(3)
+  vals = torch.randn([shape[d] for d in dims], generator=g, device='cuda') * 3 + 280
+  f = xr.DataArray(vals, dims=dims, coords={'latitude': lat, 'longitude': lon})
+  metrics = {'spec': spectra.ZonalPowerSpectrum()}
+  reduce_dims = ['lead_time'] if case.endswith('_rows') else ['latitude']
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()] if 'latitude' in reduce_dims else None)
+
+  def run():
+    fresh = xr.DataArray(vals, dims=dims, coords={'latitude': lat, 'longitude': lon})
+    res = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': fresh}, {'v': fresh}))
+    return np.ascontiguousarray(np.asarray(res.metric_values(metrics)['spec.v'].values))
+  first = run()
+  for i in range(19):
+    again = run()
+    bad = np.argwhere(again.view(np.uint64) != first.view(np.uint64))
+    assert bad.size == 0, f'{case}: run {i + 2} differs from the first in {len(bad)} of {first.size} outputs, e.g. at {bad[:3].tolist()}'
+  # ... and the numbers are the oracle's
+  host = vals.cpu().numpy()
+  lon_ax = dims.index('longitude')
+  per_row = np.moveaxis(O.zonal_power_spectrum(host, lon_axis=lon_ax), lon_ax, -1)
+  rd = tuple(d for d in dims if d != 'longitude')
+  if 'latitude' in reduce_dims:
+    wv = O.expand_to(O.grid_area_weights(lat), ('latitude',), rd)[..., None]
+    ax = rd.index('latitude')
+    want = (per_row * wv).sum(axis=ax) / (wv * np.ones_like(per_row)).sum(axis=ax)
+    res_dims = [d for d in rd if d != 'latitude']
+  else:
+    want = per_row.mean(axis=rd.index('lead_time'))
+    res_dims = [d for d in rd if d != 'lead_time']
+  fresh = xr.DataArray(vals, dims=dims, coords={'latitude': lat, 'longitude': lon})
+  res = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, {'v': fresh}, {'v': fresh}))
+  got = np.asarray(res.metric_values(metrics)['spec.v'].transpose(*res_dims, 'zonal_wavenumber').values)
+  np.testing.assert_allclose(got[..., 1:], want[..., 1:], rtol=2e-4, atol=2e-6 * want[..., 1:].max())
+  np.testing.assert_allclose(got[..., 0], want[..., 0], rtol=1e-6 if nlon == 1440 or nlon <= 256 else 2e-4)
+
+
+def test_fused_det_spectra_are_bit_reproducible(ctx, monkeypatch):
+  """The same for the spectra that come out of the deterministic sweep (wbx_det_spectrum: records of 2 x 721 values), both
+  layouts' routes: five jobs of four chunks, bit-identical accumulators."""
+  import torch
+  from weatherbenchx_amd import pipeline, replay, spectra, time_chunks
+  from weatherbenchx_amd.metrics import deterministic
+  nlat, nlon, nlead, nlev, n = 45, 1440, 2, 3, 4
+  g = torch.Generator(device='cuda')
+  g.manual_seed(9)
+  lat, lon = np.linspace(-66, 66, nlat), np.arange(nlon) * 0.25
+  lead = (np.arange(nlead) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
+  inits = np.datetime64('2020-01-01T00', 'ns') + np.arange(n) * np.timedelta64(24, 'h')
+  for layout in ('lon_fastest', 'lat_fastest'):
+    sp = ('latitude', 'longitude') if layout == 'lon_fastest' else ('longitude', 'latitude')
+    zd = ('init_time', 'lead_time', 'level') + sp
+    shp = (1, nlead, nlev) + tuple({'latitude': nlat, 'longitude': nlon}[d] for d in sp)
+    pool = [(torch.randn(shp, generator=g, device='cuda') + 280, torch.randn(shp, generator=g, device='cuda') + 280) for _ in range(2)]
+    index = {int(t.astype('int64')): i for i, t in enumerate(inits)}
+
+    def load(ic, lc):
+      i = index[int(ic[0].astype('int64'))]
+      cs = {'init_time': ic, 'lead_time': lead, 'level': np.arange(nlev), 'latitude': lat, 'longitude': lon}
+      return {'z': xr.DataArray(pool[i % 2][0], dims=zd, coords=cs)}, {'z': xr.DataArray(pool[i % 2][1], dims=zd, coords=cs)}
+    det = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
+    spec = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalPowerSpectrum('targets')}
+    area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+    zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+    passes = [('deterministic', load, det, area), ('spectra', load, spec, zonal)]
+    if layout == 'lat_fastest':
+      monkeypatch.setattr(engine, 'FUSE_DET_SPECTRA_LATFAST', True)
+
+    def run():
+      engine.S1_EVENT_LOG = []
+      try:
+        out = pipeline.evaluate_passes(time_chunks.TimeChunks(inits, lead, init_time_chunk_size=1), passes)
+        kinds = {e['kind'] for e in engine.S1_EVENT_LOG}
+      finally:
+        engine.S1_EVENT_LOG = None
+      vals = out['spectra'][None].metric_values(spec)
+      return {k: np.ascontiguousarray(np.asarray(v.values)) for k, v in vals.items()}, kinds
+    first, kinds = run()
+    assert 'det_spectrum' in kinds, kinds
+    for _ in range(4):
+      again, _ = run()
+      for k in first:
+        assert np.array_equal(again[k].view(np.uint64), first[k].view(np.uint64)), (layout, k)

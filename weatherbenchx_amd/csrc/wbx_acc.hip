@@ -77,11 +77,16 @@ extern "C" int wbx_notnan_mask(wbx_ctx* ctx, const void* data, int dtype, int64_
   return 0;
 }
 
+namespace wbx {
+void spectrum_note_write(const void* dst, size_t bytes);  // wbx_spectrum.hip
+}
+
 extern "C" int wbx_memcpy_d2d(wbx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (bytes == 0) return 0;
   WBX_REQUIRE(dst != nullptr && src != nullptr, "NULL pointer");
   WBX_HIP(hipSetDevice(ctx->device));
+  wbx::spectrum_note_write(dst, bytes);
   WBX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return 0;
 }
@@ -91,6 +96,7 @@ extern "C" int wbx_memcpy_h2d_async(wbx_ctx* ctx, void* dptr, const void* h_pinn
   if (bytes == 0) return 0;
   WBX_REQUIRE(dptr != nullptr && h_pinned != nullptr, "NULL pointer");
   WBX_HIP(hipSetDevice(ctx->device));
+  wbx::spectrum_note_write(dptr, bytes);
   WBX_HIP(hipMemcpyAsync(dptr, h_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
   return 0;
 }

@@ -61,6 +61,7 @@ extern "C" int wbx_ctx_create(int device_id, void* hip_stream, wbx_ctx** out) {
 
 namespace wbx {
 void spectrum_release(wbx_ctx* ctx);
+void spectrum_note_write(const void* dst, size_t bytes);  // wbx_spectrum.hip: cached facts about tables at these addresses are dropped
 }
 
 extern "C" int wbx_ctx_destroy(wbx_ctx* ctx) {
@@ -118,6 +119,7 @@ extern "C" int wbx_memcpy_h2d(wbx_ctx* ctx, void* dptr, const void* h_src, size_
   if (bytes == 0) return 0;
   WBX_REQUIRE(dptr != nullptr && h_src != nullptr, "NULL pointer");
   WBX_HIP(hipSetDevice(ctx->device));
+  wbx::spectrum_note_write(dptr, bytes);
   // pageable source: the async copy returns once the source has been staged.
   WBX_HIP(hipMemcpyAsync(dptr, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -204,6 +206,7 @@ extern "C" int wbx_memset(wbx_ctx* ctx, void* dptr, int value, size_t bytes) {
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (bytes == 0) return 0;
   WBX_REQUIRE(dptr != nullptr, "NULL pointer");
+  wbx::spectrum_note_write(dptr, bytes);
   WBX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
   return 0;
 }

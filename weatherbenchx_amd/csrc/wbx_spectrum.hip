@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -24,7 +25,32 @@ struct FftPlan {
   size_t work_size = 0;
 };
 
+// ---- order-independent sums (r5) ---------------------------------------------------------------------------------------
+// The spectra of a group are summed over rows that many teams (waves, blocks) share.  Rounds 1-4 let every team ADD its sums to
+// power[group][k] with fp64 atomics: correct, but the order of the additions -- and with it the last bits of 9-14 % of the
+// outputs -- differed from run to run: the one order-dependent sum of the library.  Now a team's sums for one group over one
+// run of its rows are a RECORD: {group, key = team << 24 | sequence number} + the values, written with plain stores into a slot
+// taken from a counter, and spec_close_kernel adds the records of every group in KEY order -- which is fixed by the launch
+// geometry, not by who arrived first.  No atomic touches a value; the slot counter is the only atomic left.
+//   * capacity: a team opens a record when its group changes and when it is done, and one more for the second row of a pair
+//     that straddles two groups: teams + 2 x (group changes along the rows) for teams that walk contiguous rows, stated per
+//     kernel by its launcher.  The group changes are counted once per group table (a tiny kernel + one read-back, cached by the
+//     table's device address; every copy / memset through this library into that address drops the entry);
+//   * a launch that still runs out of slots (a table rewritten behind the library's back) turns its outputs NaN, never wrong;
+//   * the closing kernel also does what the memset in front of the transform did (accumulate = 0 starts from zero).
+struct SpecRecs {
+  double* data;             // [capacity + 1][width]: width = wavenumbers x fields; the last row takes what does not fit
+  int32_t* group;           // [capacity]
+  unsigned long long* key;  // [capacity]
+  unsigned int* count;      // [0], [1]: slots taken (launches alternate: this one counts in count[parity], its closing kernel
+                            // clears the other); [2 + parity]: this launch ran out of slots
+  unsigned int capacity;
+  int32_t width, parity;
+};
+
 struct FftState {
+  SpecRecs recs = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  size_t recs_bytes = 0;  // of recs.data
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, FftPlan> plans;  // (nlon, lon_stride, row_stride, batch)
   void* scratch = nullptr;  // complex tile
   std::map<int, void*> twiddles;  // nlon -> device float2[n/2] + float2[n/2 + 1] of the fused path
@@ -46,6 +72,10 @@ void spectrum_release(wbx_ctx* ctx) {
   if (!st) return;
   for (auto& kv : st->plans) destroy_plan(kv.second);
   if (st->scratch) (void)hipFree(st->scratch);
+  if (st->recs.data) (void)hipFree(st->recs.data);
+  if (st->recs.group) (void)hipFree(st->recs.group);
+  if (st->recs.key) (void)hipFree(st->recs.key);
+  if (st->recs.count) (void)hipFree(st->recs.count);
   for (auto& kv : st->twiddles) (void)hipFree(kv.second);
   for (auto& kv : st->slab_offsets) (void)hipFree(kv.second);
   if (st->setup) rocfft_cleanup();
@@ -90,31 +120,302 @@ static int get_plan(wbx_ctx* ctx, FftState* st, int nlon, int64_t lon_stride, in
   return 0;
 }
 
-// One block = 256 wavenumbers x a run of rows; consecutive rows of the same group are summed in registers and
-// flushed with one fp64 atomic per (group change, k).  F is [rows][nk] interleaved complex (coalesced along k).
+// A record for (group g, key): called by every lane of a wave (lane = its lane id), one slot per call; -> where the wave
+// stores the record's `width` values.
+__device__ __forceinline__ double* spec_rec_open(const SpecRecs& R, int32_t g, unsigned long long key, int lane) {
+  unsigned int r = 0;
+  if (lane == 0) {
+    r = atomicAdd(R.count + R.parity, 1u);
+    if (r < R.capacity) {
+      R.group[r] = g;
+      R.key[r] = key;
+    } else {
+      R.count[2 + R.parity] = 1u;
+      r = R.capacity;
+    }
+  }
+  r = (unsigned int)__builtin_amdgcn_readfirstlane((int)r);
+  return R.data + (size_t)r * (size_t)R.width;
+}
+__device__ __forceinline__ unsigned long long spec_key(int64_t team, unsigned int seq) {
+  return ((unsigned long long)team << 24) | (unsigned long long)(seq & 0xffffffu);
+}
+// The same for a team that is a whole BLOCK (every thread calls; `slot` is a word of the block's LDS; two block barriers).
+__device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_t g, unsigned long long key, unsigned int* slot) {
+  if (threadIdx.x == 0) {
+    unsigned int r = atomicAdd(R.count + R.parity, 1u);
+    if (r < R.capacity) {
+      R.group[r] = g;
+      R.key[r] = key;
+    } else {
+      R.count[2 + R.parity] = 1u;
+      r = R.capacity;
+    }
+    *slot = r;
+  }
+  __syncthreads();
+  const unsigned int r = *slot;
+  __syncthreads();
+  return R.data + (size_t)r * (size_t)R.width;
+}
+
+// power[f][g][k] (+)= the records of group g added in key order; one block per group.  The block scans the slot headers
+// (coalesced, a few KB), collects its group's (key, slot) pairs in the LDS, sorts them (bitonic), and every thread adds its
+// wavenumbers down the sorted list.  More records than the LDS list holds: further rounds, each taking the next LIST keys in
+// order (the sum still runs in key order).
+constexpr int SPEC_CLOSE_LIST = 2048;
+__global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngroup, int32_t nk, int32_t nfield, double* __restrict__ power0,
+                                                        double* __restrict__ power1, int32_t accumulate) {
+  __shared__ unsigned long long keys[SPEC_CLOSE_LIST];
+  __shared__ unsigned int slots[SPEC_CLOSE_LIST];
+  __shared__ unsigned int n_list, n_more;
+  const int32_t g = (int32_t)blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  const unsigned int taken = R.count[R.parity] < R.capacity ? R.count[R.parity] : R.capacity;
+  const bool overflow = R.count[2 + R.parity] != 0u;
+  const int nval = nk * nfield;
+  auto out_of = [&](int v) -> double* { return (v < nk ? power0 : power1) + (int64_t)g * nk + (v < nk ? v : v - nk); };
+  unsigned long long floor_key = 0ull;  // keys below it have been added in earlier rounds
+  bool first_round = true;
+  while (true) {
+    if (tid == 0) {
+      n_list = 0u;
+      n_more = 0u;
+    }
+    __syncthreads();
+    for (unsigned int r = tid; r < taken; r += 256) {
+      if (R.group[r] == g && R.key[r] >= floor_key) {
+        const unsigned int at = atomicAdd(&n_list, 1u);
+        if (at < SPEC_CLOSE_LIST) {
+          keys[at] = R.key[r];
+          slots[at] = r;
+        } else {
+          atomicAdd(&n_more, 1u);
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned int more = n_more;
+    unsigned int n = n_list < SPEC_CLOSE_LIST ? n_list : SPEC_CLOSE_LIST;
+    unsigned long long next_floor = ~0ull;
+    if (more) {
+      // (rare: one group holds more than LIST records left)  This round takes the keys in [floor, T): T = the largest bound
+      // with at most LIST keys below it, found by bisection over the key space; the list collected above is discarded.
+      unsigned long long lo = floor_key, hi = ~0ull;
+      while (hi - lo > 1ull) {
+        const unsigned long long mid = lo + (hi - lo) / 2ull;
+        __syncthreads();
+        if (tid == 0) n_list = 0u;
+        __syncthreads();
+        unsigned int mine = 0u;
+        for (unsigned int r = tid; r < taken; r += 256)
+          if (R.group[r] == g && R.key[r] >= floor_key && R.key[r] < mid) mine += 1u;
+        if (mine) atomicAdd(&n_list, mine);
+        __syncthreads();
+        if (n_list <= SPEC_CLOSE_LIST) lo = mid; else hi = mid;
+      }
+      next_floor = lo;
+      __syncthreads();
+      if (tid == 0) n_list = 0u;
+      __syncthreads();
+      for (unsigned int r = tid; r < taken; r += 256) {
+        if (R.group[r] == g && R.key[r] >= floor_key && R.key[r] < lo) {
+          const unsigned int at = atomicAdd(&n_list, 1u);
+          keys[at] = R.key[r];
+          slots[at] = r;
+        }
+      }
+      __syncthreads();
+      n = n_list;
+    }
+    // bitonic sort of (keys, slots)[0, n) by key, padded to a power of two with the largest key
+    unsigned int np = 1u;
+    while (np < n) np <<= 1;
+    for (unsigned int i = n + tid; i < np; i += 256) {
+      keys[i] = ~0ull;
+      slots[i] = 0u;
+    }
+    __syncthreads();
+    for (unsigned int size = 2u; size <= np; size <<= 1) {
+      for (unsigned int stride = size >> 1; stride > 0u; stride >>= 1) {
+        for (unsigned int i = tid; i < np; i += 256) {
+          const unsigned int j = i ^ stride;
+          if (j > i) {
+            const bool up = (i & size) == 0u;
+            const unsigned long long a = keys[i], b = keys[j];
+            if ((a > b) == up) {
+              keys[i] = b;
+              keys[j] = a;
+              const unsigned int t = slots[i];
+              slots[i] = slots[j];
+              slots[j] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // every thread adds its values down the sorted list; between rounds the running sums live in the output itself (this
+    // block is their only reader and writer)
+    for (int base = 0; base < nval; base += 2048) {  // (eight values per thread at a time: their loads are independent)
+      double sum[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int v = base + tid + 256 * i;
+        sum[i] = (v < nval && !(first_round && !accumulate)) ? *out_of(v) : 0.0;
+      }
+      for (unsigned int q = 0; q < n; ++q) {
+        const double* rec = R.data + (size_t)slots[q] * (size_t)R.width;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int v = base + tid + 256 * i;
+          if (v < nval) sum[i] += rec[v];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int v = base + tid + 256 * i;
+        if (v < nval) *out_of(v) = (overflow && !more) ? __builtin_nan("") : sum[i];
+      }
+    }
+    __syncthreads();
+    if (!more) break;
+    floor_key = next_floor;
+    first_round = false;
+  }
+  // the other parity's counters are the next launch's: clear them (nobody reads them now; stream order puts this in front of
+  // that launch)
+  if (g == 0 && tid == 0) {
+    R.count[1 - R.parity] = 0u;
+    R.count[2 + (1 - R.parity)] = 0u;
+  }
+}
+
+// group changes along rows [0, n): #{i >= 1 : group[i] != group[i - 1]}
+__global__ void __launch_bounds__(256) spec_changes_kernel(const int32_t* __restrict__ group, int64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long mine = 0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x + 1; i < n; i += (int64_t)gridDim.x * 256)
+    mine += group[i] != group[i - 1] ? 1ull : 0ull;
+  if (mine) atomicAdd(out, mine);
+}
+
+static std::mutex g_changes_lock;
+static std::map<std::pair<const void*, int64_t>, int64_t> g_changes;  // (group table, rows) -> group changes
+
+// Every write through this library into [dst, dst + bytes) drops the cached counts of tables inside it (wbx_ctx.hip calls it).
+void spectrum_note_write(const void* dst, size_t bytes) {
+  std::lock_guard<std::mutex> hold(g_changes_lock);
+  if (g_changes.empty()) return;
+  const char* lo = reinterpret_cast<const char*>(dst);
+  for (auto it = g_changes.begin(); it != g_changes.end();) {
+    const char* p = reinterpret_cast<const char*>(it->first.first);
+    if (p + (size_t)it->first.second * sizeof(int32_t) > lo && p < lo + bytes)
+      it = g_changes.erase(it);
+    else
+      ++it;
+  }
+}
+
+static int spec_group_changes(wbx_ctx* ctx, const int32_t* group, int64_t nrows, int64_t* out) {
+  {
+    std::lock_guard<std::mutex> hold(g_changes_lock);
+    auto it = g_changes.find(std::make_pair((const void*)group, nrows));
+    if (it != g_changes.end()) {
+      *out = it->second;
+      return 0;
+    }
+  }
+  unsigned long long* d = nullptr;
+  WBX_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
+  WBX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+  const unsigned blocks = (unsigned)((nrows + 255) / 256 < 1024 ? (nrows + 255) / 256 : 1024);
+  if (nrows > 1) hipLaunchKernelGGL(spec_changes_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, ctx->stream, group, nrows, d);
+  unsigned long long h = 0;
+  WBX_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  WBX_HIP(hipStreamSynchronize(ctx->stream));
+  WBX_HIP(hipFree(d));
+  *out = (int64_t)h;
+  std::lock_guard<std::mutex> hold(g_changes_lock);
+  if (g_changes.size() > 256) g_changes.clear();
+  g_changes[std::make_pair((const void*)group, nrows)] = (int64_t)h;
+  return 0;
+}
+
+// The launch's record store: `teams` one-record-at-the-end teams (or blocks), `extra` further records the kernel may open
+// (2 x group changes for contiguous walkers).  Grows the context's buffers when needed; alternates the counter parity.
+static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t teams, int64_t extra, int32_t width, SpecRecs* out) {
+  const int64_t cap = teams + extra + 64;
+  WBX_REQUIRE(cap < ((int64_t)1 << 31), "too many spectrum records (%lld)", (long long)cap);
+  SpecRecs& R = st->recs;
+  const size_t need = (size_t)(cap + 1) * (size_t)width * sizeof(double);
+  if (!R.count) {
+    WBX_HIP(hipMalloc(reinterpret_cast<void**>(&R.count), 4 * sizeof(unsigned int)));
+    WBX_HIP(hipMemsetAsync(R.count, 0, 4 * sizeof(unsigned int), ctx->stream));
+  }
+  if (R.capacity < (unsigned int)cap || st->recs_bytes < need) {
+    WBX_HIP(hipStreamSynchronize(ctx->stream));
+    if (R.data) (void)hipFree(R.data);
+    if (R.group) (void)hipFree(R.group);
+    if (R.key) (void)hipFree(R.key);
+    const int64_t grown = cap + cap / 4;
+    const size_t bytes = (size_t)(grown + 1) * (size_t)width * sizeof(double);
+    R.data = nullptr;
+    R.group = nullptr;
+    R.key = nullptr;
+    WBX_HIP(hipMalloc(reinterpret_cast<void**>(&R.data), bytes));
+    WBX_HIP(hipMalloc(reinterpret_cast<void**>(&R.group), (size_t)grown * sizeof(int32_t)));
+    WBX_HIP(hipMalloc(reinterpret_cast<void**>(&R.key), (size_t)grown * sizeof(unsigned long long)));
+    st->recs_bytes = bytes;
+    R.capacity = (unsigned int)grown;
+  }
+  R.parity ^= 1;
+  *out = R;
+  // (the slots actually usable with this width inside the buffer)
+  out->width = width;
+  const size_t fit = st->recs_bytes / ((size_t)width * sizeof(double));
+  if (fit - 1 < out->capacity) out->capacity = (unsigned int)(fit - 1);
+  return 0;
+}
+
+static int spec_close(wbx_ctx* ctx, const SpecRecs& R, int32_t ngroup, int32_t nk, int32_t nfield, double* power0, double* power1,
+                      int32_t accumulate) {
+  if (ngroup <= 0) return 0;
+  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup), dim3(256), 0, ctx->stream, R, ngroup, nk, nfield, power0, power1, accumulate);
+  WBX_HIP(hipGetLastError());
+  return 0;
+}
+
+// One block = a run of rows x ALL wavenumbers (256 at a time); consecutive rows of the same group are summed in registers and
+// stored as one record per (group change) of the block.  F is [rows][nk] interleaved complex (coalesced along k).
 __global__ void __launch_bounds__(256) power_kernel(const float2* __restrict__ F, int64_t row0, int64_t nrows_tile,
                                                     int rows_per_block, int nk, int nlon,
                                                     const int32_t* __restrict__ group, const double* __restrict__ scale,
-                                                    double* __restrict__ power) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t r_begin = (int64_t)blockIdx.y * rows_per_block;
+                                                    SpecRecs recs, int64_t team_base) {
+  __shared__ unsigned int rec_slot;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = r_begin + rows_per_block < nrows_tile ? r_begin + rows_per_block : nrows_tile;
-  if (k >= nk || r_begin >= r_end) return;
-  const double norm = 1.0 / ((double)nlon * (double)nlon) * (k == 0 ? 1.0 : 2.0);
-  int32_t cur = group[row0 + r_begin];
-  double acc = 0.0;
-  for (int64_t r = r_begin; r < r_end; ++r) {
-    const int32_t g = group[row0 + r];
-    if (g != cur) {
-      unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc);
-      acc = 0.0;
-      cur = g;
+  if (r_begin >= r_end) return;  // (block-uniform)
+  const int64_t team = team_base + blockIdx.x;
+  unsigned int seq = 0;
+  // runs of rows of one group: [ra, rb) -> one record, all wavenumbers
+  int64_t ra = r_begin;
+  while (ra < r_end) {
+    const int32_t cur = group[row0 + ra];
+    int64_t rb = ra + 1;
+    while (rb < r_end && group[row0 + rb] == cur) ++rb;
+    double* const rec = spec_rec_open_block(recs, cur, spec_key(team, seq++), &rec_slot);
+    for (int k = (int)threadIdx.x; k < nk; k += 256) {
+      const double norm = 1.0 / ((double)nlon * (double)nlon) * (k == 0 ? 1.0 : 2.0);
+      double acc = 0.0;
+      for (int64_t r = ra; r < rb; ++r) {
+        const float2 f = F[r * nk + k];
+        const double re = (double)f.x, im = (double)f.y;
+        acc += (re * re + im * im) * norm * scale[row0 + r];
+      }
+      rec[k] = acc;
     }
-    const float2 f = F[r * nk + k];
-    const double re = (double)f.x, im = (double)f.y;
-    acc += (re * re + im * im) * norm * scale[row0 + r];
+    ra = rb;
   }
-  unsafeAtomicAdd(&power[(int64_t)cur * nk + k], acc);
 }
 
 
@@ -391,10 +692,11 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
                                                           const float2* __restrict__ tw_pass_g,
                                                           const float2* __restrict__ tw_real_g,
                                                           const int32_t* __restrict__ group,
-                                                          const double* __restrict__ scale, double* __restrict__ power) {
+                                                          const double* __restrict__ scale, SpecRecs recs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ unsigned int rec_slot;  // (teams of a whole block: the record slot thread 0 took, see spec_rec_open_block)
   constexpr int NTEAM = G == 64 ? 4 : 1;
-  const int n2 = fs.n2, nk = n2 + 1;
+  const int n2 = fs.n2;
   float2* tw_pass = reinterpret_cast<float2*>(lds_raw);
   float2* tw_real = tw_pass + n2;
   // team index in an SGPR: the row bookkeeping (group / scale look-ups, row pointers) then compiles to scalar loads on
@@ -416,13 +718,21 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < KPT; ++i) acc[i] = accm[i] = 0.0;
   int32_t cur = group[r0];
+  unsigned int seq = 0;  // the team's records carry the key (team, sequence number): spec_close_kernel adds them in that order
+  auto open = [&](int32_t g) -> double* {
+    if constexpr (G == 64)
+      return spec_rec_open(recs, g, spec_key(w, seq++), tid);
+    else
+      return spec_rec_open_block(recs, g, spec_key(w, seq++), &rec_slot);
+  };
   auto flush = [&](int32_t next) {
+    double* const rec = open(cur);
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = tid + G * i;
-      if (k <= nh) {
-        unsafeAtomicAdd(&power[(int64_t)cur * nk + k], k == 0 ? acc[i] : 2.0 * acc[i]);
-        if (n2 - k != k) unsafeAtomicAdd(&power[(int64_t)cur * nk + n2 - k], 2.0 * accm[i]);
+      if (k <= nh) {  // every wavenumber of the record is written once (k and its mirror n2 - k)
+        rec[k] = k == 0 ? acc[i] : 2.0 * acc[i];
+        if (n2 - k != k) rec[n2 - k] = 2.0 * accm[i];
       }
       acc[i] = accm[i] = 0.0;
     }
@@ -488,7 +798,8 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     // widened once per row for the fp64 sums; the factor 2 of k > 0 is applied when the sums are flushed.
     const double sca = scale[r] * inv_nn, scb = two ? scale[r + 1] * inv_nn : 0.0;
     if (ga != cur) flush(ga);  // team-uniform
-    const bool split = gb != ga;  // the pair straddles a group boundary (rare): row B goes out through its own atomics
+    const bool split = gb != ga;  // the pair straddles a group boundary (rare): row B's values are a record of their own
+    double* const rec_b = split ? open(gb) : nullptr;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = tid + G * i;
@@ -512,10 +823,10 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
         const bool mirror = km != k;
         if (split) {
           acc[i] = fma(pxd, sca, acc[i]);
-          unsafeAtomicAdd(&power[(int64_t)gb * nk + k], pyd * scb * (k == 0 ? 1.0 : 2.0));
+          rec_b[k] = pyd * scb * (k == 0 ? 1.0 : 2.0);
           if (mirror) {
             accm[i] = fma((double)pm.x, sca, accm[i]);
-            unsafeAtomicAdd(&power[(int64_t)gb * nk + km], (double)pm.y * scb * 2.0);
+            rec_b[km] = (double)pm.y * scb * 2.0;
           }
         } else {
           acc[i] = fma(pxd, sca, fma(pyd, scb, acc[i]));
@@ -575,7 +886,7 @@ static const char* spectrum_prof_path() { return nullptr; }
 #endif
 
 static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t row_stride, int64_t nrows,
-                       const int32_t* group, const double* scale, double* power_out) {
+                       const int32_t* group, const double* scale, double* power_out, int32_t ngroup, int32_t accumulate) {
   void*& tab = st->twiddles[-Z14_N];
   if (!tab) {
     std::vector<float2> host;
@@ -610,6 +921,11 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   int skew = 0;
   if (nteam == 12 && rows_per_team >= 16) skew = 2 * (int)(((int64_t)rows_per_team * skew_permille + 1000) / 2000);
   if (skew >= rows_per_team) skew = 0;
+  // the records of this launch (teams walk contiguous rows: one record per team + one per group change + one per straddling pair)
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, nrows, &changes)) return rc;
+  SpecRecs recs;
+  if (int rc = spec_recs_prepare(ctx, st, (int64_t)blocks * nteam, 2 * changes, Z14_N2 + 1, &recs)) return rc;
   if (prof_path) {
     static unsigned long long* prof = nullptr;  // (diagnostic path: one device, never freed)
     unsigned long long host[26];
@@ -621,8 +937,9 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
       WBX_HIP(hipStreamSynchronize(ctx->stream));
     }
     hipLaunchKernelGGL((zspec1440_kernel<true, 0>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows,
-                       rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+                       rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, recs, prof);
     WBX_HIP(hipGetLastError());
+    if (int rc = spec_close(ctx, recs, ngroup, Z14_N2 + 1, 1, power_out, nullptr, accumulate)) return rc;
     if (timing_only) return 0;
     WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     WBX_HIP(hipStreamSynchronize(ctx->stream));
@@ -635,7 +952,7 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
   const int knock = spectrum_knock();  // diagnostic, wrong results
 #define WBX_Z14_LAUNCH(KN)                                                                                                 \
   hipLaunchKernelGGL((zspec1440_kernel<false, KN>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, \
-                     rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out,                   \
+                     rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, recs,                        \
                      static_cast<unsigned long long*>(nullptr))
   switch (knock) {
     case 1: WBX_Z14_LAUNCH(1); break;
@@ -645,13 +962,13 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
     case 8: WBX_Z14_LAUNCH(8); break;
     case 14: WBX_Z14_LAUNCH(14); break;
     case 15: WBX_Z14_LAUNCH(15); break;
-    case 17: hipLaunchKernelGGL((zspec1440_kernel<false, 0, true, true>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // loads in front of pass 1
-    case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
+    case 17: hipLaunchKernelGGL((zspec1440_kernel<false, 0, true, true>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, recs, static_cast<unsigned long long*>(nullptr)); break;  // loads in front of pass 1
+    case 16: hipLaunchKernelGGL((zspec1440_kernel<false, 0, false>), dim3(blocks), dim3(64 * nteam), lds, ctx->stream, field, row_stride, nrows, rows_per_team, skew, reinterpret_cast<const float2*>(tab), group, scale, recs, static_cast<unsigned long long*>(nullptr)); break;  // no priority rotation
     default: WBX_Z14_LAUNCH(0); break;
   }
 #undef WBX_Z14_LAUNCH
   WBX_HIP(hipGetLastError());
-  return 0;
+  return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 1, power_out, nullptr, accumulate);
 }
 
 // Launches zspec1440_latfast_kernel over nslab slabs of rps adjacent rows (row_stride 1, longitude strided).
@@ -660,7 +977,8 @@ static int launch_1440(wbx_ctx* ctx, FftState* st, const float* field, int64_t r
 #endif
 
 static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, int64_t lon_stride, const int64_t* d_slab_off,
-                               int64_t rps, int64_t nslab, const int32_t* group, const double* scale, double* power_out) {
+                               int64_t rps, int64_t nslab, const int32_t* group, const double* scale, double* power_out,
+                               int32_t ngroup, int32_t accumulate) {
   void*& tab = st->twiddles[-Z14_N];
   if (!tab) {
     std::vector<float2> host;
@@ -689,6 +1007,15 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   static const int lf_prio = getenv("WBX_SPECTRUM_LF_PRIO") ? atoi(getenv("WBX_SPECTRUM_LF_PRIO")) : WBX_SPECTRUM_LF_PRIO_DEFAULT;
   const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
   if (per_xcd < nlocal) nlocal = (int)per_xcd;
+  // the records of this launch: the block's table goes out when the step's group differs from the last one's (at most once per
+  // step, and once when the block is done); a team whose rows are not of its step's group -- a run that crosses a group change --
+  // and the second row of a straddling pair write records of their own: at most 13 per group change, and never more than two
+  // per row
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, rps * nslab, &changes)) return rc;
+  const int64_t own = 13 * changes < 2 * rps * nslab ? 13 * changes : 2 * rps * nslab;
+  SpecRecs recs;
+  if (int rc = spec_recs_prepare(ctx, st, nslab * runs + 8 * (int64_t)nlocal, own, Z14_N2 + 1, &recs)) return rc;
   if (prof_path) {
     static unsigned long long* prof = nullptr;  // (diagnostic path, see launch_1440)
     unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -698,11 +1025,12 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
     if (spectrum_knock() == 3)
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 3>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
                          lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,
-                         reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+                         reinterpret_cast<const float2*>(tab), group, scale, recs, prof);
     else
       hipLaunchKernelGGL((zspec1440_latfast_kernel<true, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,
                          lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,
-                         reinterpret_cast<const float2*>(tab), group, scale, power_out, prof);
+                         reinterpret_cast<const float2*>(tab), group, scale, recs, prof);
+    if (int rc = spec_close(ctx, recs, ngroup, Z14_N2 + 1, 1, power_out, nullptr, accumulate)) return rc;
     WBX_HIP(hipMemcpyAsync(host, prof, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
     WBX_HIP(hipStreamSynchronize(ctx->stream));
     if (FILE* f = fopen(prof_path, "a")) {
@@ -717,17 +1045,17 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
 #define WBX_Z14LF_LAUNCH(KN)                                                                                               \
   hipLaunchKernelGGL((zspec1440_latfast_kernel<false, KN>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field,  \
                      lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio,           \
-                     reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr))
+                     reinterpret_cast<const float2*>(tab), group, scale, recs, static_cast<unsigned long long*>(nullptr))
   if (knock == 1) WBX_Z14LF_LAUNCH(1);
   else if (knock == 2) WBX_Z14LF_LAUNCH(2);
   else if (knock == 3) WBX_Z14LF_LAUNCH(3);
-  else if (knock == 9) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 1>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // a quarter of the loads in front of pass 1, none behind the unpack
-  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, power_out, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
+  else if (knock == 9) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 1>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, recs, static_cast<unsigned long long*>(nullptr));  // a quarter of the loads in front of pass 1, none behind the unpack
+  else if (knock == 8) hipLaunchKernelGGL((zspec1440_latfast_kernel<false, 0, 0>), dim3(8 * nlocal), dim3(64 * Z14_TEAMS), lds, ctx->stream, field, lon_stride, d_slab_off, rps, nslab, (nslab + 7) / 8, (int)runs, (int)(rps / runs), (int)(rps % runs), lf_prio, reinterpret_cast<const float2*>(tab), group, scale, recs, static_cast<unsigned long long*>(nullptr));  // the next run's loads in one burst
 
   else WBX_Z14LF_LAUNCH(0);
 #undef WBX_Z14LF_LAUNCH
   WBX_HIP(hipGetLastError());
-  return 0;
+  return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 1, power_out, nullptr, accumulate);
 }
 
 static bool fused_factor(int n, FusedSpec& fs) {
@@ -755,11 +1083,15 @@ static bool fused_factor(int n, FusedSpec& fs) {
 
 // Launches zspec_fused_kernel over `nrows` contiguous rows (row r at field + r * row_stride, unit longitude stride).
 static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const float* field, int64_t row_stride,
-                        int64_t nrows, const int32_t* group, const double* scale, double* power_out) {
+                        int64_t nrows, const int32_t* group, const double* scale, double* power_out, int32_t ngroup,
+                        int32_t accumulate) {
   const int nlon = fs.n, n2 = fs.n2;
   static const bool use_1440 = getenv("WBX_SPECTRUM_1440") == nullptr || atoi(getenv("WBX_SPECTRUM_1440")) != 0;
   if (nlon == Z14_N && use_1440 && !getenv("WBX_SPECTRUM_TEAM"))  // (WBX_SPECTRUM_TEAM pins the generic kernel's team size)
-    return launch_1440(ctx, st, field, row_stride, nrows, group, scale, power_out);
+    return launch_1440(ctx, st, field, row_stride, nrows, group, scale, power_out, ngroup, accumulate);
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, nrows, &changes)) return rc;
+  SpecRecs recs;
   void*& tw = st->twiddles[nlon];
   if (!tw) {
     std::vector<float2> host((size_t)n2 + n2 + 1);
@@ -812,8 +1144,9 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
     rows_per_team += rows_per_team & 1; /* whole pairs */                                                           \
     teams = (nrows + rows_per_team - 1) / rows_per_team;                                                            \
     const unsigned blocks = (unsigned)((teams + nteam - 1) / nteam);                                                \
+    if (int rc = spec_recs_prepare(ctx, st, (int64_t)blocks * nteam, 2 * changes, n2 + 1, &recs)) return rc;         \
     hipLaunchKernelGGL((zspec_fused_kernel<KPT, GG, RR>), dim3(blocks), dim3(GG == 64 ? 256 : GG), lds, ctx->stream, field, row_stride, \
-                       nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, power_out);                        \
+                       nrows, rows_per_team, fs, tw_pass, tw_real, group, scale, recs);                             \
   } while (0)
 #define WBX_LAUNCH_FUSED(KPT, GG) WBX_LAUNCH_FUSED_R(KPT, GG, 0)
 #define WBX_LAUNCH_FUSED_256(KPT)                                  \
@@ -839,7 +1172,7 @@ static int launch_fused(wbx_ctx* ctx, FftState* st, const FusedSpec& fs, const f
 #undef WBX_LAUNCH_FUSED_R
 #undef WBX_LAUNCH_FUSED
   WBX_HIP(hipGetLastError());
-  return 0;
+  return spec_close(ctx, recs, ngroup, n2 + 1, 1, power_out, nullptr, accumulate);
 }
 
 // scratch[(row - row0) * nlon + j] = field[slab_off[row / rps] + (row % rps) + j * lon_stride] for rows of unit row
@@ -872,12 +1205,20 @@ __global__ void __launch_bounds__(256) transpose_rows_kernel(const float* __rest
 
 // rocFFT route for one slab: batched strided R2C + power_kernel, in row tiles of <= 256 MiB of complex scratch.
 static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t lon_stride, int64_t row_stride,
-                        int64_t nrows, int32_t nlon, const int32_t* group, const double* scale, double* power_out) {
+                        int64_t nrows, int32_t nlon, const int32_t* group, const double* scale, double* power_out, int32_t ngroup,
+                        int32_t accumulate) {
   const int nk = nlon / 2 + 1;
+  const int rows_per_block = 64;
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, nrows, &changes)) return rc;
+  SpecRecs recs;  // one record per 64-row block (+ one per tile for its ragged last block) + one per group change inside a block
+  int64_t team_base = 0;
   // tile of rows: <= 256 MiB of complex scratch
   int64_t tile = ((int64_t)256 << 20) / ((int64_t)nk * 8);
   if (tile < 1) tile = 1;
   if (tile > nrows) tile = nrows;
+  if (int rc = spec_recs_prepare(ctx, st, (nrows + rows_per_block - 1) / rows_per_block + (nrows + tile - 1) / tile, changes, nk, &recs))
+    return rc;
   // a strided batch only tiles cleanly when rows are uniformly spaced, which they are by construction
   const size_t need = (size_t)tile * nk * 8;
   if (st->scratch_size < need) {
@@ -895,19 +1236,19 @@ static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t 
     void* in = const_cast<float*>(field + r0 * row_stride);
     void* out = st->scratch;
     WBX_FFT(rocfft_execute(plan->plan, &in, &out, plan->info));
-    const int rows_per_block = 64;
-    dim3 grid((nk + 255) / 256, (unsigned)((n + rows_per_block - 1) / rows_per_block));
-    hipLaunchKernelGGL(power_kernel, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float2*>(st->scratch), r0, n,
-                       rows_per_block, nk, nlon, group, scale, power_out);
+    const unsigned blocks = (unsigned)((n + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(power_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const float2*>(st->scratch), r0, n,
+                       rows_per_block, nk, nlon, group, scale, recs, team_base);
     WBX_HIP(hipGetLastError());
+    team_base += blocks;
   }
-  return 0;
+  return spec_close(ctx, recs, ngroup, nk, 1, power_out, nullptr, accumulate);
 }
 
 // ---- spectra of (p, t) + the deterministic lanes of the same rows in one sweep (wbx_zspec_det.hpp) --------------------------
 static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, bool has_c, const void* p, const void* t,
                            const void* c, const int32_t* group, const double* scale, double* partial_out, double* power_p,
-                           double* power_t) {
+                           double* power_t, int32_t ngroup) {
   void*& tab = st->twiddles[-Z14_N];
   if (!tab) {
     std::vector<float2> host;
@@ -937,20 +1278,26 @@ static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, 
   if (rows_per_team < 1) rows_per_team = 1;
   const int64_t blocks = (nrows + rows_per_team * ZD_TEAMS - 1) / (rows_per_team * ZD_TEAMS);
   WBX_REQUIRE(blocks < (int64_t)1 << 31 && rows_per_team < (int64_t)1 << 31, "launch too large");
+  // records of 2 x 721 values (the predictions' spectrum, then the targets'): one per team + one per group change (a pair is
+  // the p and the t row of ONE location: no straddling)
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, nrows, &changes)) return rc;
+  SpecRecs recs;
+  if (int rc = spec_recs_prepare(ctx, st, blocks * ZD_TEAMS, changes, 2 * (Z14_N2 + 1), &recs)) return rc;
   if (has_c)
     hipLaunchKernelGGL((zspec1440_det_kernel<true>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
-                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_p, power_t);
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs);
   else
     hipLaunchKernelGGL((zspec1440_det_kernel<false>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
-                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, power_p, power_t);
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs);
   WBX_HIP(hipGetLastError());
-  return 0;
+  return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 2, power_p, power_t, 0);
 }
 
 // ---- the same for latitude-fastest fields (wbx_zspec_det_latfast.hpp) -------------------------------------------------------
 static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, bool has_c, const void* p, const void* t,
                                    const void* c, int64_t rps, const int32_t* group, const double* scale, double* partial_out,
-                                   double* power_p, double* power_t) {
+                                   double* power_p, double* power_t, int32_t ngroup) {
   void*& tab = st->twiddles[-Z14_N];
   if (!tab) {
     std::vector<float2> host;
@@ -989,12 +1336,20 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
   const int64_t per_xcd = ((nslab + 7) / 8) * runs;  // (slab, run) pairs of the busiest XCD
   if (per_xcd < nlocal) nlocal = (int)per_xcd;
   WBX_REQUIRE(runs < (int64_t)1 << 30, "launch too large");
+  // records of 2 x 721 values: the block's tables once per step at most (+ once at the end); a team whose row is of another group
+  // than its step's -- a run that crosses a group change -- writes its own: at most 8 per group change, one per row
+  int64_t changes = 0;
+  if (int rc = spec_group_changes(ctx, group, rps * nslab, &changes)) return rc;
+  SpecRecs recs;
+  if (int rc = spec_recs_prepare(ctx, st, nslab * runs + 8 * (int64_t)nlocal, 8 * changes < rps * nslab ? 8 * changes : rps * nslab,
+                                 2 * (Z14_N2 + 1), &recs))
+    return rc;
 #ifdef WBX_DIAGNOSTICS  // (knock-out instantiations, wrong results by design: `make diag` only, like WBX_SPECTRUM_KNOCK)
   static const int knock = getenv("WBX_ZL_KNOCK") ? atoi(getenv("WBX_ZL_KNOCK")) : 0;  // diagnostic, wrong results
 #define WBX_ZL_LAUNCH(KN)                                                                                                      \
   hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true, KN>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab, \
                      (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group, \
-                     scale, power_p, power_t)
+                     scale, recs)
   if (has_c && knock) {
     switch (knock) {
       case 1: WBX_ZL_LAUNCH(1); break;
@@ -1005,20 +1360,20 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
       default: WBX_ZL_LAUNCH(11); break;
     }
     WBX_HIP(hipGetLastError());
-    return 0;
+    return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 2, power_p, power_t, 0);
   }
 #undef WBX_ZL_LAUNCH
 #endif
   if (has_c)
     hipLaunchKernelGGL((zspec1440_det_latfast_kernel<true>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab,
                        (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group,
-                       scale, power_p, power_t);
+                       scale, recs);
   else
     hipLaunchKernelGGL((zspec1440_det_latfast_kernel<false>), dim3(8 * nlocal), dim3(ZL_THREADS), lds, ctx->stream, a, rps, nslab,
                        (nslab + 7) / 8, (int)runs, run_base, run_rem, reinterpret_cast<const float2*>(tab), group,
-                       scale, power_p, power_t);
+                       scale, recs);
   WBX_HIP(hipGetLastError());
-  return 0;
+  return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 2, power_p, power_t, 0);
 }
 
 }  // namespace wbx
@@ -1051,10 +1406,8 @@ extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func,
     WBX_FFT(rocfft_setup());  // (the state is shared with wbx_zonal_spectrum, which may take the rocFFT route later)
     st->setup = true;
   }
-  constexpr int nk = Z14_N2 + 1;
-  WBX_HIP(hipMemsetAsync(power_p, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  WBX_HIP(hipMemsetAsync(power_t, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, partial_out, power_p, power_t);
+  // (no memset: the closing kernel of the records starts both spectra from zero)
+  return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, partial_out, power_p, power_t, (int32_t)ngroup);
 }
 
 
@@ -1088,10 +1441,8 @@ extern "C" int wbx_det_spectrum_slabs(wbx_ctx* ctx, const wbx_s1_plan* plan, int
     WBX_FFT(rocfft_setup());  // (the state is shared with wbx_zonal_spectrum, which may take the rocFFT route later)
     st->setup = true;
   }
-  constexpr int nk = Z14_N2 + 1;
-  WBX_HIP(hipMemsetAsync(power_p, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  WBX_HIP(hipMemsetAsync(power_t, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  return launch_1440_det_latfast(ctx, st, plan, func == WBX_DET6, p, t, c, rows_per_slab, group, scale, partial_out, power_p, power_t);
+  return launch_1440_det_latfast(ctx, st, plan, func == WBX_DET6, p, t, c, rows_per_slab, group, scale, partial_out, power_p, power_t,
+                                 (int32_t)ngroup);
 }
 
 
@@ -1108,9 +1459,10 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
   const int64_t nrows = rps * nslab;
   WBX_REQUIRE(power_out != nullptr || ngroup == 0, "power_out is NULL");
   WBX_HIP(hipSetDevice(ctx->device));
-  if (!accumulate && ngroup > 0)
-    WBX_HIP(hipMemsetAsync(power_out, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
-  if (nrows == 0) return 0;
+  if (nrows == 0) {  // (with rows, the closing kernel of the first launch starts the sums from zero: no memset in front)
+    if (!accumulate && ngroup > 0) WBX_HIP(hipMemsetAsync(power_out, 0, (size_t)ngroup * nk * sizeof(double), ctx->stream));
+    return 0;
+  }
   WBX_REQUIRE(field && group && scale, "field/group/scale is NULL");
   auto* st = reinterpret_cast<FftState*>(ctx->fft_state);
   if (!st) {
@@ -1129,7 +1481,9 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
     if (aligned) {
       for (int64_t o = 0; o < nslab; ++o) {
         const int64_t off = nslab > 1 ? h_slab_offsets[o] : (h_slab_offsets ? h_slab_offsets[0] : 0);
-        if (int rc = launch_fused(ctx, st, fs, field + off, row_stride, rps, group + o * rps, scale + o * rps, power_out))
+        // (every launch closes its own records; launches after the first add to what the earlier ones left)
+        if (int rc = launch_fused(ctx, st, fs, field + off, row_stride, rps, group + o * rps, scale + o * rps, power_out, ngroup,
+                                  o == 0 ? accumulate : 1))
           return rc;
       }
       return 0;
@@ -1170,7 +1524,7 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
     static const bool use_latfast = (getenv("WBX_SPECTRUM_1440") == nullptr || atoi(getenv("WBX_SPECTRUM_1440")) != 0) &&
                                     (getenv("WBX_SPECTRUM_LATFAST") == nullptr || atoi(getenv("WBX_SPECTRUM_LATFAST")) != 0);
     if (nlon == Z14_N && use_latfast && !getenv("WBX_SPECTRUM_TEAM"))
-      return launch_1440_latfast(ctx, st, field, lon_stride, d_off, rps, nslab, group, scale, power_out);
+      return launch_1440_latfast(ctx, st, field, lon_stride, d_off, rps, nslab, group, scale, power_out, ngroup, accumulate);
     const size_t need = (size_t)tile * nlon * sizeof(float);
     if (st->scratch_size < need) {
       if (st->scratch) {
@@ -1188,14 +1542,15 @@ static int zonal_spectrum_impl(wbx_ctx* ctx, const float* field, int64_t lon_str
       dim3 grid((unsigned)((nlon + 63) / 64), (unsigned)((n + 63) / 64));
       hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, ctx->stream, field, lon_stride, d_off, rps, r0, n, (int)nlon, rows);
       WBX_HIP(hipGetLastError());
-      if (int rc = launch_fused(ctx, st, fs, rows, nlon, n, group + r0, scale + r0, power_out)) return rc;
+      if (int rc = launch_fused(ctx, st, fs, rows, nlon, n, group + r0, scale + r0, power_out, ngroup, r0 == 0 ? accumulate : 1)) return rc;
     }
     return 0;
   }
   // library route, one strided batch per slab
   for (int64_t o = 0; o < nslab; ++o) {
     const int64_t off = h_slab_offsets ? h_slab_offsets[o] : 0;
-    if (int rc = rocfft_route(ctx, st, field + off, lon_stride, row_stride, rps, nlon, group + o * rps, scale + o * rps, power_out))
+    if (int rc = rocfft_route(ctx, st, field + off, lon_stride, row_stride, rps, nlon, group + o * rps, scale + o * rps, power_out, ngroup,
+                              o == 0 ? accumulate : 1))
       return rc;
   }
   return 0;

@@ -117,22 +117,25 @@ __device__ __forceinline__ void z14_store(v4* p, C2 a) {
 // A lane's twelve sums go to k = L + 60 s (acc) and 720 - L - 60 s (accm), s < 6; lane 60 owns k = 360 (acc[0]).
 // weight = true applies S_k = |F_k|^2 * (k == 0 ? 1 : 2) (include/wbx.h); the block table of the latitude-fastest kernel
 // takes the raw sums.
+// (r5) `out` is a RECORD (spec_rec_open) or a table of the caller's own: every wavenumber is written exactly once, with a plain
+// store -- the sums over teams happen in spec_close_kernel, in an order that does not depend on who arrives first.
+// (k = 0 of lane 0 is written by the first line; its "mirror" 720 is the Nyquist term.)
 template <bool WEIGHT>
 __device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const double (&acc)[6], const double (&accm)[6]) {
   if (c.lane < Z14_LANES) {
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
-      unsafeAtomicAdd(out + c.L + 60 * s, (!WEIGHT || (s == 0 && c.L == 0)) ? acc[s] : 2.0 * acc[s]);
-      unsafeAtomicAdd(out + Z14_N2 - c.L - 60 * s, WEIGHT ? 2.0 * accm[s] : accm[s]);
+      out[c.L + 60 * s] = (!WEIGHT || (s == 0 && c.L == 0)) ? acc[s] : 2.0 * acc[s];
+      out[Z14_N2 - c.L - 60 * s] = WEIGHT ? 2.0 * accm[s] : accm[s];
     }
   } else if (c.lane == Z14_LANES) {
-    unsafeAtomicAdd(out + Z14_N2 / 2, WEIGHT ? 2.0 * acc[0] : acc[0]);
+    out[Z14_N2 / 2] = WEIGHT ? 2.0 * acc[0] : acc[0];
   }
 }
 
 // One row pair: passes 1-3 on v (the pass-1 inputs), the mirror exchange and the Hermitian unpack; adds scale * |X_k|^2
-// into acc (k = L + 60 s, s < 6; lane 60: k = 360 in slot 0) and accm (720 - k) -- row B straight into `power` when the pair
-// straddles two groups.
+// into acc (k = L + 60 s, s < 6; lane 60: k = 360 in slot 0) and accm (720 - k) -- row B's values straight into `power`, a
+// record of its own, when the pair straddles two groups (`split`).
 // at(i) is called at six points: 0 pass 1 has issued its stores | 1 pass 2 has its loads | 2 pass 2 has issued its stores |
 // 3 pass 3 has its loads | 4 the mirror stores are issued | 5 done.  The longitude-fastest kernel stamps the clock there
 // (PROF), the latitude-fastest one issues a part of the next run's global loads at 0, 2, 4.
@@ -147,7 +150,6 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
                                          double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at,
                                          double (&accb)[6], double (&accmb)[6], v2 msh = (v2){0.f, 0.f}) {
-  constexpr int nk = Z14_N2 + 1;
   constexpr bool DROP = (KNOCK & 2) != 0;
   const int L = c.L;
   // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
@@ -230,11 +232,12 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     } else if (split) {
       acc[s] = fma(pxd, sca, acc[s]);
       accm[s] = fma((double)pm.x, sca, accm[s]);
+      // (r5) `power` is row B's OWN record here (the caller opened it for group gb): one plain store per wavenumber
       if (c.lane < Z14_LANES) {
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + L + 60 * s], pyd * scb * ((s == 0 && L == 0) ? 1.0 : 2.0));
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 - L - 60 * s], (double)pm.y * scb * 2.0);
+        power[L + 60 * s] = pyd * scb * ((s == 0 && L == 0) ? 1.0 : 2.0);
+        power[Z14_N2 - L - 60 * s] = (double)pm.y * scb * 2.0;
       } else if (self360 && s == 0) {
-        unsafeAtomicAdd(&power[(int64_t)gb * nk + Z14_N2 / 2], pyd * scb * 2.0);
+        power[Z14_N2 / 2] = pyd * scb * 2.0;
       }
     } else {
       if constexpr (KNOCK & 8) {
@@ -260,7 +263,7 @@ template <bool PROF, int KNOCK, bool ROTATE = true, bool FETCH_EARLY = false>
 __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
                                                         int rows_per_team, int skew, const float2* __restrict__ tables_g,
                                                         const int32_t* __restrict__ group,
-                                                        const double* __restrict__ scale, double* __restrict__ power,
+                                                        const double* __restrict__ scale, SpecRecs recs,
                                                         unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const unsigned long long t_start = PROF ? __builtin_readcyclecounter() : 0ull;
@@ -284,7 +287,6 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   const int64_t mine = rows_per_team + (int64_t)skew * (1 - g);
   const int64_t r1 = r0 + mine < nrows ? r0 + mine : nrows;
   if (r0 >= r1) return;  // only wave-level ordering below
-  constexpr int nk = Z14_N2 + 1;
   const Z14Lane c = z14_lane(lane, buf, tw2);
   const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
@@ -293,8 +295,10 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 #pragma unroll
   for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
   int32_t cur = group[r0];
+  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;  // the records' keys: (team, sequence number) -- fixed by the launch
+  unsigned int seq = 0;
   auto flush = [&](int32_t next) {
-    z14_send<true>(power + (int64_t)cur * nk, c, acc, accm);
+    z14_send<true>(spec_rec_open(recs, cur, spec_key(team_id, seq++), lane), c, acc, accm);
 #pragma unroll
     for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
     cur = next;
@@ -350,9 +354,11 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     }
 
     if (ga != cur) flush(ga);  // wave-uniform
+    // (a pair that straddles two groups: row B's values are a record of their own)
+    double* const rec_b = gb != ga ? spec_rec_open(recs, gb, spec_key(team_id, seq++), lane) : nullptr;
     // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
     // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
-    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, power,
+    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, rec_b,
                            [&](int i) {
                              mark(i + 2, i == 1 || i == 3 || i == 5);
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads
@@ -414,8 +420,10 @@ template <bool PROF, int KNOCK = 0, int SPREAD = 2>
 __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     const float* __restrict__ field, int64_t lon_stride, const int64_t* __restrict__ slab_off, int64_t rps, int64_t nslab,
     int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, int prio, const float2* __restrict__ tables_g,
-    const int32_t* __restrict__ group, const double* __restrict__ scale, double* __restrict__ power, unsigned long long* __restrict__ prof) {
+    const int32_t* __restrict__ group, const double* __restrict__ scale, SpecRecs recs, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ unsigned int rec_slot;        // spec_rec_open_block
+  __shared__ int team_in_table[Z14_TEAMS];  // the team's sums of the last step sit in its buffer, for the block's table
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
   float2* const tw2 = tw1 + Z14_TW1;
   float2* const twr = tw2 + Z14_TW2;
@@ -488,33 +496,40 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
 #pragma unroll
     for (int part = 0; part < 4; ++part) load_part(oo, rr, part);
   };
-  // Sums: fp64 registers per team (k = L + 60 s) while its rows stay in one group; when the group changes they are added to
-  // the BLOCK's [721] table in the LDS (ds_add_f64), and the table goes out with one global atomic per wavenumber when the
-  // block's group changes.  (A run of rows belongs to one slab = normally one group, but consecutive steps of a block are
-  // different slabs: twelve teams sending 721 atomics each per step cost more than the transform -- 0.93 against 0.41 ms.)
+  // Sums (r5: no atomics, in a fixed order).  A team's sums of ONE step (fp64 registers, k = L + 60 s and the mirrors) go into
+  // its own staging buffer when the step's passes are done -- the buffer is idle then -- and behind the next barrier every
+  // thread adds the twelve buffers, team 0 first, into the BLOCK's [721] table in the LDS.  The table goes out as ONE RECORD
+  // (plain stores; spec_close_kernel adds the records of a group in key order) when the block's group changes: consecutive
+  // steps of a block are different slabs, i.e. normally different groups, so a record holds the 24 rows of a step -- 5.8 KB
+  // written per 138 KB read.  A team whose rows are not of the step's group (a run that crosses a group boundary) writes
+  // records of its own.
   double* const blk = reinterpret_cast<double*>(bufs + Z14_TEAMS * Z14_BUFL);
   for (int k = tid; k < nk; k += 64 * Z14_TEAMS) blk[k] = 0.0;
+  if (tid < Z14_TEAMS) team_in_table[tid] = 0;
   int32_t blk_group = -1;  // block-uniform
   double acc[6], accm[6];
 #pragma unroll
   for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
-  int32_t cur = -1;
-  auto dump = [&](int32_t next) {  // the team's sums of group `cur` -> the block's table, or straight out if that holds another group
-    if (cur >= 0) {
-      if (cur == blk_group)
-        z14_send<false>(blk, c, acc, accm);
-      else
-        z14_send<true>(power + (int64_t)cur * nk, c, acc, accm);
-    }
+  const int64_t block_id = (int64_t)blockIdx.x;
+  unsigned int seq_block = 0, seq_team = 0;  // record keys: (block, 0, n) for the table, (block, 1 + team, n) for a team's own
+  auto team_key = [&]() { return spec_key(block_id * (Z14_TEAMS + 1) + 1 + team, seq_team++); };
+  double* const own = reinterpret_cast<double*>(buf);  // the team's buffer as 721 doubles (5.8 of its 11.7 KB)
+  // the teams' sums of the step that just ended -> the block's table, in team order (every thread; between two block barriers)
+  auto gather_teams = [&]() {
+    for (int k = tid; k < nk; k += 64 * Z14_TEAMS) {
+      double sum = blk[k];
 #pragma unroll
-    for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
-    cur = next;
+      for (int t = 0; t < Z14_TEAMS; ++t)
+        if (team_in_table[t]) sum += reinterpret_cast<const double*>(bufs + t * Z14_BUFL)[k];
+      blk[k] = sum;
+    }
   };
-  auto flush_block = [&](int32_t next) {  // every thread of the block; the callers put barriers around it
+  auto flush_block = [&](int32_t next) {  // every thread of the block, block-uniformly; contains block barriers
     if (blk_group >= 0) {
+      double* const rec = spec_rec_open_block(recs, blk_group, spec_key(block_id * (Z14_TEAMS + 1), seq_block++), &rec_slot);
       for (int k = tid; k < nk; k += 64 * Z14_TEAMS) {
         const double sum = blk[k];
-        if (sum != 0.0) unsafeAtomicAdd(power + (int64_t)blk_group * nk + k, k == 0 ? sum : 2.0 * sum);  // S_k, include/wbx.h
+        rec[k] = k == 0 ? sum : 2.0 * sum;  // S_k, include/wbx.h
         blk[k] = 0.0;
       }
     }
@@ -532,27 +547,29 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     mark(0);
     __syncthreads();  // every team is done with its buffer (and, the first time, the tables are in place)
     mark(1);
+    gather_teams();   // the sums of the step that just ended (they sit in the teams' buffers) -> the block's table
+    __syncthreads();  // ... before the buffers are filled again
+    if (tid < Z14_TEAMS) team_in_table[tid] = 0;
     int64_t rbeg, rend;
     run_rows(run, rbeg, rend);
     const int64_t row0 = o * rps;
     const int64_t ra = rbeg + 2 * team;
     const bool active = ra < rend, two = ra + 1 < rend;  // team-uniform
-    int32_t ga = cur, gb = cur;
+    const int32_t g0 = group[row0 + rbeg];               // the step's group (block-uniform)
+    int32_t ga = g0, gb = g0;
     double sca = 0.0, scb = 0.0;
     if (active) {
       ga = group[row0 + ra];
       gb = two ? group[row0 + ra + 1] : ga;
       sca = scale[row0 + ra] * quarter_inv_nn;
       scb = two ? scale[row0 + ra + 1] * quarter_inv_nn : 0.0;
-      if (ga != cur) dump(ga);  // (the table still belongs to the previous step's group: it is flushed behind the next barrier)
     }
 #pragma unroll
     for (int n = 0; n < Z14_STAGE; ++n)
       if (n < Z14_STAGE - 1 || j0 + 64 * n < Z14_N) stage_dst[64 * n] = held[n];
     __syncthreads();
     mark(2);
-    const int32_t g0 = group[row0 + rbeg];
-    if (g0 != blk_group) flush_block(g0);  // block-uniform; the teams touch the table again behind the next barrier
+    if (g0 != blk_group) flush_block(g0);  // block-uniform: the table holds the sums of the steps of the previous group
     int64_t on = o;
     int rn = run + nlocal;
     normalise(on, rn);
@@ -578,7 +595,9 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
         } else if constexpr (SPREAD == 1) {
           if (more) load_part(on, rn, 0);
         }
-        z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, power, [&](int i) {
+        // (a pair that straddles two groups: row B's values are a record of their own)
+        double* const rec_b = gb != ga ? spec_rec_open(recs, gb, team_key(), lane) : nullptr;
+        z14_pair<0>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, rec_b, [&](int i) {
           if constexpr (SPREAD == 1) {
             if (more && !(i & 1) && i < 6) load_part(on, rn, i / 2 + 1);
           } else if constexpr (SPREAD == 2) {
@@ -586,6 +605,17 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
           }
         }, acc, accm, msh);
       }
+      // this step's sums leave the registers: into the team's own buffer for the block's table (the buffer is idle until the
+      // next step's staging stores, two barriers away), or -- rows of another group than the step's -- into a record
+      __builtin_amdgcn_wave_barrier();
+      if (ga == g0) {
+        z14_send<false>(own, c, acc, accm);
+        if (lane == 0) team_in_table[team] = 1;
+      } else {
+        z14_send<true>(spec_rec_open(recs, ga, team_key(), lane), c, acc, accm);
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
       mark(5);
       if constexpr (PROF) {
 #pragma unroll
@@ -605,7 +635,7 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     }
   }
   __syncthreads();
-  dump(-1);
+  gather_teams();  // the last step's sums
   __syncthreads();
   flush_block(-1);
 }

@@ -41,8 +41,7 @@ template <bool HAS_C>
 __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, int64_t nrows, int rows_per_team,
                                                                       const float2* __restrict__ tables_g,
                                                                       const int32_t* __restrict__ group,
-                                                                      const double* __restrict__ scale,
-                                                                      double* __restrict__ power_p, double* __restrict__ power_t) {
+                                                                      const double* __restrict__ scale, SpecRecs recs) {
   constexpr int NA = HAS_C ? 6 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
@@ -69,9 +68,12 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
 #pragma unroll
   for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
   int32_t cur = group[r0];
-  auto flush = [&](int32_t next) {
-    z14_send<true>(power_p + (int64_t)cur * nk, c, accp, accmp);
-    z14_send<true>(power_t + (int64_t)cur * nk, c, acct, accmt);
+  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;
+  unsigned int seq = 0;
+  auto flush = [&](int32_t next) {  // (r5) one record of 2 x 721 values: the predictions' sums, then the targets'
+    double* const rec = spec_rec_open(recs, cur, spec_key(team_id, seq++), lane);
+    z14_send<true>(rec, c, accp, accmp);
+    z14_send<true>(rec + nk, c, acct, accmt);
 #pragma unroll
     for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
     cur = next;

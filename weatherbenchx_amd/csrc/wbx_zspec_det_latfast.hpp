@@ -40,8 +40,9 @@ constexpr int ZL_GROUPS = ZL_THREADS / 16;                 // DPP rows of the bl
 template <bool HAS_C, int KNOCK = 0>
 __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
     S1Args a, int64_t rps, int64_t nslab, int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem,
-    const float2* __restrict__ tables_g, const int32_t* __restrict__ group, const double* __restrict__ scale,
-    double* __restrict__ power_p, double* __restrict__ power_t) {
+    const float2* __restrict__ tables_g, const int32_t* __restrict__ group, const double* __restrict__ scale, SpecRecs recs) {
+  __shared__ unsigned int rec_slot;         // spec_rec_open_block
+  __shared__ int team_in_table[ZL_TEAMS];   // the team's sums of the last step sit in its buffer, for the block's tables
   constexpr int NA = HAS_C ? 6 : 3;
   constexpr int NIN = HAS_C ? 3 : 2;
   constexpr int BUFL = WBX_ZL_BUFL;
@@ -146,30 +147,34 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
   double accp[6], accmp[6], acct[6], accmt[6];
 #pragma unroll
   for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
+  // (r5: no atomics, fixed order -- see zspec1440_latfast_kernel)  A team's sums of ONE step go into its own staging buffer (2 x 721
+  // doubles: the predictions', then the targets') when its passes are done; behind the next barrier every thread adds the
+  // teams' buffers, team 0 first, into the block's two tables; the tables go out as ONE record of 2 x 721 values when the
+  // step's group changes.  A team whose row is of another group than the step's writes a record of its own.
   int32_t blk_group = -1;  // block-uniform
-  int32_t cur = -1;
-  auto dump = [&](int32_t next) {  // the team's sums of group `cur` -> the block's tables, or straight out if those hold another group
-    if (cur >= 0) {
-      if (cur == blk_group) {
-        z14_send<false>(blkp, c, accp, accmp);
-        z14_send<false>(blkt, c, acct, accmt);
-      } else {
-        z14_send<true>(power_p + (int64_t)cur * nk, c, accp, accmp);
-        z14_send<true>(power_t + (int64_t)cur * nk, c, acct, accmt);
-      }
-    }
+  if (tid < ZL_TEAMS) team_in_table[tid] = 0;
+  const int64_t block_id = (int64_t)blockIdx.x;
+  unsigned int seq_block = 0, seq_team = 0;
+  double* const own = reinterpret_cast<double*>(buf);
+  auto gather_teams = [&]() {
+    for (int k = tid; k < 2 * nk; k += ZL_THREADS) {
+      double* tab = k >= nk ? blkt + (k - nk) : blkp + k;
+      double sum = *tab;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
-    cur = next;
+      for (int t = 0; t < ZL_TEAMS; ++t)
+        if (team_in_table[t]) sum += reinterpret_cast<const double*>(bufs + t * BUFL)[k];
+      *tab = sum;
+    }
   };
-  auto flush_block = [&](int32_t next) {  // every thread of the block; the callers put barriers around it
+  auto flush_block = [&](int32_t next) {  // every thread of the block, block-uniformly; contains block barriers
     if (blk_group >= 0) {
+      double* const rec = spec_rec_open_block(recs, blk_group, spec_key(block_id * (ZL_TEAMS + 1), seq_block++), &rec_slot);
       for (int k = tid; k < 2 * nk; k += ZL_THREADS) {
         const bool second = k >= nk;
         const int kk = second ? k - nk : k;
         double* tab = second ? blkt : blkp;
         const double sum = tab[kk];
-        if (sum != 0.0) unsafeAtomicAdd((second ? power_t : power_p) + (int64_t)blk_group * nk + kk, kk == 0 ? sum : 2.0 * sum);  // S_k, include/wbx.h
+        rec[k] = kk == 0 ? sum : 2.0 * sum;  // S_k, include/wbx.h
         tab[kk] = 0.0;
       }
     }
@@ -183,17 +188,20 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
   rows_held = rows_next;
   while (o < o_end) {  // block-uniform
     __syncthreads();  // every team is done with its buffer (and, the first time, the tables are in place)
+    gather_teams();   // the sums of the step that just ended (in the teams' buffers) -> the block's tables
+    __syncthreads();  // ... before the buffers are filled again
+    if (tid < ZL_TEAMS) team_in_table[tid] = 0;
     int64_t rbeg, rend;
     run_rows(run, rbeg, rend);
     const int64_t row0 = o * rps;
     const int64_t ra = rbeg + team;
     const bool active = ra < rend;  // team-uniform
-    int32_t g = cur;
+    const int32_t g0 = group[row0 + rbeg];  // the step's group (block-uniform)
+    int32_t g = g0;
     double sc = 0.0;
     if (active) {
       g = group[row0 + ra];
       sc = scale[row0 + ra] * quarter_inv_nn;
-      if (g != cur) dump(g);  // (the tables still belong to the previous step's group: they are flushed behind the next barrier)
     }
     // the next run's bases: two dependent table lookups (key -> climatology slot -> offset), asked for here so that their
     // latency passes under the arithmetic below instead of in front of the first loads behind pass 1
@@ -261,8 +269,7 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
         a.out[(row0 + rbeg + i) * NA + l] = tot;
       }
     }
-    const int32_t g0 = group[row0 + rbeg];
-    if (g0 != blk_group) flush_block(g0);  // block-uniform; the teams touch the tables again behind the next barrier
+    if (g0 != blk_group) flush_block(g0);  // block-uniform: the tables hold the sums of the steps of the previous group
     if (active) {
       C2 v[12];
 #pragma unroll
@@ -279,6 +286,20 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
       z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
         if (more && (!(i & 1) || i == 5)) load_part(i == 5 ? 3 : i / 2);
       }, acct, accmt, msh);
+      // this step's sums leave the registers: into the team's own buffer for the block's tables, or -- a row of another group
+      // than the step's -- into a record of its own
+      __builtin_amdgcn_wave_barrier();
+      if (g == g0) {
+        z14_send<false>(own, c, accp, accmp);
+        z14_send<false>(own + nk, c, acct, accmt);
+        if (lane == 0) team_in_table[team] = 1;
+      } else {
+        double* const rec = spec_rec_open(recs, g, spec_key(block_id * (ZL_TEAMS + 1) + 1 + team, seq_team++), lane);
+        z14_send<true>(rec, c, accp, accmp);
+        z14_send<true>(rec + nk, c, acct, accmt);
+      }
+#pragma unroll
+      for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
     } else if (more) {
 #pragma unroll
       for (int part = 0; part < 4; ++part) load_part(part);  // (a team without a row in this run still loads its share of the next one)
@@ -289,7 +310,7 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
   }
   (void)rows_held;
   __syncthreads();
-  dump(-1);
+  gather_teams();  // the last step's sums
   __syncthreads();
   flush_block(-1);
 }
