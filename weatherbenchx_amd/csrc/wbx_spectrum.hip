@@ -44,12 +44,13 @@ struct SpecRecs {
   unsigned long long* key;  // [capacity]
   unsigned int* count;      // [0], [1]: slots taken (launches alternate: this one counts in count[parity], its closing kernel
                             // clears the other); [2 + parity]: this launch ran out of slots
-  unsigned int capacity;
+  unsigned int capacity;    // slots in all: [0, nstatic) are spoken for by the launch geometry (a team's last record, a step's table:
+  unsigned int nstatic;     // no counter, no waiting for one), [nstatic, capacity) are dealt out by count[parity]
   int32_t width, parity;
 };
 
 struct FftState {
-  SpecRecs recs = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  SpecRecs recs = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   size_t recs_bytes = 0;  // of recs.data
   std::map<std::tuple<int, int64_t, int64_t, int64_t>, FftPlan> plans;  // (nlon, lon_stride, row_stride, batch)
   void* scratch = nullptr;  // complex tile
@@ -125,7 +126,7 @@ static int get_plan(wbx_ctx* ctx, FftState* st, int nlon, int64_t lon_stride, in
 __device__ __forceinline__ double* spec_rec_open(const SpecRecs& R, int32_t g, unsigned long long key, int lane) {
   unsigned int r = 0;
   if (lane == 0) {
-    r = atomicAdd(R.count + R.parity, 1u);
+    r = R.nstatic + atomicAdd(R.count + R.parity, 1u);
     if (r < R.capacity) {
       R.group[r] = g;
       R.key[r] = key;
@@ -140,10 +141,19 @@ __device__ __forceinline__ double* spec_rec_open(const SpecRecs& R, int32_t g, u
 __device__ __forceinline__ unsigned long long spec_key(int64_t team, unsigned int seq) {
   return ((unsigned long long)team << 24) | (unsigned long long)(seq & 0xffffffu);
 }
+// The slot the launch geometry reserves for this team / step (slot < R.nstatic): no counter to wait for.  One thread writes the
+// header; g < 0 marks a reserved slot that stays empty (every reserved slot gets a header from exactly one thread per launch).
+__device__ __forceinline__ double* spec_rec_static(const SpecRecs& R, unsigned int slot, int32_t g, unsigned long long key, bool writer) {
+  if (writer) {
+    R.group[slot] = g;
+    R.key[slot] = key;
+  }
+  return R.data + (size_t)slot * (size_t)R.width;
+}
 // The same for a team that is a whole BLOCK (every thread calls; `slot` is a word of the block's LDS; two block barriers).
 __device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_t g, unsigned long long key, unsigned int* slot) {
   if (threadIdx.x == 0) {
-    unsigned int r = atomicAdd(R.count + R.parity, 1u);
+    unsigned int r = R.nstatic + atomicAdd(R.count + R.parity, 1u);
     if (r < R.capacity) {
       R.group[r] = g;
       R.key[r] = key;
@@ -164,6 +174,7 @@ __device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_
 // wavenumbers down the sorted list.  More records than the LDS list holds: further rounds, each taking the next LIST keys in
 // order (the sum still runs in key order).
 constexpr int SPEC_CLOSE_LIST = 2048;
+constexpr int SPEC_CLOSE_BATCH = 16;  // headers / record values a thread asks for before it looks at any of them
 __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngroup, int32_t nk, int32_t nfield, double* __restrict__ power0,
                                                         double* __restrict__ power1, int32_t accumulate) {
   __shared__ unsigned long long keys[SPEC_CLOSE_LIST];
@@ -171,10 +182,39 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
   __shared__ unsigned int n_list, n_more;
   const int32_t g = (int32_t)blockIdx.x;
   const int tid = (int)threadIdx.x;
-  const unsigned int taken = R.count[R.parity] < R.capacity ? R.count[R.parity] : R.capacity;
+  const unsigned int dyn = R.count[R.parity];
+  const unsigned int taken = R.nstatic + dyn < R.capacity ? R.nstatic + dyn : R.capacity;
   const bool overflow = R.count[2 + R.parity] != 0u;
   const int nval = nk * nfield;
   auto out_of = [&](int v) -> double* { return (v < nk ? power0 : power1) + (int64_t)g * nk + (v < nk ? v : v - nk); };
+  // the slots whose header names this group and whose key is in [floor, below): appended to the LDS list (past LIST entries they
+  // are only counted).  The headers are read BATCH at a time into registers -- the loads of a batch are in flight together.
+  auto collect = [&](unsigned long long floor_key, unsigned long long below) {
+    for (unsigned int base = 0; base < taken; base += 256 * SPEC_CLOSE_BATCH) {
+      int32_t gr[SPEC_CLOSE_BATCH];
+#pragma unroll
+      for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) {
+        const unsigned int r = base + tid + 256u * i;
+        gr[i] = r < taken ? R.group[r] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) {
+        if (gr[i] == g) {
+          const unsigned int r = base + tid + 256u * i;
+          const unsigned long long k = R.key[r];
+          if (k >= floor_key && k < below) {
+            const unsigned int at = atomicAdd(&n_list, 1u);
+            if (at < SPEC_CLOSE_LIST) {
+              keys[at] = k;
+              slots[at] = r;
+            } else {
+              atomicAdd(&n_more, 1u);
+            }
+          }
+        }
+      }
+    }
+  };
   unsigned long long floor_key = 0ull;  // keys below it have been added in earlier rounds
   bool first_round = true;
   while (true) {
@@ -183,48 +223,35 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
       n_more = 0u;
     }
     __syncthreads();
-    for (unsigned int r = tid; r < taken; r += 256) {
-      if (R.group[r] == g && R.key[r] >= floor_key) {
-        const unsigned int at = atomicAdd(&n_list, 1u);
-        if (at < SPEC_CLOSE_LIST) {
-          keys[at] = R.key[r];
-          slots[at] = r;
-        } else {
-          atomicAdd(&n_more, 1u);
-        }
-      }
-    }
+    collect(floor_key, ~0ull);
     __syncthreads();
     const unsigned int more = n_more;
     unsigned int n = n_list < SPEC_CLOSE_LIST ? n_list : SPEC_CLOSE_LIST;
     unsigned long long next_floor = ~0ull;
     if (more) {
-      // (rare: one group holds more than LIST records left)  This round takes the keys in [floor, T): T = the largest bound
-      // with at most LIST keys below it, found by bisection over the key space; the list collected above is discarded.
+      // (rare: one group holds more than LIST records)  This round takes the keys in [floor, T): T = the largest bound with at
+      // most LIST keys below it, found by bisection over the key space; the list collected above is discarded.
       unsigned long long lo = floor_key, hi = ~0ull;
       while (hi - lo > 1ull) {
         const unsigned long long mid = lo + (hi - lo) / 2ull;
         __syncthreads();
-        if (tid == 0) n_list = 0u;
+        if (tid == 0) {
+          n_list = 0u;
+          n_more = 0u;
+        }
         __syncthreads();
-        unsigned int mine = 0u;
-        for (unsigned int r = tid; r < taken; r += 256)
-          if (R.group[r] == g && R.key[r] >= floor_key && R.key[r] < mid) mine += 1u;
-        if (mine) atomicAdd(&n_list, mine);
+        collect(floor_key, mid);
         __syncthreads();
-        if (n_list <= SPEC_CLOSE_LIST) lo = mid; else hi = mid;
+        if (n_more == 0u) lo = mid; else hi = mid;
       }
       next_floor = lo;
       __syncthreads();
-      if (tid == 0) n_list = 0u;
-      __syncthreads();
-      for (unsigned int r = tid; r < taken; r += 256) {
-        if (R.group[r] == g && R.key[r] >= floor_key && R.key[r] < lo) {
-          const unsigned int at = atomicAdd(&n_list, 1u);
-          keys[at] = R.key[r];
-          slots[at] = r;
-        }
+      if (tid == 0) {
+        n_list = 0u;
+        n_more = 0u;
       }
+      __syncthreads();
+      collect(floor_key, lo);
       __syncthreads();
       n = n_list;
     }
@@ -255,28 +282,19 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
         __syncthreads();
       }
     }
-    // every thread adds its values down the sorted list; between rounds the running sums live in the output itself (this
-    // block is their only reader and writer)
-    for (int base = 0; base < nval; base += 2048) {  // (eight values per thread at a time: their loads are independent)
-      double sum[8];
+    // every thread adds its values down the sorted list (BATCH records' values asked for at a time; the additions run in list
+    // order); between rounds the running sums live in the output itself (this block is their only reader and writer)
+    for (int v = tid; v < nval; v += 256) {
+      double* const dst = out_of(v);
+      double sum = (first_round && !accumulate) ? 0.0 : *dst;
+      for (unsigned int q0 = 0; q0 < n; q0 += SPEC_CLOSE_BATCH) {
+        double x[SPEC_CLOSE_BATCH];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int v = base + tid + 256 * i;
-        sum[i] = (v < nval && !(first_round && !accumulate)) ? *out_of(v) : 0.0;
-      }
-      for (unsigned int q = 0; q < n; ++q) {
-        const double* rec = R.data + (size_t)slots[q] * (size_t)R.width;
+        for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) x[i] = q0 + i < n ? R.data[(size_t)slots[q0 + i] * (size_t)R.width + v] : 0.0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int v = base + tid + 256 * i;
-          if (v < nval) sum[i] += rec[v];
-        }
+        for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) sum += x[i];  // (+ 0.0 past the end of the list leaves every sum as it is)
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int v = base + tid + 256 * i;
-        if (v < nval) *out_of(v) = (overflow && !more) ? __builtin_nan("") : sum[i];
-      }
+      *dst = (overflow && !more) ? __builtin_nan("") : sum;
     }
     __syncthreads();
     if (!more) break;
@@ -343,8 +361,8 @@ static int spec_group_changes(wbx_ctx* ctx, const int32_t* group, int64_t nrows,
 
 // The launch's record store: `teams` one-record-at-the-end teams (or blocks), `extra` further records the kernel may open
 // (2 x group changes for contiguous walkers).  Grows the context's buffers when needed; alternates the counter parity.
-static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t teams, int64_t extra, int32_t width, SpecRecs* out) {
-  const int64_t cap = teams + extra + 64;
+static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t nstatic, int64_t dynamic, int32_t width, SpecRecs* out) {
+  const int64_t cap = nstatic + dynamic + 64;
   WBX_REQUIRE(cap < ((int64_t)1 << 31), "too many spectrum records (%lld)", (long long)cap);
   SpecRecs& R = st->recs;
   const size_t need = (size_t)(cap + 1) * (size_t)width * sizeof(double);
@@ -357,8 +375,8 @@ static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t teams, int64_t 
     if (R.data) (void)hipFree(R.data);
     if (R.group) (void)hipFree(R.group);
     if (R.key) (void)hipFree(R.key);
-    const int64_t grown = cap + cap / 4;
-    const size_t bytes = (size_t)(grown + 1) * (size_t)width * sizeof(double);
+    const int64_t grown = (cap > (int64_t)R.capacity ? cap : (int64_t)R.capacity) + cap / 4;
+    const size_t bytes = (need > st->recs_bytes ? need : st->recs_bytes) + need / 4;
     R.data = nullptr;
     R.group = nullptr;
     R.key = nullptr;
@@ -370,10 +388,9 @@ static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t teams, int64_t 
   }
   R.parity ^= 1;
   *out = R;
-  // (the slots actually usable with this width inside the buffer)
   out->width = width;
-  const size_t fit = st->recs_bytes / ((size_t)width * sizeof(double));
-  if (fit - 1 < out->capacity) out->capacity = (unsigned int)(fit - 1);
+  out->nstatic = (unsigned int)nstatic;
+  out->capacity = (unsigned int)cap;  // (the headers hold `grown` >= cap slots, the values at least (cap + 1) x width doubles)
   return 0;
 }
 
@@ -394,16 +411,20 @@ __global__ void __launch_bounds__(256) power_kernel(const float2* __restrict__ F
   __shared__ unsigned int rec_slot;
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = r_begin + rows_per_block < nrows_tile ? r_begin + rows_per_block : nrows_tile;
-  if (r_begin >= r_end) return;  // (block-uniform)
   const int64_t team = team_base + blockIdx.x;
+  if (r_begin >= r_end) {  // (block-uniform)
+    spec_rec_static(recs, (unsigned int)team, -1, 0ull, threadIdx.x == 0);
+    return;
+  }
   unsigned int seq = 0;
-  // runs of rows of one group: [ra, rb) -> one record, all wavenumbers
+  // runs of rows of one group: [ra, rb) -> one record, all wavenumbers; the block's LAST run goes into its reserved slot
   int64_t ra = r_begin;
   while (ra < r_end) {
     const int32_t cur = group[row0 + ra];
     int64_t rb = ra + 1;
     while (rb < r_end && group[row0 + rb] == cur) ++rb;
-    double* const rec = spec_rec_open_block(recs, cur, spec_key(team, seq++), &rec_slot);
+    double* const rec = rb == r_end ? spec_rec_static(recs, (unsigned int)team, cur, spec_key(team, 0xffffffu), threadIdx.x == 0)
+                                    : spec_rec_open_block(recs, cur, spec_key(team, seq++), &rec_slot);
     for (int k = (int)threadIdx.x; k < nk; k += 256) {
       const double norm = 1.0 / ((double)nlon * (double)nlon) * (k == 0 ? 1.0 : 2.0);
       double acc = 0.0;
@@ -711,7 +732,10 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
   const int64_t w = (int64_t)blockIdx.x * NTEAM + team;
   const int64_t r0 = w * rows_per_team;
   int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
-  if (r0 >= r1) return;  // G == 64: only wave-level syncs follow; G > 64: the whole block leaves together
+  if (r0 >= r1) {  // G == 64: only wave-level syncs follow; G > 64: the whole block leaves together
+    spec_rec_static(recs, (unsigned int)w, -1, 0ull, tid == 0);  // (the team's reserved slot stays empty)
+    return;
+  }
   const double inv_nn = 1.0 / ((double)fs.n * (double)fs.n);
   const int nh = n2 / 2;  // a thread owns wavenumbers k = tid + G i <= nh and their mirrors n2 - k
   double acc[KPT], accm[KPT];
@@ -725,8 +749,8 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     else
       return spec_rec_open_block(recs, g, spec_key(w, seq++), &rec_slot);
   };
-  auto flush = [&](int32_t next) {
-    double* const rec = open(cur);
+  auto flush = [&](int32_t next, bool last = false) {  // (the team's LAST record sits in the slot the launch reserved for it)
+    double* const rec = last ? spec_rec_static(recs, (unsigned int)w, cur, spec_key(w, 0xffffffu), tid == 0) : open(cur);
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
       const int k = tid + G * i;
@@ -836,7 +860,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
     }
     team_sync<G>();  // buf is overwritten by the next pair of rows
   }
-  flush(cur);
+  flush(cur, true);
 }
 
 #include "wbx_zspec1440.hpp"
@@ -1015,7 +1039,7 @@ static int launch_1440_latfast(wbx_ctx* ctx, FftState* st, const float* field, i
   if (int rc = spec_group_changes(ctx, group, rps * nslab, &changes)) return rc;
   const int64_t own = 13 * changes < 2 * rps * nslab ? 13 * changes : 2 * rps * nslab;
   SpecRecs recs;
-  if (int rc = spec_recs_prepare(ctx, st, nslab * runs + 8 * (int64_t)nlocal, own, Z14_N2 + 1, &recs)) return rc;
+  if (int rc = spec_recs_prepare(ctx, st, nslab * runs, own, Z14_N2 + 1, &recs)) return rc;  // static: one slot per step
   if (prof_path) {
     static unsigned long long* prof = nullptr;  // (diagnostic path, see launch_1440)
     unsigned long long host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1217,8 +1241,9 @@ static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t 
   int64_t tile = ((int64_t)256 << 20) / ((int64_t)nk * 8);
   if (tile < 1) tile = 1;
   if (tile > nrows) tile = nrows;
-  if (int rc = spec_recs_prepare(ctx, st, (nrows + rows_per_block - 1) / rows_per_block + (nrows + tile - 1) / tile, changes, nk, &recs))
-    return rc;
+  int64_t nblocks = 0;  // every block of every tile has a reserved slot and writes its header: the count has to be exact
+  for (int64_t r0 = 0; r0 < nrows; r0 += tile) nblocks += ((r0 + tile <= nrows ? tile : nrows - r0) + rows_per_block - 1) / rows_per_block;
+  if (int rc = spec_recs_prepare(ctx, st, nblocks, changes, nk, &recs)) return rc;
   // a strided batch only tiles cleanly when rows are uniformly spaced, which they are by construction
   const size_t need = (size_t)tile * nk * 8;
   if (st->scratch_size < need) {
@@ -1341,7 +1366,7 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
   int64_t changes = 0;
   if (int rc = spec_group_changes(ctx, group, rps * nslab, &changes)) return rc;
   SpecRecs recs;
-  if (int rc = spec_recs_prepare(ctx, st, nslab * runs + 8 * (int64_t)nlocal, 8 * changes < rps * nslab ? 8 * changes : rps * nslab,
+  if (int rc = spec_recs_prepare(ctx, st, nslab * runs, 8 * changes < rps * nslab ? 8 * changes : rps * nslab,
                                  2 * (Z14_N2 + 1), &recs))
     return rc;
 #ifdef WBX_DIAGNOSTICS  // (knock-out instantiations, wrong results by design: `make diag` only, like WBX_SPECTRUM_KNOCK)

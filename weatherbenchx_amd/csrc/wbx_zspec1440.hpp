@@ -286,7 +286,11 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   const int64_t r0 = ((int64_t)blockIdx.x * nteam + team) * rows_per_team + lead;
   const int64_t mine = rows_per_team + (int64_t)skew * (1 - g);
   const int64_t r1 = r0 + mine < nrows ? r0 + mine : nrows;
-  if (r0 >= r1) return;  // only wave-level ordering below
+  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;  // the records' keys: (team, sequence number) -- fixed by the launch
+  if (r0 >= r1) {  // only wave-level ordering below
+    spec_rec_static(recs, (unsigned int)team_id, -1, 0ull, lane == 0);  // (the team's reserved slot stays empty)
+    return;
+  }
   const Z14Lane c = z14_lane(lane, buf, tw2);
   const int L = c.L;
   const double quarter_inv_nn = 0.25 / ((double)Z14_N * (double)Z14_N);  // E and O are used without their factor 1/2
@@ -295,10 +299,12 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
 #pragma unroll
   for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
   int32_t cur = group[r0];
-  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;  // the records' keys: (team, sequence number) -- fixed by the launch
   unsigned int seq = 0;
-  auto flush = [&](int32_t next) {
-    z14_send<true>(spec_rec_open(recs, cur, spec_key(team_id, seq++), lane), c, acc, accm);
+  // a team's LAST record (for most teams the only one) goes into the slot the launch reserved for it: no counter to wait for
+  auto flush = [&](int32_t next, bool last = false) {
+    double* const rec = last ? spec_rec_static(recs, (unsigned int)team_id, cur, spec_key(team_id, 0xffffffu), lane == 0)
+                             : spec_rec_open(recs, cur, spec_key(team_id, seq++), lane);
+    z14_send<true>(rec, c, acc, accm);
 #pragma unroll
     for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
     cur = next;
@@ -372,7 +378,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     }
   }
   const unsigned long long t_flush = PROF ? __builtin_readcyclecounter() : 0ull;
-  flush(cur);
+  flush(cur, true);
   if constexpr (PROF) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     spent[9] = __builtin_readcyclecounter() - t_flush;  // the closing atomics
@@ -422,7 +428,6 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
     int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem, int prio, const float2* __restrict__ tables_g,
     const int32_t* __restrict__ group, const double* __restrict__ scale, SpecRecs recs, unsigned long long* __restrict__ prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ unsigned int rec_slot;        // spec_rec_open_block
   __shared__ int team_in_table[Z14_TEAMS];  // the team's sums of the last step sit in its buffer, for the block's table
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
   float2* const tw2 = tw1 + Z14_TW1;
@@ -511,8 +516,8 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
 #pragma unroll
   for (int s = 0; s < 6; ++s) acc[s] = accm[s] = 0.0;
   const int64_t block_id = (int64_t)blockIdx.x;
-  unsigned int seq_block = 0, seq_team = 0;  // record keys: (block, 0, n) for the table, (block, 1 + team, n) for a team's own
-  auto team_key = [&]() { return spec_key(block_id * (Z14_TEAMS + 1) + 1 + team, seq_team++); };
+  unsigned int seq_team = 0;  // keys: a step's slot number for the table; (1 << 30) + (block, team, n) for a team's own records
+  auto team_key = [&]() { return (1ull << 62) | spec_key(block_id * Z14_TEAMS + team, seq_team++); };
   double* const own = reinterpret_cast<double*>(buf);  // the team's buffer as 721 doubles (5.8 of its 11.7 KB)
   // the teams' sums of the step that just ended -> the block's table, in team order (every thread; between two block barriers)
   auto gather_teams = [&]() {
@@ -524,9 +529,13 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
       blk[k] = sum;
     }
   };
-  auto flush_block = [&](int32_t next) {  // every thread of the block, block-uniformly; contains block barriers
+  // Every step (slab o, run) of the launch has a record slot of its own (slot = o * runs_per_slab + run: fixed by the geometry,
+  // no counter, no barrier).  The table is written into the slot of the LAST step that added to it; the slots of the steps in
+  // between stay empty (header group -1).
+  int64_t table_slot = -1;  // the slot of the step whose sums are in the table (block-uniform)
+  auto flush_block = [&](int32_t next) {  // every thread of the block, block-uniformly
     if (blk_group >= 0) {
-      double* const rec = spec_rec_open_block(recs, blk_group, spec_key(block_id * (Z14_TEAMS + 1), seq_block++), &rec_slot);
+      double* const rec = spec_rec_static(recs, (unsigned int)table_slot, blk_group, (unsigned long long)table_slot, tid == 0);
       for (int k = tid; k < nk; k += 64 * Z14_TEAMS) {
         const double sum = blk[k];
         rec[k] = k == 0 ? sum : 2.0 * sum;  // S_k, include/wbx.h
@@ -569,7 +578,11 @@ __global__ void __launch_bounds__(64 * Z14_TEAMS) zspec1440_latfast_kernel(
       if (n < Z14_STAGE - 1 || j0 + 64 * n < Z14_N) stage_dst[64 * n] = held[n];
     __syncthreads();
     mark(2);
-    if (g0 != blk_group) flush_block(g0);  // block-uniform: the table holds the sums of the steps of the previous group
+    // block-uniform: the table holds the sums of the earlier steps -- of another group: out they go (into the last of those steps'
+    // slot); of this step's group: they stay, and that step's slot is marked empty
+    if (g0 != blk_group) flush_block(g0);
+    else if (table_slot >= 0) spec_rec_static(recs, (unsigned int)table_slot, -1, 0ull, tid == 0);
+    table_slot = o * runs_per_slab + run;
     int64_t on = o;
     int rn = run + nlocal;
     normalise(on, rn);

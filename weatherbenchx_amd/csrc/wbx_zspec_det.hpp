@@ -58,7 +58,11 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   __syncthreads();
   const int64_t r0 = ((int64_t)blockIdx.x * nteam + team) * rows_per_team;
   const int64_t r1 = r0 + rows_per_team < nrows ? r0 + rows_per_team : nrows;
-  if (r0 >= r1) return;  // only wave-level ordering below
+  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;
+  if (r0 >= r1) {  // only wave-level ordering below
+    spec_rec_static(recs, (unsigned int)team_id, -1, 0ull, lane == 0);  // (the team's reserved slot stays empty)
+    return;
+  }
   constexpr int nk = Z14_N2 + 1;
   const Z14Lane c = z14_lane(lane, buf, tw2);
   const int L = c.L;
@@ -68,10 +72,11 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
 #pragma unroll
   for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
   int32_t cur = group[r0];
-  const int64_t team_id = (int64_t)blockIdx.x * nteam + team;
   unsigned int seq = 0;
-  auto flush = [&](int32_t next) {  // (r5) one record of 2 x 721 values: the predictions' sums, then the targets'
-    double* const rec = spec_rec_open(recs, cur, spec_key(team_id, seq++), lane);
+  // (r5) one record of 2 x 721 values: the predictions' sums, then the targets'; the team's LAST record sits in its reserved slot
+  auto flush = [&](int32_t next, bool last = false) {
+    double* const rec = last ? spec_rec_static(recs, (unsigned int)team_id, cur, spec_key(team_id, 0xffffffu), lane == 0)
+                             : spec_rec_open(recs, cur, spec_key(team_id, seq++), lane);
     z14_send<true>(rec, c, accp, accmp);
     z14_send<true>(rec + nk, c, acct, accmt);
 #pragma unroll
@@ -188,7 +193,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
       }
     }, acct, accmt, msh);
   }
-  flush(cur);
+  flush(cur, true);
 }
 #pragma clang diagnostic pop
 

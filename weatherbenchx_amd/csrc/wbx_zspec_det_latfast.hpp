@@ -41,7 +41,6 @@ template <bool HAS_C, int KNOCK = 0>
 __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
     S1Args a, int64_t rps, int64_t nslab, int64_t slabs_per_xcd, int runs_per_slab, int run_base, int run_rem,
     const float2* __restrict__ tables_g, const int32_t* __restrict__ group, const double* __restrict__ scale, SpecRecs recs) {
-  __shared__ unsigned int rec_slot;         // spec_rec_open_block
   __shared__ int team_in_table[ZL_TEAMS];   // the team's sums of the last step sit in its buffer, for the block's tables
   constexpr int NA = HAS_C ? 6 : 3;
   constexpr int NIN = HAS_C ? 3 : 2;
@@ -154,7 +153,8 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
   int32_t blk_group = -1;  // block-uniform
   if (tid < ZL_TEAMS) team_in_table[tid] = 0;
   const int64_t block_id = (int64_t)blockIdx.x;
-  unsigned int seq_block = 0, seq_team = 0;
+  unsigned int seq_team = 0;
+  int64_t table_slot = -1;  // the slot (= step number, o * runs_per_slab + run) of the last step whose sums are in the tables
   double* const own = reinterpret_cast<double*>(buf);
   auto gather_teams = [&]() {
     for (int k = tid; k < 2 * nk; k += ZL_THREADS) {
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
   };
   auto flush_block = [&](int32_t next) {  // every thread of the block, block-uniformly; contains block barriers
     if (blk_group >= 0) {
-      double* const rec = spec_rec_open_block(recs, blk_group, spec_key(block_id * (ZL_TEAMS + 1), seq_block++), &rec_slot);
+      double* const rec = spec_rec_static(recs, (unsigned int)table_slot, blk_group, (unsigned long long)table_slot, tid == 0);
       for (int k = tid; k < 2 * nk; k += ZL_THREADS) {
         const bool second = k >= nk;
         const int kk = second ? k - nk : k;
@@ -269,7 +269,11 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
         a.out[(row0 + rbeg + i) * NA + l] = tot;
       }
     }
-    if (g0 != blk_group) flush_block(g0);  // block-uniform: the tables hold the sums of the steps of the previous group
+    // block-uniform: the tables hold the sums of the earlier steps -- of another group: out they go (into the last of those steps'
+    // slot); of this step's group: they stay, and that step's slot is marked empty
+    if (g0 != blk_group) flush_block(g0);
+    else if (table_slot >= 0) spec_rec_static(recs, (unsigned int)table_slot, -1, 0ull, tid == 0);
+    table_slot = o * runs_per_slab + run;
     if (active) {
       C2 v[12];
 #pragma unroll
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(ZL_THREADS) zspec1440_det_latfast_kernel(
         z14_send<false>(own + nk, c, acct, accmt);
         if (lane == 0) team_in_table[team] = 1;
       } else {
-        double* const rec = spec_rec_open(recs, g, spec_key(block_id * (ZL_TEAMS + 1) + 1 + team, seq_team++), lane);
+        double* const rec = spec_rec_open(recs, g, (1ull << 62) | spec_key(block_id * ZL_TEAMS + team, seq_team++), lane);
         z14_send<true>(rec, c, accp, accmp);
         z14_send<true>(rec + nk, c, acct, accmt);
       }
