@@ -9,7 +9,7 @@ tail -12 gpurun_out/r5_pytest_spectra_$TAG.log
 OUT=gpurun_out/r5_bench_spectra_$TAG.txt
 : > $OUT
 for rep in 1 2; do
-for lib in libwbx_hip_r4.so libwbx_hip.so; do
+for lib in libwbx_hip.so; do  # (the round-4 library lacks wbx_chunk_replay: its numbers are profiles/r04_*)
   for lay in lon_fastest lat_fastest; do
     echo "== $lib $lay" >> $OUT
     WBX_CHUNK_REPLAY=0 WBX_LIBRARY_PATH=$PWD/weatherbenchx_amd/$lib timeout 300 python bench.py --legs spectrum --no-cpu --no-config5 --steps 10 --warmup 3 --layout $lay > /dev/null 2>>$OUT.err

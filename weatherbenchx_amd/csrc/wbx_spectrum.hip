@@ -169,9 +169,9 @@ __device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_
   return R.data + (size_t)r * (size_t)R.width;
 }
 
-// power[f][g][k] (+)= the records of group g added in key order; one block per group.  The block scans the slot headers
-// (coalesced, a few KB), collects its group's (key, slot) pairs in the LDS, sorts them (bitonic), and every thread adds its
-// wavenumbers down the sorted list.  More records than the LDS list holds: further rounds, each taking the next LIST keys in
+// power[f][g][k] (+)= the records of group g added in key order; one block per (group, 64 values).  The block scans the slot
+// headers (coalesced, a few KB), collects its group's (key, slot) pairs in the LDS, sorts them, and its four waves add their
+// values down a quarter of the sorted list each.  More records than the LDS list holds: further rounds, each taking the next LIST keys in
 // order (the sum still runs in key order).
 constexpr int SPEC_CLOSE_LIST = 2048;
 constexpr int SPEC_CLOSE_BATCH = 16;  // headers / record values a thread asks for before it looks at any of them
@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
   __shared__ unsigned long long keys[SPEC_CLOSE_LIST];
   __shared__ unsigned int slots[SPEC_CLOSE_LIST];
   __shared__ unsigned int n_list, n_more;
+  __shared__ double part[4][64];
   const int32_t g = (int32_t)blockIdx.x;
   const int tid = (int)threadIdx.x;
   const unsigned int dyn = R.count[R.parity];
@@ -255,55 +256,81 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
       __syncthreads();
       n = n_list;
     }
-    // bitonic sort of (keys, slots)[0, n) by key, padded to a power of two with the largest key
-    unsigned int np = 1u;
-    while (np < n) np <<= 1;
-    for (unsigned int i = n + tid; i < np; i += 256) {
-      keys[i] = ~0ull;
-      slots[i] = 0u;
-    }
-    __syncthreads();
-    for (unsigned int size = 2u; size <= np; size <<= 1) {
-      for (unsigned int stride = size >> 1; stride > 0u; stride >>= 1) {
-        for (unsigned int i = tid; i < np; i += 256) {
-          const unsigned int j = i ^ stride;
-          if (j > i) {
-            const bool up = (i & size) == 0u;
-            const unsigned long long a = keys[i], b = keys[j];
-            if ((a > b) == up) {
-              keys[i] = b;
-              keys[j] = a;
-              const unsigned int t = slots[i];
-              slots[i] = slots[j];
-              slots[j] = t;
+    if (n <= 256u) {
+      // (the usual case) rank sort: thread i counts the keys below its own (keys are unique) and puts its slot there
+      const unsigned long long mine = tid < (int)n ? keys[tid] : 0ull;
+      const unsigned int my_slot = tid < (int)n ? slots[tid] : 0u;
+      unsigned int rank = 0u;
+      if (tid < (int)n) {
+        for (unsigned int j = 0; j < n; ++j) rank += keys[j] < mine ? 1u : 0u;
+      }
+      __syncthreads();
+      if (tid < (int)n) slots[rank] = my_slot;
+      __syncthreads();
+    } else {
+      // bitonic sort of (keys, slots)[0, n) by key, padded to a power of two with the largest key
+      unsigned int np = 1u;
+      while (np < n) np <<= 1;
+      for (unsigned int i = n + tid; i < np; i += 256) {
+        keys[i] = ~0ull;
+        slots[i] = 0u;
+      }
+      __syncthreads();
+      for (unsigned int size = 2u; size <= np; size <<= 1) {
+        for (unsigned int stride = size >> 1; stride > 0u; stride >>= 1) {
+          for (unsigned int i = tid; i < np; i += 256) {
+            const unsigned int j = i ^ stride;
+            if (j > i) {
+              const bool up = (i & size) == 0u;
+              const unsigned long long a = keys[i], b = keys[j];
+              if ((a > b) == up) {
+                keys[i] = b;
+                keys[j] = a;
+                const unsigned int t = slots[i];
+                slots[i] = slots[j];
+                slots[j] = t;
+              }
             }
           }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
-    // every thread adds its values down the sorted list (BATCH records' values asked for at a time; the additions run in list
-    // order); between rounds the running sums live in the output itself (this block is their only reader and writer)
-    for (int v = tid; v < nval; v += 256) {
-      double* const dst = out_of(v);
-      double sum = (first_round && !accumulate) ? 0.0 : *dst;
-      for (unsigned int q0 = 0; q0 < n; q0 += SPEC_CLOSE_BATCH) {
-        double x[SPEC_CLOSE_BATCH];
+    // The block's 64 values (blockIdx.y), one per lane; wave w adds the w-th quarter [n w / 4, n (w + 1) / 4) of the sorted list
+    // in list order (BATCH records' values asked for at a time), the four partial sums are then added in wave order: a fixed
+    // function of the record SET.  Between rounds the running sums live in the output (this block is their only reader / writer).
+    {
+      const int wv = tid >> 6, ln = tid & 63;
+      const int v = (int)blockIdx.y * 64 + ln;
+      const unsigned int q_lo = (unsigned int)(((unsigned long long)n * (unsigned)wv) >> 2);
+      const unsigned int q_hi = (unsigned int)(((unsigned long long)n * (unsigned)(wv + 1)) >> 2);
+      double* const dst = v < nval ? out_of(v) : nullptr;
+      double sum = 0.0, start = 0.0;
+      if (dst) {
+        if (wv == 0 && !(first_round && !accumulate)) start = *dst;
+        for (unsigned int q0 = q_lo; q0 < q_hi; q0 += SPEC_CLOSE_BATCH) {
+          double x[SPEC_CLOSE_BATCH];
 #pragma unroll
-        for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) x[i] = q0 + i < n ? R.data[(size_t)slots[q0 + i] * (size_t)R.width + v] : 0.0;
+          for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) x[i] = q0 + i < q_hi ? R.data[(size_t)slots[q0 + i] * (size_t)R.width + v] : 0.0;
 #pragma unroll
-        for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) sum += x[i];  // (+ 0.0 past the end of the list leaves every sum as it is)
+          for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) sum += x[i];  // (+ 0.0 past the end of the list leaves every sum as it is)
+        }
       }
-      *dst = (overflow && !more) ? __builtin_nan("") : sum;
+      part[wv][ln] = sum;
+      __syncthreads();
+      if (dst && wv == 0) {
+        const double total = (((start + part[0][ln]) + part[1][ln]) + part[2][ln]) + part[3][ln];
+        *dst = (overflow && !more) ? __builtin_nan("") : total;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (!more) break;
     floor_key = next_floor;
     first_round = false;
   }
   // the other parity's counters are the next launch's: clear them (nobody reads them now; stream order puts this in front of
   // that launch)
-  if (g == 0 && tid == 0) {
+  if (g == 0 && blockIdx.y == 0 && tid == 0) {
     R.count[1 - R.parity] = 0u;
     R.count[2 + (1 - R.parity)] = 0u;
   }
@@ -397,7 +424,7 @@ static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t nstatic, int64_
 static int spec_close(wbx_ctx* ctx, const SpecRecs& R, int32_t ngroup, int32_t nk, int32_t nfield, double* power0, double* power1,
                       int32_t accumulate) {
   if (ngroup <= 0) return 0;
-  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup), dim3(256), 0, ctx->stream, R, ngroup, nk, nfield, power0, power1, accumulate);
+  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup, (unsigned)((nk * nfield + 63) / 64)), dim3(256), 0, ctx->stream, R, ngroup, nk, nfield, power0, power1, accumulate);
   WBX_HIP(hipGetLastError());
   return 0;
 }

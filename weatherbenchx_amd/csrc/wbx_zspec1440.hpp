@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
   // finished after 175 / 226 / 275 us (configs[3]) and the SIMD ran its last 100 us under-occupied.  Rotating the user
   // priority pair by pair gives every wave the same share of the issue slots.
   int turn = team >> 2;  // waves t, t + 4, t + 8 of a block share a SIMD
-  for (int64_t r = r0; r < r1; r += 2) {
+  for (int64_t r = r0; r < r1;) {
     if constexpr (ROTATE) {
       turn = turn == 2 ? 0 : turn + 1;
       if (turn == 0) __builtin_amdgcn_s_setprio(0);
@@ -346,8 +346,12 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
       else __builtin_amdgcn_s_setprio(2);
     }
     mark(0, false);
-    const bool two = r + 1 < r1;  // a missing second row is a row of zeros with scale 0
-    const int32_t ga = group[r], gb = two ? group[r + 1] : ga;
+    // a missing second row is a row of zeros with scale 0.  (r5) So is the second row of a pair that would straddle two
+    // groups: row r goes alone and row r + 1 opens the next pair (its loads are issued again; ~0.6 % of configs[3]'s pairs)
+    // -- the sums in flight always belong to ONE group and a record is only ever written from the accumulators.
+    const int32_t ga = group[r];
+    const bool two = r + 1 < r1 && group[r + 1] == ga;
+    const int64_t rn = r + (two ? 2 : 1);
     const double sca = scale[r] * quarter_inv_nn, scb = two ? scale[r + 1] * quarter_inv_nn : 0.0;
     C2 v[12];
 #pragma unroll
@@ -356,21 +360,20 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     if constexpr (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     mark(1, false);  // 0 -> 1: scalar bookkeeping + the wait for the prefetched rows
     if constexpr (FETCH_EARLY) {
-      if (r + 2 < r1) fetch(r + 2);
+      if (rn < r1) fetch(rn);
     }
 
     if (ga != cur) flush(ga);  // wave-uniform
-    // (a pair that straddles two groups: row B's values are a record of their own)
-    double* const rec_b = gb != ga ? spec_rec_open(recs, gb, spec_key(team_id, seq++), lane) : nullptr;
     // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
     // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
-    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, gb != ga, gb, acc, accm, rec_b,
+    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, false, ga, acc, accm, nullptr,
                            [&](int i) {
                              mark(i + 2, i == 1 || i == 3 || i == 5);
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads
-                               if (i == 0 && r + 2 < r1) fetch(r + 2);
+                               if (i == 0 && rn < r1) fetch(rn);
                              }
                            }, acc, accm, msh);
+    r = rn;
     if constexpr (PROF) {
 #pragma unroll
       for (int i = 1; i < 8; ++i) spent[i] += stamp[i] - stamp[i - 1];
