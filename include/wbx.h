@@ -401,8 +401,19 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
  * otherwise a batched 1-D R2C rocFFT along longitude, then a HIP |.|^2 reduction:
  *   power_out[group[r]][k] (+)= scale[r] * S_k(row r)
  * group[nrows] (int32 in [0, ngroup)) and scale[nrows] (float64, e.g. area weight / count) are device arrays;
- * power_out is float64[ngroup][nlon/2 + 1]; accumulate = 0 overwrites it, 1 adds to it (fp64 atomics, so the
- * summation order -- not the value beyond ~1e-16 relative -- may differ between runs).
+ * power_out is float64[ngroup][nlon/2 + 1]; accumulate = 0 overwrites it, 1 adds to it.
+ * Order of the sums (round 5; every route, also wbx_det_spectrum / wbx_det_spectrum_slabs): NO atomics on the result path.
+ * A team of the transform kernel sums the rows it walks (a fixed share of the launch geometry, in row order) in registers
+ * and stores the sums of each run of one group as a RECORD (group, key = (team, sequence number), nlon/2 + 1 values) in a
+ * scratch store of the context; a closing kernel on the same stream then adds every group's records in KEY order -- the
+ * result is a function of (inputs, launch geometry) only and bit-identical from run to run
+ * (tests/test_gpu_round5.py::test_spectra_*_bit_reproducible: 20 runs each).  `group` and `scale` are read by this call's
+ * kernels in stream order; the number of group changes along `group` is cached per (pointer, nrows) to size the store and
+ * the cache entry is dropped by every write this library makes into the table (wbx_memcpy_h2d*, wbx_memset, wbx_memcpy_d2d):
+ * a table rewritten by anybody else's kernel must go through one of those calls first (a stale count that is too small does not
+ * give wrong sums: the records that do not fit set every value of the call's result to NaN).
+ * Cost against round 4's atomics on the same box: +3.1 % (lon-fastest), +2.7 % (lat-fastest), +3.7 % (fused det + spectra);
+ * profiles/r05_spectra_records_ab.txt.
  * Accuracy (the one family that is not held to north_star's 1e-6 per value: the transform itself is fp32, only |F|^2 and the
  * sums over rows are fp64).  1440-point rows (0.25 degree grids, both layouts): a row is shifted by an estimate of its mean
  * before the transform and F_0 is restored in fp64, so the error does not scale with the field's mean --
@@ -435,7 +446,7 @@ int wbx_zonal_spectrum_slabs(wbx_ctx* ctx, const float* field, int64_t lon_strid
  *   partial_out[key][lane]      exactly what wbx_det_partial writes for this plan (nchunk = 1): the unweighted per-row sums of
  *                               e, |e|, e^2 (, (p-c)^2, (t-c)^2, (p-c)(t-c)); wbx_contract consumes it unchanged
  *   power_p / power_t[g][k]     what wbx_zonal_spectrum returns for the rows of p resp. t: sum over the rows of group g of
- *                               scale[row] * S_k(row), k = 0 .. 720; zeroed here first
+ *                               scale[row] * S_k(row), k = 0 .. 720; overwritten (ordered sums, see wbx_zonal_spectrum)
  * `plan` is the deterministic plan of (p, t[, c]) with x = longitude (nx = 1440, unit x strides, even row offsets), summed,
  * ndepth = 1, nchunk = 1, no mask: a row of the spectra = a key of the plan, group / scale are indexed by key.
  * Spectrum accuracy: as wbx_zonal_spectrum on 1440-point rows (fp32 transform of the mean-shifted rows); the deterministic lanes

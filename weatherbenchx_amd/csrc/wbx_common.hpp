@@ -25,6 +25,7 @@ struct wbx_ctx {
   void* atoms_clean = nullptr;  // std::set<const void*>*: prepared atom tables (wbx_binned_atoms) without an overflowing patch
   void* patch_counters = nullptr;  // wbx_ens_binned: arrival counters of its in-kernel sums over patches (uint32, kept zero)
   size_t patch_counters_size = 0;
+  uint32_t ens_queue_parity = 0;   // which of the two ticket sets at the head of patch_counters the next persistent launch uses
   hipEvent_t* marks = nullptr;  // wbx_mark: timing events, created on demand and recycled by wbx_marks_reset
   int marks_used = 0, marks_made = 0, marks_cap = 0;
 };

@@ -110,6 +110,15 @@ extern "C" int wbx_free(wbx_ctx* ctx, void* dptr) {
   if (!dptr) return 0;
   WBX_HIP(hipSetDevice(ctx->device));
   WBX_HIP(hipStreamSynchronize(ctx->stream));
+  {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, dptr) != hipSuccess) {
+      (void)hipGetLastError();
+      size = 1;
+    }
+    wbx::spectrum_note_write(dptr, size);  // (the next owner of these addresses holds other tables)
+  }
   WBX_HIP(hipFree(dptr));
   return 0;
 }

@@ -121,6 +121,9 @@ struct EnsAtomsArgs {
   double* part1;       // [cell][ng1][NOUT][64]
   double* part2;       // [cell][ng2][NP]
   uint32_t* counters;  // [cell][ng1] | [cell][ng2] | [cell], zero before the first launch and after every launch
+  uint32_t* queue;     // persistent launches: [64] patch tickets, one queue per (XCD, eighth of its patches); zero at launch
+  int32_t queue_static;  // A/B (WBX_ENS_ATOMS_STATIC=1): no tickets, a fixed share of the patches per wave
+  uint32_t* queue_next;  // the next launch's [64]: zeroed by this one (nobody else touches it meanwhile: stream order)
   double* out;         // [cell][NOUT][nbin]
   int32_t ng1, ng2;
   int32_t masked;      // 0: no mask; 1: the atom ids are g.aidm, 255 = masked out; 2 (twin): g.aidm, id | 0x80 = masked out -- such
@@ -136,6 +139,12 @@ struct EnsAtomsArgs {
   unsigned long long* prof;  // diagnostic builds (WBX_EA_PROF): eight time stamps per patch, else NULL
 };
 
+#ifndef WBX_EA_PERSIST
+#define WBX_EA_PERSIST 0  // make ab-eapersist: persistent waves on one-wave blocks (see ens_atoms_kernel<.., PERSIST>); measured
+#endif                    // SLOWER than one block per patch (profiles/r05_ens_atoms_persistent_ab.txt) and not in the shipped library
+#ifndef WBX_EA_PERSIST_RELOAD
+#define WBX_EA_PERSIST_RELOAD 1  // make ab-eanoreload: the persistent kernel keeps its arguments in registers across patches
+#endif
 #ifndef WBX_EA_PROF
 #define WBX_EA_PROF 0  // make ab-eaprof: phase stamps of every wave, dumped to $WBX_EA_PROF_DUMP after each launch
 #endif
@@ -159,26 +168,52 @@ struct EnsAtomsArgs {
 // MODE 0: the id bytes are [bk][br][x] (bins, or bins + a mask on the W dims) -- the round-4 kernel, nothing added to its loop;
 //      1: one id byte per point of the chunk (a mask with strides along A / the depth dims);
 //      2: Aggregator(skipna=True), either kind of id table (run-time)
-template <int MP, bool EXACT, bool NT, int MODE = 0>
-__global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB), WBX_ENS_PIPE_WAVES)
-ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+// The kernel's arguments field by field out of the kernel-argument segment (scalar loads; whole-struct copies through a word
+// pointer stay in scratch memory)
+__device__ __forceinline__ void load_args(S1Args& d, const_ptr<S1Args> s) {
+#pragma unroll
+  for (int i = 0; i < WBX_MAX_INPUTS; ++i) {
+    d.in[i] = s->in[i];
+    d.key_off[i] = s->key_off[i];
+    d.depth_off[i] = s->depth_off[i];
+    d.xstride[i] = s->xstride[i];
+  }
+  d.gk = s->gk, d.gd = s->gd, d.gtab = s->gtab, d.ngd = s->ngd;
+  d.nkey = s->nkey, d.D = s->D, d.nx = s->nx, d.dchunk = s->dchunk;
+  d.nchunk = s->nchunk, d.nxtile = s->nxtile, d.flags = s->flags;
+  d.out = s->out, d.xw = s->xw, d.M = s->M, d.mstride = s->mstride, d.lane = s->lane, d.ngd_t = s->ngd_t;
+}
+__device__ __forceinline__ void load_args(BinnedArgs& d, const_ptr<BinnedArgs> s) {  // (all but split_br: this kernel reads split_tab)
+  d.wt = s->wt, d.bits = s->bits, d.nBk = s->nBk, d.nBr = s->nBr, d.nj = s->nj;
+  d.nbin = s->nbin, d.nxt = s->nxt, d.nrs = s->nrs, d.rows_per_split = s->rows_per_split;
+  d.ncell = s->ncell, d.nblocks = s->nblocks, d.tmp = s->tmp, d.tmp_poison = s->tmp_poison, d.uni = s->uni;
+  d.aid = s->aid, d.aidm = s->aidm, d.words = s->words, d.nwords = s->nwords, d.atoms = s->atoms, d.order = s->order;
+  d.taper = s->taper, d.split_tab = s->split_tab;
+}
+__device__ __forceinline__ void load_args(EnsAtomsArgs& d, const_ptr<EnsAtomsArgs> s) {
+  d.wx = s->wx, d.wrow = s->wrow, d.tab = s->tab, d.part1 = s->part1, d.part2 = s->part2;
+  d.counters = s->counters, d.queue = s->queue, d.queue_next = s->queue_next, d.queue_static = s->queue_static, d.out = s->out, d.ng1 = s->ng1, d.ng2 = s->ng2;
+  d.masked = s->masked, d.twin_rows = s->twin_rows, d.out_mode = s->out_mode;
+  d.id_cell_rows = s->id_cell_rows, d.br_per_split = s->br_per_split, d.prof = s->prof;
+}
+
+// One patch, by one wave: (virtual) block `vb` of patch_grid<WPB>(g); lds_raw = the wave's staging slice.
+template <int MP, bool EXACT, bool NT, int MODE>
+__device__ __forceinline__ void ens_atoms_patch(const S1Args& a, const BinnedArgs& g, const EnsAtomsArgs& e, uint32_t vb,
+                                                unsigned char* const lds_raw) {
   constexpr bool SKIPNA = MODE == 2;
   constexpr int WPB = NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB;
   using Op = EnsOpF32<MP, EXACT, WBX_ENS_SORT>;
   constexpr int NQ = ENS_ATOMS_NQ, NOUT = ENS_ATOMS_NOUT;
   constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;  // members staged through the LDS
   constexpr int NREG = MP - NLDS;                                        // members prefetched into VGPRs
-  constexpr int NST = NLDS < 48 ? 48 : NLDS;                             // (the level-1 finisher borrows 12 KB of it)
   constexpr int NONE = 255;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB][NST * 256];
-  const int wave_in_block = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  unsigned char* const lds_raw = lds_all[wave_in_block];  // (every wave works in its own slice: no block-level sync anywhere)
   float(*stage)[64] = reinterpret_cast<float(*)[64]>(lds_raw);
   const int lane = threadIdx.x & 63;
   const int M = EXACT ? MP : a.M;
   int64_t cell;
   int xt, rs;
-  if (!patch_decode<WPB>(g, cell, xt, rs)) return;
+  if (!patch_decode<WPB>(g, cell, xt, rs, vb)) return;
   const int64_t bk = cell % g.nBk;
   const int64_t A = cell / g.nBk;
   const int64_t npatch = (int64_t)g.nrs * g.nxt;
@@ -605,6 +640,78 @@ ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
   }
   WBX_EA_STAMP(7);
 }
+
+// PERSIST (r5; one-wave blocks): the launch is as many waves as the device holds at once (or fewer), and a wave that has
+// finished a patch draws the next one from a queue instead of exiting and leaving its slot to a new wave (2 800 of 3 072 slots
+// were occupied in the middle of a launch, profiles/r04_ens_atoms_phases.txt).  64 queues = (XCD y, eighth s of its patches):
+// ticket t of queue (y, s) is block 8 (8 t + s) + y of the plain launch, so an XCD still walks its contiguous eighth of the patches
+// in order; a wave's home queue is blockIdx & 63.  (One queue per XCD was 2 x SLOWER than the plain launch: atomics on one address
+// are served one after the other, ~100 ns each -- 5 000 draws per address and a departures counter that every wave hit once.
+// Now ~280 draws per address.)  A wave whose queue has run dry reads all 64 tickets with ONE load (lane = queue), prefers what is
+// left on its own XCD, and leaves when every queue is dry.  The tickets are not reset at the end (no departures counter): the
+// launches of a context alternate between two sets, and every launch clears the other one.
+template <int MP, bool EXACT, bool NT, int MODE = 0, bool PERSIST = false>
+__global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB), WBX_ENS_PIPE_WAVES)
+ens_atoms_kernel(S1Args a, BinnedArgs g, EnsAtomsArgs e) {
+  constexpr int WPB = NT ? 1 : WBX_ENS_ATOMS_RAGGED_WPB;
+  constexpr int NLDS = MP < WBX_ENS_PIPE_NLDS ? MP : WBX_ENS_PIPE_NLDS;
+  constexpr int NST = NLDS < 48 ? 48 : NLDS;  // (the level-1 finisher borrows 12 KB of it)
+  __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB][NST * 256];
+  const int wave_in_block = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  unsigned char* const lds_raw = lds_all[wave_in_block];  // (every wave works in its own slice: no block-level sync anywhere)
+  if constexpr (!PERSIST) {
+    ens_atoms_patch<MP, EXACT, NT, MODE>(a, g, e, blockIdx.x, lds_raw);
+  } else {
+    static_assert(!PERSIST || WPB == 1, "persistent waves are one-wave blocks");
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0) st_dev(e.queue_next + lane, 0u);
+    const uint32_t per_xcd = patch_per_xcd<WPB>(g);
+    const uint32_t home = blockIdx.x & 63u;
+    uint32_t q = home;
+    uint32_t static_round = 0;
+    const uint32_t mine_n = (per_xcd + 7u - ((uint32_t)lane >> 3)) >> 3;  // tickets of queue `lane`
+#pragma unroll 1
+    for (;;) {
+      uint32_t t = 0;
+      if (e.queue_static) {  // (A/B) no queue: block b takes the tickets b / 64, b / 64 + gridDim / 64, .. of queue b & 63
+        t = (blockIdx.x >> 6) + static_round * (gridDim.x >> 6);
+        ++static_round;
+        if (t >= ((per_xcd + 7u - (q >> 3)) >> 3)) break;
+      } else {
+        if (lane == 0) t = __hip_atomic_fetch_add(e.queue + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      }
+      if (t < ((per_xcd + 7u - (q >> 3)) >> 3)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging slice is this patch's now
+        // The patch reads its arguments from the kernel-argument segment again (scalar loads through a pointer the compiler
+        // cannot see through): hoisted out of this loop, everything the prologue and the finish levels derive from them stays
+        // live across the sweep -- 154 spilled scalar and 21 spilled vector registers against 63 / 0 of the one-patch kernel.
+        const_ptr<char> kp = (const_ptr<char>)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        constexpr size_t off_g = (sizeof(S1Args) + alignof(BinnedArgs) - 1) / alignof(BinnedArgs) * alignof(BinnedArgs);
+        [[maybe_unused]] constexpr size_t off_e = (off_g + sizeof(BinnedArgs) + alignof(EnsAtomsArgs) - 1) / alignof(EnsAtomsArgs) * alignof(EnsAtomsArgs);
+#if WBX_EA_PERSIST_RELOAD
+        S1Args a2;
+        BinnedArgs g2;
+        EnsAtomsArgs e2;
+        load_args(a2, (const_ptr<S1Args>)kp);
+        load_args(g2, (const_ptr<BinnedArgs>)(kp + off_g));
+        load_args(e2, (const_ptr<EnsAtomsArgs>)(kp + off_e));
+        ens_atoms_patch<MP, EXACT, NT, MODE>(a2, g2, e2, ((t << 3) + (q >> 3)) * 8u + (q & 7u), lds_raw);
+#else
+        ens_atoms_patch<MP, EXACT, NT, MODE>(a, g, e, ((t << 3) + (q >> 3)) * 8u + (q & 7u), lds_raw);
+#endif
+        continue;
+      }
+      // dry: what is left anywhere?  (a queue seen non-empty may be dry by the time of the draw: then once more)
+      const uint32_t seen = ld_dev(e.queue + lane);
+      const unsigned long long left = __builtin_amdgcn_ballot_w64(seen < mine_n);
+      if (!left) break;
+      const unsigned long long near = left & (0x0101010101010101ull << (home & 7u));
+      q = (uint32_t)__builtin_ctzll(near ? near : left);
+    }
+  }
+}
 #pragma clang diagnostic pop
 
 // What wbx_ens_binned was called with, besides the plan and the inputs in S1Args.
@@ -674,7 +781,12 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   e.out = c.out;
   e.ng1 = ng1;
   e.ng2 = ng2;
-  if (int rc = ens_atoms_counters(ctx, (size_t)cells * (ng1 + ng2 + 1), &e.counters)) return rc;
+  if (int rc = ens_atoms_counters(ctx, (size_t)cells * (ng1 + ng2 + 1) + 128, &e.counters)) return rc;
+  e.queue = e.counters;  // (the two ticket sets sit at the head of the buffer: the same addresses whatever the geometry)
+  e.queue_next = e.counters + 64;
+  static const int static_env = getenv("WBX_ENS_ATOMS_STATIC") ? atoi(getenv("WBX_ENS_ATOMS_STATIC")) : 0;
+  e.queue_static = static_env;
+  e.counters += 128;
   e.masked = 0;
   e.twin_rows = twin ? 1 : 0;
   e.out_mode = skipna ? (twin_out ? 3 : 2) : (twin_out ? 1 : 0);
@@ -706,6 +818,26 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   const int mode = skipna ? 2 : (e.id_cell_rows ? 1 : 0);
   const dim3 block(nt ? 64 : 64 * WBX_ENS_ATOMS_RAGGED_WPB);
 #define WBX_EA_LAUNCH(NTV, MODEV) hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, NTV, MODEV>), dim3((unsigned)grid), block, 0, ctx->stream, a, g, e)
+#define WBX_EA_LAUNCH_P(MODEV) hipLaunchKernelGGL((ens_atoms_kernel<MP, EXACT, true, MODEV, true>), dim3((unsigned)pgrid), block, 0, ctx->stream, a, g, e)
+#if WBX_EA_PERSIST
+  // (diagnostic build, make ab-eapersist) one-wave blocks: persistent waves, as many as the device holds at once
+  // (WBX_ENS_ATOMS_PERSIST=0: one block per patch; = N > 1: N waves; WBX_ENS_ATOMS_STATIC=1: fixed shares instead of tickets)
+  static const int persist_env = getenv("WBX_ENS_ATOMS_PERSIST") ? atoi(getenv("WBX_ENS_ATOMS_PERSIST")) : 1;
+  const int64_t slots = (int64_t)ctx->num_cus * 4 * WBX_ENS_PIPE_WAVES / 8 * 8;
+  const bool persist = nt && persist_env != 0 && slots >= 8;
+  const int64_t pgrid = persist_env > 1 ? (grid < (int64_t)persist_env ? grid : (int64_t)persist_env / 8 * 8) : (grid < slots ? grid : slots);
+  if (persist) {
+    if (ctx->ens_queue_parity) {
+      uint32_t* const t = e.queue;
+      e.queue = e.queue_next;
+      e.queue_next = t;
+    }
+    ctx->ens_queue_parity ^= 1u;
+    if (mode == 0) WBX_EA_LAUNCH_P(0);
+    else if (mode == 1) WBX_EA_LAUNCH_P(1);
+    else WBX_EA_LAUNCH_P(2);
+  } else
+#endif
   if (nt) {
     if (mode == 0) WBX_EA_LAUNCH(true, 0);
     else if (mode == 1) WBX_EA_LAUNCH(true, 1);
@@ -716,6 +848,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
     else WBX_EA_LAUNCH(false, 2);
   }
 #undef WBX_EA_LAUNCH
+#undef WBX_EA_LAUNCH_P
   WBX_HIP(hipGetLastError());
 #if WBX_EA_PROF
   {

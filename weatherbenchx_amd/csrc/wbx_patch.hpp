@@ -357,15 +357,23 @@ inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out
 // The waves are independent (own slots, own sweeps) but start together and walk the same rows, so a row's WPB x 256 B
 // are requested at about the same time.  (Tried for DRAM page locality with WPB = 4; measured slower than lone waves,
 // see wbx_det_binned.hip -- both patch kernels run WPB = 1.)  grid = patch_grid<WPB>(g).
+// blocks per XCD of patch_grid<WPB>(g): the tickets of a persistent kernel's per-XCD queue (ens_atoms_kernel)
 template <int WPB>
-__device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs) {
+__device__ __forceinline__ uint32_t patch_per_xcd(const BinnedArgs& g) {
+  const uint32_t nxq = ((uint32_t)g.nxt + WPB - 1) / WPB;
+  return ((uint32_t)g.ncell * nxq * (uint32_t)g.nrs + 7u) >> 3;
+}
+
+// `vb`: the block index to decode -- blockIdx.x, or the virtual one a persistent wave drew from a queue
+template <int WPB>
+__device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs, uint32_t vb) {
   // 32-bit arithmetic (the launcher checks nblocks < 2^31): a 64-bit divide is a ~100-instruction sequence on this ISA,
   // and a patch is only a few thousand instructions long
   const uint32_t ncell = (uint32_t)g.ncell, nxt = (uint32_t)g.nxt;
   const uint32_t nxq = (nxt + WPB - 1) / WPB;
   const uint32_t nblocks = ncell * nxq * (uint32_t)g.nrs;
   const uint32_t per_xcd = (nblocks + 7u) >> 3;
-  uint32_t b = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  uint32_t b = (vb & 7u) * per_xcd + (vb >> 3);
   if (b >= nblocks) return false;
   const uint32_t wave = WPB > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
   if (g.order == 1) {
@@ -391,6 +399,11 @@ __device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell,
   xt = (int)x;
   rs = (int)q2;
   return true;
+}
+
+template <int WPB>
+__device__ __forceinline__ bool patch_decode(const BinnedArgs& g, int64_t& cell, int& xt, int& rs) {
+  return patch_decode<WPB>(g, cell, xt, rs, blockIdx.x);
 }
 
 template <int WPB>
