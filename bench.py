@@ -227,7 +227,7 @@ def ens_kernel_name(e, m=51):
     if (os.environ.get('WBX_ENS_PIPE', '1') != '0' and os.environ.get('WBX_ENS_PIPE_SKIPNA', '1') != '0' and e.get('block') == 64
         and not e.get('x_kept') and not (e.get('flags', 0) & 3) and not e.get('x_weighted')):
       return (f'ens_pipe_kernel<{m},true,SKIPNA_SORT> (r5: NaN members -> +inf, sorted in registers, rank form over the first n members '
-              'with per-point n, fp64 sums; next tile through LDS-DMA, 2 waves per SIMD)')
+              'with per-point n, fp64 sums; next tile through LDS-DMA, 3 waves per SIMD)')
     return (f"s1_{'xk' if e.get('x_kept') else 'xr'}_kernel<EnsOpF32<{m},true,SKIPNA_SORT>,1> (NaN members -> +inf, sorted in registers, rank form "
             'over the first n members with per-point n, fp64 sums)')
   if e.get('algo') == 1:
@@ -583,8 +583,9 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
                                 crps=float(np.asarray(pout[f'crps_default.{k0}'].values).mean())) if plog else None),
          'skipna_ensemble': ({'what': 'CRPSEnsemble(skipna_ensemble=True) on one variable through the API (WBX_FLAG_SKIPNA_ENS: per-point member '
                                       'counts; round 4: register-resident rank form over the valid members -- the generic from-memory pair '
-                                      'form it replaces took 10.7 ms = 2 % of the HBM peak; round 5: on the pipelined sweep, 0.455 -> 0.424 ms)',
+                                      'form it replaces took 10.7 ms = 2 % of the HBM peak; round 5: on the pipelined sweep 0.455 -> 0.424 ms; members past the n-th = the shift, compile-time rank coefficients, v_rcp_f64 + Newton for 1/n: 209 -> 151 VGPRs, three waves per SIMD, 0.378 ms)',
                               'launches_per_variable': len(slog) // 2,
+                              'launch': {k: slog[0].get(k) for k in ('block', 'grid', 'flags', 'x_kept', 'x_weighted', 'algo')},
                               'roofline': kernel_roofline(ens_kernel_name(slog[0], m), float(np.sum([e['ms'] for e in slog]) / 2),
                                                           epoints * (m + 1) * 4, None),
                               'crps': float(np.asarray(sout[f'crps_skipna.{k0}'].values).mean())} if slog else None),
