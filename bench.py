@@ -587,7 +587,10 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
                               'launches_per_variable': len(slog) // 2,
                               'launch': {k: slog[0].get(k) for k in ('block', 'grid', 'flags', 'x_kept', 'x_weighted', 'algo')},
                               'roofline': kernel_roofline(ens_kernel_name(slog[0], m), float(np.sum([e['ms'] for e in slog]) / 2),
-                                                          epoints * (m + 1) * 4, None),
+                                                          epoints * (m + 1) * 4,
+                                                          pmc_traffic('ens_pipe_kernel_skipna' if ens_kernel_name(slog[0], m).startswith('ens_pipe')
+                                                                      else ens_kernel_name(slog[0], m),
+                                                                      nlead == 8 and not args.small, f'ensemble@{env.layout}')),
                               'crps': float(np.asarray(sout[f'crps_skipna.{k0}'].values).mean())} if slog else None),
          'check': {'crps_v0_mean': float(np.asarray(eout['crps.v0'].values).mean()),
                    'spread_skill_v0_mean': float(np.asarray(eout['unbiased_spread_skill.v0'].values).mean())}}

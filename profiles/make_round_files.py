@@ -89,6 +89,8 @@ def bench_key(name: str) -> str:
   n = name.replace('wbx::', '')
   if n.startswith('ens_atoms_kernel<51'):
     return 'ens_atoms_kernel'
+  if n.startswith('ens_pipe_kernel<51, true, 97'):  # WBX_ENS_SKIPNA_SORT: skipna_ensemble's per-point member counts
+    return 'ens_pipe_kernel_skipna'
   if n.startswith('ens_pipe_kernel<51'):
     return 'ens_pipe_kernel'
   if n.startswith('s1_xf1_kernel<EnsOpF32<51'):
