@@ -407,7 +407,7 @@ int wbx_ens_map(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int M, int64_t
  * and stores the sums of each run of one group as a RECORD (group, key = (team, sequence number), nlon/2 + 1 values) in a
  * scratch store of the context; a closing kernel on the same stream then adds every group's records in KEY order -- the
  * result is a function of (inputs, launch geometry) only and bit-identical from run to run
- * (tests/test_gpu_round5.py::test_spectra_*_bit_reproducible: 20 runs each).  `group` and `scale` are read by this call's
+ * (tests/test_gpu_round5.py::test_spectra_are_bit_reproducible, ::test_fused_det_spectra_are_bit_reproducible: 20 runs each).  `group` and `scale` are read by this call's
  * kernels in stream order; the number of group changes along `group` is cached per (pointer, nrows) to size the store and
  * the cache entry is dropped by every write this library makes into the table (wbx_memcpy_h2d*, wbx_memset, wbx_memcpy_d2d):
  * a table rewritten by anybody else's kernel must go through one of those calls first (a stale count that is too small does not

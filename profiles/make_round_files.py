@@ -66,8 +66,10 @@ def compare_events(rows):
       if token == 'wbx_det_binned':
         token = 'det_atoms_kernel'
       pair = 'true, 1>' if 'PAIRWISE' in roof['kernel'] else None
+      skipna = 'SKIPNA_SORT' in roof['kernel']  # (template argument 97: another instantiation of the same kernel name)
       match = [r for r in rows if r[0] == run and ('wbx::' + token + '<' in r[1] or 'wbx::' + token + '(' in r[1])
-               and (pair is None or pair in r[1]) and (pair is not None or 'true, 1>' not in r[1])]
+               and (pair is None or pair in r[1]) and (pair is not None or 'true, 1>' not in r[1])
+               and skipna == bool(re.search(r'true, 97[,>]', r[1]))]
       if not match:
         continue
       r = max(match, key=lambda r: float(r[3]))
