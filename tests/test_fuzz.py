@@ -504,3 +504,48 @@ def test_random_ensemble_grids_under_region_bins(backend, seed):
   state, log = EB.run(stats, agg, p, t)
   assert [e['kind'] for e in log] == ['ens_binned'], (layout, m, nlat, nlon, log)
   EB.check_against_oracle(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=valid)
+
+
+@pytest.mark.parametrize('seed', range(16 * FUZZ_SCALE))
+def test_random_ensemble_grids_under_nan_masks_and_skipna(backend, seed):
+  """Round 5's widened one-pass route on random grids: a NaN mask over every dim of the targets (add_nan_mask_to_data,
+  data_loaders/base.py:25-56: another hole pattern per init / lead) under Aggregator(masked=True), or Aggregator(skipna=True) with
+  NaN targets and NaN members (optionally with a (latitude, longitude) mask coordinate on top): ragged and whole-line rows, 2-51
+  members, the three recorded dim orders -- every bin of all five lanes and of their weights, ONE wbx_ens_binned launch."""
+  import test_ens_binned as EB
+  from weatherbenchx_amd import binning, weighting
+  from weatherbenchx_amd import data as wdata
+  rng = np.random.default_rng(47000 + seed)
+  layout = str(rng.choice(sorted(EB.LAYOUTS)))
+  m = int(rng.choice([2, 5, 16, 33, 50, 51]))
+  nlat = int(rng.choice([19, 33, 64, 91]))
+  nlon = int(rng.choice([36, 64, 90, 128, 145]))
+  nlead = int(rng.integers(1, 4))
+  land = rng.random((nlat, nlon)) > rng.uniform(0.2, 0.8)
+  mode = ['nanmask', 'skipna', 'skipna+mask'][seed % 3]
+  if layout == 'ifs' and mode != 'nanmask':
+    layout = 'lon_fastest'  # (the skipna route keeps init_time: the IFS case reduces it)
+  valid = (rng.random((nlat, nlon)) > 0.25) if mode == 'skipna+mask' else None
+  p, t, pv, tv, lat, lon = EB.make_case(layout, m, nlat, nlon, nlead, seed=seed, mask=valid, ninit=int(rng.integers(1, 3)))
+  tv[rng.random(tv.shape) < rng.uniform(0.02, 0.3)] = np.nan
+  pd, td = EB.LAYOUTS[layout]
+  lsm = xr.DataArray(land, dims=('latitude', 'longitude'), coords={'latitude': lat, 'longitude': lon})
+  reduce_dims = ['latitude', 'longitude'] + (['init_time'] if layout == 'ifs' else [])
+  stats = EB.lane_statistics()
+  if mode == 'nanmask':
+    t = wdata.add_nan_mask_to_data({'v': xr.DataArray(tv, dims=td, coords={k: t.coords[k].values for k in td})})['v']
+    agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                                 bin_by=[binning.Regions(EB.REGIONS, land_sea_mask=lsm)], masked=True)
+    state, log = EB.run(stats, agg, p, t)
+    assert [(e['kind'], e['flags'] & 1) for e in log] == [('ens_binned', 1)], (layout, m, nlat, nlon, log)
+    EB._check_lanes(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=~np.isnan(tv), mask_dims=td)  # pylint: disable=protected-access
+    return
+  pv[rng.random(pv.shape) < 0.01] = np.nan
+  p = xr.DataArray(pv, dims=pd, coords={k: p.coords[k].values for k in pd if k != 'number'})
+  t2 = xr.DataArray(tv, dims=td, coords={k: t.coords[k].values for k in td})
+  t = t2.assign_coords(mask=t.coords['mask']) if valid is not None else t2
+  agg = aggregation.Aggregator(reduce_dims=reduce_dims, weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.Regions(EB.REGIONS, land_sea_mask=lsm)], masked=valid is not None, skipna=True)
+  state, log = EB.run(stats, agg, p, t)
+  assert [e['kind'] for e in log] == ['ens_binned'], (layout, m, nlat, nlon, log)
+  EB._check_lanes(state, stats, pv, tv, layout, lat, lon, land, reduce_dims, mask=valid, mask_dims=('latitude', 'longitude'), skipna=True)  # pylint: disable=protected-access

@@ -343,3 +343,74 @@ def test_fused_det_spectra_are_bit_reproducible(ctx, monkeypatch):
       again, _ = run()
       for k in first:
         assert np.array_equal(again[k].view(np.uint64), first[k].view(np.uint64)), (layout, k)
+
+
+# ---- ordered spectrum sums under arbitrary group tables (the records' store, the closing kernel's rounds) ----------------------
+def _spectrum_reference(rows64, group, scale, ngroup):
+  """sum over the rows of a group of scale[row] * S_k(row): S = |rfft / n|^2 x (1 for k = 0, else 2) in float64."""
+  n = rows64.shape[-1]
+  f = np.fft.rfft(rows64, axis=-1) / n
+  s = (f.real ** 2 + f.imag ** 2) * np.where(np.arange(n // 2 + 1) == 0, 1.0, 2.0)
+  out = np.zeros((ngroup, n // 2 + 1))
+  np.add.at(out, group, s * scale[:, None])
+  return out
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_raw_spectrum_with_random_group_tables(ctx, seed, monkeypatch):
+  """wbx_zonal_spectrum / wbx_zonal_spectrum_slabs through the raw C ABI with group tables the labeled-array layer never builds:
+  unsorted groups, a change at every row (one record per row: more than 2048 records of one group, the closing kernel's further
+  rounds), groups nobody belongs to, one group for everything, zero scales; rows of 1440 points in both layouts, the generic
+  fused kernel and the rocFFT route; accumulate = 0 and 1.  Twice each: bit-identical, and the float64 numpy.fft oracle."""
+  rng = np.random.default_rng(52000 + seed)
+  route = ['lon1440', 'lat1440', 'generic', 'rocfft'][seed % 4]
+  if route == 'rocfft':
+    monkeypatch.setenv('WBX_SPECTRUM_PATH', 'rocfft')
+  nlon = {'lon1440': 1440, 'lat1440': 1440, 'generic': int(rng.choice([64, 240, 360, 512])), 'rocfft': int(rng.choice([90, 250, 1000]))}[route]
+  pattern = ['alternate', 'random', 'blocks', 'single'][(seed // 4 + seed) % 4]
+  if route == 'lat1440':
+    nslab, rps = int(rng.integers(2, 7)), int(rng.choice([24, 47, 121, 721]))
+    nrows = nslab * rps
+  else:
+    nrows = int(rng.choice([1, 2, 97, 2000, 5001])) if pattern != 'alternate' else 5001
+    nslab, rps = 1, nrows
+  ngroup = 1 if pattern == 'single' else int(rng.integers(2, 9))
+  if pattern == 'alternate':
+    group = (np.arange(nrows) % 2 * (ngroup - 1)).astype(np.int32)  # ~2500 one-row records in each of two groups, the rest empty
+  elif pattern == 'random':
+    group = rng.integers(0, ngroup, nrows).astype(np.int32)
+  elif pattern == 'blocks':
+    group = np.sort(rng.integers(0, ngroup, nrows)).astype(np.int32)[::-1].copy()
+  else:
+    group = np.zeros(nrows, np.int32)
+  scale = rng.random(nrows) + 0.5
+  scale[rng.random(nrows) < 0.1] = 0.0
+  field = (rng.normal(size=(nrows, nlon)) * 2 + rng.normal() * 50).astype(np.float32)
+  if route == 'lat1440':
+    stored = np.ascontiguousarray(field.reshape(nslab, rps, nlon).transpose(0, 2, 1))  # [slab][lon][row]
+    lon_stride, row_stride = rps, 1
+    offs = (np.arange(nslab) * rps * nlon).astype(np.int64)
+  else:
+    stored, lon_stride, row_stride, offs = field, 1, nlon, np.zeros(1, np.int64)
+  dev, g_dev, s_dev = ctx.upload(stored), ctx.upload(group), ctx.upload(scale)
+  nk = nlon // 2 + 1
+  want = _spectrum_reference(field.astype(np.float64), group, scale, ngroup)
+  seedv = rng.normal(size=(ngroup, nk))
+  results = []
+  for accumulate in (0, 1, 0, 1):
+    out = ctx.upload(seedv.copy())
+    if route == 'lat1440':
+      _hip.check(ctx.lib.wbx_zonal_spectrum_slabs(ctx.handle, C.c_void_p(dev.ptr), lon_stride, row_stride, rps, nslab,
+                                                  offs.ctypes.data_as(C.c_void_p), nlon, C.c_void_p(g_dev.ptr), C.c_void_p(s_dev.ptr),
+                                                  ngroup, accumulate, C.c_void_p(out.ptr)), 'wbx_zonal_spectrum_slabs')
+    else:
+      _hip.check(ctx.lib.wbx_zonal_spectrum(ctx.handle, C.c_void_p(dev.ptr), lon_stride, row_stride, nrows, nlon, C.c_void_p(g_dev.ptr),
+                                            C.c_void_p(s_dev.ptr), ngroup, accumulate, C.c_void_p(out.ptr)), 'wbx_zonal_spectrum')
+    results.append(ctx.download(out.ptr, (ngroup, nk), np.float64))
+  for accumulate, got in zip((0, 1), results[:2]):
+    ref = want + (seedv if accumulate else 0.0)
+    tol = 2e-4 if (route == 'rocfft' or (route == 'generic' and nlon > 256)) else 5e-6
+    np.testing.assert_allclose(got[:, 1:], ref[:, 1:], rtol=tol, atol=tol * np.abs(want).max() + 1e-12, err_msg=f'{route} {pattern} accumulate={accumulate}')
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-5 if tol < 1e-4 else 2e-4, atol=1e-9, err_msg=f'{route} {pattern} k = 0')
+  assert np.array_equal(results[0].view(np.uint64), results[2].view(np.uint64)), (route, pattern)
+  assert np.array_equal(results[1].view(np.uint64), results[3].view(np.uint64)), (route, pattern)
