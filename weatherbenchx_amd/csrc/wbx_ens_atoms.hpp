@@ -139,6 +139,9 @@ struct EnsAtomsArgs {
   unsigned long long* prof;  // diagnostic builds (WBX_EA_PROF): eight time stamps per patch, else NULL
 };
 
+#ifndef WBX_ENS_ATOMS_ROW_BARRIER
+#define WBX_ENS_ATOMS_ROW_BARRIER 0  // rows between two block barriers of the ragged-row flavour (power of two; 0 = none)
+#endif
 #ifndef WBX_EA_PERSIST
 #define WBX_EA_PERSIST 0  // make ab-eapersist: persistent waves on one-wave blocks (see ens_atoms_kernel<.., PERSIST>); measured
 #endif                    // SLOWER than one block per patch (profiles/r05_ens_atoms_persistent_ab.txt) and not in the shipped library
@@ -397,6 +400,13 @@ __device__ __forceinline__ void ens_atoms_patch(const S1Args& a, const BinnedArg
   WBX_EA_STAMP(9);  // first row asked for
   for (int i = 0; i < nrows; ++i) {
     typename Op::Regs r;
+#if WBX_ENS_ATOMS_ROW_BARRIER > 0
+    // (A/B, make ab-eabar*) the waves of a block -- adjacent x tiles of the same rows -- meet every few rows, so that the boundary
+    // lines two tiles share are asked for within the few microseconds a streamed line survives in the XCD's L2
+    if constexpr (WPB > 1) {
+      if ((i & (WBX_ENS_ATOMS_ROW_BARRIER - 1)) == 0) __builtin_amdgcn_s_barrier();
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if WBX_EA_PROF
     if (i == 0) WBX_EA_STAMP(10);  // first row has landed
