@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define WBX_ABI_VERSION 11
+#define WBX_ABI_VERSION 12
 
 typedef enum wbx_status {
   WBX_OK = 0,
@@ -321,6 +321,11 @@ int wbx_cat_exceed_field(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, int n
 #define WBX_BINNED_WT_ROW_ONLY 4
 #define WBX_BINNED_TWIN_MASK 16 /* wbx_ens_binned with WBX_FLAG_MASKED: 12 output lanes instead of 6 -- lanes 0-5 with the mask applied,
                                    lanes 6-11 the same statistics over ALL points (mask ignored) from the same pass over the members */
+#define WBX_BINNED_ACCUMULATE 32 /* (ABI 12) out[i] += result[i] instead of out[i] = result[i]: `out` is an accumulator of a chunk loop
+                                    (the caller's CombinePerKey(CombiningSum()), beam_pipeline.py:509-510) and the launch adds its sums into
+                                    it itself -- one thread per element reads, adds and writes, in the kernel that forms the sums, so
+                                    there is no wbx_acc_add launch (4 us + a dependency gap) behind a 0.3 ms chunk.  wbx_det_binned and
+                                    wbx_ens_binned; an empty reduction (no rows) then leaves `out` as it is */
 #define WBX_BINNED_MASK_ON_W 8 /* the validity mask (WBX_FLAG_MASKED) depends on the Bk / Br / x dims only (a (latitude, longitude)
                                   mask under Regions bins): its byte is folded into the atom-id byte, one load less per point.
                                   wbx_ens_binned without this flag: a per-point mask (strides along any dim), see there */

@@ -414,3 +414,60 @@ def test_raw_spectrum_with_random_group_tables(ctx, seed, monkeypatch):
     np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-5 if tol < 1e-4 else 2e-4, atol=1e-9, err_msg=f'{route} {pattern} k = 0')
   assert np.array_equal(results[0].view(np.uint64), results[2].view(np.uint64)), (route, pattern)
   assert np.array_equal(results[1].view(np.uint64), results[3].view(np.uint64)), (route, pattern)
+
+
+def test_raw_binned_launches_add_into_out(ctx):
+  """WBX_BINNED_ACCUMULATE through the raw C ABI: wbx_ens_binned (plain, twin, skipna) and wbx_det_binned with the flag leave
+  out = seed + result -- bit for bit the sum of the seed and the result of the same launch without the flag -- and an empty
+  reduction leaves `out` untouched."""
+  rng = np.random.default_rng(3)
+  nlead, m, nlat, nlon, nbin = 3, 8, 40, 200, 9
+  tv = rng.normal(size=(nlead, nlat, nlon)).astype(np.float32)
+  pv = (tv[:, None] + rng.normal(size=(nlead, m, nlat, nlon))).astype(np.float32)
+  tv[rng.random(tv.shape) < 0.05] = np.nan
+  mask = rng.random((nlat, nlon)) > 0.2
+  dims = ('lead_time', 'latitude', 'longitude')
+  sizes = {'lead_time': nlead, 'latitude': nlat, 'longitude': nlon}
+  lay_p = planner.InputLayout(strides={'lead_time': m * nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_t = planner.InputLayout(strides={'lead_time': nlat * nlon, 'latitude': nlon, 'longitude': 1}, itemsize=4, base_alignment=256)
+  lay_m = planner.InputLayout(strides={'lead_time': 0, 'latitude': nlon, 'longitude': 1}, itemsize=1, base_alignment=256)
+  boxy = np.zeros((nlat, nlon, nbin), bool)
+  for b in range(nbin):
+    boxy[(b * 5) % nlat:(b * 5) % nlat + 14, (b * 37) % nlon:(b * 37) % nlon + 60, b] = True
+  bits = np.zeros((nlat, nlon), np.uint64)
+  for b in range(nbin):
+    bits |= boxy[..., b].astype(np.uint64) << np.uint64(b)
+  wrow = rng.random(nlat) + 0.5
+  bits_buf, w_buf, m_buf = ctx.upload(bits), ctx.upload(wrow), ctx.upload(mask.astype(np.uint8))
+  pb, tb = ctx.upload(pv), ctx.upload(tv)
+  base = _hip.BINNED_W_ON_X | _hip.BINNED_WT_ROW_ONLY
+  for flags, wf, nl in ((0, base, 6), (_hip.FLAG_MASKED, base | _hip.BINNED_MASK_ON_W | _hip.BINNED_TWIN_MASK, 12),
+                        (_hip.FLAG_SKIPNA, base, 10)):
+    plan = planner.build_s1_plan(dims, sizes, [lay_p, lay_t, None, lay_m if flags & _hip.FLAG_MASKED else None], ('latitude', 'longitude'),
+                                 wdep_dims={'latitude', 'longitude'}, flags=_hip.FLAG_FAIR | flags, allow_vec4=False)
+    dplan = engine._PlanOnDevice(ctx, plan)  # pylint: disable=protected-access
+    seed = rng.normal(size=(nlead, nl, nbin))
+    plain, added = ctx.alloc(seed.nbytes), ctx.upload(seed.copy())
+    for wflags, out in ((wf, plain), (wf | _hip.BINNED_ACCUMULATE, added)):
+      _hip.check(R4._raw_call(ctx, plan, dplan, m, nlat * nlon, pb, tb, m_buf if flags & _hip.FLAG_MASKED else None, w_buf, bits_buf,  # pylint: disable=protected-access
+                              nlead, 1, nlat, wflags, nbin, None, out), 'wbx_ens_binned')
+    res, got = ctx.download(plain.ptr, seed.shape, np.float64), ctx.download(added.ptr, seed.shape, np.float64)
+    assert np.array_equal((seed + res).view(np.uint64), got.view(np.uint64)), (flags, np.argwhere((seed + res) != got)[:4])
+  # the deterministic launch
+  tclean = np.nan_to_num(tv, nan=0.0)
+  t2 = ctx.upload(tclean)
+  p2 = ctx.upload(np.ascontiguousarray(pv[:, 0]))
+  plan = planner.build_s1_plan(dims, sizes, [lay_t, lay_t, None, None], ('latitude', 'longitude'), wdep_dims={'latitude', 'longitude'},
+                               flags=0, allow_vec4=False)
+  dplan = engine._PlanOnDevice(ctx, plan)  # pylint: disable=protected-access
+  wfull = ctx.upload(np.ascontiguousarray(np.broadcast_to(wrow[:, None], (nlat, nlon))))
+  seed = rng.normal(size=(nlead, 3, nbin))
+  plain, added = ctx.alloc(seed.nbytes), ctx.upload(seed.copy())
+  for wflags, out in ((_hip.BINNED_W_ON_X, plain), (_hip.BINNED_W_ON_X | _hip.BINNED_ACCUMULATE, added)):
+    _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), _hip.DET3, _hip.F32, C.c_void_p(p2.ptr), C.c_void_p(t2.ptr), None, None,
+                                      C.c_void_p(wfull.ptr), C.c_void_p(bits_buf.ptr), nlead, 1, nlat, wflags, nbin, None,
+                                      C.c_void_p(out.ptr)), 'wbx_det_binned')
+  res, got = ctx.download(plain.ptr, seed.shape, np.float64), ctx.download(added.ptr, seed.shape, np.float64)
+  want = np.einsum('ayx,y,yxb->ab', pv[:, 0].astype(np.float64) - tclean, wrow, boxy.astype(np.float64))
+  np.testing.assert_allclose(res[:, 0], want, rtol=1e-9, atol=1e-9)
+  assert np.array_equal((seed + res).view(np.uint64), got.view(np.uint64))

@@ -347,3 +347,41 @@ def test_passes_with_spectra_fused_into_the_deterministic_sweep_replay(monkeypat
     a = np.asarray(on['spectra'].sum_weighted_statistics[stat]['z'].values)
     b = np.asarray(off['spectra'].sum_weighted_statistics[stat]['z'].values)
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12 * np.abs(b).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['det', 'ens', 'ens_mask', 'ens_skipna'])
+def test_launches_that_add_into_the_accumulator_themselves(monkeypatch, kind):
+  """WBX_BINNED_ACCUMULATE (ABI 12): from the second chunk on wbx_det_binned / wbx_ens_binned get the result's accumulator slot as
+  `out` and add into it in the kernel that forms the sums -- no scratch round trip and no wbx_acc_add launch.  The accumulators of
+  a loop are bit for bit those of the scratch + wbx_acc_add path (the same fp64 addition, made by another kernel), with and
+  without chunk records, and the recorded chunks hold no wbx_acc_add for those results."""
+  n = 8
+  job = {'det': lambda: _det_job(n), 'ens': lambda: _ens_job(n, False), 'ens_mask': lambda: _ens_job(n, True),
+         'ens_skipna': lambda: _ens_job(n, True, skipna=True)}[kind]
+  results = {}
+  for fused in (True, False):
+    for rep in (True, False):
+      engine.clear_caches()
+      replay.reset_stats()
+      monkeypatch.setattr(engine, 'FUSED_ACC_ADD', fused)
+      monkeypatch.setattr(replay, 'ENABLED', rep)
+      seen = []
+      real = replay.ChunkRecord.__init__
+
+      def spy(self, calls, *a, _real=real, _seen=seen, **k):
+        _seen.append([c[0] for c in calls])
+        _real(self, calls, *a, **k)
+      monkeypatch.setattr(replay.ChunkRecord, '__init__', spy)
+      times, load, metrics, aggs = job()
+      results[fused, rep] = pipeline.evaluate_chunks(times, load, metrics, aggs)
+      monkeypatch.setattr(replay.ChunkRecord, '__init__', real)
+      if rep:
+        assert seen, 'no chunk was recorded'
+        binned = sum(name in ('wbx_det_binned', 'wbx_ens_binned') for name in seen[0])
+        adds = sum(name == 'wbx_acc_add' for name in seen[0])
+        assert binned >= 1
+        results[fused, 'adds'] = (binned, adds)
+  assert results[True, 'adds'][1] <= results[False, 'adds'][1] - results[True, 'adds'][0], results  # one add less per binned launch
+  for key in ((True, False), (False, True), (False, False)):
+    _states_equal(results[True, True], results[key])

@@ -26,6 +26,7 @@ ENS_SORT, ENS_PAIRWISE = 0, 1
 COMM_ID_BYTES = 128
 FLAG_MASKED, FLAG_SKIPNA, FLAG_FAIR, FLAG_SKIPNA_ENS = 1, 2, 4, 8
 BINNED_W_ON_X, BINNED_WT_X_ONLY, BINNED_WT_ROW_ONLY, BINNED_MASK_ON_W, BINNED_TWIN_MASK = 1, 2, 4, 8, 16  # `w_on_x` flags (WBX_BINNED_*)
+BINNED_ACCUMULATE = 32  # out += result: the launch adds into a chunk loop's accumulator itself (ABI 12)
 
 # every symbol include/wbx.h declares (tests check the built library exports all of them)
 EXPORTED_SYMBOLS = (

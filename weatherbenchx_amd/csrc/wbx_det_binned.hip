@@ -574,7 +574,7 @@ static int atoms_setting(const char* name, int dflt) {
 template <typename T, int FUNC, int MM, int K, int PD>
 static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
                          int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared,
-                         bool mask_on_w) {
+                         bool mask_on_w, bool accumulate) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   static const int use_atoms = atoms_setting("WBX_BINNED_ATOMS", 1);
@@ -638,7 +638,7 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   // where the finish kernel spreads them over a block per (cell, statistic).)
   const bool no_overflow = atoms && prepared && ctx->atoms_clean &&
                            static_cast<std::set<const void*>*>(ctx->atoms_clean)->count(prepared) != 0;
-  if (no_overflow) return patch_finish(ctx, g, NA, out);
+  if (no_overflow) return patch_finish(ctx, g, NA, out, accumulate);
   if (wmode == 1)
     hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 1>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   else if (wmode == 2)
@@ -646,42 +646,44 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
   else
     hipLaunchKernelGGL((det_binned_kernel<T, FUNC, MM, K, PD, 0>), dim3((unsigned)grid), dim3(64 * BINNED_WPB), 0, ctx->stream, a, g);
   WBX_HIP(hipGetLastError());
-  return patch_finish(ctx, g, NA, out);
+  return patch_finish(ctx, g, NA, out, accumulate);
 }
 
 template <typename T, int FUNC, int MM>
 static int launch_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits,
-                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w) {
+                         int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w,
+                         bool accumulate) {
   constexpr int NL = FUNC == WBX_DET6 ? 6 : (FUNC == WBX_DET3 ? 3 : 1);
   constexpr int NA = NL + (MM == 1 ? 1 : (MM >= 2 ? NL : 0));
   // Slots: 2 * NA * K accumulator VGPRs + ~70 working registers must stay <= 168 for 3 waves / SIMD.  Measured on the
   // public-benchmark chunk (DET6, 34 bins): K = 6 / 8 / 12 -> 0.92 / 0.85 / 0.95 ms; 2 rows of p, t, c in flight are
   // enough (4: 1.01 ms, the extra registers cost a wave).
   constexpr int K = NA <= 1 ? 32 : (NA <= 2 ? 24 : (NA <= 3 ? 16 : (NA <= 4 ? 12 : (NA <= 6 ? 8 : (NA <= 7 ? 6 : 3)))));
-  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  return launch_binned_k<T, FUNC, MM, K, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
 }
 
 template <typename T, int FUNC>
 static int binned_mm(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const double* wt, const uint64_t* bits, int64_t nA,
-                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w) {
+                     int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared, bool mask_on_w,
+                     bool accumulate) {
   if ((plan->flags & WBX_FLAG_SKIPNA) && (plan->flags & WBX_FLAG_MASKED))
-    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
-  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
-  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
-  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+    return launch_binned<T, FUNC, 3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
+  if (plan->flags & WBX_FLAG_SKIPNA) return launch_binned<T, FUNC, 2>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
+  if (plan->flags & WBX_FLAG_MASKED) return launch_binned<T, FUNC, 1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
+  return launch_binned<T, FUNC, 0>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
 }
 
 template <typename T>
 static int binned_func(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, S1Args& a, const double* wt,
                        const uint64_t* bits, int64_t nA, int64_t nBk, int64_t nBr, int64_t nj, int nbin, double* out, int wmode, const void* prepared,
-                       bool mask_on_w) {
+                       bool mask_on_w, bool accumulate) {
   switch (func) {
     case WBX_DET3:
-      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+      return binned_mm<T, WBX_DET3>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
     case WBX_DET6:
-      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+      return binned_mm<T, WBX_DET6>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
     case WBX_PASS1:
-      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+      return binned_mm<T, WBX_PASS1>(ctx, plan, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
   }
   return fail(WBX_ERR_INVALID, "unknown deterministic family %d", func);
 }
@@ -745,8 +747,9 @@ extern "C" int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, i
   if (nout == 0) return 0;
   WBX_REQUIRE(out != nullptr, "out is NULL");
   WBX_HIP(hipSetDevice(ctx->device));
+  const bool accumulate = (w_on_x & WBX_BINNED_ACCUMULATE) != 0;
   if (nBr * plan->ndepth * plan->nx == 0) {
-    WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
+    if (!accumulate) WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
     return 0;
   }
   WBX_REQUIRE(p != nullptr && wt != nullptr && bits != nullptr, "p/wt/bits is NULL");
@@ -759,11 +762,11 @@ extern "C" int wbx_det_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, i
   a.in[1] = t;
   a.in[2] = c;
   a.in[3] = mask;
-  WBX_REQUIRE((w_on_x & ~15) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
+  WBX_REQUIRE((w_on_x & ~(15 | WBX_BINNED_ACCUMULATE)) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
   const bool mask_on_w = (w_on_x & WBX_BINNED_MASK_ON_W) != 0 && (plan->flags & WBX_FLAG_MASKED);
   const int64_t nj = (w_on_x & WBX_BINNED_W_ON_X) ? plan->nx : 1;
   const int wmode = (w_on_x & WBX_BINNED_WT_X_ONLY) ? 1 : ((w_on_x & WBX_BINNED_WT_ROW_ONLY) ? 2 : 0);
-  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
-  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w);
+  if (dtype == WBX_F32) return binned_func<float>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
+  if (dtype == WBX_F64) return binned_func<double>(ctx, plan, func, a, wt, bits, nA, nBk, nBr, nj, nbin, out, wmode, prepared, mask_on_w, accumulate);
   return fail(WBX_ERR_INVALID, "unknown dtype %d", dtype);
 }

@@ -120,7 +120,7 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
   WBX_REQUIRE(!(plan->flags & WBX_FLAG_SKIPNA_ENS), "wbx_ens_binned does not take skipna_ensemble (per-point member counts)");
   WBX_REQUIRE(nbin >= 1 && nbin <= 64, "wbx_ens_binned handles 1..64 bins (got %d)", nbin);
   WBX_REQUIRE(nA >= 0 && nBk >= 0 && nBr >= 0 && nA * nBk * nBr == plan->nkey, "nA*nBk*nBr must equal plan->nkey");
-  WBX_REQUIRE((w_on_x & ~31) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
+  WBX_REQUIRE((w_on_x & ~63) == 0 && (w_on_x & 6) != 6, "w_on_x: unknown or contradictory WBX_BINNED_* flags (%d)", w_on_x);
   WBX_REQUIRE(wt == nullptr || (w_on_x & (WBX_BINNED_WT_X_ONLY | WBX_BINNED_WT_ROW_ONLY)),
               "wbx_ens_binned takes factored weights only (WBX_BINNED_WT_X_ONLY / WBX_BINNED_WT_ROW_ONLY), or wt = NULL");
   WBX_REQUIRE(!(w_on_x & WBX_BINNED_WT_X_ONLY) || (w_on_x & WBX_BINNED_W_ON_X), "WBX_BINNED_WT_X_ONLY needs WBX_BINNED_W_ON_X");
@@ -131,7 +131,7 @@ extern "C" int wbx_ens_binned(wbx_ctx* ctx, const wbx_s1_plan* plan, int dtype, 
   WBX_REQUIRE(out != nullptr, "out is NULL");
   WBX_HIP(hipSetDevice(ctx->device));
   if (nBr * plan->ndepth * plan->nx == 0) {
-    WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
+    if (!(w_on_x & WBX_BINNED_ACCUMULATE)) WBX_HIP(hipMemsetAsync(out, 0, (size_t)nout * sizeof(double), ctx->stream));
     return 0;
   }
   WBX_REQUIRE(p != nullptr && t != nullptr && bits != nullptr, "p/t/bits is NULL");

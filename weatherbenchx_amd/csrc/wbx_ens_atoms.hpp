@@ -133,6 +133,7 @@ struct EnsAtomsArgs {
   int32_t twin_rows;   // the twin half of the atom tables is in use: masked == 2, or the SKIPNA flavour (NaN targets)
   int32_t out_mode;    // 0: out[cell][6][nbin]; 1 (twin): [12]; 2 (SKIPNA): [10] = five values + their five counts; 3 (SKIPNA +
                        // twin): [20] = the masked ten, then the ten over all points (see wbx.h)
+  int32_t accumulate;  // WBX_BINNED_ACCUMULATE: level 3 adds the cell's sums into `out` (a chunk loop's accumulator) instead of storing them
   int64_t id_cell_rows;  // 0: the id bytes are [bk][br][nj] (bins / a mask on the W dims); R = nBr * D: one id byte per point,
                          // [cell][r][nj] (a mask with strides along A / the depth dims)
   int64_t br_per_split;  // g.rows_per_split / D
@@ -196,7 +197,7 @@ __device__ __forceinline__ void load_args(BinnedArgs& d, const_ptr<BinnedArgs> s
 __device__ __forceinline__ void load_args(EnsAtomsArgs& d, const_ptr<EnsAtomsArgs> s) {
   d.wx = s->wx, d.wrow = s->wrow, d.tab = s->tab, d.part1 = s->part1, d.part2 = s->part2;
   d.counters = s->counters, d.queue = s->queue, d.queue_next = s->queue_next, d.queue_static = s->queue_static, d.out = s->out, d.ng1 = s->ng1, d.ng2 = s->ng2;
-  d.masked = s->masked, d.twin_rows = s->twin_rows, d.out_mode = s->out_mode;
+  d.masked = s->masked, d.twin_rows = s->twin_rows, d.out_mode = s->out_mode, d.accumulate = s->accumulate;
   d.id_cell_rows = s->id_cell_rows, d.br_per_split = s->br_per_split, d.prof = s->prof;
 }
 
@@ -623,11 +624,14 @@ __device__ __forceinline__ void ens_atoms_patch(const S1Args& a, const BinnedArg
   if (!last_of(cnt3, (uint32_t)e.ng2)) return;
   add_records(e.part2 + cell * e.ng2 * NP, e.ng2, sum);
   if (lane < g.nbin) {
+    // (one lane per output element: with `accumulate` it reads, adds and writes the element of the caller's accumulator itself)
+    const bool add = e.accumulate != 0;
+    auto put = [&](int64_t i, double v) { e.out[i] = add ? e.out[i] + v : v; };
     if constexpr (!SKIPNA) {
       const int nout = twin ? NOUT2 : NOUT;
 #pragma unroll
       for (int l = 0; l < NOUT2; ++l)
-        if (l < nout) e.out[(cell * nout + l) * g.nbin + lane] = sum[l];
+        if (l < nout) put((cell * nout + l) * g.nbin + lane, sum[l]);
     } else {
       // five values, then their five counts (the layout of every skipna reduction in this library); sums 0-5 are over the atom
       // rows (targets valid), 6-11 over atom + twin rows
@@ -636,7 +640,7 @@ __device__ __forceinline__ void ens_atoms_patch(const S1Args& a, const BinnedArg
         // no twin output: the member-only statistics of THIS group are the sums over atoms + twins (NaN-target points included)
         const double v[10] = {sum[0], sum[7], sum[8], sum[3], sum[4], sum[5], sum[11], sum[11], sum[5], sum[5]};
 #pragma unroll
-        for (int l = 0; l < 10; ++l) e.out[(cell * 10 + l) * g.nbin + lane] = v[l];
+        for (int l = 0; l < 10; ++l) put((cell * 10 + l) * g.nbin + lane, v[l]);
       } else {
         // twin output: the twins also hold the masked-out points, so the masked spread / variance (valid mask AND valid members,
         // whatever the target) is not among the sums: NaN, and nobody asks for it -- the member-only statistics of such a variable
@@ -644,7 +648,7 @@ __device__ __forceinline__ void ens_atoms_patch(const S1Args& a, const BinnedArg
         const double v[20] = {sum[0], nan, nan, sum[3], sum[4], sum[5], sum[5], sum[5], sum[5], sum[5],
                               nan, sum[7], sum[8], nan, nan, sum[11], sum[11], sum[11], sum[11], sum[11]};
 #pragma unroll
-        for (int l = 0; l < 20; ++l) e.out[(cell * 20 + l) * g.nbin + lane] = v[l];
+        for (int l = 0; l < 20; ++l) put((cell * 20 + l) * g.nbin + lane, v[l]);
       }
     }
   }
@@ -800,6 +804,7 @@ int launch_ens_atoms(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, const Ens
   e.masked = 0;
   e.twin_rows = twin ? 1 : 0;
   e.out_mode = skipna ? (twin_out ? 3 : 2) : (twin_out ? 1 : 0);
+  e.accumulate = (c.w_on_x & WBX_BINNED_ACCUMULATE) ? 1 : 0;
   e.id_cell_rows = 0;
   e.br_per_split = g.rows_per_split / plan->ndepth;
   if (masked) {

@@ -185,9 +185,11 @@ static __global__ void __launch_bounds__(64) binned_atoms_kernel(BinnedArgs g, i
 
 // out[cell][lane][bin] = sum over patches of tmp[cell][patch][lane][bin] + poison[cell][patch][lane].
 // One block per (cell, lane): thread (pg, bin) sums every (256 / nbin)-th patch, LDS folds the pg.
+// accumulate: out += the sums (WBX_BINNED_ACCUMULATE: `out` is a chunk loop's accumulator)
 static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, int nacc, int nbin,
                                                          const double* __restrict__ tmp,
-                                                         const double* __restrict__ poison, double* __restrict__ out) {
+                                                         const double* __restrict__ poison, double* __restrict__ out,
+                                                         int accumulate) {
   __shared__ double red[256];
   const int64_t cell = blockIdx.x / nacc;
   const int l = (int)(blockIdx.x % nacc);
@@ -201,7 +203,8 @@ static __global__ void __launch_bounds__(256) det_binned_finish(int64_t npatch, 
   __syncthreads();
   if (threadIdx.x < nbin) {
     for (int q = 1; q < ng; ++q) s += red[q * nbin + threadIdx.x];
-    out[(cell * nacc + l) * nbin + threadIdx.x] = s;
+    double* const dst = out + (cell * nacc + l) * nbin + threadIdx.x;
+    *dst = accumulate ? *dst + s : s;
   }
 }
 
@@ -341,9 +344,9 @@ inline int patch_setup(wbx_ctx* ctx, BinnedArgs& g, const double* wt, const uint
   return atoms_launch(ctx, g, bits, D, nx, atoms);
 }
 
-inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out) {
+inline int patch_finish(wbx_ctx* ctx, const BinnedArgs& g, int nacc, double* out, bool accumulate = false) {
   hipLaunchKernelGGL(det_binned_finish, dim3((unsigned)(g.ncell * nacc)), dim3(256), 0, ctx->stream,
-                     (int64_t)g.nrs * g.nxt, nacc, (int)g.nbin, g.tmp, g.tmp_poison, out);
+                     (int64_t)g.nrs * g.nxt, nacc, (int)g.nbin, g.tmp, g.tmp_poison, out, accumulate ? 1 : 0);
   WBX_HIP(hipGetLastError());
   return 0;
 }

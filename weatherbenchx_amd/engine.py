@@ -817,9 +817,28 @@ class _HostResult:
     self.view = view
 
 
-def _result_target(ctx, shape, scratch_name):
-  """(pointer the kernel writes its float64 `shape` result to, what to hand to _deliver)."""
+class _AccumulatedInPlace:
+  """What _result_target hands to _deliver when the kernel adds its result into the accumulator slot itself."""
+
+  def __init__(self, ptr):
+    self.ptr = ptr
+
+
+# WBX_FUSED_ACC_ADD=0: every chunk result goes through a scratch buffer + wbx_acc_add (A/B; the round-4 path)
+FUSED_ACC_ADD = os.environ.get('WBX_FUSED_ACC_ADD', '1') != '0'
+
+
+def _result_target(ctx, shape, scratch_name, can_accumulate=False):
+  """(pointer the kernel writes its float64 `shape` result to, what to hand to _deliver[, add?]).  With `can_accumulate` (the
+  launch understands WBX_BINNED_ACCUMULATE) a third value says whether the pointer is the chunk loop's accumulator slot of this
+  result -- it exists from the second chunk on -- and the kernel must ADD into it: no scratch round trip, no wbx_acc_add launch."""
   n = int(np.prod(shape, dtype=np.int64))
+  if can_accumulate:
+    if FUSED_ACC_ADD and _accum is not None and n and S1_EVENT_LOG is None:  # (timed launches are repeated: they must not add)
+      ptr = _accum.slot_pointer(ctx, n)
+      if ptr is not None:
+        return ptr, _AccumulatedInPlace(ptr), True
+    return _result_target(ctx, shape, scratch_name) + (False,)
   if DIRECT_RESULTS and _deferred is not None and _accum is None and n:
     view = ctx.pinned_result(shape)
     return view.ctypes.data, _HostResult(view)
@@ -837,6 +856,8 @@ def _deliver(ctx, ptr, shape) -> np.ndarray:
   if _accum is not None:
     if _deferred is not None:
       _deferred.ctxs[id(ctx)] = ctx
+    if isinstance(ptr, _AccumulatedInPlace):
+      return _accum.accumulate(ctx, None, shape, in_place=ptr.ptr)
     return _accum.accumulate(ctx, ptr, shape)
   if _deferred is not None:
     _deferred.ctxs[id(ctx)] = ctx
@@ -917,14 +938,30 @@ class Accumulation:
     return (turn + (self.chunk_index if ALTERNATE_CHUNKS else 0)) % n
 
   # -- engine side ------------------------------------------------------------------------------------------------
-  def accumulate(self, ctx, src_ptr, shape) -> np.ndarray:
-    n = int(np.prod(shape, dtype=np.int64))
+  def _slot_key(self, ctx):
     key = (self.label, self._ordinal)
     turn = next((i for i, c in enumerate(_stream_ring) if c is ctx), 0)
     if turn:
       key += (turn,)  # this launch stream's own slot for the result: its adds are ordered by its stream alone
+    return key
+
+  def slot_pointer(self, ctx, n: int):
+    """Device address of the slot the NEXT accumulate() on `ctx` will add `n` values into, or None while that slot does not
+    exist (the first chunk creates it) -- for launches that add into the slot themselves (WBX_BINNED_ACCUMULATE)."""
+    slot = self.slots.get(self._slot_key(ctx))
+    if slot is None or slot[2] != n or slot[3] is not ctx:
+      return None
+    return slot[0].dev.ptr + 8 * int(slot[1])
+
+  def accumulate(self, ctx, src_ptr, shape, in_place=None) -> np.ndarray:
+    """Adds the float64 `shape` result at `src_ptr` into its slot (wbx_acc_add).  `in_place` = the slot address a launch was
+    given by slot_pointer(): the kernel has added its result already, only the bookkeeping is left."""
+    n = int(np.prod(shape, dtype=np.int64))
+    key = self._slot_key(ctx)
     self._ordinal += 1
     slot = self.slots.get(key)
+    if in_place is not None and (slot is None or slot[0].dev.ptr + 8 * int(slot[1]) != in_place or slot[2] != n):
+      raise RuntimeError(f'accumulating {key}: a launch added into an address that is not this result\'s slot')
     if slot is None:
       blk = next((b for b in self.blocks if b.ctx is ctx and b.cap - b.used >= n), None)
       if blk is None:
@@ -946,7 +983,7 @@ class Accumulation:
       first = False
       self.multi = True
     blk, off = slot[0], slot[1]
-    if n:
+    if n and in_place is None:
       _acc_add(ctx, blk.dev, off, src_ptr, n, first)
     self.ctxs[id(ctx)] = ctx
     return blk.shadow[off:off + n].reshape(shape)
@@ -1124,7 +1161,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   nA, nBk, nBr = plan.n(plan.a_dims), plan.n(plan.bk_dims), plan.n(plan.br_dims)
   nbin = w_buf.shape[-1]
   shape = (nA, nBk, nl_total, 1, nbin)
-  out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
+  out_ptr, handle, add = _result_target(ctx, shape, 's2out', can_accumulate=True)  # (the finish kernel writes every element once)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   w_flags = _hip.BINNED_W_ON_X if (plan.x_kept and plan.nj > 1) else 0
   wt_buf = w_buf.bufs[0]
@@ -1153,7 +1190,7 @@ def _run_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype_cod
   def call():
     _hip.check(ctx.lib.wbx_det_binned(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
                                       ptr(devs[2]), ptr(devs[3]), C.c_void_p(wt_buf.ptr),
-                                      C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags, nbin,
+                                      C.c_void_p(w_buf.bufs[1].ptr), nA, nBk, nBr, w_flags | (_hip.BINNED_ACCUMULATE if add else 0), nbin,
                                       C.c_void_p(atoms.ptr) if atoms is not None else None,
                                       C.c_void_p(out_ptr)), 'wbx_det_binned')
   timed_launch(ctx, call, kind='det_binned', nbin=nbin, w_flags=w_flags)
@@ -1268,14 +1305,15 @@ def _run_ens_binned(ctx, dplan: _PlanOnDevice, plan: planner.S1Plan, devs, dtype
   # six lanes (five values + the shared count), under skipna ten (five values + their five counts); twice that in twin mode
   per_set = 2 * _hip.ENS_LANES if (plan.flags & _hip.FLAG_SKIPNA) else ENS_BINNED_LANES
   shape = (nA, nBk, per_set * (2 if (w_flags & _hip.BINNED_TWIN_MASK) else 1), 1, nbin)
-  out_ptr, handle = _result_target(ctx, shape, 's2out')  # (the finish kernel writes every element once)
+  out_ptr, handle, add = _result_target(ctx, shape, 's2out', can_accumulate=True)  # (level 3 writes every element once)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
   m, mstride, algo = ens_args
 
   def call():
     _hip.check(ctx.lib.wbx_ens_binned(ctx.handle, C.byref(dplan.struct), dtype_code, int(m), int(mstride), int(algo), ptr(devs[0]),
                                       ptr(devs[1]), ptr(devs[3]), C.c_void_p(w_buf.factored[1].ptr), C.c_void_p(w_buf.bufs[1].ptr),
-                                      nA, nBk, nBr, w_flags, nbin, C.c_void_p(atoms.ptr), C.c_void_p(out_ptr)), 'wbx_ens_binned')
+                                      nA, nBk, nBr, w_flags | (_hip.BINNED_ACCUMULATE if add else 0), nbin, C.c_void_p(atoms.ptr),
+                                      C.c_void_p(out_ptr)), 'wbx_ens_binned')
   timed_launch(ctx, call, kind='ens_binned', nbin=nbin, w_flags=w_flags, flags=int(plan.flags))
   return handle, shape
 
