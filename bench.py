@@ -583,7 +583,7 @@ def ens_leg(env, lead_dim, nlead, nvar, name, describe):
                                 crps=float(np.asarray(pout[f'crps_default.{k0}'].values).mean())) if plog else None),
          'skipna_ensemble': ({'what': 'CRPSEnsemble(skipna_ensemble=True) on one variable through the API (WBX_FLAG_SKIPNA_ENS: per-point member '
                                       'counts; round 4: register-resident rank form over the valid members -- the generic from-memory pair '
-                                      'form it replaces took 10.7 ms = 2 % of the HBM peak; round 5: on the pipelined sweep 0.455 -> 0.424 ms; members past the n-th = the shift, compile-time rank coefficients, v_rcp_f64 + Newton for 1/n: 209 -> 151 VGPRs, three waves per SIMD, 0.378 ms)',
+                                      'form it replaces took 10.7 ms = 2 % of the HBM peak; round 5: on the pipelined sweep 0.455 -> 0.424 ms; members past the n-th = the shift, compile-time rank coefficients, v_rcp_f64 + Newton for 1/n: 209 -> 151 VGPRs, three waves per SIMD, 0.378 ms; missing members = copies of the shift in the sorted order (rank correction k (sum |e| + sum e)), no selects or class tests: 0.336 ms)',
                               'launches_per_variable': len(slog) // 2,
                               'launch': {k: slog[0].get(k) for k in ('block', 'grid', 'flags', 'x_kept', 'x_weighted', 'algo')},
                               'roofline': kernel_roofline(ens_kernel_name(slog[0], m), float(np.sum([e['ms'] for e in slog]) / 2),

@@ -192,16 +192,44 @@ struct EnsOpF32 {
     float poison = 0.f;  // NaN iff any member is NaN/inf (v_min/v_max would silently drop a NaN)
     int nvalid = 0;      // (WBX_ENS_SKIPNA_SORT) members that are not NaN
     bool weird = false;  // ... and whether one of them is infinite
+    float shift32 = 0.f; // ... and what the missing ones are replaced by
     if constexpr (ALGO == WBX_ENS_SKIPNA_SORT) {
+      // (r5, second step) A missing member becomes the SHIFT of the sums below -- the target, e = x - t = 0: it adds nothing to
+      // any sum, so no sum has to select "the first n" of the sorted registers; it only sits in the sorted order, k = M - n of
+      // them at the shift, and lifts the rank of every valid member above the shift by k: stats_skipna takes that out again
+      // (sum (2 idx + 1) e = sum (2 rank + 1) e + 2 k sum max(e, 0), and sum max(e, 0) = (sum |e| + sum e) / 2).  Against
+      // NaN -> +inf and a per-member `m < n` select: 51 compares + 51 selects less; infinite members are found from the sorted
+      // extremes (exact sizes) or by one max3 fold over |x| (bucketed sizes) instead of a class test per member.
+      const bool tfin32 = (r.t - r.t) == 0.f;
+      shift32 = r.t;
+      if (__builtin_amdgcn_ballot_w64(!tfin32)) {  // wave-uniform, rare: a NaN / infinite target -- the smallest valid member instead
+        float lo = INFINITY;
+#pragma unroll
+        for (int m = 0; m < MP; ++m)
+          if (EXACT || m < M) lo = fminf(lo, xm[m]);  // (fminf ignores NaN; no valid member: +inf, and every output is NaN anyway)
+        shift32 = tfin32 ? r.t : lo;
+      }
 #pragma unroll
       for (int m = 0; m < MP; ++m) {
         if (EXACT || m < M) {
           const float x = xm[m];
           const bool missing = x != x;
-          weird = weird || fabsf(x) == INFINITY;
           nvalid += missing ? 0 : 1;
-          xm[m] = missing ? INFINITY : x;
+          xm[m] = missing ? shift32 : x;
         }
+      }
+      if constexpr (!EXACT) {  // (bucketed sizes: the padding behind the M members is +inf, so the sorted extremes say nothing)
+        float big = 0.f;  // max |x| over the members as they are now (no NaN among them unless the shift is one)
+        int m = 0;
+        for (; m + 1 < MP; m += 2) {
+          const float a = m < M ? xm[m] : 0.f, b = m + 1 < M ? xm[m + 1] : 0.f;
+          asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(big) : "v"(big), "v"(a), "v"(b));
+        }
+        if (m < MP) {
+          const float a = m < M ? xm[m] : 0.f;
+          asm("v_max3_f32 %0, %1, |%2|, |%2|" : "=v"(big) : "v"(big), "v"(a));
+        }
+        weird = big == INFINITY;
       }
     }
     if constexpr (ALGO == WBX_ENS_PAIRWISE) {
@@ -266,7 +294,10 @@ struct EnsOpF32 {
 
     bool redo = false;
     if constexpr (ALGO == WBX_ENS_SKIPNA_SORT) {
-      stats_skipna(a, xm, nvalid, td, val);
+      // (exact sizes: every register is a member or a copy of the shift, all finite unless a member is infinite -- and then the
+      //  sorted extremes are: two compares instead of a fold over the members)
+      if constexpr (EXACT) weird = xm[0] == -INFINITY || xm[MP - 1] == INFINITY;
+      stats_skipna(a, xm, nvalid, td, shift32, val);
       r.poison = 0.f;
       return weird;  // per lane: the caller redoes such a point with the generic operator
     }
@@ -309,12 +340,13 @@ struct EnsOpF32 {
     }
   }
 
-  // The rank form over the first n (sorted, valid) members, n per lane; the formulas of EnsOpGeneric::values on e = x - shift.
+  // The rank form over the n valid members of a point, n per lane; the formulas of EnsOpGeneric::values on e = x - shift.
   // sum_{i<j} |x_i - x_j| = sum_i (2 i - (n - 1)) x_(i): the coefficients add up to 0 over i < n, so the shift drops out.
-  // (r5) The members past the n-th (+inf: they were NaN) are replaced by the shift itself -- e = 0, one fp32 select instead of a
-  // 64-bit one -- so every sum runs over all MP registers with compile-time coefficients: sum (2 m + 1 - n) e = sum (2 m + 1) e
-  // - n sum e.  1 / n and 1 / (n - 1) come from v_rcp_f64 + two Newton steps (n is a small integer: no scaling, no fix-up;
-  // correctly rounded for every n <= 64) instead of five full fp64 divisions per point (~35 instructions each).
+  // (r5) The registers hold the n valid members AND k = M - n copies of the shift itself (compute(): what the missing members
+  // were replaced by) in sorted order: e = 0 for the copies, so every sum runs over all registers with compile-time
+  // coefficients; a valid member above the shift sits k places too high, which  sum (2 idx + 1) e  pays back as
+  // 2 k sum max(e, 0) = k (sum |e| + sum e).  1 / n and 1 / (n - 1) come from v_rcp_f64 + two Newton steps (n is a small
+  // integer: no scaling, no fix-up) instead of five full fp64 divisions per point (~35 instructions each).
   __device__ __forceinline__ static double recip_small(double n) {
     double r = __builtin_amdgcn_rcp(n);
     r = fma(fma(-n, r, 1.0), r, r);
@@ -322,25 +354,23 @@ struct EnsOpF32 {
     return r;
   }
   __device__ __forceinline__ static void stats_skipna(const S1Args& a, const float (&xm)[MP], const int n, const double td,
-                                                      double (&val)[NLANE]) {
+                                                      const float shift32, double (&val)[NLANE]) {
     const int M = EXACT ? MP : a.M;
-    const bool tfin = (td - td) == 0.0;
-    const float shift32 = tfin ? (float)td : (n > 0 ? xm[0] : 0.f);  // (td is a widened float: exact)
     const double shift = (double)shift32;
     const double x0t = shift - td;  // 0 for a finite target, else NaN / -+inf
-    const double dM = (double)n;
+    const double dM = (double)n, dK = (double)(M - n);
     double se = 0.0, sq = 0.0, sabs = 0.0, dot1 = 0.0;
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
       if (EXACT || m < M) {
-        const double e = (double)(m < n ? xm[m] : shift32) - shift;
+        const double e = (double)xm[m] - shift;
         se += e;
         sq = fma(e, e, sq);
         sabs += fabs(e);
         dot1 = fma((double)(2 * m + 1), e, dot1);
       }
     }
-    const double dot = fma(-dM, se, dot1);
+    const double dot = fma(-dM, se, fma(-dK, sabs + se, dot1));
     sabs += n > 0 ? fabs(x0t) : 0.0;  // mean |x - t| is NaN / inf with the target
     const double nan = __builtin_nan("");
     const double inv_n = n > 0 ? recip_small(dM) : nan;          // (0 / 0 in the reference's means: NaN)
@@ -584,7 +614,8 @@ struct EnsMasked {
 #endif
 // (the skipna_ensemble flavour -- per-lane member counts, fp64 sums over the valid members -- needed 209 registers = two waves per
 //  SIMD while its sums selected and weighted every member in fp64 by the per-lane count; with stats_skipna's compile-time
-//  coefficients it is 151 registers and runs three: 0.423 -> 0.378 ms on the 1.73 GB variable, 51 -> 57 % of the HBM peak)
+//  coefficients it is 151 registers and runs three: 0.423 -> 0.378 ms on the 1.73 GB variable, 51 -> 57 % of the HBM peak; with the
+//  missing members replaced by the shift itself -- no per-member select, no class tests -- 113 registers, 0.336 ms = 64 %)
 #ifndef WBX_ENS_PIPE_SKIPNA_WAVES
 #define WBX_ENS_PIPE_SKIPNA_WAVES 3
 #endif
