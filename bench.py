@@ -680,7 +680,7 @@ def public_chunk_leg(env):
   def make_chunk(i, ic):
     cs = dict(pcoords, init_time=ic, valid_time=(('init_time', 'lead_time'), ring[i % 4] + pcoords['lead_time'][None, :]))
     return {'z': xr.DataArray(pp_t, dims=pdims, coords=cs)}, {'z': xr.DataArray(pt_t, dims=pdims, coords=cs)}
-  loop_ms, loop_stats, _ = chunk_loop_ms(env, make_chunk, pmetrics, pagg, pcoords['lead_time'], 100 if not args.small else 12)
+  loop_ms, loop_stats, _ = chunk_loop_ms(env, make_chunk, pmetrics, pagg, pcoords['lead_time'], int(os.environ.get('WBX_BENCH_CHUNKS', 100 if not args.small else 12)))
   return {'workload': f'public benchmark chunk: f32[1 init,{pl} lead,{plev} level,{env.nlat},{env.nlon}] p,t + climatology, '
                       f'rmse/mse/bias/acc/activity, GridAreaWeighting, {len(REGIONS)} regions x land/sea = '
                       f'{2 * len(REGIONS)} bins, masked=True, {env.layout}',
@@ -825,7 +825,7 @@ def public_chunk_ens_leg(env, ifs_layout=False, with_mask=True):
     elif with_mask:
       t = t.assign_coords(mask=mask_da)
     return {'v': p}, {'v': t}
-  loop_ms, loop_stats, _ = chunk_loop_ms(env, make_chunk, metrics, agg, coords['lead_time'], 120 if not args.small else 12)
+  loop_ms, loop_stats, _ = chunk_loop_ms(env, make_chunk, metrics, agg, coords['lead_time'], int(os.environ.get('WBX_BENCH_CHUNKS', 120 if not args.small else 12)))
   del ens, tv
   return {'workload': f"public benchmark chunk, probabilistic: f32[1 init,{nl} lead,{m} member,{env.nlat},{env.nlon}] "
                       f"({'init,number,lead' if ifs_layout else 'init,lead,number'} order) vs f32[1,{nl},{env.nlat},{env.nlon}] "
