@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5: spectra records (ordered sums) against the round-4 tree (atomics) on the SAME box, alternating.
-# ab_r4/ = `git archive <round-4 commit>` + its library (git-ignored; made by hand in the build container).
+# ab_r4/ = `git archive <round-4 commit> | tar -x -C ab_r4` + its library as ab_r4/weatherbenchx_amd/libwbx_hip.so (made by hand in the build
+# container for the measurement, not kept in the tree).
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
