@@ -328,3 +328,41 @@ def test_slab_detection_for_the_latitude_fastest_fused_sweep():
   plan3 = planner.build_s1_plan(dims, sizes, [lay, lay, clay, None], ['init_time', 'level', 'latitude', 'longitude'], wdep_dims=['latitude'],
                                 gather=gather, force_x_dim='longitude', allow_vec4=False)
   assert engine._fused_slab_rows(plan3, dict(entry, dev={}), 3) is None
+
+
+def test_accumulator_slot_handed_to_a_launch(monkeypatch):
+  """engine.Accumulation.slot_pointer / accumulate(in_place=): from the second chunk on a launch that understands
+  WBX_BINNED_ACCUMULATE gets the address of its result's slot and adds into it itself; the bookkeeping (ordinal, layout views,
+  `multi`) is what the scratch + wbx_acc_add path does, no add is enqueued, and an address that is not the slot's is refused."""
+  from weatherbenchx_amd import engine
+
+  class Buf:
+    def __init__(self, ptr, nbytes):
+      self.ptr, self.nbytes = ptr, nbytes
+
+  class Ctx:
+    def __init__(self):
+      self.next = 0x7f0000000000
+
+    def alloc(self, nbytes):
+      b = Buf(self.next, nbytes)
+      self.next += (nbytes + 255) // 256 * 256
+      return b
+  adds = []
+  monkeypatch.setattr(engine, '_acc_add', lambda ctx, buf, off, src, n, first: adds.append((buf.ptr + 8 * off, src, n, first)))
+  ctx, acc = Ctx(), engine.Accumulation()
+  acc.set_label('job')
+  assert acc.slot_pointer(ctx, 12) is None                      # first chunk: the slot does not exist yet
+  v0 = acc.accumulate(ctx, 0x1000, (3, 4))
+  v1 = acc.accumulate(ctx, 0x2000, (5,))
+  assert adds == [(acc.blocks[0].dev.ptr, 0x1000, 12, True), (acc.blocks[0].dev.ptr + 96, 0x2000, 5, True)] and not acc.multi
+  acc.set_label('job')                                          # the next chunk under the same label
+  p0 = acc.slot_pointer(ctx, 12)
+  assert p0 == acc.blocks[0].dev.ptr and acc.slot_pointer(ctx, 11) is None and acc.slot_pointer(Ctx(), 12) is None
+  w0 = acc.accumulate(ctx, None, (3, 4), in_place=p0)
+  assert len(adds) == 2 and acc.multi                           # nothing enqueued: the kernel has added already
+  assert w0.shape == (3, 4) and acc.locate(w0) == acc.locate(v0)
+  p1 = acc.slot_pointer(ctx, 5)
+  assert p1 == acc.blocks[0].dev.ptr + 96
+  with pytest.raises(RuntimeError, match='not this result'):
+    acc.accumulate(ctx, None, (5,), in_place=p1 + 8)
