@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 5, first visit: parity of the widened wbx_ens_binned (per-point NaN masks, skipna) + the compact bench line on --small,
 # then same-box A/B of ens_atoms_kernel against the round-4 library (weatherbenchx_amd/libwbx_hip_r4.so) and the new legs.
+# (the A/B half needs weatherbenchx_amd/libwbx_hip_r4.so, a build of the round-4 commit, AND a binding without wbx_chunk_replay:
+#  it ran before chunk records went in -- profiles/r05_ens_binned_ab.txt; today only the second half runs)
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp

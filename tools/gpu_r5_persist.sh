@@ -1,4 +1,7 @@
 #!/bin/bash
+# (the persistent-wave flavour only exists in the diagnostic build: `make -C weatherbenchx_amd/csrc ab-eapersist` first;
+#  WBX_ENS_ATOMS_PERSIST / WBX_ENS_ATOMS_STATIC are read by that build alone -- profiles/r05_ens_atoms_persistent_ab.txt)
+export WBX_LIBRARY_PATH=${WBX_LIBRARY_PATH:-${GRAFT_REPO_ROOT:-$PWD}/weatherbenchx_amd/libwbx_hip_eapersist.so}
 # Round 5: ens_atoms_kernel with persistent waves (per-XCD patch queues) against one block per patch (WBX_ENS_ATOMS_PERSIST=0),
 # same box, alternating; parity first.
 set -u
