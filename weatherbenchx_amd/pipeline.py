@@ -379,33 +379,32 @@ def _consume(chunk_streams, passes, acc):
 
 def _run_chunk(group, passes, acc):
   """One chunk of every pass through the ordinary path: statistics -> fused launches -> adds into the accumulators."""
-  if True:  # pylint: disable=using-constant-test
-    states = []
-    # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
-    # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates
-    # them one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
-    uniques = [list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
-               for (_, metrics, _), (_, predictions, targets) in zip(passes, group)]
-    if len(passes) > 1:
-      _plan_fusion([(u, aggs) for u, (_, _, aggs) in zip(uniques, passes)])
-    for (pass_name, metrics, aggregators), (offsets, predictions, targets), unique in zip(passes, group, uniques):
-      # (the spread lane of an ensemble group decides which kernel variant serves all its lanes: Aggregator.note_statistics)
-      aggregation.Aggregator.note_statistics(dict(unique))
-      for stat_name, stats in unique:
-        for var_name, stat in stats.items():
-          for agg_name, agg in aggregators.items():
-            dims = getattr(stat, 'dims', ())
-            key = _offset_key(offsets, dims, set(agg.reduce_dims))
-            acc.set_label((pass_name, agg_name, stat_name, str(var_name), key))
-            state = agg.aggregate_stat_var(stat)
-            if state is None:
-              continue
-            got = state.sum_weighted_statistics.dims
-            assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
-            for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
-              acc.capture((pass_name, agg_name, kind, stat_name, str(var_name), key), da)
-            states.append(state)
-    engine.clear_det_spectra_requests()
+  states = []
+  # Built-in statistics are lazy (no payload), so all of them can exist before the first launch: every statistic of a
+  # (predictions, targets, climatology) triple then shares ONE fused launch (the reference generates and aggregates
+  # them one at a time to bound the memory of materialised statistics, beam_pipeline.py:186-197)
+  uniques = [list(metrics_base.generate_unique_statistics_for_all_metrics(metrics, predictions, targets))
+             for (_, metrics, _), (_, predictions, targets) in zip(passes, group)]
+  if len(passes) > 1:
+    _plan_fusion([(u, aggs) for u, (_, _, aggs) in zip(uniques, passes)])
+  for (pass_name, metrics, aggregators), (offsets, predictions, targets), unique in zip(passes, group, uniques):
+    # (the spread lane of an ensemble group decides which kernel variant serves all its lanes: Aggregator.note_statistics)
+    aggregation.Aggregator.note_statistics(dict(unique))
+    for stat_name, stats in unique:
+      for var_name, stat in stats.items():
+        for agg_name, agg in aggregators.items():
+          dims = getattr(stat, 'dims', ())
+          key = _offset_key(offsets, dims, set(agg.reduce_dims))
+          acc.set_label((pass_name, agg_name, stat_name, str(var_name), key))
+          state = agg.aggregate_stat_var(stat)
+          if state is None:
+            continue
+          got = state.sum_weighted_statistics.dims
+          assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
+          for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
+            acc.capture((pass_name, agg_name, kind, stat_name, str(var_name), key), da)
+          states.append(state)
+  engine.clear_det_spectra_requests()
   return states
 
 
