@@ -1064,11 +1064,15 @@ def config5_leg(env):
   run(warm)
   env.sync()
   times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
+  from weatherbenchx_amd import replay as _replay
+  _replay.reset_stats()
   t0 = time.perf_counter()
   out = run(times)
   env.sync()
   rank_s = time.perf_counter() - t0
   dt = env.max_over_ranks(rank_s)
+  record_stats = {k: v for k, v in _replay.STATS.items() if k != 'refusals'}
+  record_stats['refusals'] = [str(x)[:160] for x in _replay.STATS['refusals'][:2]]
   # per-pass pace of this rank (outside the timed region, a sixth of the chunks, no collective)
   sub = time_chunks.TimeChunks(init_times[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
   nsub = len(distributed_shard(sub, env))
@@ -1101,6 +1105,7 @@ def config5_leg(env):
           'ms_per_chunk_by_pass_rank0': {k: round(v, 3) for k, v in pass_s.items()},
           'ms_per_chunk_by_pass_note': 'subsets of the evaluations as their own jobs on a sixth of the chunks, outside the timed region',
           'z_bytes_per_point': 12, 'z_traffic_bytes_per_point': 12 if fused else 20, 'fused_det_spectra': bool(fused),
+          'chunk_records': record_stats,
           'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),
