@@ -407,6 +407,26 @@ def unbiased_spread_skill_ratio(mean_var, mean_uemse):
 # the build (WeatherBench-2 lineage): F_k = rfft(f)/n, S_k = |F_k|^2 * (1 if k == 0 else 2).
 
 
+def relative_intensity(p, t, spatial_axes, mask=None, epsilon=1e-6):
+  """RelativeIntensity (metrics/deterministic.py:30-88): |(mean p + eps) / (mean t + eps) - 1| over `spatial_axes`, the means
+  with skipna=False.  With `mask` (True = valid, same shape as p): means over the valid points only -- masked-out values count as
+  0, sums with skipna=False, divided by the count; a slice without a valid point has both means 0 (result 0).  -> (values, mask
+  of the result = count > 0, or None)."""
+  p, t = np.asarray(p, np.float64), np.asarray(t, np.float64)
+  axes = tuple(spatial_axes)
+  with np.errstate(all='ignore'):
+    if mask is None:
+      pm, tm, out_mask = p.mean(axis=axes), t.mean(axis=axes), None
+    else:
+      m = np.asarray(mask, bool)
+      count = m.sum(axis=axes)
+      ps, ts = np.where(m, p, 0.0).sum(axis=axes), np.where(m, t, 0.0).sum(axis=axes)
+      pm = np.where(count > 0, ps / np.where(count > 0, count, 1), 0.0)
+      tm = np.where(count > 0, ts / np.where(count > 0, count, 1), 0.0)
+      out_mask = (count > 0).astype(int)
+    return np.abs((pm + epsilon) / (tm + epsilon) - 1), out_mask
+
+
 def zonal_power_spectrum(field, lon_axis=-1):
   f = f64(field)
   n = f.shape[lon_axis]

@@ -293,3 +293,53 @@ def test_crps_target_spread_is_the_spread_statistic_of_the_targets():
   spread = mean(*O.crps_spread(p, pd_, 'realization', fair=False))
   np.testing.assert_allclose(skill, spread, rtol=1e-12)
   np.testing.assert_allclose(O.crps_ensemble_distance(skill, spread, spread), 0.0, atol=1e-14)
+
+
+# ---- RelativeIntensity: the reference's own known answers (metrics/deterministic_test.py:27-225) through the product -----------------
+def _relative_intensity(predictions, targets, mask=None, dims=('latitude', 'longitude')):
+  from weatherbenchx_amd import aggregation
+  from weatherbenchx_amd import xarray_lite as xr
+  from weatherbenchx_amd.metrics import base as metrics_base
+  from weatherbenchx_amd.metrics import deterministic, wrappers
+  coords = {d: np.arange(n) for d, n in zip(dims, np.shape(predictions))}
+  p = xr.DataArray(np.asarray(predictions, float), dims=dims, coords=coords)
+  t = xr.DataArray(np.asarray(targets, float), dims=dims, coords=coords)
+  if mask is not None:
+    t = t.assign_coords(mask=xr.DataArray(np.asarray(mask), dims=dims, coords=coords))
+  metric = wrappers.WrappedMetric(deterministic.RelativeIntensity(spatial_dims=['latitude', 'longitude']), [])
+  stats = metrics_base.compute_unique_statistics_for_all_metrics({'metric': metric}, {'var': p}, {'var': t})
+  return aggregation.Aggregator(reduce_dims=[]).aggregate_statistics(stats).metric_values({'metric': metric})['metric.var']
+
+
+def test_relative_intensity_known_answers(backend):
+  """deterministic_test.py: test_regular (mean 25 against 10: |2.5 - 1|), test_with_mask_and_nans_masked ((80 / 3) / 10, mask 1),
+  test_with_mask_and_time_dimension ([1.5, 0], mask [1, 0]), test_all_nans_masked (0, mask 0), test_nans_not_covered_by_mask
+  (NaN, mask 1) -- and the oracle's restatement on the same inputs."""
+  nan = np.nan
+  r = _relative_intensity([[10., 20.], [30., 40.]], [[10., 10.], [10., 10.]])
+  np.testing.assert_allclose(np.asarray(r.values), 1.5, atol=1e-5)
+  r = _relative_intensity([[10., nan], [30., 40.]], [[10., nan], [10., 10.]], mask=[[1, 0], [1, 1]])
+  np.testing.assert_allclose(np.asarray(r.values), abs((80 / 3) / 10 - 1), atol=1e-5)
+  assert 'mask' in r.coords and int(np.asarray(r.coords['mask'].values)) == 1
+  p3 = [[[10., 20.], [30., 40.]], [[100., 200.], [300., 400.]]]
+  t3 = np.full((2, 2, 2), 10.0)
+  m3 = [[[1, 1], [1, 1]], [[0, 0], [0, 0]]]
+  r = _relative_intensity(p3, t3, mask=m3, dims=('time', 'latitude', 'longitude'))
+  np.testing.assert_allclose(np.asarray(r.values), [1.5, 0.0], atol=1e-5)
+  np.testing.assert_array_equal(np.asarray(r.coords['mask'].values), [1, 0])
+  r = _relative_intensity(np.full((2, 2), nan), np.full((2, 2), nan), mask=np.zeros((2, 2), int))
+  np.testing.assert_allclose(np.asarray(r.values), 0)
+  assert int(np.asarray(r.coords['mask'].values)) == 0
+  r = _relative_intensity([[10., nan], [30., 40.]], [[10., 10.], [10., 10.]], mask=np.ones((2, 2), int))
+  assert np.isnan(np.asarray(r.values)) and int(np.asarray(r.coords['mask'].values)) == 1
+  # the oracle's restatement (oracle/wbx_oracle.py::relative_intensity) on random fields with and without a mask
+  rng = np.random.default_rng(5)
+  p, t = rng.random((3, 9, 14)) * 5, rng.random((3, 9, 14)) * 5
+  m = rng.random((3, 9, 14)) > 0.3
+  m[1] = False
+  for mask in (None, m):
+    want, wmask = O.relative_intensity(p, t, (1, 2), mask=mask)
+    r = _relative_intensity(p, t, mask=None if mask is None else mask.astype(int), dims=('time', 'latitude', 'longitude'))
+    np.testing.assert_allclose(np.asarray(r.values), want, rtol=1e-9, atol=1e-12)
+    if mask is not None:
+      np.testing.assert_array_equal(np.asarray(r.coords['mask'].values), wmask)

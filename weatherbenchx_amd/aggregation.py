@@ -352,7 +352,9 @@ class Aggregator:
       frame_coords, lane, scale = stat._coords, 0, 1.0  # pylint: disable=protected-access
 
     final_dims = tuple(d for d in stat.dims if d in out_dims) + tuple(bin_dims)
-    coords = {k: v for k, v in frame_coords.items() if set(v[0]) <= set(final_dims) and k != 'mask'}
+    # (a `mask` coordinate whose dims all survive stays on the result, like every other coordinate: xr.dot keeps it,
+    #  aggregation.py:335 -- RelativeIntensity's per-slice mask reaches the metric values that way, deterministic_test.py:87-89)
+    coords = {k: v for k, v in frame_coords.items() if set(v[0]) <= set(final_dims)}
     if w_da is not None:
       for k, v in w_da._coords.items():  # pylint: disable=protected-access
         if set(v[0]) <= set(final_dims):

@@ -24,6 +24,58 @@ def _clim_key(ref):
   return (id(ref.source.data), ref.source.__dict__.get('_mutations', 0))
 
 
+class RelativeIntensity(base.PerVariableStatistic):
+  """|mean(predictions) / mean(targets) - 1| over `spatial_dims` (deterministic.py:30-88): the ratio of the spatial means, for
+  non-negative fields such as precipitation.  With a `mask` coordinate on the targets the means run over mask == 1 alone (a NaN
+  inside that region still makes the result NaN: the reference sums with skipna=False), a slice without any valid point gives 0,
+  and the result carries `mask` = 1 where at least one point was valid.
+
+  The spatial sums are reductions of the PASS1 family on the device (one launch per field: the unweighted sum and the count of
+  the valid points per remaining index); the ratio is formed on the few numbers that are left."""
+
+  def __init__(self, spatial_dims: Sequence[str] = ('latitude', 'longitude')):
+    self._spatial_dims = spatial_dims
+
+  def _compute_per_variable(self, predictions, targets):
+    from weatherbenchx_amd import engine  # pylint: disable=g-import-not-at-top
+    spatial = [str(d) for d in self._spatial_dims]
+    epsilon = 1e-6  # (in numerator and denominator: no division by zero, and 0 / 0 counts as a perfect ratio)
+    predictions, targets = xr.as_dataarray(predictions), xr.as_dataarray(targets)
+    for name, da in (('predictions', predictions), ('targets', targets)):
+      missing = [d for d in spatial if d not in da.dims]
+      if missing:
+        raise ValueError(f'{name} have no dimension(s) {missing} to take the spatial mean over (dims {da.dims})')
+    mask = None
+    if 'mask' in targets.coords:
+      mc = targets.coords['mask']
+      valid = mc.data == 1 if xr._is_torch(mc.data) else np.asarray(mc.values) == 1  # pylint: disable=protected-access
+      mask = xr.DataArray(valid, dims=mc.dims)
+
+    def spatial_sum(da):
+      plain = xr.DataArray(da.data, dims=da.dims)
+      if not xr._is_float(plain.data):  # pylint: disable=protected-access
+        plain = plain.astype(np.float64)
+      with engine.synchronous_results():  # (the ratio below needs the numbers now, whatever loop this runs in)
+        vals, counts, out_dims = engine.reduce_statistics('det', [plain], da.dims, da.sizes, spatial, None, (), func=_hip.PASS1, mask=mask)
+      coords = {d: da.coords[d] for d in out_dims if d in da.coords}
+      return (xr.DataArray(np.array(vals[0], dtype=np.float64), dims=out_dims, coords=coords),
+              xr.DataArray(np.array(np.broadcast_to(counts[0], np.shape(vals[0])), dtype=np.float64), dims=out_dims, coords=coords))
+    psum, count = spatial_sum(predictions)
+    tsum, _ = spatial_sum(targets)
+    if mask is None:
+      pmean, tmean = psum / count, tsum / count
+    else:
+      some = count.values > 0
+      with np.errstate(all='ignore'):
+        pmean = xr.DataArray(np.where(some, psum.values / np.where(some, count.values, 1.0), 0.0), dims=psum.dims, coords=dict(psum.coords))
+        tmean = xr.DataArray(np.where(some, tsum.values / np.where(some, count.values, 1.0), 0.0), dims=tsum.dims, coords=dict(tsum.coords))
+    with np.errstate(all='ignore'):
+      result = abs((pmean + epsilon) / (tmean + epsilon) - 1)
+    if mask is not None:
+      result = result.assign_coords(mask=xr.DataArray((count.values > 0).astype(int), dims=count.dims))
+    return result
+
+
 class Error(base.PerVariableStatistic):
   """predictions - targets (deterministic.py:91-100)."""
 
