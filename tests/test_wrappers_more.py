@@ -1,0 +1,122 @@
+"""The small input transforms (weatherbenchX/metrics/wrappers.py:50-89, 214-267, 587-645, 745-808, 1072-1134): the reference's own
+known answers (wrappers_test.py:27-130, 227-245) on this package's labeled arrays, and wrapped metrics through the Aggregator against
+the float64 oracle."""
+import numpy as np
+import pytest
+
+import mock_data
+from oracle import wbx_oracle as O
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import wrappers
+
+
+def _target():
+  return mock_data.mock_target_data(random=True, seed=0, time_start='2020-01-01', time_stop='2020-01-09')
+
+
+def test_continuous_to_binary_constant_and_iterable_thresholds():
+  x = _target()['geopotential']
+  ctb = wrappers.ContinuousToBinary(which='both', threshold_value=0.5, threshold_dim='threshold', unique_name_suffix='test')
+  y = ctb.transform_fn(x)
+  np.testing.assert_array_equal(np.asarray(y.coords['threshold'].values), [0.5])
+  np.testing.assert_array_equal(np.asarray(y.sel(threshold=0.5, drop=True).values), np.asarray(x.values) > 0.5)
+  assert ctb.unique_name_suffix == 'threshold=test'
+  ts = [0.2, 0.7]
+  ctb = wrappers.ContinuousToBinary(which='both', threshold_value=ts, threshold_dim='threshold')
+  y = ctb.transform_fn(x)
+  np.testing.assert_array_equal(np.asarray(y.coords['threshold'].values), ts)
+  for t in ts:
+    np.testing.assert_array_equal(np.asarray(y.sel(threshold=t, drop=True).values), np.asarray(x.values) > t)
+  assert ctb.unique_name_suffix == 'threshold=0.2,0.7' and y.dtype == np.float32
+  # NaN stays NaN
+  xn = x.copy()
+  vals = np.array(xn.values)
+  vals[0, 0, 0, 0] = np.nan
+  yn = ctb.transform_fn(xr.DataArray(vals, dims=x.dims, coords={d: x.coords[d] for d in x.dims}, name='geopotential'))
+  assert np.isnan(np.asarray(yn.values)[0, 0, 0, 0]).all() and np.isfinite(np.asarray(yn.values)).sum() == yn.values.size - 2
+
+
+def test_continuous_to_binary_labeled_thresholds():
+  ds = _target()
+  q = [0.25, 0.75]
+  for labeled in ('dataarray', 'dataset'):
+    per_var = {}
+    for var in ('geopotential', '2m_temperature'):
+      v = ds[var]
+      tq = np.quantile(np.asarray(v.values), q, axis=v.dims.index('time'))
+      rest = tuple(d for d in v.dims if d != 'time')
+      per_var[var] = xr.DataArray(tq, dims=('threshold',) + rest, coords={'threshold': np.array(q), **{d: v.coords[d] for d in rest}}, name=var)
+    thr = per_var['geopotential'] if labeled == 'dataarray' else xr.Dataset(per_var)
+    with pytest.raises(ValueError, match='unique_name_suffix must be provided'):
+      wrappers.ContinuousToBinary(which='both', threshold_value=thr, threshold_dim='threshold')
+    ctb = wrappers.ContinuousToBinary(which='both', threshold_value=thr, threshold_dim='threshold', unique_name_suffix='test')
+    for var in (('geopotential',) if labeled == 'dataarray' else ('geopotential', '2m_temperature')):
+      x = ds[var]
+      y = ctb.transform_fn(x)
+      np.testing.assert_array_equal(np.asarray(y.coords['threshold'].values), q)
+      for k, t in enumerate(q):
+        want = np.asarray(x.values) > np.expand_dims(np.asarray(per_var[var].values)[k], x.dims.index('time'))
+        np.testing.assert_array_equal(np.asarray(y.sel(threshold=t).transpose(*x.dims).values), want)
+
+
+def test_inline_relu_rename_select():
+  x = _target()['geopotential'] - 0.5
+  y = wrappers.Inline('both', lambda da: -da, 'negate').transform_fn(x)
+  np.testing.assert_array_equal(np.asarray(y.values), -np.asarray(x.values))
+  vals = np.array(x.values)
+  vals[1, 2, 3, 0] = np.nan
+  xn = xr.DataArray(vals, dims=x.dims, coords={d: x.coords[d] for d in x.dims})
+  relu = wrappers.ReLU('both')
+  got = np.asarray(relu.transform_fn(xn).values)
+  want = np.where(np.isnan(vals), np.nan, np.maximum(vals, 0))
+  np.testing.assert_array_equal(got, want)
+  assert relu.unique_name_suffix == 'relu'
+  r = wrappers.Rename('both', {'level': 'pressure'})
+  assert r.transform_fn(x).dims == tuple('pressure' if d == 'level' else d for d in x.dims) and r.unique_name_suffix == "rename_{'level': 'pressure'}"
+  sel = wrappers.Select('both', sel={'level': 500}, isel={'time': slice(0, 3)})
+  got = sel.transform_fn(x)
+  assert 'level' not in got.dims and got.sizes['time'] == 3
+  np.testing.assert_array_equal(np.asarray(got.values), np.asarray(x.values)[:3, :, :, list(np.asarray(x.coords['level'].values)).index(500)])
+  assert sel.unique_name_suffix == ("select_self._isel={'time': slice(0, 3, None)}_self._isel_kwargs={}_self._sel={'level': 500}_self._sel_kwargs={}")
+  with pytest.raises(ValueError, match='Invalid value for `which`'):
+    wrappers.ReLU('nobody')
+
+
+def test_wrapped_metrics_through_the_aggregator(backend):
+  """MSE of exceedance indicators (the Brier-type score of two deterministic fields) under GridAreaWeighting, RMSE of one level
+  picked with Select, and SubselectVariables: against the float64 oracle."""
+  rng = np.random.default_rng(2)
+  nt, nlat, nlon, nlev = 4, 13, 24, 3
+  lat, lon = np.linspace(-90, 90, nlat), np.linspace(0, 360, nlon, endpoint=False)
+  dims = ('time', 'level', 'latitude', 'longitude')
+  cs = {'time': np.datetime64('2020-01-01', 'ns') + np.arange(nt) * np.timedelta64(24, 'h'), 'level': np.array([500, 700, 850]), 'latitude': lat, 'longitude': lon}
+  pv, tv = rng.random((nt, nlev, nlat, nlon)), rng.random((nt, nlev, nlat, nlon))
+  pv[0, 1, 2, 3] = np.nan
+  p = {'z': xr.DataArray(pv, dims=dims, coords=cs, name='z'), 'q': xr.DataArray(pv * 2, dims=dims, coords=cs, name='q')}
+  t = {'z': xr.DataArray(tv, dims=dims, coords=cs, name='z'), 'q': xr.DataArray(tv * 2, dims=dims, coords=cs, name='q')}
+  ts = [0.3, 0.6]
+  metrics = {
+      'brier': wrappers.WrappedMetric(deterministic.MSE(), [wrappers.ContinuousToBinary('both', ts, 'threshold')]),
+      'rmse500': wrappers.WrappedMetric(deterministic.RMSE(), [wrappers.Select('both', sel={'level': 500})]),
+      'mse_z': wrappers.SubselectVariables(deterministic.MSE(), ['z']),
+  }
+  agg = aggregation.Aggregator(reduce_dims=['time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], skipna=True)
+  out = agg.aggregate_statistics(metrics_base.compute_unique_statistics_for_all_metrics(metrics, p, t)).metric_values(metrics)
+  assert set(out) == {'brier.z', 'brier.q', 'rmse500.z', 'rmse500.q', 'mse_z.z'}
+  w = (O.grid_area_weights(lat), ('latitude',))
+
+  def mean(stat, sdims):
+    sws, sw, od = O.aggregate(stat, sdims, ['time', 'latitude', 'longitude'], weights=[w], skipna=True)
+    return sws / sw, od
+  for k, th in enumerate(ts):
+    bp = np.where(np.isnan(pv), np.nan, (pv > th).astype(float))
+    want, od = mean((bp - (tv > th)) ** 2, dims)
+    np.testing.assert_allclose(np.asarray(out['brier.z'].sel(threshold=th).transpose(*od).values), want, rtol=1e-6)
+  want, od = mean((pv[:, 0] - tv[:, 0]) ** 2, ('time', 'latitude', 'longitude'))
+  np.testing.assert_allclose(np.asarray(out['rmse500.z'].values), np.sqrt(want), rtol=1e-6)
+  want, od = mean((pv - tv) ** 2, dims)
+  np.testing.assert_allclose(np.asarray(out['mse_z.z'].transpose(*od).values), want, rtol=1e-6)

@@ -1,12 +1,16 @@
 """Input transforms needed on the hot path (counterpart of weatherbenchX/metrics/wrappers.py:95-148,
 967-1069): InputTransform, EnsembleMean, WrappedStatistic, RenamedStatistic, WrappedMetric -- what
 `mean_rmse` of the public benchmark uses (public_benchmark/run_benchmark_evaluation.py:346-353).
-The thresholding / tiling transforms are out of scope.
+Also the small input transforms that are plain labeled-array operations -- Inline, ReLU, Rename, Select, ContinuousToBinary
+(wrappers.py:50-89, 214-267, 587-645, 745-808) -- and SubselectVariables (wrappers.py:1072-1120): they run on the arrays as they
+are (host or HBM) and hand the statistics ordinary inputs.  The binning / CDF / tiling / quantile transforms are out of scope.
 """
 from __future__ import annotations
 
 import abc
-from typing import Hashable, Mapping
+from typing import Any, Callable, Hashable, Iterable, Mapping, Sequence
+
+import numpy as np
 
 from weatherbenchx_amd import lazy
 from weatherbenchx_amd import xarray_lite as xr
@@ -118,3 +122,151 @@ class WrappedMetric(base.Metric):
 
   def values_from_mean_statistics(self, statistic_values):
     return self.metric.values_from_mean_statistics(statistic_values)
+
+
+# ---- small input transforms: plain labeled-array operations ---------------------------------------------------------------------------
+def binarize_thresholds(x: xr.DataArray, thresholds, threshold_dim: str) -> xr.DataArray:
+  """x > threshold for every threshold along a new (or the thresholds' own) `threshold_dim`; NaN stays NaN, so the result is
+  float32 (wrappers.py:50-89).  `thresholds`: values, a DataArray with `threshold_dim`, or a Dataset with one such array per
+  variable name."""
+  x = xr.as_dataarray(x)
+  if isinstance(thresholds, xr.Dataset):
+    assert threshold_dim in thresholds.dims, f'threshold_dim ({threshold_dim}) not found in thresholds ({thresholds.dims})'
+    assert x.name in thresholds.data_vars, f'Input DataArray name ({x.name}) not found in thresholds ({list(thresholds.data_vars)})'
+    threshold = thresholds[x.name]
+  elif isinstance(thresholds, xr.DataArray):
+    assert threshold_dim in thresholds.dims, f'threshold_dim ({threshold_dim}) not found in thresholds ({thresholds.dims})'
+    threshold = thresholds
+  else:
+    values = np.asarray(list(thresholds))
+    threshold = xr.DataArray(values, dims=[threshold_dim], coords={threshold_dim: values})
+  out = (x > threshold).where(~x.isnull()).astype(np.float32)
+  return out.rename(x.name) if x.name is not None else out
+
+
+class ContinuousToBinary(InputTransform):
+  """A continuous input as exceedance indicators along `threshold_dim` (wrappers.py:214-267)."""
+
+  def __init__(self, which: str, threshold_value, threshold_dim: str, unique_name_suffix: str | None = None):
+    super().__init__(which)
+    labeled = isinstance(threshold_value, (xr.DataArray, xr.Dataset))
+    self._threshold_value = threshold_value if (labeled or isinstance(threshold_value, Iterable)) else [threshold_value]
+    self._threshold_dim = threshold_dim
+    if labeled and unique_name_suffix is None:
+      raise ValueError('unique_name_suffix must be provided if threshold_value is an xarray.DataArray or xarray.Dataset.')
+    self._unique_name_suffix = unique_name_suffix
+
+  @property
+  def unique_name_suffix(self) -> str:
+    suffix = self._unique_name_suffix
+    if suffix is None:
+      suffix = ','.join(str(t) for t in self._threshold_value)
+    return f'{self._threshold_dim}={suffix}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    return binarize_thresholds(da, self._threshold_value, self._threshold_dim)
+
+
+class Inline(InputTransform):
+  """Any function of a DataArray, under a name of the caller's choosing (wrappers.py:587-622)."""
+
+  def __init__(self, which: str, transform_fn: Callable[[xr.DataArray], xr.DataArray], unique_name_suffix: str):
+    super().__init__(which)
+    self._transform_fn = transform_fn
+    self._unique_name_suffix = unique_name_suffix
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return f'{self._unique_name_suffix}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    return self._transform_fn(da)
+
+
+class ReLU(InputTransform):
+  """max(x, 0) with NaN kept (wrappers.py:625-645)."""
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return 'relu'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    return da.where(da > 0, 0).where(~da.isnull())
+
+
+class Rename(InputTransform):
+  """Renames the variable, coordinates and dimensions (wrappers.py:745-768)."""
+
+  def __init__(self, which: str, renames: Mapping[Hashable, Hashable]):
+    super().__init__(which)
+    self._renames = renames
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return f'rename_{self._renames}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    return xr.as_dataarray(da).rename(self._renames)
+
+
+class Select(InputTransform):
+  """`.sel` and / or `.isel` on the inputs (wrappers.py:771-808)."""
+
+  def __init__(self, which: str, sel: Mapping[Hashable, Any] | None = None, isel: Mapping[Hashable, Any] | None = None,
+               sel_kwargs: Mapping[Hashable, Any] | None = None, isel_kwargs: Mapping[Hashable, Any] | None = None):
+    super().__init__(which)
+    self._isel = isel
+    self._sel = sel
+    self._isel_kwargs = isel_kwargs or {}
+    self._sel_kwargs = sel_kwargs or {}
+
+  @property
+  def unique_name_suffix(self) -> str:
+    # (the reference's f-string with `=` specifiers, spelled out)
+    return (f'select_self._isel={self._isel!r}_self._isel_kwargs={self._isel_kwargs!r}_self._sel={self._sel!r}'
+            f'_self._sel_kwargs={self._sel_kwargs!r}')
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    if self._sel is not None:
+      da = da.sel(self._sel, **self._sel_kwargs)
+    if self._isel is not None:
+      da = da.isel(self._isel, **self._isel_kwargs)
+    return da
+
+
+class SubselectVariablesForStatistic(base.Statistic):
+  """A statistic for some of the variables only (wrappers.py:1072-1099)."""
+
+  def __init__(self, statistic: base.Statistic, variables: Sequence[str]):
+    self.statistic = statistic
+    self.variables = variables
+
+  @property
+  def unique_name(self) -> str:
+    return f'{self.statistic.unique_name}_{"_".join(self.variables)}'
+
+  def compute(self, predictions, targets):
+    return self.statistic.compute({k: v for k, v in predictions.items() if k in self.variables},
+                                  {k: v for k, v in targets.items() if k in self.variables})
+
+
+class SubselectVariables(base.Metric):
+  """A metric for some of the variables only (wrappers.py:1102-1127)."""
+
+  def __init__(self, metric: base.Metric, variables: Sequence[str]):
+    self.metric = metric
+    self.variables = variables
+
+  @property
+  def statistics(self) -> Mapping[Hashable, base.Statistic]:
+    return {name: SubselectVariablesForStatistic(stat, self.variables) for name, stat in self.metric.statistics.items()}
+
+  def values_from_mean_statistics(self, statistic_values):
+    return self.metric.values_from_mean_statistics(statistic_values)
+
+
+# (deprecated in the reference: PerVariableStatistic / PerVariableMetric intersect the variables themselves, wrappers.py:1130-1134)
+IntersectPredictionAndTargetVariablesForStatistic = lambda statistic: statistic  # pylint: disable=invalid-name
+IntersectPredictionAndTargetVariables = lambda metric: metric  # pylint: disable=invalid-name
