@@ -120,3 +120,62 @@ def test_wrapped_metrics_through_the_aggregator(backend):
   np.testing.assert_allclose(np.asarray(out['rmse500.z'].values), np.sqrt(want), rtol=1e-6)
   want, od = mean((pv - tv) ** 2, dims)
   np.testing.assert_allclose(np.asarray(out['mse_z.z'].transpose(*od).values), want, rtol=1e-6)
+
+
+@pytest.mark.parametrize('skipna', [True, False])
+@pytest.mark.parametrize('quantiles', [0.5, [0.1, 0.5, 0.9]])
+def test_ensemble_quantiles(skipna, quantiles):
+  """wrappers_test.py:151-190: quantiles over `realization` with NaNs in one latitude row, against numpy's (nan)quantile."""
+  ds = mock_data.mock_target_data(random=True, seed=1, ensemble_size=3, time_start='2020-01-01', time_stop='2020-01-04')
+  x = ds['geopotential'].isel(latitude=slice(0, 2), longitude=slice(0, 2), level=0)
+  vals = np.array(x.values)
+  vals[:, 0] = np.nan
+  x = xr.DataArray(vals, dims=x.dims, coords={d: x.coords[d] for d in x.dims}, name='geopotential')
+  eq = wrappers.EnsembleQuantiles('both', quantiles, quantile_dim='my_quantile', ensemble_dim='realization', skipna=skipna)
+  y = eq.transform_fn(x)
+  qs = quantiles if isinstance(quantiles, list) else [quantiles]
+  assert y.dims == ('my_quantile',) + tuple(d for d in x.dims if d != 'realization')
+  np.testing.assert_array_equal(np.asarray(y.coords['my_quantile'].values), qs)
+  import warnings
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore', RuntimeWarning)
+    want = (np.nanquantile if skipna else np.quantile)(vals, qs, axis=x.dims.index('realization'))
+  np.testing.assert_array_equal(np.asarray(y.values), want)
+  with pytest.raises(ValueError, match='already has a `quantile` dimension'):
+    eq.transform_fn(xr.DataArray(np.zeros((2, 3)), dims=('quantile', 'realization')))
+  plain = xr.DataArray(np.zeros(3), dims=('time',))
+  assert wrappers.EnsembleQuantiles('both', 0.5, ensemble_dim='realization', skip_if_ensemble_dim_missing=True).transform_fn(plain) is plain
+
+
+def test_weibull_and_shift_along_new_dim():
+  ds = mock_data.mock_target_data(random=True, seed=2, ensemble_size=3, time_start='2020-01-01', time_stop='2020-01-04')
+  x = ds['geopotential']
+  for skipna in (True, False):
+    binary = wrappers.ContinuousToBinary('both', 0.5, 'threshold').transform_fn(x)
+    y = wrappers.WeibullEnsembleToProbabilistic('predictions', ensemble_dim='realization', skipna=skipna).transform_fn(binary)
+    want = (np.asarray(x.values) > 0.5).sum(axis=x.dims.index('realization')) / 4
+    np.testing.assert_allclose(np.asarray(y.sel(threshold=0.5, drop=True).transpose(*[d for d in x.dims if d != 'realization']).values), want)
+  with pytest.raises(AssertionError, match='Only predictions'):
+    wrappers.WeibullEnsembleToProbabilistic('both')
+  t = mock_data.mock_target_data(random=True, seed=3, time_start='2020-01-01', time_stop='2020-01-06')
+  x = t['geopotential']
+  y = wrappers.ShiftAlongNewDim('both', 0.5, 'threshold', 'shift_0.5').transform_fn(x)
+  assert y.sizes['threshold'] == 1 and np.asarray(y.coords['threshold'].values).tolist() == [0.5]
+  np.testing.assert_array_equal(np.asarray(y.sel(threshold=0.5, drop=True).transpose(*x.dims).values), np.asarray(x.values) + 0.5)
+  y = wrappers.ShiftAlongNewDim('both', [0.2, 0.7], 'threshold', 'shift_two').transform_fn(x)
+  for th in (0.2, 0.7):
+    np.testing.assert_array_equal(np.asarray(y.sel(threshold=th, drop=True).transpose(*x.dims).values), np.asarray(x.values) + th)
+  # per-variable fields from a Dataset that already carries the shift dim (here: time quantiles)
+  per_var = {}
+  for var in ('geopotential', '2m_temperature'):
+    v = t[var]
+    tq = np.quantile(np.asarray(v.values), [0.25, 0.75], axis=v.dims.index('time'))
+    rest = tuple(d for d in v.dims if d != 'time')
+    per_var[var] = xr.DataArray(tq, dims=('quantile',) + rest, coords={'quantile': np.array([0.25, 0.75]), **{d: v.coords[d] for d in rest}}, name=var)
+  shift = wrappers.ShiftAlongNewDim('both', xr.Dataset(per_var), 'quantile', 'shift_q')
+  y = shift.transform_fn(x)
+  for k, qv in enumerate((0.25, 0.75)):
+    want = np.asarray(x.values) + np.expand_dims(np.asarray(per_var['geopotential'].values)[k], x.dims.index('time'))
+    np.testing.assert_allclose(np.asarray(y.sel(quantile=qv, drop=True).transpose(*x.dims).values), want)
+  with pytest.raises(RuntimeError, match='Expected to find'):
+    wrappers.ShiftAlongNewDim('both', xr.Dataset(per_var), 'threshold', 'x').transform_fn(x)

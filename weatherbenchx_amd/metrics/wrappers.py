@@ -1,9 +1,9 @@
 """Input transforms needed on the hot path (counterpart of weatherbenchX/metrics/wrappers.py:95-148,
 967-1069): InputTransform, EnsembleMean, WrappedStatistic, RenamedStatistic, WrappedMetric -- what
 `mean_rmse` of the public benchmark uses (public_benchmark/run_benchmark_evaluation.py:346-353).
-Also the small input transforms that are plain labeled-array operations -- Inline, ReLU, Rename, Select, ContinuousToBinary
-(wrappers.py:50-89, 214-267, 587-645, 745-808) -- and SubselectVariables (wrappers.py:1072-1120): they run on the arrays as they
-are (host or HBM) and hand the statistics ordinary inputs.  The binning / CDF / tiling / quantile transforms are out of scope.
+Also the small input transforms that are plain labeled-array operations -- Inline, ReLU, Rename, Select, ContinuousToBinary,
+EnsembleQuantiles, ShiftAlongNewDim, WeibullEnsembleToProbabilistic (wrappers.py:50-89, 151-267, 550-742, 745-808) -- and SubselectVariables (wrappers.py:1072-1120): they run on the arrays as they
+are (host or HBM) and hand the statistics ordinary inputs.  The binning / CDF / tiling / stacking transforms are out of scope.
 """
 from __future__ import annotations
 
@@ -165,6 +165,94 @@ class ContinuousToBinary(InputTransform):
 
   def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
     return binarize_thresholds(da, self._threshold_value, self._threshold_dim)
+
+
+class EnsembleQuantiles(InputTransform):
+  """Quantiles over the ensemble dim along a new leading `quantile_dim` (wrappers.py:151-211; numpy's linear interpolation, as
+  xarray's default).  `skipna` takes the quantiles of the members that are there (a point without any stays NaN)."""
+
+  def __init__(self, which: str, quantiles, quantile_dim: str = 'quantile', ensemble_dim: str = 'number', skipna: bool = False,
+               skip_if_ensemble_dim_missing: bool = False):
+    super().__init__(which)
+    self._quantiles = quantiles if isinstance(quantiles, Iterable) else [quantiles]
+    self._quantile_dim = quantile_dim
+    self._ensemble_dim = ensemble_dim
+    self._skipna = skipna
+    self._skip_if_ensemble_dim_missing = skip_if_ensemble_dim_missing
+
+  @property
+  def unique_name_suffix(self) -> str:
+    quantiles_str = ','.join(str(q) for q in self._quantiles)
+    return (f'ensemble_quantiles_self._ensemble_dim={self._ensemble_dim!r}_self._quantile_dim={self._quantile_dim!r}_'
+            f'self._skipna={self._skipna!r}_{quantiles_str}')
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    if self._ensemble_dim not in da.dims and self._skip_if_ensemble_dim_missing:
+      return da
+    if 'quantile' in da.dims:
+      raise ValueError('Input DataArray already has a `quantile` dimension. Please rename it before applying the EnsembleQuantiles '
+                       'wrapper.')
+    if self._ensemble_dim not in da.dims:
+      raise ValueError(f'Dimension {self._ensemble_dim!r} not found in {da.dims}')
+    q = np.asarray(list(self._quantiles), dtype=np.float64)
+    axis = da.dims.index(self._ensemble_dim)
+    values = np.asarray(da.values)
+    with np.errstate(all='ignore'):
+      import warnings  # pylint: disable=g-import-not-at-top
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)  # (all-NaN slices)
+        out = (np.nanquantile if self._skipna else np.quantile)(values, q, axis=axis)
+    rest = tuple(d for d in da.dims if d != self._ensemble_dim)
+    coords = {k: v for k, v in da.coords.items() if self._ensemble_dim not in v.dims}
+    coords[self._quantile_dim] = q
+    return xr.DataArray(out, dims=(self._quantile_dim,) + rest, coords=coords, name=da.name, attrs=da.attrs)
+
+
+class WeibullEnsembleToProbabilistic(InputTransform):
+  """Binarised members -> probability by Weibull's plotting position, sum / (M + 1) (wrappers.py:550-584; Makkonen 2006)."""
+
+  def __init__(self, which, ensemble_dim='number', skipna=False):
+    assert which == 'predictions', 'Only predictions can be converted to probabilities'
+    super().__init__(which)
+    self._ensemble_dim = ensemble_dim
+    self._skipna = skipna
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return 'ensemble_to_probabilistic_by_weibull_plotting_position'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    members = da.sizes[self._ensemble_dim]
+    return da.sum(self._ensemble_dim, skipna=self._skipna) / (members + 1)
+
+
+class ShiftAlongNewDim(InputTransform):
+  """x + shift for every shift along a new dim: constants, or per-variable fields from a Dataset that already carries `shift_dim`
+  (wrappers.py:648-742)."""
+
+  def __init__(self, which: str, shift_value, shift_dim: str, unique_name_suffix: str):
+    super().__init__(which)
+    self._shift_value = shift_value if isinstance(shift_value, (Iterable, xr.Dataset)) else [shift_value]
+    self._shift_dim = shift_dim
+    self._unique_name_suffix = unique_name_suffix
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return self._unique_name_suffix
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    if isinstance(self._shift_value, xr.Dataset):
+      shifts = self._shift_value[da.name]
+      if self._shift_dim not in shifts.dims:
+        raise RuntimeError(f'Expected to find self._shift_dim={self._shift_dim!r} in shifts.dims={shifts.dims!r} but did not. This is '
+                           'probably an error.')
+    else:
+      values = np.asarray(list(self._shift_value))
+      shifts = xr.DataArray(values, dims=[self._shift_dim], coords={self._shift_dim: values})
+    return da + shifts
 
 
 class Inline(InputTransform):
