@@ -179,3 +179,20 @@ def test_weibull_and_shift_along_new_dim():
     np.testing.assert_allclose(np.asarray(y.sel(quantile=qv, drop=True).transpose(*x.dims).values), want)
   with pytest.raises(RuntimeError, match='Expected to find'):
     wrappers.ShiftAlongNewDim('both', xr.Dataset(per_var), 'threshold', 'x').transform_fn(x)
+
+
+def test_ensemble_quantiles_of_a_tensor_payload_stay_a_tensor():
+  """A payload that is a torch tensor (in HBM on a GPU box) goes through torch's quantile kernels and stays a tensor."""
+  torch = pytest.importorskip('torch')
+  rng = np.random.default_rng(4)
+  v = rng.random((4, 3, 5)).astype(np.float32)
+  v[0, :, 0] = np.nan
+  x = xr.DataArray(torch.from_numpy(v.copy()), dims=('time', 'realization', 'latitude'))
+  import warnings
+  for skipna in (True, False):
+    y = wrappers.EnsembleQuantiles('both', [0.1, 0.5], ensemble_dim='realization', skipna=skipna).transform_fn(x)
+    assert xr._is_torch(y.data) and y.dims == ('quantile', 'time', 'latitude')  # pylint: disable=protected-access
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore', RuntimeWarning)
+      want = (np.nanquantile if skipna else np.quantile)(v, [0.1, 0.5], axis=1)
+    np.testing.assert_allclose(np.asarray(y.values), want, rtol=1e-6, equal_nan=True)

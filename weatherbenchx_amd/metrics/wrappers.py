@@ -197,12 +197,18 @@ class EnsembleQuantiles(InputTransform):
       raise ValueError(f'Dimension {self._ensemble_dim!r} not found in {da.dims}')
     q = np.asarray(list(self._quantiles), dtype=np.float64)
     axis = da.dims.index(self._ensemble_dim)
-    values = np.asarray(da.values)
-    with np.errstate(all='ignore'):
-      import warnings  # pylint: disable=g-import-not-at-top
-      with warnings.catch_warnings():
-        warnings.simplefilter('ignore', RuntimeWarning)  # (all-NaN slices)
-        out = (np.nanquantile if self._skipna else np.quantile)(values, q, axis=axis)
+    if xr._is_torch(da.data):  # pylint: disable=protected-access
+      import torch  # pylint: disable=g-import-not-at-top  (a payload in HBM stays there: torch's own quantile kernels)
+      data = da.data if da.data.is_floating_point() else da.data.double()
+      qt = torch.as_tensor(q, dtype=data.dtype, device=data.device)
+      out = (torch.nanquantile if self._skipna else torch.quantile)(data, qt, dim=axis)
+    else:
+      values = np.asarray(da.values)
+      with np.errstate(all='ignore'):
+        import warnings  # pylint: disable=g-import-not-at-top
+        with warnings.catch_warnings():
+          warnings.simplefilter('ignore', RuntimeWarning)  # (all-NaN slices)
+          out = (np.nanquantile if self._skipna else np.quantile)(values, q, axis=axis)
     rest = tuple(d for d in da.dims if d != self._ensemble_dim)
     coords = {k: v for k, v in da.coords.items() if self._ensemble_dim not in v.dims}
     coords[self._quantile_dim] = q
