@@ -196,3 +196,118 @@ def test_ensemble_quantiles_of_a_tensor_payload_stay_a_tensor():
       warnings.simplefilter('ignore', RuntimeWarning)
       want = (np.nanquantile if skipna else np.quantile)(v, [0.1, 0.5], axis=1)
     np.testing.assert_allclose(np.asarray(y.values), want, rtol=1e-6, equal_nan=True)
+
+
+def _labeled_like(x, edges, dim):
+  e = np.asarray(edges, float)
+  return xr.DataArray(e, dims=[dim], coords={dim: e}) * xr.ones_like(x)
+
+
+def test_continuous_to_bins_and_cdf():
+  """wrappers_test.py:310-376: three right-inclusive bins from [-inf, 0.2, 0.7, inf], as values, as a field and as a Dataset of
+  fields; non-monotonic edges refused; NaN propagated."""
+  ds = mock_data.mock_target_data(random=True, seed=5, time_start='2020-01-01', time_stop='2020-01-05')
+  x = ds['geopotential']
+  edges = [-np.inf, 0.2, 0.7, np.inf]
+  fields = {v: _labeled_like(ds[v], edges, 'bin_values') for v in ('geopotential', '2m_temperature')}
+  for bin_values in (edges, fields['geopotential'], xr.Dataset({k: v.rename(k) for k, v in fields.items()})):
+    ctb = wrappers.ContinuousToBins('both', bin_values, 'bin_values', unique_name_suffix='test')
+    y = ctb.transform_fn(x)
+    np.testing.assert_array_equal(np.asarray(y.coords['bin_values_left'].values), [-np.inf, 0.2, 0.7])
+    np.testing.assert_array_equal(np.asarray(y.coords['bin_values_right'].values), [0.2, 0.7, np.inf])
+    v = np.asarray(x.values)
+    for k, want in enumerate((v <= 0.2, (v > 0.2) & (v <= 0.7), v > 0.7)):
+      np.testing.assert_array_equal(np.asarray(y.isel(bin_values=k, drop=True).transpose(*x.dims).values), want)
+  assert np.asarray(wrappers.ContinuousToBins('both', edges, 'b').transform_fn(x).coords['b'].values).tolist() == \
+      ['-inf < p <= 0.20', '0.20 < p <= 0.70', '0.70 < p <= inf']
+  with pytest.raises(ValueError, match='monotonically increasing'):
+    wrappers.ContinuousToBins('both', [0.7, 0.2], 'bin_values').transform_fn(x)
+  with pytest.raises(ValueError, match='unique_name_suffix must be provided'):
+    wrappers.ContinuousToBins('both', fields['geopotential'], 'bin_values')
+  nan_x = xr.DataArray(np.full(x.shape, np.nan), dims=x.dims, coords={d: x.coords[d] for d in x.dims}, name='geopotential')
+  assert np.isnan(np.asarray(wrappers.ContinuousToBins('both', [0.2, 0.7], 'bin_values').transform_fn(nan_x).values)).all()
+  for right in (True, False):
+    cdf = wrappers.ContinuousToCDF('both', [0.25, 0.5], 'threshold', right_inclusive=right)
+    y = cdf.transform_fn(x)
+    v = np.asarray(x.values)
+    for k, t in enumerate((0.25, 0.5)):
+      np.testing.assert_array_equal(np.asarray(y.isel(threshold=k, drop=True).transpose(*x.dims).values), (v <= t) if right else (v < t))
+    assert cdf.unique_name_suffix == f'ContinuousToCDF_threshold_0.25,0.5_right_inclusive_{right}'
+  with pytest.raises(ValueError, match='must be an Iterable'):
+    wrappers.compute_cdf(0.5, x, 'threshold', True)
+
+
+def test_select_bin_thresholds_by_time_from_chunk():
+  """wrappers_test.py:398-470: day-of-year thresholds picked by (init_time + lead_time), by valid_time, by a station chunk's `time`
+  coordinate; plus valid_time- and (init_time, lead_time)-indexed thresholds and the pass-through cases."""
+  doys = np.arange(1, 366)
+  thr = xr.DataArray(np.arange(1, 366), dims=['dayofyear'], coords={'dayofyear': doys})
+  inits = np.array(['2023-01-01', '2023-01-02'], dtype='datetime64[ns]')
+  leads = np.array([24, 48], dtype='timedelta64[h]').astype('timedelta64[ns]')
+  chunk = xr.DataArray(np.random.rand(2, 2), dims=['init_time', 'lead_time'], coords={'init_time': inits, 'lead_time': leads})
+  got = wrappers.select_bin_thresholds_by_time_from_chunk(thr, chunk)
+  assert got.dims == ('init_time', 'lead_time')
+  np.testing.assert_array_equal(np.asarray(got.values), [[2, 3], [3, 4]])
+  np.testing.assert_array_equal(np.asarray(got.coords['dayofyear'].values), [[2, 3], [3, 4]])
+  np.testing.assert_array_equal(np.asarray(got.coords['init_time'].values), inits)
+  valid = np.array(['2023-01-02', '2023-01-03'], dtype='datetime64[ns]')
+  got = wrappers.select_bin_thresholds_by_time_from_chunk(thr, xr.DataArray(np.random.rand(2), dims=['valid_time'], coords={'valid_time': valid}))
+  assert got.dims == ('valid_time',) and np.asarray(got.values).tolist() == [2, 3]
+  station = xr.DataArray(np.random.rand(2), dims=['index'], coords={'time': (('index',), valid)})
+  got = wrappers.select_bin_thresholds_by_time_from_chunk(thr, station)
+  assert got.dims == ('index',) and np.asarray(got.values).tolist() == [2, 3]
+  np.testing.assert_array_equal(np.asarray(got.coords['time'].values), valid)
+  # thresholds by valid_time with a spatial dim, picked for an (init, lead) chunk
+  vt = np.datetime64('2023-01-01', 'ns') + np.arange(6) * np.timedelta64(24, 'h')
+  by_valid = xr.DataArray(np.arange(12.).reshape(6, 2), dims=['valid_time', 'latitude'], coords={'valid_time': vt, 'latitude': np.array([0., 10.])})
+  got = wrappers.select_bin_thresholds_by_time_from_chunk(by_valid, chunk)
+  assert got.dims == ('init_time', 'lead_time', 'latitude')
+  np.testing.assert_array_equal(np.asarray(got.values)[..., 0], [[2, 4], [4, 6]])
+  by_il = xr.DataArray(np.arange(12.).reshape(3, 4), dims=['init_time', 'lead_time'],
+                       coords={'init_time': np.datetime64('2023-01-01', 'ns') + np.arange(3) * np.timedelta64(24, 'h'),
+                               'lead_time': (np.arange(4) * 24).astype('timedelta64[h]').astype('timedelta64[ns]')})
+  got = wrappers.select_bin_thresholds_by_time_from_chunk(by_il, chunk)
+  np.testing.assert_array_equal(np.asarray(got.values), [[1, 2], [5, 6]])
+  plain = xr.DataArray(np.arange(3.), dims=['threshold'], coords={'threshold': np.arange(3.)})
+  assert wrappers.select_bin_thresholds_by_time_from_chunk(plain, chunk) is plain
+  assert wrappers.select_bin_thresholds_by_time_from_chunk(thr, xr.DataArray(np.zeros(3), dims=['latitude'])) is thr
+  with pytest.raises(KeyError, match='not all values found'):
+    wrappers.select_bin_thresholds_by_time_from_chunk(by_valid.isel(valid_time=slice(0, 2)), chunk)
+  # ... and a CDF against day-of-year thresholds that follow the chunk
+  field = xr.DataArray(np.array([[1.5, 3.5], [2.5, 4.5]]), dims=['init_time', 'lead_time'], coords={'init_time': inits, 'lead_time': leads}, name='v')
+  thr2 = xr.DataArray(np.stack([np.arange(1, 366) - 0.25, np.arange(1, 366) + 0.25]).astype(float), dims=['threshold', 'dayofyear'],
+                      coords={'threshold': np.array([0, 1]), 'dayofyear': doys})
+  cdf = wrappers.ContinuousToCDF('both', thr2, 'threshold', unique_name_suffix='doy').transform_fn(field)
+  # thresholds at (init, lead): doy -+ 0.25 = [[1.75|2.25, 2.75|3.25], [2.75|3.25, 3.75|4.25]]
+  np.testing.assert_array_equal(np.asarray(cdf.sel(threshold=0, drop=True).transpose('init_time', 'lead_time').values), [[1, 0], [1, 0]])
+  np.testing.assert_array_equal(np.asarray(cdf.sel(threshold=1, drop=True).transpose('init_time', 'lead_time').values), [[1, 0], [1, 0]])
+
+
+def test_stack_to_new_dimension_and_tiles():
+  x = mock_data.mock_target_data(random=True, seed=6, time_start='2020-01-01', time_stop='2020-01-03')['geopotential']
+  st = wrappers.StackToNewDimension('both', ['latitude', 'longitude'], 'latitude')
+  y = st.transform_fn(x)
+  n = x.sizes['latitude'] * x.sizes['longitude']
+  assert y.dims == ('time', 'level', 'latitude') and y.sizes['latitude'] == n
+  np.testing.assert_array_equal(np.asarray(y.coords['latitude'].values), np.arange(n))
+  np.testing.assert_array_equal(np.asarray(y.values), np.asarray(x.transpose('time', 'level', 'latitude', 'longitude').values).reshape(x.sizes['time'], x.sizes['level'], n))
+  assert st.unique_name_suffix == "stack_['latitude', 'longitude']_to_latitude"
+  v = np.asarray(x.values)
+  nlat, nlon = x.sizes['latitude'], x.sizes['longitude']
+  ilat, ilon = x.dims.index('latitude'), x.dims.index('longitude')
+  for wrap in (False, True):
+    t = wrappers.Tile('both', window_size=3, wrap_longitude=wrap).transform_fn(x)
+    assert t.dims == ('window',) + x.dims and t.sizes['window'] == 9
+    assert t.sizes['latitude'] == nlat - 2 and t.sizes['longitude'] == (nlon if wrap else nlon - 2)
+    np.testing.assert_array_equal(np.asarray(t.coords['latitude'].values), np.asarray(x.coords['latitude'].values)[1:-1])
+    got = np.asarray(t.values)
+    for w, (di, dj) in enumerate((i - 1, j - 1) for i in range(3) for j in range(3)):
+      rolled = np.roll(np.roll(v, di, axis=ilat), dj, axis=ilon)
+      sl = [slice(None)] * v.ndim
+      sl[ilat] = slice(1, nlat - 1)
+      if not wrap:
+        sl[ilon] = slice(1, nlon - 1)
+      np.testing.assert_array_equal(got[w], rolled[tuple(sl)])
+  t5 = wrappers.construct_tiles(x, window_size=4)
+  assert t5.sizes['window'] == 16 and t5.sizes['latitude'] == nlat - 3 and t5.sizes['longitude'] == nlon - 3
+  assert wrappers.Tile('both', 3, 'w', True).unique_name_suffix == 'tiled_window_size_3_wrap_True_dim_w'

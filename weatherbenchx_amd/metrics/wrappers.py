@@ -3,7 +3,8 @@
 `mean_rmse` of the public benchmark uses (public_benchmark/run_benchmark_evaluation.py:346-353).
 Also the small input transforms that are plain labeled-array operations -- Inline, ReLU, Rename, Select, ContinuousToBinary,
 EnsembleQuantiles, ShiftAlongNewDim, WeibullEnsembleToProbabilistic (wrappers.py:50-89, 151-267, 550-742, 745-808) -- and SubselectVariables (wrappers.py:1072-1120): they run on the arrays as they
-are (host or HBM) and hand the statistics ordinary inputs.  The binning / CDF / tiling / stacking transforms are out of scope.
+are (host or HBM) and hand the statistics ordinary inputs; likewise the CDF / bin indicators with thresholds that follow a
+chunk's time labels (wrappers.py:270-547), StackToNewDimension and Tile (wrappers.py:811-964).
 """
 from __future__ import annotations
 
@@ -364,3 +365,227 @@ class SubselectVariables(base.Metric):
 # (deprecated in the reference: PerVariableStatistic / PerVariableMetric intersect the variables themselves, wrappers.py:1130-1134)
 IntersectPredictionAndTargetVariablesForStatistic = lambda statistic: statistic  # pylint: disable=invalid-name
 IntersectPredictionAndTargetVariables = lambda metric: metric  # pylint: disable=invalid-name
+
+
+# ---- CDF / bin indicators, stacking, tiles --------------------------------------------------------------------------------------------
+def _take_along(da: xr.DataArray, dim: str, labels: np.ndarray, label_dims, label_coords) -> xr.DataArray:
+  """da.sel({dim: labels}) for an indexer of any rank: `dim` is replaced by `label_dims`; the labels stay as a coordinate `dim`."""
+  da = xr.as_dataarray(da)
+  have = np.asarray(da.coords[dim].values)
+  labels = np.asarray(labels)
+  if have.dtype.kind in 'mM' or labels.dtype.kind in 'mM':
+    have, want = have.astype('datetime64[ns]' if have.dtype.kind == 'M' else 'timedelta64[ns]').astype(np.int64), \
+        labels.astype('datetime64[ns]' if labels.dtype.kind == 'M' else 'timedelta64[ns]').astype(np.int64)
+  else:
+    want = labels
+  order = np.argsort(have, kind='stable')
+  pos = np.searchsorted(have[order], want.reshape(-1))
+  pos = np.clip(pos, 0, len(have) - 1)
+  idx = order[pos]
+  if not np.array_equal(have[idx], want.reshape(-1)):
+    missing = want.reshape(-1)[have[idx] != want.reshape(-1)][:3]
+    raise KeyError(f'not all values found in index {dim!r}: {missing}')
+  axis = da.dims.index(dim)
+  data = da.data
+  if xr._is_torch(data):  # pylint: disable=protected-access
+    import torch  # pylint: disable=g-import-not-at-top
+    taken = torch.index_select(data, axis, torch.as_tensor(idx, device=data.device))
+  else:
+    taken = np.take(np.asarray(data), idx, axis=axis)
+  shape = tuple(da.shape[:axis]) + tuple(labels.shape) + tuple(da.shape[axis + 1:])
+  taken = taken.reshape(shape)
+  dims = tuple(da.dims[:axis]) + tuple(label_dims) + tuple(da.dims[axis + 1:])
+  coords = {k: v for k, v in da.coords.items() if dim not in v.dims}
+  coords.update(label_coords)
+  coords[dim] = (tuple(label_dims), np.asarray(da.coords[dim].values)[idx].reshape(labels.shape))
+  return xr.DataArray(taken, dims=dims, coords=coords, name=da.name, attrs=da.attrs)
+
+
+def _dayofyear(t: np.ndarray) -> np.ndarray:
+  t = np.asarray(t).astype('datetime64[ns]')
+  return (t.astype('datetime64[D]') - t.astype('datetime64[Y]').astype('datetime64[D]')).astype(np.int64) + 1
+
+
+def select_bin_thresholds_by_time_from_chunk(bin_thresholds: xr.DataArray, chunk: xr.DataArray) -> xr.DataArray:
+  """The thresholds that belong to a chunk's time labels (wrappers.py:270-346).  The chunk has (init_time, lead_time), or
+  valid_time / time, or no time at all (thresholds unchanged); the thresholds are indexed by valid_time / time, by (init_time,
+  lead_time), by dayofyear (+ lead_time), or by nothing."""
+  bt, chunk = xr.as_dataarray(bin_thresholds), xr.as_dataarray(chunk)
+  cc = chunk.coords
+
+  def coord(name):
+    c = cc[name]
+    return np.asarray(c.values), tuple(c.dims), {k: v for k, v in cc.items() if set(v.dims) <= set(c.dims) and k in c.dims}
+  if 'init_time' in cc and 'lead_time' in cc:
+    it, idims, icoords = coord('init_time')
+    lt, ldims, lcoords = coord('lead_time')
+    if idims == ldims:  # sparse: both on one dim
+      valid, vdims = it + lt, idims
+    else:
+      valid, vdims = it[:, None] + lt[None, :], idims + ldims
+    vcoords = {**icoords, **lcoords}
+    for name in ('valid_time', 'time'):
+      if name in bt.dims:
+        return _take_along(bt, name, valid, vdims, vcoords)
+    if {'init_time', 'lead_time'} <= set(bt.dims):
+      return _take_along(_take_along(bt, 'init_time', it, idims, icoords), 'lead_time', lt, ldims, lcoords)
+    if 'dayofyear' in bt.dims:
+      if 'lead_time' in bt.dims:
+        return _take_along(_take_along(bt, 'dayofyear', _dayofyear(it), idims, icoords), 'lead_time', lt, ldims, lcoords)
+      return _take_along(bt, 'dayofyear', _dayofyear(valid), vdims, vcoords)
+    return bt
+  for name in ('valid_time', 'time'):
+    if name in cc:
+      t, tdims, tcoords = coord(name)
+      if tdims != (name,):
+        tcoords = {name: (tdims, t), **{k: v for k, v in cc.items() if k in tdims}}
+      for tname in ('valid_time', 'time'):
+        if tname in bt.dims:
+          return _take_along(bt, tname, t, tdims, tcoords)
+      if 'dayofyear' in bt.dims:
+        return _take_along(bt, 'dayofyear', _dayofyear(t), tdims, tcoords)
+      return bt
+  return bt
+
+
+def compute_cdf(threshold_values, da: xr.DataArray, threshold_dim: str, enforce_monotonicity: bool, right_inclusive: bool = True) -> xr.DataArray:
+  """[x <= threshold] (or <) for every threshold as float, NaN where x or the threshold is NaN (wrappers.py:349-390)."""
+  da = xr.as_dataarray(da)
+  if isinstance(threshold_values, (xr.DataArray, xr.Dataset)):
+    thresholds = threshold_values[da.name] if isinstance(threshold_values, xr.Dataset) else threshold_values
+    thresholds = select_bin_thresholds_by_time_from_chunk(thresholds, da)
+  elif isinstance(threshold_values, Iterable):
+    values = np.array(list(threshold_values))
+    thresholds = xr.DataArray(values, dims=[threshold_dim], coords={threshold_dim: values})
+  else:
+    raise ValueError('Bin values must be an Iterable, xr.DataArray, or xr.Dataset.')
+  if enforce_monotonicity:
+    tv = np.asarray(thresholds.values)
+    if not np.all(np.diff(tv, axis=thresholds.dims.index(threshold_dim)) > 0):
+      raise ValueError('Bin values must be monotonically increasing. To turn off this check, set `enforce_monotonicity=False`.')
+  cdf = ((da <= thresholds) if right_inclusive else (da < thresholds)).astype(np.float64)
+  return cdf.where(~da.isnull()).where(~thresholds.isnull())
+
+
+class ContinuousToCDF(InputTransform):
+  """A continuous input as the indicators [x <= t] (or [x < t]) along `threshold_dim` (wrappers.py:480-547)."""
+
+  def __init__(self, which: str, threshold_values, threshold_dim: str, unique_name_suffix: str | None = None,
+               enforce_monotonicity: bool = True, right_inclusive: bool = True):
+    super().__init__(which)
+    self._threshold_values = threshold_values
+    self._threshold_dim = threshold_dim
+    if isinstance(threshold_values, (xr.DataArray, xr.Dataset)) and unique_name_suffix is None:
+      raise ValueError('unique_name_suffix must be provided if threshold_values is an xarray.DataArray or xarray.Dataset.')
+    self._unique_name_suffix = unique_name_suffix
+    self._enforce_monotonicity = enforce_monotonicity
+    self._right_inclusive = right_inclusive
+
+  @property
+  def unique_name_suffix(self) -> str:
+    suffix = self._unique_name_suffix if self._unique_name_suffix is not None else ','.join(str(t) for t in self._threshold_values)
+    return f'ContinuousToCDF_{self._threshold_dim}_{suffix}_right_inclusive_{self._right_inclusive}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    return compute_cdf(self._threshold_values, da, self._threshold_dim, self._enforce_monotonicity, self._right_inclusive)
+
+
+class ContinuousToBins(InputTransform):
+  """A continuous input as indicators of the right-inclusive bins (t[i-1], t[i]] along `bin_dim` -- len(bin_values) - 1 of them,
+  +-inf at the ends for open bins -- labelled '{left:.2f} < p <= {right:.2f}' with `{bin_dim}_left` / `_right` coordinates
+  (wrappers.py:393-477)."""
+
+  def __init__(self, which: str, bin_values, bin_dim: str, unique_name_suffix: str | None = None, enforce_monotonicity: bool = True):
+    super().__init__(which)
+    self._bin_values = bin_values
+    self._bin_dim = bin_dim
+    if isinstance(bin_values, (xr.DataArray, xr.Dataset)) and unique_name_suffix is None:
+      raise ValueError('unique_name_suffix must be provided if bin_values is an xarray.DataArray or xarray.Dataset.')
+    self._unique_name_suffix = unique_name_suffix
+    self._enforce_monotonicity = enforce_monotonicity
+
+  @property
+  def unique_name_suffix(self) -> str:
+    suffix = self._unique_name_suffix if self._unique_name_suffix is not None else ','.join(str(t) for t in self._bin_values)
+    return f'ContinuousToBins_{self._bin_dim}_{suffix}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    cdf = compute_cdf(self._bin_values, da, self._bin_dim, self._enforce_monotonicity)
+    edges = np.asarray(cdf.coords[self._bin_dim].values)
+    left, right = edges[:-1], edges[1:]
+    n = cdf.sizes[self._bin_dim]
+    upper = cdf.isel({self._bin_dim: slice(1, n)})
+    lower = cdf.isel({self._bin_dim: slice(0, n - 1)})
+    # (the difference of two slices whose labels differ: put the same labels on both first)
+    names = np.array([f'{a:.2f} < p <= {b:.2f}' for a, b in zip(left, right)])
+    upper, lower = upper.assign_coords({self._bin_dim: names}), lower.assign_coords({self._bin_dim: names})
+    out = upper - lower
+    return out.assign_coords({f'{self._bin_dim}_left': ((self._bin_dim,), left), f'{self._bin_dim}_right': ((self._bin_dim,), right)})
+
+
+class StackToNewDimension(InputTransform):
+  """Several dims flattened (in the order given, the last one fastest) into one dim labelled 0 .. n - 1, whose name may be one of
+  theirs (wrappers.py:811-848)."""
+
+  def __init__(self, which: str, dims_to_stack: Sequence[Hashable], new_dim_name: Hashable):
+    super().__init__(which)
+    self._dims_to_stack = dims_to_stack
+    self._new_dim_name = new_dim_name
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return f'stack_{self._dims_to_stack}_to_{self._new_dim_name}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    da = xr.as_dataarray(da)
+    stack = list(self._dims_to_stack)
+    keep = [d for d in da.dims if d not in stack]
+    moved = da.transpose(*keep, *stack)
+    n = int(np.prod([da.sizes[d] for d in stack], dtype=np.int64))
+    data = moved.data.reshape(tuple(da.sizes[d] for d in keep) + (n,))
+    coords = {k: v for k, v in da.coords.items() if not set(v.dims) & set(stack)}
+    coords[self._new_dim_name] = np.arange(n)
+    return xr.DataArray(data, dims=tuple(keep) + (self._new_dim_name,), coords=coords, name=da.name, attrs=da.attrs)
+
+
+def construct_tiles(da: xr.DataArray, window_size: int = 3, window_dim: str = 'window', wrap_longitude: bool = False) -> xr.DataArray:
+  """At every (latitude, longitude) pixel the window_size x window_size patch around it, along a new leading `window_dim`
+  (latitude offset slowest); pixels whose patch would cross the latitude edges -- and, unless `wrap_longitude`, the longitude edges
+  -- are dropped (wrappers.py:851-909)."""
+  da = xr.as_dataarray(da)
+  half = window_size // 2
+  lo, hi = half, window_size - 1 - half
+  ilat, ilon = da.dims.index('latitude'), da.dims.index('longitude')
+  data = da.data
+  roll = (lambda x, s, ax: x.roll(s, ax)) if xr._is_torch(data) else (lambda x, s, ax: np.roll(x, s, axis=ax))  # pylint: disable=protected-access
+  layers = []
+  for i in range(window_size):
+    for j in range(window_size):
+      layers.append(roll(roll(data, i - half, ilat), j - half, ilon))
+  if xr._is_torch(data):  # pylint: disable=protected-access
+    import torch  # pylint: disable=g-import-not-at-top
+    stacked = torch.stack(layers)
+  else:
+    stacked = np.stack(layers)
+  out = xr.DataArray(stacked, dims=(window_dim,) + tuple(da.dims), coords=dict(da.coords), name=da.name, attrs=da.attrs)
+  out = out.isel(latitude=slice(lo, da.sizes['latitude'] - hi))
+  if not wrap_longitude:
+    out = out.isel(longitude=slice(lo, da.sizes['longitude'] - hi))
+  return out
+
+
+class Tile(InputTransform):
+  """construct_tiles as an input transform (wrappers.py:912-964)."""
+
+  def __init__(self, which: str, window_size: int = 3, window_dim: str = 'window', wrap_longitude: bool = False):
+    super().__init__(which)
+    self._window_size = window_size
+    self._window_dim = window_dim
+    self._wrap_longitude = wrap_longitude
+
+  @property
+  def unique_name_suffix(self) -> str:
+    return f'tiled_window_size_{self._window_size}_wrap_{self._wrap_longitude}_dim_{self._window_dim}'
+
+  def transform_fn(self, da: xr.DataArray) -> xr.DataArray:
+    return construct_tiles(da, window_size=self._window_size, window_dim=self._window_dim, wrap_longitude=self._wrap_longitude)
