@@ -311,3 +311,27 @@ def test_stack_to_new_dimension_and_tiles():
   t5 = wrappers.construct_tiles(x, window_size=4)
   assert t5.sizes['window'] == 16 and t5.sizes['latitude'] == nlat - 3 and t5.sizes['longitude'] == nlon - 3
   assert wrappers.Tile('both', 3, 'w', True).unique_name_suffix == 'tiled_window_size_3_wrap_True_dim_w'
+
+
+def test_tensor_payloads_take_the_same_paths():
+  """The transforms on torch payloads (what a chunk in HBM is): same numbers, and the result stays a tensor."""
+  torch = pytest.importorskip('torch')
+  rng = np.random.default_rng(7)
+  v = rng.random((2, 5, 6)).astype(np.float32)
+  dims = ('time', 'latitude', 'longitude')
+  cs = {'time': np.datetime64('2023-01-02', 'ns') + np.arange(2) * np.timedelta64(24, 'h'), 'latitude': np.linspace(-40, 40, 5), 'longitude': np.arange(6) * 60.0}
+  xn = xr.DataArray(v.copy(), dims=dims, coords=cs, name='v')
+  xt = xr.DataArray(torch.from_numpy(v.copy()), dims=dims, coords=cs, name='v')
+  thr = xr.DataArray(torch.from_numpy(np.stack([np.arange(1, 366) / 400.0, np.arange(1, 366) / 300.0]).astype(np.float32)), dims=['threshold', 'dayofyear'],
+                     coords={'threshold': np.array([0, 1]), 'dayofyear': np.arange(1, 366)})
+  thr_n = xr.DataArray(np.asarray(thr.values), dims=thr.dims, coords={'threshold': np.array([0, 1]), 'dayofyear': np.arange(1, 366)})
+  for make in (lambda: wrappers.Tile('both', 3, wrap_longitude=True), lambda: wrappers.StackToNewDimension('both', ['latitude', 'longitude'], 'point'),
+               lambda: wrappers.ContinuousToBins('both', [-np.inf, 0.3, np.inf], 'bin'), lambda: wrappers.ReLU('both'),
+               lambda: wrappers.ContinuousToBinary('both', [0.2, 0.6], 'threshold')):
+    a, b = make().transform_fn(xn), make().transform_fn(xt)
+    assert xr._is_torch(b.data) and a.dims == b.dims  # pylint: disable=protected-access
+    np.testing.assert_allclose(np.asarray(b.values), np.asarray(a.values), rtol=1e-6, equal_nan=True)
+  a = wrappers.ContinuousToCDF('both', thr_n, 'threshold', unique_name_suffix='d', enforce_monotonicity=False).transform_fn(xn)
+  b = wrappers.ContinuousToCDF('both', thr, 'threshold', unique_name_suffix='d', enforce_monotonicity=False).transform_fn(xt)
+  assert xr._is_torch(b.data)  # pylint: disable=protected-access
+  np.testing.assert_array_equal(np.asarray(b.transpose(*a.dims).values), np.asarray(a.values))
