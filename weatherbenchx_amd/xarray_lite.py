@@ -566,8 +566,11 @@ class DataArray:
 
   def _index_positions(self, dim, labels, method=None):
     if dim not in self._coords:
-      raise KeyError(f'no index coordinate for dimension {dim!r}')
-    index = np.asarray(self._coords[dim][1])
+      if dim not in self.dims:
+        raise KeyError(f'no index coordinate for dimension {dim!r}')
+      index = np.arange(self.sizes[dim])  # a dimension without coordinate is indexed by position, as in xarray
+    else:
+      index = np.asarray(self._coords[dim][1])
     labels_arr = np.asarray(labels)
     if index.dtype.kind == 'M':
       labels_arr = labels_arr.astype(index.dtype)
@@ -640,7 +643,8 @@ class DataArray:
       for k, v in ia._coords.items():
         coords.setdefault(k, v)
     for d, ia in zip(vector, idx_arrays):
-      coords[d] = (tuple(new_dims), np.asarray(self._coords[d][1])[pos[d]])
+      if d in self._coords:
+        coords[d] = (tuple(new_dims), np.asarray(self._coords[d][1])[pos[d]])
     del n_new
     return self._replace(data=gathered, dims=tgt_dims, coords=coords)
 
