@@ -340,3 +340,27 @@ def test_latency_wrapper_keeps_the_wrapped_loaders_options():
   mask = np.asarray(out.coords['mask'].values)
   np.testing.assert_array_equal(mask, ~np.isnan(out.values))
   assert (~mask).sum() == 1
+
+
+def test_tensor_payloads_are_gathered_where_they_live():
+  """A dataset whose payloads are torch tensors (what a field resident in HBM is) stays a tensor through every loader: the
+  selections are index gathers on the tensor's device, no host round trip."""
+  torch = pytest.importorskip('torch')
+  target = mock_data.mock_target_data(time_start='2015-01-01T00', time_stop='2017-01-01T00', variables_3d=[], random=True,
+                                      seed=30, dtype=np.float32)
+  host = target['2m_temperature']
+  dev = xr.Dataset({'2m_temperature': xr.DataArray(torch.from_numpy(np.ascontiguousarray(host.values)), dims=host.dims,
+                                                   coords={d: host[d].values for d in host.dims})})
+  init_times, lead_times = _inits('2016-12-28T00', '2016-12-30T00'), _h([0, 24, 48])
+  for make in (lambda ds: data_loaders.TargetsFromXarray(ds=ds),
+               lambda ds: data_loaders.PersistenceFromXarray(ds=ds),
+               lambda ds: data_loaders.ProbabilisticClimatologyFromXarray(ds=ds, start_year=2015, end_year=2015),
+               lambda ds: data_loaders.XarrayConstantLatencyWrapper(
+                   data_loaders.PersistenceFromXarray(ds=ds), latency=np.timedelta64(24, 'h'), init_time_dim='valid_time')):
+    a = make(target).load_chunk(init_times, lead_times)['2m_temperature']
+    b = make(dev).load_chunk(init_times, lead_times)['2m_temperature']
+    assert xr._is_torch(b.data) and not xr._is_torch(a.data), make  # pylint: disable=protected-access
+    assert a.dims == b.dims
+    np.testing.assert_array_equal(np.asarray(b.values), a.values)
+    for d in a.dims:
+      np.testing.assert_array_equal(b[d].values, a[d].values)
