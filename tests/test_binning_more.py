@@ -120,6 +120,11 @@ def test_by_coord_bins_and_by_sets():
   np.testing.assert_array_equal(np.asarray(mask.coords['lead_time'].values), edges[:-1])
   mask = binning.ByCoordBins('lead_time', edges, add_global_bin=True).create_bin_mask(stat)
   assert mask.shape[0] == 7 and np.asarray(mask.coords['lead_time'].values)[-1] == 'global' and np.asarray(mask.values)[-1].all()
+  # with a global bin the labels are `str(edge)` (binning.py:605)
+  assert np.asarray(mask.coords['lead_time'].values)[:-1].tolist() == [str(e) for e in edges[:-1]]
+  fl = binning.ByCoordBins('lead_time', np.array([0.0, 2.5, 5.0]), add_global_bin=True).create_bin_mask(
+      stat.assign_coords(lead_time=(('index',), np.linspace(0.0, 4.9, stat.shape[0]))))
+  assert np.asarray(fl.coords['lead_time'].values).tolist() == ['0.0', '2.5', 'global']
   names = np.asarray(stat.coords['stationName'].values)
   uniq = np.unique(names)
   b = binning.BySets({'set1': uniq[:10], 'set2': uniq[10:20], 'scalar_set': uniq[0], 'empty_set': [], 'wrong_set': [1, 2, 3, 4]},
@@ -206,3 +211,23 @@ def test_time_binnings_through_the_aggregator(backend):
   want = [((ps - ts)[leads == u] ** 2).mean() for u in np.unique(leads)]
   np.testing.assert_allclose(np.asarray(vals.values), want, rtol=1e-9)
   np.testing.assert_array_equal(np.asarray(vals.coords['lead_time'].values), np.unique(leads))
+
+
+def test_latitude_and_longitude_bands_of_station_data():
+  """Sparse statistics carry latitude / longitude as coordinates over `index`; the bands broadcast along that dim, as
+  `mask.broadcast_like(statistic)` does (binning.py:232-238, 277-284)."""
+  rng = np.random.default_rng(11)
+  n = 80
+  lat, lon = rng.uniform(-90, 90, n), rng.uniform(-180, 180, n)
+  stat = xr.DataArray(rng.normal(size=(3, n)), dims=('lead_time', 'index'),
+                      coords={'lead_time': np.arange(3) * H, 'latitude': (('index',), lat), 'longitude': (('index',), lon)})
+  mask = binning.LatitudeBins(30).create_bin_mask(stat)
+  assert mask.dims == ('latitude_bins', 'lead_time', 'index') and mask.shape == (6, 3, n)
+  for i, a in enumerate(range(-90, 90, 30)):
+    np.testing.assert_array_equal(np.asarray(mask.values)[i], np.broadcast_to((lat >= a) & (lat <= a + 30), (3, n)))
+  mask = binning.LongitudeBins(90).create_bin_mask(stat)
+  assert mask.shape == (4, 3, n)
+  m360 = np.mod(lon, 360)
+  for i, a in enumerate(range(0, 360, 90)):
+    want = (m360 >= a) & (m360 <= a + 90) if a + 90 < 360 else (m360 >= a) | (m360 <= 0)
+    np.testing.assert_array_equal(np.asarray(mask.values)[i, 0], want)

@@ -153,7 +153,7 @@ class LatitudeBins(Binning):
     statistic = xr.as_dataarray(statistic)
     lat = statistic['latitude']
     bands = np.stack([np.asarray(_lat_mask(lat, (a, a + self._degrees)).values) for a in self._starts])
-    idx = (slice(None),) + tuple(slice(None) if d == 'latitude' else None for d in statistic.dims)
+    idx = (slice(None),) + tuple(slice(None) if d in lat.dims else None for d in statistic.dims)  # (latitude may be a coordinate over `index`)
     mask = np.broadcast_to(bands[idx], (len(self._starts),) + tuple(statistic.shape))  # broadcast to the statistic, as the reference
     return _mask_array(statistic, self.bin_dim_name, self._starts, mask, statistic.dims)
 
@@ -171,7 +171,7 @@ class LongitudeBins(Binning):
     statistic = xr.as_dataarray(statistic)
     lon = statistic['longitude']
     bands = np.stack([np.asarray(_lon_mask(lon, (a, a + self._degrees)).values) for a in self._starts])
-    idx = (slice(None),) + tuple(slice(None) if d == 'longitude' else None for d in statistic.dims)
+    idx = (slice(None),) + tuple(slice(None) if d in lon.dims else None for d in statistic.dims)  # (longitude may be a coordinate over `index`)
     mask = np.broadcast_to(bands[idx], (len(self._starts),) + tuple(statistic.shape))
     return _mask_array(statistic, self.bin_dim_name, np.mod(self._starts, 360), mask, statistic.dims)
 
@@ -315,7 +315,8 @@ class ByCoordBins(Binning):
     mask = np.stack([(values >= a) & (values < b) for a, b in zip(starts, stops)]) if len(starts) else np.zeros((0,) + values.shape, bool)
     labels = starts
     if self.add_global_bin:
-      labels, mask = _with_global(labels, mask, first=False)
+      # `str(start)` per edge (binning.py:605): '1 hours' for a timedelta64 edge, where `.astype(str)` would say '1'
+      labels, mask = _with_global(np.array([str(a) for a in starts], dtype=str), mask, first=False)
     if dims == (self.dim_name,):
       # binning a DIMENSION by its own name: the mask keeps that dim under a private name so that [bin, dim] stays a matrix
       # (the reference drops the coordinate and reuses the name for the bin dim, which only works for non-dimension coordinates)
