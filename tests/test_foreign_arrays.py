@@ -3,13 +3,11 @@ plugin API (metrics/base.py:184-197, aggregation.py:411-435): accepted, and FUSE
 (predictions, targets) pair shares one conversion, so RMSE + MSE + MAE + bias + ACC are one stage-1 launch and three uploads,
 the CRPS suite one launch."""
 import numpy as np
-import pytest
 
 from weatherbenchx_amd import aggregation
 from weatherbenchx_amd import engine
 from weatherbenchx_amd import weighting
 from weatherbenchx_amd import xarray_lite as xr
-from weatherbenchx_amd.metrics import base as metrics_base
 from weatherbenchx_amd.metrics import deterministic
 from weatherbenchx_amd.metrics import probabilistic
 

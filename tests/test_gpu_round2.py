@@ -12,7 +12,6 @@ from weatherbenchx_amd import _hip
 from weatherbenchx_amd import aggregation
 from weatherbenchx_amd import binning
 from weatherbenchx_amd import data as wdata
-from weatherbenchx_amd import engine
 from weatherbenchx_amd import weighting
 from weatherbenchx_amd import xarray_lite as xr
 from weatherbenchx_amd.metrics import base as metrics_base

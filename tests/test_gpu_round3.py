@@ -4,7 +4,6 @@ CRPSEnsemble(), the configs[4] composite (three evaluations, device accumulators
 oracle, and the C-ABI collective (wbx_comm_* / wbx_acc_allreduce) on a one-rank communicator.
 Tolerance: rtol 1e-6 (north_star) unless a test says otherwise."""
 import ctypes as C
-import os
 
 import numpy as np
 import pytest

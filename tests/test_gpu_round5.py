@@ -3,7 +3,6 @@ NaN mask of add_nan_mask_to_data (data_loaders/base.py:25-56), another hole at e
 Aggregator(skipna=True) (aggregation.py:339-357), at M = 51 on the full 0.25 degree grid with the public benchmark's 34 bins:
 every bin of all five lanes and of their weights against the float64 oracle, ONE launch.  Tolerance: rtol 1e-6 (north_star)."""
 import ctypes as C
-import dataclasses
 
 import numpy as np
 import pytest
@@ -301,7 +300,7 @@ def test_fused_det_spectra_are_bit_reproducible(ctx, monkeypatch):
   """The same for the spectra that come out of the deterministic sweep (wbx_det_spectrum: records of 2 x 721 values), both
   layouts' routes: five jobs of four chunks, bit-identical accumulators."""
   import torch
-  from weatherbenchx_amd import pipeline, replay, spectra, time_chunks
+  from weatherbenchx_amd import pipeline, spectra, time_chunks
   from weatherbenchx_amd.metrics import deterministic
   nlat, nlon, nlead, nlev, n = 45, 1440, 2, 3, 4
   g = torch.Generator(device='cuda')
