@@ -427,6 +427,63 @@ def relative_intensity(p, t, spatial_axes, mask=None, epsilon=1e-6):
     return np.abs((pm + epsilon) / (tm + epsilon) - 1), out_mask
 
 
+# ---- multivariate / distribution scores: the tables of the reference written out (probabilistic.py:339-603, 785-833) ---------
+def energy_score_skill(p, t, norm_axes, ensemble_axis):
+  """mean_m sqrt(sum_norm (p_m - t)**2); `t` broadcastable to `p` (size 1 along the ensemble axis).  probabilistic.py:480-503."""
+  norm_axes = tuple(a % p.ndim for a in np.atleast_1d(norm_axes))
+  ensemble_axis %= p.ndim
+  norms = np.sqrt(np.sum((p - t) ** 2, axis=norm_axes, keepdims=True))
+  return np.squeeze(norms.mean(axis=ensemble_axis, keepdims=True), axis=norm_axes + (ensemble_axis,))
+
+
+def energy_score_spread(p, norm_axes, ensemble_axis, fair=True):
+  """sum over the full M x M table of ||p_m - p_m'|| / (M (M - 1)) or / M**2.  probabilistic.py:506-551."""
+  norm_axes = tuple(a % p.ndim for a in np.atleast_1d(norm_axes))
+  ensemble_axis %= p.ndim
+  m = p.shape[ensemble_axis]
+  q = np.moveaxis(p, ensemble_axis, 0)                               # [M, ...]
+  moved = tuple(sorted((a + 1 if a < ensemble_axis else a) for a in norm_axes))  # norm axes in q's numbering
+  table = q[:, None] - q[None, :]                                    # [M, M', ...]
+  norms = np.sqrt(np.sum(table ** 2, axis=tuple(a + 1 for a in moved)))
+  with np.errstate(all='ignore'):
+    return norms.sum(axis=(0, 1)) / (m * (m - 1) if fair else m * m)
+
+
+def variogram_score(p, t, pair_axis, ensemble_axis, power=0.5):
+  """sum_{i,j} (|t_i - t_j|**power - mean_m |p_i^m - p_j^m|**power)**2 with the full [N, N] tables; `t` has p's axes with size 1
+  along the ensemble axis.  probabilistic.py:554-603."""
+  pair_axis %= p.ndim
+  ensemble_axis %= p.ndim
+  q = np.moveaxis(p, (pair_axis, ensemble_axis), (0, 1))             # [N, M, ...]
+  u = np.moveaxis(t, (pair_axis, ensemble_axis), (0, 1))[:, 0]       # [N, ...]
+  tx = (np.abs(q[:, None] - q[None, :]) ** power).mean(axis=2)       # [N, N', ...]
+  ty = np.abs(u[:, None] - u[None, :]) ** power
+  return ((ty - tx) ** 2).sum(axis=(0, 1))
+
+
+def wasserstein_1d(u, v):
+  """1-Wasserstein distance of two samples: integral of |F_u - F_v| over the pooled support (what
+  scipy.stats.wasserstein_distance evaluates; probabilistic.py:823-832 calls it point by point)."""
+  u, v = np.sort(np.asarray(u, dtype=np.float64)), np.sort(np.asarray(v, dtype=np.float64))
+  pooled = np.sort(np.concatenate([u, v]))
+  total = 0.0
+  for a, b in zip(pooled[:-1], pooled[1:]):
+    total += abs(np.searchsorted(u, a, side='right') / u.size - np.searchsorted(v, a, side='right') / v.size) * (b - a)
+  return total
+
+
+def ensemble_rps(p_members, t_value, thresholds, fair=True, right_inclusive=True):
+  """Ranked probability score of ONE point: p_members [M], scalar target, thresholds [K] (probabilistic.py:339-477):
+  sum_k of (mean_m 1[p_m <= b_k] - 1[t <= b_k])**2, minus var_m(1[p_m <= b_k]) / M per threshold when fair."""
+  p_members = np.asarray(p_members, dtype=np.float64)
+  cmp = np.less_equal if right_inclusive else np.less
+  total = 0.0
+  for b in thresholds:
+    cp, ct = cmp(p_members, b).astype(np.float64), float(cmp(t_value, b))
+    total += (cp.mean() - ct) ** 2 - (cp.var(ddof=1) / cp.size if fair else 0.0)
+  return total
+
+
 def zonal_power_spectrum(field, lon_axis=-1):
   f = f64(field)
   n = f.shape[lon_axis]
