@@ -484,6 +484,31 @@ def ensemble_rps(p_members, t_value, thresholds, fair=True, right_inclusive=True
   return total
 
 
+def contingency_table(decision, event, weights=None):
+  """Mean TP, FP, FN, TN of boolean decisions against boolean events over all points (categorical.py:25-101 under a
+  weighted mean)."""
+  decision, event = np.asarray(decision, dtype=bool).ravel(), np.asarray(event, dtype=bool).ravel()
+  w = np.ones(decision.size) if weights is None else np.asarray(weights, dtype=np.float64).ravel()
+  mean = lambda x: float((x * w).sum() / w.sum())
+  return mean(decision & event), mean(decision & ~event), mean(~decision & event), mean(~decision & ~event)
+
+
+def relative_economic_value(probability, event, thresholds, cost_loss_ratios):
+  """REV [threshold (with 0 and 1 added at the ends), cost_loss_ratio] of probability forecasts of a binary event, one decision
+  rule `probability > threshold` per row (probabilistic.py:1062-1303): expenses per unit loss
+  forecast = r (TP + FP) + FN, perfect = r (TP + FN), climate = min(r, TP + FN); REV = (climate - forecast) / (climate - perfect)."""
+  probability, event = np.asarray(probability, dtype=np.float64).ravel(), np.asarray(event, dtype=bool).ravel()
+  rows = [np.ones(event.size, dtype=bool)] + [probability > b for b in thresholds] + [np.zeros(event.size, dtype=bool)]
+  out = np.empty((len(rows), len(cost_loss_ratios)))
+  for i, decision in enumerate(rows):
+    tp, fp, fn, _ = contingency_table(decision, event)
+    for j, r in enumerate(cost_loss_ratios):
+      climate = min(r, tp + fn)
+      with np.errstate(all='ignore'):
+        out[i, j] = np.float64(climate - (r * (tp + fp) + fn)) / np.float64(climate - r * (tp + fn))
+  return out
+
+
 def zonal_power_spectrum(field, lon_axis=-1):
   f = f64(field)
   n = f.shape[lon_axis]
