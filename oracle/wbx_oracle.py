@@ -509,6 +509,34 @@ def relative_economic_value(probability, event, thresholds, cost_loss_ratios):
   return out
 
 
+def neighborhood_mean(field, n, wrap_longitude=False):
+  """n x n neighbourhood mean of ONE [lat, lon] field, the window written out point by point: cyclic in both directions, then
+  the (n - 1) / 2 outermost rows (and columns unless wrap_longitude) set to 0; a window holding a NaN is NaN.  spatial.py:24-56."""
+  field = np.asarray(field, dtype=np.float64)
+  if n == 1:
+    return field
+  h = (n - 1) // 2
+  nlat, nlon = field.shape
+  out = np.zeros((nlat, nlon))
+  for i in range(nlat):
+    for j in range(nlon):
+      out[i, j] = np.mean([field[(i + a) % nlat, (j + b) % nlon] for a in range(-h, h + 1) for b in range(-h, h + 1)])
+  out[:h] = 0
+  out[nlat - h:] = 0
+  if not wrap_longitude:
+    out[:, :h] = 0
+    out[:, nlon - h:] = 0
+  return out
+
+
+def fractions_skill_score(p, t, n, wrap_longitude=False):
+  """FSS of binary [..., lat, lon] arrays with plain means over everything (spatial.py:280-339)."""
+  p, t = np.asarray(p, dtype=np.float64), np.asarray(t, dtype=np.float64)
+  pf = np.stack([neighborhood_mean(f, n, wrap_longitude) for f in p.reshape((-1,) + p.shape[-2:])])
+  tf = np.stack([neighborhood_mean(f, n, wrap_longitude) for f in t.reshape((-1,) + t.shape[-2:])])
+  return 1 - np.mean((pf - tf) ** 2) / (np.mean(pf ** 2) + np.mean(tf ** 2))
+
+
 def zonal_power_spectrum(field, lon_axis=-1):
   f = f64(field)
   n = f.shape[lon_axis]
