@@ -1,0 +1,74 @@
+"""Per-unit metric values linearised around the mean statistics -- the delta method (counterpart of
+weatherbenchX/statistical_inference/autodiff.py:33-233, which differentiates with jax; there is no jax here).
+
+A metric is f(mean_i x_i) with x_i the per-unit accumulators (sum of weighted statistics AND sum of weights: the normalisation
+of a weighted mean is part of f).  Inference methods for means apply to  f(m) + J_f(m) (x_i - m),  whose mean is the metric itself
+and whose variance approximates the metric's to first order.  J_f(m) (x_i - m) is a directional derivative, taken here by central
+differences  [f(m + h d_i) - f(m - h d_i)] / 2h  for all units in ONE pair of evaluations: the unit dimension rides along as a
+trailing dim, which `values_from_mean_statistics` broadcasts over like any other.  h is chosen so that no accumulator moves by
+more than 1e-5 of its scale: exact to rounding for the linear metrics (means, differences of means), about 1e-10 relative for the
+smooth non-linear ones (RMSE, ACC, spread/skill)."""
+from __future__ import annotations
+
+from typing import Hashable, Mapping
+
+import numpy as np
+
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd import xarray_tree
+from weatherbenchx_amd.metrics import base as metrics_base
+from weatherbenchx_amd.statistical_inference import utils
+
+StatsValues = Mapping[str, Mapping[Hashable, xr.DataArray]]
+MetricValues = Mapping[str, Mapping[Hashable, xr.DataArray]]
+
+_RELATIVE_STEP = 1e-5
+
+
+def _host(x) -> xr.DataArray:
+  x = xr.as_dataarray(x)
+  return x._replace(data=np.asarray(x.values, dtype=np.float64))  # pylint: disable=protected-access
+
+
+def per_unit_values_linearized_around_mean_statistics(metrics: Mapping[str, metrics_base.Metric],
+                                                      aggregation_state: aggregation.AggregationState,
+                                                      experimental_unit_dim: str) -> tuple[MetricValues, MetricValues]:
+  """(value, per_unit_tangents): the metrics at the mean over units of the accumulators, and per unit the first-order change
+  J (x_i - mean) -- zero-mean along `experimental_unit_dim`, which is the LAST dim of every tangent."""
+  unit = experimental_unit_dim
+  unit_coord = utils.get_and_check_experimental_unit_coord(aggregation_state, unit)
+  per_unit = aggregation_state.map(lambda x: _host(x).transpose(*[d for d in xr.as_dataarray(x).dims if d != unit], unit))
+  mean = per_unit.map(lambda x: x.mean(unit, skipna=False))
+  direction = aggregation.AggregationState.map_multi(lambda x, m: x - m, per_unit, mean)
+
+  def evaluate(state: aggregation.AggregationState):
+    return metrics_base.compute_metrics_from_statistics(metrics, state.mean_statistics())
+
+  value = evaluate(mean)
+  # one step for everything: the largest move of any accumulator relative to its own scale is _RELATIVE_STEP
+  worst = 0.0
+  for field in ('sum_weighted_statistics', 'sum_weights'):
+    for stat, per_var in getattr(direction, field).items():
+      for var, d in per_var.items():
+        scale = float(np.nanmax(np.abs(np.asarray(getattr(mean, field)[stat][var].values)), initial=0.0))
+        size = float(np.nanmax(np.abs(np.asarray(d.values)), initial=0.0))
+        if size > 0:
+          worst = max(worst, size / (scale if scale > 0 else 1.0))
+  if worst == 0.0:                                                      # every unit equals the mean: nothing moves
+    zeros = xarray_tree.map_structure(
+        lambda v: (xr.as_dataarray(v) * 0.0).expand_dims({unit: np.asarray(unit_coord.values)}, axis=-1), value)
+    return value, zeros
+  h = _RELATIVE_STEP / worst
+  plus = evaluate(aggregation.AggregationState.map_multi(lambda m, d: m + h * d, mean, direction))
+  minus = evaluate(aggregation.AggregationState.map_multi(lambda m, d: m - h * d, mean, direction))
+
+  def tangent(p, q, v):
+    p, q, v = xr.as_dataarray(p), xr.as_dataarray(q), xr.as_dataarray(v)
+    t = (p - q) / (2 * h)
+    if unit not in t.dims:                                              # a metric that does not depend on the sampled statistics
+      t = (v * 0.0).expand_dims({unit: np.asarray(unit_coord.values)}, axis=-1)
+    t = t.transpose(*[d for d in t.dims if d != unit], unit)
+    return t.assign_coords({unit: np.asarray(unit_coord.values)})
+
+  return value, xarray_tree.map_structure(tangent, plus, minus, value)
