@@ -289,3 +289,136 @@ def test_inference_on_accumulators_from_the_device(backend):
   assert diff < 0 and bool(paired.significance_tests(0.0, 0.05)['rmse']['t'].values)   # 'good' has the smaller RMSE, significantly
   lower, upper = paired.confidence_intervals(0.05)
   assert float(lower['rmse']['t'].values) < diff < float(upper['rmse']['t'].values) < 0
+
+
+# ---- bootstraps (statistical_inference/bootstrap_test.py:26-391, scaled down) ---------------------------------------------------------
+from weatherbenchx_amd.statistical_inference import bootstrap  # pylint: disable=g-import-not-at-top,wrong-import-position
+
+
+class ExpMean(metrics_base.PerVariableMetric):
+
+  @property
+  def statistics(self):
+    return {'mean_prediction': MeanPrediction()}
+
+  def _values_from_mean_statistics_per_variable(self, statistic_values):
+    return statistic_values['mean_prediction']._unary(np.exp, 'exp')  # pylint: disable=protected-access
+
+
+def simulate_ar1(rng, mean, sigma_marginal, phi, steps, replicates):
+  sigma = sigma_marginal * np.sqrt(1 - phi ** 2)
+  out = [sigma_marginal * rng.normal(size=replicates)]
+  for _ in range(steps - 1):
+    out.append(phi * out[-1] + rng.normal(size=replicates) * sigma)
+  return np.stack(out) + mean
+
+
+def ar1_true_stderr_of_sample_mean(sigma_marginal, phi, n):
+  correction = 1 + 2 * phi / (1 - phi) * (1 - (1 - phi ** n) / (1 - phi) / n)
+  return sigma_marginal / np.sqrt(n / correction)
+
+
+def test_iid_bootstrap_inference_of_exp_of_mean():
+  rng = np.random.default_rng(0)
+  n, datasets, sigma = 100, 1500, 2.0
+  sampling = scipy.stats.lognorm(s=sigma / np.sqrt(n), scale=1.0)       # the law of exp(mean of n N(0, sigma) draws)
+  data = xr.DataArray(rng.normal(scale=sigma, size=(n, datasets)), dims=('samples', 'replicates'), coords={'samples': np.arange(n)})
+  inference = bootstrap.IIDBootstrap(metrics={'exp_mean': ExpMean()}, aggregated_statistics=_state({'MeanPrediction': data}),
+                                     experimental_unit_dim='samples', n_replicates=600, rng=rng)
+  resampled = inference.resampled_values['exp_mean']['variable']
+  assert set(resampled.dims) == {'bootstrap_replicate', 'replicates'} and resampled.sizes['bootstrap_replicate'] == 600
+  point = np.asarray(inference.point_estimates()['exp_mean']['variable'].values)
+  np.testing.assert_allclose(point, np.exp(data.values.mean(axis=0)), rtol=1e-12)
+  np.testing.assert_allclose(point.mean(), sampling.mean(), rtol=0.03)
+  stderr = np.asarray(inference.standard_error_estimates()['exp_mean']['variable'].values)
+  np.testing.assert_allclose(np.sqrt((stderr ** 2).mean()), sampling.std(), rtol=0.08)
+  for alpha in (0.05, 0.2):
+    miss = 1 - _coverage(inference, sampling.mean(), alpha, name='exp_mean')
+    assert alpha * 0.6 - 3 * np.sqrt(alpha / datasets) <= miss <= alpha * 1.5 + 3 * np.sqrt(alpha / datasets), (alpha, miss)
+  # p-values against intervals: the same empirical distribution read two ways (up to the interpolation between order statistics)
+  p = np.asarray(inference.p_values(sampling.mean())['exp_mean']['variable'].values)
+  lower, upper = inference.confidence_intervals(0.1)
+  inside = (np.asarray(lower['exp_mean']['variable'].values) <= sampling.mean()) & (sampling.mean() <= np.asarray(upper['exp_mean']['variable'].values))
+  assert ((p > 0.1) == inside).mean() > 0.99
+
+
+def test_cluster_bootstrap_with_equal_values_in_each_cluster():
+  rng = np.random.default_rng(1)
+  effective, repeat, datasets = 100, 2, 300
+  original = rng.normal(size=(effective, datasets))
+  ids = np.repeat(rng.choice(effective * 10, size=effective, replace=False), repeat)
+  data = xr.DataArray(np.repeat(original, repeat, axis=0), dims=('samples', 'replicates'),
+                      coords={'samples': np.arange(effective * repeat), 'cluster': (('samples',), ids)})
+  inference = bootstrap.ClusterBootstrap(metrics={'mean': MeanPrediction()}, aggregated_statistics=_state({'MeanPrediction': data}),
+                                         experimental_unit_coord='cluster', n_replicates=2000, rng=rng)
+  stderr = np.asarray(inference.standard_error_estimates()['mean']['variable'].values)
+  np.testing.assert_allclose(np.sqrt((stderr ** 2).mean()), 1 / np.sqrt(effective), rtol=0.03)   # the duplicates add nothing
+  naive = bootstrap.IIDBootstrap(metrics={'mean': MeanPrediction()}, aggregated_statistics=_state({'MeanPrediction': data}),
+                                 experimental_unit_dim='samples', n_replicates=500, rng=rng)
+  naive_stderr = np.asarray(naive.standard_error_estimates()['mean']['variable'].values)
+  np.testing.assert_allclose(np.sqrt((naive_stderr ** 2).mean()), 1 / np.sqrt(effective * repeat), rtol=0.05)  # ... which the i.i.d. one misses
+
+
+def test_stationary_bootstrap_paths_and_block_length():
+  np.random.seed(0)
+  paths = bootstrap.stationary_bootstrap_indices(n_data=500, mean_block_length=10.0, n_replicates=400)
+  assert paths.shape == (500, 400) and paths.min() >= 0 and paths.max() < 500
+  continues = (np.diff(paths, axis=0) % 500) == 1
+  np.testing.assert_allclose(1 - continues.mean(), 0.1, atol=0.01)     # a block ends with probability 1 / mean length
+  assert (bootstrap.stationary_bootstrap_indices(50, 1e9, 3, rng=np.random.default_rng(1))[1:] ==
+          (bootstrap.stationary_bootstrap_indices(50, 1e9, 3, rng=np.random.default_rng(1))[:-1] + 1) % 50).all()
+  rng = np.random.default_rng(2)
+  assert bootstrap.optimal_block_length(rng.normal(size=5000)) < 3.0   # white noise needs no blocks
+  assert bootstrap.optimal_block_length(np.ones(100)) == 1.0
+  n = 20000
+  for phi in (0.5, 0.9):                                                # AR(1): b = (2 phi / (1 - phi**2))**(2/3) N**(1/3)
+    got = np.mean([bootstrap.optimal_block_length(simulate_ar1(rng, 0.0, 1.0, phi, n, 1)[:, 0]) for _ in range(6)])
+    want = (2 * phi / (1 - phi ** 2)) ** (2 / 3) * n ** (1 / 3)
+    assert 0.7 * want < got < 1.3 * want, (phi, got, want)
+  assert bootstrap.optimal_block_length(simulate_ar1(rng, 0.0, 1.0, 0.999, 90, 1)[:, 0]) <= np.ceil(min(3 * np.sqrt(90), 30))   # the cap
+
+
+def test_stationary_bootstrap_inference_of_means_of_ar1_processes():
+  """bootstrap_test.py:153-293: the standard error of the mean of AR(1) series, a different block length for each output point."""
+  rng = np.random.default_rng(3)
+  n, datasets = 3000, 40
+  high = simulate_ar1(rng, -10.0, 1.0, 0.9, n, datasets)
+  low = simulate_ar1(rng, 10.0, 1.0, 0.2, n, datasets)
+  data = xr.DataArray(np.stack([high, low], axis=-1), dims=('steps', 'replicates', 'autocorr'),
+                      coords={'steps': np.arange(n), 'autocorr': ['high', 'low']})
+  inference = bootstrap.StationaryBootstrap(metrics={'mean': MeanPrediction()}, aggregated_statistics=_state({'MeanPrediction': data}),
+                                            experimental_unit_dim='steps', n_replicates=200, rng=rng)
+  point = inference.point_estimates()['mean']['variable']
+  np.testing.assert_allclose(np.asarray(point.transpose('replicates', 'autocorr').values), data.values.mean(axis=0), rtol=1e-12)
+  stderr = inference.standard_error_estimates()['mean']['variable'].transpose('replicates', 'autocorr')
+  rms = np.sqrt((np.asarray(stderr.values) ** 2).mean(axis=0))
+  np.testing.assert_allclose(rms[0], ar1_true_stderr_of_sample_mean(1.0, 0.9, n), rtol=0.15)
+  np.testing.assert_allclose(rms[1], ar1_true_stderr_of_sample_mean(1.0, 0.2, n), rtol=0.10)
+  assert rms[0] > 2.5 * rms[1]
+  fixed = bootstrap.StationaryBootstrap(metrics={'mean': MeanPrediction()}, aggregated_statistics=_state({'MeanPrediction': data.isel(replicates=[0])}),
+                                        experimental_unit_dim='steps', n_replicates=50, mean_block_length=1.0, rng=rng)
+  iid_like = np.asarray(fixed.standard_error_estimates()['mean']['variable'].values).ravel()
+  np.testing.assert_allclose(iid_like, data.values[:, 0].std(axis=0) / np.sqrt(n), rtol=0.35)   # blocks of one: the i.i.d. answer
+  short = _state({'MeanPrediction': data.isel(steps=slice(0, 5), replicates=[0])})
+  with pytest.raises(ValueError, match='at least 8 data points'):
+    bootstrap.StationaryBootstrap(metrics={'mean': MeanPrediction()}, aggregated_statistics=short, experimental_unit_dim='steps', n_replicates=5)
+
+
+def test_stationary_bootstrap_of_a_nonlinear_function_of_two_means():
+  """bootstrap_test.py:296-388: ratio of the means of two autocorrelated series."""
+  rng = np.random.default_rng(4)
+  n = 1000
+
+  def setup(datasets):
+    num = xr.DataArray(simulate_ar1(rng, 2.0, 6.6, 0.3, n, datasets), dims=('steps', 'replicates'), coords={'steps': np.arange(n)})
+    den = xr.DataArray(simulate_ar1(rng, 1.0, 3.3, 0.3, n, datasets) * 0.1 + 4.0, dims=('steps', 'replicates'), coords={'steps': np.arange(n)})
+    return {'ratio_of_means': RatioOfMeans()}, _state({'MeanPrediction': num, 'MeanTarget': den})
+
+  metrics, big = setup(4000)
+  draws = np.asarray(metrics_base.compute_metrics_from_statistics(metrics, big.sum_along_dims(['steps']).mean_statistics())[
+      'ratio_of_means']['variable'].values)
+  metrics, state = setup(60)
+  inference = bootstrap.StationaryBootstrap(metrics=metrics, aggregated_statistics=state, experimental_unit_dim='steps', n_replicates=200, rng=rng)
+  stderr = np.asarray(inference.standard_error_estimates()['ratio_of_means']['variable'].values)
+  np.testing.assert_allclose(np.sqrt((stderr ** 2).mean()), draws.std(ddof=1), rtol=0.2)
+  assert 0.8 <= _coverage(inference, draws.mean(), 0.1, name='ratio_of_means') <= 0.99
