@@ -1,4 +1,4 @@
-"""In-memory chunk loaders with the reference's names and `load_chunk` contract (counterpart of
+"""In-memory chunk loaders (re-exported by the package and its `base` / `xarray_loaders` / `latency_wrappers` modules) with the reference's names and `load_chunk` contract (counterpart of
 weatherbenchX/data_loaders/base.py:58-170 and weatherbenchX/data_loaders/xarray_loaders.py:58-460).
 
 The reference's loaders read zarr / NetCDF through xarray + dask, neither of which exists in this image; what a scoring job

@@ -1,0 +1,235 @@
+"""Station / point observations stored as time-partitioned Parquet (counterpart of
+weatherbenchX/data_loaders/sparse_parquet.py:27-523): one row per observation, one file per month, day or hour at
+`<path>/year=Y/month=M[/day=D[/hour=H]]/<stamp>.parquet`.  A chunk is a set of DataArrays over one `index` dim with the station
+coordinates, `valid_time` (the observation's own time) and -- with lead times -- `init_time` / `lead_time` as coordinates: the
+"sparse" layout the coordinate binnings, `StationDensityWeighting` and `InterpolateToReferenceCoords` work on.
+
+Outside the path SURVEY section 8 names (host side, pandas + pyarrow).  Unlike the reference, which re-reads the partition files
+for every (init time, lead time) pair, a chunk reads each file it needs ONCE and selects every time window from the frame in
+memory; the rows that come back are the same.
+"""
+from __future__ import annotations
+
+import functools
+import os
+from typing import Callable, Hashable, Mapping, Optional, Sequence, Union
+
+import numpy as np
+import pandas as pd
+
+from weatherbenchx_amd import xarray_lite as xr
+from weatherbenchx_amd.data_loaders import _memory
+
+_UNITS = {'month': 'M', 'day': 'D', 'hour': 'h'}
+
+
+def parquet_filename_for_time(path: str, time: np.datetime64, unit: str) -> str:
+  """The partition file that holds `time` (sparse_parquet.py:53-69)."""
+  stamp = time.item()
+  year, month = stamp.year, stamp.month
+  if unit == 'M':
+    rel = f'year={year}/month={month}/{year}-{month:02d}.parquet'
+  elif unit == 'D':
+    rel = f'year={year}/month={month}/day={stamp.day}/{year}-{month:02d}-{stamp.day:02d}.parquet'
+  elif unit == 'h':
+    rel = (f'year={year}/month={month}/day={stamp.day}/hour={stamp.hour}/'
+           f'{year}-{month:02d}-{stamp.day:02d}T{stamp.hour:02d}.parquet')
+  else:
+    raise NotImplementedError
+  return os.path.join(path, rel)
+
+
+def get_parquet_files_subset(path: str, time_start, time_end, partition_by: str):
+  """Every partition file between the two times, ends included (sparse_parquet.py:27-50)."""
+  if partition_by not in _UNITS:
+    raise NotImplementedError(f'{partition_by} not implemented.')
+  unit = _UNITS[partition_by]
+  first, last = np.datetime64(time_start, unit), np.datetime64(time_end, unit)
+  step = np.timedelta64(1, unit)
+  return [parquet_filename_for_time(path, t, unit) for t in np.arange(first, last + step, step)]
+
+
+class SparseObservationsFromParquet(_memory.DataLoader):
+  """General reader (sparse_parquet.py:72-389).
+
+  Which rows a request returns, with `time_dim` the column compared (and returned as `valid_time`):
+    * exact lead times (or none: the init times are the valid times): rows AT valid_time = init + lead, or with `tolerance` rows in
+      [valid_time + tolerance[0], valid_time + tolerance[1])  (a single timedelta means +-; the end is included with
+      `include_slice_end_time`); they get the REQUESTED init_time / lead_time;
+    * a lead-time slice: rows in [init - slice.start, init + slice.stop) -- the reference subtracts the start
+      (sparse_parquet.py:229) --, lead_time = valid_time - init_time.
+  `file_tolerance` widens which partition files are opened, for time columns that do not line up with the partitioning (METAR
+  `timeObs`); it never widens the selection.  `remove_duplicates` keeps one row per `observation_dim` value and requested time: the
+  one whose `pick_closest_duplicate_by` column is nearest to the valid time."""
+
+  def __init__(self, path: str, partitioned_by: str, time_dim: str, variables: Sequence[str], coordinate_variables: Sequence[str] = (),
+               split_variables: bool = False, dropna: bool = False, tolerance=None, rename_variables: Optional[Mapping[str, str]] = None,
+               include_slice_end_time: bool = False, remove_duplicates: bool = False, pick_closest_duplicate_by: Optional[str] = None,
+               observation_dim: Optional[str] = None, file_tolerance: np.timedelta64 = np.timedelta64(1, 'h'),
+               preprocessing_fn: Optional[Callable[[pd.DataFrame], pd.DataFrame]] = None, **kwargs):
+    super().__init__(compute=False, **kwargs)
+    self._path = path
+    if partitioned_by not in _UNITS:
+      raise ValueError(f'Unsupported partitioned_by: {partitioned_by}')
+    self._partitioned_by = partitioned_by
+    self._time_dim = time_dim
+    self._variables = list(variables)
+    self._coordinate_variables = list(coordinate_variables) + ['valid_time']
+    self._split_variables = split_variables
+    self._dropna = dropna
+    if tolerance is not None:
+      if isinstance(tolerance, np.timedelta64):
+        tolerance = (-tolerance, tolerance)
+      if len(tolerance) != 2:
+        raise ValueError('Tolerance must be a a single np.timedelta64 or a 2-tuple.')
+      if (tolerance[1] - tolerance[0]) <= np.timedelta64(0, 'h'):
+        raise ValueError('Tolerance range should be non-empty. This will always return an empty array.')
+    self._tolerance = tolerance
+    self._rename_variables = rename_variables
+    self._include_slice_end_time = include_slice_end_time
+    self._remove_duplicates = remove_duplicates
+    self._pick_closest_duplicate_by = pick_closest_duplicate_by
+    if remove_duplicates and observation_dim is None:
+      raise ValueError('station_dim must be specified if remove_duplicates is True.')
+    self._observation_dim = observation_dim
+    self._file_tolerance = file_tolerance
+    self._preprocessing_fn = preprocessing_fn
+
+  # ---- one time window ---------------------------------------------------------------------------------------------------------
+  def _window(self, valid_time: np.datetime64, lead_time_slice: Optional[slice]):
+    """(start, stop or None for "exactly start")."""
+    if self._tolerance is not None:
+      return valid_time + self._tolerance[0], valid_time + self._tolerance[1]
+    if lead_time_slice is None:
+      return valid_time, None
+    return valid_time - lead_time_slice.start, valid_time + lead_time_slice.stop
+
+  def _rows_for_single_time(self, read, valid_time: np.datetime64, lead_time_slice: Optional[slice] = None) -> pd.DataFrame:
+    start, stop = self._window(valid_time, lead_time_slice)
+    last = start if stop is None else stop
+    files = get_parquet_files_subset(self._path, start - self._file_tolerance, last + self._file_tolerance, self._partitioned_by)
+    parts = []
+    for fn in files:
+      frame = read(fn)
+      t = frame[self._time_dim]
+      if stop is None:
+        keep = t == pd.Timestamp(start)
+      elif self._include_slice_end_time:
+        keep = (t >= pd.Timestamp(start)) & (t <= pd.Timestamp(stop))
+      else:
+        keep = (t >= pd.Timestamp(start)) & (t < pd.Timestamp(stop))
+      parts.append(frame[keep])
+    df = pd.concat(parts, ignore_index=True)
+    if self._preprocessing_fn is not None:
+      df = self._preprocessing_fn(df)
+    if self._remove_duplicates:
+      assert lead_time_slice is None, 'Removing duplicates not compatible with slice lead_time.'
+      if self._pick_closest_duplicate_by is not None:
+        df = df.assign(time_diff=np.abs(df[self._pick_closest_duplicate_by] - valid_time)).sort_values('time_diff', ascending=True)
+      df = df[~df[self._observation_dim].duplicated(keep='first')]
+    if self._rename_variables is not None:
+      df = df.rename(columns=self._rename_variables)
+    df = df.rename(columns={self._time_dim: 'valid_time'})
+    return df.loc[:, self._variables + self._coordinate_variables].copy()
+
+  # ---- a chunk --------------------------------------------------------------------------------------------------------------------
+  def _load_chunk_from_source(self, init_times, lead_times=None):
+    read = functools.lru_cache(maxsize=None)(pd.read_parquet)             # each partition file once per chunk
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    frames = []
+    if isinstance(lead_times, slice):
+      assert self._tolerance is None, 'Tolerance not compatible with lead_time slice.'
+      for init_time in init_times:
+        df = self._rows_for_single_time(read, init_time, lead_time_slice=lead_times)
+        df['init_time'] = init_time
+        df['lead_time'] = df['valid_time'] - df['init_time']
+        frames.append(df)
+    elif lead_times is None:
+      frames = [self._rows_for_single_time(read, init_time) for init_time in init_times]
+    else:
+      for init_time in init_times:
+        for lead_time in np.asarray(lead_times).astype('timedelta64[ns]'):
+          df = self._rows_for_single_time(read, init_time + lead_time)
+          df['init_time'] = init_time
+          df['lead_time'] = lead_time
+          frames.append(df)
+    combined = pd.concat(frames, ignore_index=True)
+    coordinate_names = self._coordinate_variables + ([] if lead_times is None else ['init_time', 'lead_time'])
+    return self._as_arrays(combined, coordinate_names)
+
+  def _as_arrays(self, df: pd.DataFrame, coordinate_names) -> Union[xr.Dataset, Mapping[Hashable, xr.DataArray]]:
+    if self._dropna and not self._split_variables:
+      df = df[df[self._variables].notna().all(axis=1)]                    # rows where every variable is there
+
+    def build(frame: pd.DataFrame, name: str) -> xr.DataArray:
+      coords = {'index': np.asarray(frame.index)}
+      for c in coordinate_names:
+        coords[c] = (('index',), _column(frame[c]))
+      return xr.DataArray(_column(frame[name]), dims=('index',), coords=coords, name=name)
+
+    if self._split_variables:
+      return {v: build(df[df[v].notna()] if self._dropna else df, v) for v in self._variables}
+    return xr.Dataset({v: build(df, v) for v in self._variables})
+
+
+def _column(series: pd.Series) -> np.ndarray:
+  """A column as a NumPy array; strings (object columns) as fixed-width unicode."""
+  values = series.to_numpy()
+  if values.dtype == object:
+    return np.asarray(series.fillna('').astype(str).to_numpy(), dtype=str)
+  return values
+
+
+# ---- METAR ------------------------------------------------------------------------------------------------------------------------------
+METAR_TO_ERA5_NAMES = {
+    'seaLevelPress': 'mean_sea_level_pressure', 'temperature': '2m_temperature', 'dewpoint': '2m_dewpoint_temperature',
+    'windSpeed': '10m_wind_speed', 'windGust': '10m_wind_gust', 'windDir': '10m_wind_direction',
+    'minTemp24Hour': 'min_2m_temperature_24hr', 'maxTemp24Hour': 'max_2m_temperature_24hr',
+    'precip1Hour': 'total_precipitation_1hr', 'precip3Hour': 'total_precipitation_3hr', 'precip6Hour': 'total_precipitation_6hr',
+    'precip24Hour': 'total_precipitation_24hr', 'precipRate': 'precipitation_rate',
+}
+ERA5_TO_METAR_NAMES = {v: k for k, v in METAR_TO_ERA5_NAMES.items()}
+METAR_QC_SUFFIX = 'DD'
+METAR_BAD_QUALITY_FLAGS = ('Z', 'B', 'X', 'Q', 'k')
+METAR_COORDINATE_VARIABLES = ('latitude', 'longitude', 'elevation', 'stationName')
+
+
+def set_bad_quality_to_nan(df: pd.DataFrame, variables: Sequence[str], qc_suffix: str, bad_quality_flags: Sequence[str]) -> pd.DataFrame:
+  """NaN wherever the variable's quality-control column holds one of the bad flags (sparse_parquet.py:392-402)."""
+  for variable in variables:
+    df[variable] = df[variable].where(~np.isin(df[variable + qc_suffix], bad_quality_flags), np.nan)
+  return df
+
+
+def convert_longitude_to_0_to_360(df: pd.DataFrame, longitude_dim: str = 'longitude') -> pd.DataFrame:
+  df[longitude_dim] = np.mod(df[longitude_dim], 360)
+  return df
+
+
+class METARFromParquet(SparseObservationsFromParquet):
+  """METAR surface reports with their conventions filled in (sparse_parquet.py:412-523): raw column names mapped to the ERA5-style
+  ones (`variables` are given in the latter), values with a bad quality flag set to NaN, longitude in [0, 360), the elevation fill
+  value 9999 as NaN, station coordinates (latitude, longitude, elevation, stationName) attached, duplicates by `stationName`."""
+
+  def __init__(self, path: str, variables: Sequence[str], time_dim: str, split_variables: bool = False, dropna: bool = False,
+               tolerance: Optional[np.timedelta64] = None, partitioned_by: str = 'month', rename_variables: Optional[Mapping[str, str]] = None,
+               include_slice_end_time: bool = False, remove_duplicates: bool = False, pick_closest_duplicate_by: Optional[str] = None,
+               file_tolerance: np.timedelta64 = np.timedelta64(1, 'h'),
+               preprocessing_fn: Optional[Callable[[pd.DataFrame], pd.DataFrame]] = None, **kwargs):
+    del rename_variables                                                  # (accepted and ignored, as in the reference: the METAR map is used)
+    raw_names = [ERA5_TO_METAR_NAMES[v] for v in variables]
+
+    def prepare(df: pd.DataFrame) -> pd.DataFrame:
+      df = df.copy()
+      if preprocessing_fn is not None:
+        df = preprocessing_fn(df)
+      df = set_bad_quality_to_nan(df, raw_names, METAR_QC_SUFFIX, METAR_BAD_QUALITY_FLAGS)
+      df = convert_longitude_to_0_to_360(df)
+      df['elevation'] = df['elevation'].where(df['elevation'] < 9.999e03, np.nan)
+      return df
+
+    super().__init__(path=path, variables=variables, time_dim=time_dim, coordinate_variables=METAR_COORDINATE_VARIABLES,
+                     observation_dim='stationName', split_variables=split_variables, dropna=dropna, tolerance=tolerance,
+                     partitioned_by=partitioned_by, rename_variables=METAR_TO_ERA5_NAMES, include_slice_end_time=include_slice_end_time,
+                     remove_duplicates=remove_duplicates, pick_closest_duplicate_by=pick_closest_duplicate_by,
+                     file_tolerance=file_tolerance, preprocessing_fn=prepare, **kwargs)
