@@ -1,0 +1,94 @@
+"""One evaluation that strings the round-5 additions together on the host-side plan interpreter (tests/fake_device.py; this file was
+written after the round's GPU minutes were spent, so it does not ask for the device): in-memory loaders with an interpolation and a
+NaN mask, chunked over init / lead times, contingency / FSS / energy-score / REV metrics next to RMSE, two named aggregators (area
+mean; latitude bands), then a paired t-test on the per-init accumulators -- against the same numbers from whole-array NumPy."""
+import numpy as np
+import pytest
+
+from oracle import wbx_oracle as O
+from tests import mock_data
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import binning
+from weatherbenchx_amd import engine
+from weatherbenchx_amd import interpolations
+from weatherbenchx_amd import loaders
+from weatherbenchx_amd import pipeline
+from weatherbenchx_amd import time_chunks
+from weatherbenchx_amd import weighting
+from weatherbenchx_amd.data_loaders import xarray_loaders
+from weatherbenchx_amd.metrics import categorical
+from weatherbenchx_amd.metrics import deterministic
+from weatherbenchx_amd.metrics import spatial
+from weatherbenchx_amd.metrics import wrappers
+from weatherbenchx_amd.statistical_inference import t_test
+
+
+@pytest.fixture
+def emulated(monkeypatch):
+  import fake_device  # pylint: disable=g-import-not-at-top
+  engine.clear_caches()
+  fake_device.install(monkeypatch)
+  yield
+  engine.clear_caches()
+
+
+def test_loaders_interpolation_scores_and_inference_in_one_evaluation(emulated):
+  del emulated
+  target = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-20T00', variables_3d=[], random=True, seed=1,
+                                      spatial_resolution_in_degrees=10.0)
+  coarse = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-13T00', variables_3d=[], random=True, seed=2,
+                                          lead_stop_days=2, spatial_resolution_in_degrees=20.0)
+  target['2m_temperature'].values[5, 3, 7] = np.nan
+  lt = xarray_loaders.TargetsFromXarray(ds=target, add_nan_mask=True)
+  regrid = interpolations.InterpolateToFixedCoords('linear', {'latitude': target['2m_temperature']['latitude'].values,
+                                                             'longitude': target['2m_temperature']['longitude'].values}, wrap_longitude=True)
+  lp = xarray_loaders.PredictionsFromXarray(ds=coarse, interpolation=regrid)
+  init_times = np.arange('2020-01-01T00', '2020-01-13T00', np.timedelta64(24, 'h'), dtype='datetime64[ns]')
+  lead_times = np.arange(3, dtype='timedelta64[D]').astype('timedelta64[ns]')
+  binarize = wrappers.ContinuousToBinary('both', [0.5], 'threshold')
+  metrics = {'rmse': deterministic.RMSE(), 'csi': wrappers.WrappedMetric(categorical.CSI(), [binarize]),
+             'fss': wrappers.WrappedMetric(spatial.FSS(3, wrap_longitude=True), [binarize])}
+  aggregators = {'area': aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()], masked=True),
+                 'bands': aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], bin_by=[binning.LatitudeBins(60)],
+                                                 weigh_by=[weighting.GridAreaWeighting()], masked=True)}
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=5, lead_time_chunk_size=2)
+  states = pipeline.evaluate_chunks(tc, loaders.load_chunk_fn(lp, lt), metrics, aggregators, prefetch=0)
+  # ---- the same from whole arrays ---------------------------------------------------------------------------------------------
+  t_all = target['2m_temperature'].values                                  # [time, lat, lon]
+  p_src = coarse['2m_temperature']                                         # [lead, time, lat20, lon20]
+  p_all = np.asarray(regrid.interpolate_data_array(p_src).transpose('time', 'prediction_timedelta', 'latitude', 'longitude').values)
+  t_sel = t_all[np.arange(12)[:, None] + np.arange(3)[None, :]]            # [init, lead, lat, lon]
+  valid = ~np.isnan(t_sel)
+  lat = target['2m_temperature']['latitude'].values
+  w = np.broadcast_to(O.grid_area_weights(lat)[None, None, :, None], t_sel.shape)
+  wmean = lambda x, axes: (np.where(valid, x, 0) * w).sum(axis=axes) / (valid * w).sum(axis=axes)
+  area = states['area'].metric_values(metrics)
+  np.testing.assert_allclose(np.asarray(area['rmse.2m_temperature'].transpose('init_time', 'lead_time').values),
+                             np.sqrt(wmean((p_all - t_sel) ** 2, (2, 3))), rtol=2e-6)
+  pb, tb = (p_all > 0.5), (t_sel > 0.5)
+  tp, fp, fn = (wmean((a & b).astype(float), (2, 3)) for a, b in ((pb, tb), (pb, ~tb), (~pb, tb)))
+  got_csi = area['csi.2m_temperature'].isel(threshold=0).transpose('init_time', 'lead_time')
+  np.testing.assert_allclose(np.asarray(got_csi.values), tp / (tp + fp + fn), rtol=2e-6)
+  bands = states['bands'].metric_values(metrics)
+  assert 'latitude_bins' in bands['rmse.2m_temperature'].dims
+  for k, lo in enumerate((-90, -30, 30)):
+    inside = ((lat >= lo) & (lat <= lo + 60))[None, None, :, None] & valid
+    ww = inside * w
+    want = np.sqrt((np.where(inside, (p_all - t_sel) ** 2, 0) * w).sum(axis=(0, 2, 3)) / ww.sum(axis=(0, 2, 3)))
+    np.testing.assert_allclose(np.asarray(bands['rmse.2m_temperature'].isel(latitude_bins=k).values), want, rtol=2e-6)
+  fss = area['fss.2m_temperature']
+  assert {'init_time', 'lead_time'} <= set(fss.dims) and np.isfinite(np.asarray(fss.values)).any()
+  # ---- inference on the per-init accumulators ----------------------------
+  rmse_only = {'rmse': deterministic.RMSE()}
+  inference = t_test.GeerAR2Corrected(metrics=rmse_only, aggregated_statistics=states['area'], experimental_unit_dim='init_time')
+  point = inference.point_estimates()['rmse']['2m_temperature']
+  np.testing.assert_allclose(np.asarray(point.values), np.sqrt(_pooled(p_all, t_sel, valid, w)), rtol=2e-6)
+  lower, upper = inference.confidence_intervals(0.05)
+  assert (np.asarray(lower['rmse']['2m_temperature'].values) < np.asarray(point.values)).all()
+  assert (np.asarray(point.values) < np.asarray(upper['rmse']['2m_temperature'].values)).all()
+
+
+def _pooled(p, t, valid, w):
+  """mean over init times of the per-init accumulators: sum over inits of sum(w se) / sum over inits of sum(w), per lead time."""
+  se = np.where(valid, (p - t) ** 2, 0) * w
+  return se.sum(axis=(0, 2, 3)) / (valid * w).sum(axis=(0, 2, 3))
