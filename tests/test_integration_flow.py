@@ -92,3 +92,49 @@ def _pooled(p, t, valid, w):
   """mean over init times of the per-init accumulators: sum over inits of sum(w se) / sum over inits of sum(w), per lead time."""
   se = np.where(valid, (p - t) ** 2, 0) * w
   return se.sum(axis=(0, 2, 3)) / (valid * w).sum(axis=(0, 2, 3))
+
+
+def test_define_pipeline_writes_what_the_chunk_loop_computes(emulated, tmp_path):
+  """beam_pipeline_test.py:82-284 in spirit: chunked == one chunk, files per named aggregator, the targets handed to the predictions
+  loader as the interpolation reference."""
+  del emulated
+  from weatherbenchx_amd import beam_pipeline  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd import io as wio  # pylint: disable=g-import-not-at-top
+  target = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-08T00', variables_3d=[], random=True, seed=3,
+                                      spatial_resolution_in_degrees=10.0)
+  coarse = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', variables_3d=[], random=True, seed=4,
+                                          lead_stop_days=1, spatial_resolution_in_degrees=30.0)
+  calls = []
+  lt = xarray_loaders.TargetsFromXarray(ds=target)
+  lp = xarray_loaders.PredictionsFromXarray(ds=coarse, interpolation=interpolations.InterpolateToReferenceCoords(
+      'linear', dims=['latitude', 'longitude'], wrap_longitude=True))
+  init_times = np.arange('2020-01-01T00', '2020-01-05T00', np.timedelta64(24, 'h'), dtype='datetime64[ns]')
+  lead_times = np.arange(2, dtype='timedelta64[D]').astype('timedelta64[ns]')
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  aggregators = {'global': aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()]),
+                 'per_init': aggregation.Aggregator(reduce_dims=['latitude', 'longitude'])}
+  out, state_out = str(tmp_path / 'metrics.nc'), {'global': str(tmp_path / 'g.nc'), 'per_init': str(tmp_path / 'p.nc')}
+  chunked = beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=1),
+                                          lp, lt, metrics, aggregators, out_path=out, aggregation_state_out_path=state_out,
+                                          setup_fn=lambda: calls.append('setup'))
+  assert calls == ['setup']
+  whole = beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times), lp, lt, metrics, aggregators,
+                                        out_path={'global': str(tmp_path / 'w_g.nc'), 'per_init': str(tmp_path / 'w_p.nc')})
+  for name in aggregators:
+    a, b = chunked[name].metric_values(metrics), whole[name].metric_values(metrics)
+    for key in a:
+      np.testing.assert_allclose(np.asarray(a[key].transpose(*b[key].dims).values), np.asarray(b[key].values), atol=1e-5)   # beam_pipeline_test.py:150-155
+    written = wio.open_dataset(str(tmp_path / f'metrics_{name}.nc'))
+    for key in a:
+      np.testing.assert_allclose(np.asarray(written[key].transpose(*a[key].dims).values), np.asarray(a[key].values), rtol=1e-12)
+    back = wio.read_aggregation_state(state_out[name])
+    for key in a:
+      np.testing.assert_allclose(np.asarray(back.metric_values(metrics)[key].transpose(*a[key].dims).values), np.asarray(a[key].values), rtol=1e-12)
+  assert chunked['per_init'].metric_values(metrics)['rmse.2m_temperature'].sizes['init_time'] == 4
+  # the predictions really were regridded to the targets' 10 degree grid (else the statistics could not have been formed)
+  t_chunk = lt.load_chunk(init_times[:1], lead_times[:1])
+  assert lp.load_chunk(init_times[:1], lead_times[:1], t_chunk)['2m_temperature'].sizes['latitude'] == 19
+  with pytest.raises(ValueError, match='At least one of'):
+    beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times), lp, lt, metrics, aggregators)
+  with pytest.raises(ValueError, match="don't match aggregator names"):
+    beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times), lp, lt, metrics, aggregators, out_path={'x': 'y'})

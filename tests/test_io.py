@@ -54,3 +54,28 @@ def test_metrics_file_round_trip(tmp_path):
   np.testing.assert_allclose(back['rmse.z'].values, [[1.0, 2.0]])
   assert list(back['rmse.z']['region'].values) == ['a', 'bb'] and back['rmse.z']['level'].values.tolist() == [500]
   assert float(back['bias.t2m'].values) == 0.25
+
+
+def test_non_index_coordinates_round_trip(tmp_path):
+  """Accumulators that keep init_time and lead_time carry the 2-D coordinate valid_time(init_time, lead_time) (targets loaders,
+  xarray_loaders.py:259-262); station results carry latitude / longitude over `index`.  They are written as CF auxiliary
+  coordinates (the `coordinates` attribute) and come back as coordinates, not as data variables."""
+  st = _state()
+  a = st.sum_weighted_statistics['SquaredError']['z']
+  valid = a['init_time'].values[:, None] + a['lead_time'].values[None, :]
+  for tree in (st.sum_weighted_statistics, st.sum_weights):
+    tree['SquaredError']['z'] = tree['SquaredError']['z'].assign_coords(valid_time=(('init_time', 'lead_time'), valid))
+  path = os.path.join(tmp_path, 'state.nc')
+  wio.write_aggregation_state(st, path)
+  back = wio.read_aggregation_state(path)
+  assert set(back.sum_weighted_statistics) == set(st.sum_weighted_statistics)
+  z = back.sum_weighted_statistics['SquaredError']['z']
+  np.testing.assert_array_equal(z.coords['valid_time'].values, valid)
+  assert z.coords['valid_time'].dims == ('init_time', 'lead_time')
+  assert 'valid_time' not in back.sum_weighted_statistics['SquaredError']['t2m'].coords    # only where its dims are
+  stations = xr.Dataset({'rmse.t': xr.DataArray(np.arange(3.0), dims=('index',), coords={
+      'index': np.arange(3), 'latitude': (('index',), np.array([10.0, 20.0, 30.0])), 'stationName': (('index',), np.array(['A', 'BB', 'C']))})})
+  wio.write_metrics(stations, os.path.join(tmp_path, 'm.nc'))
+  m = wio.open_dataset(os.path.join(tmp_path, 'm.nc'))
+  assert set(m) == {'rmse.t'} and m['rmse.t'].coords['latitude'].values.tolist() == [10.0, 20.0, 30.0]
+  assert m['rmse.t'].coords['stationName'].values.tolist() == ['A', 'BB', 'C']

@@ -1,0 +1,66 @@
+"""`define_pipeline` with the reference's signature, without Beam (counterpart of weatherbenchX/beam_pipeline.py:35-116, 446-537).
+
+The reference builds a Beam graph under `root` -- load chunks, per-chunk statistics and aggregation, CombinePerKey sum, concat,
+compute and write metrics -- that a runner executes later.  Here the same graph IS `pipeline.evaluate_chunks` (accumulators in HBM,
+one collective per job, see pipeline.py), so `define_pipeline` runs it on the spot: `root` is accepted for signature parity and
+ignored, the files named by `out_path` / `aggregation_state_out_path` exist when the call returns, and the aggregation states come
+back as well.  Under `torch.distributed` every rank calls it with its `rank` / `world_size`; rank 0 writes."""
+from __future__ import annotations
+
+import inspect
+from typing import Callable, Mapping, Optional
+
+from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import io as wio
+from weatherbenchx_amd import pipeline
+from weatherbenchx_amd import time_chunks
+from weatherbenchx_amd.metrics import base as metrics_base
+
+
+def load_predictions_and_targets(predictions_loader, targets_loader, setup_fn: Optional[Callable[[], None]] = None):
+  """(init_times, lead_times) -> (predictions, targets) the way LoadPredictionsAndTargets.process does (beam_pipeline.py:69-116):
+  the targets first, then the predictions WITH the targets as `reference` (what an interpolation to the targets' coordinates
+  needs); `setup_fn` once, before the first chunk.  Loaders whose `load_chunk` takes no reference (the file-backed ones) are
+  called without."""
+  takes_reference = len(inspect.signature(predictions_loader.load_chunk).parameters) >= 3
+  state = {'ready': setup_fn is None}
+
+  def load(init_times, lead_times):
+    if not state['ready']:
+      setup_fn()
+      state['ready'] = True
+    targets = targets_loader.load_chunk(init_times, lead_times)
+    if takes_reference:
+      return predictions_loader.load_chunk(init_times, lead_times, targets), targets
+    return predictions_loader.load_chunk(init_times, lead_times), targets
+
+  load.loaders = (predictions_loader, targets_loader)
+  return load
+
+
+def define_pipeline(root, times: time_chunks.TimeChunks, predictions_loader, targets_loader,
+                    metrics: Mapping[str, metrics_base.Metric],
+                    aggregator: aggregation.Aggregator | Mapping[str, aggregation.Aggregator],
+                    out_path: str | Mapping[str, str] | None = None,
+                    aggregation_state_out_path: str | Mapping[str, str] | None = None,
+                    setup_fn: Optional[Callable[[], None]] = None, *, rank: int = 0, world_size: int = 1, prefetch: int = 0):
+  """Evaluates `metrics` over all chunks of `times` and writes the metric values (`out_path`) and / or the final aggregation
+  state(s) (`aggregation_state_out_path`) as NetCDF.  With several named aggregators a single path gets the aggregator's name
+  appended (`metrics.nc` -> `metrics_<name>.nc`), a mapping names each file (beam_pipeline.py:388-399, 446-537).  Returns
+  {aggregator name (None for a single unnamed one): AggregationState}."""
+  del root
+  if isinstance(aggregator, Mapping):
+    for what, paths in (('out_path', out_path), ('aggregation_state_out_path', aggregation_state_out_path)):
+      if isinstance(paths, Mapping) and paths.keys() != aggregator.keys():
+        raise ValueError(f"Keys of {what} don't match aggregator names.")
+  if out_path is None and aggregation_state_out_path is None:
+    raise ValueError('At least one of (metrics) out_path or aggregation_state_out_path must be specified.')
+  states = pipeline.evaluate_chunks(times, load_predictions_and_targets(predictions_loader, targets_loader, setup_fn), metrics, aggregator,
+                                    rank=rank, world_size=world_size, prefetch=prefetch)
+  if rank == 0:
+    for name, state in states.items():
+      if out_path is not None:
+        wio.write_metrics(state.metric_values(metrics), pipeline.resolve_out_path(out_path, name))
+      if aggregation_state_out_path is not None:
+        wio.write_aggregation_state(state, pipeline.resolve_out_path(aggregation_state_out_path, name))
+  return states

@@ -103,6 +103,11 @@ def write_dataset(dataset, path: str) -> None:
         v[...] = vals
       else:
         v.data = np.array(float(vals), dtype=np.float64)  # scalar variable (scipy's assignValue indexes a 0-d array)
+      # CF: non-index coordinates (valid_time over (init_time, lead_time), a station's latitude over index) are named on the
+      # variable, which is how a reader tells them from data variables
+      aux = [str(c) for c in da._coords if c != 'mask' and c not in da.dims]  # pylint: disable=protected-access
+      if aux:
+        v.coordinates = ' '.join(aux)
   finally:
     f.close()
   commit()
@@ -113,10 +118,14 @@ def open_dataset(path: str) -> xr.Dataset:
   f = scipy.io.netcdf_file(path, 'r', mmap=False)
   try:
     dim_names = set(f.dimensions)
+    named = set()
+    for var in f.variables.values():
+      listed = getattr(var, 'coordinates', b'')
+      named.update((listed.decode() if isinstance(listed, bytes) else listed).split())
     coord_vars = {}
     for name, var in f.variables.items():
       vd = tuple(d for d in var.dimensions if not str(d).startswith('string'))
-      if name in dim_names or (len(vd) <= 1 and var.data.dtype.kind == 'S'):
+      if name in dim_names or name in named or (len(vd) <= 1 and var.data.dtype.kind == 'S'):
         coord_vars[name] = (vd, _decode_coord(var))
     out = {}
     for name, var in f.variables.items():
