@@ -138,3 +138,70 @@ def test_define_pipeline_writes_what_the_chunk_loop_computes(emulated, tmp_path)
     beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times), lp, lt, metrics, aggregators)
   with pytest.raises(ValueError, match="don't match aggregator names"):
     beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init_times, lead_times), lp, lt, metrics, aggregators, out_path={'x': 'y'})
+
+
+def test_baseline_forecasts_ensembles_from_climatology_and_inference(emulated, tmp_path):
+  """The reference's baseline loaders as forecasts: the probabilistic climatology as a 5-member ensemble (CRPS against the pairwise
+  definition), persistence against the climatology in a paired HAC test per lead time, ACC with a bootstrap interval from the
+  per-init accumulators read back from a file, a forecast served with operational latency."""
+  del emulated
+  from weatherbenchx_amd import beam_pipeline  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd import io as wio  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd import xarray_lite as xr  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd.data_loaders import latency_wrappers  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd.metrics import probabilistic  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd.statistical_inference import bootstrap  # pylint: disable=g-import-not-at-top
+  target = mock_data.mock_target_data(time_start='2015-01-01T00', time_stop='2021-01-01T00', variables_3d=[], random=True, seed=1,
+                                      spatial_resolution_in_degrees=30.0)
+  init_times = np.arange('2020-06-01T00', '2020-06-21T00', np.timedelta64(24, 'h'), dtype='datetime64[ns]')
+  lead_times = np.arange(1, 4, dtype='timedelta64[D]').astype('timedelta64[ns]')
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=7)
+  lt = xarray_loaders.TargetsFromXarray(ds=target)
+  lat = target['2m_temperature']['latitude'].values
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  per_init = aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  # every year 2015..2019 a member
+  pc = xarray_loaders.ProbabilisticClimatologyFromXarray(ds=target, start_year=2015, end_year=2019)
+  metrics = {'crps': probabilistic.CRPSEnsemble(), 'ssr': probabilistic.UnbiasedSpreadSkillRatio()}
+  values = beam_pipeline.define_pipeline(None, tc, pc, lt, metrics, area, out_path=str(tmp_path / 'm.nc'))[None].metric_values(metrics)
+  pv = np.asarray(pc.load_chunk(init_times, lead_times)['2m_temperature'].transpose('number', 'init_time', 'lead_time', 'latitude', 'longitude').values)
+  tv = np.asarray(lt.load_chunk(init_times, lead_times)['2m_temperature'].transpose('init_time', 'lead_time', 'latitude', 'longitude').values)
+  w = O.grid_area_weights(lat)[None, None, :, None]
+  pointwise = np.abs(pv - tv[None]).mean(0) - 0.5 * np.abs(pv[:, None] - pv[None, :]).sum((0, 1)) / (5 * 4)
+  np.testing.assert_allclose(np.asarray(values['crps.2m_temperature'].values), (pointwise * w).sum((0, 2, 3)) / (np.ones_like(pointwise) * w).sum((0, 2, 3)),
+                             rtol=1e-5)
+  # persistence against a day-of-year climatology: per-init accumulators, written, read back, tested
+  first_year = target['2m_temperature'].isel(time=slice(0, 366))
+  clim = xr.Dataset({'2m_temperature': xr.DataArray(np.asarray(first_year.values), dims=('dayofyear', 'latitude', 'longitude'),
+                                                    coords={'dayofyear': np.arange(1, 367), 'latitude': lat, 'longitude': first_year['longitude'].values})})
+  m2 = {'rmse': deterministic.RMSE(), 'acc': deterministic.ACC(clim)}
+  persistence = xarray_loaders.PersistenceFromXarray(ds=target)
+  climatology = xarray_loaders.ClimatologyFromXarray(ds=clim, climatology_time_coords=['dayofyear'])
+  s_pers = beam_pipeline.define_pipeline(None, tc, persistence, lt, m2, per_init, aggregation_state_out_path=str(tmp_path / 'p.nc'))[None]
+  s_clim = beam_pipeline.define_pipeline(None, tc, climatology, lt, {'rmse': deterministic.RMSE()}, per_init,
+                                         aggregation_state_out_path=str(tmp_path / 'c.nc'))[None]
+  paired = t_test.LazarusHACEWC.for_baseline_comparison(metrics={'rmse': deterministic.RMSE()}, aggregated_statistics=s_pers,
+                                                        baseline_aggregated_statistics=s_clim, experimental_unit_dim='init_time')
+  diff = np.asarray(paired.point_estimates()['rmse']['2m_temperature'].values)
+  rm = lambda s: np.asarray(s.sum_along_dims(['init_time']).metric_values({'rmse': deterministic.RMSE()})['rmse.2m_temperature'].values)
+  np.testing.assert_allclose(diff, rm(s_pers) - rm(s_clim), rtol=1e-6, atol=1e-9)
+  p = np.asarray(paired.p_values()['rmse']['2m_temperature'].values)
+  assert p.shape == (3,) and ((0 <= p) & (p <= 1)).all()
+  back = wio.read_aggregation_state(str(tmp_path / 'p.nc'))
+  boot = bootstrap.StationaryBootstrap(metrics=m2, aggregated_statistics=back, experimental_unit_dim='init_time', n_replicates=60,
+                                       rng=np.random.default_rng(0))
+  lower, upper = boot.confidence_intervals(0.1)
+  acc = np.asarray(boot.point_estimates()['acc']['2m_temperature'].values)
+  np.testing.assert_allclose(acc, np.asarray(s_pers.sum_along_dims(['init_time']).metric_values(m2)['acc.2m_temperature'].values), rtol=1e-9)
+  assert (np.asarray(lower['acc']['2m_temperature'].values) < acc).all() and (acc < np.asarray(upper['acc']['2m_temperature'].values)).all()
+  # a forecast that is 30 h late: every query is answered from the run issued before it
+  forecasts = mock_data.mock_prediction_data(time_start='2020-05-25T00', time_stop='2020-06-25T00', variables_3d=[], random=True, seed=5,
+                                             lead_stop_days=6, spatial_resolution_in_degrees=30.0)
+  plain = xarray_loaders.PredictionsFromXarray(ds=forecasts)
+  late = latency_wrappers.XarrayConstantLatencyWrapper(plain, latency=np.timedelta64(30, 'h'))
+  rmse = {'rmse': deterministic.RMSE()}
+  got = beam_pipeline.define_pipeline(None, tc, late, lt, rmse, area, out_path=str(tmp_path / 'l.nc'))[None].metric_values(rmse)
+  shifted = np.asarray(plain.load_chunk(init_times - np.timedelta64(48, 'h'), lead_times + np.timedelta64(48, 'h'))['2m_temperature'].transpose(
+      'init_time', 'lead_time', 'latitude', 'longitude').values)         # 30 h late on a daily cycle: the run of two days earlier
+  want = np.sqrt((((shifted - tv) ** 2) * w).sum((0, 2, 3)) / (np.ones_like(tv) * w).sum((0, 2, 3)))
+  np.testing.assert_allclose(np.asarray(got['rmse.2m_temperature'].values), want, rtol=1e-5)
