@@ -43,20 +43,33 @@ def define_pipeline(root, times: time_chunks.TimeChunks, predictions_loader, tar
                     aggregator: aggregation.Aggregator | Mapping[str, aggregation.Aggregator],
                     out_path: str | Mapping[str, str] | None = None,
                     aggregation_state_out_path: str | Mapping[str, str] | None = None,
-                    setup_fn: Optional[Callable[[], None]] = None, *, rank: int = 0, world_size: int = 1, prefetch: int = 0):
+                    setup_fn: Optional[Callable[[], None]] = None, *, rank: int = 0, world_size: int = 1, prefetch: int = 0,
+                    accumulate: str = 'device'):
   """Evaluates `metrics` over all chunks of `times` and writes the metric values (`out_path`) and / or the final aggregation
   state(s) (`aggregation_state_out_path`) as NetCDF.  With several named aggregators a single path gets the aggregator's name
   appended (`metrics.nc` -> `metrics_<name>.nc`), a mapping names each file (beam_pipeline.py:388-399, 446-537).  Returns
-  {aggregator name (None for a single unnamed one): AggregationState}."""
+  {aggregator name (None for a single unnamed one): AggregationState}.
+
+  `accumulate='device'` (default) keeps the accumulators in HBM for the whole loop, which needs every chunk to produce the same
+  result frame per (aggregator, statistic, variable) -- always true for gridded data under fixed bins.  `accumulate='host'` adds
+  the per-chunk AggregationStates the way the reference's CombiningSum does (outer join on the labels, zeros where a chunk has
+  none): for results whose labels depend on the chunk's data, e.g. station chunks binned by the values of a coordinate."""
   del root
+  if accumulate not in ('device', 'host'):
+    raise ValueError(f"accumulate must be 'device' or 'host', got {accumulate!r}")
   if isinstance(aggregator, Mapping):
     for what, paths in (('out_path', out_path), ('aggregation_state_out_path', aggregation_state_out_path)):
       if isinstance(paths, Mapping) and paths.keys() != aggregator.keys():
         raise ValueError(f"Keys of {what} don't match aggregator names.")
   if out_path is None and aggregation_state_out_path is None:
     raise ValueError('At least one of (metrics) out_path or aggregation_state_out_path must be specified.')
-  states = pipeline.evaluate_chunks(times, load_predictions_and_targets(predictions_loader, targets_loader, setup_fn), metrics, aggregator,
-                                    rank=rank, world_size=world_size, prefetch=prefetch)
+  load = load_predictions_and_targets(predictions_loader, targets_loader, setup_fn)
+  if accumulate == 'host':
+    if world_size != 1:
+      raise ValueError("accumulate='host' runs in one process (combine the states of several processes with `+`)")
+    states = _evaluate_chunks_on_host(times, load, metrics, aggregator)
+  else:
+    states = pipeline.evaluate_chunks(times, load, metrics, aggregator, rank=rank, world_size=world_size, prefetch=prefetch)
   if rank == 0:
     for name, state in states.items():
       if out_path is not None:
@@ -64,3 +77,16 @@ def define_pipeline(root, times: time_chunks.TimeChunks, predictions_loader, tar
       if aggregation_state_out_path is not None:
         wio.write_aggregation_state(state, pipeline.resolve_out_path(aggregation_state_out_path, name))
   return states
+
+
+def _evaluate_chunks_on_host(times: time_chunks.TimeChunks, load, metrics, aggregator):
+  """Chunk by chunk: statistics, the Aggregator's reduction (still on the device), then `AggregationState + AggregationState` on
+  the host -- `combining_sum`, the outer-join zero-fill add of beam_utils.CombiningSum (aggregation.py:27-60)."""
+  named = {None: aggregator} if isinstance(aggregator, aggregation.Aggregator) else dict(aggregator)
+  totals = {name: aggregation.AggregationState.zero() for name in named}
+  for init_times, lead_times in times:
+    predictions, targets = load(init_times, lead_times)
+    statistics = metrics_base.compute_unique_statistics_for_all_metrics(metrics, predictions, targets)
+    for name, agg in named.items():
+      totals[name] = totals[name] + agg.aggregate_statistics(statistics)
+  return totals

@@ -1047,6 +1047,17 @@ class Accumulation:
         self._recorder.refuse('a result layout was met for the first time in the chunk')
       lst.append(spec)
       self.frames[(path, len(lst) - 1)] = (dict(da._coords), da.name, dict(da.attrs))  # pylint: disable=protected-access
+    else:
+      # the same slot again: its labels must be the ones it was created with -- a chunk whose bins carry other labels (bins over
+      # the values of a coordinate of sparse data) would otherwise be added position by position under the first chunk's labels
+      seen = self.frames[(path, lst.index(spec))][0]
+      mine = da._coords  # pylint: disable=protected-access
+      for k, (cdims, cvals) in mine.items():
+        if k in da.dims and k in seen and seen[k][1] is not cvals and not np.array_equal(np.asarray(seen[k][1]), np.asarray(cvals)):
+          raise ValueError(
+              f'accumulating {path}: the labels of dimension {k!r} changed between chunks.  Results whose frame depends on the '
+              "chunk's data cannot use the device accumulators: run beam_pipeline.define_pipeline(..., accumulate='host') or add "
+              'the per-chunk AggregationStates yourself.')
 
   @staticmethod
   def _host_add(table, path, val):

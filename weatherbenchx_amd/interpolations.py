@@ -76,16 +76,16 @@ def _axis_table(source: np.ndarray, wanted: np.ndarray, method: str, extrapolate
   """For every wanted coordinate: the two source positions around it (in the source's own order), the weight of the second,
   and whether it lies outside the source axis."""
   source, wanted = _as_float(source), _as_float(wanted)
-  if source.size < 2 and method == 'linear':
-    raise ValueError('linear interpolation needs at least two points along the axis')
   order = np.argsort(source, kind='stable')
   axis = source[order]
   if axis.size > 1 and not np.all(np.diff(axis) > 0):
     raise ValueError('the coordinate to interpolate along has repeated values')
   outside = (wanted < axis[0]) | (wanted > axis[-1])
   if axis.size == 1:
+    # an axis of one point (a chunk of a single init time, interpolated pointwise to the stations' init_time coordinate): that
+    # point where it is asked for; elsewhere it is out of bounds -- constant when extrapolating, NaN otherwise
     lo = np.zeros(wanted.shape, dtype=np.int64)
-    return order[lo], order[lo], np.zeros(wanted.shape), outside
+    return order[lo], order[lo], np.where(np.isnan(wanted), np.nan, 0.0), outside
   lo = np.clip(np.searchsorted(axis, wanted, side='right') - 1, 0, axis.size - 2)
   weight = (wanted - axis[lo]) / (axis[lo + 1] - axis[lo])
   if method == 'nearest':

@@ -400,7 +400,14 @@ def _run_chunk(group, passes, acc):
           if state is None:
             continue
           got = state.sum_weighted_statistics.dims
-          assert ('init_time' in got, 'lead_time' in got) == (key[0] is not None, key[1] is not None), (got, key)
+          if ('init_time' in got, 'lead_time' in got) != (key[0] is not None, key[1] is not None):
+            # e.g. ByExactCoord('lead_time') on station data: a BIN dim that is called like a chunked time dim, with labels that
+            # depend on the chunk's data.  The device accumulators need one result frame per label for the whole loop.
+            raise ValueError(
+                f'statistic {stat_name!r} / {var_name!r}: the aggregated result has dims {got} but the chunk offsets say '
+                f'init_time / lead_time survive = {key[0] is not None} / {key[1] is not None}.  Results whose frame depends on '
+                "the chunk's data (bins over coordinates of sparse data) cannot use the device accumulators: run "
+                "beam_pipeline.define_pipeline(..., accumulate='host') or add the per-chunk AggregationStates yourself.")
           for kind, da in (('sum_weighted_statistics', state.sum_weighted_statistics), ('sum_weights', state.sum_weights)):
             acc.capture((pass_name, agg_name, kind, stat_name, str(var_name), key), da)
           states.append(state)

@@ -1021,6 +1021,10 @@ def _merge_coords(a: DataArray, b: DataArray, out_dims):
       if ad != cd or not _values_equal(av, cv):
         if k not in out_dims:  # conflicting non-index coordinate: dropped (xarray semantics)
           del coords[k]
+        elif cd == (k,) and ad != (k,):
+          # `k` is a dim of the result: its index coordinate wins over a like-named auxiliary coordinate of the other operand (a bin
+          # dim `lead_time` with its labels against the stations' `lead_time` over `index`), as in xarray's merge
+          coords[k] = (cd, cv)
     else:
       coords[k] = (cd, cv)
   dset = set(out_dims)
