@@ -287,3 +287,31 @@ def test_device_accumulators_refuse_results_whose_labels_change_between_chunks(e
   out = total.metric_values(metrics)['mae.t']
   assert out.coords['stationName'].values.tolist() == ['A', 'B', 'C', 'D']
   np.testing.assert_allclose(np.asarray(out.values), [1.5, 3.0, 1.0, 2.5])
+
+
+def test_time_unit_bins_whose_labels_depend_on_the_chunk(emulated, tmp_path):
+  """Gridded data can produce chunk-dependent frames too: `ByTimeUnit('hour', 'init_time')` over chunks of two 6-hourly inits sees the
+  hours [0, 6] in one chunk and [12, 18] in the next.  Chunks that each hold all four hours accumulate on the device and equal the
+  single-chunk result; the half-day chunks are refused there and are right on the host route."""
+  del emulated
+  from weatherbenchx_amd import beam_pipeline  # pylint: disable=g-import-not-at-top
+  target = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-08T00', variables_3d=[], random=True, seed=1,
+                                      spatial_resolution_in_degrees=30.0, time_resolution_hours=6)
+  forecast = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', variables_3d=[], random=True, seed=2,
+                                            lead_stop_days=1, spatial_resolution_in_degrees=30.0, time_resolution_hours=6)
+  lt, lp = xarray_loaders.TargetsFromXarray(ds=target), xarray_loaders.PredictionsFromXarray(ds=forecast)
+  init = np.arange('2020-01-01T00', '2020-01-05T00', np.timedelta64(6, 'h'), dtype='datetime64[ns]')
+  lead = np.arange(2, dtype='timedelta64[D]').astype('timedelta64[ns]')
+  metrics = {'rmse': deterministic.RMSE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()],
+                               bin_by=[binning.ByTimeUnit('hour', 'init_time')])
+  run = lambda size, **kw: beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(init, lead, init_time_chunk_size=size), lp, lt, metrics, agg,
+                                                         out_path=str(tmp_path / 'm.nc'), **kw)[None].metric_values(metrics)['rmse.2m_temperature']
+  whole = run(None)
+  assert whole.coords['init_time_hour'].values.tolist() == [0, 6, 12, 18]
+  days = run(4)
+  np.testing.assert_allclose(np.asarray(days.transpose(*whole.dims).values), np.asarray(whole.values), rtol=1e-6)
+  with pytest.raises(ValueError, match="labels of dimension 'init_time_hour' changed between chunks"):
+    run(2)
+  halves = run(2, accumulate='host')
+  np.testing.assert_allclose(np.asarray(halves.transpose(*whole.dims).values), np.asarray(whole.values), rtol=1e-6)
