@@ -315,3 +315,36 @@ def test_time_unit_bins_whose_labels_depend_on_the_chunk(emulated, tmp_path):
     run(2)
   halves = run(2, accumulate='host')
   np.testing.assert_allclose(np.asarray(halves.transpose(*whole.dims).values), np.asarray(whole.values), rtol=1e-6)
+
+
+def test_loaders_metrics_and_interpolations_pickle():
+  """The reference ships its loaders, metrics and aggregators to Beam workers by pickle (ownership); the objects added in
+  round 5 survive the same trip with the standard pickle (no closures inside)."""
+  import os  # pylint: disable=g-import-not-at-top
+  import pickle  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd.data_loaders import latency_wrappers, sparse_parquet  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd.metrics import probabilistic  # pylint: disable=g-import-not-at-top
+  t = mock_data.mock_target_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', variables_3d=[], random=True, seed=1,
+                                 spatial_resolution_in_degrees=30.0)
+  f = mock_data.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-05T00', variables_3d=[], lead_stop_days=2,
+                                     spatial_resolution_in_degrees=30.0)
+  metar = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'metar-timeNominal-by-month')
+  objects = [
+      xarray_loaders.TargetsFromXarray(ds=t, interpolation=interpolations.InterpolateToFixedCoords('linear', {'latitude': np.arange(-80, 81, 20.0)})),
+      latency_wrappers.XarrayConstantLatencyWrapper(xarray_loaders.PredictionsFromXarray(ds=f), latency=np.timedelta64(6, 'h')),
+      sparse_parquet.METARFromParquet(path=metar, variables=['2m_temperature'], time_dim='timeNominal'),
+      wrappers.WrappedMetric(categorical.CSI(), [wrappers.ContinuousToBinary('both', [0.5], 'threshold')]),
+      spatial.FSS([1, 3], True), probabilistic.EnergyScore('longitude'), probabilistic.RelativeEconomicValue(ensemble_size=5),
+      probabilistic.EnsembleRankedProbabilityScore([0.1, 0.5], [0.1, 0.5], 'bin', 's'), categorical.SEEPS(['x'], t),
+      categorical.Opportunism('number', t, True, True, None), categorical.Reliability(),
+      aggregation.Aggregator(reduce_dims=['index'], bin_by=[binning.ByExactCoord('lead_time'), binning.BySets({'a': ['x']}, 'stationName', 'sub')],
+                             weigh_by=[weighting.StationDensityWeighting()]),
+      interpolations.GridToSparseWithAltitudeAdjustment('linear', grid_elevation=t['2m_temperature'].isel(time=0, drop=True)),
+  ]
+  for obj in objects:
+    back = pickle.loads(pickle.dumps(obj))
+    assert type(back) is type(obj)
+  loader = pickle.loads(pickle.dumps(objects[2]))
+  chunk = loader.load_chunk(np.array(['2020-01-02T00'], dtype='datetime64[ns]'), np.array([6], dtype='timedelta64[h]'))
+  assert chunk['2m_temperature'].size > 5
+  assert set(pickle.loads(pickle.dumps(objects[9])).statistics) == {'Confident', 'Covered'}

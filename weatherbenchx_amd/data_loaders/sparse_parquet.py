@@ -206,6 +206,23 @@ def convert_longitude_to_0_to_360(df: pd.DataFrame, longitude_dim: str = 'longit
   return df
 
 
+class _MetarPreparation:
+  """The METAR clean-up of a frame (a class, not a closure: loaders travel to worker processes by pickle)."""
+
+  def __init__(self, raw_names: Sequence[str], preprocessing_fn: Optional[Callable[[pd.DataFrame], pd.DataFrame]]):
+    self._raw_names = list(raw_names)
+    self._preprocessing_fn = preprocessing_fn
+
+  def __call__(self, df: pd.DataFrame) -> pd.DataFrame:
+    df = df.copy()
+    if self._preprocessing_fn is not None:
+      df = self._preprocessing_fn(df)
+    df = set_bad_quality_to_nan(df, self._raw_names, METAR_QC_SUFFIX, METAR_BAD_QUALITY_FLAGS)
+    df = convert_longitude_to_0_to_360(df)
+    df['elevation'] = df['elevation'].where(df['elevation'] < 9.999e03, np.nan)
+    return df
+
+
 class METARFromParquet(SparseObservationsFromParquet):
   """METAR surface reports with their conventions filled in (sparse_parquet.py:412-523): raw column names mapped to the ERA5-style
   ones (`variables` are given in the latter), values with a bad quality flag set to NaN, longitude in [0, 360), the elevation fill
@@ -217,17 +234,7 @@ class METARFromParquet(SparseObservationsFromParquet):
                file_tolerance: np.timedelta64 = np.timedelta64(1, 'h'),
                preprocessing_fn: Optional[Callable[[pd.DataFrame], pd.DataFrame]] = None, **kwargs):
     del rename_variables                                                  # (accepted and ignored, as in the reference: the METAR map is used)
-    raw_names = [ERA5_TO_METAR_NAMES[v] for v in variables]
-
-    def prepare(df: pd.DataFrame) -> pd.DataFrame:
-      df = df.copy()
-      if preprocessing_fn is not None:
-        df = preprocessing_fn(df)
-      df = set_bad_quality_to_nan(df, raw_names, METAR_QC_SUFFIX, METAR_BAD_QUALITY_FLAGS)
-      df = convert_longitude_to_0_to_360(df)
-      df['elevation'] = df['elevation'].where(df['elevation'] < 9.999e03, np.nan)
-      return df
-
+    prepare = _MetarPreparation([ERA5_TO_METAR_NAMES[v] for v in variables], preprocessing_fn)
     super().__init__(path=path, variables=variables, time_dim=time_dim, coordinate_variables=METAR_COORDINATE_VARIABLES,
                      observation_dim='stationName', split_variables=split_variables, dropna=dropna, tolerance=tolerance,
                      partitioned_by=partitioned_by, rename_variables=METAR_TO_ERA5_NAMES, include_slice_end_time=include_slice_end_time,

@@ -290,20 +290,26 @@ class Opportunism(base.PerVariableMetric):
                coverage_quantile_boundaries: tuple = (0.1, 0.9), jaccard_distance_quantile_boundaries: tuple = (0.1, 0.9),
                confidence_threshold: float = 0.7, jaccard_distance_threshold: float = 0.75):
     self._flags = {'Confident': is_confident, 'Covered': is_covered, 'JaccardDistant': is_jaccard_distant}
-    self._parts = {
-        'Confident': lambda: Confident(ensemble_dim=ensemble_dim, climatology=climatology,
-                                       spread_quantile_boundaries=confidence_quantile_boundaries,
-                                       confidence_threshold=confidence_threshold),
-        'Covered': lambda: Covered(ensemble_dim=ensemble_dim, interval_quantile_boundaries=coverage_quantile_boundaries),
-        'JaccardDistant': lambda: JaccardDistant(ensemble_dim=ensemble_dim, climatology=climatology,
-                                                 threshold=jaccard_distance_threshold,
-                                                 interval_quantile_boundaries=jaccard_distance_quantile_boundaries),
-    }
+    self._ensemble_dim = ensemble_dim
+    self._climatology = climatology
+    self._boundaries = {'Confident': confidence_quantile_boundaries, 'Covered': coverage_quantile_boundaries,
+                        'JaccardDistant': jaccard_distance_quantile_boundaries}
+    self._confidence_threshold = confidence_threshold
+    self._jaccard_distance_threshold = jaccard_distance_threshold
 
   @property
   def statistics(self) -> Mapping[str, base.Statistic]:
     # confidence is always evaluated; the other two only when they are used
-    return {name: make() for name, make in self._parts.items() if name == 'Confident' or self._flags[name] is not None}
+    out = {'Confident': Confident(ensemble_dim=self._ensemble_dim, climatology=self._climatology,
+                                  spread_quantile_boundaries=self._boundaries['Confident'],
+                                  confidence_threshold=self._confidence_threshold)}
+    if self._flags['Covered'] is not None:
+      out['Covered'] = Covered(ensemble_dim=self._ensemble_dim, interval_quantile_boundaries=self._boundaries['Covered'])
+    if self._flags['JaccardDistant'] is not None:
+      out['JaccardDistant'] = JaccardDistant(ensemble_dim=self._ensemble_dim, climatology=self._climatology,
+                                             threshold=self._jaccard_distance_threshold,
+                                             interval_quantile_boundaries=self._boundaries['JaccardDistant'])
+    return out
 
   def _values_from_mean_statistics_per_variable(self, statistic_values):
     out = None
