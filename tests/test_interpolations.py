@@ -232,3 +232,67 @@ def test_a_loader_that_regrids_its_chunks_to_the_targets():
   want = src.isel(latitude=i).sel(longitude=30.0) * (2 / 3) + src.isel(latitude=i).sel(longitude=60.0) * (1 / 3)
   got = same_lat.transpose('lead_time', 'init_time').values
   np.testing.assert_allclose(got, want.sel(prediction_timedelta=lead_times.astype('timedelta64[ns]'), time=init_times).values, rtol=1e-12)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_interpolations_against_scipy(seed):
+  """Random frames: 2 to 4 dims in random order, ascending or descending source axes, one to three of them interpolated --
+  orthogonally to random targets, or pointwise to random points -- in both methods, against scipy.interpolate.interpn."""
+  rng = np.random.default_rng(100 + seed)
+  ndim = int(rng.integers(2, 5))
+  names = ['a', 'b', 'c', 'd'][:ndim]
+  sizes = [int(rng.integers(2, 7)) for _ in names]
+  axes = {}
+  for n, s in zip(names, sizes):
+    ax = np.sort(rng.uniform(-10, 10, s))
+    while np.diff(ax).min() < 1e-3:
+      ax = np.sort(rng.uniform(-10, 10, s))
+    axes[n] = ax[::-1].copy() if rng.random() < 0.4 else ax
+  values = rng.normal(size=sizes)
+  order = list(rng.permutation(ndim))
+  da = xr.DataArray(np.transpose(values, order), dims=[names[i] for i in order], coords=axes)
+  k = int(rng.integers(1, min(3, ndim) + 1))
+  chosen = list(rng.choice(names, size=k, replace=False))
+  method = 'linear' if rng.random() < 0.6 else 'nearest'
+  extrapolate = bool(rng.random() < 0.5)
+  fill = None if extrapolate else np.nan
+  asc = {n: (axes[n], False) if axes[n][0] < axes[n][-1] else (axes[n][::-1], True) for n in names}
+
+  def scipy_at(points_by_dim, others_index):
+    """Values at points (arrays of one shape per chosen dim) for one index into the other dims."""
+    grid = tuple(asc[n][0] for n in chosen)
+    sub = values
+    # bring chosen dims to the front in `chosen` order, fix the others
+    perm = [names.index(n) for n in chosen] + [i for i, n in enumerate(names) if n not in chosen]
+    sub = np.transpose(sub, perm)[(slice(None),) * len(chosen) + tuple(others_index)]
+    for axis, n in enumerate(chosen):
+      if asc[n][1]:
+        sub = np.flip(sub, axis=axis)
+    pts = np.stack([points_by_dim[n] for n in chosen], axis=-1)
+    return sci.interpn(grid, sub, pts, method=method, bounds_error=False, fill_value=fill)
+
+  others = [n for n in names if n not in chosen]
+  if rng.random() < 0.5:                                                 # orthogonal
+    targets = {n: rng.uniform(-12, 12, int(rng.integers(1, 5))) for n in chosen}
+    got = interpolations.interp(da, targets, method, extrapolate).transpose(*chosen, *others)
+    mesh = np.meshgrid(*[targets[n] for n in chosen], indexing='ij')
+    for idx in np.ndindex(*[len(axes[n]) for n in others]):
+      want = scipy_at(dict(zip(chosen, mesh)), idx)
+      mine = np.asarray(got.values)[(slice(None),) * len(chosen) + idx]
+      _assert_close_away_from_ties(mine, want, method)
+  else:                                                                  # pointwise
+    npts = int(rng.integers(1, 9))
+    pts = {n: rng.uniform(-12, 12, npts) for n in chosen}
+    targets = {n: xr.DataArray(v, dims=('points',)) for n, v in pts.items()}
+    got = interpolations.interp(da, targets, method, extrapolate).transpose('points', *others)
+    for idx in np.ndindex(*[len(axes[n]) for n in others]):
+      want = scipy_at(pts, idx)
+      mine = np.asarray(got.values)[(slice(None),) + idx]
+      _assert_close_away_from_ties(mine, want, method)
+
+
+def _assert_close_away_from_ties(mine, want, method):
+  if method == 'linear':
+    np.testing.assert_allclose(mine, want, rtol=1e-9, atol=1e-9, equal_nan=True)
+  else:                                                                  # (random targets do not sit on midpoints)
+    np.testing.assert_allclose(mine, want, rtol=0, atol=0, equal_nan=True)
