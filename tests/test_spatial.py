@@ -167,3 +167,19 @@ def test_tensor_payloads_stay_tensors():
   b = stat.compute({'v': xr.DataArray(torch.from_numpy(p), dims=dims)}, {'v': xr.DataArray(torch.from_numpy(t), dims=dims)})['v']
   assert xr._is_torch(b.data) and a.dims == b.dims == ('neighborhood_size',) + dims  # pylint: disable=protected-access
   np.testing.assert_allclose(np.asarray(b.values), np.asarray(a.values), atol=1e-6)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_neighbourhood_mean_with_scattered_nans(seed):
+  """NaNs poison exactly the windows that hold them (running sums would smear them over everything behind: they are counted
+  separately), for every size and both boundary rules, also when windows wrap more than once."""
+  rng = np.random.default_rng(200 + seed)
+  nlat, nlon = int(rng.integers(4, 12)), int(rng.integers(4, 14))
+  x = rng.normal(size=(2, nlat, nlon))
+  x[rng.random(x.shape) < 0.08] = np.nan
+  n = int(rng.choice([3, 5, 7]))
+  wrap = bool(rng.random() < 0.5)
+  want = np.stack([O.neighborhood_mean(f, n, wrap) for f in x])
+  got = spatial.convolve2d_wrap_longitude(x.copy(), n, wrap)
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+  np.testing.assert_allclose(got, want, atol=2e-6, equal_nan=True)
