@@ -1,4 +1,4 @@
-"""In-memory loaders with the reference's names (weatherbenchx_amd/data_loaders.py).  The cases are the ones of
+"""In-memory loaders with the reference's names (weatherbenchx_amd/data_loaders/).  The cases are the ones of
 weatherbenchX/data_loaders/xarray_loaders_test.py:24-160 on the same mock datasets (passed as `ds=`: there is no zarr here),
 with the VALUES of every chunk checked against plain numpy indexing of the source arrays, plus the shared `load_chunk`
 steps of data_loaders/base.py:119-170 and a chunked evaluation through them against the oracle."""
