@@ -216,18 +216,18 @@ def test_linearised_per_unit_values_against_analytic_gradients():
   want = (a - ma) / mb - ma * (b - mb) / mb ** 2
   got = tangents['ratio']['variable']
   assert got.dims == ('level', 'init_time')
-  np.testing.assert_allclose(np.asarray(got.values).T, want, rtol=1e-6, atol=1e-9)
+  np.testing.assert_allclose(np.asarray(got.values).T, want, rtol=1e-9, atol=1e-11)
   np.testing.assert_allclose(np.asarray(got.values).mean(axis=1), 0.0, atol=1e-9)     # zero mean along the units
   # a weighted mean alone is already non-linear in its accumulators: d(A / W) = dA / mw - ma dW / mw**2
   value, tangents = autodiff.per_unit_values_linearized_around_mean_statistics({'mean': MeanPrediction()}, _state({'MeanPrediction': num}, weights=w),
                                                                                'init_time')
-  np.testing.assert_allclose(np.asarray(tangents['mean']['variable'].values).T, (a - ma) / mw - ma * (ww - mw) / mw ** 2, rtol=1e-6, atol=1e-9)
+  np.testing.assert_allclose(np.asarray(tangents['mean']['variable'].values).T, (a - ma) / mw - ma * (ww - mw) / mw ** 2, rtol=1e-9, atol=1e-11)
   # RMSE: sqrt of a mean
   se = xr.DataArray(rng.gamma(2.0, size=(n, 3)), dims=('init_time', 'level'), coords=unit)
   value, tangents = autodiff.per_unit_values_linearized_around_mean_statistics({'rmse': deterministic.RMSE()}, _state({'SquaredError': se}), 'init_time')
   m = se.values.mean(0)
   np.testing.assert_allclose(np.asarray(value['rmse']['variable'].values), np.sqrt(m), rtol=1e-12)
-  np.testing.assert_allclose(np.asarray(tangents['rmse']['variable'].values).T, (se.values - m) / (2 * np.sqrt(m)), rtol=1e-6, atol=1e-10)
+  np.testing.assert_allclose(np.asarray(tangents['rmse']['variable'].values).T, (se.values - m) / (2 * np.sqrt(m)), rtol=1e-9, atol=1e-12)
   with pytest.raises(ValueError, match='No experimental unit coordinate'):
     autodiff.per_unit_values_linearized_around_mean_statistics({'rmse': deterministic.RMSE()}, _state({'SquaredError': se}), 'time')
 

@@ -4,10 +4,10 @@ weatherbenchX/statistical_inference/autodiff.py:33-233, which differentiates wit
 A metric is f(mean_i x_i) with x_i the per-unit accumulators (sum of weighted statistics AND sum of weights: the normalisation
 of a weighted mean is part of f).  Inference methods for means apply to  f(m) + J_f(m) (x_i - m),  whose mean is the metric itself
 and whose variance approximates the metric's to first order.  J_f(m) (x_i - m) is a directional derivative, taken here by central
-differences  [f(m + h d_i) - f(m - h d_i)] / 2h  for all units in ONE pair of evaluations: the unit dimension rides along as a
-trailing dim, which `values_from_mean_statistics` broadcasts over like any other.  h is chosen so that no accumulator moves by
-more than 1e-5 of its scale: exact to rounding for the linear metrics (means, differences of means), about 1e-10 relative for the
-smooth non-linear ones (RMSE, ACC, spread/skill)."""
+differences  [f(m + h d_i) - f(m - h d_i)] / 2h  at two step sizes (h, h / 2; Richardson-combined) for all units at once: the unit
+dimension rides along as a trailing dim, which `values_from_mean_statistics` broadcasts over like any other -- four evaluations of
+the metrics in all.  h is chosen so that no accumulator moves by more than 1e-3 of its scale (the combination leaves an h**4 truncation error, so the step can be large and the rounding of the differences small): exact to rounding for the linear
+metrics (means, differences of means), ~1e-11 relative for the smooth non-linear ones (RMSE, ACC, ratios)."""
 from __future__ import annotations
 
 from typing import Hashable, Mapping
@@ -23,7 +23,7 @@ from weatherbenchx_amd.statistical_inference import utils
 StatsValues = Mapping[str, Mapping[Hashable, xr.DataArray]]
 MetricValues = Mapping[str, Mapping[Hashable, xr.DataArray]]
 
-_RELATIVE_STEP = 1e-5
+_RELATIVE_STEP = 1e-3
 
 
 def _host(x) -> xr.DataArray:
@@ -60,15 +60,17 @@ def per_unit_values_linearized_around_mean_statistics(metrics: Mapping[str, metr
         lambda v: (xr.as_dataarray(v) * 0.0).expand_dims({unit: np.asarray(unit_coord.values)}, axis=-1), value)
     return value, zeros
   h = _RELATIVE_STEP / worst
-  plus = evaluate(aggregation.AggregationState.map_multi(lambda m, d: m + h * d, mean, direction))
-  minus = evaluate(aggregation.AggregationState.map_multi(lambda m, d: m - h * d, mean, direction))
+  at = lambda step: evaluate(aggregation.AggregationState.map_multi(lambda m, d: m + step * d, mean, direction))
+  # central differences at h and h / 2, combined so that the h**2 term of the truncation error cancels (Richardson): what is left
+  # is O(h**4) curvature and the rounding of four evaluations
+  plus, minus, plus_half, minus_half = at(h), at(-h), at(h / 2), at(-h / 2)
 
-  def tangent(p, q, v):
-    p, q, v = xr.as_dataarray(p), xr.as_dataarray(q), xr.as_dataarray(v)
-    t = (p - q) / (2 * h)
+  def tangent(p, q, p2, q2, v):
+    p, q, p2, q2, v = (xr.as_dataarray(x) for x in (p, q, p2, q2, v))
+    t = (4 * ((p2 - q2) / h) - (p - q) / (2 * h)) / 3
     if unit not in t.dims:                                              # a metric that does not depend on the sampled statistics
       t = (v * 0.0).expand_dims({unit: np.asarray(unit_coord.values)}, axis=-1)
     t = t.transpose(*[d for d in t.dims if d != unit], unit)
     return t.assign_coords({unit: np.asarray(unit_coord.values)})
 
-  return value, xarray_tree.map_structure(tangent, plus, minus, value)
+  return value, xarray_tree.map_structure(tangent, plus, minus, plus_half, minus_half, value)
