@@ -348,3 +348,38 @@ def test_loaders_metrics_and_interpolations_pickle():
   chunk = loader.load_chunk(np.array(['2020-01-02T00'], dtype='datetime64[ns]'), np.array([6], dtype='timedelta64[h]'))
   assert chunk['2m_temperature'].size > 5
   assert set(pickle.loads(pickle.dumps(objects[9])).statistics) == {'Confident', 'Covered'}
+
+
+def test_archive_conventions_descending_latitude_lat_lon_names_level_selection_and_crop(emulated, tmp_path):
+  """Datasets as the archives have them: `lat` / `lon` / `time` / `prediction_timedelta` names, latitude from north to south, a
+  level picked with `sel_kwargs`, both sides cropped to a box (which sorts the axes ascending) -- through `define_pipeline` in chunks
+  of five init times, against whole-array NumPy with the regional area weights."""
+  del emulated
+  from weatherbenchx_amd import beam_pipeline  # pylint: disable=g-import-not-at-top
+  from weatherbenchx_amd import xarray_lite as xr  # pylint: disable=g-import-not-at-top
+  rng = np.random.default_rng(0)
+  lat, lon, lev = np.linspace(90, -90, 19), np.arange(0, 360, 20.0), np.array([500, 850])
+  times = np.datetime64('2020-01-01', 'ns') + np.arange(20) * np.timedelta64(12, 'h')
+  leads = (np.arange(3) * 12).astype('timedelta64[h]').astype('timedelta64[ns]')
+  truth, forecast = rng.normal(size=(20, 2, 19, 18)), rng.normal(size=(12, 3, 2, 19, 18))
+  tds = xr.Dataset({'z': xr.DataArray(truth, dims=('time', 'level', 'lat', 'lon'), coords={'time': times, 'level': lev, 'lat': lat, 'lon': lon})})
+  pds = xr.Dataset({'z': xr.DataArray(forecast, dims=('time', 'prediction_timedelta', 'level', 'lat', 'lon'),
+                                      coords={'time': times[:12], 'prediction_timedelta': leads, 'level': lev, 'lat': lat, 'lon': lon})})
+  box = interpolations.CropToBox(-60, 60, 0, 180)
+  lt = xarray_loaders.TargetsFromXarray(ds=tds, sel_kwargs={'level': [850]}, interpolation=box)
+  lp = xarray_loaders.PredictionsFromXarray(ds=pds, sel_kwargs={'level': [850]}, interpolation=box)
+  metrics = {'rmse': deterministic.RMSE(), 'bias': deterministic.Bias()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  state = beam_pipeline.define_pipeline(None, time_chunks.TimeChunks(times[:12], leads, init_time_chunk_size=5), lp, lt, metrics, agg,
+                                        out_path=str(tmp_path / 'm.nc'))[None]
+  got = state.metric_values(metrics)
+  assert got['rmse.z'].dims == ('lead_time', 'level') and got['rmse.z'].coords['level'].values.tolist() == [850]
+  south_to_north = lat[::-1]
+  keep_lat, keep_lon = (south_to_north >= -60) & (south_to_north <= 60), (lon >= 0) & (lon <= 180)
+  t_box = truth[:, 1][:, ::-1][:, keep_lat][:, :, keep_lon]
+  p_box = forecast[:, :, 1][:, :, ::-1][:, :, keep_lat][:, :, :, keep_lon]
+  w = O.grid_area_weights(south_to_north[keep_lat])[None, :, None]
+  for k in range(3):
+    err = p_box[:, k] - t_box[np.arange(12) + k]
+    np.testing.assert_allclose(float(np.asarray(got['rmse.z'].values)[k, 0]), np.sqrt((err ** 2 * w).sum() / (np.ones_like(err) * w).sum()), rtol=1e-6)
+    np.testing.assert_allclose(float(np.asarray(got['bias.z'].values)[k, 0]), (err * w).sum() / (np.ones_like(err) * w).sum(), rtol=1e-5, atol=1e-9)
