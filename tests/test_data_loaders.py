@@ -364,3 +364,22 @@ def test_tensor_payloads_are_gathered_where_they_live():
     np.testing.assert_array_equal(np.asarray(b.values), a.values)
     for d in a.dims:
       np.testing.assert_array_equal(b[d].values, a[d].values)
+
+
+def test_mock_datasets_with_the_reference_signatures():
+  """weatherbenchX/test_utils.py:27-104: the frames the reference's own tests build (e.g. latency_wrappers_test.py:24-33)."""
+  from weatherbenchx_amd import test_utils  # pylint: disable=g-import-not-at-top
+  ds = test_utils.mock_prediction_data(time_start='2020-01-01T00', time_stop='2020-01-04T00', time_resolution=np.timedelta64(12, 'h'),
+                                       lead_start='0 hours', lead_stop='30 hours', lead_resolution='6 hours', random=True, seed=1)
+  z = ds['geopotential']
+  assert z.dims == ('prediction_timedelta', 'time', 'latitude', 'longitude', 'level') and z.shape == (6, 6, 19, 36, 3)
+  np.testing.assert_array_equal(z['prediction_timedelta'].values, (np.arange(6) * 6).astype('timedelta64[h]').astype('timedelta64[ns]'))
+  assert z['time'].values[-1] == np.datetime64('2020-01-03T12', 'ns') and z.values.dtype == np.float64 and 0 <= z.values.min() < z.values.max() < 1
+  t = test_utils.mock_target_data(variables_3d=[], ensemble_size=3, spatial_resolution_in_degrees=30.0, time_resolution='6 hours',
+                                  time_start='2020-01-01', time_stop='2020-01-02')
+  assert list(t) == ['2m_temperature'] and t['2m_temperature'].dims == ('time', 'latitude', 'longitude', 'realization')
+  assert t['2m_temperature'].shape == (4, 7, 12, 3) and t['2m_temperature'].values.dtype == np.float32 and not t['2m_temperature'].values.any()
+  # ... and they feed the loaders as the reference's fixtures do
+  loader = data_loaders.PredictionsFromXarray(ds=ds, variables=['2m_temperature'])
+  chunk = loader.load_chunk(np.array(['2020-01-02T00'], dtype='datetime64[ns]'), np.array([6, 12], dtype='timedelta64[h]'))
+  assert chunk['2m_temperature'].sizes['lead_time'] == 2
