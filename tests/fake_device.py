@@ -358,10 +358,46 @@ def _run_spectrum(field, lon_dim, group, scale, ngroup, cache=None):
   return out
 
 
+class _FakeSlabPool:
+  """NumPy stand-in for climatology_cache._HipPool: the "device" pool is a host array, copies land at once."""
+
+  def __init__(self, nslots, slab_shape, np_dtype):
+    self.dtype = np.dtype(np_dtype)
+    self.slab_shape = tuple(int(n) for n in slab_shape)
+    self.slab_nbytes = int(np.prod(self.slab_shape, dtype=np.int64)) * self.dtype.itemsize
+    self.array = np.full((nslots,) + self.slab_shape, np.nan, self.dtype)  # (a slot that was never filled poisons a result)
+    self.writes = []  # (slot, key) in the order they landed
+
+  def payload(self, nslots):
+    return self.array
+
+  def seed(self, pool_da, dims):
+    pass
+
+  def fences_now(self):
+    return []
+
+  def submit(self, job):
+    self.array[job.slot] = np.asarray(job.src)
+    self.writes.append((job.slot, job.key))
+    job.event.set()
+
+  def order(self, job):
+    pass
+
+  def settle(self, job):
+    pass
+
+  def close(self):
+    pass
+
+
 _install_without_spectrum = install
 
 
 def install(monkeypatch):  # noqa: F811
   _install_without_spectrum(monkeypatch)
+  from weatherbenchx_amd import climatology_cache
   from weatherbenchx_amd import spectra
+  monkeypatch.setattr(climatology_cache, '_new_pool', _FakeSlabPool)
   monkeypatch.setattr(spectra, '_run_spectrum', _run_spectrum)

@@ -468,6 +468,12 @@ def _launch_context(kind: str = 'det'):
   return _stream_ring[d.turn]
 
 
+def launch_contexts():
+  """The contexts kernels are launched on: the default one and, once it exists, the second launch stream."""
+  base = _hip.default_context()
+  return [base] + [c for c in _stream_ring if c is not base]
+
+
 def known_contexts():
   """Every live context of this process (the default ones, the second launch stream, feeders' copy streams)."""
   return list(_hip.ALL_CONTEXTS or ())

@@ -101,6 +101,9 @@ class ClimatologyRef(xr.LazyPickleMixin, xr.DataArray):
   reference would hand over: touching `.data` / doing arithmetic materialises the gather (on the device for torch
   payloads)."""
 
+  origin = None    # (host climatology, its positions) when `source` is a slab pool (climatology_cache.SlabCache.ref)
+  activate = None  # slab pool: the launch streams wait for the slabs still on their way (called before the launches)
+
   def __init__(self, source: xr.DataArray, over_dims: tuple, positions: dict):
     self.source = source          # dims e.g. (dayofyear, hour, level, latitude, longitude)
     self.over_dims = tuple(over_dims)    # statistic dims the selection varies over, e.g. (init_time, lead_time)
@@ -131,17 +134,19 @@ class ClimatologyRef(xr.LazyPickleMixin, xr.DataArray):
 
   def aligned_view(self) -> xr.DataArray:
     """The aligned climatology as a plain labeled array (a gather of whole fields)."""
-    src = self.source
-    order = [src.dims.index(d) for d in self.positions] + [i for i, d in enumerate(src.dims) if d not in self.positions]
+    # (behind a slab pool: gathered from the HOST climatology the pool caches -- what a user-defined statistic is handed is
+    #  the reference's `climatology.sel(...).compute()`, metrics/base.py:396-403)
+    src, positions = self.origin if self.origin is not None else (self.source, self.positions)
+    order = [src.dims.index(d) for d in positions] + [i for i, d in enumerate(src.dims) if d not in positions]
     data = xr._transpose(src.data, order)  # pylint: disable=protected-access
-    gather = tuple(np.asarray(self.positions[d]).reshape(-1) for d in self.positions)
+    gather = tuple(np.asarray(positions[d]).reshape(-1) for d in positions)
     if xr._is_torch(data):  # pylint: disable=protected-access
       import torch  # pylint: disable=g-import-not-at-top
       gather = tuple(torch.as_tensor(g, device=data.device) for g in gather)
     g = data[gather]
-    shape = tuple(np.asarray(next(iter(self.positions.values()))).shape)
+    shape = tuple(np.asarray(next(iter(positions.values()))).shape)
     g = g.reshape(shape + tuple(xr._shape(g)[1:]))  # pylint: disable=protected-access
-    coords = {k: v for k, v in src._coords.items() if not set(v[0]) & set(self.positions)}  # pylint: disable=protected-access
+    coords = {k: v for k, v in src._coords.items() if not set(v[0]) & set(positions)}  # pylint: disable=protected-access
     return xr.DataArray(g, dims=self.aligned_dims(), coords=coords, _raw_coords=True)
 
 
@@ -220,6 +225,11 @@ def gather_from_ref(clim: ClimatologyRef, dtype_code: int) -> planner.GatherSpec
   """Element-offset gather table of an aligned climatology from its device layout (the climatology itself is uploaded once and
   cached on its DataArray)."""
   ctx = _hip.default_context()
+  if clim.origin is not None and str(clim.source.dtype) != ('float32' if dtype_code == _hip.F32 else 'float64'):
+    raise ValueError(f'the slab-cached climatology is {clim.source.dtype} but the statistic is evaluated in '
+                     f"{'float32' if dtype_code == _hip.F32 else 'float64'}: cast the climatology (or the fields) to one dtype")
+  if clim.activate is not None:
+    clim.activate()  # slab pool: the launch streams wait for slabs that are still on the copy stream (asked for a chunk ahead)
   dev = engine._to_device(ctx, clim.source, dtype_code)  # pylint: disable=protected-access
   table = np.zeros(tuple(np.asarray(next(iter(clim.positions.values()))).shape), dtype=np.int64)
   for d, pos in clim.positions.items():
@@ -254,7 +264,7 @@ def _reduce_with_gather(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, 
   gather, inputs = _gather_spec(clim, inputs, dims)
   rec = replay.active() if clim is not None else None
   if rec is not None:  # a chunk that is being recorded: what its gather plans have to be rebuilt from for the next chunk
-    rec.gather_context = {'source': clim.source, 'p': inputs[0], 'over_dims': tuple(clim.over_dims),
+    rec.gather_context = {'source': clim.origin[0] if clim.origin is not None else clim.source, 'p': inputs[0], 'over_dims': tuple(clim.over_dims),
                           'dtype_code': engine._common_dtype([i.data for i in inputs]), 'regather': _regather}  # pylint: disable=protected-access
   try:
     return engine.reduce_statistics(kind, inputs, dims, sizes, reduce_dims, w_da, bin_dims, func=func, mask=mask,

@@ -144,6 +144,18 @@ def compute_metrics_from_statistics(metrics, statistic_values):
   return {name: compute_metric_from_statistics(m, statistic_values) for name, m in metrics.items()}
 
 
+def _aligned_ref(climatology, over_dims, positions, prefetch=False):
+  """A climatology in HBM (or small enough to be uploaded whole) is gathered in place; a host-resident one -- a memory map, an
+  array beyond `climatology_cache.AUTO_RESIDENT_BYTES`, anything `climatology_cache.cached()` was called on -- goes through
+  its slab pool: only the (dayofyear, hour) slabs this chunk names are (or become) device resident (base.py:396-403 computes
+  exactly those from a lazily backed dataset)."""
+  from weatherbenchx_amd import climatology_cache  # pylint: disable=g-import-not-at-top
+  cache = climatology_cache.cache_for(climatology)
+  if cache is not None:
+    return cache.ref(over_dims, positions, prefetch=prefetch)
+  return lazy.ClimatologyRef(climatology, over_dims, positions)
+
+
 class PerVariableStatisticWithClimatology(Statistic):
   """Statistics of (prediction, target, climatology at valid_time) (base.py:338-415).
 
@@ -168,16 +180,22 @@ class PerVariableStatisticWithClimatology(Statistic):
   def _compute_per_variable(self, predictions, targets, climatology):
     # ACC asks for the same alignment three times per variable (base.py:403): resolve it once per
     # (predictions object, climatology variable).
+    ref = self.resolve_climatology(predictions, climatology)
+    return self._compute_per_variable_with_aligned_climatology(predictions, targets, ref)
+
+  @classmethod
+  def resolve_climatology(cls, predictions, climatology, prefetch=False) -> 'lazy.ClimatologyRef':
+    """The alignment of `climatology` with these predictions, resolved once per (predictions object, climatology variable)."""
     cache = predictions.__dict__.setdefault('_wbx_clim_refs', {})
     hit = cache.get(id(climatology))
     version = climatology.__dict__.get('_mutations', 0)
     if hit is None or hit[0] is not climatology or hit[2] != version:
-      hit = (climatology, self._climatology_ref(predictions, climatology), version)
+      hit = (climatology, cls._climatology_ref(predictions, climatology, prefetch=prefetch), version)
       cache[id(climatology)] = hit
-    return self._compute_per_variable_with_aligned_climatology(predictions, targets, hit[1])
+    return hit[1]
 
   @staticmethod
-  def _climatology_ref(predictions, climatology) -> 'lazy.ClimatologyRef':
+  def _climatology_ref(predictions, climatology, prefetch=False) -> 'lazy.ClimatologyRef':
     # The index tables depend on the time labels only: chunks that carry the same (init_time, lead_time) / valid_time values
     # against the same (unmodified) climatology object reuse them (datetime arithmetic and dayofyear / hour extraction
     # were ~0.1 ms of every chunk's host time).
@@ -194,7 +212,7 @@ class PerVariableStatisticWithClimatology(Statistic):
       key = (id(climatology), climatology.__dict__.get('_mutations', 0), labels_key)
       hit = _CLIM_REF_CACHE.get(key)
       if hit is not None and hit[0] is climatology:
-        return lazy.ClimatologyRef(climatology, hit[1], hit[2])
+        return _aligned_ref(climatology, hit[1], hit[2], prefetch)
     except (TypeError, ValueError):
       key = None
     if names == ('valid_time',):
@@ -212,7 +230,7 @@ class PerVariableStatisticWithClimatology(Statistic):
       if len(_CLIM_REF_CACHE) > 64:
         _CLIM_REF_CACHE.clear()
       _CLIM_REF_CACHE[key] = (climatology, tuple(valid_time.dims), positions)  # (holds the object: its id cannot be recycled)
-    return lazy.ClimatologyRef(climatology, tuple(valid_time.dims), positions)
+    return _aligned_ref(climatology, tuple(valid_time.dims), positions, prefetch)
 
   @abc.abstractmethod
   def _compute_per_variable_with_aligned_climatology(self, predictions, targets, aligned_climatology):

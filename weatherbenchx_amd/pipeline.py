@@ -13,6 +13,7 @@ from typing import Callable, Mapping
 import numpy as np
 
 from weatherbenchx_amd import aggregation
+from weatherbenchx_amd import climatology_cache
 from weatherbenchx_amd import distributed
 from weatherbenchx_amd import engine
 from weatherbenchx_amd import replay
@@ -354,13 +355,24 @@ def _consume(chunk_streams, passes, acc):
       for state in in_flight.popleft():
         state.wait()  # the fence of that chunk's kernels: lets go of its inputs (nothing is read back here)
   replayer = _Replayer(passes, acc)
-  for group in zip(*chunk_streams):
-    acc.next_chunk()
-    # steady state: a chunk like one that has been recorded is ONE call into the library (replay.py; wbx_chunk_replay)
-    done = replayer.try_replay(group)
-    if done is not None:
-      retire(done)
-      continue
+  groups = iter(zip(*chunk_streams))
+  group = next(groups, None)
+  with climatology_cache.chunk_loop():
+    while group is not None:
+      group = _consume_one(group, groups, passes, acc, replayer, retire)
+  while in_flight:
+    for state in in_flight.popleft():
+      state.wait()
+
+
+def _consume_one(group, groups, passes, acc, replayer, retire):
+  """Chunk `group` enqueued; -> the next group (loaded before this one's kernels have run)."""
+  acc.next_chunk()
+  # steady state: a chunk like one that has been recorded is ONE call into the library (replay.py; wbx_chunk_replay)
+  done = replayer.try_replay(group)
+  if done is not None:
+    retire(done)
+  else:
     if replayer.recorder is not None:
       with replayer.recorder:
         try:
@@ -372,9 +384,16 @@ def _consume(chunk_streams, passes, acc):
     else:
       states = _run_chunk(group, passes, acc)
     retire(states)
-  while in_flight:
-    for state in in_flight.popleft():
-      state.wait()
+  # climatology slab pools (climatology_cache.py): this chunk's slabs are stamped with fences behind its launches, and the
+  # slabs of the NEXT chunk are asked for now -- one chunk ahead on the copy stream
+  climatology_cache.chunk_enqueued()
+  nxt = next(groups, None)
+  if nxt is not None and climatology_cache.active():
+    try:
+      climatology_cache.prefetch_for(passes, nxt)
+    except Exception:  # pylint: disable=broad-except  (the statistic itself raises it where the reference would)
+      pass
+  return nxt
 
 
 def _run_chunk(group, passes, acc):
