@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert hasattr(lib, name), f'{name} declared in include/wbx.h but not exported'
   import re
   header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wbx.h')).read()
-  assert _hip.load_library().wbx_abi_version() == int(re.search(r'#define\s+WBX_ABI_VERSION\s+(\d+)', header).group(1)) == 12
+  assert _hip.load_library().wbx_abi_version() == int(re.search(r'#define\s+WBX_ABI_VERSION\s+(\d+)', header).group(1)) == 13
 
 
 def test_struct_layout_matches_header():

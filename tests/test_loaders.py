@@ -108,3 +108,88 @@ def test_lead_time_slice_is_selected_by_label_with_inclusive_bounds(tmp_path):
   p = lp.load_chunk(init_chunk, slice(np.timedelta64(1, 'h'), None))['z']
   np.testing.assert_array_equal(p['lead_time'].values, lead_times[1:])
   assert lp.load_chunk(init_chunk, slice(np.timedelta64(100, 'h'), None))['z'].shape[1] == 0
+
+
+@pytest.mark.parametrize('fmt', ['npy', 'nc'])
+def test_device_layout_transposes_on_the_way_into_the_chunk(tmp_path, fmt):
+  """`device_layout='lon_fastest'` over a [.., longitude, latitude] archive: the chunk arrives [.., latitude, longitude],
+  C-contiguous, value for value the stored field transposed (wbx_host_transpose: grids that are no multiple of the 32 x 32
+  tile or the 8 x 8 block, big-endian NetCDF decoded on the way, threads on)."""
+  src_p, src_t, init_times, lead_times, times, dims, coords, pv, tv = _write(str(tmp_path), fmt, nlat=43, nlon=70)
+  for threads in (1, 3):
+    lp = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=False, device_layout='lon_fastest', threads=threads)
+    lt = loaders.TargetsFromFiles(src_t, times, dims, coords, pinned=False, add_nan_mask=True, device_layout='lon_fastest', threads=threads)
+    lp._gather_swapped.__func__  # noqa: B018
+    p = lp.load_chunk(init_times[[3, 1]], lead_times[1:])['z']
+    assert p.dims == ('init_time', 'lead_time', 'level', 'latitude', 'longitude') and p.values.flags['C_CONTIGUOUS']
+    np.testing.assert_array_equal(p.values, np.swapaxes(pv[[3, 1]][:, 1:], -1, -2))
+    t = lt.load_chunk(init_times[[3, 1]], lead_times[1:])['z']
+    assert t.dims == ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
+    for a, i in enumerate((3, 1)):
+      for b, l in enumerate((1, 2)):
+        np.testing.assert_array_equal(t.values[a, b], np.swapaxes(tv[i + l], -1, -2))
+    np.testing.assert_array_equal(np.asarray(t.coords['mask'].values), ~np.isnan(t.values))
+    t0 = lt.load_chunk(times[2:4])['z']  # init times as valid times
+    np.testing.assert_array_equal(t0.values, np.swapaxes(tv[2:4], -1, -2))
+  # a layout the store already has is left alone; one it cannot be brought to by exchanging the last two dims is refused
+  same = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=False, device_layout='lat_fastest')
+  assert same.load_chunk(init_times[:1], lead_times)['z'].dims == ('init_time', 'lead_time') + dims
+  with pytest.raises(ValueError, match='do not end in'):
+    loaders.PredictionsFromFiles(src_p, init_times, lead_times, ('longitude', 'level', 'latitude'), coords, device_layout='lon_fastest')
+  with pytest.raises(ValueError, match='device_layout'):
+    loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, device_layout='tiled')
+
+
+def test_host_transpose_entry_point():
+  """The raw C entry point: float32 and float64, extents around the tile / block sizes, argument checks."""
+  import ctypes as C
+  from weatherbenchx_amd import _hip
+  lib = _hip.load_library()
+  rng = np.random.default_rng(0)
+  for dt in (np.float32, np.float64):
+    for batch, rows, cols in ((1, 1, 1), (2, 7, 9), (1, 32, 32), (3, 33, 31), (1, 64, 8), (2, 40, 100), (1, 1440 // 8, 721 // 7)):
+      src = rng.standard_normal((batch, rows, cols)).astype(dt)
+      dst = np.full((batch, cols, rows), np.nan, dt)
+      assert lib.wbx_host_transpose(dst.ctypes.data, src.ctypes.data, batch, rows, cols, src.itemsize) == 0
+      np.testing.assert_array_equal(dst, np.swapaxes(src, 1, 2))
+  a = np.zeros(64, np.float32)
+  assert lib.wbx_host_transpose(a.ctypes.data, a.ctypes.data, 1, 8, 8, 4) != 0 and b'overlap' in lib.wbx_last_error()
+  assert lib.wbx_host_transpose(a.ctypes.data, None, 1, 8, 8, 4) != 0
+  assert lib.wbx_host_transpose(a.ctypes.data, a.ctypes.data + 128, 1, 4, 4, 2) != 0 and b'elem_bytes' in lib.wbx_last_error()
+  assert lib.wbx_host_transpose(None, None, 0, 8, 8, 4) == 0
+
+
+@pytest.mark.parametrize('layout', [None, 'lon_fastest'])
+def test_both_device_layouts_from_one_latitude_fastest_file(backend, tmp_path, layout):
+  """One [.., longitude, latitude] archive, evaluated as it is stored and through the transposing loader: RMSE / MAE and the
+  zonal spectra of predictions and targets agree with the oracle on the whole arrays either way."""
+  from weatherbenchx_amd import spectra
+  src_p, src_t, init_times, lead_times, times, dims, coords, pv, tv = _write(str(tmp_path), 'npy', nlat=19, nlon=36)
+  tv = np.nan_to_num(tv, nan=280.0)
+  np.save(src_t['z'], tv)
+  lp = loaders.PredictionsFromFiles(src_p, init_times, lead_times, dims, coords, pinned=backend == 'hip', device_layout=layout)
+  lt = loaders.TargetsFromFiles(src_t, times, dims, coords, pinned=backend == 'hip', device_layout=layout)
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  spec = {'sp': spectra.ZonalPowerSpectrum('predictions'), 'st': spectra.ZonalPowerSpectrum('targets')}
+  area = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  zonal = aggregation.Aggregator(reduce_dims=['init_time', 'latitude'], weigh_by=[weighting.GridAreaWeighting()])
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=2)
+  load = loaders.load_chunk_fn(lp, lt)
+  out = pipeline.evaluate_passes(tc, [('det', load, metrics, area), ('spec', load, spec, zonal)], prefetch=1 if backend == 'hip' else 0)
+  got = out['det'][None].metric_values(metrics)
+  valid_idx = (np.arange(init_times.size)[:, None] + np.arange(lead_times.size)[None, :])
+  tfull = tv[valid_idx]
+  fdims = ('init_time', 'lead_time') + dims
+  w = (O.grid_area_weights(coords['latitude']), ('latitude',))
+  for name, lane in (('rmse', O.squared_error(pv, tfull)), ('mae', O.absolute_error(pv, tfull))):
+    sws, sw, od = O.aggregate(lane, fdims, ['init_time', 'latitude', 'longitude'], weights=[w])
+    want = np.sqrt(sws / sw) if name == 'rmse' else sws / sw
+    np.testing.assert_allclose(np.asarray(got[f'{name}.z'].transpose(*od).values), want, rtol=RTOL, err_msg=name)
+  sgot = out['spec'][None].metric_values(spec)
+  for key, field in (('sp.z', pv), ('st.z', tfull)):
+    s = O.zonal_power_spectrum(np.swapaxes(field, -1, -2).astype(np.float64), lon_axis=-1)  # [init, lead, level, lat, k]
+    wl = O.grid_area_weights(coords['latitude'])[None, None, None, :, None]
+    want = (s * wl).sum(axis=(0, 3)) / (np.ones_like(s) * wl).sum(axis=(0, 3))
+    res = sgot[key]
+    kdim = [d for d in res.dims if d not in ('lead_time', 'level')][0]
+    np.testing.assert_allclose(np.asarray(res.transpose('lead_time', 'level', kdim).values), want, rtol=2e-4, atol=2e-6 * want.max(), err_msg=key)

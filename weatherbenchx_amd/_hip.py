@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
     'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_det_spectrum_slabs', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
-    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay',
+    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay', 'wbx_host_transpose',
 )
 
 # wbx_fn (include/wbx.h): the entry points a chunk record may hold
@@ -200,6 +200,7 @@ def load_library():
         'wbx_zonal_spectrum_slabs': [vp, vp, i64, i64, i64, i64, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
     protos['wbx_chunk_replay'] = [vp, i32, vp, i32, vp, i32]
+    protos['wbx_host_transpose'] = [vp, vp, i64, i64, i64, C.c_int32]
     for name, argtypes in protos.items():
       fn = getattr(lib, name)
       fn.argtypes = argtypes

@@ -12,6 +12,12 @@ read -- decoded, if the file is big-endian -- STRAIGHT into page-locked memory (
 upload is pure DMA on its copy stream (`wbx_memcpy_h2d_async`) and overlaps both the kernels of the previous chunk and this
 loader's reads of the next one; the pool of page-locked blocks is the double buffer.  `add_nan_mask` attaches the `mask`
 coordinate of data_loaders/base.py:25-56.  `timings` accumulates what the reads cost (bytes, seconds): disk / page-cache rate.
+
+`device_layout='lon_fastest'`: real archives are stored [.., longitude, latitude] (xarray_loaders.py:185-188, 236-239 hand on the
+store's order) and the zonal transforms are bound by L1 line requests on such rows (0.38 of the HBM peak against 0.60 on
+longitude-fastest rows).  The copy into page-locked memory is then a blocked transposition of the last two dims
+(`wbx_host_transpose`: 32 x 32 tiles, AVX2, split over the loader's threads), the chunk's DataArrays are [.., latitude,
+longitude], and the DMA and every kernel see longitude-fastest fields; nothing is transposed on the device.
 """
 from __future__ import annotations
 
@@ -55,9 +61,12 @@ class FileLoader:
   every variable (after the time axes), e.g. ('level', 'longitude', 'latitude'); `coords` = {dim: values}."""
 
   def __init__(self, sources: Mapping[str, object], dims: Sequence[str], coords: Mapping[str, np.ndarray], *, add_nan_mask: bool = False,
-               pinned: bool = True, threads: int = 4):
+               pinned: bool = True, threads: int = 4, device_layout: str | None = None):
     self._sources = {k: (_FileSource(v) if isinstance(v, str) else _FileSource(*v)) for k, v in sources.items()}
-    self._dims = tuple(dims)
+    self._stored_dims = tuple(dims)
+    self._swap = _needs_swap(self._stored_dims, device_layout)
+    # the dims of the chunks handed out: the stored order, or with the last two exchanged
+    self._dims = self._stored_dims[:-2] + (self._stored_dims[-1], self._stored_dims[-2]) if self._swap else self._stored_dims
     self._coords = {k: np.asarray(v) for k, v in coords.items()}
     self._add_nan_mask = add_nan_mask
     self._pinned = pinned
@@ -74,9 +83,49 @@ class FileLoader:
         pass
     return np.empty(shape, dtype)
 
+  def _out_shape(self, shape):
+    """The shape of a stored item as it is handed out."""
+    shape = tuple(shape)
+    return shape[:-2] + (shape[-1], shape[-2]) if self._swap else shape
+
+  def _gather_swapped(self, arr, index, out):
+    """out[a] = arr[index[a]] with the last two axes exchanged: the copy out of the page cache IS the layout change
+    (`wbx_host_transpose`, blocked; planes dealt to the loader's threads -- ctypes releases the GIL)."""
+    from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+    lib = _hip.load_library()
+    t0 = time.perf_counter()
+    rows, cols = (int(n) for n in arr.shape[-2:])
+    nb = int(np.prod(arr.shape[1:-2], dtype=np.int64))
+    native = np.dtype(arr.dtype).newbyteorder('=')
+    n = len(index)
+
+    def part(a, b0, b1):
+      src = arr[int(index[a])].reshape(nb, rows, cols)[b0:b1]
+      if not (arr.dtype.isnative and src.flags['C_CONTIGUOUS']):
+        src = np.ascontiguousarray(src, dtype=native)  # a big-endian file (NetCDF-3): decoded first
+      dst = out[a].reshape(nb, cols, rows)[b0:b1]
+      _hip.check(lib.wbx_host_transpose(dst.ctypes.data, src.ctypes.data, b1 - b0, rows, cols, native.itemsize), 'wbx_host_transpose')
+    if native.itemsize not in (4, 8):
+      raise TypeError(f'device_layout: fields of {arr.dtype} cannot be transposed by the loader (float32 / float64 only)')
+    units = [(a, 0, nb) for a in range(n)]
+    if self._threads > 1 and out.nbytes >= (8 << 20):
+      per = max(1, -(-n * nb // (4 * self._threads)))  # ~4 units per thread
+      units = [(a, b0, min(b0 + per, nb)) for a in range(n) for b0 in range(0, nb, per)]
+      if self._pool is None:
+        from concurrent.futures import ThreadPoolExecutor  # pylint: disable=g-import-not-at-top
+        self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix='wbx-loader')
+      list(self._pool.map(lambda u: part(*u), units))
+    else:
+      for u in units:
+        part(*u)
+    self.timings['seconds'] += time.perf_counter() - t0
+    self.timings['bytes'] += out.nbytes
+
   def _gather(self, arr, index, out):
     """out[...] = arr[index] along the leading axis, gathered STRAIGHT into `out` (no temporary), timed.  The indices have
     been validated (`_positions`), so `mode='clip'` only switches numpy's buffered copy off."""
+    if self._swap:
+      return self._gather_swapped(arr, index, out)
     t0 = time.perf_counter()
 
     def part(lo, hi):
@@ -137,7 +186,7 @@ class PredictionsFromFiles(FileLoader):
     out = {}
     for name, src in self._sources.items():
       arr = src.array()
-      buf = self._buffer((ii.size, li.size) + tuple(arr.shape[2:]), np.dtype(arr.dtype).newbyteorder('='))
+      buf = self._buffer((ii.size, li.size) + self._out_shape(arr.shape[2:]), np.dtype(arr.dtype).newbyteorder('='))
       for a, i in enumerate(ii):
         self._gather(arr[int(i)], li, buf[a])
       coords = dict(self._coords, init_time=self._init_times[ii], lead_time=self._lead_times[li])
@@ -162,7 +211,7 @@ class TargetsFromFiles(FileLoader):
       out = {}
       for name, src in self._sources.items():
         arr = src.array()
-        buf = self._buffer((ti.size,) + tuple(arr.shape[1:]), np.dtype(arr.dtype).newbyteorder('='))
+        buf = self._buffer((ti.size,) + self._out_shape(arr.shape[1:]), np.dtype(arr.dtype).newbyteorder('='))
         self._gather(arr, ti, buf)
         out[name] = xr.DataArray(buf, dims=('init_time',) + self._dims,
                                  coords={k: v for k, v in dict(self._coords, init_time=init_times).items() if k in ('init_time',) + self._dims}, name=name)
@@ -173,13 +222,30 @@ class TargetsFromFiles(FileLoader):
     out = {}
     for name, src in self._sources.items():
       arr = src.array()
-      shape = (init_times.size, lead_times.size) + tuple(arr.shape[1:])
+      shape = (init_times.size, lead_times.size) + self._out_shape(arr.shape[1:])
       buf = self._buffer(shape, np.dtype(arr.dtype).newbyteorder('='))
-      self._gather(arr, ti, buf.reshape((ti.size,) + tuple(arr.shape[1:])))
+      self._gather(arr, ti, buf.reshape((ti.size,) + self._out_shape(arr.shape[1:])))
       coords = {k: v for k, v in dict(self._coords, init_time=init_times, lead_time=lead_times).items() if k in ('init_time', 'lead_time') + self._dims}
       da = xr.DataArray(buf, dims=('init_time', 'lead_time') + self._dims, coords=coords, name=name)
       out[name] = da.assign_coords(valid_time=xr.DataArray(valid, dims=('init_time', 'lead_time')))
     return self._finish(out)
+
+
+_LON_NAMES, _LAT_NAMES = ('longitude', 'lon'), ('latitude', 'lat')
+
+
+def _needs_swap(dims, device_layout) -> bool:
+  """Does `device_layout` ('lon_fastest' | 'lat_fastest' | None) ask for the last two stored dims to be exchanged?"""
+  if device_layout is None:
+    return False
+  if device_layout not in ('lon_fastest', 'lat_fastest'):
+    raise ValueError(f"device_layout {device_layout!r}: 'lon_fastest', 'lat_fastest' or None")
+  want, other = (_LON_NAMES, _LAT_NAMES) if device_layout == 'lon_fastest' else (_LAT_NAMES, _LON_NAMES)
+  if len(dims) >= 1 and dims[-1] in want:
+    return False
+  if len(dims) >= 2 and dims[-2] in want and dims[-1] in other:
+    return True
+  raise ValueError(f'device_layout={device_layout!r}: the stored dims {tuple(dims)} do not end in (latitude, longitude) in either order')
 
 
 def _positions(axis: np.ndarray, wanted: np.ndarray, what: str) -> np.ndarray:
