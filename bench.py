@@ -975,8 +975,70 @@ def distributed_shard(times, env):
   return distributed.shard_chunks(list(times.iter_with_chunk_offsets()), env.rank, env.world)
 
 
+def _lat_archive(env, pool, nlead, nlev, lead_time):
+  """Writes the z fields of `pool` as a latitude-fastest archive -- p [init, lead, level, longitude, latitude], t [time, level,
+  longitude, latitude] .npy files in /dev/shm --, reads every chunk back through `loaders.*FromFiles(device_layout=
+  'lon_fastest')` (the copy into page-locked memory is wbx_host_transpose) and puts what arrived into the pool.  -> what the
+  host paid: transposition against the plain copy of the same bytes, and the check that what arrived is the archive transposed."""
+  import shutil
+  import tempfile
+  from weatherbenchx_amd import loaders
+  torch = env.torch
+  npool = len(pool)
+  root = '/dev/shm' if os.path.isdir('/dev/shm') else None
+  d = tempfile.mkdtemp(prefix='wbx_lat_archive_', dir=root)
+  threads = max(1, min(16, (os.cpu_count() or 2) // 2))
+  try:
+    inits = np.datetime64('2020-01-01T00', 'ns') + np.arange(npool) * np.timedelta64(24, 'h')
+    ntime = (npool - 1) * 4 + nlead  # valid times of daily inits with 6-hourly leads
+    times = np.datetime64('2020-01-01T00', 'ns') + np.arange(ntime) * np.timedelta64(6, 'h')
+    pp, tp = os.path.join(d, 'p.npy'), os.path.join(d, 't.npy')
+    pm = np.lib.format.open_memmap(pp, mode='w+', dtype=np.float32, shape=(npool, nlead, nlev, env.nlon, env.nlat))
+    tm = np.lib.format.open_memmap(tp, mode='w+', dtype=np.float32, shape=(ntime, nlev, env.nlon, env.nlat))
+    for k, buf in enumerate(pool):  # (archive order = the pool's fields transposed; t rows that two inits share: the later one's)
+      pm[k] = buf['z_p'][0].transpose(-1, -2).contiguous().cpu().numpy()
+      tm[4 * k:4 * k + nlead] = buf['z_t'][0].transpose(-1, -2).contiguous().cpu().numpy()
+    pm.flush()
+    tm.flush()
+    del pm, tm
+    dims = ('level', 'longitude', 'latitude')
+    coords = {'level': np.arange(nlev), 'longitude': env.lon, 'latitude': env.lat}
+    out = {'files': {'p': [npool, nlead, nlev, env.nlon, env.nlat], 't': [ntime, nlev, env.nlon, env.nlat], 'dir': root or 'tmp'},
+           'loader_threads': threads}
+    for name, layout in (('plain_copy', None), ('transposed', 'lon_fastest')):
+      lp = loaders.PredictionsFromFiles({'z': pp}, inits, lead_time, dims, coords, device_layout=layout, threads=threads)
+      lt = loaders.TargetsFromFiles({'z': tp}, times, dims, coords, device_layout=layout, threads=threads)
+      for rep in range(2):  # (the second round reads from a warm page cache into warm page-locked blocks)
+        lp.timings.update(bytes=0, seconds=0.0)
+        lt.timings.update(bytes=0, seconds=0.0)
+        got = [(lp.load_chunk(inits[k:k + 1], lead_time)['z'], lt.load_chunk(inits[k:k + 1], lead_time)['z']) for k in range(npool)]
+      nbytes, secs = lp.timings['bytes'] + lt.timings['bytes'], lp.timings['seconds'] + lt.timings['seconds']
+      out[name + '_GBps'] = round(nbytes / secs / 1e9, 2)
+      out[name + '_ms_per_chunk'] = round(secs / npool * 1e3, 1)
+      if layout is not None:
+        ok = True
+        for k, (pc, tc_) in enumerate(got):
+          assert pc.dims[-2:] == ('latitude', 'longitude') and tc_.dims[-2:] == ('latitude', 'longitude')
+          zp = torch.as_tensor(np.asarray(pc.data)).to(env.dev)
+          zt = torch.as_tensor(np.asarray(tc_.data)).to(env.dev)
+          ok = ok and bool(torch.equal(zp, pool[k]['z_p'])) and (k + 1 < npool or bool(torch.equal(zt, pool[k]['z_t'])))
+          pool[k]['z_p'], pool[k]['z_t'] = zp, zt
+        out['arrived_equals_archive_transposed'] = ok
+      del got
+    out['transposition_over_plain_copy'] = round(out['plain_copy_GBps'] / out['transposed_GBps'], 2)
+    out['note'] = ('the loader threads copy every chunk from the page cache into page-locked memory either way; with device_layout= '
+                   "'lon_fastest' that copy is the blocked transposition.  A file-backed job is bound by this copy and the H2D "
+                   'behind it, not by its kernels: the chunk loop below is timed on what arrived, resident')
+    return out
+  finally:
+    shutil.rmtree(d, ignore_errors=True)
+
+
 # ---- configs[4]: the full suite streamed over (init x lead) chunks, sharded over the ranks ------------------------
-def config5_leg(env):
+def config5_leg(env, lat_archive=False):
+  """`lat_archive`: z and its climatology come from a LATITUDE-FASTEST archive ([.., longitude, latitude] .npy files in
+  /dev/shm, the layout of the public stores) through the transposing loader / slab pool (`device_layout='lon_fastest'`): the
+  device sees longitude-fastest fields and runs the same kernels as the plain leg; timed with every slab resident."""
   from weatherbenchx_amd import aggregation, pipeline, spectra, time_chunks, weighting
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.metrics import deterministic
@@ -992,10 +1054,14 @@ def config5_leg(env):
   tdims = ('init_time', 'lead_time') + env.sp
   cdims = ('dayofyear', 'hour', 'level') + env.sp
   sp_shape = env.sp_shape()
-  # resident pool (H2D excluded and stated): chunk i reads buffer i mod npool; the climatology holds every
-  # (dayofyear, hour) slot the 366 inits x 20 leads touch in a ring of 12 days (dayofyear = 1 + (i mod 6) + lead days)
-  # (its own generator, the same on every rank: chunk i holds the same numbers whichever rank runs it, so the result does
-  # not depend on N)
+  # resident pool of FIELDS (their H2D is excluded and stated): chunk i reads buffer i mod npool (its own generator, the same on
+  # every rank: chunk i holds the same numbers whichever rank runs it, so the result does not depend on N).
+  # The CLIMATOLOGY is a whole calendar -- [366 dayofyear, 4 hours, level, lat, lon], 225 GB at 37 levels -- in host memory behind
+  # a slab pool (climatology_cache.py): a chunk's valid times name 20 of its 1464 (dayofyear, hour) slabs, daily inits share 16
+  # of them with their predecessor, the 4 new ones are uploaded one chunk ahead on a copy stream.  (Host memory: the calendar is
+  # a view whose dayofyear stride is 0 over ONE page-locked day -- generating 225 GB would take longer than the whole bench; the
+  # pool sees 1464 distinct slabs all the same: a slab is keyed by its position and uploaded when it is missed.)
+  from weatherbenchx_amd import climatology_cache
   gen5 = env.torch.Generator(device=env.dev)
   gen5.manual_seed(4242)
   pool = []
@@ -1006,20 +1072,27 @@ def config5_leg(env):
     t2 += env.randn((1, nlead) + sp_shape, gen=gen5)
     pool.append({'z_p': env.randn((1, nlead, nlev) + sp_shape, 280.0, gen=gen5),
                  'z_t': env.randn((1, nlead, nlev) + sp_shape, 280.0, gen=gen5), 't2m_p': ens, 't2m_t': t2})
-  ndoy = 12
-  clim = xr.Dataset({'z': xr.DataArray(env.randn((ndoy, 4, nlev) + sp_shape, 280.0, 10.0, gen=gen5), dims=cdims, coords={
+  ndoy = 366
+  archive = None
+  c_shape, c_dims = (4, nlev) + sp_shape, cdims
+  if lat_archive:
+    archive = _lat_archive(env, pool, nlead, nlev, lead_time)  # z_p / z_t of the pool now are what the loaders delivered
+    c_shape, c_dims = (4, nlev, env.nlon, env.nlat), ('dayofyear', 'hour', 'level', 'longitude', 'latitude')
+  day = env.ctx.pinned_empty(c_shape, np.float32)
+  day[...] = env.randn(c_shape, 280.0, 10.0, gen=gen5).cpu().numpy()
+  clim_slots = 48  # two chunks' worth of slabs and some: 7.4 GB at 37 levels
+  clim = climatology_cache.cached(xr.Dataset({'z': xr.DataArray(np.broadcast_to(day[None], (ndoy,) + day.shape), dims=c_dims, coords={
       'dayofyear': np.arange(1, ndoy + 1), 'hour': np.array([0, 6, 12, 18]), 'level': level,
-      'latitude': env.lat, 'longitude': env.lon})})
+      'latitude': env.lat, 'longitude': env.lon})}), slots=clim_slots, device_layout='lon_fastest' if lat_archive else None,
+      threads=16 if lat_archive else 4)
+  slab_bytes = int(np.prod((nlev,) + sp_shape)) * 4
   env.torch.cuda.synchronize()
   index_of = {int(t.astype('int64')): i for i, t in enumerate(init_times)}
-  ring = np.datetime64('2020-01-01T00', 'ns') + np.arange(6) * np.timedelta64(24, 'h')
 
   def coords_for(inits):
-    # the chunk keeps its real init_time label for the result; the climatology is addressed through a valid_time
-    # coordinate in the 6-day ring, so that 366 inits fit a 12-day resident climatology
+    # (real labels: the climatology is addressed at dayofyear / hour of init_time + lead_time)
     i = index_of[int(inits[0].astype('int64'))]
-    return i, {'init_time': inits, 'lead_time': lead_time, 'latitude': env.lat, 'longitude': env.lon,
-               'valid_time': (('init_time', 'lead_time'), ring[i % 6] + lead_time[None, :])}
+    return i, {'init_time': inits, 'lead_time': lead_time, 'latitude': env.lat, 'longitude': env.lon}
 
   def load_det(inits, leads):
     i, cs = coords_for(inits)
@@ -1060,21 +1133,54 @@ def config5_leg(env):
     for name, _, metrics, _ in some:
       st[name][None].metric_values(metrics)
     return time.perf_counter() - tp
+  cache = climatology_cache.cache_for(clim['z'])
   warm = time_chunks.TimeChunks(init_times[:2 * env.world], lead_time, init_time_chunk_size=1)
   run(warm)
   env.sync()
   times = time_chunks.TimeChunks(init_times, lead_time, init_time_chunk_size=1)
   from weatherbenchx_amd import replay as _replay
   _replay.reset_stats()
+  ring_inits = np.tile(init_times[:6], ninit // 6 + 1)[:ninit]
+  if lat_archive:
+    # (the year-long stream is the plain leg's; here: inits cycling through six days, every slab in the pool after one round)
+    times = time_chunks.TimeChunks(ring_inits, lead_time, init_time_chunk_size=1)
+    run(time_chunks.TimeChunks(ring_inits[:12 * env.world], lead_time, init_time_chunk_size=1))
+    env.sync()
+    _replay.reset_stats()
+  c0 = dict(cache.stats)
   t0 = time.perf_counter()
   out = run(times)
   env.sync()
   rank_s = time.perf_counter() - t0
   dt = env.max_over_ranks(rank_s)
+  c1 = dict(cache.stats)
   record_stats = {k: v for k, v in _replay.STATS.items() if k != 'refusals'}
   record_stats['refusals'] = [str(x)[:160] for x in _replay.STATS['refusals'][:2]]
+  my_chunks = max(len(distributed_shard(times, env)), 1)
+  up_bytes = c1['upload_bytes'] - c0['upload_bytes']
+  clim_stats = {'host_shape': [ndoy, 4, nlev] + list(sp_shape), 'host_GB': round(ndoy * 4 * slab_bytes / 1e9, 1),
+                'slab_MB': round(slab_bytes / 1e6, 1), 'pool_slots': cache.nslots, 'pool_GB': round(cache.nslots * slab_bytes / 1e9, 2),
+                'uploads': c1['uploads'] - c0['uploads'], 'evictions': c1['evictions'] - c0['evictions'],
+                'asked_one_chunk_ahead': c1['prefetched'] - c0['prefetched'],
+                'h2d_MB_per_chunk_rank0': round(up_bytes / my_chunks / 1e6, 1),
+                'h2d_GBps_rank0': round(up_bytes / rank_s / 1e9, 1),
+                'note': ('every slab of the timed loop is in the pool (inits cycling through six days)' if lat_archive else
+                         'the timed job is bound by this stream (PCIe), not by its kernels: see all_slabs_resident')}
+  # the same loop with every slab it names already in the pool (inits cycling through six days: 40 slabs, 48 slots): what the
+  # kernels and the host cost per chunk when the copy stream is idle -- the gather tables are pool slots either way
+  hits = None
+  if not lat_archive:
+    ring = time_chunks.TimeChunks(ring_inits, lead_time, init_time_chunk_size=1)
+    run(time_chunks.TimeChunks(ring_inits[:12 * env.world], lead_time, init_time_chunk_size=1))
+    env.sync()
+    h0 = dict(cache.stats)
+    t0 = time.perf_counter()
+    run(ring)
+    env.sync()
+    hits_dt = env.max_over_ranks(time.perf_counter() - t0)
+    hits = (hits_dt, cache.stats['uploads'] - h0['uploads'])
   # per-pass pace of this rank (outside the timed region, a sixth of the chunks, no collective)
-  sub = time_chunks.TimeChunks(init_times[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
+  sub = time_chunks.TimeChunks(ring_inits[:max(2 * env.world, ninit // 6)], lead_time, init_time_chunk_size=1)
   nsub = len(distributed_shard(sub, env))
   from weatherbenchx_amd import engine as _engine
   fused = _engine.FUSE_DET_SPECTRA and env.nlon == 1440 and (env.layout == 'lon_fastest' or _engine.FUSE_DET_SPECTRA_LATFAST)
@@ -1091,11 +1197,13 @@ def config5_leg(env):
   # again by the spectra (20 B/point of traffic for the same 12 B/point of algorithmic input -- the fraction below counts 12)
   bytes_per_chunk = pz * 12 + pt * (m + 1) * 4
   rm = float(np.asarray(out['deterministic']['rmse.z'].values).mean())
-  return {'workload': f'configs[4]: full suite on {ninit} inits x {nlead} leads, streamed as [1 init x {nlead} lead] chunks from a '
-                      f'resident pool of {npool} (H2D excluded): z f32[{nlead},{nlev},{env.nlat},{env.nlon}] p,t + climatology -> '
+  return {'workload': ('z and its climatology from a latitude-fastest archive through the transposing loader / slab pool; ' if lat_archive else '') +
+                      f'configs[4]: full suite on {ninit} inits x {nlead} leads, streamed as [1 init x {nlead} lead] chunks from a '
+                      f'resident pool of {npool} (H2D excluded): z f32[{nlead},{nlev},{env.nlat},{env.nlon}] p,t + a [366,4,{nlev},..] host '
+                      f'climatology behind a {clim_slots}-slab device pool (its H2D INCLUDED) -> '
                       f'rmse/mse/mae/bias/acc/activity + zonal spectra of p and t; t2m f32[{nlead},{m},{env.nlat},{env.nlon}] -> '
                       'crps/spread-skill/unbiased-mean rmse/mean rmse; reduce (init_time, latitude, longitude) -> per (lead, level)',
-          'sharding': f'chunk i -> rank i mod {env.world}; the three evaluations interleaved chunk by chunk (pipeline.evaluate_passes), '
+          'sharding': f'contiguous runs of chunks per rank ({env.world}: consecutive inits share climatology slabs); the three evaluations interleaved chunk by chunk (pipeline.evaluate_passes), '
                       'every accumulator in HBM, ONE all-reduce for the whole job at the end',
           'collectives': stats.get('collectives'), 'accumulator_values': stats.get('accumulator_values'),
           'collective_backend': ('wbx_acc_allreduce (C ABI, RCCL)' if comm is not None else ('torch.distributed ' + args.backend)) if env.world > 1 else None,
@@ -1106,6 +1214,13 @@ def config5_leg(env):
           'ms_per_chunk_by_pass_note': 'subsets of the evaluations as their own jobs on a sixth of the chunks, outside the timed region',
           'z_bytes_per_point': 12, 'z_traffic_bytes_per_point': 12 if fused else 20, 'fused_det_spectra': bool(fused),
           'chunk_records': record_stats,
+          'climatology': clim_stats,
+          'all_slabs_resident': None if hits is None else {
+              'ms_per_chunk': hits[0] / ninit * 1e3, 'uploads_in_the_timed_loop': hits[1],
+              'value': evals_per_chunk * ninit / hits[0], 'unit': 'evals/s',
+              'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / hits[0] / 1e9 / HBM_PEAK_GBS / env.world, 4),
+              'note': 'inits cycling through six days: every slab of the loop is in the pool; kernels + host per chunk'},
+          'archive': archive,
           'value': evals_per_chunk * ninit / dt, 'unit': 'evals/s',
           'algorithmic_GBps': round(bytes_per_chunk * ninit / dt / 1e9, 1),
           'frac_of_hbm_peak_per_gpu': round(bytes_per_chunk * ninit / dt / 1e9 / HBM_PEAK_GBS / env.world, 4),
@@ -1250,7 +1365,7 @@ def _leg_record(leg):
 _NOT_LEGS = ('roofline', 'check', 'config', 'cpu_baseline', 'legs')
 _LEG_ALIASES = {'with_mask_coordinate': 'mask', 'with_nan_mask': 'nanmask', 'with_deterministic_suite': 'det', 'public_chunk_ens': 'pce',
                 'public_chunk_ens_ifs_layout': 'pce_ifs', 'public_chunk': 'pc', 'lat_fastest': 'lat', 'default_crps_ensemble': 'default',
-                'pairwise_form': 'pair', 'skipna_ensemble': 'skipna'}
+                'pairwise_form': 'pair', 'skipna_ensemble': 'skipna', 'all_slabs_resident': 'hits'}
 
 
 def _collect_legs(node, prefix, out):
@@ -1381,8 +1496,10 @@ def main():
         lf['public_chunk_ens']['with_mask_coordinate'] = public_chunk_ens_leg(env, with_mask=True)
         lf['public_chunk_ens']['with_nan_mask'] = public_chunk_ens_leg(env, with_mask='nan')
         lf['public_chunk_ens_ifs_layout'] = public_chunk_ens_leg(env, ifs_layout=True, with_mask=False)
-      result['lat_fastest'] = lf
       env.set_layout('lon_fastest')
+      if not args.no_config5 and want('config5'):
+        lf['config5'] = config5_leg(env, lat_archive=True)
+      result['lat_fastest'] = lf
   if not args.no_config5 and want('config5'):
     result['config5'] = config5_leg(env)
   if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu'):

@@ -361,8 +361,9 @@ def _run_spectrum(field, lon_dim, group, scale, ngroup, cache=None):
 class _FakeSlabPool:
   """NumPy stand-in for climatology_cache._HipPool: the "device" pool is a host array, copies land at once."""
 
-  def __init__(self, nslots, slab_shape, np_dtype):
+  def __init__(self, nslots, slab_shape, np_dtype, swap=False, threads=1):
     self.dtype = np.dtype(np_dtype)
+    self.swap = swap
     self.slab_shape = tuple(int(n) for n in slab_shape)
     self.slab_nbytes = int(np.prod(self.slab_shape, dtype=np.int64)) * self.dtype.itemsize
     self.array = np.full((nslots,) + self.slab_shape, np.nan, self.dtype)  # (a slot that was never filled poisons a result)
@@ -378,7 +379,7 @@ class _FakeSlabPool:
     return []
 
   def submit(self, job):
-    self.array[job.slot] = np.asarray(job.src)
+    self.array[job.slot] = np.swapaxes(np.asarray(job.src), -1, -2) if self.swap else np.asarray(job.src)
     self.writes.append((job.slot, job.key))
     job.event.set()
 

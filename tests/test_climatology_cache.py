@@ -194,6 +194,21 @@ def test_results_equal_the_resident_climatology(backend):
   assert climatology_cache.cache_for(pooled['z']).stats['evictions'] > 0
 
 
+def test_a_latitude_fastest_climatology_is_transposed_on_its_way_into_the_pool(backend):
+  """Archive order [.., longitude, latitude] for fields AND climatology, `device_layout='lon_fastest'` for both: the pool holds
+  [level, latitude, longitude] slabs (the staging copy is wbx_host_transpose), the statistics see one layout."""
+  full, _ = _climatology(ndoy=12)
+  coords = {'dayofyear': np.arange(1, 13), 'hour': HOURS, 'level': LEVEL, 'latitude': LAT, 'longitude': LON}
+  lat_fast = xr.DataArray(np.ascontiguousarray(np.swapaxes(full, -1, -2)), dims=CDIMS[:3] + ('longitude', 'latitude'), coords=coords)
+  clim = climatology_cache.cached(xr.Dataset({'z': lat_fast}), slots=8, device_layout='lon_fastest')
+  inits, lead, p, t, load = _job(8, 3, lead_hours=12)
+  times = time_chunks.TimeChunks(inits, lead, init_time_chunk_size=1)
+  values = pipeline.evaluate_chunks(times, load, _metrics(clim), _area())[None].metric_values(_metrics(clim))
+  _check(values, _oracle_acc(p, t, full, inits, lead))
+  cache = climatology_cache.cache_for(clim['z'])
+  assert cache.slab_dims == ('level', 'latitude', 'longitude') and cache.stats['evictions'] > 0
+
+
 def test_memory_maps_get_a_pool_by_themselves(backend, tmp_path, monkeypatch):
   full, _ = _climatology(ndoy=10)
   path = str(tmp_path / 'clim.npy')

@@ -101,7 +101,9 @@ def test_recorder_refuses_what_is_not_steady_state():
   assert rec is not None and why == []
   assert [t for t in rec.slot_tags] == [((0, 'p', 'v'), 'data', 0)] and rec.nrelocs == 3
   assert sorted((r.call, r.arg, r.offset) for r in list(rec.relocs)[:3]) == [(0, 1, 4), (1, 1, 8), (1, 2, 0)]
-  for log, text in (([('wbx_malloc', (None, 8, None)), det], 'not an enqueue-only entry point'),
+  rec, why = build([('wbx_malloc', (None, 8, None)), det])  # an allocation stays with the record: nothing to replay, nothing to refuse
+  assert rec is not None and len(rec.calls) == 1
+  for log, text in (([('wbx_free', (None, None)), det], 'not an enqueue-only entry point'),
                     ([('wbx_memcpy_h2d', (None, None, None, 8)), det], 'not an enqueue-only entry point'),
                     ([ok_call], 'no launch was seen'),
                     ([('wbx_memset', (C.c_void_p(0), C.c_void_p(0xdead0000), 0, 8)), det], 'does not own')):

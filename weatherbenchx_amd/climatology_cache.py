@@ -69,9 +69,10 @@ class _Job:
 class _HipPool:
   """The device side: one allocation of `nslots` slabs, a copy stream and the worker thread that feeds it."""
 
-  def __init__(self, nslots, slab_shape, np_dtype, threads=4):
+  def __init__(self, nslots, slab_shape, np_dtype, threads=4, swap=False):
     from weatherbenchx_amd import engine  # pylint: disable=g-import-not-at-top
     self.dtype = np.dtype(np_dtype)
+    self.swap = bool(swap)  # the slabs are stored with their last two dims exchanged (`slab_shape` is the POOL's)
     self.slab_shape = tuple(int(n) for n in slab_shape)
     self.slab_elems = int(np.prod(self.slab_shape, dtype=np.int64))
     self.slab_nbytes = self.slab_elems * self.dtype.itemsize
@@ -164,6 +165,8 @@ class _HipPool:
     return entry
 
   def _copy_rows(self, dst, src):
+    if self.swap:
+      return self._transpose_rows(dst, src)
     n = src.shape[0] if src.ndim else 0
     if self._threads > 1 and n > 1 and dst.nbytes >= (8 << 20):
       if self._pool is None:
@@ -174,6 +177,28 @@ class _HipPool:
     else:
       np.copyto(dst, src, casting='unsafe')
 
+  def _transpose_rows(self, dst, src):
+    """dst[.., c, r] = src[.., r, c] (wbx_host_transpose, planes dealt to the copy threads): the climatology archive is
+    [.., longitude, latitude] like the fields (loaders.FileLoader(device_layout=...)), the pool holds what the kernels want."""
+    lib = self.copy_ctx.lib
+    rows, cols = (int(n) for n in src.shape[-2:])
+    nb = int(np.prod(src.shape[:-2], dtype=np.int64))
+    if not (src.dtype == self.dtype and src.dtype.isnative and src.flags['C_CONTIGUOUS']):
+      src = np.ascontiguousarray(src, dtype=self.dtype)
+    s3, d3 = src.reshape(nb, rows, cols), dst.reshape(nb, cols, rows)
+
+    def part(ab):
+      _hip.check(lib.wbx_host_transpose(d3[ab[0]:ab[1]].ctypes.data, s3[ab[0]:ab[1]].ctypes.data, ab[1] - ab[0], rows, cols,
+                                        self.dtype.itemsize), 'wbx_host_transpose')
+    if self._threads > 1 and nb > 1 and dst.nbytes >= (8 << 20):
+      if self._pool is None:
+        from concurrent.futures import ThreadPoolExecutor  # pylint: disable=g-import-not-at-top
+        self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix='wbx-clim-copy')
+      cuts = np.linspace(0, nb, min(4 * self._threads, nb) + 1).astype(int)
+      list(self._pool.map(part, zip(cuts[:-1], cuts[1:])))
+    else:
+      part((0, nb))
+
   def _upload(self, job):
     import ctypes as C  # pylint: disable=g-import-not-at-top
     ctx = self.copy_ctx
@@ -181,7 +206,8 @@ class _HipPool:
       ctx.wait_fence(f)  # the last kernels that read the slab this one replaces
     src = job.src
     dst = C.c_void_p(int(self.buf.ptr) + job.slot * self.slab_nbytes)
-    plain = isinstance(src, np.ndarray) and src.dtype == self.dtype and src.flags['C_CONTIGUOUS'] and src.dtype.isnative
+    plain = (not self.swap and isinstance(src, np.ndarray) and src.dtype == self.dtype and src.flags['C_CONTIGUOUS']
+             and src.dtype.isnative)
     if plain and _hip.is_pinned(src):
       _hip.check(ctx.lib.wbx_memcpy_h2d_async(ctx.handle, dst, C.c_void_p(src.ctypes.data), self.slab_nbytes), 'wbx_memcpy_h2d_async')
       job.fence = ctx.fence()
@@ -197,21 +223,26 @@ class _HipPool:
       job.fence = entry[1] = ctx.fence()
 
 
-def _new_pool(nslots, slab_shape, np_dtype):
+def _new_pool(nslots, slab_shape, np_dtype, swap=False, threads=4):
   """(tests/fake_device.py swaps this for a NumPy pool)"""
-  return _HipPool(nslots, slab_shape, np_dtype)
+  return _HipPool(nslots, slab_shape, np_dtype, threads=threads, swap=swap)
 
 
 class SlabCache:
   """K device slabs of one climatology variable, LRU by slab key.  `source`: the host DataArray, any dim order; the dims the
   alignment selects along (`dayofyear`, `hour` / `time`) are found at the first `ref` call."""
 
-  def __init__(self, source: xr.DataArray, slots: int | None = None, pool_bytes: int | None = None):
+  def __init__(self, source: xr.DataArray, slots: int | None = None, pool_bytes: int | None = None,
+               device_layout: str | None = None, threads: int = 4):
+    """`device_layout`: 'lon_fastest' / 'lat_fastest' -- the pool holds the slabs with their last two dims exchanged when the
+    host climatology has them the other way round (the staging copy is the transposition: `loaders.FileLoader` does the
+    same to the fields of such an archive)."""
     data = source.data
     if xr._is_torch(data):  # pylint: disable=protected-access
       raise TypeError('SlabCache: the climatology is a tensor already (device-resident climatologies are gathered in place)')
     self.source = source
     self._slots_wanted, self._pool_bytes = slots, pool_bytes
+    self._device_layout, self._threads = device_layout, threads
     self.sel_dims = None
     self.pool = None
     self.pool_da = None
@@ -227,7 +258,10 @@ class SlabCache:
   def _setup(self, sel_dims):
     src = self.source
     self.sel_dims = tuple(sel_dims)
-    self.slab_dims = tuple(d for d in src.dims if d not in self.sel_dims)
+    stored = tuple(d for d in src.dims if d not in self.sel_dims)
+    from weatherbenchx_amd import loaders  # pylint: disable=g-import-not-at-top
+    swap = loaders._needs_swap(stored, self._device_layout)  # pylint: disable=protected-access
+    self.slab_dims = stored[:-2] + (stored[-1], stored[-2]) if swap else stored
     slab_shape = tuple(src.sizes[d] for d in self.slab_dims)
     dt = np.dtype(str(src.dtype))
     self.np_dtype = dt if dt in (np.dtype(np.float32), np.dtype(np.float64)) else np.dtype(np.float64)
@@ -237,7 +271,7 @@ class SlabCache:
     if n is None:
       n = max(1, int((self._pool_bytes or AUTO_POOL_BYTES) // max(slab_nbytes, 1)))
     self.nslots = int(min(n, total))
-    self.pool = _new_pool(self.nslots, slab_shape, self.np_dtype)
+    self.pool = _new_pool(self.nslots, slab_shape, self.np_dtype, swap=swap, threads=self._threads)
     weakref.finalize(self, self.pool.close)  # (the worker thread holds the pool, not the cache)
     dims = (SLAB_DIM,) + self.slab_dims
     coords = {k: v for k, v in src._coords.items() if set(v[0]) <= set(self.slab_dims)}  # pylint: disable=protected-access
@@ -245,7 +279,7 @@ class SlabCache:
     self.pool.seed(self.pool_da, dims)
     self.free = list(range(self.nslots - 1, -1, -1))
     # the source with the selected dims in front: a slab is `front[key]`
-    order = [src.dims.index(d) for d in self.sel_dims] + [src.dims.index(d) for d in self.slab_dims]
+    order = [src.dims.index(d) for d in self.sel_dims] + [src.dims.index(d) for d in stored]
     self._front = np.transpose(src.data if isinstance(src.data, np.ndarray) else xr._to_numpy(src.data), order)  # pylint: disable=protected-access
 
   # -- the slot table (chunk-loop thread only) -------------------------------------------------------------------------
@@ -374,7 +408,7 @@ _IN_LOOP = [0]  # > 0: inside pipeline._consume (launches of a replayed chunk fo
 
 
 # ---- the hooks of metrics/base.py and pipeline.py ---------------------------------------------------------------------------
-def cached(climatology, slots: int | None = None, pool_bytes: int | None = None):
+def cached(climatology, slots: int | None = None, pool_bytes: int | None = None, device_layout: str | None = None, threads: int = 4):
   """A Dataset / mapping / DataArray of host climatologies with a slab cache on every variable (explicit form of what
   `cache_for` does by itself for memory maps and large arrays).  Returns its argument."""
   arrays = [climatology] if isinstance(climatology, xr.DataArray) else [climatology[k] for k in climatology.keys()]
@@ -383,7 +417,7 @@ def cached(climatology, slots: int | None = None, pool_bytes: int | None = None)
     if not xr._is_torch(da.data):  # pylint: disable=protected-access
       # (the wish outlives what the engine caches on the object -- an in-place edit `da[...] = x` drops every `_wbx_*` entry, the
       #  pool with its stale slabs among them -- and travels with a pickled metric; the pool itself is rebuilt on first use)
-      da.__dict__['_slab_cache_config'] = (slots, pool_bytes)
+      da.__dict__['_slab_cache_config'] = (slots, pool_bytes, device_layout, threads)
       da.__dict__.pop('_wbx_slab_cache', None)
   return climatology
 
@@ -406,13 +440,32 @@ def cache_for(climatology: xr.DataArray):
   data = climatology.data
   config = climatology.__dict__.get('_slab_cache_config')
   if config is not None and not xr._is_torch(data):  # pylint: disable=protected-access
-    made = SlabCache(climatology, slots=config[0], pool_bytes=config[1])
+    made = SlabCache(climatology, slots=config[0], pool_bytes=config[1], device_layout=config[2], threads=config[3])
   elif isinstance(data, np.ndarray) and '_wbx_dev' not in climatology.__dict__ and (_is_memmap(data) or data.nbytes > AUTO_RESIDENT_BYTES):
     made = SlabCache(climatology)
   else:
     made = False
   climatology.__dict__['_wbx_slab_cache'] = made
   return made or None
+
+
+def wanted_by(metric_sets) -> bool:
+  """Does a climatology of these metrics sit (or will it sit) behind a slab pool?  Decided from the climatology objects alone --
+  every rank of a job answers alike."""
+  for metrics in metric_sets:
+    for metric in metrics.values():
+      for stat in metric.statistics.values():
+        clim = getattr(stat, '_climatology', None)
+        if clim is None:
+          continue
+        try:
+          arrays = [clim] if isinstance(clim, xr.DataArray) else [clim[k] for k in clim.keys()]
+        except (AttributeError, TypeError):
+          continue
+        for da in arrays:
+          if cache_for(xr.as_dataarray(da)) is not None:
+            return True
+  return False
 
 
 def chunk_enqueued():

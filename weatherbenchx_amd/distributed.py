@@ -36,8 +36,16 @@ def _leaves(tree, prefix=()):
     raise TypeError(f'unsupported leaf type {type(tree)}')
 
 
-def shard_chunks(chunks: list, rank: int, world_size: int) -> list:
-  """Round-robin assignment of time chunks to ranks (chunk i -> rank i mod n)."""
+def shard_chunks(chunks: list, rank: int, world_size: int, mode: str = 'round_robin') -> list:
+  """Assignment of time chunks to ranks: chunk i -> rank i mod n, or -- `mode='block'` -- contiguous blocks of
+  the chunk list (consecutive init times stay on one rank: with a climatology behind a slab pool, climatology_cache.py,
+  consecutive chunks share most of the (dayofyear, hour) slabs they name, chunks n days apart share none)."""
+  if mode == 'block':
+    n = len(chunks)
+    lo, hi = rank * n // world_size, (rank + 1) * n // world_size
+    return chunks[lo:hi]
+  if mode != 'round_robin':
+    raise ValueError(f"sharding mode {mode!r}: 'round_robin' or 'block'")
   return [c for i, c in enumerate(chunks) if i % world_size == rank]
 
 

@@ -435,7 +435,8 @@ def _run_chunk(group, passes, acc):
 
 
 def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True,
-                    prefetch: int = 0, group=None, force_collective: bool = False, comm=None, stats: dict | None = None):
+                    prefetch: int = 0, group=None, force_collective: bool = False, comm=None, stats: dict | None = None,
+                    sharding: str | None = None):
   """Several evaluations over the same time chunks -- `passes` = [(name, load_chunk, metrics, aggregator | {name: aggregator}),
   ...], e.g. a deterministic suite, zonal spectra under another aggregator and an ensemble suite from another loader -- as
   ONE job: the chunks of all passes run interleaved (chunk k of every pass before chunk k + 1), every accumulator of every
@@ -444,14 +445,18 @@ def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: 
 
   Returns {pass name: {aggregator name: AggregationState}} (aggregator key None for a single unnamed aggregator).
   `comm`: a distributed.CabiCommunicator -- the collective then goes through the library's own RCCL entry point
-  (wbx_acc_allreduce) instead of torch.distributed.  `stats`, if given, receives {'collectives': n, 'accumulator_values': n}."""
+  (wbx_acc_allreduce) instead of torch.distributed.  `stats`, if given, receives {'collectives': n, 'accumulator_values': n}.
+  `sharding`: 'round_robin' (chunk i -> rank i mod n) or 'block' (contiguous runs of chunks per rank); None picks 'block' when
+  a climatology of the job sits behind a slab pool (consecutive chunks share its slabs), else round robin."""
   norm = []
   for name, load_chunk, metrics, aggregator in passes:
     aggs = {None: aggregator} if isinstance(aggregator, aggregation.Aggregator) else dict(aggregator)
     norm.append((name, load_chunk, metrics, aggs))
   if len({n for n, *_ in norm}) != len(norm):
     raise ValueError('pass names must be unique')
-  work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size)
+  if sharding is None:
+    sharding = 'block' if climatology_cache.wanted_by([m for _, _, m, _ in norm]) else 'round_robin'
+  work = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size, sharding)
   acc = engine.Accumulation()
   # Software pipeline over chunks: nothing is waited for inside the loop except the previous chunk's kernels (to let
   # go of its inputs) after the next chunk has been enqueued, so the GPU never waits for host-side bookkeeping.
@@ -496,7 +501,7 @@ def evaluate_passes(times: tc.TimeChunks, passes, *, rank: int = 0, world_size: 
 
 def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[str, metrics_base.Metric],
                     aggregator, *, rank: int = 0, world_size: int = 1, all_reduce: bool = True, prefetch: int = 0,
-                    group=None, force_collective: bool = False, comm=None):
+                    group=None, force_collective: bool = False, comm=None, sharding: str | None = None):
   """Returns {aggregator_name: AggregationState} (key None for a single unnamed aggregator).
 
   `load_chunk(init_times, lead_times) -> (predictions, targets)`; chunks are sharded round-robin over ranks.
@@ -511,7 +516,7 @@ def evaluate_chunks(times: tc.TimeChunks, load_chunk: LoadFn, metrics: Mapping[s
   Several (loader, metrics, aggregator) evaluations of one job: `evaluate_passes` (still one collective).
   """
   out = evaluate_passes(times, [('', load_chunk, metrics, aggregator)], rank=rank, world_size=world_size, all_reduce=all_reduce,
-                        prefetch=prefetch, group=group, force_collective=force_collective, comm=comm)
+                        prefetch=prefetch, group=group, force_collective=force_collective, comm=comm, sharding=sharding)
   return out['']
 
 
