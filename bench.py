@@ -104,6 +104,18 @@ def self_launch(args):
   return subprocess.call(cmd, env=env)
 
 
+COLLECTIVE_CABI = 'wbx_acc_allreduce (C ABI, RCCL)'
+
+
+def pick_collective(world, backend, environ):
+  """Who moves the sums between the ranks: the library's own communicator on RCCL ranks unless WBX_COLLECTIVE=torch."""
+  if world <= 1:
+    return None
+  if backend == 'nccl' and environ.get('WBX_COLLECTIVE', 'cabi') != 'torch':
+    return COLLECTIVE_CABI
+  return 'torch.distributed ' + backend
+
+
 class Env:
   """Everything the legs share: process group, device, grid, generators."""
 
@@ -124,6 +136,14 @@ class Env:
       else:
         dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
     self.ctx = _hip.default_context(self.device_index)
+    # The payload collective of every leg goes through the LIBRARY's RCCL communicator (wbx_comm_create / wbx_acc_allreduce: what
+    # INTEGRATION.md documents for a host without torch); torch.distributed only carries the 128-byte unique id and the slot
+    # tables (KBs, once).  WBX_COLLECTIVE=torch: dist.all_reduce on the same device buffer instead (the A/B).
+    self.comm = None
+    self.collective = pick_collective(self.world, args.backend, os.environ)
+    if self.collective == COLLECTIVE_CABI:
+      from weatherbenchx_amd import distributed
+      self.comm = distributed.CabiCommunicator.from_torch_group()
     self.nlat, self.nlon = (721, 1440) if not args.small else (73, 144)
     self.lat = np.linspace(-90, 90, self.nlat)
     self.lon = np.linspace(0, 360, self.nlon, endpoint=False)
@@ -159,6 +179,17 @@ class Env:
     t = self.torch.tensor([seconds], device=self.dev if self.args.backend == 'nccl' else 'cpu', dtype=self.torch.float64)
     self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _collective_record(env):
+  """What the library's communicator says about the payload collectives so far: count, the last one's bytes and its own time
+  on the library's stream (event pair around wbx_acc_allreduce), the mean."""
+  if env.comm is None:
+    return None
+  t = env.comm.timings
+  return {'rccl_ranks': env.comm.nranks, 'collectives': t['collectives'], 'bytes': t['bytes_last'],
+          'us_last': None if t['us_last'] is None else round(t['us_last'], 1),
+          'us_mean': round(t['us_total'] / t['collectives'], 1) if t['collectives'] else None}
 
 
 def fresh(d):
@@ -321,7 +352,7 @@ def _main_leg(env):
         return agg.aggregate_statistics(stats()), acc
 
     def finish(pair):  # ... and are summed over the ranks with ONE all-reduce of the device buffer, read back once
-      state, plan_box[0] = distributed.resolve_state(pair[0], pair[1], plan=plan_box[0])
+      state, plan_box[0] = distributed.resolve_state(pair[0], pair[1], plan=plan_box[0], comm=env.comm)
       return state.metric_values(metrics)
 
     def run(n):
@@ -384,7 +415,8 @@ def _main_leg(env):
                                   'sums accumulated in HBM (engine.Accumulation), all-reduced on the device buffer'),
                  'sharding': f'{env.world} x one (init, lead) field per rank, 1 all-reduce/step',
                  'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0, 'backend': args.backend if env.world > 1 else None,
-                 'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0},
+                 'collectives_per_step': ((plan_box[0].collectives - c0) / args.steps) if plan_box[0] is not None else 0,
+                 'collective_backend': env.collective, 'collective': _collective_record(env)},
       'roofline': roofline,
   }
   # outside the timed region: one sampled level of the timed field against the float64 oracle, every metric of the suite
@@ -1115,11 +1147,8 @@ def config5_leg(env, lat_archive=False):
   metrics_of = {name: m for name, _, m, _ in passes}
   # ONE job: the chunks of the three evaluations run interleaved, all their accumulators live in one engine.Accumulation and
   # cross the ranks in ONE all-reduce at the end (pipeline.evaluate_passes; beam_pipeline.py:509-510 combines every key of
-  # the job in one CombinePerKey).  WBX_COLLECTIVE=cabi: through the library's own RCCL entry point (wbx_acc_allreduce).
-  comm = None
-  if env.world > 1 and args.backend == 'nccl' and os.environ.get('WBX_COLLECTIVE', 'torch') == 'cabi':
-    from weatherbenchx_amd import distributed
-    comm = distributed.CabiCommunicator.from_torch_group()
+  # the job in one CombinePerKey) -- through the library's own RCCL entry point (wbx_acc_allreduce) unless WBX_COLLECTIVE=torch.
+  comm = env.comm
   stats = {}
 
   def run(times):
@@ -1206,7 +1235,7 @@ def config5_leg(env, lat_archive=False):
           'sharding': f'contiguous runs of chunks per rank ({env.world}: consecutive inits share climatology slabs); the three evaluations interleaved chunk by chunk (pipeline.evaluate_passes), '
                       'every accumulator in HBM, ONE all-reduce for the whole job at the end',
           'collectives': stats.get('collectives'), 'accumulator_values': stats.get('accumulator_values'),
-          'collective_backend': ('wbx_acc_allreduce (C ABI, RCCL)' if comm is not None else ('torch.distributed ' + args.backend)) if env.world > 1 else None,
+          'collective_backend': env.collective, 'collective': _collective_record(env),
           'rccl_ranks': env.world if (env.world > 1 and args.backend == 'nccl') else 0,
           'scaling': 'strong', 'n_gpus': env.world, 'chunks': ninit, 'time_slices': ninit * nlead, 'seconds': dt,
           'seconds_rank0': rank_s, 'ms_per_chunk': dt / ninit * 1e3, 'ms_per_chunk_rank0': rank_s / max(len(distributed_shard(times, env)), 1) * 1e3,
@@ -1389,7 +1418,7 @@ def compact_line(result, full_path=None):
   if cfg:
     line['config'] = {'workload': _short(cfg.get('workload', ''), 330)}
     line['config'].update({k: cfg[k] for k in ('points_per_step_per_gpu', 'members', 'metrics', 'layout', 'accumulators', 'sharding',
-                                               'collectives_per_step', 'rccl_ranks', 'prewarm') if k in cfg})
+                                               'collectives_per_step', 'rccl_ranks', 'collective_backend', 'collective', 'prewarm') if k in cfg})
   roof = result.get('roofline') or {}
   if roof:
     line['roofline'] = {k: roof[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel_ms', 'kernel_ms_median',

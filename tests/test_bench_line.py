@@ -114,3 +114,29 @@ def test_gpus_8_launch_command_is_the_drivers(monkeypatch):
   script = cmd.index(os.path.join(ROOT, 'bench.py'))
   assert cmd[script + 1:] == ['--gpus', '8', '--steps', '7', '--warmup', '2']
   assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_n8_line_names_the_librarys_collective():
+  """At N > 1 on RCCL ranks the payload collective is the library's (wbx_comm_create / wbx_acc_allreduce) unless
+  WBX_COLLECTIVE=torch, and the line says so: backend, ranks, the collective's bytes and its own time."""
+  import bench
+  assert bench.pick_collective(1, 'nccl', {}) is None
+  assert bench.pick_collective(8, 'nccl', {}) == bench.COLLECTIVE_CABI
+  assert bench.pick_collective(8, 'nccl', {'WBX_COLLECTIVE': 'torch'}) == 'torch.distributed nccl'
+  assert bench.pick_collective(2, 'gloo', {}) == 'torch.distributed gloo'
+
+  class _Comm:
+    nranks = 8
+    timings = {'collectives': 21, 'us_total': 21 * 35.0, 'us_last': 33.3, 'bytes_last': 17146728}
+
+  class _Env:
+    comm = _Comm()
+  rec = bench._collective_record(_Env())
+  assert rec == {'rccl_ranks': 8, 'collectives': 21, 'bytes': 17146728, 'us_last': 33.3, 'us_mean': 35.0}
+  result = {'metric': bench.METRIC, 'value': 9.0e11, 'unit': 'evals/s', 'n_gpus': 8, 'steps': 20, 'warmup': 5, 'ms_per_step': 1.4,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32+f64', 'data': 'synthetic',
+            'config': {'workload': 'w', 'rccl_ranks': 8, 'collectives_per_step': 1.0, 'collective_backend': bench.COLLECTIVE_CABI,
+                       'collective': rec}}
+  line = json.loads(bench.compact_line(result))
+  assert line['config']['collective_backend'] == bench.COLLECTIVE_CABI and line['config']['collective']['bytes'] == 17146728
+  assert line['config']['rccl_ranks'] == 8 and line['config']['collective']['us_mean'] == 35.0

@@ -142,6 +142,8 @@ class CabiCommunicator:
     buf = C.create_string_buffer(bytes(unique_id), _hip.COMM_ID_BYTES)
     _hip.check(ctx.lib.wbx_comm_create(ctx.handle, buf, self.nranks, self.rank, C.byref(handle)), 'wbx_comm_create')
     self.handle = handle
+    # what the payload collectives cost on the library's stream (event pair around wbx_acc_allreduce) and moved
+    self.timings = {'collectives': 0, 'us_total': 0.0, 'us_last': None, 'bytes_last': 0}
 
   @staticmethod
   def new_unique_id() -> bytes:
@@ -278,8 +280,15 @@ def reduce_accumulation(acc: engine.Accumulation, group=None, *, all_reduce: boo
                                             arr.ctypes.data_as(C.c_void_p), arr.nbytes), 'wbx_memcpy_h2d')
     if comm is not None:  # all of it is enqueued on the library's stream: copies -> ncclAllReduce -> read-back
       flat = np.empty(ntot, dtype=np.float64)
+      i0 = ctx.mark()
       _hip.check(ctx.lib.wbx_acc_allreduce(ctx.handle, comm.handle, C.c_void_p(gbuf.ptr), ntot), 'wbx_acc_allreduce')
+      i1 = ctx.mark()
       _hip.check(ctx.lib.wbx_acc_read(ctx.handle, C.c_void_p(gbuf.ptr), ntot, flat.ctypes.data_as(C.c_void_p)), 'wbx_acc_read')
+      us = ctx.mark_elapsed(i0, i1) * 1e3  # (the read-back has waited for the stream)
+      if ctx is not _hip.default_context():
+        ctx.marks_reset()  # (the reduction context's marks are this function's alone)
+      comm.timings.update(collectives=comm.timings['collectives'] + 1, us_total=comm.timings['us_total'] + us, us_last=us,
+                          bytes_last=int(ntot) * 8)
     else:
       import torch  # pylint: disable=g-import-not-at-top
       import torch.distributed as dist  # pylint: disable=g-import-not-at-top
