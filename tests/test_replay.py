@@ -119,6 +119,34 @@ def test_recorder_refuses_what_is_not_steady_state():
   da.__dict__.pop('_wbx_dev')
 
 
+def test_chunk_signature_follows_coordinate_content_not_addresses():
+  """two chunks whose (large) coordinates have the same shape and sit at the same ADDRESS but hold other values --
+  station coordinates over `index`, a buffer the loader rewrites in place -- must not share a chunk record: Regions / area
+  weights / atom tables are built from exactly these numbers."""
+  n = 6000  # (> 4096 elements: the size from which round 5 hashed the data pointer)
+  lat = np.linspace(-60, 60, n)
+  payload = np.zeros(n, np.float32)
+  a = xr.DataArray(payload, dims=('index',), coords={'latitude': ('index', lat), 'index': np.arange(n)})
+  sig_a = pipeline._array_signature(a)
+  lat[:] = np.linspace(-30, 30, n)  # rewritten in place: same object, same address
+  b = xr.DataArray(payload, dims=('index',), coords={'latitude': ('index', lat), 'index': np.arange(n)})
+  sig_b = pipeline._array_signature(b)
+  assert sig_a != sig_b
+  lat[:] = np.linspace(-60, 60, n)
+  c = xr.DataArray(payload, dims=('index',), coords={'latitude': ('index', lat.copy()), 'index': np.arange(n)})
+  assert pipeline._array_signature(c) == sig_a  # equal content in fresh arrays: the same signature (records carry over)
+  # a frozen array is hashed once per object
+  frozen = np.linspace(0, 1, n)
+  frozen.flags.writeable = False
+  t1 = pipeline._coord_token(frozen)
+  assert pipeline._token_memo[id(frozen)][0] is frozen and pipeline._coord_token(frozen) is t1
+  torch = pytest.importorskip('torch')
+  big = torch.zeros(5000)
+  assert pipeline._coord_token(big) != pipeline._coord_token(big)  # large tensors: never replayed
+  small = torch.arange(10.0)
+  assert pipeline._coord_token(small) == pipeline._coord_token(small.clone())
+
+
 # ------------------------------------------------------------------------------------------------------------------- GPU
 def _torch():
   import torch

@@ -22,7 +22,11 @@ def load_predictions_and_targets(predictions_loader, targets_loader, setup_fn: O
   the targets first, then the predictions WITH the targets as `reference` (what an interpolation to the targets' coordinates
   needs); `setup_fn` once, before the first chunk.  Loaders whose `load_chunk` takes no reference (the file-backed ones) are
   called without."""
-  takes_reference = len(inspect.signature(predictions_loader.load_chunk).parameters) >= 3
+  # (by NAME: a loader with `load_chunk(init_times, lead_times, **kw)` or a wrapper that forwards *args / **kwargs gets the
+  #  reference too; an unrelated third parameter does not count)
+  params = inspect.signature(predictions_loader.load_chunk).parameters
+  takes_reference = 'reference' in params or any(p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD) for p in params.values())
+  by_keyword = 'reference' in params or not any(p.kind == p.VAR_POSITIONAL for p in params.values())
   state = {'ready': setup_fn is None}
 
   def load(init_times, lead_times):
@@ -30,6 +34,8 @@ def load_predictions_and_targets(predictions_loader, targets_loader, setup_fn: O
       setup_fn()
       state['ready'] = True
     targets = targets_loader.load_chunk(init_times, lead_times)
+    if takes_reference and by_keyword:
+      return predictions_loader.load_chunk(init_times, lead_times, reference=targets), targets
     if takes_reference:
       return predictions_loader.load_chunk(init_times, lead_times, targets), targets
     return predictions_loader.load_chunk(init_times, lead_times), targets

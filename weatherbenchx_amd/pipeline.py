@@ -206,19 +206,31 @@ def _plan_fusion(group_stats):
 _token_memo: dict = {}  # id(values array) -> (the array, its token): loaders hand the same latitude / longitude objects on
 
 
+_volatile = [0]
+
+
 def _coord_token(values):
-  """Identity of a coordinate's values that survives a loader handing out fresh (equal) arrays: content for small ones."""
+  """Identity of a coordinate's values that survives a loader handing out fresh (equal) arrays: its CONTENT.  A chunk record
+  made on one chunk runs the next with the recorded weights, bin masks and atom tables (GridAreaWeighting / Regions / LandSea
+  build them from exactly these coordinates), so two chunks may only share a signature if their coordinates hold the same
+  numbers -- an address says nothing: freed buffers come back at the same address, writeable arrays are rewritten in place
+  (ADVICE r5).  The content hash of a large array is memoised on the OBJECT, and only for arrays nobody can rewrite
+  (writeable = False; the memo keeps the object, so its id cannot come round again); a large coordinate that lives in HBM is
+  not read back per chunk: such chunks get a token of their own each time, i.e. they are never replayed."""
   hit = _token_memo.get(id(values))
   if hit is not None and hit[0] is values:
     return hit[1]
   if xr._is_torch(values):  # pylint: disable=protected-access
-    return ('torch', int(values.data_ptr()), tuple(values.shape))
+    if values.numel() > 4096:
+      _volatile[0] += 1
+      return ('volatile', _volatile[0])
+    values = values.detach().cpu().numpy()
   a = np.asarray(values)
-  if a.size <= 4096:
-    token = (a.dtype.str, a.shape, hash(a.tobytes()))
+  if a.dtype == object:
+    token = (a.dtype.str, a.shape, hash(tuple(a.reshape(-1).tolist())))
   else:
-    token = (a.dtype.str, a.shape, int(a.__array_interface__['data'][0]))
-  if isinstance(values, np.ndarray) and not values.flags.writeable:  # (only arrays nobody can rewrite in place)
+    token = (a.dtype.str, a.shape, hash(np.ascontiguousarray(a).tobytes()))
+  if isinstance(values, np.ndarray) and not values.flags.writeable:
     if len(_token_memo) > 256:
       _token_memo.clear()
     _token_memo[id(values)] = (values, token)

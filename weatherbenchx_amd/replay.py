@@ -331,7 +331,11 @@ class ChunkRecord:
     self.slot_tags = list(slots)
     self.slots = (C.c_uint64 * max(len(slots), 1))()
     self.names = [c[0] for c in calls]
-    self.gathers = recorder.gathers
+    # (what a gather plan needs to be rebuilt for another chunk: NOT the recorded chunk's predictions -- they were only there to
+    #  find `p_role`, and with their staged device copies they would pin a chunk of inputs in HBM for as long as the record lives)
+    self.gathers = [{k: v for k, v in g.items() if k != 'p'} for g in recorder.gathers]
+    recorder.gathers = []
+    recorder.arrays = {}
     self.bumps = list(recorder.bumps)
     self.acc = recorder.acc
     self.ctxs = ctxs
