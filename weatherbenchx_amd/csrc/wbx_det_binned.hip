@@ -260,6 +260,12 @@ template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = f
 #ifndef WBX_ATOMS_RAGGED_WPB
 #define WBX_ATOMS_RAGGED_WPB 4
 #endif
+#ifndef WBX_ATOMS_PD
+#define WBX_ATOMS_PD 4  // rows of p, t, c in flight per wave
+#endif
+#ifndef WBX_ATOMS_SKIP
+#define WBX_ATOMS_SKIP 1   // 0: both entries' FMAs issued every row under EXEC masks (A/B: make ab-atoms6)
+#endif
 __global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ATOMS_RAGGED_WPB))
 __attribute__((amdgpu_waves_per_eu(WBX_ATOMS_WAVES, WBX_ATOMS_WAVES)))
 det_atoms_kernel(S1Args a, BinnedArgs g) {
@@ -399,6 +405,22 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
       // each entry's FMAs run under its own lane mask (EXEC = the lanes whose point belongs to that entry) with the weight
       // as it is -- a scalar register for row weights: no `hit ? w : 0` selects (four v_cndmask + two v_mov per row), and a
       // row in which no lane uses an entry skips that entry's FMAs
+#if WBX_ATOMS_SKIP
+      // (r6) ... and the skip is real: the compiler predicates so short a block with EXEC and drops the `s_cbranch_execz` around
+      // it (SIInsertSkips keeps a branch only over 12+ instructions, or over something with side effects), so the six fp64 FMAs
+      // of an entry no lane is in were ISSUED row after row -- in the interior of a region every lane sits in one entry.  The
+      // empty asm statement is that side effect: six fp64 instructions less per row whenever an entry is idle.
+      if (hit0) {
+        asm volatile("");
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc0[l] = fma(val[l], w, acc0[l]);
+      }
+      if (hit1) {
+        asm volatile("");
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc1[l] = fma(val[l], w, acc1[l]);
+      }
+#else
       if (hit0) {
 #pragma unroll
         for (int l = 0; l < NA; ++l) acc0[l] = fma(val[l], w, acc0[l]);
@@ -407,6 +429,7 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
 #pragma unroll
         for (int l = 0; l < NA; ++l) acc1[l] = fma(val[l], w, acc1[l]);
       }
+#endif
     }
   };
 
@@ -623,7 +646,7 @@ static int launch_binned_k(wbx_ctx* ctx, const wbx_s1_plan* plan, S1Args& a, con
     } while (0)
     // (4 rows in flight per wave; 2 / 4 / 8 were measured 0.61 / 0.59 / 0.63 ms and the variants dropped: they doubled the
     // 144 instantiations of this kernel and the build time of this file)
-    if (wmode == 1) WBX_ATOMS_LAUNCH(4, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(4, 2); else WBX_ATOMS_LAUNCH(4, 0);
+    if (wmode == 1) WBX_ATOMS_LAUNCH(WBX_ATOMS_PD, 1); else if (wmode == 2) WBX_ATOMS_LAUNCH(WBX_ATOMS_PD, 2); else WBX_ATOMS_LAUNCH(WBX_ATOMS_PD, 0);
 #undef WBX_ATOMS_LAUNCH_NT
 #undef WBX_ATOMS_LAUNCH
 #undef g

@@ -31,6 +31,9 @@
 #pragma once
 
 constexpr int ZD_TEAMS = 8;
+#ifndef WBX_ZD_F32_CHAINS
+#define WBX_ZD_F32_CHAINS 1  // 0: every deterministic lane in fp64 from the first subtraction on (rounds 3-5; A/B: make ab-zdf64)
+#endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
 #endif
@@ -146,6 +149,49 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     double d[NA];
 #pragma unroll
     for (int l = 0; l < NA; ++l) d[l] = 0.0;
+#if WBX_ZD_F32_CHAINS
+    // (r6) The statistics of a POINT in fp32, as the reference forms them -- `predictions - targets`, `(p - t)**2`,
+    // `(p - c) * (t - c)` of float32 fields are float32 arrays (deterministic.py:91-123, 222-259); only the weighted
+    // dot promotes to float64 (aggregation.py:335).  The four sums of non-negative terms (|e|, e^2, pa^2, ta^2) run as fp32
+    // CHAINS of 8 points and are widened per chain -- the bound of the ensemble kernels' chain sums (include/wbx.h: <= 8
+    // non-negative terms, <= 4.8e-7 relative per chain, ~1e-7 typical, random in sign across the ~10^5 chains of an output) --;
+    // the two sums that cancel (e, pa * ta) are widened per point.  Per point 8 fp32 + 4 half-rate instructions instead of 12
+    // half-rate ones: the deterministic lanes were 0.7 of the kernel's 1.9 ms, the vector ALU being what it is bound by (the
+    // spectra alone: 1.24 ms), 12 fp64-rate instructions per point against the transform's ~12 fp32 flops per point.
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+      // (an ordering point per chain: without it the compiler forms all 48 anomalies up front, see below)
+      if constexpr (HAS_C)
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+      else
+        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]));
+#pragma unroll
+      for (int i = 4 * ch; i < 4 * ch + 4; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float p = h ? pa[i].y : pa[i].x, t = h ? pb[i].y : pb[i].x;
+          const float e = p - t;
+          d[0] += (double)e;
+          s1 += fabsf(e);
+          s2 = fmaf(e, e, s2);
+          if constexpr (HAS_C) {
+            const float cv = WBX_ZD_C_IN_REGISTERS ? (h ? pc[i].y : pc[i].x) : cbuf[(2 * i + h) * 64 + lane];
+            const float ap = p - cv, at = t - cv;
+            s3 = fmaf(ap, ap, s3);
+            s4 = fmaf(at, at, s4);
+            d[5] += (double)(ap * at);
+          }
+        }
+      }
+      d[1] += (double)s1;
+      d[2] += (double)s2;
+      if constexpr (HAS_C) {
+        d[3] += (double)s3;
+        d[4] += (double)s4;
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       // The six sums are serial fma chains over the lane's 24 points, so the compiler widens all 72 inputs and forms all 48
@@ -175,6 +221,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
         }
       }
     }
+#endif
 #pragma unroll
     for (int l = 0; l < NA; ++l) {
       const double tot = wave_sum_uniform(lane < Z14_LANES ? d[l] : 0.0);
