@@ -1391,7 +1391,7 @@ def _leg_record(leg):
   return rec
 
 
-_NOT_LEGS = ('roofline', 'check', 'config', 'cpu_baseline', 'legs')
+_NOT_LEGS = ('roofline', 'check', 'config', 'cpu_baseline', 'legs', 'box', 'climatology', 'archive', 'chunk_records', 'collective')
 _LEG_ALIASES = {'with_mask_coordinate': 'mask', 'with_nan_mask': 'nanmask', 'with_deterministic_suite': 'det', 'public_chunk_ens': 'pce',
                 'public_chunk_ens_ifs_layout': 'pce_ifs', 'public_chunk': 'pc', 'lat_fastest': 'lat', 'default_crps_ensemble': 'default',
                 'pairwise_form': 'pair', 'skipna_ensemble': 'skipna', 'all_slabs_resident': 'hits'}
@@ -1440,6 +1440,8 @@ def compact_line(result, full_path=None):
   chk = result.get('check') or {}
   if chk:
     line['check'] = {k: _sig(chk[k], 6) for k in ('crps_mean', 'unbiased_spread_skill_mean', 'oracle_max_rel_err') if k in chk}
+  if result.get('box'):
+    line['box'] = result['box']
   legs = {}
   _collect_legs(result, '', legs)
   if legs:
@@ -1534,6 +1536,11 @@ def main():
   if not args.no_cpu and env.world == 1 and env.rank == 0 and want('cpu'):
     result['cpu_baseline'] = cpu_leg(env, keep)
   if env.rank == 0:
+    try:  # the clock this box sustains under load, beside the numbers it shaped (boxes of the pool differ by 4-8 %)
+      result['box'] = {'shader_MHz_all_CUs_busy': round(env.ctx.clock_probe(2048), 1), 'shader_MHz_one_block': round(env.ctx.clock_probe(1), 1),
+                       'host_cpus': os.cpu_count()}
+    except Exception as e:  # pylint: disable=broad-except
+      result['box'] = {'error': f'{type(e).__name__}: {e}'}
     _emit(result)
   if env.world > 1:
     env.dist.destroy_process_group()

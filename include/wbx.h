@@ -196,6 +196,10 @@ int wbx_memcpy_d2d(wbx_ctx* ctx, void* dst, const void* src, size_t bytes); /* e
  * and no transposed copy is made on the device.  No context, no stream: plain host memory on both sides, which must not
  * overlap; thread-safe (callers split a chunk's planes over threads). */
 int wbx_host_transpose(void* dst, const void* src, int64_t batch, int64_t rows, int64_t cols, int32_t elem_bytes);
+/* The shader clock this device sustains with `blocks` x 256 threads of dependent fp32 FMAs running (ABI 13): s_memtime ticks
+ * over s_memrealtime's constant 100 MHz, in MHz.  A measurement aid (boxes of one pool differ by 4-8 % on the same kernel):
+ * bench.py prints it beside its numbers.  Synchronous; a few milliseconds. */
+int wbx_clock_probe(wbx_ctx* ctx, int32_t blocks, double* shader_mhz_out);
 
 /* ---- accumulators ------------------------------------------------------------------------------------------
  * The reference combines per-chunk AggregationStates on the host (beam.CombinePerKey(CombiningSum()),

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
     'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_det_spectrum_slabs', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
-    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay', 'wbx_host_transpose',
+    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay', 'wbx_host_transpose', 'wbx_clock_probe',
 )
 
 # wbx_fn (include/wbx.h): the entry points a chunk record may hold
@@ -201,6 +201,7 @@ def load_library():
     }
     protos['wbx_chunk_replay'] = [vp, i32, vp, i32, vp, i32]
     protos['wbx_host_transpose'] = [vp, vp, i64, i64, i64, C.c_int32]
+    protos['wbx_clock_probe'] = [vp, C.c_int32, C.POINTER(C.c_double)]
     for name, argtypes in protos.items():
       fn = getattr(lib, name)
       fn.argtypes = argtypes
@@ -490,6 +491,12 @@ class Context:
     ms = C.c_float(0)
     check(self.lib.wbx_mark_elapsed(self.handle, int(i0), int(i1), C.byref(ms)), 'wbx_mark_elapsed')
     return float(ms.value)
+
+  def clock_probe(self, blocks: int = 2048) -> float:
+    """Shader clock in MHz with `blocks` x 256 threads of fp32 FMAs running (wbx_clock_probe)."""
+    mhz = C.c_double(0)
+    check(self.lib.wbx_clock_probe(self.handle, int(blocks), C.byref(mhz)), 'wbx_clock_probe')
+    return float(mhz.value)
 
   def marks_reset(self):
     check(self.lib.wbx_marks_reset(self.handle), 'wbx_marks_reset')

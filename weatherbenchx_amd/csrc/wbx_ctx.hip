@@ -266,3 +266,45 @@ extern "C" int wbx_timer_stop(wbx_ctx* ctx, float* ms_out) {
   WBX_HIP(hipEventElapsedTime(ms_out, ctx->ev_start, ctx->ev_stop));
   return 0;
 }
+
+
+// ---- the box's shader clock under load -----------------------------------------------------------------------------------
+// Boxes of one pool differ by 4-8 % on the same kernel and bytes (configs[1]: 3.61 .. 3.95 ms): the clock the part sustains is
+// part of every measured number, so bench.py prints it next to them.  s_memtime ticks at the shader clock, s_memrealtime at the
+// constant 100 MHz reference: a dependent v_fma_f32 chain on `blocks` x 256 threads for a few milliseconds, ratio of the two.
+namespace {
+__global__ void clock_probe_kernel(unsigned long long* out, int iters, float seed) {
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+  float a[8];
+  for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x + i;
+  for (int it = 0; it < iters; ++it)
+    for (int i = 0; i < 8; ++i) a[i] = fmaf(a[i], 1.0001f, 0.5f);
+  float s = 0;
+  for (int i = 0; i < 8; ++i) s += a[i];
+  const unsigned long long c1 = clock64(), w1 = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+  }
+  if (s == 1234.5f) out[2] = 1;
+}
+}  // namespace
+
+extern "C" int wbx_clock_probe(wbx_ctx* ctx, int32_t blocks, double* shader_mhz_out) {
+  WBX_REQUIRE(ctx != nullptr && shader_mhz_out != nullptr && blocks > 0, "bad arguments");
+  WBX_HIP(hipSetDevice(ctx->device));
+  unsigned long long* d = nullptr;
+  WBX_HIP(hipMalloc(reinterpret_cast<void**>(&d), 24));
+  unsigned long long h[3] = {0, 0, 0};
+  hipError_t e = hipSuccess;
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {  // (the first launch brings the clocks up)
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d, 1 << 16, 1.f);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  WBX_HIP(e);
+  WBX_REQUIRE(h[1] != 0, "the reference clock did not tick");
+  *shader_mhz_out = 100.0 * (double)h[0] / (double)h[1];
+  return 0;
+}

@@ -263,6 +263,12 @@ template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = f
 #ifndef WBX_ATOMS_PD
 #define WBX_ATOMS_PD 4  // rows of p, t, c in flight per wave
 #endif
+#ifndef WBX_ATOMS_KNOCK
+#define WBX_ATOMS_KNOCK 0  // 1: timing diagnostic, see `accumulate`
+#endif
+#ifndef WBX_ATOMS_VPTR
+#define WBX_ATOMS_VPTR 1   // 0: row offsets stepped in scalar registers (rounds 3-5; A/B: make ab-novptr)
+#endif
 #ifndef WBX_ATOMS_SKIP
 #define WBX_ATOMS_SKIP 1   // 0: both entries' FMAs issued every row under EXEC masks (A/B: make ab-atoms6)
 #endif
@@ -361,8 +367,13 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
   auto accumulate = [&](T tp, T tt, T tc, uint8_t tv, double w, int id) {
     const unsigned long long m_ok = live_mask & (MERGED ? __builtin_amdgcn_ballot_w64(id != NONE) : __builtin_amdgcn_ballot_w64(tv != 0));
     unsigned long long n0 = __builtin_amdgcn_ballot_w64(id != c0), n1 = __builtin_amdgcn_ballot_w64(id != c1);
+#if WBX_ATOMS_KNOCK >= 1  // timing diagnostic (wrong sums): every point goes to entry 0 as atom 0, no hit / miss bookkeeping
+    c0 = 0;
+    n0 = 0ull;
+    n1 = ~0ull;
+#endif
     const bool ok = __builtin_amdgcn_inverse_ballot_w64(m_ok);
-    if (m_ok & n0 & n1) {  // wave-uniform: a lane meets an atom it is not accumulating
+    if (WBX_ATOMS_KNOCK == 0 && (m_ok & n0 & n1)) {  // wave-uniform: a lane meets an atom it is not accumulating
       const bool miss = __builtin_amdgcn_inverse_ballot_w64(m_ok & n0 & n1);
       // a lane with both entries taken meets a third atom (a region edge: the same row for most lanes): start over
       bool place = miss;
@@ -375,8 +386,15 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
       n0 = __builtin_amdgcn_ballot_w64(id != c0);
       n1 = __builtin_amdgcn_ballot_w64(id != c1);
     }
+#if WBX_ATOMS_SKIP
+    // (r6) the entries' masks carry `ok` themselves and the values are formed on every lane (clamped loads: any lane holds a real
+    // element): one exec save / restore and one branch per row less than `if (ok) { ... }` around it all
+    const bool hit0 = __builtin_amdgcn_inverse_ballot_w64(m_ok & ~n0), hit1 = __builtin_amdgcn_inverse_ballot_w64(m_ok & ~n1);
+    {
+#else
     const bool hit0 = __builtin_amdgcn_inverse_ballot_w64(~n0), hit1 = __builtin_amdgcn_inverse_ballot_w64(~n1);
     if (ok) {
+#endif
       const double p = (double)tp, t = (double)tt, c = (double)tc;
       double val[NA];
       if constexpr (FUNC == WBX_PASS1) {
@@ -491,6 +509,59 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
       // EVEN: the row offsets of the NEXT fetch, stepped by scalar additions.  Fetches ask for rows 0, 1, 2, ... in order and
       // stay on the last row once they reach it, so `base + j * step` (a 64-bit scalar multiplication per input and row:
       // 24 of the 41 scalar instructions a row cost in round 2; public chunk 0.443 -> 0.415 ms) is never needed.
+#if WBX_ATOMS_VPTR
+      // (r6) EVEN: the address of the NEXT fetch as a per-lane 64-bit pointer per operand, advanced by ONE vector add (the step sits
+      // in a scalar pair).  Round 3 kept the row offsets as scalars -- two scalar adds per operand and row -- and the compiler
+      // formed every load's address with a 64-bit vector add on top of that anyway (`v_lshl_add_u64 v, s[row], 2, v[lane base]`):
+      // eight of the ~21 scalar instructions a row cost, in a kernel whose gap to its load + arithmetic skeleton is scalar
+      // instructions and branches (profiles/r03_binned_vs_skeleton.txt: 52.5 M against 10.4 M, 366 against 297 us).
+      const T* vp[3] = {nullptr, nullptr, nullptr};
+      const uint8_t *vmask = nullptr, *vid = nullptr;
+      const double* vwt = nullptr;
+      if constexpr (EVEN) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) vp[i] = reinterpret_cast<const T*>(a.in[i]) + readlane64(ro[i], 0) + xo[i];
+        if constexpr (has_mask && !MERGED) vmask = reinterpret_cast<const uint8_t*>(a.in[3]) + readlane64(ro[3], 0) + xo[3];
+        vid = (MERGED ? g.aidm : g.aid) + readlane64(wrow_v, 0) + xw;
+        if constexpr (WM == 0) vwt = g.wt + readlane64(wrow_v, 0) + xw;
+      }
+      auto row_of = [&](int i, int j) -> int64_t { return readlane64(i == WBX_MAX_INPUTS ? wrow_v : ro[i], j); };  // (!EVEN)
+      auto ld = [&](const T* q) -> T {
+        if constexpr (NT) return ld_stream(q);
+        return *q;
+      };
+      auto fetch = [&](Slots& S, int j, int u, auto inside_tag) {
+        if constexpr (EVEN) {
+          S.p[u] = ld(vp[0]);
+          if constexpr (NIN > 1) S.t[u] = ld(vp[1]);
+          if constexpr (NIN > 2) S.c[u] = ld(vp[2]);
+          S.v[u] = 1;
+          if constexpr (has_mask && !MERGED) S.v[u] = *vmask;
+          S.id[u] = *vid;
+          if constexpr (WM == 0) S.w[u] = *vwt;
+          if constexpr (WM == 1) S.w[u] = w_lane;
+          if constexpr (WM == 2) S.w[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+          if (decltype(inside_tag)::value || j < last) {  // (wave-uniform; inside: row j + 1 exists, no test)
+#pragma unroll
+            for (int i = 0; i < NIN; ++i) vp[i] += step[i];
+            if constexpr (has_mask && !MERGED) vmask += step[3];
+            vid += step[WBX_MAX_INPUTS];
+            if constexpr (WM == 0) vwt += step[WBX_MAX_INPUTS];
+          }
+        } else {
+          S.p[u] = ld(reinterpret_cast<const T*>(a.in[0]) + row_of(0, j) + xo[0]);
+          if constexpr (NIN > 1) S.t[u] = ld(reinterpret_cast<const T*>(a.in[1]) + row_of(1, j) + xo[1]);
+          if constexpr (NIN > 2) S.c[u] = ld(reinterpret_cast<const T*>(a.in[2]) + row_of(2, j) + xo[2]);
+          S.v[u] = 1;
+          if constexpr (has_mask && !MERGED) S.v[u] = (reinterpret_cast<const uint8_t*>(a.in[3]) + row_of(3, j))[xo[3]];
+          const int64_t wi = row_of(WBX_MAX_INPUTS, j);
+          S.id[u] = ((MERGED ? g.aidm : g.aid) + wi)[xw];
+          if constexpr (WM == 0) S.w[u] = (g.wt + wi)[xw];
+          if constexpr (WM == 1) S.w[u] = w_lane;
+          if constexpr (WM == 2) S.w[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
+        }
+      };
+#else
       int64_t cur[WBX_MAX_INPUTS + 1];
 #pragma unroll
       for (int i = 0; i <= WBX_MAX_INPUTS; ++i) cur[i] = EVEN ? readlane64(i == WBX_MAX_INPUTS ? wrow_v : ro[i], 0) : 0;
@@ -523,6 +594,7 @@ det_atoms_kernel(S1Args a, BinnedArgs g) {
         if constexpr (WM == 2) S.w[u] = __longlong_as_double(readlane64(__double_as_longlong(wrow_w), j));
         fetched(j, inside_tag);
       };
+#endif
       // every load is unconditional (clamped row indices), see det_binned_kernel
       Slots A;
 #pragma unroll

@@ -32,7 +32,11 @@
 
 constexpr int ZD_TEAMS = 8;
 #ifndef WBX_ZD_F32_CHAINS
-#define WBX_ZD_F32_CHAINS 1  // 0: every deterministic lane in fp64 from the first subtraction on (rounds 3-5; A/B: make ab-zdf64)
+#define WBX_ZD_F32_CHAINS 0  // 1: the deterministic lanes' per-point statistics in fp32, sums of <= 8 non-negative terms as fp32
+                             // chains (A/B: make ab-zdf32).  Measured in round 6 (tools/gpu_r6_kernels_a.sh, same box, configs[4]
+                             // chunk): 1.976 / 1.994 against 2.009 / 2.012 ms -- 168 of the row's 433 fp64-rate instructions become
+                             // fp32 ones and the kernel gains < 1 %: its vector ALU is not what bounds it.  Not adopted (the fp64
+                             // lanes equal wbx_det_partial's bit for bit, tests/test_gpu_round3.py).
 #endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
 #pragma unroll
     for (int l = 0; l < NA; ++l) d[l] = 0.0;
 #if WBX_ZD_F32_CHAINS
-    // (r6) The statistics of a POINT in fp32, as the reference forms them -- `predictions - targets`, `(p - t)**2`,
+    // (r6, A/B only) The statistics of a POINT in fp32, as the reference forms them -- `predictions - targets`, `(p - t)**2`,
     // `(p - c) * (t - c)` of float32 fields are float32 arrays (deterministic.py:91-123, 222-259); only the weighted
     // dot promotes to float64 (aggregation.py:335).  The four sums of non-negative terms (|e|, e^2, pa^2, ta^2) run as fp32
     // CHAINS of 8 points and are widened per chain -- the bound of the ensemble kernels' chain sums (include/wbx.h: <= 8
