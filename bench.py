@@ -17,7 +17,9 @@ through the drop-in API (Statistic.compute -> Aggregator.aggregate_statistics ->
 A "step" is one such pass; the K timed steps are software-pipelined one deep like pipeline.evaluate_chunks (every step is
 launched and finished inside the timed region).  With N ranks every rank owns one such field = one (init, lead) time slice
 (weak scaling): the step's sums stay in HBM (engine.Accumulation) and are summed over the ranks with ONE all-reduce of the
-device buffer per step (distributed.resolve_state; the layout is exchanged once, before the first step).
+device buffer per step (distributed.resolve_state; the layout is exchanged once, before the first step) -- on RCCL ranks through
+the LIBRARY's communicator (wbx_comm_create / wbx_acc_allreduce; WBX_COLLECTIVE=torch for the A/B); `config.collective` carries
+its bytes and its own time on the library's stream.
 
 value    = (grid points per step x 4 metrics x N) / wall time per step (max over ranks), evals/s; ensemble members are not
            extra points
@@ -31,9 +33,17 @@ Side legs in the same line (N = 1 unless noted):
   public_chunk   the public benchmark's chunk (1 init x 12 lead x 13 level, 34 region x land/sea bins, masked)
   spectrum       configs[3]: zonal spectra of two f32[8, 37, 721, 1440] fields
   lat_fastest    the main line, configs1 and spectrum again on latitude-fastest arrays (the layout of the public archives)
-  config5        configs[4] (every N): the full suite streamed as [1 init x 20 lead x 37 level] chunks from a resident
-                 pool through pipeline.evaluate_chunks, 366 inits sharded i mod N, accumulators in HBM, ONE all-reduce
-                 at the end; strong scaling (total work fixed)
+  config5        configs[4] (every N): the full suite streamed as [1 init x 20 lead x 37 level] chunks through
+                 pipeline.evaluate_passes, 366 daily inits in contiguous runs per rank, accumulators in HBM, ONE all-reduce
+                 (the library's RCCL communicator) at the end; strong scaling (total work fixed).  The FIELDS come from a
+                 resident pool (their H2D excluded, stated); the CLIMATOLOGY is a whole [366, 4, 37, 721, 1440] calendar in
+                 host memory behind a 48-slab device pool (climatology_cache.py): 4 new (dayofyear, hour) slabs = 0.61 GB per
+                 chunk cross PCIe one chunk ahead -- the leg's `ms` INCLUDES that stream and is bound by it;
+                 `config5.hits` is the same loop with every slab already in the pool (kernels + host per chunk)
+  lat.config5    the same evaluations fed from a LATITUDE-FASTEST archive (.npy files [.., longitude, latitude] in /dev/shm)
+                 through the transposing loader and slab pool (`device_layout='lon_fastest'`): host cost of the transposition
+                 against the plain copy, and the chunk loop on what arrived (longitude-fastest on the device)
+  box            the shader clock this box sustains under load (wbx_clock_probe): boxes of the pool differ by 4-8 %
   cpu_baseline   the oracle's "reference structure" NumPy path (one pass per statistic + two einsums, float32
                  statistics; oracle/wbx_oracle.py) on bounded samples: the ensemble suite (the main line's workload) and the
                  deterministic suite (configs1), each on one process and on os.cpu_count() worker processes

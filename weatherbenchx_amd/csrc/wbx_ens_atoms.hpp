@@ -141,7 +141,11 @@ struct EnsAtomsArgs {
 };
 
 #ifndef WBX_ENS_ATOMS_ROW_BARRIER
-#define WBX_ENS_ATOMS_ROW_BARRIER 0  // rows between two block barriers of the ragged-row flavour (power of two; 0 = none)
+#define WBX_ENS_ATOMS_ROW_BARRIER 4  // rows between two block barriers of the ragged-row flavour (power of two; 0 = none: make
+                                     // ab-eabar0).  (r6) 4: the four waves of a block -- adjacent x tiles of the same rows -- ask for
+                                     // the 128-byte lines two tiles share within the few microseconds a streamed line survives in the
+                                     // XCD's L2: FETCH_SIZE x 2 = 1.076 x the algorithmic bytes instead of 1.141 x (NaN mask 1.10
+                                     // instead of 1.17) at the same time per chunk (profiles/r06_ens_atoms_rowbarrier.txt)
 #endif
 #ifndef WBX_EA_PERSIST
 #define WBX_EA_PERSIST 0  // make ab-eapersist: persistent waves on one-wave blocks (see ens_atoms_kernel<.., PERSIST>); measured
