@@ -311,3 +311,56 @@ def test_replayed_chunks_address_the_pool(layout, monkeypatch):
     for stat in ta:
       np.testing.assert_array_equal(np.asarray(ta[stat]['z'].values), np.asarray(tb[stat]['z'].values), err_msg=f'{kind} {stat}')
   engine.clear_caches()
+
+
+def test_time_indexed_climatology_and_two_variables(backend):
+  """A climatology over a `time` axis (metrics/base.py:389-391 selects `time=valid_time`) and two variables with a pool each."""
+  rng = np.random.default_rng(2)
+  ntime = 40
+  times_c = np.datetime64('2020-03-01T00', 'ns') + np.arange(ntime) * np.timedelta64(6, 'h')
+  full = {v: (280 + 10 * rng.standard_normal((ntime, NLEV, NLAT, NLON))).astype(np.float32) for v in ('z', 'q')}
+  coords = {'time': times_c, 'level': LEVEL, 'latitude': LAT, 'longitude': LON}
+  clim = climatology_cache.cached(xr.Dataset({v: xr.DataArray(full[v], dims=('time', 'level', 'latitude', 'longitude'), coords=coords)
+                                               for v in full}), slots=7)
+  inits, lead, p, t, _ = _job(6, 4, lead_hours=6, start='2020-03-01T00')
+  index = {int(x.astype('int64')): i for i, x in enumerate(inits)}
+
+  def load(ic, lc):
+    ii = [index[int(x.astype('int64'))] for x in np.asarray(ic, 'datetime64[ns]')]
+    cs = {'init_time': inits[ii], 'lead_time': lead, 'level': LEVEL, 'latitude': LAT, 'longitude': LON}
+    return ({v: xr.DataArray(p[ii] + k, dims=ZDIMS, coords=cs) for k, v in enumerate(full)},
+            {v: xr.DataArray(t[ii] + k, dims=ZDIMS, coords=cs) for k, v in enumerate(full)})
+  tc = time_chunks.TimeChunks(inits, lead, init_time_chunk_size=1)
+  values = pipeline.evaluate_chunks(tc, load, {'acc': deterministic.ACC(clim)}, _area())[None].metric_values({'acc': deterministic.ACC(clim)})
+  valid = inits[:, None] + lead[None, :]
+  pos = ((valid - times_c[0]) // np.timedelta64(6, 'h')).astype(int)
+  w = O.grid_area_weights(LAT)[None, None, None, :, None]
+  for k, v in enumerate(full):
+    c = full[v][pos].astype(np.float64)
+    pf, tf = p.astype(np.float64) + k, t.astype(np.float64) + k
+    mean = lambda x: (x * w).sum(axis=(0, 3, 4)) / (np.ones_like(x) * w).sum(axis=(0, 3, 4))  # noqa: E731
+    want = mean((pf - c) * (tf - c)) / np.sqrt(mean((pf - c) ** 2) * mean((tf - c) ** 2))
+    np.testing.assert_allclose(values[f'acc.{v}'].transpose('lead_time', 'level').values, want, rtol=1e-6, err_msg=v)
+    cache = climatology_cache.cache_for(clim[v])
+    assert cache.sel_dims == ('time',) and cache.stats['evictions'] > 0
+    assert cache.stats['uploads'] == len(np.unique(pos))
+
+
+def test_the_wish_for_a_pool_travels_with_a_pickled_metric(backend):
+  """Beam-style workers pickle their metrics (beam_pipeline.py:140-160): the pool and its thread stay behind, the wish
+  (`cached(..., slots=)`) arrives and the worker builds its own pool on first use."""
+  import pickle
+  full, da = _climatology(ndoy=6)
+  clim = climatology_cache.cached(xr.Dataset({'z': da}), slots=4)
+  inits, lead, p, t, load = _job(3, 2, lead_hours=12)
+  times = time_chunks.TimeChunks(inits, lead, init_time_chunk_size=1)
+  metrics = _metrics(clim)
+  pipeline.evaluate_chunks(times, load, metrics, _area())
+  assert climatology_cache.cache_for(clim['z']).pool is not None
+  there = pickle.loads(pickle.dumps(metrics))
+  c2 = there['acc']._climatology['z']  # pylint: disable=protected-access
+  assert '_wbx_slab_cache' not in c2.__dict__ and c2.__dict__['_slab_cache_config'][0] == 4
+  values = pipeline.evaluate_chunks(times, load, there, _area())[None].metric_values(there)
+  _check(values, _oracle_acc(p, t, full, inits, lead))
+  cache = climatology_cache.cache_for(c2)
+  assert cache is not climatology_cache.cache_for(clim['z']) and cache.nslots == 4 and cache.stats['uploads'] > 0

@@ -475,3 +475,58 @@ def test_config5_sharding_over_eight_ranks(tmp_path, monkeypatch):
   # the same formula at BASELINE.json's configs[4] size: 20 leads x 37 levels x 721 wavenumbers -> the 2.14 M doubles (17 MB)
   # bench.py's config5 leg reports as `accumulator_values`
   assert _config5_accumulator_values(20, 37, 1440) == 2143240 + 100
+
+
+def _slab_case():
+  """ACC / activity / RMSE against a 60-day x 4-hour climatology behind an 11-slab pool: 12 daily inits x 5 six-hourly leads."""
+  import test_climatology_cache as tcc
+  from weatherbenchx_amd import climatology_cache, time_chunks
+  from weatherbenchx_amd import xarray_lite as xr
+  full, da = tcc._climatology(ndoy=60)
+  clim = climatology_cache.cached(xr.Dataset({'z': da}), slots=11)
+  inits, lead, p, t, load = tcc._job(12, 5, start='2020-01-03T00')
+  times = time_chunks.TimeChunks(inits, lead, init_time_chunk_size=1)
+  return tcc, clim, full, inits, lead, p, t, load, times
+
+
+def _slab_worker(rank, world_size, out_dir, keep_init):
+  dist = _init(rank, world_size, out_dir)
+  from weatherbenchx_amd import aggregation, climatology_cache, distributed, pipeline, weighting
+  try:
+    tcc, clim, full, inits, lead, p, t, load, times = _slab_case()
+    metrics = tcc._metrics(clim)
+    agg = tcc._area() if not keep_init else aggregation.Aggregator(reduce_dims=['latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+    stats = {}
+    out = pipeline.evaluate_passes(times, [('', load, metrics, agg)], rank=rank, world_size=world_size, stats=stats)
+    state = out[''][None]
+    cache = climatology_cache.cache_for(clim['z'])
+    mine = distributed.shard_chunks(list(times.iter_with_chunk_offsets()), rank, world_size, 'block')
+    vals = state.metric_values(metrics)
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), uploads=cache.stats['uploads'], nmine=len(mine), collectives=stats['collectives'],
+             first=int(mine[0][0].init_time) if mine else -1, **{k: np.asarray(v.transpose(*[d for d in ('init_time', 'lead_time', 'level') if d in v.dims]).values) for k, v in vals.items()})
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,keep_init', [(2, False), (3, True)])
+def test_a_job_with_a_slab_pool_is_sharded_in_runs_of_chunks(tmp_path, world, keep_init):
+  """A climatology behind a slab pool: `evaluate_passes` deals CONTIGUOUS runs of chunks to the ranks by itself (consecutive
+  inits share 4 of their 5 slabs, inits `world` days apart share none), every rank uploads only its run's slabs, ONE
+  collective, every rank ends with the float64 oracle's numbers -- with init_time reduced and with init_time kept."""
+  _spawn(_slab_worker, world, tmp_path, keep_init)
+  tcc, clim, full, inits, lead, p, t, load, times = _slab_case()
+  n = len(inits)
+  for rank in range(world):
+    got = np.load(os.path.join(tmp_path, f'rank{rank}.npz'))
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    assert int(got['nmine']) == hi - lo and int(got['first']) == lo and int(got['collectives']) == 1
+    assert int(got['uploads']) == (hi - lo) * 4 + 1  # its run's days x 4 hours + 00 of the day after: no slab twice, none of the others'
+    if not keep_init:
+      want = tcc._oracle_acc(p, t, full, inits, lead)
+      for name, key in (('acc', 'acc.z'), ('activity', 'activity.z'), ('rmse', 'rmse.z')):
+        np.testing.assert_allclose(got[key], want[name], rtol=1e-6, err_msg=name)
+    else:
+      for i in range(n):
+        want = tcc._oracle_acc(p[i:i + 1], t[i:i + 1], full, inits[i:i + 1], lead)
+        for name, key in (('acc', 'acc.z'), ('activity', 'activity.z'), ('rmse', 'rmse.z')):
+          np.testing.assert_allclose(got[key][i], want[name], rtol=1e-6, err_msg=f'{name} init {i}')
