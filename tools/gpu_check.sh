@@ -1,16 +1,6 @@
 #!/bin/bash
-# One GPU-box visit: gpu tests, a small and a full bench run, the bare-shell --gpus 2 behaviour.  Outputs -> gpurun_out/
-set -u
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-TAG=${1:-a}
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 ) > gpurun_out/pytest_$TAG.log
-( timeout 300 python bench.py --small --steps 2 --warmup 1 > gpurun_out/bench_small_$TAG.json ) 2> gpurun_out/bench_small_$TAG.err
-echo "small rc=$?" >> gpurun_out/bench_small_$TAG.err
-( timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench_$TAG.json ) 2> gpurun_out/bench_$TAG.err
-echo "full rc=$?" >> gpurun_out/bench_$TAG.err
-( timeout 120 python bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/bench_gpus2_$TAG.json ) 2> gpurun_out/bench_gpus2_$TAG.err
-echo "gpus2 rc=$?" >> gpurun_out/bench_gpus2_$TAG.err
-tail -5 gpurun_out/pytest_$TAG.log
-tail -3 gpurun_out/bench_small_$TAG.err gpurun_out/bench_$TAG.err gpurun_out/bench_gpus2_$TAG.err
-head -c 600 gpurun_out/bench_$TAG.json
+# What the driver runs at round end, on one box: the whole `-m gpu` suite, smoke(), the default bench line.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/check_pytest_gpu.txt 2>&1; tail -4 gpurun_out/check_pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/check_smoke.txt 2>&1; tail -2 gpurun_out/check_smoke.txt
+timeout 900 python bench.py > gpurun_out/check_bench.json 2> gpurun_out/check_bench.err; tail -c 2500 gpurun_out/check_bench.json

@@ -30,7 +30,25 @@
 // Included by wbx_spectrum.hip (inside namespace wbx, after wbx_zspec1440.hpp).
 #pragma once
 
-constexpr int ZD_TEAMS = 8;
+#ifndef WBX_ZD_TEAMS
+#define WBX_ZD_TEAMS 8  // one-wave teams per block = per CU (the block's LDS fills it): 8 = two waves per SIMD at 214 VGPRs.  12 =
+                        // three waves per SIMD needs <= 168 VGPRs, which the kernel only fits with WBX_ZD_FETCH_AT = 5 (161, no
+                        // scratch): make ab-zd12f5, measured in round 6 and NOT adopted (below)
+#endif
+#ifndef WBX_ZD_KNOCK
+#define WBX_ZD_KNOCK 0  // timing diagnostics (WRONG results; make ab-zdk1 ...): 1 = every row re-reads the team's FIRST row (cache
+                        // hits, no HBM stream), 2 = no deterministic lanes, 4 = no loads after the first row
+#endif
+#ifndef WBX_ZD_FETCH_AT
+#define WBX_ZD_FETCH_AT 0  // 0: the next row's p (+ c) behind pass 1's stores, t behind pass 2's (72 registers live across the
+                           // transform's peak); 4 / 5: all of it behind the mirror exchange / at the end of the pair -- the rows'
+                           // registers are then live only across the unpack, and the latency is left to the other waves of the SIMD.
+                           // (r6, profiles/r06_det_spectrum_3waves_ab.txt) 12 teams + 5 against 8 teams + 0, same box, the kernel
+                           // alone on a configs[4] chunk: DET6 1.96-1.98 against 2.01-2.03 ms (-1 ... -2 %), DET3 -3 %; but in the
+                           // configs[4] chunk loop 2.92 against 2.85 ms per chunk: a 155 KB block owns its CU's LDS, and the
+                           // ensemble kernel of the other stream no longer fits beside it.  Not adopted.
+#endif
+constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
 #ifndef WBX_ZD_F32_CHAINS
 #define WBX_ZD_F32_CHAINS 0  // 1: the deterministic lanes' per-point statistics in fp32, sums of <= 8 non-negative terms as fp32
                              // chains (A/B: make ab-zdf32).  Measured in round 6 (tools/gpu_r6_kernels_a.sh, same box, configs[4]
@@ -146,11 +164,12 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     else __builtin_amdgcn_s_setprio(1);
     const int32_t g = group[r];
     const double sc = scale[r] * quarter_inv_nn;
-    if (r + 1 < r1) resolve(r + 1, np, nt, nc);
+    if ((WBX_ZD_KNOCK & 1) == 0 && r + 1 < r1) resolve(r + 1, np, nt, nc);
     if constexpr (HAS_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's LDS-DMA has landed in cbuf
     // ---- the deterministic lanes of this row, on the raw values (lanes 60..63 shadow lane 59: counted out)
     __builtin_amdgcn_sched_barrier(0);
     double d[NA];
+    if constexpr ((WBX_ZD_KNOCK & 2) == 0) {
 #pragma unroll
     for (int l = 0; l < NA; ++l) d[l] = 0.0;
 #if WBX_ZD_F32_CHAINS
@@ -231,6 +250,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
       const double tot = wave_sum_uniform(lane < Z14_LANES ? d[l] : 0.0);
       if (lane == 0) a.out[r * NA + l] = tot;
     }
+    }
     __builtin_amdgcn_sched_barrier(0);  // the row's deterministic sums are done before the transform starts: their temporaries die here
     C2 v[12];
 #pragma unroll
@@ -238,9 +258,17 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
     z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
-      if (r + 1 < r1) {
-        if (i == 0) fetch_p(np, nc);
-        if (i == 2) fetch_t(nt);
+      if ((WBX_ZD_KNOCK & 4) == 0 && r + 1 < r1) {
+        if constexpr (WBX_ZD_FETCH_AT == 0) {
+          if (i == 0) fetch_p(np, nc);
+          if (i == 2) fetch_t(nt);
+        } else if constexpr (WBX_ZD_FETCH_AT == 45) {  // t behind the mirror exchange, p (+ c) at the end
+          if (i == 4) fetch_t(nt);
+          if (i == 5) fetch_p(np, nc);
+        } else if (i == WBX_ZD_FETCH_AT) {
+          fetch_p(np, nc);
+          fetch_t(nt);
+        }
       }
     }, acct, accmt, msh);
   }
