@@ -259,7 +259,21 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     if (g != cur) flush(g);  // wave-uniform
     z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
       if ((WBX_ZD_KNOCK & 4) == 0 && r + 1 < r1) {
-        if constexpr (WBX_ZD_FETCH_AT == 0) {
+        if constexpr (WBX_ZD_FETCH_AT == 99) {  // spread: a fifth of the row's loads behind each of the first five exchanges
+          if (i < 5) {
+            constexpr int NLD = HAS_C ? 36 : 24;
+            const v2* rowp = reinterpret_cast<const v2*>(np) + L;
+            const v2* rowt = reinterpret_cast<const v2*>(nt) + L;
+            const v2* rowc = reinterpret_cast<const v2*>(nc) + L;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+              if (j * 5 / NLD != i) continue;
+              if (j < 12) pa[j] = __builtin_nontemporal_load(rowp + 60 * j);
+              else if (HAS_C && j < 24) pc[WBX_ZD_C_IN_REGISTERS ? j - 12 : 0] = __builtin_nontemporal_load(rowc + 60 * (j - 12));
+              else pb[j - (HAS_C ? 24 : 12)] = __builtin_nontemporal_load(rowt + 60 * (j - (HAS_C ? 24 : 12)));
+            }
+          }
+        } else if constexpr (WBX_ZD_FETCH_AT == 0) {
           if (i == 0) fetch_p(np, nc);
           if (i == 2) fetch_t(nt);
         } else if constexpr (WBX_ZD_FETCH_AT == 45) {  // t behind the mirror exchange, p (+ c) at the end
