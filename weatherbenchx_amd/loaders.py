@@ -7,7 +7,8 @@ A loader maps (init_times, lead_times) to {variable: DataArray} exactly like the
   * `TargetsFromFiles`      fields indexed by ONE time axis: the chunk is gathered at valid_time = init_time + lead_time and
                             carries init_time / lead_time dims plus a 2-D `valid_time` coordinate
                             (TargetsFromXarray, xarray_loaders.py:224-316).
-Storage: `.npy` files (numpy memory maps) or NetCDF-3 (scipy.io.netcdf_file with mmap, the format io.py writes).  A chunk is
+Storage: `.npy` files (numpy memory maps), NetCDF-3 (scipy.io.netcdf_file with mmap, the format io.py writes) or zarr v2
+array directories (`ZarrArray`: read without the zarr package; uncompressed or zlib / gzip / bz2 / lzma chunks).  A chunk is
 read -- decoded, if the file is big-endian -- STRAIGHT into page-locked memory (`pipeline.pinned_empty`), so the feeder's
 upload is pure DMA on its copy stream (`wbx_memcpy_h2d_async`) and overlaps both the kernels of the previous chunk and this
 loader's reads of the next one; the pool of page-locked blocks is the double buffer.  `add_nan_mask` attaches the `mask`
@@ -29,6 +30,113 @@ import numpy as np
 from weatherbenchx_amd import xarray_lite as xr
 
 
+class ZarrArray:
+  """A zarr v2 array directory read WITHOUT the zarr package (not in the image): `.zarray` metadata + one file per chunk.
+  The reference opens its archives with `xr.open_zarr` (data_loaders/xarray_loaders.py:143-175); this is the part of that the
+  chunk feeder needs -- `shape`, `dtype`, `arr[i]` along the leading axes (lazy) and `read()` of what is left, assembled chunk by
+  chunk.  Codecs: none, zlib, gzip, bz2, lzma (the standard library's; they release the GIL, so the loader's threads decode in
+  parallel); blosc / zstd / lz4 (numcodecs) raise and say so.  Filters are not supported.  C and F chunk order, '.' and '/' chunk
+  keys, edge chunks, missing chunks = fill_value."""
+
+  def __init__(self, path: str, _meta=None, _prefix=()):
+    import json  # pylint: disable=g-import-not-at-top
+    import os  # pylint: disable=g-import-not-at-top
+    self.path = path
+    if _meta is None:
+      meta_path = os.path.join(path, '.zarray')
+      if not os.path.exists(meta_path):
+        raise FileNotFoundError(f'{path}: no .zarray (zarr v2 array directories only; for a group pass (path, variable))')
+      _meta = json.load(open(meta_path))
+      if _meta.get('zarr_format') != 2:
+        raise ValueError(f"{path}: zarr_format {_meta.get('zarr_format')}: only zarr v2")
+      if _meta.get('filters'):
+        raise ValueError(f'{path}: filters {_meta["filters"]} are not supported')
+      comp = _meta.get('compressor')
+      if comp is not None and comp.get('id') not in ('zlib', 'gzip', 'bz2', 'lzma'):
+        raise ValueError(f"{path}: compressor {comp.get('id')!r} needs numcodecs, which this image does not have (supported: none, "
+                         'zlib, gzip, bz2, lzma): re-chunk the store with one of those, or export the variable to .npy / NetCDF-3')
+    self._meta, self._prefix = _meta, tuple(int(i) for i in _prefix)
+    self._full_shape = tuple(int(n) for n in _meta['shape'])
+    self._chunks = tuple(int(n) for n in _meta['chunks'])
+    self.dtype = np.dtype(_meta['dtype'])
+    self._sep = _meta.get('dimension_separator', '.')
+    self._order = _meta.get('order', 'C')
+    fill = _meta.get('fill_value')
+    self._fill = np.nan if fill in ('NaN', None) and self.dtype.kind == 'f' else (0 if fill is None else fill)
+    for i, n in zip(self._prefix, self._full_shape):
+      if not 0 <= i < n:
+        raise IndexError(f'index {i} out of range for an axis of {n}')
+
+  @property
+  def shape(self):
+    return self._full_shape[len(self._prefix):]
+
+  @property
+  def ndim(self):
+    return len(self.shape)
+
+  @property
+  def nbytes(self):
+    return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+  def __getitem__(self, i):
+    if isinstance(i, (int, np.integer)):
+      if not self.shape:
+        raise IndexError('too many indices')
+      return ZarrArray(self.path, self._meta, self._prefix + (int(i) % self.shape[0] if i < 0 else int(i),))
+    raise TypeError('ZarrArray: integer indices along the leading axes, then .read()')
+
+  def _decode(self, raw: bytes) -> np.ndarray:
+    comp = self._meta.get('compressor')
+    if comp is not None:
+      cid = comp['id']
+      if cid == 'zlib':
+        import zlib  # pylint: disable=g-import-not-at-top
+        raw = zlib.decompress(raw)
+      elif cid == 'gzip':
+        import gzip  # pylint: disable=g-import-not-at-top
+        raw = gzip.decompress(raw)
+      elif cid == 'bz2':
+        import bz2  # pylint: disable=g-import-not-at-top
+        raw = bz2.decompress(raw)
+      else:
+        import lzma  # pylint: disable=g-import-not-at-top
+        raw = lzma.decompress(raw)
+    return np.frombuffer(raw, dtype=self.dtype).reshape(self._chunks, order=self._order)
+
+  def read(self, out: np.ndarray | None = None) -> np.ndarray:
+    """What is left after the leading indices, as one array in the file's dtype (`out`: written in place, any dtype numpy can
+    cast to -- a big-endian store is decoded on the way)."""
+    import itertools  # pylint: disable=g-import-not-at-top
+    import os  # pylint: disable=g-import-not-at-top
+    shape = self.shape
+    if out is None:
+      out = np.empty(shape, self.dtype.newbyteorder('='))
+    elif tuple(out.shape) != tuple(shape):
+      raise ValueError(f'out has shape {out.shape}, the selection {shape}')
+    npre = len(self._prefix)
+    lead = tuple(i // c for i, c in zip(self._prefix, self._chunks))
+    within = tuple(i % c for i, c in zip(self._prefix, self._chunks))
+    grid = [range(-(-n // c)) for n, c in zip(shape, self._chunks[npre:])]
+    for idx in itertools.product(*grid):
+      key = self._sep.join(str(i) for i in lead + idx) if lead + idx else '0'
+      lo = [i * c for i, c in zip(idx, self._chunks[npre:])]
+      hi = [min(l + c, n) for l, c, n in zip(lo, self._chunks[npre:], shape)]
+      dst = out[tuple(slice(l, h) for l, h in zip(lo, hi))]
+      f = os.path.join(self.path, *key.split('/')) if self._sep == '/' else os.path.join(self.path, key)
+      if not os.path.exists(f):
+        dst[...] = self._fill
+        continue
+      with open(f, 'rb') as fh:
+        chunk = self._decode(fh.read())
+      np.copyto(dst, chunk[within + tuple(slice(0, h - l) for l, h in zip(lo, hi))], casting='unsafe')
+    return out
+
+  def __array__(self, dtype=None, copy=None):  # pylint: disable=unused-argument
+    a = self.read()
+    return a if dtype is None else a.astype(dtype)
+
+
 class _FileSource:
   """One variable in a file: an array-like that supports numpy fancy indexing along its leading axes."""
 
@@ -38,8 +146,11 @@ class _FileSource:
 
   def array(self):
     if self._arr is None:
+      import os  # pylint: disable=g-import-not-at-top
       if self.path.endswith('.npy'):
         self._arr = np.load(self.path, mmap_mode='r')
+      elif os.path.isdir(self.path):  # a zarr v2 array directory, or a group + the variable's name
+        self._arr = ZarrArray(os.path.join(self.path, self.variable) if self.variable else self.path)
       else:
         from scipy.io import netcdf_file  # pylint: disable=g-import-not-at-top
         self._file = netcdf_file(self.path, 'r', mmap=True)  # (kept open: the variable is a view of its map)
@@ -121,9 +232,42 @@ class FileLoader:
     self.timings['seconds'] += time.perf_counter() - t0
     self.timings['bytes'] += out.nbytes
 
+  def _gather_zarr(self, arr, index, out):
+    """out[a] = arr[index[a]] out of a zarr store: every item is assembled from its chunk files (decompressed on the loader's
+    threads) -- straight into `out`, or into a scratch array first when the last two dims are exchanged on the way."""
+    t0 = time.perf_counter()
+    native = np.dtype(arr.dtype).newbyteorder('=')
+
+    def part(a):
+      item = arr[int(index[a])]
+      if not self._swap:
+        item.read(out[a])
+        return
+      from weatherbenchx_amd import _hip  # pylint: disable=g-import-not-at-top
+      tmp = item.read(np.empty(item.shape, native))
+      rows, cols = (int(n) for n in tmp.shape[-2:])
+      nb = int(np.prod(tmp.shape[:-2], dtype=np.int64))
+      if native.itemsize not in (4, 8):
+        raise TypeError(f'device_layout: fields of {arr.dtype} cannot be transposed by the loader (float32 / float64 only)')
+      _hip.check(_hip.load_library().wbx_host_transpose(out[a].ctypes.data, tmp.ctypes.data, nb, rows, cols, native.itemsize),
+                 'wbx_host_transpose')
+    n = len(index)
+    if self._threads > 1 and n > 1:
+      if self._pool is None:
+        from concurrent.futures import ThreadPoolExecutor  # pylint: disable=g-import-not-at-top
+        self._pool = ThreadPoolExecutor(max_workers=self._threads, thread_name_prefix='wbx-loader')
+      list(self._pool.map(part, range(n)))
+    else:
+      for a in range(n):
+        part(a)
+    self.timings['seconds'] += time.perf_counter() - t0
+    self.timings['bytes'] += out.nbytes
+
   def _gather(self, arr, index, out):
     """out[...] = arr[index] along the leading axis, gathered STRAIGHT into `out` (no temporary), timed.  The indices have
     been validated (`_positions`), so `mode='clip'` only switches numpy's buffered copy off."""
+    if isinstance(arr, ZarrArray):
+      return self._gather_zarr(arr, index, out)
     if self._swap:
       return self._gather_swapped(arr, index, out)
     t0 = time.perf_counter()
