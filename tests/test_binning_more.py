@@ -231,3 +231,20 @@ def test_latitude_and_longitude_bands_of_station_data():
   for i, a in enumerate(range(0, 360, 90)):
     want = (m360 >= a) & (m360 <= a + 90) if a + 90 < 360 else (m360 >= a) | (m360 <= 0)
     np.testing.assert_array_equal(np.asarray(mask.values)[i, 0], want)
+
+
+def test_time_units_of_the_dt_accessor_beyond_the_calendar_fields():
+  """the reference forwards any integer field of `.dt` (binning.py: `getattr(coord.dt, unit)`): quarter, ISO week,
+  days_in_month, is_leap_year -- checked against the standard library."""
+  import calendar
+  import datetime
+  from weatherbenchx_amd import binning
+  t = np.array(['2020-01-01T05', '2021-01-03T00', '2020-12-31T23', '2024-02-29T12', '2019-12-30T00', '2022-07-15T06'], dtype='datetime64[ns]')
+  py = [datetime.datetime.fromisoformat(str(x)[:19]) for x in t]
+  assert list(binning._extract_time_unit(t, 'week')) == [d.isocalendar()[1] for d in py]
+  assert list(binning._extract_time_unit(t, 'weekofyear')) == [d.isocalendar()[1] for d in py]
+  assert list(binning._extract_time_unit(t, 'quarter')) == [(d.month - 1) // 3 + 1 for d in py]
+  assert list(binning._extract_time_unit(t, 'days_in_month')) == [calendar.monthrange(d.year, d.month)[1] for d in py]
+  assert list(binning._extract_time_unit(t, 'is_leap_year')) == [int(calendar.isleap(d.year)) for d in py]
+  with pytest.raises(ValueError, match='season'):
+    binning._extract_time_unit(t, 'season')

@@ -221,7 +221,26 @@ def _extract_time_unit(values: np.ndarray, unit: str) -> np.ndarray:
     return (t - t.astype('datetime64[h]')).astype('timedelta64[m]').astype(np.int64)
   if unit == 'second':
     return (t - t.astype('datetime64[m]')).astype('timedelta64[s]').astype(np.int64)
-  raise ValueError(f'Unsupported unit for datetime: {unit}')
+  # the other integer fields of xarray's `.dt` accessor the reference forwards to (binning.py: `getattr(coord.dt, unit)`)
+  month = t.astype('datetime64[M]').astype(np.int64) % 12 + 1
+  if unit == 'quarter':
+    return (month - 1) // 3 + 1
+  if unit in ('days_in_month', 'daysinmonth'):
+    first = t.astype('datetime64[M]')
+    return ((first + 1).astype('datetime64[D]') - first.astype('datetime64[D]')).astype(np.int64)
+  if unit in ('week', 'weekofyear'):  # ISO 8601 week number: the week of the year that holds this date's Thursday
+    thursday = day + ((3 - (day.astype(np.int64) + 3) % 7).astype('timedelta64[D]'))
+    return (thursday - thursday.astype('datetime64[Y]').astype('datetime64[D]')).astype(np.int64) // 7 + 1
+  if unit == 'is_leap_year':
+    y = t.astype('datetime64[Y]').astype(np.int64) + 1970
+    return ((y % 4 == 0) & ((y % 100 != 0) | (y % 400 == 0))).astype(np.int64)
+  if unit == 'microsecond':
+    return (t - t.astype('datetime64[s]')).astype('timedelta64[us]').astype(np.int64)
+  if unit == 'nanosecond':
+    return (t - t.astype('datetime64[us]')).astype('timedelta64[ns]').astype(np.int64)
+  raise ValueError(f'Unsupported unit for datetime: {unit} (supported: year, quarter, month, week / weekofyear, day, dayofyear, '
+                   'dayofweek / weekday, days_in_month, is_leap_year, hour, minute, second, microsecond, nanosecond; `season` is '
+                   'a string field: bin by month sets with ByTimeUnitSets)')
 
 
 class ByTimeUnit(Binning):

@@ -37,7 +37,7 @@
 #endif
 #ifndef WBX_ZD_KNOCK
 #define WBX_ZD_KNOCK 0  // timing diagnostics (WRONG results; make ab-zdk1 ...): 1 = every row re-reads the team's FIRST row (cache
-                        // hits, no HBM stream), 2 = no deterministic lanes, 4 = no loads after the first row
+                        // hits, no HBM stream), 2 = no deterministic lanes, 4 = no loads after the first row, 8 = no wave sums / stores of the deterministic lanes
 #endif
 #ifndef WBX_ZD_FETCH_AT
 #define WBX_ZD_FETCH_AT 0  // 0: the next row's p (+ c) behind pass 1's stores, t behind pass 2's (72 registers live across the
@@ -245,10 +245,17 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
       }
     }
 #endif
+    if constexpr ((WBX_ZD_KNOCK & 8) != 0) {  // (diagnostic: the lanes' sums are formed but not added over the wave)
+      double any = 0.0;
+#pragma unroll
+      for (int l = 0; l < NA; ++l) any += d[l];
+      if (any == 1.2345e300) a.out[r * NA] = any;
+    } else {
 #pragma unroll
     for (int l = 0; l < NA; ++l) {
       const double tot = wave_sum_uniform(lane < Z14_LANES ? d[l] : 0.0);
       if (lane == 0) a.out[r * NA + l] = tot;
+    }
     }
     }
     __builtin_amdgcn_sched_barrier(0);  // the row's deterministic sums are done before the transform starts: their temporaries die here

@@ -134,8 +134,31 @@ class SparseObservationsFromParquet(_memory.DataLoader):
 
   # ---- a chunk --------------------------------------------------------------------------------------------------------------------
   def _load_chunk_from_source(self, init_times, lead_times=None):
-    read = functools.lru_cache(maxsize=None)(pd.read_parquet)             # each partition file once per chunk
     init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    # Each partition file once per chunk, and only the rows the chunk can use: ONE time filter that covers the union of the
+    # chunk's windows is pushed down to the reader (the reference hands its time filters to pd.read_parquet,
+    # sparse_parquet.py:171-192; a month of METAR reports is whole minutes of rows a chunk of a few hours never looks at), the
+    # individual windows are then selected in memory as before.  Files the filter cannot be applied to (no row groups: pyarrow
+    # raises on an empty file) are read whole.
+    if isinstance(lead_times, slice):
+      valid = init_times
+    elif lead_times is None:
+      valid = init_times
+    else:
+      valid = (init_times[:, None] + np.asarray(lead_times).astype('timedelta64[ns]')[None, :]).reshape(-1)
+    windows = [self._window(v, lead_times if isinstance(lead_times, slice) else None) for v in valid]
+    lo = min((w[0] for w in windows), default=None)
+    hi = max((w[0] if w[1] is None else w[1] for w in windows), default=None)
+    filters = None if lo is None else [(self._time_dim, '>=', pd.Timestamp(lo)), (self._time_dim, '<=', pd.Timestamp(hi))]
+
+    @functools.lru_cache(maxsize=None)
+    def read(fn):
+      if filters is not None:
+        try:
+          return pd.read_parquet(fn, filters=filters)
+        except Exception:  # pylint: disable=broad-except  (ArrowTypeError / ArrowInvalid / an engine without filters)
+          pass
+      return pd.read_parquet(fn)
     frames = []
     if isinstance(lead_times, slice):
       assert self._tolerance is None, 'Tolerance not compatible with lead_time slice.'
