@@ -60,18 +60,20 @@ def _job(ninit, nlead, lead_hours=6, init_step_hours=24, start='2020-01-01T00', 
 
 
 def _oracle_acc(p, t, full, inits, lead):
-  """ACC / activity / RMSE per (lead, level), area-weighted over (init, lat, lon), float64."""
+  """ACC / activity / RMSE per (lead, level), area-weighted over (init, lat, lon), through the float64 oracle: the alignment
+  (metrics/base.py:382-403), the anomaly statistics (deterministic.py:222-259) and the weighted reduction (aggregation.py:297-366)."""
   valid = inits[:, None] + lead[None, :]
-  doy = (valid.astype('datetime64[D]') - valid.astype('datetime64[Y]').astype('datetime64[D]')).astype(int)
-  hour = (valid.astype('datetime64[h]') - valid.astype('datetime64[D]').astype('datetime64[h]')).astype(int) // 6
-  c = full[doy, hour].astype(np.float64)
-  w = O.grid_area_weights(LAT)[None, None, None, :, None]
-  pf, tf = p.astype(np.float64), t.astype(np.float64)
+  c, cdims = O.align_climatology(full, CDIMS, valid, ('init_time', 'lead_time'))
+  assert cdims == ZDIMS
+  w = (O.grid_area_weights(LAT), ('latitude',))
+  reduce = ['init_time', 'latitude', 'longitude']
 
-  def mean(x):
-    return (x * w).sum(axis=(0, 3, 4)) / (np.ones_like(x) * w).sum(axis=(0, 3, 4))
-  cov, spa, sta = mean((pf - c) * (tf - c)), mean((pf - c) ** 2), mean((tf - c) ** 2)
-  return {'acc': cov / np.sqrt(spa * sta), 'activity': np.sqrt(spa), 'rmse': np.sqrt(mean((pf - tf) ** 2))}
+  def mean(stat):
+    sws, sw, od = O.aggregate(stat, ZDIMS, reduce, weights=[w])
+    assert tuple(od) == ('lead_time', 'level')
+    return sws / sw
+  cov, spa, sta = mean(O.anomaly_covariance(p, t, c)), mean(O.squared_prediction_anomaly(p, c)), mean(O.squared_target_anomaly(t, c))
+  return {'acc': O.acc(cov, spa, sta), 'activity': np.sqrt(spa), 'rmse': O.rmse(mean(O.squared_error(p, t)))}
 
 
 def _metrics(clim_ds):
