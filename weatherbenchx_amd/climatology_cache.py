@@ -252,6 +252,7 @@ class SlabCache:
     self.last_use = {}   # slot -> fences behind the last chunk that read it (None: read since the last stamp)
     self.touched = set()  # keys named by launches that may not have been enqueued yet (+ the next chunk's, asked for ahead)
     self.stats = {'uploads': 0, 'upload_bytes': 0, 'hits': 0, 'evictions': 0, 'requests': 0, 'prefetched': 0}
+    self._stamps = collections.deque(maxlen=6)
     _LIVE.add(self)
 
   # -- set-up -----------------------------------------------------------------------------------------------------------
@@ -364,6 +365,10 @@ class SlabCache:
       if slot is not None:
         if fences is None:
           fences = self.pool.fences_now()
+          # (dropping a fence waits for it -- an event is not destroyed while a stream may be told to wait on it -- and the slots
+          #  of consecutive chunks are mostly the same: the stamps of the last few chunks are kept until their kernels are long done,
+          #  so that re-stamping a slot never blocks the host on the chunk that is still running)
+          self._stamps.append(fences)
         self.last_use[slot] = fences
     self.touched = set()
 
