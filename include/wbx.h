@@ -472,6 +472,18 @@ int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3
                      const void* p, const void* t, const void* c, const int32_t* group, const double* scale, int64_t ngroup,
                      double* partial_out, double* power_p, double* power_t);
 
+/* The same sweep with stage 2 of the deterministic lanes folded in (round 6).  Where the aggregation's W is a weight per ROW of
+ * the plan and the rows of a group are exactly the rows stage 2 would sum into one output -- GridAreaWeighting over
+ * (init_time, latitude, longitude), the spectra averaged over (init_time, latitude): configs[3] / configs[4] -- the kernel
+ * multiplies every row's sums by det_scale[row] and adds them up with the spectra's records:
+ *   det_out[g][lane] = sum over the rows of group g of det_scale[row] * (sum over the row of lane's statistic)
+ * = what wbx_contract would make of wbx_det_spectrum's partial_out with that W: [ngroup][3 | 6], overwritten; ordered sums (the
+ * records of a group are added in key order), fp64.  It saves the six fp64 wave sums and stores per row (6 % of the kernel) and
+ * the 25 MB partial + its contraction.  `group`, `scale`, `det_scale` are device arrays indexed by key. */
+int wbx_det_spectrum_folded(wbx_ctx* ctx, const wbx_s1_plan* plan, int func /* WBX_DET3 | WBX_DET6 */, int dtype /* WBX_F32 */,
+                            const void* p, const void* t, const void* c, const int32_t* group, const double* scale,
+                            const double* det_scale, int64_t ngroup, double* det_out, double* power_p, double* power_t);
+
 /* The same for LATITUDE-FASTEST fields (the layout of the public ERA5 / WeatherBench archives, [.., longitude, latitude];
  * weatherbenchX/data_loaders/xarray_loaders.py:185-188 hands such chunks on as they are stored): `plan` is the deterministic
  * plan of (p, t[, c]) with x = longitude (nx = 1440, summed, ndepth = 1, nchunk = 1, no mask) whose keys are nkey /
@@ -503,7 +515,7 @@ typedef enum wbx_fn {
   WBX_FN_DET_PARTIAL = 1, WBX_FN_ENS_PARTIAL = 2, WBX_FN_ENS2_PARTIAL = 3, WBX_FN_CAT_PARTIAL = 4, WBX_FN_CAT_EXCEED_FIELD = 5,
   WBX_FN_CONTRACT = 6, WBX_FN_CONTRACT_BITS = 7, WBX_FN_DET_BINNED = 8, WBX_FN_ENS_BINNED = 9, WBX_FN_ZONAL_SPECTRUM = 10,
   WBX_FN_ZONAL_SPECTRUM_SLABS = 11, WBX_FN_DET_SPECTRUM = 12, WBX_FN_DET_SPECTRUM_SLABS = 13, WBX_FN_ACC_ADD = 14,
-  WBX_FN_MEMSET = 15, WBX_FN_MEMCPY_D2D = 16, WBX_FN_CTX_WAIT_FENCE = 17, WBX_FN_FENCE_RECORD = 18
+  WBX_FN_MEMSET = 15, WBX_FN_MEMCPY_D2D = 16, WBX_FN_CTX_WAIT_FENCE = 17, WBX_FN_FENCE_RECORD = 18, WBX_FN_DET_SPECTRUM_FOLDED = 19
 } wbx_fn;
 #define WBX_CALL_MAX_ARGS 20
 typedef struct wbx_call {

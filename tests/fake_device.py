@@ -176,7 +176,7 @@ def _cat_lanes(plan, devs, cat):
           for k in range(ncat)]  # NaN threshold: NaN indicator (deterministic.py:293-294)
 
 
-def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None, inputs=None):  # pylint: disable=unused-argument
+def _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nlanes_total, func=0, ens=None, cat=None, inputs=None, fold=None):  # pylint: disable=unused-argument
   if engine.S1_EVENT_LOG is not None:
     engine.S1_EVENT_LOG.append({'kind': kind, 'flags': int(plan.flags), 'ms': 0.0, 'x_kept': plan.x_kept, 'block': plan.block_threads})
   with np.errstate(all='ignore'):

@@ -500,6 +500,7 @@ def test_fused_and_separate_launches_agree_through_the_chunk_loop(ctx, monkeypat
     finally:
       engine.S1_EVENT_LOG = None
     return out['det'][None].metric_values(det), out['spec'][None].metric_values(spec_metrics), kinds
+  monkeypatch.setattr(engine, 'FOLD_DET_SPECTRA', False)  # the fused launch writes wbx_det_partial's buffer: bit for bit
   d1, s1, k1 = run(spec_same, True)
   d0, s0, k0 = run(spec_same, False)
   assert k1.count('det_spectrum') == ninit and 'spectrum' not in k1
@@ -508,6 +509,14 @@ def test_fused_and_separate_launches_agree_through_the_chunk_loop(ctx, monkeypat
     np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
   for k in s0:
     np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
+  # (r6) stage 2 folded into the fused launch (the default): the same sums in another order -- fp64 rounding apart
+  monkeypatch.setattr(engine, 'FOLD_DET_SPECTRA', True)
+  df, sf, kf = run(spec_same, True)
+  assert kf.count('det_spectrum') == ninit and 'spectrum' not in kf
+  for k in d0:
+    np.testing.assert_allclose(df[k].values, d0[k].values, rtol=1e-13, err_msg=k)
+  for k in s0:
+    np.testing.assert_array_equal(sf[k].values, s1[k].values, err_msg=k)
   # spectra with different row scales (power vs energy) do not share a (group, scale) table: no fusion, same numbers
   d2, s2, k2 = run(spec, True)
   assert 'det_spectrum' not in k2

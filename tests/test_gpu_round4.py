@@ -232,8 +232,8 @@ def test_fused_spectra_of_two_variables_do_not_share_a_buffer(ctx, monkeypatch):
   assert k1.count('det_spectrum') == 2 * ninit and 'spectrum' not in k1
   assert 'det_spectrum' not in k0 and k0.count('spectrum') == 4 * ninit
   assert not np.allclose(s0['sp.z'].values, s0['sp.t'].values, rtol=1e-3)  # the variables really differ
-  for k in d0:
-    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in d0:  # (r6: the fused launch folds stage 2 in: the same sums in another order, tests/test_gpu_round3.py has the bitwise case)
+    np.testing.assert_allclose(d1[k].values, d0[k].values, rtol=1e-13, err_msg=k)
   for k in s0:
     np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
 
@@ -256,8 +256,8 @@ def test_passes_share_one_feeder_per_loader(ctx, monkeypatch):
   d1, s1, k1, ncalls, ninit = _run_passes(('det', 'spec'), True, monkeypatch, prefetch=1)
   d0, s0, _, _, _ = _run_passes(('det', 'spec'), False, monkeypatch)
   assert ncalls == ninit and k1.count('det_spectrum') == 2 * ninit
-  for k in d0:
-    np.testing.assert_array_equal(d1[k].values, d0[k].values, err_msg=k)
+  for k in d0:  # (r6: stage 2 folded into the fused launch: another summation order)
+    np.testing.assert_allclose(d1[k].values, d0[k].values, rtol=1e-13, err_msg=k)
   for k in s0:
     np.testing.assert_allclose(s1[k].values, s0[k].values, rtol=1e-12, err_msg=k)
 

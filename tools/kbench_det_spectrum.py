@@ -61,6 +61,36 @@ for i, name in ((0, 'p'), (1, 't')):
   sa = ctx.download(pw[i].ptr, (ngroup, nk)).copy()
   sb = ctx.download(pw[2 + i].ptr, (ngroup, nk)).copy()
   print(f'spectrum {name}: max rel diff', float(np.max(np.abs(sa - sb) / (np.abs(sa) + 1e-30))), 'sum_k', sa[0].sum(), sb[0].sum())
+det_out = ctx.alloc(ngroup * 6 * 8)
+
+
+def folded():
+  _hip.check(lib.wbx_det_spectrum_folded(ctx.handle, C.byref(dplan.struct), _hip.DET6, _hip.F32, ptr(devs[0]), ptr(devs[1]), ptr(devs[2]),
+                                         ptr(g_dev), ptr(s_dev), ptr(s_dev), ngroup, ptr(det_out), ptr(pw[2]), ptr(pw[3])),
+             'wbx_det_spectrum_folded')
+
+
+def folded3():
+  _hip.check(lib.wbx_det_spectrum_folded(ctx.handle, C.byref(dplan.struct), _hip.DET3, _hip.F32, ptr(devs[0]), ptr(devs[1]), None,
+                                         ptr(g_dev), ptr(s_dev), ptr(s_dev), ngroup, ptr(det_out), ptr(pw[2]), ptr(pw[3])),
+             'wbx_det_spectrum_folded')
+
+
+folded()
+ctx.synchronize()
+want = (a.reshape(ngroup, nlat, 6) * w[None, :, None]).sum(axis=1)
+got = ctx.download(det_out.ptr, (ngroup, 6)).copy()
+print('folded det sums: max rel diff to the contraction of the partial', float(np.max(np.abs(got - want) / (np.abs(want) + 1e-300))))
+for i, name in ((0, 'p'), (1, 't')):
+  sa = ctx.download(pw[i].ptr, (ngroup, nk)).copy()
+  sb = ctx.download(pw[2 + i].ptr, (ngroup, nk)).copy()
+  print(f'folded spectrum {name}: max rel diff', float(np.max(np.abs(sa - sb) / (np.abs(sa) + 1e-30))))
+folded3()
+ctx.synchronize()
+got3 = ctx.download(det_out.ptr, (ngroup, 3)).copy()
+print('folded DET3 sums: max rel diff', float(np.max(np.abs(got3 - want[:, :3]) / (np.abs(want[:, :3]) + 1e-300))))
+
+
 def fused3():
   _hip.check(lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), _hip.DET3, _hip.F32, ptr(devs[0]), ptr(devs[1]), None,
                                   ptr(g_dev), ptr(s_dev), ngroup, ptr(part_b), ptr(pw[2]), ptr(pw[3])), 'wbx_det_spectrum')
@@ -73,7 +103,8 @@ def spectra_only():
 
 
 gb = nrows * nlon * 4 / 1e9
-for name, fn, nbytes in (('separate (det + 2 spectra)', separate, 12), ('fused', fused, 12), ('fused DET3 (no c)', fused3, 8),
+for name, fn, nbytes in (('separate (det + 2 spectra)', separate, 12), ('fused', fused, 12), ('folded (stage 2 inside)', folded, 12),
+                         ('fused DET3 (no c)', fused3, 8), ('folded DET3', folded3, 8),
                          ('two spectra alone', spectra_only, 8)):
   ms = []
   for it in range(5):

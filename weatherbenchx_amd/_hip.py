@@ -39,14 +39,14 @@ EXPORTED_SYMBOLS = (
     'wbx_memcpy_d2d', 'wbx_acc_add', 'wbx_notnan_mask', 'wbx_binned_atoms_size', 'wbx_binned_atoms',
     'wbx_comm_unique_id', 'wbx_comm_create', 'wbx_comm_destroy', 'wbx_comm_info', 'wbx_acc_allreduce', 'wbx_acc_read',
     'wbx_acc_reset', 'wbx_det_spectrum', 'wbx_det_spectrum_slabs', 'wbx_ens_binned', 'wbx_ens_binned_atoms_size', 'wbx_ens_binned_atoms',
-    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay', 'wbx_host_transpose', 'wbx_clock_probe',
+    'wbx_ens2_partial', 'wbx_cat_exceed_field', 'wbx_chunk_replay', 'wbx_host_transpose', 'wbx_clock_probe', 'wbx_det_spectrum_folded',
 )
 
 # wbx_fn (include/wbx.h): the entry points a chunk record may hold
 FN_IDS = {'wbx_det_partial': 1, 'wbx_ens_partial': 2, 'wbx_ens2_partial': 3, 'wbx_cat_partial': 4, 'wbx_cat_exceed_field': 5,
           'wbx_contract': 6, 'wbx_contract_bits': 7, 'wbx_det_binned': 8, 'wbx_ens_binned': 9, 'wbx_zonal_spectrum': 10,
           'wbx_zonal_spectrum_slabs': 11, 'wbx_det_spectrum': 12, 'wbx_det_spectrum_slabs': 13, 'wbx_acc_add': 14,
-          'wbx_memset': 15, 'wbx_memcpy_d2d': 16, 'wbx_ctx_wait_fence': 17, 'wbx_fence_record': 18}
+          'wbx_memset': 15, 'wbx_memcpy_d2d': 16, 'wbx_ctx_wait_fence': 17, 'wbx_fence_record': 18, 'wbx_det_spectrum_folded': 19}
 CALL_MAX_ARGS = 20
 # pure queries: they touch neither a stream nor memory, a record simply leaves them out
 QUERY_FNS = frozenset({'wbx_s1_partial_len', 'wbx_binned_atoms_size', 'wbx_ens_binned_atoms_size', 'wbx_last_error',
@@ -197,6 +197,7 @@ def load_library():
         'wbx_zonal_spectrum': [vp, vp, i64, i64, i64, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
         'wbx_det_spectrum': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp],
         'wbx_det_spectrum_slabs': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, i64, vp, vp, i64, vp, vp, vp],
+        'wbx_det_spectrum_folded': [vp, C.POINTER(S1PlanStruct), i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
         'wbx_zonal_spectrum_slabs': [vp, vp, i64, i64, i64, i64, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp],
     }
     protos['wbx_chunk_replay'] = [vp, i32, vp, i32, vp, i32]

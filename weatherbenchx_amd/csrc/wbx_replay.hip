@@ -66,6 +66,7 @@ extern "C" int wbx_chunk_replay(wbx_call* calls, int32_t ncalls, const wbx_reloc
       WBX_REPLAY_CASE(WBX_FN_ZONAL_SPECTRUM_SLABS, wbx_zonal_spectrum_slabs)
       WBX_REPLAY_CASE(WBX_FN_DET_SPECTRUM, wbx_det_spectrum)
       WBX_REPLAY_CASE(WBX_FN_DET_SPECTRUM_SLABS, wbx_det_spectrum_slabs)
+      WBX_REPLAY_CASE(WBX_FN_DET_SPECTRUM_FOLDED, wbx_det_spectrum_folded)
       WBX_REPLAY_CASE(WBX_FN_ACC_ADD, wbx_acc_add)
       WBX_REPLAY_CASE(WBX_FN_MEMSET, wbx_memset)
       WBX_REPLAY_CASE(WBX_FN_MEMCPY_D2D, wbx_memcpy_d2d)

@@ -176,7 +176,8 @@ __device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_
 constexpr int SPEC_CLOSE_LIST = 2048;
 constexpr int SPEC_CLOSE_BATCH = 16;  // headers / record values a thread asks for before it looks at any of them
 __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngroup, int32_t nk, int32_t nfield, double* __restrict__ power0,
-                                                        double* __restrict__ power1, int32_t accumulate) {
+                                                        double* __restrict__ power1, int32_t accumulate, double* __restrict__ tail_out = nullptr,
+                                                        int32_t ntail = 0, int32_t ntail_out = 0) {
   __shared__ unsigned long long keys[SPEC_CLOSE_LIST];
   __shared__ unsigned int slots[SPEC_CLOSE_LIST];
   __shared__ unsigned int n_list, n_more;
@@ -186,8 +187,17 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
   const unsigned int dyn = R.count[R.parity];
   const unsigned int taken = R.nstatic + dyn < R.capacity ? R.nstatic + dyn : R.capacity;
   const bool overflow = R.count[2 + R.parity] != 0u;
-  const int nval = nk * nfield;
-  auto out_of = [&](int v) -> double* { return (v < nk ? power0 : power1) + (int64_t)g * nk + (v < nk ? v : v - nk); };
+  // (r6) `ntail` more values behind the fields of a record (wbx_det_spectrum_folded: the deterministic sums of the record's rows), the
+  // first `ntail_out` of them go to tail_out[g][..]; the padding is added like everything else and dropped
+  const int nval = nk * nfield + ntail;
+  __shared__ double tail_sink[64];
+  auto out_of = [&](int v) -> double* {
+    if (v >= nk * nfield) {
+      const int j = v - nk * nfield;
+      return j < ntail_out ? tail_out + (int64_t)g * ntail_out + j : tail_sink + (threadIdx.x & 63);
+    }
+    return (v < nk ? power0 : power1) + (int64_t)g * nk + (v < nk ? v : v - nk);
+  };
   // the slots whose header names this group and whose key is in [floor, below): appended to the LDS list (past LIST entries they
   // are only counted).  The headers are read BATCH at a time into registers -- the loads of a batch are in flight together.
   auto collect = [&](unsigned long long floor_key, unsigned long long below) {
@@ -422,9 +432,10 @@ static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t nstatic, int64_
 }
 
 static int spec_close(wbx_ctx* ctx, const SpecRecs& R, int32_t ngroup, int32_t nk, int32_t nfield, double* power0, double* power1,
-                      int32_t accumulate) {
+                      int32_t accumulate, double* tail_out = nullptr, int32_t ntail = 0, int32_t ntail_out = 0) {
   if (ngroup <= 0) return 0;
-  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup, (unsigned)((nk * nfield + 63) / 64)), dim3(256), 0, ctx->stream, R, ngroup, nk, nfield, power0, power1, accumulate);
+  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup, (unsigned)((nk * nfield + ntail + 63) / 64)), dim3(256), 0, ctx->stream, R,
+                     ngroup, nk, nfield, power0, power1, accumulate, tail_out, ntail, ntail_out);
   WBX_HIP(hipGetLastError());
   return 0;
 }
@@ -1300,7 +1311,8 @@ static int rocfft_route(wbx_ctx* ctx, FftState* st, const float* field, int64_t 
 // ---- spectra of (p, t) + the deterministic lanes of the same rows in one sweep (wbx_zspec_det.hpp) --------------------------
 static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, bool has_c, const void* p, const void* t,
                            const void* c, const int32_t* group, const double* scale, double* partial_out, double* power_p,
-                           double* power_t, int32_t ngroup) {
+                           double* power_t, int32_t ngroup, const double* det_scale = nullptr, double* det_out = nullptr) {
+  const bool fold = det_scale != nullptr;
   void*& tab = st->twiddles[-Z14_N];
   if (!tab) {
     std::vector<float2> host;
@@ -1317,7 +1329,8 @@ static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, 
   a.out = partial_out;
   const size_t lds = (size_t)Z14_TABLES * sizeof(float2) + (size_t)ZD_TEAMS * Z14_BUF * sizeof(v4) +
                      ((has_c && !WBX_ZD_C_IN_REGISTERS) ? (size_t)ZD_TEAMS * 24 * 64 * sizeof(float) : 0);  // + the climatology staging slots
-  const void* fn = has_c ? reinterpret_cast<const void*>(&zspec1440_det_kernel<true>) : reinterpret_cast<const void*>(&zspec1440_det_kernel<false>);
+  const void* fn = fold ? (has_c ? reinterpret_cast<const void*>(&zspec1440_det_kernel<true, true>) : reinterpret_cast<const void*>(&zspec1440_det_kernel<false, true>))
+                        : (has_c ? reinterpret_cast<const void*>(&zspec1440_det_kernel<true>) : reinterpret_cast<const void*>(&zspec1440_det_kernel<false>));
   int& per_cu = st->occupancy[std::make_pair(fn, lds)];
   if (per_cu == 0) {
     if (lds > 48 * 1024) WBX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1335,14 +1348,21 @@ static int launch_1440_det(wbx_ctx* ctx, FftState* st, const wbx_s1_plan* plan, 
   int64_t changes = 0;
   if (int rc = spec_group_changes(ctx, group, nrows, &changes)) return rc;
   SpecRecs recs;
-  if (int rc = spec_recs_prepare(ctx, st, blocks * ZD_TEAMS, changes, 2 * (Z14_N2 + 1), &recs)) return rc;
-  if (has_c)
+  if (int rc = spec_recs_prepare(ctx, st, blocks * ZD_TEAMS, changes, 2 * (Z14_N2 + 1) + (fold ? ZD_TAIL : 0), &recs)) return rc;
+  if (fold && has_c)
+    hipLaunchKernelGGL((zspec1440_det_kernel<true, true>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs, det_scale);
+  else if (fold)
+    hipLaunchKernelGGL((zspec1440_det_kernel<false, true>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs, det_scale);
+  else if (has_c)
     hipLaunchKernelGGL((zspec1440_det_kernel<true>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
-                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs);
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs, (const double*)nullptr);
   else
     hipLaunchKernelGGL((zspec1440_det_kernel<false>), dim3((unsigned)blocks), dim3(64 * ZD_TEAMS), lds, ctx->stream, a, nrows,
-                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs);
+                       (int)rows_per_team, reinterpret_cast<const float2*>(tab), group, scale, recs, (const double*)nullptr);
   WBX_HIP(hipGetLastError());
+  if (fold) return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 2, power_p, power_t, 0, det_out, ZD_TAIL, has_c ? 6 : 3);
   return spec_close(ctx, recs, ngroup, Z14_N2 + 1, 2, power_p, power_t, 0);
 }
 
@@ -1430,16 +1450,16 @@ static int launch_1440_det_latfast(wbx_ctx* ctx, FftState* st, const wbx_s1_plan
 
 }  // namespace wbx
 
-extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
-                                const void* c, const int32_t* group, const double* scale, int64_t ngroup, double* partial_out,
-                                double* power_p, double* power_t) {
+static int det_spectrum_entry(const char* who, wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                              const void* c, const int32_t* group, const double* scale, const double* det_scale, int64_t ngroup,
+                              double* det_out, double* power_p, double* power_t, bool fold) {
   using namespace wbx;
   WBX_REQUIRE(ctx != nullptr, "ctx is NULL");
   if (int rc = check_plan(plan)) return rc;
-  WBX_REQUIRE(func == WBX_DET3 || func == WBX_DET6, "wbx_det_spectrum takes WBX_DET3 or WBX_DET6 (got %d)", func);
-  WBX_REQUIRE(dtype == WBX_F32, "wbx_det_spectrum takes float32 fields");
+  WBX_REQUIRE(func == WBX_DET3 || func == WBX_DET6, "%s takes WBX_DET3 or WBX_DET6 (got %d)", who, func);
+  WBX_REQUIRE(dtype == WBX_F32, "%s takes float32 fields", who);
   WBX_REQUIRE(plan->nx == Z14_N && !plan->x_kept && plan->ndepth == 1 && plan->nchunk == 1,
-              "wbx_det_spectrum needs rows of %d points summed along x, one depth row and one chunk per key", Z14_N);
+              "%s needs rows of %d points summed along x, one depth row and one chunk per key", who, Z14_N);
   WBX_REQUIRE(!(plan->flags & (WBX_FLAG_MASKED | WBX_FLAG_SKIPNA)) && plan->x_weights == nullptr, "no masks / folded weights here");
   const int nin = func == WBX_DET6 ? 3 : 2;
   for (int i = 0; i < nin; ++i) {
@@ -1447,7 +1467,7 @@ extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func,
   }
   WBX_REQUIRE(ngroup >= 1, "ngroup must be >= 1");
   if (plan->nkey == 0) return 0;
-  WBX_REQUIRE(p && t && (func == WBX_DET3 || c) && group && scale && partial_out && power_p && power_t, "NULL pointer");
+  WBX_REQUIRE(p && t && (func == WBX_DET3 || c) && group && scale && det_out && power_p && power_t && (!fold || det_scale), "NULL pointer");
   WBX_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(c)) % 8 == 0,
               "fields must be 8-byte aligned (row offsets must be even: the caller's plan)");
   WBX_HIP(hipSetDevice(ctx->device));
@@ -1458,8 +1478,24 @@ extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func,
     WBX_FFT(rocfft_setup());  // (the state is shared with wbx_zonal_spectrum, which may take the rocFFT route later)
     st->setup = true;
   }
-  // (no memset: the closing kernel of the records starts both spectra from zero)
-  return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, partial_out, power_p, power_t, (int32_t)ngroup);
+  // (no memset: the closing kernel of the records starts both spectra -- and the folded sums -- from zero)
+  if (fold)
+    return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, nullptr, power_p, power_t, (int32_t)ngroup, det_scale, det_out);
+  return launch_1440_det(ctx, st, plan, func == WBX_DET6, p, t, c, group, scale, det_out, power_p, power_t, (int32_t)ngroup);
+}
+
+extern "C" int wbx_det_spectrum(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                                const void* c, const int32_t* group, const double* scale, int64_t ngroup, double* partial_out,
+                                double* power_p, double* power_t) {
+  return det_spectrum_entry("wbx_det_spectrum", ctx, plan, func, dtype, p, t, c, group, scale, nullptr, ngroup, partial_out, power_p,
+                            power_t, false);
+}
+
+extern "C" int wbx_det_spectrum_folded(wbx_ctx* ctx, const wbx_s1_plan* plan, int func, int dtype, const void* p, const void* t,
+                                       const void* c, const int32_t* group, const double* scale, const double* det_scale,
+                                       int64_t ngroup, double* det_out, double* power_p, double* power_t) {
+  return det_spectrum_entry("wbx_det_spectrum_folded", ctx, plan, func, dtype, p, t, c, group, scale, det_scale, ngroup, det_out,
+                            power_p, power_t, true);
 }
 
 

@@ -62,11 +62,18 @@ constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is written by the LDS-DMA statements and listed as clobbered
-template <bool HAS_C>
+// FOLD (r6, wbx_det_spectrum_folded): the rows' deterministic sums are not stored row by row for stage 2 -- each is multiplied by
+// its row's weight `dscale[row]` (what stage 2's W holds for the row: the latitude weight) and added to the team's running sums
+// PER LANE; the six wave sums and stores happen once per RECORD instead of once per row (6 % of the kernel,
+// profiles/r06_det_spectrum_knockouts.txt), and the record carries them behind the two spectra (ZD_TAIL values: spec_close_kernel
+// adds them over the records of a group in key order like every wavenumber).
+constexpr int ZD_TAIL = 8;  // doubles behind the 2 x 721 spectrum values of a folded record (6 used)
+template <bool HAS_C, bool FOLD = false>
 __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, int64_t nrows, int rows_per_team,
                                                                       const float2* __restrict__ tables_g,
                                                                       const int32_t* __restrict__ group,
-                                                                      const double* __restrict__ scale, SpecRecs recs) {
+                                                                      const double* __restrict__ scale, SpecRecs recs,
+                                                                      const double* __restrict__ dscale = nullptr) {
   constexpr int NA = HAS_C ? 6 : 3;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float2* const tw1 = reinterpret_cast<float2*>(lds_raw);
@@ -96,6 +103,9 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   double accp[6], accmp[6], acct[6], accmt[6];  // sums of k = L + 60 s and of 720 - k, predictions / targets
 #pragma unroll
   for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
+  double dsum[FOLD ? NA : 1];  // FOLD: this lane's weighted deterministic sums over the rows of the current record
+#pragma unroll
+  for (int l = 0; l < (FOLD ? NA : 1); ++l) dsum[l] = 0.0;
   int32_t cur = group[r0];
   unsigned int seq = 0;
   // (r5) one record of 2 x 721 values: the predictions' sums, then the targets'; the team's LAST record sits in its reserved slot
@@ -106,6 +116,15 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     z14_send<true>(rec + nk, c, acct, accmt);
 #pragma unroll
     for (int s = 0; s < 6; ++s) accp[s] = accmp[s] = acct[s] = accmt[s] = 0.0;
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int l = 0; l < NA; ++l) {
+        const double tot = wave_sum_uniform(lane < Z14_LANES ? dsum[l] : 0.0);  // (lanes 60..63 shadow lane 59)
+        if (lane == 0) rec[2 * nk + l] = tot;
+        dsum[l] = 0.0;
+      }
+      if (lane < ZD_TAIL - NA) rec[2 * nk + NA + lane] = 0.0;
+    }
     cur = next;
   };
 
@@ -245,7 +264,12 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
       }
     }
 #endif
-    if constexpr ((WBX_ZD_KNOCK & 8) != 0) {  // (diagnostic: the lanes' sums are formed but not added over the wave)
+    if constexpr (FOLD) {
+      const double dw = dscale[r];
+      if (g != cur) flush(g);  // (the row belongs to the next record: close the running one first; wave-uniform)
+#pragma unroll
+      for (int l = 0; l < NA; ++l) dsum[l] = fma(d[l], dw, dsum[l]);
+    } else if constexpr ((WBX_ZD_KNOCK & 8) != 0) {  // (diagnostic: the lanes' sums are formed but not added over the wave)
       double any = 0.0;
 #pragma unroll
       for (int l = 0; l < NA; ++l) any += d[l];

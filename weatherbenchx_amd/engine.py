@@ -585,9 +585,26 @@ def _fusion_latfast_plan(ctx, inputs, dims, sizes, layouts, reduce_dims, wdep, g
   return plan, dplan
 
 
-def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
-  """The fused launch when a request for these very inputs is pending and the plan qualifies: -> True (partial written to
-  `out`, both spectra parked with their source arrays), else False (the caller launches wbx_det_partial as usual)."""
+class _FoldedS2:
+  """What `_run_s1` returns when the fused launch has done stage 2 of the deterministic lanes itself (wbx_det_spectrum_folded):
+  `res` = (device pointer, shape) of out[nA][nBk][lanes][nj_out][nbin], exactly what `_run_s2` would have returned."""
+
+  def __init__(self, res):
+    self.res = res
+
+
+# Stage 2 of the deterministic lanes inside the fused det + spectra sweep where W is one weight per row of the plan
+# (GridAreaWeighting over (init_time, latitude, longitude)) and the spectra's groups are the outputs stage 2 would form: the
+# rows' sums are weighted and added up with the spectra's records instead of being stored row by row and contracted afterwards
+# (-8 % of the sweep, no 25 MB partial, no contraction launch; tools/kbench_det_spectrum.py).  0: wbx_det_spectrum + wbx_contract.
+FOLD_DET_SPECTRA = os.environ.get('WBX_FOLD_DET_SPECTRA', '1') != '0'
+
+
+def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, make_out, fold=None):
+  """The fused launch when a request for these very inputs is pending and the plan qualifies: -> the partial's buffer
+  (`make_out()`, written by the launch; both spectra parked with their source arrays) or a `_FoldedS2` (stage 2 done as well:
+  `fold` = (s2 plan, W, bin dims, W on the device) of the reduction in progress), else False (the caller launches
+  wbx_det_partial as usual)."""
   if not _fusion_requests or inputs is None:
     return False
   req = _fusion_requests.get(id(inputs[0]))
@@ -612,11 +629,27 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
     else:
       g = np.ascontiguousarray(np.asarray(entry['group'])[rows], dtype=np.int32)
       sc = np.ascontiguousarray(np.asarray(entry['scale'])[rows], dtype=np.float64)
-      entry['dev'][fkey] = bufs = (ctx.upload(g), ctx.upload(sc))
+      entry['dev'][fkey] = bufs = (ctx.upload(g), ctx.upload(sc), g)
   if bufs is False:
     return False
+  # stage 2 folded in: W is a weight per row (nothing kept along x, no bins, no count lanes) and row (a, br)'s group IS a
+  folded = None
+  if FOLD_DET_SPECTRA and fold is not None and rps is None:
+    s2, w_da, bin_dims, w_buf = fold
+    nl = _hip.DET_LANES[func]
+    if (s2.nBk == 1 and s2.nbin == 1 and s2.nj == 1 and not plan.x_kept and s2.nchunk == 1 and s2.nlane == nl and s2.nA == ngroup
+        and s2.nA * s2.nBr == plan.nkey and w_buf.kind == 'dense'):
+      key2 = fkey + ('fold', id(w_buf))
+      folded = entry['dev'].get(key2)
+      if folded is None:
+        folded = False
+        w, _ = dense_w(plan, w_da, bin_dims)
+        if w.shape == (1, s2.nBr, 1, 1) and np.array_equal(bufs[2], np.repeat(np.arange(s2.nA, dtype=np.int32), s2.nBr)):
+          folded = (ctx.upload(np.ascontiguousarray(np.tile(w[0, :, 0, 0], s2.nA))), w_buf)  # (w_buf: its id stays unique)
+        entry['dev'][key2] = folded
+      folded = folded or None
   del _fusion_requests[id(inputs[0])]
-  replay.keep(bufs, dplan, devs[2] if nin > 2 else None)
+  replay.keep(bufs[:2], folded[0] if folded else None, dplan, devs[2] if nin > 2 else None)
   nk = 721
   # this launch's OWN result buffers (pooled device blocks): several variables of a chunk are launched before the spectra
   # pass reads the first of them, so one scratch slot per context would hand every variable the last variable's spectra
@@ -624,8 +657,20 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
   pw_t = ctx.alloc(max(ngroup * nk, 1) * 8)
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
 
+  det_out = out = None
+  if folded:
+    det_shape = fold[0].out_shape()
+    det_out = _scratch(ctx, 's2out', int(np.prod(det_shape, dtype=np.int64)) * 8)
+  else:
+    out = make_out()
+
   def call():
-    if rps is None:
+    if folded:
+      _hip.check(ctx.lib.wbx_det_spectrum_folded(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
+                                                 ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
+                                                 C.c_void_p(folded[0].ptr), int(ngroup), C.c_void_p(det_out.ptr),
+                                                 C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)), 'wbx_det_spectrum_folded')
+    elif rps is None:
       _hip.check(ctx.lib.wbx_det_spectrum(ctx.handle, C.byref(dplan.struct), func, dtype_code, ptr(devs[0]), ptr(devs[1]),
                                           ptr(devs[2]) if nin > 2 else None, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr),
                                           int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr), C.c_void_p(pw_t.ptr)),
@@ -635,20 +680,24 @@ def _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
                                                 ptr(devs[2]) if nin > 2 else None, int(rps), C.c_void_p(bufs[0].ptr),
                                                 C.c_void_p(bufs[1].ptr), int(ngroup), C.c_void_p(out.ptr), C.c_void_p(pw_p.ptr),
                                                 C.c_void_p(pw_t.ptr)), 'wbx_det_spectrum_slabs')
-  timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func), slab_rows=int(rps or 0))
+  timed_launch(ctx, call, kind='det_spectrum', rows=int(plan.nkey), func=int(func), slab_rows=int(rps or 0), folded=bool(folded))
   for da, buf in ((req['p'], pw_p), (req['t'], pw_t)):
     # (the buffer object rides along: it is released -- stream ordered behind its consumer -- when the entry is dropped)
     da.__dict__['_wbx_fused_spectrum'] = {'ctx': ctx, 'ptr': buf.ptr, 'buf': buf, 'ngroup': ngroup, 'cache': entry['dev']}
     _fusion_parks.append(da)
-  return True
+  return _FoldedS2((det_out.ptr, det_shape)) if folded else out
 
 
 def _run_s1(ctx, kind: str, dplan: _PlanOnDevice, plan: planner.S1Plan, devs: Sequence[_Dev | None], dtype_code: int,
-            nlanes_total: int, func: int = 0, ens=None, cat=None, inputs=None) -> _hip.DeviceBuffer:
+            nlanes_total: int, func: int = 0, ens=None, cat=None, inputs=None, fold=None):
+  """-> the stage-1 partial's device buffer, or a `_FoldedS2` when the launch has done stage 2 as well (`fold`: see
+  _try_det_spectra)."""
   n = int(np.prod(plan.partial_shape(nlanes_total), dtype=np.int64))
+  if kind == 'det' and _fusion_requests:
+    hit = _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, lambda: _scratch(ctx, 'partial', n * 8), fold)
+    if hit is not False:
+      return hit  # the partial's buffer, or a _FoldedS2
   out = _scratch(ctx, 'partial', n * 8)
-  if kind == 'det' and _fusion_requests and _try_det_spectra(ctx, inputs, dplan, plan, devs, dtype_code, func, out):
-    return out
   ptr = lambda d: C.c_void_p(d.ptr) if d is not None else None
 
   def call():  # idempotent: a repetition overwrites the same partial buffer
@@ -1466,8 +1515,10 @@ def reduce_statistics(kind: str, inputs: Sequence[xr.DataArray | None], dims: Se
   elif _binned_eligible(kind, plan, w_buf, devs, nl_total, _hip.DET_INPUTS[func] if kind == 'det' else 2):
     res = _run_binned(ctx, dplan, plan, devs, dtype_code, nl_total, func, w_buf)
   else:
-    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args, inputs=inputs)
-    res = _run_s2(ctx, s2, partial.ptr, w_buf)  # [nA][nBk][lanes][nj_out][nbin]
+    partial = _run_s1(ctx, kind, dplan, plan, devs, dtype_code, nl_total, func=func, ens=ens_args, cat=cat_args, inputs=inputs,
+                      fold=(s2, w_da, bin_dims, w_buf))
+    # [nA][nBk][lanes][nj_out][nbin]
+    res = partial.res if isinstance(partial, _FoldedS2) else _run_s2(ctx, s2, partial.ptr, w_buf)
   out = _deliver(ctx, *res)
 
   x_out = (plan.x_dim,) if (plan.x_kept and not plan.sum_j and plan.x_dim is not None) else ()
