@@ -415,7 +415,9 @@ _IN_LOOP = [0]  # > 0: inside pipeline._consume (launches of a replayed chunk fo
 # ---- the hooks of metrics/base.py and pipeline.py ---------------------------------------------------------------------------
 def cached(climatology, slots: int | None = None, pool_bytes: int | None = None, device_layout: str | None = None, threads: int = 4):
   """A Dataset / mapping / DataArray of host climatologies with a slab cache on every variable (explicit form of what
-  `cache_for` does by itself for memory maps and large arrays).  Returns its argument."""
+  `cache_for` does by itself for memory maps and large arrays).  Returns its argument.  Call it on the object the metrics are
+  given (`ACC(cached(ds, slots=48))`): the wish is kept on the DataArray OBJECTS, and a Dataset built from DataArrays afterwards
+  holds objects of its own."""
   arrays = [climatology] if isinstance(climatology, xr.DataArray) else [climatology[k] for k in climatology.keys()]
   for da in arrays:
     da = xr.as_dataarray(da)
