@@ -152,8 +152,21 @@ class Env:
     self.comm = None
     self.collective = pick_collective(self.world, args.backend, os.environ)
     if self.collective == COLLECTIVE_CABI:
+      # (a failure to bind RCCL -- no librccl.so.1 to dlopen, a symbol missing -- is the same on every rank of a node; the ranks
+      #  still agree on the outcome through the torch group before anybody takes a path the others do not)
       from weatherbenchx_amd import distributed
-      self.comm = distributed.CabiCommunicator.from_torch_group()
+      why = None
+      try:
+        self.comm = distributed.CabiCommunicator.from_torch_group()
+      except Exception as e:  # pylint: disable=broad-except
+        why = f'{type(e).__name__}: {e}'
+      ok = torch.tensor([0 if why else 1], device=self.dev, dtype=torch.int32)
+      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+      if int(ok.item()) == 0:
+        if self.comm is not None:
+          self.comm.close()
+        self.comm = None
+        self.collective = 'torch.distributed ' + args.backend + f' (the library\'s communicator could not be created on every rank: {why or "another rank"})'
     self.nlat, self.nlon = (721, 1440) if not args.small else (73, 144)
     self.lat = np.linspace(-90, 90, self.nlat)
     self.lon = np.linspace(0, 360, self.nlon, endpoint=False)
