@@ -268,3 +268,174 @@ def test_zarr_reader_edges(tmp_path):
     loaders.ZarrArray(p2)
   with pytest.raises(FileNotFoundError):
     loaders.ZarrArray(str(tmp_path))
+
+
+def _write_baselines(tmp_path, fmt, nlat=19, nlon=36):
+  """A [dayofyear, hour, level, lon, lat] climatology and a 6-hourly analysis series around new year 2020/21 (a leap year:
+  day 366 is used), as .npy / NetCDF / zarr."""
+  rng = np.random.default_rng(11)
+  nlev, nhour = 2, 4
+  clim = (rng.normal(size=(366, nhour, nlev, nlon, nlat)) + 270).astype(np.float32)
+  times = np.datetime64('2020-12-29T00', 'ns') + np.arange(28) * np.timedelta64(6, 'h')
+  tv = (rng.normal(size=(times.size, nlev, nlon, nlat)) + 270).astype(np.float32)
+  lat, lon, level = np.linspace(-90, 90, nlat), np.arange(nlon) * (360.0 / nlon), np.array([500, 850])
+  dims, coords = ('level', 'longitude', 'latitude'), {'level': level, 'longitude': lon, 'latitude': lat}
+  if fmt == 'npy':
+    cp, tp = os.path.join(tmp_path, 'c.npy'), os.path.join(tmp_path, 't.npy')
+    np.save(cp, clim)
+    np.save(tp, tv)
+    src_c, src_t = {'z': cp}, {'z': tp}
+  elif fmt == 'zarr':
+    cp, tp = os.path.join(tmp_path, 'c.zarr'), os.path.join(tmp_path, 't.zarr')
+    _write_zarr(os.path.join(cp, 'z'), clim, (1, 1, nlev, nlon, nlat), {'id': 'zlib', 'level': 1}, '.', dtype='<f4')
+    _write_zarr(os.path.join(tp, 'z'), tv, (1, nlev, nlon, 7), None, '.', dtype='<f4')
+    src_c, src_t = {'z': (cp, 'z')}, {'z': (tp, 'z')}
+  else:
+    from scipy.io import netcdf_file
+    cp, tp = os.path.join(tmp_path, 'c.nc'), os.path.join(tmp_path, 't.nc')
+    for path, arr, names in ((cp, clim, ('dayofyear', 'hour') + dims), (tp, tv, ('time',) + dims)):
+      f = netcdf_file(path, 'w', version=2)
+      for n, s in zip(names, arr.shape):
+        f.createDimension(n, s)
+      v = f.createVariable('z', np.float32, names)
+      v[:] = arr
+      f.close()
+    src_c, src_t = {'z': (cp, 'z')}, {'z': (tp, 'z')}
+  return src_c, src_t, times, dims, coords, clim, tv
+
+
+def _doy_hour(valid):
+  day = valid.astype('datetime64[D]')
+  return (day - valid.astype('datetime64[Y]').astype('datetime64[D]')).astype(int), (valid - day).astype('timedelta64[h]').astype(int) // 6
+
+
+@pytest.mark.parametrize('fmt', ['npy', 'nc', 'zarr'])
+@pytest.mark.parametrize('layout', [None, 'lon_fastest'])
+def test_climatology_and_persistence_read_as_predictions(tmp_path, fmt, layout):
+  """ClimatologyFromXarray / PersistenceFromXarray (xarray_loaders.py:266-337; their tests xarray_loaders_test.py:60-112):
+  frames, values at dayofyear / hour of the valid time across a leap-year end, the reference's refusals."""
+  src_c, src_t, times, dims, coords, clim, tv = _write_baselines(str(tmp_path), fmt)
+  kw = dict(pinned=False, device_layout=layout)
+  lc = loaders.ClimatologyFromFiles(src_c, dims, coords, **kw)
+  lp = loaders.PersistenceFromFiles(src_t, times, dims, coords, **kw)
+  out_dims = dims if layout is None else ('level', 'latitude', 'longitude')
+  swap = (lambda a: a) if layout is None else (lambda a: np.swapaxes(a, -1, -2))
+  init_times = np.array(['2020-12-30T12', '2020-12-29T00', '2020-12-31T18'], dtype='datetime64[ns]')
+  lead_times = np.array([0, 18, 48], dtype='timedelta64[h]').astype('timedelta64[ns]')
+  c = lc.load_chunk(init_times, lead_times)['z']
+  assert c.dims == ('init_time', 'lead_time') + out_dims
+  valid = init_times[:, None] + lead_times[None, :]
+  d, h = _doy_hour(valid)
+  assert d.max() == 365 and d.min() == 0            # 2020-12-31 is day 366; 2021-01-01 wraps to day 1
+  np.testing.assert_array_equal(c.values, swap(clim[d, h]))
+  np.testing.assert_array_equal(c.coords['dayofyear'].values, d + 1)
+  np.testing.assert_array_equal(c.coords['hour'].values, h * 6)
+  np.testing.assert_array_equal(c['lead_time'].values, lead_times)
+  # no lead times: the init times are the valid times
+  c0 = lc.load_chunk(init_times)['z']
+  assert c0.dims == ('init_time',) + out_dims
+  d0, h0 = _doy_hour(init_times)
+  np.testing.assert_array_equal(c0.values, swap(clim[d0, h0]))
+  with pytest.raises(ValueError, match='Lead time slice not yet supported for climatology data loaders'):
+    lc.load_chunk(init_times, slice(None))
+  with pytest.raises(KeyError):  # 03 UTC is not one of the climatology's hours
+    lc.load_chunk(np.array(['2020-12-30T03'], dtype='datetime64[ns]'))
+
+  p = lp.load_chunk(init_times, lead_times)['z']
+  assert p.dims == ('init_time', 'lead_time') + out_dims
+  ti = ((init_times - times[0]) // np.timedelta64(6, 'h')).astype(int)
+  for b in range(lead_times.size):
+    np.testing.assert_array_equal(p.values[:, b], swap(tv[ti]))
+  np.testing.assert_array_equal(p['init_time'].values, init_times)
+  for bad in (None, slice(None)):
+    with pytest.raises(ValueError, match='Exact lead times must be specified for persistence data loader'):
+      lp.load_chunk(init_times, bad)
+  one = lp.load_chunk(init_times[:1], lead_times[:1])['z']
+  np.testing.assert_array_equal(one.values[0, 0], swap(tv[ti[0]]))
+
+
+def test_daily_climatology_without_an_hour_axis(tmp_path):
+  rng = np.random.default_rng(2)
+  clim = rng.normal(size=(366, 3, 8)).astype(np.float32)
+  path = os.path.join(str(tmp_path), 'c.npy')
+  np.save(path, clim)
+  lc = loaders.ClimatologyFromFiles({'t': path}, ('longitude', 'latitude'), {'longitude': np.arange(3.0), 'latitude': np.arange(8.0)},
+                                    hours=False, pinned=False)
+  init = np.array(['2021-03-01T06', '2020-03-01T18'], dtype='datetime64[ns]')
+  c = lc.load_chunk(init, np.array([0, 24], dtype='timedelta64[h]'))['t']
+  np.testing.assert_array_equal(c.values[:, :, ...], clim[np.array([[59, 60], [60, 61]])])  # 1 Mar = day 60 (2021) / 61 (2020)
+  assert 'hour' not in c.coords
+  with pytest.raises(ValueError, match='climatology file holds'):
+    loaders.ClimatologyFromFiles({'t': path}, ('longitude', 'latitude'), {}, pinned=False).load_chunk(init)
+
+
+def test_climatology_and_persistence_baselines_scored_against_the_oracle(backend, tmp_path):
+  """The two baselines of the reference's evaluation scripts as PREDICTIONS of a chunked evaluation, against the oracle on
+  the whole arrays."""
+  src_c, src_t, times, dims, coords, clim, tv = _write_baselines(str(tmp_path), 'npy')
+  pinned = backend == 'hip'
+  lt = loaders.TargetsFromFiles(src_t, times, dims, coords, pinned=pinned)
+  init_times = times[:8:2]
+  lead_times = np.array([0, 12, 36], dtype='timedelta64[h]').astype('timedelta64[ns]')
+  valid = init_times[:, None] + lead_times[None, :]
+  vi = ((valid - times[0]) // np.timedelta64(6, 'h')).astype(int)
+  d, h = _doy_hour(valid)
+  ii = ((init_times - times[0]) // np.timedelta64(6, 'h')).astype(int)
+  truth = tv[vi]
+  fdims = ('init_time', 'lead_time') + dims
+  w = (O.grid_area_weights(coords['latitude']), ('latitude',))
+  metrics = {'rmse': deterministic.RMSE(), 'mae': deterministic.MAE()}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=3, lead_time_chunk_size=2)
+  for loader, pred in ((loaders.ClimatologyFromFiles(src_c, dims, coords, pinned=pinned), clim[d, h]),
+                       (loaders.PersistenceFromFiles(src_t, times, dims, coords, pinned=pinned),
+                        np.broadcast_to(tv[ii][:, None], truth.shape))):
+    got = pipeline.evaluate_chunks(tc, loaders.load_chunk_fn(loader, lt), metrics, agg)[None].metric_values(metrics)
+    for name, lane in (('rmse', O.squared_error(pred, truth)), ('mae', O.absolute_error(pred, truth))):
+      sws, sw, od = O.aggregate(lane, fdims, ['init_time', 'latitude', 'longitude'], weights=[w])
+      want = np.sqrt(sws / sw) if name == 'rmse' else sws / sw
+      np.testing.assert_allclose(np.asarray(got[f'{name}.z'].transpose(*od).values), want, rtol=RTOL, err_msg=f'{type(loader).__name__} {name}')
+
+
+def test_years_as_ensemble_members_scored_with_crps(backend, tmp_path):
+  """ProbabilisticClimatologyFromXarray (xarray_loaders.py:340-409; its test xarray_loaders_test.py:114-141): members are the
+  same dayofyear / hour of 2015..2019, day 366 of a non-leap year is 1 January of the next; CRPS of that ensemble through a
+  chunked evaluation against the oracle."""
+  from weatherbenchx_amd.metrics import probabilistic
+  rng = np.random.default_rng(4)
+  nlon, nlat = 12, 7
+  times = np.arange('2015-01-01T00', '2021-01-03T00', np.timedelta64(12, 'h'), dtype='datetime64[ns]')
+  tv = (rng.normal(size=(times.size, nlon, nlat)) + 280).astype(np.float32)
+  path = os.path.join(str(tmp_path), 't.npy')
+  np.save(path, tv)
+  dims = ('longitude', 'latitude')
+  coords = {'longitude': np.arange(nlon) * 30.0, 'latitude': np.linspace(-90, 90, nlat)}
+  pinned = backend == 'hip'
+  lp = loaders.ProbabilisticClimatologyFromFiles({'t2m': path}, times, dims, coords, start_year=2015, end_year=2019, pinned=pinned)
+  lt = loaders.TargetsFromFiles({'t2m': path}, times, dims, coords, pinned=pinned)
+  init_times = np.arange('2020-12-30T00', '2021-01-01T00', np.timedelta64(24, 'h'), dtype='datetime64[ns]')
+  lead_times = np.arange(0, 3, 1, dtype='timedelta64[D]').astype('timedelta64[ns]')
+  chunk = lp.load_chunk(init_times, lead_times)['t2m']
+  assert chunk.dims == ('number', 'init_time', 'lead_time') + dims and chunk.sizes['number'] == 5
+  # the restatement: valid time -> (dayofyear, hour) -> that offset from 1 January of each year
+  valid = init_times[:, None] + lead_times[None, :]
+  doy0, _ = _doy_hour(valid)
+  members = np.stack([np.datetime64(str(y), 'ns') + doy0 * np.timedelta64(24, 'h') for y in range(2015, 2020)])
+  assert members[0, 1, 0] == np.datetime64('2016-01-01')       # 2020-12-31 = day 366 -> 2015 has none
+  assert members[1, 1, 0] == np.datetime64('2016-12-31')       # ... 2016 has
+  np.testing.assert_array_equal(chunk.coords['valid_time'].values, members)
+  pv = tv[((members - times[0]) // np.timedelta64(12, 'h')).astype(int)]
+  np.testing.assert_array_equal(chunk.values, pv)
+  with pytest.raises(ValueError, match='Exact lead times'):
+    lp.load_chunk(init_times, None)
+
+  truth = tv[((valid - times[0]) // np.timedelta64(12, 'h')).astype(int)]
+  metrics = {'crps': probabilistic.CRPSEnsemble(ensemble_dim='number')}
+  agg = aggregation.Aggregator(reduce_dims=['init_time', 'latitude', 'longitude'], weigh_by=[weighting.GridAreaWeighting()])
+  tc = time_chunks.TimeChunks(init_times, lead_times, init_time_chunk_size=1, lead_time_chunk_size=2)
+  got = pipeline.evaluate_chunks(tc, loaders.load_chunk_fn(lp, lt), metrics, agg)[None].metric_values(metrics)
+  pdims, tdims = ('number', 'init_time', 'lead_time') + dims, ('init_time', 'lead_time') + dims
+  w = (O.grid_area_weights(coords['latitude']), ('latitude',))
+  sk = O.aggregate(O.crps_skill(pv, pdims, truth, tdims, 'number')[0], tdims, ['init_time', 'latitude', 'longitude'], weights=[w])
+  sp = O.aggregate(O.crps_spread(pv, pdims, 'number')[0], tdims, ['init_time', 'latitude', 'longitude'], weights=[w])
+  np.testing.assert_allclose(np.asarray(got['crps.t2m'].values), O.crps(sk[0] / sk[1], sp[0] / sp[1]), rtol=RTOL)

@@ -6,7 +6,12 @@ A loader maps (init_times, lead_times) to {variable: DataArray} exactly like the
                             (PredictionsFromXarray, xarray_loaders.py:176-221);
   * `TargetsFromFiles`      fields indexed by ONE time axis: the chunk is gathered at valid_time = init_time + lead_time and
                             carries init_time / lead_time dims plus a 2-D `valid_time` coordinate
-                            (TargetsFromXarray, xarray_loaders.py:224-316).
+                            (TargetsFromXarray, xarray_loaders.py:224-264);
+  * `ClimatologyFromFiles`  a [dayofyear, hour, ...] climatology read as predictions at the valid times' dayofyear / hour
+                            (ClimatologyFromXarray, xarray_loaders.py:266-316);
+  * `PersistenceFromFiles`  the analysis at init_time repeated along lead_time (PersistenceFromXarray, :319-337);
+  * `ProbabilisticClimatologyFromFiles`  the same dayofyear / hour of `start_year..end_year` as ensemble members
+                            (ProbabilisticClimatologyFromXarray, :340-409).
 Storage: `.npy` files (numpy memory maps), NetCDF-3 (scipy.io.netcdf_file with mmap, the format io.py writes) or zarr v2
 array directories (`ZarrArray`: read without the zarr package; uncompressed or zlib / gzip / bz2 / lzma chunks).  A chunk is
 read -- decoded, if the file is big-endian -- STRAIGHT into page-locked memory (`pipeline.pinned_empty`), so the feeder's
@@ -372,6 +377,142 @@ class TargetsFromFiles(FileLoader):
       coords = {k: v for k, v in dict(self._coords, init_time=init_times, lead_time=lead_times).items() if k in ('init_time', 'lead_time') + self._dims}
       da = xr.DataArray(buf, dims=('init_time', 'lead_time') + self._dims, coords=coords, name=name)
       out[name] = da.assign_coords(valid_time=xr.DataArray(valid, dims=('init_time', 'lead_time')))
+    return self._finish(out)
+
+
+class ClimatologyFromFiles(FileLoader):
+  """A climatology stored [dayofyear, hour, *dims] (or [dayofyear, *dims] with `hours=False`) read as PREDICTIONS: the chunk
+  of (init_times, lead_times) holds the climatology at dayofyear / hour of valid_time = init_time + lead_time, dims
+  (init_time, lead_time, *dims) plus the 2-D `dayofyear` / `hour` coordinates the reference's vectorised `.sel` leaves --
+  `ClimatologyFromXarray` (xarray_loaders.py:266-316).  Without lead times the init times are the valid times; a lead-time
+  slice raises like the reference.  `dayofyear` / `hours`: the labels of the two leading axes (default 1..n and the
+  24/n-hourly hours of the day)."""
+
+  def __init__(self, sources, dims, coords, *, dayofyear=None, hours=None, **kw):
+    super().__init__(sources, dims, coords, **kw)
+    self._dayofyear = None if dayofyear is None else np.asarray(dayofyear)
+    self._has_hour = hours is not False
+    self._hours = None if hours is None or hours is False else np.asarray(hours)
+
+  def _axes(self, arr):
+    lead_axes = 2 if self._has_hour else 1
+    if arr.ndim != lead_axes + len(self._stored_dims):
+      raise ValueError(f'a climatology file holds [dayofyear, {"hour, " if self._has_hour else ""}*dims]: found {arr.ndim} axes for dims '
+                       f'{self._stored_dims}')
+    doy = self._dayofyear if self._dayofyear is not None else np.arange(1, arr.shape[0] + 1)
+    if not self._has_hour:
+      return doy, None
+    if self._hours is not None:
+      return doy, self._hours
+    if 24 % arr.shape[1]:
+      raise ValueError(f'{arr.shape[1]} hours of the day do not divide 24: pass hours=')
+    return doy, np.arange(arr.shape[1]) * (24 // arr.shape[1])
+
+  def load_chunk(self, init_times, lead_times=None):
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    if isinstance(lead_times, slice):
+      raise ValueError('Lead time slice not yet supported for climatology data loaders.')  # xarray_loaders.py:305-308
+    if lead_times is None:  # the init times ARE the valid times (xarray_loaders.py:309-314)
+      lead, valid = None, init_times
+      tdims, tshape = ('init_time',), (init_times.size,)
+    else:
+      lead = np.asarray(lead_times, dtype='timedelta64[ns]')
+      valid = (init_times[:, None] + lead[None, :]).reshape(-1)
+      tdims, tshape = ('init_time', 'lead_time'), (init_times.size, lead.size)
+    day = valid.astype('datetime64[D]')
+    doy_of = (day - valid.astype('datetime64[Y]').astype('datetime64[D]')).astype(np.int64) + 1
+    hour_of = (valid - day).astype('timedelta64[h]').astype(np.int64)
+    tcoords = {'init_time': init_times}
+    if lead is not None:
+      tcoords['lead_time'] = lead
+    out = {}
+    for name, src in self._sources.items():
+      arr = src.array()
+      doy, hours = self._axes(arr)
+      di = _positions(doy, doy_of, 'dayofyear')
+      item = self._out_shape(arr.shape[1 if hours is None else 2:])
+      buf = self._buffer(tshape + item, np.dtype(arr.dtype).newbyteorder('='))
+      flat = buf.reshape((valid.size,) + item)
+      if hours is None:
+        self._gather(arr, di, flat)
+      else:
+        hi = _positions(hours, hour_of, 'hour')
+        # one day's hours are adjacent on disk: gather each day's run of valid times in one call
+        order = np.argsort(di, kind='stable')
+        if np.array_equal(order, np.arange(order.size)):  # (the common case: valid times ascending within a year)
+          cuts = np.r_[0, np.nonzero(np.diff(di))[0] + 1, di.size]
+          for lo, up in zip(cuts[:-1], cuts[1:]):
+            self._gather(arr[int(di[lo])], hi[lo:up], flat[lo:up])
+        else:
+          for a in range(valid.size):
+            self._gather(arr[int(di[a])], hi[a:a + 1], flat[a:a + 1])
+      coords = {k: v for k, v in dict(self._coords, **tcoords).items() if k in tdims + self._dims}
+      da = xr.DataArray(buf, dims=tdims + self._dims, coords=coords, name=name)
+      extra = {'dayofyear': xr.DataArray(doy_of.reshape(tshape), dims=tdims)}
+      if hours is not None:
+        extra['hour'] = xr.DataArray(hour_of.reshape(tshape), dims=tdims)
+      out[name] = da.assign_coords(extra)
+    return self._finish(out)
+
+
+class PersistenceFromFiles(TargetsFromFiles):
+  """Analysis fields stored [time, *dims] read as a PERSISTENCE forecast: the field at init_time repeated along lead_time
+  (`PersistenceFromXarray`, xarray_loaders.py:319-337).  Exact lead times are required."""
+
+  def load_chunk(self, init_times, lead_times=None):
+    if lead_times is None or isinstance(lead_times, slice):
+      raise ValueError('Exact lead times must be specified for persistence data loader.')  # xarray_loaders.py:330-333
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    lead = np.asarray(lead_times, dtype='timedelta64[ns]')
+    ti = _positions(self._times, init_times, 'valid_time')
+    out = {}
+    for name, src in self._sources.items():
+      arr = src.array()
+      item = self._out_shape(arr.shape[1:])
+      buf = self._buffer((init_times.size, lead.size) + item, np.dtype(arr.dtype).newbyteorder('='))
+      if lead.size:
+        first = np.empty((init_times.size,) + item, buf.dtype) if lead.size > 1 else buf[:, 0]
+        self._gather(arr, ti, first)  # read (and transposed) once ...
+        buf[...] = first[:, None]     # ... then repeated along lead_time in page-locked memory
+      coords = {k: v for k, v in dict(self._coords, init_time=init_times, lead_time=lead).items() if k in ('init_time', 'lead_time') + self._dims}
+      out[name] = xr.DataArray(buf, dims=('init_time', 'lead_time') + self._dims, coords=coords, name=name)
+    return self._finish(out)
+
+
+class ProbabilisticClimatologyFromFiles(TargetsFromFiles):
+  """Analysis fields stored [time, *dims] read as an ENSEMBLE forecast whose members are the years `start_year..end_year`
+  (inclusive): member m at (init, lead) is the field at the valid time's dayofyear / hour in year start_year + m; day 366
+  in a non-leap year is 1 January of the next (`ProbabilisticClimatologyFromXarray`, xarray_loaders.py:340-409).  Dims
+  (ensemble_dim, init_time, lead_time, *dims) as the reference's vectorised `.sel` orders them, with its 3-D `valid_time`
+  coordinate.  Exact lead times are required."""
+
+  def __init__(self, sources, times, dims, coords, *, start_year: int, end_year: int, ensemble_dim: str = 'number', **kw):
+    super().__init__(sources, times, dims, coords, **kw)
+    self._years = np.arange(int(start_year), int(end_year) + 1)
+    self._ensemble_dim = ensemble_dim
+
+  def load_chunk(self, init_times, lead_times=None):
+    if lead_times is None or isinstance(lead_times, slice):
+      raise ValueError('Exact lead times must be specified for persistence data loader.')  # (sic) xarray_loaders.py:381-384
+    init_times = np.asarray(init_times, dtype='datetime64[ns]')
+    lead = np.asarray(lead_times, dtype='timedelta64[ns]')
+    valid = init_times[:, None] + lead[None, :]
+    day = valid.astype('datetime64[D]')
+    doy0 = (day - valid.astype('datetime64[Y]').astype('datetime64[D]')).astype(np.int64)
+    hod = (valid - day).astype('timedelta64[h]').astype(np.int64)
+    starts = np.array([np.datetime64(str(y)) for y in self._years], dtype='datetime64[ns]')
+    member_times = starts[:, None, None] + ((doy0 * 24 + hod) * np.timedelta64(1, 'h').astype('timedelta64[ns]'))[None]
+    ti = _positions(self._times, member_times.reshape(-1), 'valid_time')
+    tdims = (self._ensemble_dim, 'init_time', 'lead_time')
+    out = {}
+    for name, src in self._sources.items():
+      arr = src.array()
+      item = self._out_shape(arr.shape[1:])
+      buf = self._buffer(member_times.shape + item, np.dtype(arr.dtype).newbyteorder('='))
+      self._gather(arr, ti, buf.reshape((ti.size,) + item))
+      coords = dict(self._coords, init_time=init_times, lead_time=lead, **{self._ensemble_dim: np.arange(self._years.size)})
+      da = xr.DataArray(buf, dims=tdims + self._dims, coords={k: v for k, v in coords.items() if k in tdims + self._dims}, name=name)
+      out[name] = da.assign_coords(valid_time=xr.DataArray(member_times, dims=tdims))
     return self._finish(out)
 
 
