@@ -62,6 +62,22 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   return (const char*)(((uint64_t)hi << 32) | lo);
 }
 
+// a pointer that went through an opaque asm statement or an integer has lost its address space: say "global" again, or the
+// loads come out as flat_load (which also counts on lgkmcnt)
+template <typename T>
+using global_ptr = const __attribute__((address_space(1))) T*;
+
+// read-only tables (the plan's offset tables, the row weights) addressed with wave-uniform indices: through the constant
+// address space these are scalar loads (s_load, SGPR results, counted on lgkmcnt) -- plain global loads are vector loads even
+// when every lane asks for the same element
+template <typename T>
+using const_ptr = const __attribute__((address_space(4))) T*;
+
+// what a NULL table stands for (all zeros / all ones): selecting one of these instead of branching around a load keeps the
+// row lookups of the sweep free of control flow (the compiler waits for outstanding scalar loads wherever two paths join)
+static __constant__ int64_t wbx_zero_i64[1] = {0};
+static __constant__ double wbx_one_f64[1] = {1.0};
+
 // Broadcast of lane j's 64-bit value to the whole wave (result in SGPRs).
 __device__ __forceinline__ int64_t readlane64(int64_t v, int j) {
   const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, j);

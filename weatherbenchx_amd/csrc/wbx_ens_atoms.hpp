@@ -58,21 +58,7 @@ constexpr int ENS_ATOMS_ROWS2 = 2 * ATOM_MAX;  // table rows per patch: an atom 
 #define WBX_ENS_ATOMS_ROWS 16  // rows (= 64-point tiles) per patch; WBX_ENS_ATOMS_ROWS in the environment overrides
 #endif
 
-// a pointer that went through an opaque asm statement or an integer has lost its address space: say "global" again, or the
-// loads come out as flat_load (which also counts on lgkmcnt)
-template <typename T>
-using global_ptr = const __attribute__((address_space(1))) T*;
-
-// read-only tables (the plan's offset tables, the row weights) addressed with wave-uniform indices: through the constant
-// address space these are scalar loads (s_load, SGPR results, counted on lgkmcnt) -- plain global loads are vector loads even
-// when every lane asks for the same element
-template <typename T>
-using const_ptr = const __attribute__((address_space(4))) T*;
-
-// what a NULL table stands for (all zeros / all ones): selecting one of these instead of branching around a load keeps the
-// row lookups of the sweep free of control flow (the compiler waits for outstanding scalar loads wherever two paths join)
-static __constant__ int64_t wbx_zero_i64[1] = {0};
-static __constant__ double wbx_one_f64[1] = {1.0};
+// (global_ptr / const_ptr and the stand-in tables wbx_zero_i64 / wbx_one_f64: wbx_common.hpp)
 
 // The sum over a cell's patches happens INSIDE the kernel, in three levels, each done by whichever wave finishes last:
 //   level 1: the last wave of a group of G1 consecutive patches expands the group's atom tables to bins -> part1[cell][group]

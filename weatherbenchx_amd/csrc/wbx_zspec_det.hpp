@@ -56,6 +56,9 @@ constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
                              // fp32 ones and the kernel gains < 1 %: its vector ALU is not what bounds it.  Not adopted (the fp64
                              // lanes equal wbx_det_partial's bit for bit, tests/test_gpu_round3.py).
 #endif
+#ifndef WBX_ZD_FLAT_LOADS
+#define WBX_ZD_FLAT_LOADS 0  // 1: the rows through generic pointers = flat_load, what the kernel did up to round 6 (A/B: make ab-zdflat)
+#endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
 #endif
@@ -131,30 +134,80 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   v2 pa[12], pb[12];  // the row's p and t values of this lane's 12 packed points, fetched one row ahead (c: through cbuf)
   v2 pc[WBX_ZD_C_IN_REGISTERS ? 12 : 1];
   const uint32_t voff_c = (uint32_t)L * 8u;  // this lane's first packed point, bytes into the row
-  // A row's three base pointers come out of the plan's offset / gather tables.  They are resolved one row ahead at the TOP of a
-  // row -- where few registers are live -- and parked in SGPR pairs: the asm statements below clobber memory, so the table
-  // lookups are vector loads, and resolving them inside fetch() (in the middle of the transform, at the register peak) made the
-  // allocator spill ten of the 24 prefetch loads right behind a full vmcnt(0) wait each.
-  auto resolve = [&](int64_t r, const char*& up, const char*& ut, const char*& uc) {
-    int64_t kb[WBX_MAX_INPUTS], ro[WBX_MAX_INPUTS];
-    key_bases<HAS_C ? 3 : 2>(a, r, kb);
-    row_bases<HAS_C ? 3 : 2>(a, kb, r, 0, ro);
-    up = uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[0]) + ro[0]));
-    ut = uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[1]) + ro[1]));
-    uc = HAS_C ? uniform_ptr(reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[2]) + ro[2])) : nullptr;
+  // A row's three base pointers come out of the plan's offset / gather tables, one row ahead.
+  // (r6) Through the CONSTANT address space: scalar loads with SGPR results.  Up to round 6 `resolve` went through the generic
+  // helpers (key_bases / row_bases): behind the asm statements' memory clobbers those are VECTOR loads, and the compiler had
+  // laid them out as four dependent round trips at the top of every row -- six table entries, `s_waitcnt vmcnt(0)`, gk[row],
+  // wait, gd[0], wait, gtab[..], wait -- each an L2 latency that the one other wave of the SIMD cannot cover.  Now: the
+  // entries that do not depend on the row (depth_off[i][0], gd[0]) are read once; `lookup` issues the row's four scalar loads
+  // at the TOP of the previous row and `pointers` consumes them behind its deterministic lanes (~300 instructions later), where
+  // it issues the one dependent load (the climatology's gather table, a few hundred hot bytes), consumed behind pass 1.
+  // NULL tables are stood in for by a one-element table of zeros (index mask 0): no control flow around a load.
+  constexpr int NIN = HAS_C ? 3 : 2;
+  const const_ptr<int64_t> zero64 = (const_ptr<int64_t>)wbx_zero_i64;
+  const_ptr<int64_t> tk[NIN];
+  int64_t mk[NIN], dep[NIN];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    tk[i] = a.key_off[i] ? (const_ptr<int64_t>)a.key_off[i] : zero64;
+    mk[i] = a.key_off[i] ? -1 : 0;
+    dep[i] = a.depth_off[i] ? ((const_ptr<int64_t>)a.depth_off[i])[0] : 0;
+  }
+  const bool has_g = HAS_C && a.gtab != nullptr;
+  const const_ptr<int32_t> tgk = (has_g && a.gk) ? (const_ptr<int32_t>)a.gk : (const_ptr<int32_t>)wbx_zero_i64;
+  const int64_t mgk = (has_g && a.gk) ? -1 : 0;
+  const const_ptr<int64_t> tg = has_g ? (const_ptr<int64_t>)a.gtab : zero64;
+  const int64_t mg = has_g ? -1 : 0;
+  const int64_t gd0 = (has_g && a.gd) ? (int64_t)((const_ptr<int32_t>)a.gd)[0] : 0;
+  int64_t kbn[NIN];    // the looked-up row's key offsets, as loaded
+  int32_t gkn = 0;     // ... its row of the gather table
+  int64_t gvn = 0;     // ... its gather-table entry (elements), as loaded: added where the climatology row is fetched
+  int32_t gn = 0;      // ... its group, scale and (FOLD) weight: the row's own scalars are loaded a row ahead as well, so that
+  double scn = 0.0;    //     nothing at the top of a row waits for a scalar load
+  double dwn = 0.0;
+  const const_ptr<int32_t> tgroup = (const_ptr<int32_t>)group;
+  const const_ptr<double> tscale = (const_ptr<double>)scale;
+  const const_ptr<double> tdscale = FOLD ? (const_ptr<double>)dscale : (const_ptr<double>)wbx_one_f64;
+  auto lookup = [&](int64_t r) {
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) kbn[i] = tk[i][r & mk[i]];
+    if constexpr (HAS_C) gkn = tgk[r & mgk];
+    gn = tgroup[r];
+    scn = tscale[r];
+    if constexpr (FOLD) dwn = tdscale[r];
+  };
+  auto pointers = [&](const char*& up, const char*& ut, const char*& uc) {
+    up = reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[0]) + (kbn[0] + dep[0]));
+    ut = reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[1]) + (kbn[1] + dep[1]));
+    if constexpr (HAS_C) {
+      uc = reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[2]) + (kbn[2] + dep[2]));
+      gvn = tg[((int64_t)gkn * a.ngd + gd0) & mg];
+    } else {
+      uc = nullptr;
+    }
   };
   // The next row's loads are spread over the transform so that they never sit on top of its register peak (pass 2 holds 60
   // registers of butterflies): p and the climatology's LDS-DMA (no registers) behind pass 1's stores, t behind pass 2's.
+  // (r6) The row pointers went through integers (uniform_ptr) and lost their address space: as generic pointers the 36 loads
+  // of a row came out as flat_load -- issued to the LDS pipeline as well and counted on lgkmcnt, the counter every exchange of
+  // the transform waits on.  `gv2` says "global" again.
+#if WBX_ZD_FLAT_LOADS
+  using gv2 = const v2*;
+#else
+  using gv2 = const __attribute__((address_space(1))) v2*;
+#endif
   auto fetch_p = [&](const char* up, const char* uc) {
-    const v2* rowp = reinterpret_cast<const v2*>(up) + L;
+    // (the twelve loads of a row address it from its MIDDLE: offsets -2880 .. +2400 bytes all fit the instruction's 13-bit
+    // immediate, so a row is one SGPR base + one 32-bit lane offset; from its start the last three needed a 64-bit base of their own)
+    gv2 rowp = (gv2)(reinterpret_cast<const v2*>(up + 2880) + L);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) pa[i] = __builtin_nontemporal_load(rowp + 60 * i);
+    for (int i = 0; i < 12; ++i) pa[i] = __builtin_nontemporal_load(rowp + 60 * (i - 6));
     if constexpr (HAS_C && WBX_ZD_C_IN_REGISTERS) {
-      const v2* rowc = reinterpret_cast<const v2*>(uc) + L;
+      gv2 rowc = (gv2)(reinterpret_cast<const v2*>(reinterpret_cast<const char*>(reinterpret_cast<const float*>(uc) + gvn) + 2880) + L);
 #pragma unroll
-      for (int i = 0; i < 12; ++i) pc[i] = __builtin_nontemporal_load(rowc + 60 * i);
+      for (int i = 0; i < 12; ++i) pc[i] = __builtin_nontemporal_load(rowc + 60 * (i - 6));
     } else if constexpr (HAS_C) {
-      const char* um = uc;
+      const char* um = reinterpret_cast<const char*>(reinterpret_cast<const float*>(uc) + gvn);
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
 #pragma unroll
@@ -168,12 +221,13 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     }
   };
   auto fetch_t = [&](const char* ut) {
-    const v2* rowt = reinterpret_cast<const v2*>(ut) + L;
+    gv2 rowt = (gv2)(reinterpret_cast<const v2*>(ut + 2880) + L);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) pb[i] = __builtin_nontemporal_load(rowt + 60 * i);
+    for (int i = 0; i < 12; ++i) pb[i] = __builtin_nontemporal_load(rowt + 60 * (i - 6));
   };
   const char *np = nullptr, *nt = nullptr, *nc = nullptr;
-  resolve(r0, np, nt, nc);
+  lookup(r0);
+  pointers(np, nt, nc);
   fetch_p(np, nc);
   fetch_t(nt);
   int turn = team >> 2;  // waves t and t + 4 of a block share a SIMD: the user priority alternates row by row (see zspec1440_kernel)
@@ -181,9 +235,10 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     turn ^= 1;
     if (turn == 0) __builtin_amdgcn_s_setprio(0);
     else __builtin_amdgcn_s_setprio(1);
-    const int32_t g = group[r];
-    const double sc = scale[r] * quarter_inv_nn;
-    if ((WBX_ZD_KNOCK & 1) == 0 && r + 1 < r1) resolve(r + 1, np, nt, nc);
+    const int32_t g = gn;
+    const double sc = scn * quarter_inv_nn;
+    const double dw = dwn;
+    lookup(r + 1 < r1 ? r + 1 : r);  // (unconditional: the last row looks itself up again)
     if constexpr (HAS_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's LDS-DMA has landed in cbuf
     // ---- the deterministic lanes of this row, on the raw values (lanes 60..63 shadow lane 59: counted out)
     __builtin_amdgcn_sched_barrier(0);
@@ -265,7 +320,6 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     }
 #endif
     if constexpr (FOLD) {
-      const double dw = dscale[r];
       if (g != cur) flush(g);  // (the row belongs to the next record: close the running one first; wave-uniform)
 #pragma unroll
       for (int l = 0; l < NA; ++l) dsum[l] = fma(d[l], dw, dsum[l]);
@@ -283,19 +337,25 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     }
     }
     __builtin_amdgcn_sched_barrier(0);  // the row's deterministic sums are done before the transform starts: their temporaries die here
+    if constexpr ((WBX_ZD_KNOCK & 1) == 0) pointers(np, nt, nc);  // the next row's: `lookup`'s loads have had the lanes above to land
+    __builtin_amdgcn_sched_barrier(0);  // (or the gather table's load sinks to its use behind pass 1 and is waited for on the spot)
     C2 v[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) v[i] = {{pa[i].x, pb[i].x}, {pa[i].y, pb[i].y}};
     const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
     z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
-      if ((WBX_ZD_KNOCK & 4) == 0 && r + 1 < r1) {
+      // (r6) Unconditional: behind a team's last row the row is asked for once more (`lookup` clamps; 1 row in ~260, found in the
+      // L2 / Infinity Cache).  Under `r + 1 < r1` the loads sat in a block of their own: the compiler sank the gather-table
+      // load into it (issued and waited for on the spot) and, at 254 registers, joined the two paths with copies of three
+      // prefetched registers behind an `s_waitcnt vmcnt(0)` at the END of every row.
+      if constexpr ((WBX_ZD_KNOCK & 4) == 0) {
         if constexpr (WBX_ZD_FETCH_AT == 99) {  // spread: a fifth of the row's loads behind each of the first five exchanges
           if (i < 5) {
             constexpr int NLD = HAS_C ? 36 : 24;
-            const v2* rowp = reinterpret_cast<const v2*>(np) + L;
-            const v2* rowt = reinterpret_cast<const v2*>(nt) + L;
-            const v2* rowc = reinterpret_cast<const v2*>(nc) + L;
+            gv2 rowp = (gv2)(reinterpret_cast<const v2*>(np) + L);
+            gv2 rowt = (gv2)(reinterpret_cast<const v2*>(nt) + L);
+            gv2 rowc = (gv2)(reinterpret_cast<const v2*>(reinterpret_cast<const float*>(nc) + gvn) + L);
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
               if (j * 5 / NLD != i) continue;
