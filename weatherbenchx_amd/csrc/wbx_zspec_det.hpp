@@ -24,6 +24,10 @@
 //     per team, read back with ds_read2st64_b32; WBX_ZD_C_IN_REGISTERS = 0): 192 VGPRs, 1.98 ms -- twice the vector-memory
 //     instructions for the same bytes; kept as the A/B build (`make ab-zdlds`).
 //   * without a climatology (DET3): 190 VGPRs, 1.44-1.51 ms (the two spectra alone: 1.22-1.26 ms).
+//   * (r6) where the time went next: the kernel's time follows its vector-ALU time almost one to one at two waves per SIMD
+//     (knock-out 16: 144 fp64 instructions fewer per row = -10.4 %), and every row began with four dependent VECTOR-load round
+//     trips for its three base pointers.  Scalar lookups one row ahead + global instead of flat loads: 1.83 -> 1.68 ms (folded,
+//     5.0 -> 5.5 TB/s), 232 VGPRs (profiles/r06_det_spectrum_scalar_lookup_ab.txt).
 //
 // Rows = the keys of the deterministic plan (wbx_s1_plan with x = longitude summed, nx = 1440, unit x strides, ndepth = 1,
 // nchunk = 1), addressed through the plan's own offset / gather tables; `group` / `scale` are per key.
@@ -37,7 +41,7 @@
 #endif
 #ifndef WBX_ZD_KNOCK
 #define WBX_ZD_KNOCK 0  // timing diagnostics (WRONG results; make ab-zdk1 ...): 1 = every row re-reads the team's FIRST row (cache
-                        // hits, no HBM stream), 2 = no deterministic lanes, 4 = no loads after the first row, 8 = no wave sums / stores of the deterministic lanes
+                        // hits, no HBM stream), 2 = no deterministic lanes, 4 = no loads after the first row, 8 = no wave sums / stores of the deterministic lanes, 16 = the deterministic lanes over every other point pair
 #endif
 #ifndef WBX_ZD_FETCH_AT
 #define WBX_ZD_FETCH_AT 0  // 0: the next row's p (+ c) behind pass 1's stores, t behind pass 2's (72 registers live across the
@@ -162,9 +166,6 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   int64_t kbn[NIN];    // the looked-up row's key offsets, as loaded
   int32_t gkn = 0;     // ... its row of the gather table
   int64_t gvn = 0;     // ... its gather-table entry (elements), as loaded: added where the climatology row is fetched
-  int32_t gn = 0;      // ... its group, scale and (FOLD) weight: the row's own scalars are loaded a row ahead as well, so that
-  double scn = 0.0;    //     nothing at the top of a row waits for a scalar load
-  double dwn = 0.0;
   const const_ptr<int32_t> tgroup = (const_ptr<int32_t>)group;
   const const_ptr<double> tscale = (const_ptr<double>)scale;
   const const_ptr<double> tdscale = FOLD ? (const_ptr<double>)dscale : (const_ptr<double>)wbx_one_f64;
@@ -172,9 +173,6 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
 #pragma unroll
     for (int i = 0; i < NIN; ++i) kbn[i] = tk[i][r & mk[i]];
     if constexpr (HAS_C) gkn = tgk[r & mgk];
-    gn = tgroup[r];
-    scn = tscale[r];
-    if constexpr (FOLD) dwn = tdscale[r];
   };
   auto pointers = [&](const char*& up, const char*& ut, const char*& uc) {
     up = reinterpret_cast<const char*>(reinterpret_cast<const float*>(a.in[0]) + (kbn[0] + dep[0]));
@@ -235,18 +233,53 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     turn ^= 1;
     if (turn == 0) __builtin_amdgcn_s_setprio(0);
     else __builtin_amdgcn_s_setprio(1);
-    const int32_t g = gn;
-    const double sc = scn * quarter_inv_nn;
-    const double dw = dwn;
+    // (the row's own scalars; loading them a row ahead with the lookups measured the same -- 1.808 against 1.809-1.817 ms -- at
+    // 250 instead of 232 registers and with three prefetched registers copied behind an `s_waitcnt vmcnt(0)` at the row's end)
+    const int32_t g = tgroup[r];
+    const double sc = tscale[r] * quarter_inv_nn;
+    const double dw = FOLD ? tdscale[r] : 1.0;
     lookup(r + 1 < r1 ? r + 1 : r);  // (unconditional: the last row looks itself up again)
-    if constexpr (HAS_C) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's LDS-DMA has landed in cbuf
+    if constexpr (HAS_C && !WBX_ZD_C_IN_REGISTERS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row's LDS-DMA has landed in cbuf
     // ---- the deterministic lanes of this row, on the raw values (lanes 60..63 shadow lane 59: counted out)
     __builtin_amdgcn_sched_barrier(0);
     double d[NA];
     if constexpr ((WBX_ZD_KNOCK & 2) == 0) {
 #pragma unroll
     for (int l = 0; l < NA; ++l) d[l] = 0.0;
-#if WBX_ZD_F32_CHAINS
+#if WBX_ZD_F32_CHAINS >= 2
+    // (r6, A/B only: make ab-zdf32p2 / ab-zdf32p3)  PACKED fp32: the differences e = p - t, p - c, t - c of a packed point (two
+    // longitudes) are one v_pk_add_f32 each -- float32 differences are what the reference forms (deterministic.py:91-123) --, the
+    // sums of non-negative terms (|e|, e^2, (p-c)^2, (t-c)^2) run as two fp32 chains of the lane's 12 packed points and are widened
+    // once per row.  2: the two sums that cancel (e, (p-c)(t-c)) stay fp64 per point (9 instructions per point instead of 12);
+    // 3: they are fp32 chains as well (5.75 per point).
+    {
+      v2 s_ee = {0.f, 0.f}, s_pp = {0.f, 0.f}, s_tt = {0.f, 0.f}, s_ab = {0.f, 0.f}, s_e = {0.f, 0.f}, s_pt = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const v2 e = pa[i] - pb[i];
+        s_ab.x += fabsf(e.x);
+        s_ab.y += fabsf(e.y);
+        s_ee = __builtin_elementwise_fma(e, e, s_ee);
+        if constexpr (WBX_ZD_F32_CHAINS >= 3) s_e += e;
+        else d[0] += (double)e.x + (double)e.y;
+        if constexpr (HAS_C) {
+          const v2 ap = pa[i] - pc[i], at = pb[i] - pc[i];
+          s_pp = __builtin_elementwise_fma(ap, ap, s_pp);
+          s_tt = __builtin_elementwise_fma(at, at, s_tt);
+          if constexpr (WBX_ZD_F32_CHAINS >= 3) s_pt = __builtin_elementwise_fma(ap, at, s_pt);
+          else d[5] = fma((double)ap.y, (double)at.y, fma((double)ap.x, (double)at.x, d[5]));
+        }
+      }
+      if constexpr (WBX_ZD_F32_CHAINS >= 3) d[0] = (double)s_e.x + (double)s_e.y;
+      d[1] = (double)s_ab.x + (double)s_ab.y;
+      d[2] = (double)s_ee.x + (double)s_ee.y;
+      if constexpr (HAS_C) {
+        d[3] = (double)s_pp.x + (double)s_pp.y;
+        d[4] = (double)s_tt.x + (double)s_tt.y;
+        if constexpr (WBX_ZD_F32_CHAINS >= 3) d[5] = (double)s_pt.x + (double)s_pt.y;
+      }
+    }
+#elif WBX_ZD_F32_CHAINS
     // (r6, A/B only) The statistics of a POINT in fp32, as the reference forms them -- `predictions - targets`, `(p - t)**2`,
     // `(p - c) * (t - c)` of float32 fields are float32 arrays (deterministic.py:91-123, 222-259); only the weighted
     // dot promotes to float64 (aggregation.py:335).  The four sums of non-negative terms (|e|, e^2, pa^2, ta^2) run as fp32
@@ -290,7 +323,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     }
 #else
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < 12; i += (WBX_ZD_KNOCK & 16) ? 2 : 1) {  // (knock-out 16: every other point pair -- half the lanes' instructions)
       // The six sums are serial fma chains over the lane's 24 points, so the compiler widens all 72 inputs and forms all 48
       // anomalies up front to have independent work for the chains' latency: ~100 fp64 temporaries (v160..v253 in the ISA), 287
       // VGPRs, the prefetch loads spilled behind vmcnt(0) waits.  An opaque redefinition of the point pair's inputs AND of the
@@ -342,6 +375,9 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     C2 v[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) v[i] = {{pa[i].x, pb[i].x}, {pa[i].y, pb[i].y}};
+    // (r6, measured and dropped: forming x - m with 48 opaque scalar subtractions that ARE this interleave instead of 48 moves + 24
+    // packed subtractions -- bit-identical, 9 instructions fewer per row: 1.7226-1.7260 against 1.7260-1.7289 ms here, and the
+    // three-wave spectrum kernel, at its 168 registers, reloads one more spilled value inside its loop: 0.355-0.357 -> 0.361 ms)
     const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
     z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
