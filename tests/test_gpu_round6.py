@@ -101,7 +101,7 @@ def test_folded_entry_point_equals_partial_times_weights(func):
   assert b'NULL' in ctx.lib.wbx_last_error()
 
 
-def _job(torch, n, nlat=61, nlev=2, nlead=2, seed=8):
+def _job(torch, n, nlat=61, nlev=2, nlead=2, seed=8, permuted=False):
   nlon = 1440
   g = torch.Generator(device='cuda')
   g.manual_seed(seed)
@@ -112,6 +112,12 @@ def _job(torch, n, nlat=61, nlev=2, nlead=2, seed=8):
   zd = ('init_time', 'lead_time', 'level', 'latitude', 'longitude')
   fields = [tuple(torch.randn((1, nlead, nlev, nlat, nlon), generator=g, device='cuda') * 3 + 280 for _ in range(2)) for _ in range(n)]
   clim_t = torch.randn((n + 3, 4, nlev, nlat, nlon), generator=g, device='cuda') * 10 + 280
+  if permuted:
+    # the SAME values in another storage order: level outermost in the fields, level before (dayofyear, hour) in the climatology
+    # -- the DataArrays are strided views, the plan's key-offset tables are no longer monotonic in the key
+    fields = [tuple(f.permute(0, 2, 1, 3, 4).contiguous().permute(0, 2, 1, 3, 4) for f in pt) for pt in fields]
+    clim_t = clim_t.permute(2, 0, 1, 3, 4).contiguous().permute(1, 2, 0, 3, 4)
+    assert not fields[0][0].is_contiguous() and not clim_t.is_contiguous()
   clim = xr.Dataset({'z': xr.DataArray(clim_t, dims=('dayofyear', 'hour', 'level', 'latitude', 'longitude'),
                                        coords={'dayofyear': np.arange(1, n + 4), 'hour': np.array([0, 6, 12, 18]), 'level': level,
                                                'latitude': lat, 'longitude': lon})})
@@ -185,6 +191,33 @@ def test_chunk_loop_folds_stage_two_into_the_fused_sweep(monkeypatch, records):
     for k, v in want.items():
       got = np.asarray(out[fold][2][k].transpose('lead_time', 'level').values)
       np.testing.assert_allclose(got, v, rtol=1e-6, atol=1e-9 if k == 'bias.z' else 0, err_msg=f'{k} fold={fold}')
+  engine.clear_caches()
+
+
+@pytest.mark.parametrize('fold', [True, False])
+def test_fused_sweep_on_strided_storage_equals_contiguous(monkeypatch, fold):
+  """The fused sweep resolves a row's three base pointers from the plan's offset / gather tables with scalar loads, one row
+  ahead (r6).  The same job on fields stored level-outermost and a climatology stored level-first (strided views: key offsets that
+  jump back and forth from row to row) must give the sums of the contiguous job bit for bit -- same rows, same order."""
+  torch = _torch()
+  n = 3
+  out = {}
+  for permuted in (False, True):
+    engine.clear_caches()
+    monkeypatch.setattr(engine, 'FOLD_DET_SPECTRA', fold)
+    monkeypatch.setattr(replay, 'ENABLED', False)
+    passes, times, det, spec, *_ = _job(torch, n, nlat=37, nlev=3, nlead=3, seed=21, permuted=permuted)
+    log = []
+    monkeypatch.setattr(engine, 'S1_EVENT_LOG', log)
+    st = pipeline.evaluate_passes(times, passes)
+    monkeypatch.setattr(engine, 'S1_EVENT_LOG', None)
+    assert len([e for e in log if e.get('kind') == 'det_spectrum']) == n, [e.get('kind') for e in log]
+    out[permuted] = (st['det'][None], st['spec'][None])
+  for part in (0, 1):
+    for kind in ('sum_weighted_statistics', 'sum_weights'):
+      ta, tb = getattr(out[True][part], kind), getattr(out[False][part], kind)
+      for stat in ta:
+        np.testing.assert_array_equal(np.asarray(ta[stat]['z'].values), np.asarray(tb[stat]['z'].values), err_msg=f'{kind} {stat}')
   engine.clear_caches()
 
 
