@@ -145,7 +145,11 @@ __device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const do
 // the pass-1 stores.)
 // PT (wbx_zspec_det.hpp): rows A and B are the predictions' and the targets' row of ONE location; B's sums go to their own
 // accumulators accb / accmb instead of joining A's (no `split` then).
-template <int KNOCK, bool PT = false, typename At>
+// TW_EARLY (r6, the fused det + spectra sweep): the lane's eleven pass-1 twiddles are ASKED FOR in front of the 12-point DFT and
+// used behind it -- left alone the compiler reads them from the LDS just in time, two or three at a stretch, each stretch behind
+// its own `s_waitcnt lgkmcnt(0)` (five LDS latencies inside pass 1, with one other wave on the SIMD to cover them); the 22
+// registers are there: the row's prefetch registers are empty between the interleave and pass 1's stores.
+template <int KNOCK, bool PT = false, bool TW_EARLY = false, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
                                          double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at,
@@ -153,9 +157,19 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
   constexpr bool DROP = (KNOCK & 2) != 0;
   const int L = c.L;
   // ---- pass 1: 12-point DFT over a, twiddle W720^(b k1), transpose 1: buf[k1 * S1 + b]
-  dft12(v);
+  if constexpr (TW_EARLY) {
+    float2 w[11];
 #pragma unroll
-  for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
+    for (int k1 = 1; k1 < 12; ++k1) w[k1 - 1] = tw1[(k1 - 1) * 60 + L];
+    __builtin_amdgcn_sched_barrier(0);  // the eleven reads are issued here ...
+    dft12(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], w[k1 - 1]);  // ... and waited for once, here
+  } else {
+    dft12(v);
+#pragma unroll
+    for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], tw1[(k1 - 1) * 60 + L]);
+  }
 #pragma unroll
   for (int k1 = 0; k1 < 12; ++k1) z14_store<DROP>(buf + k1 * Z14_S1 + L, v[k1]);
   __builtin_amdgcn_wave_barrier();
@@ -167,13 +181,22 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) u[i][cc] = (KNOCK & 4) ? v[(5 * i + cc) % 12] : ld_c2(c.rd5 + 4 * i + 12 * cc);
   }
+  float2 w5[3][4];  // (TW_EARLY) pass 2's twelve twiddles, asked for with its data
+  if constexpr (TW_EARLY) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int q = 1; q < 5; ++q) w5[i][q - 1] = c.tw5[4 * i + 12 * (q - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __builtin_amdgcn_wave_barrier();  // every load of the first layout precedes the stores of the second
   at(1);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     butterfly<5>(u[i]);
 #pragma unroll
-    for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], c.tw5[4 * i + 12 * (q - 1)]);
+    for (int q = 1; q < 5; ++q) u[i][q] = ctw(u[i][q], TW_EARLY ? w5[i][q - 1] : c.tw5[4 * i + 12 * (q - 1)]);
 #pragma unroll
     for (int q = 0; q < 5; ++q) z14_store<DROP>(c.wr5 + 240 * i + 12 * q, u[i][q]);
   }
@@ -198,10 +221,20 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
   // left over: the otherwise idle lane 60 takes it in its s = 0 slot.  |X|^2 in packed fp32 (as the transform), fp64 sums.
   const bool self360 = c.lane == Z14_LANES;
   const C2 z360 = ld_c2(buf + Z14_N2 / 2);
+  C2 zm[6];      // (TW_EARLY) the six mirror partners and the six W1440^k of the unpack, asked for together
+  float2 wu[6];
+  if constexpr (TW_EARLY) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      zm[s] = ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+      wu[s] = twr[s == 0 ? c.k0 : L + 60 * s];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     C2 zk = v[s];
-    C2 zc = (KNOCK & 4) ? v[11 - s] : ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
+    C2 zc = (KNOCK & 4) ? v[11 - s] : (TW_EARLY ? zm[s] : ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L));
     if (s == 0) {
       zk.re = self360 ? z360.re : zk.re;
       zk.im = self360 ? z360.im : zk.im;
@@ -210,7 +243,7 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     }
     const C2 e = {zk.re + zc.re, zk.im - zc.im};
     const C2 o = {zk.im + zc.im, zc.re - zk.re};
-    const C2 wo = (KNOCK & 8) ? o : ctw(o, twr[s == 0 ? c.k0 : L + 60 * s]);
+    const C2 wo = (KNOCK & 8) ? o : ctw(o, TW_EARLY ? wu[s] : twr[s == 0 ? c.k0 : L + 60 * s]);
     const C2 x = cadd(e, wo), xm = csub(e, wo);
     const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;      // (row A, row B) of k
     const v2 pm = (KNOCK & 8) ? xm.re : xm.re * xm.re + xm.im * xm.im;  // ... of 720 - k
@@ -259,6 +292,9 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
 // KNOCK (diagnostic, wrong results; tools/kbench_spectrum_raw.py): 1 = every pair re-reads the team's first rows (L2 hits,
 // no HBM stream), 2 = the LDS stores of the three exchanges are dropped, 4 = their loads too, 8 = no unpack arithmetic.
 // FETCH_EARLY (A/B): the next pair's 24 loads in front of pass 1 instead of behind its stores (0.285 vs 0.275 ms per field)
+#ifndef WBX_Z14_TW_EARLY
+#define WBX_Z14_TW_EARLY 0  // z14_pair<.., TW_EARLY> in the three-wave spectrum kernel too (A/B: make ab-z14twearly)
+#endif
 template <bool PROF, int KNOCK, bool ROTATE = true, bool FETCH_EARLY = false>
 __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
                                                         int rows_per_team, int skew, const float2* __restrict__ tables_g,
@@ -366,7 +402,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     if (ga != cur) flush(ga);  // wave-uniform
     // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
     // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
-    z14_pair<(KNOCK & 14)>(v, buf, c, tw1, twr, sca, scb, false, ga, acc, accm, nullptr,
+    z14_pair<(KNOCK & 14), false, WBX_Z14_TW_EARLY != 0>(v, buf, c, tw1, twr, sca, scb, false, ga, acc, accm, nullptr,
                            [&](int i) {
                              mark(i + 2, i == 1 || i == 3 || i == 5);
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads

@@ -63,6 +63,12 @@ constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
 #ifndef WBX_ZD_FLAT_LOADS
 #define WBX_ZD_FLAT_LOADS 0  // 1: the rows through generic pointers = flat_load, what the kernel did up to round 6 (A/B: make ab-zdflat)
 #endif
+#ifndef WBX_ZD_PRIO
+#define WBX_ZD_PRIO 1  // the two waves of a SIMD alternate their user priority row by row (0: A/B, make ab-zdnoprio)
+#endif
+#ifndef WBX_ZD_TW_EARLY
+#define WBX_ZD_TW_EARLY 1  // pass 1's eleven twiddle reads in front of its 12-point DFT (z14_pair<.., TW_EARLY>; 0: A/B, make ab-zdtwlate)
+#endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
 #endif
@@ -230,9 +236,11 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
   fetch_t(nt);
   int turn = team >> 2;  // waves t and t + 4 of a block share a SIMD: the user priority alternates row by row (see zspec1440_kernel)
   for (int64_t r = r0; r < r1; ++r) {
+#if WBX_ZD_PRIO
     turn ^= 1;
     if (turn == 0) __builtin_amdgcn_s_setprio(0);
     else __builtin_amdgcn_s_setprio(1);
+#endif
     // (the row's own scalars; loading them a row ahead with the lookups measured the same -- 1.808 against 1.809-1.817 ms -- at
     // 250 instead of 232 registers and with three prefetched registers copied behind an `s_waitcnt vmcnt(0)` at the row's end)
     const int32_t g = tgroup[r];
@@ -380,7 +388,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     // three-wave spectrum kernel, at its 168 registers, reloads one more spilled value inside its loop: 0.355-0.357 -> 0.361 ms)
     const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
-    z14_pair<0, true>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
+    z14_pair<0, true, WBX_ZD_TW_EARLY != 0>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
       // (r6) Unconditional: behind a team's last row the row is asked for once more (`lookup` clamps; 1 row in ~260, found in the
       // L2 / Infinity Cache).  Under `r + 1 < r1` the loads sat in a block of their own: the compiler sank the gather-table
       // load into it (issued and waited for on the spot) and, at 254 registers, joined the two paths with copies of three
