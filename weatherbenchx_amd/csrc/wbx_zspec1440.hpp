@@ -145,11 +145,13 @@ __device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const do
 // the pass-1 stores.)
 // PT (wbx_zspec_det.hpp): rows A and B are the predictions' and the targets' row of ONE location; B's sums go to their own
 // accumulators accb / accmb instead of joining A's (no `split` then).
-// TW_EARLY (r6, the fused det + spectra sweep): the lane's eleven pass-1 twiddles are ASKED FOR in front of the 12-point DFT and
-// used behind it -- left alone the compiler reads them from the LDS just in time, two or three at a stretch, each stretch behind
-// its own `s_waitcnt lgkmcnt(0)` (five LDS latencies inside pass 1, with one other wave on the SIMD to cover them); the 22
-// registers are there: the row's prefetch registers are empty between the interleave and pass 1's stores.
-template <int KNOCK, bool PT = false, bool TW_EARLY = false, typename At>
+// TW_EARLY (r6, A/B only: make ab-zdtwearly): the lane's twiddles of a stage (and the unpack's mirror partners) are ASKED FOR ahead
+// of the arithmetic in front of their use -- left alone the compiler reads them from the LDS just in time, two or three at a
+// stretch, each stretch behind its own `s_waitcnt lgkmcnt(0)` (~30 waits per row; with the reads grouped ~12).  In the fused det +
+// spectra sweep: -1.1 % at unchanged registers (profiles/r06_det_spectrum_twearly_ab.txt).  NOT adopted: with the other source
+// shape the compiler pairs the butterflies' multiplies and adds into FMAs differently, and the sweep's spectra then differ from
+// the separate launches' in the last fp32 bit (8.9e-8 relative) -- tests/test_gpu_round3.py pins them to 1e-12.
+template <int KNOCK, bool PT = false, int TW_EARLY = 0, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
                                          double (&acc)[6], double (&accm)[6], double* __restrict__ power, At&& at,
@@ -161,7 +163,7 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     float2 w[11];
 #pragma unroll
     for (int k1 = 1; k1 < 12; ++k1) w[k1 - 1] = tw1[(k1 - 1) * 60 + L];
-    __builtin_amdgcn_sched_barrier(0);  // the eleven reads are issued here ...
+    if constexpr (TW_EARLY == 1) __builtin_amdgcn_sched_barrier(0);  // the eleven reads are issued here ...
     dft12(v);
 #pragma unroll
     for (int k1 = 1; k1 < 12; ++k1) v[k1] = ctw(v[k1], w[k1 - 1]);  // ... and waited for once, here
@@ -188,7 +190,7 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
 #pragma unroll
       for (int q = 1; q < 5; ++q) w5[i][q - 1] = c.tw5[4 * i + 12 * (q - 1)];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TW_EARLY == 1) __builtin_amdgcn_sched_barrier(0);
   }
   __builtin_amdgcn_wave_barrier();  // every load of the first layout precedes the stores of the second
   at(1);
@@ -229,7 +231,7 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
       zm[s] = ld_c2(s == 0 ? buf + c.mir0 : buf + (Z14_N2 - 60 * s) - L);
       wu[s] = twr[s == 0 ? c.k0 : L + 60 * s];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TW_EARLY == 1) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
@@ -293,7 +295,8 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
 // no HBM stream), 2 = the LDS stores of the three exchanges are dropped, 4 = their loads too, 8 = no unpack arithmetic.
 // FETCH_EARLY (A/B): the next pair's 24 loads in front of pass 1 instead of behind its stores (0.285 vs 0.275 ms per field)
 #ifndef WBX_Z14_TW_EARLY
-#define WBX_Z14_TW_EARLY 0  // z14_pair<.., TW_EARLY> in the three-wave spectrum kernel too (A/B: make ab-z14twearly)
+#define WBX_Z14_TW_EARLY 0  // z14_pair<.., TW_EARLY> in the three-wave spectrum kernel (1: +45 %, 116 B of scratch; 2 = the source shape without the
+                            // scheduling barriers: the same)
 #endif
 template <bool PROF, int KNOCK, bool ROTATE = true, bool FETCH_EARLY = false>
 __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict__ field, int64_t row_stride, int64_t nrows,
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(768) zspec1440_kernel(const float* __restrict_
     if (ga != cur) flush(ga);  // wave-uniform
     // stamps (PROF): 1 -> 2 pass 1 | 2 -> 3 transpose 1 round trip (stores drain, 15 loads return) | 3 -> 4 pass 2 |
     // 4 -> 5 transpose 2 round trip | 5 -> 6 pass 3 | 6 -> 7 mirror exchange + unpack + fp64 sums
-    z14_pair<(KNOCK & 14), false, WBX_Z14_TW_EARLY != 0>(v, buf, c, tw1, twr, sca, scb, false, ga, acc, accm, nullptr,
+    z14_pair<(KNOCK & 14), false, WBX_Z14_TW_EARLY>(v, buf, c, tw1, twr, sca, scb, false, ga, acc, accm, nullptr,
                            [&](int i) {
                              mark(i + 2, i == 1 || i == 3 || i == 5);
                              if constexpr (!FETCH_EARLY) {  // the registers of pass 1's inputs are free: the next pair's loads

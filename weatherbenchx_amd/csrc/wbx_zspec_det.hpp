@@ -67,7 +67,7 @@ constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
 #define WBX_ZD_PRIO 1  // the two waves of a SIMD alternate their user priority row by row (0: A/B, make ab-zdnoprio)
 #endif
 #ifndef WBX_ZD_TW_EARLY
-#define WBX_ZD_TW_EARLY 1  // pass 1's eleven twiddle reads in front of its 12-point DFT (z14_pair<.., TW_EARLY>; 0: A/B, make ab-zdtwlate)
+#define WBX_ZD_TW_EARLY 0  // 1: z14_pair<.., TW_EARLY> (A/B: make ab-zdtwearly; -1.1 %, but other FMA pairings than the plain spectrum kernel's)
 #endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(64 * ZD_TEAMS) zspec1440_det_kernel(S1Args a, 
     // three-wave spectrum kernel, at its 168 registers, reloads one more spilled value inside its loop: 0.355-0.357 -> 0.361 ms)
     const v2 msh = z14_demean(v);  // (the deterministic lanes above took the raw values)
     if (g != cur) flush(g);  // wave-uniform
-    z14_pair<0, true, WBX_ZD_TW_EARLY != 0>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
+    z14_pair<0, true, WBX_ZD_TW_EARLY>(v, buf, c, tw1, twr, sc, sc, false, g, accp, accmp, nullptr, [&](int i) {
       // (r6) Unconditional: behind a team's last row the row is asked for once more (`lookup` clamps; 1 row in ~260, found in the
       // L2 / Infinity Cache).  Under `r + 1 < r1` the loads sat in a block of their own: the compiler sank the gather-table
       // load into it (issued and waited for on the spot) and, at 254 registers, joined the two paths with copies of three
