@@ -904,7 +904,8 @@ def configs3_composite(env, nlead, nlev):
   from weatherbenchx_amd import xarray_lite as xr
   from weatherbenchx_amd.metrics import deterministic
   args = env.args
-  nchunk = max(8, args.steps * 2) if not args.small else 4
+  # (a job's set-up and read-back are paid once: 80 chunks per job by default -- configs[4] has 366 -- so that a chunk carries 1/80 of them)
+  nchunk = max(8, args.steps * 8) if not args.small else 4
   lead_time = (np.arange(nlead) * 6).astype('timedelta64[h]').astype('timedelta64[ns]')
   init_times = np.datetime64('2020-01-01T00', 'ns') + np.arange(nchunk) * np.timedelta64(24, 'h')
   level = np.arange(nlev)
@@ -936,7 +937,7 @@ def configs3_composite(env, nlead, nlev):
     return st['deterministic'][None].metric_values(det), st['spectra'][None].metric_values(spec)
   run(time_chunks.TimeChunks(init_times[:3], lead_time, init_time_chunk_size=1))
   env.sync()
-  # a job of this size is ~40 ms: nine of them.  The first still builds launch plans for time labels the warm-up did not see and
+  # a job of this size is ~60 ms: nine of them.  The first still builds launch plans for time labels the warm-up did not see and
   # runs on ramping clocks (2.2-2.7 ms per chunk against 0.95-1.0 for the others), and inside the full bench line (not when
   # this leg runs alone) one or two further jobs take 1.5-2.1 ms: the median of the last eight is reported, every job is listed
   runs = []

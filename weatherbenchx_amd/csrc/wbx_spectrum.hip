@@ -169,9 +169,9 @@ __device__ __forceinline__ double* spec_rec_open_block(const SpecRecs& R, int32_
   return R.data + (size_t)r * (size_t)R.width;
 }
 
-// power[f][g][k] (+)= the records of group g added in key order; one block per (group, 64 values).  The block scans the slot
-// headers (coalesced, a few KB), collects its group's (key, slot) pairs in the LDS, sorts them, and its four waves add their
-// values down a quarter of the sorted list each.  More records than the LDS list holds: further rounds, each taking the next LIST keys in
+// power[f][g][k] (+)= the records of group g added in key order; one block per (group, 256 values).  The block scans the slot
+// headers (coalesced, a few KB), collects its group's (key, slot) pairs in the LDS, sorts them, and every thread adds its
+// value down the sorted list, quarter by quarter (below).  More records than the LDS list holds: further rounds, each taking the next LIST keys in
 // order (the sum still runs in key order).
 constexpr int SPEC_CLOSE_LIST = 2048;
 constexpr int SPEC_CLOSE_BATCH = 16;  // headers / record values a thread asks for before it looks at any of them
@@ -181,7 +181,6 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
   __shared__ unsigned long long keys[SPEC_CLOSE_LIST];
   __shared__ unsigned int slots[SPEC_CLOSE_LIST];
   __shared__ unsigned int n_list, n_more;
-  __shared__ double part[4][64];
   const int32_t g = (int32_t)blockIdx.x;
   const int tid = (int)threadIdx.x;
   const unsigned int dyn = R.count[R.parity];
@@ -190,11 +189,11 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
   // (r6) `ntail` more values behind the fields of a record (wbx_det_spectrum_folded: the deterministic sums of the record's rows), the
   // first `ntail_out` of them go to tail_out[g][..]; the padding is added like everything else and dropped
   const int nval = nk * nfield + ntail;
-  __shared__ double tail_sink[64];
+  __shared__ double tail_sink[256];
   auto out_of = [&](int v) -> double* {
     if (v >= nk * nfield) {
       const int j = v - nk * nfield;
-      return j < ntail_out ? tail_out + (int64_t)g * ntail_out + j : tail_sink + (threadIdx.x & 63);
+      return j < ntail_out ? tail_out + (int64_t)g * ntail_out + j : tail_sink + threadIdx.x;
     }
     return (v < nk ? power0 : power1) + (int64_t)g * nk + (v < nk ? v : v - nk);
   };
@@ -306,33 +305,34 @@ __global__ void __launch_bounds__(256) spec_close_kernel(SpecRecs R, int32_t ngr
         }
       }
     }
-    // The block's 64 values (blockIdx.y), one per lane; wave w adds the w-th quarter [n w / 4, n (w + 1) / 4) of the sorted list
-    // in list order (BATCH records' values asked for at a time), the four partial sums are then added in wave order: a fixed
-    // function of the record SET.  Between rounds the running sums live in the output (this block is their only reader / writer).
+    // The block's 256 values (blockIdx.y), one per thread.  The sum of a value is a fixed function of the record SET: the sorted
+    // list is cut in four quarters [n w / 4, n (w + 1) / 4), each quarter is added in list order (BATCH records' values asked for at
+    // a time), and the four partial sums are added in quarter order.  (Rounds 5-6 gave a block 64 values and each of its four waves
+    // one quarter -- the same association, so the same bits --; with four times the values per block the slot headers are scanned
+    // by a quarter of the blocks: configs[4]'s close, 740 groups x 1450 values, 17 020 -> 4 440 blocks.)  Between rounds the running
+    // sums live in the output (this block is their only reader / writer).
     {
-      const int wv = tid >> 6, ln = tid & 63;
-      const int v = (int)blockIdx.y * 64 + ln;
-      const unsigned int q_lo = (unsigned int)(((unsigned long long)n * (unsigned)wv) >> 2);
-      const unsigned int q_hi = (unsigned int)(((unsigned long long)n * (unsigned)(wv + 1)) >> 2);
+      const int v = (int)blockIdx.y * 256 + tid;
       double* const dst = v < nval ? out_of(v) : nullptr;
-      double sum = 0.0, start = 0.0;
       if (dst) {
-        if (wv == 0 && !(first_round && !accumulate)) start = *dst;
-        for (unsigned int q0 = q_lo; q0 < q_hi; q0 += SPEC_CLOSE_BATCH) {
-          double x[SPEC_CLOSE_BATCH];
+        double total = (first_round && !accumulate) ? 0.0 : *dst;
+#pragma unroll 1
+        for (int wv = 0; wv < 4; ++wv) {
+          const unsigned int q_lo = (unsigned int)(((unsigned long long)n * (unsigned)wv) >> 2);
+          const unsigned int q_hi = (unsigned int)(((unsigned long long)n * (unsigned)(wv + 1)) >> 2);
+          double sum = 0.0;
+          for (unsigned int q0 = q_lo; q0 < q_hi; q0 += SPEC_CLOSE_BATCH) {
+            double x[SPEC_CLOSE_BATCH];
 #pragma unroll
-          for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) x[i] = q0 + i < q_hi ? R.data[(size_t)slots[q0 + i] * (size_t)R.width + v] : 0.0;
+            for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) x[i] = q0 + i < q_hi ? R.data[(size_t)slots[q0 + i] * (size_t)R.width + v] : 0.0;
 #pragma unroll
-          for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) sum += x[i];  // (+ 0.0 past the end of the list leaves every sum as it is)
+            for (int i = 0; i < SPEC_CLOSE_BATCH; ++i) sum += x[i];  // (+ 0.0 past the end of the list leaves every sum as it is)
+          }
+          total += sum;
         }
-      }
-      part[wv][ln] = sum;
-      __syncthreads();
-      if (dst && wv == 0) {
-        const double total = (((start + part[0][ln]) + part[1][ln]) + part[2][ln]) + part[3][ln];
         *dst = (overflow && !more) ? __builtin_nan("") : total;
       }
-      __syncthreads();
+      __syncthreads();  // the list is rebuilt by the next round
     }
     if (!more) break;
     floor_key = next_floor;
@@ -434,7 +434,7 @@ static int spec_recs_prepare(wbx_ctx* ctx, FftState* st, int64_t nstatic, int64_
 static int spec_close(wbx_ctx* ctx, const SpecRecs& R, int32_t ngroup, int32_t nk, int32_t nfield, double* power0, double* power1,
                       int32_t accumulate, double* tail_out = nullptr, int32_t ntail = 0, int32_t ntail_out = 0) {
   if (ngroup <= 0) return 0;
-  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup, (unsigned)((nk * nfield + ntail + 63) / 64)), dim3(256), 0, ctx->stream, R,
+  hipLaunchKernelGGL(spec_close_kernel, dim3((unsigned)ngroup, (unsigned)((nk * nfield + ntail + 255) / 256)), dim3(256), 0, ctx->stream, R,
                      ngroup, nk, nfield, power0, power1, accumulate, tail_out, ntail, ntail_out);
   WBX_HIP(hipGetLastError());
   return 0;
