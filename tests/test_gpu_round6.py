@@ -221,6 +221,20 @@ def test_fused_sweep_on_strided_storage_equals_contiguous(monkeypatch, fold):
   engine.clear_caches()
 
 
+def test_spectrum_entry_points_return_the_pinned_bits():
+  """A REGRESSION pin, not a parity vector: sha256 of what wbx_zonal_spectrum (x3, accumulate), wbx_det_spectrum and
+  wbx_det_spectrum_folded return for seeded host-generated inputs and four group tables, as the library of round 6 returned them
+  (tests/golden/spectra_bits.json, written by `python tools/spectra_bits.py --write` on an MI355X).  The sums are ordered and the
+  kernels deterministic, so a build whose hashes differ has changed its ARITHMETIC (round 6: grouping the transform's LDS reads
+  changed how the compiler paired multiplies and adds into FMAs -- the last fp32 bit of the fused sweep's spectra)."""
+  import subprocess
+  _torch()
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  proc = subprocess.run([sys.executable, os.path.join(root, 'tools', 'spectra_bits.py')], capture_output=True, text=True, timeout=300)
+  assert proc.returncode == 0, proc.stderr[-2000:]
+  assert 'golden: equal' in proc.stdout, proc.stdout[-2000:]
+
+
 def test_clock_probe_and_host_transpose_on_the_box():
   _torch()
   ctx = _hip.default_context(0)
