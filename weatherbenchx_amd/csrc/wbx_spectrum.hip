@@ -517,9 +517,22 @@ __device__ __forceinline__ C2 csub(C2 a, C2 b) { return {a.re - b.re, a.im - b.i
 __device__ __forceinline__ C2 mul_mi(C2 a) { return {a.im, -a.re}; }  // a * (-i)
 __device__ __forceinline__ C2 mul_pi(C2 a) { return {-a.im, a.re}; }  // a * (+i)
 __device__ __forceinline__ C2 cscale(C2 a, float s) { return {a.re * s, a.im * s}; }
-__device__ __forceinline__ C2 ctw(C2 a, float2 w) {  // a * (w.x + i w.y), the same twiddle for both rows
-  return {a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x};
+// (r6) Where TWO products meet in one sum, which of them the compiler fuses with the addition (a rounding each way) depended on
+// the shape of the surrounding code: grouping a stage's LDS reads changed the last fp32 bit of the fused sweep's spectra against
+// the plain kernel's.  The product that is to STAY a product is formed by `prod` (no contraction allowed on it); the other one
+// then is the only candidate and fuses.  Sums with a single product were never ambiguous.
+__device__ __forceinline__ v2 prod(v2 a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
 }
+__device__ __forceinline__ v2 prod(v2 a, v2 b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ C2 ctw(C2 a, float2 w) {  // a * (w.x + i w.y), the same twiddle for both rows
+  return {a.re * w.x - prod(a.im, w.y), a.im * w.x + prod(a.re, w.y)};
+}
+__device__ __forceinline__ v2 norm2(C2 x) { return x.re * x.re + prod(x.im, x.im); }  // |x|^2 of both rows
 __device__ __forceinline__ C2 ld_c2(const v4* p) {
   const v4 q = *p;
   return {{q.x, q.y}, {q.z, q.w}};
@@ -574,10 +587,12 @@ __device__ __forceinline__ void butterfly(C2 (&v)[R]) {
     const C2 a = v[0];
     const C2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
     v[0] = cadd(a, cadd(t1, t2));
-    const C2 m1 = cadd(a, cadd(cscale(t1, c1), cscale(t2, c2)));
-    const C2 m2 = cadd(a, cadd(cscale(t1, c2), cscale(t2, c1)));
-    const C2 n1 = cadd(cscale(t3, s1), cscale(t4, s2));
-    const C2 n2v = csub(cscale(t3, s2), cscale(t4, s1));
+    // (a + c2 t2) + c1 t1: two fused multiply-adds, each with ONE product (r6; it was a + (c1 t1 + c2 t2): a product, a fused
+    // multiply-add whose pairing was the compiler's, and an addition)
+    const C2 m1 = cadd(cscale(t1, c1), cadd(cscale(t2, c2), a));
+    const C2 m2 = cadd(cscale(t1, c2), cadd(cscale(t2, c1), a));
+    const C2 n1 = {t3.re * s1 + prod(t4.re, s2), t3.im * s1 + prod(t4.im, s2)};   // s1 t3 + s2 t4
+    const C2 n2v = {t3.re * s2 - prod(t4.re, s1), t3.im * s2 - prod(t4.im, s1)};  // s2 t3 - s1 t4
     v[1] = cadd(m1, mul_mi(n1));
     v[4] = cadd(m1, mul_pi(n1));
     v[2] = cadd(m2, mul_mi(n2v));
@@ -873,7 +888,7 @@ __global__ void __launch_bounds__(256) zspec_fused_kernel(const float* __restric
         const C2 o = {(zk.im + zc.im) * 0.5f, (zc.re - zk.re) * 0.5f};
         const C2 wo = ctw(o, tw_real[k]);
         const C2 x = cadd(e, wo), xm = csub(e, wo);
-        const v2 p = x.re * x.re + x.im * x.im, pm = xm.re * xm.re + xm.im * xm.im;  // (row A, row B)
+        const v2 p = norm2(x), pm = norm2(xm);  // (row A, row B)
         double pxd = (double)p.x, pyd = (double)p.y;
         if constexpr (WBX_SPECTRUM_DEMEAN) {
           if (k == 0) {  // x.re = F'_0 of the shifted rows, x.im = 0: F_0 = F'_0 + n m, formed and squared in fp64

@@ -145,12 +145,13 @@ __device__ __forceinline__ void z14_send(double* out, const Z14Lane& c, const do
 // the pass-1 stores.)
 // PT (wbx_zspec_det.hpp): rows A and B are the predictions' and the targets' row of ONE location; B's sums go to their own
 // accumulators accb / accmb instead of joining A's (no `split` then).
-// TW_EARLY (r6, A/B only: make ab-zdtwearly): the lane's twiddles of a stage (and the unpack's mirror partners) are ASKED FOR ahead
-// of the arithmetic in front of their use -- left alone the compiler reads them from the LDS just in time, two or three at a
-// stretch, each stretch behind its own `s_waitcnt lgkmcnt(0)` (~30 waits per row; with the reads grouped ~12).  In the fused det +
-// spectra sweep: -1.1 % at unchanged registers (profiles/r06_det_spectrum_twearly_ab.txt).  NOT adopted: with the other source
-// shape the compiler pairs the butterflies' multiplies and adds into FMAs differently, and the sweep's spectra then differ from
-// the separate launches' in the last fp32 bit (8.9e-8 relative) -- tests/test_gpu_round3.py pins them to 1e-12.
+// TW_EARLY (r6; 1 in the fused det + spectra sweep): the lane's twiddles of a stage (and the unpack's mirror partners) are ASKED FOR
+// ahead of the arithmetic in front of their use -- left alone the compiler reads them from the LDS just in time, two or three at a
+// stretch, each stretch behind its own `s_waitcnt lgkmcnt(0)` (~30 waits per row; with the reads grouped ~12): -1 % at unchanged
+// registers (profiles/r06_det_spectrum_twearly_ab.txt).  The first attempt changed the last fp32 bit of the sweep's spectra -- the
+// other source shape made the compiler fuse other products with their sums -- until the ambiguous sums were pinned (`prod`,
+// wbx_spectrum.hip): with them the plain kernel (TW_EARLY = 0: no registers for the grouping at three waves per SIMD) and the sweep
+// return the same bits again, whatever their schedules.
 template <int KNOCK, bool PT = false, int TW_EARLY = 0, typename At>
 __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c, const float2* __restrict__ tw1,
                                          const float2* __restrict__ twr, double sca, double scb, bool split, int32_t gb,
@@ -247,8 +248,8 @@ __device__ __forceinline__ void z14_pair(C2 (&v)[12], v4* buf, const Z14Lane& c,
     const C2 o = {zk.im + zc.im, zc.re - zk.re};
     const C2 wo = (KNOCK & 8) ? o : ctw(o, TW_EARLY ? wu[s] : twr[s == 0 ? c.k0 : L + 60 * s]);
     const C2 x = cadd(e, wo), xm = csub(e, wo);
-    const v2 p = (KNOCK & 8) ? x.re : x.re * x.re + x.im * x.im;      // (row A, row B) of k
-    const v2 pm = (KNOCK & 8) ? xm.re : xm.re * xm.re + xm.im * xm.im;  // ... of 720 - k
+    const v2 p = (KNOCK & 8) ? x.re : norm2(x);     // (row A, row B) of k
+    const v2 pm = (KNOCK & 8) ? xm.re : norm2(xm);  // ... of 720 - k
     double pxd = (double)p.x, pyd = (double)p.y;
     if constexpr (WBX_SPECTRUM_DEMEAN && !(KNOCK & 8)) {
       // k = 0 (lane 0, s = 0): x.re = 2 F'_0 of the shifted rows and x.im = 0 exactly; F_0 = F'_0 + n m (2 F_0 here: E and O

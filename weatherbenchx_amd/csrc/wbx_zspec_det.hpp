@@ -67,7 +67,7 @@ constexpr int ZD_TEAMS = WBX_ZD_TEAMS;
 #define WBX_ZD_PRIO 1  // the two waves of a SIMD alternate their user priority row by row (0: A/B, make ab-zdnoprio)
 #endif
 #ifndef WBX_ZD_TW_EARLY
-#define WBX_ZD_TW_EARLY 0  // 1: z14_pair<.., TW_EARLY> (A/B: make ab-zdtwearly; -1.1 %, but other FMA pairings than the plain spectrum kernel's)
+#define WBX_ZD_TW_EARLY 1  // z14_pair<.., TW_EARLY>: a stage's LDS reads grouped ahead of the arithmetic before their use (-1 %; 0: A/B, make ab-zdtwlate)
 #endif
 #ifndef WBX_ZD_C_IN_REGISTERS
 #define WBX_ZD_C_IN_REGISTERS 1  // 0: the climatology row staged through the LDS (24 LDS-DMA dwords per row) instead of 24 VGPRs (A/B: make ab-zdlds)
