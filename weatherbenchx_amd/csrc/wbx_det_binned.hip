@@ -263,6 +263,10 @@ template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = f
 #ifndef WBX_ATOMS_PD
 #define WBX_ATOMS_PD 4  // rows of p, t, c in flight per wave
 #endif
+#ifndef WBX_ATOMS_WAVES_COUNTS
+#define WBX_ATOMS_WAVES_COUNTS 3  // waves per SIMD of the flavours with one count lane per statistic (MM >= 2: Aggregator(skipna=True)): twice the
+                                  // accumulators; at four waves (128 VGPRs) they spilled 152-184 B per lane
+#endif
 #ifndef WBX_ATOMS_KNOCK
 #define WBX_ATOMS_KNOCK 0  // 1: timing diagnostic, see `accumulate`
 #endif
@@ -273,7 +277,7 @@ template <typename T, int FUNC, int MM, int PD, int WM, bool NT, bool MERGED = f
 #define WBX_ATOMS_SKIP 1   // 0: both entries' FMAs issued every row under EXEC masks (A/B: make ab-atoms6)
 #endif
 __global__ void __launch_bounds__(64 * (NT ? 1 : WBX_ATOMS_RAGGED_WPB))
-__attribute__((amdgpu_waves_per_eu(WBX_ATOMS_WAVES, WBX_ATOMS_WAVES)))
+__attribute__((amdgpu_waves_per_eu(MM >= 2 ? WBX_ATOMS_WAVES_COUNTS : WBX_ATOMS_WAVES, MM >= 2 ? WBX_ATOMS_WAVES_COUNTS : WBX_ATOMS_WAVES)))
 det_atoms_kernel(S1Args a, BinnedArgs g) {
   constexpr int W = NT ? 1 : WBX_ATOMS_RAGGED_WPB;
   constexpr int NIN = FUNC == WBX_DET6 ? 3 : (FUNC == WBX_DET3 ? 2 : 1);
